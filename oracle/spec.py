@@ -1,0 +1,77 @@
+"""Model hyper-parameters used by the oracle (test infrastructure, see oracle/__init__.py).
+
+Values follow the reference configs:
+  configs/pretrain/mq-glip-t.yaml, configs/vision_query_5shot/lvis_minival.yaml and
+  maskrcnn_benchmark/config/defaults.py (SWINT :720-731, DYHEAD :440-532, ATSS :407-436,
+  LANGUAGE_BACKBONE :264-287, VISION_QUERY :899-938, RPN anchors :553-557).
+"""
+from dataclasses import dataclass, replace
+from typing import Tuple
+
+
+@dataclass(frozen=True)
+class Spec:
+    # Swin (defaults.py:720-731)
+    swin_embed: int = 96
+    swin_depths: Tuple[int, ...] = (2, 2, 6, 2)
+    swin_heads: Tuple[int, ...] = (3, 6, 12, 24)
+    window: int = 7
+    mlp_ratio: int = 4
+    # FPN
+    fpn_out: int = 256
+    # BERT-base (HF BertConfig defaults)
+    vocab: int = 30522
+    max_pos: int = 512
+    bert_layers: int = 12
+    bert_hidden: int = 768
+    bert_heads: int = 12
+    bert_inter: int = 3072
+    bert_eps: float = 1e-12
+    max_query_len: int = 256
+    n_lang_layers: int = 1          # MODEL.LANGUAGE_BACKBONE.N_LAYERS
+    # GCP (modeling_bert_new.py:522-543, 642-659)
+    vision_query: bool = True
+    qv_start: int = 6
+    gcp_heads: int = 8
+    gcp_dim_head: int = 64
+    pre_dim_head: int = 32
+    pre_layers: int = 2
+    ff_mult: int = 4
+    vision_scale: float = 1.0
+    num_query_per_class: int = 5
+    # VLDyHead
+    dyhead_convs: int = 6
+    dyhead_channels: int = 256
+    fuse_embed: int = 2048
+    fuse_heads: int = 8
+    gn_groups: int = 16
+    gn_eps: float = 1e-5
+    num_classes: int = 1204         # MODEL.DYHEAD.NUM_CLASSES (cls_logits width = num_classes-1)
+    prior_prob: float = 0.01
+    log_scale: float = 0.0
+    # anchors / post-process
+    anchor_sizes: Tuple[int, ...] = (64, 128, 256, 512, 1024)
+    anchor_strides: Tuple[int, ...] = (8, 16, 32, 64, 128)
+    pre_nms_thresh: float = 0.05
+    pre_nms_top_n: int = 1000
+    nms_thresh: float = 0.6
+    detections_per_img: int = 300
+    mdetr_class_num: int = 3000     # TEST.MDETR_STYLE_AGGREGATE_CLASS_NUM (-1 => use num_classes-1)
+    size_divisibility: int = 32
+
+    @property
+    def swin_dims(self):
+        return tuple(self.swin_embed * 2 ** i for i in range(len(self.swin_depths)))
+
+
+def glip_t_spec(**kw) -> Spec:
+    """MQ-GLIP-T (BASELINE.json configs[1])."""
+    return replace(Spec(), **kw)
+
+
+def tiny_spec(**kw) -> Spec:
+    """Same widths / head dims as MQ-GLIP-T (kernels see the real tile shapes) but shallow,
+    with a small vocabulary, so the full model runs in seconds on CPU."""
+    base = Spec(swin_depths=(2, 2, 2, 2), bert_layers=4, qv_start=2, dyhead_convs=2,
+                vocab=2048, num_classes=81, mdetr_class_num=-1)
+    return replace(base, **kw)
