@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of the MQ-GLIP-T vision-language forward on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one `model(images, captions, positive_map)` forward (Swin -> FPN -> BERT+GCP -> VLDyHead -> ATSS
+post-processing to list[BoxList]) on a batch of 8 synthetic 800x1333 images per GPU (BASELINE.json configs[1]:
+MQ-GLIP-T, 5 vision queries per class, 40-class caption, fp16), inputs resident in HBM, followed (N > 1) by
+the fixed-shape RCCL all-gather of the detections.  Weak scaling: per-GPU batch is fixed.
+Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant hand-written kernel, timed
+live with HIP events on the launch stream) and, at N = 1, `cpu_baseline` (the CPU oracle on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_PER_GPU = 8
+IMG_HW = (800, 1333)
+NUM_CLASSES_IN_CAPTION = 40
+# algorithmic work of one image-forward (2*MAC), BASELINE.md section 2 / SURVEY.md 8(d)
+GFLOP_PER_IMAGE = 1451.0
+MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def build_model(dev, full=True):
+    from transformers import AutoTokenizer
+    from mq_det_amd import get_cfg
+    from mq_det_amd.modeling.detector import GeneralizedVLRCNN_New
+    from mq_det_amd.utils.synth import randomize_, synthetic_bank
+    from mq_det_amd.utils.tokenizer import build_synthetic_tokenizer, synthetic_caption, positive_map_from_spans
+    cfg = get_cfg()
+    # LVIS-style evaluation settings of configs/vision_query_5shot/lvis_minival.yaml
+    cfg.MODEL.DYHEAD.NUM_CLASSES = 1204
+    cfg.MODEL.ATSS.DETECTIONS_PER_IMG = 300
+    cfg.TEST.MDETR_STYLE_AGGREGATE_CLASS_NUM = 3000
+    tok_dir = build_synthetic_tokenizer(tempfile.mkdtemp(prefix="mqdet_tok_"))
+    cfg.MODEL.LANGUAGE_BACKBONE.TOKENIZER_TYPE = tok_dir
+    tk = AutoTokenizer.from_pretrained(tok_dir)
+    model = GeneralizedVLRCNN_New(cfg, tokenizer=tk)
+    randomize_(model, seed=0)
+    caption, spans = synthetic_caption(NUM_CLASSES_IN_CAPTION)
+    pmap = positive_map_from_spans(tk, caption, spans, list(range(1, NUM_CLASSES_IN_CAPTION + 1)))
+    model.load_query_bank(synthetic_bank(pmap.keys(), cfg.MODEL.BACKBONE.OUT_CHANNELS, cfg.VISION_QUERY.NUM_QUERY_PER_CLASS))
+    model.to(dev)
+    model.prepare(dev)
+    return cfg, model, caption, pmap
+
+
+def cpu_baseline():
+    """CPU oracle (pure-PyTorch fp32 restatement of the reference; the reference itself has no CPU path) on
+    ONE 800x1333 image, one forward, all host cores."""
+    from oracle import glip_t_spec
+    from oracle import detector as od
+    from oracle.weights import make_state_dict, make_query_bank
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    spec = glip_t_spec()
+    sd = make_state_dict(spec, 0)
+    g = torch.Generator().manual_seed(0)
+    images, sizes = od.pad_images([torch.randn(3, *IMG_HW, generator=g)], 32)
+    T = spec.max_query_len
+    nvalid = 2 * NUM_CLASSES_IN_CAPTION + 1
+    ids = torch.zeros(1, T, dtype=torch.long)
+    ids[:, :nvalid] = torch.randint(1000, spec.vocab, (nvalid,), generator=g)
+    am = torch.zeros(1, T, dtype=torch.long)
+    am[:, :nvalid] = 1
+    pm = {i + 1: [1 + 2 * i] for i in range(NUM_CLASSES_IN_CAPTION)}
+    bank = make_query_bank(pm.keys(), spec)
+    t = time.time()
+    od.forward(sd, spec, images, sizes, ids, am, pm, bank)
+    dt = time.time() - t
+    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"1 image 800x1333 (padded 800x1344), 1 forward of the fp32 CPU oracle, {dt:.1f} s, "
+                      f"torch {torch.get_num_threads()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=B_PER_GPU)
+    args = ap.parse_args()
+
+    from mq_det_amd import parallel
+    from mq_det_amd import ops
+    from mq_det_amd.structures import ImageList
+    rank, local, world = parallel.init_distributed()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    ops.load_library()
+    cfg, model, caption, pmap = build_model(dev)
+
+    Bn = args.batch
+    g = torch.Generator().manual_seed(1000 + rank)
+    H, W = IMG_HW
+    Hp, Wp = -(-H // 32) * 32, -(-W // 32) * 32
+    imgs = torch.zeros(Bn, 3, Hp, Wp)
+    imgs[:, :, :H, :W] = torch.randn(Bn, 3, H, W, generator=g)
+    images = ImageList(imgs.to(dev), [(H, W)] * Bn)
+    captions = [caption] * Bn
+    K = cfg.MODEL.ATSS.DETECTIONS_PER_IMG
+
+    def step():
+        out = model(images, captions=captions, positive_map=pmap)
+        if world > 1:
+            parallel.gather_detections(model.last_packed)       # [world*B, 300, 6], one fixed-shape collective
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    ops.start_timing()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    kern = ops.stop_timing()
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        ips = world * Bn * args.steps / dt
+        # dominant hand-written kernel: the D=256 fused attention of VLFuse (both directions)
+        N_img = sum(h * w for h, w in [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)])
+        flops_per_launch = 4.0 * Bn * 8 * N_img * 256 * 256          # QK^T + PV, 2*MAC each (SURVEY 8d / DESIGN.md)
+        vl = {k: v for k, v in kern.items() if k.startswith("attn_d256")}
+        n_l = sum(v[0] for v in vl.values())
+        ms = sum(v[1] for v in vl.values())
+        roof = None
+        if n_l:
+            avg_ms = ms / n_l
+            ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "attn_fwd_kernel<256,2> (VLFuse image<->text attention)",
+                    "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                    "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": n_l,
+                    "flops_per_launch": flops_per_launch}
+        res = {
+            "metric": "images/sec MQ-GLIP-T 800\u00d71333 5-shot vision queries, 1/2/4/8 MI355X", "value": round(ips, 3), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: MQ-GLIP-T (Swin-T + BERT-base + GCP + 6-layer VLDyHead), "
+                                   "5 vision queries x 40 classes, caption padded to 256 tokens, LVIS-style post-processing",
+                       "global_batch": world * Bn, "batch_per_gpu": Bn, "image": "800x1333 -> 800x1344",
+                       "parallelism": f"dp{world}", "weights": "seeded random init (no checkpoints offline)"},
+            "model_tflops": round(ips * GFLOP_PER_IMAGE / 1e3, 2),
+            "model_frac_of_mfma_peak": round(ips * GFLOP_PER_IMAGE / 1e3 / (MFMA_PEAK_TFLOPS * world), 4),
+            "detections_img0": len(out[0]),
+            "roofline": roof,
+            "kernels_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(kern.items())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # noqa: BLE001
+                res["cpu_baseline"] = {"error": repr(e)[:200]}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

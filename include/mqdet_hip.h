@@ -1,0 +1,93 @@
+/* mqdet_hip.h -- C ABI of libmqdet_hip.so: the MI355X (gfx950) kernels behind the MQ-Det / GLIP
+ * vision-language inference forward.  Plain pointers + sizes, no torch types; all pointers are DEVICE
+ * pointers unless stated; every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL =
+ * default stream).  Return value: 0 on success, a positive hipError_t for launch failures, a negative
+ * value for unsupported shapes / arguments.  The caller owns and allocates every buffer (outputs and
+ * workspaces); nothing is retained between calls.
+ *
+ * Each entry point names the reference interface it replaces (paths under the reference repository
+ * YifanXu74/MQ-Det).  The Python-side binding is mq_det_amd/ops.py (ctypes); the binding a maintainer of
+ * the reference would add is shown in INTEGRATION.md.
+ */
+#ifndef MQDET_HIP_H
+#define MQDET_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Library / ABI version (bumped on any signature change). */
+int mq_abi_version(void);
+
+/* Fused multi-head attention forward  O = softmax(clamp(scale*Q.K^T, +-clamp) + key_bias) V,
+ * fp16 in/out, fp32 accumulate; logits never leave the chip.  D in {32, 64, 256}.
+ *   q  [B,Nq,*], k [B,Nk,*] (element (b,i,h,d) at base + b*bs + i*rs + h*D + d),
+ *   vt [B,H*D,>=Nk] = V transposed (element (b,h,d,j) at vt + b*vt_bs + (h*D+d)*vt_rs + j; vt_rs % 8 == 0,
+ *   columns Nk..ceil8(Nk) must be finite), o [B,Nq,*]; key_bias [B,Nk] fp32 or NULL; clamp <= 0 disables.
+ *   nsplit > 1 splits the key range over grid.z (few queries / many keys) and needs
+ *   mq_attn_workspace_bytes() bytes of workspace.
+ * Replaces the unfused bmm -> (+mask) -> softmax -> bmm chains of
+ *   maskrcnn_benchmark/modeling/rpn/modeling_bert.py:119-170 (BertSelfAttention, with clamp) and HF BertSelfAttention,
+ *   maskrcnn_benchmark/modeling/language_backbone/modeling_bert_new.py:204-240 (MaskedCrossAttention, dense),
+ *   maskrcnn_benchmark/utils/fuse_helper.py:233-279 (BiMultiHeadAttention, both directions). */
+long mq_attn_workspace_bytes(int B, int H, int Nq, int D, int nsplit);
+int mq_attn_fwd(const void* q, const void* k, const void* vt, void* o, const float* key_bias, void* workspace,
+                int B, int H, int Nq, int Nk, int D,
+                long q_bs, long q_rs, long k_bs, long k_rs, long vt_bs, long vt_rs, long o_bs, long o_rs,
+                float scale, float clamp, int nsplit, void* stream);
+
+/* Swin (shifted-)window attention with pad / roll / window partition folded into addressing.
+ *   qkv [B,H,W,3C] fp16, qkv_bias [3C] fp16 (pad tokens), rel_bias [heads,N,N] fp32, out [B,H,W,C] fp16;
+ *   C == heads*32, N = ws*ws <= 64.
+ * Replaces maskrcnn_benchmark/modeling/backbone/swint.py:111-142 (WindowAttention.forward) together with the
+ *   pad/roll/window_partition/window_reverse/crop copies of SwinTransformerBlock.forward (:201-234) and the
+ *   per-forward SW-MSA mask construction of BasicLayer.forward (:354-373). */
+int mq_window_attn_fwd(const void* qkv, const void* qkv_bias, const float* rel_bias, void* out,
+                       int B, int H, int W, int C, int heads, int ws, int shift, void* stream);
+
+/* GCP sparse cross-attention: text token t attends to the vision rows idx[b,t,0..S) (-1 = none).
+ *   q [B,T,512] fp16, kv [B,V,1024] fp16 (k|v of the UNIQUE vision tokens), idx [B,T,S] int32, out [B,T,512].
+ * Replaces MaskedCrossAttention.forward (sparse branch) + _construct_sparse_inputs,
+ *   maskrcnn_benchmark/modeling/language_backbone/modeling_bert_new.py:162-184,204-240. */
+int mq_gcp_sparse_attn_fwd(const void* q, const void* kv, const int* idx, void* out, int B, int T, int V, int S,
+                           int heads, int dim_head, void* stream);
+
+/* GCP conditional gate fused into the residual:  out = sup * tanh(w2 . gelu(h)) + x   (rows M, widths C / G).
+ *   gate_out [M] fp32 optional (VISION_QUERY.RETURN_ATTN_GATE_VALUE).
+ * Replaces GatedCrossAttentionBlock.forward lines modeling_bert_new.py:359,368. */
+int mq_gcp_gate_residual_fwd(const void* sup, const void* h, const void* w2, const void* x, void* out,
+                             float* gate_out, long M, int C, int G, void* stream);
+
+/* DCNv2 (modulated deformable 3x3 conv, pad 1) column gather, NHWC fp16, whole batch.
+ *   x [B,H,W,C], om [B,27,oH,oW] fp32 NCHW (18 offsets + 9 mask LOGITS; may come from another pyramid level:
+ *   indexed flat by the output dims like the reference kernel), cols [B,Ho*Wo,9*C] (k = tap*C + c).
+ * Replaces _C.modulated_deform_conv_forward's im2col half: maskrcnn_benchmark/csrc/cuda/deform_conv_kernel_cuda.cu:578-640,
+ *   deform_conv_cuda.cu:538-552 (bound as maskrcnn_benchmark/csrc/vision.cpp:11-12). */
+int mq_dcn_im2col_fwd(const void* x, const float* om, void* cols, int B, int H, int W, int C, int oH, int oW,
+                      int stride, void* stream);
+
+/* Region-word alignment scores for the L labels of the caption.
+ *   dot [B,HW,T] fp16, tbias [B,T] fp32, tokidx [L,MT] int32, ctr [B,HW] fp16 -> out [B,HW,L] fp32
+ *   ((cls > thr) ? cls*sigmoid(ctr) : -1), cls_out [B,HW,L] fp32 optional.
+ * Replaces vldyhead.py:884-887 (bias, clamp) + rpn/inference.py:656-683,772-824. */
+int mq_align_scores_fwd(const void* dot, const float* tbias, const int* tokidx, const void* ctr, float* out,
+                        float* cls_out, int B, int HW, int T, int L, int MT, float thr, void* stream);
+
+/* Decode + clip the top-K candidates of one level into the per-image candidate arrays (at column out_off).
+ *   val/flat [B,K] (score, flat index loc*L + l), reg [B,HW,4] fp16, anchors [HW,4] fp32, label_ids [L] int32,
+ *   im_wh [B,2] fp32 (w,h) -> boxes [B,out_stride,4] fp32, scores [B,out_stride] fp32 (sqrt), labels int32.
+ * Replaces BoxCoder.decode (vldyhead.py:78-108), clip_to_image, rpn/inference.py:696-708. */
+int mq_box_decode(const float* val, const long* flat, const void* reg, const float* anchors, const int* label_ids,
+                  const float* im_wh, float* boxes, float* scores, int* labels, int B, int K, int HW, int L,
+                  long out_stride, long out_off, void* stream);
+
+/* Class-aware NMS on score-sorted boxes, mask + sweep entirely on the device.
+ *   boxes [B,N,4] fp32 (sorted by score desc per image), labels [B,N] int32, nvalid [B] int32 -> keep [B,N] uint8.
+ * Replaces _C.ml_nms: maskrcnn_benchmark/csrc/ml_nms.h:10-27, csrc/cuda/ml_nms.cu:15-149 (vision.cpp:23). */
+long mq_ml_nms_workspace_bytes(int B, int N);
+int mq_ml_nms(const float* boxes, const int* labels, const int* nvalid, void* workspace, unsigned char* keep,
+              int B, int N, float thr, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,288 @@
+// mq_attn_fwd: fused (flash-style) multi-head attention forward for gfx950.
+//
+//   O[b, i, h*D:(h+1)*D] = sum_j softmax_j( clamp(scale * Q_i.K_j, +-clamp) + key_bias[b, j] ) * V_j
+//
+// One kernel family serves every dense attention on the MQ-Det hot path (fp16 in / fp32 accumulate):
+//   * BERT self-attention, T=256, 12 heads x 64 (language backbone x12; VLDyHead copy x6 with the
+//     +-50000 clamp)                      -- reference rpn/modeling_bert.py:119-170, HF BertSelfAttention
+//   * GCP pre-select: vision queries -> pooled image tokens, 8 heads x 32, Nk = 5577
+//                                          -- reference modeling_bert_new.py:204-240 (dense branch)
+//   * VLFuse image->text (Nq = 22400, Nk = 256, key mask) and text->image (Nq = 256, Nk = 22400,
+//     split over keys) attention, 8 heads x 256, +-50000 clamp
+//                                          -- reference utils/fuse_helper.py:233-279
+// The QK^T logits never reach HBM (the reference materialises them: 183 MB / VLFuse layer / image).
+//
+// Layout (all "NT", i.e. K-contiguous for the MFMA fragments; see common.h):
+//   Q  : [B, Nq, *] halfs, element (b,i,h,d) at q  + b*q_bs  + i*q_rs  + h*D + d
+//   K  : [B, Nk, *]                           k  + b*k_bs  + j*k_rs  + h*D + d
+//   Vt : [B, H*D, >=Nk] (V transposed)         vt + b*vt_bs + (h*D+d)*vt_rs + j     (vt_rs % 8 == 0)
+//   O  : [B, Nq, *]                           o  + b*o_bs  + i*o_rs  + h*D + d
+// Work decomposition: grid = (ceil(Nq / BM), B*H, nsplit); a workgroup = 4 waves, each wave owns
+// RB*16 query rows and sweeps the keys in tiles of 64 staged through LDS (K tile [64][D+8],
+// Vt tile [D][64+8], per-wave P tile).  Online softmax in fp32 with wave-shuffle row reductions.
+// nsplit > 1 (few queries, many keys): each split writes un-normalised partials (O, m, l) to a
+// workspace and mq_attn_combine merges them.
+#include "common.h"
+
+struct AttnParams {
+  const half_t* q; const half_t* k; const half_t* vt; half_t* o;
+  const float* key_bias;     // [B, Nk] or nullptr
+  float* ws;                 // split-K workspace or nullptr
+  int B, H, Nq, Nk;
+  long q_bs, q_rs, k_bs, k_rs, vt_bs, vt_rs, o_bs, o_rs;
+  float scale, clamp;
+  int nsplit;
+};
+
+template <int D, int RB>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+  constexpr int BM = 4 * RB * 16, BN = 64;
+  constexpr int KS = D + 8, VS = BN + 8, PS = BN + 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* Ks = (half_t*)smem;              // [BN][KS]
+  half_t* Vs = Ks + BN * KS;               // [D][VS]
+  half_t* Ps = Vs + D * VS;                // [4][RB*16][PS]
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+  const int split = blockIdx.z;
+  const half_t* Q = p.q + (long)b * p.q_bs + h * D;
+  const half_t* K = p.k + (long)b * p.k_bs + h * D;
+  const half_t* Vt = p.vt + (long)b * p.vt_bs + (long)(h * D) * p.vt_rs;
+  const float* bias = p.key_bias ? p.key_bias + (long)b * p.Nk : nullptr;
+  half_t* Pw = Ps + wave * (RB * 16 * PS);
+
+  const int ntiles = (p.Nk + BN - 1) / BN;
+  const int tps = (ntiles + p.nsplit - 1) / p.nsplit;
+  const int t0 = split * tps;
+  const int t1 = min(ntiles, t0 + tps);
+  const int row0 = blockIdx.x * BM + wave * (RB * 16);
+
+  half8 qf[RB][D / 32];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    int row = min(row0 + rb * 16 + l15, p.Nq - 1);
+#pragma unroll
+    for (int kk = 0; kk < D / 32; ++kk)
+      qf[rb][kk] = *(const half8*)(Q + (long)row * p.q_rs + kk * 32 + lg * 8);
+  }
+  float4_ o[RB][D / 16];
+  float m[RB][4], lsum[RB][4];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+    for (int db = 0; db < D / 16; ++db) o[rb][db] = (float4_){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m[rb][r] = MQ_NEG_BIG; lsum[rb][r] = 0.f; }
+  }
+
+  for (int t = t0; t < t1; ++t) {
+    __syncthreads();
+    // ---- stage K tile [64 keys][D] and Vt tile [D][64 keys] (16-byte coalesced chunks)
+    for (int c = tid; c < BN * (D / 8); c += 256) {
+      int r = c / (D / 8), ch = c % (D / 8);
+      int key = t * BN + r;
+      half8 v = zero8();
+      if (key < p.Nk) v = *(const half8*)(K + (long)key * p.k_rs + ch * 8);
+      *(half8*)(Ks + r * KS + ch * 8) = v;
+    }
+    for (int c = tid; c < D * (BN / 8); c += 256) {
+      int d = c / (BN / 8), ch = c % (BN / 8);
+      int key0 = t * BN + ch * 8;
+      half8 v = zero8();
+      if (key0 < p.Nk) v = *(const half8*)(Vt + (long)d * p.vt_rs + key0);
+      *(half8*)(Vs + d * VS + ch * 8) = v;
+    }
+    __syncthreads();
+
+    // ---- S = Q K^T  (RB x 4 blocks of 16x16 per wave)
+    float4_ s[RB][4];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) s[rb][nb] = (float4_){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+      for (int kk = 0; kk < D / 32; ++kk) {
+        half8 kf = *(const half8*)(Ks + (nb * 16 + l15) * KS + kk * 32 + lg * 8);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) s[rb][nb] = mfma16(qf[rb][kk], kf, s[rb][nb]);
+      }
+    }
+    // ---- scale / clamp / key bias / out-of-range keys
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      int key = t * BN + nb * 16 + l15;
+      bool valid = key < p.Nk;
+      float kb = (valid && bias) ? bias[key] : 0.f;
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = s[rb][nb][r] * p.scale;
+          if (p.clamp > 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
+          v += kb;
+          v = fmaxf(v, MQ_NEG_BIG);
+          s[rb][nb][r] = valid ? v : MQ_NEG_BIG;
+        }
+    }
+    // ---- online softmax (rows live in the 16-lane groups), P -> per-wave LDS tile as fp16
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float mx = fmaxf(fmaxf(s[rb][0][r], s[rb][1][r]), fmaxf(s[rb][2][r], s[rb][3][r]));
+        mx = group16_max(mx);
+        float mnew = fmaxf(m[rb][r], mx);
+        float alpha = __expf(m[rb][r] - mnew);
+        float rs = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          float pv = __expf(s[rb][nb][r] - mnew);
+          rs += pv;
+          Pw[(rb * 16 + lg * 4 + r) * PS + nb * 16 + l15] = (half_t)pv;
+        }
+        rs = group16_sum(rs);
+        lsum[rb][r] = lsum[rb][r] * alpha + rs;
+        m[rb][r] = mnew;
+#pragma unroll
+        for (int db = 0; db < D / 16; ++db) o[rb][db][r] *= alpha;
+      }
+    wave_lds_fence();
+    // ---- O += P V   (A = P from LDS, B = V from the transposed tile)
+#pragma unroll
+    for (int kk = 0; kk < BN / 32; ++kk) {
+      half8 pf[RB];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) pf[rb] = *(const half8*)(Pw + (rb * 16 + l15) * PS + kk * 32 + lg * 8);
+#pragma unroll
+      for (int db = 0; db < D / 16; ++db) {
+        half8 vf = *(const half8*)(Vs + (db * 16 + l15) * VS + kk * 32 + lg * 8);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) o[rb][db] = mfma16(pf[rb], vf, o[rb][db]);
+      }
+    }
+  }
+
+  // ---- epilogue
+  if (p.nsplit == 1) {
+    half_t* O = p.o + (long)b * p.o_bs + h * D;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = row0 + rb * 16 + lg * 4 + r;
+        if (row < p.Nq) {
+          float inv = 1.f / lsum[rb][r];
+#pragma unroll
+          for (int db = 0; db < D / 16; ++db) O[(long)row * p.o_rs + db * 16 + l15] = (half_t)(o[rb][db][r] * inv);
+        }
+      }
+  } else {
+    // workspace: [nsplit][B*H][Nq][D + 2] floats  (O unnormalised, then m, l)
+    float* W = p.ws + ((long)split * gridDim.y + bh) * (long)p.Nq * (D + 2);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = row0 + rb * 16 + lg * 4 + r;
+        if (row < p.Nq) {
+          float* wr = W + (long)row * (D + 2);
+#pragma unroll
+          for (int db = 0; db < D / 16; ++db) wr[db * 16 + l15] = o[rb][db][r];
+          if (l15 == 0) { wr[D] = m[rb][r]; wr[D + 1] = lsum[rb][r]; }
+        }
+      }
+  }
+}
+
+// merge split-K partials: one wave per (b*h, row)
+template <int D>
+__global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
+  const int lane = threadIdx.x & 63;
+  const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long total = (long)p.B * p.H * p.Nq;
+  if (gw >= total) return;
+  const int row = gw % p.Nq;
+  const int bh = gw / p.Nq, b = bh / p.H, h = bh % p.H;
+  const long stride = (long)p.B * p.H * p.Nq * (D + 2);
+  const float* base = p.ws + gw * (D + 2);
+  float mx = MQ_NEG_BIG;
+  for (int s = 0; s < p.nsplit; ++s) mx = fmaxf(mx, base[s * stride + D]);
+  float l = 0.f;
+  constexpr int NA = D >= 64 ? D / 64 : 1;
+  float acc[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) acc[i] = 0.f;
+  float acc_small = 0.f;     // D < 64 (D = 32): lanes 0..31 only
+  for (int s = 0; s < p.nsplit; ++s) {
+    const float* w = base + s * stride;
+    float f = __expf(w[D] - mx);
+    l += w[D + 1] * f;
+    if (D >= 64) {
+#pragma unroll
+      for (int i = 0; i < D / 64; ++i) acc[i] += w[i * 64 + lane] * f;
+    } else if (lane < D) {
+      acc_small += w[lane] * f;
+    }
+  }
+  half_t* O = p.o + (long)b * p.o_bs + (long)row * p.o_rs + h * D;
+  float inv = 1.f / l;
+  if (D >= 64) {
+#pragma unroll
+    for (int i = 0; i < D / 64; ++i) O[i * 64 + lane] = (half_t)(acc[i] * inv);
+  } else if (lane < D) {
+    O[lane] = (half_t)(acc_small * inv);
+  }
+}
+
+template <int D, int RB>
+static int launch_attn(const AttnParams& p, hipStream_t stream) {
+  constexpr int BM = 4 * RB * 16, BN = 64;
+  constexpr size_t smem = (size_t)(BN * (D + 8) + D * (BN + 8) + 4 * RB * 16 * (BN + 8)) * sizeof(half_t);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<D, RB>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  dim3 grid((p.Nq + BM - 1) / BM, p.B * p.H, p.nsplit);
+  hipLaunchKernelGGL((attn_fwd_kernel<D, RB>), grid, dim3(256), smem, stream, p);
+  MQ_CHECK_LAUNCH();
+  if (p.nsplit > 1) {
+    long total = (long)p.B * p.H * p.Nq;
+    hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, p);
+    MQ_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+extern "C" long mq_attn_workspace_bytes(int B, int H, int Nq, int D, int nsplit) {
+  return nsplit > 1 ? (long)nsplit * B * H * Nq * (D + 2) * (long)sizeof(float) : 0;
+}
+
+extern "C" int mq_attn_fwd(const void* q, const void* k, const void* vt, void* o, const float* key_bias,
+                           void* workspace, int B, int H, int Nq, int Nk, int D,
+                           long q_bs, long q_rs, long k_bs, long k_rs, long vt_bs, long vt_rs,
+                           long o_bs, long o_rs, float scale, float clamp, int nsplit, void* stream) {
+  if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return 0;
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > 1 && workspace == nullptr) return -2;
+  if ((vt_rs % 8) || (q_rs % 8) || (k_rs % 8)) return -3;
+  AttnParams p;
+  p.q = (const half_t*)q; p.k = (const half_t*)k; p.vt = (const half_t*)vt; p.o = (half_t*)o;
+  p.key_bias = key_bias; p.ws = (float*)workspace;
+  p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk;
+  p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.vt_bs = vt_bs; p.vt_rs = vt_rs;
+  p.o_bs = o_bs; p.o_rs = o_rs; p.scale = scale; p.clamp = clamp; p.nsplit = nsplit;
+  hipStream_t s = (hipStream_t)stream;
+  switch (D) {
+    case 32: return launch_attn<32, 2>(p, s);
+    case 64: return launch_attn<64, 2>(p, s);
+    case 256: return launch_attn<256, 2>(p, s);
+    default: return -1;
+  }
+}

@@ -1,0 +1,67 @@
+// Shared device helpers for the MQ-Det gfx950 (CDNA4 / MI355X) kernels.
+// Wavefront = 64 lanes.  MFMA tile used everywhere: v_mfma_f32_16x16x32_f16
+//   A frag: lane l holds A[row = l&15][k = 8*(l>>4) .. +7]      (8 halfs = 16 B, K-contiguous)
+//   B frag: lane l holds B[k = 8*(l>>4) .. +7][col = l&15]      (same bytes as a row of B^T)
+//   C/D   : lane l holds C[row = 4*(l>>4) + r][col = l&15], r = 0..3
+// so every contraction here is written in "NT" form: both operands K-contiguous in memory.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
+typedef float float4_ __attribute__((ext_vector_type(4)));
+
+#define MQ_NEG_BIG (-1.0e30f)
+
+__device__ __forceinline__ float4_ mfma16(half8 a, half8 b, float4_ c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ half8 zero8() {
+  half8 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z[i] = (half_t)0.f;
+  return z;
+}
+
+// reduce across the 16 lanes that share (lane >> 4): lanes differ in their low 4 bits
+__device__ __forceinline__ float group16_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 1));
+  v = fmaxf(v, __shfl_xor(v, 2));
+  v = fmaxf(v, __shfl_xor(v, 4));
+  v = fmaxf(v, __shfl_xor(v, 8));
+  return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// Make this wave's earlier LDS writes visible to its own later LDS reads (other lanes of the SAME wave).
+// LDS ops of one wave retire in order; the explicit wait + scheduling barrier keeps the compiler honest.
+__device__ __forceinline__ void wave_lds_fence() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+#define MQ_CHECK_LAUNCH()                                   \
+  do {                                                      \
+    hipError_t e__ = hipGetLastError();                     \
+    if (e__ != hipSuccess) return (int)e__;                 \
+  } while (0)

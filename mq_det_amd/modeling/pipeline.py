@@ -1,0 +1,412 @@
+"""Functional MI355X forward of MQ-GLIP over an fp16 "plan" (packed inference weights).
+
+Activations are fp16 (fp32 accumulation inside every kernel / GEMM); feature maps are NHWC in memory.
+Hand-written HIP kernels (mq_det_amd.ops -> libmqdet_hip.so) do: Swin window attention, every dense
+attention (BERT, GCP pre-select, VLFuse both directions), the GCP sparse cross-attention + gated residual,
+the DCNv2 gather, alignment scoring, box decode and class-aware NMS.  Library GEMMs / convs (hipBLASLt,
+MIOpen through torch) do the plain projections.  Reference call stack: SURVEY.md section 3.3; each function
+cites the reference lines it re-implements.  Nothing here imports the oracle, and nothing runs on CPU.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+
+NEG = -1.0e30
+
+
+# ----------------------------------------------------------------------------- plan
+def build_plan(sd, cfg, device, dtype=torch.float16):
+    """Pack the fp32 state_dict into inference tensors: fp16 casts, fused / folded / re-laid-out weights."""
+    P = {}
+    M = cfg.MODEL
+
+    def h(name):
+        return sd[name].detach().to(device=device, dtype=dtype).contiguous()
+
+    def f32(name):
+        return sd[name].detach().to(device=device, dtype=torch.float32).contiguous()
+    for k, v in sd.items():
+        if v.dtype.is_floating_point:
+            P[k] = v.detach().to(device=device, dtype=dtype).contiguous()
+    # Swin: relative-position bias gathered once (reference re-gathers every call, swint.py:124-126)
+    ws = M.SWINT.WINDOW_SIZE
+    N = ws * ws
+    for i, (depth, heads) in enumerate(zip(M.SWINT.DEPTHS, M.SWINT.NUM_HEADS)):
+        for j in range(depth):
+            b = f"backbone.body.layers.{i}.blocks.{j}.attn"
+            idx = sd[b + ".relative_position_index"].to(device).reshape(-1)
+            P[b + ".rel_bias"] = f32(b + ".relative_position_bias_table")[idx].reshape(N, N, heads) \
+                .permute(2, 0, 1).contiguous()
+    # convs: channels_last weights
+    for k in list(P):
+        if P[k].dim() == 4:
+            P[k] = P[k].contiguous(memory_format=torch.channels_last)
+    # BERT layers: fused q|k projection
+    def bert(b):
+        P[b + ".qk.weight"] = torch.cat([h(b + ".attention.self.query.weight"), h(b + ".attention.self.key.weight")], 0)
+        P[b + ".qk.bias"] = torch.cat([h(b + ".attention.self.query.bias"), h(b + ".attention.self.key.bias")], 0)
+    nl = M.LANGUAGE_BACKBONE.get("NUM_HIDDEN_LAYERS", 12)
+    for i in range(nl):
+        bert(f"language_backbone.body.model.encoder.layer.{i}")
+    if cfg.VISION_QUERY.ENABLED:
+        qv0 = M.LANGUAGE_BACKBONE.get("QV_START", 6)
+        for i in range(nl - qv0):
+            b = f"language_backbone.body.model.encoder.qv_layer.{i}"
+            # tanh(ff_gate) folded into the last FFN projection (modeling_bert_new.py:373)
+            P[b + ".ff.linear2.gated"] = (f32(b + ".ff.linear2.weight") * torch.tanh(f32(b + ".ff_gate"))).to(dtype)
+            P[b + ".attn_gate.w2"] = h(b + ".attn_gate.linear2.weight").reshape(-1)
+        for i in range(2):
+            b = f"language_backbone.body.model.pre_select.layers.{i}.image_condition"
+            wkv = h(b + ".to_kv.weight")
+            half = wkv.shape[0] // 2
+            P[b + ".to_k.weight"], P[b + ".to_v.weight"] = wkv[:half].contiguous(), wkv[half:].contiguous()
+    # VLDyHead
+    D = M.DYHEAD
+    hd = 2048 // 8
+    for i in range(D.NUM_CONVS):
+        b = f"rpn.head.dyhead_tower.{3 * i}.b_attn"
+        sc = hd ** -0.5
+        P[b + ".q.weight"] = (f32(b + ".attn.v_proj.weight") * sc).to(dtype)        # scale folded (fuse_helper.py:221)
+        P[b + ".q.bias"] = (f32(b + ".attn.v_proj.bias") * sc).to(dtype)
+        gv, gl = f32(b + ".gamma_v"), f32(b + ".gamma_l")                            # layer scale folded (:424-425)
+        P[b + ".ov.weight"] = (f32(b + ".attn.out_v_proj.weight") * gv[:, None]).to(dtype)
+        P[b + ".ov.bias"] = (f32(b + ".attn.out_v_proj.bias") * gv).to(dtype)
+        P[b + ".ol.weight"] = (f32(b + ".attn.out_l_proj.weight") * gl[:, None]).to(dtype)
+        P[b + ".ol.bias"] = (f32(b + ".attn.out_l_proj.bias") * gl).to(dtype)
+        bert(f"rpn.head.dyhead_tower.{3 * i + 1}")
+        b = f"rpn.head.dyhead_tower.{3 * i + 2}"
+        for k in range(3):
+            w = f32(f"{b}.DyConv.{k}.conv.weight")                                   # [O, C, 3, 3] -> [O, tap*C + c]
+            P[f"{b}.DyConv.{k}.packed"] = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dtype).contiguous()
+        P[b + ".attn_w"] = f32(b + ".AttnConv.1.weight").reshape(-1)
+        P[b + ".attn_b"] = f32(b + ".AttnConv.1.bias")
+    for l in range(5):
+        s = f32(f"rpn.head.scales.{l}.scale")
+        P[f"rpn.head.bbox_pred.{l}.weight"] = (f32("rpn.head.bbox_pred.weight") * s).to(dtype) \
+            .contiguous(memory_format=torch.channels_last)
+        P[f"rpn.head.bbox_pred.{l}.bias"] = (f32("rpn.head.bbox_pred.bias") * s).to(dtype)
+    P["rpn.head.tok.weight"] = f32("rpn.head.dot_product_projection_text.weight")
+    P["rpn.head.tok.bias"] = f32("rpn.head.dot_product_projection_text.bias")
+    P["rpn.head.bias_lang32"] = f32("rpn.head.bias_lang")
+    P["rpn.head.bias0_32"] = f32("rpn.head.bias0")
+    P["rpn.head.inv_scale"] = float(math.exp(-float(sd["rpn.head.log_scale"])))
+    for l in range(5):
+        P[f"anchors.cell.{l}"] = f32(f"rpn.anchor_generator.cell_anchors.{l}")
+    return P
+
+
+def _ln(P, name, x, eps=1e-5):
+    return F.layer_norm(x, (x.shape[-1],), P[name + ".weight"], P[name + ".bias"], eps)
+
+
+def _lin(P, name, x):
+    return F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
+
+
+def _nsplit(n_blocks, n_key_tiles, target=768):
+    """Split the key range when a launch would leave most of the 256 CUs idle."""
+    if n_blocks >= 256 or n_key_tiles < 8:
+        return 1
+    return max(1, min(n_key_tiles // 4, -(-target // n_blocks), 32))
+
+
+# ----------------------------------------------------------------------------- Swin + FPN
+def swin_forward(P, cfg, img):
+    """swint.py:591-615.  img [B,3,H,W] fp16 -> [c3, c4, c5] as NHWC tensors (c2 is never used by the FPN,
+    fpn.py:82-84, so its output norm / layout change is skipped)."""
+    M = cfg.MODEL.SWINT
+    ws = M.WINDOW_SIZE
+    p = "backbone.body"
+    _, _, H0, W0 = img.shape
+    if W0 % 4 or H0 % 4:
+        img = F.pad(img, (0, (4 - W0 % 4) % 4, 0, (4 - H0 % 4) % 4))
+    x = F.conv2d(img, P[p + ".patch_embed.proj.weight"], P[p + ".patch_embed.proj.bias"], stride=4)
+    B, C, H, W = x.shape
+    x = _ln(P, p + ".patch_embed.norm", x.permute(0, 2, 3, 1).reshape(B, H * W, C))
+    outs = []
+    for i, (depth, heads) in enumerate(zip(M.DEPTHS, M.NUM_HEADS)):
+        C = x.shape[-1]
+        for j in range(depth):
+            b = f"{p}.layers.{i}.blocks.{j}"
+            shift = 0 if j % 2 == 0 else ws // 2
+            qkv = _lin(P, b + ".attn.qkv", _ln(P, b + ".norm1", x)).reshape(B, H, W, 3 * C)
+            a = ops.window_attention(qkv, P[b + ".attn.qkv.bias"], P[b + ".attn.rel_bias"], heads, ws, shift)
+            x = x + _lin(P, b + ".attn.proj", a.reshape(B, H * W, C))
+            x = x + _lin(P, b + ".mlp.fc2", F.gelu(_lin(P, b + ".mlp.fc1", _ln(P, b + ".norm2", x))))
+        if i > 0:
+            outs.append(_ln(P, f"{p}.norm{i}", x).reshape(B, H, W, C))
+        if i < len(M.DEPTHS) - 1:                      # PatchMerging, swint.py:258-284
+            d = f"{p}.layers.{i}.downsample"
+            y = x.reshape(B, H, W, C)
+            if H % 2 or W % 2:
+                y = F.pad(y, (0, 0, 0, W % 2, 0, H % 2))
+            y = torch.cat([y[:, 0::2, 0::2], y[:, 1::2, 0::2], y[:, 0::2, 1::2], y[:, 1::2, 1::2]], -1)
+            H, W = (H + 1) // 2, (W + 1) // 2
+            x = F.linear(_ln(P, d + ".norm", y.reshape(B, H * W, 4 * C)), P[d + ".reduction.weight"])
+    return outs
+
+
+def fpn_forward(P, feats_nhwc):
+    """fpn.py:59-129 + LastLevelP6P7 (:150-154).  In / out: NHWC-memory tensors viewed as NCHW."""
+    p = "backbone.fpn"
+    c3, c4, c5 = [f.permute(0, 3, 1, 2) for f in feats_nhwc]
+
+    def conv(name, x, stride=1, pad=0):
+        return F.conv2d(x, P[f"{p}.{name}.weight"], P[f"{p}.{name}.bias"], stride=stride, padding=pad)
+    inner = conv("fpn_inner4", c5)
+    res = [conv("fpn_layer4", inner, pad=1)]
+    for feat, idx in ((c4, 3), (c3, 2)):
+        lat = conv(f"fpn_inner{idx}", feat)
+        inner = lat + F.interpolate(inner, size=lat.shape[-2:], mode="nearest")
+        res.insert(0, conv(f"fpn_layer{idx}", inner, pad=1))
+    p6 = conv("top_blocks.p6", res[-1], stride=2, pad=1)
+    p7 = conv("top_blocks.p7", F.relu(p6), stride=2, pad=1)
+    return [t.contiguous(memory_format=torch.channels_last) for t in res + [p6, p7]]
+
+
+def pooled_fpn_tokens(feats):
+    """generalized_vl_rcnn_new.py:291-293 -> [B, sum(hw/4), C]."""
+    return torch.cat([F.avg_pool2d(f, 2).permute(0, 2, 3, 1).flatten(1, 2) for f in feats], 1)
+
+
+# ----------------------------------------------------------------------------- language backbone
+def bert_layer(P, b, x, key_bias, clamp):
+    """HF BertLayer / rpn/modeling_bert.py:71-272 (clamp=True): QK^T, mask, softmax, PV in one HIP kernel."""
+    Bn, T, C = x.shape
+    qk = _lin(P, b + ".qk", x)                                                          # [B, T, 2C]
+    vt = torch.baddbmm(P[b + ".attention.self.value.bias"][None, :, None], P[b + ".attention.self.value.weight"][None]
+                       .expand(Bn, -1, -1), x.transpose(1, 2))                          # V^T [B, C, T]
+    ctx = ops.attention(qk[:, :, :C], qk[:, :, C:], vt, 12, C // 12, key_bias=key_bias, clamp=50000.0 if clamp else 0.0)
+    a = _ln(P, b + ".attention.output.LayerNorm", _lin(P, b + ".attention.output.dense", ctx) + x, 1e-12)
+    hmid = _lin(P, b + ".intermediate.dense", a)
+    if clamp:
+        hmid = F.gelu(hmid.clamp(-50000, 50000)).clamp(-50000, 50000)
+        o = _lin(P, b + ".output.dense", hmid).clamp(-50000, 50000)
+        return _ln(P, b + ".output.LayerNorm", o + a, 1e-12).clamp(-50000, 50000)
+    o = _lin(P, b + ".output.dense", F.gelu(hmid))
+    return _ln(P, b + ".output.LayerNorm", o + a, 1e-12)
+
+
+def pre_select(P, p, vision, image, scale):
+    """modeling_bert_new.py:398-409,433-448: vision queries attend to the pooled image tokens (8 x 32)."""
+    vision, image = vision * scale, image * scale
+    Bn, Np, C = image.shape
+    pad = (-Np) % 8
+    if pad:
+        image = F.pad(image, (0, 0, 0, pad))
+    for i in range(2):
+        b = f"{p}.layers.{i}"
+        ic = b + ".image_condition"
+        q = F.linear(_ln(P, ic + ".norm", vision), P[ic + ".to_q.weight"])
+        kn = _ln(P, ic + ".norm_kv", image)
+        k = F.linear(kn, P[ic + ".to_k.weight"])
+        vt = torch.matmul(P[ic + ".to_v.weight"], kn.transpose(1, 2))                    # [B, 256, Np_pad]
+        nq_tiles = -(-q.shape[1] // 128)
+        att = ops.attention(q, k, vt, 8, 32, nk=Np, nsplit=_nsplit(nq_tiles * Bn * 8, -(-Np // 64)))
+        res = F.linear(vision, P[b + ".res_mapping.weight"]) if (b + ".res_mapping.weight") in P else vision
+        vision = F.linear(att, P[ic + ".to_out.weight"]) + res
+        ff = b + ".ff"
+        vision = vision + F.linear(F.gelu(F.linear(_ln(P, ff + ".norm", vision), P[ff + ".linear1.weight"])),
+                                   P[ff + ".linear2.weight"])
+    return vision
+
+
+def gcp_block(P, b, x, vision, idx, gates=None):
+    """GatedCrossAttentionBlock.forward (modeling_bert_new.py:298-374): K/V projected once per unique vision
+    token, sparse gather-attention kernel, gate MLP + tanh + residual fused."""
+    q = F.linear(_ln(P, b + ".attn.norm", x), P[b + ".attn.to_q.weight"])
+    kv = F.linear(_ln(P, b + ".attn.norm_kv", vision), P[b + ".attn.to_kv.weight"])
+    sup = F.linear(ops.gcp_sparse_attention(q, kv, idx), P[b + ".attn.to_out.weight"])
+    gh = F.linear(_ln(P, b + ".attn_gate.norm", sup), P[b + ".attn_gate.linear1.weight"])
+    if gates is not None:
+        x, g = ops.gcp_gate_residual(sup, gh, P[b + ".attn_gate.w2"], x, want_gate=True)
+        gates.append(g)
+    else:
+        x = ops.gcp_gate_residual(sup, gh, P[b + ".attn_gate.w2"], x)
+    ff = b + ".ff"
+    return x + F.linear(F.gelu(F.linear(_ln(P, ff + ".norm", x), P[ff + ".linear1.weight"])), P[ff + ".linear2.gated"])
+
+
+def language_backbone(P, cfg, input_ids, attention_mask, vision, images, idx, want_gates=False):
+    """bert_model_new.BertEncoder.forward (:39-104) over QVBertModel.forward (modeling_bert_new.py:690-848)."""
+    p = "language_backbone.body.model"
+    LB = cfg.MODEL.LANGUAGE_BACKBONE
+    T = input_ids.shape[1]
+    e = P[p + ".embeddings.word_embeddings.weight"][input_ids].float() \
+        + P[p + ".embeddings.token_type_embeddings.weight"][0].float() \
+        + P[p + ".embeddings.position_embeddings.weight"][:T].float()[None]
+    x = F.layer_norm(e, (e.shape[-1],), P[p + ".embeddings.LayerNorm.weight"].float(),
+                     P[p + ".embeddings.LayerNorm.bias"].float(), 1e-12).to(P[p + ".embeddings.LayerNorm.weight"].dtype)
+    key_bias = ((1.0 - attention_mask.float()) * NEG).contiguous()
+    use_vq = vision is not None
+    if use_vq:
+        vision = pre_select(P, p + ".pre_select", vision, images, cfg.VISION_QUERY.VISION_SCALE)
+    nl, qv0 = LB.get("NUM_HIDDEN_LAYERS", 12), LB.get("QV_START", 6)
+    gates = [] if want_gates else None
+    hidden = []
+    for i in range(nl):
+        if use_vq and i >= qv0:
+            x = gcp_block(P, f"{p}.encoder.qv_layer.{i - qv0}", x, vision, idx, gates)
+        x = bert_layer(P, f"{p}.encoder.layer.{i}", x, key_bias, clamp=False)
+        hidden.append(x)
+    n = LB.N_LAYERS
+    feats = torch.stack(hidden[-n:], 1).float().mean(1) / n
+    m = attention_mask.unsqueeze(-1).float()
+    embedded = feats * m
+    aggregate = embedded.sum(1) / attention_mask.sum(-1, keepdim=True).float()
+    return {"aggregate": aggregate, "embedded": embedded, "masks": attention_mask, "hidden": hidden[-1],
+            "key_bias": key_bias, "vision_query_gates": gates, "augmented_vision": vision}
+
+
+# ----------------------------------------------------------------------------- VLDyHead
+def vl_fuse(P, b, feats, hidden, key_bias):
+    """BiAttentionBlockForCheckpoint / BiMultiHeadAttention (fuse_helper.py:218-303,377-426): one set of logits,
+    softmax over text for the image side and over image tokens for the text side -- two launches of the fused
+    attention kernel, logits never materialised (reference: 3 x [B*8, 22400, 256] fp32 tensors)."""
+    Bn = feats[0].shape[0]
+    sizes = [f.shape[-2:] for f in feats]
+    v = torch.cat([f.permute(0, 2, 3, 1).flatten(1, 2) for f in feats], 1)              # [B, N, 256]
+    N = v.shape[1]
+    pad = (-N) % 8
+    v_ln = _ln(P, b + ".layer_norm_v", v)
+    l_ln = _ln(P, b + ".layer_norm_l", hidden)
+    v_pad = F.pad(v_ln, (0, 0, 0, pad)) if pad else v_ln
+    a = b + ".attn"
+    q = _lin(P, b + ".q", v_ln)                                                          # [B, N, 2048], pre-scaled
+    k = _lin(P, a + ".l_proj", l_ln)                                                     # [B, T, 2048]
+    val_l_t = torch.baddbmm(P[a + ".values_l_proj.bias"][None, :, None],
+                            P[a + ".values_l_proj.weight"][None].expand(Bn, -1, -1), l_ln.transpose(1, 2))
+    val_v_t = torch.baddbmm(P[a + ".values_v_proj.bias"][None, :, None],
+                            P[a + ".values_v_proj.weight"][None].expand(Bn, -1, -1), v_pad.transpose(1, 2))
+    out_v = ops.attention(q, k, val_l_t, 8, 256, key_bias=key_bias, scale=1.0, clamp=50000.0)
+    T = k.shape[1]
+    out_l = ops.attention(k, q, val_v_t, 8, 256, scale=1.0, clamp=50000.0, nk=N,
+                          nsplit=_nsplit(-(-T // 128) * Bn * 8, -(-N // 64)))
+    v_new = v_ln + _lin(P, b + ".ov", out_v)                                             # residual on the NORMED v, l
+    l_new = l_ln + _lin(P, b + ".ol", out_l)
+    out, s = [], 0
+    for (hh, ww) in sizes:
+        out.append(v_new[:, s:s + hh * ww].reshape(Bn, hh, ww, -1).contiguous().permute(0, 3, 1, 2))
+        s += hh * ww
+    return out, l_new
+
+
+def _dcn_gn(P, cfg, b, k, x, om, stride):
+    """Conv3x3Norm(deformable) (vldyhead.py:148-152): DCNv2 = HIP gather + library GEMM, then GroupNorm(16)."""
+    x_nhwc = x.permute(0, 2, 3, 1)
+    cols, (Ho, Wo) = ops.dcn_im2col(x_nhwc.contiguous(), om, stride)
+    y = F.linear(cols, P[f"{b}.DyConv.{k}.packed"], P[f"{b}.DyConv.{k}.conv.bias"])      # [B, Ho*Wo, C]
+    y = y.reshape(x.shape[0], Ho, Wo, -1).permute(0, 3, 1, 2)
+    G = cfg.MODEL.GROUP_NORM
+    return F.group_norm(y, G.NUM_GROUPS, P[f"{b}.DyConv.{k}.bn.weight"], P[f"{b}.DyConv.{k}.bn.bias"], G.EPSILON)
+
+
+def dyconv(P, cfg, b, feats):
+    """DyConv.forward (vldyhead.py:205-247) incl. offset re-use across levels, scale attention, DyReLU."""
+    out = []
+    for lvl, f in enumerate(feats):
+        om = F.conv2d(f, P[b + ".offset.weight"], P[b + ".offset.bias"], padding=1).float().contiguous()
+        br = [_dcn_gn(P, cfg, b, 1, f, om, 1)]
+        if lvl > 0:
+            br.append(_dcn_gn(P, cfg, b, 2, feats[lvl - 1], om, 2))
+        if lvl < len(feats) - 1:
+            up = _dcn_gn(P, cfg, b, 0, feats[lvl + 1], om, 1)
+            br.append(F.interpolate(up, size=f.shape[-2:], mode="bilinear", align_corners=True))
+        acc = None
+        for t in br:
+            pooled = t.float().mean((2, 3))                                               # [B, C]
+            a = F.relu(pooled @ P[b + ".attn_w"] + P[b + ".attn_b"])                      # [B]
+            a = (F.relu6(a + 3) / 6 / len(br)).to(t.dtype)[:, None, None, None]
+            acc = t * a if acc is None else acc + t * a
+        out.append(acc)
+    res = []
+    for o in out:                                                                         # DYReLU, dyrelu.py:78-112
+        Bn, C = o.shape[:2]
+        y = o.float().mean((2, 3)).to(o.dtype)
+        y = F.relu6(_lin(P, b + ".relu.fc.2", F.relu(_lin(P, b + ".relu.fc.0", y))).float() + 3) / 6
+        a1, b1, a2, b2 = [t.to(o.dtype)[:, :, None, None] for t in torch.split(y, C, 1)]
+        res.append(torch.max(o * ((a1 - 0.5) * 2 + 1.0) + (b1 - 0.5), o * ((a2 - 0.5) * 2) + (b2 - 0.5)))
+    return res
+
+
+def vldyhead(P, cfg, feats, lang):
+    """VLDyHead.forward (vldyhead.py:769-900), eval outputs."""
+    p = "rpn.head"
+    hidden, key_bias = lang["hidden"], lang["key_bias"]
+    for i in range(cfg.MODEL.DYHEAD.NUM_CONVS):
+        t = f"{p}.dyhead_tower"
+        feats, hidden = vl_fuse(P, f"{t}.{3 * i}.b_attn", feats, hidden, key_bias)
+        hidden = bert_layer(P, f"{t}.{3 * i + 1}", hidden, key_bias, clamp=True)
+        feats = dyconv(P, cfg, f"{t}.{3 * i + 2}", feats)
+    emb = F.normalize(hidden.float(), p=2, dim=-1)
+    tok = F.linear(emb / 2.0, P[p + ".tok.weight"], P[p + ".tok.bias"]) * P[p + ".inv_scale"]      # [B, T, 256]
+    tbias = (emb @ P[p + ".bias_lang32"] + P[p + ".bias0_32"]).contiguous()                           # [B, T]
+    tok16_t = tok.to(feats[0].dtype).transpose(1, 2)
+    bbox, ctr, dots = [], [], []
+    for l, f in enumerate(feats):
+        Bn, C, H, W = f.shape
+        fc = f.contiguous(memory_format=torch.channels_last)
+        bbox.append(F.conv2d(fc, P[f"{p}.bbox_pred.{l}.weight"], P[f"{p}.bbox_pred.{l}.bias"]))
+        ctr.append(F.conv2d(fc, P[p + ".centerness.weight"], P[p + ".centerness.bias"]))
+        dots.append(torch.bmm(fc.permute(0, 2, 3, 1).reshape(Bn, H * W, C), tok16_t))                # [B, HW, T]
+    return {"bbox_reg": bbox, "centerness": ctr, "dot": dots, "tbias": tbias, "feats": feats, "hidden": hidden}
+
+
+# ----------------------------------------------------------------------------- anchors + post-processing
+def grid_anchors(P, sizes, strides, device):
+    """anchor_generator.py:73-95."""
+    out = []
+    for l, ((H, W), s) in enumerate(zip(sizes, strides)):
+        sx = torch.arange(0, W * s, step=s, dtype=torch.float32, device=device)
+        sy = torch.arange(0, H * s, step=s, dtype=torch.float32, device=device)
+        yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+        sh = torch.stack([xx.reshape(-1), yy.reshape(-1), xx.reshape(-1), yy.reshape(-1)], 1)
+        out.append((sh[:, None, :] + P[f"anchors.cell.{l}"][None]).reshape(-1, 4).contiguous())
+    return out
+
+
+def postprocess(cfg, head, anchors, image_sizes, tokidx, label_ids, want_cls=False):
+    """ATSSPostProcessor.forward (rpn/inference.py:620-769) without per-image Python loops or host syncs:
+    fixed-shape top-k per level, one sort, device-side NMS, fixed-shape top-`DETECTIONS_PER_IMG`.
+    Returns boxes [B,K,4], scores [B,K] (<= 0 => empty slot), labels [B,K], counts [B] -- all on device."""
+    A = cfg.MODEL.ATSS
+    dev = head["tbias"].device
+    Bn = head["tbias"].shape[0]
+    L = tokidx.shape[0]
+    im_wh = torch.tensor([[w, h] for (h, w) in image_sizes], dtype=torch.float32, device=dev)
+    ks = [min(A.PRE_NMS_TOP_N, d.shape[1] * L) for d in head["dot"]]
+    tot = sum(ks)
+    boxes = torch.empty(Bn, tot, 4, dtype=torch.float32, device=dev)
+    scores = torch.empty(Bn, tot, dtype=torch.float32, device=dev)
+    labels = torch.empty(Bn, tot, dtype=torch.int32, device=dev)
+    cls_all = []
+    off = 0
+    for l, (dot, reg, ctr, anc, k) in enumerate(zip(head["dot"], head["bbox_reg"], head["centerness"], anchors, ks)):
+        HW = dot.shape[1]
+        ctr_flat = ctr.permute(0, 2, 3, 1).reshape(Bn, HW).contiguous()
+        r = ops.align_scores(dot.contiguous(), head["tbias"], tokidx, ctr_flat, A.INFERENCE_TH, want_cls=want_cls)
+        if want_cls:
+            r, cls = r
+            cls_all.append(cls)
+        val, flat = torch.topk(r.reshape(Bn, HW * L), k, dim=1, sorted=False)
+        reg_nhwc = reg.permute(0, 2, 3, 1).reshape(Bn, HW, 4).contiguous()
+        ops.box_decode(val.contiguous(), flat.contiguous(), reg_nhwc, anc, label_ids, im_wh, boxes, scores, labels, HW, L, off)
+        off += k
+    order = torch.argsort(scores, dim=1, descending=True, stable=True)
+    scores = torch.gather(scores, 1, order)
+    labels = torch.gather(labels, 1, order.to(torch.int64)).contiguous()
+    boxes = torch.gather(boxes, 1, order[:, :, None].expand(-1, -1, 4)).contiguous()
+    nvalid = (scores > 0).sum(1).to(torch.int32)
+    keep = ops.ml_nms(boxes, labels, nvalid, A.NMS_TH)
+    kept_scores = torch.where(keep, scores, torch.full_like(scores, -1.0))
+    K = min(A.DETECTIONS_PER_IMG, tot) if A.DETECTIONS_PER_IMG > 0 else tot
+    top, ti = torch.topk(kept_scores, K, dim=1, sorted=True)
+    out = {"boxes": torch.gather(boxes, 1, ti[:, :, None].expand(-1, -1, 4)), "scores": top,
+           "labels": torch.gather(labels, 1, ti).to(torch.int64), "counts": (top > 0).sum(1),
+           "pre_nms": {"boxes": boxes, "scores": scores, "labels": labels, "nvalid": nvalid, "keep": keep}}
+    if want_cls:
+        out["cls"] = cls_all
+    return out

@@ -1,0 +1,229 @@
+"""ctypes binding of libmqdet_hip.so + thin torch-tensor wrappers (device memory and streams only).
+
+There is NO fallback: if the HIP library is missing or a tensor is not on a GPU these functions raise.
+Signatures mirror include/mqdet_hip.h one to one.
+"""
+import ctypes
+import math
+import os
+
+import torch
+
+_LIB = None
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmqdet_hip.so")
+
+_vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+_SIGNATURES = {
+    "mq_abi_version": (_i, []),
+    "mq_attn_workspace_bytes": (_l, [_i, _i, _i, _i, _i]),
+    "mq_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _l, _l, _l, _f, _f, _i, _vp]),
+    "mq_window_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "mq_gcp_sparse_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "mq_gcp_gate_residual_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
+    "mq_dcn_im2col_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "mq_align_scores_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "mq_box_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _vp]),
+    "mq_ml_nms_workspace_bytes": (_l, [_i, _i]),
+    "mq_ml_nms": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """dlopen libmqdet_hip.so (built by mq_det_amd.build / __graft_entry__.build).  Raises if absent."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} not found: the MI355X HIP library is required (python -m mq_det_amd.build); "
+                               "there is no CPU / eager fallback for the MQ-Det hot path")
+        lib = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)           # AttributeError if a declared symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _LIB = lib
+    return _LIB
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline numbers)
+_TIMING = None
+
+
+def start_timing():
+    global _TIMING
+    _TIMING = []
+
+
+def stop_timing():
+    """-> {tag: (launches, total_ms)}; synchronises."""
+    global _TIMING
+    rec, _TIMING = _TIMING or [], None
+    torch.cuda.synchronize()
+    out = {}
+    for tag, a, b in rec:
+        n, t = out.get(tag, (0, 0.0))
+        out[tag] = (n + 1, t + a.elapsed_time(b))
+    return out
+
+
+class _timed:
+    def __init__(self, tag):
+        self.tag = tag
+
+    def __enter__(self):
+        if _TIMING is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if _TIMING is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            _TIMING.append((self.tag, self.a, b))
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _chk(rc, name):
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with code {rc}")
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("mq_det_amd ops need GPU tensors: the hot path has no CPU fallback")
+
+
+def attention(q, k, vt, num_heads, head_dim, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None):
+    """q [B,Nq,H*D], k [B,Nk,H*D], vt [B,H*D,Nk_pad] (V transposed, Nk_pad % 8 == 0) fp16 -> [B,Nq,H*D] fp16."""
+    lib = load_library()
+    _need_gpu(q, k, vt, key_bias)
+    B, Nq, HD = q.shape
+    Nk = k.shape[1] if nk is None else nk
+    H, D = num_heads, head_dim
+    assert HD == H * D and k.shape[2] == HD and vt.shape[1] == HD and vt.shape[2] >= Nk
+    assert q.dtype == k.dtype == vt.dtype == torch.float16
+    assert q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1
+    if key_bias is not None:
+        assert key_bias.dtype == torch.float32 and key_bias.shape == (B, Nk) and key_bias.is_contiguous()
+    o = torch.empty(B, Nq, HD, dtype=torch.float16, device=q.device)
+    ws = None
+    if nsplit > 1:
+        ws = torch.empty(lib.mq_attn_workspace_bytes(B, H, Nq, D, nsplit) // 4, dtype=torch.float32, device=q.device)
+    with _timed(f"attn_d{D}_nq{Nq}_nk{Nk}_s{nsplit}"):
+        rc = lib.mq_attn_fwd(_ptr(q), _ptr(k), _ptr(vt), _ptr(o), _ptr(key_bias), _ptr(ws), B, H, Nq, Nk, D,
+                             q.stride(0), q.stride(1), k.stride(0), k.stride(1), vt.stride(0), vt.stride(1),
+                             o.stride(0), o.stride(1), float(scale if scale is not None else 1.0 / math.sqrt(D)),
+                             float(clamp), int(nsplit), _stream())
+    _chk(rc, "mq_attn_fwd")
+    return o
+
+
+def window_attention(qkv, qkv_bias, rel_bias, heads, ws, shift):
+    """qkv [B,H,W,3C] fp16, qkv_bias [3C] fp16, rel_bias [heads,N,N] fp32 -> [B,H,W,C] fp16."""
+    lib = load_library()
+    _need_gpu(qkv, qkv_bias, rel_bias)
+    B, H, W, C3 = qkv.shape
+    C = C3 // 3
+    assert qkv.is_contiguous() and qkv.dtype == torch.float16 and qkv_bias.dtype == torch.float16
+    assert rel_bias.dtype == torch.float32 and rel_bias.is_contiguous() and rel_bias.shape == (heads, ws * ws, ws * ws)
+    out = torch.empty(B, H, W, C, dtype=torch.float16, device=qkv.device)
+    with _timed(f"window_attn_c{C}"):
+        _chk(lib.mq_window_attn_fwd(_ptr(qkv), _ptr(qkv_bias), _ptr(rel_bias), _ptr(out), B, H, W, C, heads, ws, shift,
+                                    _stream()), "mq_window_attn_fwd")
+    return out
+
+
+def gcp_sparse_attention(q, kv, idx, heads=8, dim_head=64):
+    """q [B,T,512] fp16, kv [B,V,1024] fp16, idx [B,T,S] int32 (-1 pad) -> [B,T,512] fp16."""
+    lib = load_library()
+    _need_gpu(q, kv, idx)
+    B, T, HD = q.shape
+    V, S = kv.shape[1], idx.shape[2]
+    assert q.is_contiguous() and kv.is_contiguous() and idx.is_contiguous() and idx.dtype == torch.int32
+    assert q.dtype == kv.dtype == torch.float16 and kv.shape[2] == 2 * HD
+    out = torch.empty_like(q)
+    _chk(lib.mq_gcp_sparse_attn_fwd(_ptr(q), _ptr(kv), _ptr(idx), _ptr(out), B, T, V, S, heads, dim_head, _stream()),
+         "mq_gcp_sparse_attn_fwd")
+    return out
+
+
+def gcp_gate_residual(sup, h, w2, x, want_gate=False):
+    """out = sup * tanh(w2 . gelu(h)) + x ; sup/x [..., C], h [..., G], w2 [G] (all fp16)."""
+    lib = load_library()
+    _need_gpu(sup, h, w2, x)
+    C, G = sup.shape[-1], h.shape[-1]
+    M = sup.numel() // C
+    assert sup.is_contiguous() and h.is_contiguous() and x.is_contiguous() and w2.is_contiguous()
+    assert sup.dtype == h.dtype == w2.dtype == x.dtype == torch.float16
+    out = torch.empty_like(x)
+    gate = torch.empty(M, dtype=torch.float32, device=x.device) if want_gate else None
+    _chk(lib.mq_gcp_gate_residual_fwd(_ptr(sup), _ptr(h), _ptr(w2), _ptr(x), _ptr(out), _ptr(gate), M, C, G, _stream()),
+         "mq_gcp_gate_residual_fwd")
+    return (out, gate) if want_gate else out
+
+
+def dcn_im2col(x_nhwc, om, stride):
+    """x [B,H,W,C] fp16 (NHWC contiguous), om [B,27,oH,oW] fp32 -> cols [B, Ho*Wo, 9*C] fp16, (Ho, Wo)."""
+    lib = load_library()
+    _need_gpu(x_nhwc, om)
+    B, H, W, C = x_nhwc.shape
+    assert x_nhwc.is_contiguous() and x_nhwc.dtype == torch.float16
+    assert om.is_contiguous() and om.dtype == torch.float32 and om.shape[1] == 27
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    cols = torch.empty(B, Ho * Wo, 9 * C, dtype=torch.float16, device=x_nhwc.device)
+    with _timed("dcn_im2col"):
+        _chk(lib.mq_dcn_im2col_fwd(_ptr(x_nhwc), _ptr(om), _ptr(cols), B, H, W, C, om.shape[2], om.shape[3], stride,
+                                   _stream()), "mq_dcn_im2col_fwd")
+    return cols, (Ho, Wo)
+
+
+def align_scores(dot, tbias, tokidx, ctr, thr, want_cls=False):
+    """dot [B,HW,T] fp16, tbias [B,T] fp32, tokidx [L,MT] int32, ctr [B,HW] fp16 -> ranked [B,HW,L] fp32 (, cls)."""
+    lib = load_library()
+    _need_gpu(dot, tbias, tokidx, ctr)
+    B, HW, T = dot.shape
+    L, MT = tokidx.shape
+    assert dot.is_contiguous() and dot.dtype == torch.float16 and ctr.dtype == torch.float16 and ctr.is_contiguous()
+    assert tbias.dtype == torch.float32 and tbias.is_contiguous() and tokidx.dtype == torch.int32 and tokidx.is_contiguous()
+    out = torch.empty(B, HW, L, dtype=torch.float32, device=dot.device)
+    cls = torch.empty_like(out) if want_cls else None
+    _chk(lib.mq_align_scores_fwd(_ptr(dot), _ptr(tbias), _ptr(tokidx), _ptr(ctr), _ptr(out), _ptr(cls), B, HW, T, L, MT,
+                                 float(thr), _stream()), "mq_align_scores_fwd")
+    return (out, cls) if want_cls else out
+
+
+def box_decode(val, flat, reg, anchors, label_ids, im_wh, boxes, scores, labels, HW, L, out_off):
+    """Decode top-K candidates of one level into columns [out_off, out_off+K) of the per-image arrays."""
+    lib = load_library()
+    _need_gpu(val, flat, reg, anchors, label_ids, im_wh, boxes, scores, labels)
+    B, K = val.shape
+    assert val.dtype == torch.float32 and flat.dtype == torch.int64 and reg.dtype == torch.float16
+    assert val.is_contiguous() and flat.is_contiguous() and reg.is_contiguous() and anchors.is_contiguous()
+    assert boxes.dtype == torch.float32 and scores.dtype == torch.float32 and labels.dtype == torch.int32
+    _chk(lib.mq_box_decode(_ptr(val), _ptr(flat), _ptr(reg), _ptr(anchors), _ptr(label_ids), _ptr(im_wh), _ptr(boxes),
+                           _ptr(scores), _ptr(labels), B, K, HW, L, boxes.shape[1], out_off, _stream()), "mq_box_decode")
+
+
+def ml_nms(boxes, labels, nvalid, thresh):
+    """boxes [B,N,4] fp32 sorted by score desc, labels [B,N] int32, nvalid [B] int32 -> keep [B,N] bool."""
+    lib = load_library()
+    _need_gpu(boxes, labels, nvalid)
+    B, N, _ = boxes.shape
+    assert boxes.is_contiguous() and labels.is_contiguous() and boxes.dtype == torch.float32
+    assert labels.dtype == torch.int32 and nvalid.dtype == torch.int32
+    ws = torch.empty(max(lib.mq_ml_nms_workspace_bytes(B, N), 8), dtype=torch.uint8, device=boxes.device)
+    keep = torch.empty(B, N, dtype=torch.uint8, device=boxes.device)
+    _chk(lib.mq_ml_nms(_ptr(boxes), _ptr(labels), _ptr(nvalid), _ptr(ws), _ptr(keep), B, N, float(thresh), _stream()),
+         "mq_ml_nms")
+    return keep.bool()

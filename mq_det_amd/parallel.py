@@ -1,0 +1,57 @@
+"""Data-parallel inference helpers: one process per GPU, RCCL over xGMI via torch.distributed ("nccl" on ROCm).
+
+The MQ-Det forward shards by image (contiguous blocks per rank like the reference sampler,
+data/samplers/distributed.py:57-64); the only exchange is the gather of detections.  The reference pickles
+variable-length BoxLists and runs two all_gathers of uint8 tensors (utils/comm.py:61-101); here each rank
+contributes one fixed-shape [B_local, K, 6] fp32 block (x1, y1, x2, y2, score, label; score <= 0 = empty
+slot) in a single all_gather_into_tensor -- 7.2 KB / image, latency-bound on any fabric.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env (torch.distributed.run contract)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous block of ceil(n/world) items per rank, wrapping around at the end (reference sampler)."""
+    per = -(-n_items // world)
+    return [(rank * per + i) % n_items for i in range(per)]
+
+
+def pack_detections(boxes, scores, labels):
+    """[B,K,4], [B,K], [B,K] -> [B,K,6] fp32."""
+    return torch.cat([boxes.float(), scores.float()[..., None], labels.float()[..., None]], -1).contiguous()
+
+
+def gather_detections(packed):
+    """All ranks receive [world * B_local, K, 6] (rank-major order).  Single fixed-shape collective."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return packed
+    world = dist.get_world_size()
+    out = packed.new_empty((world * packed.shape[0],) + tuple(packed.shape[1:]))
+    dist.all_gather_into_tensor(out, packed.contiguous())
+    return out
+
+
+def unpack_detections(packed):
+    """[N,K,6] -> list of dicts with the non-empty rows."""
+    res = []
+    for p in packed:
+        keep = p[:, 4] > 0
+        res.append({"boxes": p[keep, :4], "scores": p[keep, 4], "labels": p[keep, 5].long()})
+    return res

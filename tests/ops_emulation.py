@@ -1,0 +1,153 @@
+"""TEST-ONLY pure-torch emulations of the mq_det_amd.ops entry points (same signatures / layouts).
+
+Purpose: validate, on the CPU-only build box, all the HOST-SIDE glue of the product pipeline (weight packing and
+folding, NHWC layouts, strides, padding conventions, index construction, post-processing plumbing) against the
+oracle BEFORE spending GPU minutes -- tests/test_pipeline_glue_cpu.py monkeypatches these into
+mq_det_amd.modeling.pipeline.ops.  They are never imported by the product; the real kernels are tested
+on the GPU by tests/test_gpu_parity.py.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def attention(q, k, vt, num_heads, head_dim, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None):
+    B, Nq, HD = q.shape
+    Nk = k.shape[1] if nk is None else nk
+    H, D = num_heads, head_dim
+    assert vt.shape[2] % 8 == 0 and vt.shape[2] >= Nk and q.stride(2) == 1 and k.stride(2) == 1
+    qh = q.float().reshape(B, Nq, H, D).transpose(1, 2)
+    kh = k.float()[:, :Nk].reshape(B, Nk, H, D).transpose(1, 2)
+    vh = vt.float()[:, :, :Nk].reshape(B, H, D, Nk).transpose(2, 3)
+    s = qh @ kh.transpose(-1, -2) * (scale if scale is not None else 1.0 / math.sqrt(D))
+    if clamp > 0:
+        s = s.clamp(-clamp, clamp)
+    if key_bias is not None:
+        s = s + key_bias[:, None, None, :]
+    return (s.softmax(-1) @ vh).transpose(1, 2).reshape(B, Nq, HD).to(q.dtype)
+
+
+def window_attention(qkv, qkv_bias, rel_bias, heads, ws, shift):
+    B, H, W, C3 = qkv.shape
+    C = C3 // 3
+    pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
+    Hp, Wp = H + pad_b, W + pad_r
+    full = qkv_bias.float().expand(B, Hp, Wp, C3).clone()
+    full[:, :H, :W] = qkv.float()
+    if shift:
+        full = torch.roll(full, (-shift, -shift), (1, 2))
+    xw = full.reshape(B, Hp // ws, ws, Wp // ws, ws, C3).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C3)
+    Bw, N, _ = xw.shape
+    t = xw.reshape(Bw, N, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
+    attn = (t[0] * (C // heads) ** -0.5) @ t[1].transpose(-1, -2) + rel_bias[None]
+    if shift:
+        region = torch.zeros(Hp, Wp)
+        k = 0
+        for h0, h1 in ((0, Hp - ws), (Hp - ws, Hp - shift), (Hp - shift, Hp)):
+            for w0, w1 in ((0, Wp - ws), (Wp - ws, Wp - shift), (Wp - shift, Wp)):
+                region[h0:h1, w0:w1] = k
+                k += 1
+        r = region.reshape(Hp // ws, ws, Wp // ws, ws).permute(0, 2, 1, 3).reshape(-1, N)
+        m = (r[:, None, :] != r[:, :, None]).float() * -100.0
+        nW = m.shape[0]
+        attn = (attn.reshape(B, nW, heads, N, N) + m[None, :, None]).reshape(Bw, heads, N, N)
+    o = (attn.softmax(-1) @ t[2]).transpose(1, 2).reshape(Bw, N, C)
+    o = o.reshape(B, Hp // ws, Wp // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
+    if shift:
+        o = torch.roll(o, (shift, shift), (1, 2))
+    return o[:, :H, :W].contiguous().to(qkv.dtype)
+
+
+def gcp_sparse_attention(q, kv, idx, heads=8, dim_head=64):
+    B, T, HD = q.shape
+    S = idx.shape[2]
+    out = torch.zeros_like(q, dtype=torch.float32)
+    k, v = kv.float()[..., :HD], kv.float()[..., HD:]
+    for b in range(B):
+        for t in range(T):
+            ids = [int(i) for i in idx[b, t] if int(i) >= 0]
+            if not ids:
+                continue
+            qq = q[b, t].float().reshape(heads, dim_head) * dim_head ** -0.5
+            kk = k[b, ids].reshape(len(ids), heads, dim_head)
+            vv = v[b, ids].reshape(len(ids), heads, dim_head)
+            w = torch.einsum("hd,shd->hs", qq, kk).softmax(-1)
+            out[b, t] = torch.einsum("hs,shd->hd", w, vv).reshape(-1)
+    return out.to(q.dtype)
+
+
+def gcp_gate_residual(sup, h, w2, x, want_gate=False):
+    gate = torch.tanh((F.gelu(h.float()) * w2.float()).sum(-1, keepdim=True))
+    out = (sup.float() * gate + x.float()).to(x.dtype)
+    return (out, gate.reshape(-1)) if want_gate else out
+
+
+def dcn_im2col(x_nhwc, om, stride):
+    B, H, W, C = x_nhwc.shape
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    n = Ho * Wo
+    plane = om.shape[2] * om.shape[3]
+    flat = om.reshape(B, -1)
+    pos = torch.arange(n)
+    ho, wo = (pos // Wo).float() * stride - 1, (pos % Wo).float() * stride - 1
+    x = x_nhwc.float().reshape(B, H * W, C)
+    cols = torch.zeros(B, n, 9, C)
+    for k in range(9):
+        dh, dw = flat[:, (2 * k) * n + pos], flat[:, (2 * k + 1) * n + pos]
+        mk = torch.sigmoid(flat[:, 18 * plane + k * n + pos])
+        hf, wf = ho[None] + k // 3 + dh, wo[None] + k % 3 + dw
+        inside = (hf > -1) & (wf > -1) & (hf < H) & (wf < W)
+        h0, w0 = torch.floor(hf), torch.floor(wf)
+        lh, lw = hf - h0, wf - w0
+        acc = torch.zeros(B, n, C)
+        for dy, dx, wgt in ((0, 0, (1 - lh) * (1 - lw)), (0, 1, (1 - lh) * lw), (1, 0, lh * (1 - lw)), (1, 1, lh * lw)):
+            hh, ww = h0.long() + dy, w0.long() + dx
+            ok = (hh >= 0) & (hh <= H - 1) & (ww >= 0) & (ww <= W - 1) & inside
+            g = torch.gather(x, 1, (hh.clamp(0, H - 1) * W + ww.clamp(0, W - 1))[..., None].expand(-1, -1, C))
+            acc += g * (wgt * ok.float())[..., None]
+        cols[:, :, k] = acc * mk[..., None]
+    return cols.reshape(B, n, 9 * C).to(x_nhwc.dtype), (Ho, Wo)
+
+
+def align_scores(dot, tbias, tokidx, ctr, thr, want_cls=False):
+    v = (dot.float() + tbias[:, None, :]).clamp(-50000, 50000).sigmoid()
+    L, MT = tokidx.shape
+    cls = torch.zeros(dot.shape[0], dot.shape[1], L)
+    for l in range(L):
+        toks = [int(t) for t in tokidx[l] if int(t) >= 0]
+        if toks:
+            cls[:, :, l] = v[:, :, toks].mean(-1)
+    out = torch.where(cls > thr, cls * ctr.float().sigmoid()[..., None], torch.full_like(cls, -1.0))
+    return (out, cls) if want_cls else out
+
+
+def box_decode(val, flat, reg, anchors, label_ids, im_wh, boxes, scores, labels, HW, L, out_off):
+    B, K = val.shape
+    loc, l = flat // L, flat % L
+    r = torch.gather(reg.float(), 1, loc[..., None].expand(-1, -1, 4))
+    a = anchors[loc]
+    w, h = a[..., 2] - a[..., 0] + 1, a[..., 3] - a[..., 1] + 1
+    cx, cy = (a[..., 2] + a[..., 0]) / 2, (a[..., 3] + a[..., 1]) / 2
+    lim = math.log(1000.0 / 16)
+    pcx, pcy = r[..., 0] / 10 * w + cx, r[..., 1] / 10 * h + cy
+    pw, ph = torch.exp((r[..., 2] / 5).clamp(max=lim)) * w, torch.exp((r[..., 3] / 5).clamp(max=lim)) * h
+    W, H = im_wh[:, 0:1], im_wh[:, 1:2]
+    bx = torch.stack([(pcx - 0.5 * (pw - 1)).clamp(min=0).minimum(W - 1), (pcy - 0.5 * (ph - 1)).clamp(min=0).minimum(H - 1),
+                      (pcx + 0.5 * (pw - 1)).clamp(min=0).minimum(W - 1), (pcy + 0.5 * (ph - 1)).clamp(min=0).minimum(H - 1)], -1)
+    ok = val > 0
+    boxes[:, out_off:out_off + K] = torch.where(ok[..., None], bx, torch.zeros_like(bx))
+    scores[:, out_off:out_off + K] = torch.where(ok, val.clamp(min=0).sqrt(), torch.full_like(val, -1.0))
+    labels[:, out_off:out_off + K] = torch.where(ok, label_ids[l], torch.zeros_like(label_ids[l]))
+
+
+def ml_nms(boxes, labels, nvalid, thresh):
+    from oracle.postprocess import ml_nms as ref
+    B, N, _ = boxes.shape
+    keep = torch.zeros(B, N, dtype=torch.bool)
+    for b in range(B):
+        nv = int(nvalid[b])
+        if nv:
+            sc = torch.arange(nv, 0, -1).float()          # already sorted by score
+            keep[b, ref(boxes[b, :nv], sc, labels[b, :nv].float(), thresh)] = True
+    return keep

@@ -1,0 +1,414 @@
+"""HIP path vs CPU oracle parity checks (run on the GPU box; used by tests/test_gpu_parity.py, by
+tests/gpu_diag.py which prints the whole table, and by __graft_entry__.smoke()).
+
+Tolerance (stated here once): the kernels take fp16 inputs and accumulate in fp32; the oracle is fp32 on the
+same (fp16-rounded) inputs.  A check passes when   max|hip - ref| <= TOL * max(1, max|ref|)   with
+TOL = 2e-3 (about two fp16 ulps at the output scale) for single kernels / blocks, and the looser, per-check
+values given below for deep stacks (every layer re-rounds its activations to fp16; the reference itself runs
+fp32).  Integer / index outputs (NMS keep sets, labels) must match exactly on well-separated inputs.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+TOL = 2e-3
+
+
+def _stat(name, got, ref, tol=TOL):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    err = (got - ref).abs().max().item() if ref.numel() else 0.0
+    scale = max(1.0, ref.abs().max().item() if ref.numel() else 1.0)
+    mean = (got - ref).abs().mean().item() if ref.numel() else 0.0
+    bad = not math.isfinite(err)
+    return {"name": name, "max_err": err, "mean_err": mean, "ref_absmax": scale, "norm_err": err / scale,
+            "tol": tol, "ok": (not bad) and err <= tol * scale}
+
+
+def _ref_attention(q, k, v, H, key_bias=None, scale=None, clamp=0.0):
+    B, Nq, HD = q.shape
+    D = HD // H
+    qh = q.float().reshape(B, Nq, H, D).transpose(1, 2)
+    kh = k.float().reshape(B, -1, H, D).transpose(1, 2)
+    vh = v.float().reshape(B, -1, H, D).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2) * (scale if scale is not None else D ** -0.5)
+    if clamp > 0:
+        s = s.clamp(-clamp, clamp)
+    if key_bias is not None:
+        s = s + key_bias[:, None, None, :]
+    return (s.softmax(-1) @ vh).transpose(1, 2).reshape(B, Nq, HD)
+
+
+def check_attention(dev, B, H, D, Nq, Nk, mask=False, clamp=0.0, nsplit=1, scale=None, big=False, seed=0):
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    amp = 4.0 if big else 1.0
+    q = (torch.randn(B, Nq, H * D, generator=g) * amp).half()
+    k = torch.randn(B, Nk, H * D, generator=g).half()
+    v = torch.randn(B, Nk, H * D, generator=g).half()
+    kb = None
+    if mask:
+        kb = torch.zeros(B, Nk)
+        for b in range(B):
+            kb[b, max(1, Nk // (b + 2)):] = -1e30
+    ref = _ref_attention(q, k, v, H, kb, scale, clamp)
+    pad = (-Nk) % 8
+    vt = F.pad(v, (0, 0, 0, pad)).transpose(1, 2).contiguous()
+    out = ops.attention(q.to(dev), k.to(dev), vt.to(dev), H, D, key_bias=kb.to(dev) if kb is not None else None,
+                        scale=scale, clamp=clamp, nsplit=nsplit, nk=Nk)
+    return _stat(f"attn D={D} H={H} Nq={Nq} Nk={Nk} mask={mask} clamp={clamp} nsplit={nsplit}", out, ref)
+
+
+def check_attention_strided(dev):
+    """q|k fused projection views (row stride 2C) as used by the BERT layers."""
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, T, H, D = 2, 256, 12, 64
+    qk = torch.randn(B, T, 2 * H * D, generator=g).half()
+    v = torch.randn(B, T, H * D, generator=g).half()
+    ref = _ref_attention(qk[:, :, :H * D], qk[:, :, H * D:], v, H)
+    qkd = qk.to(dev)
+    out = ops.attention(qkd[:, :, :H * D], qkd[:, :, H * D:], v.transpose(1, 2).contiguous().to(dev), H, D)
+    return _stat("attn strided q|k views (BERT)", out, ref)
+
+
+def _tiny(dev, image_hw=(160, 192), B=2, seed=0):
+    """Shared tiny model: oracle state dict + product model with the same weights."""
+    from oracle import tiny_spec
+    from oracle.weights import make_state_dict
+    from mq_det_amd import get_cfg
+    from mq_det_amd.modeling.detector import GeneralizedVLRCNN_New
+    spec = tiny_spec()
+    sd = make_state_dict(spec, seed)
+    cfg = get_cfg()
+    cfg.MODEL.SWINT.DEPTHS = spec.swin_depths
+    cfg.MODEL.LANGUAGE_BACKBONE.NUM_HIDDEN_LAYERS = spec.bert_layers
+    cfg.MODEL.LANGUAGE_BACKBONE.QV_START = spec.qv_start
+    cfg.MODEL.LANGUAGE_BACKBONE.VOCAB_SIZE = spec.vocab
+    cfg.MODEL.DYHEAD.NUM_CONVS = spec.dyhead_convs
+    cfg.MODEL.DYHEAD.NUM_CLASSES = spec.num_classes
+    cfg.MODEL.ATSS.DETECTIONS_PER_IMG = spec.detections_per_img
+    model = GeneralizedVLRCNN_New(cfg, tokenizer=object())
+    model.load_state_dict(sd, strict=True)
+    model.to(dev)
+    P = model.prepare(dev)
+    return spec, sd, cfg, model, P
+
+
+_CACHE = {}
+
+
+def tiny(dev):
+    if "tiny" not in _CACHE:
+        _CACHE["tiny"] = _tiny(dev)
+    return _CACHE["tiny"]
+
+
+def check_swin_fpn(dev):
+    from oracle import backbone as ob
+    from mq_det_amd.modeling import pipeline
+    spec, sd, cfg, model, P = tiny(dev)
+    img = torch.randn(2, 3, 90, 122, generator=torch.Generator().manual_seed(1)).half()
+    with torch.no_grad():
+        c = ob.swin_forward(sd, "backbone.body", img.float(), spec)
+        p = ob.fpn_forward(sd, "backbone.fpn", c)
+        x = img.to(dev).contiguous(memory_format=torch.channels_last)
+        cg = pipeline.swin_forward(P, cfg, x)
+        pg = pipeline.fpn_forward(P, cg)
+    out = [_stat(f"swin c{i + 3}", cg[i].permute(0, 3, 1, 2), c[i + 1], tol=1e-2) for i in range(3)]
+    out += [_stat(f"fpn p{i + 3}", pg[i], p[i], tol=1e-2) for i in range(5)]
+    return out
+
+
+def check_window_attention(dev):
+    """One Swin block's attention (shifted, H/W not multiples of 7) vs the oracle's window_attention path."""
+    from oracle import backbone as ob
+    from mq_det_amd import ops
+    spec, sd, cfg, model, P = tiny(dev)
+    res = []
+    for stage, (H, W) in ((0, (23, 31)), (1, (12, 16))):
+        C, heads, ws = spec.swin_dims[stage], spec.swin_heads[stage], spec.window
+        for shift in (0, ws // 2):
+            b = f"backbone.body.layers.{stage}.blocks.{1 if shift else 0}.attn"
+            g = torch.Generator().manual_seed(7 + shift)
+            y = torch.randn(2, H, W, C, generator=g).half()            # = norm1(x)
+            # oracle: pad, roll, partition, attention (without proj), reverse, roll back, crop
+            yf = y.float()
+            pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
+            yp = F.pad(yf, (0, 0, 0, pad_r, 0, pad_b))
+            Hp, Wp = H + pad_b, W + pad_r
+            if shift:
+                yp = torch.roll(yp, (-shift, -shift), (1, 2))
+            xw = ob.to_windows(yp, ws)
+            qkv = F.linear(xw, sd[b + ".qkv.weight"].half().float(), sd[b + ".qkv.bias"].half().float())
+            Bw, N, _ = qkv.shape
+            qkv = qkv.half().float().reshape(Bw, N, 3, heads, 32).permute(2, 0, 3, 1, 4)
+            attn = (qkv[0] * 32 ** -0.5) @ qkv[1].transpose(-1, -2)
+            bias = sd[b + ".relative_position_bias_table"][ob.rel_pos_index(ws).reshape(-1)].reshape(N, N, heads).permute(2, 0, 1)
+            attn = attn + bias[None]
+            if shift:
+                m = ob.shift_mask(Hp, Wp, ws, shift)
+                nW = m.shape[0]
+                attn = (attn.reshape(Bw // nW, nW, heads, N, N) + m[None, :, None]).reshape(Bw, heads, N, N)
+            o = (attn.softmax(-1) @ qkv[2]).transpose(1, 2).reshape(Bw, N, C)
+            o = ob.from_windows(o, ws, 2, Hp, Wp)
+            if shift:
+                o = torch.roll(o, (shift, shift), (1, 2))
+            ref = o[:, :H, :W]
+            qkv_dev = F.linear(y.to(dev), P[b + ".qkv.weight"], P[b + ".qkv.bias"]).reshape(2, H, W, 3 * C)
+            got = ops.window_attention(qkv_dev, P[b + ".qkv.bias"], P[b + ".rel_bias"], heads, ws, shift)
+            res.append(_stat(f"window_attn stage{stage} {H}x{W} shift={shift}", got, ref, tol=4e-3))
+    return res
+
+
+def _gcp_inputs(spec, T=40):
+    g = torch.Generator().manual_seed(11)
+    B, C = 2, spec.bert_hidden
+    x = torch.randn(B, T, C, generator=g).half()
+    vis = torch.randn(B, 15, C, generator=g).half()
+    vis[1, 10:] = 0
+    tok = {0: [2], 1: [5, 6, 7], 2: [10, 11]}
+    vmask = torch.zeros(B, 15, T)
+    idx = torch.full((B, T, 5), -1, dtype=torch.int32)
+    for lab, toks in tok.items():
+        for b in range(B):
+            if b == 1 and lab == 2:
+                continue
+            vmask[b, lab * 5:(lab + 1) * 5, toks] = 1
+            for t in toks:
+                idx[b, t] = torch.arange(lab * 5, lab * 5 + 5, dtype=torch.int32)
+    return x, vis, vmask, idx
+
+
+def check_gcp_block(dev):
+    from oracle import language as ol
+    from mq_det_amd.modeling import pipeline
+    spec, sd, cfg, model, P = tiny(dev)
+    x, vis, vmask, idx = _gcp_inputs(spec)
+    b = "language_backbone.body.model.encoder.qv_layer.0"
+    with torch.no_grad():
+        ref = ol.gated_cross_attention_block(sd, b, x.float(), vis.float(), vmask, spec)
+        got = pipeline.gcp_block(P, b, x.to(dev), vis.to(dev), idx.to(dev))
+        # exactly-zero cross attention for tokens without queries (quirk 5)
+        from mq_det_amd import ops
+        q = F.linear(pipeline._ln(P, b + ".attn.norm", x.to(dev)), P[b + ".attn.to_q.weight"])
+        kv = F.linear(pipeline._ln(P, b + ".attn.norm_kv", vis.to(dev)), P[b + ".attn.to_kv.weight"])
+        sup = ops.gcp_sparse_attention(q, kv, idx.to(dev))
+    noq = (vmask.sum(1) == 0)
+    z = _stat("gcp sparse attn: zero rows for tokens w/o query", sup.cpu()[noq], torch.zeros_like(sup.cpu()[noq]), tol=0.0)
+    return [_stat("gcp gated cross-attention block", got, ref, tol=6e-3), z]
+
+
+def check_pre_select(dev):
+    from oracle import language as ol
+    from mq_det_amd.modeling import pipeline
+    spec, sd, cfg, model, P = tiny(dev)
+    g = torch.Generator().manual_seed(12)
+    vis = torch.randn(2, 15, spec.fpn_out, generator=g).half()
+    img = torch.randn(2, 333, spec.fpn_out, generator=g).half()
+    p = "language_backbone.body.model.pre_select"
+    with torch.no_grad():
+        ref = ol.pre_select(sd, p, vis.float(), img.float(), spec)
+        got = pipeline.pre_select(P, p, vis.to(dev), img.to(dev), 1.0)
+    return _stat("gcp pre-select (2 layers, Nk=333 ragged)", got, ref, tol=1e-2)
+
+
+def check_bert_layer(dev, clamp):
+    from oracle import language as ol
+    from mq_det_amd.modeling import pipeline
+    spec, sd, cfg, model, P = tiny(dev)
+    g = torch.Generator().manual_seed(13)
+    T = 64
+    x = torch.randn(2, T, spec.bert_hidden, generator=g).half()
+    am = torch.ones(2, T, dtype=torch.long)
+    am[0, 25:] = 0
+    am[1, 50:] = 0
+    b = "rpn.head.dyhead_tower.1" if clamp else "language_backbone.body.model.encoder.layer.0"
+    with torch.no_grad():
+        ref = ol.bert_layer(sd, b, x.float(), ol.extended_mask(am), spec.bert_heads, spec.bert_eps, clamp=clamp)
+        kb = ((1.0 - am.float()) * -1e30).to(dev)
+        got = pipeline.bert_layer(P, b, x.to(dev), kb, clamp)
+    return _stat(f"bert layer clamp={clamp}", got, ref, tol=8e-3)
+
+
+def check_vl_fuse(dev):
+    from oracle import head as oh
+    from mq_det_amd.modeling import pipeline
+    spec, sd, cfg, model, P = tiny(dev)
+    g = torch.Generator().manual_seed(14)
+    sizes = [(20, 24), (10, 12), (5, 6), (3, 3), (2, 2)]
+    feats = [torch.randn(2, 256, h, w, generator=g).half() for h, w in sizes]
+    l = torch.randn(2, 64, spec.bert_hidden, generator=g).half()
+    am = torch.ones(2, 64, dtype=torch.long)
+    am[0, 30:] = 0
+    b = "rpn.head.dyhead_tower.0.b_attn"
+    with torch.no_grad():
+        rv, rl = oh.vl_fuse(sd, b, [f.float() for f in feats], l.float(), am, spec)
+        kb = ((1.0 - am.float()) * -1e30).to(dev)
+        gv, gl = pipeline.vl_fuse(P, b, [f.to(dev).contiguous(memory_format=torch.channels_last) for f in feats], l.to(dev), kb)
+    out = [_stat(f"vlfuse image side lvl{i}", gv[i], rv[i], tol=8e-3) for i in range(5)]
+    out.append(_stat("vlfuse text side", gl, rl, tol=8e-3))
+    return out
+
+
+def check_dcn(dev):
+    """HIP gather + GEMM vs oracle dcn_v2, incl. stride 2 and the flat-offset-indexing quirk (offsets from a
+    bigger level)."""
+    from oracle import head as oh
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(15)
+    res = []
+    for name, (H, W), (oH, oW), stride in (("same level s1", (13, 17), (13, 17), 1), ("from level-1 s2", (26, 33), (13, 17), 2),
+                                           ("from level+1 (quirk)", (7, 9), (13, 17), 1)):
+        x = torch.randn(2, 256, H, W, generator=g).half()
+        om = torch.randn(2, 27, oH, oW, generator=g) * 1.5
+        w = (torch.randn(256, 256, 3, 3, generator=g) / 48).half()
+        bias = torch.randn(256, generator=g).half()
+        ref = oh.dcn_v2(x.float(), om[:, :18], om[:, 18:].sigmoid(), w.float(), bias.float(), stride)
+        cols, (Ho, Wo) = ops.dcn_im2col(x.to(dev).permute(0, 2, 3, 1).contiguous(), om.to(dev).contiguous(), stride)
+        wp = w.permute(0, 2, 3, 1).reshape(256, -1).to(dev)
+        y = F.linear(cols, wp, bias.to(dev)).reshape(2, Ho, Wo, 256).permute(0, 3, 1, 2)
+        res.append(_stat(f"dcnv2 {name}", y, ref, tol=4e-3))
+    return res
+
+
+def check_dyconv(dev):
+    from oracle import head as oh
+    from mq_det_amd.modeling import pipeline
+    spec, sd, cfg, model, P = tiny(dev)
+    g = torch.Generator().manual_seed(16)
+    sizes = [(20, 24), (10, 12), (5, 6), (3, 3), (2, 2)]
+    feats = [torch.randn(2, 256, h, w, generator=g).half() for h, w in sizes]
+    b = "rpn.head.dyhead_tower.2"
+    with torch.no_grad():
+        ref = oh.dyconv(sd, b, [f.float() for f in feats], spec)
+        got = pipeline.dyconv(P, cfg, b, [f.to(dev).contiguous(memory_format=torch.channels_last) for f in feats])
+    return [_stat(f"dyconv lvl{i}", got[i], ref[i], tol=1e-2) for i in range(5)]
+
+
+def check_nms(dev):
+    from oracle import postprocess as op
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(17)
+    res = []
+    for n in (0, 1, 63, 64, 65, 700, 4100):
+        B = 2
+        N = max(n, 1)
+        xy = torch.rand(B, N, 2, generator=g) * 300
+        wh = torch.rand(B, N, 2, generator=g) * 120 + 4
+        boxes = torch.cat([xy, xy + wh], -1)
+        scores = torch.rand(B, N, generator=g)
+        labels = torch.randint(1, 6, (B, N), generator=g).int()
+        order = torch.argsort(scores, 1, descending=True, stable=True)
+        boxes = torch.gather(boxes, 1, order[:, :, None].expand(-1, -1, 4)).contiguous()
+        labels = torch.gather(labels, 1, order).contiguous()
+        scores = torch.gather(scores, 1, order)
+        nvalid = torch.tensor([n, max(n - 7, 0)], dtype=torch.int32)
+        keep = ops.ml_nms(boxes.to(dev), labels.to(dev), nvalid.to(dev), 0.6).cpu()
+        ok = True
+        for b in range(B):
+            nv = int(nvalid[b])
+            ref = torch.zeros(N, dtype=torch.bool)
+            if nv:
+                ref[op.ml_nms(boxes[b, :nv], scores[b, :nv], labels[b, :nv].float(), 0.6)] = True
+            ok &= bool(torch.equal(ref, keep[b]))
+        res.append({"name": f"ml_nms n={n}", "max_err": 0.0 if ok else 1.0, "mean_err": 0.0, "ref_absmax": 1.0,
+                    "norm_err": 0.0 if ok else 1.0, "tol": 0.0, "ok": ok})
+    return res
+
+
+def make_inputs(spec, B=2, hw=((150, 190), (160, 170)), nvalid=30, seed=3):
+    from oracle import detector as od
+    from oracle.weights import make_query_bank
+    g = torch.Generator().manual_seed(seed)
+    imgs = [torch.randn(3, h, w, generator=g).half().float() for (h, w) in hw[:B]]
+    images, sizes = od.pad_images(imgs, spec.size_divisibility)
+    T = spec.max_query_len
+    ids = torch.zeros(B, T, dtype=torch.long)
+    ids[:, :nvalid] = torch.randint(1, spec.vocab, (nvalid,), generator=g)[None]
+    am = torch.zeros(B, T, dtype=torch.long)
+    am[:, :nvalid] = 1
+    pm = {1: [1], 2: [3, 4], 3: [6], 4: [8, 9, 10], 5: [12], 6: [14, 15]}
+    bank = make_query_bank(pm.keys(), spec)
+    return images, sizes, ids, am, pm, bank
+
+
+def check_full_model(dev):
+    """Whole forward, tiny-depth MQ-GLIP (real widths / head dims), fp16 HIP path vs fp32 oracle."""
+    from oracle import detector as od
+    from mq_det_amd.structures import ImageList
+    spec, sd, cfg, model, P = tiny(dev)
+    images, sizes, ids, am, pm, bank = make_inputs(spec)
+    model.load_query_bank(bank)
+    with torch.no_grad():
+        dets, inter = od.forward(sd, spec, images, sizes, ids, am, pm, bank, return_intermediates=True)
+        raw = model(ImageList(images.to(dev), sizes), captions=None, positive_map=pm, return_raw=True,
+                    input_ids=ids.to(dev), attention_mask=am.to(dev))
+    res = [_stat(f"full: fpn p{i + 3}", raw["feats"][i], inter["fpn"][i], tol=1.5e-2) for i in range(5)]
+    res.append(_stat("full: language hidden", raw["lang"]["hidden"], inter["lang"]["hidden"], tol=2e-2))
+    h = inter["head"]
+    res.append(_stat("full: head text hidden", raw["head"]["hidden"], h["hidden"], tol=3e-2))
+    nv = int(am[0].sum())
+    for l in range(5):
+        res.append(_stat(f"full: head feats lvl{l}", raw["head"]["feats"][l], h["feats"][l], tol=3e-2))
+        res.append(_stat(f"full: bbox_reg lvl{l}", raw["head"]["bbox_reg"][l], h["bbox_reg"][l], tol=3e-2))
+        res.append(_stat(f"full: centerness lvl{l}", raw["head"]["centerness"][l], h["centerness"][l], tol=3e-2))
+        logit = raw["head"]["dot"][l].float() + raw["head"]["tbias"][:, None, :]
+        res.append(_stat(f"full: dot logits lvl{l}", logit[:, :, :nv], h["dot_product_logits"][l][:, :, :nv], tol=3e-2))
+        cls_ref = torch.stack([h["dot_product_logits"][l].sigmoid()[:, :, torch.tensor(pm[k])].mean(-1) for k in pm], -1)
+        res.append(_stat(f"full: class scores lvl{l}", raw["post"]["cls"][l], cls_ref, tol=1e-2))
+    # final detections: match by IoU against the oracle's detections
+    post = raw["post"]
+    for b in range(len(dets)):
+        n = int(post["counts"][b])
+        gb, gs, gl = post["boxes"][b, :n].cpu(), post["scores"][b, :n].cpu(), post["labels"][b, :n].cpu()
+        rb, rs, rl = dets[b]["boxes"], dets[b]["scores"], dets[b]["labels"]
+        top = torch.argsort(rs, descending=True)[:50]
+        matched = 0
+        for i in top.tolist():
+            same = (gl == rl[i])
+            if not same.any():
+                continue
+            lt = torch.max(gb[:, :2], rb[i, :2])
+            br = torch.min(gb[:, 2:], rb[i, 2:])
+            inter_a = (br - lt + 1).clamp(min=0).prod(1)
+            a1 = (gb[:, 2] - gb[:, 0] + 1) * (gb[:, 3] - gb[:, 1] + 1)
+            a2 = (rb[i, 2] - rb[i, 0] + 1) * (rb[i, 3] - rb[i, 1] + 1)
+            iou = torch.where(same, inter_a / (a1 + a2 - inter_a), torch.zeros_like(a1))
+            j = int(iou.argmax())
+            if iou[j] > 0.9 and abs(float(gs[j] - rs[i])) < 0.02:
+                matched += 1
+        frac = matched / max(1, len(top))
+        res.append({"name": f"full: top-50 detections matched (IoU>0.9, |ds|<0.02) img{b} n_hip={n} n_ref={len(rb)}",
+                    "max_err": 1 - frac, "mean_err": 0.0, "ref_absmax": 1.0, "norm_err": 1 - frac, "tol": 0.2, "ok": frac >= 0.8})
+    return res
+
+
+def all_checks(dev):
+    """Every parity check, flattened (name -> result)."""
+    out = []
+    specs = [
+        dict(B=2, H=12, D=64, Nq=256, Nk=256, mask=True),
+        dict(B=2, H=12, D=64, Nq=256, Nk=256, mask=True, clamp=50000.0, big=True),
+        dict(B=1, H=8, D=32, Nq=200, Nk=5577, nsplit=4),
+        dict(B=1, H=8, D=32, Nq=37, Nk=61),
+        dict(B=1, H=8, D=256, Nq=1500, Nk=256, mask=True, clamp=50000.0, scale=1.0 / 16),
+        dict(B=1, H=8, D=256, Nq=256, Nk=1500, clamp=50000.0, scale=1.0 / 16, nsplit=3),
+        dict(B=1, H=2, D=256, Nq=130, Nk=22400, scale=1.0 / 16, nsplit=8),
+        dict(B=1, H=8, D=256, Nq=22400, Nk=256, mask=True, scale=1.0 / 16),
+    ]
+    for s in specs:
+        out.append(("attention", lambda s=s: check_attention(dev, **s)))
+    out += [("attention", lambda: check_attention_strided(dev)),
+            ("window_attn", lambda: check_window_attention(dev)),
+            ("swin_fpn", lambda: check_swin_fpn(dev)),
+            ("gcp", lambda: check_gcp_block(dev)),
+            ("gcp", lambda: check_pre_select(dev)),
+            ("bert", lambda: check_bert_layer(dev, False)),
+            ("bert", lambda: check_bert_layer(dev, True)),
+            ("vlfuse", lambda: check_vl_fuse(dev)),
+            ("dcn", lambda: check_dcn(dev)),
+            ("dyconv", lambda: check_dyconv(dev)),
+            ("nms", lambda: check_nms(dev)),
+            ("full", lambda: check_full_model(dev))]
+    return out

@@ -1,0 +1,114 @@
+"""CPU check of the product pipeline's HOST-SIDE glue (weight packing / folding, NHWC layouts, padding, index
+construction, post-processing plumbing) with the HIP entry points swapped for the test-only torch emulations of
+tests/ops_emulation.py, in fp32, against the oracle.  The kernels themselves are covered by -m gpu tests."""
+import os
+import sys
+import types
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ops_emulation as emu  # noqa: E402
+import parity_checks as pc   # noqa: E402
+
+from oracle import tiny_spec, detector as od  # noqa: E402
+from oracle.weights import make_state_dict    # noqa: E402
+from mq_det_amd import get_cfg                 # noqa: E402
+from mq_det_amd.modeling import pipeline       # noqa: E402
+from mq_det_amd.modeling.query_selector import QuerySelector, build_token_index  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def setup():
+    spec = tiny_spec()
+    sd = make_state_dict(spec, 0)
+    cfg = get_cfg()
+    cfg.MODEL.SWINT.DEPTHS = spec.swin_depths
+    cfg.MODEL.LANGUAGE_BACKBONE.NUM_HIDDEN_LAYERS = spec.bert_layers
+    cfg.MODEL.LANGUAGE_BACKBONE.QV_START = spec.qv_start
+    cfg.MODEL.LANGUAGE_BACKBONE.VOCAB_SIZE = spec.vocab
+    cfg.MODEL.DYHEAD.NUM_CONVS = spec.dyhead_convs
+    cfg.MODEL.DYHEAD.NUM_CLASSES = spec.num_classes
+    cfg.MODEL.ATSS.DETECTIONS_PER_IMG = spec.detections_per_img
+    P = pipeline.build_plan(sd, cfg, torch.device("cpu"), dtype=torch.float32)
+    return spec, sd, cfg, P
+
+
+@pytest.fixture()
+def emulated_ops(monkeypatch):
+    fake = types.SimpleNamespace(**{n: getattr(emu, n) for n in (
+        "attention", "window_attention", "gcp_sparse_attention", "gcp_gate_residual", "dcn_im2col", "align_scores",
+        "box_decode", "ml_nms")})
+    monkeypatch.setattr(pipeline, "ops", fake)
+    return fake
+
+
+def close(a, b, tol=2e-4):
+    a, b = a.float(), b.float()
+    err = (a - b).abs().max().item()
+    assert err <= tol * max(1.0, b.abs().max().item()), f"max err {err} vs scale {b.abs().max().item()}"
+
+
+def test_full_pipeline_glue(setup, emulated_ops):
+    spec, sd, cfg, P = setup
+    images, sizes, ids, am, pm, bank = pc.make_inputs(spec)
+    with torch.no_grad():
+        dets, inter = od.forward(sd, spec, images, sizes, ids, am, pm, bank, return_intermediates=True)
+        x = images.contiguous(memory_format=torch.channels_last)
+        feats = pipeline.fpn_forward(P, pipeline.swin_forward(P, cfg, x))
+        for a, b in zip(feats, inter["fpn"]):
+            close(a, b)
+        qs = QuerySelector(cfg)
+        qs.load_query_bank(bank)
+        labels = [k for k, v in pm.items() if len(v)]
+        vision, idx = qs.select([labels] * 2, [pm] * 2, ids.shape[1], torch.device("cpu"), torch.float32)
+        close(vision, inter["vision"], 0)
+        pooled = pipeline.pooled_fpn_tokens(feats)
+        close(pooled, inter["pooled"])
+        lang = pipeline.language_backbone(P, cfg, ids, am, vision, pooled, idx)
+        close(lang["hidden"], inter["lang"]["hidden"], 5e-4)
+        close(lang["embedded"], inter["lang"]["embedded"], 5e-4)
+        head = pipeline.vldyhead(P, cfg, feats, lang)
+        h = inter["head"]
+        close(head["hidden"], h["hidden"], 1e-3)
+        nv = int(am[0].sum())
+        for l in range(5):
+            close(head["feats"][l], h["feats"][l], 1e-3)
+            close(head["bbox_reg"][l], h["bbox_reg"][l], 1e-3)
+            close(head["centerness"][l], h["centerness"][l], 1e-3)
+            close((head["dot"][l] + head["tbias"][:, None])[:, :, :nv], h["dot_product_logits"][l][:, :, :nv], 2e-3)
+        anchors = pipeline.grid_anchors(P, [f.shape[-2:] for f in feats], cfg.MODEL.RPN.ANCHOR_STRIDE, torch.device("cpu"))
+        for a, b in zip(anchors, inter["anchors"]):
+            close(a, b, 0)
+        tokidx, label_ids = build_token_index(pm, labels, torch.device("cpu"))
+        # feed the ORACLE head outputs to the product post-processing -> detections must agree as sets
+        ohead = {"dot": [d - head["tbias"][:, None] for d in h["dot_product_logits"]], "tbias": head["tbias"],
+                 "bbox_reg": h["bbox_reg"], "centerness": h["centerness"]}
+        post = pipeline.postprocess(cfg, ohead, anchors, sizes, tokidx, label_ids)
+    for b, d in enumerate(dets):
+        n = int(post["counts"][b])
+        assert n == len(d["boxes"])
+        o = torch.argsort(d["scores"], descending=True, stable=True)
+        close(post["scores"][b, :n], d["scores"][o], 1e-5)
+        close(post["boxes"][b, :n], d["boxes"][o], 1e-4)
+        assert torch.equal(post["labels"][b, :n], d["labels"][o])
+
+
+def test_gcp_index_matches_reference_topk_trick(setup):
+    """The host-built gather index == the reference's mask -> topk index (modeling_bert_new.py:40-63)."""
+    from oracle.language import padded_nonzero_index
+    spec, sd, cfg, P = setup
+    images, sizes, ids, am, pm, bank = pc.make_inputs(spec)
+    qs = QuerySelector(cfg)
+    qs.load_query_bank(bank)
+    labels = list(pm)
+    vision, idx = qs.select([labels] * 2, [pm] * 2, ids.shape[1], torch.device("cpu"), torch.float32)
+    _, amap = od.labels_and_maps(pm, spec.max_query_len)
+    _, vmask = od.select_queries(bank, [labels] * 2, [amap] * 2, 5)
+    ref = padded_nonzero_index(vmask.transpose(2, 1))
+    V = vmask.shape[1]
+    ref = torch.where(ref == V, torch.full_like(ref, -1), ref)
+    assert torch.equal(ref.int(), idx)
+    q, m, _ = qs([labels] * 2, [amap] * 2)
+    assert torch.equal(m, vmask) and torch.equal(q, vision)
