@@ -65,6 +65,28 @@ int mq_gcp_gate_residual_fwd(const void* sup, const void* h, const void* w2, con
 int mq_dcn_im2col_fwd(const void* x, const float* om, void* cols, int B, int H, int W, int C, int oH, int oW,
                       int stride, void* stream);
 
+/* DyConv epilogue (GroupNorm(16) + bilinear up-sampling of the level+1 branch + scale attention + branch mean,
+ * then DYReLU), NHWC fp16 with fp32 statistics; C == 256.
+ *   mq_dyconv_stats : y [B,n,C] -> sums [B,C,3] fp32 += (sum, sum sq, weighted sum); wy [n/W], wx [W] fp32 give the
+ *                     per-pixel weights wy*wx (spatial mean of the up-sampled map) or NULL for 1/n.  Caller zeroes sums.
+ *   mq_dyconv_coef  : sums + GN gamma/beta fp16 [C] + AttnConv weight [C] / bias [1] fp32 -> coef [B,C,2] fp32
+ *                     (a*rstd*gamma, a*(beta - mean*rstd*gamma)), a = h_sigmoid(relu(w . pooled + b)) / nbranches.
+ *   mq_dyconv_fuse  : out [B,H*W,C] = sum_k coef_k[.,0]*y_k^ + coef_k[.,1], y_k^ = y_k or its bilinear
+ *                     (align_corners) sample from (hs_k, ws_k); pool [B,C] fp32 += sum_p out.  Caller zeroes pool.
+ *   mq_dyrelu_coef  : pool, fc.0 / fc.2 weights+biases fp16 -> coef [B,4,C] fp32 (a1,b1,a2,b2).
+ *   mq_dyrelu_apply : x [B,n,C] <- max(a1 x + b1, a2 x + b2) in place.
+ * Replaces DyConv.forward's post-conv part, maskrcnn_benchmark/modeling/rpn/vldyhead.py:148-152,224-242 and
+ *   DYReLU.forward, maskrcnn_benchmark/layers/dyrelu.py:78-112. */
+int mq_dyconv_stats(const void* y, float* sums, const float* wy, const float* wx, int B, int n, int W, int C, void* stream);
+int mq_dyconv_coef(const float* sums, const void* gamma, const void* beta, const float* attn_w, const float* attn_b,
+                   float* coef, int B, int n, int C, int G, float eps, int nbranches, void* stream);
+int mq_dyconv_fuse(const void* y0, const float* coef0, int hs0, int ws0, const void* y1, const float* coef1, int hs1,
+                   int ws1, const void* y2, const float* coef2, int hs2, int ws2, int nbranches, void* out, float* pool,
+                   int B, int H, int W, int C, void* stream);
+int mq_dyrelu_coef(const float* pool, const void* w0, const void* b0, const void* w2, const void* b2, float* coef,
+                   int B, int n, int C, void* stream);
+int mq_dyrelu_apply(void* x, const float* coef, int B, int n, int C, void* stream);
+
 /* Region-word alignment scores for the L labels of the caption.
  *   dot [B,HW,T] fp16, tbias [B,T] fp32, tokidx [L,MT] int32, ctr [B,HW] fp16 -> out [B,HW,L] fp32
  *   ((cls > thr) ? cls*sigmoid(ctr) : -1), cls_out [B,HW,L] fp32 optional.

@@ -42,6 +42,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   half_t* Ks = (half_t*)smem;              // [BN][KS]
   half_t* Vs = Ks + BN * KS;               // [D][VS]
   half_t* Ps = Vs + D * VS;                // [4][RB*16][PS]
+  constexpr bool QLDS = (D >= 256);        // D=256: Q fragments (64 VGPRs) live in LDS instead, see below
+  half_t* Qs = Ps + 4 * RB * 16 * PS;      // [BM][KS] when QLDS
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -59,14 +61,32 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const int t1 = min(ntiles, t0 + tps);
   const int row0 = blockIdx.x * BM + wave * (RB * 16);
 
-  half8 qf[RB][D / 32];
+  half8 qf[QLDS ? 1 : RB][QLDS ? 1 : D / 32];
+  if constexpr (QLDS) {
+    // the whole register file is needed for O (128 acc regs) + the prefetched K/V tile (64): park Q in LDS
+    constexpr int QCH = BM * (D / 8) / 256;
+    half8 qtmp[QCH];
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb) {
-    int row = min(row0 + rb * 16 + l15, p.Nq - 1);
+    for (int i = 0; i < QCH; ++i) {          // all loads in flight first, then the LDS stores
+      int c = tid + i * 256;
+      int row = min((int)blockIdx.x * BM + c / (D / 8), p.Nq - 1);
+      qtmp[i] = *(const half8*)(Q + (long)row * p.q_rs + (c % (D / 8)) * 8);
+    }
 #pragma unroll
-    for (int kk = 0; kk < D / 32; ++kk)
-      qf[rb][kk] = *(const half8*)(Q + (long)row * p.q_rs + kk * 32 + lg * 8);
+    for (int i = 0; i < QCH; ++i) {
+      int c = tid + i * 256;
+      *(half8*)(Qs + (c / (D / 8)) * KS + (c % (D / 8)) * 8) = qtmp[i];
+    }
+  } else {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      int row = min(row0 + rb * 16 + l15, p.Nq - 1);
+#pragma unroll
+      for (int kk = 0; kk < D / 32; ++kk)
+        qf[rb][kk] = *(const half8*)(Q + (long)row * p.q_rs + kk * 32 + lg * 8);
+    }
   }
+  const half_t* Qw = Qs + (wave * RB * 16) * KS;
   float4_ o[RB][D / 16];
   float m[RB][4], lsum[RB][4];
 #pragma unroll
@@ -77,24 +97,42 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     for (int r = 0; r < 4; ++r) { m[rb][r] = MQ_NEG_BIG; lsum[rb][r] = 0.f; }
   }
 
-  for (int t = t0; t < t1; ++t) {
-    __syncthreads();
-    // ---- stage K tile [64 keys][D] and Vt tile [D][64 keys] (16-byte coalesced chunks)
-    for (int c = tid; c < BN * (D / 8); c += 256) {
+  // ---- software pipeline: the global loads of tile t+1 are issued before the math of tile t and land in
+  // registers while the MFMAs run; they are committed to LDS at the top of the next iteration.  (v1 issued
+  // one load -> LDS store at a time: 16 exposed L2 round trips per tile, ~28k cycles vs ~2.5k of MFMA work.)
+  // Out-of-range keys are NOT zero-filled: addresses are clamped to valid data and the logits of those
+  // columns are forced to -1e30 below (P == 0 exactly), so they contribute nothing.
+  constexpr int NCH = (BN * (D / 8)) / 256;          // 16-byte chunks per thread per tile (K and V each)
+  static_assert((BN * (D / 8)) % 256 == 0, "tile chunks must divide the block");
+  half8 kreg[NCH], vreg[NCH];
+  const int vlast = ((p.Nk - 1) / 8) * 8;            // last valid 8-key chunk start of a Vt row
+  auto issue = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int c = tid + i * 256;
       int r = c / (D / 8), ch = c % (D / 8);
-      int key = t * BN + r;
-      half8 v = zero8();
-      if (key < p.Nk) v = *(const half8*)(K + (long)key * p.k_rs + ch * 8);
-      *(half8*)(Ks + r * KS + ch * 8) = v;
+      int key = min(t * BN + r, p.Nk - 1);
+      kreg[i] = *(const half8*)(K + (long)key * p.k_rs + ch * 8);
+      int d = c / (BN / 8), cv = c % (BN / 8);
+      int key0 = min(t * BN + cv * 8, vlast);
+      vreg[i] = *(const half8*)(Vt + (long)d * p.vt_rs + key0);
     }
-    for (int c = tid; c < D * (BN / 8); c += 256) {
-      int d = c / (BN / 8), ch = c % (BN / 8);
-      int key0 = t * BN + ch * 8;
-      half8 v = zero8();
-      if (key0 < p.Nk) v = *(const half8*)(Vt + (long)d * p.vt_rs + key0);
-      *(half8*)(Vs + d * VS + ch * 8) = v;
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int c = tid + i * 256;
+      *(half8*)(Ks + (c / (D / 8)) * KS + (c % (D / 8)) * 8) = kreg[i];
+      *(half8*)(Vs + (c / (BN / 8)) * VS + (c % (BN / 8)) * 8) = vreg[i];
     }
+  };
+  if (t0 < t1) issue(t0);
+
+  for (int t = t0; t < t1; ++t) {
+    __syncthreads();                                  // every wave is done reading the previous tiles
+    commit();
     __syncthreads();
+    if (t + 1 < t1) issue(t + 1);
 
     // ---- S = Q K^T  (RB x 4 blocks of 16x16 per wave)
     float4_ s[RB][4];
@@ -103,12 +141,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) s[rb][nb] = (float4_){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
+    for (int kk = 0; kk < D / 32; ++kk) {
+      half8 qa[RB];
 #pragma unroll
-      for (int kk = 0; kk < D / 32; ++kk) {
+      for (int rb = 0; rb < RB; ++rb) {
+        if constexpr (QLDS) qa[rb] = *(const half8*)(Qw + (rb * 16 + l15) * KS + kk * 32 + lg * 8);
+        else qa[rb] = qf[rb][kk];
+      }
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
         half8 kf = *(const half8*)(Ks + (nb * 16 + l15) * KS + kk * 32 + lg * 8);
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) s[rb][nb] = mfma16(qf[rb][kk], kf, s[rb][nb]);
+        for (int rb = 0; rb < RB; ++rb) s[rb][nb] = mfma16(qa[rb], kf, s[rb][nb]);
       }
     }
     // ---- scale / clamp / key bias / out-of-range keys
@@ -168,18 +212,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 
   // ---- epilogue
   if (p.nsplit == 1) {
-    half_t* O = p.o + (long)b * p.o_bs + h * D;
+    // transpose through LDS (the K/V tiles are dead) so that every row leaves as 16-byte coalesced stores
+    constexpr int OS = D + 8;
+    static_assert(4 * RB * 16 * OS <= BN * KS + D * VS + 4 * RB * 16 * PS + (QLDS ? 0 : 0), "O staging must fit in the LDS tiles");
+    __syncthreads();
+    half_t* Ow = Ks + wave * (RB * 16 * OS);
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int row = row0 + rb * 16 + lg * 4 + r;
-        if (row < p.Nq) {
-          float inv = 1.f / lsum[rb][r];
+        float inv = 1.f / lsum[rb][r];
 #pragma unroll
-          for (int db = 0; db < D / 16; ++db) O[(long)row * p.o_rs + db * 16 + l15] = (half_t)(o[rb][db][r] * inv);
-        }
+        for (int db = 0; db < D / 16; ++db)
+          Ow[(rb * 16 + lg * 4 + r) * OS + db * 16 + l15] = (half_t)(o[rb][db][r] * inv);
       }
+    wave_lds_fence();
+    half_t* O = p.o + (long)b * p.o_bs + h * D;
+    for (int c = lane; c < RB * 16 * (D / 8); c += 64) {
+      int rr = c / (D / 8), ch = c % (D / 8);
+      int row = row0 + rr;
+      if (row < p.Nq) *(half8*)(O + (long)row * p.o_rs + ch * 8) = *(const half8*)(Ow + rr * OS + ch * 8);
+    }
   } else {
     // workspace: [nsplit][B*H][Nq][D + 2] floats  (O unnormalised, then m, l)
     float* W = p.ws + ((long)split * gridDim.y + bh) * (long)p.Nq * (D + 2);
@@ -241,7 +294,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
 template <int D, int RB>
 static int launch_attn(const AttnParams& p, hipStream_t stream) {
   constexpr int BM = 4 * RB * 16, BN = 64;
-  constexpr size_t smem = (size_t)(BN * (D + 8) + D * (BN + 8) + 4 * RB * 16 * (BN + 8)) * sizeof(half_t);
+  constexpr size_t smem = (size_t)(BN * (D + 8) + D * (BN + 8) + 4 * RB * 16 * (BN + 8) + (D >= 256 ? BM * (D + 8) : 0)) * sizeof(half_t);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<D, RB>,

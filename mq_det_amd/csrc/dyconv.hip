@@ -1,0 +1,284 @@
+// DyConv epilogue kernels for gfx950 (HBM-bound, NHWC fp16, fp32 statistics).
+//
+// Reference: modeling/rpn/vldyhead.py:148-152 (GroupNorm(16) after each DCNv2), :224 (bilinear up-sampling,
+// align_corners=True, of the branch coming from level+1), :228-238 (scale attention: AvgPool -> 1x1 conv -> ReLU
+// -> h_sigmoid per branch, mean over branches) and layers/dyrelu.py:78-112 (DYReLU: global pool -> FC 256->64->1024
+// -> h_sigmoid -> max(a1 x + b1, a2 x + b2)).  In the reference (and in v1 of this repo) that is ~150 small
+// launches per DyConv layer and ~10 full passes over every feature map; torch's fp16 NHWC bilinear kernel alone
+// cost 14.5 ms / step.  Here:
+//   mq_dyconv_stats   one pass over a branch's DCN output y[B,n,C]: per-(b,c) sum, sum of squares and the
+//                     WEIGHTED sum that equals the spatial mean of the (optionally up-sampled) map;
+//   mq_dyconv_coef    per (b, branch): GroupNorm mean/rstd from the channel sums, GN affine folded with the
+//                     scale-attention scalar into  A[b,c], Bc[b,c]  (GN is affine per channel, so it commutes
+//                     with the bilinear interpolation and with the spatial mean);
+//   mq_dyconv_fuse    out[p,c] = sum_branches A*y^(p,c) + Bc  (y^ = y or its bilinear sample), plus the channel
+//                     sums of `out` for DyReLU's pooling -- one read of every branch, one write;
+//   mq_dyrelu_coef    the two tiny FCs + h_sigmoid -> per (b,c) a1,b1,a2,b2;
+//   mq_dyrelu_apply   out = max(a1 x + b1, a2 x + b2) in place.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------- stats
+// sums[b, c, 0..2] += (sum y, sum y^2, sum w_p y).  wy/wx == nullptr -> w_p = 1/n.
+__global__ __launch_bounds__(256) void dyconv_stats_kernel(const half_t* __restrict__ y, float* __restrict__ sums,
+                                                           const float* __restrict__ wy, const float* __restrict__ wx,
+                                                           int n, int W, int C, int rows_per_block) {
+  __shared__ float red[8][256 * 3 / 8 * 8];     // [row group][c0 lanes(32) * 8 ch * 3]  (C == 256 path)
+  const int b = blockIdx.y;
+  const int lane_c = threadIdx.x % (C / 8), rg = threadIdx.x / (C / 8);
+  const int nrg = 256 / (C / 8);
+  const int c0 = lane_c * 8;
+  const int p0 = blockIdx.x * rows_per_block;
+  const int p1 = min(n, p0 + rows_per_block);
+  float s1[8], s2[8], s3[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = s3[j] = 0.f;
+  const float inv_n = 1.f / (float)n;
+  for (int p = p0 + rg; p < p1; p += nrg) {
+    half8 v = *(const half8*)(y + ((long)b * n + p) * C + c0);
+    float w = wy ? wy[p / W] * wx[p % W] : inv_n;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = (float)v[j];
+      s1[j] += f; s2[j] += f * f; s3[j] += w * f;
+    }
+  }
+  float* r = &red[0][0] + (rg * (C / 8) + lane_c) * 24;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { r[j] = s1[j]; r[8 + j] = s2[j]; r[16 + j] = s3[j]; }
+  __syncthreads();
+  // thread t < C*3/... : reduce over row groups.  256 threads handle C*3 = 768 values -> 3 each
+  for (int idx = threadIdx.x; idx < (C / 8) * 24; idx += 256) {
+    int lc = idx / 24, k = idx % 24;
+    float acc = 0.f;
+    for (int g = 0; g < nrg; ++g) acc += (&red[0][0])[(g * (C / 8) + lc) * 24 + k];
+    int c = lc * 8 + (k % 8), which = k / 8;
+    atomicAdd(sums + ((long)b * C + c) * 3 + which, acc);
+  }
+}
+
+extern "C" int mq_dyconv_stats(const void* y, float* sums, const float* wy, const float* wx, int B, int n, int W, int C,
+                               void* stream) {
+  if (B <= 0 || n <= 0) return 0;
+  if (C != 256) return -1;
+  int rows = 256;
+  dim3 grid((n + rows - 1) / rows, B);
+  hipLaunchKernelGGL(dyconv_stats_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)y, sums, wy, wx, n, W, C, rows);
+  MQ_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- coef
+// one block (C threads) per batch element.  coef[b, c, 0] = a*rstd*gamma, coef[b, c, 1] = a*(beta - mean*rstd*gamma)
+// with a = h_sigmoid(relu(attn_w . pooled + attn_b)) / nbranches, pooled_c = GN affine of the weighted mean.
+__global__ void dyconv_coef_kernel(const float* __restrict__ sums, const half_t* __restrict__ gamma,
+                                   const half_t* __restrict__ beta, const float* __restrict__ attn_w,
+                                   const float* __restrict__ attn_b, float* __restrict__ coef, int n, int C, int G,
+                                   float eps, float inv_nbr) {
+  __shared__ float gs[64], gss[64];
+  __shared__ float dotp[256];
+  const int b = blockIdx.x, c = threadIdx.x;
+  const float* s = sums + ((long)b * C + c) * 3;
+  const int cpg = C / G;
+  if (c < G) { gs[c] = 0.f; gss[c] = 0.f; }
+  __syncthreads();
+  atomicAdd(&gs[c / cpg], s[0]);
+  atomicAdd(&gss[c / cpg], s[1]);
+  __syncthreads();
+  const float cnt = (float)n * cpg;
+  const float mean = gs[c / cpg] / cnt;
+  const float var = fmaxf(gss[c / cpg] / cnt - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + eps);
+  const float sc = rstd * (float)gamma[c];
+  const float sh = (float)beta[c] - mean * sc;
+  dotp[c] = attn_w[c] * (sc * s[2] + sh);          // s[2] = weighted spatial mean of y
+  __syncthreads();
+  for (int o = C / 2; o > 0; o >>= 1) {
+    if (c < o) dotp[c] += dotp[c + o];
+    __syncthreads();
+  }
+  float a = fmaxf(dotp[0] + attn_b[0], 0.f);
+  a = fminf(fmaxf(a + 3.f, 0.f), 6.f) / 6.f * inv_nbr;
+  coef[((long)b * C + c) * 2 + 0] = a * sc;
+  coef[((long)b * C + c) * 2 + 1] = a * sh;
+}
+
+extern "C" int mq_dyconv_coef(const float* sums, const void* gamma, const void* beta, const float* attn_w,
+                              const float* attn_b, float* coef, int B, int n, int C, int G, float eps, int nbranches,
+                              void* stream) {
+  if (B <= 0) return 0;
+  if (C != 256 || G > 64 || C % G) return -1;
+  hipLaunchKernelGGL(dyconv_coef_kernel, dim3(B), dim3(C), 0, (hipStream_t)stream, sums, (const half_t*)gamma,
+                     (const half_t*)beta, attn_w, attn_b, coef, n, C, G, eps, 1.f / (float)nbranches);
+  MQ_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- fuse
+struct FuseBranch {
+  const half_t* y;      // [B, hs*ws, C]
+  const float* coef;    // [B, C, 2]
+  int hs, ws;           // source dims; (hs, ws) == (H, W) -> direct, else bilinear align_corners=True
+};
+struct FuseParams {
+  FuseBranch br[3];
+  int nbr;
+  half_t* out;          // [B, H*W, C]
+  float* pool;          // [B, C] += sum_p out
+  int B, H, W, C, rows_per_block;
+};
+
+__global__ __launch_bounds__(256) void dyconv_fuse_kernel(FuseParams p) {
+  __shared__ float red[256 * 8];
+  const int b = blockIdx.y;
+  const int cpt = p.C / 8;
+  const int lane_c = threadIdx.x % cpt, rg = threadIdx.x / cpt, nrg = 256 / cpt;
+  const int c0 = lane_c * 8;
+  const int n = p.H * p.W;
+  const int p0 = blockIdx.x * p.rows_per_block, p1 = min(n, p0 + p.rows_per_block);
+  float A[3][8], Bc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) Bc[j] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (k < p.nbr) {
+      const float* cf = p.br[k].coef + ((long)b * p.C + c0) * 2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { A[k][j] = cf[j * 2]; Bc[j] += cf[j * 2 + 1]; }
+    }
+  }
+  float ps[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ps[j] = 0.f;
+  for (int pos = p0 + rg; pos < p1; pos += nrg) {
+    const int oy = pos / p.W, ox = pos % p.W;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = Bc[j];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (k >= p.nbr) break;
+      const FuseBranch& br = p.br[k];
+      const half_t* yb = br.y + (long)b * br.hs * br.ws * p.C + c0;
+      if (br.hs == p.H && br.ws == p.W) {
+        half8 v = *(const half8*)(yb + (long)pos * p.C);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += A[k][j] * (float)v[j];
+      } else {
+        const float sy = p.H > 1 ? (float)oy * (float)(br.hs - 1) / (float)(p.H - 1) : 0.f;
+        const float sx = p.W > 1 ? (float)ox * (float)(br.ws - 1) / (float)(p.W - 1) : 0.f;
+        const int y0 = min((int)sy, br.hs - 1), x0 = min((int)sx, br.ws - 1);
+        const int y1 = min(y0 + 1, br.hs - 1), x1 = min(x0 + 1, br.ws - 1);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        half8 v00 = *(const half8*)(yb + ((long)y0 * br.ws + x0) * p.C);
+        half8 v01 = *(const half8*)(yb + ((long)y0 * br.ws + x1) * p.C);
+        half8 v10 = *(const half8*)(yb + ((long)y1 * br.ws + x0) * p.C);
+        half8 v11 = *(const half8*)(yb + ((long)y1 * br.ws + x1) * p.C);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float v = (1.f - ly) * ((1.f - lx) * (float)v00[j] + lx * (float)v01[j]) +
+                    ly * ((1.f - lx) * (float)v10[j] + lx * (float)v11[j]);
+          acc[j] += A[k][j] * v;
+        }
+      }
+    }
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { o[j] = (half_t)acc[j]; ps[j] += (float)o[j]; }
+    *(half8*)(p.out + ((long)b * n + pos) * p.C + c0) = o;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[(rg * cpt + lane_c) * 8 + j] = ps[j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < p.C; c += 256) {
+    float acc = 0.f;
+    for (int g = 0; g < nrg; ++g) acc += red[(g * cpt + c / 8) * 8 + (c % 8)];
+    atomicAdd(p.pool + (long)b * p.C + c, acc);
+  }
+}
+
+extern "C" int mq_dyconv_fuse(const void* y0, const float* coef0, int hs0, int ws0, const void* y1, const float* coef1,
+                              int hs1, int ws1, const void* y2, const float* coef2, int hs2, int ws2, int nbranches,
+                              void* out, float* pool, int B, int H, int W, int C, void* stream) {
+  if (B <= 0) return 0;
+  if (C != 256 || nbranches < 1 || nbranches > 3) return -1;
+  FuseParams p;
+  p.br[0] = {(const half_t*)y0, coef0, hs0, ws0};
+  p.br[1] = {(const half_t*)y1, coef1, hs1, ws1};
+  p.br[2] = {(const half_t*)y2, coef2, hs2, ws2};
+  p.nbr = nbranches; p.out = (half_t*)out; p.pool = pool; p.B = B; p.H = H; p.W = W; p.C = C;
+  p.rows_per_block = 128;
+  dim3 grid((H * W + p.rows_per_block - 1) / p.rows_per_block, B);
+  hipLaunchKernelGGL(dyconv_fuse_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  MQ_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- DyReLU
+// one block (256 threads) per batch element: y = pool / n -> fc0 (C -> C/4) ReLU -> fc2 (C/4 -> 4C) -> h_sigmoid
+// coef[b, 0..3, c] = a1, b1, a2, b2  (lambda_a = 2, init_a = (1, 0), init_b = (0, 0))
+__global__ __launch_bounds__(256) void dyrelu_coef_kernel(const float* __restrict__ pool, const half_t* __restrict__ w0,
+                                                          const half_t* __restrict__ b0, const half_t* __restrict__ w2,
+                                                          const half_t* __restrict__ b2, float* __restrict__ coef, int n,
+                                                          int C) {
+  __shared__ float yv[256], hv[64];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int S = C / 4;
+  yv[t] = pool[(long)b * C + t] / (float)n;
+  __syncthreads();
+  if (t < S) {
+    float acc = (float)b0[t];
+    for (int c = 0; c < C; ++c) acc += (float)w0[t * C + c] * yv[c];
+    hv[t] = fmaxf(acc, 0.f);
+  }
+  __syncthreads();
+  for (int o = t; o < 4 * C; o += 256) {
+    float acc = (float)b2[o];
+    for (int k = 0; k < S; ++k) acc += (float)w2[o * S + k] * hv[k];
+    float hs = fminf(fmaxf(acc + 3.f, 0.f), 6.f) / 6.f;
+    int which = o / C, c = o % C;
+    float v = which == 0 ? (hs - 0.5f) * 2.f + 1.f : (which == 2 ? (hs - 0.5f) * 2.f : hs - 0.5f);
+    coef[((long)b * 4 + which) * C + c] = v;
+  }
+}
+
+extern "C" int mq_dyrelu_coef(const float* pool, const void* w0, const void* b0, const void* w2, const void* b2,
+                              float* coef, int B, int n, int C, void* stream) {
+  if (B <= 0) return 0;
+  if (C != 256) return -1;
+  hipLaunchKernelGGL(dyrelu_coef_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pool, (const half_t*)w0,
+                     (const half_t*)b0, (const half_t*)w2, (const half_t*)b2, coef, n, C);
+  MQ_CHECK_LAUNCH();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void dyrelu_apply_kernel(half_t* __restrict__ x, const float* __restrict__ coef, long n,
+                                                           int C) {
+  const int b = blockIdx.y;
+  const int cpt = C / 8;
+  const long total = n * cpt;
+  const float* cf = coef + (long)b * 4 * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c0 = (int)(i % cpt) * 8;
+    half_t* px = x + ((long)b * n + i / cpt) * C + c0;
+    half8 v = *(const half8*)px;
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = (float)v[j];
+      o[j] = (half_t)fmaxf(f * cf[c0 + j] + cf[C + c0 + j], f * cf[2 * C + c0 + j] + cf[3 * C + c0 + j]);
+    }
+    *(half8*)px = o;
+  }
+}
+
+extern "C" int mq_dyrelu_apply(void* x, const float* coef, int B, int n, int C, void* stream) {
+  if (B <= 0 || n <= 0) return 0;
+  if (C % 8) return -1;
+  long total = (long)n * (C / 8);
+  long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(dyrelu_apply_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, (half_t*)x, coef,
+                     (long)n, C);
+  MQ_CHECK_LAUNCH();
+  return 0;
+}

@@ -294,42 +294,59 @@ def vl_fuse(P, b, feats, hidden, key_bias):
     return out, l_new
 
 
-def _dcn_gn(P, cfg, b, k, x, om, stride):
-    """Conv3x3Norm(deformable) (vldyhead.py:148-152): DCNv2 = HIP gather + library GEMM, then GroupNorm(16)."""
-    x_nhwc = x.permute(0, 2, 3, 1)
-    cols, (Ho, Wo) = ops.dcn_im2col(x_nhwc.contiguous(), om, stride)
-    y = F.linear(cols, P[f"{b}.DyConv.{k}.packed"], P[f"{b}.DyConv.{k}.conv.bias"])      # [B, Ho*Wo, C]
-    y = y.reshape(x.shape[0], Ho, Wo, -1).permute(0, 3, 1, 2)
-    G = cfg.MODEL.GROUP_NORM
-    return F.group_norm(y, G.NUM_GROUPS, P[f"{b}.DyConv.{k}.bn.weight"], P[f"{b}.DyConv.{k}.bn.bias"], G.EPSILON)
+_UP_W = {}
+
+
+def _upsample_pool_weights(hs, ws, H, W, device):
+    """Per-source-pixel weights (wy[hs], wx[ws]) such that  mean_{H x W}(bilinear_up(y)) == sum wy*wx*y
+    (align_corners=True, F.upsample_bilinear semantics of vldyhead.py:224)."""
+    key = (hs, ws, H, W, device)
+    if key not in _UP_W:
+        def axis(n_src, n_dst):
+            w = torch.zeros(n_src, dtype=torch.float64)
+            for o in range(n_dst):
+                s = o * (n_src - 1) / (n_dst - 1) if n_dst > 1 else 0.0
+                i0 = min(int(s), n_src - 1)
+                i1 = min(i0 + 1, n_src - 1)
+                l = s - i0
+                w[i0] += 1 - l
+                w[i1] += l
+            return (w / n_dst).float().to(device)
+        _UP_W[key] = (axis(hs, H), axis(ws, W))
+    return _UP_W[key]
 
 
 def dyconv(P, cfg, b, feats):
-    """DyConv.forward (vldyhead.py:205-247) incl. offset re-use across levels, scale attention, DyReLU."""
+    """DyConv.forward (vldyhead.py:205-247).  Per level: 27-channel offset/mask conv (library), up to three DCNv2
+    branches = HIP gather + library GEMM, then the fused HIP epilogue (GroupNorm statistics, bilinear up-sampling of
+    the level+1 branch, scale attention, branch mean, DYReLU) -- offsets of the CURRENT level are re-used for all
+    three branches exactly like the reference (flat-index quirk handled inside the gather)."""
+    G = cfg.MODEL.GROUP_NORM
     out = []
+    nl = len(feats)
     for lvl, f in enumerate(feats):
+        Bn, C, H, W = f.shape
         om = F.conv2d(f, P[b + ".offset.weight"], P[b + ".offset.bias"], padding=1).float().contiguous()
-        br = [_dcn_gn(P, cfg, b, 1, f, om, 1)]
+        spec = [(1, f, 1)]
         if lvl > 0:
-            br.append(_dcn_gn(P, cfg, b, 2, feats[lvl - 1], om, 2))
-        if lvl < len(feats) - 1:
-            up = _dcn_gn(P, cfg, b, 0, feats[lvl + 1], om, 1)
-            br.append(F.interpolate(up, size=f.shape[-2:], mode="bilinear", align_corners=True))
-        acc = None
-        for t in br:
-            pooled = t.float().mean((2, 3))                                               # [B, C]
-            a = F.relu(pooled @ P[b + ".attn_w"] + P[b + ".attn_b"])                      # [B]
-            a = (F.relu6(a + 3) / 6 / len(br)).to(t.dtype)[:, None, None, None]
-            acc = t * a if acc is None else acc + t * a
-        out.append(acc)
-    res = []
-    for o in out:                                                                         # DYReLU, dyrelu.py:78-112
-        Bn, C = o.shape[:2]
-        y = o.float().mean((2, 3)).to(o.dtype)
-        y = F.relu6(_lin(P, b + ".relu.fc.2", F.relu(_lin(P, b + ".relu.fc.0", y))).float() + 3) / 6
-        a1, b1, a2, b2 = [t.to(o.dtype)[:, :, None, None] for t in torch.split(y, C, 1)]
-        res.append(torch.max(o * ((a1 - 0.5) * 2 + 1.0) + (b1 - 0.5), o * ((a2 - 0.5) * 2) + (b2 - 0.5)))
-    return res
+            spec.append((2, feats[lvl - 1], 2))
+        if lvl < nl - 1:
+            spec.append((0, feats[lvl + 1], 1))
+        branches = []
+        for k, x, stride in spec:
+            cols, (Ho, Wo) = ops.dcn_im2col(x.permute(0, 2, 3, 1).contiguous(), om, stride)
+            y = F.linear(cols, P[f"{b}.DyConv.{k}.packed"], P[f"{b}.DyConv.{k}.conv.bias"])          # [B, Ho*Wo, C]
+            wy = wx = None
+            if (Ho, Wo) != (H, W):
+                wy, wx = _upsample_pool_weights(Ho, Wo, H, W, y.device)
+            coef = ops.dyconv_branch_coef(y, Wo, P[f"{b}.DyConv.{k}.bn.weight"], P[f"{b}.DyConv.{k}.bn.bias"],
+                                          P[b + ".attn_w"], P[b + ".attn_b"], G.NUM_GROUPS, G.EPSILON, len(spec), wy, wx)
+            branches.append((y, coef, Ho, Wo))
+        o, pool = ops.dyconv_fuse(branches, H, W)
+        ops.dyrelu_(o, pool, P[b + ".relu.fc.0.weight"], P[b + ".relu.fc.0.bias"], P[b + ".relu.fc.2.weight"],
+                    P[b + ".relu.fc.2.bias"])
+        out.append(o.reshape(Bn, H, W, C).permute(0, 3, 1, 2))
+    return out
 
 
 def vldyhead(P, cfg, feats, lang):

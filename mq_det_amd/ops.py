@@ -21,6 +21,11 @@ _SIGNATURES = {
     "mq_gcp_sparse_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_gcp_gate_residual_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
     "mq_dcn_im2col_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "mq_dyconv_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mq_dyconv_coef": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "mq_dyconv_fuse": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mq_dyrelu_coef": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mq_dyrelu_apply": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "mq_align_scores_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "mq_box_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _vp]),
     "mq_ml_nms_workspace_bytes": (_l, [_i, _i]),
@@ -186,6 +191,57 @@ def dcn_im2col(x_nhwc, om, stride):
         _chk(lib.mq_dcn_im2col_fwd(_ptr(x_nhwc), _ptr(om), _ptr(cols), B, H, W, C, om.shape[2], om.shape[3], stride,
                                    _stream()), "mq_dcn_im2col_fwd")
     return cols, (Ho, Wo)
+
+
+def dyconv_branch_coef(y, Wsrc, gamma, beta, attn_w, attn_b, groups, eps, nbranches, wy=None, wx=None):
+    """y [B,n,C] fp16 (DCN output of one branch) -> coef [B,C,2] fp32 (GN affine x scale attention / nbranches)."""
+    lib = load_library()
+    _need_gpu(y, gamma, beta, attn_w, attn_b, wy, wx)
+    B, n, C = y.shape
+    assert y.is_contiguous() and y.dtype == torch.float16 and gamma.dtype == torch.float16
+    assert attn_w.dtype == torch.float32 and attn_b.dtype == torch.float32
+    sums = torch.zeros(B, C, 3, dtype=torch.float32, device=y.device)
+    coef = torch.empty(B, C, 2, dtype=torch.float32, device=y.device)
+    with _timed("dyconv_stats"):
+        _chk(lib.mq_dyconv_stats(_ptr(y), _ptr(sums), _ptr(wy), _ptr(wx), B, n, Wsrc, C, _stream()), "mq_dyconv_stats")
+    _chk(lib.mq_dyconv_coef(_ptr(sums), _ptr(gamma), _ptr(beta), _ptr(attn_w), _ptr(attn_b), _ptr(coef), B, n, C, groups,
+                            float(eps), nbranches, _stream()), "mq_dyconv_coef")
+    return coef
+
+
+def dyconv_fuse(branches, H, W):
+    """branches: list of (y [B,hs*ws,C], coef [B,C,2], hs, ws) -> out [B,H*W,C] fp16, pool [B,C] fp32."""
+    lib = load_library()
+    y0 = branches[0][0]
+    B, _, C = y0.shape
+    out = torch.empty(B, H * W, C, dtype=torch.float16, device=y0.device)
+    pool = torch.zeros(B, C, dtype=torch.float32, device=y0.device)
+    args = []
+    for k in range(3):
+        if k < len(branches):
+            y, cf, hs, ws = branches[k]
+            _need_gpu(y, cf)
+            assert y.is_contiguous() and cf.is_contiguous() and y.shape[1] == hs * ws
+            args += [_ptr(y), _ptr(cf), hs, ws]
+        else:
+            args += [_ptr(None), _ptr(None), 0, 0]
+    with _timed("dyconv_fuse"):
+        _chk(lib.mq_dyconv_fuse(*args, len(branches), _ptr(out), _ptr(pool), B, H, W, C, _stream()), "mq_dyconv_fuse")
+    return out, pool
+
+
+def dyrelu_(x, pool, w0, b0, w2, b2):
+    """In-place DYReLU on x [B,n,C] fp16 given pool [B,C] = sum over positions of x."""
+    lib = load_library()
+    _need_gpu(x, pool, w0, b0, w2, b2)
+    B, n, C = x.shape
+    assert x.is_contiguous() and w0.is_contiguous() and w2.is_contiguous() and w0.dtype == torch.float16
+    coef = torch.empty(B, 4, C, dtype=torch.float32, device=x.device)
+    _chk(lib.mq_dyrelu_coef(_ptr(pool), _ptr(w0), _ptr(b0), _ptr(w2), _ptr(b2), _ptr(coef), B, n, C, _stream()),
+         "mq_dyrelu_coef")
+    with _timed("dyrelu_apply"):
+        _chk(lib.mq_dyrelu_apply(_ptr(x), _ptr(coef), B, n, C, _stream()), "mq_dyrelu_apply")
+    return x
 
 
 def align_scores(dot, tbias, tokidx, ctr, thr, want_cls=False):

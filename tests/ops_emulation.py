@@ -151,3 +151,47 @@ def ml_nms(boxes, labels, nvalid, thresh):
             sc = torch.arange(nv, 0, -1).float()          # already sorted by score
             keep[b, ref(boxes[b, :nv], sc, labels[b, :nv].float(), thresh)] = True
     return keep
+
+
+def dyconv_branch_coef(y, Wsrc, gamma, beta, attn_w, attn_b, groups, eps, nbranches, wy=None, wx=None):
+    B, n, C = y.shape
+    yf = y.float()
+    g = yf.reshape(B, n, groups, C // groups)
+    mean = g.mean((1, 3))
+    var = g.var((1, 3), unbiased=False)
+    rstd = (var + eps).rsqrt()
+    mean_c = mean.repeat_interleave(C // groups, 1)
+    rstd_c = rstd.repeat_interleave(C // groups, 1)
+    sc = rstd_c * gamma.float()
+    sh = beta.float() - mean_c * sc
+    if wy is None:
+        wmean = yf.mean(1)
+    else:
+        w = (wy[:, None] * wx[None, :]).reshape(-1)
+        wmean = (yf * w[None, :, None]).sum(1)
+    pooled = sc * wmean + sh
+    a = F.relu6(F.relu(pooled @ attn_w + attn_b) + 3) / 6 / nbranches
+    return torch.stack([a[:, None] * sc, a[:, None] * sh], -1)
+
+
+def dyconv_fuse(branches, H, W):
+    B, _, C = branches[0][0].shape
+    acc = torch.zeros(B, H * W, C)
+    for y, cf, hs, ws in branches:
+        v = y.float().reshape(B, hs, ws, C).permute(0, 3, 1, 2)
+        if (hs, ws) != (H, W):
+            v = F.interpolate(v, size=(H, W), mode="bilinear", align_corners=True)
+        v = v.permute(0, 2, 3, 1).reshape(B, H * W, C)
+        acc = acc + v * cf[:, None, :, 0] + cf[:, None, :, 1]
+    out = acc.to(branches[0][0].dtype)
+    return out, out.float().sum(1)
+
+
+def dyrelu_(x, pool, w0, b0, w2, b2):
+    B, n, C = x.shape
+    y = pool / n
+    y = F.relu6(F.linear(F.relu(F.linear(y, w0.float(), b0.float())), w2.float(), b2.float()) + 3) / 6
+    a1, b1, a2, b2_ = torch.split(y, C, 1)
+    xf = x.float()
+    x.copy_(torch.max(xf * ((a1 - 0.5) * 2 + 1)[:, None] + (b1 - 0.5)[:, None], xf * ((a2 - 0.5) * 2)[:, None] + (b2_ - 0.5)[:, None]).to(x.dtype))
+    return x
