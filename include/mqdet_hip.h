@@ -20,9 +20,11 @@ int mq_abi_version(void);
 
 /* Fused multi-head attention forward  O = softmax(clamp(scale*Q.K^T, +-clamp) + key_bias) V,
  * fp16 in/out, fp32 accumulate; logits never leave the chip.  D in {32, 64, 256}.
- *   q  [B,Nq,*], k [B,Nk,*] (element (b,i,h,d) at base + b*bs + i*rs + h*D + d),
- *   vt [B,H*D,>=Nk] = V transposed (element (b,h,d,j) at vt + b*vt_bs + (h*D+d)*vt_rs + j; vt_rs % 8 == 0,
- *   columns Nk..ceil8(Nk) must be finite), o [B,Nq,*]; key_bias [B,Nk] fp32 or NULL; clamp <= 0 disables.
+ *   q, k: element (b,i,h,d) at base + b*bs + i*rs + h*hs + d (batch / row / head strides in elements; a head
+ *   stride of 0 shares the operand across heads -- used by the folded VLFuse projections),
+ *   vt = V transposed: element (b,h,d,j) at vt + b*vt_bs + h*vt_hs + d*vt_rs + j (strides % 8 == 0, columns
+ *   Nk..ceil8(Nk) must be finite), o [B,Nq,H*D] at o + b*o_bs + i*o_rs + h*D + d; key_bias fp32 (b,h,j) at
+ *   key_bias + b*bias_bs + h*bias_hs + j or NULL; clamp <= 0 disables.
  *   nsplit > 1 splits the key range over grid.z (few queries / many keys) and needs
  *   mq_attn_workspace_bytes() bytes of workspace.
  * Replaces the unfused bmm -> (+mask) -> softmax -> bmm chains of
@@ -32,8 +34,8 @@ int mq_abi_version(void);
 long mq_attn_workspace_bytes(int B, int H, int Nq, int D, int nsplit);
 int mq_attn_fwd(const void* q, const void* k, const void* vt, void* o, const float* key_bias, void* workspace,
                 int B, int H, int Nq, int Nk, int D,
-                long q_bs, long q_rs, long k_bs, long k_rs, long vt_bs, long vt_rs, long o_bs, long o_rs,
-                float scale, float clamp, int nsplit, void* stream);
+                long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long vt_bs, long vt_rs, long vt_hs,
+                long o_bs, long o_rs, long bias_bs, long bias_hs, float scale, float clamp, int nsplit, void* stream);
 
 /* Swin (shifted-)window attention with pad / roll / window partition folded into addressing.
  *   qkv [B,H,W,3C] fp16, qkv_bias [3C] fp16 (pad tokens), rel_bias [heads,N,N] fp32, out [B,H,W,C] fp16;

@@ -13,9 +13,10 @@
 // The QK^T logits never reach HBM (the reference materialises them: 183 MB / VLFuse layer / image).
 //
 // Layout (all "NT", i.e. K-contiguous for the MFMA fragments; see common.h):
-//   Q  : [B, Nq, *] halfs, element (b,i,h,d) at q  + b*q_bs  + i*q_rs  + h*D + d
-//   K  : [B, Nk, *]                           k  + b*k_bs  + j*k_rs  + h*D + d
-//   Vt : [B, H*D, >=Nk] (V transposed)         vt + b*vt_bs + (h*D+d)*vt_rs + j     (vt_rs % 8 == 0)
+//   Q  : element (b,i,h,d) at q  + b*q_bs  + i*q_rs + h*q_hs + d     (q_hs = 0: one Q shared by all heads)
+//   K  : element (b,j,h,d) at k  + b*k_bs  + j*k_rs + h*k_hs + d
+//   Vt : V transposed, element (b,h,d,j) at vt + b*vt_bs + h*vt_hs + d*vt_rs + j     (strides % 8 == 0)
+//   key_bias : fp32 (b,h,j) at key_bias + b*bias_bs + h*bias_hs + j
 //   O  : [B, Nq, *]                           o  + b*o_bs  + i*o_rs  + h*D + d
 // Work decomposition: grid = (ceil(Nq / BM), B*H, nsplit); a workgroup = 4 waves, each wave owns
 // RB*16 query rows and sweeps the keys in tiles of 64 staged through LDS (K tile [64][D+8],
@@ -29,7 +30,7 @@ struct AttnParams {
   const float* key_bias;     // [B, Nk] or nullptr
   float* ws;                 // split-K workspace or nullptr
   int B, H, Nq, Nk;
-  long q_bs, q_rs, k_bs, k_rs, vt_bs, vt_rs, o_bs, o_rs;
+  long q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, vt_bs, vt_rs, vt_hs, o_bs, o_rs, bias_bs, bias_hs;
   float scale, clamp;
   int nsplit;
 };
@@ -49,10 +50,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const int l15 = lane & 15, lg = lane >> 4;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
   const int split = blockIdx.z;
-  const half_t* Q = p.q + (long)b * p.q_bs + h * D;
-  const half_t* K = p.k + (long)b * p.k_bs + h * D;
-  const half_t* Vt = p.vt + (long)b * p.vt_bs + (long)(h * D) * p.vt_rs;
-  const float* bias = p.key_bias ? p.key_bias + (long)b * p.Nk : nullptr;
+  // head strides are free parameters: 0 shares one operand across all heads (folded VLFuse projections)
+  const half_t* Q = p.q + (long)b * p.q_bs + (long)h * p.q_hs;
+  const half_t* K = p.k + (long)b * p.k_bs + (long)h * p.k_hs;
+  const half_t* Vt = p.vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+  const float* bias = p.key_bias ? p.key_bias + (long)b * p.bias_bs + (long)h * p.bias_hs : nullptr;
   half_t* Pw = Ps + wave * (RB * 16 * PS);
 
   const int ntiles = (p.Nk + BN - 1) / BN;
@@ -160,16 +162,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     for (int nb = 0; nb < 4; ++nb) {
       int key = t * BN + nb * 16 + l15;
       bool valid = key < p.Nk;
+      // key_bias carries a finite additive term (folded projection bias, added BEFORE the clamp like the
+      // reference's q.k logits) and/or the padding mask (<= -1e29 => the key is masked AFTER the clamp).
       float kb = (valid && bias) ? bias[key] : 0.f;
+      const bool masked = kb < -1.0e29f;
+      if (masked) kb = 0.f;
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = s[rb][nb][r] * p.scale;
+          float v = s[rb][nb][r] * p.scale + kb;
           if (p.clamp > 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
-          v += kb;
-          v = fmaxf(v, MQ_NEG_BIG);
-          s[rb][nb][r] = valid ? v : MQ_NEG_BIG;
+          s[rb][nb][r] = (valid && !masked) ? v : MQ_NEG_BIG;
         }
     }
     // ---- online softmax (rows live in the 16-lane groups), P -> per-wave LDS tile as fp16
@@ -319,17 +323,19 @@ extern "C" long mq_attn_workspace_bytes(int B, int H, int Nq, int D, int nsplit)
 
 extern "C" int mq_attn_fwd(const void* q, const void* k, const void* vt, void* o, const float* key_bias,
                            void* workspace, int B, int H, int Nq, int Nk, int D,
-                           long q_bs, long q_rs, long k_bs, long k_rs, long vt_bs, long vt_rs,
-                           long o_bs, long o_rs, float scale, float clamp, int nsplit, void* stream) {
+                           long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs,
+                           long vt_bs, long vt_rs, long vt_hs, long o_bs, long o_rs, long bias_bs, long bias_hs,
+                           float scale, float clamp, int nsplit, void* stream) {
   if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return 0;
   if (nsplit < 1) nsplit = 1;
   if (nsplit > 1 && workspace == nullptr) return -2;
-  if ((vt_rs % 8) || (q_rs % 8) || (k_rs % 8)) return -3;
+  if ((vt_rs % 8) || (q_rs % 8) || (k_rs % 8) || (q_hs % 8) || (k_hs % 8) || (vt_hs % 8)) return -3;
   AttnParams p;
   p.q = (const half_t*)q; p.k = (const half_t*)k; p.vt = (const half_t*)vt; p.o = (half_t*)o;
   p.key_bias = key_bias; p.ws = (float*)workspace;
   p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk;
-  p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.vt_bs = vt_bs; p.vt_rs = vt_rs;
+  p.q_bs = q_bs; p.q_rs = q_rs; p.q_hs = q_hs; p.k_bs = k_bs; p.k_rs = k_rs; p.k_hs = k_hs;
+  p.vt_bs = vt_bs; p.vt_rs = vt_rs; p.vt_hs = vt_hs; p.bias_bs = bias_bs; p.bias_hs = bias_hs;
   p.o_bs = o_bs; p.o_rs = o_rs; p.scale = scale; p.clamp = clamp; p.nsplit = nsplit;
   hipStream_t s = (hipStream_t)stream;
   switch (D) {

@@ -76,6 +76,17 @@ def build_plan(sd, cfg, device, dtype=torch.float16):
         P[b + ".ov.bias"] = (f32(b + ".attn.out_v_proj.bias") * gv).to(dtype)
         P[b + ".ol.weight"] = (f32(b + ".attn.out_l_proj.weight") * gl[:, None]).to(dtype)
         P[b + ".ol.bias"] = (f32(b + ".attn.out_l_proj.bias") * gl).to(dtype)
+        # folded projections (DESIGN.md "VLFuse folding"): the image tokens are never projected to 2048-d.
+        #   logits_h = LN(v) . (Wq_h^T k_h)          -> Wq8 [8, 256 hd, 256 in] folds into the (tiny) text keys
+        #   text side: sum_i P_h[t,i] (Wvv_h LN(v)_i + b) = Wvv_h (P_h^T LN(v))[t] + b, then out_l_proj and
+        #   the layer scale -> ONE static [768, 8*256] weight applied to the per-head pooled image features
+        P[b + ".Wq8"] = P[b + ".q.weight"].reshape(8, hd, -1).contiguous()
+        P[b + ".bq8"] = (f32(b + ".attn.v_proj.bias") * sc).reshape(8, hd).contiguous()
+        wol = (f32(b + ".attn.out_l_proj.weight") * gl[:, None]).reshape(-1, 8, hd)            # [768, h, e]
+        wvv = f32(b + ".attn.values_v_proj.weight").reshape(8, hd, -1)                          # [h, e, c]
+        P[b + ".olc.weight"] = torch.einsum("ohe,hec->ohc", wol, wvv).reshape(wol.shape[0], -1).to(dtype).contiguous()
+        P[b + ".olc.bias"] = (torch.einsum("ohe,he->o", wol, f32(b + ".attn.values_v_proj.bias").reshape(8, hd))
+                              + f32(b + ".attn.out_l_proj.bias") * gl).to(dtype)
         bert(f"rpn.head.dyhead_tower.{3 * i + 1}")
         b = f"rpn.head.dyhead_tower.{3 * i + 2}"
         for k in range(3):
@@ -265,28 +276,35 @@ def language_backbone(P, cfg, input_ids, attention_mask, vision, images, idx, wa
 def vl_fuse(P, b, feats, hidden, key_bias):
     """BiAttentionBlockForCheckpoint / BiMultiHeadAttention (fuse_helper.py:218-303,377-426): one set of logits,
     softmax over text for the image side and over image tokens for the text side -- two launches of the fused
-    attention kernel, logits never materialised (reference: 3 x [B*8, 22400, 256] fp32 tensors)."""
+    attention kernel; the logits are never materialised (reference: 3 x [B*8, 22400, 256] fp32 tensors) and, with
+    the projections folded into the text-side operands, neither are the [B, 22400, 2048] q / value tensors:
+    the kernel reads LN(v) [B, N, 256] directly with a head stride of 0."""
     Bn = feats[0].shape[0]
     sizes = [f.shape[-2:] for f in feats]
     v = torch.cat([f.permute(0, 2, 3, 1).flatten(1, 2) for f in feats], 1)              # [B, N, 256]
-    N = v.shape[1]
-    pad = (-N) % 8
+    N, C = v.shape[1], v.shape[2]
     v_ln = _ln(P, b + ".layer_norm_v", v)
     l_ln = _ln(P, b + ".layer_norm_l", hidden)
+    pad = (-N) % 8
     v_pad = F.pad(v_ln, (0, 0, 0, pad)) if pad else v_ln
     a = b + ".attn"
-    q = _lin(P, b + ".q", v_ln)                                                          # [B, N, 2048], pre-scaled
-    k = _lin(P, a + ".l_proj", l_ln)                                                     # [B, T, 2048]
+    T = l_ln.shape[1]
+    k8 = _lin(P, a + ".l_proj", l_ln).reshape(Bn, T, 8, -1)                              # [B, T, 8, 256]
+    kf = torch.matmul(k8.permute(0, 2, 1, 3), P[b + ".Wq8"][None])                       # [B, 8, T, 256 in]
+    kf4 = kf.permute(0, 2, 1, 3)                                                         # [B, T, 8, 256] view
+    bias = torch.einsum("bthd,hd->bht", k8.float(), P[b + ".bq8"]) + key_bias[:, None, :]        # [B, 8, T] fp32
     val_l_t = torch.baddbmm(P[a + ".values_l_proj.bias"][None, :, None],
                             P[a + ".values_l_proj.weight"][None].expand(Bn, -1, -1), l_ln.transpose(1, 2))
-    val_v_t = torch.baddbmm(P[a + ".values_v_proj.bias"][None, :, None],
-                            P[a + ".values_v_proj.weight"][None].expand(Bn, -1, -1), v_pad.transpose(1, 2))
-    out_v = ops.attention(q, k, val_l_t, 8, 256, key_bias=key_bias, scale=1.0, clamp=50000.0)
-    T = k.shape[1]
-    out_l = ops.attention(k, q, val_v_t, 8, 256, scale=1.0, clamp=50000.0, nk=N,
-                          nsplit=_nsplit(-(-T // 128) * Bn * 8, -(-N // 64)))
+    # image side: queries = LN(v) shared by the 8 heads, keys = folded text keys, values = text values
+    out_v = ops.attention4(v_ln[:, :, None, :].expand(Bn, N, 8, C), kf4, val_l_t.reshape(Bn, 8, -1, T),
+                           key_bias=bias.contiguous(), scale=1.0, clamp=50000.0)
+    # text side: queries = folded text keys, keys = values = LN(v) (shared by the heads)
+    v_t = v_pad.transpose(1, 2).contiguous()                                             # [B, 256, N_pad]
+    out_l = ops.attention4(kf4, v_pad[:, :, None, :].expand(Bn, v_pad.shape[1], 8, C),
+                           v_t[:, None].expand(Bn, 8, C, v_t.shape[2]), scale=1.0, clamp=50000.0, nk=N,
+                           nsplit=_nsplit(-(-T // 128) * Bn * 8, -(-N // 64)))
     v_new = v_ln + _lin(P, b + ".ov", out_v)                                             # residual on the NORMED v, l
-    l_new = l_ln + _lin(P, b + ".ol", out_l)
+    l_new = l_ln + _lin(P, b + ".olc", out_l)
     out, s = [], 0
     for (hh, ww) in sizes:
         out.append(v_new[:, s:s + hh * ww].reshape(Bn, hh, ww, -1).contiguous().permute(0, 3, 1, 2))

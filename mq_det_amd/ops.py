@@ -16,7 +16,7 @@ _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 _SIGNATURES = {
     "mq_abi_version": (_i, []),
     "mq_attn_workspace_bytes": (_l, [_i, _i, _i, _i, _i]),
-    "mq_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _l, _l, _l, _f, _f, _i, _vp]),
+    "mq_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _i, _vp]),
     "mq_window_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_gcp_sparse_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_gcp_gate_residual_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
@@ -109,29 +109,49 @@ def _need_gpu(*ts):
             raise RuntimeError("mq_det_amd ops need GPU tensors: the hot path has no CPU fallback")
 
 
-def attention(q, k, vt, num_heads, head_dim, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None):
-    """q [B,Nq,H*D], k [B,Nk,H*D], vt [B,H*D,Nk_pad] (V transposed, Nk_pad % 8 == 0) fp16 -> [B,Nq,H*D] fp16."""
+def attention4(q4, k4, vt4, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None):
+    """General strided form.  q4 [B,Nq,H,D], k4 [B,Nk,H,D], vt4 [B,H,D,Nk_pad] fp16 views with unit last stride
+    (a head stride of 0, e.g. from .expand(), shares the operand across heads); key_bias None, [B,Nk] or [B,H,Nk]
+    fp32.  Returns [B,Nq,H*D] fp16."""
     lib = load_library()
-    _need_gpu(q, k, vt, key_bias)
-    B, Nq, HD = q.shape
-    Nk = k.shape[1] if nk is None else nk
-    H, D = num_heads, head_dim
-    assert HD == H * D and k.shape[2] == HD and vt.shape[1] == HD and vt.shape[2] >= Nk
-    assert q.dtype == k.dtype == vt.dtype == torch.float16
-    assert q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1
+    _need_gpu(q4, k4, vt4, key_bias)
+    B, Nq, H, D = q4.shape
+    Nk = k4.shape[1] if nk is None else nk
+    assert k4.shape[0] == B and k4.shape[2:] == (H, D) and vt4.shape[:3] == (B, H, D) and vt4.shape[3] >= Nk
+    assert q4.dtype == k4.dtype == vt4.dtype == torch.float16
+    assert q4.stride(3) == 1 and k4.stride(3) == 1 and vt4.stride(3) == 1
+    bias_bs = bias_hs = 0
     if key_bias is not None:
-        assert key_bias.dtype == torch.float32 and key_bias.shape == (B, Nk) and key_bias.is_contiguous()
-    o = torch.empty(B, Nq, HD, dtype=torch.float16, device=q.device)
+        assert key_bias.dtype == torch.float32 and key_bias.shape[-1] == Nk and key_bias.stride(-1) == 1
+        if key_bias.dim() == 2:
+            assert key_bias.shape == (B, Nk)
+            bias_bs = key_bias.stride(0)
+        else:
+            assert key_bias.shape == (B, H, Nk)
+            bias_bs, bias_hs = key_bias.stride(0), key_bias.stride(1)
+    o = torch.empty(B, Nq, H * D, dtype=torch.float16, device=q4.device)
     ws = None
     if nsplit > 1:
-        ws = torch.empty(lib.mq_attn_workspace_bytes(B, H, Nq, D, nsplit) // 4, dtype=torch.float32, device=q.device)
+        ws = torch.empty(lib.mq_attn_workspace_bytes(B, H, Nq, D, nsplit) // 4, dtype=torch.float32, device=q4.device)
     with _timed(f"attn_d{D}_nq{Nq}_nk{Nk}_s{nsplit}"):
-        rc = lib.mq_attn_fwd(_ptr(q), _ptr(k), _ptr(vt), _ptr(o), _ptr(key_bias), _ptr(ws), B, H, Nq, Nk, D,
-                             q.stride(0), q.stride(1), k.stride(0), k.stride(1), vt.stride(0), vt.stride(1),
-                             o.stride(0), o.stride(1), float(scale if scale is not None else 1.0 / math.sqrt(D)),
-                             float(clamp), int(nsplit), _stream())
+        rc = lib.mq_attn_fwd(_ptr(q4), _ptr(k4), _ptr(vt4), _ptr(o), _ptr(key_bias), _ptr(ws), B, H, Nq, Nk, D,
+                             q4.stride(0), q4.stride(1), q4.stride(2), k4.stride(0), k4.stride(1), k4.stride(2),
+                             vt4.stride(0), vt4.stride(2), vt4.stride(1), o.stride(0), o.stride(1), bias_bs, bias_hs,
+                             float(scale if scale is not None else 1.0 / math.sqrt(D)), float(clamp), int(nsplit), _stream())
     _chk(rc, "mq_attn_fwd")
     return o
+
+
+def attention(q, k, vt, num_heads, head_dim, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None):
+    """q [B,Nq,H*D], k [B,Nk,H*D], vt [B,H*D,Nk_pad] (V transposed, Nk_pad % 8 == 0) fp16 -> [B,Nq,H*D] fp16."""
+    B, Nq, HD = q.shape
+    H, D = num_heads, head_dim
+    assert HD == H * D and k.shape[2] == HD and vt.shape[1] == HD
+    assert q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1
+    q4 = q.as_strided((B, Nq, H, D), (q.stride(0), q.stride(1), D, 1), q.storage_offset())
+    k4 = k.as_strided((B, k.shape[1], H, D), (k.stride(0), k.stride(1), D, 1), k.storage_offset())
+    vt4 = vt.as_strided((B, H, D, vt.shape[2]), (vt.stride(0), D * vt.stride(1), vt.stride(1), 1), vt.storage_offset())
+    return attention4(q4, k4, vt4, key_bias, scale, clamp, nsplit, nk)
 
 
 def window_attention(qkv, qkv_bias, rel_bias, heads, ws, shift):

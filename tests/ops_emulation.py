@@ -28,6 +28,27 @@ def attention(q, k, vt, num_heads, head_dim, key_bias=None, scale=None, clamp=0.
     return (s.softmax(-1) @ vh).transpose(1, 2).reshape(B, Nq, HD).to(q.dtype)
 
 
+def attention4(q4, k4, vt4, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None):
+    B, Nq, H, D = q4.shape
+    Nk = k4.shape[1] if nk is None else nk
+    assert vt4.shape[3] % 8 == 0 and q4.stride(3) == 1 and k4.stride(3) == 1 and vt4.stride(3) == 1
+    for t in (q4, k4, vt4):
+        assert all(st % 8 == 0 for st in t.stride()[:-1])
+    qh = q4.float().permute(0, 2, 1, 3)
+    kh = k4.float()[:, :Nk].permute(0, 2, 1, 3)
+    vh = vt4.float()[..., :Nk].transpose(2, 3)
+    s = qh @ kh.transpose(-1, -2) * (scale if scale is not None else 1.0 / math.sqrt(D))
+    if key_bias is not None:
+        kb = key_bias if key_bias.dim() == 3 else key_bias[:, None, :]
+        masked = kb < -1e29
+        s = s + torch.where(masked, torch.zeros_like(kb), kb)[:, :, None, :]
+    if clamp > 0:
+        s = s.clamp(-clamp, clamp)
+    if key_bias is not None:
+        s = s.masked_fill(masked[:, :, None, :].expand_as(s), -1e30)
+    return (s.softmax(-1) @ vh).transpose(1, 2).reshape(B, Nq, H * D).to(q4.dtype)
+
+
 def window_attention(qkv, qkv_bias, rel_bias, heads, ws, shift):
     B, H, W, C3 = qkv.shape
     C = C3 // 3

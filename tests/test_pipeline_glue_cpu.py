@@ -38,7 +38,7 @@ def setup():
 @pytest.fixture()
 def emulated_ops(monkeypatch):
     fake = types.SimpleNamespace(**{n: getattr(emu, n) for n in (
-        "attention", "window_attention", "gcp_sparse_attention", "gcp_gate_residual", "dcn_im2col", "align_scores",
+        "attention", "attention4", "window_attention", "gcp_sparse_attention", "gcp_gate_residual", "dcn_im2col", "align_scores",
         "dyconv_branch_coef", "dyconv_fuse", "dyrelu_",
         "box_decode", "ml_nms")})
     monkeypatch.setattr(pipeline, "ops", fake)
