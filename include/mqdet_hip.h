@@ -69,12 +69,13 @@ int mq_dcn_im2col_fwd(const void* x, const float* om, void* cols, int B, int H, 
 
 /* DyConv epilogue (GroupNorm(16) + bilinear up-sampling of the level+1 branch + scale attention + branch mean,
  * then DYReLU), NHWC fp16 with fp32 statistics; C == 256.
- *   mq_dyconv_stats : y [B,n,C] -> sums [B,C,3] fp32 += (sum, sum sq, weighted sum); wy [n/W], wx [W] fp32 give the
- *                     per-pixel weights wy*wx (spatial mean of the up-sampled map) or NULL for 1/n.  Caller zeroes sums.
+ *   mq_dyconv_stats : y [B,n,C] -> sums [B,ceil(n/256),C,3] fp32 per-block partials (sum, sum sq, weighted sum; fixed
+ *                     reduction order = reproducible); wy [n/W], wx [W] fp32 give the per-pixel weights wy*wx
+ *                     (spatial mean of the up-sampled map) or NULL for 1/n.
  *   mq_dyconv_coef  : sums + GN gamma/beta fp16 [C] + AttnConv weight [C] / bias [1] fp32 -> coef [B,C,2] fp32
  *                     (a*rstd*gamma, a*(beta - mean*rstd*gamma)), a = h_sigmoid(relu(w . pooled + b)) / nbranches.
  *   mq_dyconv_fuse  : out [B,H*W,C] = sum_k coef_k[.,0]*y_k^ + coef_k[.,1], y_k^ = y_k or its bilinear
- *                     (align_corners) sample from (hs_k, ws_k); pool [B,C] fp32 += sum_p out.  Caller zeroes pool.
+ *                     (align_corners) sample from (hs_k, ws_k); pool [B,ceil(H*W/128),C] fp32 per-block sums of out.
  *   mq_dyrelu_coef  : pool, fc.0 / fc.2 weights+biases fp16 -> coef [B,4,C] fp32 (a1,b1,a2,b2).
  *   mq_dyrelu_apply : x [B,n,C] <- max(a1 x + b1, a2 x + b2) in place.
  * Replaces DyConv.forward's post-conv part, maskrcnn_benchmark/modeling/rpn/vldyhead.py:148-152,224-242 and

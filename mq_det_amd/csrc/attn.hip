@@ -130,41 +130,58 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   };
   if (t0 < t1) issue(t0);
 
+  constexpr float THR = 8.0f;     // deferred rescale: O / l are rescaled only when a row max grows by > THR
+
   for (int t = t0; t < t1; ++t) {
     __syncthreads();                                  // every wave is done reading the previous tiles
     commit();
     __syncthreads();
+    // key bias first (older in the VMEM queue than the prefetch below, so waiting for it does not drain the prefetch)
+    float kbias[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      int key = t * BN + nb * 16 + l15;
+      kbias[nb] = (bias && key < p.Nk) ? bias[key] : 0.f;
+    }
     if (t + 1 < t1) issue(t + 1);
 
-    // ---- S = Q K^T  (RB x 4 blocks of 16x16 per wave)
+    // ---- S = Q K^T  (RB x 4 blocks of 16x16 per wave).  LDS fragment reads are software-pipelined one
+    // k-step ahead of the MFMAs that consume them: with one wave per SIMD nothing else hides LDS latency.
     float4_ s[RB][4];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) s[rb][nb] = (float4_){0.f, 0.f, 0.f, 0.f};
+    {
+      half8 qa[2][RB], kf[2][4];
+      auto ld = [&](int kk, int buf) {
 #pragma unroll
-    for (int kk = 0; kk < D / 32; ++kk) {
-      half8 qa[RB];
+        for (int rb = 0; rb < RB; ++rb) {
+          if constexpr (QLDS) qa[buf][rb] = *(const half8*)(Qw + (rb * 16 + l15) * KS + kk * 32 + lg * 8);
+          else qa[buf][rb] = qf[rb][kk];
+        }
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) {
-        if constexpr (QLDS) qa[rb] = *(const half8*)(Qw + (rb * 16 + l15) * KS + kk * 32 + lg * 8);
-        else qa[rb] = qf[rb][kk];
-      }
+        for (int nb = 0; nb < 4; ++nb) kf[buf][nb] = *(const half8*)(Ks + (nb * 16 + l15) * KS + kk * 32 + lg * 8);
+      };
+      ld(0, 0);
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) {
-        half8 kf = *(const half8*)(Ks + (nb * 16 + l15) * KS + kk * 32 + lg * 8);
+      for (int kk = 0; kk < D / 32; ++kk) {
+        const int cur = kk & 1;
+        if (kk + 1 < D / 32) ld(kk + 1, cur ^ 1);
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) s[rb][nb] = mfma16(qa[rb], kf, s[rb][nb]);
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) s[rb][nb] = mfma16(qa[cur][rb], kf[cur][nb], s[rb][nb]);
       }
     }
-    // ---- scale / clamp / key bias / out-of-range keys
+    // ---- scale / key bias / clamp / masks
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
       int key = t * BN + nb * 16 + l15;
       bool valid = key < p.Nk;
       // key_bias carries a finite additive term (folded projection bias, added BEFORE the clamp like the
       // reference's q.k logits) and/or the padding mask (<= -1e29 => the key is masked AFTER the clamp).
-      float kb = (valid && bias) ? bias[key] : 0.f;
+      float kb = kbias[nb];
       const bool masked = kb < -1.0e29f;
       if (masked) kb = 0.f;
 #pragma unroll
@@ -176,40 +193,66 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
           s[rb][nb][r] = (valid && !masked) ? v : MQ_NEG_BIG;
         }
     }
-    // ---- online softmax (rows live in the 16-lane groups), P -> per-wave LDS tile as fp16
+    // ---- online softmax with deferred rescale: the decision is taken BEFORE this tile's P is exponentiated and
+    // after the previous tile's P.V has been fully accumulated, so O, l and P always share one reference max.
+    float mx[RB][4];
+    bool grow = false;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float mx = fmaxf(fmaxf(s[rb][0][r], s[rb][1][r]), fmaxf(s[rb][2][r], s[rb][3][r]));
-        mx = group16_max(mx);
-        float mnew = fmaxf(m[rb][r], mx);
-        float alpha = __expf(m[rb][r] - mnew);
+        float v = fmaxf(fmaxf(s[rb][0][r], s[rb][1][r]), fmaxf(s[rb][2][r], s[rb][3][r]));
+        mx[rb][r] = group16_max(v);
+        grow |= mx[rb][r] > m[rb][r] + THR;
+      }
+    if (__any(grow)) {                                  // wave-uniform, rare after the first tiles
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float mnew = fmaxf(m[rb][r], mx[rb][r]);
+          float alpha = __expf(m[rb][r] - mnew);
+          lsum[rb][r] *= alpha;
+          m[rb][r] = mnew;
+#pragma unroll
+          for (int db = 0; db < D / 16; ++db) o[rb][db][r] *= alpha;
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
         float rs = 0.f;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-          float pv = __expf(s[rb][nb][r] - mnew);
+          float pv = __expf(s[rb][nb][r] - m[rb][r]);      // <= e^THR, exact softmax after the final 1/l
           rs += pv;
           Pw[(rb * 16 + lg * 4 + r) * PS + nb * 16 + l15] = (half_t)pv;
         }
-        rs = group16_sum(rs);
-        lsum[rb][r] = lsum[rb][r] * alpha + rs;
-        m[rb][r] = mnew;
-#pragma unroll
-        for (int db = 0; db < D / 16; ++db) o[rb][db][r] *= alpha;
+        lsum[rb][r] += group16_sum(rs);
       }
     wave_lds_fence();
-    // ---- O += P V   (A = P from LDS, B = V from the transposed tile)
+    // ---- O += P V   (A = P from LDS, B = V from the transposed tile), V fragments prefetched 4 blocks ahead
 #pragma unroll
     for (int kk = 0; kk < BN / 32; ++kk) {
       half8 pf[RB];
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) pf[rb] = *(const half8*)(Pw + (rb * 16 + l15) * PS + kk * 32 + lg * 8);
+      constexpr int G = (D / 16) < 4 ? (D / 16) : 4, NG = (D / 16) / G;
+      half8 vf[2][G];
+      auto ldv = [&](int g, int buf) {
 #pragma unroll
-      for (int db = 0; db < D / 16; ++db) {
-        half8 vf = *(const half8*)(Vs + (db * 16 + l15) * VS + kk * 32 + lg * 8);
+        for (int i = 0; i < G; ++i) vf[buf][i] = *(const half8*)(Vs + ((g * G + i) * 16 + l15) * VS + kk * 32 + lg * 8);
+      };
+      ldv(0, 0);
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) o[rb][db] = mfma16(pf[rb], vf, o[rb][db]);
+      for (int g = 0; g < NG; ++g) {
+        const int cur = g & 1;
+        if (g + 1 < NG) ldv(g + 1, cur ^ 1);
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) o[rb][g * G + i] = mfma16(pf[rb], vf[cur][i], o[rb][g * G + i]);
       }
     }
   }

@@ -18,7 +18,8 @@
 #include "common.h"
 
 // ---------------------------------------------------------------------------------------------- stats
-// sums[b, c, 0..2] += (sum y, sum y^2, sum w_p y).  wy/wx == nullptr -> w_p = 1/n.
+// part[b, blk, c, 0..2] = per-block (sum y, sum y^2, sum w_p y); wy/wx == nullptr -> w_p = 1/n.  Partials (not atomics)
+// keep the reduction order fixed -> bitwise reproducible statistics.
 __global__ __launch_bounds__(256) void dyconv_stats_kernel(const half_t* __restrict__ y, float* __restrict__ sums,
                                                            const float* __restrict__ wy, const float* __restrict__ wx,
                                                            int n, int W, int C, int rows_per_block) {
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void dyconv_stats_kernel(const half_t* __restr
     float acc = 0.f;
     for (int g = 0; g < nrg; ++g) acc += (&red[0][0])[(g * (C / 8) + lc) * 24 + k];
     int c = lc * 8 + (k % 8), which = k / 8;
-    atomicAdd(sums + ((long)b * C + c) * 3 + which, acc);
+    sums[(((long)b * gridDim.x + blockIdx.x) * C + c) * 3 + which] = acc;
   }
 }
 
@@ -70,19 +71,27 @@ extern "C" int mq_dyconv_stats(const void* y, float* sums, const float* wy, cons
 // ---------------------------------------------------------------------------------------------- coef
 // one block (C threads) per batch element.  coef[b, c, 0] = a*rstd*gamma, coef[b, c, 1] = a*(beta - mean*rstd*gamma)
 // with a = h_sigmoid(relu(attn_w . pooled + attn_b)) / nbranches, pooled_c = GN affine of the weighted mean.
-__global__ void dyconv_coef_kernel(const float* __restrict__ sums, const half_t* __restrict__ gamma,
+__global__ void dyconv_coef_kernel(const float* __restrict__ part, int nblk, const half_t* __restrict__ gamma,
                                    const half_t* __restrict__ beta, const float* __restrict__ attn_w,
                                    const float* __restrict__ attn_b, float* __restrict__ coef, int n, int C, int G,
                                    float eps, float inv_nbr) {
+  __shared__ float cs[256], css[256];
   __shared__ float gs[64], gss[64];
   __shared__ float dotp[256];
   const int b = blockIdx.x, c = threadIdx.x;
-  const float* s = sums + ((long)b * C + c) * 3;
+  float s[3] = {0.f, 0.f, 0.f};
+  for (int k = 0; k < nblk; ++k) {                      // fixed order
+    const float* pp = part + (((long)b * nblk + k) * C + c) * 3;
+    s[0] += pp[0]; s[1] += pp[1]; s[2] += pp[2];
+  }
   const int cpg = C / G;
-  if (c < G) { gs[c] = 0.f; gss[c] = 0.f; }
+  cs[c] = s[0]; css[c] = s[1];
   __syncthreads();
-  atomicAdd(&gs[c / cpg], s[0]);
-  atomicAdd(&gss[c / cpg], s[1]);
+  if (c < G) {
+    float a0 = 0.f, a1 = 0.f;
+    for (int j = 0; j < cpg; ++j) { a0 += cs[c * cpg + j]; a1 += css[c * cpg + j]; }
+    gs[c] = a0; gss[c] = a1;
+  }
   __syncthreads();
   const float cnt = (float)n * cpg;
   const float mean = gs[c / cpg] / cnt;
@@ -107,7 +116,7 @@ extern "C" int mq_dyconv_coef(const float* sums, const void* gamma, const void* 
                               void* stream) {
   if (B <= 0) return 0;
   if (C != 256 || G > 64 || C % G) return -1;
-  hipLaunchKernelGGL(dyconv_coef_kernel, dim3(B), dim3(C), 0, (hipStream_t)stream, sums, (const half_t*)gamma,
+  hipLaunchKernelGGL(dyconv_coef_kernel, dim3(B), dim3(C), 0, (hipStream_t)stream, sums, (n + 255) / 256, (const half_t*)gamma,
                      (const half_t*)beta, attn_w, attn_b, coef, n, C, G, eps, 1.f / (float)nbranches);
   MQ_CHECK_LAUNCH();
   return 0;
@@ -123,7 +132,7 @@ struct FuseParams {
   FuseBranch br[3];
   int nbr;
   half_t* out;          // [B, H*W, C]
-  float* pool;          // [B, C] += sum_p out
+  float* pool;          // [B, nblk, C] per-block partial sums of out (fixed-order reduction in mq_dyrelu_coef)
   int B, H, W, C, rows_per_block;
 };
 
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(256) void dyconv_fuse_kernel(FuseParams p) {
   for (int c = threadIdx.x; c < p.C; c += 256) {
     float acc = 0.f;
     for (int g = 0; g < nrg; ++g) acc += red[(g * cpt + c / 8) * 8 + (c % 8)];
-    atomicAdd(p.pool + (long)b * p.C + c, acc);
+    p.pool[((long)b * gridDim.x + blockIdx.x) * p.C + c] = acc;
   }
 }
 
@@ -216,14 +225,17 @@ extern "C" int mq_dyconv_fuse(const void* y0, const float* coef0, int hs0, int w
 // ---------------------------------------------------------------------------------------------- DyReLU
 // one block (256 threads) per batch element: y = pool / n -> fc0 (C -> C/4) ReLU -> fc2 (C/4 -> 4C) -> h_sigmoid
 // coef[b, 0..3, c] = a1, b1, a2, b2  (lambda_a = 2, init_a = (1, 0), init_b = (0, 0))
-__global__ __launch_bounds__(256) void dyrelu_coef_kernel(const float* __restrict__ pool, const half_t* __restrict__ w0,
+__global__ __launch_bounds__(256) void dyrelu_coef_kernel(const float* __restrict__ pool, int nblk,
+                                                          const half_t* __restrict__ w0,
                                                           const half_t* __restrict__ b0, const half_t* __restrict__ w2,
                                                           const half_t* __restrict__ b2, float* __restrict__ coef, int n,
                                                           int C) {
   __shared__ float yv[256], hv[64];
   const int b = blockIdx.x, t = threadIdx.x;
   const int S = C / 4;
-  yv[t] = pool[(long)b * C + t] / (float)n;
+  float acc0 = 0.f;
+  for (int k = 0; k < nblk; ++k) acc0 += pool[((long)b * nblk + k) * C + t];
+  yv[t] = acc0 / (float)n;
   __syncthreads();
   if (t < S) {
     float acc = (float)b0[t];
@@ -245,7 +257,7 @@ extern "C" int mq_dyrelu_coef(const float* pool, const void* w0, const void* b0,
                               float* coef, int B, int n, int C, void* stream) {
   if (B <= 0) return 0;
   if (C != 256) return -1;
-  hipLaunchKernelGGL(dyrelu_coef_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pool, (const half_t*)w0,
+  hipLaunchKernelGGL(dyrelu_coef_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pool, (n + 127) / 128, (const half_t*)w0,
                      (const half_t*)b0, (const half_t*)w2, (const half_t*)b2, coef, n, C);
   MQ_CHECK_LAUNCH();
   return 0;

@@ -33,6 +33,8 @@ class GeneralizedVLRCNN_New(nn.Module):
         self._plan = None
         self._plan_key = None
         self._anchor_cache = {}
+        self._graphs, self._tok_cache, self._tokidx_cache, self._wh_cache = {}, {}, {}, {}
+        self.use_hip_graph = bool(cfg.MODEL.get("USE_HIP_GRAPH", True))
         self.eval()
 
     @staticmethod
@@ -50,6 +52,7 @@ class GeneralizedVLRCNN_New(nn.Module):
     def _invalidate(self):
         self._plan = None
         self._anchor_cache = {}
+        self._graphs = {}
 
     def load_state_dict(self, *a, **k):
         out = super().load_state_dict(*a, **k)
@@ -91,11 +94,69 @@ class GeneralizedVLRCNN_New(nn.Module):
         return labels_and_maps(positive_map, self.cfg.MODEL.LANGUAGE_BACKBONE.MAX_QUERY_LEN)
 
     def tokenize(self, captions, device):
-        LB = self.cfg.MODEL.LANGUAGE_BACKBONE
-        tok = self.tokenizer(list(captions), max_length=LB.MAX_QUERY_LEN,
-                             padding="max_length" if LB.PAD_MAX else "longest",
-                             return_special_tokens_mask=True, return_tensors="pt", truncation=True)
-        return tok["input_ids"].to(device, non_blocking=True), tok["attention_mask"].to(device, non_blocking=True)
+        """HF tokenizer on the host (generalized_vl_rcnn_new.py:378-383); memoised per caption tuple -- the LVIS
+        protocol re-sends the same 31 chunk captions for every image (engine/inference.py:605-625)."""
+        key = (tuple(captions), str(device))
+        hit = self._tok_cache.get(key)
+        if hit is None:
+            LB = self.cfg.MODEL.LANGUAGE_BACKBONE
+            tok = self.tokenizer(list(captions), max_length=LB.MAX_QUERY_LEN,
+                                 padding="max_length" if LB.PAD_MAX else "longest",
+                                 return_special_tokens_mask=True, return_tensors="pt", truncation=True)
+            hit = (tok["input_ids"].to(device), tok["attention_mask"].to(device))
+            if len(self._tok_cache) > 256:
+                self._tok_cache.clear()
+            self._tok_cache[key] = hit
+        return hit
+
+    # ------------------------------------------------------------------ device part (capturable in a HIP graph)
+    def _device_forward(self, x, input_ids, attention_mask, vision, idx, tokidx, label_ids, im_wh, want_raw=False):
+        P, cfg = self._plan, self.cfg
+        feats = pipeline.fpn_forward(P, pipeline.swin_forward(P, cfg, x))
+        pooled = pipeline.pooled_fpn_tokens(feats) if vision is not None else None
+        lang = pipeline.language_backbone(P, cfg, input_ids, attention_mask, vision, pooled, idx,
+                                          want_gates=cfg.VISION_QUERY.RETURN_ATTN_GATE_VALUE)
+        head = pipeline.vldyhead(P, cfg, feats, lang)
+        sizes = tuple(tuple(f.shape[-2:]) for f in feats)
+        if sizes not in self._anchor_cache:                       # constant per feature-map geometry
+            self._anchor_cache[sizes] = pipeline.grid_anchors(P, sizes, cfg.MODEL.RPN.ANCHOR_STRIDE, x.device)
+        anchors = self._anchor_cache[sizes]
+        post = pipeline.postprocess(cfg, head, anchors, im_wh, tokidx, label_ids, want_cls=want_raw)
+        if want_raw:
+            return {"post": post, "head": head, "lang": lang, "feats": feats, "anchors": anchors,
+                    "vision": vision, "idx": idx, "pooled": pooled}
+        packed = torch.cat([post["boxes"], post["scores"][..., None], post["labels"].float()[..., None]], -1)
+        return {"packed": packed, "counts": post["counts"], "feats": feats, "gates": lang["vision_query_gates"]}
+
+    def _graph_forward(self, key, inputs):
+        """Replay the whole device forward as ONE HIP graph (static shapes per key).  The eager forward issues
+        ~1500 launches per step and was host-bound by ~17 ms / step (profiles/r01_call3); a replay costs one launch.
+        First call with a key runs eagerly (library autotuning, caches), the second captures."""
+        ent = self._graphs.get(key)
+        if ent is None:
+            self._graphs[key] = {"stage": 1}
+            return self._device_forward(*inputs)
+        if ent["stage"] == 1:
+            static_in = [t.clone() if torch.is_tensor(t) else t for t in inputs]
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            try:
+                with torch.cuda.graph(g):
+                    static_out = self._device_forward(*static_in)
+            except Exception as e:                              # keep running eagerly, but say so loudly
+                import warnings
+                warnings.warn(f"mq_det_amd: HIP graph capture failed ({type(e).__name__}: {e}); staying eager")
+                self._graphs[key] = {"stage": -1}
+                torch.cuda.synchronize()
+                return self._device_forward(*inputs)
+            ent.update(stage=2, graph=g, inp=static_in, out=static_out)
+        if ent["stage"] == -1:
+            return self._device_forward(*inputs)
+        for dst, src in zip(ent["inp"], inputs):
+            if torch.is_tensor(dst):
+                dst.copy_(src, non_blocking=True)
+        ent["graph"].replay()
+        return ent["out"]
 
     @torch.no_grad()
     def forward(self, images, targets=None, captions=None, positive_map=None, greenlight_map=None,
@@ -110,46 +171,51 @@ class GeneralizedVLRCNN_New(nn.Module):
         dtype = P["backbone.body.patch_embed.proj.weight"].dtype
         x = images.tensors.to(dtype).contiguous(memory_format=torch.channels_last)
         Bn = x.shape[0]
-
-        feats = pipeline.fpn_forward(P, pipeline.swin_forward(P, cfg, x))
-
         if input_ids is None:
             input_ids, attention_mask = self.tokenize(captions, dev)
         T = input_ids.shape[1]
 
-        vision = idx = pooled = None
+        # host-side glue: all memoised, no device sync
         labels_in_caption = [k for k, v in positive_map.items() if len(v) != 0]
+        pm_key = tuple((k, tuple(positive_map[k])) for k in labels_in_caption)
+        vision = idx = None
         if cfg.VISION_QUERY.ENABLED and self.query_selector is not None and self.query_selector.query_bank is not None:
-            vision, idx = self.query_selector.select([labels_in_caption] * Bn, [positive_map] * Bn, T, dev, dtype)
-            pooled = pipeline.pooled_fpn_tokens(feats)
-        lang = pipeline.language_backbone(P, cfg, input_ids, attention_mask, vision, pooled, idx,
-                                          want_gates=cfg.VISION_QUERY.RETURN_ATTN_GATE_VALUE)
-        head = pipeline.vldyhead(P, cfg, feats, lang)
-
-        sizes = tuple(tuple(f.shape[-2:]) for f in feats)
-        if sizes not in self._anchor_cache:                       # constant per feature-map geometry
-            self._anchor_cache[sizes] = pipeline.grid_anchors(P, sizes, cfg.MODEL.RPN.ANCHOR_STRIDE, dev)
-        anchors = self._anchor_cache[sizes]
-        tokidx, label_ids = build_token_index(positive_map, labels_in_caption, dev)
-        post = pipeline.postprocess(cfg, head, anchors, images.image_sizes, tokidx, label_ids, want_cls=return_raw)
+            vision, idx = self.query_selector.select_cached(pm_key, labels_in_caption, positive_map, Bn, T, dev, dtype)
+        hit = self._tokidx_cache.get((pm_key, str(dev)))
+        if hit is None:
+            hit = self._tokidx_cache[(pm_key, str(dev))] = build_token_index(positive_map, labels_in_caption, dev)
+        tokidx, label_ids = hit
+        wh_key = (tuple(images.image_sizes), str(dev))
+        im_wh = self._wh_cache.get(wh_key)
+        if im_wh is None:
+            im_wh = self._wh_cache[wh_key] = torch.tensor([[w, h] for (h, w) in images.image_sizes],
+                                                          dtype=torch.float32, device=dev)
+        inputs = (x, input_ids, attention_mask, vision, idx, tokidx, label_ids, im_wh)
         if return_raw:
-            return {"post": post, "head": head, "lang": lang, "feats": feats, "anchors": anchors,
-                    "vision": vision, "idx": idx, "pooled": pooled}
+            return self._device_forward(*inputs, want_raw=True)
+        from .. import ops
+        use_graph = self.use_hip_graph and not ops.timing_active()
+        if use_graph:
+            key = (tuple(x.shape), T, None if vision is None else tuple(vision.shape), None if idx is None else tuple(idx.shape),
+                   tuple(tokidx.shape), wh_key)
+            out = self._graph_forward(key, inputs)
+        else:
+            out = self._device_forward(*inputs)
 
         # fixed-shape detections [B, K, 6] for the RCCL all-gather (mq_det_amd.parallel.gather_detections)
-        self.last_packed = torch.cat([post["boxes"], post["scores"][..., None], post["labels"].float()[..., None]], -1)
-        counts = post["counts"].tolist()                          # the one device->host sync of the forward
+        self.last_packed = packed = out["packed"]
+        counts = out["counts"].tolist()                           # the one device->host sync of the forward
         result = []
         for b, (h, w) in enumerate(images.image_sizes):
             n = counts[b]
-            bl = BoxList(post["boxes"][b, :n], (int(w), int(h)), mode="xyxy")
-            bl.add_field("labels", post["labels"][b, :n])
-            bl.add_field("scores", post["scores"][b, :n])
+            bl = BoxList(packed[b, :n, :4].clone(), (int(w), int(h)), mode="xyxy")
+            bl.add_field("labels", packed[b, :n, 5].to(torch.int64))
+            bl.add_field("scores", packed[b, :n, 4].clone())
             result.append(bl)
         if cfg.VISION_QUERY.RETURN_ATTN_GATE_VALUE:
-            return result, lang["vision_query_gates"]
+            return result, out["gates"]
         if return_backbone_features:
-            return result, [f.float().contiguous() for f in feats]
+            return result, [f.float().contiguous() for f in out["feats"]]
         return result
 
 

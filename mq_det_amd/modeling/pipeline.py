@@ -403,7 +403,7 @@ def grid_anchors(P, sizes, strides, device):
     return out
 
 
-def postprocess(cfg, head, anchors, image_sizes, tokidx, label_ids, want_cls=False):
+def postprocess(cfg, head, anchors, im_wh, tokidx, label_ids, want_cls=False):
     """ATSSPostProcessor.forward (rpn/inference.py:620-769) without per-image Python loops or host syncs:
     fixed-shape top-k per level, one sort, device-side NMS, fixed-shape top-`DETECTIONS_PER_IMG`.
     Returns boxes [B,K,4], scores [B,K] (<= 0 => empty slot), labels [B,K], counts [B] -- all on device."""
@@ -411,7 +411,8 @@ def postprocess(cfg, head, anchors, image_sizes, tokidx, label_ids, want_cls=Fal
     dev = head["tbias"].device
     Bn = head["tbias"].shape[0]
     L = tokidx.shape[0]
-    im_wh = torch.tensor([[w, h] for (h, w) in image_sizes], dtype=torch.float32, device=dev)
+    if not torch.is_tensor(im_wh):                       # list of (h, w) -> [B, 2] (w, h)
+        im_wh = torch.tensor([[w, h] for (h, w) in im_wh], dtype=torch.float32, device=dev)
     ks = [min(A.PRE_NMS_TOP_N, d.shape[1] * L) for d in head["dot"]]
     tot = sum(ks)
     boxes = torch.empty(Bn, tot, 4, dtype=torch.float32, device=dev)

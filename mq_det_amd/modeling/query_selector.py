@@ -39,6 +39,7 @@ class QuerySelector(nn.Module):
         self.num_query_per_class = cfg.VISION_QUERY.NUM_QUERY_PER_CLASS
         self.query_bank = None
         self._dev_bank = {}
+        self._sel_cache = {}
         path = cfg.VISION_QUERY.QUERY_BANK_PATH
         if path:
             if not os.path.exists(path):
@@ -49,6 +50,7 @@ class QuerySelector(nn.Module):
         """`bank`: path to a torch-saved dict or the dict itself: {label: Tensor[n, scales, C]}."""
         self.query_bank = torch.load(bank, map_location="cpu") if isinstance(bank, (str, os.PathLike)) else bank
         self._dev_bank = {}
+        self._sel_cache = {}
 
     def _rows(self, label, device, dtype):
         key = (label, device, dtype)
@@ -82,6 +84,16 @@ class QuerySelector(nn.Module):
                 if o:
                     idx[b, t, :len(o)] = torch.tensor(sorted(o), dtype=torch.int32)
         return vision.contiguous(), idx.to(device, non_blocking=True)
+
+    def select_cached(self, key, labels, positive_map, B, T, device, dtype):
+        """Memoised `select` for B images sharing one caption (eval protocol): no per-call host or device work."""
+        k = (key, B, T, str(device), dtype)
+        hit = self._sel_cache.get(k)
+        if hit is None:
+            if len(self._sel_cache) > 128:
+                self._sel_cache.clear()
+            hit = self._sel_cache[k] = self.select([labels] * B, [positive_map] * B, T, device, dtype)
+        return hit
 
     def forward(self, batched_label_list, batched_location_map, batched_pos_labels=None):
         """Reference-compatible output (queries, 0/1 attention masks [B,V,T], has_vision_query)."""

@@ -61,6 +61,10 @@ def _stream():
 _TIMING = None
 
 
+def timing_active():
+    return _TIMING is not None
+
+
 def start_timing():
     global _TIMING
     _TIMING = []
@@ -220,7 +224,7 @@ def dyconv_branch_coef(y, Wsrc, gamma, beta, attn_w, attn_b, groups, eps, nbranc
     B, n, C = y.shape
     assert y.is_contiguous() and y.dtype == torch.float16 and gamma.dtype == torch.float16
     assert attn_w.dtype == torch.float32 and attn_b.dtype == torch.float32
-    sums = torch.zeros(B, C, 3, dtype=torch.float32, device=y.device)
+    sums = torch.empty(B, (n + 255) // 256, C, 3, dtype=torch.float32, device=y.device)
     coef = torch.empty(B, C, 2, dtype=torch.float32, device=y.device)
     with _timed("dyconv_stats"):
         _chk(lib.mq_dyconv_stats(_ptr(y), _ptr(sums), _ptr(wy), _ptr(wx), B, n, Wsrc, C, _stream()), "mq_dyconv_stats")
@@ -235,7 +239,7 @@ def dyconv_fuse(branches, H, W):
     y0 = branches[0][0]
     B, _, C = y0.shape
     out = torch.empty(B, H * W, C, dtype=torch.float16, device=y0.device)
-    pool = torch.zeros(B, C, dtype=torch.float32, device=y0.device)
+    pool = torch.empty(B, (H * W + 127) // 128, C, dtype=torch.float32, device=y0.device)
     args = []
     for k in range(3):
         if k < len(branches):

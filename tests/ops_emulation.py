@@ -205,12 +205,12 @@ def dyconv_fuse(branches, H, W):
         v = v.permute(0, 2, 3, 1).reshape(B, H * W, C)
         acc = acc + v * cf[:, None, :, 0] + cf[:, None, :, 1]
     out = acc.to(branches[0][0].dtype)
-    return out, out.float().sum(1)
+    return out, out.float().sum(1, keepdim=True)          # [B, nblk=1, C]
 
 
 def dyrelu_(x, pool, w0, b0, w2, b2):
     B, n, C = x.shape
-    y = pool / n
+    y = pool.sum(1) / n
     y = F.relu6(F.linear(F.relu(F.linear(y, w0.float(), b0.float())), w2.float(), b2.float()) + 3) / 6
     a1, b1, a2, b2_ = torch.split(y, C, 1)
     xf = x.float()
