@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (for PMC profiling)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -126,6 +127,8 @@ def main():
     dev = torch.device("cuda", local)
     ops.load_library()
     cfg, model, caption, pmap = build_model(dev)
+    if args.no_graph:
+        model.use_hip_graph = False
 
     Bn = args.batch
     g = torch.Generator().manual_seed(1000 + rank)

@@ -24,7 +24,8 @@ int mq_abi_version(void);
  *   stride of 0 shares the operand across heads -- used by the folded VLFuse projections),
  *   vt = V transposed: element (b,h,d,j) at vt + b*vt_bs + h*vt_hs + d*vt_rs + j (strides % 8 == 0, columns
  *   Nk..ceil8(Nk) must be finite), o [B,Nq,H*D] at o + b*o_bs + i*o_rs + h*D + d; key_bias fp32 (b,h,j) at
- *   key_bias + b*bias_bs + h*bias_hs + j or NULL; clamp <= 0 disables.
+ *   key_bias + b*bias_bs + h*bias_hs + j or NULL; clamp <= 0 disables.  kv_len [B] int32 or NULL: keys >= kv_len[b]
+ *   are masked by the caller's key_bias (text padding) and their tiles are skipped (exactly-zero contribution).
  *   nsplit > 1 splits the key range over grid.z (few queries / many keys) and needs
  *   mq_attn_workspace_bytes() bytes of workspace.
  * Replaces the unfused bmm -> (+mask) -> softmax -> bmm chains of
@@ -32,7 +33,8 @@ int mq_abi_version(void);
  *   maskrcnn_benchmark/modeling/language_backbone/modeling_bert_new.py:204-240 (MaskedCrossAttention, dense),
  *   maskrcnn_benchmark/utils/fuse_helper.py:233-279 (BiMultiHeadAttention, both directions). */
 long mq_attn_workspace_bytes(int B, int H, int Nq, int D, int nsplit);
-int mq_attn_fwd(const void* q, const void* k, const void* vt, void* o, const float* key_bias, void* workspace,
+int mq_attn_fwd(const void* q, const void* k, const void* vt, void* o, const float* key_bias, const int* kv_len,
+                void* workspace,
                 int B, int H, int Nq, int Nk, int D,
                 long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long vt_bs, long vt_rs, long vt_hs,
                 long o_bs, long o_rs, long bias_bs, long bias_hs, float scale, float clamp, int nsplit, void* stream);
@@ -66,6 +68,28 @@ int mq_gcp_gate_residual_fwd(const void* sup, const void* h, const void* w2, con
  *   deform_conv_cuda.cu:538-552 (bound as maskrcnn_benchmark/csrc/vision.cpp:11-12). */
 int mq_dcn_im2col_fwd(const void* x, const float* om, void* cols, int B, int H, int W, int C, int oH, int oW,
                       int stride, void* stream);
+
+/* Row LayerNorm, fp16 in/out, fp32 statistics: y[r,:] = (x[r,:] - mean) * rstd * gamma + beta, C % 8 == 0, C <= 2048.
+ *   yt != NULL additionally writes the transpose yt[b, c, n] (r = b*rows_per_batch + n, row pitch yt_ld halfs).
+ * Replaces every nn.LayerNorm call on the path (backbone/swint.py:198,240,281,425,611; HF BertLayer / embeddings;
+ *   language_backbone/modeling_bert_new.py:121,150-153; utils/fuse_helper.py:420-421). */
+int mq_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, void* yt, long rows, int C, float eps,
+                     long rows_per_batch, long yt_ld, void* stream);
+
+/* 3x3 convolution (pad 1, stride 1|2) and DCNv2 (modulated deformable 3x3) as one implicit-GEMM MFMA kernel,
+ * NHWC fp16, fp32 accumulation over the whole K = 9*C in a fixed order (bitwise reproducible).
+ *   x [B,H,W,C] (batch stride x_bs elements, C % 32 == 0), w [Npad, 9*C] fp16 with k = tap*C + c (Npad = 32 if
+ *   N <= 32 else 256; rows >= N zero), bias [N] fp16 or NULL, out [B*Ho*Wo, out_ld] fp16 (first N columns written).
+ *   mq_dcnv2_fwd additionally takes om [B,27,oH,oW] fp32 NCHW = 18 offsets + 9 mask LOGITS, indexed flat by the output
+ *   dims like the reference kernel (the buffer may come from another pyramid level); N must be 256.
+ * mq_dcnv2_fwd replaces _C.modulated_deform_conv_forward (maskrcnn_benchmark/csrc/vision.cpp:11-12,
+ *   csrc/cuda/deform_conv_cuda.cu:496-575, deform_conv_kernel_cuda.cu:578-640) without the im2col buffer;
+ * mq_conv3x3_fwd replaces the nn.Conv2d 3x3 calls of backbone/fpn.py:41,141-146 and the DyConv offset conv
+ *   (rpn/vldyhead.py:186,214). */
+int mq_conv3x3_fwd(const void* x, const void* w, const void* bias, void* out, int B, int H, int W, int C, long x_bs,
+                   int N, int out_ld, int stride, void* stream);
+int mq_dcnv2_fwd(const void* x, const float* om, const void* w, const void* bias, void* out, int B, int H, int W, int C,
+                 long x_bs, int oH, int oW, int N, int out_ld, int stride, void* stream);
 
 /* DyConv epilogue (GroupNorm(16) + bilinear up-sampling of the level+1 branch + scale attention + branch mean,
  * then DYReLU), NHWC fp16 with fp32 statistics; C == 256.

@@ -28,6 +28,7 @@
 struct AttnParams {
   const half_t* q; const half_t* k; const half_t* vt; half_t* o;
   const float* key_bias;     // [B, Nk] or nullptr
+  const int* kv_len;         // [B] or nullptr: keys >= kv_len[b] are masked (contribute exactly 0) -> their tiles are skipped
   float* ws;                 // split-K workspace or nullptr
   int B, H, Nq, Nk;
   long q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, vt_bs, vt_rs, vt_hs, o_bs, o_rs, bias_bs, bias_hs;
@@ -57,7 +58,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const float* bias = p.key_bias ? p.key_bias + (long)b * p.bias_bs + (long)h * p.bias_hs : nullptr;
   half_t* Pw = Ps + wave * (RB * 16 * PS);
 
-  const int ntiles = (p.Nk + BN - 1) / BN;
+  // trailing masked keys (text padding) contribute exactly zero: do not even visit their tiles
+  const int nk_eff = p.kv_len ? max(1, min(p.Nk, p.kv_len[b])) : p.Nk;
+  const int ntiles = (nk_eff + BN - 1) / BN;
   const int tps = (ntiles + p.nsplit - 1) / p.nsplit;
   const int t0 = split * tps;
   const int t1 = min(ntiles, t0 + tps);
@@ -365,7 +368,7 @@ extern "C" long mq_attn_workspace_bytes(int B, int H, int Nq, int D, int nsplit)
 }
 
 extern "C" int mq_attn_fwd(const void* q, const void* k, const void* vt, void* o, const float* key_bias,
-                           void* workspace, int B, int H, int Nq, int Nk, int D,
+                           const int* kv_len, void* workspace, int B, int H, int Nq, int Nk, int D,
                            long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs,
                            long vt_bs, long vt_rs, long vt_hs, long o_bs, long o_rs, long bias_bs, long bias_hs,
                            float scale, float clamp, int nsplit, void* stream) {
@@ -375,7 +378,7 @@ extern "C" int mq_attn_fwd(const void* q, const void* k, const void* vt, void* o
   if ((vt_rs % 8) || (q_rs % 8) || (k_rs % 8) || (q_hs % 8) || (k_hs % 8) || (vt_hs % 8)) return -3;
   AttnParams p;
   p.q = (const half_t*)q; p.k = (const half_t*)k; p.vt = (const half_t*)vt; p.o = (half_t*)o;
-  p.key_bias = key_bias; p.ws = (float*)workspace;
+  p.key_bias = key_bias; p.kv_len = kv_len; p.ws = (float*)workspace;
   p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk;
   p.q_bs = q_bs; p.q_rs = q_rs; p.q_hs = q_hs; p.k_bs = k_bs; p.k_rs = k_rs; p.k_hs = k_hs;
   p.vt_bs = vt_bs; p.vt_rs = vt_rs; p.vt_hs = vt_hs; p.bias_bs = bias_bs; p.bias_hs = bias_hs;

@@ -92,8 +92,15 @@ def build_plan(sd, cfg, device, dtype=torch.float16):
         for k in range(3):
             w = f32(f"{b}.DyConv.{k}.conv.weight")                                   # [O, C, 3, 3] -> [O, tap*C + c]
             P[f"{b}.DyConv.{k}.packed"] = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dtype).contiguous()
+        wo = f32(b + ".offset.weight").permute(0, 2, 3, 1).reshape(27, -1)            # 27 -> 32 zero-padded rows
+        P[b + ".offset.packed"] = torch.cat([wo, wo.new_zeros(5, wo.shape[1])], 0).to(dtype).contiguous()
         P[b + ".attn_w"] = f32(b + ".AttnConv.1.weight").reshape(-1)
         P[b + ".attn_b"] = f32(b + ".AttnConv.1.bias")
+    for n in ("fpn_layer2", "fpn_layer3", "fpn_layer4", "top_blocks.p6", "top_blocks.p7"):
+        w = f32(f"backbone.fpn.{n}.weight")
+        P[f"backbone.fpn.{n}.packed"] = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dtype).contiguous()
+    for n in ("fpn_inner2", "fpn_inner3", "fpn_inner4"):
+        P[f"backbone.fpn.{n}.lin"] = h(f"backbone.fpn.{n}.weight").reshape(sd[f"backbone.fpn.{n}.weight"].shape[0], -1).contiguous()
     for l in range(5):
         s = f32(f"rpn.head.scales.{l}.scale")
         P[f"rpn.head.bbox_pred.{l}.weight"] = (f32("rpn.head.bbox_pred.weight") * s).to(dtype) \
@@ -110,7 +117,8 @@ def build_plan(sd, cfg, device, dtype=torch.float16):
 
 
 def _ln(P, name, x, eps=1e-5):
-    return F.layer_norm(x, (x.shape[-1],), P[name + ".weight"], P[name + ".bias"], eps)
+    """LayerNorm through the HIP kernel (mq_layernorm_fwd)."""
+    return ops.layer_norm(x.contiguous(), P[name + ".weight"], P[name + ".bias"], eps)
 
 
 def _lin(P, name, x):
@@ -161,21 +169,26 @@ def swin_forward(P, cfg, img):
 
 
 def fpn_forward(P, feats_nhwc):
-    """fpn.py:59-129 + LastLevelP6P7 (:150-154).  In / out: NHWC-memory tensors viewed as NCHW."""
+    """fpn.py:59-129 + LastLevelP6P7 (:150-154).  NHWC in, NCHW-views of NHWC tensors out.  1x1 laterals are
+    library GEMMs on the NHWC tokens, 3x3 convs the deterministic HIP implicit-GEMM kernel (mq_conv3x3_fwd)."""
     p = "backbone.fpn"
-    c3, c4, c5 = [f.permute(0, 3, 1, 2) for f in feats_nhwc]
+    c3, c4, c5 = feats_nhwc
 
-    def conv(name, x, stride=1, pad=0):
-        return F.conv2d(x, P[f"{p}.{name}.weight"], P[f"{p}.{name}.bias"], stride=stride, padding=pad)
-    inner = conv("fpn_inner4", c5)
-    res = [conv("fpn_layer4", inner, pad=1)]
+    def lateral(name, x):
+        return F.linear(x, P[f"{p}.{name}.lin"], P[f"{p}.{name}.bias"])
+
+    def conv3(name, x, stride=1):
+        return ops.conv3x3(x, P[f"{p}.{name}.packed"], P[f"{p}.{name}.bias"], P[f"{p}.{name}.packed"].shape[0], stride)
+    inner = lateral("fpn_inner4", c5)
+    res = [conv3("fpn_layer4", inner)]
     for feat, idx in ((c4, 3), (c3, 2)):
-        lat = conv(f"fpn_inner{idx}", feat)
-        inner = lat + F.interpolate(inner, size=lat.shape[-2:], mode="nearest")
-        res.insert(0, conv(f"fpn_layer{idx}", inner, pad=1))
-    p6 = conv("top_blocks.p6", res[-1], stride=2, pad=1)
-    p7 = conv("top_blocks.p7", F.relu(p6), stride=2, pad=1)
-    return [t.contiguous(memory_format=torch.channels_last) for t in res + [p6, p7]]
+        lat = lateral(f"fpn_inner{idx}", feat)
+        up = F.interpolate(inner.permute(0, 3, 1, 2), size=lat.shape[1:3], mode="nearest").permute(0, 2, 3, 1)
+        inner = (lat + up).contiguous()
+        res.insert(0, conv3(f"fpn_layer{idx}", inner))
+    p6 = conv3("top_blocks.p6", res[-1], 2)
+    p7 = conv3("top_blocks.p7", F.relu(p6), 2)
+    return [t.permute(0, 3, 1, 2) for t in res + [p6, p7]]
 
 
 def pooled_fpn_tokens(feats):
@@ -184,13 +197,14 @@ def pooled_fpn_tokens(feats):
 
 
 # ----------------------------------------------------------------------------- language backbone
-def bert_layer(P, b, x, key_bias, clamp):
+def bert_layer(P, b, x, key_bias, clamp, kv_len=None):
     """HF BertLayer / rpn/modeling_bert.py:71-272 (clamp=True): QK^T, mask, softmax, PV in one HIP kernel."""
     Bn, T, C = x.shape
     qk = _lin(P, b + ".qk", x)                                                          # [B, T, 2C]
     vt = torch.baddbmm(P[b + ".attention.self.value.bias"][None, :, None], P[b + ".attention.self.value.weight"][None]
                        .expand(Bn, -1, -1), x.transpose(1, 2))                          # V^T [B, C, T]
-    ctx = ops.attention(qk[:, :, :C], qk[:, :, C:], vt, 12, C // 12, key_bias=key_bias, clamp=50000.0 if clamp else 0.0)
+    ctx = ops.attention(qk[:, :, :C], qk[:, :, C:], vt, 12, C // 12, key_bias=key_bias, clamp=50000.0 if clamp else 0.0,
+                        kv_len=kv_len)
     a = _ln(P, b + ".attention.output.LayerNorm", _lin(P, b + ".attention.output.dense", ctx) + x, 1e-12)
     hmid = _lin(P, b + ".intermediate.dense", a)
     if clamp:
@@ -252,6 +266,9 @@ def language_backbone(P, cfg, input_ids, attention_mask, vision, images, idx, wa
     x = F.layer_norm(e, (e.shape[-1],), P[p + ".embeddings.LayerNorm.weight"].float(),
                      P[p + ".embeddings.LayerNorm.bias"].float(), 1e-12).to(P[p + ".embeddings.LayerNorm.weight"].dtype)
     key_bias = ((1.0 - attention_mask.float()) * NEG).contiguous()
+    # index of the last valid text token + 1: the attention kernels skip key tiles that hold padding only
+    kv_len = (attention_mask.to(torch.int32) * torch.arange(1, T + 1, device=attention_mask.device, dtype=torch.int32)) \
+        .amax(1).to(torch.int32).contiguous()
     use_vq = vision is not None
     if use_vq:
         vision = pre_select(P, p + ".pre_select", vision, images, cfg.VISION_QUERY.VISION_SCALE)
@@ -261,7 +278,7 @@ def language_backbone(P, cfg, input_ids, attention_mask, vision, images, idx, wa
     for i in range(nl):
         if use_vq and i >= qv0:
             x = gcp_block(P, f"{p}.encoder.qv_layer.{i - qv0}", x, vision, idx, gates)
-        x = bert_layer(P, f"{p}.encoder.layer.{i}", x, key_bias, clamp=False)
+        x = bert_layer(P, f"{p}.encoder.layer.{i}", x, key_bias, clamp=False, kv_len=kv_len)
         hidden.append(x)
     n = LB.N_LAYERS
     feats = torch.stack(hidden[-n:], 1).float().mean(1) / n
@@ -269,11 +286,11 @@ def language_backbone(P, cfg, input_ids, attention_mask, vision, images, idx, wa
     embedded = feats * m
     aggregate = embedded.sum(1) / attention_mask.sum(-1, keepdim=True).float()
     return {"aggregate": aggregate, "embedded": embedded, "masks": attention_mask, "hidden": hidden[-1],
-            "key_bias": key_bias, "vision_query_gates": gates, "augmented_vision": vision}
+            "key_bias": key_bias, "kv_len": kv_len, "vision_query_gates": gates, "augmented_vision": vision}
 
 
 # ----------------------------------------------------------------------------- VLDyHead
-def vl_fuse(P, b, feats, hidden, key_bias):
+def vl_fuse(P, b, feats, hidden, key_bias, kv_len=None):
     """BiAttentionBlockForCheckpoint / BiMultiHeadAttention (fuse_helper.py:218-303,377-426): one set of logits,
     softmax over text for the image side and over image tokens for the text side -- two launches of the fused
     attention kernel; the logits are never materialised (reference: 3 x [B*8, 22400, 256] fp32 tensors) and, with
@@ -283,7 +300,8 @@ def vl_fuse(P, b, feats, hidden, key_bias):
     sizes = [f.shape[-2:] for f in feats]
     v = torch.cat([f.permute(0, 2, 3, 1).flatten(1, 2) for f in feats], 1)              # [B, N, 256]
     N, C = v.shape[1], v.shape[2]
-    v_ln = _ln(P, b + ".layer_norm_v", v)
+    # LN(v) and LN(v)^T (the V^T operand of the text side) from ONE pass over v
+    v_ln, v_t = ops.layer_norm(v, P[b + ".layer_norm_v.weight"], P[b + ".layer_norm_v.bias"], 1e-5, transposed_out=True)
     l_ln = _ln(P, b + ".layer_norm_l", hidden)
     pad = (-N) % 8
     v_pad = F.pad(v_ln, (0, 0, 0, pad)) if pad else v_ln
@@ -297,9 +315,8 @@ def vl_fuse(P, b, feats, hidden, key_bias):
                             P[a + ".values_l_proj.weight"][None].expand(Bn, -1, -1), l_ln.transpose(1, 2))
     # image side: queries = LN(v) shared by the 8 heads, keys = folded text keys, values = text values
     out_v = ops.attention4(v_ln[:, :, None, :].expand(Bn, N, 8, C), kf4, val_l_t.reshape(Bn, 8, -1, T),
-                           key_bias=bias.contiguous(), scale=1.0, clamp=50000.0)
+                           key_bias=bias.contiguous(), scale=1.0, clamp=50000.0, kv_len=kv_len)
     # text side: queries = folded text keys, keys = values = LN(v) (shared by the heads)
-    v_t = v_pad.transpose(1, 2).contiguous()                                             # [B, 256, N_pad]
     out_l = ops.attention4(kf4, v_pad[:, :, None, :].expand(Bn, v_pad.shape[1], 8, C),
                            v_t[:, None].expand(Bn, 8, C, v_t.shape[2]), scale=1.0, clamp=50000.0, nk=N,
                            nsplit=_nsplit(-(-T // 128) * Bn * 8, -(-N // 64)))
@@ -336,15 +353,17 @@ def _upsample_pool_weights(hs, ws, H, W, device):
 
 def dyconv(P, cfg, b, feats):
     """DyConv.forward (vldyhead.py:205-247).  Per level: 27-channel offset/mask conv (library), up to three DCNv2
-    branches = HIP gather + library GEMM, then the fused HIP epilogue (GroupNorm statistics, bilinear up-sampling of
+    branches (HIP gather + library GEMM, or the fused implicit-GEMM kernel with MODEL.DYHEAD.FUSED_DCN), then the fused HIP epilogue (GroupNorm statistics, bilinear up-sampling of
     the level+1 branch, scale attention, branch mean, DYReLU) -- offsets of the CURRENT level are re-used for all
     three branches exactly like the reference (flat-index quirk handled inside the gather)."""
     G = cfg.MODEL.GROUP_NORM
+    fused_dcn = bool(cfg.MODEL.DYHEAD.get("FUSED_DCN", False))
     out = []
     nl = len(feats)
     for lvl, f in enumerate(feats):
         Bn, C, H, W = f.shape
-        om = F.conv2d(f, P[b + ".offset.weight"], P[b + ".offset.bias"], padding=1).float().contiguous()
+        f_nhwc = f.permute(0, 2, 3, 1).contiguous()
+        om = ops.conv3x3(f_nhwc, P[b + ".offset.packed"], P[b + ".offset.bias"], 27).permute(0, 3, 1, 2).float().contiguous()
         spec = [(1, f, 1)]
         if lvl > 0:
             spec.append((2, feats[lvl - 1], 2))
@@ -352,8 +371,12 @@ def dyconv(P, cfg, b, feats):
             spec.append((0, feats[lvl + 1], 1))
         branches = []
         for k, x, stride in spec:
-            cols, (Ho, Wo) = ops.dcn_im2col(x.permute(0, 2, 3, 1).contiguous(), om, stride)
-            y = F.linear(cols, P[f"{b}.DyConv.{k}.packed"], P[f"{b}.DyConv.{k}.conv.bias"])          # [B, Ho*Wo, C]
+            x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+            if fused_dcn:      # one implicit-GEMM kernel; per-CU-ingest bound, slower than the split form
+                y, (Ho, Wo) = ops.dcnv2(x_nhwc, om, P[f"{b}.DyConv.{k}.packed"], P[f"{b}.DyConv.{k}.conv.bias"], stride)
+            else:              # HIP gather (HBM-bound, ~6 TB/s) + library GEMM against the tap-major packed weight
+                cols, (Ho, Wo) = ops.dcn_im2col(x_nhwc, om, stride)
+                y = F.linear(cols, P[f"{b}.DyConv.{k}.packed"], P[f"{b}.DyConv.{k}.conv.bias"])      # [B, Ho*Wo, C]
             wy = wx = None
             if (Ho, Wo) != (H, W):
                 wy, wx = _upsample_pool_weights(Ho, Wo, H, W, y.device)
@@ -370,11 +393,11 @@ def dyconv(P, cfg, b, feats):
 def vldyhead(P, cfg, feats, lang):
     """VLDyHead.forward (vldyhead.py:769-900), eval outputs."""
     p = "rpn.head"
-    hidden, key_bias = lang["hidden"], lang["key_bias"]
+    hidden, key_bias, kv_len = lang["hidden"], lang["key_bias"], lang.get("kv_len")
     for i in range(cfg.MODEL.DYHEAD.NUM_CONVS):
         t = f"{p}.dyhead_tower"
-        feats, hidden = vl_fuse(P, f"{t}.{3 * i}.b_attn", feats, hidden, key_bias)
-        hidden = bert_layer(P, f"{t}.{3 * i + 1}", hidden, key_bias, clamp=True)
+        feats, hidden = vl_fuse(P, f"{t}.{3 * i}.b_attn", feats, hidden, key_bias, kv_len)
+        hidden = bert_layer(P, f"{t}.{3 * i + 1}", hidden, key_bias, clamp=True, kv_len=kv_len)
         feats = dyconv(P, cfg, f"{t}.{3 * i + 2}", feats)
     emb = F.normalize(hidden.float(), p=2, dim=-1)
     tok = F.linear(emb / 2.0, P[p + ".tok.weight"], P[p + ".tok.bias"]) * P[p + ".inv_scale"]      # [B, T, 256]

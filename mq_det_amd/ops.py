@@ -16,11 +16,14 @@ _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 _SIGNATURES = {
     "mq_abi_version": (_i, []),
     "mq_attn_workspace_bytes": (_l, [_i, _i, _i, _i, _i]),
-    "mq_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _i, _vp]),
+    "mq_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _i, _vp]),
     "mq_window_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_gcp_sparse_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_gcp_gate_residual_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
     "mq_dcn_im2col_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "mq_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _f, _l, _l, _vp]),
+    "mq_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _vp]),
+    "mq_dcnv2_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _vp]),
     "mq_dyconv_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mq_dyconv_coef": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "mq_dyconv_fuse": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -113,13 +116,15 @@ def _need_gpu(*ts):
             raise RuntimeError("mq_det_amd ops need GPU tensors: the hot path has no CPU fallback")
 
 
-def attention4(q4, k4, vt4, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None):
+def attention4(q4, k4, vt4, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None, kv_len=None):
     """General strided form.  q4 [B,Nq,H,D], k4 [B,Nk,H,D], vt4 [B,H,D,Nk_pad] fp16 views with unit last stride
     (a head stride of 0, e.g. from .expand(), shares the operand across heads); key_bias None, [B,Nk] or [B,H,Nk]
     fp32.  Returns [B,Nq,H*D] fp16."""
     lib = load_library()
-    _need_gpu(q4, k4, vt4, key_bias)
+    _need_gpu(q4, k4, vt4, key_bias, kv_len)
     B, Nq, H, D = q4.shape
+    if kv_len is not None:
+        assert kv_len.dtype == torch.int32 and kv_len.shape == (B,) and kv_len.is_contiguous()
     Nk = k4.shape[1] if nk is None else nk
     assert k4.shape[0] == B and k4.shape[2:] == (H, D) and vt4.shape[:3] == (B, H, D) and vt4.shape[3] >= Nk
     assert q4.dtype == k4.dtype == vt4.dtype == torch.float16
@@ -138,7 +143,7 @@ def attention4(q4, k4, vt4, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=N
     if nsplit > 1:
         ws = torch.empty(lib.mq_attn_workspace_bytes(B, H, Nq, D, nsplit) // 4, dtype=torch.float32, device=q4.device)
     with _timed(f"attn_d{D}_nq{Nq}_nk{Nk}_s{nsplit}"):
-        rc = lib.mq_attn_fwd(_ptr(q4), _ptr(k4), _ptr(vt4), _ptr(o), _ptr(key_bias), _ptr(ws), B, H, Nq, Nk, D,
+        rc = lib.mq_attn_fwd(_ptr(q4), _ptr(k4), _ptr(vt4), _ptr(o), _ptr(key_bias), _ptr(kv_len), _ptr(ws), B, H, Nq, Nk, D,
                              q4.stride(0), q4.stride(1), q4.stride(2), k4.stride(0), k4.stride(1), k4.stride(2),
                              vt4.stride(0), vt4.stride(2), vt4.stride(1), o.stride(0), o.stride(1), bias_bs, bias_hs,
                              float(scale if scale is not None else 1.0 / math.sqrt(D)), float(clamp), int(nsplit), _stream())
@@ -146,7 +151,7 @@ def attention4(q4, k4, vt4, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=N
     return o
 
 
-def attention(q, k, vt, num_heads, head_dim, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None):
+def attention(q, k, vt, num_heads, head_dim, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None, kv_len=None):
     """q [B,Nq,H*D], k [B,Nk,H*D], vt [B,H*D,Nk_pad] (V transposed, Nk_pad % 8 == 0) fp16 -> [B,Nq,H*D] fp16."""
     B, Nq, HD = q.shape
     H, D = num_heads, head_dim
@@ -155,7 +160,7 @@ def attention(q, k, vt, num_heads, head_dim, key_bias=None, scale=None, clamp=0.
     q4 = q.as_strided((B, Nq, H, D), (q.stride(0), q.stride(1), D, 1), q.storage_offset())
     k4 = k.as_strided((B, k.shape[1], H, D), (k.stride(0), k.stride(1), D, 1), k.storage_offset())
     vt4 = vt.as_strided((B, H, D, vt.shape[2]), (vt.stride(0), D * vt.stride(1), vt.stride(1), 1), vt.storage_offset())
-    return attention4(q4, k4, vt4, key_bias, scale, clamp, nsplit, nk)
+    return attention4(q4, k4, vt4, key_bias, scale, clamp, nsplit, nk, kv_len)
 
 
 def window_attention(qkv, qkv_bias, rel_bias, heads, ws, shift):
@@ -215,6 +220,60 @@ def dcn_im2col(x_nhwc, om, stride):
         _chk(lib.mq_dcn_im2col_fwd(_ptr(x_nhwc), _ptr(om), _ptr(cols), B, H, W, C, om.shape[2], om.shape[3], stride,
                                    _stream()), "mq_dcn_im2col_fwd")
     return cols, (Ho, Wo)
+
+
+def layer_norm(x, gamma, beta, eps=1e-5, transposed_out=False, pad_to=8):
+    """LayerNorm over the last dim of a contiguous fp16 tensor.  transposed_out: x is [B, N, C]; also returns
+    LN(x)^T as [B, C, N_pad] (N_pad = N rounded up to `pad_to`, tail zero-filled)."""
+    lib = load_library()
+    _need_gpu(x, gamma, beta)
+    C = x.shape[-1]
+    assert x.is_contiguous() and x.dtype == torch.float16 and gamma.dtype == torch.float16 and beta.dtype == torch.float16
+    rows = x.numel() // C
+    y = torch.empty_like(x)
+    yt, rpb, ld = None, 0, 0
+    if transposed_out:
+        B, N = x.shape[0], x.shape[1]
+        ld = (N + pad_to - 1) // pad_to * pad_to
+        yt = torch.zeros(B, C, ld, dtype=torch.float16, device=x.device) if ld != N else \
+            torch.empty(B, C, ld, dtype=torch.float16, device=x.device)
+        rpb = N
+    with _timed(f"layernorm_c{C}"):
+        _chk(lib.mq_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(yt), rows, C, float(eps), rpb, ld, _stream()),
+             "mq_layernorm_fwd")
+    return (y, yt) if transposed_out else y
+
+
+def conv3x3(x_nhwc, w_packed, bias, n_out, stride=1):
+    """x [B,H,W,C] fp16 (NHWC, contiguous H,W,C; any batch stride), w_packed [32|256, 9*C] fp16 (k = tap*C + c),
+    bias [n_out] fp16 -> [B, Ho, Wo, n_out] fp16."""
+    lib = load_library()
+    _need_gpu(x_nhwc, w_packed, bias)
+    B, H, W, C = x_nhwc.shape
+    assert x_nhwc.dtype == torch.float16 and x_nhwc.stride(3) == 1 and x_nhwc.stride(2) == C and x_nhwc.stride(1) == W * C
+    assert w_packed.is_contiguous() and w_packed.shape == (32 if n_out <= 32 else 256, 9 * C)
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    ld = n_out if n_out % 8 == 0 else (n_out + 7) // 8 * 8
+    out = torch.empty(B, Ho, Wo, ld, dtype=torch.float16, device=x_nhwc.device)
+    with _timed("conv3x3"):
+        _chk(lib.mq_conv3x3_fwd(_ptr(x_nhwc), _ptr(w_packed), _ptr(bias), _ptr(out), B, H, W, C, x_nhwc.stride(0), n_out, ld,
+                                stride, _stream()), "mq_conv3x3_fwd")
+    return out if ld == n_out else out[..., :n_out]
+
+
+def dcnv2(x_nhwc, om, w_packed, bias, stride):
+    """Fused DCNv2: x [B,H,W,C] fp16 NHWC, om [B,27,oH,oW] fp32, w_packed [256, 9*C] -> y [B, Ho*Wo, 256] fp16, (Ho, Wo)."""
+    lib = load_library()
+    _need_gpu(x_nhwc, om, w_packed, bias)
+    B, H, W, C = x_nhwc.shape
+    assert x_nhwc.dtype == torch.float16 and x_nhwc.stride(3) == 1 and x_nhwc.stride(2) == C and x_nhwc.stride(1) == W * C
+    assert om.is_contiguous() and om.dtype == torch.float32 and om.shape[1] == 27 and w_packed.shape == (256, 9 * C)
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    y = torch.empty(B, Ho * Wo, 256, dtype=torch.float16, device=x_nhwc.device)
+    with _timed("dcnv2_fused"):
+        _chk(lib.mq_dcnv2_fwd(_ptr(x_nhwc), _ptr(om), _ptr(w_packed), _ptr(bias), _ptr(y), B, H, W, C, x_nhwc.stride(0),
+                              om.shape[2], om.shape[3], 256, 256, stride, _stream()), "mq_dcnv2_fwd")
+    return y, (Ho, Wo)
 
 
 def dyconv_branch_coef(y, Wsrc, gamma, beta, attn_w, attn_b, groups, eps, nbranches, wy=None, wx=None):

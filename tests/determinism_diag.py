@@ -61,7 +61,7 @@ rep("bert layer", lambda: pipeline.bert_layer(P, "rpn.head.dyhead_tower.1", l, k
 img = torch.randn(2, 3, 320, 448, generator=g).half().to(dev).contiguous(memory_format=torch.channels_last)
 rep("swin", lambda: pipeline.swin_forward(P, cfg, img))
 c = pipeline.swin_forward(P, cfg, img)
-rep("fpn", lambda: pipeline.fpn_forward(P, c))
+rep("fpn (HIP implicit-GEMM convs)", lambda: pipeline.fpn_forward(P, c))
 
 images, sizes, ids, am, pm, bank = pc.make_inputs(spec)
 model.load_query_bank(bank)

@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 
-def attention(q, k, vt, num_heads, head_dim, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None):
+def attention(q, k, vt, num_heads, head_dim, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None, kv_len=None):
     B, Nq, HD = q.shape
     Nk = k.shape[1] if nk is None else nk
     H, D = num_heads, head_dim
@@ -28,7 +28,7 @@ def attention(q, k, vt, num_heads, head_dim, key_bias=None, scale=None, clamp=0.
     return (s.softmax(-1) @ vh).transpose(1, 2).reshape(B, Nq, HD).to(q.dtype)
 
 
-def attention4(q4, k4, vt4, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None):
+def attention4(q4, k4, vt4, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None, kv_len=None):
     B, Nq, H, D = q4.shape
     Nk = k4.shape[1] if nk is None else nk
     assert vt4.shape[3] % 8 == 0 and q4.stride(3) == 1 and k4.stride(3) == 1 and vt4.stride(3) == 1
@@ -216,3 +216,24 @@ def dyrelu_(x, pool, w0, b0, w2, b2):
     xf = x.float()
     x.copy_(torch.max(xf * ((a1 - 0.5) * 2 + 1)[:, None] + (b1 - 0.5)[:, None], xf * ((a2 - 0.5) * 2)[:, None] + (b2_ - 0.5)[:, None]).to(x.dtype))
     return x
+
+
+def conv3x3(x_nhwc, w_packed, bias, n_out, stride=1):
+    B, H, W, C = x_nhwc.shape
+    w = w_packed[:n_out].float().reshape(n_out, 3, 3, C).permute(0, 3, 1, 2)
+    y = F.conv2d(x_nhwc.float().permute(0, 3, 1, 2), w, bias.float() if bias is not None else None, stride=stride, padding=1)
+    return y.permute(0, 2, 3, 1).to(x_nhwc.dtype)
+
+
+def dcnv2(x_nhwc, om, w_packed, bias, stride):
+    cols, hw = dcn_im2col(x_nhwc, om, stride)
+    return F.linear(cols.float(), w_packed.float(), bias.float()).to(x_nhwc.dtype), hw
+
+
+def layer_norm(x, gamma, beta, eps=1e-5, transposed_out=False, pad_to=8):
+    y = F.layer_norm(x.float(), (x.shape[-1],), gamma.float(), beta.float(), eps).to(x.dtype)
+    if not transposed_out:
+        return y
+    N = x.shape[1]
+    yt = F.pad(y.transpose(1, 2), (0, (-N) % pad_to)).contiguous()
+    return y, yt

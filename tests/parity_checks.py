@@ -39,24 +39,26 @@ def _ref_attention(q, k, v, H, key_bias=None, scale=None, clamp=0.0):
     return (s.softmax(-1) @ vh).transpose(1, 2).reshape(B, Nq, HD)
 
 
-def check_attention(dev, B, H, D, Nq, Nk, mask=False, clamp=0.0, nsplit=1, scale=None, big=False, seed=0):
+def check_attention(dev, B, H, D, Nq, Nk, mask=False, clamp=0.0, nsplit=1, scale=None, big=False, seed=0, kvlen=False):
     from mq_det_amd import ops
     g = torch.Generator().manual_seed(seed)
     amp = 4.0 if big else 1.0
     q = (torch.randn(B, Nq, H * D, generator=g) * amp).half()
     k = torch.randn(B, Nk, H * D, generator=g).half()
     v = torch.randn(B, Nk, H * D, generator=g).half()
-    kb = None
+    kb = kl = None
     if mask:
         kb = torch.zeros(B, Nk)
+        kl = torch.zeros(B, dtype=torch.int32)
         for b in range(B):
             kb[b, max(1, Nk // (b + 2)):] = -1e30
+            kl[b] = max(1, Nk // (b + 2))
     ref = _ref_attention(q, k, v, H, kb, scale, clamp)
     pad = (-Nk) % 8
     vt = F.pad(v, (0, 0, 0, pad)).transpose(1, 2).contiguous()
     out = ops.attention(q.to(dev), k.to(dev), vt.to(dev), H, D, key_bias=kb.to(dev) if kb is not None else None,
-                        scale=scale, clamp=clamp, nsplit=nsplit, nk=Nk)
-    return _stat(f"attn D={D} H={H} Nq={Nq} Nk={Nk} mask={mask} clamp={clamp} nsplit={nsplit}", out, ref)
+                        scale=scale, clamp=clamp, nsplit=nsplit, nk=Nk, kv_len=kl.to(dev) if (kvlen and kl is not None) else None)
+    return _stat(f"attn D={D} H={H} Nq={Nq} Nk={Nk} mask={mask} clamp={clamp} nsplit={nsplit} kvlen={kvlen}", out, ref)
 
 
 def check_attention_strided(dev):
@@ -268,7 +270,48 @@ def check_dcn(dev):
         cols, (Ho, Wo) = ops.dcn_im2col(x.to(dev).permute(0, 2, 3, 1).contiguous(), om.to(dev).contiguous(), stride)
         wp = w.permute(0, 2, 3, 1).reshape(256, -1).to(dev)
         y = F.linear(cols, wp, bias.to(dev)).reshape(2, Ho, Wo, 256).permute(0, 3, 1, 2)
-        res.append(_stat(f"dcnv2 {name}", y, ref, tol=4e-3))
+        res.append(_stat(f"dcnv2 im2col+gemm {name}", y, ref, tol=4e-3))
+        y2, _ = ops.dcnv2(x.to(dev).permute(0, 2, 3, 1).contiguous(), om.to(dev).contiguous(), wp, bias.to(dev), stride)
+        res.append(_stat(f"dcnv2 fused implicit-GEMM {name}", y2.reshape(2, Ho, Wo, 256).permute(0, 3, 1, 2), ref, tol=4e-3))
+    return res
+
+
+def check_layernorm(dev):
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(22)
+    res = []
+    for rows, C, eps in ((1000, 96, 1e-5), (777, 192, 1e-5), (130, 384, 1e-5), (65, 768, 1e-12), (50, 1536, 1e-5), (300, 256, 1e-5)):
+        x = (torch.randn(rows, C, generator=g) * 2 + 0.5).half()
+        w, b = (torch.randn(C, generator=g) * 0.1 + 1).half(), (torch.randn(C, generator=g) * 0.1).half()
+        ref = F.layer_norm(x.float(), (C,), w.float(), b.float(), eps)
+        res.append(_stat(f"layernorm rows={rows} C={C}", ops.layer_norm(x.to(dev), w.to(dev), b.to(dev), eps), ref))
+    for B, N in ((2, 128), (2, 333), (1, 22400)):
+        x = torch.randn(B, N, 256, generator=g).half()
+        w, b = (torch.randn(256, generator=g) * 0.1 + 1).half(), (torch.randn(256, generator=g) * 0.1).half()
+        ref = F.layer_norm(x.float(), (256,), w.float(), b.float(), 1e-5)
+        y, yt = ops.layer_norm(x.to(dev), w.to(dev), b.to(dev), 1e-5, transposed_out=True)
+        res.append(_stat(f"layernorm+transpose B={B} N={N}: y", y, ref))
+        res.append(_stat(f"layernorm+transpose B={B} N={N}: yT", yt[:, :, :N], ref.transpose(1, 2)))
+        if yt.shape[2] > N:
+            res.append(_stat(f"layernorm+transpose B={B} N={N}: zero tail", yt[:, :, N:], torch.zeros_like(yt[:, :, N:]).float(), tol=0.0))
+    return res
+
+
+def check_conv3x3(dev):
+    """Implicit-GEMM 3x3 conv vs F.conv2d (fp32, CPU): strides, N = 256 / 27, sizes that straddle tiles and images."""
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(21)
+    res = []
+    for (B, H, W, N, stride) in ((2, 13, 21, 256, 1), (3, 25, 42, 256, 2), (2, 100, 168, 27, 1), (1, 7, 11, 27, 1), (2, 50, 84, 256, 1)):
+        x = torch.randn(B, 256, H, W, generator=g).half()
+        w = (torch.randn(N, 256, 3, 3, generator=g) / 48).half()
+        bias = torch.randn(N, generator=g).half()
+        ref = F.conv2d(x.float(), w.float(), bias.float(), stride=stride, padding=1)
+        wp = w.permute(0, 2, 3, 1).reshape(N, -1)
+        rows = 32 if N <= 32 else 256
+        wp = torch.cat([wp, wp.new_zeros(rows - N, wp.shape[1])], 0).contiguous()
+        y = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().to(dev), wp.to(dev), bias.to(dev), N, stride)
+        res.append(_stat(f"conv3x3 igemm B={B} {H}x{W} N={N} s={stride}", y.permute(0, 3, 1, 2), ref, tol=3e-3))
     return res
 
 
@@ -397,6 +440,8 @@ def all_checks(dev):
         dict(B=1, H=8, D=256, Nq=256, Nk=1500, clamp=50000.0, scale=1.0 / 16, nsplit=3),
         dict(B=1, H=2, D=256, Nq=130, Nk=22400, scale=1.0 / 16, nsplit=8),
         dict(B=1, H=8, D=256, Nq=22400, Nk=256, mask=True, scale=1.0 / 16),
+        dict(B=2, H=8, D=256, Nq=700, Nk=256, mask=True, scale=1.0 / 16, clamp=50000.0, kvlen=True),
+        dict(B=2, H=12, D=64, Nq=256, Nk=256, mask=True, kvlen=True),
     ]
     for s in specs:
         out.append(("attention", lambda s=s: check_attention(dev, **s)))
@@ -409,6 +454,8 @@ def all_checks(dev):
             ("bert", lambda: check_bert_layer(dev, True)),
             ("vlfuse", lambda: check_vl_fuse(dev)),
             ("dcn", lambda: check_dcn(dev)),
+            ("conv", lambda: check_conv3x3(dev)),
+            ("layernorm", lambda: check_layernorm(dev)),
             ("dyconv", lambda: check_dyconv(dev)),
             ("nms", lambda: check_nms(dev)),
             ("full", lambda: check_full_model(dev))]
