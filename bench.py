@@ -175,20 +175,33 @@ def main():
 
     if rank == 0:
         ips = world * Bn * args.steps / dt
-        # dominant hand-written kernel: the D=256 fused attention of VLFuse (both directions)
+        # dominant hand-written kernel: the D=256 fused attention of VLFuse (both directions, 6 + 6 launches / forward).
+        # Algorithmic FLOPs per launch = QK^T + PV = 4 * B * heads * Nq * Nk * 256 (2*MAC each), DESIGN.md section 3.
+        # Image->text launches only visit the key tiles that hold real caption tokens (padding is masked to an exact
+        # zero contribution and skipped), so their work is counted with the visited keys, not with T = 256.
         N_img = sum(h * w for h, w in [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)])
-        flops_per_launch = 4.0 * Bn * 8 * N_img * 256 * 256          # QK^T + PV, 2*MAC each (SURVEY 8d / DESIGN.md)
-        vl = {k: v for k, v in kern.items() if k.startswith("attn_d256")}
-        n_l = sum(v[0] for v in vl.values())
-        ms = sum(v[1] for v in vl.values())
+        n_tok = int(model.tokenize(captions, dev)[1][0].sum())
+        nk_vis = min(256, -(-n_tok // 64) * 64)
+        fl = {"i2t": 4.0 * Bn * 8 * N_img * nk_vis * 256, "t2i": 4.0 * Bn * 8 * 256 * N_img * 256}
         roof = None
-        if n_l:
-            avg_ms = ms / n_l
-            ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        i2t = [v for k, v in kern.items() if k.startswith("attn_d256_nq%d_" % N_img)]
+        t2i = [v for k, v in kern.items() if k.startswith("attn_d256_nq256_")]
+        if i2t and t2i:
+            n_l = i2t[0][0] + t2i[0][0]
+            ms = i2t[0][1] + t2i[0][1]
+            flops = i2t[0][0] * fl["i2t"] + t2i[0][0] * fl["t2i"]
+            ach = flops / (ms * 1e-3) / 1e12
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_attn256.json")
+            if os.path.exists(pmc):                 # PMC passes are separate rocprofv3 runs (see profiles/README.md)
+                traffic = json.load(open(pmc)).get("traffic_bytes_per_launch_avg")
             roof = {"bound": "mfma", "kernel": "attn_fwd_kernel<256,2> (VLFuse image<->text attention)",
                     "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                    "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": n_l,
-                    "flops_per_launch": flops_per_launch}
+                    "traffic": traffic, "avg_launch_ms": round(ms / n_l, 4), "launches": n_l,
+                    "flops_per_launch": {"image_to_text": fl["i2t"], "text_to_image": fl["t2i"], "visited_text_keys": nk_vis},
+                    "per_direction_tflops": {"image_to_text": round(fl["i2t"] * i2t[0][0] / (i2t[0][1] * 1e-3) / 1e12, 1),
+                                             "text_to_image": round(fl["t2i"] * t2i[0][0] / (t2i[0][1] * 1e-3) / 1e12, 1)},
+                    "timing": "HIP events on the launch stream around each launch, eager pass of the same steps"}
         res = {
             "metric": "images/sec MQ-GLIP-T 800\u00d71333 5-shot vision queries, 1/2/4/8 MI355X", "value": round(ips, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),

@@ -61,6 +61,11 @@ int mq_gcp_sparse_attn_fwd(const void* q, const void* kv, const int* idx, void* 
 int mq_gcp_gate_residual_fwd(const void* sup, const void* h, const void* w2, const void* x, void* out,
                              float* gate_out, long M, int C, int G, void* stream);
 
+/* out[m,c] = res[m,c] + bias[c] + sum_h x[m,h,c]  (fp16, M rows, H heads, C channels).  VLFuse image side: the
+ * per-head attention outputs (out_v_proj and gamma_v already folded into the text values) summed over heads and added
+ * to the residual -- replaces the out_v_proj GEMM + residual add of utils/fuse_helper.py:300,424. */
+int mq_headsum_residual_fwd(const void* x, const void* res, const void* bias, void* out, long M, int H, int C, void* stream);
+
 /* DCNv2 (modulated deformable 3x3 conv, pad 1) column gather, NHWC fp16, whole batch.
  *   x [B,H,W,C], om [B,27,oH,oW] fp32 NCHW (18 offsets + 9 mask LOGITS; may come from another pyramid level:
  *   indexed flat by the output dims like the reference kernel), cols [B,Ho*Wo,9*C] (k = tap*C + c).

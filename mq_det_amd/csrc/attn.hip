@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   half_t* Ps = Vs + D * VS;                // [4][RB*16][PS]
   constexpr bool QLDS = (D >= 256);        // D=256: Q fragments (64 VGPRs) live in LDS instead, see below
   half_t* Qs = Ps + 4 * RB * 16 * PS;      // [BM][KS] when QLDS
+  float* Bias_s = (float*)(Qs + (QLDS ? BM * KS : 0));      // [BN] key bias of the current tile
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   constexpr int NCH = (BN * (D / 8)) / 256;          // 16-byte chunks per thread per tile (K and V each)
   static_assert((BN * (D / 8)) % 256 == 0, "tile chunks must divide the block");
   half8 kreg[NCH], vreg[NCH];
+  float breg = 0.f;                                    // key-bias element of the prefetched tile (threads < BN)
   const int vlast = ((p.Nk - 1) / 8) * 8;            // last valid 8-key chunk start of a Vt row
   auto issue = [&](int t) {
 #pragma unroll
@@ -122,6 +124,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
       int key0 = min(t * BN + cv * 8, vlast);
       vreg[i] = *(const half8*)(Vt + (long)d * p.vt_rs + key0);
     }
+    // the bias rides with the tile prefetch: any OTHER load consumed inside the iteration makes hipcc drain the whole
+    // VMEM queue (s_waitcnt vmcnt(0)) right after the prefetch is issued, which serialises it (seen in the ISA of v2)
+    if (bias && tid < BN) breg = bias[min(t * BN + tid, p.Nk - 1)];
   };
   auto commit = [&]() {
 #pragma unroll
@@ -130,6 +135,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
       *(half8*)(Ks + (c / (D / 8)) * KS + (c % (D / 8)) * 8) = kreg[i];
       *(half8*)(Vs + (c / (BN / 8)) * VS + (c % (BN / 8)) * 8) = vreg[i];
     }
+    if (tid < BN) Bias_s[tid] = breg;
   };
   if (t0 < t1) issue(t0);
 
@@ -139,13 +145,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     __syncthreads();                                  // every wave is done reading the previous tiles
     commit();
     __syncthreads();
-    // key bias first (older in the VMEM queue than the prefetch below, so waiting for it does not drain the prefetch)
     float kbias[4];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-      int key = t * BN + nb * 16 + l15;
-      kbias[nb] = (bias && key < p.Nk) ? bias[key] : 0.f;
-    }
+    for (int nb = 0; nb < 4; ++nb) kbias[nb] = Bias_s[nb * 16 + l15];
     if (t + 1 < t1) issue(t + 1);
 
     // ---- S = Q K^T  (RB x 4 blocks of 16x16 per wave).  LDS fragment reads are software-pipelined one
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
 template <int D, int RB>
 static int launch_attn(const AttnParams& p, hipStream_t stream) {
   constexpr int BM = 4 * RB * 16, BN = 64;
-  constexpr size_t smem = (size_t)(BN * (D + 8) + D * (BN + 8) + 4 * RB * 16 * (BN + 8) + (D >= 256 ? BM * (D + 8) : 0)) * sizeof(half_t);
+  constexpr size_t smem = (size_t)(BN * (D + 8) + D * (BN + 8) + 4 * RB * 16 * (BN + 8) + (D >= 256 ? BM * (D + 8) : 0)) * sizeof(half_t) + BN * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<D, RB>,

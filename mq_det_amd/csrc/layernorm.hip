@@ -14,9 +14,8 @@ template <int LPR>
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, const half_t* __restrict__ gamma,
                                                         const half_t* __restrict__ beta, half_t* __restrict__ y,
                                                         half_t* __restrict__ yt, long rows, int C, float eps,
-                                                        long rows_per_batch, long yt_ld) {
-  constexpr int RPB = 64;                          // rows per block
-  constexpr int ROWS_PER_PASS = 256 / LPR;
+                                                        long rows_per_batch, long yt_ld, int RPB) {
+  constexpr int ROWS_PER_PASS = 256 / LPR;          // RPB = rows per block: 64 (big inputs / transposed output) or one pass
   extern __shared__ __attribute__((aligned(16))) half_t tile[];      // [RPB][C + 8] when yt
   const int sub = threadIdx.x % LPR, rg = threadIdx.x / LPR;
   const int nch = C / 8;
@@ -66,8 +65,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
     __syncthreads();
     // yt[b, c, n0 .. n0+63]: one 16-byte store per (channel, 8 consecutive rows); a block never straddles a batch
     // element when rows_per_batch % 64 == 0, otherwise rows are handled one by one
-    for (int t = threadIdx.x; t < C * (RPB / 8); t += 256) {
-      const int c = t / (RPB / 8), g8 = t % (RPB / 8);
+    for (int t = threadIdx.x; t < C * (64 / 8); t += 256) {
+      const int c = t / (64 / 8), g8 = t % (64 / 8);
       const long row = r0 + g8 * 8;
       if (row >= rows) continue;
       const long b = row / rows_per_batch, n = row % rows_per_batch;
@@ -92,12 +91,15 @@ extern "C" int mq_layernorm_fwd(const void* x, const void* gamma, const void* be
   if (rows <= 0) return 0;
   if (C % 8 || C > 2048) return -1;
   const int nch = C / 8;
-  const unsigned grid = (unsigned)((rows + 63) / 64);
+  const int lpr = nch <= 16 ? 16 : (nch <= 32 ? 32 : 64);
+  // small inputs (BERT / GCP: 2048 rows): one pass per block so that the launch still covers the chip
+  const int rpb = (yt || rows >= 64 * 2048) ? 64 : 256 / lpr;
+  const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
   const size_t smem = yt ? (size_t)64 * (C + 8) * sizeof(half_t) : 0;
   if (yt && rows_per_batch <= 0) return -2;
 #define MQ_LN(L)                                                                                                          \
   hipLaunchKernelGGL((layernorm_kernel<L>), dim3(grid), dim3(256), smem, (hipStream_t)stream, (const half_t*)x,          \
-                     (const half_t*)gamma, (const half_t*)beta, (half_t*)y, (half_t*)yt, rows, C, eps, rows_per_batch, yt_ld)
+                     (const half_t*)gamma, (const half_t*)beta, (half_t*)y, (half_t*)yt, rows, C, eps, rows_per_batch, yt_ld, rpb)
   if (nch <= 16) { MQ_LN(16); }
   else if (nch <= 32) { MQ_LN(32); }
   else { MQ_LN(64); }

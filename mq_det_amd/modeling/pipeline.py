@@ -80,6 +80,9 @@ def build_plan(sd, cfg, device, dtype=torch.float16):
         #   logits_h = LN(v) . (Wq_h^T k_h)          -> Wq8 [8, 256 hd, 256 in] folds into the (tiny) text keys
         #   text side: sum_i P_h[t,i] (Wvv_h LN(v)_i + b) = Wvv_h (P_h^T LN(v))[t] + b, then out_l_proj and
         #   the layer scale -> ONE static [768, 8*256] weight applied to the per-head pooled image features
+        #   image side: sum_h P_h (val_l_h) Wov_h^T = sum_h P_h (val_l_h Wov_h^T): out_v_proj * gamma_v folds into the text
+        #   values -> Wov8 [8, 256 hd, 256 out]; the kernel's per-head outputs are then just summed over heads
+        P[b + ".Wov8"] = P[b + ".ov.weight"].reshape(-1, 8, hd).permute(1, 2, 0).contiguous()
         P[b + ".Wq8"] = P[b + ".q.weight"].reshape(8, hd, -1).contiguous()
         P[b + ".bq8"] = (f32(b + ".attn.v_proj.bias") * sc).reshape(8, hd).contiguous()
         wol = (f32(b + ".attn.out_l_proj.weight") * gl[:, None]).reshape(-1, 8, hd)            # [768, h, e]
@@ -311,16 +314,16 @@ def vl_fuse(P, b, feats, hidden, key_bias, kv_len=None):
     kf = torch.matmul(k8.permute(0, 2, 1, 3), P[b + ".Wq8"][None])                       # [B, 8, T, 256 in]
     kf4 = kf.permute(0, 2, 1, 3)                                                         # [B, T, 8, 256] view
     bias = torch.einsum("bthd,hd->bht", k8.float(), P[b + ".bq8"]) + key_bias[:, None, :]        # [B, 8, T] fp32
-    val_l_t = torch.baddbmm(P[a + ".values_l_proj.bias"][None, :, None],
-                            P[a + ".values_l_proj.weight"][None].expand(Bn, -1, -1), l_ln.transpose(1, 2))
-    # image side: queries = LN(v) shared by the 8 heads, keys = folded text keys, values = text values
-    out_v = ops.attention4(v_ln[:, :, None, :].expand(Bn, N, 8, C), kf4, val_l_t.reshape(Bn, 8, -1, T),
-                           key_bias=bias.contiguous(), scale=1.0, clamp=50000.0, kv_len=kv_len)
+    val_l8 = _lin(P, a + ".values_l_proj", l_ln).reshape(Bn, T, 8, -1).permute(0, 2, 1, 3)        # [B, 8, T, 256 hd]
+    vo_t = torch.matmul(val_l8, P[b + ".Wov8"][None]).transpose(2, 3).contiguous()                # [B, 8, 256 out, T]
+    # image side: queries = LN(v) shared by the 8 heads, keys = folded text keys, values = text values x out_v_proj
+    out_v = ops.attention4(v_ln[:, :, None, :].expand(Bn, N, 8, C), kf4, vo_t,
+                           key_bias=bias.contiguous(), scale=1.0, clamp=50000.0, kv_len=kv_len)   # [B, N, 8*256]
     # text side: queries = folded text keys, keys = values = LN(v) (shared by the heads)
     out_l = ops.attention4(kf4, v_pad[:, :, None, :].expand(Bn, v_pad.shape[1], 8, C),
                            v_t[:, None].expand(Bn, 8, C, v_t.shape[2]), scale=1.0, clamp=50000.0, nk=N,
                            nsplit=_nsplit(-(-T // 128) * Bn * 8, -(-N // 64)))
-    v_new = v_ln + _lin(P, b + ".ov", out_v)                                             # residual on the NORMED v, l
+    v_new = ops.headsum_residual(out_v, v_ln, P[b + ".ov.bias"], 8)                      # residual on the NORMED v, l
     l_new = l_ln + _lin(P, b + ".olc", out_l)
     out, s = [], 0
     for (hh, ww) in sizes:

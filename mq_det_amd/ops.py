@@ -20,6 +20,7 @@ _SIGNATURES = {
     "mq_window_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_gcp_sparse_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_gcp_gate_residual_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
+    "mq_headsum_residual_fwd": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
     "mq_dcn_im2col_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _f, _l, _l, _vp]),
     "mq_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _vp]),
@@ -205,6 +206,21 @@ def gcp_gate_residual(sup, h, w2, x, want_gate=False):
     _chk(lib.mq_gcp_gate_residual_fwd(_ptr(sup), _ptr(h), _ptr(w2), _ptr(x), _ptr(out), _ptr(gate), M, C, G, _stream()),
          "mq_gcp_gate_residual_fwd")
     return (out, gate) if want_gate else out
+
+
+def headsum_residual(x, res, bias, heads):
+    """x [..., heads*C] fp16 (per-head outputs), res [..., C], bias [C] -> res + bias + sum_h x_h."""
+    lib = load_library()
+    _need_gpu(x, res, bias)
+    C = res.shape[-1]
+    M = res.numel() // C
+    assert x.is_contiguous() and res.is_contiguous() and x.shape[-1] == heads * C and x.numel() == M * heads * C
+    assert x.dtype == res.dtype == bias.dtype == torch.float16
+    out = torch.empty_like(res)
+    with _timed("headsum_residual"):
+        _chk(lib.mq_headsum_residual_fwd(_ptr(x), _ptr(res), _ptr(bias), _ptr(out), M, heads, C, _stream()),
+             "mq_headsum_residual_fwd")
+    return out
 
 
 def dcn_im2col(x_nhwc, om, stride):

@@ -237,3 +237,8 @@ def layer_norm(x, gamma, beta, eps=1e-5, transposed_out=False, pad_to=8):
     N = x.shape[1]
     yt = F.pad(y.transpose(1, 2), (0, (-N) % pad_to)).contiguous()
     return y, yt
+
+
+def headsum_residual(x, res, bias, heads):
+    C = res.shape[-1]
+    return (res.float() + bias.float() + x.float().reshape(*res.shape[:-1], heads, C).sum(-2)).to(res.dtype)
