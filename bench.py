@@ -44,6 +44,8 @@ def build_model(dev, full=True):
     cfg.MODEL.DYHEAD.NUM_CLASSES = 1204
     cfg.MODEL.ATSS.DETECTIONS_PER_IMG = 300
     cfg.TEST.MDETR_STYLE_AGGREGATE_CLASS_NUM = 3000
+    if os.environ.get("MQ_FUSED_DCN") is not None:     # A/B switch between the two DCNv2 implementations (same results)
+        cfg.MODEL.DYHEAD.FUSED_DCN = os.environ["MQ_FUSED_DCN"] == "1"
     tok_dir = build_synthetic_tokenizer(tempfile.mkdtemp(prefix="mqdet_tok_"))
     cfg.MODEL.LANGUAGE_BACKBONE.TOKENIZER_TYPE = tok_dir
     tk = AutoTokenizer.from_pretrained(tok_dir)

@@ -112,7 +112,7 @@ def get_cfg():
         ATSS=dict(NUM_CLASSES=81, PRIOR_PROB=0.01, INFERENCE_TH=0.05, NMS_TH=0.6, PRE_NMS_TOP_N=1000,
                   DETECTIONS_PER_IMG=100),                                                             # :407-436
         DYHEAD=dict(NUM_CLASSES=81, PRIOR_PROB=0.01, NUM_CONVS=6, CHANNELS=256, USE_GN=True, USE_DYRELU=True,
-                    USE_DFCONV=True, USE_DYFUSE=True, FUSED_DCN=False, SCORE_AGG="MEAN", LOG_SCALE=0.0, USE_CHECKPOINT=False,
+                    USE_DFCONV=True, USE_DYFUSE=True, FUSED_DCN=True, LEVEL_STREAMS=True, SCORE_AGG="MEAN", LOG_SCALE=0.0, USE_CHECKPOINT=False,
                     FUSE_CONFIG=dict(EARLY_FUSE_ON=True, TYPE="MHA-B", USE_DOT_PRODUCT_TOKEN_LOSS=True,
                                      USE_FUSED_FEATURES_DOT_PRODUCT=True, USE_LAYER_SCALE=True,
                                      CLAMP_MIN_FOR_UNDERFLOW=True, CLAMP_MAX_FOR_OVERFLOW=True,

@@ -1,4 +1,5 @@
-// mq_conv3x3_fwd / mq_dcnv2_fwd: 3x3 (modulated deformable) convolution as ONE implicit-GEMM MFMA kernel, gfx950.
+// mq_conv3x3_fwd: 3x3 convolution as ONE implicit-GEMM MFMA kernel, gfx950.  (The DEFORM = true instantiation is the
+// 4-wave v1 of the fused DCNv2; the shipped mq_dcnv2_fwd is the 8-wave kernel in dcn_fused.hip.)
 //
 //   out[m, n] = bias[n] + sum_{tap, c} A[m, tap, c] * W[n, tap*C + c],      m = (b, ho, wo), NHWC fp16 in / out
 //   plain  : A[m, tap, c] = x[b, ho*s - 1 + ky, wo*s - 1 + kx, c]            (zero padding)
@@ -238,16 +239,4 @@ extern "C" int mq_conv3x3_fwd(const void* x, const void* w, const void* bias, vo
   if (N <= 32) return launch_conv<false, 32, 4, 1>(p, (hipStream_t)stream);
   if (N <= 256) return launch_conv<false, 256, 2, 2>(p, (hipStream_t)stream);
   return -1;
-}
-
-// DCNv2 3x3, pad 1, N = 256 output channels (w: [256, 9*C]); om [B, 27, oH, oW] fp32 (offsets + mask logits).
-extern "C" int mq_dcnv2_fwd(const void* x, const float* om, const void* w, const void* bias, void* out, int B, int H, int W,
-                            int C, long x_bs, int oH, int oW, int N, int out_ld, int stride, void* stream) {
-  ConvParams p;
-  int rc = conv_common(p, x, w, bias, out, B, H, W, C, x_bs, N, out_ld, stride);
-  if (rc <= 0) return rc;
-  if (N != 256) return -1;
-  if ((long)p.Ho * p.Wo > (long)oH * oW) return -2;          // flat reads must stay inside the om buffer
-  p.om = om; p.oH = oH; p.oW = oW;
-  return launch_conv<true, 256, 2, 2>(p, (hipStream_t)stream);
 }

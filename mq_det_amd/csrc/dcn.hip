@@ -30,7 +30,12 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(DcnParams p) {
   const long total = npos * 9;
   const int n = p.Ho * p.Wo;
   const long om_plane = (long)p.oH * p.oW;
-  for (long pair = (long)blockIdx.x * pairs_per_block + sub; pair < total; pair += (long)gridDim.x * pairs_per_block) {
+  // XCD-aware order (workgroup i runs on XCD i % 8, one L2 per XCD): XCD x sweeps the contiguous pair range
+  // [x * chunk, (x + 1) * chunk) so that the re-use of input rows between neighbouring positions / taps hits ITS L2.
+  const long chunk = ((total + 8L * pairs_per_block - 1) / (8L * pairs_per_block)) * pairs_per_block;
+  const int xcd = blockIdx.x & 7, lblk = blockIdx.x >> 3, nlblk = gridDim.x >> 3;
+  const long pend = min(total, (xcd + 1) * chunk);
+  for (long pair = xcd * chunk + (long)lblk * pairs_per_block + sub; pair < pend; pair += (long)nlblk * pairs_per_block) {
     const int k = pair % 9;
     const long pos = pair / 9;
     const int b = pos / n, rem = pos % n;
@@ -81,6 +86,7 @@ extern "C" int mq_dcn_im2col_fwd(const void* x, const float* om, void* cols, int
   int ppb = 256 / (C / 8);
   long blocks = (total + ppb - 1) / ppb;
   if (blocks > 256 * 16) blocks = 256 * 16;
+  blocks = (blocks + 7) / 8 * 8;                  // whole groups of 8: one block per XCD
   hipLaunchKernelGGL(dcn_im2col_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
   MQ_CHECK_LAUNCH();
   return 0;

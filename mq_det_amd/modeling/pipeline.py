@@ -360,10 +360,11 @@ def dyconv(P, cfg, b, feats):
     the level+1 branch, scale attention, branch mean, DYReLU) -- offsets of the CURRENT level are re-used for all
     three branches exactly like the reference (flat-index quirk handled inside the gather)."""
     G = cfg.MODEL.GROUP_NORM
-    fused_dcn = bool(cfg.MODEL.DYHEAD.get("FUSED_DCN", False))
-    out = []
+    fused_dcn = bool(cfg.MODEL.DYHEAD.get("FUSED_DCN", True))
     nl = len(feats)
-    for lvl, f in enumerate(feats):
+
+    def level(lvl):
+        f = feats[lvl]
         Bn, C, H, W = f.shape
         f_nhwc = f.permute(0, 2, 3, 1).contiguous()
         om = ops.conv3x3(f_nhwc, P[b + ".offset.packed"], P[b + ".offset.bias"], 27).permute(0, 3, 1, 2).float().contiguous()
@@ -375,9 +376,9 @@ def dyconv(P, cfg, b, feats):
         branches = []
         for k, x, stride in spec:
             x_nhwc = x.permute(0, 2, 3, 1).contiguous()
-            if fused_dcn:      # one implicit-GEMM kernel; per-CU-ingest bound, slower than the split form
+            if fused_dcn:      # one implicit-GEMM kernel (dcn_fused.hip)
                 y, (Ho, Wo) = ops.dcnv2(x_nhwc, om, P[f"{b}.DyConv.{k}.packed"], P[f"{b}.DyConv.{k}.conv.bias"], stride)
-            else:              # HIP gather (HBM-bound, ~6 TB/s) + library GEMM against the tap-major packed weight
+            else:              # HIP gather + library GEMM against the tap-major packed weight
                 cols, (Ho, Wo) = ops.dcn_im2col(x_nhwc, om, stride)
                 y = F.linear(cols, P[f"{b}.DyConv.{k}.packed"], P[f"{b}.DyConv.{k}.conv.bias"])      # [B, Ho*Wo, C]
             wy = wx = None
@@ -389,8 +390,35 @@ def dyconv(P, cfg, b, feats):
         o, pool = ops.dyconv_fuse(branches, H, W)
         ops.dyrelu_(o, pool, P[b + ".relu.fc.0.weight"], P[b + ".relu.fc.0.bias"], P[b + ".relu.fc.2.weight"],
                     P[b + ".relu.fc.2.bias"])
-        out.append(o.reshape(Bn, H, W, C).permute(0, 3, 1, 2))
+        return o.reshape(Bn, H, W, C).permute(0, 3, 1, 2)
+
+    # The five pyramid levels of one DyConv layer are independent given the layer input, and the small ones (P5-P7:
+    # 96 / 32 / 8 workgroup tiles for B = 8) cannot fill 256 CUs on their own: run every level on its own HIP stream
+    # (fork / join around the layer; inside the HIP-graph capture this becomes parallel graph branches).
+    if not (cfg.MODEL.DYHEAD.get("LEVEL_STREAMS", True) and feats[0].is_cuda and nl > 1):
+        return [level(l) for l in range(nl)]
+    main = torch.cuda.current_stream()
+    side = _side_streams(feats[0].device, nl - 1)
+    out = [None] * nl
+    for s in side:
+        s.wait_stream(main)
+    for lvl in range(1, nl):
+        with torch.cuda.stream(side[lvl - 1]):
+            out[lvl] = level(lvl)
+    out[0] = level(0)                                     # the big level (75 % of the positions) on the main stream
+    for s in side:
+        main.wait_stream(s)
     return out
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device, n):
+    key = (device.index, n)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _SIDE_STREAMS[key]
 
 
 def vldyhead(P, cfg, feats, lang):

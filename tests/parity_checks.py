@@ -325,8 +325,15 @@ def check_dyconv(dev):
     b = "rpn.head.dyhead_tower.2"
     with torch.no_grad():
         ref = oh.dyconv(sd, b, [f.float() for f in feats], spec)
-        got = pipeline.dyconv(P, cfg, b, [f.to(dev).contiguous(memory_format=torch.channels_last) for f in feats])
-    return [_stat(f"dyconv lvl{i}", got[i], ref[i], tol=1e-2) for i in range(5)]
+        x = [f.to(dev).contiguous(memory_format=torch.channels_last) for f in feats]
+        got = pipeline.dyconv(P, cfg, b, x)
+        cfg.MODEL.DYHEAD.FUSED_DCN = True         # the one-kernel DCNv2 (dcn_fused.hip) must give the same layer
+        try:
+            got2 = pipeline.dyconv(P, cfg, b, x)
+        finally:
+            cfg.MODEL.DYHEAD.FUSED_DCN = False
+    return ([_stat(f"dyconv lvl{i}", got[i], ref[i], tol=1e-2) for i in range(5)]
+            + [_stat(f"dyconv (fused DCNv2) lvl{i}", got2[i], ref[i], tol=1e-2) for i in range(5)])
 
 
 def check_nms(dev):
@@ -376,12 +383,17 @@ def make_inputs(spec, B=2, hw=((150, 190), (160, 170)), nvalid=30, seed=3):
     return images, sizes, ids, am, pm, bank
 
 
-def check_full_model(dev):
-    """Whole forward, tiny-depth MQ-GLIP (real widths / head dims), fp16 HIP path vs fp32 oracle."""
+def check_full_model(dev, vision_queries=True):
+    """Whole forward, tiny-depth MQ-GLIP (real widths / head dims), fp16 HIP path vs fp32 oracle.
+    vision_queries=False: plain GLIP path (no query bank -> no pre-select / GCP blocks), BASELINE configs[0] shape."""
     from oracle import detector as od
     from mq_det_amd.structures import ImageList
     spec, sd, cfg, model, P = tiny(dev)
     images, sizes, ids, am, pm, bank = make_inputs(spec)
+    if not vision_queries:
+        bank = None
+        images, sizes = images[:1], sizes[:1]
+        ids, am = ids[:1], am[:1]
     model.load_query_bank(bank)
     with torch.no_grad():
         dets, inter = od.forward(sd, spec, images, sizes, ids, am, pm, bank, return_intermediates=True)
@@ -458,5 +470,6 @@ def all_checks(dev):
             ("layernorm", lambda: check_layernorm(dev)),
             ("dyconv", lambda: check_dyconv(dev)),
             ("nms", lambda: check_nms(dev)),
-            ("full", lambda: check_full_model(dev))]
+            ("full", lambda: check_full_model(dev)),
+            ("full-novq", lambda: [dict(r, name=r["name"].replace("full:", "GLIP (no vision queries) B=1:")) for r in check_full_model(dev, False)])]
     return out

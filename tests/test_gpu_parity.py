@@ -59,6 +59,12 @@ def test_block(dev, name):
     _assert(getattr(pc, name)(dev))
 
 
+def test_full_model_without_vision_queries(dev):
+    """Plain GLIP-T path (no query bank), B = 1 -- BASELINE.json configs[0] shape."""
+    import parity_checks as pc
+    _assert(pc.check_full_model(dev, vision_queries=False))
+
+
 @pytest.mark.parametrize("clamp", [False, True])
 def test_bert_layer(dev, clamp):
     import parity_checks as pc
