@@ -177,7 +177,8 @@ def main():
 
     if rank == 0:
         ips = world * Bn * args.steps / dt
-        # dominant hand-written kernel: the D=256 fused attention of VLFuse (both directions, 6 + 6 launches / forward).
+        # dominant hand-written kernels: the two VLFuse attention kernels (image side / text side, 6 + 6 launches / forward;
+        # the text-side time includes its split-merge launch).
         # Algorithmic FLOPs per launch = QK^T + PV = 4 * B * heads * Nq * Nk * 256 (2*MAC each), DESIGN.md section 3.
         # Image->text launches only visit the key tiles that hold real caption tokens (padding is masked to an exact
         # zero contribution and skipped), so their work is counted with the visited keys, not with T = 256.
@@ -186,18 +187,18 @@ def main():
         nk_vis = min(256, -(-n_tok // 64) * 64)
         fl = {"i2t": 4.0 * Bn * 8 * N_img * nk_vis * 256, "t2i": 4.0 * Bn * 8 * 256 * N_img * 256}
         roof = None
-        i2t = [v for k, v in kern.items() if k.startswith("attn_d256_nq%d_" % N_img)]
-        t2i = [v for k, v in kern.items() if k.startswith("attn_d256_nq256_")]
+        i2t = [v for k, v in kern.items() if k.startswith("vlfuse_i2t_n%d_" % N_img)]
+        t2i = [v for k, v in kern.items() if k.startswith("vlfuse_t2i_n%d_" % N_img)]
         if i2t and t2i:
             n_l = i2t[0][0] + t2i[0][0]
             ms = i2t[0][1] + t2i[0][1]
             flops = i2t[0][0] * fl["i2t"] + t2i[0][0] * fl["t2i"]
             ach = flops / (ms * 1e-3) / 1e12
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_attn256.json")
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_vlfuse.json")
             if os.path.exists(pmc):                 # PMC passes are separate rocprofv3 runs (see profiles/README.md)
                 traffic = json.load(open(pmc)).get("traffic_bytes_per_launch_avg")
-            roof = {"bound": "mfma", "kernel": "attn_fwd_kernel<256,2> (VLFuse image<->text attention)",
+            roof = {"bound": "mfma", "kernel": "vlfuse_i2t_kernel + vlfuse_t2i_kernel (VLFuse image<->text attention, 8 heads x 256)",
                     "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                     "traffic": traffic, "avg_launch_ms": round(ms / n_l, 4), "launches": n_l,
                     "flops_per_launch": {"image_to_text": fl["i2t"], "text_to_image": fl["t2i"], "visited_text_keys": nk_vis},

@@ -66,6 +66,28 @@ int mq_gcp_gate_residual_fwd(const void* sup, const void* h, const void* w2, con
  * to the residual -- replaces the out_v_proj GEMM + residual add of utils/fuse_helper.py:300,424. */
 int mq_headsum_residual_fwd(const void* x, const void* res, const void* bias, void* out, long M, int H, int C, void* stream);
 
+/* VLFuse image side in ONE launch (8 heads x 256, text tokens T <= 256), projections folded into the text operands:
+ *   out[b,n,:] = v_ln[b,n,:] + out_bias + sum_h softmax_t( clamp(v_ln[b,n,:] . kf[b,h,t,:] + bias[b,h,t], +-clamp) ) vo[b,h,t,:]
+ *   v_ln [B,N,256] fp16 (LN(v): queries AND residual), kf / vo [B,8,T,256] fp16 (folded text keys / values),
+ *   bias [B,8,T] fp32 or NULL (<= -1e29: key masked), kv_len [B] int32 or NULL (keys >= kv_len[b] masked),
+ *   max_kv: host-side upper bound of kv_len (<= 0: T) -- the caller guarantees kv_len[b] <= max_kv,
+ *   out_bias [256] fp16, out [B,N,256] fp16.
+ * Replaces BiMultiHeadAttention's image branch: v_proj, the [B*8, N, T] logits, clamp, softmax over text,
+ *   bmm with values_l, out_v_proj, and the gamma_v residual of BiAttentionBlock
+ *   (maskrcnn_benchmark/utils/fuse_helper.py:221-279,290-300,424). */
+int mq_vlfuse_i2t_fwd(const void* v_ln, const void* kf, const void* vo, const float* bias, const int* kv_len,
+                      const void* out_bias, void* out, int B, int N, int T, int max_kv, float clamp, void* stream);
+
+/* VLFuse text side: keys = values = image tokens, split over the keys (nsplit >= 1) + merge:
+ *   out[b,t,h*256:(h+1)*256] = sum_n softmax_n( clamp(kf[b,h,t,:] . v_ln[b,n,:], +-clamp) ) v_ln[b,n,:]
+ *   workspace: mq_vlfuse_t2i_workspace_bytes(B, T, nsplit) bytes of device memory; out [B,T,2048] fp16.
+ * Replaces the text branch of BiMultiHeadAttention: the transposed logits, their softmax over image tokens and the
+ *   bmm with values_v (fuse_helper.py:246-262,281-288); values_v_proj / out_l_proj are applied to the result by the
+ *   caller as one folded [768, 2048] weight. */
+long mq_vlfuse_t2i_workspace_bytes(int B, int T, int nsplit);
+int mq_vlfuse_t2i_fwd(const void* kf, const void* v_ln, void* workspace, void* out, int B, int N, int T, int nsplit,
+                      float clamp, void* stream);
+
 /* DCNv2 (modulated deformable 3x3 conv, pad 1) column gather, NHWC fp16, whole batch.
  *   x [B,H,W,C], om [B,27,oH,oW] fp32 NCHW (18 offsets + 9 mask LOGITS; may come from another pyramid level:
  *   indexed flat by the output dims like the reference kernel), cols [B,Ho*Wo,9*C] (k = tap*C + c).

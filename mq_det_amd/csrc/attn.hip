@@ -50,8 +50,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l15 = lane & 15, lg = lane >> 4;
-  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
-  const int split = blockIdx.z;
+  // XCD-aware work order.  Workgroup i runs on XCD i % 8 and every XCD has its own 4 MB L2, so all workgroups that
+  // stream the SAME K/V data -- the H heads x q-tiles of one (batch element, key split) "group" -- are placed on ONE XCD,
+  // consecutive in time, heads fastest (the heads of one q-tile also share Q when q_hs == 0).  With the naive
+  // (q-tile, b*H + h, split) grid the 16 workgroups of a VLFuse text->image group sat on 8 different XCDs and each
+  // pulled its 3.8 MB of image tokens through the Infinity-Cache path (~11 B/clk/CU instead of ~50 from L2,
+  // profiles/r01_ingest_microbench.txt).
+  const int qtiles = (p.Nq + BM - 1) / BM;
+  const int members = p.H * qtiles;
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int group = (seq / members) * 8 + xcd;                 // group = b * nsplit + split
+  if (group >= p.B * p.nsplit) return;
+  const int wq = seq % members;
+  const int h = wq % p.H, qtile = wq / p.H;
+  const int b = group / p.nsplit, split = group % p.nsplit;
+  const int bh = b * p.H + h;
   // head strides are free parameters: 0 shares one operand across all heads (folded VLFuse projections)
   const half_t* Q = p.q + (long)b * p.q_bs + (long)h * p.q_hs;
   const half_t* K = p.k + (long)b * p.k_bs + (long)h * p.k_hs;
@@ -65,7 +78,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const int tps = (ntiles + p.nsplit - 1) / p.nsplit;
   const int t0 = split * tps;
   const int t1 = min(ntiles, t0 + tps);
-  const int row0 = blockIdx.x * BM + wave * (RB * 16);
+  const int row0 = qtile * BM + wave * (RB * 16);
 
   half8 qf[QLDS ? 1 : RB][QLDS ? 1 : D / 32];
   if constexpr (QLDS) {
@@ -75,7 +88,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int i = 0; i < QCH; ++i) {          // all loads in flight first, then the LDS stores
       int c = tid + i * 256;
-      int row = min((int)blockIdx.x * BM + c / (D / 8), p.Nq - 1);
+      int row = min(qtile * BM + c / (D / 8), p.Nq - 1);
       qtmp[i] = *(const half8*)(Q + (long)row * p.q_rs + (c % (D / 8)) * 8);
     }
 #pragma unroll
@@ -287,7 +300,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     }
   } else {
     // workspace: [nsplit][B*H][Nq][D + 2] floats  (O unnormalised, then m, l)
-    float* W = p.ws + ((long)split * gridDim.y + bh) * (long)p.Nq * (D + 2);
+    float* W = p.ws + ((long)split * (p.B * p.H) + bh) * (long)p.Nq * (D + 2);
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -354,7 +367,8 @@ static int launch_attn(const AttnParams& p, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  dim3 grid((p.Nq + BM - 1) / BM, p.B * p.H, p.nsplit);
+  const int groups = p.B * p.nsplit, members = p.H * ((p.Nq + BM - 1) / BM);
+  dim3 grid((unsigned)(8 * ((groups + 7) / 8) * members));
   hipLaunchKernelGGL((attn_fwd_kernel<D, RB>), grid, dim3(256), smem, stream, p);
   MQ_CHECK_LAUNCH();
   if (p.nsplit > 1) {

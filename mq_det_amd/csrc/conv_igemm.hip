@@ -43,7 +43,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
   const int wr = wave / WN, wc = wave % WN;
   const int n_pos = p.Ho * p.Wo;
   const long M = (long)p.B * n_pos;
-  const long m0 = (long)blockIdx.x * BM;
+  // XCD-aware tile order (workgroup i runs on XCD i % 8, one 4 MB L2 per XCD): XCD x owns the contiguous tile range
+  // [x * tpx, (x + 1) * tpx), so the 3-row halo shared by vertically adjacent tiles is re-used from ITS L2.
+  const long ntiles = (M + BM - 1) / BM, tpx = (ntiles + 7) >> 3;
+  const long tile = (blockIdx.x & 7) * tpx + (blockIdx.x >> 3);
+  if (tile >= ntiles) return;
+  const long m0 = tile * BM;
   const int K = 9 * p.C;
   const int ksteps = K / BK;
   const int steps_per_tap = p.C / BK;
@@ -214,7 +219,7 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
     attr_set = true;
   }
   long M = (long)p.B * p.Ho * p.Wo;
-  hipLaunchKernelGGL((conv_igemm_kernel<DEFORM, BN, WM, WN>), dim3((unsigned)((M + BM - 1) / BM)), dim3(256), smem, stream, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<DEFORM, BN, WM, WN>), dim3((unsigned)(8 * (((M + BM - 1) / BM + 7) / 8))), dim3(256), smem, stream, p);
   MQ_CHECK_LAUNCH();
   return 0;
 }

@@ -1,0 +1,553 @@
+// VLFuse bi-directional cross attention (BiMultiHeadAttention, reference utils/fuse_helper.py:218-303) for gfx950:
+// two kernels specialised for 8 heads x 256, image tokens N ~ 22400 / image, text tokens T <= 256, with the image-side
+// projections folded into the text operands, so that both read LN(v) [B, N, 256] directly.
+//
+//   mq_vlfuse_i2t_fwd   (image side):  out[b,n,:] = LN(v)[b,n,:] + ob + sum_h softmax_t( clamp(LN(v)[b,n].Kf[b,h,t] + bias[b,h,t]) ) Vo[b,h,t,:]
+//   mq_vlfuse_t2i_fwd   (text side):   out[b,t,h,:] = softmax_n( clamp(Kf[b,h,t].LN(v)[b,n]) ) LN(v)[b,n,:]
+//
+// What the generic mq_attn_fwd (attn.hip) left on the table for these two shapes (profiles/README.md):
+//   * image side: one workgroup per (q-tile, head) re-read the 64 KB Q tile and wrote a 64 KB per-head output for each
+//     of the 8 heads (1.5 GB of HBM traffic per launch, then a separate head-sum kernel read it all back).  Here a
+//     workgroup keeps its Q fragments in registers, loops over the 8 heads, accumulates sum_h P_h Vo_h in ONE fp32
+//     accumulator (exact softmax per head: all <= 256 logits of a row stay in registers) and writes the final
+//     residual-added [128, 256] tile once: 92 MB read + 92 MB written per launch.
+//   * text side: keys and values are the SAME rows (LN(v)); the generic kernel loaded them twice (row-major K tile and
+//     a strided V^T tile).  Here one row-major tile in LDS feeds both MFMAs: QK^T reads it with ds_read_b128, PV reads
+//     it TRANSPOSED with ds_read_b64_tr_b16.
+//   * both: S^T = K Q^T is computed instead of S (operands swapped), so a lane that owns column `query` of S^T already
+//     holds exactly the P^T B-fragment the PV MFMA needs (k-slot (lg, j) <-> key 16*(j/4) + 4*lg + j%4, the same
+//     permutation the transposed V read produces): P never goes through LDS, row reductions are 2 shuffles.
+//   * both: XCD-aware work order (all workgroups streaming the same tiles sit on one XCD -> its L2 serves them),
+//     two-slot register prefetch ring (tiles u+1 and u+2 in flight while tile u is on the MFMAs), double-buffered LDS
+//     tiles with row pitch 272 halfs (conflict-free for both the b128 and the tr_b16 reads), one barrier per tile.
+#include "common.h"
+#include <type_traits>
+
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(8)));
+typedef __attribute__((address_space(3))) fp16x4_t* lds_fp16x4_ptr;
+
+// 4x16 fp16 block, row-major in LDS (row pitch free), read column-wise: within a 16-lane group lane i passes the
+// address of the 4 contiguous halfs (row i/4, cols 4*(i%4)..+3) and receives (row 0..3, col i).
+__device__ __forceinline__ half4 lds_read_tr16(const half_t* p) {
+  fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4_ptr)p);
+  half4 o;
+  __builtin_memcpy(&o, &v, 8);
+  return o;
+}
+
+namespace {
+constexpr int VH = 8, VD = 256;            // heads, head dim
+constexpr int BM = 128;                    // query rows per workgroup (4 waves x 32)
+constexpr int TK = 64;                     // keys per tile
+constexpr int KS = VD + 16;                // LDS row pitch (halfs): 544 B -> 8 consecutive rows cover all 64 banks
+constexpr int TILE = TK * KS;              // halfs per LDS tile
+using S0 = std::integral_constant<int, 0>;
+using S1 = std::integral_constant<int, 1>;
+}  // namespace
+
+struct I2TParams {
+  const half_t* v;        // [B, N, 256] LN(v): queries and residual
+  const half_t* kf;       // [B, 8, T, 256] folded text keys
+  const half_t* vo;       // [B, 8, T, 256] folded text values
+  const float* bias;      // [B, 8, T] additive logit bias; <= -1e29 marks a masked key
+  const int* kv_len;      // [B] or nullptr: keys >= kv_len[b] are masked
+  const half_t* obias;    // [256]
+  half_t* out;            // [B, N, 256]
+  int B, N, T;
+  float clamp;
+};
+
+// One tile = 64 rows x 256 halfs (32 KB): 8 x 16-byte chunks per thread.
+struct TileRegs { half8 r[8]; };
+
+__device__ __forceinline__ void tile_issue(TileRegs& t, const half_t* src, int row0, int last_row, int tid) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = tid + i * 256;
+    const int row = min(row0 + (c >> 5), last_row);
+    t.r[i] = *(const half8*)(src + (long)row * VD + (c & 31) * 8);
+  }
+}
+__device__ __forceinline__ void tile_commit(const TileRegs& t, half_t* dst, int tid) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = tid + i * 256;
+    *(half8*)(dst + (c >> 5) * KS + (c & 31) * 8) = t.r[i];
+  }
+}
+
+// S^T[nb][qb] = K_tile . Q^T : A = K rows (keys) from LDS, B = Q fragments from registers (QLDS: from the LDS copy)
+template <bool QLDS>
+__device__ __forceinline__ void qk_tile(const half_t* tile, const half8 (&qf)[2][8], const half_t* qw, float4_ (&s)[4][2],
+                                        int l15, int lg) {
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) s[nb][qb] = (float4_){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kk = 0; kk < VD / 32; ++kk) {
+    half8 kf[4], qq[2];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) kf[nb] = *(const half8*)(tile + (nb * 16 + l15) * KS + kk * 32 + lg * 8);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      if constexpr (QLDS) qq[qb] = *(const half8*)(qw + (qb * 16 + l15) * KS + kk * 32 + lg * 8);
+      else qq[qb] = qf[qb][kk];
+    }
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) s[nb][qb] = mfma16(kf[nb], qq[qb], s[nb][qb]);
+  }
+}
+
+// O^T[db][qb] += V_tile^T . P^T : A = transposed reads of the row-major tile, B = P^T fragments from registers
+__device__ __forceinline__ void pv_tile(const half_t* tile, const half8 (&pf)[2][2], float4_ (&o)[16][2], int l15, int lg) {
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const half_t* base = tile + (st * 32 + 4 * lg + (l15 >> 2)) * KS + (l15 & 3) * 4;
+#pragma unroll
+    for (int db = 0; db < 16; ++db) {
+      const half4 lo = lds_read_tr16(base + db * 16);
+      const half4 hi = lds_read_tr16(base + 16 * KS + db * 16);
+      half8 a;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[j] = lo[j]; a[4 + j] = hi[j]; }
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) o[db][qb] = mfma16(a, pf[st][qb], o[db][qb]);
+    }
+  }
+}
+
+// NT = number of 64-key tiles whose logits stay in registers.  NT <= 2 (<= 128 text tokens): Q fragments in registers and a
+// two-slot prefetch ring.  NT >= 3 ("lean"): the logits alone take 96-128 VGPRs, so Q moves to LDS and the ring has one slot.
+template <int NT>
+__global__ __launch_bounds__(256) void vlfuse_i2t_kernel(I2TParams p) {
+  constexpr bool LEAN = NT >= 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* tiles = (half_t*)smem;                           // [2][TK][KS]
+  half_t* Qs = tiles + 2 * TILE;                           // [BM][KS] (LEAN only)
+  float* bias_s = (float*)(Qs + (LEAN ? BM * KS : 0));     // [8][NT*64]
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l15 = lane & 15, lg = lane >> 4;
+  // XCD-aware order: workgroup i runs on XCD i % 8; XCD x takes images x, x + 8, ... (their text operands stay in its L2)
+  const int qtiles = (p.N + BM - 1) / BM;
+  const int seq = blockIdx.x >> 3;
+  const int b = (seq / qtiles) * 8 + (blockIdx.x & 7);
+  if (b >= p.B) return;
+  const int qtile = seq % qtiles;
+  const int row0 = qtile * BM + wave * 32;
+
+  const int kv_eff = p.kv_len ? max(1, min(p.T, p.kv_len[b])) : p.T;
+  for (int i = tid; i < VH * NT * TK; i += 256) {
+    const int h = i / (NT * TK), t = i % (NT * TK);
+    float v = MQ_NEG_BIG;
+    if (t < kv_eff) v = p.bias ? p.bias[((long)b * VH + h) * p.T + t] : 0.f;
+    bias_s[i] = v;
+  }
+
+  half8 qf[2][8];
+  const half_t* vb = p.v + (long)b * p.N * VD;
+  const half_t* qw = Qs + wave * 32 * KS;
+  if constexpr (LEAN) {
+    TileRegs q0, q1;                                        // 128 rows = two 64-row tiles
+    tile_issue(q0, vb, qtile * BM, p.N - 1, tid);
+    tile_issue(q1, vb, qtile * BM + 64, p.N - 1, tid);
+    tile_commit(q0, Qs, tid);
+    tile_commit(q1, Qs + 64 * KS, tid);
+  } else {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int row = min(row0 + qb * 16 + l15, p.N - 1);
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = *(const half8*)(vb + (long)row * VD + kk * 32 + lg * 8);
+    }
+  }
+
+  float4_ o[16][2];
+#pragma unroll
+  for (int db = 0; db < 16; ++db)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) o[db][qb] = (float4_){0.f, 0.f, 0.f, 0.f};
+
+  // tile stream: u = h * 2NT + j;  j < NT: key tile j of head h,  j >= NT: value tile j - NT.  2NT is even, so the
+  // position parity inside a head is also the parity of u: LDS buffer and register slot indices are compile-time.
+  constexpr int PER_HEAD = 2 * NT, U = VH * PER_HEAD;
+  TileRegs slot[LEAN ? 1 : 2];
+  auto issue = [&](auto SLOT, int u) {
+    constexpr int sl = decltype(SLOT)::value;
+    u = min(u, U - 1);                                     // the tail re-loads the last tile: one code path, no branches
+    const int h = u / PER_HEAD, j = u % PER_HEAD;
+    const half_t* src = (j < NT ? p.kf : p.vo) + ((long)b * VH + h) * p.T * VD;
+    tile_issue(slot[sl], src, (j < NT ? j : j - NT) * TK, p.T - 1, tid);
+  };
+  // begin(pos): prefetch;  end(pos): commit the next tile into the other LDS buffer + barrier
+  auto begin = [&](auto POS, int u) {
+    constexpr int par = decltype(POS)::value & 1;
+    if constexpr (LEAN) issue(S0{}, u + 1);
+    else issue(std::integral_constant<int, par>{}, u + 2);  // the slot of tile u was committed one step ago
+    __builtin_amdgcn_sched_barrier(0);                     // keep the prefetch ahead of everything that waits on VMEM
+  };
+  auto end = [&](auto POS) {
+    constexpr int par = decltype(POS)::value & 1;
+    __builtin_amdgcn_sched_barrier(0);
+    tile_commit(slot[LEAN ? 0 : (par ^ 1)], tiles + (par ^ 1) * TILE, tid);
+    __syncthreads();
+  };
+  issue(S0{}, 0);
+  if constexpr (!LEAN) issue(S1{}, 1);
+  tile_commit(slot[0], tiles, tid);
+  __syncthreads();
+
+  for (int h = 0; h < VH; ++h) {
+    const int u0 = h * PER_HEAD;
+    float4_ s[NT][4][2];
+    // ---- logits of all key tiles of this head (kept in registers: exact softmax, no running rescale)
+    auto qk_step = [&](auto J) {
+      constexpr int j = decltype(J)::value;
+      begin(J, u0 + j);
+      qk_tile<LEAN>(tiles + (j & 1) * TILE, qf, qw, s[j], l15, lg);
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const float4_ kb = *(const float4_*)(bias_s + (h * NT + j) * TK + nb * 16 + 4 * lg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool masked = kb[r] < -1.0e29f;
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb) {
+            float v = s[j][nb][qb][r] + kb[r];
+            if (p.clamp > 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
+            s[j][nb][qb][r] = masked ? MQ_NEG_BIG : v;
+          }
+        }
+      }
+      end(J);
+    };
+    qk_step(std::integral_constant<int, 0>{});
+    if constexpr (NT > 1) qk_step(std::integral_constant<int, 1>{});
+    if constexpr (NT > 2) qk_step(std::integral_constant<int, 2>{});
+    if constexpr (NT > 3) qk_step(std::integral_constant<int, 3>{});
+
+    // ---- softmax over the text keys: a lane owns query column l15 of block qb; its keys are spread over (j, nb, r)
+    // in-lane and over the 4 lane groups lg.  s <- exp(s - max) / sum
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float mx = MQ_NEG_BIG;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[j][nb][qb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __expf(s[j][nb][qb][r] - mx);
+            s[j][nb][qb][r] = e;
+            sum += e;
+          }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      const float inv = 1.f / sum;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[j][nb][qb][r] *= inv;
+    }
+    // ---- O^T += Vo_h^T P_h^T over the value tiles of this head (P^T fragments are built from s[j] right before use)
+    auto pv_step = [&](auto J) {
+      constexpr int j = decltype(J)::value;
+      using POS = std::integral_constant<int, NT + j>;
+      begin(POS{}, u0 + NT + j);
+      half8 pf[2][2];
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pf[st][qb][r] = (half_t)s[j][2 * st][qb][r];
+            pf[st][qb][4 + r] = (half_t)s[j][2 * st + 1][qb][r];
+          }
+      pv_tile(tiles + ((NT + j) & 1) * TILE, pf, o, l15, lg);
+      end(POS{});
+    };
+    pv_step(std::integral_constant<int, 0>{});
+    if constexpr (NT > 1) pv_step(std::integral_constant<int, 1>{});
+    if constexpr (NT > 2) pv_step(std::integral_constant<int, 2>{});
+    if constexpr (NT > 3) pv_step(std::integral_constant<int, 3>{});
+  }
+
+  // ---- epilogue: O^T -> LDS (row = query), + residual LN(v) + out-proj bias, 16-byte coalesced stores
+  constexpr int OS = VD + 8;
+  half_t* Os = tiles + wave * (32 * OS);                   // [4][32][OS] aliases the tiles (all waves passed the last barrier)
+#pragma unroll
+  for (int db = 0; db < 16; ++db)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      half4 v4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v4[r] = (half_t)o[db][qb][r];
+      *(half4*)(Os + (qb * 16 + l15) * OS + db * 16 + 4 * lg) = v4;
+    }
+  wave_lds_fence();
+  half_t* ob = p.out + (long)b * p.N * VD;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + i * 64;
+    const int rr = c >> 5, ch = c & 31;
+    const int row = row0 + rr;
+    if (row < p.N) {
+      const half8 a = *(const half8*)(Os + rr * OS + ch * 8);
+      const half8 res = *(const half8*)(vb + (long)row * VD + ch * 8);
+      const half8 bb = *(const half8*)(p.obias + ch * 8);
+      half8 y;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) y[j] = (half_t)((float)a[j] + (float)res[j] + (float)bb[j]);
+      *(half8*)(ob + (long)row * VD + ch * 8) = y;
+    }
+  }
+}
+
+template <int NT>
+static int launch_i2t(const I2TParams& p, hipStream_t stream) {
+  constexpr size_t smem = (size_t)(2 * TILE + (NT >= 3 ? BM * KS : 0)) * sizeof(half_t) + (size_t)VH * NT * TK * sizeof(float);
+  static_assert(4 * 32 * (VD + 8) <= 2 * TILE, "O staging must fit in the tiles");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)vlfuse_i2t_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int qtiles = (p.N + BM - 1) / BM;
+  hipLaunchKernelGGL((vlfuse_i2t_kernel<NT>), dim3((unsigned)(8 * ((p.B + 7) / 8) * qtiles)), dim3(256), smem, stream, p);
+  MQ_CHECK_LAUNCH();
+  return 0;
+}
+
+// Image side of VLFuse.  max_kv: host-known upper bound of kv_len (T if unknown) -- picks the number of 64-key tiles
+// kept in registers.  See include/mqdet_hip.h.
+extern "C" int mq_vlfuse_i2t_fwd(const void* v_ln, const void* kf, const void* vo, const float* bias, const int* kv_len,
+                                 const void* out_bias, void* out, int B, int N, int T, int max_kv, float clamp, void* stream) {
+  if (B <= 0 || N <= 0) return 0;
+  if (T < 1 || T > 256) return -1;
+  I2TParams p;
+  p.v = (const half_t*)v_ln; p.kf = (const half_t*)kf; p.vo = (const half_t*)vo; p.bias = bias; p.kv_len = kv_len;
+  p.obias = (const half_t*)out_bias; p.out = (half_t*)out; p.B = B; p.N = N; p.T = T; p.clamp = clamp;
+  const int kv = (kv_len && max_kv > 0) ? min(max_kv, T) : T;
+  switch ((kv + TK - 1) / TK) {
+    case 1: return launch_i2t<1>(p, (hipStream_t)stream);
+    case 2: return launch_i2t<2>(p, (hipStream_t)stream);
+    case 3: return launch_i2t<3>(p, (hipStream_t)stream);
+    default: return launch_i2t<4>(p, (hipStream_t)stream);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ text side
+struct T2IParams {
+  const half_t* kf;       // [B, 8, T, 256] queries = folded text keys
+  const half_t* v;        // [B, N, 256] LN(v): keys AND values
+  float* ws;              // [nsplit][B*8][T][WS_LD] fp32 partials: O (un-normalised), then m, l
+  half_t* out;            // [B, T, 8*256]
+  int B, N, T, nsplit;
+  float clamp;
+};
+namespace { constexpr int WS_LD = VD + 4; }               // 260 floats: rows stay 16-byte aligned
+
+__global__ __launch_bounds__(256) void vlfuse_t2i_kernel(T2IParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* tiles = (half_t*)smem;                           // [2][TK][KS]
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l15 = lane & 15, lg = lane >> 4;
+  // XCD-aware order: the 8 heads x q-tiles of one (image, key split) stream the SAME image tokens -> one XCD, adjacent
+  const int qtiles = (p.T + BM - 1) / BM;
+  const int members = VH * qtiles;
+  const int seq = blockIdx.x >> 3;
+  const int group = (seq / members) * 8 + (blockIdx.x & 7);
+  if (group >= p.B * p.nsplit) return;
+  const int wq = seq % members, h = wq % VH, qtile = wq / VH;
+  const int b = group / p.nsplit, split = group % p.nsplit;
+  const int row0 = qtile * BM + wave * 32;
+
+  const int ntiles = (p.N + TK - 1) / TK;
+  const int tps = (ntiles + p.nsplit - 1) / p.nsplit;
+  const int t0 = split * tps, t1 = min(ntiles, t0 + tps);
+  const int nt = max(t1 - t0, 0);
+
+  half8 qf[2][8];
+  const half_t* qb_ = p.kf + ((long)b * VH + h) * p.T * VD;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int row = min(row0 + qb * 16 + l15, p.T - 1);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = *(const half8*)(qb_ + (long)row * VD + kk * 32 + lg * 8);
+  }
+  float4_ o[16][2];
+#pragma unroll
+  for (int db = 0; db < 16; ++db)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) o[db][qb] = (float4_){0.f, 0.f, 0.f, 0.f};
+  float m[2] = {MQ_NEG_BIG, MQ_NEG_BIG}, lsum[2] = {0.f, 0.f};   // per query column (m replicated over lg, lsum a per-lane partial)
+
+  const half_t* vb = p.v + (long)b * p.N * VD;
+  TileRegs slot[2];
+  auto issue = [&](auto SLOT, int pos) {
+    constexpr int sl = decltype(SLOT)::value;
+    const int t = t0 + min(pos, max(nt - 1, 0));
+    tile_issue(slot[sl], vb, t * TK, p.N - 1, tid);
+  };
+  constexpr float THR = 8.0f;     // deferred rescale: O / l are rescaled only when a row max grows by more than THR
+  auto body = [&](auto PAR, int pos) {
+    constexpr int par = decltype(PAR)::value;
+    issue(PAR, pos + 2);                                   // the slot of tile pos was committed one step ago
+    __builtin_amdgcn_sched_barrier(0);
+    if (pos < nt) {
+      const half_t* tile = tiles + par * TILE;
+      float4_ s[4][2];
+      qk_tile<false>(tile, qf, nullptr, s, l15, lg);
+      const int key0 = (t0 + pos) * TK;
+      float mx[2] = {MQ_NEG_BIG, MQ_NEG_BIG};
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool valid = key0 + nb * 16 + 4 * lg + r < p.N;
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb) {
+            float v = s[nb][qb][r];
+            if (p.clamp > 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
+            v = valid ? v : MQ_NEG_BIG;
+            s[nb][qb][r] = v;
+            mx[qb] = fmaxf(mx[qb], v);
+          }
+        }
+      bool grow = false;
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        mx[qb] = fmaxf(mx[qb], __shfl_xor(mx[qb], 16));
+        mx[qb] = fmaxf(mx[qb], __shfl_xor(mx[qb], 32));
+        grow |= mx[qb] > m[qb] + THR;
+      }
+      if (__any(grow)) {                                   // wave-uniform, rare after the first tiles
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+          const float mnew = fmaxf(m[qb], mx[qb]);
+          const float alpha = __expf(m[qb] - mnew);
+          m[qb] = mnew;
+          lsum[qb] *= alpha;
+#pragma unroll
+          for (int db = 0; db < 16; ++db)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[db][qb][r] *= alpha;
+        }
+      }
+      half8 pf[2][2];
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e0 = __expf(s[2 * st][qb][r] - m[qb]);          // <= e^THR; exact after the final 1/l
+            const float e1 = __expf(s[2 * st + 1][qb][r] - m[qb]);
+            lsum[qb] += e0 + e1;
+            pf[st][qb][r] = (half_t)e0;
+            pf[st][qb][4 + r] = (half_t)e1;
+          }
+      pv_tile(tile, pf, o, l15, lg);                       // the SAME tile: values = keys
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    tile_commit(slot[par ^ 1], tiles + (par ^ 1) * TILE, tid);
+    __syncthreads();
+  };
+  issue(S0{}, 0);
+  issue(S1{}, 1);
+  tile_commit(slot[0], tiles, tid);
+  __syncthreads();
+  for (int pos = 0; pos < nt; pos += 2) {
+    body(S0{}, pos);
+    body(S1{}, pos + 1);
+  }
+
+  // ---- partials -> workspace (O^T: lane owns 4 consecutive d of one query row -> one 16-byte store)
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    float l = lsum[qb];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const int row = row0 + qb * 16 + l15;
+    if (row < p.T) {
+      float* w = p.ws + (((long)split * p.B * VH + (long)b * VH + h) * p.T + row) * WS_LD;
+#pragma unroll
+      for (int db = 0; db < 16; ++db) *(float4_*)(w + db * 16 + 4 * lg) = o[db][qb];
+      if (lg == 0) { w[VD] = m[qb]; w[VD + 1] = l; }
+    }
+  }
+}
+
+// merge the key-split partials: one wave per (b, h, text row); out[b, row, h*256 + d]
+__global__ __launch_bounds__(256) void vlfuse_t2i_combine_kernel(T2IParams p) {
+  const int lane = threadIdx.x & 63;
+  const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long total = (long)p.B * VH * p.T;
+  if (gw >= total) return;
+  const int row = gw % p.T;
+  const int bh = gw / p.T, b = bh / VH, h = bh % VH;
+  const long stride = total * WS_LD;
+  const float* base = p.ws + gw * WS_LD;
+  float mx = MQ_NEG_BIG;
+  for (int s = 0; s < p.nsplit; ++s) mx = fmaxf(mx, base[s * stride + VD]);
+  float l = 0.f;
+  float4_ acc = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < p.nsplit; ++s) {
+    const float* w = base + s * stride;
+    const float f = __expf(w[VD] - mx);
+    l += w[VD + 1] * f;
+    const float4_ v = *(const float4_*)(w + lane * 4);
+    acc += v * f;
+  }
+  const float inv = 1.f / l;
+  half4 y;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) y[j] = (half_t)(acc[j] * inv);
+  *(half4*)(p.out + ((long)b * p.T + row) * (VH * VD) + h * VD + lane * 4) = y;
+}
+
+extern "C" long mq_vlfuse_t2i_workspace_bytes(int B, int T, int nsplit) {
+  return (long)(nsplit < 1 ? 1 : nsplit) * B * VH * T * WS_LD * (long)sizeof(float);
+}
+
+// Text side of VLFuse (always through the split workspace + combine, nsplit >= 1).  See include/mqdet_hip.h.
+extern "C" int mq_vlfuse_t2i_fwd(const void* kf, const void* v_ln, void* workspace, void* out, int B, int N, int T, int nsplit,
+                                 float clamp, void* stream) {
+  if (B <= 0 || T <= 0) return 0;
+  if (N < 1 || workspace == nullptr) return -1;
+  if (nsplit < 1) nsplit = 1;
+  T2IParams p;
+  p.kf = (const half_t*)kf; p.v = (const half_t*)v_ln; p.ws = (float*)workspace; p.out = (half_t*)out;
+  p.B = B; p.N = N; p.T = T; p.nsplit = nsplit; p.clamp = clamp;
+  constexpr size_t smem = (size_t)2 * TILE * sizeof(half_t);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)vlfuse_t2i_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int groups = B * nsplit, members = VH * ((T + BM - 1) / BM);
+  hipLaunchKernelGGL(vlfuse_t2i_kernel, dim3((unsigned)(8 * ((groups + 7) / 8) * members)), dim3(256), smem, (hipStream_t)stream, p);
+  MQ_CHECK_LAUNCH();
+  const long total = (long)B * VH * T;
+  hipLaunchKernelGGL(vlfuse_t2i_combine_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+  MQ_CHECK_LAUNCH();
+  return 0;
+}

@@ -103,19 +103,24 @@ class GeneralizedVLRCNN_New(nn.Module):
             tok = self.tokenizer(list(captions), max_length=LB.MAX_QUERY_LEN,
                                  padding="max_length" if LB.PAD_MAX else "longest",
                                  return_special_tokens_mask=True, return_tensors="pt", truncation=True)
-            hit = (tok["input_ids"].to(device), tok["attention_mask"].to(device))
+            am = tok["attention_mask"]
+            # host-side bound of the per-caption key length (last attended position + 1): picks the kernel variant of
+            # the VLFuse image-side attention, and is part of the HIP-graph key
+            max_kv = int((am * torch.arange(1, am.shape[1] + 1)).max())
+            hit = (tok["input_ids"].to(device), am.to(device), max_kv)
             if len(self._tok_cache) > 256:
                 self._tok_cache.clear()
             self._tok_cache[key] = hit
         return hit
 
     # ------------------------------------------------------------------ device part (capturable in a HIP graph)
-    def _device_forward(self, x, input_ids, attention_mask, vision, idx, tokidx, label_ids, im_wh, want_raw=False):
+    def _device_forward(self, x, input_ids, attention_mask, vision, idx, tokidx, label_ids, im_wh, max_kv=0, want_raw=False):
         P, cfg = self._plan, self.cfg
         feats = pipeline.fpn_forward(P, pipeline.swin_forward(P, cfg, x))
         pooled = pipeline.pooled_fpn_tokens(feats) if vision is not None else None
         lang = pipeline.language_backbone(P, cfg, input_ids, attention_mask, vision, pooled, idx,
                                           want_gates=cfg.VISION_QUERY.RETURN_ATTN_GATE_VALUE)
+        lang["max_kv"] = max_kv
         head = pipeline.vldyhead(P, cfg, feats, lang)
         sizes = tuple(tuple(f.shape[-2:]) for f in feats)
         if sizes not in self._anchor_cache:                       # constant per feature-map geometry
@@ -172,7 +177,9 @@ class GeneralizedVLRCNN_New(nn.Module):
         x = images.tensors.to(dtype).contiguous(memory_format=torch.channels_last)
         Bn = x.shape[0]
         if input_ids is None:
-            input_ids, attention_mask = self.tokenize(captions, dev)
+            input_ids, attention_mask, max_kv = self.tokenize(captions, dev)
+        else:                                                     # caller-supplied ids (tests): one host sync
+            max_kv = int((attention_mask.cpu() * torch.arange(1, attention_mask.shape[1] + 1)).max())
         T = input_ids.shape[1]
 
         # host-side glue: all memoised, no device sync
@@ -190,14 +197,14 @@ class GeneralizedVLRCNN_New(nn.Module):
         if im_wh is None:
             im_wh = self._wh_cache[wh_key] = torch.tensor([[w, h] for (h, w) in images.image_sizes],
                                                           dtype=torch.float32, device=dev)
-        inputs = (x, input_ids, attention_mask, vision, idx, tokidx, label_ids, im_wh)
+        inputs = (x, input_ids, attention_mask, vision, idx, tokidx, label_ids, im_wh, max_kv)
         if return_raw:
             return self._device_forward(*inputs, want_raw=True)
         from .. import ops
         use_graph = self.use_hip_graph and not ops.timing_active()
         if use_graph:
             key = (tuple(x.shape), T, None if vision is None else tuple(vision.shape), None if idx is None else tuple(idx.shape),
-                   tuple(tokidx.shape), wh_key)
+                   tuple(tokidx.shape), wh_key, -(-max_kv // 64))
             out = self._graph_forward(key, inputs)
         else:
             out = self._device_forward(*inputs)

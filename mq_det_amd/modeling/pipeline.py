@@ -293,37 +293,29 @@ def language_backbone(P, cfg, input_ids, attention_mask, vision, images, idx, wa
 
 
 # ----------------------------------------------------------------------------- VLDyHead
-def vl_fuse(P, b, feats, hidden, key_bias, kv_len=None):
+def vl_fuse(P, b, feats, hidden, key_bias, kv_len=None, max_kv=0):
     """BiAttentionBlockForCheckpoint / BiMultiHeadAttention (fuse_helper.py:218-303,377-426): one set of logits,
-    softmax over text for the image side and over image tokens for the text side -- two launches of the fused
-    attention kernel; the logits are never materialised (reference: 3 x [B*8, 22400, 256] fp32 tensors) and, with
-    the projections folded into the text-side operands, neither are the [B, 22400, 2048] q / value tensors:
-    the kernel reads LN(v) [B, N, 256] directly with a head stride of 0."""
+    softmax over text for the image side and over image tokens for the text side -- one launch each of the two
+    VLFuse kernels (vlfuse_attn.hip); the logits are never materialised (reference: 3 x [B*8, 22400, 256] fp32
+    tensors) and, with the projections folded into the text-side operands, neither are the [B, 22400, 2048] q / value
+    tensors: both kernels read LN(v) [B, N, 256] directly."""
     Bn = feats[0].shape[0]
     sizes = [f.shape[-2:] for f in feats]
     v = torch.cat([f.permute(0, 2, 3, 1).flatten(1, 2) for f in feats], 1)              # [B, N, 256]
-    N, C = v.shape[1], v.shape[2]
-    # LN(v) and LN(v)^T (the V^T operand of the text side) from ONE pass over v
-    v_ln, v_t = ops.layer_norm(v, P[b + ".layer_norm_v.weight"], P[b + ".layer_norm_v.bias"], 1e-5, transposed_out=True)
+    N = v.shape[1]
+    v_ln = ops.layer_norm(v, P[b + ".layer_norm_v.weight"], P[b + ".layer_norm_v.bias"], 1e-5)
     l_ln = _ln(P, b + ".layer_norm_l", hidden)
-    pad = (-N) % 8
-    v_pad = F.pad(v_ln, (0, 0, 0, pad)) if pad else v_ln
     a = b + ".attn"
     T = l_ln.shape[1]
-    k8 = _lin(P, a + ".l_proj", l_ln).reshape(Bn, T, 8, -1)                              # [B, T, 8, 256]
-    kf = torch.matmul(k8.permute(0, 2, 1, 3), P[b + ".Wq8"][None])                       # [B, 8, T, 256 in]
-    kf4 = kf.permute(0, 2, 1, 3)                                                         # [B, T, 8, 256] view
-    bias = torch.einsum("bthd,hd->bht", k8.float(), P[b + ".bq8"]) + key_bias[:, None, :]        # [B, 8, T] fp32
+    k8 = _lin(P, a + ".l_proj", l_ln).reshape(Bn, T, 8, -1).permute(0, 2, 1, 3)         # [B, 8, T, 256 hd]
+    kf = torch.matmul(k8, P[b + ".Wq8"][None])                                           # [B, 8, T, 256 in] folded keys
+    bias = torch.einsum("bhtd,hd->bht", k8.float(), P[b + ".bq8"]) + key_bias[:, None, :]        # [B, 8, T] fp32
     val_l8 = _lin(P, a + ".values_l_proj", l_ln).reshape(Bn, T, 8, -1).permute(0, 2, 1, 3)        # [B, 8, T, 256 hd]
-    vo_t = torch.matmul(val_l8, P[b + ".Wov8"][None]).transpose(2, 3).contiguous()                # [B, 8, 256 out, T]
-    # image side: queries = LN(v) shared by the 8 heads, keys = folded text keys, values = text values x out_v_proj
-    out_v = ops.attention4(v_ln[:, :, None, :].expand(Bn, N, 8, C), kf4, vo_t,
-                           key_bias=bias.contiguous(), scale=1.0, clamp=50000.0, kv_len=kv_len)   # [B, N, 8*256]
-    # text side: queries = folded text keys, keys = values = LN(v) (shared by the heads)
-    out_l = ops.attention4(kf4, v_pad[:, :, None, :].expand(Bn, v_pad.shape[1], 8, C),
-                           v_t[:, None].expand(Bn, 8, C, v_t.shape[2]), scale=1.0, clamp=50000.0, nk=N,
-                           nsplit=_nsplit(-(-T // 128) * Bn * 8, -(-N // 64)))
-    v_new = ops.headsum_residual(out_v, v_ln, P[b + ".ov.bias"], 8)                      # residual on the NORMED v, l
+    vo = torch.matmul(val_l8, P[b + ".Wov8"][None])                                      # [B, 8, T, 256 out] folded values
+    # image side: queries = LN(v) shared by the 8 heads; head sum, out-proj bias and the residual (on the NORMED v) fused
+    v_new = ops.vlfuse_i2t(v_ln, kf, vo, bias.contiguous(), P[b + ".ov.bias"], kv_len=kv_len, max_kv=max_kv)
+    # text side: queries = folded text keys, keys = values = LN(v)
+    out_l = ops.vlfuse_t2i(kf, v_ln, _nsplit(-(-T // 128) * Bn * 8, -(-N // 64)))
     l_new = l_ln + _lin(P, b + ".olc", out_l)
     out, s = [], 0
     for (hh, ww) in sizes:
@@ -427,7 +419,7 @@ def vldyhead(P, cfg, feats, lang):
     hidden, key_bias, kv_len = lang["hidden"], lang["key_bias"], lang.get("kv_len")
     for i in range(cfg.MODEL.DYHEAD.NUM_CONVS):
         t = f"{p}.dyhead_tower"
-        feats, hidden = vl_fuse(P, f"{t}.{3 * i}.b_attn", feats, hidden, key_bias, kv_len)
+        feats, hidden = vl_fuse(P, f"{t}.{3 * i}.b_attn", feats, hidden, key_bias, kv_len, lang.get("max_kv", 0))
         hidden = bert_layer(P, f"{t}.{3 * i + 1}", hidden, key_bias, clamp=True, kv_len=kv_len)
         feats = dyconv(P, cfg, f"{t}.{3 * i + 2}", feats)
     emb = F.normalize(hidden.float(), p=2, dim=-1)

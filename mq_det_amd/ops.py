@@ -21,6 +21,9 @@ _SIGNATURES = {
     "mq_gcp_sparse_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_gcp_gate_residual_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
     "mq_headsum_residual_fwd": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
+    "mq_vlfuse_i2t_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "mq_vlfuse_t2i_workspace_bytes": (_l, [_i, _i, _i]),
+    "mq_vlfuse_t2i_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mq_dcn_im2col_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _f, _l, _l, _vp]),
     "mq_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _vp]),
@@ -220,6 +223,46 @@ def headsum_residual(x, res, bias, heads):
     with _timed("headsum_residual"):
         _chk(lib.mq_headsum_residual_fwd(_ptr(x), _ptr(res), _ptr(bias), _ptr(out), M, heads, C, _stream()),
              "mq_headsum_residual_fwd")
+    return out
+
+
+def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.0):
+    """VLFuse image side (mq_vlfuse_i2t_fwd).  v_ln [B,N,256], kf / vo [B,8,T,256] fp16, bias [B,8,T] fp32 or None,
+    out_bias [256] fp16, kv_len [B] int32 or None (max_kv: host-side upper bound, 0 = T) -> [B,N,256] fp16:
+    v_ln + out_bias + sum_h softmax_t(clamp(v_ln.kf_h + bias_h)) vo_h."""
+    lib = load_library()
+    _need_gpu(v_ln, kf, vo, out_bias)
+    B, N, C = v_ln.shape
+    T = kf.shape[2]
+    assert C == 256 and kf.shape == (B, 8, T, 256) and vo.shape == kf.shape and T <= 256
+    assert v_ln.is_contiguous() and kf.is_contiguous() and vo.is_contiguous() and out_bias.is_contiguous()
+    assert v_ln.dtype == kf.dtype == vo.dtype == out_bias.dtype == torch.float16
+    if bias is not None:
+        assert bias.shape == (B, 8, T) and bias.dtype == torch.float32 and bias.is_contiguous()
+    if kv_len is not None:
+        assert kv_len.dtype == torch.int32 and kv_len.numel() == B and kv_len.is_contiguous()
+    out = torch.empty_like(v_ln)
+    with _timed(f"vlfuse_i2t_n{N}_t{T}"):
+        _chk(lib.mq_vlfuse_i2t_fwd(_ptr(v_ln), _ptr(kf), _ptr(vo), _ptr(bias), _ptr(kv_len), _ptr(out_bias), _ptr(out),
+                                   B, N, T, int(max_kv), float(clamp), _stream()), "mq_vlfuse_i2t_fwd")
+    return out
+
+
+def vlfuse_t2i(kf, v_ln, nsplit, clamp=50000.0):
+    """VLFuse text side (mq_vlfuse_t2i_fwd).  kf [B,8,T,256] (queries), v_ln [B,N,256] (keys = values) fp16
+    -> [B,T,8*256] fp16 = softmax_n(clamp(kf.v_ln)) v_ln per head."""
+    lib = load_library()
+    _need_gpu(kf, v_ln)
+    B, N, C = v_ln.shape
+    T = kf.shape[2]
+    assert C == 256 and kf.shape == (B, 8, T, 256) and kf.is_contiguous() and v_ln.is_contiguous()
+    assert kf.dtype == v_ln.dtype == torch.float16
+    nsplit = max(1, int(nsplit))
+    ws = torch.empty(lib.mq_vlfuse_t2i_workspace_bytes(B, T, nsplit) // 4, dtype=torch.float32, device=kf.device)
+    out = torch.empty(B, T, 8 * 256, dtype=torch.float16, device=kf.device)
+    with _timed(f"vlfuse_t2i_n{N}_t{T}_s{nsplit}"):
+        _chk(lib.mq_vlfuse_t2i_fwd(_ptr(kf), _ptr(v_ln), _ptr(ws), _ptr(out), B, N, T, nsplit, float(clamp), _stream()),
+             "mq_vlfuse_t2i_fwd")
     return out
 
 

@@ -242,3 +242,32 @@ def layer_norm(x, gamma, beta, eps=1e-5, transposed_out=False, pad_to=8):
 def headsum_residual(x, res, bias, heads):
     C = res.shape[-1]
     return (res.float() + bias.float() + x.float().reshape(*res.shape[:-1], heads, C).sum(-2)).to(res.dtype)
+
+
+def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.0):
+    B, N, C = v_ln.shape
+    T = kf.shape[2]
+    s = torch.einsum("bnc,bhtc->bhnt", v_ln.float(), kf.float())
+    masked = torch.zeros(B, 8, T, dtype=torch.bool)
+    if bias is not None:
+        masked = bias < -1e29
+        s = s + torch.where(masked, torch.zeros_like(bias), bias)[:, :, None, :]
+    if clamp > 0:
+        s = s.clamp(-clamp, clamp)
+    if kv_len is not None:
+        if max_kv > 0:
+            assert int(kv_len.max()) <= max_kv
+        masked = masked | (torch.arange(T)[None, None, :] >= kv_len.clamp(1, T)[:, None, None])
+    s = s.masked_fill(masked[:, :, None, :].expand_as(s), -1e30)
+    o = torch.einsum("bhnt,bhtc->bnc", s.softmax(-1), vo.float())
+    return (v_ln.float() + out_bias.float() + o).to(v_ln.dtype)
+
+
+def vlfuse_t2i(kf, v_ln, nsplit, clamp=50000.0):
+    B, N, C = v_ln.shape
+    T = kf.shape[2]
+    s = torch.einsum("bhtc,bnc->bhtn", kf.float(), v_ln.float())
+    if clamp > 0:
+        s = s.clamp(-clamp, clamp)
+    o = torch.einsum("bhtn,bnc->bthc", s.softmax(-1), v_ln.float())
+    return o.reshape(B, T, 8 * C).to(kf.dtype)

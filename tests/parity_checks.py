@@ -253,6 +253,36 @@ def check_vl_fuse(dev):
     return out
 
 
+def check_vlfuse_kernels(dev):
+    """The two VLFuse attention kernels (vlfuse_attn.hip) against a plain fp32 restatement on the same fp16 inputs:
+    every register-tile variant (NT = 1..4 text tiles), ragged N / T, kv_len, masked-bias keys, several key splits.
+    Inputs are random (not symmetric), so a transposed operand or a wrong k-slot permutation cannot cancel out."""
+    import ops_emulation as emu
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(21)
+    res = []
+    for B, N, T, kv in ((2, 645, 64, None), (3, 300, 100, [100, 37, 70]), (2, 200, 160, [131, 160]), (1, 130, 256, [256]),
+                        (9, 128, 40, None)):
+        v_ln = torch.randn(B, N, 256, generator=g).half()
+        kf = (torch.randn(B, 8, T, 256, generator=g) / 8).half()
+        vo = torch.randn(B, 8, T, 256, generator=g).half()
+        bias = torch.randn(B, 8, T, generator=g)
+        bias[:, :, T // 3] = -1e30                       # a masked key in the middle of the valid range
+        ob = torch.randn(256, generator=g).half()
+        kv_len = None if kv is None else torch.tensor(kv, dtype=torch.int32)
+        ref = emu.vlfuse_i2t(v_ln.float(), kf.float(), vo.float(), bias, ob.float(), kv_len, 0)
+        got = ops.vlfuse_i2t(v_ln.to(dev), kf.to(dev), vo.to(dev), bias.to(dev), ob.to(dev),
+                             None if kv_len is None else kv_len.to(dev), max_kv=0 if kv is None else max(kv))
+        res.append(_stat(f"vlfuse image side B={B} N={N} T={T} kv_len={kv}", got, ref, tol=2e-3))
+    for B, N, T, ns in ((2, 645, 64, 1), (1, 22400, 256, 6), (3, 1000, 100, 3), (2, 130, 160, 2), (9, 70, 40, 1)):
+        v_ln = torch.randn(B, N, 256, generator=g).half()
+        kf = (torch.randn(B, 8, T, 256, generator=g) / 8).half()
+        ref = emu.vlfuse_t2i(kf.float(), v_ln.float(), ns)
+        got = ops.vlfuse_t2i(kf.to(dev), v_ln.to(dev), ns)
+        res.append(_stat(f"vlfuse text side B={B} N={N} T={T} nsplit={ns}", got, ref, tol=2e-3))
+    return res
+
+
 def check_dcn(dev):
     """HIP gather + GEMM vs oracle dcn_v2, incl. stride 2 and the flat-offset-indexing quirk (offsets from a
     bigger level)."""
@@ -326,13 +356,15 @@ def check_dyconv(dev):
     with torch.no_grad():
         ref = oh.dyconv(sd, b, [f.float() for f in feats], spec)
         x = [f.to(dev).contiguous(memory_format=torch.channels_last) for f in feats]
-        got = pipeline.dyconv(P, cfg, b, x)
-        cfg.MODEL.DYHEAD.FUSED_DCN = True         # the one-kernel DCNv2 (dcn_fused.hip) must give the same layer
-        try:
+        prev = cfg.MODEL.DYHEAD.FUSED_DCN
+        try:                                      # both DCNv2 implementations must give the same layer
+            cfg.MODEL.DYHEAD.FUSED_DCN = False    # gather kernel + library GEMM
+            got = pipeline.dyconv(P, cfg, b, x)
+            cfg.MODEL.DYHEAD.FUSED_DCN = True     # one implicit-GEMM kernel (dcn_fused.hip)
             got2 = pipeline.dyconv(P, cfg, b, x)
         finally:
-            cfg.MODEL.DYHEAD.FUSED_DCN = False
-    return ([_stat(f"dyconv lvl{i}", got[i], ref[i], tol=1e-2) for i in range(5)]
+            cfg.MODEL.DYHEAD.FUSED_DCN = prev
+    return ([_stat(f"dyconv (im2col + GEMM) lvl{i}", got[i], ref[i], tol=1e-2) for i in range(5)]
             + [_stat(f"dyconv (fused DCNv2) lvl{i}", got2[i], ref[i], tol=1e-2) for i in range(5)])
 
 
@@ -464,6 +496,7 @@ def all_checks(dev):
             ("gcp", lambda: check_pre_select(dev)),
             ("bert", lambda: check_bert_layer(dev, False)),
             ("bert", lambda: check_bert_layer(dev, True)),
+            ("vlfuse", lambda: check_vlfuse_kernels(dev)),
             ("vlfuse", lambda: check_vl_fuse(dev)),
             ("dcn", lambda: check_dcn(dev)),
             ("conv", lambda: check_conv3x3(dev)),
