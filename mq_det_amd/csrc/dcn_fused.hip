@@ -18,8 +18,9 @@
 //   * all per-(row, tap) sampling state (4 corner offsets, 4 weights x mask) is computed ONCE into LDS in the prologue,
 //     so no global load other than the tile prefetch is ever consumed inside the k-loop (which would make hipcc drain
 //     the VMEM queue);
-//   * a two-slot register ring keeps the gathers of k-steps ks+1 and ks+2 in flight while step ks runs on the MFMAs
-//     (24 x 16-byte loads per thread outstanding), LDS tiles are double-buffered, one barrier per step.
+//   * a two-slot register ring keeps the gathers of two k-steps in flight, LDS tiles are double-buffered;
+//   * v5 "ping-pong": the two waves of a SIMD alternate roles every half step -- one runs the MFMAs of step ks while
+//     the other does the bilinear blend / LDS staging of step ks + 1 -- so VALU + LDS work hides under the matrix pipe.
 #include "common.h"
 #include <type_traits>
 
@@ -29,21 +30,25 @@ struct DcnFParams {
   int B, H, W, C, Ho, Wo, stride, oH, oW, out_ld, tiles_x, tiles_y, tiles_total;
 };
 
-struct alignas(16) TapState { int off[4]; float w[4]; };
+// per (output position, tap): BYTE offsets of the 4 bilinear corners inside the image, and corner weight x mask
+struct alignas(16) TapState { unsigned off[4]; float w[4]; };
 
 static constexpr int DCN_PH = 8, DCN_PW = 16;                // patch of output positions per workgroup
 
 __global__ __launch_bounds__(512) void dcn_igemm8_kernel(DcnFParams p) {
-  constexpr int BM = DCN_PH * DCN_PW, BN = 256, BK = 64, LP = BK + 8;
+  constexpr int BM = DCN_PH * DCN_PW, BN = 256, BK = 64;
   static_assert(BM == 128, "tile is 128 positions");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  half_t* As = (half_t*)smem;                                // [2][BM][LP]
-  half_t* Bs = As + 2 * BM * LP;                             // [2][BN][LP]
-  TapState* Ts = (TapState*)(Bs + 2 * BN * LP);              // [BM][9]
+  // LDS tiles: rows of 64 halfs = 128 B = 8 chunks of 16 B, NO padding; chunk c of row r is stored at chunk position
+  // c ^ (r & 7): conflict-free for the ds_read_b128 fragment reads (16 rows x one chunk) AND for the row-wise
+  // ds_write_b128 of the staging pass (8 lanes = one row).  (The padded 144-byte pitch of v3 lost 39 % of the LDS
+  // cycles to bank conflicts, profiles/r01_pmc_dcn_v3.txt.)
+  half_t* As = (half_t*)smem;                                // [2][BM][BK]
+  half_t* Bs = As + 2 * BM * BK;                             // [2][BN][BK]
+  TapState* Ts = (TapState*)(Bs + 2 * BN * BK);              // [BM][9]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l15 = lane & 15, lg = lane >> 4;
-  const int wr = wave >> 2, wc = wave & 3;
   const int n_pos = p.Ho * p.Wo;
   // XCD-aware tile order: workgroup i runs on XCD i % 8 (each XCD has its own 4 MB L2), so XCD x gets the CONTIGUOUS range
   // of patches [x * tpx, (x + 1) * tpx): the ~36-fold re-use of every input line (9 taps x 4 corners x neighbours) is then
@@ -56,83 +61,136 @@ __global__ __launch_bounds__(512) void dcn_igemm8_kernel(DcnFParams p) {
   const int K = 9 * p.C;
   const int nslice = p.C / BK;
   const int ksteps = 9 * nslice;                             // k-step ks = (slice ks / 9, tap ks % 9)
-
-  // ---- prologue: sampling state of every (row, tap) of this patch -> LDS
-  for (int t = tid; t < BM * 9; t += 512) {
-    const int row = t / 9, tap = t % 9;
-    const int ho = ho0 + row / DCN_PW, wo = wo0 + row % DCN_PW;
-    const bool ok_row = ho < p.Ho && wo < p.Wo;
-    const int pos = ok_row ? ho * p.Wo + wo : 0;
-    const float* omb = p.om + (long)b * 27 * p.oH * p.oW;
-    const float dh = omb[(long)(2 * tap) * n_pos + pos];
-    const float dw = omb[(long)(2 * tap + 1) * n_pos + pos];
-    const float ml = omb[(long)18 * p.oH * p.oW + (long)tap * n_pos + pos];
-    const float mk = 1.f / (1.f + __expf(-ml));
-    const float hf = (float)(ho * p.stride - 1 + tap / 3) + dh, wf = (float)(wo * p.stride - 1 + tap % 3) + dw;
-    const bool inside = ok_row && hf > -1.f && wf > -1.f && hf < (float)p.H && wf < (float)p.W;
-    const int h0 = (int)floorf(hf), w0 = (int)floorf(wf);
-    const float lh = hf - (float)h0, lw = wf - (float)w0;
-    const float wq[4] = {(1.f - lh) * (1.f - lw), (1.f - lh) * lw, lh * (1.f - lw), lh * lw};
-    TapState st;
+  // ---- L2 warm-up.  Every step of the k-loop gathers lines this XCD has never touched (compulsory misses), and a
+  // wave's wait ends with its slowest lane: measured, the step time was the loaded HBM latency (~1.5 us) whatever else
+  // the step did (profiles/README.md, DCN section).  So the expected footprint of the patch -- the regular 3x3 window
+  // grown by DCN_WARM pixels, all channel lines -- is touched once here, overlapped with the sampling-state prologue;
+  // the loop's gathers then find their lines in the L2.  The loads are inline asm (a C++ load without a consumer is
+  // dropped, a volatile one is waited for on the spot); their destination registers stay reserved until the first
+  // counted wait of the k-loop prologue has passed (VMEM returns in order, so they have landed by then).
+  constexpr int DCN_WARM = 1, WARM_N = 8;
+  unsigned warm[WARM_N];
+  {
+    const int fh = (DCN_PH - 1) * p.stride + 3 + 2 * DCN_WARM, fw = (DCN_PW - 1) * p.stride + 3 + 2 * DCN_WARM;
+    const int h_lo = ho0 * p.stride - 1 - DCN_WARM, w_lo = wo0 * p.stride - 1 - DCN_WARM;
+    const int lpp = (p.C * 2) >> 7;                          // 128-byte lines per pixel
+    const int nlines = fh * fw * lpp;
+    const char* xw = (const char*)(p.x + (long)b * p.x_bs);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int hh = h0 + (q >> 1), ww = w0 + (q & 1);
-      const bool ok = inside && hh >= 0 && hh <= p.H - 1 && ww >= 0 && ww <= p.W - 1;
-      st.off[q] = ok ? (hh * p.W + ww) * p.C : 0;            // invalid corners: harmless address, zero weight
-      st.w[q] = ok ? wq[q] * mk : 0.f;
+    for (int i = 0; i < WARM_N; ++i) {
+      warm[i] = 0;
+      const int idx = tid + i * 512;
+      if (idx < nlines) {
+        const int px = idx / lpp, ln = idx - px * lpp;
+        const int hh = min(max(h_lo + px / fw, 0), p.H - 1), ww = min(max(w_lo + px % fw, 0), p.W - 1);
+        const char* a = xw + ((long)(hh * p.W + ww) * p.C * 2 + ln * 128);
+        asm volatile("global_load_dword %0, %1, off" : "=v"(warm[i]) : "v"(a) : "memory");
+      }
     }
-    Ts[t] = st;
   }
 
-  // ---- this thread's A tasks: row = tid / 4, 8-channel chunks (tid % 4) and (tid % 4) + 4;  B tasks: chunks tid + j*512
-  const int arow = tid >> 2, ach = tid & 3;
-  const half_t* xb = p.x + (long)b * p.x_bs;
+  // ---- prologue: sampling state of every (row, tap) of this patch -> LDS.  All offset / mask loads of a thread's (up
+  // to 3) tasks are issued before any of them is consumed (one memory round trip instead of three).
+  {
+    constexpr int NTASK = (BM * 9 + 511) / 512;
+    float dh[NTASK], dw[NTASK], ml[NTASK];
+    const float* omb = p.om + (long)b * 27 * p.oH * p.oW;
+#pragma unroll
+    for (int i = 0; i < NTASK; ++i) {
+      const int t = min(tid + i * 512, BM * 9 - 1);
+      const int row = t / 9, tap = t - row * 9;
+      const int ho = ho0 + row / DCN_PW, wo = wo0 + row % DCN_PW;
+      const int pos = (ho < p.Ho && wo < p.Wo) ? ho * p.Wo + wo : 0;
+      dh[i] = omb[(long)(2 * tap) * n_pos + pos];
+      dw[i] = omb[(long)(2 * tap + 1) * n_pos + pos];
+      ml[i] = omb[(long)18 * p.oH * p.oW + (long)tap * n_pos + pos];
+    }
+#pragma unroll
+    for (int i = 0; i < NTASK; ++i) {
+      const int t = tid + i * 512;
+      if (t < BM * 9) {
+        const int row = t / 9, tap = t - row * 9;
+        const int ho = ho0 + row / DCN_PW, wo = wo0 + row % DCN_PW;
+        const bool ok_row = ho < p.Ho && wo < p.Wo;
+        const float mk = 1.f / (1.f + __expf(-ml[i]));
+        const float hf = (float)(ho * p.stride - 1 + tap / 3) + dh[i], wf = (float)(wo * p.stride - 1 + tap % 3) + dw[i];
+        const bool inside = ok_row && hf > -1.f && wf > -1.f && hf < (float)p.H && wf < (float)p.W;
+        const int h0 = (int)floorf(hf), w0 = (int)floorf(wf);
+        const float lh = hf - (float)h0, lw = wf - (float)w0;
+        const float wq[4] = {(1.f - lh) * (1.f - lw), (1.f - lh) * lw, lh * (1.f - lw), lh * lw};
+        TapState st;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int hh = h0 + (q >> 1), ww = w0 + (q & 1);
+          const bool ok = inside && hh >= 0 && hh <= p.H - 1 && ww >= 0 && ww <= p.W - 1;
+          st.off[q] = ok ? (unsigned)((hh * p.W + ww) * p.C) * 2u : 0u;  // invalid corners: harmless address, zero weight
+          st.w[q] = ok ? wq[q] * mk : 0.f;
+        }
+        Ts[t] = st;
+      }
+    }
+  }
   __syncthreads();
 
-  float c_w[2][4];
+  // ---- staging tasks.  A: rows ar and ar + 64, 16-byte chunk ac (8 lanes = one 128-byte line of one corner);
+  //      B: chunks tid + j*512 (row = chunk / 8).  Addresses are 32-bit byte offsets from wave-uniform bases.
+  const int wr = wave >> 2, wc = wave & 3;
+  const int ar = tid >> 3, ac = tid & 7;
+  const char* xb = (const char*)(p.x + (long)b * p.x_bs);
+  const char* wb = (const char*)p.w;
+  const unsigned a_lds = (unsigned)(ar * BK + ((ac ^ (ar & 7)) << 3));                 // + 64 * BK for the second row
+  unsigned b_goff[4], b_lds[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = tid + j * 512, row = c >> 3, ch = c & 7;
+    b_goff[j] = (unsigned)(row * K + ch * 8) * 2u;
+    b_lds[j] = (unsigned)(row * BK + ((ch ^ (row & 7)) << 3));
+  }
+
+  float c_w[2][2][4];
   half8 a_raw[2][2][4], b_raw[4];
-  auto issue_a = [&](auto SLOT, int ks) {                    // gather of k-step ks (distance 2)
+  auto issue_a = [&](auto SLOT, int ks) {                    // gather of k-step ks
     constexpr int s = decltype(SLOT)::value;
+    ks = min(ks, ksteps - 1);                                // tail: re-load the last step (one code path, no branches)
     const int slice = ks / 9, tap = ks - slice * 9;
-    const TapState st = Ts[arow * 9 + tap];
+    const unsigned cb = (unsigned)(slice * BK + ac * 8) * 2u;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) c_w[s][q] = st.w[q];
-    const int cbase = slice * BK + ach * 8;
+    for (int rr = 0; rr < 2; ++rr) {
+      const TapState st = Ts[(ar + rr * 64) * 9 + tap];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) a_raw[s][e][q] = *(const half8*)(xb + st.off[q] + cbase + e * 32);
-  };
-  auto issue_b = [&](int ks) {                               // weight tile of k-step ks (distance 1: L2-resident, regular)
-    const int slice = ks / 9, tap = ks - slice * 9;
-    const half_t* wk = p.w + tap * p.C + slice * BK;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = tid + j * 512;
-      b_raw[j] = __builtin_nontemporal_load((const half8*)(wk + (long)(c >> 3) * K + (c & 7) * 8));
+      for (int q = 0; q < 4; ++q) {
+        c_w[s][rr][q] = st.w[q];
+        a_raw[s][rr][q] = *(const half8*)(xb + (st.off[q] + cb));
+      }
     }
   };
-  auto commit = [&](auto SLOT, int buf) {
+  auto issue_b = [&](int ks) {                               // weight tile of k-step ks
+    ks = min(ks, ksteps - 1);
+    const int slice = ks / 9, tap = ks - slice * 9;
+    const unsigned kb = (unsigned)(tap * p.C + slice * BK) * 2u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b_raw[j] = *(const half8*)(wb + (b_goff[j] + kb));
+  };
+  // staging of one k-step by this thread: bilinear blend of its gathered slot (fp32 accumulate like the im2col kernel,
+  // one rounding to fp16) -> its two A-tile rows, and its four weight chunks -> B tile
+  auto stage = [&](auto SLOT, int buf) {
     constexpr int s = decltype(SLOT)::value;
+    half8 v[2];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      float acc[8];
+    for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+      for (int j = 0; j < 8; ++j) {
+        float t = c_w[s][rr][0] * (float)a_raw[s][rr][0][j];
+        t = __builtin_fmaf(c_w[s][rr][1], (float)a_raw[s][rr][1][j], t);
+        t = __builtin_fmaf(c_w[s][rr][2], (float)a_raw[s][rr][2][j], t);
+        t = __builtin_fmaf(c_w[s][rr][3], (float)a_raw[s][rr][3][j], t);
+        v[rr][j] = (half_t)t;
+      }
+    half_t* a = As + buf * BM * BK + a_lds;
+    *(half8*)a = v[0];
+    *(half8*)(a + 64 * BK) = v[1];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += c_w[s][q] * (float)a_raw[s][e][q][j];
-      half8 v;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (half_t)acc[j];
-      *(half8*)(As + (buf * BM + arow) * LP + ach * 8 + e * 32) = v;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = tid + j * 512;
-      *(half8*)(Bs + (buf * BN + (c >> 3)) * LP + (c & 7) * 8) = b_raw[j];
-    }
+    for (int j = 0; j < 4; ++j) *(half8*)(Bs + buf * BN * BK + b_lds[j]) = b_raw[j];
   };
 
   float4_ acc[4][4];
@@ -141,40 +199,77 @@ __global__ __launch_bounds__(512) void dcn_igemm8_kernel(DcnFParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (float4_){0.f, 0.f, 0.f, 0.f};
 
+  // fragment addressing: row = w? * 64 + i * 16 + l15 (row & 7 == l15 & 7), chunk = kk * 4 + lg
+  const unsigned fa = (unsigned)((wr * 64 + l15) * BK), fb = (unsigned)((wc * 64 + l15) * BK);
+  const unsigned sw0 = (unsigned)((lg ^ (l15 & 7)) << 3), sw1 = (unsigned)(((4 + lg) ^ (l15 & 7)) << 3);
+  auto mfma_phase = [&](int cur) {                           // this wave's 64 x 64 block of one k-step (32 MFMAs)
+    const half_t* At = As + cur * BM * BK + fa;
+    const half_t* Bt = Bs + cur * BN * BK + fb;
+    half8 af[2][4], bf[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[kk][i] = *(const half8*)(At + i * 16 * BK + (kk ? sw1 : sw0));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[kk][j] = *(const half8*)(Bt + j * 16 * BK + (kk ? sw1 : sw0));
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = mfma16(af[kk][i], bf[kk][j], acc[i][j]);
+  };
+
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
+  // ---- pipeline fill: every thread stages step 0; gathers of steps 1, 2 and the weights of step 1 are in flight
   issue_a(S0{}, 0);
   issue_b(0);
   issue_a(S1{}, 1);
-  commit(S0{}, 0);
+  stage(S0{}, 0);
+  issue_b(1);
+  issue_a(S0{}, 2);
   __syncthreads();
+#pragma unroll
+  for (int i = 0; i < WARM_N; ++i) asm volatile("" ::"v"(warm[i]));     // warm-up destinations released here
 
-  auto body = [&](int ks, auto SLOT, auto OTHER) {
-    const int cur = ks & 1;
-    // slot of step ks is free again: prefetch step ks + 2 into it.  Unconditional (the last two steps re-load the final
-    // tile) so that hipcc's vmcnt bookkeeping sees ONE path and lets these loads stay in flight across the next commit.
-    issue_b(min(ks + 1, ksteps - 1));                    // older than the gather below: commit() waits for it with vmcnt(8)
-    issue_a(SLOT, min(ks + 2, ksteps - 1));
-    __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch ahead of everything that waits on VMEM
-#pragma unroll
-    for (int kk = 0; kk < BK / 32; ++kk) {
-      half8 af[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const half8*)(As + (cur * BM + wr * 64 + i * 16 + l15) * LP + kk * 32 + lg * 8);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const half8 bf = *(const half8*)(Bs + (cur * BN + wc * 64 + j * 16 + l15) * LP + kk * 32 + lg * 8);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = mfma16(af[i], bf, acc[i][j]);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    commit(OTHER, cur ^ 1);                              // step ks + 1 was issued one full step ago
-    __syncthreads();
+  // ---- k-loop, "ping-pong": the two waves that share a SIMD (wave w and w + 4) are never in the same phase.  While
+  // group 0 (waves 0-3) runs its 32 MFMAs of step ks, group 1 stages ITS share of step ks + 1 (blend, LDS stores, next
+  // prefetch); then they swap.  (v3/v4: all 8 waves MFMA, then all 8 blend -- 51 % issue stalls,
+  // profiles/r01_pmc_dcn_v3.txt.)  Per thread, VMEM issue order is  ... A(k+1) | B(k+2) A(k+3) | ...  so the staging
+  // of step k+1 waits with a counted vmcnt: its own gather (issued two steps ago) and weights (one step ago) have
+  // landed, the newest gather stays in flight.
+  auto stage_next = [&](auto SLOT, int ks) {                 // SLOT holds step ks + 1
+    stage(SLOT, (ks + 1) & 1);
+    issue_b(ks + 2);
+    issue_a(SLOT, ks + 3);
   };
-  for (int ks = 0; ks < ksteps; ks += 2) {               // ksteps = 9 * C/64 is even (C % 128 == 0)
-    body(ks, S0{}, S1{});
-    body(ks + 1, S1{}, S0{});
+  // One loop per wave group (the branch is wave-uniform; s_barrier only counts arrivals, and both groups execute the
+  // same number of barriers).  A single loop with `if (grp == ...)` around the phases makes hipcc merge the two paths'
+  // VMEM bookkeeping and wait with vmcnt(0), which throws away one step of prefetch distance.
+  if (wave < 4) {
+    for (int ks = 0; ks < ksteps; ks += 2) {                 // ksteps = 9 * C/64 is even (C % 128 == 0)
+      mfma_phase(0);
+      __syncthreads();
+      stage_next(S1{}, ks);
+      __syncthreads();
+      mfma_phase(1);
+      __syncthreads();
+      stage_next(S0{}, ks + 1);
+      __syncthreads();
+    }
+  } else {
+    for (int ks = 0; ks < ksteps; ks += 2) {
+      stage_next(S1{}, ks);
+      __syncthreads();
+      mfma_phase(0);
+      __syncthreads();
+      stage_next(S0{}, ks + 1);
+      __syncthreads();
+      mfma_phase(1);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: + bias, fp16, transpose through LDS, 16-byte coalesced NHWC stores
@@ -211,7 +306,7 @@ extern "C" int mq_dcnv2_fwd(const void* x, const float* om, const void* w, const
   if ((long)p.Ho * p.Wo > (long)oH * oW) return -2;          // flat reads must stay inside the om buffer
   p.tiles_y = (p.Ho + DCN_PH - 1) / DCN_PH; p.tiles_x = (p.Wo + DCN_PW - 1) / DCN_PW;
   p.tiles_total = B * p.tiles_y * p.tiles_x;
-  constexpr size_t tiles = (size_t)(2 * 128 * 72 + 2 * 256 * 72) * sizeof(half_t) + 128 * 9 * sizeof(TapState);
+  constexpr size_t tiles = (size_t)(2 * 128 * 64 + 2 * 256 * 64) * sizeof(half_t) + 128 * 9 * sizeof(TapState);
   constexpr size_t ostage = (size_t)128 * (256 + 8) * sizeof(half_t);
   constexpr size_t smem = tiles > ostage ? tiles : ostage;
   static bool attr_set = false;

@@ -104,11 +104,18 @@ def build_plan(sd, cfg, device, dtype=torch.float16):
         P[f"backbone.fpn.{n}.packed"] = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dtype).contiguous()
     for n in ("fpn_inner2", "fpn_inner3", "fpn_inner4"):
         P[f"backbone.fpn.{n}.lin"] = h(f"backbone.fpn.{n}.weight").reshape(sd[f"backbone.fpn.{n}.weight"].shape[0], -1).contiguous()
+    # patch embedding (4x4 stride-4 conv) as a GEMM over (kh, kw, c)-ordered patches; box / centerness 1x1 convs of every
+    # level as ONE [8, 256] GEMM weight (4 box rows with the level's Scale folded, 1 centerness row, 3 zero rows): no
+    # MIOpen call is left on the path (its solver choice -- down to a naive kernel -- varies from box to box)
+    w = f32("backbone.body.patch_embed.proj.weight")
+    P["backbone.body.patch_embed.lin"] = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dtype).contiguous()
     for l in range(5):
         s = f32(f"rpn.head.scales.{l}.scale")
-        P[f"rpn.head.bbox_pred.{l}.weight"] = (f32("rpn.head.bbox_pred.weight") * s).to(dtype) \
-            .contiguous(memory_format=torch.channels_last)
-        P[f"rpn.head.bbox_pred.{l}.bias"] = (f32("rpn.head.bbox_pred.bias") * s).to(dtype)
+        wb = (f32("rpn.head.bbox_pred.weight") * s).reshape(4, -1)
+        wc = f32("rpn.head.centerness.weight").reshape(1, -1)
+        P[f"rpn.head.boxctr.{l}.weight"] = torch.cat([wb, wc, wb.new_zeros(3, wb.shape[1])], 0).to(dtype).contiguous()
+        P[f"rpn.head.boxctr.{l}.bias"] = torch.cat([f32("rpn.head.bbox_pred.bias") * s, f32("rpn.head.centerness.bias"),
+                                                    wb.new_zeros(3)], 0).to(dtype).contiguous()
     P["rpn.head.tok.weight"] = f32("rpn.head.dot_product_projection_text.weight")
     P["rpn.head.tok.bias"] = f32("rpn.head.dot_product_projection_text.bias")
     P["rpn.head.bias_lang32"] = f32("rpn.head.bias_lang")
@@ -145,9 +152,11 @@ def swin_forward(P, cfg, img):
     _, _, H0, W0 = img.shape
     if W0 % 4 or H0 % 4:
         img = F.pad(img, (0, (4 - W0 % 4) % 4, 0, (4 - H0 % 4) % 4))
-    x = F.conv2d(img, P[p + ".patch_embed.proj.weight"], P[p + ".patch_embed.proj.bias"], stride=4)
-    B, C, H, W = x.shape
-    x = _ln(P, p + ".patch_embed.norm", x.permute(0, 2, 3, 1).reshape(B, H * W, C))
+    B, Cin, Hi, Wi = img.shape
+    H, W = Hi // 4, Wi // 4
+    patches = img.permute(0, 2, 3, 1).reshape(B, H, 4, W, 4, Cin).permute(0, 1, 3, 2, 4, 5).reshape(B, H * W, 16 * Cin)
+    x = F.linear(patches, P[p + ".patch_embed.lin"], P[p + ".patch_embed.proj.bias"])      # PatchEmbed.proj, swint.py:447-471
+    x = _ln(P, p + ".patch_embed.norm", x)
     outs = []
     for i, (depth, heads) in enumerate(zip(M.DEPTHS, M.NUM_HEADS)):
         C = x.shape[-1]
@@ -429,10 +438,11 @@ def vldyhead(P, cfg, feats, lang):
     bbox, ctr, dots = [], [], []
     for l, f in enumerate(feats):
         Bn, C, H, W = f.shape
-        fc = f.contiguous(memory_format=torch.channels_last)
-        bbox.append(F.conv2d(fc, P[f"{p}.bbox_pred.{l}.weight"], P[f"{p}.bbox_pred.{l}.bias"]))
-        ctr.append(F.conv2d(fc, P[p + ".centerness.weight"], P[p + ".centerness.bias"]))
-        dots.append(torch.bmm(fc.permute(0, 2, 3, 1).reshape(Bn, H * W, C), tok16_t))                # [B, HW, T]
+        tokens = f.permute(0, 2, 3, 1).reshape(Bn, H * W, C)                                         # NHWC memory: a view
+        bc = F.linear(tokens, P[f"{p}.boxctr.{l}.weight"], P[f"{p}.boxctr.{l}.bias"]).reshape(Bn, H, W, 8)
+        bbox.append(bc[..., :4].permute(0, 3, 1, 2))                                                 # [B, 4, H, W] view
+        ctr.append(bc[..., 4:5].permute(0, 3, 1, 2))
+        dots.append(torch.bmm(tokens, tok16_t))                                                      # [B, HW, T]
     return {"bbox_reg": bbox, "centerness": ctr, "dot": dots, "tbias": tbias, "feats": feats, "hidden": hidden}
 
 

@@ -1,0 +1,17 @@
+mkdir -p gpurun_out/pmc18
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --list-avail > $GRAFT_REPO_ROOT/gpurun_out/pmc18/list_avail.txt 2>&1
+i=0
+for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_WAIT_INST_LDS SQ_INSTS_LDS" \
+           "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_IFETCH SQ_IFETCH_LEVEL SQ_CYCLES" \
+           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TA_BUSY_avr"; do
+  i=$((i+1))
+  timeout 120 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc18/g$i -o p -- python $GRAFT_REPO_ROOT/tools/dcn_probe1.py > $GRAFT_REPO_ROOT/gpurun_out/pmc18/g$i.log 2>&1
+  echo "group $i rc=$?"
+done
+cd $GRAFT_REPO_ROOT
+ls gpurun_out/pmc18/*
