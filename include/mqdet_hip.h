@@ -80,13 +80,15 @@ int mq_vlfuse_i2t_fwd(const void* v_ln, const void* kf, const void* vo, const fl
 
 /* VLFuse text side: keys = values = image tokens, split over the keys (nsplit >= 1) + merge:
  *   out[b,t,h*256:(h+1)*256] = sum_n softmax_n( clamp(kf[b,h,t,:] . v_ln[b,n,:], +-clamp) ) v_ln[b,n,:]
- *   workspace: mq_vlfuse_t2i_workspace_bytes(B, T, nsplit) bytes of device memory; out [B,T,2048] fp16.
+ *   workspace: mq_vlfuse_t2i_workspace_bytes(B, T, nsplit) bytes of device memory; out [B,T,2048] fp16;
+ *   kv_len [B] int32 or NULL: caption length -- 128-row tiles that hold only padding tokens (rows >= kv_len[b]) are not
+ *   computed and come back as zeros (padding rows never influence a detection: masked as keys, never scored).
  * Replaces the text branch of BiMultiHeadAttention: the transposed logits, their softmax over image tokens and the
  *   bmm with values_v (fuse_helper.py:246-262,281-288); values_v_proj / out_l_proj are applied to the result by the
  *   caller as one folded [768, 2048] weight. */
 long mq_vlfuse_t2i_workspace_bytes(int B, int T, int nsplit);
-int mq_vlfuse_t2i_fwd(const void* kf, const void* v_ln, void* workspace, void* out, int B, int N, int T, int nsplit,
-                      float clamp, void* stream);
+int mq_vlfuse_t2i_fwd(const void* kf, const void* v_ln, const int* kv_len, void* workspace, void* out, int B, int N, int T,
+                      int nsplit, float clamp, void* stream);
 
 /* DCNv2 (modulated deformable 3x3 conv, pad 1) column gather, NHWC fp16, whole batch.
  *   x [B,H,W,C], om [B,27,oH,oW] fp32 NCHW (18 offsets + 9 mask LOGITS; may come from another pyramid level:

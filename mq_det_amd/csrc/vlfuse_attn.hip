@@ -358,6 +358,7 @@ struct T2IParams {
   const half_t* v;        // [B, N, 256] LN(v): keys AND values
   float* ws;              // [nsplit][B*8][T][WS_LD] fp32 partials: O (un-normalised), then m, l
   half_t* out;            // [B, T, 8*256]
+  const int* kv_len;      // [B] or nullptr: text rows >= kv_len[b] are padding -> not computed, written as zeros
   int B, N, T, nsplit;
   float clamp;
 };
@@ -377,6 +378,9 @@ __global__ __launch_bounds__(256) void vlfuse_t2i_kernel(T2IParams p) {
   if (group >= p.B * p.nsplit) return;
   const int wq = seq % members, h = wq % VH, qtile = wq / VH;
   const int b = group / p.nsplit, split = group % p.nsplit;
+  // padded caption tokens: as keys they are masked everywhere downstream and the post-processor never reads their
+  // logits, so their rows of this attention are dead -- whole q-tiles of padding are skipped (the merge writes zeros)
+  if (p.kv_len && qtile * BM >= max(1, min(p.T, p.kv_len[b]))) return;
   const int row0 = qtile * BM + wave * 32;
 
   const int ntiles = (p.N + TK - 1) / TK;
@@ -503,6 +507,14 @@ __global__ __launch_bounds__(256) void vlfuse_t2i_combine_kernel(T2IParams p) {
   if (gw >= total) return;
   const int row = gw % p.T;
   const int bh = gw / p.T, b = bh / VH, h = bh % VH;
+  half_t* dst = p.out + ((long)b * p.T + row) * (VH * VD) + h * VD + lane * 4;
+  if (p.kv_len) {                                          // rows of skipped (all-padding) q-tiles: zeros
+    const int kv = max(1, min(p.T, p.kv_len[b]));
+    if ((row / BM) * BM >= kv) {
+      *(half4*)dst = (half4){(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+      return;
+    }
+  }
   const long stride = total * WS_LD;
   const float* base = p.ws + gw * WS_LD;
   float mx = MQ_NEG_BIG;
@@ -520,7 +532,7 @@ __global__ __launch_bounds__(256) void vlfuse_t2i_combine_kernel(T2IParams p) {
   half4 y;
 #pragma unroll
   for (int j = 0; j < 4; ++j) y[j] = (half_t)(acc[j] * inv);
-  *(half4*)(p.out + ((long)b * p.T + row) * (VH * VD) + h * VD + lane * 4) = y;
+  *(half4*)dst = y;
 }
 
 extern "C" long mq_vlfuse_t2i_workspace_bytes(int B, int T, int nsplit) {
@@ -528,13 +540,13 @@ extern "C" long mq_vlfuse_t2i_workspace_bytes(int B, int T, int nsplit) {
 }
 
 // Text side of VLFuse (always through the split workspace + combine, nsplit >= 1).  See include/mqdet_hip.h.
-extern "C" int mq_vlfuse_t2i_fwd(const void* kf, const void* v_ln, void* workspace, void* out, int B, int N, int T, int nsplit,
-                                 float clamp, void* stream) {
+extern "C" int mq_vlfuse_t2i_fwd(const void* kf, const void* v_ln, const int* kv_len, void* workspace, void* out, int B, int N,
+                                 int T, int nsplit, float clamp, void* stream) {
   if (B <= 0 || T <= 0) return 0;
   if (N < 1 || workspace == nullptr) return -1;
   if (nsplit < 1) nsplit = 1;
   T2IParams p;
-  p.kf = (const half_t*)kf; p.v = (const half_t*)v_ln; p.ws = (float*)workspace; p.out = (half_t*)out;
+  p.kf = (const half_t*)kf; p.v = (const half_t*)v_ln; p.ws = (float*)workspace; p.out = (half_t*)out; p.kv_len = kv_len;
   p.B = B; p.N = N; p.T = T; p.nsplit = nsplit; p.clamp = clamp;
   constexpr size_t smem = (size_t)2 * TILE * sizeof(half_t);
   static bool attr_set = false;

@@ -116,10 +116,20 @@ class GeneralizedVLRCNN_New(nn.Module):
     # ------------------------------------------------------------------ device part (capturable in a HIP graph)
     def _device_forward(self, x, input_ids, attention_mask, vision, idx, tokidx, label_ids, im_wh, max_kv=0, want_raw=False):
         P, cfg = self._plan, self.cfg
+        # the image-independent part of the language backbone (embeddings + BERT layers below the first GCP block) runs on
+        # a side stream under the Swin backbone: its launches are tiny (B x 256 tokens) and would otherwise serialise
+        front = None
+        if x.is_cuda and cfg.MODEL.DYHEAD.get("LEVEL_STREAMS", True):
+            main, text = torch.cuda.current_stream(), pipeline._side_streams(x.device, 1, "text")[0]
+            text.wait_stream(main)
+            with torch.cuda.stream(text):
+                front = pipeline.language_front(P, cfg, input_ids, attention_mask, vision is not None)
         feats = pipeline.fpn_forward(P, pipeline.swin_forward(P, cfg, x))
+        if front is not None:
+            main.wait_stream(text)
         pooled = pipeline.pooled_fpn_tokens(feats) if vision is not None else None
         lang = pipeline.language_backbone(P, cfg, input_ids, attention_mask, vision, pooled, idx,
-                                          want_gates=cfg.VISION_QUERY.RETURN_ATTN_GATE_VALUE)
+                                          want_gates=cfg.VISION_QUERY.RETURN_ATTN_GATE_VALUE, front=front)
         lang["max_kv"] = max_kv
         head = pipeline.vldyhead(P, cfg, feats, lang)
         sizes = tuple(tuple(f.shape[-2:]) for f in feats)

@@ -267,8 +267,9 @@ def gcp_block(P, b, x, vision, idx, gates=None):
     return x + F.linear(F.gelu(F.linear(_ln(P, ff + ".norm", x), P[ff + ".linear1.weight"])), P[ff + ".linear2.gated"])
 
 
-def language_backbone(P, cfg, input_ids, attention_mask, vision, images, idx, want_gates=False):
-    """bert_model_new.BertEncoder.forward (:39-104) over QVBertModel.forward (modeling_bert_new.py:690-848)."""
+def language_front(P, cfg, input_ids, attention_mask, use_vq):
+    """Embeddings + the BERT layers that do not depend on the image (all 12 without vision queries, the first QV_START
+    with them): the detector runs this on a side stream while the Swin backbone occupies the main one."""
     p = "language_backbone.body.model"
     LB = cfg.MODEL.LANGUAGE_BACKBONE
     T = input_ids.shape[1]
@@ -281,13 +282,29 @@ def language_backbone(P, cfg, input_ids, attention_mask, vision, images, idx, wa
     # index of the last valid text token + 1: the attention kernels skip key tiles that hold padding only
     kv_len = (attention_mask.to(torch.int32) * torch.arange(1, T + 1, device=attention_mask.device, dtype=torch.int32)) \
         .amax(1).to(torch.int32).contiguous()
+    nl, qv0 = LB.get("NUM_HIDDEN_LAYERS", 12), LB.get("QV_START", 6)
+    n_front = qv0 if use_vq else nl
+    hidden = []
+    for i in range(n_front):
+        x = bert_layer(P, f"{p}.encoder.layer.{i}", x, key_bias, clamp=False, kv_len=kv_len)
+        hidden.append(x)
+    return {"x": x, "hidden": hidden, "key_bias": key_bias, "kv_len": kv_len, "next": n_front}
+
+
+def language_backbone(P, cfg, input_ids, attention_mask, vision, images, idx, want_gates=False, front=None):
+    """bert_model_new.BertEncoder.forward (:39-104) over QVBertModel.forward (modeling_bert_new.py:690-848).
+    `front`: result of language_front (computed concurrently with the image backbone); None -> computed here."""
+    p = "language_backbone.body.model"
+    LB = cfg.MODEL.LANGUAGE_BACKBONE
     use_vq = vision is not None
+    if front is None:
+        front = language_front(P, cfg, input_ids, attention_mask, use_vq)
+    x, hidden, key_bias, kv_len = front["x"], list(front["hidden"]), front["key_bias"], front["kv_len"]
     if use_vq:
         vision = pre_select(P, p + ".pre_select", vision, images, cfg.VISION_QUERY.VISION_SCALE)
     nl, qv0 = LB.get("NUM_HIDDEN_LAYERS", 12), LB.get("QV_START", 6)
     gates = [] if want_gates else None
-    hidden = []
-    for i in range(nl):
+    for i in range(front["next"], nl):
         if use_vq and i >= qv0:
             x = gcp_block(P, f"{p}.encoder.qv_layer.{i - qv0}", x, vision, idx, gates)
         x = bert_layer(P, f"{p}.encoder.layer.{i}", x, key_bias, clamp=False, kv_len=kv_len)
@@ -324,7 +341,8 @@ def vl_fuse(P, b, feats, hidden, key_bias, kv_len=None, max_kv=0):
     # image side: queries = LN(v) shared by the 8 heads; head sum, out-proj bias and the residual (on the NORMED v) fused
     v_new = ops.vlfuse_i2t(v_ln, kf, vo, bias.contiguous(), P[b + ".ov.bias"], kv_len=kv_len, max_kv=max_kv)
     # text side: queries = folded text keys, keys = values = LN(v)
-    out_l = ops.vlfuse_t2i(kf, v_ln, _nsplit(-(-T // 128) * Bn * 8, -(-N // 64)))
+    t_live = min(T, max_kv) if (kv_len is not None and max_kv > 0) else T             # 128-row tiles of pure padding are skipped
+    out_l = ops.vlfuse_t2i(kf, v_ln, _nsplit(-(-t_live // 128) * Bn * 8, -(-N // 64)), kv_len=kv_len)
     l_new = l_ln + _lin(P, b + ".olc", out_l)
     out, s = [], 0
     for (hh, ww) in sizes:
@@ -415,8 +433,8 @@ def dyconv(P, cfg, b, feats):
 _SIDE_STREAMS = {}
 
 
-def _side_streams(device, n):
-    key = (device.index, n)
+def _side_streams(device, n, tag="levels"):
+    key = (device.index, n, tag)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
     return _SIDE_STREAMS[key]
@@ -429,8 +447,17 @@ def vldyhead(P, cfg, feats, lang):
     for i in range(cfg.MODEL.DYHEAD.NUM_CONVS):
         t = f"{p}.dyhead_tower"
         feats, hidden = vl_fuse(P, f"{t}.{3 * i}.b_attn", feats, hidden, key_bias, kv_len, lang.get("max_kv", 0))
-        hidden = bert_layer(P, f"{t}.{3 * i + 1}", hidden, key_bias, clamp=True, kv_len=kv_len)
-        feats = dyconv(P, cfg, f"{t}.{3 * i + 2}", feats)
+        # the text-only BERT layer (a dozen small launches) and the image-only DyConv are independent: side stream
+        if hidden.is_cuda and cfg.MODEL.DYHEAD.get("LEVEL_STREAMS", True):
+            main, text = torch.cuda.current_stream(), _side_streams(hidden.device, 1, "text")[0]
+            text.wait_stream(main)
+            with torch.cuda.stream(text):
+                hidden = bert_layer(P, f"{t}.{3 * i + 1}", hidden, key_bias, clamp=True, kv_len=kv_len)
+            feats = dyconv(P, cfg, f"{t}.{3 * i + 2}", feats)
+            main.wait_stream(text)
+        else:
+            hidden = bert_layer(P, f"{t}.{3 * i + 1}", hidden, key_bias, clamp=True, kv_len=kv_len)
+            feats = dyconv(P, cfg, f"{t}.{3 * i + 2}", feats)
     emb = F.normalize(hidden.float(), p=2, dim=-1)
     tok = F.linear(emb / 2.0, P[p + ".tok.weight"], P[p + ".tok.bias"]) * P[p + ".inv_scale"]      # [B, T, 256]
     tbias = (emb @ P[p + ".bias_lang32"] + P[p + ".bias0_32"]).contiguous()                           # [B, T]

@@ -23,7 +23,7 @@ _SIGNATURES = {
     "mq_headsum_residual_fwd": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
     "mq_vlfuse_i2t_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mq_vlfuse_t2i_workspace_bytes": (_l, [_i, _i, _i]),
-    "mq_vlfuse_t2i_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "mq_vlfuse_t2i_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mq_dcn_im2col_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _f, _l, _l, _vp]),
     "mq_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _vp]),
@@ -248,9 +248,10 @@ def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.
     return out
 
 
-def vlfuse_t2i(kf, v_ln, nsplit, clamp=50000.0):
+def vlfuse_t2i(kf, v_ln, nsplit, clamp=50000.0, kv_len=None):
     """VLFuse text side (mq_vlfuse_t2i_fwd).  kf [B,8,T,256] (queries), v_ln [B,N,256] (keys = values) fp16
-    -> [B,T,8*256] fp16 = softmax_n(clamp(kf.v_ln)) v_ln per head."""
+    -> [B,T,8*256] fp16 = softmax_n(clamp(kf.v_ln)) v_ln per head.  kv_len [B] int32: 128-row tiles of pure padding
+    (rows >= kv_len[b]) are skipped and returned as zeros."""
     lib = load_library()
     _need_gpu(kf, v_ln)
     B, N, C = v_ln.shape
@@ -258,10 +259,12 @@ def vlfuse_t2i(kf, v_ln, nsplit, clamp=50000.0):
     assert C == 256 and kf.shape == (B, 8, T, 256) and kf.is_contiguous() and v_ln.is_contiguous()
     assert kf.dtype == v_ln.dtype == torch.float16
     nsplit = max(1, int(nsplit))
+    if kv_len is not None:
+        assert kv_len.dtype == torch.int32 and kv_len.numel() == B and kv_len.is_contiguous()
     ws = torch.empty(lib.mq_vlfuse_t2i_workspace_bytes(B, T, nsplit) // 4, dtype=torch.float32, device=kf.device)
     out = torch.empty(B, T, 8 * 256, dtype=torch.float16, device=kf.device)
     with _timed(f"vlfuse_t2i_n{N}_t{T}_s{nsplit}"):
-        _chk(lib.mq_vlfuse_t2i_fwd(_ptr(kf), _ptr(v_ln), _ptr(ws), _ptr(out), B, N, T, nsplit, float(clamp), _stream()),
+        _chk(lib.mq_vlfuse_t2i_fwd(_ptr(kf), _ptr(v_ln), _ptr(kv_len), _ptr(ws), _ptr(out), B, N, T, nsplit, float(clamp), _stream()),
              "mq_vlfuse_t2i_fwd")
     return out
 

@@ -263,11 +263,14 @@ def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.
     return (v_ln.float() + out_bias.float() + o).to(v_ln.dtype)
 
 
-def vlfuse_t2i(kf, v_ln, nsplit, clamp=50000.0):
+def vlfuse_t2i(kf, v_ln, nsplit, clamp=50000.0, kv_len=None):
     B, N, C = v_ln.shape
     T = kf.shape[2]
     s = torch.einsum("bhtc,bnc->bhtn", kf.float(), v_ln.float())
     if clamp > 0:
         s = s.clamp(-clamp, clamp)
     o = torch.einsum("bhtn,bnc->bthc", s.softmax(-1), v_ln.float())
+    if kv_len is not None:                      # 128-row tiles of pure padding come back as zeros
+        dead = (torch.arange(T)[None, :] // 128) * 128 >= kv_len.clamp(1, T)[:, None]
+        o = o.masked_fill(dead[:, :, None, None], 0.0)
     return o.reshape(B, T, 8 * C).to(kf.dtype)

@@ -72,7 +72,9 @@ def test_full_pipeline_glue(setup, emulated_ops):
         close(lang["embedded"], inter["lang"]["embedded"], 5e-4)
         head = pipeline.vldyhead(P, cfg, feats, lang)
         h = inter["head"]
-        close(head["hidden"], h["hidden"], 1e-3)
+        for bi in range(am.shape[0]):       # rows of padding tokens are dead (never keys, never scored): the text side of
+            nb = int(am[bi].sum())          # VLFuse skips their 128-row tiles, so only real caption tokens are compared
+            close(head["hidden"][bi, :nb], h["hidden"][bi, :nb], 1e-3)
         nv = int(am[0].sum())
         for l in range(5):
             close(head["feats"][l], h["feats"][l], 1e-3)
