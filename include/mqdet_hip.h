@@ -127,21 +127,22 @@ int mq_dcnv2_fwd(const void* x, const float* om, const void* w, const void* bias
  *                     (spatial mean of the up-sampled map) or NULL for 1/n.
  *   mq_dyconv_coef  : sums + GN gamma/beta fp16 [C] + AttnConv weight [C] / bias [1] fp32 -> coef [B,C,2] fp32
  *                     (a*rstd*gamma, a*(beta - mean*rstd*gamma)), a = h_sigmoid(relu(w . pooled + b)) / nbranches.
- *   mq_dyconv_fuse  : out [B,H*W,C] = sum_k coef_k[.,0]*y_k^ + coef_k[.,1], y_k^ = y_k or its bilinear
+ *   mq_dyconv_fuse  : out [B,H*W,C] (batch stride out_bs elements: a level's slice of the [B,N,C] pyramid token buffer)
+ *                     = sum_k coef_k[.,0]*y_k^ + coef_k[.,1], y_k^ = y_k or its bilinear
  *                     (align_corners) sample from (hs_k, ws_k); pool [B,ceil(H*W/128),C] fp32 per-block sums of out.
  *   mq_dyrelu_coef  : pool, fc.0 / fc.2 weights+biases fp16 -> coef [B,4,C] fp32 (a1,b1,a2,b2).
- *   mq_dyrelu_apply : x [B,n,C] <- max(a1 x + b1, a2 x + b2) in place.
+ *   mq_dyrelu_apply : x [B,n,C] (batch stride x_bs) <- max(a1 x + b1, a2 x + b2) in place.
  * Replaces DyConv.forward's post-conv part, maskrcnn_benchmark/modeling/rpn/vldyhead.py:148-152,224-242 and
  *   DYReLU.forward, maskrcnn_benchmark/layers/dyrelu.py:78-112. */
 int mq_dyconv_stats(const void* y, float* sums, const float* wy, const float* wx, int B, int n, int W, int C, void* stream);
 int mq_dyconv_coef(const float* sums, const void* gamma, const void* beta, const float* attn_w, const float* attn_b,
                    float* coef, int B, int n, int C, int G, float eps, int nbranches, void* stream);
 int mq_dyconv_fuse(const void* y0, const float* coef0, int hs0, int ws0, const void* y1, const float* coef1, int hs1,
-                   int ws1, const void* y2, const float* coef2, int hs2, int ws2, int nbranches, void* out, float* pool,
-                   int B, int H, int W, int C, void* stream);
+                   int ws1, const void* y2, const float* coef2, int hs2, int ws2, int nbranches, void* out, long out_bs,
+                   float* pool, int B, int H, int W, int C, void* stream);
 int mq_dyrelu_coef(const float* pool, const void* w0, const void* b0, const void* w2, const void* b2, float* coef,
                    int B, int n, int C, void* stream);
-int mq_dyrelu_apply(void* x, const float* coef, int B, int n, int C, void* stream);
+int mq_dyrelu_apply(void* x, const float* coef, int B, int n, int C, long x_bs, void* stream);
 
 /* Region-word alignment scores for the L labels of the caption.
  *   dot [B,HW,T] fp16, tbias [B,T] fp32, tokidx [L,MT] int32, ctr [B,HW] fp16 -> out [B,HW,L] fp32

@@ -131,7 +131,8 @@ struct FuseBranch {
 struct FuseParams {
   FuseBranch br[3];
   int nbr;
-  half_t* out;          // [B, H*W, C]
+  half_t* out;          // [B, H*W, C], batch stride out_bs elements (a level's slice of the [B, N, C] token buffer)
+  long out_bs;
   float* pool;          // [B, nblk, C] per-block partial sums of out (fixed-order reduction in mq_dyrelu_coef)
   int B, H, W, C, rows_per_block;
 };
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void dyconv_fuse_kernel(FuseParams p) {
     half8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { o[j] = (half_t)acc[j]; ps[j] += (float)o[j]; }
-    *(half8*)(p.out + ((long)b * n + pos) * p.C + c0) = o;
+    *(half8*)(p.out + (long)b * p.out_bs + (long)pos * p.C + c0) = o;
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) red[(rg * cpt + lane_c) * 8 + j] = ps[j];
@@ -207,14 +208,14 @@ __global__ __launch_bounds__(256) void dyconv_fuse_kernel(FuseParams p) {
 
 extern "C" int mq_dyconv_fuse(const void* y0, const float* coef0, int hs0, int ws0, const void* y1, const float* coef1,
                               int hs1, int ws1, const void* y2, const float* coef2, int hs2, int ws2, int nbranches,
-                              void* out, float* pool, int B, int H, int W, int C, void* stream) {
+                              void* out, long out_bs, float* pool, int B, int H, int W, int C, void* stream) {
   if (B <= 0) return 0;
   if (C != 256 || nbranches < 1 || nbranches > 3) return -1;
   FuseParams p;
   p.br[0] = {(const half_t*)y0, coef0, hs0, ws0};
   p.br[1] = {(const half_t*)y1, coef1, hs1, ws1};
   p.br[2] = {(const half_t*)y2, coef2, hs2, ws2};
-  p.nbr = nbranches; p.out = (half_t*)out; p.pool = pool; p.B = B; p.H = H; p.W = W; p.C = C;
+  p.nbr = nbranches; p.out = (half_t*)out; p.out_bs = out_bs; p.pool = pool; p.B = B; p.H = H; p.W = W; p.C = C;
   p.rows_per_block = 128;
   dim3 grid((H * W + p.rows_per_block - 1) / p.rows_per_block, B);
   hipLaunchKernelGGL(dyconv_fuse_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -264,14 +265,14 @@ extern "C" int mq_dyrelu_coef(const float* pool, const void* w0, const void* b0,
 }
 
 __global__ __launch_bounds__(256) void dyrelu_apply_kernel(half_t* __restrict__ x, const float* __restrict__ coef, long n,
-                                                           int C) {
+                                                           int C, long x_bs) {
   const int b = blockIdx.y;
   const int cpt = C / 8;
   const long total = n * cpt;
   const float* cf = coef + (long)b * 4 * C;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c0 = (int)(i % cpt) * 8;
-    half_t* px = x + ((long)b * n + i / cpt) * C + c0;
+    half_t* px = x + (long)b * x_bs + (i / cpt) * C + c0;
     half8 v = *(const half8*)px;
     half8 o;
 #pragma unroll
@@ -283,14 +284,14 @@ __global__ __launch_bounds__(256) void dyrelu_apply_kernel(half_t* __restrict__ 
   }
 }
 
-extern "C" int mq_dyrelu_apply(void* x, const float* coef, int B, int n, int C, void* stream) {
+extern "C" int mq_dyrelu_apply(void* x, const float* coef, int B, int n, int C, long x_bs, void* stream) {
   if (B <= 0 || n <= 0) return 0;
   if (C % 8) return -1;
   long total = (long)n * (C / 8);
   long blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(dyrelu_apply_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, (half_t*)x, coef,
-                     (long)n, C);
+                     (long)n, C, x_bs);
   MQ_CHECK_LAUNCH();
   return 0;
 }

@@ -319,16 +319,30 @@ def language_backbone(P, cfg, input_ids, attention_mask, vision, images, idx, wa
 
 
 # ----------------------------------------------------------------------------- VLDyHead
-def vl_fuse(P, b, feats, hidden, key_bias, kv_len=None, max_kv=0):
-    """BiAttentionBlockForCheckpoint / BiMultiHeadAttention (fuse_helper.py:218-303,377-426): one set of logits,
-    softmax over text for the image side and over image tokens for the text side -- one launch each of the two
-    VLFuse kernels (vlfuse_attn.hip); the logits are never materialised (reference: 3 x [B*8, 22400, 256] fp32
-    tensors) and, with the projections folded into the text-side operands, neither are the [B, 22400, 2048] q / value
-    tensors: both kernels read LN(v) [B, N, 256] directly."""
-    Bn = feats[0].shape[0]
-    sizes = [f.shape[-2:] for f in feats]
-    v = torch.cat([f.permute(0, 2, 3, 1).flatten(1, 2) for f in feats], 1)              # [B, N, 256]
-    N = v.shape[1]
+def _to_tokens(feats):
+    """list of [B,C,H,W] (NHWC memory) -> ([B, N, C] token buffer, [(H, W)])."""
+    sizes = [tuple(f.shape[-2:]) for f in feats]
+    return torch.cat([f.permute(0, 2, 3, 1).flatten(1, 2) for f in feats], 1), sizes
+
+
+def _level_views(tok, sizes):
+    """[B, N, C] token buffer -> per-level [B, C, H, W] views (NHWC memory, batch stride N*C; no copies)."""
+    Bn, N, C = tok.shape
+    out, s = [], 0
+    for (hh, ww) in sizes:
+        out.append(tok[:, s:s + hh * ww].reshape(Bn, hh, ww, C).permute(0, 3, 1, 2))
+        s += hh * ww
+    return out
+
+
+def vl_fuse_tokens(P, b, v, hidden, key_bias, kv_len=None, max_kv=0):
+    """BiAttentionBlockForCheckpoint / BiMultiHeadAttention (fuse_helper.py:218-303,377-426) on the pyramid token
+    buffer v [B, N, 256] (all levels concatenated, the layout the whole head keeps): one set of logits, softmax over text
+    for the image side and over image tokens for the text side -- one launch each of the two VLFuse kernels
+    (vlfuse_attn.hip); the logits are never materialised (reference: 3 x [B*8, 22400, 256] fp32 tensors) and, with the
+    projections folded into the text-side operands, neither are the [B, 22400, 2048] q / value tensors: both kernels
+    read LN(v) directly."""
+    Bn, N, _ = v.shape
     v_ln = ops.layer_norm(v, P[b + ".layer_norm_v.weight"], P[b + ".layer_norm_v.bias"], 1e-5)
     l_ln = _ln(P, b + ".layer_norm_l", hidden)
     a = b + ".attn"
@@ -344,11 +358,14 @@ def vl_fuse(P, b, feats, hidden, key_bias, kv_len=None, max_kv=0):
     t_live = min(T, max_kv) if (kv_len is not None and max_kv > 0) else T             # 128-row tiles of pure padding are skipped
     out_l = ops.vlfuse_t2i(kf, v_ln, _nsplit(-(-t_live // 128) * Bn * 8, -(-N // 64)), kv_len=kv_len)
     l_new = l_ln + _lin(P, b + ".olc", out_l)
-    out, s = [], 0
-    for (hh, ww) in sizes:
-        out.append(v_new[:, s:s + hh * ww].reshape(Bn, hh, ww, -1).contiguous().permute(0, 3, 1, 2))
-        s += hh * ww
-    return out, l_new
+    return v_new, l_new
+
+
+def vl_fuse(P, b, feats, hidden, key_bias, kv_len=None, max_kv=0):
+    """List-of-levels form of vl_fuse_tokens."""
+    v, sizes = _to_tokens(feats)
+    v_new, l_new = vl_fuse_tokens(P, b, v.contiguous(), hidden, key_bias, kv_len, max_kv)
+    return _level_views(v_new, sizes), l_new
 
 
 _UP_W = {}
@@ -373,32 +390,37 @@ def _upsample_pool_weights(hs, ws, H, W, device):
     return _UP_W[key]
 
 
-def dyconv(P, cfg, b, feats):
-    """DyConv.forward (vldyhead.py:205-247).  Per level: 27-channel offset/mask conv (library), up to three DCNv2
-    branches (HIP gather + library GEMM, or the fused implicit-GEMM kernel with MODEL.DYHEAD.FUSED_DCN), then the fused HIP epilogue (GroupNorm statistics, bilinear up-sampling of
-    the level+1 branch, scale attention, branch mean, DYReLU) -- offsets of the CURRENT level are re-used for all
-    three branches exactly like the reference (flat-index quirk handled inside the gather)."""
+def dyconv_tokens(P, cfg, b, tok, sizes):
+    """DyConv.forward (vldyhead.py:205-247) on the pyramid token buffer tok [B, N, 256] -> new buffer of the same shape.
+    Per level: 27-channel offset/mask conv (implicit-GEMM kernel), up to three DCNv2 branches (one fused kernel each,
+    dcn_fused.hip; or HIP gather + library GEMM with MODEL.DYHEAD.FUSED_DCN = False), then the fused HIP epilogue
+    (GroupNorm statistics, bilinear up-sampling of the level+1 branch, scale attention, branch mean, DYReLU) written
+    straight into the level's slice of the output buffer -- offsets of the CURRENT level are re-used for all three
+    branches exactly like the reference (flat-index quirk handled inside the gather)."""
     G = cfg.MODEL.GROUP_NORM
     fused_dcn = bool(cfg.MODEL.DYHEAD.get("FUSED_DCN", True))
-    nl = len(feats)
+    nl = len(sizes)
+    Bn, N, C = tok.shape
+    offs = [0]
+    for (hh, ww) in sizes:
+        offs.append(offs[-1] + hh * ww)
+    lv = [tok[:, offs[l]:offs[l + 1]].reshape(Bn, sizes[l][0], sizes[l][1], C) for l in range(nl)]      # NHWC views
+    out = torch.empty_like(tok)
 
     def level(lvl):
-        f = feats[lvl]
-        Bn, C, H, W = f.shape
-        f_nhwc = f.permute(0, 2, 3, 1).contiguous()
-        om = ops.conv3x3(f_nhwc, P[b + ".offset.packed"], P[b + ".offset.bias"], 27).permute(0, 3, 1, 2).float().contiguous()
-        spec = [(1, f, 1)]
+        H, W = sizes[lvl]
+        om = ops.conv3x3(lv[lvl], P[b + ".offset.packed"], P[b + ".offset.bias"], 27).permute(0, 3, 1, 2).float().contiguous()
+        spec = [(1, lv[lvl], 1)]
         if lvl > 0:
-            spec.append((2, feats[lvl - 1], 2))
+            spec.append((2, lv[lvl - 1], 2))
         if lvl < nl - 1:
-            spec.append((0, feats[lvl + 1], 1))
+            spec.append((0, lv[lvl + 1], 1))
         branches = []
-        for k, x, stride in spec:
-            x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+        for k, x_nhwc, stride in spec:
             if fused_dcn:      # one implicit-GEMM kernel (dcn_fused.hip)
                 y, (Ho, Wo) = ops.dcnv2(x_nhwc, om, P[f"{b}.DyConv.{k}.packed"], P[f"{b}.DyConv.{k}.conv.bias"], stride)
             else:              # HIP gather + library GEMM against the tap-major packed weight
-                cols, (Ho, Wo) = ops.dcn_im2col(x_nhwc, om, stride)
+                cols, (Ho, Wo) = ops.dcn_im2col(x_nhwc.contiguous(), om, stride)
                 y = F.linear(cols, P[f"{b}.DyConv.{k}.packed"], P[f"{b}.DyConv.{k}.conv.bias"])      # [B, Ho*Wo, C]
             wy = wx = None
             if (Ho, Wo) != (H, W):
@@ -406,28 +428,35 @@ def dyconv(P, cfg, b, feats):
             coef = ops.dyconv_branch_coef(y, Wo, P[f"{b}.DyConv.{k}.bn.weight"], P[f"{b}.DyConv.{k}.bn.bias"],
                                           P[b + ".attn_w"], P[b + ".attn_b"], G.NUM_GROUPS, G.EPSILON, len(spec), wy, wx)
             branches.append((y, coef, Ho, Wo))
-        o, pool = ops.dyconv_fuse(branches, H, W)
+        o = out[:, offs[lvl]:offs[lvl + 1]]
+        _, pool = ops.dyconv_fuse(branches, H, W, out=o)
         ops.dyrelu_(o, pool, P[b + ".relu.fc.0.weight"], P[b + ".relu.fc.0.bias"], P[b + ".relu.fc.2.weight"],
                     P[b + ".relu.fc.2.bias"])
-        return o.reshape(Bn, H, W, C).permute(0, 3, 1, 2)
 
     # The five pyramid levels of one DyConv layer are independent given the layer input, and the small ones (P5-P7:
     # 96 / 32 / 8 workgroup tiles for B = 8) cannot fill 256 CUs on their own: run every level on its own HIP stream
     # (fork / join around the layer; inside the HIP-graph capture this becomes parallel graph branches).
-    if not (cfg.MODEL.DYHEAD.get("LEVEL_STREAMS", True) and feats[0].is_cuda and nl > 1):
-        return [level(l) for l in range(nl)]
+    if not (cfg.MODEL.DYHEAD.get("LEVEL_STREAMS", True) and tok.is_cuda and nl > 1):
+        for l in range(nl):
+            level(l)
+        return out
     main = torch.cuda.current_stream()
-    side = _side_streams(feats[0].device, nl - 1)
-    out = [None] * nl
+    side = _side_streams(tok.device, nl - 1)
     for s in side:
         s.wait_stream(main)
     for lvl in range(1, nl):
         with torch.cuda.stream(side[lvl - 1]):
-            out[lvl] = level(lvl)
-    out[0] = level(0)                                     # the big level (75 % of the positions) on the main stream
+            level(lvl)
+    level(0)                                              # the big level (75 % of the positions) on the main stream
     for s in side:
         main.wait_stream(s)
     return out
+
+
+def dyconv(P, cfg, b, feats):
+    """List-of-levels form of dyconv_tokens."""
+    tok, sizes = _to_tokens(feats)
+    return _level_views(dyconv_tokens(P, cfg, b, tok.contiguous(), sizes), sizes)
 
 
 _SIDE_STREAMS = {}
@@ -441,36 +470,43 @@ def _side_streams(device, n, tag="levels"):
 
 
 def vldyhead(P, cfg, feats, lang):
-    """VLDyHead.forward (vldyhead.py:769-900), eval outputs."""
+    """VLDyHead.forward (vldyhead.py:769-900), eval outputs.  The pyramid lives in ONE token buffer [B, N, 256] (levels
+    concatenated) from the first fusion layer to the prediction heads: VLFuse reads / writes it whole, DyConv reads
+    per-level NHWC views of it and writes per-level slices -- no concatenation or split copies between layers."""
     p = "rpn.head"
     hidden, key_bias, kv_len = lang["hidden"], lang["key_bias"], lang.get("kv_len")
+    tok, sizes = _to_tokens(feats)
+    tok = tok.contiguous()
     for i in range(cfg.MODEL.DYHEAD.NUM_CONVS):
         t = f"{p}.dyhead_tower"
-        feats, hidden = vl_fuse(P, f"{t}.{3 * i}.b_attn", feats, hidden, key_bias, kv_len, lang.get("max_kv", 0))
+        tok, hidden = vl_fuse_tokens(P, f"{t}.{3 * i}.b_attn", tok, hidden, key_bias, kv_len, lang.get("max_kv", 0))
         # the text-only BERT layer (a dozen small launches) and the image-only DyConv are independent: side stream
         if hidden.is_cuda and cfg.MODEL.DYHEAD.get("LEVEL_STREAMS", True):
             main, text = torch.cuda.current_stream(), _side_streams(hidden.device, 1, "text")[0]
             text.wait_stream(main)
             with torch.cuda.stream(text):
                 hidden = bert_layer(P, f"{t}.{3 * i + 1}", hidden, key_bias, clamp=True, kv_len=kv_len)
-            feats = dyconv(P, cfg, f"{t}.{3 * i + 2}", feats)
+            tok = dyconv_tokens(P, cfg, f"{t}.{3 * i + 2}", tok, sizes)
             main.wait_stream(text)
         else:
             hidden = bert_layer(P, f"{t}.{3 * i + 1}", hidden, key_bias, clamp=True, kv_len=kv_len)
-            feats = dyconv(P, cfg, f"{t}.{3 * i + 2}", feats)
+            tok = dyconv_tokens(P, cfg, f"{t}.{3 * i + 2}", tok, sizes)
     emb = F.normalize(hidden.float(), p=2, dim=-1)
-    tok = F.linear(emb / 2.0, P[p + ".tok.weight"], P[p + ".tok.bias"]) * P[p + ".inv_scale"]      # [B, T, 256]
+    tk = F.linear(emb / 2.0, P[p + ".tok.weight"], P[p + ".tok.bias"]) * P[p + ".inv_scale"]       # [B, T, 256]
     tbias = (emb @ P[p + ".bias_lang32"] + P[p + ".bias0_32"]).contiguous()                           # [B, T]
-    tok16_t = tok.to(feats[0].dtype).transpose(1, 2)
+    tok16_t = tk.to(tok.dtype).transpose(1, 2)
+    Bn, N, C = tok.shape
+    dots_all = torch.bmm(tok, tok16_t)                                                               # [B, N, T], all levels
     bbox, ctr, dots = [], [], []
-    for l, f in enumerate(feats):
-        Bn, C, H, W = f.shape
-        tokens = f.permute(0, 2, 3, 1).reshape(Bn, H * W, C)                                         # NHWC memory: a view
+    off = 0
+    for l, (H, W) in enumerate(sizes):
+        tokens = tok[:, off:off + H * W]
         bc = F.linear(tokens, P[f"{p}.boxctr.{l}.weight"], P[f"{p}.boxctr.{l}.bias"]).reshape(Bn, H, W, 8)
         bbox.append(bc[..., :4].permute(0, 3, 1, 2))                                                 # [B, 4, H, W] view
         ctr.append(bc[..., 4:5].permute(0, 3, 1, 2))
-        dots.append(torch.bmm(tokens, tok16_t))                                                      # [B, HW, T]
-    return {"bbox_reg": bbox, "centerness": ctr, "dot": dots, "tbias": tbias, "feats": feats, "hidden": hidden}
+        dots.append(dots_all[:, off:off + H * W])                                                    # [B, HW, T] view
+        off += H * W
+    return {"bbox_reg": bbox, "centerness": ctr, "dot": dots, "tbias": tbias, "feats": _level_views(tok, sizes), "hidden": hidden}
 
 
 # ----------------------------------------------------------------------------- anchors + post-processing

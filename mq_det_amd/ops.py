@@ -30,9 +30,9 @@ _SIGNATURES = {
     "mq_dcnv2_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _vp]),
     "mq_dyconv_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mq_dyconv_coef": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
-    "mq_dyconv_fuse": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mq_dyconv_fuse": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _l, _vp, _i, _i, _i, _i, _vp]),
     "mq_dyrelu_coef": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "mq_dyrelu_apply": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "mq_dyrelu_apply": (_i, [_vp, _vp, _i, _i, _i, _l, _vp]),
     "mq_align_scores_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "mq_box_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _vp]),
     "mq_ml_nms_workspace_bytes": (_l, [_i, _i]),
@@ -354,12 +354,16 @@ def dyconv_branch_coef(y, Wsrc, gamma, beta, attn_w, attn_b, groups, eps, nbranc
     return coef
 
 
-def dyconv_fuse(branches, H, W):
-    """branches: list of (y [B,hs*ws,C], coef [B,C,2], hs, ws) -> out [B,H*W,C] fp16, pool [B,C] fp32."""
+def dyconv_fuse(branches, H, W, out=None):
+    """branches: list of (y [B,hs*ws,C], coef [B,C,2], hs, ws) -> out [B,H*W,C] fp16, pool [B,C] fp32.
+    out: optional destination view [B,H*W,C] with contiguous rows and any batch stride (a level's slice of the pyramid
+    token buffer)."""
     lib = load_library()
     y0 = branches[0][0]
     B, _, C = y0.shape
-    out = torch.empty(B, H * W, C, dtype=torch.float16, device=y0.device)
+    if out is None:
+        out = torch.empty(B, H * W, C, dtype=torch.float16, device=y0.device)
+    assert out.shape == (B, H * W, C) and out.dtype == torch.float16 and out.stride(2) == 1 and out.stride(1) == C
     pool = torch.empty(B, (H * W + 127) // 128, C, dtype=torch.float32, device=y0.device)
     args = []
     for k in range(3):
@@ -371,21 +375,21 @@ def dyconv_fuse(branches, H, W):
         else:
             args += [_ptr(None), _ptr(None), 0, 0]
     with _timed("dyconv_fuse"):
-        _chk(lib.mq_dyconv_fuse(*args, len(branches), _ptr(out), _ptr(pool), B, H, W, C, _stream()), "mq_dyconv_fuse")
+        _chk(lib.mq_dyconv_fuse(*args, len(branches), _ptr(out), out.stride(0), _ptr(pool), B, H, W, C, _stream()), "mq_dyconv_fuse")
     return out, pool
 
 
 def dyrelu_(x, pool, w0, b0, w2, b2):
-    """In-place DYReLU on x [B,n,C] fp16 given pool [B,C] = sum over positions of x."""
+    """In-place DYReLU on x [B,n,C] fp16 (contiguous rows, any batch stride) given pool [B,C] = sum over positions of x."""
     lib = load_library()
     _need_gpu(x, pool, w0, b0, w2, b2)
     B, n, C = x.shape
-    assert x.is_contiguous() and w0.is_contiguous() and w2.is_contiguous() and w0.dtype == torch.float16
+    assert x.stride(2) == 1 and x.stride(1) == C and w0.is_contiguous() and w2.is_contiguous() and w0.dtype == torch.float16
     coef = torch.empty(B, 4, C, dtype=torch.float32, device=x.device)
     _chk(lib.mq_dyrelu_coef(_ptr(pool), _ptr(w0), _ptr(b0), _ptr(w2), _ptr(b2), _ptr(coef), B, n, C, _stream()),
          "mq_dyrelu_coef")
     with _timed("dyrelu_apply"):
-        _chk(lib.mq_dyrelu_apply(_ptr(x), _ptr(coef), B, n, C, _stream()), "mq_dyrelu_apply")
+        _chk(lib.mq_dyrelu_apply(_ptr(x), _ptr(coef), B, n, C, x.stride(0), _stream()), "mq_dyrelu_apply")
     return x
 
 

@@ -195,7 +195,7 @@ def dyconv_branch_coef(y, Wsrc, gamma, beta, attn_w, attn_b, groups, eps, nbranc
     return torch.stack([a[:, None] * sc, a[:, None] * sh], -1)
 
 
-def dyconv_fuse(branches, H, W):
+def dyconv_fuse(branches, H, W, out=None):
     B, _, C = branches[0][0].shape
     acc = torch.zeros(B, H * W, C)
     for y, cf, hs, ws in branches:
@@ -204,8 +204,11 @@ def dyconv_fuse(branches, H, W):
             v = F.interpolate(v, size=(H, W), mode="bilinear", align_corners=True)
         v = v.permute(0, 2, 3, 1).reshape(B, H * W, C)
         acc = acc + v * cf[:, None, :, 0] + cf[:, None, :, 1]
-    out = acc.to(branches[0][0].dtype)
-    return out, out.float().sum(1, keepdim=True)          # [B, nblk=1, C]
+    res = acc.to(branches[0][0].dtype)
+    if out is not None:
+        out.copy_(res)
+        res = out
+    return res, res.float().sum(1, keepdim=True)          # [B, nblk=1, C]
 
 
 def dyrelu_(x, pool, w0, b0, w2, b2):
