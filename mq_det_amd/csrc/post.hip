@@ -199,6 +199,92 @@ __global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long*
   for (int i = nchunks * 64 + lane; i < N; i += 64) kb[i] = 0;
 }
 
+// Same sweep, two waves per image: wave 1 streams the 64-row block of mask words of chunk c + 1 into LDS (coalesced,
+// double-buffered) while wave 0 resolves chunk c out of LDS.  The one-wave version above follows every surviving row
+// with a dependent global load (~0.5 us each, ~5000 candidates): 1.0 ms per forward, all of it on the critical path.
+template <int SLOTS>
+__global__ __launch_bounds__(128) void nms_sweep_lds_kernel(const unsigned long long* __restrict__ mask,
+                                                            const int* __restrict__ nvalid, unsigned char* __restrict__ keep,
+                                                            int N, int col_blocks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long rows_s[];      // [2][64 * col_blocks]
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = nvalid[b];
+  const unsigned long long* mb = mask + (long)b * N * col_blocks;
+  unsigned char* kb = keep + (long)b * N;
+  const int nchunks = (n + 63) / 64;
+  const int blk = 64 * col_blocks;
+  auto stage = [&](int c, int buf) {
+    const unsigned long long* src = mb + (long)c * blk;
+    const int avail = (min(N, c * 64 + 64) - c * 64) * col_blocks;       // rows that exist in the workspace
+    unsigned long long* dst = rows_s + buf * blk;
+    for (int idx = lane; idx < blk; idx += 64) dst[idx] = idx < avail ? src[idx] : 0ULL;
+  };
+  if (wave == 1 && nchunks > 0) stage(0, 0);
+  __syncthreads();
+  unsigned long long remv[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) remv[s] = 0ULL;
+  for (int c = 0; c < nchunks; ++c) {
+    if (wave == 1) {
+      if (c + 1 < nchunks) stage(c + 1, (c + 1) & 1);
+    } else {
+      const unsigned long long* L = rows_s + (c & 1) * blk;
+      const int i = c * 64 + lane;
+      unsigned long long word = 0ULL;                      // word c of remv lives in lane (c % 64), slot (c / 64)
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s)
+        if (s == c / 64) word = remv[s];
+      word = __shfl(word, c % 64);
+      const unsigned long long diag = (i < n) ? L[lane * col_blocks + c] : 0ULL;
+      int alive = (i < n) && !((word >> lane) & 1ULL);
+      for (int j = 0; j < 64; ++j) {
+        const int aj = __shfl(alive, j);
+        const unsigned long long dj = __shfl(diag, j);
+        if (aj && ((dj >> lane) & 1ULL)) alive = 0;        // only bits > j are ever set in row j's diagonal word
+      }
+      if (i < N) kb[i] = (unsigned char)alive;
+      const unsigned long long alive_mask = __ballot(alive);
+      // OR the rows of the survivors into remv: LDS reads are issued 8 rows at a time, the test is wave-uniform.
+      // (words <= c are OR-ed too: they belong to chunks already resolved and are never read again)
+      for (int r0 = 0; r0 < 64; r0 += 8) {
+        if (((alive_mask >> r0) & 0xFFULL) == 0ULL) continue;
+        unsigned long long v[8][SLOTS];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+          for (int s = 0; s < SLOTS; ++s) {
+            const int w = lane + 64 * s;
+            v[k][s] = (w < col_blocks) ? L[(r0 + k) * col_blocks + w] : 0ULL;
+          }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if ((alive_mask >> (r0 + k)) & 1ULL) {
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) remv[s] |= v[k][s];
+          }
+      }
+    }
+    __syncthreads();
+  }
+  if (wave == 0)
+    for (int i = nchunks * 64 + lane; i < N; i += 64) kb[i] = 0;
+}
+
+template <int SLOTS>
+static int launch_sweep_lds(const unsigned long long* mask, const int* nvalid, unsigned char* keep, int B, int N, int col_blocks,
+                            hipStream_t stream) {
+  const size_t smem = (size_t)2 * 64 * col_blocks * sizeof(unsigned long long);
+  static size_t attr_set = 0;
+  if (smem > attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)nms_sweep_lds_kernel<SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = smem;
+  }
+  hipLaunchKernelGGL((nms_sweep_lds_kernel<SLOTS>), dim3(B), dim3(128), smem, stream, mask, nvalid, keep, N, col_blocks);
+  MQ_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" long mq_ml_nms_workspace_bytes(int B, int N) {
   long col_blocks = (N + 63) / 64;
   return (long)B * N * col_blocks * 8;
@@ -214,9 +300,9 @@ extern "C" int mq_ml_nms(const float* boxes, const int* labels, const int* nvali
                      nvalid, mask, N, col_blocks, thr);
   MQ_CHECK_LAUNCH();
   if (col_blocks <= 64)
-    hipLaunchKernelGGL((nms_sweep_kernel<1>), dim3(B), dim3(64), 0, (hipStream_t)stream, mask, nvalid, keep, N, col_blocks);
+    return launch_sweep_lds<1>(mask, nvalid, keep, B, N, col_blocks, (hipStream_t)stream);
   else if (col_blocks <= 128)
-    hipLaunchKernelGGL((nms_sweep_kernel<2>), dim3(B), dim3(64), 0, (hipStream_t)stream, mask, nvalid, keep, N, col_blocks);
+    return launch_sweep_lds<2>(mask, nvalid, keep, B, N, col_blocks, (hipStream_t)stream);
   else
     hipLaunchKernelGGL((nms_sweep_kernel<4>), dim3(B), dim3(64), 0, (hipStream_t)stream, mask, nvalid, keep, N, col_blocks);
   MQ_CHECK_LAUNCH();

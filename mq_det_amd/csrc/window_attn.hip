@@ -8,13 +8,28 @@
 //   qkv      : [B, H, W, 3*C] fp16 = Linear(norm1(x)) on the UNPADDED tokens, C = heads*32
 //   qkv_bias : [3*C] fp16 -- q/k/v of a pad token (pad happens after norm1, so a pad token is an exact
 //              zero vector and its qkv row equals the bias; pad tokens DO act as keys, swint.py quirk 7)
-//   rel_bias : [heads, N, N] fp32 (relative_position_bias_table gathered by relative_position_index)
+//   rel_bias : [heads, 64, 64] fp32: relative_position_bias_table gathered by relative_position_index into rows = query,
+//              cols = key, zero-padded from N = ws*ws to 64 (the kernel masks the padded keys itself)
 //   out      : [B, H, W, C] fp16 (attention output before `proj`)
 // One wave per (window, head): N = ws*ws <= 64 tokens padded to 64, head_dim 32.
-//   S (64x64)  = 16 x mfma 16x16x32 (K = head_dim = 32, one MFMA per 16x16 block), Q/K fragments are
-//                read straight from global memory (16 B per lane, each element is used once);
-//   P.V        = 16 x mfma, V goes through a transposed LDS tile, P through a per-wave LDS tile.
+//   S^T (64 keys x 64 queries) = 16 x mfma 16x16x32 with the operands SWAPPED (A = K rows, B = Q rows; K = head_dim = 32,
+//     one MFMA per 16x16 block), fragments read straight from global memory (16 B per lane, each element used once).
+//     A lane then owns one QUERY column (l15) and 4 keys (4*lg + r) per 16-key block: bias rows are 16-byte loads, the
+//     softmax reduction is in-lane + 2 shuffles, and the normalised probabilities already ARE the P^T B-fragments of
+//     the second MFMA -- P never goes through LDS;
+//   O^T = V^T P^T: V is staged row-major in LDS ([key][32], one 16-byte store per lane and block) and read transposed
+//     with ds_read_b64_tr_b16; a lane ends with 4 consecutive channels of one query -> 8-byte stores.
+// (v1 computed S, wrote P and a scalar-transposed V through LDS, fetched the bias with 64 scalar loads per lane and
+//  stored 2 bytes per lane: ~1 TB/s.  profiles/README.md.)
 #include "common.h"
+
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(8)));
+__device__ __forceinline__ half4 win_lds_tr16(const half_t* p) {
+  fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)p);
+  half4 o;
+  __builtin_memcpy(&o, &v, 8);
+  return o;
+}
 
 struct WinParams {
   const half_t* qkv; const half_t* qkv_bias; const float* rel_bias; half_t* out;
@@ -23,9 +38,8 @@ struct WinParams {
 };
 
 __global__ __launch_bounds__(256) void window_attn_kernel(WinParams p) {
-  constexpr int VS = 64 + 8, PS = 64 + 8;
-  __shared__ __attribute__((aligned(16))) half_t Vs_all[4][32 * VS];
-  __shared__ __attribute__((aligned(16))) half_t Ps_all[4][64 * PS];
+  constexpr int VP = 32 + 8;                               // V row pitch (halfs)
+  __shared__ __attribute__((aligned(16))) half_t Vs_all[4][64 * VP];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l15 = lane & 15, lg = lane >> 4;
   const long unit = (long)blockIdx.x * 4 + wave;          // (b, wy, wx, head)
@@ -38,116 +52,111 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinParams p) {
   const int b = win / p.nWy;
   const int N = p.ws * p.ws;
   half_t* Vs = Vs_all[wave];
-  half_t* Ps = Ps_all[wave];
 
-  // token i of this window -> pointer to its qkv row (or the bias row for pad tokens), region id
-  auto tok_ptr = [&](int i, bool& real, int& y, int& x, int& region) -> const half_t* {
-    int ii = min(i, N - 1);
-    int ys = wy * p.ws + ii / p.ws, xs = wx * p.ws + ii % p.ws;       // coords in the shifted frame
-    y = ys + p.shift; if (y >= p.Hp) y -= p.Hp;                       // shifted[ys] = x[(ys+shift) % Hp]
-    x = xs + p.shift; if (x >= p.Wp) x -= p.Wp;
-    int ry = ys < p.Hp - p.ws ? 0 : (ys < p.Hp - p.shift ? 1 : 2);
-    int rx = xs < p.Wp - p.ws ? 0 : (xs < p.Wp - p.shift ? 1 : 2);
-    region = ry * 3 + rx;
-    real = (y < p.H) && (x < p.W);
-    return real ? p.qkv + (((long)b * p.H + y) * p.W + x) * (3 * p.C) : p.qkv_bias;
+  // window token i -> SW-MSA region id (img_mask of swint.py:570-588) in the shifted frame
+  auto region_of = [&](int i) {
+    const int ii = min(i, N - 1);
+    const int ys = wy * p.ws + ii / p.ws, xs = wx * p.ws + ii % p.ws;
+    const int ry = ys < p.Hp - p.ws ? 0 : (ys < p.Hp - p.shift ? 1 : 2);
+    const int rx = xs < p.Wp - p.ws ? 0 : (xs < p.Wp - p.shift ? 1 : 2);
+    return ry * 3 + rx;
   };
 
-  // ---- V -> transposed LDS tile Vs[d][key]; keys >= N are zero
-  for (int c = lane; c < 64 * 4; c += 64) {
-    int key = c >> 2, ch = c & 3;
-    half8 v = zero8();
-    if (key < N) {
-      bool real; int y, x, rg;
-      const half_t* row = tok_ptr(key, real, y, x, rg);
-      v = *(const half8*)(row + 2 * p.C + head * 32 + ch * 8);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) Vs[(ch * 8 + j) * VS + key] = v[j];
-  }
-
-  // ---- Q, K fragments (A: rows = queries, B: rows of K), token index = block*16 + l15
+  // ---- the 4 tokens this lane addresses (token = blk*16 + l15): K / Q fragments, V chunk, output pixel
   half8 qf[4], kf[4];
-  int region_q[4];          // region of the rows this lane owns in C layout is needed per (rb, r) below
+  long out_off[4];                                         // element offset of the token's output row, -1: pad / beyond N
+  int region_q[4];
 #pragma unroll
   for (int blk = 0; blk < 4; ++blk) {
-    bool real; int y, x, rg;
-    const half_t* row = tok_ptr(blk * 16 + l15, real, y, x, rg);
+    const int i = blk * 16 + l15, ii = min(i, N - 1);
+    const int ys = wy * p.ws + ii / p.ws, xs = wx * p.ws + ii % p.ws;       // coords in the shifted frame
+    int y = ys + p.shift; if (y >= p.Hp) y -= p.Hp;                       // shifted[ys] = x[(ys+shift) % Hp]
+    int x = xs + p.shift; if (x >= p.Wp) x -= p.Wp;
+    const bool real = (y < p.H) && (x < p.W);
+    const half_t* row = real ? p.qkv + (((long)b * p.H + y) * p.W + x) * (3 * p.C) : p.qkv_bias;
     qf[blk] = *(const half8*)(row + head * 32 + lg * 8);
     kf[blk] = *(const half8*)(row + p.C + head * 32 + lg * 8);
-    region_q[blk] = rg;     // region of token blk*16 + l15 (used as the KEY region: col = l15)
+    const half8 v = *(const half8*)(row + 2 * p.C + head * 32 + lg * 8);
+    *(half8*)(Vs + i * VP + lg * 8) = v;                   // keys >= N hold a copy of key N-1: finite, weight exactly 0
+    out_off[blk] = (real && i < N) ? (((long)b * p.H + y) * p.W + x) * p.C + head * 32 : -1;
+    region_q[blk] = region_of(i);
   }
 
-  const float* rel = p.rel_bias + (long)head * N * N;
+  int region_k[4][4];
+  if (p.shift > 0) {
 #pragma unroll
-  for (int rb = 0; rb < 4; ++rb) {
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) region_k[nb][r] = region_of(nb * 16 + 4 * lg + r);
+  }
+  const float* rel = p.rel_bias + (long)head * 64 * 64;
+  wave_lds_fence();                                        // V tile written by this wave's own lanes
+  // one 16-query block at a time (keeps the kernel under 128 VGPRs -> 4 waves / SIMD for this load / store bound op)
+#pragma unroll
+  for (int qb = 0; qb < 4; ++qb) {
+    // ---- S^T = K Q^T : s[nb], element r <-> key nb*16 + 4*lg + r, query qb*16 + l15
     float4_ s[4];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) s[nb] = mfma16(qf[rb], kf[nb], (float4_){0.f, 0.f, 0.f, 0.f});
-    // C layout: row i = rb*16 + lg*4 + r (query), col j = nb*16 + l15 (key)
+    for (int nb = 0; nb < 4; ++nb) s[nb] = mfma16(kf[nb], qf[qb], (float4_){0.f, 0.f, 0.f, 0.f});
+    const float* relq = rel + (qb * 16 + l15) * 64 + 4 * lg;
+    float mx = MQ_NEG_BIG;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int i = rb * 16 + lg * 4 + r;
-      int ic = min(i, N - 1);
-      int region_i;
-      {
-        int ys = wy * p.ws + ic / p.ws, xs = wx * p.ws + ic % p.ws;
-        int ry = ys < p.Hp - p.ws ? 0 : (ys < p.Hp - p.shift ? 1 : 2);
-        int rx = xs < p.Wp - p.ws ? 0 : (xs < p.Wp - p.shift ? 1 : 2);
-        region_i = ry * 3 + rx;
-      }
-      float mx = MQ_NEG_BIG;
+    for (int nb = 0; nb < 4; ++nb) {
+      const float4_ rb = *(const float4_*)(relq + nb * 16);
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) {
-        int j = nb * 16 + l15;
-        float v = MQ_NEG_BIG;
-        if (j < N) {
-          v = s[nb][r] * p.scale + rel[ic * N + j];
-          if (p.shift > 0 && region_i != region_q[nb]) v += -100.0f;
-        }
+      for (int r = 0; r < 4; ++r) {
+        float v = s[nb][r] * p.scale + rb[r];
+        if (p.shift > 0 && region_k[nb][r] != region_q[qb]) v += -100.0f;
+        if (nb * 16 + 4 * lg + r >= N) v = MQ_NEG_BIG;
         s[nb][r] = v;
         mx = fmaxf(mx, v);
       }
-      mx = group16_max(mx);
-      float sum = 0.f;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) {
-        float e = __expf(s[nb][r] - mx);
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(s[nb][r] - mx);
         s[nb][r] = e;
         sum += e;
       }
-      sum = group16_sum(sum);
-      float inv = 1.f / sum;
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.f / sum;
+    half8 pf[2];                                           // P^T B-fragments of the two 32-key steps
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) Ps[i * PS + nb * 16 + l15] = (half_t)(s[nb][r] * inv);
-    }
-  }
-
-  wave_lds_fence();
-  // ---- O = P V : rows rb*16.., cols (d) db*16.., K over 64 keys
+    for (int st = 0; st < 2; ++st)
 #pragma unroll
-  for (int rb = 0; rb < 4; ++rb) {
+      for (int r = 0; r < 4; ++r) {
+        pf[st][r] = (half_t)(s[2 * st][r] * inv);
+        pf[st][4 + r] = (half_t)(s[2 * st + 1][r] * inv);
+      }
+    // ---- O^T[db] = V^T P^T : A = transposed reads of the row-major V tile (k-slot (lg, j) <-> key 16*(j/4) + 4*lg + j%4)
     float4_ o[2] = {(float4_){0.f, 0.f, 0.f, 0.f}, (float4_){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      half8 pf = *(const half8*)(Ps + (rb * 16 + l15) * PS + kk * 32 + lg * 8);
+    for (int st = 0; st < 2; ++st) {
+      const half_t* base = Vs + (st * 32 + 4 * lg + (l15 >> 2)) * VP + (l15 & 3) * 4;
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
-        half8 vf = *(const half8*)(Vs + (db * 16 + l15) * VS + kk * 32 + lg * 8);
-        o[db] = mfma16(pf, vf, o[db]);
+        const half4 lo = win_lds_tr16(base + db * 16);
+        const half4 hi = win_lds_tr16(base + 16 * VP + db * 16);
+        half8 a;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = lo[j]; a[4 + j] = hi[j]; }
+        o[db] = mfma16(a, pf[st], o[db]);
       }
     }
+    // O^T C layout: row = channel db*16 + 4*lg + r, col = query qb*16 + l15  ->  4 consecutive channels per lane
+    if (out_off[qb] >= 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int i = rb * 16 + lg * 4 + r;
-      if (i < N) {
-        bool real; int y, x, rg;
-        tok_ptr(i, real, y, x, rg);
-        if (real) {
-          half_t* dst = p.out + (((long)b * p.H + y) * p.W + x) * p.C + head * 32;
-          dst[l15] = (half_t)o[0][r];
-          dst[16 + l15] = (half_t)o[1][r];
-        }
+      for (int db = 0; db < 2; ++db) {
+        half4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (half_t)o[db][r];
+        *(half4*)(p.out + out_off[qb] + db * 16 + 4 * lg) = v;
       }
     }
   }

@@ -38,8 +38,8 @@ def build_plan(sd, cfg, device, dtype=torch.float16):
         for j in range(depth):
             b = f"backbone.body.layers.{i}.blocks.{j}.attn"
             idx = sd[b + ".relative_position_index"].to(device).reshape(-1)
-            P[b + ".rel_bias"] = f32(b + ".relative_position_bias_table")[idx].reshape(N, N, heads) \
-                .permute(2, 0, 1).contiguous()
+            rel = f32(b + ".relative_position_bias_table")[idx].reshape(N, N, heads).permute(2, 0, 1)
+            P[b + ".rel_bias"] = F.pad(rel, (0, 64 - N, 0, 64 - N)).contiguous()        # [heads, 64, 64], see ops.pad_rel_bias
     # convs: channels_last weights
     for k in list(P):
         if P[k].dim() == 4:

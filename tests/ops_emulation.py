@@ -61,7 +61,7 @@ def window_attention(qkv, qkv_bias, rel_bias, heads, ws, shift):
     xw = full.reshape(B, Hp // ws, ws, Wp // ws, ws, C3).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C3)
     Bw, N, _ = xw.shape
     t = xw.reshape(Bw, N, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
-    attn = (t[0] * (C // heads) ** -0.5) @ t[1].transpose(-1, -2) + rel_bias[None]
+    attn = (t[0] * (C // heads) ** -0.5) @ t[1].transpose(-1, -2) + rel_bias[None, :, :N, :N]
     if shift:
         region = torch.zeros(Hp, Wp)
         k = 0
