@@ -111,22 +111,27 @@ int mq_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y
  *   x [B,H,W,C] (batch stride x_bs elements, C % 32 == 0), w [Npad, 9*C] fp16 with k = tap*C + c (Npad = 32 if
  *   N <= 32 else 256; rows >= N zero), bias [N] fp16 or NULL, out [B*Ho*Wo, out_ld] fp16 (first N columns written).
  *   mq_dcnv2_fwd additionally takes om [B,27,oH,oW] fp32 NCHW = 18 offsets + 9 mask LOGITS, indexed flat by the output
- *   dims like the reference kernel (the buffer may come from another pyramid level); N must be 256.
+ *   dims like the reference kernel (the buffer may come from another pyramid level); N must be 256.  With stats != NULL it
+ *   also emits the GroupNorm / scale-attention statistics of its output (layout of mq_dyconv_stats with
+ *   mq_dcnv2_stats_blocks(H, W, stride) blocks per image; wy [Ho], wx [Wo] position weights or NULL for 1/(Ho*Wo)).
  * mq_dcnv2_fwd replaces _C.modulated_deform_conv_forward (maskrcnn_benchmark/csrc/vision.cpp:11-12,
  *   csrc/cuda/deform_conv_cuda.cu:496-575, deform_conv_kernel_cuda.cu:578-640) without the im2col buffer;
  * mq_conv3x3_fwd replaces the nn.Conv2d 3x3 calls of backbone/fpn.py:41,141-146 and the DyConv offset conv
  *   (rpn/vldyhead.py:186,214). */
 int mq_conv3x3_fwd(const void* x, const void* w, const void* bias, void* out, int B, int H, int W, int C, long x_bs,
                    int N, int out_ld, int stride, void* stream);
-int mq_dcnv2_fwd(const void* x, const float* om, const void* w, const void* bias, void* out, int B, int H, int W, int C,
-                 long x_bs, int oH, int oW, int N, int out_ld, int stride, void* stream);
+int mq_dcnv2_stats_blocks(int H, int W, int stride);
+int mq_dcnv2_fwd(const void* x, const float* om, const void* w, const void* bias, void* out, float* stats, const float* wy,
+                 const float* wx, int B, int H, int W, int C, long x_bs, int oH, int oW, int N, int out_ld, int stride,
+                 void* stream);
 
 /* DyConv epilogue (GroupNorm(16) + bilinear up-sampling of the level+1 branch + scale attention + branch mean,
  * then DYReLU), NHWC fp16 with fp32 statistics; C == 256.
  *   mq_dyconv_stats : y [B,n,C] -> sums [B,ceil(n/256),C,3] fp32 per-block partials (sum, sum sq, weighted sum; fixed
  *                     reduction order = reproducible); wy [n/W], wx [W] fp32 give the per-pixel weights wy*wx
  *                     (spatial mean of the up-sampled map) or NULL for 1/n.
- *   mq_dyconv_coef  : sums + GN gamma/beta fp16 [C] + AttnConv weight [C] / bias [1] fp32 -> coef [B,C,2] fp32
+ *   mq_dyconv_coef  : sums [B,nblk,C,3] (nblk <= 0: ceil(n/256), the mq_dyconv_stats layout; mq_dcnv2_fwd's fused
+ *                     statistics use nblk = mq_dcnv2_stats_blocks) + GN gamma/beta fp16 [C] + AttnConv weight [C] / bias [1] fp32 -> coef [B,C,2] fp32
  *                     (a*rstd*gamma, a*(beta - mean*rstd*gamma)), a = h_sigmoid(relu(w . pooled + b)) / nbranches.
  *   mq_dyconv_fuse  : out [B,H*W,C] (batch stride out_bs elements: a level's slice of the [B,N,C] pyramid token buffer)
  *                     = sum_k coef_k[.,0]*y_k^ + coef_k[.,1], y_k^ = y_k or its bilinear
@@ -137,7 +142,7 @@ int mq_dcnv2_fwd(const void* x, const float* om, const void* w, const void* bias
  *   DYReLU.forward, maskrcnn_benchmark/layers/dyrelu.py:78-112. */
 int mq_dyconv_stats(const void* y, float* sums, const float* wy, const float* wx, int B, int n, int W, int C, void* stream);
 int mq_dyconv_coef(const float* sums, const void* gamma, const void* beta, const float* attn_w, const float* attn_b,
-                   float* coef, int B, int n, int C, int G, float eps, int nbranches, void* stream);
+                   float* coef, int B, int n, int nblk, int C, int G, float eps, int nbranches, void* stream);
 int mq_dyconv_fuse(const void* y0, const float* coef0, int hs0, int ws0, const void* y1, const float* coef1, int hs1,
                    int ws1, const void* y2, const float* coef2, int hs2, int ws2, int nbranches, void* out, long out_bs,
                    float* pool, int B, int H, int W, int C, void* stream);

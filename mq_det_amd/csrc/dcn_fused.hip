@@ -26,6 +26,8 @@
 
 struct DcnFParams {
   const half_t* x; const half_t* w; const half_t* bias; const float* om; half_t* out;
+  float* stats;            // optional [B, tiles_y*tiles_x, 256, 3]: per-patch (sum y, sum y^2, sum w_p y) of the fp16 output
+  const float* wy; const float* wx;    // position weights w_p = wy[ho]*wx[wo] of the third statistic; NULL -> 1/(Ho*Wo)
   long x_bs;
   int B, H, W, C, Ho, Wo, stride, oH, oW, out_ld, tiles_x, tiles_y, tiles_total;
 };
@@ -291,23 +293,72 @@ __global__ __launch_bounds__(512) void dcn_igemm8_kernel(DcnFParams p) {
     if (ho < p.Ho && wo < p.Wo)
       *(half8*)(p.out + ((long)b * n_pos + ho * p.Wo + wo) * p.out_ld + ch * 8) = *(const half8*)(Os + row * OS + ch * 8);
   }
+  // ---- GroupNorm / scale-attention statistics of this patch (what mq_dyconv_stats would re-read y from HBM for):
+  // per channel sum, sum of squares and position-weighted sum of the fp16-rounded outputs; fixed summation order.
+  if (p.stats) {
+    const int chunk = tid & 31, rg = tid >> 5;               // 8 channels x 8 rows per thread
+    float s1[8], s2[8], s3[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = s3[j] = 0.f;
+    const float inv_n = 1.f / (float)n_pos;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int row = rg * 8 + k;
+      const int ho = ho0 + row / DCN_PW, wo = wo0 + row % DCN_PW;
+      if (ho < p.Ho && wo < p.Wo) {
+        const half8 v = *(const half8*)(Os + row * OS + chunk * 8);
+        const float w = p.wy ? p.wy[ho] * p.wx[wo] : inv_n;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = (float)v[j];
+          s1[j] += f; s2[j] += f * f; s3[j] += w * f;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                            // lanes l and l ^ 32 hold the same channels
+      s1[j] += __shfl_xor(s1[j], 32); s2[j] += __shfl_xor(s2[j], 32); s3[j] += __shfl_xor(s3[j], 32);
+    }
+    float* red = (float*)(smem + (size_t)BM * OS * sizeof(half_t));      // [8 waves][32 chunks][24], behind the O staging
+    if (lane < 32) {
+      float* r = red + (wave * 32 + chunk) * 24;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { r[j] = s1[j]; r[8 + j] = s2[j]; r[16 + j] = s3[j]; }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 32 * 24; idx += 512) {
+      const int lc = idx / 24, k = idx % 24;
+      float a = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) a += red[(g * 32 + lc) * 24 + k];
+      p.stats[(((long)b * (p.tiles_x * p.tiles_y) + trem) * BN + lc * 8 + (k & 7)) * 3 + (k >> 3)] = a;
+    }
+  }
 }
 
 // DCNv2 3x3, pad 1, 256 output channels.  x [B,H,W,C] fp16 NHWC (batch stride x_bs, C % 128 == 0), om [B,27,oH,oW] fp32
-// (18 offsets + 9 mask logits, NCHW), w [256, 9*C] fp16 (k = tap*C + c), bias [256] fp16 or NULL, out [B*Ho*Wo, out_ld].
-extern "C" int mq_dcnv2_fwd(const void* x, const float* om, const void* w, const void* bias, void* out, int B, int H, int W,
-                            int C, long x_bs, int oH, int oW, int N, int out_ld, int stride, void* stream) {
+// (18 offsets + 9 mask logits, NCHW), w [256, 9*C] fp16 (k = tap*C + c), bias [256] fp16 or NULL, out [B*Ho*Wo, out_ld];
+// stats (optional) [B, mq_dcnv2_stats_blocks(H, W, stride), 256, 3] fp32 with position weights wy [Ho] x wx [Wo] (or NULL).
+extern "C" int mq_dcnv2_stats_blocks(int H, int W, int stride) {
+  const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  return ((Ho + DCN_PH - 1) / DCN_PH) * ((Wo + DCN_PW - 1) / DCN_PW);
+}
+
+extern "C" int mq_dcnv2_fwd(const void* x, const float* om, const void* w, const void* bias, void* out, float* stats,
+                            const float* wy, const float* wx, int B, int H, int W, int C, long x_bs, int oH, int oW, int N,
+                            int out_ld, int stride, void* stream) {
   if (B <= 0) return 0;
   if (N != 256 || C % 128 || stride < 1 || stride > 2 || out_ld < N || out_ld % 8) return -1;
   DcnFParams p;
   p.x = (const half_t*)x; p.w = (const half_t*)w; p.bias = (const half_t*)bias; p.om = om; p.out = (half_t*)out;
+  p.stats = stats; p.wy = wy; p.wx = wx;
   p.x_bs = x_bs; p.B = B; p.H = H; p.W = W; p.C = C; p.stride = stride; p.oH = oH; p.oW = oW; p.out_ld = out_ld;
   p.Ho = (H + 2 - 3) / stride + 1; p.Wo = (W + 2 - 3) / stride + 1;
   if ((long)p.Ho * p.Wo > (long)oH * oW) return -2;          // flat reads must stay inside the om buffer
   p.tiles_y = (p.Ho + DCN_PH - 1) / DCN_PH; p.tiles_x = (p.Wo + DCN_PW - 1) / DCN_PW;
   p.tiles_total = B * p.tiles_y * p.tiles_x;
   constexpr size_t tiles = (size_t)(2 * 128 * 64 + 2 * 256 * 64) * sizeof(half_t) + 128 * 9 * sizeof(TapState);
-  constexpr size_t ostage = (size_t)128 * (256 + 8) * sizeof(half_t);
+  constexpr size_t ostage = (size_t)128 * (256 + 8) * sizeof(half_t) + (size_t)8 * 32 * 24 * sizeof(float);
   constexpr size_t smem = tiles > ostage ? tiles : ostage;
   static bool attr_set = false;
   if (!attr_set) {

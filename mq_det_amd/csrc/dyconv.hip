@@ -112,11 +112,11 @@ __global__ void dyconv_coef_kernel(const float* __restrict__ part, int nblk, con
 }
 
 extern "C" int mq_dyconv_coef(const float* sums, const void* gamma, const void* beta, const float* attn_w,
-                              const float* attn_b, float* coef, int B, int n, int C, int G, float eps, int nbranches,
-                              void* stream) {
+                              const float* attn_b, float* coef, int B, int n, int nblk, int C, int G, float eps,
+                              int nbranches, void* stream) {
   if (B <= 0) return 0;
   if (C != 256 || G > 64 || C % G) return -1;
-  hipLaunchKernelGGL(dyconv_coef_kernel, dim3(B), dim3(C), 0, (hipStream_t)stream, sums, (n + 255) / 256, (const half_t*)gamma,
+  hipLaunchKernelGGL(dyconv_coef_kernel, dim3(B), dim3(C), 0, (hipStream_t)stream, sums, nblk > 0 ? nblk : (n + 255) / 256, (const half_t*)gamma,
                      (const half_t*)beta, attn_w, attn_b, coef, n, C, G, eps, 1.f / (float)nbranches);
   MQ_CHECK_LAUNCH();
   return 0;

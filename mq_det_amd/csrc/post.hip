@@ -199,36 +199,55 @@ __global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long*
   for (int i = nchunks * 64 + lane; i < N; i += 64) kb[i] = 0;
 }
 
-// Same sweep, two waves per image: wave 1 streams the 64-row block of mask words of chunk c + 1 into LDS (coalesced,
-// double-buffered) while wave 0 resolves chunk c out of LDS.  The one-wave version above follows every surviving row
-// with a dependent global load (~0.5 us each, ~5000 candidates): 1.0 ms per forward, all of it on the critical path.
+// Same sweep, five waves per image: waves 1-4 stream the 64-row block of mask words of chunk c + 2 into LDS (coalesced
+// 16-byte loads, all of a wave's loads in flight before the first store, triple-buffered) while wave 0 resolves chunk c
+// out of LDS.  The one-wave version above follows every surviving row with a dependent global load (~0.5 us each,
+// ~5000 candidates): 1.0 ms per forward, all of it on the critical path.
 template <int SLOTS>
-__global__ __launch_bounds__(128) void nms_sweep_lds_kernel(const unsigned long long* __restrict__ mask,
+__global__ __launch_bounds__(320) void nms_sweep_lds_kernel(const unsigned long long* __restrict__ mask,
                                                             const int* __restrict__ nvalid, unsigned char* __restrict__ keep,
                                                             int N, int col_blocks) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long rows_s[];      // [2][64 * col_blocks]
+  extern __shared__ __attribute__((aligned(16))) unsigned long long rows_s[];      // [3][64 * col_blocks]
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
   const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = nvalid[b];
   const unsigned long long* mb = mask + (long)b * N * col_blocks;
   unsigned char* kb = keep + (long)b * N;
   const int nchunks = (n + 63) / 64;
-  const int blk = 64 * col_blocks;
-  auto stage = [&](int c, int buf) {
+  const int blk = 64 * col_blocks;                          // words per chunk block (even)
+  auto stage = [&](int c) {                                 // loader waves: chunk c -> buffer c % 3
+    if (c >= nchunks) return;
     const unsigned long long* src = mb + (long)c * blk;
-    const int avail = (min(N, c * 64 + 64) - c * 64) * col_blocks;       // rows that exist in the workspace
-    unsigned long long* dst = rows_s + buf * blk;
-    for (int idx = lane; idx < blk; idx += 64) dst[idx] = idx < avail ? src[idx] : 0ULL;
+    const int avail = (min(N, c * 64 + 64) - c * 64) * col_blocks;       // words of rows that exist in the workspace
+    unsigned long long* dst = rows_s + (c % 3) * blk;
+    const int lt = (wave - 1) * 64 + lane;                  // 0..255
+    constexpr int U = 8;
+    for (int base = 0; base < blk; base += 256 * 2 * U) {
+      u64x2 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = base + (u * 256 + lt) * 2;
+        v[u] = (u64x2){0ULL, 0ULL};
+        if (idx + 1 < avail) v[u] = *(const u64x2*)(src + idx);
+        else if (idx < avail) v[u][0] = src[idx];             // odd tail: never read past the workspace
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = base + (u * 256 + lt) * 2;
+        if (idx < blk) *(u64x2*)(dst + idx) = v[u];
+      }
+    }
   };
-  if (wave == 1 && nchunks > 0) stage(0, 0);
+  if (wave > 0) { stage(0); stage(1); }
   __syncthreads();
   unsigned long long remv[SLOTS];
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) remv[s] = 0ULL;
   for (int c = 0; c < nchunks; ++c) {
-    if (wave == 1) {
-      if (c + 1 < nchunks) stage(c + 1, (c + 1) & 1);
+    if (wave > 0) {
+      stage(c + 2);                                         // buffer (c + 2) % 3 was last read for chunk c - 1
     } else {
-      const unsigned long long* L = rows_s + (c & 1) * blk;
+      const unsigned long long* L = rows_s + (c % 3) * blk;
       const int i = c * 64 + lane;
       unsigned long long word = 0ULL;                      // word c of remv lives in lane (c % 64), slot (c / 64)
 #pragma unroll
@@ -273,14 +292,14 @@ __global__ __launch_bounds__(128) void nms_sweep_lds_kernel(const unsigned long 
 template <int SLOTS>
 static int launch_sweep_lds(const unsigned long long* mask, const int* nvalid, unsigned char* keep, int B, int N, int col_blocks,
                             hipStream_t stream) {
-  const size_t smem = (size_t)2 * 64 * col_blocks * sizeof(unsigned long long);
+  const size_t smem = (size_t)3 * 64 * col_blocks * sizeof(unsigned long long);
   static size_t attr_set = 0;
   if (smem > attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)nms_sweep_lds_kernel<SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr_set = smem;
   }
-  hipLaunchKernelGGL((nms_sweep_lds_kernel<SLOTS>), dim3(B), dim3(128), smem, stream, mask, nvalid, keep, N, col_blocks);
+  hipLaunchKernelGGL((nms_sweep_lds_kernel<SLOTS>), dim3(B), dim3(320), smem, stream, mask, nvalid, keep, N, col_blocks);
   MQ_CHECK_LAUNCH();
   return 0;
 }
@@ -299,10 +318,12 @@ extern "C" int mq_ml_nms(const float* boxes, const int* labels, const int* nvali
   hipLaunchKernelGGL(nms_mask_kernel, dim3(col_blocks, col_blocks, B), dim3(64), 0, (hipStream_t)stream, boxes, labels,
                      nvalid, mask, N, col_blocks, thr);
   MQ_CHECK_LAUNCH();
-  if (col_blocks <= 64)
+  if (col_blocks <= 64)                                    // three 64-row blocks of mask words fit the 160 KB LDS
     return launch_sweep_lds<1>(mask, nvalid, keep, B, N, col_blocks, (hipStream_t)stream);
-  else if (col_blocks <= 128)
+  else if (col_blocks <= 104)
     return launch_sweep_lds<2>(mask, nvalid, keep, B, N, col_blocks, (hipStream_t)stream);
+  else if (col_blocks <= 128)
+    hipLaunchKernelGGL((nms_sweep_kernel<2>), dim3(B), dim3(64), 0, (hipStream_t)stream, mask, nvalid, keep, N, col_blocks);
   else
     hipLaunchKernelGGL((nms_sweep_kernel<4>), dim3(B), dim3(64), 0, (hipStream_t)stream, mask, nvalid, keep, N, col_blocks);
   MQ_CHECK_LAUNCH();

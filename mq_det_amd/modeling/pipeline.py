@@ -417,16 +417,18 @@ def dyconv_tokens(P, cfg, b, tok, sizes):
             spec.append((0, lv[lvl + 1], 1))
         branches = []
         for k, x_nhwc, stride in spec:
-            if fused_dcn:      # one implicit-GEMM kernel (dcn_fused.hip)
-                y, (Ho, Wo) = ops.dcnv2(x_nhwc, om, P[f"{b}.DyConv.{k}.packed"], P[f"{b}.DyConv.{k}.conv.bias"], stride)
-            else:              # HIP gather + library GEMM against the tap-major packed weight
-                cols, (Ho, Wo) = ops.dcn_im2col(x_nhwc.contiguous(), om, stride)
-                y = F.linear(cols, P[f"{b}.DyConv.{k}.packed"], P[f"{b}.DyConv.{k}.conv.bias"])      # [B, Ho*Wo, C]
-            wy = wx = None
+            Ho, Wo = (x_nhwc.shape[1] - 1) // stride + 1, (x_nhwc.shape[2] - 1) // stride + 1
+            wy = wx = sums = None
             if (Ho, Wo) != (H, W):
-                wy, wx = _upsample_pool_weights(Ho, Wo, H, W, y.device)
+                wy, wx = _upsample_pool_weights(Ho, Wo, H, W, tok.device)
+            if fused_dcn:      # one implicit-GEMM kernel (dcn_fused.hip); GroupNorm statistics come out of its epilogue
+                y, _, sums = ops.dcnv2(x_nhwc, om, P[f"{b}.DyConv.{k}.packed"], P[f"{b}.DyConv.{k}.conv.bias"], stride,
+                                       want_stats=True, wy=wy, wx=wx)
+            else:              # HIP gather + library GEMM against the tap-major packed weight
+                cols, _ = ops.dcn_im2col(x_nhwc.contiguous(), om, stride)
+                y = F.linear(cols, P[f"{b}.DyConv.{k}.packed"], P[f"{b}.DyConv.{k}.conv.bias"])      # [B, Ho*Wo, C]
             coef = ops.dyconv_branch_coef(y, Wo, P[f"{b}.DyConv.{k}.bn.weight"], P[f"{b}.DyConv.{k}.bn.bias"],
-                                          P[b + ".attn_w"], P[b + ".attn_b"], G.NUM_GROUPS, G.EPSILON, len(spec), wy, wx)
+                                          P[b + ".attn_w"], P[b + ".attn_b"], G.NUM_GROUPS, G.EPSILON, len(spec), wy, wx, sums=sums)
             branches.append((y, coef, Ho, Wo))
         o = out[:, offs[lvl]:offs[lvl + 1]]
         _, pool = ops.dyconv_fuse(branches, H, W, out=o)

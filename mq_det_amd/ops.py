@@ -27,9 +27,10 @@ _SIGNATURES = {
     "mq_dcn_im2col_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _f, _l, _l, _vp]),
     "mq_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _vp]),
-    "mq_dcnv2_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _vp]),
+    "mq_dcnv2_stats_blocks": (_i, [_i, _i, _i]),
+    "mq_dcnv2_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _vp]),
     "mq_dyconv_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "mq_dyconv_coef": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "mq_dyconv_coef": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "mq_dyconv_fuse": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _l, _vp, _i, _i, _i, _i, _vp]),
     "mq_dyrelu_coef": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mq_dyrelu_apply": (_i, [_vp, _vp, _i, _i, _i, _l, _vp]),
@@ -334,33 +335,47 @@ def conv3x3(x_nhwc, w_packed, bias, n_out, stride=1):
     return out if ld == n_out else out[..., :n_out]
 
 
-def dcnv2(x_nhwc, om, w_packed, bias, stride):
-    """Fused DCNv2: x [B,H,W,C] fp16 NHWC, om [B,27,oH,oW] fp32, w_packed [256, 9*C] -> y [B, Ho*Wo, 256] fp16, (Ho, Wo)."""
+def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None):
+    """Fused DCNv2: x [B,H,W,C] fp16 NHWC, om [B,27,oH,oW] fp32, w_packed [256, 9*C] -> y [B, Ho*Wo, 256] fp16, (Ho, Wo)
+    (, sums [B, nblk, 256, 3] fp32 = per-patch GroupNorm / scale-attention statistics of y when want_stats; wy [Ho] /
+    wx [Wo] fp32 weight the third statistic, None -> 1/(Ho*Wo))."""
     lib = load_library()
-    _need_gpu(x_nhwc, om, w_packed, bias)
+    _need_gpu(x_nhwc, om, w_packed, bias, wy, wx)
     B, H, W, C = x_nhwc.shape
     assert x_nhwc.dtype == torch.float16 and x_nhwc.stride(3) == 1 and x_nhwc.stride(2) == C and x_nhwc.stride(1) == W * C
-    assert om.is_contiguous() and om.dtype == torch.float32 and om.shape[1] == 27 and w_packed.shape == (256, 9 * C)
+    assert om.is_contiguous() and om.dtype == torch.float32 and om.shape[1] == 27
+    assert w_packed.is_contiguous() and w_packed.shape == (256, 9 * C) and w_packed.dtype == torch.float16
     Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
     y = torch.empty(B, Ho * Wo, 256, dtype=torch.float16, device=x_nhwc.device)
+    sums = None
+    if want_stats:
+        sums = torch.empty(B, lib.mq_dcnv2_stats_blocks(H, W, stride), 256, 3, dtype=torch.float32, device=y.device)
+        if wy is not None:
+            assert wy.dtype == wx.dtype == torch.float32 and wy.numel() == Ho and wx.numel() == Wo
     with _timed("dcnv2_fused"):
-        _chk(lib.mq_dcnv2_fwd(_ptr(x_nhwc), _ptr(om), _ptr(w_packed), _ptr(bias), _ptr(y), B, H, W, C, x_nhwc.stride(0),
-                              om.shape[2], om.shape[3], 256, 256, stride, _stream()), "mq_dcnv2_fwd")
-    return y, (Ho, Wo)
+        _chk(lib.mq_dcnv2_fwd(_ptr(x_nhwc), _ptr(om), _ptr(w_packed), _ptr(bias), _ptr(y), _ptr(sums), _ptr(wy), _ptr(wx),
+                              B, H, W, C, x_nhwc.stride(0), om.shape[2], om.shape[3], 256, 256, stride, _stream()), "mq_dcnv2_fwd")
+    return (y, (Ho, Wo), sums) if want_stats else (y, (Ho, Wo))
 
 
-def dyconv_branch_coef(y, Wsrc, gamma, beta, attn_w, attn_b, groups, eps, nbranches, wy=None, wx=None):
-    """y [B,n,C] fp16 (DCN output of one branch) -> coef [B,C,2] fp32 (GN affine x scale attention / nbranches)."""
+def dyconv_branch_coef(y, Wsrc, gamma, beta, attn_w, attn_b, groups, eps, nbranches, wy=None, wx=None, sums=None):
+    """y [B,n,C] fp16 (DCN output of one branch) -> coef [B,C,2] fp32 (GN affine x scale attention / nbranches).
+    sums: statistics already produced by the fused DCNv2 kernel ([B, nblk, C, 3]); None -> one pass over y here."""
     lib = load_library()
     _need_gpu(y, gamma, beta, attn_w, attn_b, wy, wx)
     B, n, C = y.shape
     assert y.is_contiguous() and y.dtype == torch.float16 and gamma.dtype == torch.float16
     assert attn_w.dtype == torch.float32 and attn_b.dtype == torch.float32
-    sums = torch.empty(B, (n + 255) // 256, C, 3, dtype=torch.float32, device=y.device)
     coef = torch.empty(B, C, 2, dtype=torch.float32, device=y.device)
-    with _timed("dyconv_stats"):
-        _chk(lib.mq_dyconv_stats(_ptr(y), _ptr(sums), _ptr(wy), _ptr(wx), B, n, Wsrc, C, _stream()), "mq_dyconv_stats")
-    _chk(lib.mq_dyconv_coef(_ptr(sums), _ptr(gamma), _ptr(beta), _ptr(attn_w), _ptr(attn_b), _ptr(coef), B, n, C, groups,
+    nblk = 0
+    if sums is None:
+        sums = torch.empty(B, (n + 255) // 256, C, 3, dtype=torch.float32, device=y.device)
+        with _timed("dyconv_stats"):
+            _chk(lib.mq_dyconv_stats(_ptr(y), _ptr(sums), _ptr(wy), _ptr(wx), B, n, Wsrc, C, _stream()), "mq_dyconv_stats")
+    else:
+        assert sums.dtype == torch.float32 and sums.is_contiguous() and sums.shape[0] == B and sums.shape[2:] == (C, 3)
+        nblk = sums.shape[1]
+    _chk(lib.mq_dyconv_coef(_ptr(sums), _ptr(gamma), _ptr(beta), _ptr(attn_w), _ptr(attn_b), _ptr(coef), B, n, nblk, C, groups,
                             float(eps), nbranches, _stream()), "mq_dyconv_coef")
     return coef
 

@@ -174,8 +174,21 @@ def ml_nms(boxes, labels, nvalid, thresh):
     return keep
 
 
-def dyconv_branch_coef(y, Wsrc, gamma, beta, attn_w, attn_b, groups, eps, nbranches, wy=None, wx=None):
+def dyconv_branch_coef(y, Wsrc, gamma, beta, attn_w, attn_b, groups, eps, nbranches, wy=None, wx=None, sums=None):
     B, n, C = y.shape
+    if sums is not None:                             # fused-statistics path: coefficients from (sum, sum sq, weighted sum)
+        t = sums.sum(1)
+        gs = t[..., 0].reshape(B, groups, C // groups).sum(-1)
+        gss = t[..., 1].reshape(B, groups, C // groups).sum(-1)
+        cnt = n * (C // groups)
+        mean = gs / cnt
+        var = (gss / cnt - mean * mean).clamp(min=0)
+        rstd = (var + eps).rsqrt()
+        sc = rstd.repeat_interleave(C // groups, 1) * gamma.float()
+        sh = beta.float() - mean.repeat_interleave(C // groups, 1) * sc
+        pooled = sc * t[..., 2] + sh
+        a = F.relu6(F.relu(pooled @ attn_w + attn_b) + 3) / 6 / nbranches
+        return torch.stack([a[:, None] * sc, a[:, None] * sh], -1)
     yf = y.float()
     g = yf.reshape(B, n, groups, C // groups)
     mean = g.mean((1, 3))
@@ -228,9 +241,15 @@ def conv3x3(x_nhwc, w_packed, bias, n_out, stride=1):
     return y.permute(0, 2, 3, 1).to(x_nhwc.dtype)
 
 
-def dcnv2(x_nhwc, om, w_packed, bias, stride):
-    cols, hw = dcn_im2col(x_nhwc, om, stride)
-    return F.linear(cols.float(), w_packed.float(), bias.float()).to(x_nhwc.dtype), hw
+def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None):
+    cols, hw = dcn_im2col(x_nhwc.contiguous(), om, stride)
+    y = F.linear(cols.float(), w_packed.float(), bias.float()).to(x_nhwc.dtype)
+    if not want_stats:
+        return y, hw
+    yf = y.float()                                   # one "block" per image: [B, 1, C, 3] = (sum, sum sq, weighted sum)
+    w = torch.full((yf.shape[1],), 1.0 / yf.shape[1]) if wy is None else (wy[:, None] * wx[None, :]).reshape(-1)
+    sums = torch.stack([yf.sum(1), (yf * yf).sum(1), (yf * w[None, :, None]).sum(1)], -1)[:, None]
+    return y, hw, sums
 
 
 def layer_norm(x, gamma, beta, eps=1e-5, transposed_out=False, pad_to=8):

@@ -303,8 +303,16 @@ def check_dcn(dev):
         wp = w.permute(0, 2, 3, 1).reshape(256, -1).to(dev)
         y = F.linear(cols, wp, bias.to(dev)).reshape(2, Ho, Wo, 256).permute(0, 3, 1, 2)
         res.append(_stat(f"dcnv2 im2col+gemm {name}", y, ref, tol=4e-3))
-        y2, _ = ops.dcnv2(x.to(dev).permute(0, 2, 3, 1).contiguous(), om.to(dev).contiguous(), wp, bias.to(dev), stride)
+        wy = torch.rand(Ho, generator=g).to(dev)
+        wx = torch.rand(Wo, generator=g).to(dev)
+        y2, _, sums = ops.dcnv2(x.to(dev).permute(0, 2, 3, 1).contiguous(), om.to(dev).contiguous(), wp, bias.to(dev), stride,
+                                want_stats=True, wy=wy, wx=wx)
         res.append(_stat(f"dcnv2 fused implicit-GEMM {name}", y2.reshape(2, Ho, Wo, 256).permute(0, 3, 1, 2), ref, tol=4e-3))
+        # statistics emitted by the kernel's epilogue == the same sums over its own fp16 output
+        yf = y2.float()
+        wpos = (wy[:, None] * wx[None, :]).reshape(-1)
+        st_ref = torch.stack([yf.sum(1), (yf * yf).sum(1), (yf * wpos[None, :, None]).sum(1)], -1)
+        res.append(_stat(f"dcnv2 fused GroupNorm statistics {name}", sums.sum(1), st_ref, tol=1e-4))
     return res
 
 
