@@ -120,6 +120,12 @@ int mq_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y
  *   (rpn/vldyhead.py:186,214). */
 int mq_conv3x3_fwd(const void* x, const void* w, const void* bias, void* out, int B, int H, int W, int C, long x_bs,
                    int N, int out_ld, int stride, void* stream);
+/* 3x3 convolution (pad 1, stride 1) with N <= 32 output channels, fp32 NCHW output: the 27-channel offset / mask conv of
+ * every DyConv level.  x [B,H,W,C] fp16 NHWC (batch stride x_bs; C % 32 == 0, C <= 256), w [32, 9*C] fp16 (k = tap*C + c,
+ * rows >= N zero), bias [N] fp16 or NULL -> out [B,N,H,W] fp32.  The input window of an 8x16 output patch is staged once
+ * in LDS.  Replaces nn.Conv2d(256, 27, 3) + the fp32 offset/mask split of rpn/vldyhead.py:186,214-216. */
+int mq_conv3x3_nchw32_fwd(const void* x, const void* w, const void* bias, float* out, int B, int H, int W, int C, long x_bs,
+                          int N, void* stream);
 int mq_dcnv2_stats_blocks(int H, int W, int stride);
 int mq_dcnv2_fwd(const void* x, const float* om, const void* w, const void* bias, void* out, float* stats, const float* wy,
                  const float* wx, int B, int H, int W, int C, long x_bs, int oH, int oW, int N, int out_ld, int stride,

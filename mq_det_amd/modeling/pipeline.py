@@ -409,7 +409,7 @@ def dyconv_tokens(P, cfg, b, tok, sizes):
 
     def level(lvl):
         H, W = sizes[lvl]
-        om = ops.conv3x3(lv[lvl], P[b + ".offset.packed"], P[b + ".offset.bias"], 27).permute(0, 3, 1, 2).float().contiguous()
+        om = ops.conv3x3_nchw32(lv[lvl], P[b + ".offset.packed"], P[b + ".offset.bias"], 27)      # [B, 27, H, W] fp32
         spec = [(1, lv[lvl], 1)]
         if lvl > 0:
             spec.append((2, lv[lvl - 1], 2))

@@ -27,6 +27,7 @@ _SIGNATURES = {
     "mq_dcn_im2col_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _f, _l, _l, _vp]),
     "mq_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _vp]),
+    "mq_conv3x3_nchw32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _vp]),
     "mq_dcnv2_stats_blocks": (_i, [_i, _i, _i]),
     "mq_dcnv2_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _vp]),
     "mq_dyconv_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -333,6 +334,21 @@ def conv3x3(x_nhwc, w_packed, bias, n_out, stride=1):
         _chk(lib.mq_conv3x3_fwd(_ptr(x_nhwc), _ptr(w_packed), _ptr(bias), _ptr(out), B, H, W, C, x_nhwc.stride(0), n_out, ld,
                                 stride, _stream()), "mq_conv3x3_fwd")
     return out if ld == n_out else out[..., :n_out]
+
+
+def conv3x3_nchw32(x_nhwc, w_packed, bias, n_out):
+    """x [B,H,W,C] fp16 (NHWC rows contiguous, any batch stride), w_packed [32, 9*C] fp16, bias [n_out] fp16
+    -> [B, n_out, H, W] fp32 (stride 1, pad 1; n_out <= 32): the DyConv offset / mask conv."""
+    lib = load_library()
+    _need_gpu(x_nhwc, w_packed, bias)
+    B, H, W, C = x_nhwc.shape
+    assert x_nhwc.dtype == torch.float16 and x_nhwc.stride(3) == 1 and x_nhwc.stride(2) == C and x_nhwc.stride(1) == W * C
+    assert w_packed.is_contiguous() and w_packed.shape == (32, 9 * C) and w_packed.dtype == torch.float16 and n_out <= 32
+    out = torch.empty(B, n_out, H, W, dtype=torch.float32, device=x_nhwc.device)
+    with _timed("conv3x3_small"):
+        _chk(lib.mq_conv3x3_nchw32_fwd(_ptr(x_nhwc), _ptr(w_packed), _ptr(bias), _ptr(out), B, H, W, C, x_nhwc.stride(0), n_out,
+                                       _stream()), "mq_conv3x3_nchw32_fwd")
+    return out
 
 
 def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None):

@@ -241,6 +241,10 @@ def conv3x3(x_nhwc, w_packed, bias, n_out, stride=1):
     return y.permute(0, 2, 3, 1).to(x_nhwc.dtype)
 
 
+def conv3x3_nchw32(x_nhwc, w_packed, bias, n_out):
+    return conv3x3(x_nhwc, w_packed, bias, n_out).permute(0, 3, 1, 2).float().contiguous()
+
+
 def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None):
     cols, hw = dcn_im2col(x_nhwc.contiguous(), om, stride)
     y = F.linear(cols.float(), w_packed.float(), bias.float()).to(x_nhwc.dtype)

@@ -352,6 +352,13 @@ def check_conv3x3(dev):
         wp = torch.cat([wp, wp.new_zeros(rows - N, wp.shape[1])], 0).contiguous()
         y = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().to(dev), wp.to(dev), bias.to(dev), N, stride)
         res.append(_stat(f"conv3x3 igemm B={B} {H}x{W} N={N} s={stride}", y.permute(0, 3, 1, 2), ref, tol=3e-3))
+        if N <= 32 and stride == 1:       # LDS-window kernel of the offset conv: fp32 NCHW out; also from a strided level view
+            y2 = ops.conv3x3_nchw32(x.permute(0, 2, 3, 1).contiguous().to(dev), wp.to(dev), bias.to(dev), N)
+            res.append(_stat(f"conv3x3 LDS-window (fp32 NCHW) B={B} {H}x{W} N={N}", y2, ref, tol=2e-3))
+            big = torch.zeros(B, H * W + 37, 256, dtype=torch.float16, device=dev)
+            big[:, 5:5 + H * W] = x.permute(0, 2, 3, 1).reshape(B, H * W, 256).to(dev)
+            y3 = ops.conv3x3_nchw32(big[:, 5:5 + H * W].reshape(B, H, W, 256), wp.to(dev), bias.to(dev), N)
+            res.append(_stat(f"conv3x3 LDS-window, level view of a token buffer B={B} {H}x{W}", y3, ref, tol=2e-3))
     return res
 
 
