@@ -335,30 +335,47 @@ def _level_views(tok, sizes):
     return out
 
 
+def vl_text_prep(P, b, hidden, key_bias):
+    """Text-only operands of one VLFuse layer (fuse_helper.py:221-231 with the image-side projections folded in, DESIGN.md
+    section 4): LN(l), folded keys kf [B,8,T,256], folded values vo [B,8,T,256], per-(head, key) logit bias [B,8,T]."""
+    Bn = hidden.shape[0]
+    l_ln = _ln(P, b + ".layer_norm_l", hidden)
+    a = b + ".attn"
+    T = l_ln.shape[1]
+    k8 = _lin(P, a + ".l_proj", l_ln).reshape(Bn, T, 8, -1).permute(0, 2, 1, 3)         # [B, 8, T, 256 hd]
+    kf = torch.matmul(k8, P[b + ".Wq8"][None])                                           # [B, 8, T, 256 in] folded keys
+    bias = (torch.einsum("bhtd,hd->bht", k8.float(), P[b + ".bq8"]) + key_bias[:, None, :]).contiguous()   # [B, 8, T] fp32
+    val_l8 = _lin(P, a + ".values_l_proj", l_ln).reshape(Bn, T, 8, -1).permute(0, 2, 1, 3)        # [B, 8, T, 256 hd]
+    vo = torch.matmul(val_l8, P[b + ".Wov8"][None])                                      # [B, 8, T, 256 out] folded values
+    return {"l_ln": l_ln, "kf": kf, "vo": vo, "bias": bias}
+
+
+def vl_image_side(P, b, v_ln, prep, kv_len=None, max_kv=0):
+    """Image side of VLFuse: queries = LN(v) shared by the 8 heads; head sum, out-proj bias and the residual (on the
+    NORMED v, fuse_helper.py:424) fused into the kernel."""
+    return ops.vlfuse_i2t(v_ln, prep["kf"], prep["vo"], prep["bias"], P[b + ".ov.bias"], kv_len=kv_len, max_kv=max_kv)
+
+
+def vl_text_side(P, b, v_ln, prep, kv_len=None, max_kv=0):
+    """Text side of VLFuse: queries = folded text keys, keys = values = LN(v); values_v_proj, out_l_proj and gamma_l are
+    one folded [768, 2048] weight applied to the result; residual on the NORMED l (fuse_helper.py:425)."""
+    Bn, N, _ = v_ln.shape
+    T = prep["l_ln"].shape[1]
+    t_live = min(T, max_kv) if (kv_len is not None and max_kv > 0) else T             # 128-row tiles of pure padding are skipped
+    out_l = ops.vlfuse_t2i(prep["kf"], v_ln, _nsplit(-(-t_live // 128) * Bn * 8, -(-N // 64)), kv_len=kv_len)
+    return prep["l_ln"] + _lin(P, b + ".olc", out_l)
+
+
 def vl_fuse_tokens(P, b, v, hidden, key_bias, kv_len=None, max_kv=0):
     """BiAttentionBlockForCheckpoint / BiMultiHeadAttention (fuse_helper.py:218-303,377-426) on the pyramid token
     buffer v [B, N, 256] (all levels concatenated, the layout the whole head keeps): one set of logits, softmax over text
     for the image side and over image tokens for the text side -- one launch each of the two VLFuse kernels
     (vlfuse_attn.hip); the logits are never materialised (reference: 3 x [B*8, 22400, 256] fp32 tensors) and, with the
     projections folded into the text-side operands, neither are the [B, 22400, 2048] q / value tensors: both kernels
-    read LN(v) directly."""
-    Bn, N, _ = v.shape
+    read LN(v) directly.  (Serial composition; vldyhead runs the text pieces on a side stream.)"""
     v_ln = ops.layer_norm(v, P[b + ".layer_norm_v.weight"], P[b + ".layer_norm_v.bias"], 1e-5)
-    l_ln = _ln(P, b + ".layer_norm_l", hidden)
-    a = b + ".attn"
-    T = l_ln.shape[1]
-    k8 = _lin(P, a + ".l_proj", l_ln).reshape(Bn, T, 8, -1).permute(0, 2, 1, 3)         # [B, 8, T, 256 hd]
-    kf = torch.matmul(k8, P[b + ".Wq8"][None])                                           # [B, 8, T, 256 in] folded keys
-    bias = torch.einsum("bhtd,hd->bht", k8.float(), P[b + ".bq8"]) + key_bias[:, None, :]        # [B, 8, T] fp32
-    val_l8 = _lin(P, a + ".values_l_proj", l_ln).reshape(Bn, T, 8, -1).permute(0, 2, 1, 3)        # [B, 8, T, 256 hd]
-    vo = torch.matmul(val_l8, P[b + ".Wov8"][None])                                      # [B, 8, T, 256 out] folded values
-    # image side: queries = LN(v) shared by the 8 heads; head sum, out-proj bias and the residual (on the NORMED v) fused
-    v_new = ops.vlfuse_i2t(v_ln, kf, vo, bias.contiguous(), P[b + ".ov.bias"], kv_len=kv_len, max_kv=max_kv)
-    # text side: queries = folded text keys, keys = values = LN(v)
-    t_live = min(T, max_kv) if (kv_len is not None and max_kv > 0) else T             # 128-row tiles of pure padding are skipped
-    out_l = ops.vlfuse_t2i(kf, v_ln, _nsplit(-(-t_live // 128) * Bn * 8, -(-N // 64)), kv_len=kv_len)
-    l_new = l_ln + _lin(P, b + ".olc", out_l)
-    return v_new, l_new
+    prep = vl_text_prep(P, b, hidden, key_bias)
+    return vl_image_side(P, b, v_ln, prep, kv_len, max_kv), vl_text_side(P, b, v_ln, prep, kv_len, max_kv)
 
 
 def vl_fuse(P, b, feats, hidden, key_bias, kv_len=None, max_kv=0):
@@ -474,25 +491,48 @@ def _side_streams(device, n, tag="levels"):
 def vldyhead(P, cfg, feats, lang):
     """VLDyHead.forward (vldyhead.py:769-900), eval outputs.  The pyramid lives in ONE token buffer [B, N, 256] (levels
     concatenated) from the first fusion layer to the prediction heads: VLFuse reads / writes it whole, DyConv reads
-    per-level NHWC views of it and writes per-level slices -- no concatenation or split copies between layers."""
+    per-level NHWC views of it and writes per-level slices -- no concatenation or split copies between layers.
+
+    Two-stream schedule per fusion layer (text work never waits for image work it does not need, and vice versa):
+        main : LN(v) -> image-side attention -> DyConv (itself forked over the five levels)
+        text : text-side attention (needs LN(v)) -> folded out-projection -> BERT layer -> operands of the NEXT layer
+    The text chain (~0.8 ms of small or tail-heavy launches) hides under the image chain (~1.3 ms)."""
     p = "rpn.head"
     hidden, key_bias, kv_len = lang["hidden"], lang["key_bias"], lang.get("kv_len")
+    max_kv = lang.get("max_kv", 0)
     tok, sizes = _to_tokens(feats)
     tok = tok.contiguous()
-    for i in range(cfg.MODEL.DYHEAD.NUM_CONVS):
-        t = f"{p}.dyhead_tower"
-        tok, hidden = vl_fuse_tokens(P, f"{t}.{3 * i}.b_attn", tok, hidden, key_bias, kv_len, lang.get("max_kv", 0))
-        # the text-only BERT layer (a dozen small launches) and the image-only DyConv are independent: side stream
-        if hidden.is_cuda and cfg.MODEL.DYHEAD.get("LEVEL_STREAMS", True):
-            main, text = torch.cuda.current_stream(), _side_streams(hidden.device, 1, "text")[0]
-            text.wait_stream(main)
-            with torch.cuda.stream(text):
-                hidden = bert_layer(P, f"{t}.{3 * i + 1}", hidden, key_bias, clamp=True, kv_len=kv_len)
-            tok = dyconv_tokens(P, cfg, f"{t}.{3 * i + 2}", tok, sizes)
-            main.wait_stream(text)
-        else:
+    L = cfg.MODEL.DYHEAD.NUM_CONVS
+    t = f"{p}.dyhead_tower"
+    two_streams = bool(tok.is_cuda and cfg.MODEL.DYHEAD.get("LEVEL_STREAMS", True))
+    if not two_streams:
+        for i in range(L):
+            tok, hidden = vl_fuse_tokens(P, f"{t}.{3 * i}.b_attn", tok, hidden, key_bias, kv_len, max_kv)
             hidden = bert_layer(P, f"{t}.{3 * i + 1}", hidden, key_bias, clamp=True, kv_len=kv_len)
             tok = dyconv_tokens(P, cfg, f"{t}.{3 * i + 2}", tok, sizes)
+    else:
+        main, text = torch.cuda.current_stream(), _side_streams(tok.device, 1, "text")[0]
+        text.wait_stream(main)
+        with torch.cuda.stream(text):
+            prep = vl_text_prep(P, f"{t}.0.b_attn", hidden, key_bias)
+        keep = []                                             # main-stream tensors the text stream still reads
+        for i in range(L):
+            b = f"{t}.{3 * i}.b_attn"
+            v_ln = ops.layer_norm(tok, P[b + ".layer_norm_v.weight"], P[b + ".layer_norm_v.bias"], 1e-5)
+            main.wait_stream(text)                            # operands of this layer ready; previous text chain done
+            keep.clear()                                      # ... so last layer's LN(v) may be recycled now
+            keep.append(v_ln)
+            text.wait_stream(main)                            # LN(v) ready
+            cur = prep
+            with torch.cuda.stream(text):
+                hidden = vl_text_side(P, b, v_ln, cur, kv_len, max_kv)
+                hidden = bert_layer(P, f"{t}.{3 * i + 1}", hidden, key_bias, clamp=True, kv_len=kv_len)
+                if i + 1 < L:
+                    prep = vl_text_prep(P, f"{t}.{3 * (i + 1)}.b_attn", hidden, key_bias)
+            tok = vl_image_side(P, b, v_ln, cur, kv_len, max_kv)
+            tok = dyconv_tokens(P, cfg, f"{t}.{3 * i + 2}", tok, sizes)
+        main.wait_stream(text)
+        keep.clear()
     emb = F.normalize(hidden.float(), p=2, dim=-1)
     tk = F.linear(emb / 2.0, P[p + ".tok.weight"], P[p + ".tok.bias"]) * P[p + ".inv_scale"]       # [B, T, 256]
     tbias = (emb @ P[p + ".bias_lang32"] + P[p + ".bias0_32"]).contiguous()                           # [B, T]
