@@ -169,11 +169,18 @@ def main():
     kern, prof_steps = {}, 0
     if rank == 0:
         prof_steps = min(3, args.steps)
-        ops.start_timing()
-        for _ in range(prof_steps):
-            step_out = model(images, captions=captions, positive_map=pmap)
-        kern = ops.stop_timing()
-        del step_out
+        # single-stream for this pass: with the level / text streams active, concurrent kernels share the CUs and an
+        # event-bracketed duration would include its neighbours (the timed region above keeps the multi-stream schedule)
+        streams_on = cfg.MODEL.DYHEAD.LEVEL_STREAMS
+        cfg.MODEL.DYHEAD.LEVEL_STREAMS = False
+        try:
+            ops.start_timing()
+            for _ in range(prof_steps):
+                step_out = model(images, captions=captions, positive_map=pmap)
+            kern = ops.stop_timing()
+            del step_out
+        finally:
+            cfg.MODEL.DYHEAD.LEVEL_STREAMS = streams_on
 
     if rank == 0:
         ips = world * Bn * args.steps / dt

@@ -100,11 +100,12 @@ int mq_dcn_im2col_fwd(const void* x, const float* om, void* cols, int B, int H, 
                       int stride, void* stream);
 
 /* Row LayerNorm, fp16 in/out, fp32 statistics: y[r,:] = (x[r,:] - mean) * rstd * gamma + beta, C % 8 == 0, C <= 2048.
+ *   res != NULL: the row is fp16(x + res) (the fused residual add), also written to xsum when xsum != NULL;
  *   yt != NULL additionally writes the transpose yt[b, c, n] (r = b*rows_per_batch + n, row pitch yt_ld halfs).
  * Replaces every nn.LayerNorm call on the path (backbone/swint.py:198,240,281,425,611; HF BertLayer / embeddings;
  *   language_backbone/modeling_bert_new.py:121,150-153; utils/fuse_helper.py:420-421). */
-int mq_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, void* yt, long rows, int C, float eps,
-                     long rows_per_batch, long yt_ld, void* stream);
+int mq_layernorm_fwd(const void* x, const void* res, const void* gamma, const void* beta, void* y, void* xsum, void* yt,
+                     long rows, int C, float eps, long rows_per_batch, long yt_ld, void* stream);
 
 /* 3x3 convolution (pad 1, stride 1|2) and DCNv2 (modulated deformable 3x3) as one implicit-GEMM MFMA kernel,
  * NHWC fp16, fp32 accumulation over the whole K = 9*C in a fixed order (bitwise reproducible).
@@ -157,11 +158,12 @@ int mq_dyrelu_coef(const float* pool, const void* w0, const void* b0, const void
 int mq_dyrelu_apply(void* x, const float* coef, int B, int n, int C, long x_bs, void* stream);
 
 /* Region-word alignment scores for the L labels of the caption.
- *   dot [B,HW,T] fp16, tbias [B,T] fp32, tokidx [L,MT] int32, ctr [B,HW] fp16 -> out [B,HW,L] fp32
+ *   dot [B,HW,T] fp16 (batch stride dot_bs elements, <= 0: HW*T), tbias [B,T] fp32, tokidx [L,MT] int32,
+ *   ctr [B,HW] fp16 -> out [B,HW,L] fp32
  *   ((cls > thr) ? cls*sigmoid(ctr) : -1), cls_out [B,HW,L] fp32 optional.
  * Replaces vldyhead.py:884-887 (bias, clamp) + rpn/inference.py:656-683,772-824. */
 int mq_align_scores_fwd(const void* dot, const float* tbias, const int* tokidx, const void* ctr, float* out,
-                        float* cls_out, int B, int HW, int T, int L, int MT, float thr, void* stream);
+                        float* cls_out, int B, int HW, int T, int L, int MT, float thr, long dot_bs, void* stream);
 
 /* Decode + clip the top-K candidates of one level into the per-image candidate arrays (at column out_off).
  *   val/flat [B,K] (score, flat index loc*L + l), reg [B,HW,4] fp16, anchors [HW,4] fp32, label_ids [L] int32,

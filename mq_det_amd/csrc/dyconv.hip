@@ -233,20 +233,45 @@ __global__ __launch_bounds__(256) void dyrelu_coef_kernel(const float* __restric
                                                           int C) {
   __shared__ float yv[256], hv[64];
   const int b = blockIdx.x, t = threadIdx.x;
-  const int S = C / 4;
+  const int S = C / 4;                                   // C == 256, S == 64 (checked by the host wrapper)
+  // spatial mean: fixed-order sum of the per-block partials, 8 independent loads in flight
   float acc0 = 0.f;
-  for (int k = 0; k < nblk; ++k) acc0 += pool[((long)b * nblk + k) * C + t];
+  const float* pb = pool + (long)b * nblk * C + t;
+  int k = 0;
+  for (; k + 8 <= nblk; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = pb[(long)(k + u) * C];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc0 += v[u];
+  }
+  for (; k < nblk; ++k) acc0 += pb[(long)k * C];
   yv[t] = acc0 / (float)n;
   __syncthreads();
-  if (t < S) {
-    float acc = (float)b0[t];
-    for (int c = 0; c < C; ++c) acc += (float)w0[t * C + c] * yv[c];
-    hv[t] = fmaxf(acc, 0.f);
+  {  // fc.0 (C -> S) + ReLU: 4 lanes per output, 16-byte weight loads, fixed-order combine
+    const int o = t >> 2, q = t & 3;
+    const half_t* wr = w0 + (long)o * C + q * (C / 4);
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                          // C / 4 = 64 weights = 8 x half8
+      const half8 w = *(const half8*)(wr + i * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a += (float)w[j] * yv[q * (C / 4) + i * 8 + j];
+    }
+    a += __shfl_xor(a, 1);
+    a += __shfl_xor(a, 2);
+    if (q == 0) hv[o] = fmaxf(a + (float)b0[o], 0.f);
   }
   __syncthreads();
-  for (int o = t; o < 4 * C; o += 256) {
+  for (int o = t; o < 4 * C; o += 256) {                   // fc.2 (S -> 4C) + h_sigmoid, 16-byte weight loads
     float acc = (float)b2[o];
-    for (int k = 0; k < S; ++k) acc += (float)w2[o * S + k] * hv[k];
+    const half_t* wr = w2 + (long)o * S;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const half8 w = *(const half8*)(wr + i * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += (float)w[j] * hv[i * 8 + j];
+    }
     float hs = fminf(fmaxf(acc + 3.f, 0.f), 6.f) / 6.f;
     int which = o / C, c = o % C;
     float v = which == 0 ? (hs - 0.5f) * 2.f + 1.f : (which == 2 ? (hs - 0.5f) * 2.f : hs - 0.5f);

@@ -7,12 +7,15 @@
 // LPR = 16 / 32 / 64 lanes (C/8 sixteen-byte chunks, several rows per wave for small C) so every access is a
 // coalesced 16-byte vector, ~HBM speed.  With `yt` != NULL (VLFuse: the text->image attention needs LN(v)^T as its
 // V^T operand) the normalised tile is also transposed through LDS and written as yt[b, c, n] -- this replaces a
-// separate 92 MB transpose copy per fusion layer.
+// separate 92 MB transpose copy per fusion layer.  With `res` != NULL the row is x + res (rounded to fp16 first, exactly
+// what a separate elementwise add would hand to LayerNorm), optionally written out as `xsum`: the residual adds of the
+// Swin blocks (swint.py:236,240) and of the BERT output blocks (LayerNorm(dense(h) + input)) cost no extra pass.
 #include "common.h"
 
 template <int LPR>
-__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, const half_t* __restrict__ gamma,
-                                                        const half_t* __restrict__ beta, half_t* __restrict__ y,
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, const half_t* __restrict__ res,
+                                                        const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
+                                                        half_t* __restrict__ y, half_t* __restrict__ xsum,
                                                         half_t* __restrict__ yt, long rows, int C, float eps,
                                                         long rows_per_batch, long yt_ld, int RPB) {
   constexpr int ROWS_PER_PASS = 256 / LPR;          // RPB = rows per block: 64 (big inputs / transposed output) or one pass
@@ -30,7 +33,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
     for (int k = 0; k < MAXC; ++k) {
       const int ch = sub + k * LPR;
       v[k] = zero8();
-      if (ok && ch < nch) v[k] = *(const half8*)(x + row * C + ch * 8);
+      if (ok && ch < nch) {
+        v[k] = *(const half8*)(x + row * C + ch * 8);
+        if (res) {
+          const half8 r = *(const half8*)(res + row * C + ch * 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[k][j] = (half_t)((float)v[k][j] + (float)r[j]);
+          if (xsum) *(half8*)(xsum + row * C + ch * 8) = v[k];
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += (float)v[k][j];
     }
@@ -86,8 +97,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
   }
 }
 
-extern "C" int mq_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, void* yt, long rows, int C,
-                                float eps, long rows_per_batch, long yt_ld, void* stream) {
+extern "C" int mq_layernorm_fwd(const void* x, const void* res, const void* gamma, const void* beta, void* y, void* xsum,
+                                void* yt, long rows, int C, float eps, long rows_per_batch, long yt_ld, void* stream) {
   if (rows <= 0) return 0;
   if (C % 8 || C > 2048) return -1;
   const int nch = C / 8;
@@ -99,7 +110,8 @@ extern "C" int mq_layernorm_fwd(const void* x, const void* gamma, const void* be
   if (yt && rows_per_batch <= 0) return -2;
 #define MQ_LN(L)                                                                                                          \
   hipLaunchKernelGGL((layernorm_kernel<L>), dim3(grid), dim3(256), smem, (hipStream_t)stream, (const half_t*)x,          \
-                     (const half_t*)gamma, (const half_t*)beta, (half_t*)y, (half_t*)yt, rows, C, eps, rows_per_batch, yt_ld, rpb)
+                     (const half_t*)res, (const half_t*)gamma, (const half_t*)beta, (half_t*)y, (half_t*)xsum, (half_t*)yt, rows, C, \
+                     eps, rows_per_batch, yt_ld, rpb)
   if (nch <= 16) { MQ_LN(16); }
   else if (nch <= 32) { MQ_LN(32); }
   else { MQ_LN(64); }

@@ -4,7 +4,8 @@
 //   rpn/inference.py:656-683: sigmoid, token -> class MEAN (convert_grounding_to_od_logits[_v2]),
 //   threshold 0.05, x sigmoid(centerness).  The reference builds a dense [B, HW, 3000] (LVIS) score
 //   tensor of which <= 40 columns are non-zero; here only the L labels of the caption are produced.
-//     dot    : [B, HW, T] fp16 = feat . (proj_tokens / exp(log_scale))^T       (library GEMM outside)
+//     dot    : [B, HW, T] fp16 = feat . (proj_tokens / exp(log_scale))^T       (library GEMM outside; batch stride
+//              dot_bs elements: a level's slice of the all-level [B, N, T] product)
 //     tbias  : [B, T] fp32     = emb . bias_lang + bias0
 //     tokidx : [L, MT] int32   token positions of each label (-1 padded)
 //     ctr    : [B, HW] fp16/fp32 centerness logits
@@ -23,17 +24,31 @@
 __global__ __launch_bounds__(256) void align_scores_kernel(const half_t* __restrict__ dot, const float* __restrict__ tbias,
                                                            const int* __restrict__ tokidx, const half_t* __restrict__ ctr,
                                                            float* __restrict__ out, float* __restrict__ cls_out,
-                                                           int B, int HW, int T, int L, int MT, float thr) {
+                                                           int B, int HW, int T, int L, int MT, float thr, long dot_bs) {
   extern __shared__ float sig[];                 // [4][T]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long loc = (long)blockIdx.x * 4 + wave;
   if (loc >= (long)B * HW) return;
   const int b = loc / HW;
+  const half_t* drow = dot + (long)b * dot_bs + (loc - (long)b * HW) * T;
   float* sw = sig + wave * T;
-  for (int t = lane; t < T; t += 64) {
-    float v = (float)dot[loc * T + t] + tbias[b * T + t];
-    v = fminf(fmaxf(v, -50000.f), 50000.f);
-    sw[t] = 1.f / (1.f + __expf(-v));
+  if ((T & 3) == 0 && (dot_bs & 3) == 0) {       // 8-byte loads: one per lane for T = 256
+    for (int t = lane * 4; t < T; t += 256) {
+      const half4 d = *(const half4*)(drow + t);
+      const float4_ tb = *(const float4_*)(tbias + (long)b * T + t);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = (float)d[j] + tb[j];
+        v = fminf(fmaxf(v, -50000.f), 50000.f);
+        sw[t + j] = 1.f / (1.f + __expf(-v));
+      }
+    }
+  } else {
+    for (int t = lane; t < T; t += 64) {
+      float v = (float)drow[t] + tbias[(long)b * T + t];
+      v = fminf(fmaxf(v, -50000.f), 50000.f);
+      sw[t] = 1.f / (1.f + __expf(-v));
+    }
   }
   wave_lds_fence();
   const float c = 1.f / (1.f + __expf(-(float)ctr[loc]));
@@ -51,12 +66,12 @@ __global__ __launch_bounds__(256) void align_scores_kernel(const half_t* __restr
 }
 
 extern "C" int mq_align_scores_fwd(const void* dot, const float* tbias, const int* tokidx, const void* ctr, float* out,
-                                   float* cls_out, int B, int HW, int T, int L, int MT, float thr, void* stream) {
+                                   float* cls_out, int B, int HW, int T, int L, int MT, float thr, long dot_bs, void* stream) {
   if (B <= 0 || HW <= 0 || L <= 0) return 0;
   long locs = (long)B * HW;
   hipLaunchKernelGGL(align_scores_kernel, dim3((unsigned)((locs + 3) / 4)), dim3(256), 4 * T * sizeof(float),
                      (hipStream_t)stream, (const half_t*)dot, tbias, tokidx, (const half_t*)ctr, out, cls_out, B, HW, T, L,
-                     MT, thr);
+                     MT, thr, dot_bs > 0 ? dot_bs : (long)HW * T);
   MQ_CHECK_LAUNCH();
   return 0;
 }

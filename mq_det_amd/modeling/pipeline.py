@@ -131,6 +131,11 @@ def _ln(P, name, x, eps=1e-5):
     return ops.layer_norm(x.contiguous(), P[name + ".weight"], P[name + ".bias"], eps)
 
 
+def _add_ln(P, name, x, res, eps=1e-5, want_sum=True):
+    """LayerNorm(x + res) with the residual add fused into the kernel -> (y, x + res) or y."""
+    return ops.layer_norm(x.contiguous(), P[name + ".weight"], P[name + ".bias"], eps, residual=res.contiguous(), want_sum=want_sum)
+
+
 def _lin(P, name, x):
     return F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
 
@@ -160,15 +165,23 @@ def swin_forward(P, cfg, img):
     outs = []
     for i, (depth, heads) in enumerate(zip(M.DEPTHS, M.NUM_HEADS)):
         C = x.shape[-1]
+        pend = None                                    # MLP output whose residual add is fused into the next LayerNorm
         for j in range(depth):
             b = f"{p}.layers.{i}.blocks.{j}"
             shift = 0 if j % 2 == 0 else ws // 2
-            qkv = _lin(P, b + ".attn.qkv", _ln(P, b + ".norm1", x)).reshape(B, H, W, 3 * C)
+            if pend is None:
+                h1 = _ln(P, b + ".norm1", x)
+            else:
+                h1, x = _add_ln(P, b + ".norm1", x, pend)                                   # x = x + mlp(...)  (swint.py:240)
+            qkv = _lin(P, b + ".attn.qkv", h1).reshape(B, H, W, 3 * C)
             a = ops.window_attention(qkv, P[b + ".attn.qkv.bias"], P[b + ".attn.rel_bias"], heads, ws, shift)
-            x = x + _lin(P, b + ".attn.proj", a.reshape(B, H * W, C))
-            x = x + _lin(P, b + ".mlp.fc2", F.gelu(_lin(P, b + ".mlp.fc1", _ln(P, b + ".norm2", x))))
+            h2, x = _add_ln(P, b + ".norm2", x, _lin(P, b + ".attn.proj", a.reshape(B, H * W, C)))   # x = x + attn(...)  (:236)
+            pend = _lin(P, b + ".mlp.fc2", F.gelu(_lin(P, b + ".mlp.fc1", h2)))
         if i > 0:
-            outs.append(_ln(P, f"{p}.norm{i}", x).reshape(B, H, W, C))
+            o, x = _add_ln(P, f"{p}.norm{i}", x, pend)
+            outs.append(o.reshape(B, H, W, C))
+        else:
+            x = x + pend
         if i < len(M.DEPTHS) - 1:                      # PatchMerging, swint.py:258-284
             d = f"{p}.layers.{i}.downsample"
             y = x.reshape(B, H, W, C)
@@ -217,14 +230,14 @@ def bert_layer(P, b, x, key_bias, clamp, kv_len=None):
                        .expand(Bn, -1, -1), x.transpose(1, 2))                          # V^T [B, C, T]
     ctx = ops.attention(qk[:, :, :C], qk[:, :, C:], vt, 12, C // 12, key_bias=key_bias, clamp=50000.0 if clamp else 0.0,
                         kv_len=kv_len)
-    a = _ln(P, b + ".attention.output.LayerNorm", _lin(P, b + ".attention.output.dense", ctx) + x, 1e-12)
+    a = _add_ln(P, b + ".attention.output.LayerNorm", _lin(P, b + ".attention.output.dense", ctx), x, 1e-12, want_sum=False)
     hmid = _lin(P, b + ".intermediate.dense", a)
     if clamp:
         hmid = F.gelu(hmid.clamp(-50000, 50000)).clamp(-50000, 50000)
         o = _lin(P, b + ".output.dense", hmid).clamp(-50000, 50000)
-        return _ln(P, b + ".output.LayerNorm", o + a, 1e-12).clamp(-50000, 50000)
+        return _add_ln(P, b + ".output.LayerNorm", o, a, 1e-12, want_sum=False).clamp(-50000, 50000)
     o = _lin(P, b + ".output.dense", F.gelu(hmid))
-    return _ln(P, b + ".output.LayerNorm", o + a, 1e-12)
+    return _add_ln(P, b + ".output.LayerNorm", o, a, 1e-12, want_sum=False)
 
 
 def pre_select(P, p, vision, image, scale):
@@ -579,19 +592,37 @@ def postprocess(cfg, head, anchors, im_wh, tokidx, label_ids, want_cls=False):
     boxes = torch.empty(Bn, tot, 4, dtype=torch.float32, device=dev)
     scores = torch.empty(Bn, tot, dtype=torch.float32, device=dev)
     labels = torch.empty(Bn, tot, dtype=torch.int32, device=dev)
-    cls_all = []
-    off = 0
-    for l, (dot, reg, ctr, anc, k) in enumerate(zip(head["dot"], head["bbox_reg"], head["centerness"], anchors, ks)):
+    cls_all = [None] * len(ks)
+    offs = [0]
+    for k in ks:
+        offs.append(offs[-1] + k)
+
+    def level(l):
+        dot, reg, ctr, anc, k = head["dot"][l], head["bbox_reg"][l], head["centerness"][l], anchors[l], ks[l]
         HW = dot.shape[1]
         ctr_flat = ctr.permute(0, 2, 3, 1).reshape(Bn, HW).contiguous()
-        r = ops.align_scores(dot.contiguous(), head["tbias"], tokidx, ctr_flat, A.INFERENCE_TH, want_cls=want_cls)
+        r = ops.align_scores(dot, head["tbias"], tokidx, ctr_flat, A.INFERENCE_TH, want_cls=want_cls)
         if want_cls:
-            r, cls = r
-            cls_all.append(cls)
+            r, cls_all[l] = r
         val, flat = torch.topk(r.reshape(Bn, HW * L), k, dim=1, sorted=False)
         reg_nhwc = reg.permute(0, 2, 3, 1).reshape(Bn, HW, 4).contiguous()
-        ops.box_decode(val.contiguous(), flat.contiguous(), reg_nhwc, anc, label_ids, im_wh, boxes, scores, labels, HW, L, off)
-        off += k
+        ops.box_decode(val.contiguous(), flat.contiguous(), reg_nhwc, anc, label_ids, im_wh, boxes, scores, labels, HW, L, offs[l])
+
+    # the five levels are independent until the sort: one HIP stream each (the small levels are pure launch latency)
+    if boxes.is_cuda and cfg.MODEL.DYHEAD.get("LEVEL_STREAMS", True) and len(ks) > 1:
+        main = torch.cuda.current_stream()
+        side = _side_streams(dev, len(ks) - 1)
+        for s_ in side:
+            s_.wait_stream(main)
+        for l in range(1, len(ks)):
+            with torch.cuda.stream(side[l - 1]):
+                level(l)
+        level(0)
+        for s_ in side:
+            main.wait_stream(s_)
+    else:
+        for l in range(len(ks)):
+            level(l)
     order = torch.argsort(scores, dim=1, descending=True, stable=True)
     scores = torch.gather(scores, 1, order)
     labels = torch.gather(labels, 1, order.to(torch.int64)).contiguous()

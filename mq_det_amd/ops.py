@@ -25,7 +25,7 @@ _SIGNATURES = {
     "mq_vlfuse_t2i_workspace_bytes": (_l, [_i, _i, _i]),
     "mq_vlfuse_t2i_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mq_dcn_im2col_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "mq_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _f, _l, _l, _vp]),
+    "mq_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _l, _l, _vp]),
     "mq_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _vp]),
     "mq_conv3x3_nchw32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _vp]),
     "mq_dcnv2_stats_blocks": (_i, [_i, _i, _i]),
@@ -297,15 +297,20 @@ def dcn_im2col(x_nhwc, om, stride):
     return cols, (Ho, Wo)
 
 
-def layer_norm(x, gamma, beta, eps=1e-5, transposed_out=False, pad_to=8):
+def layer_norm(x, gamma, beta, eps=1e-5, transposed_out=False, pad_to=8, residual=None, want_sum=True):
     """LayerNorm over the last dim of a contiguous fp16 tensor.  transposed_out: x is [B, N, C]; also returns
-    LN(x)^T as [B, C, N_pad] (N_pad = N rounded up to `pad_to`, tail zero-filled)."""
+    LN(x)^T as [B, C, N_pad] (N_pad = N rounded up to `pad_to`, tail zero-filled).
+    residual: same shape as x -> normalises fp16(x + residual) and returns (y, x + residual) (only y if not want_sum)."""
     lib = load_library()
-    _need_gpu(x, gamma, beta)
+    _need_gpu(x, gamma, beta, residual)
     C = x.shape[-1]
     assert x.is_contiguous() and x.dtype == torch.float16 and gamma.dtype == torch.float16 and beta.dtype == torch.float16
     rows = x.numel() // C
     y = torch.empty_like(x)
+    xsum = None
+    if residual is not None:
+        assert residual.shape == x.shape and residual.is_contiguous() and residual.dtype == torch.float16 and not transposed_out
+        xsum = torch.empty_like(x) if want_sum else None
     yt, rpb, ld = None, 0, 0
     if transposed_out:
         B, N = x.shape[0], x.shape[1]
@@ -314,8 +319,10 @@ def layer_norm(x, gamma, beta, eps=1e-5, transposed_out=False, pad_to=8):
             torch.empty(B, C, ld, dtype=torch.float16, device=x.device)
         rpb = N
     with _timed(f"layernorm_c{C}"):
-        _chk(lib.mq_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(yt), rows, C, float(eps), rpb, ld, _stream()),
-             "mq_layernorm_fwd")
+        _chk(lib.mq_layernorm_fwd(_ptr(x), _ptr(residual), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(xsum), _ptr(yt), rows, C,
+                                  float(eps), rpb, ld, _stream()), "mq_layernorm_fwd")
+    if residual is not None:
+        return (y, xsum) if want_sum else y
     return (y, yt) if transposed_out else y
 
 
@@ -436,17 +443,19 @@ def dyrelu_(x, pool, w0, b0, w2, b2):
 
 
 def align_scores(dot, tbias, tokidx, ctr, thr, want_cls=False):
-    """dot [B,HW,T] fp16, tbias [B,T] fp32, tokidx [L,MT] int32, ctr [B,HW] fp16 -> ranked [B,HW,L] fp32 (, cls)."""
+    """dot [B,HW,T] fp16 (contiguous rows, any batch stride), tbias [B,T] fp32, tokidx [L,MT] int32, ctr [B,HW] fp16
+    -> ranked [B,HW,L] fp32 (, cls)."""
     lib = load_library()
     _need_gpu(dot, tbias, tokidx, ctr)
     B, HW, T = dot.shape
     L, MT = tokidx.shape
-    assert dot.is_contiguous() and dot.dtype == torch.float16 and ctr.dtype == torch.float16 and ctr.is_contiguous()
+    assert dot.stride(2) == 1 and dot.stride(1) == T and dot.dtype == torch.float16
+    assert ctr.dtype == torch.float16 and ctr.is_contiguous()
     assert tbias.dtype == torch.float32 and tbias.is_contiguous() and tokidx.dtype == torch.int32 and tokidx.is_contiguous()
     out = torch.empty(B, HW, L, dtype=torch.float32, device=dot.device)
     cls = torch.empty_like(out) if want_cls else None
     _chk(lib.mq_align_scores_fwd(_ptr(dot), _ptr(tbias), _ptr(tokidx), _ptr(ctr), _ptr(out), _ptr(cls), B, HW, T, L, MT,
-                                 float(thr), _stream()), "mq_align_scores_fwd")
+                                 float(thr), dot.stride(0), _stream()), "mq_align_scores_fwd")
     return (out, cls) if want_cls else out
 
 

@@ -256,8 +256,12 @@ def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None
     return y, hw, sums
 
 
-def layer_norm(x, gamma, beta, eps=1e-5, transposed_out=False, pad_to=8):
+def layer_norm(x, gamma, beta, eps=1e-5, transposed_out=False, pad_to=8, residual=None, want_sum=True):
+    if residual is not None:
+        x = (x.float() + residual.float()).to(x.dtype)
     y = F.layer_norm(x.float(), (x.shape[-1],), gamma.float(), beta.float(), eps).to(x.dtype)
+    if residual is not None:
+        return (y, x) if want_sum else y
     if not transposed_out:
         return y
     N = x.shape[1]

@@ -325,6 +325,11 @@ def check_layernorm(dev):
         w, b = (torch.randn(C, generator=g) * 0.1 + 1).half(), (torch.randn(C, generator=g) * 0.1).half()
         ref = F.layer_norm(x.float(), (C,), w.float(), b.float(), eps)
         res.append(_stat(f"layernorm rows={rows} C={C}", ops.layer_norm(x.to(dev), w.to(dev), b.to(dev), eps), ref))
+        r = torch.randn(rows, C, generator=g).half()                 # fused residual add: LN(fp16(x + r)), sum returned
+        xs = (x.float() + r.float()).half()
+        y, s_out = ops.layer_norm(x.to(dev), w.to(dev), b.to(dev), eps, residual=r.to(dev))
+        res.append(_stat(f"add+layernorm rows={rows} C={C}: y", y, F.layer_norm(xs.float(), (C,), w.float(), b.float(), eps)))
+        res.append(_stat(f"add+layernorm rows={rows} C={C}: sum (bit-exact)", s_out, xs.float(), tol=0.0))
     for B, N in ((2, 128), (2, 333), (1, 22400)):
         x = torch.randn(B, N, 256, generator=g).half()
         w, b = (torch.randn(256, generator=g) * 0.1 + 1).half(), (torch.randn(256, generator=g) * 0.1).half()
