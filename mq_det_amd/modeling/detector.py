@@ -156,7 +156,9 @@ class GeneralizedVLRCNN_New(nn.Module):
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
             try:
-                with torch.cuda.graph(g):
+                # thread_local: with torch.distributed initialised, the RCCL watchdog thread polls events concurrently;
+                # under the default "global" mode that would invalidate the capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     static_out = self._device_forward(*static_in)
             except Exception as e:                              # keep running eagerly, but say so loudly
                 import warnings

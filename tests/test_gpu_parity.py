@@ -99,9 +99,9 @@ def test_boundary_returns_boxlists(dev):
 
 
 def _same_detections(a, b, frac=0.85):
-    """Order-insensitive IoU matching.  NOTE: the eager path itself is not bitwise reproducible from run to run --
-    tests/determinism_diag.py pins that on MIOpen's fp16 conv solvers used for the FPN / offset convs (every
-    hand-written HIP kernel here IS bitwise reproducible) -- so near-threshold detections may come and go."""
+    """Order-insensitive IoU matching (library GEMMs may pick different kernels for eager warm-up and capture, so
+    near-threshold detections are allowed to come and go; every hand-written HIP kernel is bitwise reproducible,
+    tests/determinism_diag.py)."""
     if len(b) == 0:
         return len(a) == 0
     ab, asc, al = a.bbox.cpu(), a.get_field("scores").cpu(), a.get_field("labels").cpu()
@@ -133,7 +133,7 @@ def test_hip_graph_replay_matches_eager(dev):
     for out in outs:
         for a, b in zip(out, ref):
             assert _same_detections(a, b)
-    for a, b in zip(outs[2], outs[3]):                   # two replays of one graph (MIOpen convs jitter in the last bits)
+    for a, b in zip(outs[2], outs[3]):                   # two replays of one graph
         assert _same_detections(a, b, frac=0.9)
     # new pixels through the same graph
     il2 = ImageList(torch.flip(images, dims=[3]).to(dev), sizes)
@@ -143,3 +143,41 @@ def test_hip_graph_replay_matches_eager(dev):
     out2 = model(il2, **kw)
     for a, b in zip(out2, ref2):
         assert _same_detections(a, b)
+
+
+def test_hip_graph_capture_with_process_group(dev):
+    """bench.py --gpus N initialises torch.distributed before the first forward: the HIP-graph capture must survive the
+    RCCL watchdog thread (capture_error_mode="thread_local"); world size 1 here, one GPU."""
+    import os
+    import socket
+    import torch.distributed as dist
+    import parity_checks as pc
+    from mq_det_amd import parallel
+    from mq_det_amd.structures import ImageList
+    created = False
+    if not dist.is_initialized():
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        spec, sd, cfg, model, P = pc.tiny(dev)
+        images, sizes, ids, am, pm, bank = pc.make_inputs(spec)
+        model.load_query_bank(bank)
+        il = ImageList(images.to(dev), sizes)
+        kw = dict(captions=None, positive_map=pm, input_ids=ids.to(dev), attention_mask=am.to(dev))
+        model.use_hip_graph = True
+        model._graphs = {}
+        t = torch.ones(4, device=dev)
+        dist.all_reduce(t)                                   # make sure the communicator (and its watchdog) is alive
+        outs = [model(il, **kw) for _ in range(3)]
+        assert any(e.get("stage") == 2 for e in model._graphs.values()), "HIP graph was not captured under a process group"
+        g = parallel.gather_detections(model.last_packed)
+        assert g.shape == model.last_packed.shape
+        for a, b in zip(outs[1], outs[2]):
+            assert _same_detections(a, b, frac=0.9)
+    finally:
+        if created:
+            dist.destroy_process_group()
