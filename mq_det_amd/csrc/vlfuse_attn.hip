@@ -22,6 +22,7 @@
 //     tiles with row pitch 272 halfs (conflict-free for both the b128 and the tr_b16 reads), one barrier per tile.
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(8)));
 typedef __attribute__((address_space(3))) fp16x4_t* lds_fp16x4_ptr;
@@ -57,52 +58,58 @@ struct I2TParams {
   float clamp;
 };
 
-// One tile = 64 rows x 256 halfs (32 KB): 8 x 16-byte chunks per thread.
-struct TileRegs { half8 r[8]; };
+// One tile = 64 rows x 256 halfs (32 KB): 2048 16-byte chunks, 8 per thread with 256 threads, 4 with 512.
+// QB = 16-query blocks per wave: 2 -> 4 waves x 32 rows (one wave per SIMD), 1 -> 8 waves x 16 rows (two per SIMD: a second
+// wave hides the LDS latency and the softmax VALU work of the first; each wave then re-reads the K / V fragments for
+// half as many MFMAs, which the LDS still sustains).
+template <int NTH> struct TileRegs { half8 r[2048 / NTH]; };
 
-__device__ __forceinline__ void tile_issue(TileRegs& t, const half_t* src, int row0, int last_row, int tid) {
+template <int NTH>
+__device__ __forceinline__ void tile_issue(TileRegs<NTH>& t, const half_t* src, int row0, int last_row, int tid) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = tid + i * 256;
+  for (int i = 0; i < 2048 / NTH; ++i) {
+    const int c = tid + i * NTH;
     const int row = min(row0 + (c >> 5), last_row);
     t.r[i] = *(const half8*)(src + (long)row * VD + (c & 31) * 8);
   }
 }
-__device__ __forceinline__ void tile_commit(const TileRegs& t, half_t* dst, int tid) {
+template <int NTH>
+__device__ __forceinline__ void tile_commit(const TileRegs<NTH>& t, half_t* dst, int tid) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = tid + i * 256;
+  for (int i = 0; i < 2048 / NTH; ++i) {
+    const int c = tid + i * NTH;
     *(half8*)(dst + (c >> 5) * KS + (c & 31) * 8) = t.r[i];
   }
 }
 
 // S^T[nb][qb] = K_tile . Q^T : A = K rows (keys) from LDS, B = Q fragments from registers (QLDS: from the LDS copy)
-template <bool QLDS>
-__device__ __forceinline__ void qk_tile(const half_t* tile, const half8 (&qf)[2][8], const half_t* qw, float4_ (&s)[4][2],
+template <bool QLDS, int QB>
+__device__ __forceinline__ void qk_tile(const half_t* tile, const half8 (&qf)[QB][8], const half_t* qw, float4_ (&s)[4][QB],
                                         int l15, int lg) {
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) s[nb][qb] = (float4_){0.f, 0.f, 0.f, 0.f};
+    for (int qb = 0; qb < QB; ++qb) s[nb][qb] = (float4_){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int kk = 0; kk < VD / 32; ++kk) {
-    half8 kf[4], qq[2];
+    half8 kf[4], qq[QB];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) kf[nb] = *(const half8*)(tile + (nb * 16 + l15) * KS + kk * 32 + lg * 8);
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < QB; ++qb) {
       if constexpr (QLDS) qq[qb] = *(const half8*)(qw + (qb * 16 + l15) * KS + kk * 32 + lg * 8);
       else qq[qb] = qf[qb][kk];
     }
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb) s[nb][qb] = mfma16(kf[nb], qq[qb], s[nb][qb]);
+      for (int qb = 0; qb < QB; ++qb) s[nb][qb] = mfma16(kf[nb], qq[qb], s[nb][qb]);
   }
 }
 
 // O^T[db][qb] += V_tile^T . P^T : A = transposed reads of the row-major tile, B = P^T fragments from registers
-__device__ __forceinline__ void pv_tile(const half_t* tile, const half8 (&pf)[2][2], float4_ (&o)[16][2], int l15, int lg) {
+template <int QB>
+__device__ __forceinline__ void pv_tile(const half_t* tile, const half8 (&pf)[2][QB], float4_ (&o)[16][QB], int l15, int lg) {
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
     const half_t* base = tile + (st * 32 + 4 * lg + (l15 >> 2)) * KS + (l15 & 3) * 4;
@@ -114,16 +121,17 @@ __device__ __forceinline__ void pv_tile(const half_t* tile, const half8 (&pf)[2]
 #pragma unroll
       for (int j = 0; j < 4; ++j) { a[j] = lo[j]; a[4 + j] = hi[j]; }
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb) o[db][qb] = mfma16(a, pf[st][qb], o[db][qb]);
+      for (int qb = 0; qb < QB; ++qb) o[db][qb] = mfma16(a, pf[st][qb], o[db][qb]);
     }
   }
 }
 
 // NT = number of 64-key tiles whose logits stay in registers.  NT <= 2 (<= 128 text tokens): Q fragments in registers and a
 // two-slot prefetch ring.  NT >= 3 ("lean"): the logits alone take 96-128 VGPRs, so Q moves to LDS and the ring has one slot.
-template <int NT>
-__global__ __launch_bounds__(256) void vlfuse_i2t_kernel(I2TParams p) {
+template <int NT, int QB>
+__global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p) {
   constexpr bool LEAN = NT >= 3;
+  constexpr int NTH = 2048 / (QB * 4), WR = 16 * QB;        // threads per workgroup (512 / 256), query rows per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* tiles = (half_t*)smem;                           // [2][TK][KS]
   half_t* Qs = tiles + 2 * TILE;                           // [BM][KS] (LEAN only)
@@ -137,44 +145,44 @@ __global__ __launch_bounds__(256) void vlfuse_i2t_kernel(I2TParams p) {
   const int b = (seq / qtiles) * 8 + (blockIdx.x & 7);
   if (b >= p.B) return;
   const int qtile = seq % qtiles;
-  const int row0 = qtile * BM + wave * 32;
+  const int row0 = qtile * BM + wave * WR;
 
   const int kv_eff = p.kv_len ? max(1, min(p.T, p.kv_len[b])) : p.T;
-  for (int i = tid; i < VH * NT * TK; i += 256) {
+  for (int i = tid; i < VH * NT * TK; i += NTH) {
     const int h = i / (NT * TK), t = i % (NT * TK);
     float v = MQ_NEG_BIG;
     if (t < kv_eff) v = p.bias ? p.bias[((long)b * VH + h) * p.T + t] : 0.f;
     bias_s[i] = v;
   }
 
-  half8 qf[2][8];
+  half8 qf[QB][8];
   const half_t* vb = p.v + (long)b * p.N * VD;
-  const half_t* qw = Qs + wave * 32 * KS;
+  const half_t* qw = Qs + wave * WR * KS;
   if constexpr (LEAN) {
-    TileRegs q0, q1;                                        // 128 rows = two 64-row tiles
+    TileRegs<NTH> q0, q1;                                        // 128 rows = two 64-row tiles
     tile_issue(q0, vb, qtile * BM, p.N - 1, tid);
     tile_issue(q1, vb, qtile * BM + 64, p.N - 1, tid);
     tile_commit(q0, Qs, tid);
     tile_commit(q1, Qs + 64 * KS, tid);
   } else {
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < QB; ++qb) {
       const int row = min(row0 + qb * 16 + l15, p.N - 1);
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = *(const half8*)(vb + (long)row * VD + kk * 32 + lg * 8);
     }
   }
 
-  float4_ o[16][2];
+  float4_ o[16][QB];
 #pragma unroll
   for (int db = 0; db < 16; ++db)
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) o[db][qb] = (float4_){0.f, 0.f, 0.f, 0.f};
+    for (int qb = 0; qb < QB; ++qb) o[db][qb] = (float4_){0.f, 0.f, 0.f, 0.f};
 
   // tile stream: u = h * 2NT + j;  j < NT: key tile j of head h,  j >= NT: value tile j - NT.  2NT is even, so the
   // position parity inside a head is also the parity of u: LDS buffer and register slot indices are compile-time.
   constexpr int PER_HEAD = 2 * NT, U = VH * PER_HEAD;
-  TileRegs slot[LEAN ? 1 : 2];
+  TileRegs<NTH> slot[LEAN ? 1 : 2];
   auto issue = [&](auto SLOT, int u) {
     constexpr int sl = decltype(SLOT)::value;
     u = min(u, U - 1);                                     // the tail re-loads the last tile: one code path, no branches
@@ -202,12 +210,12 @@ __global__ __launch_bounds__(256) void vlfuse_i2t_kernel(I2TParams p) {
 
   for (int h = 0; h < VH; ++h) {
     const int u0 = h * PER_HEAD;
-    float4_ s[NT][4][2];
+    float4_ s[NT][4][QB];
     // ---- logits of all key tiles of this head (kept in registers: exact softmax, no running rescale)
     auto qk_step = [&](auto J) {
       constexpr int j = decltype(J)::value;
       begin(J, u0 + j);
-      qk_tile<LEAN>(tiles + (j & 1) * TILE, qf, qw, s[j], l15, lg);
+      qk_tile<LEAN, QB>(tiles + (j & 1) * TILE, qf, qw, s[j], l15, lg);
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) {
         const float4_ kb = *(const float4_*)(bias_s + (h * NT + j) * TK + nb * 16 + 4 * lg);
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(256) void vlfuse_i2t_kernel(I2TParams p) {
         for (int r = 0; r < 4; ++r) {
           const bool masked = kb[r] < -1.0e29f;
 #pragma unroll
-          for (int qb = 0; qb < 2; ++qb) {
+          for (int qb = 0; qb < QB; ++qb) {
             float v = s[j][nb][qb][r] + kb[r];
             if (p.clamp > 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
             s[j][nb][qb][r] = masked ? MQ_NEG_BIG : v;
@@ -232,7 +240,7 @@ __global__ __launch_bounds__(256) void vlfuse_i2t_kernel(I2TParams p) {
     // ---- softmax over the text keys: a lane owns query column l15 of block qb; its keys are spread over (j, nb, r)
     // in-lane and over the 4 lane groups lg.  s <- exp(s - max) / sum
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < QB; ++qb) {
       float mx = MQ_NEG_BIG;
 #pragma unroll
       for (int j = 0; j < NT; ++j)
@@ -268,11 +276,11 @@ __global__ __launch_bounds__(256) void vlfuse_i2t_kernel(I2TParams p) {
       constexpr int j = decltype(J)::value;
       using POS = std::integral_constant<int, NT + j>;
       begin(POS{}, u0 + NT + j);
-      half8 pf[2][2];
+      half8 pf[2][QB];
 #pragma unroll
       for (int st = 0; st < 2; ++st)
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
+        for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             pf[st][qb][r] = (half_t)s[j][2 * st][qb][r];
@@ -289,11 +297,11 @@ __global__ __launch_bounds__(256) void vlfuse_i2t_kernel(I2TParams p) {
 
   // ---- epilogue: O^T -> LDS (row = query), + residual LN(v) + out-proj bias, 16-byte coalesced stores
   constexpr int OS = VD + 8;
-  half_t* Os = tiles + wave * (32 * OS);                   // [4][32][OS] aliases the tiles (all waves passed the last barrier)
+  half_t* Os = tiles + wave * (WR * OS);                   // [waves][WR][OS] aliases the tiles (all waves passed the last barrier)
 #pragma unroll
   for (int db = 0; db < 16; ++db)
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < QB; ++qb) {
       half4 v4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) v4[r] = (half_t)o[db][qb][r];
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(256) void vlfuse_i2t_kernel(I2TParams p) {
   wave_lds_fence();
   half_t* ob = p.out + (long)b * p.N * VD;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < 8 * QB; ++i) {
     const int c = lane + i * 64;
     const int rr = c >> 5, ch = c & 31;
     const int row = row0 + rr;
@@ -318,20 +326,26 @@ __global__ __launch_bounds__(256) void vlfuse_i2t_kernel(I2TParams p) {
   }
 }
 
-template <int NT>
+template <int NT, int QB>
 static int launch_i2t(const I2TParams& p, hipStream_t stream) {
   constexpr size_t smem = (size_t)(2 * TILE + (NT >= 3 ? BM * KS : 0)) * sizeof(half_t) + (size_t)VH * NT * TK * sizeof(float);
   static_assert(4 * 32 * (VD + 8) <= 2 * TILE, "O staging must fit in the tiles");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)vlfuse_i2t_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)vlfuse_i2t_kernel<NT, QB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   const int qtiles = (p.N + BM - 1) / BM;
-  hipLaunchKernelGGL((vlfuse_i2t_kernel<NT>), dim3((unsigned)(8 * ((p.B + 7) / 8) * qtiles)), dim3(256), smem, stream, p);
+  hipLaunchKernelGGL((vlfuse_i2t_kernel<NT, QB>), dim3((unsigned)(8 * ((p.B + 7) / 8) * qtiles)), dim3(2048 / (QB * 4)), smem, stream, p);
   MQ_CHECK_LAUNCH();
   return 0;
+}
+
+// waves x rows shape of both VLFuse kernels: 8 waves x 16 query rows (default) or 4 waves x 32 (MQ_VLFUSE_QB=2, A/B switch)
+static int vlfuse_qb() {
+  static const int qb = [] { const char* e = getenv("MQ_VLFUSE_QB"); return (e && e[0] == '2') ? 2 : 1; }();
+  return qb;
 }
 
 // Image side of VLFuse.  max_kv: host-known upper bound of kv_len (T if unknown) -- picks the number of 64-key tiles
@@ -344,11 +358,20 @@ extern "C" int mq_vlfuse_i2t_fwd(const void* v_ln, const void* kf, const void* v
   p.v = (const half_t*)v_ln; p.kf = (const half_t*)kf; p.vo = (const half_t*)vo; p.bias = bias; p.kv_len = kv_len;
   p.obias = (const half_t*)out_bias; p.out = (half_t*)out; p.B = B; p.N = N; p.T = T; p.clamp = clamp;
   const int kv = (kv_len && max_kv > 0) ? min(max_kv, T) : T;
-  switch ((kv + TK - 1) / TK) {
-    case 1: return launch_i2t<1>(p, (hipStream_t)stream);
-    case 2: return launch_i2t<2>(p, (hipStream_t)stream);
-    case 3: return launch_i2t<3>(p, (hipStream_t)stream);
-    default: return launch_i2t<4>(p, (hipStream_t)stream);
+  const int nt = (kv + TK - 1) / TK;
+  if (vlfuse_qb() == 1) {
+    switch (nt) {
+      case 1: return launch_i2t<1, 1>(p, (hipStream_t)stream);
+      case 2: return launch_i2t<2, 1>(p, (hipStream_t)stream);
+      case 3: return launch_i2t<3, 1>(p, (hipStream_t)stream);
+      default: return launch_i2t<4, 1>(p, (hipStream_t)stream);
+    }
+  }
+  switch (nt) {
+    case 1: return launch_i2t<1, 2>(p, (hipStream_t)stream);
+    case 2: return launch_i2t<2, 2>(p, (hipStream_t)stream);
+    case 3: return launch_i2t<3, 2>(p, (hipStream_t)stream);
+    default: return launch_i2t<4, 2>(p, (hipStream_t)stream);
   }
 }
 
@@ -364,7 +387,9 @@ struct T2IParams {
 };
 namespace { constexpr int WS_LD = VD + 4; }               // 260 floats: rows stay 16-byte aligned
 
-__global__ __launch_bounds__(256) void vlfuse_t2i_kernel(T2IParams p) {
+template <int QB>
+__global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p) {
+  constexpr int NTH = 2048 / (QB * 4), WR = 16 * QB;        // threads per workgroup (512 / 256), query rows per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* tiles = (half_t*)smem;                           // [2][TK][KS]
 
@@ -381,30 +406,32 @@ __global__ __launch_bounds__(256) void vlfuse_t2i_kernel(T2IParams p) {
   // padded caption tokens: as keys they are masked everywhere downstream and the post-processor never reads their
   // logits, so their rows of this attention are dead -- whole q-tiles of padding are skipped (the merge writes zeros)
   if (p.kv_len && qtile * BM >= max(1, min(p.T, p.kv_len[b]))) return;
-  const int row0 = qtile * BM + wave * 32;
+  const int row0 = qtile * BM + wave * WR;
 
   const int ntiles = (p.N + TK - 1) / TK;
   const int tps = (ntiles + p.nsplit - 1) / p.nsplit;
   const int t0 = split * tps, t1 = min(ntiles, t0 + tps);
   const int nt = max(t1 - t0, 0);
 
-  half8 qf[2][8];
+  half8 qf[QB][8];
   const half_t* qb_ = p.kf + ((long)b * VH + h) * p.T * VD;
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
+  for (int qb = 0; qb < QB; ++qb) {
     const int row = min(row0 + qb * 16 + l15, p.T - 1);
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = *(const half8*)(qb_ + (long)row * VD + kk * 32 + lg * 8);
   }
-  float4_ o[16][2];
+  float4_ o[16][QB];
 #pragma unroll
   for (int db = 0; db < 16; ++db)
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) o[db][qb] = (float4_){0.f, 0.f, 0.f, 0.f};
-  float m[2] = {MQ_NEG_BIG, MQ_NEG_BIG}, lsum[2] = {0.f, 0.f};   // per query column (m replicated over lg, lsum a per-lane partial)
+    for (int qb = 0; qb < QB; ++qb) o[db][qb] = (float4_){0.f, 0.f, 0.f, 0.f};
+  float m[QB], lsum[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) { m[qb] = MQ_NEG_BIG; lsum[qb] = 0.f; }   // per query column (m replicated over lg, lsum a per-lane partial)
 
   const half_t* vb = p.v + (long)b * p.N * VD;
-  TileRegs slot[2];
+  TileRegs<NTH> slot[2];
   auto issue = [&](auto SLOT, int pos) {
     constexpr int sl = decltype(SLOT)::value;
     const int t = t0 + min(pos, max(nt - 1, 0));
@@ -417,17 +444,19 @@ __global__ __launch_bounds__(256) void vlfuse_t2i_kernel(T2IParams p) {
     __builtin_amdgcn_sched_barrier(0);
     if (pos < nt) {
       const half_t* tile = tiles + par * TILE;
-      float4_ s[4][2];
-      qk_tile<false>(tile, qf, nullptr, s, l15, lg);
+      float4_ s[4][QB];
+      qk_tile<false, QB>(tile, qf, nullptr, s, l15, lg);
       const int key0 = (t0 + pos) * TK;
-      float mx[2] = {MQ_NEG_BIG, MQ_NEG_BIG};
+      float mx[QB];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) mx[qb] = MQ_NEG_BIG;
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const bool valid = key0 + nb * 16 + 4 * lg + r < p.N;
 #pragma unroll
-          for (int qb = 0; qb < 2; ++qb) {
+          for (int qb = 0; qb < QB; ++qb) {
             float v = s[nb][qb][r];
             if (p.clamp > 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
             v = valid ? v : MQ_NEG_BIG;
@@ -437,14 +466,14 @@ __global__ __launch_bounds__(256) void vlfuse_t2i_kernel(T2IParams p) {
         }
       bool grow = false;
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
+      for (int qb = 0; qb < QB; ++qb) {
         mx[qb] = fmaxf(mx[qb], __shfl_xor(mx[qb], 16));
         mx[qb] = fmaxf(mx[qb], __shfl_xor(mx[qb], 32));
         grow |= mx[qb] > m[qb] + THR;
       }
       if (__any(grow)) {                                   // wave-uniform, rare after the first tiles
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
+        for (int qb = 0; qb < QB; ++qb) {
           const float mnew = fmaxf(m[qb], mx[qb]);
           const float alpha = __expf(m[qb] - mnew);
           m[qb] = mnew;
@@ -455,9 +484,9 @@ __global__ __launch_bounds__(256) void vlfuse_t2i_kernel(T2IParams p) {
             for (int r = 0; r < 4; ++r) o[db][qb][r] *= alpha;
         }
       }
-      half8 pf[2][2];
+      half8 pf[2][QB];
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
+      for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -485,7 +514,7 @@ __global__ __launch_bounds__(256) void vlfuse_t2i_kernel(T2IParams p) {
 
   // ---- partials -> workspace (O^T: lane owns 4 consecutive d of one query row -> one 16-byte store)
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
+  for (int qb = 0; qb < QB; ++qb) {
     float l = lsum[qb];
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
@@ -551,12 +580,15 @@ extern "C" int mq_vlfuse_t2i_fwd(const void* kf, const void* v_ln, const int* kv
   constexpr size_t smem = (size_t)2 * TILE * sizeof(half_t);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)vlfuse_t2i_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)vlfuse_t2i_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)vlfuse_t2i_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   const int groups = B * nsplit, members = VH * ((T + BM - 1) / BM);
-  hipLaunchKernelGGL(vlfuse_t2i_kernel, dim3((unsigned)(8 * ((groups + 7) / 8) * members)), dim3(256), smem, (hipStream_t)stream, p);
+  const dim3 grid((unsigned)(8 * ((groups + 7) / 8) * members));
+  if (vlfuse_qb() == 1) hipLaunchKernelGGL(vlfuse_t2i_kernel<1>, grid, dim3(512), smem, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(vlfuse_t2i_kernel<2>, grid, dim3(256), smem, (hipStream_t)stream, p);
   MQ_CHECK_LAUNCH();
   const long total = (long)B * VH * T;
   hipLaunchKernelGGL(vlfuse_t2i_combine_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
