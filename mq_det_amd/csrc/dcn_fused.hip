@@ -23,6 +23,7 @@
 //     the other does the bilinear blend / LDS staging of step ks + 1 -- so VALU + LDS work hides under the matrix pipe.
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 
 struct DcnFParams {
   const half_t* x; const half_t* w; const half_t* bias; const float* om; half_t* out;
@@ -37,8 +38,12 @@ struct alignas(16) TapState { unsigned off[4]; float w[4]; };
 
 static constexpr int DCN_PH = 8, DCN_PW = 16;                // patch of output positions per workgroup
 
-__global__ __launch_bounds__(512) void dcn_igemm8_kernel(DcnFParams p) {
+// NW = waves per workgroup: 8 (two per SIMD, wave tile 64 x 64) or 16 (four per SIMD, wave tile 32 x 64, <= 128 VGPRs): the
+// staging phase is a dependent LDS -> VALU -> LDS chain, more resident waves overlap more of those chains.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnFParams p) {
   constexpr int BM = DCN_PH * DCN_PW, BN = 256, BK = 64;
+  constexpr int NTH = 64 * NW, RA = 1024 / NTH, JB = 2048 / NTH, IM = 32 / NW;   // threads, A rows / thread, B chunks / thread, row blocks / wave
   static_assert(BM == 128, "tile is 128 positions");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // LDS tiles: rows of 64 halfs = 128 B = 8 chunks of 16 B, NO padding; chunk c of row r is stored at chunk position
@@ -70,7 +75,7 @@ __global__ __launch_bounds__(512) void dcn_igemm8_kernel(DcnFParams p) {
   // the loop's gathers then find their lines in the L2.  The loads are inline asm (a C++ load without a consumer is
   // dropped, a volatile one is waited for on the spot); their destination registers stay reserved until the first
   // counted wait of the k-loop prologue has passed (VMEM returns in order, so they have landed by then).
-  constexpr int DCN_WARM = 1, WARM_N = 8;
+  constexpr int DCN_WARM = 1, WARM_N = 4096 / NTH;
   unsigned warm[WARM_N];
   {
     const int fh = (DCN_PH - 1) * p.stride + 3 + 2 * DCN_WARM, fw = (DCN_PW - 1) * p.stride + 3 + 2 * DCN_WARM;
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(512) void dcn_igemm8_kernel(DcnFParams p) {
 #pragma unroll
     for (int i = 0; i < WARM_N; ++i) {
       warm[i] = 0;
-      const int idx = tid + i * 512;
+      const int idx = tid + i * NTH;
       if (idx < nlines) {
         const int px = idx / lpp, ln = idx - px * lpp;
         const int hh = min(max(h_lo + px / fw, 0), p.H - 1), ww = min(max(w_lo + px % fw, 0), p.W - 1);
@@ -94,12 +99,12 @@ __global__ __launch_bounds__(512) void dcn_igemm8_kernel(DcnFParams p) {
   // ---- prologue: sampling state of every (row, tap) of this patch -> LDS.  All offset / mask loads of a thread's (up
   // to 3) tasks are issued before any of them is consumed (one memory round trip instead of three).
   {
-    constexpr int NTASK = (BM * 9 + 511) / 512;
+    constexpr int NTASK = (BM * 9 + NTH - 1) / NTH;
     float dh[NTASK], dw[NTASK], ml[NTASK];
     const float* omb = p.om + (long)b * 27 * p.oH * p.oW;
 #pragma unroll
     for (int i = 0; i < NTASK; ++i) {
-      const int t = min(tid + i * 512, BM * 9 - 1);
+      const int t = min(tid + i * NTH, BM * 9 - 1);
       const int row = t / 9, tap = t - row * 9;
       const int ho = ho0 + row / DCN_PW, wo = wo0 + row % DCN_PW;
       const int pos = (ho < p.Ho && wo < p.Wo) ? ho * p.Wo + wo : 0;
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(512) void dcn_igemm8_kernel(DcnFParams p) {
     }
 #pragma unroll
     for (int i = 0; i < NTASK; ++i) {
-      const int t = tid + i * 512;
+      const int t = tid + i * NTH;
       if (t < BM * 9) {
         const int row = t / 9, tap = t - row * 9;
         const int ho = ho0 + row / DCN_PW, wo = wo0 + row % DCN_PW;
@@ -136,29 +141,29 @@ __global__ __launch_bounds__(512) void dcn_igemm8_kernel(DcnFParams p) {
 
   // ---- staging tasks.  A: rows ar and ar + 64, 16-byte chunk ac (8 lanes = one 128-byte line of one corner);
   //      B: chunks tid + j*512 (row = chunk / 8).  Addresses are 32-bit byte offsets from wave-uniform bases.
-  const int wr = wave >> 2, wc = wave & 3;
-  const int ar = tid >> 3, ac = tid & 7;
+  const int wr = wave >> 2, wc = wave & 3;                   // wave tile: rows wr * IM*16.., columns wc * 64..
+  const int ar = tid >> 3, ac = tid & 7;                     // A rows ar + rr * (NTH / 8), rr < RA
   const char* xb = (const char*)(p.x + (long)b * p.x_bs);
   const char* wb = (const char*)p.w;
   const unsigned a_lds = (unsigned)(ar * BK + ((ac ^ (ar & 7)) << 3));                 // + 64 * BK for the second row
-  unsigned b_goff[4], b_lds[4];
+  unsigned b_goff[JB], b_lds[JB];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = tid + j * 512, row = c >> 3, ch = c & 7;
+  for (int j = 0; j < JB; ++j) {
+    const int c = tid + j * NTH, row = c >> 3, ch = c & 7;
     b_goff[j] = (unsigned)(row * K + ch * 8) * 2u;
     b_lds[j] = (unsigned)(row * BK + ((ch ^ (row & 7)) << 3));
   }
 
-  float c_w[2][2][4];
-  half8 a_raw[2][2][4], b_raw[4];
+  float c_w[2][RA][4];
+  half8 a_raw[2][RA][4], b_raw[JB];
   auto issue_a = [&](auto SLOT, int ks) {                    // gather of k-step ks
     constexpr int s = decltype(SLOT)::value;
     ks = min(ks, ksteps - 1);                                // tail: re-load the last step (one code path, no branches)
     const int slice = ks / 9, tap = ks - slice * 9;
     const unsigned cb = (unsigned)(slice * BK + ac * 8) * 2u;
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const TapState st = Ts[(ar + rr * 64) * 9 + tap];
+    for (int rr = 0; rr < RA; ++rr) {
+      const TapState st = Ts[(ar + rr * (NTH / 8)) * 9 + tap];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         c_w[s][rr][q] = st.w[q];
@@ -171,56 +176,54 @@ __global__ __launch_bounds__(512) void dcn_igemm8_kernel(DcnFParams p) {
     const int slice = ks / 9, tap = ks - slice * 9;
     const unsigned kb = (unsigned)(tap * p.C + slice * BK) * 2u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b_raw[j] = *(const half8*)(wb + (b_goff[j] + kb));
+    for (int j = 0; j < JB; ++j) b_raw[j] = *(const half8*)(wb + (b_goff[j] + kb));
   };
   // staging of one k-step by this thread: bilinear blend of its gathered slot (fp32 accumulate like the im2col kernel,
   // one rounding to fp16) -> its two A-tile rows, and its four weight chunks -> B tile
   auto stage = [&](auto SLOT, int buf) {
     constexpr int s = decltype(SLOT)::value;
-    half8 v[2];
+    half_t* a = As + buf * BM * BK + a_lds;
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr)
+    for (int rr = 0; rr < RA; ++rr) {
+      half8 v;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float t = c_w[s][rr][0] * (float)a_raw[s][rr][0][j];
         t = __builtin_fmaf(c_w[s][rr][1], (float)a_raw[s][rr][1][j], t);
         t = __builtin_fmaf(c_w[s][rr][2], (float)a_raw[s][rr][2][j], t);
         t = __builtin_fmaf(c_w[s][rr][3], (float)a_raw[s][rr][3][j], t);
-        v[rr][j] = (half_t)t;
+        v[j] = (half_t)t;
       }
-    half_t* a = As + buf * BM * BK + a_lds;
-    *(half8*)a = v[0];
-    *(half8*)(a + 64 * BK) = v[1];
+      *(half8*)(a + rr * (NTH / 8) * BK) = v;
+    }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *(half8*)(Bs + buf * BN * BK + b_lds[j]) = b_raw[j];
+    for (int j = 0; j < JB; ++j) *(half8*)(Bs + buf * BN * BK + b_lds[j]) = b_raw[j];
   };
 
-  float4_ acc[4][4];
+  float4_ acc[IM][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < IM; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (float4_){0.f, 0.f, 0.f, 0.f};
 
   // fragment addressing: row = w? * 64 + i * 16 + l15 (row & 7 == l15 & 7), chunk = kk * 4 + lg
-  const unsigned fa = (unsigned)((wr * 64 + l15) * BK), fb = (unsigned)((wc * 64 + l15) * BK);
+  const unsigned fa = (unsigned)((wr * IM * 16 + l15) * BK), fb = (unsigned)((wc * 64 + l15) * BK);
   const unsigned sw0 = (unsigned)((lg ^ (l15 & 7)) << 3), sw1 = (unsigned)(((4 + lg) ^ (l15 & 7)) << 3);
   auto mfma_phase = [&](int cur) {                           // this wave's 64 x 64 block of one k-step (32 MFMAs)
     const half_t* At = As + cur * BM * BK + fa;
     const half_t* Bt = Bs + cur * BN * BK + fb;
-    half8 af[2][4], bf[2][4];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
+      half8 af[IM], bf[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[kk][i] = *(const half8*)(At + i * 16 * BK + (kk ? sw1 : sw0));
+      for (int i = 0; i < IM; ++i) af[i] = *(const half8*)(At + i * 16 * BK + (kk ? sw1 : sw0));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bf[kk][j] = *(const half8*)(Bt + j * 16 * BK + (kk ? sw1 : sw0));
-    }
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+      for (int j = 0; j < 4; ++j) bf[j] = *(const half8*)(Bt + j * 16 * BK + (kk ? sw1 : sw0));
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = mfma16(af[kk][i], bf[kk][j], acc[i][j]);
+        for (int i = 0; i < IM; ++i) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
+    }
   };
 
   using S0 = std::integral_constant<int, 0>;
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(512) void dcn_igemm8_kernel(DcnFParams p) {
   // One loop per wave group (the branch is wave-uniform; s_barrier only counts arrivals, and both groups execute the
   // same number of barriers).  A single loop with `if (grp == ...)` around the phases makes hipcc merge the two paths'
   // VMEM bookkeeping and wait with vmcnt(0), which throws away one step of prefetch distance.
-  if (wave < 4) {
+  if (wave < NW / 2) {
     for (int ks = 0; ks < ksteps; ks += 2) {                 // ksteps = 9 * C/64 is even (C % 128 == 0)
       mfma_phase(0);
       __syncthreads();
@@ -282,12 +285,12 @@ __global__ __launch_bounds__(512) void dcn_igemm8_kernel(DcnFParams p) {
     const int col = wc * 64 + j * 16 + l15;
     const float bv = p.bias ? (float)p.bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < IM; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Os[(wr * 64 + i * 16 + lg * 4 + r) * OS + col] = (half_t)(acc[i][j][r] + bv);
+      for (int r = 0; r < 4; ++r) Os[(wr * IM * 16 + i * 16 + lg * 4 + r) * OS + col] = (half_t)(acc[i][j][r] + bv);
   }
   __syncthreads();
-  for (int c = tid; c < BM * (BN / 8); c += 512) {
+  for (int c = tid; c < BM * (BN / 8); c += NTH) {
     const int row = c / (BN / 8), ch = c % (BN / 8);
     const int ho = ho0 + row / DCN_PW, wo = wo0 + row % DCN_PW;
     if (ho < p.Ho && wo < p.Wo)
@@ -296,14 +299,15 @@ __global__ __launch_bounds__(512) void dcn_igemm8_kernel(DcnFParams p) {
   // ---- GroupNorm / scale-attention statistics of this patch (what mq_dyconv_stats would re-read y from HBM for):
   // per channel sum, sum of squares and position-weighted sum of the fp16-rounded outputs; fixed summation order.
   if (p.stats) {
-    const int chunk = tid & 31, rg = tid >> 5;               // 8 channels x 8 rows per thread
+    constexpr int RPT = BM / (NTH / 32);                     // rows per thread (8 or 4)
+    const int chunk = tid & 31, rg = tid >> 5;               // 8 channels x RPT rows per thread
     float s1[8], s2[8], s3[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s1[j] = s2[j] = s3[j] = 0.f;
     const float inv_n = 1.f / (float)n_pos;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int row = rg * 8 + k;
+    for (int k = 0; k < RPT; ++k) {
+      const int row = rg * RPT + k;
       const int ho = ho0 + row / DCN_PW, wo = wo0 + row % DCN_PW;
       if (ho < p.Ho && wo < p.Wo) {
         const half8 v = *(const half8*)(Os + row * OS + chunk * 8);
@@ -319,18 +323,18 @@ __global__ __launch_bounds__(512) void dcn_igemm8_kernel(DcnFParams p) {
     for (int j = 0; j < 8; ++j) {                            // lanes l and l ^ 32 hold the same channels
       s1[j] += __shfl_xor(s1[j], 32); s2[j] += __shfl_xor(s2[j], 32); s3[j] += __shfl_xor(s3[j], 32);
     }
-    float* red = (float*)(smem + (size_t)BM * OS * sizeof(half_t));      // [8 waves][32 chunks][24], behind the O staging
+    float* red = (float*)(smem + (size_t)BM * OS * sizeof(half_t));      // [NW waves][32 chunks][24], behind the O staging
     if (lane < 32) {
       float* r = red + (wave * 32 + chunk) * 24;
 #pragma unroll
       for (int j = 0; j < 8; ++j) { r[j] = s1[j]; r[8 + j] = s2[j]; r[16 + j] = s3[j]; }
     }
     __syncthreads();
-    for (int idx = tid; idx < 32 * 24; idx += 512) {
+    for (int idx = tid; idx < 32 * 24; idx += NTH) {
       const int lc = idx / 24, k = idx % 24;
       float a = 0.f;
 #pragma unroll
-      for (int g = 0; g < 8; ++g) a += red[(g * 32 + lc) * 24 + k];
+      for (int g = 0; g < NW; ++g) a += red[(g * 32 + lc) * 24 + k];
       p.stats[(((long)b * (p.tiles_x * p.tiles_y) + trem) * BN + lc * 8 + (k & 7)) * 3 + (k >> 3)] = a;
     }
   }
@@ -358,15 +362,19 @@ extern "C" int mq_dcnv2_fwd(const void* x, const float* om, const void* w, const
   p.tiles_y = (p.Ho + DCN_PH - 1) / DCN_PH; p.tiles_x = (p.Wo + DCN_PW - 1) / DCN_PW;
   p.tiles_total = B * p.tiles_y * p.tiles_x;
   constexpr size_t tiles = (size_t)(2 * 128 * 64 + 2 * 256 * 64) * sizeof(half_t) + 128 * 9 * sizeof(TapState);
-  constexpr size_t ostage = (size_t)128 * (256 + 8) * sizeof(half_t) + (size_t)8 * 32 * 24 * sizeof(float);
+  constexpr size_t ostage = (size_t)128 * (256 + 8) * sizeof(half_t) + (size_t)16 * 32 * 24 * sizeof(float);
   constexpr size_t smem = tiles > ostage ? tiles : ostage;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)dcn_igemm8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)dcn_igemm8_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dcn_igemm8_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(dcn_igemm8_kernel, dim3((unsigned)(8 * ((p.tiles_total + 7) / 8))), dim3(512), smem, (hipStream_t)stream, p);
+  static const int nw = [] { const char* e = getenv("MQ_DCN_WAVES"); return (e && e[0] == '8') ? 8 : 16; }();   // A/B switch
+  const dim3 grid((unsigned)(8 * ((p.tiles_total + 7) / 8)));
+  if (nw == 16) hipLaunchKernelGGL(dcn_igemm8_kernel<16>, grid, dim3(1024), smem, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(dcn_igemm8_kernel<8>, grid, dim3(512), smem, (hipStream_t)stream, p);
   MQ_CHECK_LAUNCH();
   return 0;
 }
