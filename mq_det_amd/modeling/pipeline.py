@@ -2,9 +2,11 @@
 
 Activations are fp16 (fp32 accumulation inside every kernel / GEMM); feature maps are NHWC in memory.
 Hand-written HIP kernels (mq_det_amd.ops -> libmqdet_hip.so) do: Swin window attention, every dense
-attention (BERT, GCP pre-select, VLFuse both directions), the GCP sparse cross-attention + gated residual,
-the DCNv2 gather, alignment scoring, box decode and class-aware NMS.  Library GEMMs / convs (hipBLASLt,
-MIOpen through torch) do the plain projections.  Reference call stack: SURVEY.md section 3.3; each function
+attention (BERT, GCP pre-select, the two VLFuse directions), the GCP sparse cross-attention + gated residual,
+LayerNorm (+ fused residual add), every 3x3 convolution, DCNv2 (gather + blend + MFMA + GroupNorm statistics in
+one kernel), the DyConv / DyReLU epilogue, alignment scoring, box decode and class-aware NMS.  Library GEMMs
+(hipBLASLt through torch) do the plain projections; no MIOpen call is on the path.  Independent work is forked
+onto side HIP streams (pyramid levels, text chain).  Reference call stack: SURVEY.md section 3.3; each function
 cites the reference lines it re-implements.  Nothing here imports the oracle, and nothing runs on CPU.
 """
 import math
