@@ -10,6 +10,7 @@ onto side HIP streams (pyramid levels, text chain).  Reference call stack: SURVE
 cites the reference lines it re-implements.  Nothing here imports the oracle, and nothing runs on CPU.
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -142,8 +143,12 @@ def _lin(P, name, x):
     return F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
 
 
-def _nsplit(n_blocks, n_key_tiles, target=768):
+_NSPLIT_TARGET = int(os.environ.get("MQ_NSPLIT_TARGET", "768"))       # workgroups aimed at by the key split (tuning knob)
+
+
+def _nsplit(n_blocks, n_key_tiles, target=None):
     """Split the key range when a launch would leave most of the 256 CUs idle."""
+    target = target or _NSPLIT_TARGET
     if n_blocks >= 256 or n_key_tiles < 8:
         return 1
     return max(1, min(n_key_tiles // 4, -(-target // n_blocks), 32))
