@@ -1,0 +1,102 @@
+"""CPU tests of host-side edge cases on the hot path: ragged / empty label maps, banks with fewer queries than asked,
+ragged batches, empty detections, sharding arithmetic.  No GPU, no HIP calls (the oracle is the checker)."""
+import torch
+
+from mq_det_amd import get_cfg, parallel
+from mq_det_amd.modeling import pipeline
+from mq_det_amd.modeling.query_selector import QuerySelector, build_token_index, labels_and_maps
+from oracle import detector as od
+from oracle import postprocess as op
+
+
+def test_token_index_ragged_and_empty_labels():
+    pm = {3: [1, 2, 5], 7: [9], 11: [], 12: [20, 21]}
+    labels = [k for k, v in pm.items() if len(v)]
+    idx, ids = build_token_index(pm, labels, torch.device("cpu"))
+    assert ids.tolist() == [3, 7, 12]                       # label 11 has no token -> dropped like the reference
+    assert idx.shape == (3, 3) and idx.dtype == torch.int32
+    assert idx.tolist() == [[1, 2, 5], [9, -1, -1], [20, 21, -1]]
+    idx0, ids0 = build_token_index({}, [], torch.device("cpu"))   # caption without any positive: well-formed, all padding
+    assert idx0.shape == (1, 1) and int(idx0[0, 0]) == -1 and ids0.numel() == 1
+
+
+def test_labels_and_maps_normalisation():
+    pm = {1: [2, 3], 2: [], 5: [7]}
+    labels, m = labels_and_maps(pm, 12)
+    assert labels == [1, 5] and m.shape == (2, 12)
+    assert torch.allclose(m.sum(1), torch.ones(2), atol=1e-5)
+    ref_labels, ref_m = od.labels_and_maps(pm, 12)
+    assert labels == ref_labels and torch.allclose(m, ref_m)
+
+
+def test_query_selector_short_bank_and_ragged_batch():
+    """A label with fewer queries than NUM_QUERY_PER_CLASS contributes what it has; images of one batch may carry
+    different label sets (zero-padded vision rows, -1 padded gather index); index == nonzeros of the reference mask."""
+    cfg = get_cfg()
+    C, k, T = cfg.MODEL.BACKBONE.OUT_CHANNELS, cfg.VISION_QUERY.NUM_QUERY_PER_CLASS, 32
+    g = torch.Generator().manual_seed(3)
+    bank = {1: torch.randn(k, 1, C, generator=g), 2: torch.randn(2, 1, C, generator=g), 4: torch.randn(k + 3, 1, C, generator=g)}
+    pm_a = {1: [1, 2], 2: [4], 4: [6, 7, 8]}
+    pm_b = {4: [3]}
+    qs = QuerySelector(cfg)
+    qs.load_query_bank(bank)
+    la, lb = list(pm_a), list(pm_b)
+    vision, idx = qs.select([la, lb], [pm_a, pm_b], T, torch.device("cpu"), torch.float32)
+    _, amap_a = od.labels_and_maps(pm_a, T)
+    _, amap_b = od.labels_and_maps(pm_b, T)
+    ref_v, ref_m = od.select_queries(bank, [la, lb], [amap_a, amap_b], k)
+    assert vision.shape == ref_v.shape == (2, k + 2 + k, C)
+    assert torch.equal(vision, ref_v)
+    for b in range(2):
+        for t in range(T):
+            want = torch.nonzero(ref_m[b, :, t]).flatten().tolist()
+            got = [i for i in idx[b, t].tolist() if i >= 0]
+            assert got == want, (b, t, got, want)
+    assert idx.shape[2] == k                                  # widest token owns one label's rows (label 4 capped at k)
+
+
+def test_pyramid_token_views_round_trip():
+    g = torch.Generator().manual_seed(5)
+    sizes = [(6, 7), (3, 4), (2, 2)]
+    feats = [torch.randn(2, 16, h, w, generator=g).contiguous(memory_format=torch.channels_last) for h, w in sizes]
+    tok, got_sizes = pipeline._to_tokens(feats)
+    tok = tok.contiguous()
+    assert got_sizes == sizes and tok.shape == (2, sum(h * w for h, w in sizes), 16)
+    views = pipeline._level_views(tok, sizes)
+    for v, f in zip(views, feats):
+        assert v.shape == f.shape and torch.equal(v, f)
+    views[1][:] = 0                                          # views alias the token buffer (no copies)
+    off = sizes[0][0] * sizes[0][1]
+    assert float(tok[:, off:off + sizes[1][0] * sizes[1][1]].abs().sum()) == 0.0
+    assert torch.equal(pipeline._level_views(tok, sizes)[0], feats[0])
+
+
+def test_nsplit_heuristic_bounds():
+    assert pipeline._nsplit(1024, 400) == 1                  # enough workgroups already
+    assert pipeline._nsplit(64, 4) == 1                      # too few key tiles to split
+    for blocks, tiles in ((64, 350), (16, 88), (128, 350), (1, 1000)):
+        n = pipeline._nsplit(blocks, tiles)
+        assert 1 <= n <= 32 and n <= max(1, tiles // 4)
+
+
+def test_shard_range_and_detection_packing():
+    assert parallel.shard_range(10, 0, 4) == [0, 1, 2] and parallel.shard_range(10, 3, 4) == [9, 0, 1]   # wrap-around tail
+    assert sorted(set(sum((parallel.shard_range(10, r, 4) for r in range(4)), []))) == list(range(10))
+    boxes = torch.zeros(2, 3, 4)
+    boxes[0, 0] = torch.tensor([1.0, 2.0, 3.0, 4.0])
+    scores = torch.tensor([[0.9, -1.0, -1.0], [-1.0, -1.0, -1.0]])          # image 1: no detection at all
+    labels = torch.tensor([[5, 0, 0], [0, 0, 0]])
+    packed = parallel.pack_detections(boxes, scores, labels)
+    assert packed.shape == (2, 3, 6) and parallel.gather_detections(packed) is packed          # world size 1: identity
+    out = parallel.unpack_detections(packed)
+    assert len(out[0]["boxes"]) == 1 and out[0]["labels"].tolist() == [5] and len(out[1]["boxes"]) == 0
+
+
+def test_oracle_nms_degenerate_inputs():
+    """Class-aware NMS of 0 / 1 / duplicate boxes (reference csrc/cuda/ml_nms.cu:15-26: IoU 0 across labels)."""
+    assert op.ml_nms(torch.zeros(0, 4), torch.zeros(0), torch.zeros(0, dtype=torch.long), 0.6).numel() == 0
+    assert op.ml_nms(torch.tensor([[0.0, 0.0, 5.0, 5.0]]), torch.tensor([0.3]), torch.tensor([1]), 0.6).tolist() == [0]
+    # identical boxes, different labels: class-aware NMS keeps both; same label: keeps the higher score only
+    b = torch.tensor([[0.0, 0.0, 9.0, 9.0], [0.0, 0.0, 9.0, 9.0]])
+    assert sorted(op.ml_nms(b, torch.tensor([0.5, 0.6]), torch.tensor([1, 2]), 0.6).tolist()) == [0, 1]
+    assert op.ml_nms(b, torch.tensor([0.5, 0.6]), torch.tensor([2, 2]), 0.6).tolist() == [1]
