@@ -19,7 +19,7 @@ extern "C" {
 int mq_abi_version(void);
 
 /* Fused multi-head attention forward  O = softmax(clamp(scale*Q.K^T, +-clamp) + key_bias) V,
- * fp16 in/out, fp32 accumulate; logits never leave the chip.  D in {32, 64, 256}.
+ * fp16 in/out, fp32 accumulate; logits never leave the chip.  D in {32, 64}.
  *   q, k: element (b,i,h,d) at base + b*bs + i*rs + h*hs + d (batch / row / head strides in elements; a head
  *   stride of 0 shares the operand across heads -- used by the folded VLFuse projections),
  *   vt = V transposed: element (b,h,d,j) at vt + b*vt_bs + h*vt_hs + d*vt_rs + j (strides % 8 == 0, columns
@@ -30,8 +30,8 @@ int mq_abi_version(void);
  *   mq_attn_workspace_bytes() bytes of workspace.
  * Replaces the unfused bmm -> (+mask) -> softmax -> bmm chains of
  *   maskrcnn_benchmark/modeling/rpn/modeling_bert.py:119-170 (BertSelfAttention, with clamp) and HF BertSelfAttention,
- *   maskrcnn_benchmark/modeling/language_backbone/modeling_bert_new.py:204-240 (MaskedCrossAttention, dense),
- *   maskrcnn_benchmark/utils/fuse_helper.py:233-279 (BiMultiHeadAttention, both directions). */
+ *   maskrcnn_benchmark/modeling/language_backbone/modeling_bert_new.py:204-240 (MaskedCrossAttention, dense).
+ *   (The 8 x 256 VLFuse attention has its own kernels, mq_vlfuse_*.) */
 long mq_attn_workspace_bytes(int B, int H, int Nq, int D, int nsplit);
 int mq_attn_fwd(const void* q, const void* k, const void* vt, void* o, const float* key_bias, const int* kv_len,
                 void* workspace,
@@ -50,22 +50,18 @@ int mq_window_attn_fwd(const void* qkv, const void* qkv_bias, const float* rel_b
                        int B, int H, int W, int C, int heads, int ws, int shift, void* stream);
 
 /* GCP sparse cross-attention: text token t attends to the vision rows idx[b,t,0..S) (-1 = none).
- *   q [B,T,512] fp16, kv [B,V,1024] fp16 (k|v of the UNIQUE vision tokens), idx [B,T,S] int32, out [B,T,512].
+ *   q [B,T,512] fp16, kv [B,V,1024] fp16 (k|v of the UNIQUE vision tokens), idx [B,T,S] int32 (any S >= 0), out [B,T,512].
  * Replaces MaskedCrossAttention.forward (sparse branch) + _construct_sparse_inputs,
  *   maskrcnn_benchmark/modeling/language_backbone/modeling_bert_new.py:162-184,204-240. */
 int mq_gcp_sparse_attn_fwd(const void* q, const void* kv, const int* idx, void* out, int B, int T, int V, int S,
                            int heads, int dim_head, void* stream);
 
 /* GCP conditional gate fused into the residual:  out = sup * tanh(w2 . gelu(h)) + x   (rows M, widths C / G).
+ *   sup, h, w2 fp16; x and out are the residual stream: fp32 when x_f32 != 0, else fp16.
  *   gate_out [M] fp32 optional (VISION_QUERY.RETURN_ATTN_GATE_VALUE).
  * Replaces GatedCrossAttentionBlock.forward lines modeling_bert_new.py:359,368. */
-int mq_gcp_gate_residual_fwd(const void* sup, const void* h, const void* w2, const void* x, void* out,
+int mq_gcp_gate_residual_fwd(const void* sup, const void* h, const void* w2, const void* x, int x_f32, void* out,
                              float* gate_out, long M, int C, int G, void* stream);
-
-/* out[m,c] = res[m,c] + bias[c] + sum_h x[m,h,c]  (fp16, M rows, H heads, C channels).  VLFuse image side: the
- * per-head attention outputs (out_v_proj and gamma_v already folded into the text values) summed over heads and added
- * to the residual -- replaces the out_v_proj GEMM + residual add of utils/fuse_helper.py:300,424. */
-int mq_headsum_residual_fwd(const void* x, const void* res, const void* bias, void* out, long M, int H, int C, void* stream);
 
 /* VLFuse image side in ONE launch (8 heads x 256, text tokens T <= 256), projections folded into the text operands:
  *   out[b,n,:] = v_ln[b,n,:] + out_bias + sum_h softmax_t( clamp(v_ln[b,n,:] . kf[b,h,t,:] + bias[b,h,t], +-clamp) ) vo[b,h,t,:]
@@ -91,21 +87,17 @@ long mq_vlfuse_t2i_workspace_bytes(int B, int T, int nsplit);
 int mq_vlfuse_t2i_fwd(const void* kf, const void* v_ln, const int* kv_len, void* workspace, void* out, int B, int N, int T,
                       int nsplit, float clamp, void* stream);
 
-/* DCNv2 (modulated deformable 3x3 conv, pad 1) column gather, NHWC fp16, whole batch.
- *   x [B,H,W,C], om [B,27,oH,oW] fp32 NCHW (18 offsets + 9 mask LOGITS; may come from another pyramid level:
- *   indexed flat by the output dims like the reference kernel), cols [B,Ho*Wo,9*C] (k = tap*C + c).
- * Replaces _C.modulated_deform_conv_forward's im2col half: maskrcnn_benchmark/csrc/cuda/deform_conv_kernel_cuda.cu:578-640,
- *   deform_conv_cuda.cu:538-552 (bound as maskrcnn_benchmark/csrc/vision.cpp:11-12). */
-int mq_dcn_im2col_fwd(const void* x, const float* om, void* cols, int B, int H, int W, int C, int oH, int oW,
-                      int stride, void* stream);
-
-/* Row LayerNorm, fp16 in/out, fp32 statistics: y[r,:] = (x[r,:] - mean) * rstd * gamma + beta, C % 8 == 0, C <= 2048.
- *   res != NULL: the row is fp16(x + res) (the fused residual add), also written to xsum when xsum != NULL;
- *   yt != NULL additionally writes the transpose yt[b, c, n] (r = b*rows_per_batch + n, row pitch yt_ld halfs).
+/* Row LayerNorm with the residual add fused in, mixed-precision streams, fp32 statistics; C % 8 == 0, C <= 2048.
+ *   s = x (+ res);  x is fp32 when x_f32 != 0 else fp16, res likewise (res_f32); res may be NULL.
+ *   y    [rows,C] fp16 = (s - mean) * rstd * gamma + beta    (may be NULL)
+ *   y32  [rows,C] fp32 = the same, unrounded                 (may be NULL; post-LN residual stream of the BERT layers)
+ *   xsum [rows,C]      = s (may be NULL; needs res): fp32 when x or res is fp32, otherwise fp16 -- s is then rounded to
+ *                        fp16 before the statistics, exactly what a separate elementwise add would hand to LayerNorm.
  * Replaces every nn.LayerNorm call on the path (backbone/swint.py:198,240,281,425,611; HF BertLayer / embeddings;
- *   language_backbone/modeling_bert_new.py:121,150-153; utils/fuse_helper.py:420-421). */
-int mq_layernorm_fwd(const void* x, const void* res, const void* gamma, const void* beta, void* y, void* xsum, void* yt,
-                     long rows, int C, float eps, long rows_per_batch, long yt_ld, void* stream);
+ *   language_backbone/modeling_bert_new.py:121,150-153; utils/fuse_helper.py:420-421) together with the residual adds
+ *   in front of them (swint.py:236,240; BertSelfOutput / BertOutput). */
+int mq_layernorm_fwd(const void* x, int x_f32, const void* res, int res_f32, const void* gamma, const void* beta, void* y,
+                     float* y32, void* xsum, long rows, int C, float eps, void* stream);
 
 /* 3x3 convolution (pad 1, stride 1|2) and DCNv2 (modulated deformable 3x3) as one implicit-GEMM MFMA kernel,
  * NHWC fp16, fp32 accumulation over the whole K = 9*C in a fixed order (bitwise reproducible).
@@ -128,6 +120,15 @@ int mq_conv3x3_fwd(const void* x, const void* w, const void* bias, void* out, in
 int mq_conv3x3_nchw32_fwd(const void* x, const void* w, const void* bias, float* out, int B, int H, int W, int C, long x_bs,
                           int N, void* stream);
 int mq_dcnv2_stats_blocks(int H, int W, int stride);
+/* One launch for up to 16 DCNv2 calls (the 13 branches of one DyConv layer): `branches` is a HOST array, copied into the
+ * kernel arguments; fields as the arguments of mq_dcnv2_fwd.  The tiles of all branches form one work list, so small
+ * pyramid levels do not pay a launch (and a partial wave of workgroups) each. */
+typedef struct mq_dcn_branch {
+  const void* x; const float* om; const void* w; const void* bias; void* out; float* stats; const float* wy; const float* wx;
+  long x_bs;
+  int B, H, W, C, oH, oW, N, out_ld, stride, reserved;
+} mq_dcn_branch;
+int mq_dcnv2_group_fwd(const mq_dcn_branch* branches, int n, void* stream);
 int mq_dcnv2_fwd(const void* x, const float* om, const void* w, const void* bias, void* out, float* stats, const float* wy,
                  const float* wx, int B, int H, int W, int C, long x_bs, int oH, int oW, int N, int out_ld, int stride,
                  void* stream);
@@ -158,18 +159,21 @@ int mq_dyrelu_coef(const float* pool, const void* w0, const void* b0, const void
 int mq_dyrelu_apply(void* x, const float* coef, int B, int n, int C, long x_bs, void* stream);
 
 /* Region-word alignment scores for the L labels of the caption.
- *   dot [B,HW,T] fp16 (batch stride dot_bs elements, <= 0: HW*T), tbias [B,T] fp32, tokidx [L,MT] int32,
- *   ctr [B,HW] fp16 -> out [B,HW,L] fp32
- *   ((cls > thr) ? cls*sigmoid(ctr) : -1), cls_out [B,HW,L] fp32 optional.
+ *   dot [B,HW,T] fp16 (fp32 when dot_f32 != 0; batch stride dot_bs elements, <= 0: HW*T), tbias [B,T] fp32,
+ *   tokidx [L,MT] int32 token positions per label, -1 padded (batch stride tok_bs elements: 0 = one caption for the whole
+ *   batch, L*MT = one caption per batch item), ctr [B,HW] fp16 -> out [B,HW,L] fp32
+ *   ((cls > thr) ? max(cls*sigmoid(ctr), FLT_MIN) : -1), cls_out [B,HW,L] fp32 optional.  Token -> class aggregation is the
+ *   MEAN of DYHEAD.SCORE_AGG (the reference default; MAX / POWER / ONEHOT are not implemented and rejected by the host).
  * Replaces vldyhead.py:884-887 (bias, clamp) + rpn/inference.py:656-683,772-824. */
-int mq_align_scores_fwd(const void* dot, const float* tbias, const int* tokidx, const void* ctr, float* out,
-                        float* cls_out, int B, int HW, int T, int L, int MT, float thr, long dot_bs, void* stream);
+int mq_align_scores_fwd(const void* dot, int dot_f32, const float* tbias, const int* tokidx, long tok_bs, const void* ctr,
+                        float* out, float* cls_out, int B, int HW, int T, int L, int MT, float thr, long dot_bs, void* stream);
 
 /* Decode + clip the top-K candidates of one level into the per-image candidate arrays (at column out_off).
- *   val/flat [B,K] (score, flat index loc*L + l), reg [B,HW,4] fp16, anchors [HW,4] fp32, label_ids [L] int32,
- *   im_wh [B,2] fp32 (w,h) -> boxes [B,out_stride,4] fp32, scores [B,out_stride] fp32 (sqrt), labels int32.
+ *   val/flat [B,K] (score, flat index loc*L + l), reg [B,HW,4] fp16, anchors [HW,4] fp32, label_ids [L] int32 (batch
+ *   stride lab_bs elements, 0 = shared), im_wh [B,2] fp32 (w,h) -> boxes [B,out_stride,4] fp32, scores [B,out_stride]
+ *   fp32 (sqrt), labels int32; val <= 0 marks an empty slot.
  * Replaces BoxCoder.decode (vldyhead.py:78-108), clip_to_image, rpn/inference.py:696-708. */
-int mq_box_decode(const float* val, const long* flat, const void* reg, const float* anchors, const int* label_ids,
+int mq_box_decode(const float* val, const long* flat, const void* reg, const float* anchors, const int* label_ids, long lab_bs,
                   const float* im_wh, float* boxes, float* scores, int* labels, int B, int K, int HW, int L,
                   long out_stride, long out_off, void* stream);
 

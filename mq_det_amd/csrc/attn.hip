@@ -403,7 +403,6 @@ extern "C" int mq_attn_fwd(const void* q, const void* k, const void* vt, void* o
   switch (D) {
     case 32: return launch_attn<32, 2>(p, s);
     case 64: return launch_attn<64, 2>(p, s);
-    case 256: return launch_attn<256, 2>(p, s);
     default: return -1;
   }
 }

@@ -38,10 +38,21 @@ struct alignas(16) TapState { unsigned off[4]; float w[4]; };
 
 static constexpr int DCN_PH = 8, DCN_PW = 16;                // patch of output positions per workgroup
 
+// One launch for SEVERAL convolutions ("branches": the up-to-13 DCNv2 calls of one DyConv layer, vldyhead.py:205-247).
+// A branch alone gives 8 ... 1144 tiles at B = 8 and every launch rounds its tile count up to whole waves of 256 CUs
+// (263 tiles -> two rounds, the second with 7 workgroups); 13 launches on 5 streams cost ~2.7x the CU time of their
+// tiles (profiles/README.md "launch quantisation").  Grouped, the ~2100 tiles of a layer fill the chip back to back.
+static constexpr int DCN_MAX_BRANCH = 16;
+struct DcnGroup {
+  DcnFParams br[DCN_MAX_BRANCH];
+  int first_tile[DCN_MAX_BRANCH + 1];                        // prefix sums of tiles_total
+  int n, tiles_all;
+};
+
 // NW = waves per workgroup: 8 (two per SIMD, wave tile 64 x 64) or 16 (four per SIMD, wave tile 32 x 64, <= 128 VGPRs): the
 // staging phase is a dependent LDS -> VALU -> LDS chain, more resident waves overlap more of those chains.
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnFParams p) {
+__global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   constexpr int BM = DCN_PH * DCN_PW, BN = 256, BK = 64;
   constexpr int NTH = 64 * NW, RA = 1024 / NTH, JB = 2048 / NTH, IM = 32 / NW;   // threads, A rows / thread, B chunks / thread, row blocks / wave
   static_assert(BM == 128, "tile is 128 positions");
@@ -56,13 +67,18 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnFParams p) {
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l15 = lane & 15, lg = lane >> 4;
-  const int n_pos = p.Ho * p.Wo;
   // XCD-aware tile order: workgroup i runs on XCD i % 8 (each XCD has its own 4 MB L2), so XCD x gets the CONTIGUOUS range
   // of patches [x * tpx, (x + 1) * tpx): the ~36-fold re-use of every input line (9 taps x 4 corners x neighbours) is then
   // served by that XCD's L2 (~50 B/clk/CU) instead of the Infinity Cache / HBM path (~11 B/clk/CU, tools/ingest_microbench).
-  const int tpx = (p.tiles_total + 7) >> 3;
-  const int tile = (blockIdx.x & 7) * tpx + (blockIdx.x >> 3);
-  if (tile >= p.tiles_total) return;
+  // (grouped launch: the same mapping over the concatenated tile list; tiles of one branch / image stay contiguous)
+  const int tpx = (g.tiles_all + 7) >> 3;
+  int tile = (blockIdx.x & 7) * tpx + (blockIdx.x >> 3);
+  if (tile >= g.tiles_all) return;
+  int bi = 0;
+  while (bi + 1 < g.n && tile >= g.first_tile[bi + 1]) ++bi;           // <= 13 branches: scalar scan
+  tile -= g.first_tile[bi];
+  const DcnFParams p = g.br[bi];
+  const int n_pos = p.Ho * p.Wo;
   const int b = tile / (p.tiles_x * p.tiles_y), trem = tile % (p.tiles_x * p.tiles_y);
   const int ho0 = (trem / p.tiles_x) * DCN_PH, wo0 = (trem % p.tiles_x) * DCN_PW;
   const int K = 9 * p.C;
@@ -348,19 +364,35 @@ extern "C" int mq_dcnv2_stats_blocks(int H, int W, int stride) {
   return ((Ho + DCN_PH - 1) / DCN_PH) * ((Wo + DCN_PW - 1) / DCN_PW);
 }
 
-extern "C" int mq_dcnv2_fwd(const void* x, const float* om, const void* w, const void* bias, void* out, float* stats,
-                            const float* wy, const float* wx, int B, int H, int W, int C, long x_bs, int oH, int oW, int N,
-                            int out_ld, int stride, void* stream) {
-  if (B <= 0) return 0;
-  if (N != 256 || C % 128 || stride < 1 || stride > 2 || out_ld < N || out_ld % 8) return -1;
-  DcnFParams p;
-  p.x = (const half_t*)x; p.w = (const half_t*)w; p.bias = (const half_t*)bias; p.om = om; p.out = (half_t*)out;
-  p.stats = stats; p.wy = wy; p.wx = wx;
-  p.x_bs = x_bs; p.B = B; p.H = H; p.W = W; p.C = C; p.stride = stride; p.oH = oH; p.oW = oW; p.out_ld = out_ld;
-  p.Ho = (H + 2 - 3) / stride + 1; p.Wo = (W + 2 - 3) / stride + 1;
-  if ((long)p.Ho * p.Wo > (long)oH * oW) return -2;          // flat reads must stay inside the om buffer
-  p.tiles_y = (p.Ho + DCN_PH - 1) / DCN_PH; p.tiles_x = (p.Wo + DCN_PW - 1) / DCN_PW;
-  p.tiles_total = B * p.tiles_y * p.tiles_x;
+struct mq_dcn_branch {          // mirrors include/mqdet_hip.h
+  const void* x; const float* om; const void* w; const void* bias; void* out; float* stats; const float* wy; const float* wx;
+  long x_bs;
+  int B, H, W, C, oH, oW, N, out_ld, stride, reserved;
+};
+
+extern "C" int mq_dcnv2_group_fwd(const mq_dcn_branch* br, int n, void* stream) {
+  if (n <= 0) return 0;
+  if (n > DCN_MAX_BRANCH) return -3;
+  DcnGroup g;
+  g.n = 0;
+  g.first_tile[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    const mq_dcn_branch& a = br[i];
+    if (a.B <= 0) continue;
+    if (a.N != 256 || a.C % 128 || a.stride < 1 || a.stride > 2 || a.out_ld < a.N || a.out_ld % 8) return -1;
+    DcnFParams& p = g.br[g.n];
+    p.x = (const half_t*)a.x; p.w = (const half_t*)a.w; p.bias = (const half_t*)a.bias; p.om = a.om; p.out = (half_t*)a.out;
+    p.stats = a.stats; p.wy = a.wy; p.wx = a.wx;
+    p.x_bs = a.x_bs; p.B = a.B; p.H = a.H; p.W = a.W; p.C = a.C; p.stride = a.stride; p.oH = a.oH; p.oW = a.oW; p.out_ld = a.out_ld;
+    p.Ho = (a.H + 2 - 3) / a.stride + 1; p.Wo = (a.W + 2 - 3) / a.stride + 1;
+    if ((long)p.Ho * p.Wo > (long)a.oH * a.oW) return -2;    // flat reads must stay inside the om buffer
+    p.tiles_y = (p.Ho + DCN_PH - 1) / DCN_PH; p.tiles_x = (p.Wo + DCN_PW - 1) / DCN_PW;
+    p.tiles_total = a.B * p.tiles_y * p.tiles_x;
+    g.first_tile[g.n + 1] = g.first_tile[g.n] + p.tiles_total;
+    ++g.n;
+  }
+  if (g.n == 0) return 0;
+  g.tiles_all = g.first_tile[g.n];
   constexpr size_t tiles = (size_t)(2 * 128 * 64 + 2 * 256 * 64) * sizeof(half_t) + 128 * 9 * sizeof(TapState);
   constexpr size_t ostage = (size_t)128 * (256 + 8) * sizeof(half_t) + (size_t)16 * 32 * 24 * sizeof(float);
   constexpr size_t smem = tiles > ostage ? tiles : ostage;
@@ -372,9 +404,18 @@ extern "C" int mq_dcnv2_fwd(const void* x, const float* om, const void* w, const
     attr_set = true;
   }
   static const int nw = [] { const char* e = getenv("MQ_DCN_WAVES"); return (e && e[0] == '8') ? 8 : 16; }();   // A/B switch
-  const dim3 grid((unsigned)(8 * ((p.tiles_total + 7) / 8)));
-  if (nw == 16) hipLaunchKernelGGL(dcn_igemm8_kernel<16>, grid, dim3(1024), smem, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(dcn_igemm8_kernel<8>, grid, dim3(512), smem, (hipStream_t)stream, p);
+  const dim3 grid((unsigned)(8 * ((g.tiles_all + 7) / 8)));
+  if (nw == 16) hipLaunchKernelGGL(dcn_igemm8_kernel<16>, grid, dim3(1024), smem, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL(dcn_igemm8_kernel<8>, grid, dim3(512), smem, (hipStream_t)stream, g);
   MQ_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int mq_dcnv2_fwd(const void* x, const float* om, const void* w, const void* bias, void* out, float* stats,
+                            const float* wy, const float* wx, int B, int H, int W, int C, long x_bs, int oH, int oW, int N,
+                            int out_ld, int stride, void* stream) {
+  mq_dcn_branch a;
+  a.x = x; a.om = om; a.w = w; a.bias = bias; a.out = out; a.stats = stats; a.wy = wy; a.wx = wx; a.x_bs = x_bs;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.oH = oH; a.oW = oW; a.N = N; a.out_ld = out_ld; a.stride = stride; a.reserved = 0;
+  return mq_dcnv2_group_fwd(&a, 1, stream);
 }

@@ -7,7 +7,8 @@
 //     dot    : [B, HW, T] fp16 = feat . (proj_tokens / exp(log_scale))^T       (library GEMM outside; batch stride
 //              dot_bs elements: a level's slice of the all-level [B, N, T] product)
 //     tbias  : [B, T] fp32     = emb . bias_lang + bias0
-//     tokidx : [L, MT] int32   token positions of each label (-1 padded)
+//     tokidx : [L, MT] int32   token positions of each label (-1 padded); batch stride tok_bs elements (0: one caption
+//              shared by the batch; L*MT: one caption per batch item -- chunk batching of the LVIS protocol)
 //     ctr    : [B, HW] fp16/fp32 centerness logits
 //     out    : [B, HW, L] fp32 = (cls > thr) ? cls * sigmoid(ctr) : -1 ;  cls_out (optional) = cls
 //   One wave per location: 256 token logits -> LDS, lanes then average their label's tokens.
@@ -21,24 +22,35 @@
 //   image, 64 boxes at a time (intra-chunk dependencies via wave shuffles).
 #include "common.h"
 
-__global__ __launch_bounds__(256) void align_scores_kernel(const half_t* __restrict__ dot, const float* __restrict__ tbias,
+template <typename TD>
+__global__ __launch_bounds__(256) void align_scores_kernel(const TD* __restrict__ dot, const float* __restrict__ tbias,
                                                            const int* __restrict__ tokidx, const half_t* __restrict__ ctr,
                                                            float* __restrict__ out, float* __restrict__ cls_out,
-                                                           int B, int HW, int T, int L, int MT, float thr, long dot_bs) {
+                                                           int B, int HW, int T, int L, int MT, float thr, long dot_bs, long tok_bs) {
   extern __shared__ float sig[];                 // [4][T]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long loc = (long)blockIdx.x * 4 + wave;
   if (loc >= (long)B * HW) return;
   const int b = loc / HW;
-  const half_t* drow = dot + (long)b * dot_bs + (loc - (long)b * HW) * T;
+  const TD* drow = dot + (long)b * dot_bs + (loc - (long)b * HW) * T;
+  const int* tix = tokidx + (long)b * tok_bs;
   float* sw = sig + wave * T;
-  if ((T & 3) == 0 && (dot_bs & 3) == 0) {       // 8-byte loads: one per lane for T = 256
+  if ((T & 3) == 0 && (dot_bs & 3) == 0) {       // 8-byte (fp16) / 16-byte (fp32) loads: one per lane for T = 256
     for (int t = lane * 4; t < T; t += 256) {
-      const half4 d = *(const half4*)(drow + t);
+      float d[4];
+      if constexpr (sizeof(TD) == 2) {
+        const half4 h = *(const half4*)(drow + t);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = (float)h[j];
+      } else {
+        const float4_ f = *(const float4_*)(drow + t);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = f[j];
+      }
       const float4_ tb = *(const float4_*)(tbias + (long)b * T + t);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float v = (float)d[j] + tb[j];
+        float v = d[j] + tb[j];
         v = fminf(fmaxf(v, -50000.f), 50000.f);
         sw[t + j] = 1.f / (1.f + __expf(-v));
       }
@@ -56,22 +68,30 @@ __global__ __launch_bounds__(256) void align_scores_kernel(const half_t* __restr
     float s = 0.f;
     int n = 0;
     for (int j = 0; j < MT; ++j) {
-      int t = tokidx[l * MT + j];
+      int t = tix[l * MT + j];
       if (t >= 0) { s += sw[t]; ++n; }
     }
     float cls = n > 0 ? s / (float)n : 0.f;
     if (cls_out) cls_out[loc * L + l] = cls;
-    out[loc * L + l] = cls > thr ? cls * c : -1.f;
+    // candidates are decided by the class score alone (rpn/inference.py:677): keep them > 0 even if the product with a
+    // vanishing centerness underflows, so that "value > 0" identifies a candidate downstream
+    out[loc * L + l] = cls > thr ? fmaxf(cls * c, 1.17549435e-38f) : -1.f;
   }
 }
 
-extern "C" int mq_align_scores_fwd(const void* dot, const float* tbias, const int* tokidx, const void* ctr, float* out,
-                                   float* cls_out, int B, int HW, int T, int L, int MT, float thr, long dot_bs, void* stream) {
+extern "C" int mq_align_scores_fwd(const void* dot, int dot_f32, const float* tbias, const int* tokidx, long tok_bs,
+                                   const void* ctr, float* out, float* cls_out, int B, int HW, int T, int L, int MT, float thr,
+                                   long dot_bs, void* stream) {
   if (B <= 0 || HW <= 0 || L <= 0) return 0;
   long locs = (long)B * HW;
-  hipLaunchKernelGGL(align_scores_kernel, dim3((unsigned)((locs + 3) / 4)), dim3(256), 4 * T * sizeof(float),
-                     (hipStream_t)stream, (const half_t*)dot, tbias, tokidx, (const half_t*)ctr, out, cls_out, B, HW, T, L,
-                     MT, thr, dot_bs > 0 ? dot_bs : (long)HW * T);
+  const dim3 grid((unsigned)((locs + 3) / 4));
+  const long dbs = dot_bs > 0 ? dot_bs : (long)HW * T;
+  if (dot_f32)
+    hipLaunchKernelGGL(align_scores_kernel<float>, grid, dim3(256), 4 * T * sizeof(float), (hipStream_t)stream, (const float*)dot,
+                       tbias, tokidx, (const half_t*)ctr, out, cls_out, B, HW, T, L, MT, thr, dbs, tok_bs);
+  else
+    hipLaunchKernelGGL(align_scores_kernel<half_t>, grid, dim3(256), 4 * T * sizeof(float), (hipStream_t)stream, (const half_t*)dot,
+                       tbias, tokidx, (const half_t*)ctr, out, cls_out, B, HW, T, L, MT, thr, dbs, tok_bs);
   MQ_CHECK_LAUNCH();
   return 0;
 }
@@ -80,7 +100,7 @@ extern "C" int mq_align_scores_fwd(const void* dot, const float* tbias, const in
 __global__ void box_decode_kernel(const float* __restrict__ val, const long* __restrict__ flat, const half_t* __restrict__ reg,
                                   const float* __restrict__ anchors, const int* __restrict__ label_ids,
                                   const float* __restrict__ im_wh, float* __restrict__ boxes, float* __restrict__ scores,
-                                  int* __restrict__ labels, int B, int K, int HW, int L, long out_stride, long out_off) {
+                                  int* __restrict__ labels, int B, int K, int HW, int L, long out_stride, long out_off, long lab_bs) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)B * K) return;
   const int b = i / K, k = i % K;
@@ -108,16 +128,16 @@ __global__ void box_decode_kernel(const float* __restrict__ val, const long* __r
   boxes[o * 4 + 2] = fminf(fmaxf(pcx + 0.5f * (pw - 1.f), 0.f), W - 1.f);
   boxes[o * 4 + 3] = fminf(fmaxf(pcy + 0.5f * (ph - 1.f), 0.f), H - 1.f);
   scores[o] = sqrtf(v);
-  labels[o] = label_ids[l];
+  labels[o] = label_ids[(long)b * lab_bs + l];
 }
 
 extern "C" int mq_box_decode(const float* val, const long* flat, const void* reg, const float* anchors, const int* label_ids,
-                             const float* im_wh, float* boxes, float* scores, int* labels, int B, int K, int HW, int L,
-                             long out_stride, long out_off, void* stream) {
+                             long lab_bs, const float* im_wh, float* boxes, float* scores, int* labels, int B, int K, int HW,
+                             int L, long out_stride, long out_off, void* stream) {
   if (B <= 0 || K <= 0) return 0;
   long n = (long)B * K;
   hipLaunchKernelGGL(box_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, val, flat,
-                     (const half_t*)reg, anchors, label_ids, im_wh, boxes, scores, labels, B, K, HW, L, out_stride, out_off);
+                     (const half_t*)reg, anchors, label_ids, im_wh, boxes, scores, labels, B, K, HW, L, out_stride, out_off, lab_bs);
   MQ_CHECK_LAUNCH();
   return 0;
 }

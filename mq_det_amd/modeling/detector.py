@@ -10,6 +10,7 @@ Differences by design: fp16 compute on MI355X HIP kernels; B > 1 is allowed with
 reference asserts B == 1, :354); post-processing has a single device->host sync per forward.
 """
 import os
+from collections import OrderedDict
 
 import torch
 from torch import nn
@@ -33,8 +34,17 @@ class GeneralizedVLRCNN_New(nn.Module):
         self._plan = None
         self._plan_key = None
         self._anchor_cache = {}
-        self._graphs, self._tok_cache, self._tokidx_cache, self._wh_cache = {}, {}, {}, {}
+        self._graphs = OrderedDict()                              # LRU of captured HIP graphs, keyed by static shapes only
+        self._graph_pool = None                                   # one memory pool shared by every captured graph
+        self._tok_cache, self._tokidx_cache, self._wh_cache = {}, {}, {}
+        self._feat_cache = None                                   # Swin + FPN + pooled tokens of the last image batch (f1)
+        self._front_cache = OrderedDict()                         # image-independent BERT layers per caption (f1)
         self.use_hip_graph = bool(cfg.MODEL.get("USE_HIP_GRAPH", True))
+        self.graph_cache_size = int(cfg.MODEL.get("HIP_GRAPH_CACHE", 8))
+        self.graph_warm_calls = int(cfg.MODEL.get("HIP_GRAPH_WARM_CALLS", 1))
+        self.backbone_cache = bool(cfg.MODEL.get("BACKBONE_CACHE", True))
+        self.cache_stats = {"backbone_hit": 0, "backbone_miss": 0, "front_hit": 0, "front_miss": 0,
+                            "graph_replay": 0, "graph_capture": 0, "eager": 0, "graph_evict": 0}
         self.eval()
 
     @staticmethod
@@ -52,7 +62,15 @@ class GeneralizedVLRCNN_New(nn.Module):
     def _invalidate(self):
         self._plan = None
         self._anchor_cache = {}
-        self._graphs = {}
+        self._drop_graphs()
+        self._feat_cache = None
+        self._front_cache = OrderedDict()
+
+    def _drop_graphs(self):
+        """Release every captured graph together with its static buffers (the shared pool empties with them)."""
+        for ent in list(getattr(self, "_graphs", {}).values()):
+            ent.clear()
+        self._graphs = OrderedDict()
 
     def load_state_dict(self, *a, **k):
         out = super().load_state_dict(*a, **k)
@@ -114,66 +132,155 @@ class GeneralizedVLRCNN_New(nn.Module):
         return hit
 
     # ------------------------------------------------------------------ device part (capturable in a HIP graph)
-    def _device_forward(self, x, input_ids, attention_mask, vision, idx, tokidx, label_ids, im_wh, max_kv=0, want_raw=False):
+    def _backbone_stage(self, x):
+        """Swin + FPN (+ the pooled FPN tokens the GCP pre-select attends to): depends on the pixels only."""
         P, cfg = self._plan, self.cfg
-        # the image-independent part of the language backbone (embeddings + BERT layers below the first GCP block) runs on
-        # a side stream under the Swin backbone: its launches are tiny (B x 256 tokens) and would otherwise serialise
+        feats = pipeline.fpn_forward(P, pipeline.swin_forward(P, cfg, x))
+        pooled = pipeline.pooled_fpn_tokens(feats) if self._use_vq() else None
+        return feats, pooled
+
+    def _use_vq(self):
+        return bool(self.cfg.VISION_QUERY.ENABLED and self.query_selector is not None
+                    and self.query_selector.query_bank is not None)
+
+    def _head_stage(self, feats, pooled, front, input_ids, attention_mask, vision, idx, tokidx, label_ids, im_wh, max_kv,
+                    want_raw=False):
+        """Image-dependent half of the language backbone (pre-select + GCP / BERT layers), VLDyHead, post-processing."""
+        P, cfg = self._plan, self.cfg
+        lang = pipeline.language_backbone(P, cfg, input_ids, attention_mask, vision, pooled, idx,
+                                          want_gates=cfg.VISION_QUERY.RETURN_ATTN_GATE_VALUE, front=front)
+        lang["max_kv"] = max_kv
+        trace = [] if want_raw else None                          # raw mode: per-layer tensors, single-stream schedule
+        head = pipeline.vldyhead(P, cfg, feats, lang, trace=trace)
+        sizes = tuple(tuple(f.shape[-2:]) for f in feats)
+        if sizes not in self._anchor_cache:                       # constant per feature-map geometry
+            self._anchor_cache[sizes] = pipeline.grid_anchors(P, sizes, cfg.MODEL.RPN.ANCHOR_STRIDE, feats[0].device)
+        anchors = self._anchor_cache[sizes]
+        post = pipeline.postprocess(cfg, head, anchors, im_wh, tokidx, label_ids, want_cls=want_raw)
+        if want_raw:
+            return {"post": post, "head": head, "head_trace": trace, "lang": lang, "feats": feats, "anchors": anchors,
+                    "vision": vision, "idx": idx, "pooled": pooled}
+        packed = torch.cat([post["boxes"], post["scores"][..., None], post["labels"].float()[..., None]], -1)
+        gates = lang["vision_query_gates"]
+        if gates is not None:                                     # reference: attn_gate.mean().item() per GCP layer (a float)
+            gates = torch.stack([g.float().mean() for g in gates])
+        return {"packed": packed, "counts": post["counts"], "gates": gates}
+
+    def _full_program(self, x, input_ids, attention_mask, vision, idx, tokidx, label_ids, im_wh, max_kv=0, want_raw=False):
+        """Whole device forward.  The image-independent part of the language backbone (embeddings + BERT layers below
+        the first GCP block) runs on a side stream under the Swin backbone: its launches are tiny (B x 256 tokens)."""
+        P, cfg = self._plan, self.cfg
         front = None
         if x.is_cuda and cfg.MODEL.DYHEAD.get("LEVEL_STREAMS", True):
             main, text = torch.cuda.current_stream(), pipeline._side_streams(x.device, 1, "text")[0]
             text.wait_stream(main)
             with torch.cuda.stream(text):
                 front = pipeline.language_front(P, cfg, input_ids, attention_mask, vision is not None)
-        feats = pipeline.fpn_forward(P, pipeline.swin_forward(P, cfg, x))
+        feats, pooled = self._backbone_stage(x)
         if front is not None:
             main.wait_stream(text)
-        pooled = pipeline.pooled_fpn_tokens(feats) if vision is not None else None
-        lang = pipeline.language_backbone(P, cfg, input_ids, attention_mask, vision, pooled, idx,
-                                          want_gates=cfg.VISION_QUERY.RETURN_ATTN_GATE_VALUE, front=front)
-        lang["max_kv"] = max_kv
-        head = pipeline.vldyhead(P, cfg, feats, lang)
-        sizes = tuple(tuple(f.shape[-2:]) for f in feats)
-        if sizes not in self._anchor_cache:                       # constant per feature-map geometry
-            self._anchor_cache[sizes] = pipeline.grid_anchors(P, sizes, cfg.MODEL.RPN.ANCHOR_STRIDE, x.device)
-        anchors = self._anchor_cache[sizes]
-        post = pipeline.postprocess(cfg, head, anchors, im_wh, tokidx, label_ids, want_cls=want_raw)
-        if want_raw:
-            return {"post": post, "head": head, "lang": lang, "feats": feats, "anchors": anchors,
-                    "vision": vision, "idx": idx, "pooled": pooled}
-        packed = torch.cat([post["boxes"], post["scores"][..., None], post["labels"].float()[..., None]], -1)
-        return {"packed": packed, "counts": post["counts"], "feats": feats, "gates": lang["vision_query_gates"]}
+        else:
+            front = pipeline.language_front(P, cfg, input_ids, attention_mask, vision is not None)
+        out = self._head_stage(feats, pooled, front, input_ids, attention_mask, vision, idx, tokidx, label_ids, im_wh, max_kv,
+                               want_raw=want_raw)
+        if not want_raw:
+            out.update(feats=feats, pooled=pooled, front=front)
+        return out
 
-    def _graph_forward(self, key, inputs):
-        """Replay the whole device forward as ONE HIP graph (static shapes per key).  The eager forward issues
-        ~1500 launches per step and was host-bound by ~17 ms / step (profiles/r01_call3); a replay costs one launch.
-        First call with a key runs eagerly (library autotuning, caches), the second captures."""
+    def _rest_program(self, feats, pooled, front, input_ids, attention_mask, vision, idx, tokidx, label_ids, im_wh, max_kv=0):
+        """Device forward from cached Swin / FPN features and a cached language front (the LVIS protocol
+        sends the same pixels 31 times, engine/inference.py:605-625, and the same 31 captions for every image)."""
+        out = self._head_stage(list(feats), pooled, front, input_ids, attention_mask, vision, idx, tokidx, label_ids, im_wh, max_kv)
+        out.update(feats=list(feats), pooled=pooled, front=front)
+        return out
+
+    @staticmethod
+    def _tree_map(fn, obj):
+        if torch.is_tensor(obj):
+            return fn(obj)
+        if isinstance(obj, dict):
+            return {k: GeneralizedVLRCNN_New._tree_map(fn, v) for k, v in obj.items()}
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(GeneralizedVLRCNN_New._tree_map(fn, v) for v in obj)
+        return obj
+
+    @staticmethod
+    def _tree_copy_(dst, src):
+        if torch.is_tensor(dst):
+            dst.copy_(src, non_blocking=True)
+        elif isinstance(dst, dict):
+            for k in dst:
+                GeneralizedVLRCNN_New._tree_copy_(dst[k], src[k])
+        elif isinstance(dst, (list, tuple)):
+            for d, s_ in zip(dst, src):
+                GeneralizedVLRCNN_New._tree_copy_(d, s_)
+
+    def _shape_key(self, obj):
+        if torch.is_tensor(obj):
+            return tuple(obj.shape)
+        if isinstance(obj, dict):
+            return tuple((k, self._shape_key(v)) for k, v in obj.items())
+        if isinstance(obj, (list, tuple)):
+            return tuple(self._shape_key(v) for v in obj)
+        return obj
+
+    def _run(self, program, inputs, use_graph):
+        """Run `program(*inputs)`, as a HIP-graph replay when its static-shape key is warm.
+
+        Key = the program and the SHAPES of its tensor inputs (+ the key-length bucket that selects a kernel variant);
+        image sizes are a tensor input (`im_wh`) and therefore not part of the key.  A key runs eagerly for its first
+        `HIP_GRAPH_WARM_CALLS` calls (library autotuning, caches; cold keys never pay a capture), is captured on the next
+        one and replayed afterwards.  At most `HIP_GRAPH_CACHE` graphs are kept (LRU): evicting one releases the graph,
+        its static input / output buffers and its private activation pool.  The eager forward issues ~1500 launches
+        (host-bound by ~17 ms / step at B = 8, profiles/r01_call3); a replay costs one launch."""
+        fn = getattr(self, program)
+        if not use_graph:
+            self.cache_stats["eager"] += 1
+            return fn(*inputs)
+        key = (program, self._shape_key(inputs[:-1]), -(-int(inputs[-1]) // 64))
         ent = self._graphs.get(key)
         if ent is None:
-            self._graphs[key] = {"stage": 1}
-            return self._device_forward(*inputs)
-        if ent["stage"] == 1:
-            static_in = [t.clone() if torch.is_tensor(t) else t for t in inputs]
+            ent = self._graphs[key] = {"stage": 0, "calls": 0}
+            while len(self._graphs) > max(1, self.graph_cache_size):
+                _, old = self._graphs.popitem(last=False)
+                old.clear()
+                self.cache_stats["graph_evict"] += 1
+        self._graphs.move_to_end(key)
+        if ent["stage"] == 0:
+            ent["calls"] += 1
+            if ent["calls"] <= self.graph_warm_calls:
+                self.cache_stats["eager"] += 1
+                return fn(*inputs)
+            static_in = self._tree_map(lambda t: t.clone(), inputs)
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
             try:
                 # thread_local: with torch.distributed initialised, the RCCL watchdog thread polls events concurrently;
                 # under the default "global" mode that would invalidate the capture
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    static_out = self._device_forward(*static_in)
+                    static_out = fn(*static_in)
             except Exception as e:                              # keep running eagerly, but say so loudly
                 import warnings
                 warnings.warn(f"mq_det_amd: HIP graph capture failed ({type(e).__name__}: {e}); staying eager")
-                self._graphs[key] = {"stage": -1}
+                ent.update(stage=-1)
                 torch.cuda.synchronize()
-                return self._device_forward(*inputs)
+                self.cache_stats["eager"] += 1
+                return fn(*inputs)
             ent.update(stage=2, graph=g, inp=static_in, out=static_out)
+            self.cache_stats["graph_capture"] += 1
         if ent["stage"] == -1:
-            return self._device_forward(*inputs)
-        for dst, src in zip(ent["inp"], inputs):
-            if torch.is_tensor(dst):
-                dst.copy_(src, non_blocking=True)
+            self.cache_stats["eager"] += 1
+            return fn(*inputs)
+        self._tree_copy_(ent["inp"], inputs)
         ent["graph"].replay()
+        self.cache_stats["graph_replay"] += 1
         return ent["out"]
+
+    def clear_caches(self):
+        """Drop the per-image feature cache, the per-caption language cache and every captured graph."""
+        self._feat_cache = None
+        self._front_cache = OrderedDict()
+        self._drop_graphs()
 
     @torch.no_grad()
     def forward(self, images, targets=None, captions=None, positive_map=None, greenlight_map=None,
@@ -186,44 +293,82 @@ class GeneralizedVLRCNN_New(nn.Module):
             self.prepare(dev)
         P, cfg = self._plan, self.cfg
         dtype = P["backbone.body.patch_embed.proj.weight"].dtype
-        x = images.tensors.to(dtype).contiguous(memory_format=torch.channels_last)
-        Bn = x.shape[0]
+        Bn = images.tensors.shape[0]
         if input_ids is None:
             input_ids, attention_mask, max_kv = self.tokenize(captions, dev)
+            cap_key = tuple(captions)
         else:                                                     # caller-supplied ids (tests): one host sync
             max_kv = int((attention_mask.cpu() * torch.arange(1, attention_mask.shape[1] + 1)).max())
+            cap_key = None
         T = input_ids.shape[1]
 
         # host-side glue: all memoised, no device sync
         labels_in_caption = [k for k, v in positive_map.items() if len(v) != 0]
         pm_key = tuple((k, tuple(positive_map[k])) for k in labels_in_caption)
         vision = idx = None
-        if cfg.VISION_QUERY.ENABLED and self.query_selector is not None and self.query_selector.query_bank is not None:
+        if self._use_vq():
             vision, idx = self.query_selector.select_cached(pm_key, labels_in_caption, positive_map, Bn, T, dev, dtype)
+            if vision.shape[1] == 0:                              # no label of this caption has a vision query: text only
+                vision = idx = None
         hit = self._tokidx_cache.get((pm_key, str(dev)))
         if hit is None:
+            if len(self._tokidx_cache) > 256:
+                self._tokidx_cache.clear()
             hit = self._tokidx_cache[(pm_key, str(dev))] = build_token_index(positive_map, labels_in_caption, dev)
         tokidx, label_ids = hit
         wh_key = (tuple(images.image_sizes), str(dev))
         im_wh = self._wh_cache.get(wh_key)
         if im_wh is None:
+            if len(self._wh_cache) > 256:
+                self._wh_cache.clear()
             im_wh = self._wh_cache[wh_key] = torch.tensor([[w, h] for (h, w) in images.image_sizes],
                                                           dtype=torch.float32, device=dev)
-        inputs = (x, input_ids, attention_mask, vision, idx, tokidx, label_ids, im_wh, max_kv)
+        tail = (input_ids, attention_mask, vision, idx, tokidx, label_ids, im_wh, max_kv)
         if return_raw:
-            return self._device_forward(*inputs, want_raw=True)
+            x = images.tensors.to(dtype).contiguous(memory_format=torch.channels_last)
+            return self._full_program(x, *tail, want_raw=True)
         from .. import ops
         use_graph = self.use_hip_graph and not ops.timing_active()
-        if use_graph:
-            key = (tuple(x.shape), T, None if vision is None else tuple(vision.shape), None if idx is None else tuple(idx.shape),
-                   tuple(tokidx.shape), wh_key, -(-max_kv // 64))
-            out = self._graph_forward(key, inputs)
-        else:
-            out = self._device_forward(*inputs)
 
-        # fixed-shape detections [B, K, 6] for the RCCL all-gather (mq_det_amd.parallel.gather_detections)
-        self.last_packed = packed = out["packed"]
-        counts = out["counts"].tolist()                           # the one device->host sync of the forward
+        # f1: the pixels of the previous call (same tensor object, not modified since) -> cached Swin / FPN features;
+        # a caption seen before -> cached image-independent BERT layers.  The strong reference to the input tensor keeps
+        # its storage alive, so object identity + version counter cannot alias a different batch.
+        fc = self._feat_cache if self.backbone_cache else None
+        src = images.tensors
+        if fc is not None and fc["src"] is src and fc["version"] == src._version and (vision is None or fc["pooled"] is not None):
+            self.cache_stats["backbone_hit"] += 1
+            fkey = (cap_key, Bn, vision is not None)
+            front = self._front_cache.get(fkey) if cap_key is not None else None
+            if front is None:
+                self.cache_stats["front_miss"] += 1
+                front = pipeline.language_front(P, cfg, input_ids, attention_mask, vision is not None)
+                if cap_key is not None:
+                    self._front_cache[fkey] = front
+                    while len(self._front_cache) > int(cfg.MODEL.get("LANG_FRONT_CACHE", 64)):
+                        self._front_cache.popitem(last=False)
+            else:
+                self.cache_stats["front_hit"] += 1
+                self._front_cache.move_to_end(fkey)
+            out = self._run("_rest_program", (fc["feats"], fc["pooled"], front) + tail, use_graph)
+        else:
+            x = src.to(dtype).contiguous(memory_format=torch.channels_last)
+            out = self._run("_full_program", (x,) + tail, use_graph)
+            if self.backbone_cache:
+                self.cache_stats["backbone_miss"] += 1
+                keep = self._tree_map(lambda t: t.clone(), {"feats": out["feats"], "pooled": out["pooled"], "front": out["front"]})
+                self._feat_cache = {"src": src, "version": src._version, "feats": keep["feats"], "pooled": keep["pooled"]}
+                if cap_key is not None:
+                    self._front_cache[(cap_key, Bn, vision is not None)] = keep["front"]
+
+        # fixed-shape detections [B, K, 6] for the RCCL all-gather (mq_det_amd.parallel.gather_detections); cloned: under
+        # HIP-graph replay `out` are the graph's static buffers, which the next forward overwrites
+        self.last_packed = packed = out["packed"].clone()
+        gates = out["gates"]
+        if gates is not None:
+            counts, gates = torch.cat([out["counts"].float(), gates.float()]).tolist(), None
+            counts, gates = [int(c) for c in counts[:Bn]], counts[Bn:]
+        else:
+            counts = out["counts"].tolist()                       # the one device->host sync of the forward
         result = []
         for b, (h, w) in enumerate(images.image_sizes):
             n = counts[b]
@@ -232,7 +377,7 @@ class GeneralizedVLRCNN_New(nn.Module):
             bl.add_field("scores", packed[b, :n, 4].clone())
             result.append(bl)
         if cfg.VISION_QUERY.RETURN_ATTN_GATE_VALUE:
-            return result, out["gates"]
+            return result, gates
         if return_backbone_features:
             return result, [f.float().contiguous() for f in out["feats"]]
         return result

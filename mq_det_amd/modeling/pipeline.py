@@ -1,6 +1,8 @@
 """Functional MI355X forward of MQ-GLIP over an fp16 "plan" (packed inference weights).
 
-Activations are fp16 (fp32 accumulation inside every kernel / GEMM); feature maps are NHWC in memory.
+Activations that feed MFMA contractions are fp16 (fp32 accumulation inside every kernel / GEMM); the RESIDUAL STREAMS of the
+transformer stacks (Swin tokens, BERT / GCP / VLDyHead text hidden states) are fp32 (MODEL.RESIDUAL_FP32, default on); feature
+maps are NHWC in memory.
 Hand-written HIP kernels (mq_det_amd.ops -> libmqdet_hip.so) do: Swin window attention, every dense
 attention (BERT, GCP pre-select, the two VLFuse directions), the GCP sparse cross-attention + gated residual,
 LayerNorm (+ fused residual add), every 3x3 convolution, DCNv2 (gather + blend + MFMA + GroupNorm statistics in
@@ -25,6 +27,7 @@ def build_plan(sd, cfg, device, dtype=torch.float16):
     """Pack the fp32 state_dict into inference tensors: fp16 casts, fused / folded / re-laid-out weights."""
     P = {}
     M = cfg.MODEL
+    P["_r32"] = bool(M.get("RESIDUAL_FP32", True))        # fp32 residual streams (Swin tokens, text hidden states)
 
     def h(name):
         return sd[name].detach().to(device=device, dtype=dtype).contiguous()
@@ -45,7 +48,7 @@ def build_plan(sd, cfg, device, dtype=torch.float16):
             P[b + ".rel_bias"] = F.pad(rel, (0, 64 - N, 0, 64 - N)).contiguous()        # [heads, 64, 64], see ops.pad_rel_bias
     # convs: channels_last weights
     for k in list(P):
-        if P[k].dim() == 4:
+        if torch.is_tensor(P[k]) and P[k].dim() == 4:
             P[k] = P[k].contiguous(memory_format=torch.channels_last)
     # BERT layers: fused q|k projection
     def bert(b):
@@ -129,14 +132,14 @@ def build_plan(sd, cfg, device, dtype=torch.float16):
     return P
 
 
-def _ln(P, name, x, eps=1e-5):
-    """LayerNorm through the HIP kernel (mq_layernorm_fwd)."""
-    return ops.layer_norm(x.contiguous(), P[name + ".weight"], P[name + ".bias"], eps)
+def _ln(P, name, x, eps=1e-5, **kw):
+    """LayerNorm through the HIP kernel (mq_layernorm_fwd); x fp16 or fp32 -> fp16 (see ops.layer_norm for **kw)."""
+    return ops.layer_norm(x.contiguous(), P[name + ".weight"], P[name + ".bias"], eps, **kw)
 
 
-def _add_ln(P, name, x, res, eps=1e-5, want_sum=True):
-    """LayerNorm(x + res) with the residual add fused into the kernel -> (y, x + res) or y."""
-    return ops.layer_norm(x.contiguous(), P[name + ".weight"], P[name + ".bias"], eps, residual=res.contiguous(), want_sum=want_sum)
+def _add_ln(P, name, x, res, eps=1e-5, **kw):
+    """LayerNorm(x + res) with the residual add fused into the kernel; res is the residual stream (fp32 or fp16)."""
+    return ops.layer_norm(x.contiguous(), P[name + ".weight"], P[name + ".bias"], eps, residual=res.contiguous(), **kw)
 
 
 def _lin(P, name, x):
@@ -167,8 +170,11 @@ def swin_forward(P, cfg, img):
     B, Cin, Hi, Wi = img.shape
     H, W = Hi // 4, Wi // 4
     patches = img.permute(0, 2, 3, 1).reshape(B, H, 4, W, 4, Cin).permute(0, 1, 3, 2, 4, 5).reshape(B, H * W, 16 * Cin)
+    r32 = P["_r32"]
     x = F.linear(patches, P[p + ".patch_embed.lin"], P[p + ".patch_embed.proj.bias"])      # PatchEmbed.proj, swint.py:447-471
-    x = _ln(P, p + ".patch_embed.norm", x)
+    # x is the residual stream of the stage: fp32 with RESIDUAL_FP32 (the LayerNorm kernel reads / writes it in fp32 and
+    # hands fp16 to the GEMMs), fp16 otherwise
+    x = _ln(P, p + ".patch_embed.norm", x, want_y=not r32, want_y32=r32)
     outs = []
     for i, (depth, heads) in enumerate(zip(M.DEPTHS, M.NUM_HEADS)):
         C = x.shape[-1]
@@ -179,13 +185,13 @@ def swin_forward(P, cfg, img):
             if pend is None:
                 h1 = _ln(P, b + ".norm1", x)
             else:
-                h1, x = _add_ln(P, b + ".norm1", x, pend)                                   # x = x + mlp(...)  (swint.py:240)
+                h1, x = _add_ln(P, b + ".norm1", pend, x)                                   # x = x + mlp(...)  (swint.py:240)
             qkv = _lin(P, b + ".attn.qkv", h1).reshape(B, H, W, 3 * C)
             a = ops.window_attention(qkv, P[b + ".attn.qkv.bias"], P[b + ".attn.rel_bias"], heads, ws, shift)
-            h2, x = _add_ln(P, b + ".norm2", x, _lin(P, b + ".attn.proj", a.reshape(B, H * W, C)))   # x = x + attn(...)  (:236)
+            h2, x = _add_ln(P, b + ".norm2", _lin(P, b + ".attn.proj", a.reshape(B, H * W, C)), x)   # x = x + attn(...)  (:236)
             pend = _lin(P, b + ".mlp.fc2", F.gelu(_lin(P, b + ".mlp.fc1", h2)))
         if i > 0:
-            o, x = _add_ln(P, f"{p}.norm{i}", x, pend)
+            o, x = _add_ln(P, f"{p}.norm{i}", pend, x)
             outs.append(o.reshape(B, H, W, C))
         else:
             x = x + pend
@@ -197,6 +203,8 @@ def swin_forward(P, cfg, img):
             y = torch.cat([y[:, 0::2, 0::2], y[:, 1::2, 0::2], y[:, 0::2, 1::2], y[:, 1::2, 1::2]], -1)
             H, W = (H + 1) // 2, (W + 1) // 2
             x = F.linear(_ln(P, d + ".norm", y.reshape(B, H * W, 4 * C)), P[d + ".reduction.weight"])
+            if r32:
+                x = x.float()
     return outs
 
 
@@ -229,22 +237,33 @@ def pooled_fpn_tokens(feats):
 
 
 # ----------------------------------------------------------------------------- language backbone
-def bert_layer(P, b, x, key_bias, clamp, kv_len=None):
-    """HF BertLayer / rpn/modeling_bert.py:71-272 (clamp=True): QK^T, mask, softmax, PV in one HIP kernel."""
+def bert_layer(P, b, x, key_bias, clamp, kv_len=None, x32=None):
+    """HF BertLayer / rpn/modeling_bert.py:71-272 (clamp=True): QK^T, mask, softmax, PV in one HIP kernel.
+    x [B,T,C] fp16 (GEMM operand); x32: the same hidden state unrounded (fp32 residual stream) or None.
+    Returns y16 (and y32 when x32 is given)."""
     Bn, T, C = x.shape
+    r32 = x32 is not None
     qk = _lin(P, b + ".qk", x)                                                          # [B, T, 2C]
     vt = torch.baddbmm(P[b + ".attention.self.value.bias"][None, :, None], P[b + ".attention.self.value.weight"][None]
                        .expand(Bn, -1, -1), x.transpose(1, 2))                          # V^T [B, C, T]
     ctx = ops.attention(qk[:, :, :C], qk[:, :, C:], vt, 12, C // 12, key_bias=key_bias, clamp=50000.0 if clamp else 0.0,
                         kv_len=kv_len)
-    a = _add_ln(P, b + ".attention.output.LayerNorm", _lin(P, b + ".attention.output.dense", ctx), x, 1e-12, want_sum=False)
-    hmid = _lin(P, b + ".intermediate.dense", a)
+    a = _add_ln(P, b + ".attention.output.LayerNorm", _lin(P, b + ".attention.output.dense", ctx), x32 if r32 else x, 1e-12,
+                want_sum=False, want_y32=r32)
+    a16, a32 = a if r32 else (a, None)
+    hmid = _lin(P, b + ".intermediate.dense", a16)
     if clamp:
         hmid = F.gelu(hmid.clamp(-50000, 50000)).clamp(-50000, 50000)
         o = _lin(P, b + ".output.dense", hmid).clamp(-50000, 50000)
-        return _add_ln(P, b + ".output.LayerNorm", o, a, 1e-12, want_sum=False).clamp(-50000, 50000)
-    o = _lin(P, b + ".output.dense", F.gelu(hmid))
-    return _add_ln(P, b + ".output.LayerNorm", o, a, 1e-12, want_sum=False)
+    else:
+        o = _lin(P, b + ".output.dense", F.gelu(hmid))
+    y = _add_ln(P, b + ".output.LayerNorm", o, a32 if r32 else a16, 1e-12, want_sum=False, want_y32=r32)
+    if not r32:
+        return y.clamp(-50000, 50000) if clamp else y
+    y16, y32 = y
+    if clamp:
+        y16, y32 = y16.clamp(-50000, 50000), y32.clamp(-50000, 50000)
+    return y16, y32
 
 
 def pre_select(P, p, vision, image, scale):
@@ -263,8 +282,10 @@ def pre_select(P, p, vision, image, scale):
         vt = torch.matmul(P[ic + ".to_v.weight"], kn.transpose(1, 2))                    # [B, 256, Np_pad]
         nq_tiles = -(-q.shape[1] // 128)
         att = ops.attention(q, k, vt, 8, 32, nk=Np, nsplit=_nsplit(nq_tiles * Bn * 8, -(-Np // 64)))
-        res = F.linear(vision, P[b + ".res_mapping.weight"]) if (b + ".res_mapping.weight") in P else vision
-        vision = F.linear(att, P[ic + ".to_out.weight"]) + res
+        v16 = vision if vision.dtype == image.dtype else vision.to(image.dtype)
+        res = F.linear(v16, P[b + ".res_mapping.weight"]) if (b + ".res_mapping.weight") in P else vision
+        att_o = F.linear(att, P[ic + ".to_out.weight"])
+        vision = att_o.float() + res.float() if P["_r32"] else att_o + res              # residual stream of the vision queries
         ff = b + ".ff"
         vision = vision + F.linear(F.gelu(F.linear(_ln(P, ff + ".norm", vision), P[ff + ".linear1.weight"])),
                                    P[ff + ".linear2.weight"])
@@ -273,16 +294,17 @@ def pre_select(P, p, vision, image, scale):
 
 def gcp_block(P, b, x, vision, idx, gates=None):
     """GatedCrossAttentionBlock.forward (modeling_bert_new.py:298-374): K/V projected once per unique vision
-    token, sparse gather-attention kernel, gate MLP + tanh + residual fused."""
+    token, sparse gather-attention kernel, gate MLP + tanh + residual fused.  x: the text residual stream (fp32 with
+    RESIDUAL_FP32, else fp16), returned in the same dtype; vision: fp16 or fp32."""
     q = F.linear(_ln(P, b + ".attn.norm", x), P[b + ".attn.to_q.weight"])
     kv = F.linear(_ln(P, b + ".attn.norm_kv", vision), P[b + ".attn.to_kv.weight"])
     sup = F.linear(ops.gcp_sparse_attention(q, kv, idx), P[b + ".attn.to_out.weight"])
     gh = F.linear(_ln(P, b + ".attn_gate.norm", sup), P[b + ".attn_gate.linear1.weight"])
     if gates is not None:
-        x, g = ops.gcp_gate_residual(sup, gh, P[b + ".attn_gate.w2"], x, want_gate=True)
+        x, g = ops.gcp_gate_residual(sup, gh, P[b + ".attn_gate.w2"], x.contiguous(), want_gate=True)
         gates.append(g)
     else:
-        x = ops.gcp_gate_residual(sup, gh, P[b + ".attn_gate.w2"], x)
+        x = ops.gcp_gate_residual(sup, gh, P[b + ".attn_gate.w2"], x.contiguous())
     ff = b + ".ff"
     return x + F.linear(F.gelu(F.linear(_ln(P, ff + ".norm", x), P[ff + ".linear1.weight"])), P[ff + ".linear2.gated"])
 
@@ -296,8 +318,11 @@ def language_front(P, cfg, input_ids, attention_mask, use_vq):
     e = P[p + ".embeddings.word_embeddings.weight"][input_ids].float() \
         + P[p + ".embeddings.token_type_embeddings.weight"][0].float() \
         + P[p + ".embeddings.position_embeddings.weight"][:T].float()[None]
-    x = F.layer_norm(e, (e.shape[-1],), P[p + ".embeddings.LayerNorm.weight"].float(),
-                     P[p + ".embeddings.LayerNorm.bias"].float(), 1e-12).to(P[p + ".embeddings.LayerNorm.weight"].dtype)
+    x32 = F.layer_norm(e, (e.shape[-1],), P[p + ".embeddings.LayerNorm.weight"].float(),
+                       P[p + ".embeddings.LayerNorm.bias"].float(), 1e-12)
+    x = x32.to(P[p + ".embeddings.LayerNorm.weight"].dtype)
+    if not P["_r32"]:
+        x32 = None
     key_bias = ((1.0 - attention_mask.float()) * NEG).contiguous()
     # index of the last valid text token + 1: the attention kernels skip key tiles that hold padding only
     kv_len = (attention_mask.to(torch.int32) * torch.arange(1, T + 1, device=attention_mask.device, dtype=torch.int32)) \
@@ -306,9 +331,16 @@ def language_front(P, cfg, input_ids, attention_mask, use_vq):
     n_front = qv0 if use_vq else nl
     hidden = []
     for i in range(n_front):
-        x = bert_layer(P, f"{p}.encoder.layer.{i}", x, key_bias, clamp=False, kv_len=kv_len)
-        hidden.append(x)
-    return {"x": x, "hidden": hidden, "key_bias": key_bias, "kv_len": kv_len, "next": n_front}
+        x, x32 = _bert(P, f"{p}.encoder.layer.{i}", x, x32, key_bias, False, kv_len)
+        hidden.append(x if x32 is None else x32)
+    return {"x": x, "x32": x32, "hidden": hidden, "key_bias": key_bias, "kv_len": kv_len, "next": n_front}
+
+
+def _bert(P, b, x, x32, key_bias, clamp, kv_len):
+    """bert_layer on the (fp16 operand, fp32 stream or None) pair."""
+    if x32 is None:
+        return bert_layer(P, b, x, key_bias, clamp, kv_len), None
+    return bert_layer(P, b, x, key_bias, clamp, kv_len, x32=x32)
 
 
 def language_backbone(P, cfg, input_ids, attention_mask, vision, images, idx, want_gates=False, front=None):
@@ -319,22 +351,26 @@ def language_backbone(P, cfg, input_ids, attention_mask, vision, images, idx, wa
     use_vq = vision is not None
     if front is None:
         front = language_front(P, cfg, input_ids, attention_mask, use_vq)
-    x, hidden, key_bias, kv_len = front["x"], list(front["hidden"]), front["key_bias"], front["kv_len"]
+    x, x32, hidden, key_bias, kv_len = front["x"], front.get("x32"), list(front["hidden"]), front["key_bias"], front["kv_len"]
     if use_vq:
         vision = pre_select(P, p + ".pre_select", vision, images, cfg.VISION_QUERY.VISION_SCALE)
     nl, qv0 = LB.get("NUM_HIDDEN_LAYERS", 12), LB.get("QV_START", 6)
     gates = [] if want_gates else None
     for i in range(front["next"], nl):
         if use_vq and i >= qv0:
-            x = gcp_block(P, f"{p}.encoder.qv_layer.{i - qv0}", x, vision, idx, gates)
-        x = bert_layer(P, f"{p}.encoder.layer.{i}", x, key_bias, clamp=False, kv_len=kv_len)
-        hidden.append(x)
+            if x32 is None:
+                x = gcp_block(P, f"{p}.encoder.qv_layer.{i - qv0}", x, vision, idx, gates)
+            else:
+                x32 = gcp_block(P, f"{p}.encoder.qv_layer.{i - qv0}", x32, vision, idx, gates)
+                x = x32.to(x.dtype)
+        x, x32 = _bert(P, f"{p}.encoder.layer.{i}", x, x32, key_bias, False, kv_len)
+        hidden.append(x if x32 is None else x32)
     n = LB.N_LAYERS
     feats = torch.stack(hidden[-n:], 1).float().mean(1) / n
     m = attention_mask.unsqueeze(-1).float()
     embedded = feats * m
     aggregate = embedded.sum(1) / attention_mask.sum(-1, keepdim=True).float()
-    return {"aggregate": aggregate, "embedded": embedded, "masks": attention_mask, "hidden": hidden[-1],
+    return {"aggregate": aggregate, "embedded": embedded, "masks": attention_mask, "hidden": x, "hidden32": x32,
             "key_bias": key_bias, "kv_len": kv_len, "vision_query_gates": gates, "augmented_vision": vision}
 
 
@@ -355,11 +391,15 @@ def _level_views(tok, sizes):
     return out
 
 
-def vl_text_prep(P, b, hidden, key_bias):
+def vl_text_prep(P, b, hidden, key_bias, hidden32=None):
     """Text-only operands of one VLFuse layer (fuse_helper.py:221-231 with the image-side projections folded in, DESIGN.md
-    section 4): LN(l), folded keys kf [B,8,T,256], folded values vo [B,8,T,256], per-(head, key) logit bias [B,8,T]."""
+    section 4): LN(l), folded keys kf [B,8,T,256], folded values vo [B,8,T,256], per-(head, key) logit bias [B,8,T].
+    hidden32: the text stream unrounded (fp32) or None; LN(l) is then kept in fp32 for the residual (fuse_helper.py:425)."""
     Bn = hidden.shape[0]
-    l_ln = _ln(P, b + ".layer_norm_l", hidden)
+    if hidden32 is not None:
+        l_ln, l_res = _ln(P, b + ".layer_norm_l", hidden32, want_y32=True)
+    else:
+        l_ln = l_res = _ln(P, b + ".layer_norm_l", hidden)
     a = b + ".attn"
     T = l_ln.shape[1]
     k8 = _lin(P, a + ".l_proj", l_ln).reshape(Bn, T, 8, -1).permute(0, 2, 1, 3)         # [B, 8, T, 256 hd]
@@ -367,7 +407,7 @@ def vl_text_prep(P, b, hidden, key_bias):
     bias = (torch.einsum("bhtd,hd->bht", k8.float(), P[b + ".bq8"]) + key_bias[:, None, :]).contiguous()   # [B, 8, T] fp32
     val_l8 = _lin(P, a + ".values_l_proj", l_ln).reshape(Bn, T, 8, -1).permute(0, 2, 1, 3)        # [B, 8, T, 256 hd]
     vo = torch.matmul(val_l8, P[b + ".Wov8"][None])                                      # [B, 8, T, 256 out] folded values
-    return {"l_ln": l_ln, "kf": kf, "vo": vo, "bias": bias}
+    return {"l_ln": l_ln, "l_res": l_res, "kf": kf, "vo": vo, "bias": bias}
 
 
 def vl_image_side(P, b, v_ln, prep, kv_len=None, max_kv=0):
@@ -383,7 +423,7 @@ def vl_text_side(P, b, v_ln, prep, kv_len=None, max_kv=0):
     T = prep["l_ln"].shape[1]
     t_live = min(T, max_kv) if (kv_len is not None and max_kv > 0) else T             # 128-row tiles of pure padding are skipped
     out_l = ops.vlfuse_t2i(prep["kf"], v_ln, _nsplit(-(-t_live // 128) * Bn * 8, -(-N // 64)), kv_len=kv_len)
-    return prep["l_ln"] + _lin(P, b + ".olc", out_l)
+    return prep["l_res"] + _lin(P, b + ".olc", out_l)                  # fp32 when the text stream is fp32
 
 
 def vl_fuse_tokens(P, b, v, hidden, key_bias, kv_len=None, max_kv=0):
@@ -429,13 +469,13 @@ def _upsample_pool_weights(hs, ws, H, W, device):
 
 def dyconv_tokens(P, cfg, b, tok, sizes):
     """DyConv.forward (vldyhead.py:205-247) on the pyramid token buffer tok [B, N, 256] -> new buffer of the same shape.
-    Per level: 27-channel offset/mask conv (implicit-GEMM kernel), up to three DCNv2 branches (one fused kernel each,
-    dcn_fused.hip; or HIP gather + library GEMM with MODEL.DYHEAD.FUSED_DCN = False), then the fused HIP epilogue
-    (GroupNorm statistics, bilinear up-sampling of the level+1 branch, scale attention, branch mean, DYReLU) written
-    straight into the level's slice of the output buffer -- offsets of the CURRENT level are re-used for all three
-    branches exactly like the reference (flat-index quirk handled inside the gather)."""
+      1. per level: 27-channel offset / mask conv (LDS-window kernel)                       -- five streams
+      2. ALL DCNv2 branches of the layer (3 per level, 13 in total) in ONE grouped launch (dcn_fused.hip): gather + bilinear
+         blend + MFMA + GroupNorm statistics; offsets of the CURRENT level are re-used for the level's three branches exactly
+         like the reference (flat-index quirk handled inside the gather)
+      3. per level: the fused HIP epilogue (GroupNorm affine, bilinear up-sampling of the level+1 branch, scale attention,
+         branch mean, DYReLU) written straight into the level's slice of the output buffer     -- five streams"""
     G = cfg.MODEL.GROUP_NORM
-    fused_dcn = bool(cfg.MODEL.DYHEAD.get("FUSED_DCN", True))
     nl = len(sizes)
     Bn, N, C = tok.shape
     offs = [0]
@@ -443,52 +483,64 @@ def dyconv_tokens(P, cfg, b, tok, sizes):
         offs.append(offs[-1] + hh * ww)
     lv = [tok[:, offs[l]:offs[l + 1]].reshape(Bn, sizes[l][0], sizes[l][1], C) for l in range(nl)]      # NHWC views
     out = torch.empty_like(tok)
+    streams = bool(cfg.MODEL.DYHEAD.get("LEVEL_STREAMS", True) and tok.is_cuda and nl > 1)
 
-    def level(lvl):
+    def fan_out(fn):
+        """fn(level) for every level: the big level (75 % of the positions) on the main stream, the others on side streams
+        (inside the HIP-graph capture: parallel graph branches); P5-P7 alone cannot fill 256 CUs."""
+        if not streams:
+            for l in range(nl):
+                fn(l)
+            return
+        main = torch.cuda.current_stream()
+        side = _side_streams(tok.device, nl - 1)
+        for s_ in side:
+            s_.wait_stream(main)
+        for l in range(1, nl):
+            with torch.cuda.stream(side[l - 1]):
+                fn(l)
+        fn(0)
+        for s_ in side:
+            main.wait_stream(s_)
+
+    om = [None] * nl
+
+    def offsets(lvl):
+        om[lvl] = ops.conv3x3_nchw32(lv[lvl], P[b + ".offset.packed"], P[b + ".offset.bias"], 27)      # [B, 27, H, W] fp32
+    fan_out(offsets)
+
+    branches, owner = [], []
+    for lvl in range(nl):
         H, W = sizes[lvl]
-        om = ops.conv3x3_nchw32(lv[lvl], P[b + ".offset.packed"], P[b + ".offset.bias"], 27)      # [B, 27, H, W] fp32
         spec = [(1, lv[lvl], 1)]
         if lvl > 0:
             spec.append((2, lv[lvl - 1], 2))
         if lvl < nl - 1:
             spec.append((0, lv[lvl + 1], 1))
-        branches = []
         for k, x_nhwc, stride in spec:
             Ho, Wo = (x_nhwc.shape[1] - 1) // stride + 1, (x_nhwc.shape[2] - 1) // stride + 1
-            wy = wx = sums = None
+            wy = wx = None
             if (Ho, Wo) != (H, W):
                 wy, wx = _upsample_pool_weights(Ho, Wo, H, W, tok.device)
-            if fused_dcn:      # one implicit-GEMM kernel (dcn_fused.hip); GroupNorm statistics come out of its epilogue
-                y, _, sums = ops.dcnv2(x_nhwc, om, P[f"{b}.DyConv.{k}.packed"], P[f"{b}.DyConv.{k}.conv.bias"], stride,
-                                       want_stats=True, wy=wy, wx=wx)
-            else:              # HIP gather + library GEMM against the tap-major packed weight
-                cols, _ = ops.dcn_im2col(x_nhwc.contiguous(), om, stride)
-                y = F.linear(cols, P[f"{b}.DyConv.{k}.packed"], P[f"{b}.DyConv.{k}.conv.bias"])      # [B, Ho*Wo, C]
+            branches.append({"x": x_nhwc, "om": om[lvl], "w": P[f"{b}.DyConv.{k}.packed"], "bias": P[f"{b}.DyConv.{k}.conv.bias"],
+                             "stride": stride, "wy": wy, "wx": wx})
+            owner.append((lvl, k, len(spec)))
+    ys = ops.dcnv2_group(branches, want_stats=True)
+
+    def epilogue(lvl):
+        H, W = sizes[lvl]
+        fused = []
+        for (l2, k, nb), br, (y, (Ho, Wo), sums) in zip(owner, branches, ys):
+            if l2 != lvl:
+                continue
             coef = ops.dyconv_branch_coef(y, Wo, P[f"{b}.DyConv.{k}.bn.weight"], P[f"{b}.DyConv.{k}.bn.bias"],
-                                          P[b + ".attn_w"], P[b + ".attn_b"], G.NUM_GROUPS, G.EPSILON, len(spec), wy, wx, sums=sums)
-            branches.append((y, coef, Ho, Wo))
+                                          P[b + ".attn_w"], P[b + ".attn_b"], G.NUM_GROUPS, G.EPSILON, nb, br["wy"], br["wx"], sums=sums)
+            fused.append((y, coef, Ho, Wo))
         o = out[:, offs[lvl]:offs[lvl + 1]]
-        _, pool = ops.dyconv_fuse(branches, H, W, out=o)
+        _, pool = ops.dyconv_fuse(fused, H, W, out=o)
         ops.dyrelu_(o, pool, P[b + ".relu.fc.0.weight"], P[b + ".relu.fc.0.bias"], P[b + ".relu.fc.2.weight"],
                     P[b + ".relu.fc.2.bias"])
-
-    # The five pyramid levels of one DyConv layer are independent given the layer input, and the small ones (P5-P7:
-    # 96 / 32 / 8 workgroup tiles for B = 8) cannot fill 256 CUs on their own: run every level on its own HIP stream
-    # (fork / join around the layer; inside the HIP-graph capture this becomes parallel graph branches).
-    if not (cfg.MODEL.DYHEAD.get("LEVEL_STREAMS", True) and tok.is_cuda and nl > 1):
-        for l in range(nl):
-            level(l)
-        return out
-    main = torch.cuda.current_stream()
-    side = _side_streams(tok.device, nl - 1)
-    for s in side:
-        s.wait_stream(main)
-    for lvl in range(1, nl):
-        with torch.cuda.stream(side[lvl - 1]):
-            level(lvl)
-    level(0)                                              # the big level (75 % of the positions) on the main stream
-    for s in side:
-        main.wait_stream(s)
+    fan_out(epilogue)
     return out
 
 
@@ -508,7 +560,7 @@ def _side_streams(device, n, tag="levels"):
     return _SIDE_STREAMS[key]
 
 
-def vldyhead(P, cfg, feats, lang):
+def vldyhead(P, cfg, feats, lang, trace=None):
     """VLDyHead.forward (vldyhead.py:769-900), eval outputs.  The pyramid lives in ONE token buffer [B, N, 256] (levels
     concatenated) from the first fusion layer to the prediction heads: VLFuse reads / writes it whole, DyConv reads
     per-level NHWC views of it and writes per-level slices -- no concatenation or split copies between layers.
@@ -516,25 +568,42 @@ def vldyhead(P, cfg, feats, lang):
     Two-stream schedule per fusion layer (text work never waits for image work it does not need, and vice versa):
         main : LN(v) -> image-side attention -> DyConv (itself forked over the five levels)
         text : text-side attention (needs LN(v)) -> folded out-projection -> BERT layer -> operands of the NEXT layer
-    The text chain (~0.8 ms of small or tail-heavy launches) hides under the image chain (~1.3 ms)."""
+    The text chain (~0.8 ms of small or tail-heavy launches) hides under the image chain (~1.3 ms).
+    trace: optional list; receives per fusion layer {"fuse_tok", "fuse_hidden", "bert_hidden", "dyconv_tok"} (parity ladder,
+    single-stream schedule)."""
     p = "rpn.head"
     hidden, key_bias, kv_len = lang["hidden"], lang["key_bias"], lang.get("kv_len")
+    h32 = lang.get("hidden32")
     max_kv = lang.get("max_kv", 0)
     tok, sizes = _to_tokens(feats)
     tok = tok.contiguous()
     L = cfg.MODEL.DYHEAD.NUM_CONVS
     t = f"{p}.dyhead_tower"
-    two_streams = bool(tok.is_cuda and cfg.MODEL.DYHEAD.get("LEVEL_STREAMS", True))
+    two_streams = bool(tok.is_cuda and cfg.MODEL.DYHEAD.get("LEVEL_STREAMS", True)) and trace is None
+
+    def text_side(b, v_ln, prep):
+        """-> (hidden16, hidden32 or None) after the text half of VLFuse"""
+        hnew = vl_text_side(P, b, v_ln, prep, kv_len, max_kv)
+        return (hnew.to(tok.dtype), hnew) if h32 is not None else (hnew, None)
+
     if not two_streams:
         for i in range(L):
-            tok, hidden = vl_fuse_tokens(P, f"{t}.{3 * i}.b_attn", tok, hidden, key_bias, kv_len, max_kv)
-            hidden = bert_layer(P, f"{t}.{3 * i + 1}", hidden, key_bias, clamp=True, kv_len=kv_len)
+            b = f"{t}.{3 * i}.b_attn"
+            v_ln = ops.layer_norm(tok, P[b + ".layer_norm_v.weight"], P[b + ".layer_norm_v.bias"], 1e-5)
+            prep = vl_text_prep(P, b, hidden, key_bias, h32)
+            tok = vl_image_side(P, b, v_ln, prep, kv_len, max_kv)
+            hidden, h32 = text_side(b, v_ln, prep)
+            rec = {"fuse_tok": tok, "fuse_hidden": hidden if h32 is None else h32}
+            hidden, h32 = _bert(P, f"{t}.{3 * i + 1}", hidden, h32, key_bias, True, kv_len)
             tok = dyconv_tokens(P, cfg, f"{t}.{3 * i + 2}", tok, sizes)
+            if trace is not None:
+                rec.update(bert_hidden=hidden if h32 is None else h32, dyconv_tok=tok)
+                trace.append(rec)
     else:
         main, text = torch.cuda.current_stream(), _side_streams(tok.device, 1, "text")[0]
         text.wait_stream(main)
         with torch.cuda.stream(text):
-            prep = vl_text_prep(P, f"{t}.0.b_attn", hidden, key_bias)
+            prep = vl_text_prep(P, f"{t}.0.b_attn", hidden, key_bias, h32)
         keep = []                                             # main-stream tensors the text stream still reads
         for i in range(L):
             b = f"{t}.{3 * i}.b_attn"
@@ -545,15 +614,15 @@ def vldyhead(P, cfg, feats, lang):
             text.wait_stream(main)                            # LN(v) ready
             cur = prep
             with torch.cuda.stream(text):
-                hidden = vl_text_side(P, b, v_ln, cur, kv_len, max_kv)
-                hidden = bert_layer(P, f"{t}.{3 * i + 1}", hidden, key_bias, clamp=True, kv_len=kv_len)
+                hidden, h32 = text_side(b, v_ln, cur)
+                hidden, h32 = _bert(P, f"{t}.{3 * i + 1}", hidden, h32, key_bias, True, kv_len)
                 if i + 1 < L:
-                    prep = vl_text_prep(P, f"{t}.{3 * (i + 1)}.b_attn", hidden, key_bias)
+                    prep = vl_text_prep(P, f"{t}.{3 * (i + 1)}.b_attn", hidden, key_bias, h32)
             tok = vl_image_side(P, b, v_ln, cur, kv_len, max_kv)
             tok = dyconv_tokens(P, cfg, f"{t}.{3 * i + 2}", tok, sizes)
         main.wait_stream(text)
         keep.clear()
-    emb = F.normalize(hidden.float(), p=2, dim=-1)
+    emb = F.normalize((hidden if h32 is None else h32).float(), p=2, dim=-1)
     tk = F.linear(emb / 2.0, P[p + ".tok.weight"], P[p + ".tok.bias"]) * P[p + ".inv_scale"]       # [B, T, 256]
     tbias = (emb @ P[p + ".bias_lang32"] + P[p + ".bias0_32"]).contiguous()                           # [B, T]
     tok16_t = tk.to(tok.dtype).transpose(1, 2)
@@ -568,7 +637,8 @@ def vldyhead(P, cfg, feats, lang):
         ctr.append(bc[..., 4:5].permute(0, 3, 1, 2))
         dots.append(dots_all[:, off:off + H * W])                                                    # [B, HW, T] view
         off += H * W
-    return {"bbox_reg": bbox, "centerness": ctr, "dot": dots, "tbias": tbias, "feats": _level_views(tok, sizes), "hidden": hidden}
+    return {"bbox_reg": bbox, "centerness": ctr, "dot": dots, "tbias": tbias, "feats": _level_views(tok, sizes),
+            "hidden": hidden if h32 is None else h32}
 
 
 # ----------------------------------------------------------------------------- anchors + post-processing
@@ -591,7 +661,7 @@ def postprocess(cfg, head, anchors, im_wh, tokidx, label_ids, want_cls=False):
     A = cfg.MODEL.ATSS
     dev = head["tbias"].device
     Bn = head["tbias"].shape[0]
-    L = tokidx.shape[0]
+    L = tokidx.shape[-2]
     if not torch.is_tensor(im_wh):                       # list of (h, w) -> [B, 2] (w, h)
         im_wh = torch.tensor([[w, h] for (h, w) in im_wh], dtype=torch.float32, device=dev)
     ks = [min(A.PRE_NMS_TOP_N, d.shape[1] * L) for d in head["dot"]]

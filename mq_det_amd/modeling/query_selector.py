@@ -9,6 +9,7 @@ positive_map the caller already holds -- no device work, no sync.
 """
 import os
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -52,29 +53,70 @@ class QuerySelector(nn.Module):
         self._dev_bank = {}
         self._sel_cache = {}
 
-    def _rows(self, label, device, dtype):
+    def _candidates(self, label):
+        """Bank entry of a label; None when the label has no vision query.  Reference banks are `defaultdict(list)`
+        (engine/inference.py:401): a label without queries reads as `[]` and contributes no vision rows
+        (query_selector.py:77-78, `isinstance(candidate_queries, list)`); a plain dict without the key is treated alike."""
+        bank = self.query_bank
+        cand = bank[label] if (label in bank or hasattr(bank, "default_factory")) else None
+        if cand is None or isinstance(cand, (list, tuple)) or len(cand) == 0:
+            return None
+        return cand
+
+    def deterministic(self, labels):
+        """True when no label of `labels` holds more bank rows than NUM_QUERY_PER_CLASS: the reference's eval-mode draw
+        `sorted(np.random.choice(len, n, replace=False))` (query_selector.py:74-76) is then the identity, and the
+        selection may be memoised.  Otherwise every forward draws again, from numpy's global generator like the reference."""
+        for lab in labels:
+            cand = self._candidates(lab)
+            if cand is not None and len(cand) > self.num_query_per_class:
+                return False
+        return True
+
+    def _rows(self, label, device, dtype, draw=False):
+        """[n * scales, C] vision rows of one label (n = min(len, k)); None when the label has none.
+        draw: consume numpy's global generator exactly like the reference does for EVERY label (:74), also when the draw is
+        the identity -- used when some label of the caption holds more than k rows, so that the same seed gives the same
+        selection as the reference."""
+        cand = self._candidates(label)
+        k = self.num_query_per_class
+        if draw:
+            n_tot = 0 if cand is None else len(cand)
+            idx = sorted(np.random.choice(n_tot, min(n_tot, k), replace=False).tolist())
+            if cand is None:
+                return None
+            if n_tot > k:
+                return cand[idx].flatten(0, 1).to(device=device, dtype=dtype)
+        if cand is None:
+            return None
         key = (label, device, dtype)
         if key not in self._dev_bank:
-            cand = self.query_bank[label]
-            n = min(len(cand), self.num_query_per_class)
-            # eval: sorted(np.random.choice(len, n, replace=False)) -- deterministic when len == n (the published
-            # banks); otherwise we take the first n rows (documented deviation)
-            self._dev_bank[key] = cand[:n].flatten(0, 1).to(device=device, dtype=dtype)
+            self._dev_bank[key] = cand[:k].flatten(0, 1).to(device=device, dtype=dtype)
         return self._dev_bank[key]
 
+    def _width(self):
+        for v in self.query_bank.values():
+            if torch.is_tensor(v) and v.numel():
+                return v.shape[-1]
+        return 1
+
     def select(self, batched_labels, batched_positive_maps, T, device, dtype):
-        """-> vision [B, V, C] (zero padded), idx [B, T, S] int32 (-1 padded)."""
+        """-> vision [B, V, C] (zero padded), idx [B, T, S] int32 (-1 padded).  Labels without bank rows are skipped
+        (text-only for that label, like the reference)."""
         per_image, tok_lists = [], []
         for labels, pmap in zip(batched_labels, batched_positive_maps):
             rows, owners = [], [[] for _ in range(T)]
             base = 0
+            draw = not self.deterministic(labels)
             for lab in labels:
-                r = self._rows(lab, device, dtype)
+                r = self._rows(lab, device, dtype, draw)
+                if r is None:
+                    continue
                 rows.append(r)
                 for t in pmap[lab]:
                     owners[t].extend(range(base, base + r.shape[0]))
                 base += r.shape[0]
-            per_image.append(torch.cat(rows) if rows else torch.zeros(0, 1, device=device, dtype=dtype))
+            per_image.append(torch.cat(rows) if rows else torch.zeros(0, self._width(), device=device, dtype=dtype))
             tok_lists.append(owners)
         vision = torch.nn.utils.rnn.pad_sequence(per_image, batch_first=True)
         S = max(1, max(len(o) for owners in tok_lists for o in owners))
@@ -87,6 +129,8 @@ class QuerySelector(nn.Module):
 
     def select_cached(self, key, labels, positive_map, B, T, device, dtype):
         """Memoised `select` for B images sharing one caption (eval protocol): no per-call host or device work."""
+        if not self.deterministic(labels):
+            return self.select([labels] * B, [positive_map] * B, T, device, dtype)
         k = (key, B, T, str(device), dtype)
         hit = self._sel_cache.get(k)
         if hit is None:
@@ -102,13 +146,18 @@ class QuerySelector(nn.Module):
         qs, ms, has = [], [], []
         for labels, maps in zip(batched_label_list, batched_location_map):
             q_img, m_img = [], []
+            flags = []
+            draw = not self.deterministic(labels)
             for lab, loc in zip(labels, maps):
-                r = self._rows(lab, loc.device, loc.dtype)
+                r = self._rows(lab, loc.device, loc.dtype, draw)
+                flags.append(0 if r is None else 1)
+                if r is None:
+                    continue
                 q_img.append(r)
                 m_img.append(loc[None].expand(r.shape[0], -1))
             qs.append(torch.cat(q_img))
             ms.append(torch.cat(m_img))
-            has.append([1] * len(labels))
+            has.append(flags)
         q = torch.nn.utils.rnn.pad_sequence(qs, batch_first=True)
         m = torch.nn.utils.rnn.pad_sequence(ms, batch_first=True).clone()
         m[m != 0] = 1

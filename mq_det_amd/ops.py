@@ -1,7 +1,7 @@
 """ctypes binding of libmqdet_hip.so + thin torch-tensor wrappers (device memory and streams only).
 
 There is NO fallback: if the HIP library is missing or a tensor is not on a GPU these functions raise.
-Signatures mirror include/mqdet_hip.h one to one.
+Signatures mirror include/mqdet_hip.h one to one (tests/test_host_cpu.py parses the header and compares).
 """
 import ctypes
 import math
@@ -19,24 +19,23 @@ _SIGNATURES = {
     "mq_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _i, _vp]),
     "mq_window_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_gcp_sparse_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "mq_gcp_gate_residual_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
-    "mq_headsum_residual_fwd": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
+    "mq_gcp_gate_residual_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _l, _i, _i, _vp]),
     "mq_vlfuse_i2t_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mq_vlfuse_t2i_workspace_bytes": (_l, [_i, _i, _i]),
     "mq_vlfuse_t2i_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
-    "mq_dcn_im2col_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "mq_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _l, _l, _vp]),
+    "mq_layernorm_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
     "mq_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _vp]),
     "mq_conv3x3_nchw32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _vp]),
     "mq_dcnv2_stats_blocks": (_i, [_i, _i, _i]),
     "mq_dcnv2_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _vp]),
+    "mq_dcnv2_group_fwd": (_i, [_vp, _i, _vp]),
     "mq_dyconv_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mq_dyconv_coef": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "mq_dyconv_fuse": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _l, _vp, _i, _i, _i, _i, _vp]),
     "mq_dyrelu_coef": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mq_dyrelu_apply": (_i, [_vp, _vp, _i, _i, _i, _l, _vp]),
-    "mq_align_scores_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
-    "mq_box_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _vp]),
+    "mq_align_scores_fwd": (_i, [_vp, _i, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _l, _vp]),
+    "mq_box_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _vp]),
     "mq_ml_nms_workspace_bytes": (_l, [_i, _i]),
     "mq_ml_nms": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
 }
@@ -210,33 +209,19 @@ def gcp_sparse_attention(q, kv, idx, heads=8, dim_head=64):
 
 
 def gcp_gate_residual(sup, h, w2, x, want_gate=False):
-    """out = sup * tanh(w2 . gelu(h)) + x ; sup/x [..., C], h [..., G], w2 [G] (all fp16)."""
+    """out = sup * tanh(w2 . gelu(h)) + x ; sup [..., C], h [..., G], w2 [G] fp16; x (the residual stream) fp16 or fp32,
+    the result has x's dtype."""
     lib = load_library()
     _need_gpu(sup, h, w2, x)
     C, G = sup.shape[-1], h.shape[-1]
     M = sup.numel() // C
     assert sup.is_contiguous() and h.is_contiguous() and x.is_contiguous() and w2.is_contiguous()
-    assert sup.dtype == h.dtype == w2.dtype == x.dtype == torch.float16
+    assert sup.dtype == h.dtype == w2.dtype == torch.float16 and x.dtype in (torch.float16, torch.float32)
     out = torch.empty_like(x)
     gate = torch.empty(M, dtype=torch.float32, device=x.device) if want_gate else None
-    _chk(lib.mq_gcp_gate_residual_fwd(_ptr(sup), _ptr(h), _ptr(w2), _ptr(x), _ptr(out), _ptr(gate), M, C, G, _stream()),
-         "mq_gcp_gate_residual_fwd")
+    _chk(lib.mq_gcp_gate_residual_fwd(_ptr(sup), _ptr(h), _ptr(w2), _ptr(x), int(x.dtype == torch.float32), _ptr(out), _ptr(gate),
+                                      M, C, G, _stream()), "mq_gcp_gate_residual_fwd")
     return (out, gate) if want_gate else out
-
-
-def headsum_residual(x, res, bias, heads):
-    """x [..., heads*C] fp16 (per-head outputs), res [..., C], bias [C] -> res + bias + sum_h x_h."""
-    lib = load_library()
-    _need_gpu(x, res, bias)
-    C = res.shape[-1]
-    M = res.numel() // C
-    assert x.is_contiguous() and res.is_contiguous() and x.shape[-1] == heads * C and x.numel() == M * heads * C
-    assert x.dtype == res.dtype == bias.dtype == torch.float16
-    out = torch.empty_like(res)
-    with _timed("headsum_residual"):
-        _chk(lib.mq_headsum_residual_fwd(_ptr(x), _ptr(res), _ptr(bias), _ptr(out), M, heads, C, _stream()),
-             "mq_headsum_residual_fwd")
-    return out
 
 
 def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.0):
@@ -282,48 +267,34 @@ def vlfuse_t2i(kf, v_ln, nsplit, clamp=50000.0, kv_len=None):
     return out
 
 
-def dcn_im2col(x_nhwc, om, stride):
-    """x [B,H,W,C] fp16 (NHWC contiguous), om [B,27,oH,oW] fp32 -> cols [B, Ho*Wo, 9*C] fp16, (Ho, Wo)."""
-    lib = load_library()
-    _need_gpu(x_nhwc, om)
-    B, H, W, C = x_nhwc.shape
-    assert x_nhwc.is_contiguous() and x_nhwc.dtype == torch.float16
-    assert om.is_contiguous() and om.dtype == torch.float32 and om.shape[1] == 27
-    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
-    cols = torch.empty(B, Ho * Wo, 9 * C, dtype=torch.float16, device=x_nhwc.device)
-    with _timed("dcn_im2col"):
-        _chk(lib.mq_dcn_im2col_fwd(_ptr(x_nhwc), _ptr(om), _ptr(cols), B, H, W, C, om.shape[2], om.shape[3], stride,
-                                   _stream()), "mq_dcn_im2col_fwd")
-    return cols, (Ho, Wo)
-
-
-def layer_norm(x, gamma, beta, eps=1e-5, transposed_out=False, pad_to=8, residual=None, want_sum=True):
-    """LayerNorm over the last dim of a contiguous fp16 tensor.  transposed_out: x is [B, N, C]; also returns
-    LN(x)^T as [B, C, N_pad] (N_pad = N rounded up to `pad_to`, tail zero-filled).
-    residual: same shape as x -> normalises fp16(x + residual) and returns (y, x + residual) (only y if not want_sum)."""
+def layer_norm(x, gamma, beta, eps=1e-5, residual=None, want_sum=True, want_y32=False, want_y=True):
+    """LayerNorm over the last dim (mq_layernorm_fwd).  x: contiguous fp16 or fp32; residual (optional, same shape):
+    fp16 or fp32, s = x + residual is normalised.  Returns, in this order and only those asked for:
+      y   fp16  (want_y)              -- GEMM operand
+      y32 fp32  (want_y32)            -- unrounded, the post-LN residual stream
+      sum       (residual given and want_sum) -- s: fp32 if x or residual is fp32, else fp16 (s rounded before the statistics)
+    A single result is returned bare, several as a tuple."""
     lib = load_library()
     _need_gpu(x, gamma, beta, residual)
     C = x.shape[-1]
-    assert x.is_contiguous() and x.dtype == torch.float16 and gamma.dtype == torch.float16 and beta.dtype == torch.float16
+    assert x.is_contiguous() and x.dtype in (torch.float16, torch.float32)
+    assert gamma.dtype == torch.float16 and beta.dtype == torch.float16
     rows = x.numel() // C
-    y = torch.empty_like(x)
+    xf = x.dtype == torch.float32
+    rf = False
+    y = torch.empty(x.shape, dtype=torch.float16, device=x.device) if want_y else None
+    y32 = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_y32 else None
     xsum = None
     if residual is not None:
-        assert residual.shape == x.shape and residual.is_contiguous() and residual.dtype == torch.float16 and not transposed_out
-        xsum = torch.empty_like(x) if want_sum else None
-    yt, rpb, ld = None, 0, 0
-    if transposed_out:
-        B, N = x.shape[0], x.shape[1]
-        ld = (N + pad_to - 1) // pad_to * pad_to
-        yt = torch.zeros(B, C, ld, dtype=torch.float16, device=x.device) if ld != N else \
-            torch.empty(B, C, ld, dtype=torch.float16, device=x.device)
-        rpb = N
+        assert residual.shape == x.shape and residual.is_contiguous() and residual.dtype in (torch.float16, torch.float32)
+        rf = residual.dtype == torch.float32
+        if want_sum:
+            xsum = torch.empty(x.shape, dtype=torch.float32 if (xf or rf) else torch.float16, device=x.device)
     with _timed(f"layernorm_c{C}"):
-        _chk(lib.mq_layernorm_fwd(_ptr(x), _ptr(residual), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(xsum), _ptr(yt), rows, C,
-                                  float(eps), rpb, ld, _stream()), "mq_layernorm_fwd")
-    if residual is not None:
-        return (y, xsum) if want_sum else y
-    return (y, yt) if transposed_out else y
+        _chk(lib.mq_layernorm_fwd(_ptr(x), int(xf), _ptr(residual), int(rf), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(y32), _ptr(xsum),
+                                  rows, C, float(eps), _stream()), "mq_layernorm_fwd")
+    out = [t for t in (y, y32, xsum) if t is not None]
+    return out[0] if len(out) == 1 else tuple(out)
 
 
 def conv3x3(x_nhwc, w_packed, bias, n_out, stride=1):
@@ -379,6 +350,46 @@ def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None
         _chk(lib.mq_dcnv2_fwd(_ptr(x_nhwc), _ptr(om), _ptr(w_packed), _ptr(bias), _ptr(y), _ptr(sums), _ptr(wy), _ptr(wx),
                               B, H, W, C, x_nhwc.stride(0), om.shape[2], om.shape[3], 256, 256, stride, _stream()), "mq_dcnv2_fwd")
     return (y, (Ho, Wo), sums) if want_stats else (y, (Ho, Wo))
+
+
+class _DcnBranch(ctypes.Structure):
+    """mq_dcn_branch of include/mqdet_hip.h."""
+    _fields_ = [(n, _vp) for n in ("x", "om", "w", "bias", "out", "stats", "wy", "wx")] + [("x_bs", _l)] + \
+               [(n, _i) for n in ("B", "H", "W", "C", "oH", "oW", "N", "out_ld", "stride", "reserved")]
+
+
+def dcnv2_group(branches, want_stats=True):
+    """ONE launch for several DCNv2 calls (mq_dcnv2_group_fwd).  branches: list of dicts with x [B,H,W,C] fp16 NHWC view,
+    om [B,27,oH,oW] fp32, w [256, 9*C] fp16, bias [256] fp16, stride, wy / wx (or None)
+    -> list of (y [B, Ho*Wo, 256] fp16, (Ho, Wo), sums or None) in the same order."""
+    lib = load_library()
+    arr = (_DcnBranch * len(branches))()
+    outs = []
+    for a, br in zip(arr, branches):
+        x, om, w, bias, stride = br["x"], br["om"], br["w"], br["bias"], br["stride"]
+        wy, wx = br.get("wy"), br.get("wx")
+        _need_gpu(x, om, w, bias, wy, wx)
+        B, H, W, C = x.shape
+        assert x.dtype == torch.float16 and x.stride(3) == 1 and x.stride(2) == C and x.stride(1) == W * C
+        assert om.is_contiguous() and om.dtype == torch.float32 and om.shape[1] == 27
+        assert w.is_contiguous() and w.shape == (256, 9 * C) and w.dtype == torch.float16
+        Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+        y = torch.empty(B, Ho * Wo, 256, dtype=torch.float16, device=x.device)
+        sums = None
+        if want_stats:
+            sums = torch.empty(B, lib.mq_dcnv2_stats_blocks(H, W, stride), 256, 3, dtype=torch.float32, device=y.device)
+            if wy is not None:
+                assert wy.dtype == wx.dtype == torch.float32 and wy.numel() == Ho and wx.numel() == Wo
+        a.x, a.om, a.w, a.bias, a.out = x.data_ptr(), om.data_ptr(), w.data_ptr(), bias.data_ptr(), y.data_ptr()
+        a.stats = sums.data_ptr() if sums is not None else None
+        a.wy = wy.data_ptr() if wy is not None else None
+        a.wx = wx.data_ptr() if wx is not None else None
+        a.x_bs, a.B, a.H, a.W, a.C, a.oH, a.oW = x.stride(0), B, H, W, C, om.shape[2], om.shape[3]
+        a.N, a.out_ld, a.stride, a.reserved = 256, 256, stride, 0
+        outs.append((y, (Ho, Wo), sums))
+    with _timed("dcnv2_fused"):
+        _chk(lib.mq_dcnv2_group_fwd(ctypes.cast(arr, _vp), len(branches), _stream()), "mq_dcnv2_group_fwd")
+    return outs
 
 
 def dyconv_branch_coef(y, Wsrc, gamma, beta, attn_w, attn_b, groups, eps, nbranches, wy=None, wx=None, sums=None):
@@ -443,32 +454,37 @@ def dyrelu_(x, pool, w0, b0, w2, b2):
 
 
 def align_scores(dot, tbias, tokidx, ctr, thr, want_cls=False):
-    """dot [B,HW,T] fp16 (contiguous rows, any batch stride), tbias [B,T] fp32, tokidx [L,MT] int32, ctr [B,HW] fp16
-    -> ranked [B,HW,L] fp32 (, cls)."""
+    """dot [B,HW,T] fp16 or fp32 (contiguous rows, any batch stride), tbias [B,T] fp32, tokidx [L,MT] (one caption for the
+    batch) or [B,L,MT] (one per item) int32, ctr [B,HW] fp16 -> ranked [B,HW,L] fp32 (, cls)."""
     lib = load_library()
     _need_gpu(dot, tbias, tokidx, ctr)
     B, HW, T = dot.shape
-    L, MT = tokidx.shape
-    assert dot.stride(2) == 1 and dot.stride(1) == T and dot.dtype == torch.float16
+    L, MT = tokidx.shape[-2:]
+    assert dot.stride(2) == 1 and dot.stride(1) == T and dot.dtype in (torch.float16, torch.float32)
     assert ctr.dtype == torch.float16 and ctr.is_contiguous()
     assert tbias.dtype == torch.float32 and tbias.is_contiguous() and tokidx.dtype == torch.int32 and tokidx.is_contiguous()
+    assert tokidx.dim() == 2 or tokidx.shape[0] == B
     out = torch.empty(B, HW, L, dtype=torch.float32, device=dot.device)
     cls = torch.empty_like(out) if want_cls else None
-    _chk(lib.mq_align_scores_fwd(_ptr(dot), _ptr(tbias), _ptr(tokidx), _ptr(ctr), _ptr(out), _ptr(cls), B, HW, T, L, MT,
+    _chk(lib.mq_align_scores_fwd(_ptr(dot), int(dot.dtype == torch.float32), _ptr(tbias), _ptr(tokidx),
+                                 L * MT if tokidx.dim() == 3 else 0, _ptr(ctr), _ptr(out), _ptr(cls), B, HW, T, L, MT,
                                  float(thr), dot.stride(0), _stream()), "mq_align_scores_fwd")
     return (out, cls) if want_cls else out
 
 
 def box_decode(val, flat, reg, anchors, label_ids, im_wh, boxes, scores, labels, HW, L, out_off):
-    """Decode top-K candidates of one level into columns [out_off, out_off+K) of the per-image arrays."""
+    """Decode top-K candidates of one level into columns [out_off, out_off+K) of the per-image arrays.
+    label_ids [L] (shared) or [B, L] int32."""
     lib = load_library()
     _need_gpu(val, flat, reg, anchors, label_ids, im_wh, boxes, scores, labels)
     B, K = val.shape
     assert val.dtype == torch.float32 and flat.dtype == torch.int64 and reg.dtype == torch.float16
     assert val.is_contiguous() and flat.is_contiguous() and reg.is_contiguous() and anchors.is_contiguous()
     assert boxes.dtype == torch.float32 and scores.dtype == torch.float32 and labels.dtype == torch.int32
-    _chk(lib.mq_box_decode(_ptr(val), _ptr(flat), _ptr(reg), _ptr(anchors), _ptr(label_ids), _ptr(im_wh), _ptr(boxes),
-                           _ptr(scores), _ptr(labels), B, K, HW, L, boxes.shape[1], out_off, _stream()), "mq_box_decode")
+    assert label_ids.is_contiguous() and label_ids.dtype == torch.int32 and (label_ids.dim() == 1 or label_ids.shape[0] == B)
+    _chk(lib.mq_box_decode(_ptr(val), _ptr(flat), _ptr(reg), _ptr(anchors), _ptr(label_ids), L if label_ids.dim() == 2 else 0,
+                           _ptr(im_wh), _ptr(boxes), _ptr(scores), _ptr(labels), B, K, HW, L, boxes.shape[1], out_off, _stream()),
+         "mq_box_decode")
 
 
 def ml_nms(boxes, labels, nvalid, thresh):

@@ -35,14 +35,19 @@ def build_synthetic_tokenizer(root, size=30522):
     return path
 
 
-def synthetic_caption(num_classes, start=0, sep=". "):
-    """'obj0. obj1. ...' caption + char spans, the shape create_queries_and_maps builds (engine/inference.py:212-283)."""
-    names = [f"obj{start + i}" for i in range(num_classes)]
-    caption, spans = "", []
-    for i, n in enumerate(names):
-        spans.append((len(caption), len(caption) + len(n)))
-        caption += n
-        if i != len(names) - 1:
+def synthetic_caption(num_classes, start=0, sep=". ", words=(1, 2, 3, 4, 3, 2)):
+    """Synthetic class-name caption + char spans, the shape create_queries_and_maps builds (engine/inference.py:212-283).
+    Class i has words[i % len(words)] words ('obj7 obj8 obj9'), like LVIS names that split into several word pieces: the
+    default gives 2.5 tokens + 1 separator per class = 142 tokens for 40 classes (120-200 tokens
+    for an LVIS chunk); words=(1,) is the 81-token 'obj0. obj1. ...' caption of round 1."""
+    caption, spans, w = "", [], start
+    for i in range(num_classes):
+        n = words[i % len(words)]
+        name = " ".join(f"obj{w + j}" for j in range(n))
+        w += n
+        spans.append((len(caption), len(caption) + len(name)))
+        caption += name
+        if i != num_classes - 1:
             caption += sep
     return caption, spans
 

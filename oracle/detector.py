@@ -3,10 +3,11 @@
 Restates maskrcnn_benchmark/modeling/detector/generalized_vl_rcnn_new.py:291-305 (pooled FPN
 tokens, label -> token maps), :332-455 (eval branch of forward) and
 maskrcnn_benchmark/modeling/query_selector/query_selector.py:40-116 (vision-query selection, eval
-mode: the first min(n, k) bank rows of each label in ascending order, `pad_sequence`, 0/1 mask).
+mode: `sorted(np.random.choice(len, min(len, k), replace=False))` rows of each label, `pad_sequence`, 0/1 mask).
 The reference asserts B == 1 when vision queries are on (:354); like the product we lift it by
 repeating the (identical) caption maps for every image of the batch.
 """
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -48,9 +49,13 @@ def select_queries(bank, batched_labels, batched_maps, k):
         for lab, loc in zip(labels, maps):
             cand = bank[lab]
             n = min(len(cand), k)
-            # reference: sorted(np.random.choice(len, n, replace=False)) -- deterministic only when the
-            # bank holds exactly k rows; otherwise we take the first n rows.
-            q = cand[:n]
+            # reference (:74-78): idx = sorted(np.random.choice(len, n, replace=False)); a `[]` entry of the
+            # defaultdict(list) bank contributes nothing.  The draw is the identity when the bank holds <= k rows.
+            idx = sorted(np.random.choice(len(cand), n, replace=False).tolist())
+            if isinstance(cand, list):
+                assert len(idx) == 0
+                continue
+            q = cand[idx]
             scales = q.shape[1]
             q_img.append(q.flatten(0, 1))
             m_img.append(loc[None].expand(n * scales, -1))
@@ -81,11 +86,12 @@ def forward(sd, spec, images, image_sizes, input_ids, attention_mask, positive_m
         vision, vmask = select_queries(bank, [labels] * B, [amap] * B, spec.num_query_per_class)
         pooled = pooled_fpn_tokens(feats)
     lang = language_backbone(sd, "language_backbone.body", input_ids, attention_mask, vision, pooled, vmask, spec)
-    head = vldyhead(sd, "rpn.head", feats, dict(lang), spec)
+    trace = [] if return_intermediates else None
+    head = vldyhead(sd, "rpn.head", feats, dict(lang), spec, trace=trace)
     anchors = grid_anchors([f.shape[-2:] for f in feats], spec)
     dets = atss_postprocess(head["bbox_reg"], head["centerness"], head["dot_product_logits"], anchors,
                             image_sizes, positive_map, spec)
     if return_intermediates:
-        return dets, {"swin": c, "fpn": feats, "lang": lang, "head": head, "anchors": anchors,
+        return dets, {"swin": c, "fpn": feats, "lang": lang, "head": head, "head_trace": trace, "anchors": anchors,
                       "vision": vision, "vision_mask": vmask, "pooled": pooled}
     return dets

@@ -165,18 +165,23 @@ def dyconv(sd, p, feats, spec):
 
 
 # --------------------------------------------------------------------------- head
-def vldyhead(sd, p, feats, lang, spec):
+def vldyhead(sd, p, feats, lang, spec, trace=None):
     """VLDyHead.forward (vldyhead.py:769-900), eval outputs only.  `p` = 'rpn.head'.
     lang: dict with 'hidden' [B,T,768], 'masks' [B,T] int64.
     Returns bbox_reg[5] (B,4,H,W), centerness[5] (B,1,H,W), dot_product_logits[5] (B,HW,T),
-    plus the tower outputs (visual feats, text hidden) for layer-wise checks."""
+    plus the tower outputs (visual feats, text hidden) for layer-wise checks.  trace: optional list that receives, per
+    fusion layer, {"fuse_feats", "fuse_hidden", "bert_hidden", "dyconv_feats"} (the parity error ladder)."""
     hidden, masks = lang["hidden"], lang["masks"]
     ext = extended_mask(masks)
     for i in range(spec.dyhead_convs):
         t = f"{p}.dyhead_tower"
         feats, hidden = vl_fuse(sd, f"{t}.{3 * i}.b_attn", feats, hidden, masks, spec)
+        rec = {"fuse_feats": feats, "fuse_hidden": hidden}
         hidden = bert_layer(sd, f"{t}.{3 * i + 1}", hidden, ext, spec.bert_heads, spec.bert_eps, clamp=True)
         feats = dyconv(sd, f"{t}.{3 * i + 2}", feats, spec)
+        if trace is not None:
+            rec.update(bert_hidden=hidden, dyconv_feats=feats)
+            trace.append(rec)
     emb = F.normalize(hidden, p=2, dim=-1)
     tok = _lin(sd, p + ".dot_product_projection_text", emb / 2.0)        # [B, T, 256]
     tok_bias = emb @ sd[p + ".bias_lang"] + sd[p + ".bias0"]              # [B, T]

@@ -104,7 +104,7 @@ def gcp_gate_residual(sup, h, w2, x, want_gate=False):
     return (out, gate.reshape(-1)) if want_gate else out
 
 
-def dcn_im2col(x_nhwc, om, stride):
+def _dcn_cols(x_nhwc, om, stride):
     B, H, W, C = x_nhwc.shape
     Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
     n = Ho * Wo
@@ -133,13 +133,16 @@ def dcn_im2col(x_nhwc, om, stride):
 
 def align_scores(dot, tbias, tokidx, ctr, thr, want_cls=False):
     v = (dot.float() + tbias[:, None, :]).clamp(-50000, 50000).sigmoid()
-    L, MT = tokidx.shape
-    cls = torch.zeros(dot.shape[0], dot.shape[1], L)
-    for l in range(L):
-        toks = [int(t) for t in tokidx[l] if int(t) >= 0]
-        if toks:
-            cls[:, :, l] = v[:, :, toks].mean(-1)
-    out = torch.where(cls > thr, cls * ctr.float().sigmoid()[..., None], torch.full_like(cls, -1.0))
+    L, MT = tokidx.shape[-2:]
+    B = dot.shape[0]
+    cls = torch.zeros(B, dot.shape[1], L)
+    for b in range(B):
+        tix = tokidx if tokidx.dim() == 2 else tokidx[b]
+        for l in range(L):
+            toks = [int(t) for t in tix[l] if int(t) >= 0]
+            if toks:
+                cls[b, :, l] = v[b][:, toks].mean(-1)
+    out = torch.where(cls > thr, (cls * ctr.float().sigmoid()[..., None]).clamp(min=1.17549435e-38), torch.full_like(cls, -1.0))
     return (out, cls) if want_cls else out
 
 
@@ -159,7 +162,8 @@ def box_decode(val, flat, reg, anchors, label_ids, im_wh, boxes, scores, labels,
     ok = val > 0
     boxes[:, out_off:out_off + K] = torch.where(ok[..., None], bx, torch.zeros_like(bx))
     scores[:, out_off:out_off + K] = torch.where(ok, val.clamp(min=0).sqrt(), torch.full_like(val, -1.0))
-    labels[:, out_off:out_off + K] = torch.where(ok, label_ids[l], torch.zeros_like(label_ids[l]))
+    lab = label_ids[l] if label_ids.dim() == 1 else torch.gather(label_ids, 1, l)
+    labels[:, out_off:out_off + K] = torch.where(ok, lab, torch.zeros_like(lab))
 
 
 def ml_nms(boxes, labels, nvalid, thresh):
@@ -246,7 +250,7 @@ def conv3x3_nchw32(x_nhwc, w_packed, bias, n_out):
 
 
 def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None):
-    cols, hw = dcn_im2col(x_nhwc.contiguous(), om, stride)
+    cols, hw = _dcn_cols(x_nhwc.contiguous(), om, stride)
     y = F.linear(cols.float(), w_packed.float(), bias.float()).to(x_nhwc.dtype)
     if not want_stats:
         return y, hw
@@ -256,22 +260,32 @@ def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None
     return y, hw, sums
 
 
-def layer_norm(x, gamma, beta, eps=1e-5, transposed_out=False, pad_to=8, residual=None, want_sum=True):
+def layer_norm(x, gamma, beta, eps=1e-5, residual=None, want_sum=True, want_y32=False, want_y=True):
+    """ops.layer_norm: y in the plan's activation dtype (gamma's), y32 fp32, sum fp32 when x or residual is fp32 (else the
+    activation dtype, rounded BEFORE the statistics)."""
+    act = gamma.dtype
+    s = x.float()
+    sum_dt = torch.float32 if x.dtype == torch.float32 else act
     if residual is not None:
-        x = (x.float() + residual.float()).to(x.dtype)
-    y = F.layer_norm(x.float(), (x.shape[-1],), gamma.float(), beta.float(), eps).to(x.dtype)
-    if residual is not None:
-        return (y, x) if want_sum else y
-    if not transposed_out:
-        return y
-    N = x.shape[1]
-    yt = F.pad(y.transpose(1, 2), (0, (-N) % pad_to)).contiguous()
-    return y, yt
+        s = s + residual.float()
+        if residual.dtype == torch.float32:
+            sum_dt = torch.float32
+        if sum_dt != torch.float32:
+            s = s.to(act).float()
+    yf = F.layer_norm(s, (x.shape[-1],), gamma.float(), beta.float(), eps)
+    out = []
+    if want_y:
+        out.append(yf.to(act))
+    if want_y32:
+        out.append(yf)
+    if residual is not None and want_sum:
+        out.append(s.to(sum_dt))
+    return out[0] if len(out) == 1 else tuple(out)
 
 
-def headsum_residual(x, res, bias, heads):
-    C = res.shape[-1]
-    return (res.float() + bias.float() + x.float().reshape(*res.shape[:-1], heads, C).sum(-2)).to(res.dtype)
+def dcnv2_group(branches, want_stats=True):
+    return [dcnv2(br["x"], br["om"], br["w"], br["bias"], br["stride"], want_stats=True, wy=br.get("wy"), wx=br.get("wx"))
+            for br in branches]
 
 
 def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.0):

@@ -41,10 +41,16 @@ def test_query_selector_short_bank_and_ragged_batch():
     qs = QuerySelector(cfg)
     qs.load_query_bank(bank)
     la, lb = list(pm_a), list(pm_b)
+    # label 4 holds more rows than k: like the reference (query_selector.py:74-76) the rows are drawn with
+    # sorted(np.random.choice(len, k, replace=False)) from numpy's global generator -> same seed, same draw
+    import numpy as np
+    np.random.seed(11)
     vision, idx = qs.select([la, lb], [pm_a, pm_b], T, torch.device("cpu"), torch.float32)
     _, amap_a = od.labels_and_maps(pm_a, T)
     _, amap_b = od.labels_and_maps(pm_b, T)
+    np.random.seed(11)
     ref_v, ref_m = od.select_queries(bank, [la, lb], [amap_a, amap_b], k)
+    assert not qs.deterministic(la) and qs.deterministic([1, 2])       # only deterministic selections are memoised
     assert vision.shape == ref_v.shape == (2, k + 2 + k, C)
     assert torch.equal(vision, ref_v)
     for b in range(2):
@@ -53,6 +59,37 @@ def test_query_selector_short_bank_and_ragged_batch():
             got = [i for i in idx[b, t].tolist() if i >= 0]
             assert got == want, (b, t, got, want)
     assert idx.shape[2] == k                                  # widest token owns one label's rows (label 4 capped at k)
+
+
+def test_query_selector_defaultdict_bank_with_empty_labels():
+    """reference banks are `defaultdict(list)` (engine/inference.py:401); a caption label without queries reads
+    as `[]` and contributes no vision rows (query_selector.py:77-78) -- text-only for that label, no exception; a plain
+    dict that lacks the key behaves the same."""
+    from collections import defaultdict
+    cfg = get_cfg()
+    C, k, T = cfg.MODEL.BACKBONE.OUT_CHANNELS, cfg.VISION_QUERY.NUM_QUERY_PER_CLASS, 16
+    g = torch.Generator().manual_seed(4)
+    rows = {2: torch.randn(k, 1, C, generator=g), 7: torch.randn(3, 1, C, generator=g)}
+    pm = {1: [1], 2: [3, 4], 5: [6], 7: [8]}
+    _, amap = od.labels_and_maps(pm, T)
+    for bank in (defaultdict(list, rows), dict(rows)):
+        qs = QuerySelector(cfg)
+        qs.load_query_bank(bank)
+        vision, idx = qs.select([list(pm)], [pm], T, torch.device("cpu"), torch.float32)
+        assert vision.shape == (1, k + 3, C)
+        assert torch.equal(vision[0, :k], rows[2].flatten(0, 1)) and torch.equal(vision[0, k:], rows[7].flatten(0, 1))
+        assert [i for i in idx[0, 1].tolist() if i >= 0] == [] and [i for i in idx[0, 6].tolist() if i >= 0] == []
+        assert [i for i in idx[0, 3].tolist() if i >= 0] == list(range(k)) and [i for i in idx[0, 8].tolist() if i >= 0] == [k, k + 1, k + 2]
+        q, m, has = qs([list(pm)], [amap])
+        assert torch.equal(q, vision) and has == [[0, 1, 0, 1]]
+        if isinstance(bank, defaultdict):                      # the oracle follows the reference on the same bank
+            ref_v, ref_m = od.select_queries(bank, [list(pm)], [amap], k)
+            assert torch.equal(ref_v, vision) and torch.equal(ref_m, m)
+    # a caption none of whose labels has a query -> zero vision rows (the detector then runs text-only)
+    qs = QuerySelector(cfg)
+    qs.load_query_bank(defaultdict(list, rows))
+    v0, i0 = qs.select([[1, 5]], [{1: [1], 5: [2]}], T, torch.device("cpu"), torch.float32)
+    assert v0.shape == (1, 0, C) and int((i0 >= 0).sum()) == 0
 
 
 def test_pyramid_token_views_round_trip():

@@ -21,7 +21,7 @@ def test_c_abi_exports_match_header():
     lib = ops.load_library()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.mq_abi_version() == 14
+    assert lib.mq_abi_version() == 15
     assert lib.mq_attn_workspace_bytes(2, 8, 256, 256, 4) == 4 * 2 * 8 * 256 * 258 * 4
     assert lib.mq_ml_nms_workspace_bytes(2, 130) == 2 * 130 * 3 * 8
 
@@ -95,11 +95,16 @@ def test_tokenizer_and_positive_map():
     from transformers import AutoTokenizer
     from mq_det_amd.utils.tokenizer import build_synthetic_tokenizer, synthetic_caption, positive_map_from_spans
     tk = AutoTokenizer.from_pretrained(build_synthetic_tokenizer(tempfile.mkdtemp(), size=3000))
-    cap, spans = synthetic_caption(40)
+    cap, spans = synthetic_caption(40, words=(1,))                     # round-1 caption: one token per class
     pm = positive_map_from_spans(tk, cap, spans, list(range(1, 41)))
     assert len(pm) == 40 and pm[1] == [1] and pm[2] == [3]
     t = tk([cap], max_length=256, padding="max_length", return_tensors="pt", truncation=True)
     assert t["input_ids"].shape == (1, 256) and t["input_ids"][0, 0] == 101 and int(t["attention_mask"].sum()) == 81
+    cap, spans = synthetic_caption(40)                                  # default: 1-4 word names, LVIS-chunk length
+    pm = positive_map_from_spans(tk, cap, spans, list(range(1, 41)))
+    assert len(pm) == 40 and pm[1] == [1] and pm[2] == [3, 4] and pm[4] == [10, 11, 12, 13]
+    t = tk([cap], max_length=256, padding="max_length", return_tensors="pt", truncation=True)
+    assert 120 <= int(t["attention_mask"].sum()) <= 200
 
 
 def test_gloo_world2_detection_gather():
@@ -111,3 +116,31 @@ def test_gloo_world2_detection_gather():
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("GATHER_OK") == 2
+
+
+def test_ctypes_signatures_match_header():
+    """every `_SIGNATURES` entry of mq_det_amd/ops.py has the argument kinds of its declaration in
+    include/mqdet_hip.h (pointer / int / long / float, in order) -- parsed from the header text."""
+    import ctypes
+    import re
+    from mq_det_amd import ops
+    text = open(os.path.join(ROOT, "include", "mqdet_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"typedef struct.*?}\s*\w+;", " ", text, flags=re.S)
+    decls = dict((m.group(2), (m.group(1), m.group(3))) for m in re.finditer(r"\b(int|long)\s+(mq_\w+)\s*\(([^)]*)\)\s*;", text))
+    assert set(decls) == set(ops._SIGNATURES), set(decls) ^ set(ops._SIGNATURES)
+
+    def kind(arg):
+        arg = arg.strip()
+        if arg in ("void", ""):
+            return None
+        if "*" in arg:
+            return ctypes.c_void_p
+        base = arg.replace("const", "").split()
+        ty = " ".join(base[:-1]) if len(base) > 1 else base[0]
+        return {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float}[ty]
+    for name, (ret, args) in decls.items():
+        want = [k for k in (kind(a) for a in args.split(",")) if k is not None]
+        res, got = ops._SIGNATURES[name]
+        assert got == want, (name, got, want)
+        assert res == {"int": ctypes.c_int, "long": ctypes.c_long}[ret], name

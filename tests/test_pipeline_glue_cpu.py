@@ -38,8 +38,8 @@ def setup():
 @pytest.fixture()
 def emulated_ops(monkeypatch):
     fake = types.SimpleNamespace(**{n: getattr(emu, n) for n in (
-        "attention", "attention4", "window_attention", "gcp_sparse_attention", "gcp_gate_residual", "dcn_im2col", "align_scores",
-        "dyconv_branch_coef", "dyconv_fuse", "dyrelu_", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "headsum_residual", "vlfuse_i2t", "vlfuse_t2i",
+        "attention", "attention4", "window_attention", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores",
+        "dyconv_branch_coef", "dyconv_fuse", "dyrelu_", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "vlfuse_i2t", "vlfuse_t2i",
         "box_decode", "ml_nms")})
     monkeypatch.setattr(pipeline, "ops", fake)
     return fake
