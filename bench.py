@@ -5,16 +5,32 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one `model(images, captions, positive_map)` forward (Swin -> FPN -> BERT+GCP -> VLDyHead -> ATSS
-post-processing to list[BoxList]) on a batch of 8 synthetic 800x1333 images per GPU (BASELINE.json configs[1]:
-MQ-GLIP-T, 5 vision queries per class, 40-class caption, fp16), inputs resident in HBM, followed (N > 1) by
-the fixed-shape RCCL all-gather of the detections.  Weak scaling: per-GPU batch is fixed.
-Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant hand-written kernel, timed
-live with HIP events on the launch stream) and, at N = 1, `cpu_baseline` (the CPU oracle on a bounded sample).
+Default workload = BASELINE.json configs[1]: one "step" = one `model(images, captions, positive_map)` forward (Swin -> FPN ->
+BERT+GCP -> VLDyHead -> ATSS post-processing to list[BoxList]) on a batch of 8 synthetic 800x1333 images per GPU, MQ-GLIP-T,
+5 vision queries per class, a 40-class caption of 141 tokens (the length of an LVIS chunk caption), fp16 operands, inputs
+resident in HBM, followed (N > 1) by the fixed-shape RCCL all-gather of the detections.  Weak scaling: per-GPU batch fixed.
+EVERY step computes the whole forward: the per-image feature cache and the per-caption language cache of the boundary
+ are switched OFF for this workload -- the synthetic loop re-sends the same tensors, and skipping the
+backbone would be work skipped inside the timed region.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline       the hand-written kernel that takes the most time per step (timed live with HIP events on the launch stream)
+  rooflines      the same record for every hot hand-written kernel: MFMA-bound (TFLOP/s vs 2.5 PFLOP/s dense fp16) with the
+                 ALGORITHMIC and the EXECUTED flop counts side by side, HBM-bound (algorithmic GB/s vs 8 TB/s)
+  lang_path_b64  north-star target line: the language path (12 BERT + 6 GCP + pre-select) at B = 64 on one GPU, with the
+                 MFMA utilisation of its attention kernels
+  cpu_baseline   (N = 1) BASELINE.md section 3 / configs[0]: the fp32 CPU oracle, GLIP-T without vision queries, one 800x1333
+                 image, 20-token caption, 2 warm-up + 5 timed forwards, median.
+
+    --workload lvis   BASELINE.json configs[2] shape on this many GPUs: 1203 synthetic categories -> 31 chunk captions of
+                      <= 40 classes, each step = a NEW batch of images x 31 forwards (the LVIS protocol of
+                      engine/inference.py:605-625) with the boundary's caches ON; value = forwards/s, plus LVIS-style
+                      images/s = forwards/s / 31.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import tempfile
 import time
@@ -27,13 +43,14 @@ sys.path.insert(0, ROOT)
 B_PER_GPU = 8
 IMG_HW = (800, 1333)
 NUM_CLASSES_IN_CAPTION = 40
+LEVELS = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
 # algorithmic work of one image-forward (2*MAC), BASELINE.md section 2 / SURVEY.md 8(d)
 GFLOP_PER_IMAGE = 1451.0
 MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
 
-def build_model(dev, full=True):
+def build_model(dev, caches=False, n_classes=NUM_CLASSES_IN_CAPTION, n_categories=None):
     from transformers import AutoTokenizer
     from mq_det_amd import get_cfg
     from mq_det_amd.modeling.detector import GeneralizedVLRCNN_New
@@ -44,55 +61,65 @@ def build_model(dev, full=True):
     cfg.MODEL.DYHEAD.NUM_CLASSES = 1204
     cfg.MODEL.ATSS.DETECTIONS_PER_IMG = 300
     cfg.TEST.MDETR_STYLE_AGGREGATE_CLASS_NUM = 3000
-    if os.environ.get("MQ_FUSED_DCN") is not None:     # A/B switch between the two DCNv2 implementations (same results)
-        cfg.MODEL.DYHEAD.FUSED_DCN = os.environ["MQ_FUSED_DCN"] == "1"
+    cfg.MODEL.BACKBONE_CACHE = bool(caches)
+    if os.environ.get("MQ_RESIDUAL_FP32") is not None:        # A/B switch (precision of the residual streams)
+        cfg.MODEL.RESIDUAL_FP32 = os.environ["MQ_RESIDUAL_FP32"] == "1"
     tok_dir = build_synthetic_tokenizer(tempfile.mkdtemp(prefix="mqdet_tok_"))
     cfg.MODEL.LANGUAGE_BACKBONE.TOKENIZER_TYPE = tok_dir
     tk = AutoTokenizer.from_pretrained(tok_dir)
     model = GeneralizedVLRCNN_New(cfg, tokenizer=tk)
     randomize_(model, seed=0)
-    caption, spans = synthetic_caption(NUM_CLASSES_IN_CAPTION)
-    pmap = positive_map_from_spans(tk, caption, spans, list(range(1, NUM_CLASSES_IN_CAPTION + 1)))
-    model.load_query_bank(synthetic_bank(pmap.keys(), cfg.MODEL.BACKBONE.OUT_CHANNELS, cfg.VISION_QUERY.NUM_QUERY_PER_CLASS))
+    chunks = []
+    n_categories = n_categories or n_classes
+    for c0 in range(0, n_categories, n_classes):            # chunk captions (engine/inference.py:190-192)
+        n = min(n_classes, n_categories - c0)
+        caption, spans = synthetic_caption(n, start=3 * c0)
+        chunks.append((caption, positive_map_from_spans(tk, caption, spans, list(range(c0 + 1, c0 + n + 1)))))
+    model.load_query_bank(synthetic_bank(range(1, n_categories + 1), cfg.MODEL.BACKBONE.OUT_CHANNELS, cfg.VISION_QUERY.NUM_QUERY_PER_CLASS))
     model.to(dev)
     model.prepare(dev)
-    return cfg, model, caption, pmap
+    return cfg, model, chunks
 
 
 CPU_BASELINE_THREADS = 32      # the oracle's many small torch ops stop scaling (and can crawl) far below 256 threads
 
 
 def _cpu_baseline_worker():
-    """CPU oracle (pure-PyTorch fp32 restatement of the reference; the reference itself has no CPU path) on
-    one 800x1333 image, a few forwards (bounded sample)."""
+    """BASELINE.md section 3 (configs[0]): the CPU oracle (pure-PyTorch fp32 restatement of the reference; the reference
+    itself has no CPU path) as GLIP-T WITHOUT vision queries on one 800x1333 image with a 20-token caption; 2 warm-up +
+    5 timed forwards, median.  A bounded sample: ~45 s of CPU work."""
     from oracle import glip_t_spec
     from oracle import detector as od
-    from oracle.weights import make_state_dict, make_query_bank
+    from oracle.weights import make_state_dict
     threads = min(os.cpu_count() or 1, CPU_BASELINE_THREADS)
     torch.set_num_threads(threads)
-    spec = glip_t_spec()
+    spec = glip_t_spec(vision_query=False)
     sd = make_state_dict(spec, 0)
     g = torch.Generator().manual_seed(0)
     images, sizes = od.pad_images([torch.randn(3, *IMG_HW, generator=g)], 32)
     T = spec.max_query_len
-    nvalid = 2 * NUM_CLASSES_IN_CAPTION + 1
+    nvalid = 20
     ids = torch.zeros(1, T, dtype=torch.long)
     ids[:, :nvalid] = torch.randint(1000, spec.vocab, (nvalid,), generator=g)
     am = torch.zeros(1, T, dtype=torch.long)
     am[:, :nvalid] = 1
-    pm = {i + 1: [1 + 2 * i] for i in range(NUM_CLASSES_IN_CAPTION)}
-    bank = make_query_bank(pm.keys(), spec)
-    n_fwd = 3                      # ~20 s of CPU work on the GPU box's host
-    t = time.time()
-    for _ in range(n_fwd):
-        od.forward(sd, spec, images, sizes, ids, am, pm, bank)
-    dt = time.time() - t
-    print(json.dumps({"value": round(n_fwd / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port",
-                      "sample": f"{n_fwd} forwards of the fp32 CPU oracle on one 800x1333 image (padded 800x1344), {dt:.1f} s, "
-                                f"{threads} torch threads on a {os.cpu_count()}-core host"}), flush=True)
+    pm = {1: [1], 2: [3], 3: [5, 6], 4: [8], 5: [10, 11], 6: [13]}          # SURVEY.md 8(d) config 1
+    times = []
+    t_all = time.time()
+    for i in range(7):
+        t = time.time()
+        od.forward(sd, spec, images, sizes, ids, am, pm, None)
+        if i >= 2:
+            times.append(time.time() - t)
+    med = statistics.median(times)
+    print(json.dumps({"value": round(1.0 / med, 4), "unit": "images/sec", "cores": threads, "kind": "port",
+                      "median_s_per_forward": round(med, 3),
+                      "sample": f"GLIP-T (no vision queries), one 800x1333 image (padded 800x1344), 20-token caption; 2 warm-up + "
+                                f"5 timed forwards of the fp32 CPU oracle, median; {time.time() - t_all:.1f} s in total, {threads} torch "
+                                f"threads on a {os.cpu_count()}-core host"}), flush=True)
 
 
-def cpu_baseline(timeout=300):
+def cpu_baseline(timeout=420):
     """Run the worker in a subprocess with a hard time limit so the default bench run stays bounded."""
     import subprocess
     env = dict(os.environ, OMP_NUM_THREADS=str(CPU_BASELINE_THREADS), MKL_NUM_THREADS=str(CPU_BASELINE_THREADS),
@@ -108,13 +135,145 @@ def cpu_baseline(timeout=300):
         return {"error": f"cpu baseline worker exceeded {timeout} s", "cores": CPU_BASELINE_THREADS, "kind": "port"}
 
 
+def _mfma(kernel, flops_alg, flops_exec, n_launch, ms, note, traffic=None):
+    ach = flops_alg / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "avg_launch_ms": round(ms / max(n_launch, 1), 4),
+            "launches_per_step": n_launch, "ms_per_step": round(ms, 3),
+            "flops_per_step": {"algorithmic": flops_alg, "executed": flops_exec},
+            "executed_tflops": round(flops_exec / (ms * 1e-3) / 1e12, 2), "note": note}
+
+
+def _hbm(kernel, nbytes, n_launch, ms, note):
+    ach = nbytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(ms / max(n_launch, 1), 4),
+            "launches_per_step": n_launch, "ms_per_step": round(ms, 3), "algorithmic_bytes_per_step": nbytes, "note": note}
+
+
+def kernel_rooflines(kern, steps, Bn, n_tok):
+    """kern: ops.stop_timing() of `steps` eager single-stream forwards -> per-kernel roofline records (per step)."""
+    N_img = sum(h * w for h, w in LEVELS)
+    per = {k: (v[0] / steps, v[1] / steps, v[2] / steps) for k, v in kern.items()}
+    out = []
+    # ---- DCNv2 (grouped launch, dcn_fused.hip).  Algorithmic = executed: 2 * positions * (9 * 256) * 256 per DyConv layer,
+    # positions = 33600 / image (same-level + stride-2 + level+1 branches, vldyhead.py:205-247) -- SURVEY.md 8(d) 42.4 GF/layer
+    if "dcnv2_fused" in per:
+        n, ms, _ = per["dcnv2_fused"]
+        pos = sum(h * w for h, w in LEVELS) + 2 * sum(h * w for h, w in LEVELS[1:])
+        fl = n * 2.0 * pos * Bn * 2304 * 256
+        out.append(_mfma("dcn_igemm8_kernel (DCNv2: bilinear gather + blend + MFMA + GroupNorm statistics, 13 branches of a DyConv "
+                         "layer per launch)", fl, fl, n, ms, "flops = 2 * 33600 * B * 2304 * 256 per layer (SURVEY.md 8d: 42.4 GF / image / layer)"))
+    # ---- VLFuse attention (vlfuse_attn.hip), 8 heads x 256.  SURVEY.md 8(d) / fuse_helper.py:233 compute QK^T ONCE and two
+    # PV products: algorithmic = 3 * 2 * B * 8 * N * T_vis * 256 per layer with T_vis = the 64-key tiles that hold caption
+    # tokens.  The two kernels each recompute the logits (executed = 4 * ...); the text side only computes 128-row query tiles.
+    i2t = [v for k, v in per.items() if k.startswith("vlfuse_i2t_n%d_" % N_img)]
+    t2i = [v for k, v in per.items() if k.startswith("vlfuse_t2i_n%d_" % N_img)]
+    if i2t and t2i:
+        nk_vis = min(256, -(-n_tok // 64) * 64)
+        tq_live = min(256, -(-n_tok // 128) * 128)
+        n_l = i2t[0][0]
+        ex = n_l * 4.0 * Bn * 8 * N_img * 256 * nk_vis + t2i[0][0] * 4.0 * Bn * 8 * N_img * 256 * tq_live
+        alg = n_l * 6.0 * Bn * 8 * N_img * 256 * nk_vis
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_vlfuse.json")
+        if os.path.exists(pmc):                 # PMC passes are separate rocprofv3 runs (see profiles/README.md)
+            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch_avg")
+        out.append(_mfma("vlfuse_i2t_kernel + vlfuse_t2i_kernel (VLFuse image<->text attention)", alg, ex, n_l + t2i[0][0],
+                         i2t[0][1] + t2i[0][1], f"algorithmic = QK^T once + 2 PV over {nk_vis} visited text keys (SURVEY.md 8d); executed = "
+                         f"each direction recomputes QK^T ({nk_vis} keys image side, {tq_live} query rows text side); traffic: PMC of round 1",
+                         traffic))
+    # ---- generic attention kernel (BERT self-attention 12 x 64; GCP pre-select 8 x 32): QK^T + PV over the visited keys
+    att = [(k, v) for k, v in per.items() if k.startswith("attn_d")]
+    if att:
+        fl = 0.0
+        for k, (n, ms, _) in att:
+            d, nq, nk = (int(x[1:] if x[0] == "d" else x[2:]) for x in k.split("_")[1:4])
+            heads = 12 if d == 64 else 8
+            nk_eff = min(nk, -(-n_tok // 64) * 64) if d == 64 else nk
+            fl += n * 4.0 * Bn * heads * nq * nk_eff * d
+        out.append(_mfma("attn_fwd_kernel (BERT self-attention 12 x 64, T = 256; GCP pre-select 8 x 32 over 5577 image tokens)", fl, fl,
+                         sum(v[0] for _, v in att), sum(v[1] for _, v in att), "flops = 4 * B * heads * Nq * Nk_visited * D"))
+    # ---- HBM-bound kernels: algorithmic bytes (every input read once, every output written once) / time
+    groups = (("layernorm_kernel (all LayerNorms, residual add fused)", "layernorm_c"), ("window_attn_kernel (Swin W-MSA / SW-MSA)", "window_attn_c"),
+              ("dyconv_fuse_kernel (GroupNorm affine + up-sampling + scale attention + branch mean)", "dyconv_fuse"),
+              ("dyrelu_apply_kernel", "dyrelu_apply"), ("conv3x3_small_kernel (27-channel DyConv offset conv)", "conv3x3_small"),
+              ("align_scores_kernel (sigmoid + token->class mean + threshold)", "align_scores"))
+    for name, prefix in groups:
+        sel = [v for k, v in per.items() if k.startswith(prefix)]
+        if sel:
+            out.append(_hbm(name, sum(v[2] for v in sel), sum(v[0] for v in sel), sum(v[1] for v in sel),
+                            "algorithmic bytes = inputs read once + outputs written once"))
+    return out
+
+
+def lang_path_b64(model, cfg, dev, chunks, iters=5):
+    """North-star target line (BASELINE.json: ">= 40 % MFMA utilisation on the fused GCP+BERT attention at bs = 64 / GPU"):
+    the language path -- embeddings, 12 BERT layers, GCP pre-select (2 layers over the 5577 pooled image tokens) and the
+    6 gated cross-attention blocks -- at B = 64 on ONE GPU, eager single stream, HIP events.  Reports the whole path and,
+    separately, its attention kernels (BERT 12 x 64, pre-select 8 x 32, GCP sparse) with the flop formula used."""
+    from mq_det_amd import ops
+    from mq_det_amd.modeling import pipeline
+    from mq_det_amd.modeling.query_selector import build_token_index  # noqa: F401
+    Bn = 64
+    P = model._plan
+    caption, pmap = chunks[0]
+    ids, am, max_kv = model.tokenize([caption] * Bn, dev)
+    n_tok = int(am[0].sum())
+    labels = [k for k, v in pmap.items() if len(v)]
+    pm_key = tuple((k, tuple(pmap[k])) for k in labels)
+    dtype = P["backbone.body.patch_embed.proj.weight"].dtype
+    vision, idx = model.query_selector.select_cached(pm_key, labels, pmap, Bn, ids.shape[1], dev, dtype)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    pooled = torch.randn(Bn, 5577, 256, generator=g).to(dev, dtype)
+    streams_on = cfg.MODEL.DYHEAD.LEVEL_STREAMS
+    cfg.MODEL.DYHEAD.LEVEL_STREAMS = False
+    try:
+        for _ in range(2):
+            pipeline.language_backbone(P, cfg, ids, am, vision, pooled, idx)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            pipeline.language_backbone(P, cfg, ids, am, vision, pooled, idx)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_path = e0.elapsed_time(e1) / iters
+        ops.start_timing()
+        for _ in range(iters):
+            pipeline.language_backbone(P, cfg, ids, am, vision, pooled, idx)
+        kern = ops.stop_timing()
+    finally:
+        cfg.MODEL.DYHEAD.LEVEL_STREAMS = streams_on
+    nk_vis = min(256, -(-n_tok // 64) * 64)
+    V, S = vision.shape[1], idx.shape[2]
+    fl_bert = 12 * 4.0 * Bn * 12 * 256 * nk_vis * 64
+    fl_pre = 2 * 4.0 * Bn * 8 * V * 5577 * 32
+    fl_gcp = 6 * 4.0 * Bn * 8 * 256 * S * 64
+    att_ms = sum(v[1] for k, v in kern.items() if k.startswith("attn_d") or k.startswith("gcp_sparse")) / iters
+    att_tf = (fl_bert + fl_pre + fl_gcp) / (att_ms * 1e-3) / 1e12
+    # whole language path: SURVEY.md 8(d) per image BERT 45.9 + pre-select 7.5 + GCP 29.9 GF
+    path_tf = Bn * (45.9 + 7.5 + 29.9) * 1e9 / (ms_path * 1e-3) / 1e12
+    return {"batch": Bn, "ms_language_path": round(ms_path, 3), "language_path_tflops": round(path_tf, 1),
+            "language_path_frac_of_mfma_peak": round(path_tf / MFMA_PEAK_TFLOPS, 4),
+            "attention_kernels_ms": round(att_ms, 3), "attention_tflops": round(att_tf, 1),
+            "attention_mfma_utilisation": round(att_tf / MFMA_PEAK_TFLOPS, 4), "target": 0.40,
+            "flops": {"bert_self_attention": fl_bert, "gcp_pre_select": fl_pre, "gcp_sparse": fl_gcp,
+                      "formula": f"12 x 4*B*12*256*{nk_vis}*64 + 2 x 4*B*8*{V}*5577*32 + 6 x 4*B*8*256*{S}*64, B = {Bn} "
+                                 f"({nk_vis} = visited text keys of the {n_tok}-token caption)"},
+            "kernels_ms": {k: round(v[1] / iters, 3) for k, v in sorted(kern.items())},
+            "timing": "eager, single stream, HIP events; attention = the attn_fwd / gcp_sparse launches only"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lang-b64", action="store_true")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
+    ap.add_argument("--workload", choices=["mq-glip-t", "lvis"], default="mq-glip-t")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (for PMC profiling)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -130,7 +289,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ops.load_library()
-    cfg, model, caption, pmap = build_model(dev)
+    lvis = args.workload == "lvis"
+    cfg, model, chunks = build_model(dev, caches=lvis, n_categories=1203 if lvis else None)
     if args.no_graph:
         model.use_hip_graph = False
 
@@ -140,15 +300,27 @@ def main():
     Hp, Wp = -(-H // 32) * 32, -(-W // 32) * 32
     imgs = torch.zeros(Bn, 3, Hp, Wp)
     imgs[:, :, :H, :W] = torch.randn(Bn, 3, H, W, generator=g)
-    images = ImageList(imgs.to(dev), [(H, W)] * Bn)
+    imgs = imgs.to(dev)
+    images = ImageList(imgs, [(H, W)] * Bn)
+    caption, pmap = chunks[0]
     captions = [caption] * Bn
-    K = cfg.MODEL.ATSS.DETECTIONS_PER_IMG
+    n_tok = int(model.tokenize(captions, dev)[1][0].sum())
 
-    def step():
-        out = model(images, captions=captions, positive_map=pmap)
-        if world > 1:
-            parallel.gather_detections(model.last_packed)       # [world*B, 300, 6], one fixed-shape collective
-        return out
+    if lvis:
+        def step():
+            # a NEW batch of pixels every step (the clone is the "data loader"), then every chunk caption for it
+            il = ImageList(imgs.clone(), [(H, W)] * Bn)
+            for cap, pm in chunks:
+                out = model(il, captions=[cap] * Bn, positive_map=pm)
+                if world > 1:
+                    parallel.gather_detections(model.last_packed)
+            return out
+    else:
+        def step():
+            out = model(images, captions=captions, positive_map=pmap)
+            if world > 1:
+                parallel.gather_detections(model.last_packed)       # [world*B, 300, 6], one fixed-shape collective
+            return out
 
     for _ in range(max(args.warmup, 2)):        # >= 2: first call autotunes eagerly, second captures the HIP graph
         step()
@@ -166,10 +338,11 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
+    stats = dict(model.cache_stats)
     # per-kernel durations: HIP events around the launches (same kernels, same inputs) in a short EAGER pass --
     # inside a graph replay individual launches cannot be bracketed by events
     kern, prof_steps = {}, 0
-    if rank == 0:
+    if rank == 0 and not lvis:
         prof_steps = min(3, args.steps)
         # single-stream for this pass: with the level / text streams active, concurrent kernels share the CUs and an
         # event-bracketed duration would include its neighbours (the timed region above keeps the multi-stream schedule)
@@ -185,58 +358,48 @@ def main():
             cfg.MODEL.DYHEAD.LEVEL_STREAMS = streams_on
 
     if rank == 0:
-        ips = world * Bn * args.steps / dt
-        # dominant hand-written kernels: the two VLFuse attention kernels (image side / text side, 6 + 6 launches / forward;
-        # the text-side time includes its split-merge launch).
-        # Algorithmic FLOPs per launch = QK^T + PV = 4 * B * heads * Nq * Nk * 256 (2*MAC each), DESIGN.md section 3.
-        # Image->text launches only visit the key tiles that hold real caption tokens (padding is masked to an exact
-        # zero contribution and skipped), so their work is counted with the visited keys, not with T = 256.
-        N_img = sum(h * w for h, w in [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)])
-        n_tok = int(model.tokenize(captions, dev)[1][0].sum())
-        nk_vis = min(256, -(-n_tok // 64) * 64)
-        # Text->image launches only compute the 128-row query tiles that hold real caption tokens (all-padding tiles are
-        # skipped and come back as zeros), so their work is counted with those rows only.
-        tq_live = min(256, -(-n_tok // 128) * 128)
-        fl = {"i2t": 4.0 * Bn * 8 * N_img * nk_vis * 256, "t2i": 4.0 * Bn * 8 * tq_live * N_img * 256}
-        roof = None
-        i2t = [v for k, v in kern.items() if k.startswith("vlfuse_i2t_n%d_" % N_img)]
-        t2i = [v for k, v in kern.items() if k.startswith("vlfuse_t2i_n%d_" % N_img)]
-        if i2t and t2i:
-            n_l = i2t[0][0] + t2i[0][0]
-            ms = i2t[0][1] + t2i[0][1]
-            flops = i2t[0][0] * fl["i2t"] + t2i[0][0] * fl["t2i"]
-            ach = flops / (ms * 1e-3) / 1e12
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_vlfuse.json")
-            if os.path.exists(pmc):                 # PMC passes are separate rocprofv3 runs (see profiles/README.md)
-                traffic = json.load(open(pmc)).get("traffic_bytes_per_launch_avg")
-            roof = {"bound": "mfma", "kernel": "vlfuse_i2t_kernel + vlfuse_t2i_kernel (VLFuse image<->text attention, 8 heads x 256)",
-                    "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                    "traffic": traffic, "avg_launch_ms": round(ms / n_l, 4), "launches": n_l,
-                    "flops_per_launch": {"image_to_text": fl["i2t"], "text_to_image": fl["t2i"], "visited_text_keys": nk_vis, "computed_text_rows": tq_live},
-                    "per_direction_tflops": {"image_to_text": round(fl["i2t"] * i2t[0][0] / (i2t[0][1] * 1e-3) / 1e12, 1),
-                                             "text_to_image": round(fl["t2i"] * t2i[0][0] / (t2i[0][1] * 1e-3) / 1e12, 1)},
-                    "timing": "HIP events on the launch stream around each launch, eager pass of the same steps"}
+        fwd_per_step = len(chunks) if lvis else 1
+        ips = world * Bn * args.steps * fwd_per_step / dt
+        roofs = kernel_rooflines(kern, max(prof_steps, 1), Bn, n_tok) if kern else []
+        hot = [r for r in roofs if r["bound"] == "mfma"]
+        roof = max(hot, key=lambda r: r["ms_per_step"]) if hot else None
         res = {
-            "metric": "images/sec MQ-GLIP-T 800\u00d71333 5-shot vision queries, 1/2/4/8 MI355X", "value": round(ips, 3), "unit": "images/sec",
+            "metric": "images/sec MQ-GLIP-T 800×1333 5-shot vision queries, 1/2/4/8 MI355X", "value": round(ips, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: MQ-GLIP-T (Swin-T + BERT-base + GCP + 6-layer VLDyHead), "
-                                   "5 vision queries x 40 classes, caption padded to 256 tokens, LVIS-style post-processing",
+            "config": {"workload": ("BASELINE.json configs[1]: MQ-GLIP-T (Swin-T + BERT-base + GCP + 6-layer VLDyHead), 5 vision queries x "
+                                    f"40 classes, {n_tok}-token caption padded to 256, LVIS-style post-processing, every step a full forward "
+                                    "(feature / caption caches off)") if not lvis else
+                                   ("BASELINE.json configs[2] shape: MQ-GLIP-T, LVIS protocol -- 1203 synthetic categories in 31 chunk captions, "
+                                    "each step = a new image batch x 31 forwards with the boundary's per-image feature cache and per-caption "
+                                    "language cache ON; value counts FORWARDS (image x chunk) per second"),
                        "global_batch": world * Bn, "batch_per_gpu": Bn, "image": "800x1333 -> 800x1344",
-                       "parallelism": f"dp{world}", "weights": "seeded random init (no checkpoints offline)"},
-            "model_tflops": round(ips * GFLOP_PER_IMAGE / 1e3, 2),
-            "model_frac_of_mfma_peak": round(ips * GFLOP_PER_IMAGE / 1e3 / (MFMA_PEAK_TFLOPS * world), 4),
+                       "parallelism": f"dp{world}", "weights": "seeded random init (no checkpoints offline)",
+                       "residual_streams": "fp32" if cfg.MODEL.get("RESIDUAL_FP32", True) else "fp16"},
             "detections_img0": len(out[0]),
-            "roofline": roof,
-            "kernels_ms_per_step": {k: round(v[1] / max(prof_steps, 1), 3) for k, v in sorted(kern.items())},
             "hip_graph": bool(model.use_hip_graph and any(e.get("stage") == 2 for e in model._graphs.values())),
+            "cache_stats": stats,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                res["cpu_baseline"] = cpu_baseline()
-            except Exception as e:  # noqa: BLE001
-                res["cpu_baseline"] = {"error": repr(e)[:200]}
+        if lvis:
+            res["forwards_per_step"] = fwd_per_step
+            res["lvis_style_images_per_sec"] = round(ips / fwd_per_step, 3)
+        else:
+            res["model_tflops"] = round(ips * GFLOP_PER_IMAGE / 1e3, 2)
+            res["model_frac_of_mfma_peak"] = round(ips * GFLOP_PER_IMAGE / 1e3 / (MFMA_PEAK_TFLOPS * world), 4)
+            res["roofline"] = roof
+            res["rooflines"] = roofs
+            res["kernels_ms_per_step"] = {k: round(v[1] / max(prof_steps, 1), 3) for k, v in sorted(kern.items())}
+            res["timing"] = "roofline records: HIP events on the launch stream around each launch, eager single-stream pass of the same steps"
+            if world == 1 and not args.no_lang_b64:
+                try:
+                    res["lang_path_b64"] = lang_path_b64(model, cfg, dev, chunks)
+                except Exception as e:  # noqa: BLE001
+                    res["lang_path_b64"] = {"error": repr(e)[:300]}
+            if world == 1 and not args.no_cpu_baseline:
+                try:
+                    res["cpu_baseline"] = cpu_baseline()
+                except Exception as e:  # noqa: BLE001
+                    res["cpu_baseline"] = {"error": repr(e)[:200]}
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.barrier()

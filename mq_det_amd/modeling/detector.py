@@ -302,7 +302,10 @@ class GeneralizedVLRCNN_New(nn.Module):
             cap_key = None
         T = input_ids.shape[1]
 
-        # host-side glue: all memoised, no device sync
+        # host-side glue: all memoised, no device sync.  Token positions that the tokenizer's truncation to MAX_QUERY_LEN cut
+        # away cannot be scored (the reference indexes a [L, T] map with them, generalized_vl_rcnn_new.py:295-305): dropped
+        if any(t >= T for v in positive_map.values() for t in (v if not isinstance(v, int) else [v])):
+            positive_map = {k: [t for t in (v if not isinstance(v, int) else [v]) if t < T] for k, v in positive_map.items()}
         labels_in_caption = [k for k, v in positive_map.items() if len(v) != 0]
         pm_key = tuple((k, tuple(positive_map[k])) for k in labels_in_caption)
         vision = idx = None

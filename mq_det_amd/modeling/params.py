@@ -37,6 +37,26 @@ def cell_anchor(stride, size):
     return torch.tensor([[c - half, c - half, c + half, c + half]], dtype=torch.float32)
 
 
+def bert_vocab_size(cfg):
+    """Word-embedding rows of the BERT language backbone.  The reference takes them from HF
+    `BertConfig.from_pretrained(MODEL.LANGUAGE_BACKBONE.MODEL_TYPE)` (bert_model_new.py:24: bert-base-uncased = 30522), NOT
+    from its `LANGUAGE_BACKBONE.VOCAB_SIZE` key (defaults.py:285, the RNN language model's, default 0).  Same here: a local
+    MODEL_TYPE directory with a config.json is read like `from_pretrained` would; the product-only override key is
+    BERT_VOCAB_SIZE (tests with small vocabularies)."""
+    import json
+    import os
+    LB = cfg.MODEL.LANGUAGE_BACKBONE
+    if LB.get("BERT_VOCAB_SIZE", 0):
+        return int(LB.BERT_VOCAB_SIZE)
+    for key in ("MODEL_TYPE", "TOKENIZER_TYPE"):
+        cj = os.path.join(str(LB.get(key, "")), "config.json")
+        if os.path.isfile(cj):
+            v = json.load(open(cj)).get("vocab_size")
+            if v:
+                return int(v)
+    return 30522
+
+
 def param_specs(cfg):
     """Yield (name, shape, kind) for every parameter / buffer.  kind: w (weight, fan-in scaled),
     b (zero), one, zero, table, buf:<tag>."""
@@ -89,7 +109,7 @@ def param_specs(cfg):
     H = LB.LANG_DIM
     inter = 4 * H
     p = "language_backbone.body.model"
-    yield p + ".embeddings.word_embeddings.weight", (LB.get("VOCAB_SIZE", 30522), H), "emb"
+    yield p + ".embeddings.word_embeddings.weight", (bert_vocab_size(cfg), H), "emb"
     yield p + ".embeddings.position_embeddings.weight", (512, H), "emb"
     yield p + ".embeddings.token_type_embeddings.weight", (2, H), "emb"
     yield p + ".embeddings.LayerNorm.weight", (H,), "one"

@@ -79,20 +79,23 @@ def start_timing():
 
 
 def stop_timing():
-    """-> {tag: (launches, total_ms)}; synchronises."""
+    """-> {tag: (launches, total_ms, algorithmic_bytes)}; synchronises."""
     global _TIMING
     rec, _TIMING = _TIMING or [], None
     torch.cuda.synchronize()
     out = {}
-    for tag, a, b in rec:
-        n, t = out.get(tag, (0, 0.0))
-        out[tag] = (n + 1, t + a.elapsed_time(b))
+    for tag, a, b, nb in rec:
+        n, t, by = out.get(tag, (0, 0.0, 0))
+        out[tag] = (n + 1, t + a.elapsed_time(b), by + nb)
     return out
 
 
 class _timed:
-    def __init__(self, tag):
-        self.tag = tag
+    """HIP events on the launch stream around one launch; nbytes = the launch's ALGORITHMIC HBM bytes (inputs read once +
+    outputs written once) for the HBM-bound kernels' GB/s in bench.py."""
+
+    def __init__(self, tag, nbytes=0):
+        self.tag, self.nbytes = tag, nbytes
 
     def __enter__(self):
         if _TIMING is not None:
@@ -103,7 +106,7 @@ class _timed:
         if _TIMING is not None:
             b = torch.cuda.Event(enable_timing=True)
             b.record()
-            _TIMING.append((self.tag, self.a, b))
+            _TIMING.append((self.tag, self.a, b, int(self.nbytes)))
 
 
 def _ptr(t):
@@ -188,7 +191,7 @@ def window_attention(qkv, qkv_bias, rel_bias, heads, ws, shift):
         rel_bias = pad_rel_bias(rel_bias)
     assert rel_bias.dtype == torch.float32 and rel_bias.is_contiguous() and rel_bias.shape == (heads, 64, 64)
     out = torch.empty(B, H, W, C, dtype=torch.float16, device=qkv.device)
-    with _timed(f"window_attn_c{C}"):
+    with _timed(f"window_attn_c{C}", qkv.numel() * 2 + out.numel() * 2):
         _chk(lib.mq_window_attn_fwd(_ptr(qkv), _ptr(qkv_bias), _ptr(rel_bias), _ptr(out), B, H, W, C, heads, ws, shift,
                                     _stream()), "mq_window_attn_fwd")
     return out
@@ -203,8 +206,9 @@ def gcp_sparse_attention(q, kv, idx, heads=8, dim_head=64):
     assert q.is_contiguous() and kv.is_contiguous() and idx.is_contiguous() and idx.dtype == torch.int32
     assert q.dtype == kv.dtype == torch.float16 and kv.shape[2] == 2 * HD
     out = torch.empty_like(q)
-    _chk(lib.mq_gcp_sparse_attn_fwd(_ptr(q), _ptr(kv), _ptr(idx), _ptr(out), B, T, V, S, heads, dim_head, _stream()),
-         "mq_gcp_sparse_attn_fwd")
+    with _timed(f"gcp_sparse_attn_s{S}", q.numel() * 4 + kv.numel() * 2):
+        _chk(lib.mq_gcp_sparse_attn_fwd(_ptr(q), _ptr(kv), _ptr(idx), _ptr(out), B, T, V, S, heads, dim_head, _stream()),
+             "mq_gcp_sparse_attn_fwd")
     return out
 
 
@@ -290,7 +294,7 @@ def layer_norm(x, gamma, beta, eps=1e-5, residual=None, want_sum=True, want_y32=
         rf = residual.dtype == torch.float32
         if want_sum:
             xsum = torch.empty(x.shape, dtype=torch.float32 if (xf or rf) else torch.float16, device=x.device)
-    with _timed(f"layernorm_c{C}"):
+    with _timed(f"layernorm_c{C}", sum(t.numel() * t.element_size() for t in (x, residual, y, y32, xsum) if t is not None)):
         _chk(lib.mq_layernorm_fwd(_ptr(x), int(xf), _ptr(residual), int(rf), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(y32), _ptr(xsum),
                                   rows, C, float(eps), _stream()), "mq_layernorm_fwd")
     out = [t for t in (y, y32, xsum) if t is not None]
@@ -323,7 +327,7 @@ def conv3x3_nchw32(x_nhwc, w_packed, bias, n_out):
     assert x_nhwc.dtype == torch.float16 and x_nhwc.stride(3) == 1 and x_nhwc.stride(2) == C and x_nhwc.stride(1) == W * C
     assert w_packed.is_contiguous() and w_packed.shape == (32, 9 * C) and w_packed.dtype == torch.float16 and n_out <= 32
     out = torch.empty(B, n_out, H, W, dtype=torch.float32, device=x_nhwc.device)
-    with _timed("conv3x3_small"):
+    with _timed("conv3x3_small", B * H * W * C * 2 + out.numel() * 4):
         _chk(lib.mq_conv3x3_nchw32_fwd(_ptr(x_nhwc), _ptr(w_packed), _ptr(bias), _ptr(out), B, H, W, C, x_nhwc.stride(0), n_out,
                                        _stream()), "mq_conv3x3_nchw32_fwd")
     return out
@@ -434,7 +438,7 @@ def dyconv_fuse(branches, H, W, out=None):
             args += [_ptr(y), _ptr(cf), hs, ws]
         else:
             args += [_ptr(None), _ptr(None), 0, 0]
-    with _timed("dyconv_fuse"):
+    with _timed("dyconv_fuse", sum(b_[0].numel() * 2 for b_ in branches) + out.shape[0] * out.shape[1] * C * 2):
         _chk(lib.mq_dyconv_fuse(*args, len(branches), _ptr(out), out.stride(0), _ptr(pool), B, H, W, C, _stream()), "mq_dyconv_fuse")
     return out, pool
 
@@ -448,7 +452,7 @@ def dyrelu_(x, pool, w0, b0, w2, b2):
     coef = torch.empty(B, 4, C, dtype=torch.float32, device=x.device)
     _chk(lib.mq_dyrelu_coef(_ptr(pool), _ptr(w0), _ptr(b0), _ptr(w2), _ptr(b2), _ptr(coef), B, n, C, _stream()),
          "mq_dyrelu_coef")
-    with _timed("dyrelu_apply"):
+    with _timed("dyrelu_apply", 2 * B * n * C * 2):
         _chk(lib.mq_dyrelu_apply(_ptr(x), _ptr(coef), B, n, C, x.stride(0), _stream()), "mq_dyrelu_apply")
     return x
 
@@ -466,9 +470,10 @@ def align_scores(dot, tbias, tokidx, ctr, thr, want_cls=False):
     assert tokidx.dim() == 2 or tokidx.shape[0] == B
     out = torch.empty(B, HW, L, dtype=torch.float32, device=dot.device)
     cls = torch.empty_like(out) if want_cls else None
-    _chk(lib.mq_align_scores_fwd(_ptr(dot), int(dot.dtype == torch.float32), _ptr(tbias), _ptr(tokidx),
-                                 L * MT if tokidx.dim() == 3 else 0, _ptr(ctr), _ptr(out), _ptr(cls), B, HW, T, L, MT,
-                                 float(thr), dot.stride(0), _stream()), "mq_align_scores_fwd")
+    with _timed("align_scores", B * HW * T * dot.element_size() + out.numel() * 4):
+        _chk(lib.mq_align_scores_fwd(_ptr(dot), int(dot.dtype == torch.float32), _ptr(tbias), _ptr(tokidx),
+                                     L * MT if tokidx.dim() == 3 else 0, _ptr(ctr), _ptr(out), _ptr(cls), B, HW, T, L, MT,
+                                     float(thr), dot.stride(0), _stream()), "mq_align_scores_fwd")
     return (out, cls) if want_cls else out
 
 

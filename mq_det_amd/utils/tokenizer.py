@@ -10,11 +10,12 @@ import os
 import string
 
 
-def synthetic_vocab(size=30522):
+def synthetic_vocab(size=30522, extra_words=()):
     vocab = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"]
     vocab += [f"[unused{i}]" for i in range(99, 99 + 1000 - len(vocab))]
     vocab += list(string.punctuation) + list(string.digits) + list(string.ascii_lowercase)
     vocab += ["##" + c for c in string.digits + string.ascii_lowercase]
+    vocab += [w for w in dict.fromkeys(extra_words) if w not in vocab]           # whole words (e.g. real category names)
     i = 0
     while len(vocab) < size:
         vocab.append(f"obj{i}")
@@ -22,12 +23,12 @@ def synthetic_vocab(size=30522):
     return vocab[:size]
 
 
-def build_synthetic_tokenizer(root, size=30522):
+def build_synthetic_tokenizer(root, size=30522, extra_words=()):
     """Creates <root>/bert-base-uncased/{vocab.txt,tokenizer_config.json} and returns that path."""
     path = os.path.join(root, "bert-base-uncased")
     os.makedirs(path, exist_ok=True)
     with open(os.path.join(path, "vocab.txt"), "w") as f:
-        f.write("\n".join(synthetic_vocab(size)) + "\n")
+        f.write("\n".join(synthetic_vocab(size, extra_words)) + "\n")
     with open(os.path.join(path, "tokenizer_config.json"), "w") as f:
         json.dump({"do_lower_case": True, "tokenizer_class": "BertTokenizer", "model_max_length": 512}, f)
     with open(os.path.join(path, "config.json"), "w") as f:

@@ -183,3 +183,45 @@ def reference_cfg(*yaml_files):
     for f in yaml_files:
         cfg.merge_from_file(REF + "/" + f)
     return cfg
+
+
+def reference_functions(rel_path, names, extra_globals=None):
+    """Execute selected top-level function definitions of a reference source file IN PLACE (nothing is copied), without
+    importing the module around them -- e.g. the caption / positive-map builders of engine/inference.py, whose module
+    imports the dataset stack.  Returns {name: function}."""
+    import ast
+    import os
+    import re
+    from collections import defaultdict
+
+    import torch
+    path = REF + "/" + rel_path
+    src = open(path).read()
+    tree = ast.parse(src)
+    want = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    missing = set(names) - {n.name for n in want}
+    if missing:
+        raise KeyError(f"{rel_path}: no top-level function(s) {sorted(missing)}")
+    mod = ast.Module(body=want, type_ignores=[])
+    glb = {"re": re, "os": os, "torch": torch, "defaultdict": defaultdict}
+    glb.update(extra_globals or {})
+    exec(compile(mod, path, "exec"), glb)
+    return {n: glb[n] for n in names}
+
+
+def reference_classes(rel_path, class_names, function_names=(), extra_globals=None):
+    """Like reference_functions, for top-level classes (plus helper functions they call) of a reference source file."""
+    import ast
+    import os
+    import re
+    from collections import defaultdict
+
+    import torch
+    path = REF + "/" + rel_path
+    tree = ast.parse(open(path).read())
+    want = [n for n in tree.body if (isinstance(n, ast.ClassDef) and n.name in class_names)
+            or (isinstance(n, ast.FunctionDef) and n.name in function_names)]
+    glb = {"re": re, "os": os, "torch": torch, "defaultdict": defaultdict}
+    glb.update(extra_globals or {})
+    exec(compile(ast.Module(body=want, type_ignores=[]), path, "exec"), glb)
+    return {n: glb[n] for n in list(class_names) + list(function_names)}

@@ -39,7 +39,7 @@ def test_model_refuses_cpu_and_training():
     cfg.MODEL.SWINT.DEPTHS = (2, 2, 2, 2)
     cfg.MODEL.LANGUAGE_BACKBONE.NUM_HIDDEN_LAYERS = 2
     cfg.MODEL.LANGUAGE_BACKBONE.QV_START = 1
-    cfg.MODEL.LANGUAGE_BACKBONE.VOCAB_SIZE = 1100
+    cfg.MODEL.LANGUAGE_BACKBONE.BERT_VOCAB_SIZE = 1100
     cfg.MODEL.DYHEAD.NUM_CONVS = 1
     model = build_detection_model(cfg, tokenizer=object())
     with pytest.raises(RuntimeError, match="MI355X only"):
@@ -116,6 +116,19 @@ def test_gloo_world2_detection_gather():
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("GATHER_OK") == 2
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="compares with reference code executed in place")
+def test_gloo_world2_evaluator_gather_matches_reference():
+    """per-category top-k accumulation + cross-rank gather as tensors == the reference's LvisEvaluatorFixedAP
+    (update / _merge_lists / synchronize_between_processes over its pickling all_gather), 2 gloo processes."""
+    script = os.path.join(ROOT, "tests", "_gloo_eval_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", script],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("EVAL_GATHER_OK") == 2
 
 
 def test_ctypes_signatures_match_header():

@@ -27,7 +27,7 @@ def setup():
     cfg.MODEL.SWINT.DEPTHS = spec.swin_depths
     cfg.MODEL.LANGUAGE_BACKBONE.NUM_HIDDEN_LAYERS = spec.bert_layers
     cfg.MODEL.LANGUAGE_BACKBONE.QV_START = spec.qv_start
-    cfg.MODEL.LANGUAGE_BACKBONE.VOCAB_SIZE = spec.vocab
+    cfg.MODEL.LANGUAGE_BACKBONE.BERT_VOCAB_SIZE = spec.vocab
     cfg.MODEL.DYHEAD.NUM_CONVS = spec.dyhead_convs
     cfg.MODEL.DYHEAD.NUM_CLASSES = spec.num_classes
     cfg.MODEL.ATSS.DETECTIONS_PER_IMG = spec.detections_per_img
