@@ -177,6 +177,18 @@ int mq_box_decode(const float* val, const long* flat, const void* reg, const flo
                   const float* im_wh, float* boxes, float* scores, int* labels, int B, int K, int HW, int L,
                   long out_stride, long out_off, void* stream);
 
+/* ROIAlign (legacy and aligned) -- the box pooler of the vision-query extraction path.
+ *   feat: element (n, c, y, x) at feat + n*sn + c*sc + y*sh + x*sw (element strides; fp16, or fp32 when feat_f32 != 0),
+ *   rois [R,5] fp32 (batch index, x1, y1, x2, y2), out [R,C,PH,PW] fp32 -- or [R,C] = mean over the PH*PW bins when
+ *   reduce_mean != 0 (what extract_query keeps).  sampling_ratio <= 0: adaptive ceil(roi / bins) samples per bin.
+ *   aligned != 0: torchvision's aligned=True (box shifted by -0.5 after scaling, no 1x1 minimum size).
+ * Replaces _C.roi_align_forward (maskrcnn_benchmark/csrc/cuda/ROIAlign_cuda.cu:16-123,262-306; layers/roi_align.py:13-57)
+ *   and torchvision.ops.roi_align as called by ROIAlignV2 (layers/roi_align.py:71-81) inside Pooler / CustomPooler
+ *   (modeling/poolers.py:45-168), used by GeneralizedVLRCNN_New.extract_query (generalized_vl_rcnn_new.py:232-288). */
+int mq_roi_align_fwd(const void* feat, int feat_f32, const float* rois, float* out, int R, int C, int H, int W,
+                     long sn, long sc, long sh, long sw, int PH, int PW, float spatial_scale, int sampling_ratio,
+                     int aligned, int reduce_mean, void* stream);
+
 /* Class-aware NMS on score-sorted boxes, mask + sweep entirely on the device.
  *   boxes [B,N,4] fp32 (sorted by score desc per image), labels [B,N] int32, nvalid [B] int32 -> keep [B,N] uint8.
  * Replaces _C.ml_nms: maskrcnn_benchmark/csrc/ml_nms.h:10-27, csrc/cuda/ml_nms.cu:15-149 (vision.cpp:23). */

@@ -17,8 +17,23 @@ from torch import nn
 
 from ..structures import BoxList, to_image_list
 from . import pipeline
+from .poolers import CustomPooler, Pooler
 from .params import Container, build_param_tree
 from .query_selector import QuerySelector, labels_and_maps, build_token_index
+
+
+def expand_bbox(box_list, expand_ratio=1.5):
+    """generalized_vl_rcnn_new.py:32-49: grow every box about its centre, clip to the image, drop empty boxes."""
+    out = []
+    for boxes in box_list:
+        assert boxes.mode == "xyxy"
+        bbox = boxes.bbox
+        w, h = bbox[:, 2] - bbox[:, 0], bbox[:, 3] - bbox[:, 1]
+        dw, dh = (w * expand_ratio - w) / 2, (h * expand_ratio - h) / 2
+        nb = BoxList(bbox + torch.stack([-dw, -dh, dw, dh], dim=1), boxes.size, mode="xyxy")
+        nb.add_field("labels", boxes.get_field("labels"))
+        out.append(nb.clip_to_image(remove_empty=True))
+    return out
 
 
 class GeneralizedVLRCNN_New(nn.Module):
@@ -29,6 +44,11 @@ class GeneralizedVLRCNN_New(nn.Module):
             self.add_module(name, Container())
         build_param_tree(self, cfg)
         self.roi_heads = None                                     # RPN_ONLY (roi_heads/__init__.py:64-84)
+        # box pooler of the query-extraction path (generalized_vl_rcnn_new.py:107-121)
+        RB = cfg.MODEL.ROI_BOX_HEAD
+        pool_cls = Pooler if cfg.VISION_QUERY.SELECT_FPN_LEVEL else CustomPooler
+        self.pooler = pool_cls(output_size=(RB.POOLER_RESOLUTION, RB.POOLER_RESOLUTION), scales=RB.POOLER_SCALES,
+                               sampling_ratio=RB.POOLER_SAMPLING_RATIO, use_v2=True)
         self.query_selector = None if cfg.VISION_QUERY.DISABLE_SELECTOR else QuerySelector(cfg)
         self.tokenizer = tokenizer if tokenizer is not None else self._load_tokenizer(cfg)
         self._plan = None
@@ -102,8 +122,51 @@ class GeneralizedVLRCNN_New(nn.Module):
     def load_query_bank(self, query_path):
         self.query_selector.load_query_bank(query_path)
 
-    def extract_query(self, *a, **k):
-        raise NotImplementedError("vision-query extraction (ROIAlign pooler) is a 'next' row, SURVEY.md 8f")
+    @torch.no_grad()
+    def extract_query(self, images=None, targets=None, query_images=None, visual_features=None, exclude_similar=False,
+                      device=None, max_query_number=None):
+        """Vision-query extraction (generalized_vl_rcnn_new.py:232-288; callers: tools/extract_vision_query.py via
+        tools/train_net.py:303, engine/inference.py:474,492 `online_update`).  targets: list[BoxList] (xyxy, field
+        "labels") per image; query_images: the bank being built, `{label: Tensor[n, scales, C]}` (a `defaultdict(list)` in
+        the reference); visual_features: FPN maps from `forward(..., return_backbone_features=True)`, or None -> Swin + FPN run
+        here on `images`.  Boxes are grown by VISION_QUERY.EXPAND_RATIO, pooled with the aligned ROIAlign (HIP kernel, the
+        7 x 7 bins averaged inside the kernel) from their FPN level (SELECT_FPN_LEVEL) or from all five, and appended to
+        the bank of their label up to `max_query_number`, optionally skipping near-duplicates (cosine > SIMILARITY_THRESHOLD)."""
+        cfg = self.cfg
+        device = torch.device(device) if device else (images.tensors.device if images is not None else visual_features[0].device)
+        targets = expand_bbox([t.to(device) for t in targets if t is not None], expand_ratio=cfg.VISION_QUERY.EXPAND_RATIO)
+        if visual_features is None:
+            images = to_image_list(images)
+            if self._plan is None or self._plan_key != images.tensors.device:
+                self.prepare(images.tensors.device)
+            dtype = self._plan["backbone.body.patch_embed.proj.weight"].dtype
+            x = images.tensors.to(dtype).contiguous(memory_format=torch.channels_last)
+            visual_features, _ = self._backbone_stage(x)
+        else:
+            visual_features = [v.to(device) for v in visual_features]
+        query_feats = self.pooler(visual_features, targets, reduce_mean=True)      # [boxes, C] or [scales, boxes, C]
+        if cfg.VISION_QUERY.SELECT_FPN_LEVEL:
+            query_feats = query_feats[None]
+        else:
+            assert len(visual_features) == len(query_feats) == 5
+        query_feats = query_feats.permute(1, 0, 2)                                  # boxes, scales, channels
+        labels = torch.cat([t.get_field("labels") for t in targets])
+        assert len(labels) == len(query_feats)
+        max_query_number = cfg.VISION_QUERY.MAX_QUERY_NUMBER if max_query_number is None else max_query_number
+        thr = cfg.VISION_QUERY.SIMILARITY_THRESHOLD
+        for label, feat in zip(labels.tolist(), query_feats):
+            cur = query_images[label] if (label in query_images or hasattr(query_images, "default_factory")) else []
+            n = len(cur)
+            if n >= max_query_number:
+                continue
+            if exclude_similar and n > 0:
+                assert feat.shape[0] == 1
+                bank = torch.nn.functional.normalize(cur.to(feat), p=2, dim=-1)
+                new = torch.nn.functional.normalize(feat, p=2, dim=-1)
+                if (torch.einsum("bnd,nd->bn", bank, new) > thr).sum() > 0:
+                    continue
+            query_images[label] = feat[None] if n == 0 else torch.cat([cur.to(feat), feat[None]])
+        return query_images
 
     def flatten_fpn_features(self, features):
         return pipeline.pooled_fpn_tokens(features)

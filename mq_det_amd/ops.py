@@ -36,6 +36,7 @@ _SIGNATURES = {
     "mq_dyrelu_apply": (_i, [_vp, _vp, _i, _i, _i, _l, _vp]),
     "mq_align_scores_fwd": (_i, [_vp, _i, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _l, _vp]),
     "mq_box_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _vp]),
+    "mq_roi_align_fwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _f, _i, _i, _i, _vp]),
     "mq_ml_nms_workspace_bytes": (_l, [_i, _i]),
     "mq_ml_nms": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
 }
@@ -490,6 +491,23 @@ def box_decode(val, flat, reg, anchors, label_ids, im_wh, boxes, scores, labels,
     _chk(lib.mq_box_decode(_ptr(val), _ptr(flat), _ptr(reg), _ptr(anchors), _ptr(label_ids), L if label_ids.dim() == 2 else 0,
                            _ptr(im_wh), _ptr(boxes), _ptr(scores), _ptr(labels), B, K, HW, L, boxes.shape[1], out_off, _stream()),
          "mq_box_decode")
+
+
+def roi_align(feat, rois, output_size, spatial_scale, sampling_ratio, aligned=True, reduce_mean=False):
+    """feat [N,C,H,W] (any strides -- the product's pyramid levels are NHWC memory viewed as NCHW; fp16 or fp32),
+    rois [R,5] fp32 (batch index, x1, y1, x2, y2) -> [R,C,PH,PW] fp32, or [R,C] (mean over the bins) when reduce_mean."""
+    lib = load_library()
+    _need_gpu(feat, rois)
+    N, C, H, W = feat.shape
+    PH, PW = (output_size, output_size) if isinstance(output_size, int) else output_size
+    assert feat.dtype in (torch.float16, torch.float32) and rois.dtype == torch.float32 and rois.shape[1] == 5
+    rois = rois.contiguous()
+    R = rois.shape[0]
+    out = torch.empty((R, C) if reduce_mean else (R, C, PH, PW), dtype=torch.float32, device=feat.device)
+    _chk(lib.mq_roi_align_fwd(_ptr(feat), int(feat.dtype == torch.float32), _ptr(rois), _ptr(out), R, C, H, W, feat.stride(0),
+                              feat.stride(1), feat.stride(2), feat.stride(3), PH, PW, float(spatial_scale), int(sampling_ratio),
+                              int(bool(aligned)), int(bool(reduce_mean)), _stream()), "mq_roi_align_fwd")
+    return out
 
 
 def ml_nms(boxes, labels, nvalid, thresh):

@@ -318,3 +318,10 @@ def vlfuse_t2i(kf, v_ln, nsplit, clamp=50000.0, kv_len=None):
         dead = (torch.arange(T)[None, :] // 128) * 128 >= kv_len.clamp(1, T)[:, None]
         o = o.masked_fill(dead[:, :, None, None], 0.0)
     return o.reshape(B, T, 8 * C).to(kf.dtype)
+
+
+def roi_align(feat, rois, output_size, spatial_scale, sampling_ratio, aligned=True, reduce_mean=False):
+    """Test-only stand-in: the oracle's ROIAlign on the same (strided) feature view."""
+    from oracle import roi as oroi
+    out = oroi.roi_align(feat.float().contiguous(), rois.float(), output_size, spatial_scale, sampling_ratio, aligned)
+    return out.mean((-1, -2)) if reduce_mean else out

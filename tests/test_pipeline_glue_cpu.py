@@ -40,7 +40,7 @@ def emulated_ops(monkeypatch):
     fake = types.SimpleNamespace(**{n: getattr(emu, n) for n in (
         "attention", "attention4", "window_attention", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores",
         "dyconv_branch_coef", "dyconv_fuse", "dyrelu_", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "vlfuse_i2t", "vlfuse_t2i",
-        "box_decode", "ml_nms")})
+        "box_decode", "ml_nms", "roi_align")})
     monkeypatch.setattr(pipeline, "ops", fake)
     return fake
 
@@ -115,3 +115,32 @@ def test_gcp_index_matches_reference_topk_trick(setup):
     assert torch.equal(ref.int(), idx)
     q, m, _ = qs([labels] * 2, [amap] * 2)
     assert torch.equal(m, vmask) and torch.equal(q, vision)
+
+
+def test_extract_query_host_logic(setup, emulated_ops, monkeypatch):
+    """Pooler / LevelMapper / expand_bbox / bank update of GeneralizedVLRCNN_New.extract_query (host logic; the ROIAlign
+    kernel is emulated) vs the oracle's restatement of generalized_vl_rcnn_new.py:232-288, level-selecting pooler."""
+    from collections import defaultdict
+    from oracle import backbone as ob, roi as oroi
+    from mq_det_amd import ops as real_ops
+    from mq_det_amd.modeling import poolers
+    from mq_det_amd.modeling.detector import GeneralizedVLRCNN_New
+    spec, sd, cfg, P = setup
+    monkeypatch.setattr(poolers, "ops", emulated_ops)
+    model = GeneralizedVLRCNN_New(cfg, tokenizer=object())
+    sizes = [(640, 800), (600, 720)]                          # big enough for boxes on several FPN levels
+    g = torch.Generator().manual_seed(9)
+    feats = [torch.randn(2, 256, -(-640 // s), -(-800 // s), generator=g) for s in (8, 16, 32, 64, 128)]
+    bl, tup = pc._query_targets(sizes)
+    RB = cfg.MODEL.ROI_BOX_HEAD
+    pool = (RB.POOLER_RESOLUTION, tuple(RB.POOLER_SCALES), RB.POOLER_SAMPLING_RATIO)
+    ref = oroi.extract_query(feats, tup, {}, pool, select_fpn_level=True, expand_ratio=cfg.VISION_QUERY.EXPAND_RATIO)
+    got = model.extract_query(targets=bl, query_images=defaultdict(list), visual_features=feats, device="cpu")
+    assert sorted(got) == sorted(ref)
+    for lab in ref:
+        assert got[lab].shape == ref[lab].shape and got[lab].shape[1:] == (1, 256)
+        close(got[lab], ref[lab], 1e-5)
+    # boxes land on more than one FPN level (the test is vacuous otherwise)
+    from mq_det_amd.modeling.detector import expand_bbox
+    lv = model.pooler.map_levels(expand_bbox(bl, cfg.VISION_QUERY.EXPAND_RATIO))
+    assert len(set(lv.tolist())) >= 2
