@@ -99,6 +99,19 @@ int mq_vlfuse_t2i_fwd(const void* kf, const void* v_ln, const int* kv_len, void*
 int mq_layernorm_fwd(const void* x, int x_f32, const void* res, int res_f32, const void* gamma, const void* beta, void* y,
                      float* y32, void* xsum, long rows, int C, float eps, void* stream);
 
+/* MLP half of a Swin block in one kernel (LayerNorm prologue, fc1, exact GELU, fc2, residual; the 4C-wide hidden activation
+ * stays in registers), C in {96, 192, 384}:
+ *   x' = x + delta;  out = x' + fc2(gelu(fc1(LN(x'; ln_g, ln_b, eps))));  y = LN(out; next_g, next_b, eps_next) (optional)
+ *   x [M,C] fp32 (residual stream), delta [M,C] fp16 or NULL, w1 [4C,C], b1 [4C], b2 [C] fp16, w2p [C,4C] fp16 = fc2.weight
+ *   with the k-slots of every 32-block permuted (slot 8g+t <- hidden 4g+t for t < 4, 16+4g+t-4 for t >= 4: the transposed
+ *   GEMM chain hands its accumulators to the second MFMA as B-fragments), out [M,C] fp32, y [M,C] fp16 or NULL.
+ *   Returns -1 for other C (callers fall back to library GEMMs).
+ * Replaces SwinTransformerBlock's  x = x + drop_path(mlp(norm2(x)))  (backbone/swint.py:238-240, Mlp :13-31) and, through
+ *   `y`, the following block's norm1 (:198) or the stage's output norm (:611). */
+int mq_swin_mlp_fwd(const float* x, const void* delta, const void* ln_g, const void* ln_b, float eps, const void* w1,
+                    const void* b1, const void* w2p, const void* b2, float* out, const void* next_g, const void* next_b,
+                    float eps_next, void* y, long M, int C, void* stream);
+
 /* 3x3 convolution (pad 1, stride 1|2) and DCNv2 (modulated deformable 3x3) as one implicit-GEMM MFMA kernel,
  * NHWC fp16, fp32 accumulation over the whole K = 9*C in a fixed order (bitwise reproducible).
  *   x [B,H,W,C] (batch stride x_bs elements, C % 32 == 0), w [Npad, 9*C] fp16 with k = tap*C + c (Npad = 32 if

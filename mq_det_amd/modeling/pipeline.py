@@ -46,6 +46,15 @@ def build_plan(sd, cfg, device, dtype=torch.float16):
             idx = sd[b + ".relative_position_index"].to(device).reshape(-1)
             rel = f32(b + ".relative_position_bias_table")[idx].reshape(N, N, heads).permute(2, 0, 1)
             P[b + ".rel_bias"] = F.pad(rel, (0, 64 - N, 0, 64 - N)).contiguous()        # [heads, 64, 64], see ops.pad_rel_bias
+    # Swin MLP halves that run as one fused kernel (mq_swin_mlp_fwd): fc2.weight with the k-slots of every 32-block permuted
+    P["_swin_fused_mlp"] = bool(M.SWINT.get("FUSED_MLP", True)) and P["_r32"]
+    for i, depth in enumerate(M.SWINT.DEPTHS):
+        Ci = M.SWINT.EMBED_DIM * 2 ** i
+        if P["_swin_fused_mlp"] and Ci in ops.SWIN_MLP_WIDTHS:
+            perm = ops.swin_mlp_w2_perm(4 * Ci, device)
+            for j in range(depth):
+                b = f"backbone.body.layers.{i}.blocks.{j}.mlp.fc2"
+                P[b + ".w2p"] = h(b + ".weight")[:, perm].contiguous()
     # convs: channels_last weights
     for k in list(P):
         if torch.is_tensor(P[k]) and P[k].dim() == 4:
@@ -178,19 +187,37 @@ def swin_forward(P, cfg, img):
     outs = []
     for i, (depth, heads) in enumerate(zip(M.DEPTHS, M.NUM_HEADS)):
         C = x.shape[-1]
+        fused = P["_swin_fused_mlp"] and C in ops.SWIN_MLP_WIDTHS and x.dtype == torch.float32
         pend = None                                    # MLP output whose residual add is fused into the next LayerNorm
+        h1 = None                                      # norm1 of the current block when the previous fused MLP produced it
         for j in range(depth):
             b = f"{p}.layers.{i}.blocks.{j}"
             shift = 0 if j % 2 == 0 else ws // 2
-            if pend is None:
-                h1 = _ln(P, b + ".norm1", x)
-            else:
-                h1, x = _add_ln(P, b + ".norm1", pend, x)                                   # x = x + mlp(...)  (swint.py:240)
+            if h1 is None:
+                if pend is None:
+                    h1 = _ln(P, b + ".norm1", x)
+                else:
+                    h1, x = _add_ln(P, b + ".norm1", pend, x)                               # x = x + mlp(...)  (swint.py:240)
             qkv = _lin(P, b + ".attn.qkv", h1).reshape(B, H, W, 3 * C)
             a = ops.window_attention(qkv, P[b + ".attn.qkv.bias"], P[b + ".attn.rel_bias"], heads, ws, shift)
-            h2, x = _add_ln(P, b + ".norm2", _lin(P, b + ".attn.proj", a.reshape(B, H * W, C)), x)   # x = x + attn(...)  (:236)
-            pend = _lin(P, b + ".mlp.fc2", F.gelu(_lin(P, b + ".mlp.fc1", h2)))
-        if i > 0:
+            proj = _lin(P, b + ".attn.proj", a.reshape(B, H * W, C))
+            if fused:
+                # one kernel: x += proj (swint.py:236); x += fc2(gelu(fc1(norm2(x)))) (:240); and the LayerNorm that reads
+                # the result next (the following block's norm1, or the stage's output norm :611)
+                nxt = f"{p}.layers.{i}.blocks.{j + 1}.norm1" if j + 1 < depth else (f"{p}.norm{i}" if i > 0 else None)
+                r = ops.swin_mlp(x.contiguous(), proj.contiguous(), P[b + ".norm2.weight"], P[b + ".norm2.bias"], 1e-5,
+                                 P[b + ".mlp.fc1.weight"], P[b + ".mlp.fc1.bias"], P[b + ".mlp.fc2.w2p"], P[b + ".mlp.fc2.bias"],
+                                 next_ln=None if nxt is None else (P[nxt + ".weight"], P[nxt + ".bias"], 1e-5))
+                x, h1 = r if nxt is not None else (r, None)
+                pend = None
+            else:
+                h2, x = _add_ln(P, b + ".norm2", proj, x)                                   # x = x + attn(...)  (:236)
+                pend = _lin(P, b + ".mlp.fc2", F.gelu(_lin(P, b + ".mlp.fc1", h2)))
+                h1 = None
+        if fused:
+            if i > 0:
+                outs.append(h1.reshape(B, H, W, C))                                         # = norm{i}(x), from the last fused MLP
+        elif i > 0:
             o, x = _add_ln(P, f"{p}.norm{i}", pend, x)
             outs.append(o.reshape(B, H, W, C))
         else:

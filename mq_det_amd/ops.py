@@ -24,6 +24,7 @@ _SIGNATURES = {
     "mq_vlfuse_t2i_workspace_bytes": (_l, [_i, _i, _i]),
     "mq_vlfuse_t2i_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mq_layernorm_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
+    "mq_swin_mlp_fwd": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _l, _i, _vp]),
     "mq_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _vp]),
     "mq_conv3x3_nchw32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _vp]),
     "mq_dcnv2_stats_blocks": (_i, [_i, _i, _i]),
@@ -300,6 +301,39 @@ def layer_norm(x, gamma, beta, eps=1e-5, residual=None, want_sum=True, want_y32=
                                   rows, C, float(eps), _stream()), "mq_layernorm_fwd")
     out = [t for t in (y, y32, xsum) if t is not None]
     return out[0] if len(out) == 1 else tuple(out)
+
+
+SWIN_MLP_WIDTHS = (96, 192, 384)
+
+
+def swin_mlp_w2_perm(K, device=None):
+    """Index tensor of the k-slot permutation mq_swin_mlp_fwd expects for fc2.weight: w2p = w2[:, perm]."""
+    k = torch.arange(K, device=device)
+    blk, slot = k >> 5, k & 31
+    g, t = slot >> 3, slot & 7
+    return blk * 32 + torch.where(t < 4, 4 * g + t, 16 + 4 * g + (t - 4))
+
+
+def swin_mlp(x, delta, ln_g, ln_b, eps, w1, b1, w2p, b2, next_ln=None):
+    """Fused Swin MLP half (mq_swin_mlp_fwd).  x [..., C] fp32 residual stream, delta (same shape, fp16) or None ->
+    out fp32 = x' + fc2(gelu(fc1(LN(x')))), x' = x + delta; next_ln = (gamma, beta, eps) -> also y = LN(out) fp16."""
+    lib = load_library()
+    _need_gpu(x, delta, ln_g, ln_b, w1, b1, w2p, b2)
+    C = x.shape[-1]
+    M = x.numel() // C
+    assert C in SWIN_MLP_WIDTHS and x.dtype == torch.float32 and x.is_contiguous()
+    assert delta is None or (delta.dtype == torch.float16 and delta.is_contiguous() and delta.shape == x.shape)
+    assert w1.shape == (4 * C, C) and w2p.shape == (C, 4 * C) and w1.is_contiguous() and w2p.is_contiguous()
+    assert w1.dtype == w2p.dtype == b1.dtype == b2.dtype == ln_g.dtype == torch.float16
+    out = torch.empty_like(x)
+    y, ng, nb, ne = None, None, None, 0.0
+    if next_ln is not None:
+        ng, nb, ne = next_ln
+        y = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    with _timed(f"swin_mlp_c{C}", M * C * (4 + 4 + (2 if delta is not None else 0) + (2 if y is not None else 0))):
+        _chk(lib.mq_swin_mlp_fwd(_ptr(x), _ptr(delta), _ptr(ln_g), _ptr(ln_b), float(eps), _ptr(w1), _ptr(b1), _ptr(w2p), _ptr(b2),
+                                 _ptr(out), _ptr(ng), _ptr(nb), float(ne), _ptr(y), M, C, _stream()), "mq_swin_mlp_fwd")
+    return (out, y) if y is not None else out
 
 
 def conv3x3(x_nhwc, w_packed, bias, n_out, stride=1):

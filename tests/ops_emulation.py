@@ -325,3 +325,21 @@ def roi_align(feat, rois, output_size, spatial_scale, sampling_ratio, aligned=Tr
     from oracle import roi as oroi
     out = oroi.roi_align(feat.float().contiguous(), rois.float(), output_size, spatial_scale, sampling_ratio, aligned)
     return out.mean((-1, -2)) if reduce_mean else out
+
+
+def swin_mlp(x, delta, ln_g, ln_b, eps, w1, b1, w2p, b2, next_ln=None):
+    """Plain-torch statement of mq_swin_mlp_fwd (un-permutes the k-slots of w2p first)."""
+    from mq_det_amd.ops import swin_mlp_w2_perm
+    K = w2p.shape[1]
+    perm = swin_mlp_w2_perm(K)
+    w2 = torch.empty_like(w2p)
+    w2[:, perm] = w2p
+    act = ln_g.dtype
+    xp = x.float() + (delta.float() if delta is not None else 0.0)
+    h = F.layer_norm(xp, (x.shape[-1],), ln_g.float(), ln_b.float(), eps).to(act)
+    hid = F.gelu(F.linear(h.float(), w1.float(), b1.float())).to(act)
+    out = xp + F.linear(hid.float(), w2.float(), b2.float())
+    if next_ln is None:
+        return out
+    ng, nb, ne = next_ln
+    return out, F.layer_norm(out, (x.shape[-1],), ng.float(), nb.float(), ne).to(act)

@@ -636,6 +636,7 @@ def all_checks(dev):
             ("dcn", lambda: check_dcn(dev)),
             ("ref-pin", lambda: check_ref_pins(dev)),
             ("post", lambda: check_post_golden(dev)),
+            ("swin", lambda: check_swin_mlp(dev)),
             ("roi", lambda: check_roi_align(dev)),
             ("roi", lambda: check_extract_query(dev)),
             ("conv", lambda: check_conv3x3(dev)),
@@ -937,4 +938,35 @@ def check_extract_query(dev):
             res.append(_stat(f"extract_query (all levels, oracle features) label {lab} [n, 5, C]", got5[lab], ref5[lab], tol=1e-5))
     finally:
         model.pooler, cfg.VISION_QUERY.SELECT_FPN_LEVEL = prev_pool, prev_flag
+    return res
+
+
+def check_swin_mlp(dev):
+    """mq_swin_mlp_fwd (LN prologue + fc1 + exact GELU + fc2 + residual + fused next LayerNorm in one kernel) vs a plain fp32
+    statement on the same fp16-rounded weights: every supported width, ragged token counts, with / without delta / next-LN."""
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(51)
+    res = []
+    for C, M, use_delta, use_next in ((96, 1000, True, True), (96, 128, False, False), (192, 777, True, True), (384, 333, True, True),
+                                      (384, 64, True, False), (96, 67200 * 2 + 5, True, True)):
+        x = torch.randn(M, C, generator=g) * 1.5
+        delta = (torch.randn(M, C, generator=g) * 0.5).half() if use_delta else None
+        lg, lb = (torch.randn(C, generator=g) * 0.1 + 1).half(), (torch.randn(C, generator=g) * 0.1).half()
+        w1 = (torch.randn(4 * C, C, generator=g) / math.sqrt(C)).half()
+        b1 = (torch.randn(4 * C, generator=g) * 0.1).half()
+        w2 = (torch.randn(C, 4 * C, generator=g) / math.sqrt(4 * C)).half()
+        b2 = (torch.randn(C, generator=g) * 0.1).half()
+        ng, nb = (torch.randn(C, generator=g) * 0.1 + 1).half(), (torch.randn(C, generator=g) * 0.1).half()
+        xp = x + (delta.float() if use_delta else 0.0)
+        h = F.layer_norm(xp, (C,), lg.float(), lb.float(), 1e-5).half().float()          # the kernel feeds fp16 to the MFMAs
+        hid = F.gelu(F.linear(h, w1.float(), b1.float())).half().float()
+        ref = xp + F.linear(hid, w2.float(), b2.float())
+        w2p = w2[:, ops.swin_mlp_w2_perm(4 * C)].contiguous()
+        r = ops.swin_mlp(x.to(dev), None if delta is None else delta.to(dev), lg.to(dev), lb.to(dev), 1e-5, w1.to(dev), b1.to(dev),
+                         w2p.to(dev), b2.to(dev), next_ln=(ng.to(dev), nb.to(dev), 1e-5) if use_next else None)
+        out, y = r if use_next else (r, None)
+        tag = f"swin_mlp C={C} M={M} delta={use_delta}"
+        res.append(_stat(f"{tag}: out (fp32 stream)", out, ref, tol=1e-3))
+        if use_next:
+            res.append(_stat(f"{tag}: fused next LayerNorm", y, F.layer_norm(ref, (C,), ng.float(), nb.float(), 1e-5), tol=2e-3))
     return res
