@@ -64,6 +64,8 @@ def build_model(dev, caches=False, n_classes=NUM_CLASSES_IN_CAPTION, n_categorie
     cfg.MODEL.BACKBONE_CACHE = bool(caches)
     if os.environ.get("MQ_RESIDUAL_FP32") is not None:        # A/B switch (precision of the residual streams)
         cfg.MODEL.RESIDUAL_FP32 = os.environ["MQ_RESIDUAL_FP32"] == "1"
+    if os.environ.get("MQ_SWIN_FUSED_MLP") is not None:       # A/B switch (fused Swin MLP kernel vs library GEMMs + GELU)
+        cfg.MODEL.SWINT.FUSED_MLP = os.environ["MQ_SWIN_FUSED_MLP"] == "1"
     tok_dir = build_synthetic_tokenizer(tempfile.mkdtemp(prefix="mqdet_tok_"))
     cfg.MODEL.LANGUAGE_BACKBONE.TOKENIZER_TYPE = tok_dir
     tk = AutoTokenizer.from_pretrained(tok_dir)
@@ -197,6 +199,7 @@ def kernel_rooflines(kern, steps, Bn, n_tok):
     # ---- HBM-bound kernels: algorithmic bytes (every input read once, every output written once) / time
     groups = (("layernorm_kernel (all LayerNorms, residual add fused)", "layernorm_c"), ("window_attn_kernel (Swin W-MSA / SW-MSA)", "window_attn_c"),
               ("dyconv_fuse_kernel (GroupNorm affine + up-sampling + scale attention + branch mean)", "dyconv_fuse"),
+              ("swin_mlp_kernel (LN + fc1 + GELU + fc2 + residual + next LN; HBM-bound at C = 96 / 192)", "swin_mlp_c"),
               ("dyrelu_apply_kernel", "dyrelu_apply"), ("conv3x3_small_kernel (27-channel DyConv offset conv)", "conv3x3_small"),
               ("align_scores_kernel (sigmoid + token->class mean + threshold)", "align_scores"))
     for name, prefix in groups:

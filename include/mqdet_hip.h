@@ -202,6 +202,15 @@ int mq_roi_align_fwd(const void* feat, int feat_f32, const float* rois, float* o
                      long sn, long sc, long sh, long sw, int PH, int PW, float spatial_scale, int sampling_ratio,
                      int aligned, int reduce_mean, void* stream);
 
+/* Multi-scale deformable attention forward (Deformable-DETR / GroundingDINO):
+ *   out[b,q,m*D+c] = sum_{l,p} attn[b,q,m,l,p] * bilinear(value[b, start_l.., m, c], loc[b,q,m,l,p,1]*H_l - 0.5, loc[..,0]*W_l - 0.5)
+ *   value [B,S,M,D] fp16 (fp32 when value_f32), shapes [L,2] int64 (H, W), level_start [L] int64 (device pointers),
+ *   loc [B,Q,M,L,P,2] fp32 in [0,1], attn [B,Q,M,L,P] fp32, out [B,Q,M*D] fp16 (fp32 when out_f32); D % 4 == 0.
+ * Replaces groundingdino_new._C.ms_deform_attn_forward (csrc_groundingdino/vision.cpp:54, MsDeformAttn/ms_deform_attn_cuda.cu:21-81,
+ *   ms_deform_im2col_cuda.cuh:33-84,237-299) and its torch fallback (ms_deform_attn.py:93-133). */
+int mq_msdeform_attn_fwd(const void* value, int value_f32, const long* shapes, const long* level_start, const float* loc,
+                         const float* attn, void* out, int out_f32, int B, int S, int M, int D, int L, int Q, int P, void* stream);
+
 /* Class-aware NMS on score-sorted boxes, mask + sweep entirely on the device.
  *   boxes [B,N,4] fp32 (sorted by score desc per image), labels [B,N] int32, nvalid [B] int32 -> keep [B,N] uint8.
  * Replaces _C.ml_nms: maskrcnn_benchmark/csrc/ml_nms.h:10-27, csrc/cuda/ml_nms.cu:15-149 (vision.cpp:23). */

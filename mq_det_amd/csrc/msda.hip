@@ -1,0 +1,98 @@
+// mq_msdeform_attn_fwd: multi-scale deformable attention forward (Deformable-DETR / GroundingDINO) for gfx950.
+//
+//   out[b, q, m*D + c] = sum_{l < L, p < P} attn[b,q,m,l,p] * bilinear( value[b, start_l : start_l + H_l W_l, m, c],
+//                                                                         loc[b,q,m,l,p,1] * H_l - 0.5, loc[..,0] * W_l - 0.5 )
+//   (zero padding, align_corners = False; a sample contributes only if -1 < h < H_l and -1 < w < W_l)
+//
+// Reference: groundingdino_new/models/GroundingDINO/csrc_groundingdino/MsDeformAttn/ms_deform_im2col_cuda.cuh:33-84
+// (ms_deform_attn_im2col_bilinear), :237-299 (ms_deformable_im2col_gpu_kernel), host wrapper ms_deform_attn_cuda.cu:21-81,
+// Python fallback ms_deform_attn.py:93-133.  The reference runs it in fp32 (ms_deform_attn.py:330-336) with ONE THREAD PER
+// OUTPUT ELEMENT: the 32 channels of a head sit in 32 different threads that each re-read the same sampling location and
+// weight and issue 4-byte loads.  MI355X shape: the op is a pure gather (11 GF of MACs against 22 323 x 8 x 16 random 64-byte
+// reads per image): one wave owns one (b, q); lane = (head, 4-channel group), so the D/4 lanes of a head read
+// one contiguous D-channel row per corner (64 B in fp16 for D = 32 -- one request), sampling state is computed once per
+// lane group, value may be fp16 (the value_proj GEMM's output dtype) with fp32 weights / accumulation.
+//   value  [B, S, M, D]  fp16 or fp32      shapes [L, 2] int64 (H, W)      level_start [L] int64
+//   loc    [B, Q, M, L, P, 2] fp32 (x, y in [0, 1])      attn [B, Q, M, L, P] fp32
+//   out    [B, Q, M * D]  fp16 or fp32
+#include "common.h"
+
+template <typename TV, typename TO>
+__global__ __launch_bounds__(256) void msda_kernel(const TV* __restrict__ value, const long* __restrict__ shapes,
+                                                   const long* __restrict__ level_start, const float* __restrict__ loc,
+                                                   const float* __restrict__ attn, TO* __restrict__ out, int B, int S, int M, int D,
+                                                   int L, int Q, int P) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long bq = (long)blockIdx.x * 4 + wave;
+  if (bq >= (long)B * Q) return;
+  const int b = bq / Q;
+  const int lph = D >> 2;                                   // lanes per head (4 channels per lane)
+  const int nchunk = M * lph;                               // 4-channel groups of one output row
+  for (int ch = lane; ch < nchunk; ch += 64) {
+    const int m = ch / lph, c = (ch - m * lph) << 2;
+    const float* lp = loc + ((bq * M + m) * L) * P * 2;
+    const float* ap = attn + ((bq * M + m) * L) * P;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < L; ++l) {
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const TV* vb = value + (((long)b * S + level_start[l]) * M + m) * D + c;
+      const long ws = (long)M * D, hs = (long)W * ws;       // element strides of one step in x / y
+      for (int pt = 0; pt < P; ++pt) {
+        const float loc_w = lp[(l * P + pt) * 2], loc_h = lp[(l * P + pt) * 2 + 1], wgt = ap[l * P + pt];
+        const float h = loc_h * (float)H - 0.5f, w = loc_w * (float)W - 0.5f;
+        if (h > -1.f && w > -1.f && h < (float)H && w < (float)W) {
+          const int hl = (int)floorf(h), wl = (int)floorf(w), hh = hl + 1, wh = wl + 1;
+          const float lh = h - (float)hl, lw = w - (float)wl, uh = 1.f - lh, uw = 1.f - lw;
+          float v1[4] = {0.f, 0.f, 0.f, 0.f}, v2[4] = {0.f, 0.f, 0.f, 0.f}, v3[4] = {0.f, 0.f, 0.f, 0.f}, v4[4] = {0.f, 0.f, 0.f, 0.f};
+          auto ld = [&](int y, int x, float* dst) {
+            const TV* a = vb + y * hs + x * ws;
+            if constexpr (sizeof(TV) == 2) {
+              const half4 t = *(const half4*)a;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) dst[j] = (float)t[j];
+            } else {
+              const float4_ t = *(const float4_*)a;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) dst[j] = t[j];
+            }
+          };
+          if (hl >= 0 && wl >= 0) ld(hl, wl, v1);
+          if (hl >= 0 && wh <= W - 1) ld(hl, wh, v2);
+          if (hh <= H - 1 && wl >= 0) ld(hh, wl, v3);
+          if (hh <= H - 1 && wh <= W - 1) ld(hh, wh, v4);
+          const float w1 = uh * uw, w2 = uh * lw, w3 = lh * uw, w4 = lh * lw;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] += (w1 * v1[j] + w2 * v2[j] + w3 * v3[j] + w4 * v4[j]) * wgt;
+        }
+      }
+    }
+    TO* o = out + bq * (long)(M * D) + m * D + c;
+    if constexpr (sizeof(TO) == 2) {
+      half4 t;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[j] = (half_t)acc[j];
+      *(half4*)o = t;
+    } else {
+      *(float4_*)o = (float4_){acc[0], acc[1], acc[2], acc[3]};
+    }
+  }
+}
+
+extern "C" int mq_msdeform_attn_fwd(const void* value, int value_f32, const long* shapes, const long* level_start, const float* loc,
+                                    const float* attn, void* out, int out_f32, int B, int S, int M, int D, int L, int Q, int P,
+                                    void* stream) {
+  if (B <= 0 || Q <= 0) return 0;
+  if (D % 4 || M <= 0 || L <= 0 || P <= 0) return -1;
+  const dim3 grid((unsigned)(((long)B * Q + 3) / 4));
+  hipStream_t s = (hipStream_t)stream;
+#define MQ_MSDA(TV, TO)                                                                                                 \
+  hipLaunchKernelGGL((msda_kernel<TV, TO>), grid, dim3(256), 0, s, (const TV*)value, shapes, level_start, loc, attn, (TO*)out, B, S, \
+                     M, D, L, Q, P)
+  if (value_f32 && out_f32) MQ_MSDA(float, float);
+  else if (value_f32) MQ_MSDA(float, half_t);
+  else if (out_f32) MQ_MSDA(half_t, float);
+  else MQ_MSDA(half_t, half_t);
+#undef MQ_MSDA
+  MQ_CHECK_LAUNCH();
+  return 0;
+}

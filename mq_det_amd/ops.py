@@ -38,6 +38,7 @@ _SIGNATURES = {
     "mq_align_scores_fwd": (_i, [_vp, _i, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _l, _vp]),
     "mq_box_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _vp]),
     "mq_roi_align_fwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _f, _i, _i, _i, _vp]),
+    "mq_msdeform_attn_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_ml_nms_workspace_bytes": (_l, [_i, _i]),
     "mq_ml_nms": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
 }
@@ -541,6 +542,37 @@ def roi_align(feat, rois, output_size, spatial_scale, sampling_ratio, aligned=Tr
     _chk(lib.mq_roi_align_fwd(_ptr(feat), int(feat.dtype == torch.float32), _ptr(rois), _ptr(out), R, C, H, W, feat.stride(0),
                               feat.stride(1), feat.stride(2), feat.stride(3), PH, PW, float(spatial_scale), int(sampling_ratio),
                               int(bool(aligned)), int(bool(reduce_mean)), _stream()), "mq_roi_align_fwd")
+    return out
+
+
+_MSDA_SHAPES = {}
+
+
+def ms_deform_attn(value, spatial_shapes, sampling_locations, attention_weights, out_dtype=None):
+    """value [B,S,M,D] fp16 / fp32 (contiguous), spatial_shapes: list of (H, W) (sum H*W == S), sampling_locations
+    [B,Q,M,L,P,2] fp32, attention_weights [B,Q,M,L,P] fp32 -> [B,Q,M*D] in out_dtype (default: value's dtype)."""
+    lib = load_library()
+    _need_gpu(value, sampling_locations, attention_weights)
+    B, S, M, D = value.shape
+    _, Q, _, L, P, _ = sampling_locations.shape
+    shapes = tuple((int(h), int(w)) for h, w in spatial_shapes)
+    assert len(shapes) == L and sum(h * w for h, w in shapes) == S
+    assert value.is_contiguous() and value.dtype in (torch.float16, torch.float32)
+    assert sampling_locations.dtype == attention_weights.dtype == torch.float32
+    assert sampling_locations.is_contiguous() and attention_weights.is_contiguous() and attention_weights.shape == (B, Q, M, L, P)
+    key = (shapes, value.device)
+    if key not in _MSDA_SHAPES:                   # [L, 2] (H, W) and level start indices as int64 device tensors, cached
+        hw = torch.tensor(shapes, dtype=torch.int64)
+        start = torch.cat([hw.new_zeros(1), (hw[:, 0] * hw[:, 1]).cumsum(0)[:-1]])
+        _MSDA_SHAPES[key] = (hw.to(value.device), start.to(value.device))
+    hw, start = _MSDA_SHAPES[key]
+    out_dtype = out_dtype or value.dtype
+    out = torch.empty(B, Q, M * D, dtype=out_dtype, device=value.device)
+    nb = value.numel() * value.element_size() + sampling_locations.numel() * 4 + attention_weights.numel() * 4 + out.numel() * out.element_size()
+    with _timed(f"msdeform_attn_q{Q}", nb):
+        _chk(lib.mq_msdeform_attn_fwd(_ptr(value), int(value.dtype == torch.float32), _ptr(hw), _ptr(start), _ptr(sampling_locations),
+                                      _ptr(attention_weights), _ptr(out), int(out_dtype == torch.float32), B, S, M, D, L, Q, P, _stream()),
+             "mq_msdeform_attn_fwd")
     return out
 
 

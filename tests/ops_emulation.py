@@ -343,3 +343,9 @@ def swin_mlp(x, delta, ln_g, ln_b, eps, w1, b1, w2p, b2, next_ln=None):
         return out
     ng, nb, ne = next_ln
     return out, F.layer_norm(out, (x.shape[-1],), ng.float(), nb.float(), ne).to(act)
+
+
+def ms_deform_attn(value, spatial_shapes, sampling_locations, attention_weights, out_dtype=None):
+    from oracle.gdino import ms_deform_attn_core
+    out = ms_deform_attn_core(value.float(), spatial_shapes, sampling_locations.float(), attention_weights.float())
+    return out.to(out_dtype or value.dtype)

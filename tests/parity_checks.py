@@ -637,6 +637,7 @@ def all_checks(dev):
             ("ref-pin", lambda: check_ref_pins(dev)),
             ("post", lambda: check_post_golden(dev)),
             ("swin", lambda: check_swin_mlp(dev)),
+            ("gdino", lambda: check_msdeform_attn(dev)),
             ("roi", lambda: check_roi_align(dev)),
             ("roi", lambda: check_extract_query(dev)),
             ("conv", lambda: check_conv3x3(dev)),
@@ -969,4 +970,58 @@ def check_swin_mlp(dev):
         res.append(_stat(f"{tag}: out (fp32 stream)", out, ref, tol=1e-3))
         if use_next:
             res.append(_stat(f"{tag}: fused next LayerNorm", y, F.layer_norm(ref, (C,), ng.float(), nb.float(), 1e-5), tol=2e-3))
+    return res
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# MQ-GroundingDINO path, first piece: multi-scale deformable attention
+def check_msdeform_attn(dev, golden_dir=None):
+    """mq_msdeform_attn_fwd vs (1) the reference-generated fixture tests/golden/msda.npz, (2) the reference's own CUDA kernel
+    (ms_deform_im2col_cuda.cuh:237-299 via oracle/build_ref.py) -- which also pins oracle.gdino.ms_deform_attn_core --,
+    (3) the oracle at the encoder's shape (4 levels of an 800x1344 image, Q = 22 323) with fp16 values; and the module
+    forward (value / offset / weight projections, 2-d and 4-d reference points, padding mask) vs the oracle's restatement."""
+    import os
+    import numpy as np
+    from oracle import gdino, ref_native as rn
+    from mq_det_amd import ops
+    from mq_det_amd.modeling import msdeform
+    golden_dir = golden_dir or os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    gd = np.load(os.path.join(golden_dir, "msda.npz"))
+    value, loc, attn = (torch.from_numpy(gd[k]) for k in ("value", "loc", "attn"))
+    shapes = [tuple(s) for s in gd["shapes"].tolist()]
+    res = []
+    got = ops.ms_deform_attn(value.to(dev), shapes, loc.to(dev), attn.to(dev))
+    res.append(_stat("msdeform fp32 vs reference fixture (multi_scale_deformable_attn_pytorch)", got, torch.from_numpy(gd["out"]), tol=1e-5))
+    hw = torch.tensor(shapes, dtype=torch.int64)
+    start = torch.cat([hw.new_zeros(1), (hw[:, 0] * hw[:, 1]).cumsum(0)[:-1]])
+    pin = rn.ms_deform_attn(value.to(dev), hw, start, loc.to(dev), attn.to(dev))
+    res.append(_stat("PIN mq_msdeform_attn_fwd vs reference CUDA kernel", got, pin, tol=1e-5))
+    res.append(_stat("PIN oracle.ms_deform_attn_core vs reference CUDA kernel", gdino.ms_deform_attn_core(value, shapes, loc, attn), pin, tol=1e-5))
+    # encoder shape, fp16 values (the product's dtype), ragged query count
+    g = torch.Generator().manual_seed(61)
+    shapes = [(100, 168), (50, 84), (25, 42), (13, 21)]
+    S = sum(h * w for h, w in shapes)
+    v = torch.randn(1, S, 8, 32, generator=g).half()
+    Q = 2001
+    loc = torch.rand(1, Q, 8, 4, 4, 2, generator=g) * 1.1 - 0.05
+    attn = torch.rand(1, Q, 8, 16, generator=g).softmax(-1).reshape(1, Q, 8, 4, 4)
+    ref = gdino.ms_deform_attn_core(v.float(), shapes, loc, attn)
+    got = ops.ms_deform_attn(v.to(dev), shapes, loc.to(dev), attn.to(dev))
+    res.append(_stat(f"msdeform fp16 values, 4 levels of 800x1344, Q={Q}", got, ref, tol=1e-3))
+    # module forward
+    sd = gdino.make_msda_weights(prefix="attn")
+    W = msdeform.pack_msda(sd, "attn", dev)
+    sdh = {k: t.half().float() for k, t in sd.items()}
+    shapes = [(20, 24), (10, 12), (5, 6), (3, 3)]
+    S = sum(h * w for h, w in shapes)
+    x = torch.randn(2, S, 256, generator=g).half()
+    mask = torch.zeros(2, S, dtype=torch.bool)
+    mask[1, S - 40:] = True
+    for nd in (2, 4):
+        rp = torch.rand(2, S, 4, nd, generator=g)
+        if nd == 4:
+            rp[..., 2:] = rp[..., 2:] * 0.3 + 0.05
+        ref = gdino.ms_deform_attn(sdh, "attn", x.float(), None, rp, shapes, key_padding_mask=mask)
+        got = msdeform.ms_deform_attn(W, x.to(dev), None, rp.to(dev), shapes, key_padding_mask=mask.to(dev))
+        res.append(_stat(f"MultiScaleDeformableAttention.forward reference_points[..., {nd}]", got, ref, tol=6e-3))
     return res
