@@ -40,9 +40,9 @@ int mq_attn_fwd(const void* q, const void* k, const void* vt, void* o, const flo
                 long o_bs, long o_rs, long bias_bs, long bias_hs, float scale, float clamp, int nsplit, void* stream);
 
 /* Swin (shifted-)window attention with pad / roll / window partition folded into addressing.
- *   qkv [B,H,W,3C] fp16, qkv_bias [3C] fp16 (pad tokens), rel_bias [heads,64,64] fp32 (rows = query, cols = key,
- *   zero-padded from N = ws*ws), out [B,H,W,C] fp16;
- *   C == heads*32, N = ws*ws <= 64.
+ *   qkv [B,H,W,3C] fp16, qkv_bias [3C] fp16 (pad tokens), rel_bias [heads,NP,NP] fp32 (rows = query, cols = key,
+ *   zero-padded from N = ws*ws to NP = 64 when N <= 64 -- window 7 -- or 160 when N <= 160 -- Swin-L, window 12),
+ *   out [B,H,W,C] fp16; C == heads*32.
  * Replaces maskrcnn_benchmark/modeling/backbone/swint.py:111-142 (WindowAttention.forward) together with the
  *   pad/roll/window_partition/window_reverse/crop copies of SwinTransformerBlock.forward (:201-234) and the
  *   per-forward SW-MSA mask construction of BasicLayer.forward (:354-373). */

@@ -8,11 +8,12 @@
 //   qkv      : [B, H, W, 3*C] fp16 = Linear(norm1(x)) on the UNPADDED tokens, C = heads*32
 //   qkv_bias : [3*C] fp16 -- q/k/v of a pad token (pad happens after norm1, so a pad token is an exact
 //              zero vector and its qkv row equals the bias; pad tokens DO act as keys, swint.py quirk 7)
-//   rel_bias : [heads, 64, 64] fp32: relative_position_bias_table gathered by relative_position_index into rows = query,
-//              cols = key, zero-padded from N = ws*ws to 64 (the kernel masks the padded keys itself)
+//   rel_bias : [heads, NP, NP] fp32: relative_position_bias_table gathered by relative_position_index into rows = query,
+//              cols = key, zero-padded from N = ws*ws to NP = 64 (N <= 64: Swin-T/S/B, window 7) or 160 (N <= 160:
+//              Swin-L, window 12 -> 144 tokens); the kernel masks the padded keys itself
 //   out      : [B, H, W, C] fp16 (attention output before `proj`)
-// One wave per (window, head): N = ws*ws <= 64 tokens padded to 64, head_dim 32.
-//   S^T (64 keys x 64 queries) = 16 x mfma 16x16x32 with the operands SWAPPED (A = K rows, B = Q rows; K = head_dim = 32,
+// One wave per (window, head): N = ws*ws tokens padded to NP = 16 * NB (NB = 4 or 10 blocks of 16), head_dim 32.
+//   S^T (NP keys x NP queries) = NB x NB mfma 16x16x32 with the operands SWAPPED (A = K rows, B = Q rows; K = head_dim = 32,
 //     one MFMA per 16x16 block), fragments read straight from global memory (16 B per lane, each element used once).
 //     A lane then owns one QUERY column (l15) and 4 keys (4*lg + r) per 16-key block: bias rows are 16-byte loads, the
 //     softmax reduction is in-lane + 2 shuffles, and the normalised probabilities already ARE the P^T B-fragments of
@@ -37,9 +38,12 @@ struct WinParams {
   float scale;
 };
 
+template <int NB>
 __global__ __launch_bounds__(256) void window_attn_kernel(WinParams p) {
   constexpr int VP = 32 + 8;                               // V row pitch (halfs)
-  __shared__ __attribute__((aligned(16))) half_t Vs_all[4][64 * VP];
+  constexpr int NP = 16 * NB;                              // padded window length
+  static_assert(NB % 2 == 0, "PV walks the keys in steps of 32");
+  __shared__ __attribute__((aligned(16))) half_t Vs_all[4][NP * VP];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l15 = lane & 15, lg = lane >> 4;
   const long unit = (long)blockIdx.x * 4 + wave;          // (b, wy, wx, head)
@@ -63,11 +67,11 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinParams p) {
   };
 
   // ---- the 4 tokens this lane addresses (token = blk*16 + l15): K / Q fragments, V chunk, output pixel
-  half8 qf[4], kf[4];
-  long out_off[4];                                         // element offset of the token's output row, -1: pad / beyond N
-  int region_q[4];
+  half8 qf[NB], kf[NB];
+  long out_off[NB];                                        // element offset of the token's output row, -1: pad / beyond N
+  int region_q[NB];
 #pragma unroll
-  for (int blk = 0; blk < 4; ++blk) {
+  for (int blk = 0; blk < NB; ++blk) {
     const int i = blk * 16 + l15, ii = min(i, N - 1);
     const int ys = wy * p.ws + ii / p.ws, xs = wx * p.ws + ii % p.ws;       // coords in the shifted frame
     int y = ys + p.shift; if (y >= p.Hp) y -= p.Hp;                       // shifted[ys] = x[(ys+shift) % Hp]
@@ -82,31 +86,34 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinParams p) {
     region_q[blk] = region_of(i);
   }
 
-  int region_k[4][4];
+  int region_k[NB];                                        // four 4-bit region ids per 16-key block
   if (p.shift > 0) {
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
+    for (int nb = 0; nb < NB; ++nb) {
+      region_k[nb] = 0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) region_k[nb][r] = region_of(nb * 16 + 4 * lg + r);
+      for (int r = 0; r < 4; ++r) region_k[nb] |= region_of(nb * 16 + 4 * lg + r) << (4 * r);
+    }
   }
-  const float* rel = p.rel_bias + (long)head * 64 * 64;
+  const float* rel = p.rel_bias + (long)head * NP * NP;
   wave_lds_fence();                                        // V tile written by this wave's own lanes
   // one 16-query block at a time (keeps the kernel under 128 VGPRs -> 4 waves / SIMD for this load / store bound op)
 #pragma unroll
-  for (int qb = 0; qb < 4; ++qb) {
+  for (int qb = 0; qb < NB; ++qb) {
+    if (qb * 16 >= N) break;                               // query blocks made of padding only (wave-uniform)
     // ---- S^T = K Q^T : s[nb], element r <-> key nb*16 + 4*lg + r, query qb*16 + l15
-    float4_ s[4];
+    float4_ s[NB];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) s[nb] = mfma16(kf[nb], qf[qb], (float4_){0.f, 0.f, 0.f, 0.f});
-    const float* relq = rel + (qb * 16 + l15) * 64 + 4 * lg;
+    for (int nb = 0; nb < NB; ++nb) s[nb] = mfma16(kf[nb], qf[qb], (float4_){0.f, 0.f, 0.f, 0.f});
+    const float* relq = rel + (qb * 16 + l15) * NP + 4 * lg;
     float mx = MQ_NEG_BIG;
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
       const float4_ rb = *(const float4_*)(relq + nb * 16);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = s[nb][r] * p.scale + rb[r];
-        if (p.shift > 0 && region_k[nb][r] != region_q[qb]) v += -100.0f;
+        if (p.shift > 0 && ((region_k[nb] >> (4 * r)) & 15) != region_q[qb]) v += -100.0f;
         if (nb * 16 + 4 * lg + r >= N) v = MQ_NEG_BIG;
         s[nb][r] = v;
         mx = fmaxf(mx, v);
@@ -116,7 +123,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinParams p) {
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     float sum = 0.f;
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float e = __expf(s[nb][r] - mx);
@@ -126,9 +133,9 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinParams p) {
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
     const float inv = 1.f / sum;
-    half8 pf[2];                                           // P^T B-fragments of the two 32-key steps
+    half8 pf[NB / 2];                                      // P^T B-fragments of the 32-key steps
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
+    for (int st = 0; st < NB / 2; ++st)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         pf[st][r] = (half_t)(s[2 * st][r] * inv);
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinParams p) {
     // ---- O^T[db] = V^T P^T : A = transposed reads of the row-major V tile (k-slot (lg, j) <-> key 16*(j/4) + 4*lg + j%4)
     float4_ o[2] = {(float4_){0.f, 0.f, 0.f, 0.f}, (float4_){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
+    for (int st = 0; st < NB / 2; ++st) {
       const half_t* base = Vs + (st * 32 + 4 * lg + (l15 >> 2)) * VP + (l15 & 3) * 4;
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinParams p) {
 extern "C" int mq_window_attn_fwd(const void* qkv, const void* qkv_bias, const float* rel_bias, void* out,
                                   int B, int H, int W, int C, int heads, int ws, int shift, void* stream) {
   if (B <= 0) return 0;
-  if (C != heads * 32 || ws * ws > 64 || shift < 0 || shift >= ws) return -1;
+  if (C != heads * 32 || ws * ws > 160 || shift < 0 || shift >= ws) return -1;
   WinParams p;
   p.qkv = (const half_t*)qkv; p.qkv_bias = (const half_t*)qkv_bias; p.rel_bias = rel_bias; p.out = (half_t*)out;
   p.B = B; p.H = H; p.W = W; p.C = C; p.heads = heads; p.ws = ws; p.shift = shift;
@@ -173,7 +180,10 @@ extern "C" int mq_window_attn_fwd(const void* qkv, const void* qkv_bias, const f
   p.nWy = p.Hp / ws; p.nWx = p.Wp / ws;
   p.scale = 1.0f / sqrtf(32.0f);
   long total = (long)B * p.nWy * p.nWx * heads;
-  hipLaunchKernelGGL(window_attn_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+  if (ws * ws <= 64)
+    hipLaunchKernelGGL(window_attn_kernel<4>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+  else                                                     // Swin-L: window 12 -> 144 tokens padded to 160
+    hipLaunchKernelGGL(window_attn_kernel<10>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
   MQ_CHECK_LAUNCH();
   return 0;
 }

@@ -45,7 +45,8 @@ def build_plan(sd, cfg, device, dtype=torch.float16):
             b = f"backbone.body.layers.{i}.blocks.{j}.attn"
             idx = sd[b + ".relative_position_index"].to(device).reshape(-1)
             rel = f32(b + ".relative_position_bias_table")[idx].reshape(N, N, heads).permute(2, 0, 1)
-            P[b + ".rel_bias"] = F.pad(rel, (0, 64 - N, 0, 64 - N)).contiguous()        # [heads, 64, 64], see ops.pad_rel_bias
+            NP = ops.window_pad(ws)                                                        # 64 (window 7) or 160 (window 12)
+            P[b + ".rel_bias"] = F.pad(rel, (0, NP - N, 0, NP - N)).contiguous()         # [heads, NP, NP], see ops.pad_rel_bias
     # Swin MLP halves that run as one fused kernel (mq_swin_mlp_fwd): fc2.weight with the k-slots of every 32-block permuted
     P["_swin_fused_mlp"] = bool(M.SWINT.get("FUSED_MLP", True)) and P["_r32"]
     for i, depth in enumerate(M.SWINT.DEPTHS):

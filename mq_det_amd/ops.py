@@ -174,25 +174,35 @@ def attention(q, k, vt, num_heads, head_dim, key_bias=None, scale=None, clamp=0.
     return attention4(q4, k4, vt4, key_bias, scale, clamp, nsplit, nk, kv_len)
 
 
-def pad_rel_bias(rel_bias):
-    """[heads, N, N] relative-position bias -> the [heads, 64, 64] table mq_window_attn_fwd reads with 16-byte loads."""
+def window_pad(ws):
+    """Padded window length the kernel works on: 64 for N = ws*ws <= 64 (window 7), 160 for N <= 160 (Swin-L, window 12)."""
+    n = ws * ws
+    if n > 160:
+        raise ValueError(f"window {ws}x{ws} = {n} tokens: mq_window_attn_fwd supports up to 160")
+    return 64 if n <= 64 else 160
+
+
+def pad_rel_bias(rel_bias, ws=None):
+    """[heads, N, N] relative-position bias -> the zero-padded [heads, NP, NP] table mq_window_attn_fwd reads with 16-byte loads."""
     h, n, _ = rel_bias.shape
-    out = rel_bias.new_zeros(h, 64, 64)
+    npad = window_pad(ws) if ws is not None else (64 if n <= 64 else 160)
+    out = rel_bias.new_zeros(h, npad, npad)
     out[:, :n, :n] = rel_bias
     return out.contiguous()
 
 
 def window_attention(qkv, qkv_bias, rel_bias, heads, ws, shift):
-    """qkv [B,H,W,3C] fp16, qkv_bias [3C] fp16, rel_bias [heads,64,64] fp32 (rows = query, cols = key, zero-padded from
-    N = ws*ws; a [heads,N,N] table is padded here) -> [B,H,W,C] fp16."""
+    """qkv [B,H,W,3C] fp16, qkv_bias [3C] fp16, rel_bias [heads,NP,NP] fp32 (rows = query, cols = key, zero-padded from
+    N = ws*ws to NP = window_pad(ws); a [heads,N,N] table is padded here) -> [B,H,W,C] fp16."""
     lib = load_library()
     _need_gpu(qkv, qkv_bias, rel_bias)
     B, H, W, C3 = qkv.shape
     C = C3 // 3
+    NP = window_pad(ws)
     assert qkv.is_contiguous() and qkv.dtype == torch.float16 and qkv_bias.dtype == torch.float16
-    if rel_bias.shape == (heads, ws * ws, ws * ws) and ws * ws != 64:
-        rel_bias = pad_rel_bias(rel_bias)
-    assert rel_bias.dtype == torch.float32 and rel_bias.is_contiguous() and rel_bias.shape == (heads, 64, 64)
+    if rel_bias.shape == (heads, ws * ws, ws * ws) and ws * ws != NP:
+        rel_bias = pad_rel_bias(rel_bias, ws)
+    assert rel_bias.dtype == torch.float32 and rel_bias.is_contiguous() and rel_bias.shape == (heads, NP, NP)
     out = torch.empty(B, H, W, C, dtype=torch.float16, device=qkv.device)
     with _timed(f"window_attn_c{C}", qkv.numel() * 2 + out.numel() * 2):
         _chk(lib.mq_window_attn_fwd(_ptr(qkv), _ptr(qkv_bias), _ptr(rel_bias), _ptr(out), B, H, W, C, heads, ws, shift,

@@ -19,4 +19,4 @@ Pinning status (see DESIGN.md "Oracle"):
     by known-answer properties (zero offsets == F.conv2d, integer shifts, brute-force
     NMS).  Those two ops are "parity unpinned" in the strict sense.
 """
-from .spec import Spec, tiny_spec, glip_t_spec  # noqa: F401
+from .spec import Spec, tiny_spec, glip_t_spec, glip_l_spec, tiny_l_spec  # noqa: F401

@@ -75,3 +75,16 @@ def tiny_spec(**kw) -> Spec:
     base = Spec(swin_depths=(2, 2, 2, 2), bert_layers=4, qv_start=2, dyhead_convs=2,
                 vocab=2048, num_classes=81, mdetr_class_num=-1)
     return replace(base, **kw)
+
+
+def glip_l_spec(**kw) -> Spec:
+    """MQ-GLIP-L (BASELINE.json configs[3]; configs/pretrain/mq-glip-l.yaml:11-17,41): Swin-L (embed 192, depths 2-2-18-2,
+    heads 6-12-24-48, window 12), 8 fusion layers; the language model stays bert-base (:21-22)."""
+    return replace(Spec(swin_embed=192, swin_depths=(2, 2, 18, 2), swin_heads=(6, 12, 24, 48), window=12, dyhead_convs=8), **kw)
+
+
+def tiny_l_spec(**kw) -> Spec:
+    """Swin-L widths / heads / window 12 and the real head dims, shallow (depths 2-2-2-2, 2 fusion layers)."""
+    base = Spec(swin_embed=192, swin_depths=(2, 2, 2, 2), swin_heads=(6, 12, 24, 48), window=12, bert_layers=4, qv_start=2,
+                dyhead_convs=2, vocab=2048, num_classes=81, mdetr_class_num=-1)
+    return replace(base, **kw)

@@ -74,15 +74,18 @@ def check_attention_strided(dev):
     return _stat("attn strided q|k views (BERT)", out, ref)
 
 
-def _tiny(dev, image_hw=(160, 192), B=2, seed=0):
-    """Shared tiny model: oracle state dict + product model with the same weights."""
+def _tiny(dev, image_hw=(160, 192), B=2, seed=0, spec=None):
+    """Shared tiny model: oracle state dict + product model with the same weights (spec: tiny_spec() = Swin-T widths, or
+    tiny_l_spec() = Swin-L widths / window 12)."""
     from oracle import tiny_spec
     from oracle.weights import make_state_dict
     from mq_det_amd import get_cfg
     from mq_det_amd.modeling.detector import GeneralizedVLRCNN_New
-    spec = tiny_spec()
+    spec = spec or tiny_spec()
     sd = make_state_dict(spec, seed)
     cfg = get_cfg()
+    cfg.MODEL.SWINT.EMBED_DIM, cfg.MODEL.SWINT.NUM_HEADS = spec.swin_embed, spec.swin_heads
+    cfg.MODEL.SWINT.WINDOW_SIZE, cfg.MODEL.SWINT.OUT_CHANNELS = spec.window, spec.swin_dims
     cfg.MODEL.SWINT.DEPTHS = spec.swin_depths
     cfg.MODEL.LANGUAGE_BACKBONE.NUM_HIDDEN_LAYERS = spec.bert_layers
     cfg.MODEL.LANGUAGE_BACKBONE.QV_START = spec.qv_start
@@ -100,16 +103,19 @@ def _tiny(dev, image_hw=(160, 192), B=2, seed=0):
 _CACHE = {}
 
 
-def tiny(dev):
-    if "tiny" not in _CACHE:
-        _CACHE["tiny"] = _tiny(dev)
-    return _CACHE["tiny"]
+def tiny(dev, large=False):
+    key = "tiny_l" if large else "tiny"
+    if key not in _CACHE:
+        from oracle import tiny_l_spec
+        _CACHE[key] = _tiny(dev, spec=tiny_l_spec() if large else None)
+    return _CACHE[key]
 
 
-def check_swin_fpn(dev):
+def check_swin_fpn(dev, large=False):
+    """large: Swin-L widths (192 .. 1536), heads 6 .. 48, window 12 (144-token windows) -- MQ-GLIP-L's backbone."""
     from oracle import backbone as ob
     from mq_det_amd.modeling import pipeline
-    spec, sd, cfg, model, P = tiny(dev)
+    spec, sd, cfg, model, P = tiny(dev, large)
     img = torch.randn(2, 3, 90, 122, generator=torch.Generator().manual_seed(1)).half()
     with torch.no_grad():
         c = ob.swin_forward(sd, "backbone.body", img.float(), spec)
@@ -117,18 +123,20 @@ def check_swin_fpn(dev):
         x = img.to(dev).contiguous(memory_format=torch.channels_last)
         cg = pipeline.swin_forward(P, cfg, x)
         pg = pipeline.fpn_forward(P, cg)
-    out = [_stat(f"swin c{i + 3}", cg[i].permute(0, 3, 1, 2), c[i + 1], tol=1e-2) for i in range(3)]
-    out += [_stat(f"fpn p{i + 3}", pg[i], p[i], tol=1e-2) for i in range(5)]
+    tag = "swin-L " if large else ""
+    out = [_stat(f"{tag}swin c{i + 3}", cg[i].permute(0, 3, 1, 2), c[i + 1], tol=1e-2) for i in range(3)]
+    out += [_stat(f"{tag}fpn p{i + 3}", pg[i], p[i], tol=1e-2) for i in range(5)]
     return out
 
 
-def check_window_attention(dev):
-    """One Swin block's attention (shifted, H/W not multiples of 7) vs the oracle's window_attention path."""
+def check_window_attention(dev, large=False):
+    """One Swin block's attention (shifted, H/W not multiples of the window) vs the oracle's window_attention path.
+    large: window 12 (144 tokens per window, the 160-padded kernel variant), Swin-L head counts."""
     from oracle import backbone as ob
     from mq_det_amd import ops
-    spec, sd, cfg, model, P = tiny(dev)
+    spec, sd, cfg, model, P = tiny(dev, large)
     res = []
-    for stage, (H, W) in ((0, (23, 31)), (1, (12, 16))):
+    for stage, (H, W) in (((0, (29, 41)), (1, (12, 16)), (3, (5, 7))) if large else ((0, (23, 31)), (1, (12, 16)))):
         C, heads, ws = spec.swin_dims[stage], spec.swin_heads[stage], spec.window
         for shift in (0, ws // 2):
             b = f"backbone.body.layers.{stage}.blocks.{1 if shift else 0}.attn"
@@ -159,7 +167,7 @@ def check_window_attention(dev):
             ref = o[:, :H, :W]
             qkv_dev = F.linear(y.to(dev), P[b + ".qkv.weight"], P[b + ".qkv.bias"]).reshape(2, H, W, 3 * C)
             got = ops.window_attention(qkv_dev, P[b + ".qkv.bias"], P[b + ".rel_bias"], heads, ws, shift)
-            res.append(_stat(f"window_attn stage{stage} {H}x{W} shift={shift}", got, ref, tol=4e-3))
+            res.append(_stat(f"window_attn ws={ws} stage{stage} {H}x{W} shift={shift}", got, ref, tol=4e-3))
     return res
 
 
@@ -553,12 +561,13 @@ def make_inputs(spec, B=2, hw=((150, 190), (160, 170)), nvalid=30, seed=3):
     return images, sizes, ids, am, pm, bank
 
 
-def check_full_model(dev, vision_queries=True):
+def check_full_model(dev, vision_queries=True, large=False):
     """Whole forward, tiny-depth MQ-GLIP (real widths / head dims), fp16 HIP path vs fp32 oracle.
-    vision_queries=False: plain GLIP path (no query bank -> no pre-select / GCP blocks), BASELINE configs[0] shape."""
+    vision_queries=False: plain GLIP path (no query bank -> no pre-select / GCP blocks), BASELINE configs[0] shape.
+    large: Swin-L backbone (window 12) -- the MQ-GLIP-L model family at tiny depth (BASELINE configs[3])."""
     from oracle import detector as od
     from mq_det_amd.structures import ImageList
-    spec, sd, cfg, model, P = tiny(dev)
+    spec, sd, cfg, model, P = tiny(dev, large)
     images, sizes, ids, am, pm, bank = make_inputs(spec)
     if not vision_queries:
         bank = None
@@ -644,7 +653,10 @@ def all_checks(dev):
             ("layernorm", lambda: check_layernorm(dev)),
             ("dyconv", lambda: check_dyconv(dev)),
             ("nms", lambda: check_nms(dev)),
+            ("swin-L", lambda: check_window_attention(dev, large=True)),
+            ("swin-L", lambda: check_swin_fpn(dev, large=True)),
             ("full", lambda: check_full_model(dev)),
+            ("full-L", lambda: [dict(r, name=r["name"].replace("full:", "MQ-GLIP-L (tiny depth):")) for r in check_full_model(dev, large=True)]),
             ("full-novq", lambda: [dict(r, name=r["name"].replace("full:", "GLIP (no vision queries) B=1:")) for r in check_full_model(dev, False)])]
     return out
 

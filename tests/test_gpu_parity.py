@@ -239,3 +239,12 @@ def test_backbone_and_caption_caches(dev):
     assert len(model._graphs) <= 2 and model.cache_stats["graph_evict"] >= 1
     model.graph_cache_size = 8
     model.clear_caches()
+
+
+def test_mq_glip_l_family(dev):
+    """BASELINE configs[3] model family at tiny depth: Swin-L widths / heads, window 12 (144-token windows through the
+    160-padded window-attention kernel), FPN on 384 / 768 / 1536 channels, the full MQ-GLIP forward behind it."""
+    import parity_checks as pc
+    _assert(pc.check_window_attention(dev, large=True))
+    _assert(pc.check_swin_fpn(dev, large=True))
+    _assert(pc.check_full_model(dev, large=True))
