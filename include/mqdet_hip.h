@@ -162,6 +162,13 @@ int mq_dcnv2_fwd(const void* x, const float* om, const void* w, const void* bias
  * Replaces DyConv.forward's post-conv part, maskrcnn_benchmark/modeling/rpn/vldyhead.py:148-152,224-242 and
  *   DYReLU.forward, maskrcnn_benchmark/layers/dyrelu.py:78-112. */
 int mq_dyconv_stats(const void* y, float* sums, const float* wy, const float* wx, int B, int n, int W, int C, void* stream);
+/* mq_dyconv_coef for all branches of a DyConv layer in one launch (`branches` is a HOST array of <= 16 entries; sums of
+ * branch i have nblk_i blocks and n_i positions; nbranches_i = number of branches fused into that branch's level). */
+typedef struct mq_coef_branch {
+  const float* sums; const void* gamma; const void* beta; float* coef; int nblk, n, nbranches, reserved;
+} mq_coef_branch;
+int mq_dyconv_coef_group(const mq_coef_branch* branches, int nbr, const float* attn_w, const float* attn_b, int B, int C, int G,
+                         float eps, void* stream);
 int mq_dyconv_coef(const float* sums, const void* gamma, const void* beta, const float* attn_w, const float* attn_b,
                    float* coef, int B, int n, int nblk, int C, int G, float eps, int nbranches, void* stream);
 int mq_dyconv_fuse(const void* y0, const float* coef0, int hs0, int ws0, const void* y1, const float* coef1, int hs1,

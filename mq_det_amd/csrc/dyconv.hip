@@ -122,6 +122,84 @@ extern "C" int mq_dyconv_coef(const float* sums, const void* gamma, const void* 
   return 0;
 }
 
+// Grouped form: the coefficient sets of ALL branches of a DyConv layer (13) in one launch -- grid (B, branches), 1024
+// threads = 4 partial reducers x 256 channels with independent loads in flight (the single-branch kernel walks the
+// per-tile partials of a P3 branch, 143 of them, as one dependent chain: 13 us x 78 launches per forward).
+struct CoefBranch { const float* part; const half_t* gamma; const half_t* beta; float* coef; int nblk, n; float inv_nbr; int pad; };
+struct CoefGroup { CoefBranch br[16]; const float* attn_w; const float* attn_b; int C, G; float eps; int nbr; };
+
+__global__ __launch_bounds__(1024) void dyconv_coef_group_kernel(CoefGroup g) {
+  __shared__ float red[4][256][3];
+  __shared__ float cs[256], css[256];
+  __shared__ float gs[64], gss[64];
+  __shared__ float dotp[256];
+  const CoefBranch br = g.br[blockIdx.y];
+  const int b = blockIdx.x, c = threadIdx.x & 255, q = threadIdx.x >> 8, C = g.C;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  const float* base = br.part + ((long)b * br.nblk * C + c) * 3;
+  for (int k = q; k < br.nblk; k += 4) {                  // fixed order per reducer
+    const float* pp = base + (long)k * C * 3;
+    s0 += pp[0]; s1 += pp[1]; s2 += pp[2];
+  }
+  red[q][c][0] = s0; red[q][c][1] = s1; red[q][c][2] = s2;
+  __syncthreads();
+  if (q != 0) {
+    // reducers 1..3 only feed reducer 0; they still take part in every barrier below
+  }
+  float s[3] = {0.f, 0.f, 0.f};
+  if (q == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s[0] += red[j][c][0]; s[1] += red[j][c][1]; s[2] += red[j][c][2]; }
+    cs[c] = s[0]; css[c] = s[1];
+  }
+  __syncthreads();
+  const int cpg = C / g.G;
+  if (threadIdx.x < g.G) {
+    float a0 = 0.f, a1 = 0.f;
+    for (int j = 0; j < cpg; ++j) { a0 += cs[threadIdx.x * cpg + j]; a1 += css[threadIdx.x * cpg + j]; }
+    gs[threadIdx.x] = a0; gss[threadIdx.x] = a1;
+  }
+  __syncthreads();
+  const float cnt = (float)br.n * cpg;
+  const float mean = gs[c / cpg] / cnt;
+  const float var = fmaxf(gss[c / cpg] / cnt - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + g.eps);
+  const float sc = rstd * (float)br.gamma[c];
+  const float sh = (float)br.beta[c] - mean * sc;
+  if (q == 0) dotp[c] = g.attn_w[c] * (sc * s[2] + sh);          // s[2] = weighted spatial mean of y
+  __syncthreads();
+  for (int o = C / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) dotp[threadIdx.x] += dotp[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (q == 0) {
+    float a = fmaxf(dotp[0] + g.attn_b[0], 0.f);
+    a = fminf(fmaxf(a + 3.f, 0.f), 6.f) / 6.f * br.inv_nbr;
+    br.coef[((long)b * C + c) * 2 + 0] = a * sc;
+    br.coef[((long)b * C + c) * 2 + 1] = a * sh;
+  }
+}
+
+struct mq_coef_branch {          // mirrors include/mqdet_hip.h
+  const float* sums; const void* gamma; const void* beta; float* coef; int nblk, n, nbranches, reserved;
+};
+
+extern "C" int mq_dyconv_coef_group(const mq_coef_branch* br, int nbr, const float* attn_w, const float* attn_b, int B, int C,
+                                    int G, float eps, void* stream) {
+  if (B <= 0 || nbr <= 0) return 0;
+  if (C != 256 || G > 64 || C % G || nbr > 16) return -1;
+  CoefGroup g;
+  for (int i = 0; i < nbr; ++i) {
+    g.br[i].part = br[i].sums; g.br[i].gamma = (const half_t*)br[i].gamma; g.br[i].beta = (const half_t*)br[i].beta;
+    g.br[i].coef = br[i].coef; g.br[i].nblk = br[i].nblk; g.br[i].n = br[i].n; g.br[i].inv_nbr = 1.f / (float)br[i].nbranches;
+    g.br[i].pad = 0;
+  }
+  g.attn_w = attn_w; g.attn_b = attn_b; g.C = C; g.G = G; g.eps = eps; g.nbr = nbr;
+  hipLaunchKernelGGL(dyconv_coef_group_kernel, dim3(B, nbr), dim3(1024), 0, (hipStream_t)stream, g);
+  MQ_CHECK_LAUNCH();
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------- fuse
 struct FuseBranch {
   const half_t* y;      // [B, hs*ws, C]

@@ -9,15 +9,18 @@
 // GEMMs in hipBLASLt with a torch GELU in between: at K = 96 / 192 those GEMMs are HBM-bound (115 us for 516 MB), the
 // GELU pass alone was 1.0 ms / forward.  Here the hidden activation never leaves the register file:
 //
-//   * a workgroup owns 128 tokens (8 waves x 16); the residual stream x is fp32 in HBM (read once, written once);
-//   * LayerNorm is the prologue: each wave normalises its 16 rows, parks them as fp16 in LDS and pulls them back as
-//     MFMA B-fragments that stay in registers for the whole kernel;
+//   * a workgroup owns 128 T tokens (8 waves x 16 T); the residual stream x is fp32 in HBM (read once, written once);
+//   * LayerNorm is the prologue and needs no LDS: a lane loads its token's channels directly in MFMA B-fragment order
+//     (the 4 lanes of a token read one full 128-byte line per 32 channels), row statistics are an in-lane sum plus two
+//     shuffles, and the normalised fp16 fragments stay in registers for the whole kernel;
 //   * both GEMMs are computed TRANSPOSED:  H^T = W1 . LN(x)^T  and  OUT^T = W2 . H^T.  With v_mfma_f32_16x16x32_f16 the
 //     accumulator of the first product (lane holds 4 consecutive hidden units of one token) is, after bias + GELU + cvt,
 //     exactly a B-fragment of the second one -- provided the k-slots of W2 are permuted accordingly (done once on the
 //     host: slot 8g+t of a 32-block <- hidden 4g+t (t < 4) / 16+4g+t-4 (t >= 4)).  No LDS round trip, no shuffle;
-//   * weights stream through one LDS buffer per matrix in chunks of HS hidden units, next chunk prefetched into
-//     registers during the MFMAs of the current one (L2-resident: 147 KB ... 2.4 MB per layer);
+//   * weights stream through a double-buffered LDS chunk of HS hidden units (one barrier per chunk), the next chunk is
+//     prefetched into registers during the MFMAs of the current one (L2-resident: 147 KB ... 2.4 MB per layer); their
+//     A-fragments go through a 3-deep register ring so that LDS latency hides under the preceding MFMAs, and each is
+//     re-used for T = 2 token blocks where the register file allows (C <= 192);
 //   * epilogue: + bias + residual in fp32, optional fused LayerNorm of the result (row statistics by two wave shuffles).
 // Algorithmic HBM bytes per token: C * (4 + 2 + 4 [+ 2]) vs ~40 C in the unfused form.  MFMA work 16 M C^2.
 #include "common.h"
@@ -40,22 +43,22 @@ __device__ __forceinline__ float gelu_erf(float v) {
   return 0.5f * v * (1.f + (v < 0.f ? -e : e));
 }
 
-template <int C, int HS>
+// T = 16-token blocks per wave (A-fragments of the weights are re-used T times: LDS traffic per MFMA / T)
+template <int C, int HS, int T>
 __global__ __launch_bounds__(512) void swin_mlp_kernel(SwinMlpParams p) {
-  constexpr int NW = 8, BM = 16 * NW, HID = 4 * C, KS = C / 32, CT = C / 16, NCHUNK = HID / HS, NB = HS / 32;
-  constexpr int XP = C + 8, W1P = C + 8, W2P = HS + 8;        // LDS row pitches in halfs (+16 B: conflict-free b128 rows)
+  constexpr int NW = 8, TW = 16 * T, BM = TW * NW, HID = 4 * C, KS = C / 32, CT = C / 16, NCHUNK = HID / HS, NB = HS / 32;
+  constexpr int W1P = C + 8, W2P = HS + 8;                    // LDS row pitches in halfs (+16 B: conflict-free b128 rows)
+  constexpr int CHUNK = HS * W1P + C * W2P;                   // halfs per weight chunk (W1 rows | W2 rows)
   constexpr int W1_PIECES = HS * (C / 8), W2_PIECES = C * (HS / 8), PIECES = W1_PIECES + W2_PIECES;
   constexpr int PPT = (PIECES + 511) / 512;                   // 16-byte pieces per thread and chunk
   static_assert(C % 32 == 0 && HS % 32 == 0 && HID % HS == 0, "tile shapes");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  half_t* xs = (half_t*)smem;                                  // [BM][XP]  prologue only; aliased by the weight chunks
-  half_t* w1s = (half_t*)smem;                                 // [HS][W1P]
-  half_t* w2s = w1s + HS * W1P;                                // [C][W2P]
+  half_t* wbuf = (half_t*)smem;                                // [2][CHUNK]: double-buffered weight chunks
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
-  const long row0 = (long)blockIdx.x * BM + wave * 16;        // this wave's 16 tokens
+  const long row0 = (long)blockIdx.x * BM + wave * TW;        // this wave's 16 * T tokens
 
-  // ---- weight chunk prefetch (global -> registers), chunk 0 goes out before the LayerNorm prologue
+  // ---- weight chunk pipeline: global -> registers (issued one chunk ahead) -> LDS buffer (j & 1)
   half8 wreg[PPT];
   auto fetch = [&](int j) {
 #pragma unroll
@@ -70,7 +73,9 @@ __global__ __launch_bounds__(512) void swin_mlp_kernel(SwinMlpParams p) {
       }
     }
   };
-  auto stash = [&]() {
+  auto stash = [&](int buf) {
+    half_t* w1s = wbuf + buf * CHUNK;
+    half_t* w2s = w1s + HS * W1P;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
       const int pc = tid + i * 512;
@@ -85,173 +90,178 @@ __global__ __launch_bounds__(512) void swin_mlp_kernel(SwinMlpParams p) {
   };
   fetch(0);
 
-  // ---- prologue: LayerNorm of this wave's 16 rows (fp32 statistics, two-pass in registers).  LPR lanes own one row,
-  // 4 consecutive channels per lane and step; rows of a wave are processed 64 / LPR at a time.
-  {
-    constexpr int LPR = (C / 4 <= 32) ? 32 : 64, RPP = 64 / LPR, NCH = (C / 4 + LPR - 1) / LPR;
-    const int sub = lane % LPR, rsel = lane / LPR;
-    half_t* xw = xs + wave * 16 * XP;
-#pragma unroll 2
-    for (int rr = 0; rr < 16; rr += RPP) {
-      const int r = rr + rsel;
-      const long row = row0 + r;
-      float v[NCH][4];
-      float s = 0.f;
+  // ---- prologue: LayerNorm straight into MFMA B-fragments.  Lane (g, token l15) loads x[token][32 ks + 8 g .. + 7] -- the
+  // four g-lanes of a token cover 128 contiguous bytes per ks, a full cache line -- so a row lives in 4 lanes: statistics
+  // are an in-lane sum plus two shuffles, and the normalised values already sit where the first MFMA wants them.
+  half8 xf[T][KS];
 #pragma unroll
-      for (int k = 0; k < NCH; ++k) {
-        const int c4 = sub + k * LPR;
+  for (int tb = 0; tb < T; ++tb) {
+    const long row = row0 + tb * 16 + l15;
+    const bool live = row < p.M;
+    float v[KS][8];
+    float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[k][j] = 0.f;
-        if (c4 < C / 4 && row < p.M) {
-          const float4_ a = *(const float4_*)(p.x + row * C + c4 * 4);
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = ks * 32 + g * 8;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[k][j] = a[j];
-          if (p.delta) {
-            const half4 d = *(const half4*)(p.delta + row * C + c4 * 4);
+      for (int j = 0; j < 8; ++j) v[ks][j] = 0.f;
+      if (live) {
+        const float4_ a = *(const float4_*)(p.x + row * C + c), b = *(const float4_*)(p.x + row * C + c + 4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[k][j] += (float)d[j];
-          }
-        }
+        for (int j = 0; j < 4; ++j) { v[ks][j] = a[j]; v[ks][4 + j] = b[j]; }
+        if (p.delta) {
+          const half8 d = *(const half8*)(p.delta + row * C + c);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s += v[k][j];
-      }
-#pragma unroll
-      for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
-      const float mean = s * (1.f / (float)C);
-      float q = 0.f;
-#pragma unroll
-      for (int k = 0; k < NCH; ++k) {
-        if (sub + k * LPR < C / 4) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { const float d = v[k][j] - mean; q += d * d; }
+          for (int j = 0; j < 8; ++j) v[ks][j] += (float)d[j];
         }
       }
 #pragma unroll
-      for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
-      const float rstd = rsqrtf(q * (1.f / (float)C) + p.eps);
-#pragma unroll
-      for (int k = 0; k < NCH; ++k) {
-        const int c4 = sub + k * LPR;
-        if (c4 < C / 4) {
-          const half4 gm = *(const half4*)(p.g2 + c4 * 4), bt = *(const half4*)(p.be2 + c4 * 4);
-          half4 o;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = (half_t)((v[k][j] - mean) * rstd * (float)gm[j] + (float)bt[j]);
-          *(half4*)(xw + r * XP + c4 * 4) = o;
-        }
-      }
+      for (int j = 0; j < 8; ++j) s += v[ks][j];
     }
-  }
-  wave_lds_fence();
-  // B-fragments of LN(x)^T: lane (g, token l15) holds x_ln[token][32 ks + 8 g .. + 7]
-  half8 xf[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) xf[ks] = *(const half8*)(xs + (wave * 16 + l15) * XP + ks * 32 + g * 8);
-
-  float4_ acc2[CT];
-#pragma unroll
-  for (int ct = 0; ct < CT; ++ct) acc2[ct] = (float4_){0.f, 0.f, 0.f, 0.f};
-
-  __syncthreads();                                             // every wave has its fragments: xs may be overwritten
-  stash();
-  __syncthreads();
-
-  for (int j = 0; j < NCHUNK; ++j) {
-    if (j + 1 < NCHUNK) fetch(j + 1);
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      // GEMM 1 (transposed): H^T[32 hidden, 16 tokens] over K = C
-      float4_ h0 = (float4_){0.f, 0.f, 0.f, 0.f}, h1 = h0;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const half8 a0 = *(const half8*)(w1s + (nb * 32 + l15) * W1P + ks * 32 + g * 8);
-        const half8 a1 = *(const half8*)(w1s + (nb * 32 + 16 + l15) * W1P + ks * 32 + g * 8);
-        h0 = mfma16(a0, xf[ks], h0);
-        h1 = mfma16(a1, xf[ks], h1);
-      }
-      // + bias, exact GELU, fp16: the lane's 8 values are k-slots 8g .. 8g+7 of the second product
-      const int hb = j * HS + nb * 32 + 4 * g;
-      const half4 bb0 = *(const half4*)(p.b1 + hb), bb1 = *(const half4*)(p.b1 + hb + 16);
-      half8 hf;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        hf[r] = (half_t)gelu_erf(h0[r] + (float)bb0[r]);
-        hf[4 + r] = (half_t)gelu_erf(h1[r] + (float)bb1[r]);
-      }
-      // GEMM 2 (transposed): OUT^T[C, 16 tokens] += W2p[:, 32 k-slots] . H^T
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        const half8 a = *(const half8*)(w2s + (ct * 16 + l15) * W2P + nb * 32 + g * 8);
-        acc2[ct] = mfma16(a, hf, acc2[ct]);
-      }
-    }
-    __syncthreads();
-    if (j + 1 < NCHUNK) {
-      stash();
-      __syncthreads();
-    }
-  }
-
-  // ---- epilogue: lane holds OUT^T[c = 16 ct + 4 g + r][token = l15]; + bias + residual (x' re-read: L2-hot), fp32 out
-  const long row = row0 + l15;
-  const bool live = row < p.M;
-  float s = 0.f;
-#pragma unroll
-  for (int ct = 0; ct < CT; ++ct) {
-    const int c = ct * 16 + 4 * g;
-    const half4 b2 = *(const half4*)(p.b2 + c);
-    float4_ xr = (float4_){0.f, 0.f, 0.f, 0.f};
-    if (live) {
-      xr = *(const float4_*)(p.x + row * C + c);
-      if (p.delta) {
-        const half4 d = *(const half4*)(p.delta + row * C + c);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xr[r] += (float)d[r];
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { acc2[ct][r] += (float)b2[r] + xr[r]; s += acc2[ct][r]; }
-    if (live) *(float4_*)(p.out + row * C + c) = acc2[ct];
-  }
-  if (p.y) {                                                   // fused LayerNorm of the result (next norm1 / stage norm)
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
     const float mean = s * (1.f / (float)C);
     float q = 0.f;
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const float d = acc2[ct][r] - mean; q += d * d; }
+      for (int j = 0; j < 8; ++j) { const float d = v[ks][j] - mean; q += d * d; }
     q += __shfl_xor(q, 16);
     q += __shfl_xor(q, 32);
-    const float rstd = rsqrtf(q * (1.f / (float)C) + p.eps_n);
-    if (live) {
+    const float rstd = rsqrtf(q * (1.f / (float)C) + p.eps);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = ks * 32 + g * 8;
+      const half8 gm = *(const half8*)(p.g2 + c), bt = *(const half8*)(p.be2 + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xf[tb][ks][j] = (half_t)((v[ks][j] - mean) * rstd * (float)gm[j] + (float)bt[j]);
+    }
+  }
+
+  float4_ acc2[T][CT];
+#pragma unroll
+  for (int tb = 0; tb < T; ++tb)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc2[tb][ct] = (float4_){0.f, 0.f, 0.f, 0.f};
+
+  stash(0);
+  __syncthreads();
+
+  for (int j = 0; j < NCHUNK; ++j) {
+    if (j + 1 < NCHUNK) fetch(j + 1);
+    const half_t* w1s = wbuf + (j & 1) * CHUNK;
+    const half_t* w2s = w1s + HS * W1P;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      // GEMM 1 (transposed): H^T[32 hidden, 16 T tokens] over K = C; A-fragments through a 3-deep register ring so that the
+      // LDS latency of step ks + 2 hides under the MFMAs of steps ks, ks + 1
+      float4_ h0[T], h1[T];
+#pragma unroll
+      for (int tb = 0; tb < T; ++tb) h0[tb] = h1[tb] = (float4_){0.f, 0.f, 0.f, 0.f};
+      const half_t* a0p = w1s + (nb * 32 + l15) * W1P + g * 8;
+      const half_t* a1p = a0p + 16 * W1P;
+      half8 r0[3], r1[3];
+#pragma unroll
+      for (int ks = 0; ks < 2 && ks < KS; ++ks) { r0[ks] = *(const half8*)(a0p + ks * 32); r1[ks] = *(const half8*)(a1p + ks * 32); }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 2 < KS) { r0[(ks + 2) % 3] = *(const half8*)(a0p + (ks + 2) * 32); r1[(ks + 2) % 3] = *(const half8*)(a1p + (ks + 2) * 32); }
+#pragma unroll
+        for (int tb = 0; tb < T; ++tb) {
+          h0[tb] = mfma16(r0[ks % 3], xf[tb][ks], h0[tb]);
+          h1[tb] = mfma16(r1[ks % 3], xf[tb][ks], h1[tb]);
+        }
+      }
+      // first fragments of the second product go out before the GELU arithmetic
+      const half_t* a2p = w2s + l15 * W2P + nb * 32 + g * 8;
+      half8 r2[3];
+#pragma unroll
+      for (int ct = 0; ct < 2 && ct < CT; ++ct) r2[ct] = *(const half8*)(a2p + ct * 16 * W2P);
+      // + bias, exact GELU, fp16: the lane's 8 values are k-slots 8g .. 8g+7 of the second product
+      const int hb = j * HS + nb * 32 + 4 * g;
+      const half4 bb0 = *(const half4*)(p.b1 + hb), bb1 = *(const half4*)(p.b1 + hb + 16);
+      half8 hf[T];
+#pragma unroll
+      for (int tb = 0; tb < T; ++tb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          hf[tb][r] = (half_t)gelu_erf(h0[tb][r] + (float)bb0[r]);
+          hf[tb][4 + r] = (half_t)gelu_erf(h1[tb][r] + (float)bb1[r]);
+        }
+      // GEMM 2 (transposed): OUT^T[C, 16 T tokens] += W2p[:, 32 k-slots] . H^T
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        const int c = ct * 16 + 4 * g;
-        const half4 gm = *(const half4*)(p.gn + c), bt = *(const half4*)(p.bn + c);
-        half4 o;
+        if (ct + 2 < CT) r2[(ct + 2) % 3] = *(const half8*)(a2p + (ct + 2) * 16 * W2P);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (half_t)((acc2[ct][r] - mean) * rstd * (float)gm[r] + (float)bt[r]);
-        *(half4*)(p.y + row * C + c) = o;
+        for (int tb = 0; tb < T; ++tb) acc2[tb][ct] = mfma16(r2[ct % 3], hf[tb], acc2[tb][ct]);
+      }
+    }
+    if (j + 1 < NCHUNK) stash((j + 1) & 1);
+    __syncthreads();                                           // chunk j + 1 visible; buffer (j & 1) free for chunk j + 2
+  }
+
+  // ---- epilogue: lane holds OUT^T[c = 16 ct + 4 g + r][token = l15]; + bias + residual (x' re-read: L2-hot), fp32 out
+#pragma unroll
+  for (int tb = 0; tb < T; ++tb) {
+    const long row = row0 + tb * 16 + l15;
+    const bool live = row < p.M;
+    float s = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int c = ct * 16 + 4 * g;
+      const half4 b2 = *(const half4*)(p.b2 + c);
+      float4_ xr = (float4_){0.f, 0.f, 0.f, 0.f};
+      if (live) {
+        xr = *(const float4_*)(p.x + row * C + c);
+        if (p.delta) {
+          const half4 d = *(const half4*)(p.delta + row * C + c);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xr[r] += (float)d[r];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { acc2[tb][ct][r] += (float)b2[r] + xr[r]; s += acc2[tb][ct][r]; }
+      if (live) *(float4_*)(p.out + row * C + c) = acc2[tb][ct];
+    }
+    if (p.y) {                                                 // fused LayerNorm of the result (next norm1 / stage norm)
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      const float mean = s * (1.f / (float)C);
+      float q = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = acc2[tb][ct][r] - mean; q += d * d; }
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      const float rstd = rsqrtf(q * (1.f / (float)C) + p.eps_n);
+      if (live) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int c = ct * 16 + 4 * g;
+          const half4 gm = *(const half4*)(p.gn + c), bt = *(const half4*)(p.bn + c);
+          half4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (half_t)((acc2[tb][ct][r] - mean) * rstd * (float)gm[r] + (float)bt[r]);
+          *(half4*)(p.y + row * C + c) = o;
+        }
       }
     }
   }
 }
 
-template <int C, int HS>
+template <int C, int HS, int T>
 static int launch_swin_mlp(const SwinMlpParams& p, hipStream_t s) {
-  constexpr int XP = C + 8, W1P = C + 8, W2P = HS + 8;
-  constexpr size_t xs_b = (size_t)128 * XP * 2, w_b = (size_t)(HS * W1P + C * W2P) * 2;
-  constexpr size_t smem = xs_b > w_b ? xs_b : w_b;
+  constexpr size_t smem = (size_t)2 * (HS * (C + 8) + C * (HS + 8)) * 2;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)swin_mlp_kernel<C, HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)swin_mlp_kernel<C, HS, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  const unsigned grid = (unsigned)((p.M + 127) / 128);
-  hipLaunchKernelGGL((swin_mlp_kernel<C, HS>), dim3(grid), dim3(512), smem, s, p);
+  constexpr int BM = 128 * T;
+  const unsigned grid = (unsigned)((p.M + BM - 1) / BM);
+  hipLaunchKernelGGL((swin_mlp_kernel<C, HS, T>), dim3(grid), dim3(512), smem, s, p);
   MQ_CHECK_LAUNCH();
   return 0;
 }
@@ -269,9 +279,9 @@ extern "C" int mq_swin_mlp_fwd(const float* x, const void* delta, const void* ln
   if (y && (!next_g || !next_b)) return -2;
   hipStream_t s = (hipStream_t)stream;
   switch (C) {
-    case 96: return launch_swin_mlp<96, 64>(p, s);
-    case 192: return launch_swin_mlp<192, 32>(p, s);
-    case 384: return launch_swin_mlp<384, 32>(p, s);
+    case 96: return launch_swin_mlp<96, 64, 2>(p, s);
+    case 192: return launch_swin_mlp<192, 32, 2>(p, s);
+    case 384: return launch_swin_mlp<384, 32, 1>(p, s);
     default: return -1;                                      // other widths: library GEMM path of the caller
   }
 }

@@ -554,16 +554,14 @@ def dyconv_tokens(P, cfg, b, tok, sizes):
                              "stride": stride, "wy": wy, "wx": wx})
             owner.append((lvl, k, len(spec)))
     ys = ops.dcnv2_group(branches, want_stats=True)
+    # GroupNorm affine x scale attention of every branch, one launch (the statistics came out of the DCN epilogue)
+    coefs = ops.dyconv_coef_group(
+        [{"sums": sums, "n": Ho * Wo, "gamma": P[f"{b}.DyConv.{k}.bn.weight"], "beta": P[f"{b}.DyConv.{k}.bn.bias"], "nbranches": nb}
+         for (lvl, k, nb), (y, (Ho, Wo), sums) in zip(owner, ys)], P[b + ".attn_w"], P[b + ".attn_b"], G.NUM_GROUPS, G.EPSILON)
 
     def epilogue(lvl):
         H, W = sizes[lvl]
-        fused = []
-        for (l2, k, nb), br, (y, (Ho, Wo), sums) in zip(owner, branches, ys):
-            if l2 != lvl:
-                continue
-            coef = ops.dyconv_branch_coef(y, Wo, P[f"{b}.DyConv.{k}.bn.weight"], P[f"{b}.DyConv.{k}.bn.bias"],
-                                          P[b + ".attn_w"], P[b + ".attn_b"], G.NUM_GROUPS, G.EPSILON, nb, br["wy"], br["wx"], sums=sums)
-            fused.append((y, coef, Ho, Wo))
+        fused = [(y, coef, Ho, Wo) for (l2, k, nb), (y, (Ho, Wo), sums), coef in zip(owner, ys, coefs) if l2 == lvl]
         o = out[:, offs[lvl]:offs[lvl + 1]]
         _, pool = ops.dyconv_fuse(fused, H, W, out=o)
         ops.dyrelu_(o, pool, P[b + ".relu.fc.0.weight"], P[b + ".relu.fc.0.bias"], P[b + ".relu.fc.2.weight"],

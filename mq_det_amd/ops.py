@@ -32,6 +32,7 @@ _SIGNATURES = {
     "mq_dcnv2_group_fwd": (_i, [_vp, _i, _vp]),
     "mq_dyconv_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mq_dyconv_coef": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "mq_dyconv_coef_group": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _vp]),
     "mq_dyconv_fuse": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _l, _vp, _i, _i, _i, _i, _vp]),
     "mq_dyrelu_coef": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mq_dyrelu_apply": (_i, [_vp, _vp, _i, _i, _i, _l, _vp]),
@@ -462,6 +463,32 @@ def dyconv_branch_coef(y, Wsrc, gamma, beta, attn_w, attn_b, groups, eps, nbranc
     _chk(lib.mq_dyconv_coef(_ptr(sums), _ptr(gamma), _ptr(beta), _ptr(attn_w), _ptr(attn_b), _ptr(coef), B, n, nblk, C, groups,
                             float(eps), nbranches, _stream()), "mq_dyconv_coef")
     return coef
+
+
+class _CoefBranch(ctypes.Structure):
+    """mq_coef_branch of include/mqdet_hip.h."""
+    _fields_ = [(n, _vp) for n in ("sums", "gamma", "beta", "coef")] + [(n, _i) for n in ("nblk", "n", "nbranches", "reserved")]
+
+
+def dyconv_coef_group(items, attn_w, attn_b, groups, eps):
+    """Coefficients of several DCN branches in one launch.  items: list of dicts {sums [B,nblk,C,3] fp32, n (positions),
+    gamma, beta (fp16 [C]), nbranches} -> list of coef [B,C,2] fp32."""
+    lib = load_library()
+    arr = (_CoefBranch * len(items))()
+    outs = []
+    B = C = None
+    for a, it in zip(arr, items):
+        sums = it["sums"]
+        _need_gpu(sums, it["gamma"], it["beta"], attn_w, attn_b)
+        assert sums.dtype == torch.float32 and sums.is_contiguous() and sums.shape[2:] == (256, 3)
+        B, C = sums.shape[0], sums.shape[2]
+        coef = torch.empty(B, C, 2, dtype=torch.float32, device=sums.device)
+        a.sums, a.gamma, a.beta, a.coef = sums.data_ptr(), it["gamma"].data_ptr(), it["beta"].data_ptr(), coef.data_ptr()
+        a.nblk, a.n, a.nbranches, a.reserved = sums.shape[1], int(it["n"]), int(it["nbranches"]), 0
+        outs.append(coef)
+    _chk(lib.mq_dyconv_coef_group(ctypes.cast(arr, _vp), len(items), _ptr(attn_w), _ptr(attn_b), B, C, groups, float(eps), _stream()),
+         "mq_dyconv_coef_group")
+    return outs
 
 
 def dyconv_fuse(branches, H, W, out=None):

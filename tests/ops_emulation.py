@@ -349,3 +349,12 @@ def ms_deform_attn(value, spatial_shapes, sampling_locations, attention_weights,
     from oracle.gdino import ms_deform_attn_core
     out = ms_deform_attn_core(value.float(), spatial_shapes, sampling_locations.float(), attention_weights.float())
     return out.to(out_dtype or value.dtype)
+
+
+def dyconv_coef_group(items, attn_w, attn_b, groups, eps):
+    out = []
+    for it in items:
+        B, _, C, _ = it["sums"].shape
+        y_shape = torch.empty(B, int(it["n"]), C, device="meta")          # only its shape is read on the fused-statistics path
+        out.append(dyconv_branch_coef(y_shape, 0, it["gamma"], it["beta"], attn_w, attn_b, groups, eps, it["nbranches"], sums=it["sums"]))
+    return out

@@ -322,9 +322,17 @@ def check_dcn(dev):
         res.append(_stat(f"dcnv2 fused GroupNorm statistics {name}", sums.sum(1), st_ref, tol=1e-4))
         group.append({"x": xd, "om": omd, "w": wp, "bias": bias.to(dev), "stride": stride, "wy": wy, "wx": wx})
         refs.append((name, y2, sums))
-    for (name, y2, sums), (yg, _, sg) in zip(refs, ops.dcnv2_group(group)):      # ONE launch for the three calls
+    grouped = ops.dcnv2_group(group)                                             # ONE launch for the three calls
+    for (name, y2, sums), (yg, _, sg) in zip(refs, grouped):
         res.append(_stat(f"dcnv2 grouped launch == single launch: {name}", yg, y2.float(), tol=0.0))
         res.append(_stat(f"dcnv2 grouped launch statistics: {name}", sg, sums, tol=0.0))
+    # GroupNorm / scale-attention coefficients: grouped launch (4 parallel reducers) vs the single-branch kernel
+    gam, bet = (torch.randn(256, generator=g) * 0.1 + 1).half().to(dev), (torch.randn(256, generator=g) * 0.1).half().to(dev)
+    aw, ab = (torch.randn(256, generator=g) * 0.1).to(dev), torch.randn(1, generator=g).to(dev)
+    items = [{"sums": sg, "n": yg.shape[1], "gamma": gam, "beta": bet, "nbranches": 3} for (yg, _, sg) in grouped]
+    for (name, _, _), (yg, (Ho, Wo), sg), cg in zip(refs, grouped, ops.dyconv_coef_group(items, aw, ab, 16, 1e-5)):
+        c1 = ops.dyconv_branch_coef(yg, Wo, gam, bet, aw, ab, 16, 1e-5, 3, sums=sg)
+        res.append(_stat(f"dyconv coefficients grouped vs single launch: {name}", cg, c1, tol=1e-5))
     return res
 
 

@@ -62,7 +62,7 @@ def test_reference_cfg_tree_and_caller_sequence(monkeypatch):
 
     # ---- test-only: emulated HIP entry points, CPU plan (the product refuses CPU by design)
     for n in ("attention", "attention4", "window_attention", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores",
-              "dyconv_branch_coef", "dyconv_fuse", "dyrelu_", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "vlfuse_i2t",
+              "dyconv_branch_coef", "dyconv_coef_group", "dyconv_fuse", "dyrelu_", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "vlfuse_i2t",
               "vlfuse_t2i", "box_decode", "ml_nms", "roi_align", "swin_mlp"):
         monkeypatch.setattr(ops, n, getattr(emu, n))
 

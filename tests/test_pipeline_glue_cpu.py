@@ -39,7 +39,7 @@ def setup():
 def emulated_ops(monkeypatch):
     fake = types.SimpleNamespace(**{n: getattr(emu, n) for n in (
         "attention", "attention4", "window_attention", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores",
-        "dyconv_branch_coef", "dyconv_fuse", "dyrelu_", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "vlfuse_i2t", "vlfuse_t2i",
+        "dyconv_branch_coef", "dyconv_coef_group", "dyconv_fuse", "dyrelu_", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "vlfuse_i2t", "vlfuse_t2i",
         "box_decode", "ml_nms", "roi_align", "swin_mlp")})
     fake.SWIN_MLP_WIDTHS = (96, 192, 384)
     monkeypatch.setattr(pipeline, "ops", fake)
