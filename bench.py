@@ -50,7 +50,10 @@ MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16, /opt/skills/guides/MI355X_
 HBM_PEAK_GBS = 8000.0
 
 
-def build_model(dev, caches=False, n_classes=NUM_CLASSES_IN_CAPTION, n_categories=None):
+GFLOP_PER_IMAGE_L = 3260.0         # MQ-GLIP-L (Swin-L 1625 + 8 fusion layers ...), BASELINE.md section 2
+
+
+def build_model(dev, caches=False, n_classes=NUM_CLASSES_IN_CAPTION, n_categories=None, large=False):
     from transformers import AutoTokenizer
     from mq_det_amd import get_cfg
     from mq_det_amd.modeling.detector import GeneralizedVLRCNN_New
@@ -62,6 +65,11 @@ def build_model(dev, caches=False, n_classes=NUM_CLASSES_IN_CAPTION, n_categorie
     cfg.MODEL.ATSS.DETECTIONS_PER_IMG = 300
     cfg.TEST.MDETR_STYLE_AGGREGATE_CLASS_NUM = 3000
     cfg.MODEL.BACKBONE_CACHE = bool(caches)
+    if large:                                                 # configs/pretrain/mq-glip-l.yaml:11-17,41
+        cfg.MODEL.SWINT.EMBED_DIM, cfg.MODEL.SWINT.DEPTHS = 192, (2, 2, 18, 2)
+        cfg.MODEL.SWINT.NUM_HEADS, cfg.MODEL.SWINT.WINDOW_SIZE = (6, 12, 24, 48), 12
+        cfg.MODEL.SWINT.OUT_CHANNELS = (192, 384, 768, 1536)
+        cfg.MODEL.DYHEAD.NUM_CONVS = 8
     if os.environ.get("MQ_RESIDUAL_FP32") is not None:        # A/B switch (precision of the residual streams)
         cfg.MODEL.RESIDUAL_FP32 = os.environ["MQ_RESIDUAL_FP32"] == "1"
     if os.environ.get("MQ_SWIN_FUSED_MLP") is not None:       # A/B switch (fused Swin MLP kernel vs library GEMMs + GELU)
@@ -276,7 +284,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lang-b64", action="store_true")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
-    ap.add_argument("--workload", choices=["mq-glip-t", "lvis"], default="mq-glip-t")
+    ap.add_argument("--workload", choices=["mq-glip-t", "lvis", "mq-glip-l"], default="mq-glip-t")
+    ap.add_argument("--chunk-batch", type=int, default=0, help="lvis workload: image x chunk items stacked per launch sequence "
+                                                                "through model.forward_chunks (0 = one forward per chunk)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (for PMC profiling)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -292,8 +302,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ops.load_library()
-    lvis = args.workload == "lvis"
-    cfg, model, chunks = build_model(dev, caches=lvis, n_categories=1203 if lvis else None)
+    lvis, large = args.workload == "lvis", args.workload == "mq-glip-l"
+    if large and args.batch == B_PER_GPU:
+        args.batch = 4                                        # BASELINE.json configs[3]: bs = 4 / GPU
+    cfg, model, chunks = build_model(dev, caches=lvis, n_categories=1203 if lvis else None, large=large)
     if args.no_graph:
         model.use_hip_graph = False
 
@@ -313,6 +325,9 @@ def main():
         def step():
             # a NEW batch of pixels every step (the clone is the "data loader"), then every chunk caption for it
             il = ImageList(imgs.clone(), [(H, W)] * Bn)
+            if args.chunk_batch > 0:
+                res = model.forward_chunks(il, chunks, max_items=args.chunk_batch)
+                return res[-1]
             for cap, pm in chunks:
                 out = model(il, captions=[cap] * Bn, positive_map=pm)
                 if world > 1:
@@ -370,12 +385,17 @@ def main():
             "metric": "images/sec MQ-GLIP-T 800×1333 5-shot vision queries, 1/2/4/8 MI355X", "value": round(ips, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": ("BASELINE.json configs[1]: MQ-GLIP-T (Swin-T + BERT-base + GCP + 6-layer VLDyHead), 5 vision queries x "
+            "config": {"workload": ("BASELINE.json configs[3] model: MQ-GLIP-L (Swin-L window 12 + BERT-base + GCP + 8-layer VLDyHead), fp16 operands "
+                                    f"(the config names bf16; the kernels are fp16-in / fp32-accumulate), 5 vision queries x 40 classes, {n_tok}-token "
+                                    "caption, every step a full forward") if large else
+                                   ("BASELINE.json configs[1]: MQ-GLIP-T (Swin-T + BERT-base + GCP + 6-layer VLDyHead), 5 vision queries x "
                                     f"40 classes, {n_tok}-token caption padded to 256, LVIS-style post-processing, every step a full forward "
                                     "(feature / caption caches off)") if not lvis else
                                    ("BASELINE.json configs[2] shape: MQ-GLIP-T, LVIS protocol -- 1203 synthetic categories in 31 chunk captions, "
                                     "each step = a new image batch x 31 forwards with the boundary's per-image feature cache and per-caption "
-                                    "language cache ON; value counts FORWARDS (image x chunk) per second"),
+                                    "language cache ON; value counts FORWARDS (image x chunk) per second"
+                                    + (f"; chunks stacked along the batch ({args.chunk_batch} items per launch sequence, model.forward_chunks)"
+                                       if args.chunk_batch > 0 else "")),
                        "global_batch": world * Bn, "batch_per_gpu": Bn, "image": "800x1333 -> 800x1344",
                        "parallelism": f"dp{world}", "weights": "seeded random init (no checkpoints offline)",
                        "residual_streams": "fp32" if cfg.MODEL.get("RESIDUAL_FP32", True) else "fp16"},
@@ -387,18 +407,19 @@ def main():
             res["forwards_per_step"] = fwd_per_step
             res["lvis_style_images_per_sec"] = round(ips / fwd_per_step, 3)
         else:
-            res["model_tflops"] = round(ips * GFLOP_PER_IMAGE / 1e3, 2)
-            res["model_frac_of_mfma_peak"] = round(ips * GFLOP_PER_IMAGE / 1e3 / (MFMA_PEAK_TFLOPS * world), 4)
+            gf = GFLOP_PER_IMAGE_L if large else GFLOP_PER_IMAGE
+            res["model_tflops"] = round(ips * gf / 1e3, 2)
+            res["model_frac_of_mfma_peak"] = round(ips * gf / 1e3 / (MFMA_PEAK_TFLOPS * world), 4)
             res["roofline"] = roof
             res["rooflines"] = roofs
             res["kernels_ms_per_step"] = {k: round(v[1] / max(prof_steps, 1), 3) for k, v in sorted(kern.items())}
             res["timing"] = "roofline records: HIP events on the launch stream around each launch, eager single-stream pass of the same steps"
-            if world == 1 and not args.no_lang_b64:
+            if world == 1 and not args.no_lang_b64 and not large:
                 try:
                     res["lang_path_b64"] = lang_path_b64(model, cfg, dev, chunks)
                 except Exception as e:  # noqa: BLE001
                     res["lang_path_b64"] = {"error": repr(e)[:300]}
-            if world == 1 and not args.no_cpu_baseline:
+            if world == 1 and not args.no_cpu_baseline and not large:
                 try:
                     res["cpu_baseline"] = cpu_baseline()
                 except Exception as e:  # noqa: BLE001

@@ -448,6 +448,118 @@ class GeneralizedVLRCNN_New(nn.Module):
             return result, [f.float().contiguous() for f in out["feats"]]
         return result
 
+    # ------------------------------------------------------------------ chunk batching
+    def _features(self, images):
+        """(feats, pooled) of an image batch through the per-image cache (Swin + FPN run once per distinct tensor)."""
+        dev = images.tensors.device
+        if self._plan is None or self._plan_key != dev:
+            self.prepare(dev)
+        src = images.tensors
+        fc = self._feat_cache if self.backbone_cache else None
+        if fc is not None and fc["src"] is src and fc["version"] == src._version and (fc["pooled"] is not None or not self._use_vq()):
+            self.cache_stats["backbone_hit"] += 1
+            return fc["feats"], fc["pooled"]
+        self.cache_stats["backbone_miss"] += 1
+        dtype = self._plan["backbone.body.patch_embed.proj.weight"].dtype
+        x = src.to(dtype).contiguous(memory_format=torch.channels_last)
+        feats, pooled = self._backbone_stage(x)
+        if self.backbone_cache:
+            self._feat_cache = {"src": src, "version": src._version, "feats": feats, "pooled": pooled}
+        return feats, pooled
+
+    def _front_for(self, caption, dev, use_vq):
+        """Image-independent BERT layers of ONE caption (batch 1), cached per caption."""
+        key = ((caption,), 1, use_vq)
+        fr = self._front_cache.get(key)
+        if fr is None:
+            self.cache_stats["front_miss"] += 1
+            ids, am, _ = self.tokenize([caption], dev)
+            fr = self._front_cache[key] = pipeline.language_front(self._plan, self.cfg, ids, am, use_vq)
+            while len(self._front_cache) > int(self.cfg.MODEL.get("LANG_FRONT_CACHE", 64)):
+                self._front_cache.popitem(last=False)
+        else:
+            self.cache_stats["front_hit"] += 1
+            self._front_cache.move_to_end(key)
+        return fr
+
+    @torch.no_grad()
+    def forward_chunks(self, images, chunks, max_items=32):
+        """The LVIS / ODinW evaluation protocol in ONE call: `chunks` = [(caption, positive_map), ...] (the 31 chunk captions of
+        engine/inference.py:605-625) for the SAME image batch.  Equivalent to `[model(images, captions=[c] * B,
+        positive_map=pm) for c, pm in chunks]`, but Swin + FPN run once, the image-independent BERT layers once per caption
+        (cached across images), and the image-dependent rest runs with the chunks stacked along the batch dimension
+        (up to `max_items` image x chunk items per launch sequence): B = 1 -- the reference's TEST.IMS_PER_BATCH -- no longer
+        means a batch-1 forward.  Returns list (over chunks) of list[BoxList] (over images)."""
+        if self.training:
+            raise NotImplementedError("training forward is out of scope")
+        images = to_image_list(images)
+        dev = images.tensors.device
+        feats, pooled = self._features(images)
+        P, cfg = self._plan, self.cfg
+        dtype = P["backbone.body.patch_embed.proj.weight"].dtype
+        Bn = images.tensors.shape[0]
+        use_vq = self._use_vq()
+        from .. import ops
+        use_graph = self.use_hip_graph and not ops.timing_active()
+        im_wh = torch.tensor([[w, h] for (h, w) in images.image_sizes], dtype=torch.float32, device=dev)
+        results = []
+        per = max(1, int(max_items) // Bn)
+        for g0 in range(0, len(chunks), per):
+            grp = chunks[g0:g0 + per]
+            g = len(grp)
+            ids, ams, kvs, fronts, pms, labs = [], [], [], [], [], []
+            for cap, pm in grp:
+                i, a, kv = self.tokenize([cap], dev)
+                T = i.shape[1]
+                if any(t >= T for v in pm.values() for t in (v if not isinstance(v, int) else [v])):
+                    pm = {k: [t for t in (v if not isinstance(v, int) else [v]) if t < T] for k, v in pm.items()}
+                ids.append(i)
+                ams.append(a)
+                kvs.append(kv)
+                pms.append(pm)
+                labs.append([k for k, v in pm.items() if len(v) != 0])
+            T = ids[0].shape[1]
+            vision = idx = None
+            if use_vq:                                            # item order: chunk-major (item = chunk * B + image)
+                vision, idx = self.query_selector.select([l for l in labs for _ in range(Bn)], [pm for pm in pms for _ in range(Bn)],
+                                                         T, dev, dtype)
+                if vision.shape[1] == 0:
+                    vision = idx = None
+            for cap, _ in grp:
+                fronts.append(self._front_for(cap, dev, vision is not None))
+            rep = lambda t: t.repeat_interleave(Bn, 0)            # noqa: E731  [g, ...] -> [g * B, ...] chunk-major
+            front = {"x": rep(torch.cat([f["x"] for f in fronts])),
+                     "x32": None if fronts[0].get("x32") is None else rep(torch.cat([f["x32"] for f in fronts])),
+                     "hidden": [rep(torch.cat([f["hidden"][k] for f in fronts])) for k in range(len(fronts[0]["hidden"]))],
+                     "key_bias": rep(torch.cat([f["key_bias"] for f in fronts])), "kv_len": rep(torch.cat([f["kv_len"] for f in fronts])),
+                     "next": fronts[0]["next"]}
+            L = max(1, max(len(l) for l in labs))
+            MT = max(1, max((len(pm[k]) for pm, l in zip(pms, labs) for k in l), default=1))
+            tok3 = torch.full((g, L, MT), -1, dtype=torch.int32)
+            lab2 = torch.zeros(g, L, dtype=torch.int32)
+            for c, (pm, l) in enumerate(zip(pms, labs)):
+                for j, k in enumerate(l):
+                    tok3[c, j, :len(pm[k])] = torch.tensor(pm[k], dtype=torch.int32)
+                    lab2[c, j] = k
+            tok3, lab2 = rep(tok3.to(dev)).contiguous(), rep(lab2.to(dev)).contiguous()
+            tile = lambda f: f.permute(0, 2, 3, 1).repeat(g, 1, 1, 1).permute(0, 3, 1, 2)     # noqa: E731  NHWC memory kept
+            inputs = ([tile(f) for f in feats], None if pooled is None else pooled.repeat(g, 1, 1), front, rep(torch.cat(ids)),
+                      rep(torch.cat(ams)), vision, idx, tok3, lab2, im_wh.repeat(g, 1), max(kvs))
+            out = self._run("_rest_program", inputs, use_graph)
+            packed = out["packed"].clone()
+            counts = out["counts"].tolist()
+            for c in range(g):
+                res = []
+                for b, (h, w) in enumerate(images.image_sizes):
+                    it = c * Bn + b
+                    n = counts[it]
+                    bl = BoxList(packed[it, :n, :4].clone(), (int(w), int(h)), mode="xyxy")
+                    bl.add_field("labels", packed[it, :n, 5].to(torch.int64))
+                    bl.add_field("scores", packed[it, :n, 4].clone())
+                    res.append(bl)
+                results.append(res)
+        return results
+
 
 _DETECTION_META_ARCHITECTURES = {"GeneralizedVLRCNN_New": GeneralizedVLRCNN_New}
 

@@ -120,6 +120,18 @@ def test_reference_cfg_tree_and_caller_sequence(monkeypatch):
         assert set(o["labels"].tolist()) <= set(labs)
         assert float(o["boxes"][:, 2].max()) <= 380 and float(o["boxes"][:, 3].max()) <= 300      # resized to orig_size
 
+    # ---- chunk batching: all chunk captions of the image in ONE call == the per-chunk calls above
+    with torch.no_grad():
+        batched = model.forward_chunks(images, list(zip(all_queries, all_maps)))
+    assert len(batched) == len(all_queries) and all(len(r) == 1 for r in batched)
+    for res, (_, o) in zip(batched, mdetr_style_output):
+        r = fns["resize_box"](res[0].to(cpu_device), targets)
+        o1, o2 = torch.argsort(o["scores"], descending=True, stable=True), torch.argsort(r.extra_fields["scores"], descending=True, stable=True)
+        assert len(o["scores"]) == len(r.extra_fields["scores"])
+        assert torch.allclose(o["scores"][o1], r.extra_fields["scores"][o2], atol=1e-5)
+        assert torch.equal(o["labels"][o1], r.extra_fields["labels"][o2])
+        assert torch.allclose(o["boxes"][o1], r.bbox[o2], atol=1e-3)
+
     # ---- same weights, same inputs through the oracle: the detections of chunk 0 agree (fp32 emulation: to rounding)
     tk = model.tokenizer
     t = tk([all_queries[0]], max_length=256, padding="max_length", return_special_tokens_mask=True, return_tensors="pt", truncation=True)

@@ -223,9 +223,18 @@ def test_backbone_and_caption_caches(dev):
     st = model.cache_stats
     assert st["backbone_miss"] == 4 and st["backbone_hit"] == 8, st
     assert st["front_hit"] >= 6 and st["graph_replay"] >= 4, st
+    # chunk batching: every caption for the same pixels in ONE call (chunks stacked along the batch dimension)
+    il = ImageList(images.to(dev).clone(), sizes)
+    for _ in range(3):                                      # eager, capture, replay
+        batched = model.forward_chunks(il, caps)
+    assert len(batched) == len(caps)
+    for out, r in zip(batched, ref):
+        for a, b in zip(out, r):
+            assert _same_detections(a, b, frac=0.9)
     il.tensors.add_(0.25)                                   # in-place change of the cached pixels -> version bump -> miss
+    miss = model.cache_stats["backbone_miss"]
     model(il, captions=[caps[0][0]] * 2, positive_map=caps[0][1])
-    assert model.cache_stats["backbone_miss"] == 5
+    assert model.cache_stats["backbone_miss"] == miss + 1
     # image sizes are a tensor input, not a graph key: other (h, w) of the same padded shape replay the same graph
     n_graphs = len(model._graphs)
     il2 = ImageList(images.to(dev).clone(), [(h - 3, w - 5) for (h, w) in sizes])
