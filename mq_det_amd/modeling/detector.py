@@ -109,9 +109,35 @@ class GeneralizedVLRCNN_New(nn.Module):
             raise RuntimeError("mq_det_amd runs on MI355X only (HIP kernels, no CPU fallback); got device " + str(device))
         from .. import ops
         ops.load_library()
+        self._validate_config()
         self._plan = pipeline.build_plan(self.state_dict(), self.cfg, device)
         self._plan_key = device
         return self._plan
+
+    def _validate_config(self):
+        """Fail early, with the config key named, on settings of the reference this path does not implement (instead of a
+        negative return code from a kernel in the middle of a forward)."""
+        cfg = self.cfg
+        M = cfg.MODEL
+        agg = str(M.DYHEAD.get("SCORE_AGG", "MEAN")).upper()
+        if agg != "MEAN":
+            raise NotImplementedError(f"MODEL.DYHEAD.SCORE_AGG = {agg}: only MEAN (the reference default) is implemented in "
+                                      "mq_align_scores_fwd; MAX / POWER / ONEHOT (rpn/inference.py:772-824) are not")
+        if M.LANGUAGE_BACKBONE.MAX_QUERY_LEN > 256 or M.LANGUAGE_BACKBONE.MAX_QUERY_LEN % 8:
+            raise NotImplementedError("MODEL.LANGUAGE_BACKBONE.MAX_QUERY_LEN must be a multiple of 8 and <= 256 (VLFuse kernels)")
+        if not M.LANGUAGE_BACKBONE.PAD_MAX:
+            raise NotImplementedError("MODEL.LANGUAGE_BACKBONE.PAD_MAX = False (captions padded to the longest of the batch) is not "
+                                      "supported: the attention kernels need a key count that is a multiple of 8; keep PAD_MAX = True")
+        if M.BACKBONE.OUT_CHANNELS != 256 or M.DYHEAD.CHANNELS != 256:
+            raise NotImplementedError("the VLDyHead kernels (VLFuse, DCNv2, DyConv epilogue) are written for 256 channels")
+        if M.SWINT.WINDOW_SIZE ** 2 > 160:
+            raise NotImplementedError("MODEL.SWINT.WINDOW_SIZE: windows of up to 160 tokens (7x7, 12x12) are supported")
+        fc = M.DYHEAD.FUSE_CONFIG
+        if fc.TYPE != "MHA-B" or fc.get("SEPARATE_BIDIRECTIONAL", False):
+            raise NotImplementedError("MODEL.DYHEAD.FUSE_CONFIG: only TYPE = MHA-B without SEPARATE_BIDIRECTIONAL (mq-glip-*.yaml)")
+        if cfg.VISION_QUERY.get("ADD_ADAPT_LAYER", False) or cfg.VISION_QUERY.get("QUERY_FUSION", False) or \
+                cfg.VISION_QUERY.get("AUGMENT_IMAGE_WITH_QUERY", False):
+            raise NotImplementedError("VISION_QUERY.ADD_ADAPT_LAYER / QUERY_FUSION / AUGMENT_IMAGE_WITH_QUERY are not implemented")
 
     # ------------------------------------------------------------------ reference API
     def train(self, mode=True):

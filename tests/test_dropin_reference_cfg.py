@@ -79,6 +79,7 @@ def test_reference_cfg_tree_and_caller_sequence(monkeypatch):
     assert type(model).__name__ == cfg.MODEL.META_ARCHITECTURE
     model.load_state_dict(sd, strict=True)                     # DetectronCheckpointer.load ends in a strict load
     model.eval()
+    model._validate_config()                                   # every key it reads exists in the reference tree; mq-glip-t passes
 
     # ---- engine/inference.py: captions and positive maps from the reference's own builders
     fns = _refload.reference_functions("maskrcnn_benchmark/engine/inference.py",

@@ -49,6 +49,26 @@ def test_model_refuses_cpu_and_training():
     assert model.backbone.body is not None and model.backbone.fpn is not None and model.rpn.head is not None
 
 
+def test_unsupported_config_is_rejected_by_name():
+    from mq_det_amd import get_cfg, build_detection_model
+    cfg = get_cfg()
+    cfg.MODEL.SWINT.DEPTHS = (2, 2, 2, 2)
+    cfg.MODEL.LANGUAGE_BACKBONE.NUM_HIDDEN_LAYERS = 2
+    cfg.MODEL.LANGUAGE_BACKBONE.QV_START = 1
+    cfg.MODEL.LANGUAGE_BACKBONE.BERT_VOCAB_SIZE = 1100
+    cfg.MODEL.DYHEAD.NUM_CONVS = 1
+    cfg.MODEL.DYHEAD.SCORE_AGG = "MAX"
+    model = build_detection_model(cfg, tokenizer=object())
+    with pytest.raises(NotImplementedError, match="SCORE_AGG"):
+        model._validate_config()
+    cfg.MODEL.DYHEAD.SCORE_AGG = "MEAN"
+    cfg.MODEL.LANGUAGE_BACKBONE.PAD_MAX = False
+    with pytest.raises(NotImplementedError, match="PAD_MAX"):
+        model._validate_config()
+    cfg.MODEL.LANGUAGE_BACKBONE.PAD_MAX = True
+    model._validate_config()
+
+
 def test_state_dict_names_match_reference_contract():
     """Same keys as the oracle generator, whose keys load strict=True into the reference's own classes
     (oracle/gen_golden.py)."""
