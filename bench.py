@@ -74,6 +74,8 @@ def build_model(dev, caches=False, n_classes=NUM_CLASSES_IN_CAPTION, n_categorie
         cfg.MODEL.RESIDUAL_FP32 = os.environ["MQ_RESIDUAL_FP32"] == "1"
     if os.environ.get("MQ_SWIN_FUSED_MLP") is not None:       # A/B switch (fused Swin MLP kernel vs library GEMMs + GELU)
         cfg.MODEL.SWINT.FUSED_MLP = os.environ["MQ_SWIN_FUSED_MLP"] == "1"
+    if os.environ.get("MQ_SWIN_MLP_WIDTHS") is not None:      # A/B switch: which Swin stages use the fused MLP kernel
+        cfg.MODEL.SWINT.FUSED_MLP_WIDTHS = tuple(int(w) for w in os.environ["MQ_SWIN_MLP_WIDTHS"].split(",") if w)
     tok_dir = build_synthetic_tokenizer(tempfile.mkdtemp(prefix="mqdet_tok_"))
     cfg.MODEL.LANGUAGE_BACKBONE.TOKENIZER_TYPE = tok_dir
     tk = AutoTokenizer.from_pretrained(tok_dir)

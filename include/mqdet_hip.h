@@ -87,7 +87,7 @@ long mq_vlfuse_t2i_workspace_bytes(int B, int T, int nsplit);
 int mq_vlfuse_t2i_fwd(const void* kf, const void* v_ln, const int* kv_len, void* workspace, void* out, int B, int N, int T,
                       int nsplit, float clamp, void* stream);
 
-/* Row LayerNorm with the residual add fused in, mixed-precision streams, fp32 statistics; C % 8 == 0, C <= 2048.
+/* Row LayerNorm with the residual add fused in, mixed-precision streams, fp32 statistics; C % 8 == 0, C <= 3072.
  *   s = x (+ res);  x is fp32 when x_f32 != 0 else fp16, res likewise (res_f32); res may be NULL.
  *   y    [rows,C] fp16 = (s - mean) * rstd * gamma + beta    (may be NULL)
  *   y32  [rows,C] fp32 = the same, unrounded                 (may be NULL; post-LN residual stream of the BERT layers)

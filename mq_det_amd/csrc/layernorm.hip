@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
   const int sub = threadIdx.x % LPR, rg = threadIdx.x / LPR;
   const int nch = C / 8;
   const long r0 = (long)blockIdx.x * RPB;
-  constexpr int MAXC = 4;                          // chunks per lane (C <= 8 * LPR * MAXC)
+  constexpr int MAXC = LPR == 64 ? 6 : 4;          // chunks per lane (C <= 8 * LPR * MAXC: 3072 for the Swin-L patch merging)
   for (int rr = rg; rr < RPB; rr += ROWS_PER_PASS) {
     const long row = r0 + rr;
     const bool ok = row < rows;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
 extern "C" int mq_layernorm_fwd(const void* x, int x_f32, const void* res, int res_f32, const void* gamma, const void* beta,
                                 void* y, float* y32, void* xsum, long rows, int C, float eps, void* stream) {
   if (rows <= 0) return 0;
-  if (C % 8 || C > 2048) return -1;
+  if (C % 8 || C > 3072) return -1;
   if (!res && xsum) return -2;
   const int nch = C / 8;
   const int lpr = nch <= 16 ? 16 : (nch <= 32 ? 32 : 64);

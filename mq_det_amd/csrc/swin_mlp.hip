@@ -24,6 +24,7 @@
 //   * epilogue: + bias + residual in fp32, optional fused LayerNorm of the result (row statistics by two wave shuffles).
 // Algorithmic HBM bytes per token: C * (4 + 2 + 4 [+ 2]) vs ~40 C in the unfused form.  MFMA work 16 M C^2.
 #include "common.h"
+#include <cstdlib>
 
 struct SwinMlpParams {
   const float* x; const half_t* delta;
@@ -44,13 +45,16 @@ __device__ __forceinline__ float gelu_erf(float v) {
 }
 
 // T = 16-token blocks per wave (A-fragments of the weights are re-used T times: LDS traffic per MFMA / T)
-template <int C, int HS, int T>
-__global__ __launch_bounds__(512) void swin_mlp_kernel(SwinMlpParams p) {
-  constexpr int NW = 8, TW = 16 * T, BM = TW * NW, HID = 4 * C, KS = C / 32, CT = C / 16, NCHUNK = HID / HS, NB = HS / 32;
+// NW = waves per workgroup (tokens per workgroup = 16 T NW).  Small workgroups (NW = 4) let several INDEPENDENT workgroups share
+// a CU, so that one's memory-bound prologue / epilogue and GELU arithmetic overlap another's MFMA phase; within one
+// workgroup the waves run in lock step between the per-chunk barriers.
+template <int C, int HS, int T, int NW>
+__global__ __launch_bounds__(64 * NW) void swin_mlp_kernel(SwinMlpParams p) {
+  constexpr int NT = 64 * NW, TW = 16 * T, BM = TW * NW, HID = 4 * C, KS = C / 32, CT = C / 16, NCHUNK = HID / HS, NB = HS / 32;
   constexpr int W1P = C + 8, W2P = HS + 8;                    // LDS row pitches in halfs (+16 B: conflict-free b128 rows)
   constexpr int CHUNK = HS * W1P + C * W2P;                   // halfs per weight chunk (W1 rows | W2 rows)
   constexpr int W1_PIECES = HS * (C / 8), W2_PIECES = C * (HS / 8), PIECES = W1_PIECES + W2_PIECES;
-  constexpr int PPT = (PIECES + 511) / 512;                   // 16-byte pieces per thread and chunk
+  constexpr int PPT = (PIECES + NT - 1) / NT;                  // 16-byte pieces per thread and chunk
   static_assert(C % 32 == 0 && HS % 32 == 0 && HID % HS == 0, "tile shapes");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* wbuf = (half_t*)smem;                                // [2][CHUNK]: double-buffered weight chunks
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(512) void swin_mlp_kernel(SwinMlpParams p) {
   auto fetch = [&](int j) {
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-      const int pc = tid + i * 512;
+      const int pc = tid + i * NT;
       if (pc < W1_PIECES) {
         const int r = pc / (C / 8), c8 = pc % (C / 8);
         wreg[i] = *(const half8*)(p.w1 + (long)(j * HS + r) * C + c8 * 8);
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(512) void swin_mlp_kernel(SwinMlpParams p) {
     half_t* w2s = w1s + HS * W1P;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-      const int pc = tid + i * 512;
+      const int pc = tid + i * NT;
       if (pc < W1_PIECES) {
         const int r = pc / (C / 8), c8 = pc % (C / 8);
         *(half8*)(w1s + r * W1P + c8 * 8) = wreg[i];
@@ -250,18 +254,18 @@ __global__ __launch_bounds__(512) void swin_mlp_kernel(SwinMlpParams p) {
   }
 }
 
-template <int C, int HS, int T>
+template <int C, int HS, int T, int NW>
 static int launch_swin_mlp(const SwinMlpParams& p, hipStream_t s) {
   constexpr size_t smem = (size_t)2 * (HS * (C + 8) + C * (HS + 8)) * 2;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)swin_mlp_kernel<C, HS, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)swin_mlp_kernel<C, HS, T, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  constexpr int BM = 128 * T;
+  constexpr int BM = 16 * T * NW;
   const unsigned grid = (unsigned)((p.M + BM - 1) / BM);
-  hipLaunchKernelGGL((swin_mlp_kernel<C, HS, T>), dim3(grid), dim3(512), smem, s, p);
+  hipLaunchKernelGGL((swin_mlp_kernel<C, HS, T, NW>), dim3(grid), dim3(64 * NW), smem, s, p);
   MQ_CHECK_LAUNCH();
   return 0;
 }
@@ -278,10 +282,20 @@ extern "C" int mq_swin_mlp_fwd(const float* x, const void* delta, const void* ln
   p.gn = (const half_t*)next_g; p.bn = (const half_t*)next_b; p.eps_n = eps_next; p.y = (half_t*)y; p.M = M;
   if (y && (!next_g || !next_b)) return -2;
   hipStream_t s = (hipStream_t)stream;
+  // tile variant: default = the fastest measured per width (profiles/README.md); MQ_SWIN_MLP_VARIANT = 0..2 forces one (A/B runs)
+  static const int variant = [] { const char* e = getenv("MQ_SWIN_MLP_VARIANT"); return e ? atoi(e) : -1; }();
   switch (C) {
-    case 96: return launch_swin_mlp<96, 64, 2>(p, s);
-    case 192: return launch_swin_mlp<192, 32, 2>(p, s);
-    case 384: return launch_swin_mlp<384, 32, 1>(p, s);
+    case 96:
+      if (variant == 0) return launch_swin_mlp<96, 64, 2, 8>(p, s);
+      if (variant == 1) return launch_swin_mlp<96, 32, 2, 4>(p, s);
+      return launch_swin_mlp<96, 32, 1, 4>(p, s);
+    case 192:
+      if (variant == 0) return launch_swin_mlp<192, 32, 2, 8>(p, s);
+      if (variant == 1) return launch_swin_mlp<192, 32, 2, 4>(p, s);
+      return launch_swin_mlp<192, 32, 1, 4>(p, s);
+    case 384:
+      if (variant == 0) return launch_swin_mlp<384, 32, 1, 8>(p, s);
+      return launch_swin_mlp<384, 32, 1, 4>(p, s);
     default: return -1;                                      // other widths: library GEMM path of the caller
   }
 }

@@ -49,9 +49,10 @@ def build_plan(sd, cfg, device, dtype=torch.float16):
             P[b + ".rel_bias"] = F.pad(rel, (0, NP - N, 0, NP - N)).contiguous()         # [heads, NP, NP], see ops.pad_rel_bias
     # Swin MLP halves that run as one fused kernel (mq_swin_mlp_fwd): fc2.weight with the k-slots of every 32-block permuted
     P["_swin_fused_mlp"] = bool(M.SWINT.get("FUSED_MLP", True)) and P["_r32"]
+    P["_swin_fused_widths"] = tuple(w for w in M.SWINT.get("FUSED_MLP_WIDTHS", ops.SWIN_MLP_WIDTHS) if w in ops.SWIN_MLP_WIDTHS)
     for i, depth in enumerate(M.SWINT.DEPTHS):
         Ci = M.SWINT.EMBED_DIM * 2 ** i
-        if P["_swin_fused_mlp"] and Ci in ops.SWIN_MLP_WIDTHS:
+        if P["_swin_fused_mlp"] and Ci in P["_swin_fused_widths"]:
             perm = ops.swin_mlp_w2_perm(4 * Ci, device)
             for j in range(depth):
                 b = f"backbone.body.layers.{i}.blocks.{j}.mlp.fc2"
@@ -188,7 +189,7 @@ def swin_forward(P, cfg, img):
     outs = []
     for i, (depth, heads) in enumerate(zip(M.DEPTHS, M.NUM_HEADS)):
         C = x.shape[-1]
-        fused = P["_swin_fused_mlp"] and C in ops.SWIN_MLP_WIDTHS and x.dtype == torch.float32
+        fused = P["_swin_fused_mlp"] and C in P["_swin_fused_widths"] and x.dtype == torch.float32
         pend = None                                    # MLP output whose residual add is fused into the next LayerNorm
         h1 = None                                      # norm1 of the current block when the previous fused MLP produced it
         for j in range(depth):

@@ -33,6 +33,20 @@ def main():
     ops.load_library()
     g = torch.Generator().manual_seed(0)
     out = []
+    only = os.environ.get("MQ_MICRO_ONLY", "")
+    if only in ("", "msda"):
+        msda(dev, g, out)
+    if only in ("", "swin"):
+        swin(dev, g, out)
+    if only in ("", "window"):
+        window(dev, g, out)
+    for r in out:
+        print(json.dumps(r))
+    if len(sys.argv) > 1:
+        json.dump(out, open(sys.argv[1], "w"), indent=1)
+
+
+def msda(dev, g, out):
     # ---- MSDeformAttn, encoder self-attention shape
     shapes = [(100, 168), (50, 84), (25, 42), (13, 21)]
     S = sum(h * w for h, w in shapes)
@@ -47,6 +61,9 @@ def main():
     out.append({"kernel": "msda_kernel (encoder, B=16, Q=S=22323, 8 heads x 32, 4 levels x 4 points, fp16 values)", "ms": round(ms, 3),
                 "algorithmic_GBs": round(nb / ms / 1e6, 1), "gather_GBs": round(gathered / ms / 1e6, 1),
                 "algorithmic_bytes": nb, "frac_of_hbm_peak": round(nb / ms / 1e6 / 8000, 3)})
+
+
+def swin(dev, g, out):
     # ---- fused Swin MLP per stage (B = 8, 800x1344)
     for C, M in ((96, 8 * 67200), (192, 8 * 16800), (384, 8 * 4200)):
         x = torch.randn(M, C, generator=g).to(dev)
@@ -58,9 +75,12 @@ def main():
         b2 = torch.zeros(C).half().to(dev)
         ms = timeit(lambda: ops.swin_mlp(x, d, lg, lb, 1e-5, w1, b1, w2p, b2, next_ln=(lg, lb, 1e-5)))
         fl, nb = 16.0 * M * C * C, M * C * (4 + 2 + 4 + 2)
-        out.append({"kernel": f"swin_mlp_kernel C={C} M={M}", "ms": round(ms, 3), "TFLOPs": round(fl / ms / 1e9, 1),
+        out.append({"kernel": f"swin_mlp_kernel C={C} M={M} variant={os.environ.get('MQ_SWIN_MLP_VARIANT', 'default')}", "ms": round(ms, 3), "TFLOPs": round(fl / ms / 1e9, 1),
                     "frac_of_mfma_peak": round(fl / ms / 1e9 / 2500, 3), "algorithmic_GBs": round(nb / ms / 1e6, 1),
                     "frac_of_hbm_peak": round(nb / ms / 1e6 / 8000, 3)})
+
+
+def window(dev, g, out):
     # ---- window attention, 144-token windows (Swin-L stage 1, B = 4)
     Bn, H, W, C, heads, ws = 4, 200, 336, 192, 6, 12
     qkv = torch.randn(Bn, H, W, 3 * C, generator=g).half().to(dev)
@@ -71,10 +91,6 @@ def main():
         nb = qkv.numel() * 2 + Bn * H * W * C * 2
         out.append({"kernel": f"window_attn_kernel<10> ws=12 shift={shift} (Swin-L stage 1, B=4)", "ms": round(ms, 3),
                     "algorithmic_GBs": round(nb / ms / 1e6, 1), "frac_of_hbm_peak": round(nb / ms / 1e6 / 8000, 3)})
-    for r in out:
-        print(json.dumps(r))
-    if len(sys.argv) > 1:
-        json.dump(out, open(sys.argv[1], "w"), indent=1)
 
 
 if __name__ == "__main__":
