@@ -182,18 +182,19 @@ def kernel_rooflines(kern, steps, Bn, n_tok):
     i2t = [v for k, v in per.items() if k.startswith("vlfuse_i2t_n%d_" % N_img)]
     t2i = [v for k, v in per.items() if k.startswith("vlfuse_t2i_n%d_" % N_img)]
     if i2t and t2i:
-        nk_vis = min(256, -(-n_tok // 64) * 64)
-        tq_live = min(256, -(-n_tok // 128) * 128)
+        k16, k32, r16 = -(-n_tok // 16) * 16, -(-n_tok // 32) * 32, -(-n_tok // 16) * 16
         n_l = i2t[0][0]
-        ex = n_l * 4.0 * Bn * 8 * N_img * 256 * nk_vis + t2i[0][0] * 4.0 * Bn * 8 * N_img * 256 * tq_live
-        alg = n_l * 6.0 * Bn * 8 * N_img * 256 * nk_vis
+        # executed: image side = QK^T over the live 16-key blocks + PV over the live 32-key steps; text side recomputes QK^T
+        # and does its PV for the 16-row wave blocks that hold caption tokens
+        ex = n_l * 2.0 * Bn * 8 * N_img * 256 * (k16 + k32) + t2i[0][0] * 4.0 * Bn * 8 * N_img * 256 * r16
+        alg = n_l * 6.0 * Bn * 8 * N_img * 256 * n_tok
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_vlfuse.json")
         if os.path.exists(pmc):                 # PMC passes are separate rocprofv3 runs (see profiles/README.md)
             traffic = json.load(open(pmc)).get("traffic_bytes_per_launch_avg")
         out.append(_mfma("vlfuse_i2t_kernel + vlfuse_t2i_kernel (VLFuse image<->text attention)", alg, ex, n_l + t2i[0][0],
-                         i2t[0][1] + t2i[0][1], f"algorithmic = QK^T once + 2 PV over {nk_vis} visited text keys (SURVEY.md 8d); executed = "
-                         f"each direction recomputes QK^T ({nk_vis} keys image side, {tq_live} query rows text side); traffic: PMC of round 1",
+                         i2t[0][1] + t2i[0][1], f"algorithmic = QK^T once + 2 PV over the {n_tok} caption tokens (SURVEY.md 8d); executed = each "
+                         f"direction recomputes QK^T ({k16} / {k32} keys image side, {r16} query rows text side); traffic: PMC of round 1",
                          traffic))
     # ---- generic attention kernel (BERT self-attention 12 x 64; GCP pre-select 8 x 32): QK^T + PV over the visited keys
     att = [(k, v) for k, v in per.items() if k.startswith("attn_d")]

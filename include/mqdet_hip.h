@@ -78,7 +78,7 @@ int mq_vlfuse_i2t_fwd(const void* v_ln, const void* kf, const void* vo, const fl
 /* VLFuse text side: keys = values = image tokens, split over the keys (nsplit >= 1) + merge:
  *   out[b,t,h*256:(h+1)*256] = sum_n softmax_n( clamp(kf[b,h,t,:] . v_ln[b,n,:], +-clamp) ) v_ln[b,n,:]
  *   workspace: mq_vlfuse_t2i_workspace_bytes(B, T, nsplit) bytes of device memory; out [B,T,2048] fp16;
- *   kv_len [B] int32 or NULL: caption length -- 128-row tiles that hold only padding tokens (rows >= kv_len[b]) are not
+ *   kv_len [B] int32 or NULL: caption length -- 16-row blocks that hold only padding tokens (rows >= kv_len[b]) are not
  *   computed and come back as zeros (padding rows never influence a detection: masked as keys, never scored).
  * Replaces the text branch of BiMultiHeadAttention: the transposed logits, their softmax over image tokens and the
  *   bmm with values_v (fuse_helper.py:246-262,281-288); values_v_proj / out_l_proj are applied to the result by the

@@ -83,7 +83,10 @@ __device__ __forceinline__ void tile_commit(const TileRegs<NTH>& t, half_t* dst,
 }
 
 // S^T[nb][qb] = K_tile . Q^T : A = K rows (keys) from LDS, B = Q fragments from registers (QLDS: from the LDS copy)
-template <bool QLDS, int QB>
+// NBL: 16-key blocks of this tile that hold at least one un-masked key (compile time: the caller branches, wave-uniformly,
+// on the block count of the LAST tile only); the others keep s = 0 and are masked by the caller -- a 141-token caption
+// fills 9 of the 12 blocks of its three 64-key tiles
+template <bool QLDS, int QB, int NBL = 4>
 __device__ __forceinline__ void qk_tile(const half_t* tile, const half8 (&qf)[QB][8], const half_t* qw, float4_ (&s)[4][QB],
                                         int l15, int lg) {
 #pragma unroll
@@ -94,24 +97,25 @@ __device__ __forceinline__ void qk_tile(const half_t* tile, const half8 (&qf)[QB
   for (int kk = 0; kk < VD / 32; ++kk) {
     half8 kf[4], qq[QB];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) kf[nb] = *(const half8*)(tile + (nb * 16 + l15) * KS + kk * 32 + lg * 8);
+    for (int nb = 0; nb < NBL; ++nb) kf[nb] = *(const half8*)(tile + (nb * 16 + l15) * KS + kk * 32 + lg * 8);
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       if constexpr (QLDS) qq[qb] = *(const half8*)(qw + (qb * 16 + l15) * KS + kk * 32 + lg * 8);
       else qq[qb] = qf[qb][kk];
     }
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
+    for (int nb = 0; nb < NBL; ++nb)
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) s[nb][qb] = mfma16(kf[nb], qq[qb], s[nb][qb]);
   }
 }
 
 // O^T[db][qb] += V_tile^T . P^T : A = transposed reads of the row-major tile, B = P^T fragments from registers
-template <int QB>
+// STL: 32-key steps of this tile with a non-zero probability (compile time, see qk_tile)
+template <int QB, int STL = 2>
 __device__ __forceinline__ void pv_tile(const half_t* tile, const half8 (&pf)[2][QB], float4_ (&o)[16][QB], int l15, int lg) {
 #pragma unroll
-  for (int st = 0; st < 2; ++st) {
+  for (int st = 0; st < STL; ++st) {
     const half_t* base = tile + (st * 32 + 4 * lg + (l15 >> 2)) * KS + (l15 & 3) * 4;
 #pragma unroll
     for (int db = 0; db < 16; ++db) {
@@ -128,7 +132,10 @@ __device__ __forceinline__ void pv_tile(const half_t* tile, const half8 (&pf)[2]
 
 // NT = number of 64-key tiles whose logits stay in registers.  NT <= 2 (<= 128 text tokens): Q fragments in registers and a
 // two-slot prefetch ring.  NT >= 3 ("lean"): the logits alone take 96-128 VGPRs, so Q moves to LDS and the ring has one slot.
-template <int NT, int QB>
+// NBL = live 16-key blocks of the LAST tile (1..4), chosen by the host from max_kv: a 141-token caption is NT = 3, NBL = 1
+// (144 keys instead of 192).  Compile time on purpose: any run-time branch around the MFMA loops pushes this kernel, which
+// sits at the 256-VGPR limit, into spills.  Batch items with shorter captions are handled by the key mask as before.
+template <int NT, int QB, int NBL>
 __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p) {
   constexpr bool LEAN = NT >= 3;
   constexpr int NTH = 2048 / (QB * 4), WR = 16 * QB;        // threads per workgroup (512 / 256), query rows per wave
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
     auto qk_step = [&](auto J) {
       constexpr int j = decltype(J)::value;
       begin(J, u0 + j);
-      qk_tile<LEAN, QB>(tiles + (j & 1) * TILE, qf, qw, s[j], l15, lg);
+      qk_tile<LEAN, QB, (j == NT - 1 ? NBL : 4)>(tiles + (j & 1) * TILE, qf, qw, s[j], l15, lg);
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) {
         const float4_ kb = *(const float4_*)(bias_s + (h * NT + j) * TK + nb * 16 + 4 * lg);
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
             pf[st][qb][r] = (half_t)s[j][2 * st][qb][r];
             pf[st][qb][4 + r] = (half_t)s[j][2 * st + 1][qb][r];
           }
-      pv_tile(tiles + ((NT + j) & 1) * TILE, pf, o, l15, lg);
+      pv_tile<QB, (j == NT - 1 ? (NBL + 1) / 2 : 2)>(tiles + ((NT + j) & 1) * TILE, pf, o, l15, lg);
       end(POS{});
     };
     pv_step(std::integral_constant<int, 0>{});
@@ -326,18 +333,18 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
   }
 }
 
-template <int NT, int QB>
+template <int NT, int QB, int NBL>
 static int launch_i2t(const I2TParams& p, hipStream_t stream) {
   constexpr size_t smem = (size_t)(2 * TILE + (NT >= 3 ? BM * KS : 0)) * sizeof(half_t) + (size_t)VH * NT * TK * sizeof(float);
   static_assert(4 * 32 * (VD + 8) <= 2 * TILE, "O staging must fit in the tiles");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)vlfuse_i2t_kernel<NT, QB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)vlfuse_i2t_kernel<NT, QB, NBL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   const int qtiles = (p.N + BM - 1) / BM;
-  hipLaunchKernelGGL((vlfuse_i2t_kernel<NT, QB>), dim3((unsigned)(8 * ((p.B + 7) / 8) * qtiles)), dim3(2048 / (QB * 4)), smem, stream, p);
+  hipLaunchKernelGGL((vlfuse_i2t_kernel<NT, QB, NBL>), dim3((unsigned)(8 * ((p.B + 7) / 8) * qtiles)), dim3(2048 / (QB * 4)), smem, stream, p);
   MQ_CHECK_LAUNCH();
   return 0;
 }
@@ -359,19 +366,29 @@ extern "C" int mq_vlfuse_i2t_fwd(const void* v_ln, const void* kf, const void* v
   p.obias = (const half_t*)out_bias; p.out = (half_t*)out; p.B = B; p.N = N; p.T = T; p.clamp = clamp;
   const int kv = (kv_len && max_kv > 0) ? min(max_kv, T) : T;
   const int nt = (kv + TK - 1) / TK;
+  const int nbl = min(4, max(1, (kv - (nt - 1) * TK + 15) / 16));       // live 16-key blocks of the last tile
+  hipStream_t st = (hipStream_t)stream;
   if (vlfuse_qb() == 1) {
-    switch (nt) {
-      case 1: return launch_i2t<1, 1>(p, (hipStream_t)stream);
-      case 2: return launch_i2t<2, 1>(p, (hipStream_t)stream);
-      case 3: return launch_i2t<3, 1>(p, (hipStream_t)stream);
-      default: return launch_i2t<4, 1>(p, (hipStream_t)stream);
+#define MQ_I2T(NT_)                                                        \
+    switch (nbl) {                                                         \
+      case 1: return launch_i2t<NT_, 1, 1>(p, st);                         \
+      case 2: return launch_i2t<NT_, 1, 2>(p, st);                         \
+      case 3: return launch_i2t<NT_, 1, 3>(p, st);                         \
+      default: return launch_i2t<NT_, 1, 4>(p, st);                        \
     }
+    switch (nt) {
+      case 1: MQ_I2T(1)
+      case 2: MQ_I2T(2)
+      case 3: MQ_I2T(3)
+      default: MQ_I2T(4)
+    }
+#undef MQ_I2T
   }
-  switch (nt) {
-    case 1: return launch_i2t<1, 2>(p, (hipStream_t)stream);
-    case 2: return launch_i2t<2, 2>(p, (hipStream_t)stream);
-    case 3: return launch_i2t<3, 2>(p, (hipStream_t)stream);
-    default: return launch_i2t<4, 2>(p, (hipStream_t)stream);
+  switch (nt) {                                                            // 4 waves x 32 rows (A/B switch): whole tiles only
+    case 1: return launch_i2t<1, 2, 4>(p, st);
+    case 2: return launch_i2t<2, 2, 4>(p, st);
+    case 3: return launch_i2t<3, 2, 4>(p, st);
+    default: return launch_i2t<4, 2, 4>(p, st);
   }
 }
 
@@ -383,6 +400,7 @@ struct T2IParams {
   half_t* out;            // [B, T, 8*256]
   const int* kv_len;      // [B] or nullptr: text rows >= kv_len[b] are padding -> not computed, written as zeros
   int B, N, T, nsplit;
+  int wr;                 // rows per wave of the main kernel (16 QB): granularity at which all-padding rows are skipped
   float clamp;
 };
 namespace { constexpr int WS_LD = VD + 4; }               // 260 floats: rows stay 16-byte aligned
@@ -405,8 +423,12 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
   const int b = group / p.nsplit, split = group % p.nsplit;
   // padded caption tokens: as keys they are masked everywhere downstream and the post-processor never reads their
   // logits, so their rows of this attention are dead -- whole q-tiles of padding are skipped (the merge writes zeros)
-  if (p.kv_len && qtile * BM >= max(1, min(p.T, p.kv_len[b]))) return;
+  const int kv_rows = p.kv_len ? max(1, min(p.T, p.kv_len[b])) : p.T;
+  if (qtile * BM >= kv_rows) return;
   const int row0 = qtile * BM + wave * WR;
+  // the same at wave granularity: a wave whose WR rows are all padding only helps to stage the key tiles (loads, LDS
+  // commits, barriers) and does no MFMA / softmax work; its rows are zero-filled by the merge kernel
+  const bool wave_live = row0 < kv_rows;
 
   const int ntiles = (p.N + TK - 1) / TK;
   const int tps = (ntiles + p.nsplit - 1) / p.nsplit;
@@ -442,7 +464,7 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
     constexpr int par = decltype(PAR)::value;
     issue(PAR, pos + 2);                                   // the slot of tile pos was committed one step ago
     __builtin_amdgcn_sched_barrier(0);
-    if (pos < nt) {
+    if (pos < nt && wave_live) {
       const half_t* tile = tiles + par * TILE;
       float4_ s[4][QB];
       qk_tile<false, QB>(tile, qf, nullptr, s, l15, lg);
@@ -519,7 +541,7 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
     const int row = row0 + qb * 16 + l15;
-    if (row < p.T) {
+    if (row < p.T && wave_live) {
       float* w = p.ws + (((long)split * p.B * VH + (long)b * VH + h) * p.T + row) * WS_LD;
 #pragma unroll
       for (int db = 0; db < 16; ++db) *(float4_*)(w + db * 16 + 4 * lg) = o[db][qb];
@@ -537,9 +559,9 @@ __global__ __launch_bounds__(256) void vlfuse_t2i_combine_kernel(T2IParams p) {
   const int row = gw % p.T;
   const int bh = gw / p.T, b = bh / VH, h = bh % VH;
   half_t* dst = p.out + ((long)b * p.T + row) * (VH * VD) + h * VD + lane * 4;
-  if (p.kv_len) {                                          // rows of skipped (all-padding) q-tiles: zeros
+  if (p.kv_len) {                                          // rows of skipped (all-padding) 16-row wave blocks: zeros
     const int kv = max(1, min(p.T, p.kv_len[b]));
-    if ((row / BM) * BM >= kv) {
+    if ((row / p.wr) * p.wr >= kv) {
       *(half4*)dst = (half4){(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
       return;
     }
@@ -576,7 +598,7 @@ extern "C" int mq_vlfuse_t2i_fwd(const void* kf, const void* v_ln, const int* kv
   if (nsplit < 1) nsplit = 1;
   T2IParams p;
   p.kf = (const half_t*)kf; p.v = (const half_t*)v_ln; p.ws = (float*)workspace; p.out = (half_t*)out; p.kv_len = kv_len;
-  p.B = B; p.N = N; p.T = T; p.nsplit = nsplit; p.clamp = clamp;
+  p.B = B; p.N = N; p.T = T; p.nsplit = nsplit; p.clamp = clamp; p.wr = 16 * vlfuse_qb();
   constexpr size_t smem = (size_t)2 * TILE * sizeof(half_t);
   static bool attr_set = false;
   if (!attr_set) {

@@ -314,8 +314,8 @@ def vlfuse_t2i(kf, v_ln, nsplit, clamp=50000.0, kv_len=None):
     if clamp > 0:
         s = s.clamp(-clamp, clamp)
     o = torch.einsum("bhtn,bnc->bthc", s.softmax(-1), v_ln.float())
-    if kv_len is not None:                      # 128-row tiles of pure padding come back as zeros
-        dead = (torch.arange(T)[None, :] // 128) * 128 >= kv_len.clamp(1, T)[:, None]
+    if kv_len is not None:                      # 16-row blocks of pure padding come back as zeros
+        dead = (torch.arange(T)[None, :] // 16) * 16 >= kv_len.clamp(1, T)[:, None]
         o = o.masked_fill(dead[:, :, None, None], 0.0)
     return o.reshape(B, T, 8 * C).to(kf.dtype)
 
