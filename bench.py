@@ -53,7 +53,7 @@ HBM_PEAK_GBS = 8000.0
 GFLOP_PER_IMAGE_L = 3260.0         # MQ-GLIP-L (Swin-L 1625 + 8 fusion layers ...), BASELINE.md section 2
 
 
-def build_model(dev, caches=False, n_classes=NUM_CLASSES_IN_CAPTION, n_categories=None, large=False):
+def build_model(dev, caches=False, n_classes=NUM_CLASSES_IN_CAPTION, n_categories=None, large=False, words=None):
     from transformers import AutoTokenizer
     from mq_det_amd import get_cfg
     from mq_det_amd.modeling.detector import GeneralizedVLRCNN_New
@@ -85,7 +85,7 @@ def build_model(dev, caches=False, n_classes=NUM_CLASSES_IN_CAPTION, n_categorie
     n_categories = n_categories or n_classes
     for c0 in range(0, n_categories, n_classes):            # chunk captions (engine/inference.py:190-192)
         n = min(n_classes, n_categories - c0)
-        caption, spans = synthetic_caption(n, start=3 * c0)
+        caption, spans = synthetic_caption(n, start=3 * c0, **({} if words is None else {"words": words}))
         chunks.append((caption, positive_map_from_spans(tk, caption, spans, list(range(c0 + 1, c0 + n + 1)))))
     model.load_query_bank(synthetic_bank(range(1, n_categories + 1), cfg.MODEL.BACKBONE.OUT_CHANNELS, cfg.VISION_QUERY.NUM_QUERY_PER_CLASS))
     model.to(dev)
@@ -288,6 +288,8 @@ def main():
     ap.add_argument("--no-lang-b64", action="store_true")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--workload", choices=["mq-glip-t", "lvis", "mq-glip-l"], default="mq-glip-t")
+    ap.add_argument("--caption", choices=["lvis", "short"], default="lvis", help="lvis: 1-4 word class names, 141 tokens (default); "
+                                                                                  "short: one token per class, 81 tokens (the round-1 caption)")
     ap.add_argument("--chunk-batch", type=int, default=0, help="lvis workload: image x chunk items stacked per launch sequence "
                                                                 "through model.forward_chunks (0 = one forward per chunk)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (for PMC profiling)")
@@ -308,7 +310,8 @@ def main():
     lvis, large = args.workload == "lvis", args.workload == "mq-glip-l"
     if large and args.batch == B_PER_GPU:
         args.batch = 4                                        # BASELINE.json configs[3]: bs = 4 / GPU
-    cfg, model, chunks = build_model(dev, caches=lvis, n_categories=1203 if lvis else None, large=large)
+    cfg, model, chunks = build_model(dev, caches=lvis, n_categories=1203 if lvis else None, large=large,
+                                     words=(1,) if args.caption == "short" else None)
     if args.no_graph:
         model.use_hip_graph = False
 

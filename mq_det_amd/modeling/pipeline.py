@@ -107,6 +107,25 @@ def build_plan(sd, cfg, device, dtype=torch.float16):
         P[b + ".olc.weight"] = torch.einsum("ohe,hec->ohc", wol, wvv).reshape(wol.shape[0], -1).to(dtype).contiguous()
         P[b + ".olc.bias"] = (torch.einsum("ohe,he->o", wol, f32(b + ".attn.values_v_proj.bias").reshape(8, hd))
                               + f32(b + ".attn.out_l_proj.bias") * gl).to(dtype)
+        # text operands of the layer as ONE projection of LN(l): folded keys Kf_h = (l Wl_h^T + bl_h) Wq8_h, folded values
+        # Vo_h = (l Wvl_h^T + bvl_h) Wov8_h and the per-(head, key) logit bias (l Wl_h^T + bl_h) . bq8_h  (fp32 folding, one
+        # fp16 rounding): [2048 | 2048 | 8 (+ 8 zero rows)] x 768
+        wl = f32(b + ".attn.l_proj.weight").reshape(8, hd, -1)                                      # [h, e, 768]
+        bl = f32(b + ".attn.l_proj.bias").reshape(8, hd)
+        wvl = f32(b + ".attn.values_l_proj.weight").reshape(8, hd, -1)
+        bvl = f32(b + ".attn.values_l_proj.bias").reshape(8, hd)
+        wq8 = (f32(b + ".attn.v_proj.weight") * sc).reshape(8, hd, -1)                              # [h, e, c_in]
+        bq8 = (f32(b + ".attn.v_proj.bias") * sc).reshape(8, hd)
+        wov8 = (f32(b + ".attn.out_v_proj.weight") * gv[:, None]).reshape(-1, 8, hd).permute(1, 2, 0)   # [h, e, c_out]
+        w_kf = torch.einsum("hec,hek->hck", wq8, wl).reshape(8 * wq8.shape[2], -1)                 # [h*c_in, 768]
+        b_kf = torch.einsum("hec,he->hc", wq8, bl).reshape(-1)
+        w_vo = torch.einsum("heo,hek->hok", wov8, wvl).reshape(8 * wov8.shape[2], -1)
+        b_vo = torch.einsum("heo,he->ho", wov8, bvl).reshape(-1)
+        w_b = torch.einsum("he,hek->hk", bq8, wl)                                                    # [8, 768]
+        b_b = (bq8 * bl).sum(-1)
+        z = w_b.new_zeros(8, w_b.shape[1])
+        P[b + ".tprep.weight"] = torch.cat([w_kf, w_vo, w_b, z], 0).to(dtype).contiguous()
+        P[b + ".tprep.bias"] = torch.cat([b_kf, b_vo, b_b, b_b.new_zeros(8)], 0).to(dtype).contiguous()
         bert(f"rpn.head.dyhead_tower.{3 * i + 1}")
         b = f"rpn.head.dyhead_tower.{3 * i + 2}"
         for k in range(3):
@@ -429,13 +448,12 @@ def vl_text_prep(P, b, hidden, key_bias, hidden32=None):
         l_ln, l_res = _ln(P, b + ".layer_norm_l", hidden32, want_y32=True)
     else:
         l_ln = l_res = _ln(P, b + ".layer_norm_l", hidden)
-    a = b + ".attn"
     T = l_ln.shape[1]
-    k8 = _lin(P, a + ".l_proj", l_ln).reshape(Bn, T, 8, -1).permute(0, 2, 1, 3)         # [B, 8, T, 256 hd]
-    kf = torch.matmul(k8, P[b + ".Wq8"][None])                                           # [B, 8, T, 256 in] folded keys
-    bias = (torch.einsum("bhtd,hd->bht", k8.float(), P[b + ".bq8"]) + key_bias[:, None, :]).contiguous()   # [B, 8, T] fp32
-    val_l8 = _lin(P, a + ".values_l_proj", l_ln).reshape(Bn, T, 8, -1).permute(0, 2, 1, 3)        # [B, 8, T, 256 hd]
-    vo = torch.matmul(val_l8, P[b + ".Wov8"][None])                                      # [B, 8, T, 256 out] folded values
+    C = P[b + ".Wq8"].shape[2]
+    t = _lin(P, b + ".tprep", l_ln)                                                       # [B, T, 8*C | 8*C | 8 | pad]
+    kf = t[..., :8 * C].reshape(Bn, T, 8, C).permute(0, 2, 1, 3).contiguous()           # [B, 8, T, 256] folded keys
+    vo = t[..., 8 * C:16 * C].reshape(Bn, T, 8, C).permute(0, 2, 1, 3).contiguous()     # [B, 8, T, 256] folded values
+    bias = (t[..., 16 * C:16 * C + 8].float().permute(0, 2, 1) + key_bias[:, None, :]).contiguous()   # [B, 8, T] fp32
     return {"l_ln": l_ln, "l_res": l_res, "kf": kf, "vo": vo, "bias": bias}
 
 
