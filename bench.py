@@ -163,8 +163,24 @@ def _hbm(kernel, nbytes, n_launch, ms, note):
             "launches_per_step": n_launch, "ms_per_step": round(ms, 3), "algorithmic_bytes_per_step": nbytes, "note": note}
 
 
+def _pmc():
+    """PMC traffic (HBM bytes per launch) collected by tools/pmc_traffic.sh in separate rocprofv3 passes, reduced by
+    tools/pmc_reduce.py; round 2 file first, round 1 (VLFuse only) as fallback."""
+    r2 = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if os.path.exists(r2):
+        d = json.load(open(r2))
+        out = {k: int(v["traffic_bytes"]) for k, v in d.get("kernels", {}).items()}
+        out["vlfuse"] = d.get("vlfuse_traffic_bytes_per_launch_avg")
+        return out
+    r1 = os.path.join(ROOT, "profiles", "r01_pmc_vlfuse.json")
+    if os.path.exists(r1):
+        return {"vlfuse": json.load(open(r1)).get("traffic_bytes_per_launch_avg")}
+    return {}
+
+
 def kernel_rooflines(kern, steps, Bn, n_tok):
     """kern: ops.stop_timing() of `steps` eager single-stream forwards -> per-kernel roofline records (per step)."""
+    pmc = _pmc()
     N_img = sum(h * w for h, w in LEVELS)
     per = {k: (v[0] / steps, v[1] / steps, v[2] / steps) for k, v in kern.items()}
     out = []
@@ -175,7 +191,8 @@ def kernel_rooflines(kern, steps, Bn, n_tok):
         pos = sum(h * w for h, w in LEVELS) + 2 * sum(h * w for h, w in LEVELS[1:])
         fl = n * 2.0 * pos * Bn * 2304 * 256
         out.append(_mfma("dcn_igemm8_kernel (DCNv2: bilinear gather + blend + MFMA + GroupNorm statistics, 13 branches of a DyConv "
-                         "layer per launch)", fl, fl, n, ms, "flops = 2 * 33600 * B * 2304 * 256 per layer (SURVEY.md 8d: 42.4 GF / image / layer)"))
+                         "layer per launch)", fl, fl, n, ms, "flops = 2 * 33600 * B * 2304 * 256 per layer (SURVEY.md 8d: 42.4 GF / image / layer); "
+                         "traffic: PMC bytes per launch (profiles/r02_pmc_traffic.json)", pmc.get("dcn_igemm8_kernel")))
     # ---- VLFuse attention (vlfuse_attn.hip), 8 heads x 256.  SURVEY.md 8(d) / fuse_helper.py:233 compute QK^T ONCE and two
     # PV products: algorithmic = 3 * 2 * B * 8 * N * T_vis * 256 per layer with T_vis = the 64-key tiles that hold caption
     # tokens.  The two kernels each recompute the logits (executed = 4 * ...); the text side only computes 128-row query tiles.
@@ -188,14 +205,10 @@ def kernel_rooflines(kern, steps, Bn, n_tok):
         # and does its PV for the 16-row wave blocks that hold caption tokens
         ex = n_l * 2.0 * Bn * 8 * N_img * 256 * (k16 + k32) + t2i[0][0] * 4.0 * Bn * 8 * N_img * 256 * r16
         alg = n_l * 6.0 * Bn * 8 * N_img * 256 * n_tok
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_vlfuse.json")
-        if os.path.exists(pmc):                 # PMC passes are separate rocprofv3 runs (see profiles/README.md)
-            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch_avg")
         out.append(_mfma("vlfuse_i2t_kernel + vlfuse_t2i_kernel (VLFuse image<->text attention)", alg, ex, n_l + t2i[0][0],
                          i2t[0][1] + t2i[0][1], f"algorithmic = QK^T once + 2 PV over the {n_tok} caption tokens (SURVEY.md 8d); executed = each "
-                         f"direction recomputes QK^T ({k16} / {k32} keys image side, {r16} query rows text side); traffic: PMC of round 1",
-                         traffic))
+                         f"direction recomputes QK^T ({k16} / {k32} keys image side, {r16} query rows text side); traffic: PMC bytes per "
+                         "launch, mean of the two directions (text side incl. its merge)", pmc.get("vlfuse")))
     # ---- generic attention kernel (BERT self-attention 12 x 64; GCP pre-select 8 x 32): QK^T + PV over the visited keys
     att = [(k, v) for k, v in per.items() if k.startswith("attn_d")]
     if att:

@@ -293,9 +293,9 @@ extern "C" int mq_swin_mlp_fwd(const float* x, const void* delta, const void* ln
       if (variant == 0) return launch_swin_mlp<192, 32, 2, 8>(p, s);
       if (variant == 1) return launch_swin_mlp<192, 32, 2, 4>(p, s);
       return launch_swin_mlp<192, 32, 1, 4>(p, s);
-    case 384:
-      if (variant == 0) return launch_swin_mlp<384, 32, 1, 8>(p, s);
-      return launch_swin_mlp<384, 32, 1, 4>(p, s);
+    case 384:                                                // 8 waves: 0.33 ms per launch vs 0.38 with 4 (profiles/README.md)
+      if (variant == 1 || variant == 2) return launch_swin_mlp<384, 32, 1, 4>(p, s);
+      return launch_swin_mlp<384, 32, 1, 8>(p, s);
     default: return -1;                                      // other widths: library GEMM path of the caller
   }
 }
