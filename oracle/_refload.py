@@ -176,6 +176,55 @@ def load():
     return ns
 
 
+_gd_loaded = None
+
+
+def load_gdino():
+    """The reference's MQ-GroundingDINO modules (groundingdino_new/models/GroundingDINO/*), executed in place.  torchvision,
+    the visualiser, the tokenizer download helpers, the training loss / matcher and the compiled `groundingdino_new._C` are
+    stubbed (the reference's own pure-torch `multi_scale_deformable_attn_pytorch` runs instead of the CUDA op on CPU,
+    ms_deform_attn.py:340-347)."""
+    global _gd_loaded
+    if _gd_loaded is not None:
+        return _gd_loaded
+    ns = load()
+    imp = importlib.import_module
+    G = REF + "/groundingdino_new"
+    _module("torchvision", __version__="0.15.2", _is_tracing=lambda: False)
+    _shell("torchvision.ops")
+    _module("torchvision.ops.boxes", box_area=lambda b: (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]), nms=None)
+    _shell("torchvision.models")
+    _module("torchvision.models._utils", IntermediateLayerGetter=object)
+    for sub in ("", "util", "models", "models/GroundingDINO", "models/GroundingDINO/backbone"):
+        _shell(("groundingdino_new." + sub.replace("/", ".")).rstrip("."), G + ("/" + sub if sub else ""))
+    g = types.SimpleNamespace(base=ns)
+    g.misc = imp("groundingdino_new.util.misc")
+    g.utils = imp("groundingdino_new.models.GroundingDINO.utils")
+    g.msda = imp("groundingdino_new.models.GroundingDINO.ms_deform_attn")
+    g.fuse = imp("groundingdino_new.models.GroundingDINO.fuse_modules")
+    g.vanilla = imp("groundingdino_new.models.GroundingDINO.transformer_vanilla")
+    g.transformer = imp("groundingdino_new.models.GroundingDINO.transformer")
+    g.bertwarper = imp("groundingdino_new.models.GroundingDINO.bertwarper")
+    g.position_encoding = imp("groundingdino_new.models.GroundingDINO.backbone.position_encoding")
+    g.swin = imp("groundingdino_new.models.GroundingDINO.backbone.swin_transformer")
+    g.backbone = imp("groundingdino_new.models.GroundingDINO.backbone.backbone")
+    sys.modules["groundingdino_new.models.GroundingDINO.backbone"].build_backbone = g.backbone.build_backbone
+    imp("groundingdino_new.models.registry")
+    _module("groundingdino_new.util.visualizer", COCOVisualizer=object)
+    _module("groundingdino_new.util.utils", get_phrases_from_posmap=None)
+    _module("groundingdino_new.util.vl_utils", create_positive_map_from_span=None)
+    g.get_tokenlizer = _module("groundingdino_new.util.get_tokenlizer", get_tokenlizer=None, get_pretrained_language_model=None)
+    _module("groundingdino_new.models.GroundingDINO.loss", SetCriterion=lambda **k: None)
+    _module("groundingdino_new.models.GroundingDINO.matcher", build_matcher=lambda *a, **k: None)
+    if "maskrcnn_benchmark.modeling.poolers" not in sys.modules:
+        _module("maskrcnn_benchmark.modeling.poolers", CustomPooler=lambda **k: None, Pooler=lambda **k: None)
+    sys.modules["maskrcnn_benchmark.modeling.language_backbone"].build_language_backbone = None
+    sys.modules["maskrcnn_benchmark.modeling.query_selector"].build_query_selector = lambda cfg: ns.query_selector.QuerySelector(cfg)
+    g.groundingdino = imp("groundingdino_new.models.GroundingDINO.groundingdino")
+    _gd_loaded = g
+    return g
+
+
 def reference_cfg(*yaml_files):
     """The reference's own default config tree (config/defaults.py) + its YAMLs."""
     ns = load()

@@ -1,0 +1,194 @@
+"""Generate tests/golden/gdino_*.npz by running the REFERENCE's own MQ-GroundingDINO classes (test infrastructure).
+
+Run in the build container only (needs /root/reference):   python -m oracle.gen_golden_gdino
+The reference `GroundingDINO` module (groundingdino_new/models/GroundingDINO/groundingdino.py:98-661) is constructed exactly as
+`build_groundingdino` (:670-709) does -- its own Swin backbone, position encoding, deformable transformer, BertModelWarper around
+QVBertModel, heads -- from the reference config tree (defaults.py:944-1001 + configs/pretrain/mq-groundingdino-t.yaml), shallow
+(oracle/spec.py:tiny_gdino_spec), loaded with strict=True from the seeded synthetic state_dict of oracle/weights.py (which pins
+the parameter NAMES), and its eval `forward` is run on seeded inputs.  tests/test_oracle_golden.py replays oracle/gdino.py on the
+stored inputs.  Shims: the HF tokenizer / BERT weights are not downloadable, so `from_pretrained` is redirected to the local
+synthetic tokenizer directory and to a randomly initialised config (see `build_reference_model`); the CUDA MSDeformAttn op is
+replaced by the reference's own `multi_scale_deformable_attn_pytorch` (what it runs on CPU itself).
+"""
+import os
+import tempfile
+
+import numpy as np
+import torch
+
+from . import _refload
+from .gen_golden import save, sd_fingerprint
+from .spec import tiny_gdino_spec
+from .weights import make_gdino_state_dict, make_query_bank
+
+STEP, TEXT_KEEP = 5, 40          # token-row subsampling of the stored activations; text rows kept (caption + a few pad rows)
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def reference_cfg(spec):
+    cfg = _refload.reference_cfg("configs/pretrain/mq-groundingdino-t.yaml")
+    cfg.MODEL.DEVICE = "cpu"
+    cfg.VISION_QUERY.QUERY_BANK_PATH = ""
+    cfg.VISION_QUERY.ENABLED = spec.vision_query
+    cfg.MODEL.DYHEAD.NUM_CLASSES = spec.num_classes
+    G = cfg.GROUNDINGDINO
+    G.enc_layers, G.dec_layers, G.num_queries = spec.enc_layers, spec.dec_layers, spec.num_queries
+    G.use_checkpoint = G.use_transformer_ckpt = False
+    return cfg
+
+
+def build_reference_model(spec, cfg, tokenizer_dir):
+    from transformers import AutoTokenizer, BertConfig
+    g = _refload.load_gdino()
+    gd = g.groundingdino
+    g.get_tokenlizer.get_tokenlizer = lambda name: AutoTokenizer.from_pretrained(name)
+    bcfg = BertConfig(vocab_size=spec.vocab, num_hidden_layers=spec.bert_layers)
+    gd.BertConfig.from_pretrained = classmethod(lambda cls, name, **k: bcfg)
+    gd.QVBertModel.from_pretrained = classmethod(lambda cls, name, config=None, **kw: cls(config, **kw))
+    Q = gd.QVBertModel                          # helpers transformers 5.x removed from PreTrainedModel (4.x: [None] * n for no head mask)
+    if not hasattr(Q, "get_head_mask"):
+        Q.get_head_mask = lambda self, head_mask, n, *a, **k: [None] * n
+    if not hasattr(Q, "invert_attention_mask"):
+        Q.invert_attention_mask = lambda self, m: m
+    args = cfg.GROUNDINGDINO
+    swin = g.swin.SwinTransformer(pretrain_img_size=224, embed_dim=spec.swin_embed, depths=list(spec.swin_depths),
+                                  num_heads=list(spec.swin_heads), window_size=spec.window, out_indices=(1, 2, 3),
+                                  dilation=False, use_checkpoint=False)
+    backbone = g.backbone.Joiner(swin, g.position_encoding.build_position_encoding(args))
+    backbone.num_channels = swin.num_features[1:]
+    transformer = g.transformer.build_transformer(args)
+    model = gd.GroundingDINO(
+        backbone, transformer, num_queries=args.num_queries, aux_loss=True, iter_update=True, query_dim=4,
+        num_feature_levels=args.num_feature_levels, nheads=args.nheads, dec_pred_bbox_embed_share=args.dec_pred_bbox_embed_share,
+        two_stage_type=args.two_stage_type, two_stage_bbox_embed_share=args.two_stage_bbox_embed_share,
+        two_stage_class_embed_share=args.two_stage_class_embed_share, num_patterns=args.num_patterns, dn_number=0,
+        dn_box_noise_scale=args.dn_box_noise_scale, dn_label_noise_ratio=args.dn_label_noise_ratio,
+        dn_labelbook_size=args.dn_labelbook_size, text_encoder_type=tokenizer_dir,
+        sub_sentence_present=args.sub_sentence_present, max_text_len=args.max_text_len, cfg=cfg)
+    return model.eval()
+
+
+def adapt_bert(model):
+    """transformers-5.x drift around the reference's 4.x-style BertModelWarper / QVBertEncoder calls (same shims as
+    oracle/gen_golden.py uses for QVBertModel): positional BertLayer call, dropped attributes."""
+    bert = model.bert
+    C = bert.config.hidden_size
+    for layer in bert.encoder.layer:
+        orig = layer.forward
+        probe = orig(torch.zeros(1, 4, C), attention_mask=None)
+        if isinstance(probe, tuple):
+            layer.forward = (lambda o: (lambda h, m, *a, **k: o(h, attention_mask=m)))(orig)
+        else:
+            layer.forward = (lambda o: (lambda h, m, *a, **k: (o(h, attention_mask=m),)))(orig)
+    if not hasattr(bert.embeddings, "position_embedding_type"):
+        bert.embeddings.position_embedding_type = "absolute"
+    if not hasattr(bert.encoder, "gradient_checkpointing"):
+        bert.encoder.gradient_checkpointing = False
+
+    def ext_mask(attention_mask, input_shape, device=None):   # 4.x semantics: [B,T,T] -> additive [B,1,T,T], [B,T] -> [B,1,1,T]
+        m = attention_mask[:, None, :, :] if attention_mask.dim() == 3 else attention_mask[:, None, None, :]
+        return (1.0 - m.to(torch.float32)) * torch.finfo(torch.float32).min
+    bert.get_extended_attention_mask = ext_mask
+
+
+def run_case(model, g, images, sizes, caption, pmap, bank, name, spec):
+    ns = g.base
+    rec = {}
+
+    def hook(key):
+        def f(mod, inp, out):
+            rec[key] = out
+        return f
+    hs = [model.transformer.encoder.register_forward_hook(hook("encoder")),
+          model.transformer.register_forward_hook(hook("transformer")),
+          model.bert.register_forward_hook(hook("bert")),
+          model.feat_map.register_forward_hook(hook("feat_map")),
+          model.backbone.register_forward_hook(hook("backbone"))]
+    for l in range(4):
+        hs.append(model.input_proj[l].register_forward_hook(hook(f"proj{l}")))
+    if bank is not None:
+        model.query_selector.query_bank = bank
+    il = ns.image_list.ImageList(images, sizes)
+    with torch.no_grad():
+        out = model(il, captions=[caption] * images.shape[0], positive_map=pmap)
+    for h in hs:
+        h.remove()
+    feats, poss = rec["backbone"]
+    memory, memory_text = rec["encoder"]
+    hs_, refs, hs_enc, ref_enc, init_box = rec["transformer"]
+    # big tensors are stored as every STEP-th token row (the test replays the oracle and compares the same rows)
+    tok = lambda x: x.flatten(2).transpose(1, 2)[:, ::STEP]                       # [B,C,H,W] -> [B,HW/STEP,C]
+    n_real = int((rec["bert"]["last_hidden_state"].abs().sum(-1) > 0).sum(-1).max())
+    arrays = dict(
+        images=images.half(), sizes=np.asarray(sizes), swin=[tok(f.tensors) for f in feats], masks=[f.mask for f in feats],
+        pos=[tok(p_) for p_ in poss], srcs=[tok(rec[f"proj{l}"]) for l in range(4)],
+        bert=rec["bert"]["last_hidden_state"][:, :TEXT_KEEP], encoded_text=rec["feat_map"][:, :TEXT_KEEP],
+        memory=memory[:, ::STEP], memory_text=memory_text[:, :TEXT_KEEP], hs=list(hs_), refs=list(refs), hs_enc=hs_enc[0],
+        ref_enc=ref_enc[0], init_box=init_box, n_det=np.asarray([len(o) for o in out]))
+    for i, o in enumerate(out):
+        arrays[f"det_boxes.{i}"] = o.bbox
+        arrays[f"det_scores.{i}"] = o.get_field("scores")
+        arrays[f"det_labels.{i}"] = o.get_field("labels")
+    save(name, **arrays)
+    print("   detections:", [len(o) for o in out], "score range", [(float(o.get_field("scores").min()), float(o.get_field("scores").max())) for o in out if len(o)])
+    return out
+
+
+def main():
+    torch.manual_seed(4321)
+    spec = tiny_gdino_spec()
+    cfg = reference_cfg(spec)
+    from mq_det_amd.utils.tokenizer import build_synthetic_tokenizer
+    tok_dir = build_synthetic_tokenizer(tempfile.mkdtemp(), size=spec.vocab)
+    model = build_reference_model(spec, cfg, tok_dir)
+    ref_sd = model.state_dict()
+    if os.environ.get("MQ_DUMP_KEYS"):
+        for k, v in ref_sd.items():
+            print(k, tuple(v.shape))
+        return
+    sd = make_gdino_state_dict(spec, seed=0)
+    model.load_state_dict(sd, strict=True)
+    adapt_bert(model)
+    g = _refload.load_gdino()
+    from mq_det_amd.utils.tokenizer import positive_map_from_spans, synthetic_caption
+    caption, spans = synthetic_caption(10, words=(1, 2, 3))
+    caption = caption + "."                                   # preprocess_caption (groundingdino.py:92-96) would add it
+    labels = list(range(1, 11))
+    pmap = positive_map_from_spans(model.tokenizer, caption, spans, labels)
+    bank = make_query_bank(labels, spec, seed=1, scales=1)
+    os.makedirs(OUT, exist_ok=True)
+    tok = model.tokenizer([caption], padding="max_length", return_tensors="pt")
+    save("gdino_meta", fp=sd_fingerprint(sd), caption=np.asarray(caption), spans=np.asarray(spans),
+         input_ids=tok["input_ids"].to(torch.int32), attention_mask=tok["attention_mask"].to(torch.int8),
+         special_ids=np.asarray(model.specical_tokens), pmap_labels=np.asarray(sorted(pmap)),
+         pmap_first=np.asarray([pmap[k][0] for k in sorted(pmap)]), pmap_last=np.asarray([pmap[k][-1] for k in sorted(pmap)]))
+    # A: vision queries, one image (the reference asserts B == 1, groundingdino.py:502), padded right and bottom
+    img = torch.zeros(1, 3, 128, 160)
+    img[:, :, :120, :150] = torch.randn(1, 3, 120, 150).half().float()         # fp16-representable: stored as fp16
+    run_case(model, g, img, [(120, 150)], caption, pmap, bank, "gdino_vq", spec)
+    # B: text only, two images of different sizes in one padded batch
+    cfg.VISION_QUERY.ENABLED = False
+    img = torch.zeros(2, 3, 128, 160)
+    img[0, :, :128, :130] = torch.randn(3, 128, 130).half().float()
+    img[1, :, :100, :160] = torch.randn(3, 100, 160).half().float()
+    run_case(model, g, img, [(128, 130), (100, 160)], caption, pmap, None, "gdino_text", spec)
+    # C: the output conversion alone (groundingdino.py:291-335) on seeded scores / boxes, incl. its NaN quirk: a label with an
+    # empty token list makes `logits[..., []].mean(-1)` NaN, `box_cls.max(-1)` NaN for EVERY query, so nothing passes the threshold
+    gen = torch.Generator().manual_seed(7)
+    prob = torch.sigmoid(torch.randn(2, 30, 256, generator=gen) * 1.5 - 3.5)
+    boxes = torch.rand(2, 30, 4, generator=gen) * torch.tensor([1.0, 1.0, 0.6, 0.6])
+    sizes = [(128, 130), (100, 160)]
+    res = model.convert_groundingdino_to_glip_output({"pred_logits": prob, "pred_boxes": boxes}, pmap, sizes)
+    pm_empty = dict(pmap)
+    pm_empty[11] = []
+    res_empty = model.convert_groundingdino_to_glip_output({"pred_logits": prob, "pred_boxes": boxes}, pm_empty, sizes)
+    arrays = dict(prob=prob, boxes=boxes, sizes=np.asarray(sizes), n_det=np.asarray([len(r) for r in res]),
+                  n_det_empty_label=np.asarray([len(r) for r in res_empty]))
+    for i, o in enumerate(res):
+        arrays[f"det_boxes.{i}"], arrays[f"det_scores.{i}"], arrays[f"det_labels.{i}"] = o.bbox, o.get_field("scores"), o.get_field("labels")
+    save("gdino_convert", **arrays)
+    print("   convert:", arrays["n_det"], arrays["n_det_empty_label"])
+
+
+if __name__ == "__main__":
+    main()

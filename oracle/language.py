@@ -28,18 +28,21 @@ def clamp5e4(x):
 
 
 # --------------------------------------------------------------------------- BERT
-def bert_embeddings(sd, p, input_ids, eps=1e-12):
-    """modeling_bert_new.py:487-517: word + token_type(0) + absolute position, LayerNorm."""
+def bert_embeddings(sd, p, input_ids, eps=1e-12, position_ids=None):
+    """modeling_bert_new.py:487-517: word + token_type(0) + absolute position, LayerNorm.  position_ids [B,T]: the
+    per-sub-sentence positions MQ-GroundingDINO passes (groundingdino.py:546-549); default 0..T-1."""
     T = input_ids.shape[1]
     e = sd[p + ".word_embeddings.weight"][input_ids]
     e = e + sd[p + ".token_type_embeddings.weight"][0][None, None]
-    e = e + sd[p + ".position_embeddings.weight"][:T][None]
+    e = e + (sd[p + ".position_embeddings.weight"][:T][None] if position_ids is None
+             else sd[p + ".position_embeddings.weight"][position_ids])
     return _ln(sd, p + ".LayerNorm", e, eps)
 
 
 def extended_mask(attention_mask, dtype=torch.float32):
-    """HF get_extended_attention_mask: additive key-padding mask [B,1,1,T]."""
-    m = attention_mask[:, None, None, :].to(dtype)
+    """HF get_extended_attention_mask: additive key-padding mask [B,1,1,T]; a [B,T,T] mask (the sub-sentence block mask of
+    MQ-GroundingDINO, bertwarper.py:140-144) becomes [B,1,T,T]."""
+    m = (attention_mask[:, None, :, :] if attention_mask.dim() == 3 else attention_mask[:, None, None, :]).to(dtype)
     return (1.0 - m) * torch.finfo(dtype).min
 
 
@@ -154,10 +157,11 @@ def pre_select(sd, p, vision, image, spec):
     return vision
 
 
-def qv_bert(sd, p, input_ids, attention_mask, vision, images, vision_mask, spec):
-    """QVBertModel.forward (modeling_bert_new.py:690-848) -> list of the hidden states of every
+def qv_bert(sd, p, input_ids, attention_mask, vision, images, vision_mask, spec, position_ids=None):
+    """QVBertModel.forward (modeling_bert_new.py:690-848; the same arithmetic through BertModelWarper.forward,
+    groundingdino_new/models/GroundingDINO/bertwarper.py:60-215) -> list of the hidden states of every
     layer (output_hidden_states[1:]).  `p` is e.g. 'language_backbone.body.model'."""
-    x = bert_embeddings(sd, p + ".embeddings", input_ids, spec.bert_eps)
+    x = bert_embeddings(sd, p + ".embeddings", input_ids, spec.bert_eps, position_ids)
     ext = extended_mask(attention_mask)
     use_vq = vision is not None and images is not None and vision.numel() > 0
     if use_vq:

@@ -88,3 +88,33 @@ def tiny_l_spec(**kw) -> Spec:
     base = Spec(swin_embed=192, swin_depths=(2, 2, 2, 2), swin_heads=(6, 12, 24, 48), window=12, bert_layers=4, qv_start=2,
                 dyhead_convs=2, vocab=2048, num_classes=81, mdetr_class_num=-1)
     return replace(base, **kw)
+
+
+@dataclass(frozen=True)
+class GdinoSpec(Spec):
+    """MQ-GroundingDINO-T (BASELINE.json configs[4]): defaults.py:944-1001 + configs/pretrain/mq-groundingdino-t.yaml."""
+    hidden: int = 256               # GROUNDINGDINO.hidden_dim
+    nheads: int = 8
+    enc_layers: int = 6
+    dec_layers: int = 6
+    ffn: int = 2048                 # dim_feedforward; fusion embed / text-enhancer FFN = ffn // 2, their heads = nheads // 2
+    num_queries: int = 900
+    levels: int = 4                 # num_feature_levels (Swin stages 1-3 + one stride-2 conv)
+    points: int = 4                 # enc_n_points == dec_n_points
+    pe_temperature: float = 20.0    # pe_temperatureH == pe_temperatureW
+    box_threshold: float = 0.05
+    max_text_len: int = 256
+    fusion_init: float = 1e-4       # BiAttentionBlock init_values (layer scale)
+    gn_groups: int = 32             # input_proj GroupNorm(32, hidden)
+    num_classes: int = 81           # MODEL.DYHEAD.NUM_CLASSES (defaults.py): width of the class-score tensor - 1
+
+
+def gdino_t_spec(**kw) -> GdinoSpec:
+    return replace(GdinoSpec(), **kw)
+
+
+def tiny_gdino_spec(**kw) -> GdinoSpec:
+    """Real widths / head dims, shallow: Swin depths 2-2-2-2, BERT 7 layers with one GCP block (the reference hard-codes
+    start_qv_layer_index = 6, modeling_bert_new.py:532), 2 encoder + 2 decoder layers, 40 queries, small vocabulary."""
+    base = GdinoSpec(swin_depths=(2, 2, 2, 2), bert_layers=7, qv_start=6, vocab=2048, enc_layers=2, dec_layers=2, num_queries=40)
+    return replace(base, **kw)
