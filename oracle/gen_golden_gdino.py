@@ -175,7 +175,7 @@ def main():
     # C: the output conversion alone (groundingdino.py:291-335) on seeded scores / boxes, incl. its NaN quirk: a label with an
     # empty token list makes `logits[..., []].mean(-1)` NaN, `box_cls.max(-1)` NaN for EVERY query, so nothing passes the threshold
     gen = torch.Generator().manual_seed(7)
-    prob = torch.sigmoid(torch.randn(2, 30, 256, generator=gen) * 1.5 - 3.5)
+    prob = torch.sigmoid(torch.randn(2, 30, 256, generator=gen) * 2.0 - 5.0)
     boxes = torch.rand(2, 30, 4, generator=gen) * torch.tensor([1.0, 1.0, 0.6, 0.6])
     sizes = [(128, 130), (100, 160)]
     res = model.convert_groundingdino_to_glip_output({"pred_logits": prob, "pred_boxes": boxes}, pmap, sizes)
