@@ -26,15 +26,21 @@ int mq_abi_version(void);
  *   Nk..ceil8(Nk) must be finite), o [B,Nq,H*D] at o + b*o_bs + i*o_rs + h*D + d; key_bias fp32 (b,h,j) at
  *   key_bias + b*bias_bs + h*bias_hs + j or NULL; clamp <= 0 disables.  kv_len [B] int32 or NULL: keys >= kv_len[b]
  *   are masked by the caller's key_bias (text padding) and their tiles are skipped (exactly-zero contribution).
+ *   qk_mask uint8 or NULL: per-(query, key) mask, element (b,h,i,j) at qk_mask + b*mask_bs + h*mask_hs + i*mask_rs + j,
+ *   1 = key j is hidden from query i (strides in bytes, 0 shares the mask across batch / heads): the sub-sentence block mask
+ *   of MQ-GroundingDINO's BERT (bertwarper.py:273-320 -> :140-144) and the `attn_mask` of its text-enhancer layers
+ *   (transformer_vanilla.py:108-113).
  *   nsplit > 1 splits the key range over grid.z (few queries / many keys) and needs
  *   mq_attn_workspace_bytes() bytes of workspace.
  * Replaces the unfused bmm -> (+mask) -> softmax -> bmm chains of
  *   maskrcnn_benchmark/modeling/rpn/modeling_bert.py:119-170 (BertSelfAttention, with clamp) and HF BertSelfAttention,
- *   maskrcnn_benchmark/modeling/language_backbone/modeling_bert_new.py:204-240 (MaskedCrossAttention, dense).
+ *   maskrcnn_benchmark/modeling/language_backbone/modeling_bert_new.py:204-240 (MaskedCrossAttention, dense), and the
+ *   nn.MultiheadAttention calls of MQ-GroundingDINO (decoder self-attention 8 x 32 over 900 queries and text cross-attention,
+ *   groundingdino_new/models/GroundingDINO/transformer.py:895-911; text enhancer 4 x 64, transformer_vanilla.py:92-123).
  *   (The 8 x 256 VLFuse attention has its own kernels, mq_vlfuse_*.) */
 long mq_attn_workspace_bytes(int B, int H, int Nq, int D, int nsplit);
 int mq_attn_fwd(const void* q, const void* k, const void* vt, void* o, const float* key_bias, const int* kv_len,
-                void* workspace,
+                const unsigned char* qk_mask, long mask_bs, long mask_hs, long mask_rs, void* workspace,
                 int B, int H, int Nq, int Nk, int D,
                 long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long vt_bs, long vt_rs, long vt_hs,
                 long o_bs, long o_rs, long bias_bs, long bias_hs, float scale, float clamp, int nsplit, void* stream);
@@ -63,29 +69,33 @@ int mq_gcp_sparse_attn_fwd(const void* q, const void* kv, const int* idx, void* 
 int mq_gcp_gate_residual_fwd(const void* sup, const void* h, const void* w2, const void* x, int x_f32, void* out,
                              float* gate_out, long M, int C, int G, void* stream);
 
-/* VLFuse image side in ONE launch (8 heads x 256, text tokens T <= 256), projections folded into the text operands:
+/* VLFuse image side in ONE launch (heads <= 8, head dim 256, text tokens T <= 256), projections folded into the text operands:
  *   out[b,n,:] = v_ln[b,n,:] + out_bias + sum_h softmax_t( clamp(v_ln[b,n,:] . kf[b,h,t,:] + bias[b,h,t], +-clamp) ) vo[b,h,t,:]
- *   v_ln [B,N,256] fp16 (LN(v): queries AND residual), kf / vo [B,8,T,256] fp16 (folded text keys / values),
- *   bias [B,8,T] fp32 or NULL (<= -1e29: key masked), kv_len [B] int32 or NULL (keys >= kv_len[b] masked),
+ *   v_ln [B,N,256] fp16 (LN(v): queries AND residual), kf / vo [B,heads,T,256] fp16 (folded text keys / values),
+ *   bias [B,heads,T] fp32 or NULL (<= -1e29: key masked), kv_len [B] int32 or NULL (keys >= kv_len[b] masked),
  *   max_kv: host-side upper bound of kv_len (<= 0: T) -- the caller guarantees kv_len[b] <= max_kv,
  *   out_bias [256] fp16, out [B,N,256] fp16.
  * Replaces BiMultiHeadAttention's image branch: v_proj, the [B*8, N, T] logits, clamp, softmax over text,
  *   bmm with values_l, out_v_proj, and the gamma_v residual of BiAttentionBlock
- *   (maskrcnn_benchmark/utils/fuse_helper.py:221-279,290-300,424). */
+ *   (maskrcnn_benchmark/utils/fuse_helper.py:221-279,290-300,424; heads = 8), and the same branch of MQ-GroundingDINO's
+ *   feature-enhancer fusion (groundingdino_new/models/GroundingDINO/fuse_modules.py:146-249,286-296; heads = 4). */
 int mq_vlfuse_i2t_fwd(const void* v_ln, const void* kf, const void* vo, const float* bias, const int* kv_len,
-                      const void* out_bias, void* out, int B, int N, int T, int max_kv, float clamp, void* stream);
+                      const void* out_bias, void* out, int B, int N, int T, int heads, int max_kv, float clamp, void* stream);
 
 /* VLFuse text side: keys = values = image tokens, split over the keys (nsplit >= 1) + merge:
  *   out[b,t,h*256:(h+1)*256] = sum_n softmax_n( clamp(kf[b,h,t,:] . v_ln[b,n,:], +-clamp) ) v_ln[b,n,:]
- *   workspace: mq_vlfuse_t2i_workspace_bytes(B, T, nsplit) bytes of device memory; out [B,T,2048] fp16;
+ *   kf [B,heads,T,256]; workspace: mq_vlfuse_t2i_workspace_bytes(B, T, nsplit) bytes of device memory (sized for 8 heads);
+ *   out [B,T,heads*256] fp16;
+ *   key_mask uint8 [B, key_mask_bs] or NULL: 1 = image token n is padding and masked as a key (`attention_mask_v`,
+ *   fuse_modules.py:205-210: images of different sizes in one padded batch); key_mask_bs % 4 == 0 and >= 64*ceil(N/64);
  *   kv_len [B] int32 or NULL: caption length -- 16-row blocks that hold only padding tokens (rows >= kv_len[b]) are not
  *   computed and come back as zeros (padding rows never influence a detection: masked as keys, never scored).
  * Replaces the text branch of BiMultiHeadAttention: the transposed logits, their softmax over image tokens and the
  *   bmm with values_v (fuse_helper.py:246-262,281-288); values_v_proj / out_l_proj are applied to the result by the
  *   caller as one folded [768, 2048] weight. */
 long mq_vlfuse_t2i_workspace_bytes(int B, int T, int nsplit);
-int mq_vlfuse_t2i_fwd(const void* kf, const void* v_ln, const int* kv_len, void* workspace, void* out, int B, int N, int T,
-                      int nsplit, float clamp, void* stream);
+int mq_vlfuse_t2i_fwd(const void* kf, const void* v_ln, const int* kv_len, const unsigned char* key_mask, long key_mask_bs,
+                      void* workspace, void* out, int B, int N, int T, int heads, int nsplit, float clamp, void* stream);
 
 /* Row LayerNorm with the residual add fused in, mixed-precision streams, fp32 statistics; C % 8 == 0, C <= 3072.
  *   s = x (+ res);  x is fp32 when x_f32 != 0 else fp16, res likewise (res_f32); res may be NULL.
@@ -217,6 +227,17 @@ int mq_roi_align_fwd(const void* feat, int feat_f32, const float* rois, float* o
  *   ms_deform_im2col_cuda.cuh:33-84,237-299) and its torch fallback (ms_deform_attn.py:93-133). */
 int mq_msdeform_attn_fwd(const void* value, int value_f32, const long* shapes, const long* level_start, const float* loc,
                          const float* attn, void* out, int out_f32, int B, int S, int M, int D, int L, int Q, int P, void* stream);
+
+/* The same operator fed by the query-projection GEMM directly (softmax over the L*P samples and the sampling locations are
+ * computed in registers; L == P == 4):
+ *   qproj [B,Q,M*L*P*3] fp16 = [sampling_offsets (m,l,p,xy) | attention logits (m,l,p)] of one fused projection,
+ *   ref [B,Q,L,ref_dim] fp32 normalised reference points (ref_dim 2: loc = ref + off / (W_l, H_l)) or boxes (ref_dim 4:
+ *   loc = ref.xy + off / P * ref.wh * 0.5), value element (b,s,m,c) at value + b*value_bs + s*value_ts + m*D + c.
+ * Replaces MultiScaleDeformableAttention.forward lines ms_deform_attn.py:292-347 (view / softmax / location arithmetic /
+ *   fp32 casts / _C.ms_deform_attn_forward) for the encoder (transformer.py:786-793) and decoder (:912-919) call sites. */
+int mq_msdeform_attn_q_fwd(const void* value, int value_f32, long value_bs, long value_ts, const long* shapes,
+                           const long* level_start, const void* qproj, const float* ref, int ref_dim, void* out, int out_f32,
+                           int B, int S, int M, int D, int L, int Q, int P, void* stream);
 
 /* Class-aware NMS on score-sorted boxes, mask + sweep entirely on the device.
  *   boxes [B,N,4] fp32 (sorted by score desc per image), labels [B,N] int32, nvalid [B] int32 -> keep [B,N] uint8.

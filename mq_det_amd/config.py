@@ -137,5 +137,25 @@ def get_cfg():
     cfg.INPUT = C(dict(PIXEL_MEAN=[103.530, 116.280, 123.675], PIXEL_STD=[57.375, 57.120, 58.395],
                        MIN_SIZE_TEST=800, MAX_SIZE_TEST=1333))
     cfg.GLIPKNOW = C(dict(KNOWLEDGE_FILE="", PARALLEL_LANGUAGE_INPUT=False))
-    cfg.GROUNDINGDINO = C(dict(enabled=False))
+    # config/defaults.py:944-1001 (key names are the reference's: the flag system is part of the boundary)
+    cfg.GROUNDINGDINO = C(dict(
+        enabled=False, modelname="groundingdino", backbone="swin_T_224_1k", position_embedding="sine", pe_temperatureH=20,
+        pe_temperatureW=20, return_interm_indices=[1, 2, 3], backbone_freeze_keywords=None, enc_layers=6, dec_layers=6,
+        pre_norm=False, dim_feedforward=2048, hidden_dim=256, dropout=0.0, nheads=8, num_queries=900, query_dim=4,
+        num_patterns=0, num_feature_levels=4, enc_n_points=4, dec_n_points=4, two_stage_type="standard",
+        two_stage_bbox_embed_share=False, two_stage_class_embed_share=False, transformer_activation="relu",
+        dec_pred_bbox_embed_share=True, embed_init_tgt=True, max_text_len=256, text_encoder_type="bert-base-uncased",
+        use_text_enhancer=True, use_fusion_layer=True, use_checkpoint=False, use_transformer_ckpt=False,
+        use_text_cross_attention=True, text_dropout=0.0, fusion_dropout=0.0, fusion_droppath=0.1, sub_sentence_present=True,
+        box_threshold=0.05))
+    return cfg
+
+
+def get_gdino_cfg():
+    """Defaults + configs/pretrain/mq-groundingdino-t.yaml (the keys the inference forward reads)."""
+    cfg = get_cfg()
+    cfg.GROUNDINGDINO.enabled = True
+    cfg.MODEL.ROI_BOX_HEAD.POOLER_SCALES = (0.125, 0.0625, 0.03125, 0.015625)
+    cfg.INPUT.FORMAT = "rgb"
+    cfg.INPUT.PIXEL_MEAN, cfg.INPUT.PIXEL_STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
     return cfg

@@ -29,6 +29,8 @@ struct AttnParams {
   const half_t* q; const half_t* k; const half_t* vt; half_t* o;
   const float* key_bias;     // [B, Nk] or nullptr
   const int* kv_len;         // [B] or nullptr: keys >= kv_len[b] are masked (contribute exactly 0) -> their tiles are skipped
+  const unsigned char* qk_mask;   // per-(query, key) mask, 1 = masked, element (b,h,i,j) at b*mask_bs + h*mask_hs + i*mask_rs + j, or nullptr
+  long mask_bs, mask_hs, mask_rs;
   float* ws;                 // split-K workspace or nullptr
   int B, H, Nq, Nk;
   long q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, vt_bs, vt_rs, vt_hs, o_bs, o_rs, bias_bs, bias_hs;
@@ -36,7 +38,7 @@ struct AttnParams {
   int nsplit;
 };
 
-template <int D, int RB>
+template <int D, int RB, bool MASK>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   constexpr int BM = 4 * RB * 16, BN = 64;
   constexpr int KS = D + 8, VS = BN + 8, PS = BN + 8;
@@ -71,6 +73,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const half_t* Vt = p.vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
   const float* bias = p.key_bias ? p.key_bias + (long)b * p.bias_bs + (long)h * p.bias_hs : nullptr;
   half_t* Pw = Ps + wave * (RB * 16 * PS);
+  const unsigned char* qmask = MASK ? p.qk_mask + (long)b * p.mask_bs + (long)h * p.mask_hs : nullptr;
 
   // trailing masked keys (text padding) contribute exactly zero: do not even visit their tiles
   const int nk_eff = p.kv_len ? max(1, min(p.Nk, p.kv_len[b])) : p.Nk;
@@ -208,7 +211,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         for (int r = 0; r < 4; ++r) {
           float v = s[rb][nb][r] * p.scale + kb;
           if (p.clamp > 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
-          s[rb][nb][r] = (valid && !masked) ? v : MQ_NEG_BIG;
+          bool on = valid && !masked;
+          if constexpr (MASK) {                            // sub-sentence / attn_mask style masks (text-sized attentions only)
+            const int row = min(row0 + rb * 16 + lg * 4 + r, p.Nq - 1);
+            on = on && qmask[(long)row * p.mask_rs + min(key, p.Nk - 1)] == 0;
+          }
+          s[rb][nb][r] = on ? v : MQ_NEG_BIG;
         }
     }
     // ---- online softmax with deferred rescale: the decision is taken BEFORE this tile's P is exponentiated and
@@ -356,20 +364,20 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
   }
 }
 
-template <int D, int RB>
+template <int D, int RB, bool MASK>
 static int launch_attn(const AttnParams& p, hipStream_t stream) {
   constexpr int BM = 4 * RB * 16, BN = 64;
   constexpr size_t smem = (size_t)(BN * (D + 8) + D * (BN + 8) + 4 * RB * 16 * (BN + 8) + (D >= 256 ? BM * (D + 8) : 0)) * sizeof(half_t) + BN * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<D, RB>,
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<D, RB, MASK>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   const int groups = p.B * p.nsplit, members = p.H * ((p.Nq + BM - 1) / BM);
   dim3 grid((unsigned)(8 * ((groups + 7) / 8) * members));
-  hipLaunchKernelGGL((attn_fwd_kernel<D, RB>), grid, dim3(256), smem, stream, p);
+  hipLaunchKernelGGL((attn_fwd_kernel<D, RB, MASK>), grid, dim3(256), smem, stream, p);
   MQ_CHECK_LAUNCH();
   if (p.nsplit > 1) {
     long total = (long)p.B * p.H * p.Nq;
@@ -384,7 +392,8 @@ extern "C" long mq_attn_workspace_bytes(int B, int H, int Nq, int D, int nsplit)
 }
 
 extern "C" int mq_attn_fwd(const void* q, const void* k, const void* vt, void* o, const float* key_bias,
-                           const int* kv_len, void* workspace, int B, int H, int Nq, int Nk, int D,
+                           const int* kv_len, const unsigned char* qk_mask, long mask_bs, long mask_hs, long mask_rs,
+                           void* workspace, int B, int H, int Nq, int Nk, int D,
                            long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs,
                            long vt_bs, long vt_rs, long vt_hs, long o_bs, long o_rs, long bias_bs, long bias_hs,
                            float scale, float clamp, int nsplit, void* stream) {
@@ -395,14 +404,22 @@ extern "C" int mq_attn_fwd(const void* q, const void* k, const void* vt, void* o
   AttnParams p;
   p.q = (const half_t*)q; p.k = (const half_t*)k; p.vt = (const half_t*)vt; p.o = (half_t*)o;
   p.key_bias = key_bias; p.kv_len = kv_len; p.ws = (float*)workspace;
+  p.qk_mask = qk_mask; p.mask_bs = mask_bs; p.mask_hs = mask_hs; p.mask_rs = mask_rs;
   p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk;
   p.q_bs = q_bs; p.q_rs = q_rs; p.q_hs = q_hs; p.k_bs = k_bs; p.k_rs = k_rs; p.k_hs = k_hs;
   p.vt_bs = vt_bs; p.vt_rs = vt_rs; p.vt_hs = vt_hs; p.bias_bs = bias_bs; p.bias_hs = bias_hs;
   p.o_bs = o_bs; p.o_rs = o_rs; p.scale = scale; p.clamp = clamp; p.nsplit = nsplit;
   hipStream_t s = (hipStream_t)stream;
+  if (qk_mask) {
+    switch (D) {
+      case 32: return launch_attn<32, 2, true>(p, s);
+      case 64: return launch_attn<64, 2, true>(p, s);
+      default: return -1;
+    }
+  }
   switch (D) {
-    case 32: return launch_attn<32, 2>(p, s);
-    case 64: return launch_attn<64, 2>(p, s);
+    case 32: return launch_attn<32, 2, false>(p, s);
+    case 64: return launch_attn<64, 2, false>(p, s);
     default: return -1;
   }
 }

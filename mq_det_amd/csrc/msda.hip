@@ -96,3 +96,124 @@ extern "C" int mq_msdeform_attn_fwd(const void* value, int value_f32, const long
   MQ_CHECK_LAUNCH();
   return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------ fused query side
+// mq_msdeform_attn_q_fwd: the same gather, fed with what the query projection GEMM produced instead of materialised fp32
+// sampling locations / attention weights (reference ms_deform_attn.py:292-329 builds them with a softmax, two divisions, a
+// broadcast add and several fp32 casts: ~8 elementwise passes over [B, Q, M, L, P, 2] per layer).  Per (b, q, head):
+//   logits -> softmax over the L*P samples, in registers;
+//   loc = ref[l, :2] + off / (W_l, H_l)                      (2-d reference points, encoder)
+//       = ref[l, :2] + off / P * ref[l, 2:] * 0.5            (4-d reference boxes, decoder)
+//   qproj [B, Q, M*L*P*3] fp16: offsets (m, l, p, xy) then logits (m, l, p) -- the [sampling_offsets | attention_weights]
+//   projection as ONE GEMM; ref [B, Q, L, RD] fp32; value element (b, s, m, c) at value + b*value_bs + s*value_ts + m*D + c
+//   (a token stride > M*D lets the six decoder layers share one batched value projection).
+template <typename TV, typename TO, int L, int P, int RD>
+__global__ __launch_bounds__(256) void msda_q_kernel(const TV* __restrict__ value, long value_bs, long value_ts,
+                                                     const long* __restrict__ shapes, const long* __restrict__ level_start,
+                                                     const half_t* __restrict__ qproj, const float* __restrict__ ref,
+                                                     TO* __restrict__ out, int B, int S, int M, int D, int Q) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long bq = (long)blockIdx.x * 4 + wave;
+  if (bq >= (long)B * Q) return;
+  const int b = bq / Q;
+  const int lph = D >> 2;
+  const int nchunk = M * lph;
+  constexpr int LP = L * P;
+  const half_t* qrow = qproj + bq * (long)(M * LP * 3);
+  const float* rrow = ref + bq * (long)(L * RD);
+  for (int ch = lane; ch < nchunk; ch += 64) {
+    const int m = ch / lph, c = (ch - m * lph) << 2;
+    // softmax over this head's L*P logits (16 halfs = two 16-byte loads, shared by the lanes of the head through L1)
+    float w[LP];
+    {
+      const half_t* lg = qrow + M * LP * 2 + m * LP;
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int i = 0; i < LP; i += 8) {
+        const half8 t = *(const half8*)(lg + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { w[i + j] = (float)t[j]; mx = fmaxf(mx, w[i + j]); }
+      }
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < LP; ++i) { w[i] = __expf(w[i] - mx); sum += w[i]; }
+      const float inv = 1.f / sum;
+#pragma unroll
+      for (int i = 0; i < LP; ++i) w[i] *= inv;
+    }
+    const half_t* op = qrow + m * LP * 2;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const TV* vb = value + (long)b * value_bs + level_start[l] * value_ts + m * D + c;
+      const long ws = value_ts, hs = (long)W * ws;
+      const float rx = rrow[l * RD], ry = rrow[l * RD + 1];
+      float sx, sy;                                        // offset -> normalised location scale
+      if constexpr (RD == 2) { sx = 1.f / (float)W; sy = 1.f / (float)H; }
+      else { sx = rrow[l * RD + 2] * (0.5f / (float)P); sy = rrow[l * RD + 3] * (0.5f / (float)P); }
+      const half8 o8 = *(const half8*)(op + l * P * 2);     // P == 4: the 4 (x, y) pairs of this level
+#pragma unroll
+      for (int pt = 0; pt < P; ++pt) {
+        const float loc_w = rx + (float)o8[2 * pt] * sx, loc_h = ry + (float)o8[2 * pt + 1] * sy, wgt = w[l * P + pt];
+        const float h = loc_h * (float)H - 0.5f, wq = loc_w * (float)W - 0.5f;
+        if (h > -1.f && wq > -1.f && h < (float)H && wq < (float)W) {
+          const int hl = (int)floorf(h), wl = (int)floorf(wq), hh = hl + 1, wh = wl + 1;
+          const float lh = h - (float)hl, lw = wq - (float)wl, uh = 1.f - lh, uw = 1.f - lw;
+          float v1[4] = {0.f, 0.f, 0.f, 0.f}, v2[4] = {0.f, 0.f, 0.f, 0.f}, v3[4] = {0.f, 0.f, 0.f, 0.f}, v4[4] = {0.f, 0.f, 0.f, 0.f};
+          auto ld = [&](int y, int x, float* dst) {
+            const TV* a = vb + y * hs + x * ws;
+            if constexpr (sizeof(TV) == 2) {
+              const half4 t = *(const half4*)a;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) dst[j] = (float)t[j];
+            } else {
+              const float4_ t = *(const float4_*)a;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) dst[j] = t[j];
+            }
+          };
+          if (hl >= 0 && wl >= 0) ld(hl, wl, v1);
+          if (hl >= 0 && wh <= W - 1) ld(hl, wh, v2);
+          if (hh <= H - 1 && wl >= 0) ld(hh, wl, v3);
+          if (hh <= H - 1 && wh <= W - 1) ld(hh, wh, v4);
+          const float w1 = uh * uw, w2 = uh * lw, w3 = lh * uw, w4 = lh * lw;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] += (w1 * v1[j] + w2 * v2[j] + w3 * v3[j] + w4 * v4[j]) * wgt;
+        }
+      }
+    }
+    TO* o = out + bq * (long)(M * D) + m * D + c;
+    if constexpr (sizeof(TO) == 2) {
+      half4 t;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[j] = (half_t)acc[j];
+      *(half4*)o = t;
+    } else {
+      *(float4_*)o = (float4_){acc[0], acc[1], acc[2], acc[3]};
+    }
+  }
+}
+
+extern "C" int mq_msdeform_attn_q_fwd(const void* value, int value_f32, long value_bs, long value_ts, const long* shapes,
+                                      const long* level_start, const void* qproj, const float* ref, int ref_dim, void* out,
+                                      int out_f32, int B, int S, int M, int D, int L, int Q, int P, void* stream) {
+  if (B <= 0 || Q <= 0) return 0;
+  if (D % 4 || M <= 0 || L != 4 || P != 4 || (ref_dim != 2 && ref_dim != 4) || (value_ts % 4) || (value_bs % 4)) return -1;
+  const dim3 grid((unsigned)(((long)B * Q + 3) / 4));
+  hipStream_t s = (hipStream_t)stream;
+#define MQ_MSDAQ(TV, TO, RD)                                                                                             \
+  hipLaunchKernelGGL((msda_q_kernel<TV, TO, 4, 4, RD>), grid, dim3(256), 0, s, (const TV*)value, value_bs, value_ts, shapes,  \
+                     level_start, (const half_t*)qproj, ref, (TO*)out, B, S, M, D, Q)
+#define MQ_MSDAQ_T(RD)                                       \
+  if (value_f32 && out_f32) MQ_MSDAQ(float, float, RD);      \
+  else if (value_f32) MQ_MSDAQ(float, half_t, RD);           \
+  else if (out_f32) MQ_MSDAQ(half_t, float, RD);             \
+  else MQ_MSDAQ(half_t, half_t, RD)
+  if (ref_dim == 2) { MQ_MSDAQ_T(2); } else { MQ_MSDAQ_T(4); }
+#undef MQ_MSDAQ_T
+#undef MQ_MSDAQ
+  MQ_CHECK_LAUNCH();
+  return 0;
+}

@@ -37,7 +37,7 @@ __device__ __forceinline__ half4 lds_read_tr16(const half_t* p) {
 }
 
 namespace {
-constexpr int VH = 8, VD = 256;            // heads, head dim
+constexpr int VH = 8, VD = 256;            // max heads (run-time count in the params), head dim
 constexpr int BM = 128;                    // query rows per workgroup (4 waves x 32)
 constexpr int TK = 64;                     // keys per tile
 constexpr int KS = VD + 16;                // LDS row pitch (halfs): 544 B -> 8 consecutive rows cover all 64 banks
@@ -55,6 +55,7 @@ struct I2TParams {
   const half_t* obias;    // [256]
   half_t* out;            // [B, N, 256]
   int B, N, T;
+  int H;                  // heads (8: VLDyHead fusion, 4: GroundingDINO feature enhancer), <= VH
   float clamp;
 };
 
@@ -155,10 +156,10 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
   const int row0 = qtile * BM + wave * WR;
 
   const int kv_eff = p.kv_len ? max(1, min(p.T, p.kv_len[b])) : p.T;
-  for (int i = tid; i < VH * NT * TK; i += NTH) {
+  for (int i = tid; i < p.H * NT * TK; i += NTH) {
     const int h = i / (NT * TK), t = i % (NT * TK);
     float v = MQ_NEG_BIG;
-    if (t < kv_eff) v = p.bias ? p.bias[((long)b * VH + h) * p.T + t] : 0.f;
+    if (t < kv_eff) v = p.bias ? p.bias[((long)b * p.H + h) * p.T + t] : 0.f;
     bias_s[i] = v;
   }
 
@@ -188,13 +189,14 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
 
   // tile stream: u = h * 2NT + j;  j < NT: key tile j of head h,  j >= NT: value tile j - NT.  2NT is even, so the
   // position parity inside a head is also the parity of u: LDS buffer and register slot indices are compile-time.
-  constexpr int PER_HEAD = 2 * NT, U = VH * PER_HEAD;
+  constexpr int PER_HEAD = 2 * NT;
+  const int U = p.H * PER_HEAD;
   TileRegs<NTH> slot[LEAN ? 1 : 2];
   auto issue = [&](auto SLOT, int u) {
     constexpr int sl = decltype(SLOT)::value;
     u = min(u, U - 1);                                     // the tail re-loads the last tile: one code path, no branches
     const int h = u / PER_HEAD, j = u % PER_HEAD;
-    const half_t* src = (j < NT ? p.kf : p.vo) + ((long)b * VH + h) * p.T * VD;
+    const half_t* src = (j < NT ? p.kf : p.vo) + ((long)b * p.H + h) * p.T * VD;
     tile_issue(slot[sl], src, (j < NT ? j : j - NT) * TK, p.T - 1, tid);
   };
   // begin(pos): prefetch;  end(pos): commit the next tile into the other LDS buffer + barrier
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
   tile_commit(slot[0], tiles, tid);
   __syncthreads();
 
-  for (int h = 0; h < VH; ++h) {
+  for (int h = 0; h < p.H; ++h) {
     const int u0 = h * PER_HEAD;
     float4_ s[NT][4][QB];
     // ---- logits of all key tiles of this head (kept in registers: exact softmax, no running rescale)
@@ -358,12 +360,13 @@ static int vlfuse_qb() {
 // Image side of VLFuse.  max_kv: host-known upper bound of kv_len (T if unknown) -- picks the number of 64-key tiles
 // kept in registers.  See include/mqdet_hip.h.
 extern "C" int mq_vlfuse_i2t_fwd(const void* v_ln, const void* kf, const void* vo, const float* bias, const int* kv_len,
-                                 const void* out_bias, void* out, int B, int N, int T, int max_kv, float clamp, void* stream) {
+                                 const void* out_bias, void* out, int B, int N, int T, int heads, int max_kv, float clamp,
+                                 void* stream) {
   if (B <= 0 || N <= 0) return 0;
-  if (T < 1 || T > 256) return -1;
+  if (T < 1 || T > 256 || heads < 1 || heads > VH) return -1;
   I2TParams p;
   p.v = (const half_t*)v_ln; p.kf = (const half_t*)kf; p.vo = (const half_t*)vo; p.bias = bias; p.kv_len = kv_len;
-  p.obias = (const half_t*)out_bias; p.out = (half_t*)out; p.B = B; p.N = N; p.T = T; p.clamp = clamp;
+  p.obias = (const half_t*)out_bias; p.out = (half_t*)out; p.B = B; p.N = N; p.T = T; p.H = heads; p.clamp = clamp;
   const int kv = (kv_len && max_kv > 0) ? min(max_kv, T) : T;
   const int nt = (kv + TK - 1) / TK;
   const int nbl = min(4, max(1, (kv - (nt - 1) * TK + 15) / 16));       // live 16-key blocks of the last tile
@@ -399,13 +402,16 @@ struct T2IParams {
   float* ws;              // [nsplit][B*8][T][WS_LD] fp32 partials: O (un-normalised), then m, l
   half_t* out;            // [B, T, 8*256]
   const int* kv_len;      // [B] or nullptr: text rows >= kv_len[b] are padding -> not computed, written as zeros
+  const unsigned char* kmask;   // [B, kmask_bs] or nullptr: 1 = image token is padding (masked as a key); kmask_bs % 4 == 0, >= 64*ceil(N/64)
+  long kmask_bs;
+  int H;                  // heads, <= VH
   int B, N, T, nsplit;
   int wr;                 // rows per wave of the main kernel (16 QB): granularity at which all-padding rows are skipped
   float clamp;
 };
 namespace { constexpr int WS_LD = VD + 4; }               // 260 floats: rows stay 16-byte aligned
 
-template <int QB>
+template <int QB, bool KM>
 __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p) {
   constexpr int NTH = 2048 / (QB * 4), WR = 16 * QB;        // threads per workgroup (512 / 256), query rows per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -415,11 +421,11 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
   const int l15 = lane & 15, lg = lane >> 4;
   // XCD-aware order: the 8 heads x q-tiles of one (image, key split) stream the SAME image tokens -> one XCD, adjacent
   const int qtiles = (p.T + BM - 1) / BM;
-  const int members = VH * qtiles;
+  const int members = p.H * qtiles;
   const int seq = blockIdx.x >> 3;
   const int group = (seq / members) * 8 + (blockIdx.x & 7);
   if (group >= p.B * p.nsplit) return;
-  const int wq = seq % members, h = wq % VH, qtile = wq / VH;
+  const int wq = seq % members, h = wq % p.H, qtile = wq / p.H;
   const int b = group / p.nsplit, split = group % p.nsplit;
   // padded caption tokens: as keys they are masked everywhere downstream and the post-processor never reads their
   // logits, so their rows of this attention are dead -- whole q-tiles of padding are skipped (the merge writes zeros)
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
   const int nt = max(t1 - t0, 0);
 
   half8 qf[QB][8];
-  const half_t* qb_ = p.kf + ((long)b * VH + h) * p.T * VD;
+  const half_t* qb_ = p.kf + ((long)b * p.H + h) * p.T * VD;
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int row = min(row0 + qb * 16 + l15, p.T - 1);
@@ -469,6 +475,11 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
       float4_ s[4][QB];
       qk_tile<false, QB>(tile, qf, nullptr, s, l15, lg);
       const int key0 = (t0 + pos) * TK;
+      unsigned km[4] = {0u, 0u, 0u, 0u};                   // padding flags of this lane's 4 x 4 keys (GroundingDINO batches)
+      if constexpr (KM) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) km[nb] = *(const unsigned*)(p.kmask + (long)b * p.kmask_bs + key0 + nb * 16 + 4 * lg);
+      }
       float mx[QB];
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) mx[qb] = MQ_NEG_BIG;
@@ -476,7 +487,7 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
       for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const bool valid = key0 + nb * 16 + 4 * lg + r < p.N;
+          const bool valid = key0 + nb * 16 + 4 * lg + r < p.N && (!KM || ((km[nb] >> (8 * r)) & 0xffu) == 0u);
 #pragma unroll
           for (int qb = 0; qb < QB; ++qb) {
             float v = s[nb][qb][r];
@@ -542,7 +553,7 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
     l += __shfl_xor(l, 32);
     const int row = row0 + qb * 16 + l15;
     if (row < p.T && wave_live) {
-      float* w = p.ws + (((long)split * p.B * VH + (long)b * VH + h) * p.T + row) * WS_LD;
+      float* w = p.ws + (((long)split * p.B * p.H + (long)b * p.H + h) * p.T + row) * WS_LD;
 #pragma unroll
       for (int db = 0; db < 16; ++db) *(float4_*)(w + db * 16 + 4 * lg) = o[db][qb];
       if (lg == 0) { w[VD] = m[qb]; w[VD + 1] = l; }
@@ -554,11 +565,11 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
 __global__ __launch_bounds__(256) void vlfuse_t2i_combine_kernel(T2IParams p) {
   const int lane = threadIdx.x & 63;
   const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long total = (long)p.B * VH * p.T;
+  const long total = (long)p.B * p.H * p.T;
   if (gw >= total) return;
   const int row = gw % p.T;
-  const int bh = gw / p.T, b = bh / VH, h = bh % VH;
-  half_t* dst = p.out + ((long)b * p.T + row) * (VH * VD) + h * VD + lane * 4;
+  const int bh = gw / p.T, b = bh / p.H, h = bh % p.H;
+  half_t* dst = p.out + ((long)b * p.T + row) * (p.H * VD) + h * VD + lane * 4;
   if (p.kv_len) {                                          // rows of skipped (all-padding) 16-row wave blocks: zeros
     const int kv = max(1, min(p.T, p.kv_len[b]));
     if ((row / p.wr) * p.wr >= kv) {
@@ -591,28 +602,37 @@ extern "C" long mq_vlfuse_t2i_workspace_bytes(int B, int T, int nsplit) {
 }
 
 // Text side of VLFuse (always through the split workspace + combine, nsplit >= 1).  See include/mqdet_hip.h.
-extern "C" int mq_vlfuse_t2i_fwd(const void* kf, const void* v_ln, const int* kv_len, void* workspace, void* out, int B, int N,
-                                 int T, int nsplit, float clamp, void* stream) {
+extern "C" int mq_vlfuse_t2i_fwd(const void* kf, const void* v_ln, const int* kv_len, const unsigned char* key_mask, long key_mask_bs,
+                                 void* workspace, void* out, int B, int N, int T, int heads, int nsplit, float clamp, void* stream) {
   if (B <= 0 || T <= 0) return 0;
-  if (N < 1 || workspace == nullptr) return -1;
+  if (N < 1 || workspace == nullptr || heads < 1 || heads > VH) return -1;
+  if (key_mask && ((key_mask_bs % 4) || key_mask_bs < (long)((N + TK - 1) / TK) * TK)) return -3;
   if (nsplit < 1) nsplit = 1;
   T2IParams p;
   p.kf = (const half_t*)kf; p.v = (const half_t*)v_ln; p.ws = (float*)workspace; p.out = (half_t*)out; p.kv_len = kv_len;
-  p.B = B; p.N = N; p.T = T; p.nsplit = nsplit; p.clamp = clamp; p.wr = 16 * vlfuse_qb();
+  p.B = B; p.N = N; p.T = T; p.H = heads; p.nsplit = nsplit; p.clamp = clamp; p.wr = 16 * vlfuse_qb();
+  p.kmask = key_mask; p.kmask_bs = key_mask_bs;
   constexpr size_t smem = (size_t)2 * TILE * sizeof(half_t);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)vlfuse_t2i_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)vlfuse_t2i_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)vlfuse_t2i_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)vlfuse_t2i_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)vlfuse_t2i_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)vlfuse_t2i_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  const int groups = B * nsplit, members = VH * ((T + BM - 1) / BM);
+  const int groups = B * nsplit, members = heads * ((T + BM - 1) / BM);
   const dim3 grid((unsigned)(8 * ((groups + 7) / 8) * members));
-  if (vlfuse_qb() == 1) hipLaunchKernelGGL(vlfuse_t2i_kernel<1>, grid, dim3(512), smem, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(vlfuse_t2i_kernel<2>, grid, dim3(256), smem, (hipStream_t)stream, p);
+  if (vlfuse_qb() == 1) {
+    if (key_mask) hipLaunchKernelGGL((vlfuse_t2i_kernel<1, true>), grid, dim3(512), smem, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((vlfuse_t2i_kernel<1, false>), grid, dim3(512), smem, (hipStream_t)stream, p);
+  } else {
+    if (key_mask) hipLaunchKernelGGL((vlfuse_t2i_kernel<2, true>), grid, dim3(256), smem, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((vlfuse_t2i_kernel<2, false>), grid, dim3(256), smem, (hipStream_t)stream, p);
+  }
   MQ_CHECK_LAUNCH();
-  const long total = (long)B * VH * T;
+  const long total = (long)B * heads * T;
   hipLaunchKernelGGL(vlfuse_t2i_combine_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
   MQ_CHECK_LAUNCH();
   return 0;

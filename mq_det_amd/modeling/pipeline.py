@@ -23,6 +23,68 @@ NEG = -1.0e30
 
 
 # ----------------------------------------------------------------------------- plan
+def _pack_swin(P, sd, SW, p, device, dtype):
+    """Swin inference tensors under prefix `p`: the relative-position bias gathered once (the reference re-gathers it every
+    call, swint.py:124-126) and padded to the kernel's window length; fc2 weights with permuted k-slots for the fused MLP."""
+    def h(name):
+        return sd[name].detach().to(device=device, dtype=dtype).contiguous()
+    ws = SW.WINDOW_SIZE
+    N = ws * ws
+    for i, (depth, heads) in enumerate(zip(SW.DEPTHS, SW.NUM_HEADS)):
+        for j in range(depth):
+            b = f"{p}.layers.{i}.blocks.{j}.attn"
+            idx = sd[b + ".relative_position_index"].to(device).reshape(-1)
+            rel = sd[b + ".relative_position_bias_table"].detach().to(device=device, dtype=torch.float32)[idx]
+            rel = rel.reshape(N, N, heads).permute(2, 0, 1)
+            NP = ops.window_pad(ws)                                                        # 64 (window 7) or 160 (window 12)
+            P[b + ".rel_bias"] = F.pad(rel, (0, NP - N, 0, NP - N)).contiguous()         # [heads, NP, NP], see ops.pad_rel_bias
+    # Swin MLP halves that run as one fused kernel (mq_swin_mlp_fwd): fc2.weight with the k-slots of every 32-block permuted
+    P["_swin_fused_mlp"] = bool(SW.get("FUSED_MLP", True)) and P["_r32"]
+    P["_swin_fused_widths"] = tuple(w for w in SW.get("FUSED_MLP_WIDTHS", ops.SWIN_MLP_WIDTHS) if w in ops.SWIN_MLP_WIDTHS)
+    for i, depth in enumerate(SW.DEPTHS):
+        Ci = SW.EMBED_DIM * 2 ** i
+        if P["_swin_fused_mlp"] and Ci in P["_swin_fused_widths"]:
+            perm = ops.swin_mlp_w2_perm(4 * Ci, device)
+            for j in range(depth):
+                b = f"{p}.layers.{i}.blocks.{j}.mlp.fc2"
+                P[b + ".w2p"] = h(b + ".weight")[:, perm].contiguous()
+    # patch embedding (4x4 stride-4 conv) as a GEMM over (kh, kw, c)-ordered patches
+    w = sd[p + ".patch_embed.proj.weight"].detach().to(device=device, dtype=torch.float32)
+    P[p + ".patch_embed.lin"] = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dtype).contiguous()
+
+
+def _pack_language(P, sd, cfg, p, device, dtype):
+    """BERT + GCP inference tensors under prefix `p`: fused q|k projections, gates folded, pre-select k / v split."""
+    def h(name):
+        return sd[name].detach().to(device=device, dtype=dtype).contiguous()
+
+    def f32(name):
+        return sd[name].detach().to(device=device, dtype=torch.float32).contiguous()
+    LB = cfg.MODEL.LANGUAGE_BACKBONE
+    nl = LB.get("NUM_HIDDEN_LAYERS", 12)
+    for i in range(nl):
+        _pack_bert_layer(P, sd, f"{p}.encoder.layer.{i}", device, dtype)
+    if cfg.VISION_QUERY.ENABLED:
+        qv0 = LB.get("QV_START", 6)
+        for i in range(nl - qv0):
+            b = f"{p}.encoder.qv_layer.{i}"
+            # tanh(ff_gate) folded into the last FFN projection (modeling_bert_new.py:373)
+            P[b + ".ff.linear2.gated"] = (f32(b + ".ff.linear2.weight") * torch.tanh(f32(b + ".ff_gate"))).to(dtype)
+            P[b + ".attn_gate.w2"] = h(b + ".attn_gate.linear2.weight").reshape(-1)
+        for i in range(2):
+            b = f"{p}.pre_select.layers.{i}.image_condition"
+            wkv = h(b + ".to_kv.weight")
+            half = wkv.shape[0] // 2
+            P[b + ".to_k.weight"], P[b + ".to_v.weight"] = wkv[:half].contiguous(), wkv[half:].contiguous()
+
+
+def _pack_bert_layer(P, sd, b, device, dtype):
+    def h(name):
+        return sd[name].detach().to(device=device, dtype=dtype).contiguous()
+    P[b + ".qk.weight"] = torch.cat([h(b + ".attention.self.query.weight"), h(b + ".attention.self.key.weight")], 0)
+    P[b + ".qk.bias"] = torch.cat([h(b + ".attention.self.query.bias"), h(b + ".attention.self.key.bias")], 0)
+
+
 def build_plan(sd, cfg, device, dtype=torch.float16):
     """Pack the fp32 state_dict into inference tensors: fp16 casts, fused / folded / re-laid-out weights."""
     P = {}
@@ -37,49 +99,15 @@ def build_plan(sd, cfg, device, dtype=torch.float16):
     for k, v in sd.items():
         if v.dtype.is_floating_point:
             P[k] = v.detach().to(device=device, dtype=dtype).contiguous()
-    # Swin: relative-position bias gathered once (reference re-gathers every call, swint.py:124-126)
-    ws = M.SWINT.WINDOW_SIZE
-    N = ws * ws
-    for i, (depth, heads) in enumerate(zip(M.SWINT.DEPTHS, M.SWINT.NUM_HEADS)):
-        for j in range(depth):
-            b = f"backbone.body.layers.{i}.blocks.{j}.attn"
-            idx = sd[b + ".relative_position_index"].to(device).reshape(-1)
-            rel = f32(b + ".relative_position_bias_table")[idx].reshape(N, N, heads).permute(2, 0, 1)
-            NP = ops.window_pad(ws)                                                        # 64 (window 7) or 160 (window 12)
-            P[b + ".rel_bias"] = F.pad(rel, (0, NP - N, 0, NP - N)).contiguous()         # [heads, NP, NP], see ops.pad_rel_bias
-    # Swin MLP halves that run as one fused kernel (mq_swin_mlp_fwd): fc2.weight with the k-slots of every 32-block permuted
-    P["_swin_fused_mlp"] = bool(M.SWINT.get("FUSED_MLP", True)) and P["_r32"]
-    P["_swin_fused_widths"] = tuple(w for w in M.SWINT.get("FUSED_MLP_WIDTHS", ops.SWIN_MLP_WIDTHS) if w in ops.SWIN_MLP_WIDTHS)
-    for i, depth in enumerate(M.SWINT.DEPTHS):
-        Ci = M.SWINT.EMBED_DIM * 2 ** i
-        if P["_swin_fused_mlp"] and Ci in P["_swin_fused_widths"]:
-            perm = ops.swin_mlp_w2_perm(4 * Ci, device)
-            for j in range(depth):
-                b = f"backbone.body.layers.{i}.blocks.{j}.mlp.fc2"
-                P[b + ".w2p"] = h(b + ".weight")[:, perm].contiguous()
+    _pack_swin(P, sd, M.SWINT, "backbone.body", device, dtype)
     # convs: channels_last weights
     for k in list(P):
         if torch.is_tensor(P[k]) and P[k].dim() == 4:
             P[k] = P[k].contiguous(memory_format=torch.channels_last)
-    # BERT layers: fused q|k projection
+    _pack_language(P, sd, cfg, "language_backbone.body.model", device, dtype)
+
     def bert(b):
-        P[b + ".qk.weight"] = torch.cat([h(b + ".attention.self.query.weight"), h(b + ".attention.self.key.weight")], 0)
-        P[b + ".qk.bias"] = torch.cat([h(b + ".attention.self.query.bias"), h(b + ".attention.self.key.bias")], 0)
-    nl = M.LANGUAGE_BACKBONE.get("NUM_HIDDEN_LAYERS", 12)
-    for i in range(nl):
-        bert(f"language_backbone.body.model.encoder.layer.{i}")
-    if cfg.VISION_QUERY.ENABLED:
-        qv0 = M.LANGUAGE_BACKBONE.get("QV_START", 6)
-        for i in range(nl - qv0):
-            b = f"language_backbone.body.model.encoder.qv_layer.{i}"
-            # tanh(ff_gate) folded into the last FFN projection (modeling_bert_new.py:373)
-            P[b + ".ff.linear2.gated"] = (f32(b + ".ff.linear2.weight") * torch.tanh(f32(b + ".ff_gate"))).to(dtype)
-            P[b + ".attn_gate.w2"] = h(b + ".attn_gate.linear2.weight").reshape(-1)
-        for i in range(2):
-            b = f"language_backbone.body.model.pre_select.layers.{i}.image_condition"
-            wkv = h(b + ".to_kv.weight")
-            half = wkv.shape[0] // 2
-            P[b + ".to_k.weight"], P[b + ".to_v.weight"] = wkv[:half].contiguous(), wkv[half:].contiguous()
+        _pack_bert_layer(P, sd, b, device, dtype)
     # VLDyHead
     D = M.DYHEAD
     hd = 2048 // 8
@@ -143,8 +171,6 @@ def build_plan(sd, cfg, device, dtype=torch.float16):
     # patch embedding (4x4 stride-4 conv) as a GEMM over (kh, kw, c)-ordered patches; box / centerness 1x1 convs of every
     # level as ONE [8, 256] GEMM weight (4 box rows with the level's Scale folded, 1 centerness row, 3 zero rows): no
     # MIOpen call is left on the path (its solver choice -- down to a naive kernel -- varies from box to box)
-    w = f32("backbone.body.patch_embed.proj.weight")
-    P["backbone.body.patch_embed.lin"] = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dtype).contiguous()
     for l in range(5):
         s = f32(f"rpn.head.scales.{l}.scale")
         wb = (f32("rpn.head.bbox_pred.weight") * s).reshape(4, -1)
@@ -188,12 +214,12 @@ def _nsplit(n_blocks, n_key_tiles, target=None):
 
 
 # ----------------------------------------------------------------------------- Swin + FPN
-def swin_forward(P, cfg, img):
-    """swint.py:591-615.  img [B,3,H,W] fp16 -> [c3, c4, c5] as NHWC tensors (c2 is never used by the FPN,
+def swin_forward(P, cfg, img, p="backbone.body", SW=None):
+    """swint.py:591-615 (and GroundingDINO's backbone/swin_transformer.py:688-741 with out_indices (1, 2, 3): same blocks,
+    same names under prefix `p`).  img [B,3,H,W] fp16 -> [c3, c4, c5] as NHWC tensors (c2 is never used by the FPN,
     fpn.py:82-84, so its output norm / layout change is skipped)."""
-    M = cfg.MODEL.SWINT
+    M = SW if SW is not None else cfg.MODEL.SWINT
     ws = M.WINDOW_SIZE
-    p = "backbone.body"
     _, _, H0, W0 = img.shape
     if W0 % 4 or H0 % 4:
         img = F.pad(img, (0, (4 - W0 % 4) % 4, 0, (4 - H0 % 4) % 4))
@@ -285,7 +311,7 @@ def pooled_fpn_tokens(feats):
 
 
 # ----------------------------------------------------------------------------- language backbone
-def bert_layer(P, b, x, key_bias, clamp, kv_len=None, x32=None):
+def bert_layer(P, b, x, key_bias, clamp, kv_len=None, x32=None, qk_mask=None):
     """HF BertLayer / rpn/modeling_bert.py:71-272 (clamp=True): QK^T, mask, softmax, PV in one HIP kernel.
     x [B,T,C] fp16 (GEMM operand); x32: the same hidden state unrounded (fp32 residual stream) or None.
     Returns y16 (and y32 when x32 is given)."""
@@ -295,7 +321,7 @@ def bert_layer(P, b, x, key_bias, clamp, kv_len=None, x32=None):
     vt = torch.baddbmm(P[b + ".attention.self.value.bias"][None, :, None], P[b + ".attention.self.value.weight"][None]
                        .expand(Bn, -1, -1), x.transpose(1, 2))                          # V^T [B, C, T]
     ctx = ops.attention(qk[:, :, :C], qk[:, :, C:], vt, 12, C // 12, key_bias=key_bias, clamp=50000.0 if clamp else 0.0,
-                        kv_len=kv_len)
+                        kv_len=kv_len, qk_mask=qk_mask)
     a = _add_ln(P, b + ".attention.output.LayerNorm", _lin(P, b + ".attention.output.dense", ctx), x32 if r32 else x, 1e-12,
                 want_sum=False, want_y32=r32)
     a16, a32 = a if r32 else (a, None)
@@ -357,38 +383,43 @@ def gcp_block(P, b, x, vision, idx, gates=None):
     return x + F.linear(F.gelu(F.linear(_ln(P, ff + ".norm", x), P[ff + ".linear1.weight"])), P[ff + ".linear2.gated"])
 
 
-def language_front(P, cfg, input_ids, attention_mask, use_vq):
+def language_front(P, cfg, input_ids, attention_mask, use_vq, p="language_backbone.body.model", position_ids=None, qk_mask=None):
     """Embeddings + the BERT layers that do not depend on the image (all 12 without vision queries, the first QV_START
-    with them): the detector runs this on a side stream while the Swin backbone occupies the main one."""
-    p = "language_backbone.body.model"
+    with them): the detector runs this on a side stream while the Swin backbone occupies the main one.
+    MQ-GroundingDINO (prefix "bert"): `position_ids` [B,T] restart in every sub-sentence and `qk_mask` [B,1|H,T,T] uint8 is the
+    block mask between special tokens (bertwarper.py:273-320); `attention_mask` is then None (no key-padding term: padding
+    tokens see only themselves, exactly as in the reference)."""
     LB = cfg.MODEL.LANGUAGE_BACKBONE
     T = input_ids.shape[1]
+    pe = P[p + ".embeddings.position_embeddings.weight"]
     e = P[p + ".embeddings.word_embeddings.weight"][input_ids].float() \
         + P[p + ".embeddings.token_type_embeddings.weight"][0].float() \
-        + P[p + ".embeddings.position_embeddings.weight"][:T].float()[None]
+        + (pe[:T].float()[None] if position_ids is None else pe[position_ids].float())
     x32 = F.layer_norm(e, (e.shape[-1],), P[p + ".embeddings.LayerNorm.weight"].float(),
                        P[p + ".embeddings.LayerNorm.bias"].float(), 1e-12)
     x = x32.to(P[p + ".embeddings.LayerNorm.weight"].dtype)
     if not P["_r32"]:
         x32 = None
-    key_bias = ((1.0 - attention_mask.float()) * NEG).contiguous()
-    # index of the last valid text token + 1: the attention kernels skip key tiles that hold padding only
-    kv_len = (attention_mask.to(torch.int32) * torch.arange(1, T + 1, device=attention_mask.device, dtype=torch.int32)) \
-        .amax(1).to(torch.int32).contiguous()
+    key_bias = kv_len = None
+    if attention_mask is not None:
+        key_bias = ((1.0 - attention_mask.float()) * NEG).contiguous()
+        # index of the last valid text token + 1: the attention kernels skip key tiles that hold padding only
+        kv_len = (attention_mask.to(torch.int32) * torch.arange(1, T + 1, device=attention_mask.device, dtype=torch.int32)) \
+            .amax(1).to(torch.int32).contiguous()
     nl, qv0 = LB.get("NUM_HIDDEN_LAYERS", 12), LB.get("QV_START", 6)
     n_front = qv0 if use_vq else nl
     hidden = []
     for i in range(n_front):
-        x, x32 = _bert(P, f"{p}.encoder.layer.{i}", x, x32, key_bias, False, kv_len)
+        x, x32 = _bert(P, f"{p}.encoder.layer.{i}", x, x32, key_bias, False, kv_len, qk_mask)
         hidden.append(x if x32 is None else x32)
-    return {"x": x, "x32": x32, "hidden": hidden, "key_bias": key_bias, "kv_len": kv_len, "next": n_front}
+    return {"x": x, "x32": x32, "hidden": hidden, "key_bias": key_bias, "kv_len": kv_len, "next": n_front, "qk_mask": qk_mask}
 
 
-def _bert(P, b, x, x32, key_bias, clamp, kv_len):
+def _bert(P, b, x, x32, key_bias, clamp, kv_len, qk_mask=None):
     """bert_layer on the (fp16 operand, fp32 stream or None) pair."""
     if x32 is None:
-        return bert_layer(P, b, x, key_bias, clamp, kv_len), None
-    return bert_layer(P, b, x, key_bias, clamp, kv_len, x32=x32)
+        return bert_layer(P, b, x, key_bias, clamp, kv_len, qk_mask=qk_mask), None
+    return bert_layer(P, b, x, key_bias, clamp, kv_len, x32=x32, qk_mask=qk_mask)
 
 
 def language_backbone(P, cfg, input_ids, attention_mask, vision, images, idx, want_gates=False, front=None):

@@ -16,13 +16,13 @@ _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 _SIGNATURES = {
     "mq_abi_version": (_i, []),
     "mq_attn_workspace_bytes": (_l, [_i, _i, _i, _i, _i]),
-    "mq_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _i, _vp]),
+    "mq_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _vp, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _i, _vp]),
     "mq_window_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_gcp_sparse_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_gcp_gate_residual_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _l, _i, _i, _vp]),
-    "mq_vlfuse_i2t_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "mq_vlfuse_i2t_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "mq_vlfuse_t2i_workspace_bytes": (_l, [_i, _i, _i]),
-    "mq_vlfuse_t2i_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "mq_vlfuse_t2i_fwd": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "mq_layernorm_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
     "mq_swin_mlp_fwd": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _l, _i, _vp]),
     "mq_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _vp]),
@@ -40,6 +40,7 @@ _SIGNATURES = {
     "mq_box_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _vp]),
     "mq_roi_align_fwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _f, _i, _i, _i, _vp]),
     "mq_msdeform_attn_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "mq_msdeform_attn_q_fwd": (_i, [_vp, _i, _l, _l, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_ml_nms_workspace_bytes": (_l, [_i, _i]),
     "mq_ml_nms": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
 }
@@ -128,10 +129,11 @@ def _need_gpu(*ts):
             raise RuntimeError("mq_det_amd ops need GPU tensors: the hot path has no CPU fallback")
 
 
-def attention4(q4, k4, vt4, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None, kv_len=None):
+def attention4(q4, k4, vt4, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None, kv_len=None, qk_mask=None):
     """General strided form.  q4 [B,Nq,H,D], k4 [B,Nk,H,D], vt4 [B,H,D,Nk_pad] fp16 views with unit last stride
     (a head stride of 0, e.g. from .expand(), shares the operand across heads); key_bias None, [B,Nk] or [B,H,Nk]
-    fp32.  Returns [B,Nq,H*D] fp16."""
+    fp32; qk_mask None or uint8 / bool [B,H,Nq,Nk] view (expand()-ed batch / head dims allowed), 1 = key hidden from query.
+    Returns [B,Nq,H*D] fp16."""
     lib = load_library()
     _need_gpu(q4, k4, vt4, key_bias, kv_len)
     B, Nq, H, D = q4.shape
@@ -150,12 +152,20 @@ def attention4(q4, k4, vt4, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=N
         else:
             assert key_bias.shape == (B, H, Nk)
             bias_bs, bias_hs = key_bias.stride(0), key_bias.stride(1)
+    mask_bs = mask_hs = mask_rs = 0
+    if qk_mask is not None:
+        _need_gpu(qk_mask)
+        if qk_mask.dtype == torch.bool:
+            qk_mask = qk_mask.view(torch.uint8)
+        assert qk_mask.dtype == torch.uint8 and qk_mask.shape == (B, H, Nq, Nk) and qk_mask.stride(3) == 1
+        mask_bs, mask_hs, mask_rs = qk_mask.stride(0), qk_mask.stride(1), qk_mask.stride(2)
     o = torch.empty(B, Nq, H * D, dtype=torch.float16, device=q4.device)
     ws = None
     if nsplit > 1:
         ws = torch.empty(lib.mq_attn_workspace_bytes(B, H, Nq, D, nsplit) // 4, dtype=torch.float32, device=q4.device)
     with _timed(f"attn_d{D}_nq{Nq}_nk{Nk}_s{nsplit}"):
-        rc = lib.mq_attn_fwd(_ptr(q4), _ptr(k4), _ptr(vt4), _ptr(o), _ptr(key_bias), _ptr(kv_len), _ptr(ws), B, H, Nq, Nk, D,
+        rc = lib.mq_attn_fwd(_ptr(q4), _ptr(k4), _ptr(vt4), _ptr(o), _ptr(key_bias), _ptr(kv_len), _ptr(qk_mask), mask_bs, mask_hs,
+                             mask_rs, _ptr(ws), B, H, Nq, Nk, D,
                              q4.stride(0), q4.stride(1), q4.stride(2), k4.stride(0), k4.stride(1), k4.stride(2),
                              vt4.stride(0), vt4.stride(2), vt4.stride(1), o.stride(0), o.stride(1), bias_bs, bias_hs,
                              float(scale if scale is not None else 1.0 / math.sqrt(D)), float(clamp), int(nsplit), _stream())
@@ -163,7 +173,7 @@ def attention4(q4, k4, vt4, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=N
     return o
 
 
-def attention(q, k, vt, num_heads, head_dim, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None, kv_len=None):
+def attention(q, k, vt, num_heads, head_dim, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None, kv_len=None, qk_mask=None):
     """q [B,Nq,H*D], k [B,Nk,H*D], vt [B,H*D,Nk_pad] (V transposed, Nk_pad % 8 == 0) fp16 -> [B,Nq,H*D] fp16."""
     B, Nq, HD = q.shape
     H, D = num_heads, head_dim
@@ -172,7 +182,7 @@ def attention(q, k, vt, num_heads, head_dim, key_bias=None, scale=None, clamp=0.
     q4 = q.as_strided((B, Nq, H, D), (q.stride(0), q.stride(1), D, 1), q.storage_offset())
     k4 = k.as_strided((B, k.shape[1], H, D), (k.stride(0), k.stride(1), D, 1), k.storage_offset())
     vt4 = vt.as_strided((B, H, D, vt.shape[2]), (vt.stride(0), D * vt.stride(1), vt.stride(1), 1), vt.storage_offset())
-    return attention4(q4, k4, vt4, key_bias, scale, clamp, nsplit, nk, kv_len)
+    return attention4(q4, k4, vt4, key_bias, scale, clamp, nsplit, nk, kv_len, qk_mask)
 
 
 def window_pad(ws):
@@ -243,45 +253,59 @@ def gcp_gate_residual(sup, h, w2, x, want_gate=False):
 
 
 def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.0):
-    """VLFuse image side (mq_vlfuse_i2t_fwd).  v_ln [B,N,256], kf / vo [B,8,T,256] fp16, bias [B,8,T] fp32 or None,
+    """VLFuse image side (mq_vlfuse_i2t_fwd).  v_ln [B,N,256], kf / vo [B,heads,T,256] fp16 (heads <= 8), bias [B,heads,T] fp32 or None,
     out_bias [256] fp16, kv_len [B] int32 or None (max_kv: host-side upper bound, 0 = T) -> [B,N,256] fp16:
     v_ln + out_bias + sum_h softmax_t(clamp(v_ln.kf_h + bias_h)) vo_h."""
     lib = load_library()
     _need_gpu(v_ln, kf, vo, out_bias)
     B, N, C = v_ln.shape
-    T = kf.shape[2]
-    assert C == 256 and kf.shape == (B, 8, T, 256) and vo.shape == kf.shape and T <= 256
+    Hh, T = kf.shape[1], kf.shape[2]
+    assert C == 256 and kf.shape == (B, Hh, T, 256) and vo.shape == kf.shape and T <= 256 and 1 <= Hh <= 8
     assert v_ln.is_contiguous() and kf.is_contiguous() and vo.is_contiguous() and out_bias.is_contiguous()
     assert v_ln.dtype == kf.dtype == vo.dtype == out_bias.dtype == torch.float16
     if bias is not None:
-        assert bias.shape == (B, 8, T) and bias.dtype == torch.float32 and bias.is_contiguous()
+        assert bias.shape == (B, Hh, T) and bias.dtype == torch.float32 and bias.is_contiguous()
     if kv_len is not None:
         assert kv_len.dtype == torch.int32 and kv_len.numel() == B and kv_len.is_contiguous()
     out = torch.empty_like(v_ln)
     with _timed(f"vlfuse_i2t_n{N}_t{T}"):
         _chk(lib.mq_vlfuse_i2t_fwd(_ptr(v_ln), _ptr(kf), _ptr(vo), _ptr(bias), _ptr(kv_len), _ptr(out_bias), _ptr(out),
-                                   B, N, T, int(max_kv), float(clamp), _stream()), "mq_vlfuse_i2t_fwd")
+                                   B, N, T, Hh, int(max_kv), float(clamp), _stream()), "mq_vlfuse_i2t_fwd")
     return out
 
 
-def vlfuse_t2i(kf, v_ln, nsplit, clamp=50000.0, kv_len=None):
-    """VLFuse text side (mq_vlfuse_t2i_fwd).  kf [B,8,T,256] (queries), v_ln [B,N,256] (keys = values) fp16
-    -> [B,T,8*256] fp16 = softmax_n(clamp(kf.v_ln)) v_ln per head.  kv_len [B] int32: 128-row tiles of pure padding
-    (rows >= kv_len[b]) are skipped and returned as zeros."""
+def vlfuse_t2i(kf, v_ln, nsplit, clamp=50000.0, kv_len=None, key_mask=None):
+    """VLFuse text side (mq_vlfuse_t2i_fwd).  kf [B,heads,T,256] (queries), v_ln [B,N,256] (keys = values) fp16
+    -> [B,T,heads*256] fp16 = softmax_n(clamp(kf.v_ln)) v_ln per head.  kv_len [B] int32: 128-row tiles of pure padding
+    (rows >= kv_len[b]) are skipped and returned as zeros.  key_mask uint8 [B, >= 64*ceil(N/64)] (row stride % 4 == 0):
+    1 = image token is padding (see image_key_mask)."""
     lib = load_library()
-    _need_gpu(kf, v_ln)
+    _need_gpu(kf, v_ln, key_mask)
     B, N, C = v_ln.shape
-    T = kf.shape[2]
-    assert C == 256 and kf.shape == (B, 8, T, 256) and kf.is_contiguous() and v_ln.is_contiguous()
+    Hh, T = kf.shape[1], kf.shape[2]
+    assert C == 256 and kf.shape == (B, Hh, T, 256) and kf.is_contiguous() and v_ln.is_contiguous() and 1 <= Hh <= 8
+    km_bs = 0
+    if key_mask is not None:
+        assert key_mask.dtype == torch.uint8 and key_mask.dim() == 2 and key_mask.shape[0] == B and key_mask.stride(1) == 1
+        km_bs = key_mask.stride(0)
+        assert km_bs % 4 == 0 and key_mask.shape[1] >= -(-N // 64) * 64
     assert kf.dtype == v_ln.dtype == torch.float16
     nsplit = max(1, int(nsplit))
     if kv_len is not None:
         assert kv_len.dtype == torch.int32 and kv_len.numel() == B and kv_len.is_contiguous()
     ws = torch.empty(lib.mq_vlfuse_t2i_workspace_bytes(B, T, nsplit) // 4, dtype=torch.float32, device=kf.device)
-    out = torch.empty(B, T, 8 * 256, dtype=torch.float16, device=kf.device)
+    out = torch.empty(B, T, Hh * 256, dtype=torch.float16, device=kf.device)
     with _timed(f"vlfuse_t2i_n{N}_t{T}_s{nsplit}"):
-        _chk(lib.mq_vlfuse_t2i_fwd(_ptr(kf), _ptr(v_ln), _ptr(kv_len), _ptr(ws), _ptr(out), B, N, T, nsplit, float(clamp), _stream()),
-             "mq_vlfuse_t2i_fwd")
+        _chk(lib.mq_vlfuse_t2i_fwd(_ptr(kf), _ptr(v_ln), _ptr(kv_len), _ptr(key_mask), km_bs, _ptr(ws), _ptr(out), B, N, T, Hh,
+                                   nsplit, float(clamp), _stream()), "mq_vlfuse_t2i_fwd")
+    return out
+
+
+def image_key_mask(mask):
+    """bool [B, N] (True = padding token) -> the uint8 [B, 64*ceil(N/64)] layout mq_vlfuse_t2i_fwd reads with 4-byte loads."""
+    B, N = mask.shape
+    out = torch.ones(B, -(-N // 64) * 64, dtype=torch.uint8, device=mask.device)
+    out[:, :N] = mask.to(torch.uint8)
     return out
 
 
@@ -597,12 +621,7 @@ def ms_deform_attn(value, spatial_shapes, sampling_locations, attention_weights,
     assert value.is_contiguous() and value.dtype in (torch.float16, torch.float32)
     assert sampling_locations.dtype == attention_weights.dtype == torch.float32
     assert sampling_locations.is_contiguous() and attention_weights.is_contiguous() and attention_weights.shape == (B, Q, M, L, P)
-    key = (shapes, value.device)
-    if key not in _MSDA_SHAPES:                   # [L, 2] (H, W) and level start indices as int64 device tensors, cached
-        hw = torch.tensor(shapes, dtype=torch.int64)
-        start = torch.cat([hw.new_zeros(1), (hw[:, 0] * hw[:, 1]).cumsum(0)[:-1]])
-        _MSDA_SHAPES[key] = (hw.to(value.device), start.to(value.device))
-    hw, start = _MSDA_SHAPES[key]
+    hw, start = _msda_shapes(shapes, value.device)
     out_dtype = out_dtype or value.dtype
     out = torch.empty(B, Q, M * D, dtype=out_dtype, device=value.device)
     nb = value.numel() * value.element_size() + sampling_locations.numel() * 4 + attention_weights.numel() * 4 + out.numel() * out.element_size()
@@ -610,6 +629,41 @@ def ms_deform_attn(value, spatial_shapes, sampling_locations, attention_weights,
         _chk(lib.mq_msdeform_attn_fwd(_ptr(value), int(value.dtype == torch.float32), _ptr(hw), _ptr(start), _ptr(sampling_locations),
                                       _ptr(attention_weights), _ptr(out), int(out_dtype == torch.float32), B, S, M, D, L, Q, P, _stream()),
              "mq_msdeform_attn_fwd")
+    return out
+
+
+def _msda_shapes(shapes, device):
+    key = (shapes, device)
+    if key not in _MSDA_SHAPES:                   # [L, 2] (H, W) and level start indices as int64 device tensors, cached
+        hw = torch.tensor(shapes, dtype=torch.int64)
+        start = torch.cat([hw.new_zeros(1), (hw[:, 0] * hw[:, 1]).cumsum(0)[:-1]])
+        _MSDA_SHAPES[key] = (hw.to(device), start.to(device))
+    return _MSDA_SHAPES[key]
+
+
+def ms_deform_attn_q(value, spatial_shapes, qproj, ref, heads, out_dtype=None):
+    """Fused-query form (mq_msdeform_attn_q_fwd).  value [B,S,>=heads*D] fp16 / fp32 view with unit channel stride (token /
+    batch strides free: a column slice of a wider projection is fine), qproj [B,Q,heads*16*3] fp16 contiguous =
+    [offsets | logits] of the fused projection, ref [B,Q,4,2|4] fp32 contiguous -> [B,Q,heads*D]."""
+    lib = load_library()
+    _need_gpu(value, qproj, ref)
+    B, S, C = value.shape
+    D = C // heads
+    Q = qproj.shape[1]
+    shapes = tuple((int(h), int(w)) for h, w in spatial_shapes)
+    L, P = len(shapes), 4
+    assert sum(h * w for h, w in shapes) == S and value.stride(2) == 1 and value.dtype in (torch.float16, torch.float32)
+    assert qproj.dtype == torch.float16 and qproj.is_contiguous() and qproj.shape == (B, Q, heads * L * P * 3)
+    assert ref.dtype == torch.float32 and ref.is_contiguous() and ref.shape[:3] == (B, Q, L) and ref.shape[3] in (2, 4)
+    hw, start = _msda_shapes(shapes, value.device)
+    out_dtype = out_dtype or value.dtype
+    out = torch.empty(B, Q, C, dtype=out_dtype, device=value.device)
+    nb = B * S * C * value.element_size() + qproj.numel() * 2 + ref.numel() * 4 + out.numel() * out.element_size()
+    with _timed(f"msdeform_attn_q{Q}", nb):
+        _chk(lib.mq_msdeform_attn_q_fwd(_ptr(value), int(value.dtype == torch.float32), value.stride(0), value.stride(1), _ptr(hw),
+                                        _ptr(start), _ptr(qproj), _ptr(ref), ref.shape[3], _ptr(out),
+                                        int(out_dtype == torch.float32), B, S, heads, D, L, Q, P, _stream()),
+             "mq_msdeform_attn_q_fwd")
     return out
 
 

@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 
-def attention(q, k, vt, num_heads, head_dim, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None, kv_len=None):
+def attention(q, k, vt, num_heads, head_dim, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None, kv_len=None, qk_mask=None):
     B, Nq, HD = q.shape
     Nk = k.shape[1] if nk is None else nk
     H, D = num_heads, head_dim
@@ -25,6 +25,9 @@ def attention(q, k, vt, num_heads, head_dim, key_bias=None, scale=None, clamp=0.
         s = s.clamp(-clamp, clamp)
     if key_bias is not None:
         s = s + key_bias[:, None, None, :]
+    if qk_mask is not None:
+        assert qk_mask.shape == (B, H, Nq, Nk) and qk_mask.dtype in (torch.bool, torch.uint8)
+        s = s.masked_fill(qk_mask.bool(), -1e30)
     return (s.softmax(-1) @ vh).transpose(1, 2).reshape(B, Nq, HD).to(q.dtype)
 
 
@@ -292,7 +295,7 @@ def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.
     B, N, C = v_ln.shape
     T = kf.shape[2]
     s = torch.einsum("bnc,bhtc->bhnt", v_ln.float(), kf.float())
-    masked = torch.zeros(B, 8, T, dtype=torch.bool)
+    masked = torch.zeros(B, kf.shape[1], T, dtype=torch.bool)
     if bias is not None:
         masked = bias < -1e29
         s = s + torch.where(masked, torch.zeros_like(bias), bias)[:, :, None, :]
@@ -307,17 +310,20 @@ def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.
     return (v_ln.float() + out_bias.float() + o).to(v_ln.dtype)
 
 
-def vlfuse_t2i(kf, v_ln, nsplit, clamp=50000.0, kv_len=None):
+def vlfuse_t2i(kf, v_ln, nsplit, clamp=50000.0, kv_len=None, key_mask=None):
     B, N, C = v_ln.shape
     T = kf.shape[2]
     s = torch.einsum("bhtc,bnc->bhtn", kf.float(), v_ln.float())
     if clamp > 0:
         s = s.clamp(-clamp, clamp)
+    if key_mask is not None:
+        assert key_mask.dtype == torch.uint8 and key_mask.shape[1] >= -(-N // 64) * 64 and key_mask.stride(0) % 4 == 0
+        s = s.masked_fill(key_mask[:, None, None, :N].bool(), -1e30)
     o = torch.einsum("bhtn,bnc->bthc", s.softmax(-1), v_ln.float())
     if kv_len is not None:                      # 16-row blocks of pure padding come back as zeros
         dead = (torch.arange(T)[None, :] // 16) * 16 >= kv_len.clamp(1, T)[:, None]
         o = o.masked_fill(dead[:, :, None, None], 0.0)
-    return o.reshape(B, T, 8 * C).to(kf.dtype)
+    return o.reshape(B, T, kf.shape[1] * C).to(kf.dtype)
 
 
 def roi_align(feat, rois, output_size, spatial_scale, sampling_ratio, aligned=True, reduce_mean=False):
@@ -349,6 +355,28 @@ def ms_deform_attn(value, spatial_shapes, sampling_locations, attention_weights,
     from oracle.gdino import ms_deform_attn_core
     out = ms_deform_attn_core(value.float(), spatial_shapes, sampling_locations.float(), attention_weights.float())
     return out.to(out_dtype or value.dtype)
+
+
+def image_key_mask(mask):
+    from mq_det_amd.ops import image_key_mask as f
+    return f(mask)
+
+
+def ms_deform_attn_q(value, spatial_shapes, qproj, ref, heads, out_dtype=None):
+    """Plain-torch statement of mq_msdeform_attn_q_fwd: softmax + sampling locations, then the unfused emulation."""
+    B, S, C = value.shape
+    Q, L, P = qproj.shape[1], len(spatial_shapes), 4
+    n = heads * L * P
+    qp = qproj.float()
+    off = qp[..., :2 * n].reshape(B, Q, heads, L, P, 2)
+    aw = qp[..., 2 * n:].reshape(B, Q, heads, L * P).softmax(-1).reshape(B, Q, heads, L, P)
+    if ref.shape[-1] == 2:
+        norm = torch.tensor([[w, h] for h, w in spatial_shapes], dtype=torch.float32)
+        loc = ref[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    else:
+        loc = ref[:, :, None, :, None, :2] + off / P * ref[:, :, None, :, None, 2:] * 0.5
+    return ms_deform_attn(value.reshape(B, S, heads, C // heads).contiguous(), spatial_shapes, loc.contiguous(), aw.contiguous(),
+                          out_dtype)
 
 
 def dyconv_coef_group(items, attn_w, attn_b, groups, eps):
