@@ -302,10 +302,13 @@ def decoder_layer(sd, p, tgt, query_pos, ref_input, memory_text, text_pad_mask, 
     return _ln(sd, p + ".norm3", tgt + h)
 
 
-def transformer(sd, spec, srcs, masks, poss, text):
+def transformer(sd, spec, srcs, masks, poss, text, topk_override=None):
     """Transformer.forward (transformer.py:211-400), two_stage_type 'standard', embed_init_tgt.  srcs / poss: per level
     [B,C,H,W]; masks: per level [B,H,W]; text: dict(encoded_text [B,T,C], text_token_mask [B,T] bool True = real token,
-    position_ids [B,T], text_self_attention_masks [B,T,T]).  Returns a dict of every stage."""
+    position_ids [B,T], text_self_attention_masks [B,T,T]).  Returns a dict of every stage.
+    topk_override [B, nq] (tests only): decode THESE proposals instead of the oracle's own top-k (kept as `topk_own`) -- the
+    selection is discontinuous and rank-dependent (query slot r gets tgt_embed[r]), so a device implementation is compared
+    downstream of it on identical selections, and on the selection itself as a set."""
     t = "transformer"
     shapes = [tuple(s.shape[-2:]) for s in srcs]
     src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
@@ -334,6 +337,9 @@ def transformer(sd, spec, srcs, masks, poss, text):
     cls = contrastive_embed(omem, mtext, text["text_token_mask"], spec.max_text_len)
     coord = _mlp(sd, t + ".enc_out_bbox_embed", omem, 3) + props
     topk = torch.topk(cls.max(-1)[0], spec.num_queries, dim=1)[1]
+    out["topk_own"], out["topk_logits"] = topk, cls.max(-1)[0]
+    if topk_override is not None:
+        topk = topk_override
     refpoint = torch.gather(coord, 1, topk[..., None].repeat(1, 1, 4))
     out["topk"] = topk
     out["init_box"] = torch.gather(props, 1, topk[..., None].repeat(1, 1, 4)).sigmoid()
@@ -382,7 +388,7 @@ def convert_to_glip_output(prob, boxes, positive_map, image_sizes, num_classes, 
     return res
 
 
-def forward(sd, spec, images, image_sizes, input_ids, attention_mask, positive_map, special_ids, bank=None):
+def forward(sd, spec, images, image_sizes, input_ids, attention_mask, positive_map, special_ids, bank=None, topk_override=None):
     """GroundingDINO.forward, eval (groundingdino.py:438-623).  images [B,3,H,W] padded (ImageList.tensors), image_sizes
     [(h, w)], input_ids / attention_mask [B, Ttok] = the tokenizer's output with padding='max_length' (cut to max_text_len
     here like :530-537), special_ids = ids of [CLS], [SEP], '.', '?' (:194).  Returns a dict with every stage and `detections`."""
@@ -417,7 +423,7 @@ def forward(sd, spec, images, image_sizes, input_ids, attention_mask, positive_m
     text = {"encoded_text": _lin(sd, "feat_map", hidden[-1]), "text_token_mask": tok_mask, "position_ids": position_ids,
             "text_self_attention_masks": self_masks}
     out["encoded_text"] = text["encoded_text"]
-    out.update(transformer(sd, spec, srcs, masks, poss, text))
+    out.update(transformer(sd, spec, srcs, masks, poss, text, topk_override))
     # ---- heads of the last decoder layer (groundingdino.py:585-604,641-642)
     hs, refs = out["hs"], out["refs"]
     out["pred_boxes"] = (_mlp(sd, f"bbox_embed.{spec.dec_layers - 1}", hs[-1], 3) + inverse_sigmoid(refs[-2])).sigmoid()

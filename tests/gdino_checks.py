@@ -1,0 +1,287 @@
+"""MQ-GroundingDINO: HIP path vs CPU oracle (run on the GPU box; used by tests/test_gpu_parity.py and tests/gpu_diag.py).
+
+Tolerances follow tests/parity_checks.py: 2e-3 (normalised by max(1, |ref|max)) for single kernels on the same fp16 inputs;
+stated per stage for the model (fp16 MFMA operands vs the fp32 oracle, see DESIGN.md "fp16-operand floor").  The query selection
+(top-k of ~22 k proposals) and the 0.05 score threshold are discontinuous: selected sets are compared as sets with a small
+allowance for candidates that sit on the cut, every common element must then agree numerically."""
+import os
+
+import torch
+import torch.nn.functional as F
+
+from parity_checks import _stat
+
+_CACHE = {}
+
+
+# ------------------------------------------------------------------------------------------------ kernels
+def check_attention_qk_mask(dev):
+    """mq_attn_fwd with the per-(query, key) byte mask: sub-sentence block masks (BERT 12 x 64, text enhancer 4 x 64 with the
+    per-head batch quirk), combined with a key bias; also the decoder shapes (8 x 32, 900 queries; text cross-attention)."""
+    import ops_emulation as emu
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(77)
+    res = []
+    for B, H, D, T, per_head in ((2, 12, 64, 256, False), (3, 4, 64, 256, True), (1, 4, 64, 100, False)):
+        q, k, v = (torch.randn(B, T, H * D, generator=g).half() for _ in range(3))
+        blocks = torch.randint(0, 9, (B, H if per_head else 1, T), generator=g).cumsum(-1) // 12   # random sub-sentences
+        mask = (blocks[..., :, None] != blocks[..., None, :])
+        mask = mask if per_head else mask.expand(B, H, T, T)
+        pad = (-T) % 8
+        vt = F.pad(v, (0, 0, 0, pad)).transpose(1, 2).contiguous()
+        ref = emu.attention(q.float(), k.float(), vt.float(), H, D, nk=T, qk_mask=mask)
+        md = mask.to(torch.uint8).to(dev) if per_head else mask[:, :1].to(torch.uint8).to(dev).expand(B, H, T, T)
+        got = ops.attention(q.to(dev), k.to(dev), vt.to(dev), H, D, nk=T, qk_mask=md)
+        res.append(_stat(f"attn qk_mask B={B} H={H} D={D} T={T} per_head={per_head}", got, ref))
+    # decoder: self-attention over 900 queries, text cross-attention with key padding
+    B, H, D, Nq = 2, 8, 32, 900
+    q, k, v = (torch.randn(B, Nq, H * D, generator=g).half() for _ in range(3))
+    vt = F.pad(v, (0, 0, 0, (-Nq) % 8)).transpose(1, 2).contiguous()
+    ref = emu.attention(q.float(), k.float(), vt.float(), H, D, nk=Nq)
+    got = ops.attention(q.to(dev), k.to(dev), vt.to(dev), H, D, nk=Nq)
+    res.append(_stat("attn decoder self-attention 8 x 32, 900 queries", got, ref))
+    T = 256
+    kt, vtx = torch.randn(B, T, 6 * H * D, generator=g).half(), torch.randn(B, 6 * H * D, T, generator=g).half()
+    kb = torch.zeros(B, T)
+    kb[0, 31:] = -1e30
+    kb[1, 200:] = -1e30
+    kl = torch.tensor([31, 200], dtype=torch.int32)
+    i = 3                                                       # layer slice of the batched text projections
+    ref = emu.attention(q.float(), kt[..., i * 256:(i + 1) * 256].float(), vtx[:, i * 256:(i + 1) * 256].float(), H, D, key_bias=kb)
+    ktd, vtd = kt.to(dev), vtx.to(dev)
+    got = ops.attention(q.to(dev), ktd[..., i * 256:(i + 1) * 256], vtd[:, i * 256:(i + 1) * 256], H, D, key_bias=kb.to(dev),
+                        kv_len=kl.to(dev))
+    res.append(_stat("attn decoder text cross-attention (strided K / V^T slices, kv_len)", got, ref))
+    return res
+
+
+def check_vlfuse_heads_mask(dev):
+    """VLFuse kernels with 4 heads (GroundingDINO fusion) and the image padding mask on the text side."""
+    import ops_emulation as emu
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(78)
+    res = []
+    for B, N, T, kv, ns in ((2, 3000, 256, [40, 256], 3), (1, 22323, 256, [141], 8), (3, 426, 64, None, 1)):
+        Hh = 4
+        v_ln = torch.randn(B, N, 256, generator=g).half()
+        kf = (torch.randn(B, Hh, T, 256, generator=g) / 8).half()
+        vo = torch.randn(B, Hh, T, 256, generator=g).half()
+        bias = torch.randn(B, Hh, T, generator=g)
+        ob = torch.randn(256, generator=g).half()
+        kv_len = None if kv is None else torch.tensor(kv, dtype=torch.int32)
+        ref = emu.vlfuse_i2t(v_ln.float(), kf.float(), vo.float(), bias, ob.float(), kv_len, 0)
+        got = ops.vlfuse_i2t(v_ln.to(dev), kf.to(dev), vo.to(dev), bias.to(dev), ob.to(dev), None if kv is None else kv_len.to(dev),
+                             max_kv=0 if kv is None else max(kv))
+        res.append(_stat(f"vlfuse image side, 4 heads B={B} N={N} T={T} kv_len={kv}", got, ref))
+        mask = torch.zeros(B, N, dtype=torch.bool)
+        for b in range(B):                                       # padded right columns + bottom rows of a 2-level pyramid
+            w = 61
+            cols = torch.arange(N) % w
+            mask[b] = (cols >= w - 3 - 5 * b) | (torch.arange(N) >= N - 200 * (b + 1)) | ((torch.arange(N) >= 64) & (torch.arange(N) < 192) & (b == 0))
+        km = ops.image_key_mask(mask.to(dev))
+        ref = emu.vlfuse_t2i(kf.float(), v_ln.float(), ns, kv_len=kv_len, key_mask=ops.image_key_mask(mask))
+        got = ops.vlfuse_t2i(kf.to(dev), v_ln.to(dev), ns, kv_len=None if kv is None else kv_len.to(dev), key_mask=km)
+        res.append(_stat(f"vlfuse text side, 4 heads + image key mask B={B} N={N} T={T} nsplit={ns} kv_len={kv}", got, ref))
+        ref = emu.vlfuse_t2i(kf.float(), v_ln.float(), ns, kv_len=kv_len)
+        got = ops.vlfuse_t2i(kf.to(dev), v_ln.to(dev), ns, kv_len=None if kv is None else kv_len.to(dev))
+        res.append(_stat(f"vlfuse text side, 4 heads, no mask B={B} N={N} T={T} nsplit={ns}", got, ref))
+    return res
+
+
+def check_msdeform_attn_q(dev):
+    """mq_msdeform_attn_q_fwd (softmax + sampling locations in registers, strided value) vs the unfused kernel fed with
+    torch-built fp32 locations / weights from the SAME fp16 projection, and vs the oracle's restatement of the module."""
+    import ops_emulation as emu
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(79)
+    res = []
+    shapes = [(100, 168), (50, 84), (25, 42), (13, 21)]
+    S = sum(h * w for h, w in shapes)
+    for B, Q, nd, slices in ((1, S, 2, 1), (2, 900, 4, 6), (1, 37, 4, 1)):
+        M, D = 8, 32
+        val_all = torch.randn(B, S, slices * M * D, generator=g).half()
+        qp = torch.cat([torch.randn(B, Q, M * 16 * 2, generator=g) * 2.0, torch.randn(B, Q, M * 16, generator=g)], -1).half()
+        ref_pts = torch.rand(B, Q, 4, nd, generator=g)
+        if nd == 4:
+            ref_pts[..., 2:] = ref_pts[..., 2:] * 0.3 + 0.02
+        i = slices // 2
+        vd = val_all.to(dev)
+        got = ops.ms_deform_attn_q(vd[..., i * M * D:(i + 1) * M * D], shapes, qp.to(dev), ref_pts.to(dev), M)
+        ref = emu.ms_deform_attn_q(val_all[..., i * M * D:(i + 1) * M * D].float(), shapes, qp.float(), ref_pts, M)
+        res.append(_stat(f"msdeform fused query side B={B} Q={Q} ref_dim={nd} value slice {i}/{slices} vs oracle core", got, ref, tol=2e-3))
+        # the unfused kernel on locations / weights built in torch from the same fp16 projection
+        n = M * 16
+        q32 = qp.float()
+        off = q32[..., :2 * n].reshape(B, Q, M, 4, 4, 2)
+        aw = q32[..., 2 * n:].reshape(B, Q, M, 16).softmax(-1).reshape(B, Q, M, 4, 4)
+        if nd == 2:
+            norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32)
+            loc = ref_pts[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+        else:
+            loc = ref_pts[:, :, None, :, None, :2] + off / 4 * ref_pts[:, :, None, :, None, 2:] * 0.5
+        v = val_all[..., i * M * D:(i + 1) * M * D].reshape(B, S, M, D).contiguous()
+        unf = ops.ms_deform_attn(v.to(dev), shapes, loc.contiguous().to(dev), aw.contiguous().to(dev))
+        res.append(_stat(f"msdeform fused vs unfused kernel B={B} Q={Q} ref_dim={nd}", got, unf, tol=2e-3))
+    return res
+
+
+# ------------------------------------------------------------------------------------------------ model
+def _tokenizer_dir(vocab):
+    import tempfile
+    from mq_det_amd.utils.tokenizer import build_synthetic_tokenizer
+    key = ("tok", vocab)
+    if key not in _CACHE:
+        _CACHE[key] = build_synthetic_tokenizer(tempfile.mkdtemp(), size=vocab)
+    return _CACHE[key]
+
+
+def gdino_model(dev, spec, seed=0):
+    """Product module (reference API) + the oracle's seeded state_dict, loaded strict."""
+    from test_gdino_glue_cpu import gdino_cfg
+    from mq_det_amd.modeling.detector import build_detection_model
+    from oracle.weights import make_gdino_state_dict
+    key = ("model", spec, seed)
+    if key not in _CACHE:
+        sd = make_gdino_state_dict(spec, seed=seed)
+        cfg = gdino_cfg(spec, _tokenizer_dir(spec.vocab))
+        model = build_detection_model(cfg)
+        model.load_state_dict(sd, strict=True)
+        model.to(dev)
+        _CACHE[key] = (sd, cfg, model)
+    return _CACHE[key]
+
+
+def _caption(n_classes, words=(1, 2, 3)):
+    from mq_det_amd.utils.tokenizer import synthetic_caption
+    return synthetic_caption(n_classes, words=words)
+
+
+def _iou(a, b):
+    lt, br = torch.max(a[:, None, :2], b[None, :, :2]), torch.min(a[:, None, 2:], b[None, :, 2:])
+    inter = (br - lt + 1).clamp(min=0).prod(-1)
+    aa = (a[:, 2] - a[:, 0] + 1) * (a[:, 3] - a[:, 1] + 1)
+    ab = (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1)
+    return inter / (aa[:, None] + ab[None] - inter)
+
+
+def check_gdino_model(dev, vq=True, B=1, hw=((120, 150),), spec=None, n_classes=10, tols=None, graph=True):
+    """Whole model through the product's reference API (tokenizer, sub-sentence masks, vision queries, HIP graph replay) vs
+    the oracle, stage by stage.  Default: the shallow model at the fixture's size; spec = gdino_t_spec() + hw = 800 x 1333 is
+    the BASELINE configs[4] shape (full depth, 900 queries)."""
+    from dataclasses import replace
+    from oracle import gdino as og
+    from oracle.spec import tiny_gdino_spec
+    from oracle.weights import make_query_bank
+    from mq_det_amd.structures import to_image_list
+    from mq_det_amd.utils.tokenizer import positive_map_from_spans
+    spec = replace(spec or tiny_gdino_spec(), vision_query=vq)
+    sd, cfg, model = gdino_model(dev, replace(spec, vision_query=True))
+    cfg.VISION_QUERY.ENABLED = vq
+    T = dict(swin=5e-3, srcs=1e-2, bert=3e-2, text=3e-2, memory=5e-2, hs=6e-2, refs=2e-2, logits=5e-2, boxes=2e-2)
+    T.update(tols or {})
+    caption, spans = _caption(n_classes)
+    labels = list(range(1, n_classes + 1))
+    pmap = positive_map_from_spans(model.tokenizer, caption + ".", spans, labels)
+    bank = make_query_bank(labels, spec, seed=1, scales=1) if vq else None
+    model.query_selector.query_bank = None if bank is None else {k: v.to(dev) for k, v in bank.items()}
+    g = torch.Generator().manual_seed(11)
+    imgs = [torch.randn(3, h, w, generator=g).half().float() for (h, w) in hw]
+    il = to_image_list(imgs, 32)
+    sizes = [tuple(s) for s in il.image_sizes]
+    tok = model.tokenizer([caption + "."] * B, padding="max_length", return_tensors="pt")
+    with torch.no_grad():
+        ild = to_image_list([i.to(dev) for i in imgs], 32)
+        tr = model(ild, captions=[caption] * B, positive_map=pmap, return_raw=True)
+        det = model(ild, captions=[caption] * B, positive_map=pmap)
+        # the oracle decodes the DEVICE's selection (see oracle.gdino.transformer: rank-dependent, discontinuous); its own
+        # selection is compared as a set below
+        o = og.forward({k: (v.half().float() if v.dtype.is_floating_point else v) for k, v in sd.items()}, spec, il.tensors, sizes,
+                       tok["input_ids"], tok["attention_mask"], pmap, model.specical_tokens, bank, topk_override=tr["topk"].cpu())
+        for _ in range(2 if graph else 0):                        # warm call -> capture -> replay must reproduce the eager result
+            det2 = model(ild, captions=[caption] * B, positive_map=pmap)
+    tag = f"gdino[{'vq' if vq else 'text'} B={B} {hw[0][0]}x{hw[0][1]} enc{spec.enc_layers} nq{spec.num_queries}]"
+    res = []
+    n_real = int(tok["attention_mask"][0].sum())
+    res.append(_stat(f"{tag} input projections (Swin + 1x1 / 3x3 conv + GroupNorm)", tr["srcs"],
+                     torch.cat([s.flatten(2).transpose(1, 2) for s in o["srcs"]], 1), T["srcs"]))
+    res.append(_stat(f"{tag} BERT (+GCP) last hidden", tr["bert"][:, :n_real], o["bert"][:, :n_real], T["bert"]))
+    res.append(_stat(f"{tag} encoder memory", tr["memory"], o["memory"], T["memory"]))
+    res.append(_stat(f"{tag} encoder text", tr["memory_text"][:, :n_real], o["memory_text"][:, :n_real], T["text"]))
+    # two-stage selection: compare as sets, then every common query through the decoder
+    tk_g, tk_o = tr["topk"].cpu(), o["topk_own"]
+    for b in range(B):
+        sg, so = set(tk_g[b].tolist()), set(tk_o[b].tolist())
+        frac = len(sg & so) / len(so)
+        # how far below the oracle's cut the device-only picks sit, in units of the logit range (0 = exactly on the cut)
+        lg = o["topk_logits"][b]
+        cut = lg[tk_o[b]].min()
+        miss = max([float(cut - lg[i]) for i in sg - so], default=0.0) / max(1.0, float(lg[tk_o[b]].max() - cut))
+        res.append({"name": f"{tag} two-stage top-{spec.num_queries} image {b}: overlap {frac:.3f}, worst pick {miss:.3f} of the logit range below the cut",
+                    "max_err": 1 - frac, "mean_err": miss, "ref_absmax": 1.0, "norm_err": 1 - frac, "tol": T.get("topk", 0.05),
+                    "ok": frac >= 1 - T.get("topk", 0.05) and miss < 0.05})
+    res.append(_stat(f"{tag} decoder output hs (same selection)", tr["hs"], o["hs"][-1], T["hs"]))
+    res.append(_stat(f"{tag} reference boxes of the last layer", tr["refs"][-1], o["refs"][-2], T["refs"]))
+    res.append(_stat(f"{tag} token scores", tr["pred_logits"], o["pred_logits"], T["logits"]))
+    res.append(_stat(f"{tag} predicted boxes", tr["pred_boxes"], o["pred_boxes"], T["boxes"]))
+    # detections: matched by (label, IoU, score) -- order-independent
+    for b in range(B):
+        bx, sc, lb = o["detections"][b]
+        gb, gs, gl = det[b].bbox.cpu().float(), det[b].get_field("scores").cpu().float(), det[b].get_field("labels").cpu()
+        hit = 0
+        if len(bx) and len(gb):
+            iou = _iou(bx, gb)
+            ok = (iou > 0.9) & ((sc[:, None] - gs[None]).abs() < 0.03) & (lb[:, None] == gl[None])
+            hit = int(ok.any(1).sum())
+        frac = hit / max(1, len(bx))
+        res.append({"name": f"{tag} detections matched image {b} ({len(gb)} vs {len(bx)} oracle)", "max_err": 1 - frac,
+                    "mean_err": 1 - frac, "ref_absmax": 1.0, "norm_err": 1 - frac, "tol": 0.1,
+                    "ok": frac >= 0.9 and abs(len(gb) - len(bx)) <= max(3, 0.1 * len(bx))})
+        if graph:       # library GEMMs may pick other kernels under capture: matched, not bitwise (hand-written kernels are bitwise)
+            g2, s2, l2 = det2[b].bbox.cpu().float(), det2[b].get_field("scores").cpu().float(), det2[b].get_field("labels").cpu()
+            h2 = 0
+            if len(gb) and len(g2):
+                ok2 = (_iou(gb, g2) > 0.9) & ((gs[:, None] - s2[None]).abs() < 0.03) & (gl[:, None] == l2[None])
+                h2 = int(ok2.any(1).sum())
+            f2 = h2 / max(1, len(gb))
+            captured = any(e.get("stage") == 2 for e in model._graphs.values())
+            res.append({"name": f"{tag} HIP-graph replay vs eager image {b} (captured={captured})", "max_err": 1 - f2, "mean_err": 1 - f2,
+                        "ref_absmax": 1.0, "norm_err": 1 - f2, "tol": 0.1, "ok": captured and f2 >= 0.9})
+    return res
+
+
+def check_gdino_tiny(dev):
+    return check_gdino_model(dev, vq=True) + check_gdino_model(dev, vq=False, B=2, hw=((128, 130), (100, 160)))
+
+
+def check_gdino_benchmark_config(dev):
+    """BASELINE configs[4] shape: full-depth MQ-GroundingDINO-T (6 + 6 layers, 900 queries), one 800 x 1333 image, 40 classes
+    with 5 vision queries each."""
+    from oracle.spec import gdino_t_spec
+    spec = gdino_t_spec(vocab=30522)
+    return check_gdino_model(dev, vq=True, B=1, hw=((800, 1333),), spec=spec, n_classes=40, graph=False,
+                             tols=dict(memory=8e-2, hs=0.12, logits=0.1, boxes=4e-2, refs=4e-2))
+
+
+def check_gdino_state_dict_and_quirks(dev):
+    """Reference checkpoint compatibility (names incl. the aliased box heads) and the empty-label NaN quirk."""
+    from oracle.spec import tiny_gdino_spec
+    from mq_det_amd.structures import to_image_list
+    from mq_det_amd.utils.tokenizer import positive_map_from_spans
+    spec = tiny_gdino_spec()
+    sd, cfg, model = gdino_model(dev, spec)
+    res = []
+    msd = model.state_dict()
+    ok = set(msd) == set(sd) and all(tuple(msd[k].shape) == tuple(sd[k].shape) for k in sd)
+    res.append({"name": "gdino state_dict names == reference module's (497 entries in the shallow model)", "max_err": 0.0, "mean_err": 0.0,
+                "ref_absmax": 1.0, "norm_err": 0.0 if ok else 1.0, "tol": 0.0, "ok": ok})
+    caption, spans = _caption(6)
+    pmap = positive_map_from_spans(model.tokenizer, caption + ".", spans, list(range(1, 7)))
+    cfg.VISION_QUERY.ENABLED = False
+    img = to_image_list([torch.randn(3, 96, 128).to(dev)], 32)
+    n0 = len(model(img, captions=[caption], positive_map=pmap)[0])
+    pm2 = dict(pmap)
+    pm2[9] = []
+    n1 = len(model(img, captions=[caption], positive_map=pm2)[0])
+    res.append({"name": f"gdino empty-label quirk: {n0} detections -> {n1} with a token-less label", "max_err": float(n1), "mean_err": 0.0,
+                "ref_absmax": 1.0, "norm_err": float(n1), "tol": 0.0, "ok": n0 > 0 and n1 == 0})
+    return res

@@ -49,7 +49,12 @@ def main():
     dev = torch.device("cuda:0")
     print("device:", torch.cuda.get_device_name(0), "| torch", torch.__version__, flush=True)
     rows = []
-    for group, fn in pc.all_checks(dev):
+    only = os.environ.get("MQ_DIAG_ONLY")                       # e.g. MQ_DIAG_ONLY=gdino: one group of checks
+    checks = [(g, f) for g, f in pc.all_checks(dev) if not only or g in only.split(",")]
+    if only and "gdino-bench" in only.split(","):
+        import gdino_checks as gc
+        checks.append(("gdino-bench", lambda: gc.check_gdino_benchmark_config(dev)))
+    for group, fn in checks:
         t = time.time()
         try:
             r = fn()

@@ -666,6 +666,10 @@ def all_checks(dev):
             ("full", lambda: check_full_model(dev)),
             ("full-L", lambda: [dict(r, name=r["name"].replace("full:", "MQ-GLIP-L (tiny depth):")) for r in check_full_model(dev, large=True)]),
             ("full-novq", lambda: [dict(r, name=r["name"].replace("full:", "GLIP (no vision queries) B=1:")) for r in check_full_model(dev, False)])]
+    import gdino_checks as gc
+    out += [("gdino", lambda: gc.check_attention_qk_mask(dev)), ("gdino", lambda: gc.check_vlfuse_heads_mask(dev)),
+            ("gdino", lambda: gc.check_msdeform_attn_q(dev)), ("gdino", lambda: gc.check_gdino_tiny(dev)),
+            ("gdino", lambda: gc.check_gdino_state_dict_and_quirks(dev))]
     return out
 
 

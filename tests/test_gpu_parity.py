@@ -257,3 +257,17 @@ def test_mq_glip_l_family(dev):
     _assert(pc.check_window_attention(dev, large=True))
     _assert(pc.check_swin_fpn(dev, large=True))
     _assert(pc.check_full_model(dev, large=True))
+
+
+# ------------------------------------------------------------------------------------------------ MQ-GroundingDINO (configs[4])
+@pytest.mark.parametrize("name", ["check_attention_qk_mask", "check_vlfuse_heads_mask", "check_msdeform_attn_q", "check_gdino_tiny",
+                                  "check_gdino_state_dict_and_quirks"])
+def test_groundingdino_block(dev, name):
+    import gdino_checks as gc
+    _assert(getattr(gc, name)(dev))
+
+
+def test_groundingdino_benchmark_config(dev):
+    """Full-depth MQ-GroundingDINO-T on one 800 x 1333 image, 40 classes x 5 vision queries, vs the fp32 oracle."""
+    import gdino_checks as gc
+    _assert(gc.check_gdino_benchmark_config(dev))
