@@ -77,7 +77,7 @@ def check_vlfuse_heads_mask(dev):
         for b in range(B):                                       # padded right columns + bottom rows of a 2-level pyramid
             w = 61
             cols = torch.arange(N) % w
-            mask[b] = (cols >= w - 3 - 5 * b) | (torch.arange(N) >= N - 200 * (b + 1)) | ((torch.arange(N) >= 64) & (torch.arange(N) < 192) & (b == 0))
+            mask[b] = (cols >= w - 3 - 5 * b) | (torch.arange(N) >= N - 60 * (b + 1)) | ((torch.arange(N) >= 64) & (torch.arange(N) < 192) & (b == 0))
         km = ops.image_key_mask(mask.to(dev))
         ref = emu.vlfuse_t2i(kf.float(), v_ln.float(), ns, kv_len=kv_len, key_mask=ops.image_key_mask(mask))
         got = ops.vlfuse_t2i(kf.to(dev), v_ln.to(dev), ns, kv_len=None if kv is None else kv_len.to(dev), key_mask=km)
@@ -177,7 +177,11 @@ def check_gdino_model(dev, vq=True, B=1, hw=((120, 150),), spec=None, n_classes=
     spec = replace(spec or tiny_gdino_spec(), vision_query=vq)
     sd, cfg, model = gdino_model(dev, replace(spec, vision_query=True))
     cfg.VISION_QUERY.ENABLED = vq
-    T = dict(swin=5e-3, srcs=1e-2, bert=3e-2, text=3e-2, memory=5e-2, hs=6e-2, refs=2e-2, logits=5e-2, boxes=2e-2)
+    # measured on MI355X (GPU call 7, profiles/r02_gdino_parity.txt), normalised max error, full depth at 800 x 1333: input
+    # projections 1.9e-3, BERT 3.6e-3, encoder memory 2.7e-3, encoder text 3.8e-3, decoder output 2.8e-3, boxes 5e-4, token
+    # scores 6.8e-3 -- the post-norm LayerNorms of this model re-centre every layer, so the fp16-operand error does not
+    # compound the way it does in the VLDyHead (tests/parity_checks.py BENCH_TOL); tolerances = measured x ~3
+    T = dict(srcs=6e-3, bert=1.2e-2, text=1.2e-2, memory=1e-2, hs=1e-2, refs=2e-3, logits=2e-2, boxes=2e-3)
     T.update(tols or {})
     caption, spans = _caption(n_classes)
     labels = list(range(1, n_classes + 1))
@@ -258,8 +262,7 @@ def check_gdino_benchmark_config(dev):
     with 5 vision queries each."""
     from oracle.spec import gdino_t_spec
     spec = gdino_t_spec(vocab=30522)
-    return check_gdino_model(dev, vq=True, B=1, hw=((800, 1333),), spec=spec, n_classes=40, graph=False,
-                             tols=dict(memory=8e-2, hs=0.12, logits=0.1, boxes=4e-2, refs=4e-2))
+    return check_gdino_model(dev, vq=True, B=1, hw=((800, 1333),), spec=spec, n_classes=40, graph=False)
 
 
 def check_gdino_state_dict_and_quirks(dev):
