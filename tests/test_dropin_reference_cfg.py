@@ -145,3 +145,94 @@ def test_reference_cfg_tree_and_caller_sequence(monkeypatch):
     assert torch.allclose(ref["scores"][o1], got["scores"][o2], atol=2e-4)
     assert torch.equal(ref["labels"][o1], got["labels"][o2])
     assert torch.allclose(ref["boxes"][o1] * 2.0, got["boxes"][o2], atol=2e-2)                    # resize_box: 150x190 -> 300x380
+
+
+def test_groundingdino_reference_cfg_and_caller_sequence(monkeypatch):
+    """The same evidence for the MQ-GroundingDINO family (BASELINE configs[4]): reference config tree = defaults.py +
+    configs/pretrain/mq-groundingdino-t.yaml; `build_detection_model(cfg)` switches on `cfg.GROUNDINGDINO.enabled`
+    (modeling/detector/__init__.py:9-11); strict load of a state_dict with the reference module's names; the eval loop body of
+    engine/inference.py:599-643 on captions / positive maps from the reference's own builders; results vs the oracle (which is
+    pinned to the reference's GroundingDINO module by tests/test_oracle_golden.py)."""
+    import ops_emulation as emu
+    from oracle import _refload, gdino as og
+    from oracle.spec import tiny_gdino_spec
+    from oracle.weights import make_gdino_state_dict, make_query_bank
+    import mq_det_amd
+    from mq_det_amd import ops
+    from mq_det_amd.modeling import gdino, gdino_pipeline as gp
+    from mq_det_amd.structures import to_image_list
+    from mq_det_amd.utils.tokenizer import build_synthetic_tokenizer
+
+    cfg = _refload.reference_cfg("configs/pretrain/mq-groundingdino-t.yaml")
+    assert cfg.GROUNDINGDINO.enabled and cfg.GROUNDINGDINO.num_queries == 900 and cfg.GROUNDINGDINO.box_threshold == 0.05
+    names = LVIS_LIKE[:12]
+    words = [w for n in names for w in n.lower().replace("(", " ").replace(")", " ").replace("_", " ").split()]
+    spec = tiny_gdino_spec(vocab=4000)
+    tok_dir = build_synthetic_tokenizer(tempfile.mkdtemp(), size=spec.vocab, extra_words=words)
+    # command-line style overrides: shallow model (product-only keys for the depths the reference hard-codes by name), local tokenizer
+    G = cfg.GROUNDINGDINO
+    G.enc_layers, G.dec_layers, G.num_queries, G.text_encoder_type = spec.enc_layers, spec.dec_layers, spec.num_queries, tok_dir
+    G.swin_depths = spec.swin_depths
+    cfg.MODEL.LANGUAGE_BACKBONE.TOKENIZER_TYPE = cfg.MODEL.LANGUAGE_BACKBONE.MODEL_TYPE = tok_dir     # the caption builders read it
+    cfg.MODEL.LANGUAGE_BACKBONE.NUM_HIDDEN_LAYERS, cfg.MODEL.LANGUAGE_BACKBONE.QV_START = spec.bert_layers, spec.qv_start
+    cfg.MODEL.LANGUAGE_BACKBONE.BERT_VOCAB_SIZE = spec.vocab
+    cfg.VISION_QUERY.QUERY_BANK_PATH = ""
+    sd = make_gdino_state_dict(spec, 0)
+
+    for n in ("attention", "attention4", "window_attention", "gcp_sparse_attention", "gcp_gate_residual", "layer_norm", "vlfuse_i2t",
+              "vlfuse_t2i", "swin_mlp", "conv3x3", "ms_deform_attn_q", "roi_align"):
+        monkeypatch.setattr(ops, n, getattr(emu, n))
+
+    def prepare(self, device=None):
+        self._plan = gp.build_gdino_plan(self.state_dict(), self.cfg, torch.device("cpu"), self._swin, dtype=torch.float32)
+        self._plan_key = torch.device("cpu")
+        self.use_hip_graph = False
+        return self._plan
+    monkeypatch.setattr(gdino.GroundingDINO, "prepare", prepare)
+
+    model = mq_det_amd.build_detection_model(cfg)              # tools/test_grounding_net.py:141
+    assert type(model).__name__ == "GroundingDINO"
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+
+    fns = _refload.reference_functions("maskrcnn_benchmark/engine/inference.py",
+                                       ["clean_name", "create_positive_dict", "chunks", "create_queries_and_maps",
+                                        "create_queries_and_maps_from_dataset", "resize_box"],
+                                       {"load_from_yaml_file": None})
+    dataset = types.SimpleNamespace(categories=lambda: {i + 1: n for i, n in enumerate(names)})
+    all_queries, all_maps = fns["create_queries_and_maps_from_dataset"](dataset, cfg, disable_print=True)
+    assert len(all_queries) == 1 and sorted(all_maps[0]) == list(range(1, 13))
+    bank = make_query_bank(range(1, 13), spec, seed=1, scales=1)
+    model.load_query_bank(bank)
+
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(3, 120, 150, generator=g)
+    images = to_image_list([img], cfg.DATALOADER.SIZE_DIVISIBILITY)
+    targets = [{"orig_size": torch.tensor([240, 300]), "image_id": torch.tensor(3)}]
+    with torch.no_grad():
+        output = model(images, captions=[all_queries[0]], positive_map=all_maps[0])
+        output = [o.to(torch.device("cpu")) for o in output][0]
+        res, feats = model(images, captions=[all_queries[0]], positive_map=all_maps[0], return_backbone_features=True)
+        output = fns["resize_box"](output, targets)
+    scores, labels, boxes = output.extra_fields["scores"], output.extra_fields["labels"], output.bbox
+    assert scores.dtype == torch.float32 and labels.dtype == torch.int64 and 0 < len(scores) <= spec.num_queries
+    assert set(labels.tolist()) <= set(range(1, 13)) and float(scores.min()) > cfg.GROUNDINGDINO.box_threshold
+    assert len(feats) == 4 and feats[0].shape[1] == 256 and feats[0].shape[-2:] == (16, 20)      # `srcs` for online_update
+
+    # the oracle on the same weights / pixels / caption (preprocess_caption adds the final '.')
+    tok = model.tokenizer([gdino.preprocess_caption(all_queries[0])], padding="max_length", return_tensors="pt")
+    with torch.no_grad():
+        o = og.forward(sd, spec, images.tensors, [tuple(s) for s in images.image_sizes], tok["input_ids"], tok["attention_mask"],
+                       dict(all_maps[0]), model.specical_tokens, bank)
+    bx, sc, lb = o["detections"][0]
+    assert len(bx) == len(scores)
+    assert torch.allclose(sc, scores, atol=2e-4) and torch.equal(lb, labels)
+    assert torch.allclose(bx * 2.0, boxes, atol=2e-2)                                             # resize_box: 120x150 -> 240x300
+
+    # extract_query on the projected levels (groundingdino.py:340-421) appends pooled features to the bank
+    from mq_det_amd.structures import BoxList
+    t = BoxList(torch.tensor([[10.0, 12.0, 80.0, 90.0], [30.0, 20.0, 140.0, 110.0]]), (150, 120), mode="xyxy")
+    t.add_field("labels", torch.tensor([2, 5]))
+    from collections import defaultdict
+    qi = model.extract_query(samples=images, targets=[t], query_images=defaultdict(list), visual_features=feats)
+    assert sorted(qi) == [2, 5] and qi[2].shape == (1, 1, 256)
