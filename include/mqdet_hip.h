@@ -232,12 +232,14 @@ int mq_msdeform_attn_fwd(const void* value, int value_f32, const long* shapes, c
  * computed in registers; L == P == 4):
  *   qproj [B,Q,M*L*P*3] fp16 = [sampling_offsets (m,l,p,xy) | attention logits (m,l,p)] of one fused projection,
  *   ref [B,Q,L,ref_dim] fp32 normalised reference points (ref_dim 2: loc = ref + off / (W_l, H_l)) or boxes (ref_dim 4:
- *   loc = ref.xy + off / P * ref.wh * 0.5), value element (b,s,m,c) at value + b*value_bs + s*value_ts + m*D + c.
+ *   loc = ref.xy + off / P * ref.wh * 0.5), value element (b,s,m,c) at value + b*value_bs + s*value_ts + m*D + c;
+ *   valid_hw [B,L,2] int32 or NULL: un-padded (rows, columns) of every level per image -- corners outside read as zero, which
+ *   is the reference's `value.masked_fill(key_padding_mask, 0)` (ms_deform_attn.py:286-287) without the masked copy.
  * Replaces MultiScaleDeformableAttention.forward lines ms_deform_attn.py:292-347 (view / softmax / location arithmetic /
  *   fp32 casts / _C.ms_deform_attn_forward) for the encoder (transformer.py:786-793) and decoder (:912-919) call sites. */
 int mq_msdeform_attn_q_fwd(const void* value, int value_f32, long value_bs, long value_ts, const long* shapes,
-                           const long* level_start, const void* qproj, const float* ref, int ref_dim, void* out, int out_f32,
-                           int B, int S, int M, int D, int L, int Q, int P, void* stream);
+                           const long* level_start, const void* qproj, const float* ref, int ref_dim, const int* valid_hw,
+                           void* out, int out_f32, int B, int S, int M, int D, int L, int Q, int P, void* stream);
 
 /* Class-aware NMS on score-sorted boxes, mask + sweep entirely on the device.
  *   boxes [B,N,4] fp32 (sorted by score desc per image), labels [B,N] int32, nvalid [B] int32 -> keep [B,N] uint8.

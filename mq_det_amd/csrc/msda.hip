@@ -108,11 +108,16 @@ extern "C" int mq_msdeform_attn_fwd(const void* value, int value_f32, const long
 //   qproj [B, Q, M*L*P*3] fp16: offsets (m, l, p, xy) then logits (m, l, p) -- the [sampling_offsets | attention_weights]
 //   projection as ONE GEMM; ref [B, Q, L, RD] fp32; value element (b, s, m, c) at value + b*value_bs + s*value_ts + m*D + c
 //   (a token stride > M*D lets the six decoder layers share one batched value projection).
+//   valid_hw [B, L, 2] int32 or nullptr: (rows, columns) of level l that are NOT padding for image b.  The reference zeroes the
+//   value rows of padding tokens (`value.masked_fill(key_padding_mask, 0)`, ms_deform_attn.py:286-287); the padding of a
+//   batched image is the region right of / below its valid rectangle, so a corner outside the rectangle simply reads as zero
+//   here -- no masked copy of the [B, S, 256] value tensor per layer.
 template <typename TV, typename TO, int L, int P, int RD>
 __global__ __launch_bounds__(256) void msda_q_kernel(const TV* __restrict__ value, long value_bs, long value_ts,
                                                      const long* __restrict__ shapes, const long* __restrict__ level_start,
                                                      const half_t* __restrict__ qproj, const float* __restrict__ ref,
-                                                     TO* __restrict__ out, int B, int S, int M, int D, int Q) {
+                                                     const int* __restrict__ valid_hw, TO* __restrict__ out, int B, int S, int M,
+                                                     int D, int Q) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long bq = (long)blockIdx.x * 4 + wave;
   if (bq >= (long)B * Q) return;
@@ -147,6 +152,7 @@ __global__ __launch_bounds__(256) void msda_q_kernel(const TV* __restrict__ valu
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const int Hv = valid_hw ? valid_hw[(b * L + l) * 2] : H, Wv = valid_hw ? valid_hw[(b * L + l) * 2 + 1] : W;
       const TV* vb = value + (long)b * value_bs + level_start[l] * value_ts + m * D + c;
       const long ws = value_ts, hs = (long)W * ws;
       const float rx = rrow[l * RD], ry = rrow[l * RD + 1];
@@ -174,10 +180,10 @@ __global__ __launch_bounds__(256) void msda_q_kernel(const TV* __restrict__ valu
               for (int j = 0; j < 4; ++j) dst[j] = t[j];
             }
           };
-          if (hl >= 0 && wl >= 0) ld(hl, wl, v1);
-          if (hl >= 0 && wh <= W - 1) ld(hl, wh, v2);
-          if (hh <= H - 1 && wl >= 0) ld(hh, wl, v3);
-          if (hh <= H - 1 && wh <= W - 1) ld(hh, wh, v4);
+          if (hl >= 0 && wl >= 0 && hl < Hv && wl < Wv) ld(hl, wl, v1);
+          if (hl >= 0 && wh <= Wv - 1 && hl < Hv) ld(hl, wh, v2);
+          if (hh <= Hv - 1 && wl >= 0 && wl < Wv) ld(hh, wl, v3);
+          if (hh <= Hv - 1 && wh <= Wv - 1) ld(hh, wh, v4);
           const float w1 = uh * uw, w2 = uh * lw, w3 = lh * uw, w4 = lh * lw;
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[j] += (w1 * v1[j] + w2 * v2[j] + w3 * v3[j] + w4 * v4[j]) * wgt;
@@ -197,15 +203,16 @@ __global__ __launch_bounds__(256) void msda_q_kernel(const TV* __restrict__ valu
 }
 
 extern "C" int mq_msdeform_attn_q_fwd(const void* value, int value_f32, long value_bs, long value_ts, const long* shapes,
-                                      const long* level_start, const void* qproj, const float* ref, int ref_dim, void* out,
-                                      int out_f32, int B, int S, int M, int D, int L, int Q, int P, void* stream) {
+                                      const long* level_start, const void* qproj, const float* ref, int ref_dim,
+                                      const int* valid_hw, void* out, int out_f32, int B, int S, int M, int D, int L, int Q, int P,
+                                      void* stream) {
   if (B <= 0 || Q <= 0) return 0;
   if (D % 4 || M <= 0 || L != 4 || P != 4 || (ref_dim != 2 && ref_dim != 4) || (value_ts % 4) || (value_bs % 4)) return -1;
   const dim3 grid((unsigned)(((long)B * Q + 3) / 4));
   hipStream_t s = (hipStream_t)stream;
 #define MQ_MSDAQ(TV, TO, RD)                                                                                             \
   hipLaunchKernelGGL((msda_q_kernel<TV, TO, 4, 4, RD>), grid, dim3(256), 0, s, (const TV*)value, value_bs, value_ts, shapes,  \
-                     level_start, (const half_t*)qproj, ref, (TO*)out, B, S, M, D, Q)
+                     level_start, (const half_t*)qproj, ref, valid_hw, (TO*)out, B, S, M, D, Q)
 #define MQ_MSDAQ_T(RD)                                       \
   if (value_f32 && out_f32) MQ_MSDAQ(float, float, RD);      \
   else if (value_f32) MQ_MSDAQ(float, half_t, RD);           \

@@ -21,6 +21,7 @@ Geometry that depends only on the padded batch shape and the image sizes (paddin
 reference points, two-stage proposals) is computed once per shape by `geometry()` and cached by the caller.
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -186,7 +187,9 @@ def geometry(P, cfg, H, W, image_sizes, device):
     valid = ((props > 0.01) & (props < 0.99)).all(-1)
     invalid = mask | ~valid
     props = torch.log(props / (1 - props)).masked_fill(invalid[..., None], float("inf"))
+    valid_hw = torch.stack([torch.stack([(~m[:, :, 0]).sum(1), (~m[:, 0, :]).sum(1)], -1) for m in masks], 1).to(torch.int32)
     return {"shapes": tuple(shapes), "mask": mask, "key_mask": ops.image_key_mask(mask), "pos": pos.contiguous(), "vr": vr,
+            "pos16": pos.to(P["transformer.level_embed"].dtype).contiguous(), "valid_hw": valid_hw.contiguous(),
             "enc_ref": ref, "proposals": props.contiguous(), "invalid": invalid, "any_pad": bool(mask.any())}
 
 
@@ -314,15 +317,24 @@ def text_enhancer_layer(P, b, text32, txt, heads):
 
 def deformable_encoder_layer(P, b, mem16, geo, heads):
     """transformer.py:739-804: MSDeformAttn(query = src + pos, value = src) + FFN, post-norm.  mem16: fp16 tokens."""
-    q = (mem16.float() + geo["pos"]).to(mem16.dtype)
-    qp = _lin(P, b + ".self_attn.qproj", q)
+    qp = _lin(P, b + ".self_attn.qproj", mem16 + geo["pos16"])
     val = _lin(P, b + ".self_attn.value_proj", mem16)
-    if geo["any_pad"]:
-        val = val.masked_fill(geo["mask"][..., None], 0.0)
-    a = ops.ms_deform_attn_q(val, geo["shapes"], qp, geo["enc_ref"], heads)
+    a = ops.ms_deform_attn_q(val, geo["shapes"], qp, geo["enc_ref"], heads, valid_hw=geo["valid_hw"] if geo["any_pad"] else None)
     m16, m32 = _add_ln(P, b + ".norm1", _lin(P, b + ".self_attn.output_proj", a), mem16, want_sum=False, want_y32=True)
-    h = _lin(P, b + ".linear2", F.relu(_lin(P, b + ".linear1", m16)))
+    h = _lin(P, b + ".linear2", _lin_relu(P, b + ".linear1", m16))
     return _add_ln(P, b + ".norm2", h, m32, want_sum=False, want_y32=True)
+
+
+_FUSED_RELU = os.environ.get("MQ_GDINO_FUSED_RELU", "1") == "1"
+
+
+def _lin_relu(P, name, x):
+    """relu(x W^T + b): the ReLU rides in the library GEMM's epilogue (hipBLASLt) -- the [B, S, 2048] hidden activation of the
+    encoder FFN is written once instead of written, read and written again."""
+    if not _FUSED_RELU:
+        return F.relu(_lin(P, name, x))
+    w = P[name + ".weight"]
+    return torch._addmm_activation(P[name + ".bias"], x.reshape(-1, x.shape[-1]), w.t()).view(*x.shape[:-1], w.shape[0])
 
 
 def _mlp(P, b, x, n):
@@ -415,8 +427,7 @@ def decoder(P, cfg, mem16, text32, ref0, geo, txt, trace=None):
     B = mem16.shape[0]
     dt = mem16.dtype
     val_all = _lin(P, t + ".value_all", mem16)                                                # [B, S, nl*D]
-    if geo["any_pad"]:
-        val_all = val_all.masked_fill(geo["mask"][..., None], 0.0)
+    valid_hw = geo["valid_hw"] if geo["any_pad"] else None
     text16 = text32.to(dt)
     tk_all = _lin(P, t + ".text_k_all", text16)                                               # [B, T, nl*D]
     tvt_all = _vt(P, t + ".text_v_all", text16)                                               # [B, nl*D, T]
@@ -439,7 +450,7 @@ def decoder(P, cfg, mem16, text32, ref0, geo, txt, trace=None):
         _, tgt32 = _add_ln(P, b + ".catext_norm", _lin(P, b + ".ca_text.out_proj", ctx), tgt32, want_sum=False, want_y32=True)
         # deformable cross-attention into the encoder memory
         qp = _lin(P, b + ".cross_attn.qproj", (tgt32 + qpos).to(dt))
-        a = ops.ms_deform_attn_q(val_all[..., i * D:(i + 1) * D], geo["shapes"], qp, ref_in, M)
+        a = ops.ms_deform_attn_q(val_all[..., i * D:(i + 1) * D], geo["shapes"], qp, ref_in, M, valid_hw=valid_hw)
         t16, tgt32 = _add_ln(P, b + ".norm1", _lin(P, b + ".cross_attn.output_proj", a), tgt32, want_sum=False, want_y32=True)
         hmid = _lin(P, b + ".linear2", F.relu(_lin(P, b + ".linear1", t16)))
         t16, tgt32 = _add_ln(P, b + ".norm3", hmid, tgt32, want_sum=False, want_y32=True)

@@ -40,7 +40,7 @@ _SIGNATURES = {
     "mq_box_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _vp]),
     "mq_roi_align_fwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _f, _i, _i, _i, _vp]),
     "mq_msdeform_attn_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "mq_msdeform_attn_q_fwd": (_i, [_vp, _i, _l, _l, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "mq_msdeform_attn_q_fwd": (_i, [_vp, _i, _l, _l, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_ml_nms_workspace_bytes": (_l, [_i, _i]),
     "mq_ml_nms": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
 }
@@ -641,10 +641,11 @@ def _msda_shapes(shapes, device):
     return _MSDA_SHAPES[key]
 
 
-def ms_deform_attn_q(value, spatial_shapes, qproj, ref, heads, out_dtype=None):
+def ms_deform_attn_q(value, spatial_shapes, qproj, ref, heads, out_dtype=None, valid_hw=None):
     """Fused-query form (mq_msdeform_attn_q_fwd).  value [B,S,>=heads*D] fp16 / fp32 view with unit channel stride (token /
     batch strides free: a column slice of a wider projection is fine), qproj [B,Q,heads*16*3] fp16 contiguous =
-    [offsets | logits] of the fused projection, ref [B,Q,4,2|4] fp32 contiguous -> [B,Q,heads*D]."""
+    [offsets | logits] of the fused projection, ref [B,Q,4,2|4] fp32 contiguous, valid_hw [B,4,2] int32 or None (un-padded
+    rows / columns per level: value rows outside count as zero) -> [B,Q,heads*D]."""
     lib = load_library()
     _need_gpu(value, qproj, ref)
     B, S, C = value.shape
@@ -655,13 +656,16 @@ def ms_deform_attn_q(value, spatial_shapes, qproj, ref, heads, out_dtype=None):
     assert sum(h * w for h, w in shapes) == S and value.stride(2) == 1 and value.dtype in (torch.float16, torch.float32)
     assert qproj.dtype == torch.float16 and qproj.is_contiguous() and qproj.shape == (B, Q, heads * L * P * 3)
     assert ref.dtype == torch.float32 and ref.is_contiguous() and ref.shape[:3] == (B, Q, L) and ref.shape[3] in (2, 4)
+    if valid_hw is not None:
+        _need_gpu(valid_hw)
+        assert valid_hw.dtype == torch.int32 and valid_hw.is_contiguous() and valid_hw.shape == (B, L, 2)
     hw, start = _msda_shapes(shapes, value.device)
     out_dtype = out_dtype or value.dtype
     out = torch.empty(B, Q, C, dtype=out_dtype, device=value.device)
     nb = B * S * C * value.element_size() + qproj.numel() * 2 + ref.numel() * 4 + out.numel() * out.element_size()
     with _timed(f"msdeform_attn_q{Q}", nb):
         _chk(lib.mq_msdeform_attn_q_fwd(_ptr(value), int(value.dtype == torch.float32), value.stride(0), value.stride(1), _ptr(hw),
-                                        _ptr(start), _ptr(qproj), _ptr(ref), ref.shape[3], _ptr(out),
+                                        _ptr(start), _ptr(qproj), _ptr(ref), ref.shape[3], _ptr(valid_hw), _ptr(out),
                                         int(out_dtype == torch.float32), B, S, heads, D, L, Q, P, _stream()),
              "mq_msdeform_attn_q_fwd")
     return out

@@ -122,6 +122,19 @@ def check_msdeform_attn_q(dev):
         v = val_all[..., i * M * D:(i + 1) * M * D].reshape(B, S, M, D).contiguous()
         unf = ops.ms_deform_attn(v.to(dev), shapes, loc.contiguous().to(dev), aw.contiguous().to(dev))
         res.append(_stat(f"msdeform fused vs unfused kernel B={B} Q={Q} ref_dim={nd}", got, unf, tol=2e-3))
+        # padded batch: valid extents inside the kernel == gathering from a value tensor whose padding rows were zeroed
+        vhw = torch.tensor([[[h - (3 + b) * (l < 3), w - (5 - b) * (l < 2)] for l, (h, w) in enumerate(shapes)] for b in range(B)], dtype=torch.int32)
+        vm = v.clone()
+        s0 = 0
+        for l, (h, w) in enumerate(shapes):
+            ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+            for b in range(B):
+                bad = ((ys >= int(vhw[b, l, 0])) | (xs >= int(vhw[b, l, 1]))).reshape(-1)
+                vm[b, s0:s0 + h * w][bad] = 0
+            s0 += h * w
+        got_v = ops.ms_deform_attn_q(vd[..., i * M * D:(i + 1) * M * D], shapes, qp.to(dev), ref_pts.to(dev), M, valid_hw=vhw.to(dev))
+        unf_v = ops.ms_deform_attn(vm.to(dev), shapes, loc.contiguous().to(dev), aw.contiguous().to(dev))
+        res.append(_stat(f"msdeform valid extents in-kernel vs zeroed padding rows B={B} Q={Q} ref_dim={nd}", got_v, unf_v, tol=2e-3))
     return res
 
 

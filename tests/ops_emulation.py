@@ -362,9 +362,17 @@ def image_key_mask(mask):
     return f(mask)
 
 
-def ms_deform_attn_q(value, spatial_shapes, qproj, ref, heads, out_dtype=None):
+def ms_deform_attn_q(value, spatial_shapes, qproj, ref, heads, out_dtype=None, valid_hw=None):
     """Plain-torch statement of mq_msdeform_attn_q_fwd: softmax + sampling locations, then the unfused emulation."""
     B, S, C = value.shape
+    if valid_hw is not None:                                 # rows / columns outside the valid rectangle read as zero
+        value, s0 = value.clone(), 0
+        for l, (h, w) in enumerate(spatial_shapes):
+            ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+            for b in range(B):
+                bad = (ys >= int(valid_hw[b, l, 0])) | (xs >= int(valid_hw[b, l, 1]))
+                value[b, s0:s0 + h * w][bad.reshape(-1)] = 0
+            s0 += h * w
     Q, L, P = qproj.shape[1], len(spatial_shapes), 4
     n = heads * L * P
     qp = qproj.float()
