@@ -321,6 +321,7 @@ def deformable_encoder_layer(P, b, mem16, geo, heads):
     val = _lin(P, b + ".self_attn.value_proj", mem16)
     a = ops.ms_deform_attn_q(val, geo["shapes"], qp, geo["enc_ref"], heads, valid_hw=geo["valid_hw"] if geo["any_pad"] else None)
     m16, m32 = _add_ln(P, b + ".norm1", _lin(P, b + ".self_attn.output_proj", a), mem16, want_sum=False, want_y32=True)
+    _mark("enc.deformable")
     h = _lin(P, b + ".linear2", _lin_relu(P, b + ".linear1", m16))
     return _add_ln(P, b + ".norm2", h, m32, want_sum=False, want_y32=True)
 
@@ -388,6 +389,33 @@ def language_front(P, cfg, txt, use_vq):
     return pipeline.language_front(P, cfg, txt["input_ids"], None, use_vq, p="bert", position_ids=txt["position_ids"], qk_mask=mask)
 
 
+_MARKS = None           # bench.py stage timing (eager passes only): list of (stage name, event) or None
+
+
+def start_marks():
+    global _MARKS
+    _MARKS = []
+
+
+def stop_marks():
+    """-> {stage: ms} summed over the recorded passes (time between consecutive marks is charged to the later mark's name)."""
+    global _MARKS
+    marks, _MARKS = _MARKS, None
+    torch.cuda.synchronize()
+    out = {}
+    for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+        if n1 != "start":
+            out[n1] = out.get(n1, 0.0) + e0.elapsed_time(e1)
+    return out
+
+
+def _mark(name):
+    if _MARKS is not None:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        _MARKS.append((name, e))
+
+
 # ----------------------------------------------------------------------------- transformer
 def encoder(P, cfg, src32, text32, geo, txt, max_kv=0, trace=None):
     G = cfg.GROUNDINGDINO
@@ -395,8 +423,11 @@ def encoder(P, cfg, src32, text32, geo, txt, max_kv=0, trace=None):
     for i in range(G.enc_layers):
         t = "transformer.encoder"
         mem16, text32 = fusion_layer(P, f"{t}.fusion_layers.{i}", mem32, text32, geo, txt, max_kv)
+        _mark("enc.fusion")
         text32 = text_enhancer_layer(P, f"{t}.text_layers.{i}", text32, txt, G.nheads // 2)
+        _mark("enc.text_layer")
         mem16, mem32 = deformable_encoder_layer(P, f"{t}.layers.{i}", mem16, geo, G.nheads)
+        _mark("enc.deformable+ffn")
         if trace is not None:
             trace.append({"memory": mem32, "text": text32})
     return mem16, mem32, text32
@@ -497,8 +528,11 @@ def convert(prob, boxes, class_map, nan_labels, im_hw, box_threshold):
 def forward_device(P, cfg, SW, x, geo, txt, vision, idx, class_map, im_hw, max_kv=0, nan_labels=False, front=None, trace=None):
     """The device program: pixels [B,3,H,W] fp16 (channels_last) -> packed detections.  No host synchronisation inside."""
     G = cfg.GROUNDINGDINO
+    _mark("start")
     feats = pipeline.swin_forward(P, cfg, x, p="backbone.0", SW=SW)
+    _mark("swin")
     src32 = input_projections(P, cfg, feats)
+    _mark("input_proj")
     dt = x.dtype
     images = None
     if vision is not None:                                     # flatten_fpn_features (groundingdino.py:423-425)
@@ -510,13 +544,17 @@ def forward_device(P, cfg, SW, x, geo, txt, vision, idx, class_map, im_hw, max_k
         images = pipeline.pooled_fpn_tokens(views)
     x16, x32, gates = language(P, cfg, txt, vision, images, idx, cfg.VISION_QUERY.RETURN_ATTN_GATE_VALUE, front)
     text32 = _lin(P, "feat_map", x16).float()
+    _mark("language")
     if trace is not None:
         trace.update(srcs=src32, bert=x32, encoded_text=text32, enc=[], dec=[])
     mem16, mem32, text32 = encoder(P, cfg, src32, text32, geo, txt, max_kv, None if trace is None else trace["enc"])
     ref0, topk, hs_enc, init_box = two_stage(P, cfg, mem32, text32, geo, txt)
+    _mark("two_stage")
     hs, refs = decoder(P, cfg, mem16, text32, ref0, geo, txt, None if trace is None else trace["dec"])
+    _mark("decoder")
     prob, boxes = heads(P, cfg, hs, refs[-1], text32, txt)
     packed, keep = convert(prob, boxes, class_map, nan_labels, im_hw, float(G.box_threshold))
+    _mark("heads+convert")
     out = {"packed": packed, "keep": keep, "srcs": src32}
     if gates is not None:
         out["gates"] = torch.stack([g.float().mean() for g in gates])
