@@ -433,15 +433,17 @@ def encoder(P, cfg, src32, text32, geo, txt, max_kv=0, trace=None):
     return mem16, mem32, text32
 
 
-def two_stage(P, cfg, mem32, text32, geo, txt):
+def two_stage(P, cfg, mem16, text32, geo, txt):
     """transformer.py:262-306: proposals from the encoder memory, top-k by the best token logit; the box head runs on the
-    selected rows only (a row-wise MLP: identical to selecting from the full result)."""
+    selected rows only (a row-wise MLP: identical to selecting from the full result).  mem16: the fp16 operand copy of the
+    encoder output (what the enc_output GEMM consumes anyway)."""
     G = cfg.GROUNDINGDINO
     t = "transformer"
-    omem = mem32.masked_fill(geo["invalid"][..., None], 0.0)
-    e16, e32 = _ln(P, t + ".enc_output_norm", _lin(P, t + ".enc_output", omem.to(P[t + ".enc_output.weight"].dtype)), want_y32=True)
-    logits = torch.matmul(e32, text32.transpose(1, 2))                                        # fp32: ranks 900 of ~22 k rows
-    logits = logits.masked_fill(~txt["token_mask"][:, None, :], float("-inf"))
+    omem = mem16.masked_fill(geo["invalid"][..., None], 0.0)
+    e16, e32 = _ln(P, t + ".enc_output_norm", _lin(P, t + ".enc_output", omem), want_y32=True)
+    # fp32 logits (they rank 900 of ~22 k rows); the text padding mask rides in the GEMM as its additive term (-1e30 columns)
+    B, S = e32.shape[:2]
+    logits = torch.baddbmm(txt["key_bias"][:, None, :].expand(B, S, -1), e32, text32.transpose(1, 2))
     topk = torch.topk(logits.amax(-1), G.num_queries, dim=1)[1]                               # [B, nq]
     sel16 = torch.gather(e16, 1, topk[..., None].expand(-1, -1, e16.shape[-1]))
     props = torch.gather(geo["proposals"], 1, topk[..., None].expand(-1, -1, 4))
@@ -548,7 +550,7 @@ def forward_device(P, cfg, SW, x, geo, txt, vision, idx, class_map, im_hw, max_k
     if trace is not None:
         trace.update(srcs=src32, bert=x32, encoded_text=text32, enc=[], dec=[])
     mem16, mem32, text32 = encoder(P, cfg, src32, text32, geo, txt, max_kv, None if trace is None else trace["enc"])
-    ref0, topk, hs_enc, init_box = two_stage(P, cfg, mem32, text32, geo, txt)
+    ref0, topk, hs_enc, init_box = two_stage(P, cfg, mem16, text32, geo, txt)
     _mark("two_stage")
     hs, refs = decoder(P, cfg, mem16, text32, ref0, geo, txt, None if trace is None else trace["dec"])
     _mark("decoder")

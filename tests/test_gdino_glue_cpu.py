@@ -76,7 +76,7 @@ def make_case(spec, B, sizes, seed=0):
     return img, ids, am, pmap, special
 
 
-@pytest.mark.parametrize("vq,B,sizes", [(True, 1, [(120, 150)]), (False, 2, [(128, 130), (100, 160)])])
+@pytest.mark.parametrize("vq,B,sizes", [(True, 1, [(120, 150)]), (False, 2, [(128, 130), (100, 160)]), (False, 1, [(128, 160)])])
 def test_gdino_pipeline_glue(emulated_ops, vq, B, sizes):
     spec = tiny_gdino_spec(vision_query=vq)
     sd = make_gdino_state_dict(tiny_gdino_spec(), seed=0)
