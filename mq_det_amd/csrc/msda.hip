@@ -16,6 +16,7 @@
 //   loc    [B, Q, M, L, P, 2] fp32 (x, y in [0, 1])      attn [B, Q, M, L, P] fp32
 //   out    [B, Q, M * D]  fp16 or fp32
 #include "common.h"
+#include <cstdlib>
 
 template <typename TV, typename TO>
 __global__ __launch_bounds__(256) void msda_kernel(const TV* __restrict__ value, const long* __restrict__ shapes,
@@ -117,80 +118,112 @@ __global__ __launch_bounds__(256) void msda_q_kernel(const TV* __restrict__ valu
                                                      const long* __restrict__ shapes, const long* __restrict__ level_start,
                                                      const half_t* __restrict__ qproj, const float* __restrict__ ref,
                                                      const int* __restrict__ valid_hw, TO* __restrict__ out, int B, int S, int M,
-                                                     int D, int Q) {
+                                                     int D, int Q, int xcd_order) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long bq = (long)blockIdx.x * 4 + wave;
-  if (bq >= (long)B * Q) return;
+  // XCD-aware order: workgroup i runs on XCD i % 8 and every XCD has its own 4 MB L2.  With the natural order each XCD sees
+  // every 8th group of 4 queries, i.e. ALL value rows of ALL images stream through every L2 (11.4 MB of fp16 values per
+  // 800 x 1344 image) and most corner reads miss it.  Here XCD x owns the x-th CONTIGUOUS eighth of the (image, query) range:
+  // queries that run at the same time on one XCD are spatial neighbours and sample overlapping value rows.
+  const long nblk = ((long)B * Q + 3) / 4;
+  long blk = blockIdx.x;
+  if (xcd_order) {
+    const long per = (nblk + 7) / 8;
+    blk = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per) return;
+  }
+  // wave-uniform by construction: as scalars, the row pointers below live in SGPRs and the gathers use 32-bit lane offsets
+  const int bq = __builtin_amdgcn_readfirstlane((int)(blk * 4 + wave));
+  if (blk >= nblk || bq >= B * Q) return;
   const int b = bq / Q;
   const int lph = D >> 2;
   const int nchunk = M * lph;
   constexpr int LP = L * P;
-  const half_t* qrow = qproj + bq * (long)(M * LP * 3);
-  const float* rrow = ref + bq * (long)(L * RD);
+  const half_t* qrow = qproj + (long)bq * (M * LP * 3);
+  const float* rrow = ref + (long)bq * (L * RD);
   for (int ch = lane; ch < nchunk; ch += 64) {
     const int m = ch / lph, c = (ch - m * lph) << 2;
-    // softmax over this head's L*P logits (16 halfs = two 16-byte loads, shared by the lanes of the head through L1)
-    float w[LP];
+    // softmax over this head's L*P logits: max and 1/sum here (two 16-byte loads, shared by the lanes of the head through L1),
+    // the weights themselves are formed per level below -- no 16-entry register array, the kernel stays at 8 waves / SIMD
+    const half_t* lg = qrow + M * LP * 2 + m * LP;
+    float mx = -3.0e38f, inv;
     {
-      const half_t* lg = qrow + M * LP * 2 + m * LP;
-      float mx = -3.0e38f;
+      float e[LP];
 #pragma unroll
       for (int i = 0; i < LP; i += 8) {
         const half8 t = *(const half8*)(lg + i);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { w[i + j] = (float)t[j]; mx = fmaxf(mx, w[i + j]); }
+        for (int j = 0; j < 8; ++j) { e[i + j] = (float)t[j]; mx = fmaxf(mx, e[i + j]); }
       }
       float sum = 0.f;
 #pragma unroll
-      for (int i = 0; i < LP; ++i) { w[i] = __expf(w[i] - mx); sum += w[i]; }
-      const float inv = 1.f / sum;
-#pragma unroll
-      for (int i = 0; i < LP; ++i) w[i] *= inv;
+      for (int i = 0; i < LP; ++i) sum += __expf(e[i] - mx);
+      inv = 1.f / sum;
     }
     const half_t* op = qrow + m * LP * 2;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 1                                             // one level at a time: 16 corner loads in flight, <= 64 VGPRs (8 waves / SIMD)
     for (int l = 0; l < L; ++l) {
       const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
       const int Hv = valid_hw ? valid_hw[(b * L + l) * 2] : H, Wv = valid_hw ? valid_hw[(b * L + l) * 2 + 1] : W;
-      const TV* vb = value + (long)b * value_bs + level_start[l] * value_ts + m * D + c;
-      const long ws = value_ts, hs = (long)W * ws;
+      const TV* vb = value + (long)b * value_bs + level_start[l] * value_ts;      // uniform; lane part: m * D + c + (y W + x) ts
+      const unsigned ws = (unsigned)value_ts, hs = (unsigned)W * ws, lane_off = (unsigned)(m * D + c);
       const float rx = rrow[l * RD], ry = rrow[l * RD + 1];
       float sx, sy;                                        // offset -> normalised location scale
       if constexpr (RD == 2) { sx = 1.f / (float)W; sy = 1.f / (float)H; }
       else { sx = rrow[l * RD + 2] * (0.5f / (float)P); sy = rrow[l * RD + 3] * (0.5f / (float)P); }
       const half8 o8 = *(const half8*)(op + l * P * 2);     // P == 4: the 4 (x, y) pairs of this level
+      const half4 l4 = *(const half4*)(lg + l * P);         // ... and their 4 logits
+      // branch-free gather: every corner address is clamped into the level and loaded unconditionally, corners outside the
+      // map / the valid rectangle get weight 0.  (With one guarded load per corner the compiler emitted branch + s_waitcnt
+      // vmcnt(0) after each of them -- 64 serialised L2 round trips per query, 14.3 ms per forward at B = 16.)
+      float cw[P][4];
+      unsigned ca[P][4];
 #pragma unroll
       for (int pt = 0; pt < P; ++pt) {
-        const float loc_w = rx + (float)o8[2 * pt] * sx, loc_h = ry + (float)o8[2 * pt + 1] * sy, wgt = w[l * P + pt];
+        const float loc_w = rx + (float)o8[2 * pt] * sx, loc_h = ry + (float)o8[2 * pt + 1] * sy;
+        float wgt = __expf((float)l4[pt] - mx) * inv;
         const float h = loc_h * (float)H - 0.5f, wq = loc_w * (float)W - 0.5f;
-        if (h > -1.f && wq > -1.f && h < (float)H && wq < (float)W) {
-          const int hl = (int)floorf(h), wl = (int)floorf(wq), hh = hl + 1, wh = wl + 1;
-          const float lh = h - (float)hl, lw = wq - (float)wl, uh = 1.f - lh, uw = 1.f - lw;
-          float v1[4] = {0.f, 0.f, 0.f, 0.f}, v2[4] = {0.f, 0.f, 0.f, 0.f}, v3[4] = {0.f, 0.f, 0.f, 0.f}, v4[4] = {0.f, 0.f, 0.f, 0.f};
-          auto ld = [&](int y, int x, float* dst) {
-            const TV* a = vb + y * hs + x * ws;
-            if constexpr (sizeof(TV) == 2) {
-              const half4 t = *(const half4*)a;
+        if (!(h > -1.f && wq > -1.f && h < (float)H && wq < (float)W)) wgt = 0.f;
+        const float hf = floorf(h), wf = floorf(wq);
+        const int hl = (int)hf, wl = (int)wf, hh = hl + 1, wh = wl + 1;
+        const float lh = h - hf, lw = wq - wf, uh = 1.f - lh, uw = 1.f - lw;
+        const bool y0 = hl >= 0 && hl < Hv, y1 = hh >= 0 && hh < Hv, x0 = wl >= 0 && wl < Wv, x1 = wh >= 0 && wh < Wv;
+        cw[pt][0] = (y0 && x0) ? uh * uw * wgt : 0.f;
+        cw[pt][1] = (y0 && x1) ? uh * lw * wgt : 0.f;
+        cw[pt][2] = (y1 && x0) ? lh * uw * wgt : 0.f;
+        cw[pt][3] = (y1 && x1) ? lh * lw * wgt : 0.f;
+        const unsigned yc0 = (unsigned)min(max(hl, 0), H - 1) * hs, yc1 = (unsigned)min(max(hh, 0), H - 1) * hs;
+        const unsigned xc0 = (unsigned)min(max(wl, 0), W - 1) * ws, xc1 = (unsigned)min(max(wh, 0), W - 1) * ws;
+        ca[pt][0] = yc0 + xc0 + lane_off; ca[pt][1] = yc0 + xc1 + lane_off;
+        ca[pt][2] = yc1 + xc0 + lane_off; ca[pt][3] = yc1 + xc1 + lane_off;
+      }
+      if constexpr (sizeof(TV) == 2) {
+        half4 cv[P][4];
 #pragma unroll
-              for (int j = 0; j < 4; ++j) dst[j] = (float)t[j];
-            } else {
-              const float4_ t = *(const float4_*)a;
+        for (int pt = 0; pt < P; ++pt)
 #pragma unroll
-              for (int j = 0; j < 4; ++j) dst[j] = t[j];
-            }
-          };
-          if (hl >= 0 && wl >= 0 && hl < Hv && wl < Wv) ld(hl, wl, v1);
-          if (hl >= 0 && wh <= Wv - 1 && hl < Hv) ld(hl, wh, v2);
-          if (hh <= Hv - 1 && wl >= 0 && wl < Wv) ld(hh, wl, v3);
-          if (hh <= Hv - 1 && wh <= Wv - 1) ld(hh, wh, v4);
-          const float w1 = uh * uw, w2 = uh * lw, w3 = lh * uw, w4 = lh * lw;
+          for (int q4 = 0; q4 < 4; ++q4) cv[pt][q4] = *(const half4*)(vb + ca[pt][q4]);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] += (w1 * v1[j] + w2 * v2[j] + w3 * v3[j] + w4 * v4[j]) * wgt;
-        }
+        for (int pt = 0; pt < P; ++pt)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += cw[pt][q4] * (float)cv[pt][q4][j];
+      } else {
+        float4_ cv[P][4];
+#pragma unroll
+        for (int pt = 0; pt < P; ++pt)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) cv[pt][q4] = *(const float4_*)(vb + ca[pt][q4]);
+#pragma unroll
+        for (int pt = 0; pt < P; ++pt)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += cw[pt][q4] * cv[pt][q4][j];
       }
     }
-    TO* o = out + bq * (long)(M * D) + m * D + c;
+    TO* o = out + (long)bq * (M * D) + m * D + c;
     if constexpr (sizeof(TO) == 2) {
       half4 t;
 #pragma unroll
@@ -208,11 +241,13 @@ extern "C" int mq_msdeform_attn_q_fwd(const void* value, int value_f32, long val
                                       void* stream) {
   if (B <= 0 || Q <= 0) return 0;
   if (D % 4 || M <= 0 || L != 4 || P != 4 || (ref_dim != 2 && ref_dim != 4) || (value_ts % 4) || (value_bs % 4)) return -1;
-  const dim3 grid((unsigned)(((long)B * Q + 3) / 4));
+  static const int xcd_order = [] { const char* e = getenv("MQ_MSDA_ORDER"); return (e && e[0] == '0') ? 0 : 1; }();   // A/B switch
+  const long nblk = ((long)B * Q + 3) / 4;
+  const dim3 grid((unsigned)(xcd_order ? 8 * ((nblk + 7) / 8) : nblk));
   hipStream_t s = (hipStream_t)stream;
 #define MQ_MSDAQ(TV, TO, RD)                                                                                             \
   hipLaunchKernelGGL((msda_q_kernel<TV, TO, 4, 4, RD>), grid, dim3(256), 0, s, (const TV*)value, value_bs, value_ts, shapes,  \
-                     level_start, (const half_t*)qproj, ref, valid_hw, (TO*)out, B, S, M, D, Q)
+                     level_start, (const half_t*)qproj, ref, valid_hw, (TO*)out, B, S, M, D, Q, xcd_order)
 #define MQ_MSDAQ_T(RD)                                       \
   if (value_f32 && out_f32) MQ_MSDAQ(float, float, RD);      \
   else if (value_f32) MQ_MSDAQ(float, half_t, RD);           \
