@@ -211,13 +211,16 @@ class GroundingDINO(GraphRunner, nn.Module):
         from .. import ops
         out = self._run("_program", inputs, self.use_hip_graph and not ops.timing_active())
         self.last_packed = packed = out["packed"].clone()
-        keep = out["keep"].cpu()                                   # the one device -> host sync of the forward
-        result = []
+        nz = out["keep"].nonzero()                                 # [n, 2] (image, query) in query order: the one device -> host
+        counts = torch.bincount(nz[:, 0], minlength=Bn).tolist()   # sync of the forward
+        sel = packed[nz[:, 0], nz[:, 1]]
+        result, s0 = [], 0
         for b, (h, w) in enumerate(sizes):
-            sel = packed[b][keep[b].to(dev)]
-            bl = BoxList(sel[:, :4].clone(), (int(w), int(h)), mode="xyxy")
-            bl.add_field("labels", sel[:, 5].to(torch.int64))
-            bl.add_field("scores", sel[:, 4].clone())
+            part = sel[s0:s0 + counts[b]]
+            s0 += counts[b]
+            bl = BoxList(part[:, :4].clone(), (int(w), int(h)), mode="xyxy")
+            bl.add_field("labels", part[:, 5].to(torch.int64))
+            bl.add_field("scores", part[:, 4].clone())
             result.append(bl)
         if return_backbone_features:
             s0, feats = 0, []

@@ -531,7 +531,17 @@ def forward_device(P, cfg, SW, x, geo, txt, vision, idx, class_map, im_hw, max_k
     """The device program: pixels [B,3,H,W] fp16 (channels_last) -> packed detections.  No host synchronisation inside."""
     G = cfg.GROUNDINGDINO
     _mark("start")
+    # the BERT layers below the first GCP block do not depend on the image: on a side stream under the Swin backbone
+    # (B x 256 tokens per launch: they would otherwise run alone on a nearly empty chip)
+    side = None
+    if front is None and x.is_cuda and _MARKS is None and G.get("text_stream", True):
+        main, side = torch.cuda.current_stream(), pipeline._side_streams(x.device, 1, "text")[0]
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            front = language_front(P, cfg, txt, vision is not None)
     feats = pipeline.swin_forward(P, cfg, x, p="backbone.0", SW=SW)
+    if side is not None:
+        main.wait_stream(side)
     _mark("swin")
     src32 = input_projections(P, cfg, feats)
     _mark("input_proj")
