@@ -523,7 +523,9 @@ def convert(prob, boxes, class_map, nan_labels, im_hw, box_threshold):
     x1, y1 = xy1[..., 0].clamp(min=0), xy1[..., 1].clamp(min=0)
     x1, y1 = torch.minimum(x1, W - 1), torch.minimum(y1, H - 1)
     x2, y2 = torch.minimum(xy2[..., 0].clamp(min=0), W - 1), torch.minimum(xy2[..., 1].clamp(min=0), H - 1)
-    packed = torch.stack([x1, y1, x2, y2, sc, (lab + 1).float()], -1)
+    # queries below the threshold carry score -1: the fixed-shape tensor can then cross ranks as it is
+    # (parallel.gather_detections / unpack_detections keep the rows with score > 0)
+    packed = torch.stack([x1, y1, x2, y2, torch.where(keep, sc, torch.full_like(sc, -1.0)), (lab + 1).float()], -1)
     return packed, keep
 
 

@@ -147,3 +147,27 @@ def test_text_enhancer_mask_quirk_for_different_captions():
     rep = (~attn[:, :256, :256]).repeat(4, 1, 1).view(2, 4, 256, 256)          # what torch's MHA sees: index b*4 + h
     assert torch.equal(txt["enh_mask"].bool(), rep)
     assert max_kv == 8
+
+
+def test_convert_marks_dropped_queries_for_the_cross_rank_gather():
+    """`convert` keeps the [B, nq, 6] shape (one fixed-shape all-gather across ranks): dropped queries get score -1, which is what
+    parallel.unpack_detections filters on; kept rows equal the oracle's conversion."""
+    from mq_det_amd import parallel
+    g = torch.Generator().manual_seed(3)
+    prob = torch.sigmoid(torch.randn(2, 30, 256, generator=g) * 2.0 - 5.0)
+    boxes = torch.rand(2, 30, 4, generator=g) * torch.tensor([1.0, 1.0, 0.6, 0.6])
+    pmap = {1: [1, 2], 2: [4], 5: [6, 7, 8]}
+    cmap = torch.zeros(256, 80)
+    for lab, toks in pmap.items():
+        cmap[toks, lab - 1] = 1.0 / len(toks)
+    sizes = [(128, 130), (100, 160)]
+    packed, keep = gp.convert(prob, boxes, cmap, False, torch.tensor(sizes, dtype=torch.float32), 0.05)
+    ref = og.convert_to_glip_output(prob, boxes, pmap, sizes, 81, 0.05)
+    dets = parallel.unpack_detections(packed)
+    for b in range(2):
+        assert 0 < int(keep[b].sum()) < 30 and bool((packed[b, ~keep[b], 4] == -1).all())
+        close(dets[b]["boxes"], ref[b][0], tol=1e-5)
+        close(dets[b]["scores"], ref[b][1], tol=1e-6)
+        assert torch.equal(dets[b]["labels"], ref[b][2])
+    packed, keep = gp.convert(prob, boxes, cmap, True, torch.tensor(sizes, dtype=torch.float32), 0.05)    # empty-label quirk
+    assert not bool(keep.any()) and all(len(d["boxes"]) == 0 for d in parallel.unpack_detections(packed))
