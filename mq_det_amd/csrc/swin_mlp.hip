@@ -24,6 +24,7 @@
 //   * epilogue: + bias + residual in fp32, optional fused LayerNorm of the result (row statistics by two wave shuffles).
 // Algorithmic HBM bytes per token: C * (4 + 2 + 4 [+ 2]) vs ~40 C in the unfused form.  MFMA work 16 M C^2.
 #include "common.h"
+#include <type_traits>
 #include <cstdlib>
 
 struct SwinMlpParams {
@@ -97,50 +98,58 @@ __global__ __launch_bounds__(64 * NW) void swin_mlp_kernel(SwinMlpParams p) {
   // ---- prologue: LayerNorm straight into MFMA B-fragments.  Lane (g, token l15) loads x[token][32 ks + 8 g .. + 7] -- the
   // four g-lanes of a token cover 128 contiguous bytes per ks, a full cache line -- so a row lives in 4 lanes: statistics
   // are an in-lane sum plus two shuffles, and the normalised values already sit where the first MFMA wants them.
+  // All loads of a token block are issued before anything consumes them: rows beyond M are clamped (their results are never
+  // stored) and the optional delta is a wave-uniform choice made OUTSIDE the loop -- with `if (live)` / `if (p.delta)` inside it
+  // every k-step was its own basic block ending in s_waitcnt vmcnt(0): KS serialised HBM round trips per wave (ISA of v2).
   half8 xf[T][KS];
+  auto prologue = [&](auto HAS_DELTA) {
+    constexpr bool has_delta = decltype(HAS_DELTA)::value;
 #pragma unroll
-  for (int tb = 0; tb < T; ++tb) {
-    const long row = row0 + tb * 16 + l15;
-    const bool live = row < p.M;
-    float v[KS][8];
-    float s = 0.f;
+    for (int tb = 0; tb < T; ++tb) {
+      const long row = min(row0 + tb * 16 + l15, p.M - 1);
+      const float* xr = p.x + row * C + g * 8;
+      float4_ va[KS], vb[KS];
+      half8 vd[has_delta ? KS : 1];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int c = ks * 32 + g * 8;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[ks][j] = 0.f;
-      if (live) {
-        const float4_ a = *(const float4_*)(p.x + row * C + c), b = *(const float4_*)(p.x + row * C + c + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { v[ks][j] = a[j]; v[ks][4 + j] = b[j]; }
-        if (p.delta) {
-          const half8 d = *(const half8*)(p.delta + row * C + c);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[ks][j] += (float)d[j];
-        }
+      for (int ks = 0; ks < KS; ++ks) {
+        va[ks] = *(const float4_*)(xr + ks * 32);
+        vb[ks] = *(const float4_*)(xr + ks * 32 + 4);
+        if constexpr (has_delta) vd[ks] = *(const half8*)(p.delta + row * C + ks * 32 + g * 8);
       }
+      float v[KS][8];
+      float s = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += v[ks][j];
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[ks][j] = va[ks][j]; v[ks][4 + j] = vb[ks][j]; }
+        if constexpr (has_delta) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[ks][j] += (float)vd[ks][j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[ks][j];
+      }
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      const float mean = s * (1.f / (float)C);
+      float q = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = v[ks][j] - mean; q += d * d; }
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      const float rstd = rsqrtf(q * (1.f / (float)C) + p.eps);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int c = ks * 32 + g * 8;
+        const half8 gm = *(const half8*)(p.g2 + c), bt = *(const half8*)(p.be2 + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xf[tb][ks][j] = (half_t)((v[ks][j] - mean) * rstd * (float)gm[j] + (float)bt[j]);
+      }
     }
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    const float mean = s * (1.f / (float)C);
-    float q = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { const float d = v[ks][j] - mean; q += d * d; }
-    q += __shfl_xor(q, 16);
-    q += __shfl_xor(q, 32);
-    const float rstd = rsqrtf(q * (1.f / (float)C) + p.eps);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int c = ks * 32 + g * 8;
-      const half8 gm = *(const half8*)(p.g2 + c), bt = *(const half8*)(p.be2 + c);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) xf[tb][ks][j] = (half_t)((v[ks][j] - mean) * rstd * (float)gm[j] + (float)bt[j]);
-    }
-  }
+  };
+  if (p.delta) prologue(std::true_type{}); else prologue(std::false_type{});
 
   float4_ acc2[T][CT];
 #pragma unroll
@@ -210,22 +219,38 @@ __global__ __launch_bounds__(64 * NW) void swin_mlp_kernel(SwinMlpParams p) {
     const long row = row0 + tb * 16 + l15;
     const bool live = row < p.M;
     float s = 0.f;
+    // residual x' = x (+ delta), re-read L2-hot, in groups of EG channel blocks: the loads of a group are all in flight before
+    // the first add / store (one load -> wait -> store chain per block before: `out` may alias `x`, so the compiler could not
+    // move a load above the previous store -- a lane only ever re-reads the addresses it writes itself, which makes it safe here)
+    constexpr int EG = 6;                                  // CT = C / 16 = 6, 12, 24
+    static_assert(CT % EG == 0, "channel blocks per group");
+    const long rrow = min(row, p.M - 1);
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      const int c = ct * 16 + 4 * g;
-      const half4 b2 = *(const half4*)(p.b2 + c);
-      float4_ xr = (float4_){0.f, 0.f, 0.f, 0.f};
-      if (live) {
-        xr = *(const float4_*)(p.x + row * C + c);
-        if (p.delta) {
-          const half4 d = *(const half4*)(p.delta + row * C + c);
+    for (int ct0 = 0; ct0 < CT; ct0 += EG) {
+      float4_ xr[EG];
+      half4 dl[EG], b2[EG];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) xr[r] += (float)d[r];
-        }
+      for (int i = 0; i < EG; ++i) {
+        const int c = (ct0 + i) * 16 + 4 * g;
+        xr[i] = *(const float4_*)(p.x + rrow * C + c);
+        b2[i] = *(const half4*)(p.b2 + c);
+      }
+      if (p.delta) {
+#pragma unroll
+        for (int i = 0; i < EG; ++i) dl[i] = *(const half4*)(p.delta + rrow * C + (ct0 + i) * 16 + 4 * g);
+      } else {
+#pragma unroll
+        for (int i = 0; i < EG; ++i) dl[i] = (half4){(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { acc2[tb][ct][r] += (float)b2[r] + xr[r]; s += acc2[tb][ct][r]; }
-      if (live) *(float4_*)(p.out + row * C + c) = acc2[tb][ct];
+      for (int i = 0; i < EG; ++i) {
+        const int ct = ct0 + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc2[tb][ct][r] += (float)b2[i][r] + (xr[i][r] + (float)dl[i][r]); s += acc2[tb][ct][r]; }
+      }
+#pragma unroll
+      for (int i = 0; i < EG; ++i)
+        if (live) *(float4_*)(p.out + row * C + (ct0 + i) * 16 + 4 * g) = acc2[tb][ct0 + i];
     }
     if (p.y) {                                                 // fused LayerNorm of the result (next norm1 / stage norm)
       s += __shfl_xor(s, 16);

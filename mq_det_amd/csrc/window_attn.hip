@@ -66,34 +66,45 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinParams p) {
     return ry * 3 + rx;
   };
 
-  // ---- the 4 tokens this lane addresses (token = blk*16 + l15): K / Q fragments, V chunk, output pixel
+  // ---- the NB tokens this lane addresses (token = blk*16 + l15): K / Q fragments, V chunk, output pixel.
+  // All 3*NB 16-byte loads are issued back to back BEFORE anything consumes them (addresses first, then loads, then the LDS
+  // stores of V): written as one loop, the compiler kept the per-block order load -> wait -> ds_write, i.e. NB serialised
+  // round trips to HBM / L2 per wave (ISA of v2: s_waitcnt vmcnt(2) after every third load).
   half8 qf[NB], kf[NB];
   long out_off[NB];                                        // element offset of the token's output row, -1: pad / beyond N
   int region_q[NB];
+  {
+    const half_t* rows[NB];
 #pragma unroll
-  for (int blk = 0; blk < NB; ++blk) {
-    const int i = blk * 16 + l15, ii = min(i, N - 1);
-    const int ys = wy * p.ws + ii / p.ws, xs = wx * p.ws + ii % p.ws;       // coords in the shifted frame
-    int y = ys + p.shift; if (y >= p.Hp) y -= p.Hp;                       // shifted[ys] = x[(ys+shift) % Hp]
-    int x = xs + p.shift; if (x >= p.Wp) x -= p.Wp;
-    const bool real = (y < p.H) && (x < p.W);
-    const half_t* row = real ? p.qkv + (((long)b * p.H + y) * p.W + x) * (3 * p.C) : p.qkv_bias;
-    qf[blk] = *(const half8*)(row + head * 32 + lg * 8);
-    kf[blk] = *(const half8*)(row + p.C + head * 32 + lg * 8);
-    const half8 v = *(const half8*)(row + 2 * p.C + head * 32 + lg * 8);
-    *(half8*)(Vs + i * VP + lg * 8) = v;                   // keys >= N hold a copy of key N-1: finite, weight exactly 0
-    out_off[blk] = (real && i < N) ? (((long)b * p.H + y) * p.W + x) * p.C + head * 32 : -1;
-    region_q[blk] = region_of(i);
+    for (int blk = 0; blk < NB; ++blk) {
+      const int i = blk * 16 + l15, ii = min(i, N - 1);
+      const int ys = wy * p.ws + ii / p.ws, xs = wx * p.ws + ii % p.ws;     // coords in the shifted frame
+      int y = ys + p.shift; if (y >= p.Hp) y -= p.Hp;                     // shifted[ys] = x[(ys+shift) % Hp]
+      int x = xs + p.shift; if (x >= p.Wp) x -= p.Wp;
+      const bool real = (y < p.H) && (x < p.W);
+      const long tok = ((long)b * p.H + y) * p.W + x;
+      rows[blk] = (real ? p.qkv + tok * (3 * p.C) : p.qkv_bias) + head * 32 + lg * 8;
+      out_off[blk] = (real && i < N) ? tok * p.C + head * 32 : -1;
+      region_q[blk] = region_of(i);
+    }
+    half8 vv[NB];
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+      vv[blk] = *(const half8*)(rows[blk] + 2 * p.C);
+      qf[blk] = *(const half8*)(rows[blk]);
+      kf[blk] = *(const half8*)(rows[blk] + p.C);
+    }
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk)                     // keys >= N hold a copy of key N-1: finite, weight exactly 0
+      *(half8*)(Vs + (blk * 16 + l15) * VP + lg * 8) = vv[blk];
   }
 
   int region_k[NB];                                        // four 4-bit region ids per 16-key block
-  if (p.shift > 0) {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      region_k[nb] = 0;
+  for (int nb = 0; nb < NB; ++nb) {
+    region_k[nb] = 0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) region_k[nb] |= region_of(nb * 16 + 4 * lg + r) << (4 * r);
-    }
+    for (int r = 0; r < 4; ++r) region_k[nb] |= region_of(nb * 16 + 4 * lg + r) << (4 * r);
   }
   const float* rel = p.rel_bias + (long)head * NP * NP;
   wave_lds_fence();                                        // V tile written by this wave's own lanes
@@ -105,15 +116,20 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinParams p) {
     float4_ s[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) s[nb] = mfma16(kf[nb], qf[qb], (float4_){0.f, 0.f, 0.f, 0.f});
+    // the NB bias rows of this query block: all loads first (they were consumed one by one behind a wave-uniform branch on
+    // `shift`, which cut the loop into basic blocks and put an s_waitcnt vmcnt(0) behind every load)
     const float* relq = rel + (qb * 16 + l15) * NP + 4 * lg;
+    float4_ rb[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) rb[nb] = *(const float4_*)(relq + nb * 16);
+    const float pen = p.shift > 0 ? -100.0f : 0.0f;         // SW-MSA penalty, applied branch-free
     float mx = MQ_NEG_BIG;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      const float4_ rb = *(const float4_*)(relq + nb * 16);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = s[nb][r] * p.scale + rb[r];
-        if (p.shift > 0 && ((region_k[nb] >> (4 * r)) & 15) != region_q[qb]) v += -100.0f;
+        float v = s[nb][r] * p.scale + rb[nb][r];
+        v += (((region_k[nb] >> (4 * r)) & 15) != region_q[qb]) ? pen : 0.0f;
         if (nb * 16 + 4 * lg + r >= N) v = MQ_NEG_BIG;
         s[nb][r] = v;
         mx = fmaxf(mx, v);
