@@ -183,6 +183,8 @@ def main_gdino(args, rank, world, dev):
                "stages_ms_per_step": {k: round(v / max(prof_steps, 1), 3) for k, v in stages.items()},
                "timing": "kernels_ms_per_step: HIP events around each hand-written launch in an eager pass of the same step; "
                          "stages_ms_per_step: HIP events between pipeline stages in an eager pass (host launch gaps included)"}
+        if world == 1 and args.cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(timeout=300, flag="--cpu-baseline-worker-gdino")
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.barrier()
@@ -227,13 +229,48 @@ def _cpu_baseline_worker():
                                 f"threads on a {os.cpu_count()}-core host"}), flush=True)
 
 
-def cpu_baseline(timeout=420):
+def _cpu_baseline_worker_gdino():
+    """The same for --workload mq-gdino-t: the CPU oracle of MQ-GroundingDINO-T (oracle/gdino.py, pinned to the reference's own
+    module) WITHOUT vision queries on one 800x1333 image with a 20-token caption; 1 warm-up + 3 timed forwards, median."""
+    from oracle import gdino as og
+    from oracle.spec import gdino_t_spec
+    from oracle.weights import make_gdino_state_dict
+    threads = min(os.cpu_count() or 1, CPU_BASELINE_THREADS)
+    torch.set_num_threads(threads)
+    spec = gdino_t_spec(vocab=30522, vision_query=False)
+    sd = make_gdino_state_dict(spec, 0)
+    g = torch.Generator().manual_seed(0)
+    H, W = IMG_HW
+    img = torch.zeros(1, 3, -(-H // 32) * 32, -(-W // 32) * 32)
+    img[:, :, :H, :W] = torch.randn(1, 3, H, W, generator=g)
+    ids = torch.zeros(1, 512, dtype=torch.long)
+    row = [101] + [2000 + i if (i + 1) % 3 else 1012 for i in range(18)] + [102]           # [CLS] w w . w w . ... [SEP]
+    ids[0, :len(row)] = torch.tensor(row)
+    am = (ids != 0).long()
+    pm = {k + 1: [1 + 3 * k, 2 + 3 * k] for k in range(6)}
+    times = []
+    t_all = time.time()
+    with torch.no_grad():
+        for i in range(4):
+            t = time.time()
+            og.forward(sd, spec, img, [(H, W)], ids, am, pm, [101, 102, 1012, 1029])
+            if i >= 1:
+                times.append(time.time() - t)
+    med = statistics.median(times)
+    print(json.dumps({"value": round(1.0 / med, 4), "unit": "images/sec", "cores": threads, "kind": "port",
+                      "median_s_per_forward": round(med, 3),
+                      "sample": f"MQ-GroundingDINO-T (no vision queries), one 800x1333 image (padded 800x1344), 20-token caption; 1 warm-up "
+                                f"+ 3 timed forwards of the fp32 CPU oracle, median; {time.time() - t_all:.1f} s in total, {threads} torch "
+                                f"threads on a {os.cpu_count()}-core host"}), flush=True)
+
+
+def cpu_baseline(timeout=420, flag="--cpu-baseline-worker"):
     """Run the worker in a subprocess with a hard time limit so the default bench run stays bounded."""
     import subprocess
     env = dict(os.environ, OMP_NUM_THREADS=str(CPU_BASELINE_THREADS), MKL_NUM_THREADS=str(CPU_BASELINE_THREADS),
                HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"], env=env,
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), flag], env=env,
                            capture_output=True, text=True, timeout=timeout)
         for line in reversed(r.stdout.strip().splitlines()):
             if line.startswith("{"):
@@ -403,9 +440,13 @@ def main():
                                                                 "through model.forward_chunks (0 = one forward per chunk)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (for PMC profiling)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-worker-gdino", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline", action="store_true", help="mq-gdino-t workload: also time the CPU oracle (off by default there)")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         return _cpu_baseline_worker()
+    if args.cpu_baseline_worker_gdino:
+        return _cpu_baseline_worker_gdino()
 
     from mq_det_amd import parallel
     from mq_det_amd import ops
