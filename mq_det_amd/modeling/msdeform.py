@@ -5,7 +5,9 @@ the deformable encoder layers transformer.py:482-596 and the decoder's cross-att
 operator behind it.  MI355X-first differences: the value projection's fp16 output is gathered directly (the reference casts
 value, locations and weights to fp32 first, :330-336), the sampling-offset and attention-weight projections are ONE GEMM, the
 gather kernel reads one contiguous 64-byte row per (head, corner) and accumulates in fp32.
-This is the first piece of BASELINE.json configs[4]; the surrounding GroundingDINO model is not built yet."""
+Operator-level form (materialised sampling locations, one module at a time): what the INTEGRATION.md stub for
+`groundingdino_new._C.ms_deform_attn_forward` binds.  The MQ-GroundingDINO model itself (modeling/gdino_pipeline.py) uses the
+fused-query kernel mq_msdeform_attn_q_fwd instead."""
 import torch
 import torch.nn.functional as F
 

@@ -998,7 +998,7 @@ def check_swin_mlp(dev):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-# MQ-GroundingDINO path, first piece: multi-scale deformable attention
+# MQ-GroundingDINO path: the multi-scale deformable attention operator (the model: tests/gdino_checks.py)
 def check_msdeform_attn(dev, golden_dir=None):
     """mq_msdeform_attn_fwd vs (1) the reference-generated fixture tests/golden/msda.npz, (2) the reference's own CUDA kernel
     (ms_deform_im2col_cuda.cuh:237-299 via oracle/build_ref.py) -- which also pins oracle.gdino.ms_deform_attn_core --,

@@ -177,3 +177,15 @@ def test_ctypes_signatures_match_header():
         res, got = ops._SIGNATURES[name]
         assert got == want, (name, got, want)
         assert res == {"int": ctypes.c_int, "long": ctypes.c_long}[ret], name
+
+
+def test_gather_kernels_keep_their_loads_in_flight():
+    """Static ISA check (tools/isa_wait_scan.py, no GPU): the MSDeformAttn and window-attention kernels must not fall back to
+    one `s_waitcnt vmcnt(0)` per global load -- the pattern that made the first MSDeformAttn kernel 2.3x slower."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_wait_scan
+    for f in ("msda.hip", "window_attn.hip"):
+        rows = isa_wait_scan.scan(os.path.join(ROOT, "mq_det_amd", "csrc", f))
+        assert rows, f
+        for name, loads, waits, immediate in rows:
+            assert immediate == 0, f"{f}: {name}: {immediate} of {loads} loads are waited on immediately"
