@@ -103,6 +103,7 @@ def build_gdino_model(dev, n_classes=NUM_CLASSES_IN_CAPTION):
     from mq_det_amd.utils.synth import randomize_, synthetic_bank
     from mq_det_amd.utils.tokenizer import build_synthetic_tokenizer, synthetic_caption, positive_map_from_spans
     cfg = get_gdino_cfg()
+    cfg.MODEL.BACKBONE_CACHE = False          # every step a full forward (the synthetic loop re-sends the same tensor)
     cfg.GROUNDINGDINO.text_encoder_type = build_synthetic_tokenizer(tempfile.mkdtemp(prefix="mqdet_tok_"))
     model = build_detection_model(cfg)
     randomize_(model, seed=0)

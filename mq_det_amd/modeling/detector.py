@@ -37,6 +37,35 @@ def expand_bbox(box_list, expand_ratio=1.5):
     return out
 
 
+def pool_into_bank(cfg, pooler, visual_features, targets, query_images, exclude_similar, max_query_number):
+    """Shared tail of `extract_query` (generalized_vl_rcnn_new.py:264-288 == groundingdino.py:397-421): ROI-pool the (already
+    expanded) target boxes -- from their own FPN level (SELECT_FPN_LEVEL) or from all five --, average the bins inside the kernel,
+    and append the features to the bank of their label up to `max_query_number`, optionally skipping near-duplicates."""
+    query_feats = pooler(visual_features, targets, reduce_mean=True)                # [boxes, C] or [scales, boxes, C]
+    if cfg.VISION_QUERY.SELECT_FPN_LEVEL:
+        query_feats = query_feats[None]
+    else:
+        assert len(visual_features) == len(query_feats) == 5
+    query_feats = query_feats.permute(1, 0, 2)                                      # boxes, scales, channels
+    labels = torch.cat([t.get_field("labels") for t in targets])
+    assert len(labels) == len(query_feats)
+    max_query_number = cfg.VISION_QUERY.MAX_QUERY_NUMBER if max_query_number is None else max_query_number
+    thr = cfg.VISION_QUERY.SIMILARITY_THRESHOLD
+    for label, feat in zip(labels.tolist(), query_feats):
+        cur = query_images[label] if (label in query_images or hasattr(query_images, "default_factory")) else []
+        n = len(cur)
+        if n >= max_query_number:
+            continue
+        if exclude_similar and n > 0:
+            assert feat.shape[0] == 1
+            bank = torch.nn.functional.normalize(cur.to(feat), p=2, dim=-1)
+            new = torch.nn.functional.normalize(feat, p=2, dim=-1)
+            if (torch.einsum("bnd,nd->bn", bank, new) > thr).sum() > 0:
+                continue
+        query_images[label] = feat[None] if n == 0 else torch.cat([cur.to(feat), feat[None]])
+    return query_images
+
+
 class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
     def __init__(self, cfg, tokenizer=None, **kwargs):
         super().__init__()
@@ -165,29 +194,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
             visual_features, _ = self._backbone_stage(x)
         else:
             visual_features = [v.to(device) for v in visual_features]
-        query_feats = self.pooler(visual_features, targets, reduce_mean=True)      # [boxes, C] or [scales, boxes, C]
-        if cfg.VISION_QUERY.SELECT_FPN_LEVEL:
-            query_feats = query_feats[None]
-        else:
-            assert len(visual_features) == len(query_feats) == 5
-        query_feats = query_feats.permute(1, 0, 2)                                  # boxes, scales, channels
-        labels = torch.cat([t.get_field("labels") for t in targets])
-        assert len(labels) == len(query_feats)
-        max_query_number = cfg.VISION_QUERY.MAX_QUERY_NUMBER if max_query_number is None else max_query_number
-        thr = cfg.VISION_QUERY.SIMILARITY_THRESHOLD
-        for label, feat in zip(labels.tolist(), query_feats):
-            cur = query_images[label] if (label in query_images or hasattr(query_images, "default_factory")) else []
-            n = len(cur)
-            if n >= max_query_number:
-                continue
-            if exclude_similar and n > 0:
-                assert feat.shape[0] == 1
-                bank = torch.nn.functional.normalize(cur.to(feat), p=2, dim=-1)
-                new = torch.nn.functional.normalize(feat, p=2, dim=-1)
-                if (torch.einsum("bnd,nd->bn", bank, new) > thr).sum() > 0:
-                    continue
-            query_images[label] = feat[None] if n == 0 else torch.cat([cur.to(feat), feat[None]])
-        return query_images
+        return pool_into_bank(cfg, self.pooler, visual_features, targets, query_images, exclude_similar, max_query_number)
 
     def flatten_fpn_features(self, features):
         return pipeline.pooled_fpn_tokens(features)

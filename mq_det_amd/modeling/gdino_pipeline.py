@@ -529,9 +529,15 @@ def convert(prob, boxes, class_map, nan_labels, im_hw, box_threshold):
     return packed, keep
 
 
-def forward_device(P, cfg, SW, x, geo, txt, vision, idx, class_map, im_hw, max_kv=0, nan_labels=False, front=None, trace=None):
-    """The device program: pixels [B,3,H,W] fp16 (channels_last) -> packed detections.  No host synchronisation inside."""
+def forward_device(P, cfg, SW, x, geo, txt, vision, idx, class_map, im_hw, max_kv=0, nan_labels=False, front=None, trace=None,
+                   src32=None):
+    """The device program: pixels [B,3,H,W] fp16 (channels_last) -> packed detections.  No host synchronisation inside.
+    src32 [B, S, 256] fp32: the projected levels of a previous call with the same pixels (the evaluation loop sends every image
+    once per chunk caption, engine/inference.py:605-625) -- Swin and the input projections are then skipped, `x` is ignored."""
     G = cfg.GROUNDINGDINO
+    if src32 is not None:
+        return _forward_from_src(P, cfg, src32, P["backbone.0.patch_embed.proj.weight"].dtype, geo, txt, vision, idx, class_map, im_hw,
+                                 max_kv, nan_labels, front, trace)
     _mark("start")
     # the BERT layers below the first GCP block do not depend on the image: on a side stream under the Swin backbone
     # (B x 256 tokens per launch: they would otherwise run alone on a nearly empty chip)
@@ -547,7 +553,11 @@ def forward_device(P, cfg, SW, x, geo, txt, vision, idx, class_map, im_hw, max_k
     _mark("swin")
     src32 = input_projections(P, cfg, feats)
     _mark("input_proj")
-    dt = x.dtype
+    return _forward_from_src(P, cfg, src32, x.dtype, geo, txt, vision, idx, class_map, im_hw, max_kv, nan_labels, front, trace)
+
+
+def _forward_from_src(P, cfg, src32, dt, geo, txt, vision, idx, class_map, im_hw, max_kv, nan_labels, front, trace):
+    G = cfg.GROUNDINGDINO
     images = None
     if vision is not None:                                     # flatten_fpn_features (groundingdino.py:423-425)
         views, s0 = [], 0

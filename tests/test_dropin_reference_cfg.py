@@ -213,6 +213,13 @@ def test_groundingdino_reference_cfg_and_caller_sequence(monkeypatch):
         output = model(images, captions=[all_queries[0]], positive_map=all_maps[0])
         output = [o.to(torch.device("cpu")) for o in output][0]
         res, feats = model(images, captions=[all_queries[0]], positive_map=all_maps[0], return_backbone_features=True)
+        # second call with the same pixels: Swin + input projections come from the per-image cache, same result
+        assert model.cache_stats["backbone_miss"] == 1 and model.cache_stats["backbone_hit"] == 1
+        assert len(res[0]) == len(output) and torch.equal(res[0].bbox, output.bbox)
+        assert torch.equal(res[0].get_field("scores"), output.get_field("scores"))
+        images.tensors.add_(0.0)                                   # an in-place write bumps the version counter: cache miss
+        model(images, captions=[all_queries[0]], positive_map=all_maps[0])
+        assert model.cache_stats["backbone_miss"] == 2
         output = fns["resize_box"](output, targets)
     scores, labels, boxes = output.extra_fields["scores"], output.extra_fields["labels"], output.bbox
     assert scores.dtype == torch.float32 and labels.dtype == torch.int64 and 0 < len(scores) <= spec.num_queries
