@@ -91,7 +91,7 @@ def adapt_bert(model):
     bert.get_extended_attention_mask = ext_mask
 
 
-def run_case(model, g, images, sizes, caption, pmap, bank, name, spec):
+def run_case(model, g, images, sizes, caption, pmap, bank, name, spec, captions=None):
     ns = g.base
     rec = {}
 
@@ -110,7 +110,7 @@ def run_case(model, g, images, sizes, caption, pmap, bank, name, spec):
         model.query_selector.query_bank = bank
     il = ns.image_list.ImageList(images, sizes)
     with torch.no_grad():
-        out = model(il, captions=[caption] * images.shape[0], positive_map=pmap)
+        out = model(il, captions=captions or [caption] * images.shape[0], positive_map=pmap)
     for h in hs:
         h.remove()
     feats, poss = rec["backbone"]
@@ -172,6 +172,13 @@ def main():
     img[0, :, :128, :130] = torch.randn(3, 128, 130).half().float()
     img[1, :, :100, :160] = torch.randn(3, 100, 160).half().float()
     run_case(model, g, img, [(128, 130), (100, 160)], caption, pmap, None, "gdino_text", spec)
+    # B2: two DIFFERENT captions in one batch: pins the text enhancer's `src_mask.repeat(nhead, 1, 1)` (transformer_vanilla.py:
+    # 108-109), which hands head (b, h) the sub-sentence mask of batch element (b * nhead + h) % B
+    cap2, spans2 = synthetic_caption(7, start=40, words=(3, 1, 2))
+    cap2 = cap2 + "."
+    tok2 = model.tokenizer([caption, cap2], padding="max_length", return_tensors="pt")
+    run_case(model, g, img, [(128, 130), (100, 160)], caption, pmap, None, "gdino_text2", spec, captions=[caption, cap2])
+    save("gdino_meta2", input_ids=tok2["input_ids"].to(torch.int32), attention_mask=tok2["attention_mask"].to(torch.int8))
     # C: the output conversion alone (groundingdino.py:291-335) on seeded scores / boxes, incl. its NaN quirk: a label with an
     # empty token list makes `logits[..., []].mean(-1)` NaN, `box_cls.max(-1)` NaN for EVERY query, so nothing passes the threshold
     gen = torch.Generator().manual_seed(7)

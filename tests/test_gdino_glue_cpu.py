@@ -171,3 +171,39 @@ def test_convert_marks_dropped_queries_for_the_cross_rank_gather():
         assert torch.equal(dets[b]["labels"], ref[b][2])
     packed, keep = gp.convert(prob, boxes, cmap, True, torch.tensor(sizes, dtype=torch.float32), 0.05)    # empty-label quirk
     assert not bool(keep.any()) and all(len(d["boxes"]) == 0 for d in parallel.unpack_detections(packed))
+
+
+def test_gdino_pipeline_two_different_captions(emulated_ops):
+    """B = 2 with different captions (text only): the product's expanded [B, heads, T, T] text-enhancer mask reproduces the
+    reference's `mask.repeat(nhead)` indexing, end to end against the oracle (pinned to the reference module on this very
+    situation by tests/test_oracle_golden.py::...[gdino_text2])."""
+    spec = tiny_gdino_spec(vision_query=False)
+    sd = make_gdino_state_dict(tiny_gdino_spec(), seed=0)
+    cfg = gdino_cfg(spec)
+    SW = gdino_swin_cfg(cfg)
+    dev = torch.device("cpu")
+    P = gp.build_gdino_plan(sd, cfg, dev, SW, dtype=torch.float32)
+    sizes = [(128, 130), (100, 160)]
+    img, ids, am, pmap, special = make_case(spec, 2, sizes)
+    row = [101, 1300, 1012, 1301, 1302, 1303, 1012, 1304, 1305, 1012, 1306, 1012, 102]      # other sub-sentence lengths
+    ids[1] = 0
+    ids[1, :len(row)] = torch.tensor(row)
+    am = (ids != 0).long()
+    with torch.no_grad():
+        o = og.forward(sd, spec, img, sizes, ids, am, pmap, special, None)
+        geo = gp.geometry(P, cfg, img.shape[2], img.shape[3], sizes, dev)
+        txt, max_kv = gp.text_inputs(cfg, ids, am, special, dev)
+        assert txt["enh_mask"].shape == (2, 4, 256, 256) and not torch.equal(txt["enh_mask"][0, 0], txt["enh_mask"][0, 1])
+        cmap = torch.zeros(256, spec.num_classes - 1)
+        for lab, toks in pmap.items():
+            cmap[toks, lab - 1] = 1.0 / len(toks)
+        trace = {}
+        gp.forward_device(P, cfg, SW, img.contiguous(memory_format=torch.channels_last), geo, txt, None, None, cmap,
+                          torch.tensor(sizes, dtype=torch.float32), max_kv=max_kv, trace=trace)
+    for b in range(2):
+        n = int(am[b].sum())
+        close(trace["memory_text"][b, :n], o["memory_text"][b, :n])
+    close(trace["memory"], o["memory"])
+    assert torch.equal(trace["topk"], o["topk"])
+    close(trace["pred_logits"], o["pred_logits"])
+    close(trace["pred_boxes"], o["pred_boxes"])
