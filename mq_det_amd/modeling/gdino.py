@@ -156,7 +156,7 @@ class GroundingDINO(GraphRunner, nn.Module):
         """[T, C] fp32: column label-1 holds 1/len over the label's tokens (convert_grounding_to_od_logits, MEAN);
         returns (map, has_empty_label)."""
         T, C = self.max_text_len, self.cfg.MODEL.DYHEAD.NUM_CLASSES - 1
-        key = (tuple((k, tuple(v)) for k, v in positive_map.items()), str(dev))
+        key = (tuple((k, (v,) if isinstance(v, int) else tuple(v)) for k, v in positive_map.items()), str(dev))
 
         def make():
             m = torch.zeros(T, C)
@@ -192,6 +192,11 @@ class GroundingDINO(GraphRunner, nn.Module):
             captions = kw["captions"]
         captions = [preprocess_caption(c) for c in captions]
         positive_map = kw["positive_map"]
+        # token positions cut away by the truncation to max_text_len cannot be scored (the reference would index past the
+        # [.., 256] token scores): dropped, like the MQ-GLIP class does
+        T = self.max_text_len
+        if any(t >= T for v in positive_map.values() for t in ([v] if isinstance(v, int) else v)):
+            positive_map = {k: [t for t in ([v] if isinstance(v, int) else v) if t < T] for k, v in positive_map.items()}
         return_backbone_features = kw.get("return_backbone_features", False)
         images = to_image_list(samples)
         dev = images.tensors.device

@@ -137,3 +137,42 @@ def test_oracle_nms_degenerate_inputs():
     b = torch.tensor([[0.0, 0.0, 9.0, 9.0], [0.0, 0.0, 9.0, 9.0]])
     assert sorted(op.ml_nms(b, torch.tensor([0.5, 0.6]), torch.tensor([1, 2]), 0.6).tolist()) == [0, 1]
     assert op.ml_nms(b, torch.tensor([0.5, 0.6]), torch.tensor([2, 2]), 0.6).tolist() == [1]
+
+
+def test_groundingdino_host_glue_edge_cases(tmp_path):
+    """MQ-GroundingDINO host side without a GPU: config validation by key name, class-score map (mean over a label's tokens,
+    empty label flagged, token positions beyond max_text_len dropped by forward), caption pre-processing, geometry of a batch
+    without padding and of one whose images are smaller than the padded canvas."""
+    import pytest
+    import torch
+    from mq_det_amd.config import get_gdino_cfg
+    from mq_det_amd.modeling import gdino, gdino_pipeline as gp
+    from mq_det_amd.utils.tokenizer import build_synthetic_tokenizer
+    cfg = get_gdino_cfg()
+    cfg.GROUNDINGDINO.text_encoder_type = build_synthetic_tokenizer(str(tmp_path), size=2048)
+    cfg.MODEL.LANGUAGE_BACKBONE.BERT_VOCAB_SIZE = 2048
+    cfg.GROUNDINGDINO.swin_depths, cfg.GROUNDINGDINO.enc_layers, cfg.GROUNDINGDINO.dec_layers = (2, 2, 2, 2), 1, 1
+    cfg.MODEL.LANGUAGE_BACKBONE.NUM_HIDDEN_LAYERS = 7
+    model = gdino.GroundingDINO(cfg)
+    assert gdino.preprocess_caption("  Cat. Dog ") == "cat. dog." and gdino.preprocess_caption("a.") == "a."
+    cmap, empty = model._class_map({1: [1, 2], 3: [5], 4: []}, torch.device("cpu"))
+    assert empty and cmap.shape == (256, 80) and float(cmap[1, 0]) == 0.5 and float(cmap[5, 2]) == 1.0 and float(cmap[:, 3].sum()) == 0.0
+    cmap, empty = model._class_map({2: 7}, torch.device("cpu"))                  # a single token given as an int
+    assert not empty and float(cmap[7, 1]) == 1.0
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        model.prepare(torch.device("cpu"))                                      # no CPU fallback
+    bad = get_gdino_cfg()
+    bad.GROUNDINGDINO.text_encoder_type = cfg.GROUNDINGDINO.text_encoder_type
+    bad.GROUNDINGDINO.two_stage_type = "no"
+    with pytest.raises(NotImplementedError, match="two_stage_type"):
+        gdino.GroundingDINO(bad)
+    with pytest.raises(NotImplementedError, match="inference forward only"):
+        model.train()
+    # geometry: no padding at all -> no key mask work; padded -> valid extents per level
+    P = {"level_embed32": torch.zeros(4, 256), "transformer.level_embed": torch.zeros(4, 256)}
+    g0 = gp.geometry(P, cfg, 128, 160, [(128, 160)], torch.device("cpu"))
+    assert not g0["any_pad"] and g0["shapes"] == ((16, 20), (8, 10), (4, 5), (2, 3)) and bool((g0["vr"] == 1).all())
+    g1 = gp.geometry(P, cfg, 128, 160, [(100, 160), (128, 90)], torch.device("cpu"))
+    assert g1["any_pad"] and g1["valid_hw"].tolist()[0][0] == [13, 20] and g1["valid_hw"].tolist()[1][0] == [16, 12]
+    assert torch.isinf(g1["proposals"][0][g1["mask"][0]]).all() and int(g1["key_mask"].shape[1]) % 64 == 0
+    assert gp.level_shapes(800, 1344, 4) == [(100, 168), (50, 84), (25, 42), (13, 21)]
