@@ -271,3 +271,55 @@ def test_groundingdino_benchmark_config(dev):
     """Full-depth MQ-GroundingDINO-T on one 800 x 1333 image, 40 classes x 5 vision queries, vs the fp32 oracle."""
     import gdino_checks as gc
     _assert(gc.check_gdino_benchmark_config(dev))
+
+
+# ------------------------------------------------------------------------------------------------ INTEGRATION.md stubs
+def _integration_stubs():
+    """The ctypes stubs of INTEGRATION.md section 2, executed as written (only the library path is filled in)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = [b for b in re.findall(r"```python\n(.*?)```", text, re.S) if "_lib" in b]
+    code = "\n".join(blocks).replace("/path/to/mq_det_amd/lib/libmqdet_hip.so", os.path.join(root, "mq_det_amd", "lib", "libmqdet_hip.so"))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    return ns
+
+
+def test_integration_md_operator_stubs_run_as_written(dev):
+    """VERDICT r1 (row b): the reference-side binding shown to a maintainer is executed, not only printed: `ml_nms`,
+    `modulated_deform_conv_forward`, `roi_align_forward`, `ms_deform_attn_forward` from INTEGRATION.md against the oracle."""
+    from oracle import gdino as og, head as ohead, postprocess as opost, roi as oroi
+    ns = _integration_stubs()
+    g = torch.Generator().manual_seed(91)
+    # _C.ml_nms
+    n = 300
+    xy = torch.rand(n, 2, generator=g) * 200
+    boxes = torch.cat([xy, xy + 20 + torch.rand(n, 2, generator=g) * 60], 1)
+    scores, labels = torch.rand(n, generator=g), torch.randint(1, 4, (n,), generator=g)
+    keep = ns["ml_nms"](boxes.to(dev), scores.to(dev), labels.to(dev), 0.6).cpu()
+    assert torch.equal(keep, opost.ml_nms(boxes, scores, labels, 0.6))
+    # _C.modulated_deform_conv_forward
+    x = torch.randn(2, 256, 20, 24, generator=g).half().float()
+    off = torch.randn(2, 18, 20, 24, generator=g) * 1.5
+    mask = torch.sigmoid(torch.randn(2, 9, 20, 24, generator=g))
+    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.02).half().float()
+    b = (torch.randn(256, generator=g) * 0.1).half().float()
+    y = ns["modulated_deform_conv_forward"](x.to(dev), off.to(dev), mask.to(dev), w.to(dev), b.to(dev), 1).float().cpu()
+    ref = ohead.dcn_v2(x, off, mask, w, b, 1)
+    assert float((y - ref).abs().max()) <= 4e-3 * max(1.0, float(ref.abs().max()))
+    # _C.roi_align_forward (ROIAlignV2)
+    feat = torch.randn(2, 64, 30, 40, generator=g)
+    rois = torch.tensor([[0, 3.0, 4.0, 30.0, 25.0], [1, 10.5, 2.25, 39.0, 29.0], [0, 0.0, 0.0, 8.0, 8.0]])
+    out = ns["roi_align_forward"](feat.to(dev), rois.to(dev), 0.25, 7, 7, 2, aligned=True).cpu()
+    torch.testing.assert_close(out, oroi.roi_align(feat, rois, 7, 0.25, 2, aligned=True), atol=1e-4, rtol=1e-4)
+    # groundingdino_new._C.ms_deform_attn_forward
+    shapes = [(12, 16), (6, 8), (3, 4), (2, 2)]
+    S = sum(h * w for h, w in shapes)
+    value = torch.randn(2, S, 8, 32, generator=g)
+    loc = torch.rand(2, 50, 8, 4, 4, 2, generator=g) * 1.1 - 0.05
+    attn = torch.rand(2, 50, 8, 16, generator=g).softmax(-1).reshape(2, 50, 8, 4, 4)
+    hw = torch.tensor(shapes)
+    start = torch.cat([hw.new_zeros(1), (hw[:, 0] * hw[:, 1]).cumsum(0)[:-1]])
+    out = ns["ms_deform_attn_forward"](value.to(dev), hw.to(dev), start.to(dev), loc.to(dev), attn.to(dev)).cpu()
+    torch.testing.assert_close(out, og.ms_deform_attn_core(value, shapes, loc, attn), atol=1e-4, rtol=1e-4)
