@@ -243,3 +243,94 @@ def test_groundingdino_reference_cfg_and_caller_sequence(monkeypatch):
     from collections import defaultdict
     qi = model.extract_query(samples=images, targets=[t], query_images=defaultdict(list), visual_features=feats)
     assert sorted(qi) == [2, 5] and qi[2].shape == (1, 1, 256)
+
+
+def test_glipdemo_caller_sequence(monkeypatch):
+    """north_star: "keeping the GeneralizedVLRCNN / GLIPDemo API surface".  The reference's `GLIPDemo.compute_prediction`,
+    `_post_process_fixed_thresh` and `_post_process` (engine/predictor_glip.py:178-275) and its positive-map builders (:405-445)
+    are executed IN PLACE on the product model: category-list caption (" . " separators), `create_positive_map` from the
+    tokenizer's char_to_token, `plus = 1` label ids, `model(image_list, captions=[caption], positive_map=...)` with the default
+    (non-LVIS) score aggregation, `prediction.resize`, `has_field("mask")`, `predictions[keep]`, `.sort` -- results vs the oracle."""
+    import timeit
+    import numpy as np
+    import ops_emulation as emu
+    from transformers import AutoTokenizer
+    from oracle import _refload, detector as od
+    from oracle.spec import Spec
+    from oracle.weights import make_state_dict
+    import mq_det_amd
+    from mq_det_amd import ops
+    from mq_det_amd.modeling import pipeline, detector
+    from mq_det_amd.structures import to_image_list
+    from mq_det_amd.utils.tokenizer import build_synthetic_tokenizer
+
+    names = ["person", "sports ball", "traffic light", "dog"]
+    cfg = _refload.reference_cfg("configs/pretrain/mq-glip-t.yaml")
+    assert cfg.TEST.MDETR_STYLE_AGGREGATE_CLASS_NUM == -1 and cfg.MODEL.RPN_ARCHITECTURE == "VLDYHEAD"
+    tok_dir = build_synthetic_tokenizer(tempfile.mkdtemp(), size=4000, extra_words=[w for n in names for w in n.split()])
+    cfg.MODEL.SWINT.DEPTHS, cfg.MODEL.DYHEAD.NUM_CONVS = (2, 2, 2, 2), 2
+    cfg.MODEL.LANGUAGE_BACKBONE.TOKENIZER_TYPE = cfg.MODEL.LANGUAGE_BACKBONE.MODEL_TYPE = tok_dir
+    cfg.VISION_QUERY.QUERY_BANK_PATH = ""
+    cfg.MODEL.DYHEAD.LEVEL_STREAMS = False
+    spec = Spec(swin_depths=(2, 2, 2, 2), dyhead_convs=2, vocab=4000, num_classes=cfg.MODEL.DYHEAD.NUM_CLASSES, mdetr_class_num=-1,
+                detections_per_img=cfg.MODEL.ATSS.DETECTIONS_PER_IMG, vision_query=False)
+    sd = make_state_dict(Spec(swin_depths=(2, 2, 2, 2), dyhead_convs=2, vocab=4000, num_classes=cfg.MODEL.DYHEAD.NUM_CLASSES), 0)
+    for n in ("attention", "attention4", "window_attention", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores",
+              "dyconv_branch_coef", "dyconv_coef_group", "dyconv_fuse", "dyrelu_", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "vlfuse_i2t",
+              "vlfuse_t2i", "box_decode", "ml_nms", "roi_align", "swin_mlp"):
+        monkeypatch.setattr(ops, n, getattr(emu, n))
+
+    def prepare(self, device=None):
+        self._plan = pipeline.build_plan(self.state_dict(), self.cfg, torch.device("cpu"), dtype=torch.float32)
+        self._plan_key = torch.device("cpu")
+        self.use_hip_graph = False
+        return self._plan
+    monkeypatch.setattr(detector.GeneralizedVLRCNN_New, "prepare", prepare)
+
+    ref = _refload.reference_classes("maskrcnn_benchmark/engine/predictor_glip.py", ["GLIPDemo"],
+                                     ["create_positive_map", "create_positive_map_label_to_token_from_positive_map"],
+                                     {"to_image_list": to_image_list, "timeit": timeit, "print": lambda *a, **k: None})
+    demo = ref["GLIPDemo"].__new__(ref["GLIPDemo"])            # GLIPDemo.__init__ minus checkpoint / cv2 / nltk plumbing (:29-61)
+    demo.cfg = cfg
+    demo.model = mq_det_amd.build_detection_model(cfg)
+    demo.model.load_state_dict(sd, strict=True)
+    demo.model.eval()
+    demo.device = demo.cpu_device = torch.device("cpu")
+    demo.tokenizer = AutoTokenizer.from_pretrained(tok_dir)     # build_tokenizer (:93-106)
+    mean, std = torch.tensor(cfg.INPUT.PIXEL_MEAN).view(3, 1, 1), torch.tensor(cfg.INPUT.PIXEL_STD).view(3, 1, 1)
+    demo.transforms = lambda img: (torch.from_numpy(img).permute(2, 0, 1).float() - mean) / std     # build_transform without the resize
+    demo.confidence_threshold = 0.06
+    g = np.random.default_rng(0)
+    image = (g.random((150, 190, 3)) * 255).astype(np.float32)
+
+    # (a) a list of category names: the reference joins them with " . " and wraps ALL spans into ONE entity (:185-196), i.e. a
+    # single label whose score is the mean over every token of the caption
+    pred = demo.compute_prediction(image, names)
+    assert demo.plus == 1 and sorted(demo.positive_map_label_to_token) == [1] and len(demo.positive_map_label_to_token[1]) == 6
+    assert set(pred.get_field("labels").tolist()) <= {1}
+    # (b) a caption string with one entity per phrase (`run_ner` = nltk noun phrases in the reference; here: the spans directly)
+    caption = "".join(n + " . " for n in names)
+    spans, pos = [], 0
+    for n in names:
+        spans.append([[pos, pos + len(n)]])
+        pos += len(n) + 3
+    demo.run_ner = lambda text: spans
+    pred = demo.compute_prediction(image, caption)
+    assert sorted(demo.positive_map_label_to_token) == [1, 2, 3, 4]
+    assert pred.size == (190, 150) and not pred.has_field("mask")
+    top = demo._post_process_fixed_thresh(pred)
+    top2 = demo._post_process(pred, threshold=0.06)
+    assert len(top) == len(top2) > 0 and bool((top.get_field("scores")[:-1] >= top.get_field("scores")[1:]).all())
+    assert float(top.get_field("scores").min()) > 0.06 and set(top.get_field("labels").tolist()) <= {1, 2, 3, 4}
+
+    # oracle on the same pixels / caption / label map
+    t = demo.tokenizer([caption], max_length=256, padding="max_length", return_special_tokens_mask=True, return_tensors="pt", truncation=True)
+    pimg, sizes = od.pad_images([demo.transforms(image)], cfg.DATALOADER.SIZE_DIVISIBILITY)
+    with torch.no_grad():
+        dets = od.forward(sd, spec, pimg, sizes, t["input_ids"], t["attention_mask"], dict(demo.positive_map_label_to_token), None)
+    keep = dets[0]["scores"] > 0.06
+    o1 = torch.argsort(dets[0]["scores"][keep], descending=True, stable=True)
+    assert int(keep.sum()) == len(top)
+    assert torch.allclose(dets[0]["scores"][keep][o1], top.get_field("scores"), atol=2e-4)
+    assert torch.equal(dets[0]["labels"][keep][o1], top.get_field("labels"))
+    assert torch.allclose(dets[0]["boxes"][keep][o1], top.bbox, atol=2e-2)
