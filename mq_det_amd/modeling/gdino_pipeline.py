@@ -351,15 +351,20 @@ def inverse_sigmoid(x, eps=1e-3):
     return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
 
 
-def _box_sine(box):
-    """utils.py gen_sineembed_for_position, 4-d: [B, nq, 4] (cx, cy, w, h) -> [B, nq, 512] in (y, x, w, h) order."""
-    d = torch.arange(128, dtype=torch.float32, device=box.device)
-    d = 10000 ** (2 * torch.div(d, 2, rounding_mode="floor") / 128)
+_SINE = {}
 
-    def emb(v):
-        s = v[..., None] * (2 * math.pi) / d
-        return torch.stack((s[..., 0::2].sin(), s[..., 1::2].cos()), 3).flatten(2)
-    return torch.cat((emb(box[..., 1]), emb(box[..., 0]), emb(box[..., 2]), emb(box[..., 3])), 2)
+
+def _box_sine(box):
+    """utils.py gen_sineembed_for_position, 4-d: [B, nq, 4] (cx, cy, w, h) -> [B, nq, 512] in (y, x, w, h) order.  The reference
+    interleaves sin of the even and cos of the odd frequency slots (a dozen small kernels per coordinate); cos(a) = sin(a + pi/2)
+    turns the whole embedding into ONE sine of an affine map: coordinate gather, multiply-add, sin."""
+    key = box.device
+    if key not in _SINE:
+        j = torch.arange(128, dtype=torch.float32, device=box.device)
+        freq = (2 * math.pi) / (10000 ** (2 * torch.div(j, 2, rounding_mode="floor") / 128))
+        _SINE[key] = (freq, (j % 2) * (math.pi / 2), torch.tensor([1, 0, 2, 3], device=box.device))
+    freq, phase, order = _SINE[key]
+    return torch.sin(torch.addcmul(phase, box[..., order, None], freq)).flatten(2)
 
 
 # ----------------------------------------------------------------------------- language
