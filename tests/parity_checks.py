@@ -13,6 +13,11 @@ import torch
 import torch.nn.functional as F
 
 TOL = 2e-3
+# tests/test_simt_kernels_cpu.py runs these checks on CPU tensors through the lane-by-lane emulation of the kernel sources:
+# QUICK drops the largest cases of a few sweeps (minutes on the emulator), PINS = False skips the comparisons against the
+# reference's own device kernels (oracle/_ref needs a GPU).  On the GPU box both keep their defaults.
+QUICK = False
+PINS = True
 
 
 def _stat(name, got, ref, tol=TOL):
@@ -270,7 +275,7 @@ def check_vlfuse_kernels(dev):
     g = torch.Generator().manual_seed(21)
     res = []
     for B, N, T, kv in ((2, 645, 64, None), (3, 300, 100, [100, 37, 70]), (2, 200, 160, [131, 160]), (1, 130, 256, [256]),
-                        (9, 128, 40, None)):
+                        (9, 128, 40, None))[1 if QUICK else 0:4 if QUICK else 5]:
         v_ln = torch.randn(B, N, 256, generator=g).half()
         kf = (torch.randn(B, 8, T, 256, generator=g) / 8).half()
         vo = torch.randn(B, 8, T, 256, generator=g).half()
@@ -283,7 +288,7 @@ def check_vlfuse_kernels(dev):
                              None if kv_len is None else kv_len.to(dev), max_kv=0 if kv is None else max(kv))
         res.append(_stat(f"vlfuse image side B={B} N={N} T={T} kv_len={kv}", got, ref, tol=2e-3))
     for B, N, T, ns, kv in ((2, 645, 64, 1, None), (1, 22400, 256, 6, None), (3, 1000, 100, 3, None), (2, 130, 160, 2, [160, 90]),
-                            (9, 70, 40, 1, None), (3, 500, 256, 4, [256, 128, 77])):
+                            (9, 70, 40, 1, None), (3, 500, 256, 4, [256, 128, 77]))[3 if QUICK else 0:]:
         v_ln = torch.randn(B, N, 256, generator=g).half()
         kf = (torch.randn(B, 8, T, 256, generator=g) / 8).half()
         kv_len = None if kv is None else torch.tensor(kv, dtype=torch.int32)
@@ -488,6 +493,8 @@ def check_conv3x3(dev):
     g = torch.Generator().manual_seed(21)
     res = []
     for (B, H, W, N, stride) in ((2, 13, 21, 256, 1), (3, 25, 42, 256, 2), (2, 100, 168, 27, 1), (1, 7, 11, 27, 1), (2, 50, 84, 256, 1)):
+        if QUICK and H * W > 2000:
+            continue
         x = torch.randn(B, 256, H, W, generator=g).half()
         w = (torch.randn(N, 256, 3, 3, generator=g) / 48).half()
         bias = torch.randn(N, generator=g).half()
@@ -884,7 +891,7 @@ def check_roi_align(dev):
             res.append(_stat(f"roi_align aligned={aligned} sampling={sr}: NCHW fp32 vs oracle", got32, oroi.roi_align(feat, rois, 7, 1.0 / 16, sr, aligned), tol=1e-5))
             gm = ops.roi_align(nhwc, rois.to(dev), 7, 1.0 / 16, sr, aligned=aligned, reduce_mean=True)
             res.append(_stat(f"roi_align aligned={aligned} sampling={sr}: fused bin mean", gm, got.mean((-1, -2)), tol=1e-5))
-            if not aligned:
+            if not aligned and PINS:
                 pin = rn.roi_align(feat.to(dev), rois.to(dev), 7, 1.0 / 16, sr)
                 res.append(_stat(f"PIN oracle.roi_align vs reference CUDA kernel: sampling={sr}", oroi.roi_align(feat, rois, 7, 1.0 / 16, sr, False), pin, tol=1e-5))
                 res.append(_stat(f"PIN mq_roi_align_fwd vs reference CUDA kernel: sampling={sr}", got32, pin, tol=1e-5))
@@ -973,7 +980,7 @@ def check_swin_mlp(dev):
     g = torch.Generator().manual_seed(51)
     res = []
     for C, M, use_delta, use_next in ((96, 1000, True, True), (96, 128, False, False), (192, 777, True, True), (384, 333, True, True),
-                                      (384, 64, True, False), (96, 67200 * 2 + 5, True, True)):
+                                      (384, 64, True, False), (96, 67200 * 2 + 5, True, True))[:5 if QUICK else 6]:
         x = torch.randn(M, C, generator=g) * 1.5
         delta = (torch.randn(M, C, generator=g) * 0.5).half() if use_delta else None
         lg, lb = (torch.randn(C, generator=g) * 0.1 + 1).half(), (torch.randn(C, generator=g) * 0.1).half()
@@ -1018,9 +1025,10 @@ def check_msdeform_attn(dev, golden_dir=None):
     res.append(_stat("msdeform fp32 vs reference fixture (multi_scale_deformable_attn_pytorch)", got, torch.from_numpy(gd["out"]), tol=1e-5))
     hw = torch.tensor(shapes, dtype=torch.int64)
     start = torch.cat([hw.new_zeros(1), (hw[:, 0] * hw[:, 1]).cumsum(0)[:-1]])
-    pin = rn.ms_deform_attn(value.to(dev), hw, start, loc.to(dev), attn.to(dev))
-    res.append(_stat("PIN mq_msdeform_attn_fwd vs reference CUDA kernel", got, pin, tol=1e-5))
-    res.append(_stat("PIN oracle.ms_deform_attn_core vs reference CUDA kernel", gdino.ms_deform_attn_core(value, shapes, loc, attn), pin, tol=1e-5))
+    if PINS:
+        pin = rn.ms_deform_attn(value.to(dev), hw, start, loc.to(dev), attn.to(dev))
+        res.append(_stat("PIN mq_msdeform_attn_fwd vs reference CUDA kernel", got, pin, tol=1e-5))
+        res.append(_stat("PIN oracle.ms_deform_attn_core vs reference CUDA kernel", gdino.ms_deform_attn_core(value, shapes, loc, attn), pin, tol=1e-5))
     # encoder shape, fp16 values (the product's dtype), ragged query count
     g = torch.Generator().manual_seed(61)
     shapes = [(100, 168), (50, 84), (25, 42), (13, 21)]

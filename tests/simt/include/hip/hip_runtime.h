@@ -1,0 +1,175 @@
+// TEST INFRASTRUCTURE ONLY -- never on the product path (mq_det_amd/ does not know this directory exists).
+//
+// A host stand-in for <hip/hip_runtime.h>: the kernel sources under mq_det_amd/csrc/ are compiled UNCHANGED (two textual rewrites in
+// tests/simt/build_emu.py: `extern __shared__ T x[];` and `asm volatile(...)`) for x86-64 and executed lane by lane -- every HIP
+// thread is a fiber, a wavefront is 64 fibers that meet at each cross-lane operation (MFMA, shuffles, ballot, LDS transpose read,
+// wave barrier), a workgroup meets at __syncthreads().  Purpose: run the gfx950 kernels' index arithmetic, fragment layouts, LDS
+// images and masking logic against the oracle on a machine without a GPU (tests/test_simt_kernels_cpu.py).  It says nothing
+// about speed, and floating-point results differ from the device in the last bits (expf / rounding order inside an MFMA).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+#include <algorithm>
+
+#define MQ_SIMT_EMULATION 1
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+#ifndef __restrict__
+#define __restrict__ __restrict
+#endif
+
+struct dim3 {
+  unsigned x, y, z;
+  constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3_ { unsigned x, y, z; };
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorLaunchFailure = 719 };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+
+namespace simt {
+struct Fiber;
+extern Fiber* cur;                                   // the fiber that is executing
+extern dim3 g_blockIdx, g_blockDim, g_gridDim;
+extern int g_error;
+const uint3_& tid();
+int lane();
+void* dyn_smem();
+void wave_sync();                                    // all live lanes of the wave
+void block_sync();                                   // all live threads of the workgroup
+uint64_t* xslot(int lane, int buf);                  // exchange slots of the current wave: [2][64][4] x 8 bytes
+int next_buf();                                      // alternating buffer index per collective
+bool lane_live(int lane);
+typedef void (*BodyFn)(void*);
+void launch(dim3 grid, dim3 block, size_t shmem, BodyFn fn, void* ctx);
+
+template <class F>
+inline void launch_fn(dim3 grid, dim3 block, size_t shmem, F&& f) {
+  launch(grid, block, shmem, [](void* c) { (*static_cast<F*>(c))(); }, (void*)&f);
+}
+
+template <class T>
+inline T shfl_idx(T v, int src) {
+  static_assert(sizeof(T) <= 8, "shuffle of > 8 bytes");
+  const int b = next_buf();
+  uint64_t w = 0;
+  memcpy(&w, &v, sizeof(T));
+  *xslot(lane(), b) = w;
+  wave_sync();
+  w = *xslot(src & 63, b);
+  T o;
+  memcpy(&o, &w, sizeof(T));
+  return o;
+}
+}  // namespace simt
+
+#define threadIdx (simt::tid())
+#define blockIdx (simt::g_blockIdx)
+#define blockDim (simt::g_blockDim)
+#define gridDim (simt::g_gridDim)
+#define warpSize 64
+
+inline hipError_t hipGetLastError() { int e = simt::g_error; simt::g_error = 0; return e; }
+template <class K>
+inline hipError_t hipFuncSetAttribute(K, hipFuncAttribute, int) { return hipSuccess; }
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+  simt::launch_fn(dim3(grid), dim3(block), (size_t)(shmem), [&]() { kernel(__VA_ARGS__); })
+
+inline void __syncthreads() { simt::block_sync(); }
+template <class T> inline T __shfl_xor(T v, int mask, int width = 64) { (void)width; return simt::shfl_idx(v, simt::lane() ^ mask); }
+template <class T> inline T __shfl(T v, int src, int width = 64) { (void)width; return simt::shfl_idx(v, src); }
+template <class T> inline T __shfl_down(T v, unsigned d, int width = 64) { (void)width; int s = simt::lane() + (int)d; return simt::shfl_idx(v, s < 64 ? s : simt::lane()); }
+inline unsigned long long __ballot(int pred) {
+  const int b = simt::next_buf();
+  *simt::xslot(simt::lane(), b) = pred ? 1 : 0;
+  simt::wave_sync();
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l)
+    if (simt::lane_live(l) && *simt::xslot(l, b)) m |= 1ull << l;
+  return m;
+}
+inline int __any(int pred) { return __ballot(pred) != 0; }
+inline int __all(int pred) {
+  const int b = simt::next_buf();
+  *simt::xslot(simt::lane(), b) = pred ? 1 : 0;
+  simt::wave_sync();
+  for (int l = 0; l < 64; ++l)
+    if (simt::lane_live(l) && !*simt::xslot(l, b)) return 0;
+  return 1;
+}
+inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+inline int __ffs(unsigned v) { return __builtin_ffs((int)v); }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline float __expf(float x) { return expf(x); }
+inline float __logf(float x) { return logf(x); }
+inline float __frcp_rn(float x) { return 1.0f / x; }
+inline float __fdividef(float a, float b) { return a / b; }
+inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+using std::max;
+using std::min;
+
+// ---- gfx950 builtins
+typedef _Float16 simt_half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 simt_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float simt_float4 __attribute__((ext_vector_type(4)));
+typedef __fp16 simt_fp16x4 __attribute__((__vector_size__(8)));
+typedef short simt_short4 __attribute__((__vector_size__(8)));
+
+// v_mfma_f32_16x16x32_{f16,bf16}: A lane l = A[l & 15][8 (l >> 4) ..], B lane l = B[8 (l >> 4) ..][l & 15], D lane l = D[4 (l >> 4) + r][l & 15]
+template <class V8>
+inline simt_float4 simt_mfma_16x16x32(V8 a, V8 b, simt_float4 c) {
+  const int buf = simt::next_buf(), l = simt::lane();
+  uint64_t* s = simt::xslot(l, buf);
+  memcpy(s, &a, 16);
+  memcpy(s + 2, &b, 16);
+  simt::wave_sync();
+  const int col = l & 15, r0 = 4 * (l >> 4);
+  V8 bk[4];
+  for (int g = 0; g < 4; ++g) memcpy(&bk[g], simt::xslot(col + 16 * g, buf) + 2, 16);
+  for (int r = 0; r < 4; ++r) {
+    float acc = c[r];
+    for (int g = 0; g < 4; ++g) {
+      V8 ak;
+      memcpy(&ak, simt::xslot(r0 + r + 16 * g, buf), 16);
+      for (int j = 0; j < 8; ++j) acc += (float)ak[j] * (float)bk[g][j];
+    }
+    c[r] = acc;
+  }
+  return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) simt_mfma_16x16x32<simt_half8>((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) simt_mfma_16x16x32<simt_bf16x8>((a), (b), (c))
+
+// ds_read_b64_tr_b16: inside each 16-lane group the 16 x 4 block of 16-bit elements addressed by the lanes (lane i: row i >> 2,
+// columns 4 (i & 3) .. + 3 of a [4][16] matrix) comes back transposed: lane i receives column i, rows 0..3
+inline simt_fp16x4 simt_ds_read_tr16(uintptr_t addr) {
+  const int buf = simt::next_buf(), l = simt::lane();
+  *simt::xslot(l, buf) = (uint64_t)addr;
+  simt::wave_sync();
+  const int base = l & ~15, i = l & 15;
+  simt_fp16x4 o;
+  for (int j = 0; j < 4; ++j) {
+    const uint16_t* src = (const uint16_t*)(uintptr_t)(*simt::xslot(base + 4 * j + (i >> 2), buf));
+    uint16_t h = src[i & 3];
+    memcpy((char*)&o + 2 * j, &h, 2);
+  }
+  return o;
+}
+#define __builtin_amdgcn_ds_read_tr16_b64_v4f16(p) simt_ds_read_tr16((uintptr_t)(p))
+#define __builtin_amdgcn_wave_barrier() simt::wave_sync()
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_s_barrier() simt::block_sync()
+#define SIMT_ASM(...) ((void)0)

@@ -1,0 +1,116 @@
+"""The gfx950 kernel SOURCES (mq_det_amd/csrc/*.hip), executed lane by lane on the host, against the oracle -- without a GPU.
+
+tests/simt/ compiles the .hip files unchanged for x86-64 against a stand-in HIP runtime in which every thread is a fiber: a
+wavefront's 64 lanes meet at each MFMA / shuffle / ballot / LDS transpose read, a workgroup meets at __syncthreads().  The
+same checks that run on the MI355X (tests/parity_checks.py, tests/gdino_checks.py: the product's torch wrappers -> C ABI ->
+kernels, compared with the oracle / plain fp32 restatements) run here on CPU tensors, so a wrong fragment layout, LDS image,
+index or mask in a kernel shows up in the CPU suite -- before any GPU time is spent.  What this cannot see: timing, occupancy,
+register spills, and the last bits of expf / MFMA rounding order; the `-m gpu` suite stays the parity gate.
+
+TEST INFRASTRUCTURE ONLY: the emulation library is loaded here and nowhere else; mq_det_amd/ raises without a GPU."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+CPU = torch.device("cpu")
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    import simt
+    import parity_checks as pc
+    from mq_det_amd.modeling import detector, gdino, pipeline, gdino_pipeline as gp
+
+    def prepare(self, device=None):
+        self._validate_config()
+        self._plan = pipeline.build_plan(self.state_dict(), self.cfg, CPU)
+        self._plan_key, self.use_hip_graph = CPU, False
+        return self._plan
+
+    def prepare_gdino(self, device=None):
+        self._plan = gp.build_gdino_plan(self.state_dict(), self.cfg, CPU, self._swin)
+        self._plan_key, self.use_hip_graph = CPU, False
+        return self._plan
+
+    saved = (detector.GeneralizedVLRCNN_New.prepare, gdino.GroundingDINO.prepare, pc.QUICK, pc.PINS, dict(pc._CACHE))
+    detector.GeneralizedVLRCNN_New.prepare, gdino.GroundingDINO.prepare = prepare, prepare_gdino
+    pc.QUICK, pc.PINS = os.environ.get("MQ_SIMT_FULL", "0") != "1", False
+    pc._CACHE.clear()
+    with simt.installed():
+        yield pc
+    detector.GeneralizedVLRCNN_New.prepare, gdino.GroundingDINO.prepare, pc.QUICK, pc.PINS = saved[:4]
+    pc._CACHE.clear()
+    pc._CACHE.update(saved[4])
+
+
+def _assert_ok(results):
+    results = results if isinstance(results, list) else [results]
+    assert results, "no results"
+    bad = [f"{r['name']}: norm_err {r['norm_err']:.2e} > tol {r['tol']:.1e}" for r in results if not r["ok"]]
+    assert not bad, "\n".join(bad)
+
+
+def test_emulation_library_exports_the_whole_c_abi():
+    import simt
+    from mq_det_amd import ops
+    lib = simt.library()
+    assert lib.mq_abi_version() > 0 and all(hasattr(lib, n) for n in ops.EXPORTS)
+    # the product binding is untouched by loading it
+    assert ops._LIB is None or ops._LIB is not lib
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, H=12, D=64, Nq=256, Nk=256, mask=True),
+    dict(B=2, H=12, D=64, Nq=256, Nk=256, mask=True, clamp=50000.0, big=True),
+    dict(B=1, H=8, D=32, Nq=200, Nk=1333, nsplit=4),
+    dict(B=1, H=8, D=32, Nq=37, Nk=61),
+    dict(B=2, H=12, D=64, Nq=256, Nk=256, mask=True, kvlen=True),
+])
+def test_attention_kernel(kernels, cfg):
+    _assert_ok(kernels.check_attention(CPU, **cfg))
+
+
+def test_attention_strided_views(kernels):
+    _assert_ok(kernels.check_attention_strided(CPU))
+
+
+@pytest.mark.parametrize("name", ["check_window_attention", "check_gcp_block", "check_pre_select", "check_vlfuse_kernels", "check_vl_fuse",
+                                  "check_dcn", "check_dyconv", "check_post_golden", "check_layernorm", "check_nms", "check_swin_mlp",
+                                  "check_conv3x3", "check_roi_align", "check_msdeform_attn", "check_swin_fpn"])
+def test_kernel_block(kernels, name):
+    _assert_ok(getattr(kernels, name)(CPU))
+
+
+@pytest.mark.parametrize("clamp", [False, True])
+def test_bert_layer(kernels, clamp):
+    _assert_ok(kernels.check_bert_layer(CPU, clamp))
+
+
+def test_full_model_smoke_check(kernels):
+    """exactly what __graft_entry__.smoke() runs on cuda:0: tiny-depth MQ-GLIP-T, every stage + detections against the oracle"""
+    _assert_ok(kernels.check_full_model(CPU))
+
+
+@pytest.mark.parametrize("name", ["check_attention_qk_mask", "check_msdeform_attn_q", "check_gdino_state_dict_and_quirks"])
+def test_groundingdino(kernels, name):
+    import gdino_checks as gc
+    _assert_ok(_no_graph_rows(getattr(gc, name)(CPU)))
+
+
+def _no_graph_rows(results):
+    """rows that assert an actual HIP-graph capture have no meaning without a device"""
+    return [r for r in results if "HIP-graph" not in r["name"]]
+
+
+@pytest.mark.skipif(os.environ.get("MQ_SIMT_FULL", "0") != "1", reason="minutes on the emulator: MQ_SIMT_FULL=1")
+@pytest.mark.parametrize("name", ["check_extract_query", "check_vlfuse_heads_mask", "check_gdino_tiny", "large"])
+def test_slow_blocks(kernels, name):
+    import gdino_checks as gc
+    if name == "large":
+        _assert_ok(kernels.check_window_attention(CPU, large=True) + kernels.check_swin_fpn(CPU, large=True))
+    else:
+        _assert_ok(_no_graph_rows(getattr(kernels if hasattr(kernels, name) else gc, name)(CPU)))
