@@ -192,11 +192,13 @@ int mq_dyrelu_apply(void* x, const float* coef, int B, int n, int C, long x_bs, 
  *   dot [B,HW,T] fp16 (fp32 when dot_f32 != 0; batch stride dot_bs elements, <= 0: HW*T), tbias [B,T] fp32,
  *   tokidx [L,MT] int32 token positions per label, -1 padded (batch stride tok_bs elements: 0 = one caption for the whole
  *   batch, L*MT = one caption per batch item), ctr [B,HW] fp16 -> out [B,HW,L] fp32
- *   ((cls > thr) ? max(cls*sigmoid(ctr), FLT_MIN) : -1), cls_out [B,HW,L] fp32 optional.  Token -> class aggregation is the
- *   MEAN of DYHEAD.SCORE_AGG (the reference default; MAX / POWER / ONEHOT are not implemented and rejected by the host).
+ *   ((cls > thr) ? max(cls*sigmoid(ctr), FLT_MIN) : -1), cls_out [B,HW,L] fp32 optional.  Token -> class aggregation
+ *   (DYHEAD.SCORE_AGG): agg 0 = MEAN (the reference default), 1 = MAX, 2 = POWER (prod^(1/n)); ONEHOT is expressed by the
+ *   host as MEAN over a one-token index (column j <- token j).  A label without tokens scores 0.
  * Replaces vldyhead.py:884-887 (bias, clamp) + rpn/inference.py:656-683,772-824. */
 int mq_align_scores_fwd(const void* dot, int dot_f32, const float* tbias, const int* tokidx, long tok_bs, const void* ctr,
-                        float* out, float* cls_out, int B, int HW, int T, int L, int MT, float thr, long dot_bs, void* stream);
+                        float* out, float* cls_out, int B, int HW, int T, int L, int MT, float thr, long dot_bs, int agg,
+                        void* stream);
 
 /* Decode + clip the top-K candidates of one level into the per-image candidate arrays (at column out_off).
  *   val/flat [B,K] (score, flat index loc*L + l), reg [B,HW,4] fp16, anchors [HW,4] fp32, label_ids [L] int32 (batch

@@ -1,7 +1,8 @@
 // Region-word alignment scoring and ATSS post-processing kernels for gfx950 (thin, HBM-bound).
 //
 // mq_align_scores_fwd -- reference rpn/vldyhead.py:884-887 (+bias, clamp +-50000) followed by
-//   rpn/inference.py:656-683: sigmoid, token -> class MEAN (convert_grounding_to_od_logits[_v2]),
+//   rpn/inference.py:656-683: sigmoid, token -> class aggregation (convert_grounding_to_od_logits[_v2], :772-824:
+//   agg 0 = MEAN, 1 = MAX, 2 = POWER = prod^(1/n); ONEHOT is MEAN over the one-token index the host builds for it),
 //   threshold 0.05, x sigmoid(centerness).  The reference builds a dense [B, HW, 3000] (LVIS) score
 //   tensor of which <= 40 columns are non-zero; here only the L labels of the caption are produced.
 //     dot    : [B, HW, T] fp16 = feat . (proj_tokens / exp(log_scale))^T       (library GEMM outside; batch stride
@@ -26,7 +27,8 @@ template <typename TD>
 __global__ __launch_bounds__(256) void align_scores_kernel(const TD* __restrict__ dot, const float* __restrict__ tbias,
                                                            const int* __restrict__ tokidx, const half_t* __restrict__ ctr,
                                                            float* __restrict__ out, float* __restrict__ cls_out,
-                                                           int B, int HW, int T, int L, int MT, float thr, long dot_bs, long tok_bs) {
+                                                           int B, int HW, int T, int L, int MT, float thr, long dot_bs, long tok_bs,
+                                                           int agg) {
   extern __shared__ float sig[];                 // [4][T]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long loc = (long)blockIdx.x * 4 + wave;
@@ -65,13 +67,18 @@ __global__ __launch_bounds__(256) void align_scores_kernel(const TD* __restrict_
   wave_lds_fence();
   const float c = 1.f / (1.f + __expf(-(float)ctr[loc]));
   for (int l = lane; l < L; l += 64) {
-    float s = 0.f;
+    float s = agg == 2 ? 1.f : 0.f;
     int n = 0;
     for (int j = 0; j < MT; ++j) {
       int t = tix[l * MT + j];
-      if (t >= 0) { s += sw[t]; ++n; }
+      if (t >= 0) {
+        const float v = sw[t];
+        s = agg == 0 ? s + v : (agg == 1 ? fmaxf(s, v) : s * v);          // sigmoid outputs are >= 0: 0 is the identity of max
+        ++n;
+      }
     }
-    float cls = n > 0 ? s / (float)n : 0.f;
+    float cls = 0.f;                                    // a label without tokens scores 0 (never a candidate)
+    if (n > 0) cls = agg == 0 ? s / (float)n : (agg == 1 ? s : powf(s, 1.f / (float)n));
     if (cls_out) cls_out[loc * L + l] = cls;
     // candidates are decided by the class score alone (rpn/inference.py:677): keep them > 0 even if the product with a
     // vanishing centerness underflows, so that "value > 0" identifies a candidate downstream
@@ -81,17 +88,18 @@ __global__ __launch_bounds__(256) void align_scores_kernel(const TD* __restrict_
 
 extern "C" int mq_align_scores_fwd(const void* dot, int dot_f32, const float* tbias, const int* tokidx, long tok_bs,
                                    const void* ctr, float* out, float* cls_out, int B, int HW, int T, int L, int MT, float thr,
-                                   long dot_bs, void* stream) {
+                                   long dot_bs, int agg, void* stream) {
   if (B <= 0 || HW <= 0 || L <= 0) return 0;
+  if (agg < 0 || agg > 2) return -1;
   long locs = (long)B * HW;
   const dim3 grid((unsigned)((locs + 3) / 4));
   const long dbs = dot_bs > 0 ? dot_bs : (long)HW * T;
   if (dot_f32)
     hipLaunchKernelGGL(align_scores_kernel<float>, grid, dim3(256), 4 * T * sizeof(float), (hipStream_t)stream, (const float*)dot,
-                       tbias, tokidx, (const half_t*)ctr, out, cls_out, B, HW, T, L, MT, thr, dbs, tok_bs);
+                       tbias, tokidx, (const half_t*)ctr, out, cls_out, B, HW, T, L, MT, thr, dbs, tok_bs, agg);
   else
     hipLaunchKernelGGL(align_scores_kernel<half_t>, grid, dim3(256), 4 * T * sizeof(float), (hipStream_t)stream, (const half_t*)dot,
-                       tbias, tokidx, (const half_t*)ctr, out, cls_out, B, HW, T, L, MT, thr, dbs, tok_bs);
+                       tbias, tokidx, (const half_t*)ctr, out, cls_out, B, HW, T, L, MT, thr, dbs, tok_bs, agg);
   MQ_CHECK_LAUNCH();
   return 0;
 }

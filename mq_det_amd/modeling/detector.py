@@ -144,9 +144,12 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
         cfg = self.cfg
         M = cfg.MODEL
         agg = str(M.DYHEAD.get("SCORE_AGG", "MEAN")).upper()
-        if agg != "MEAN":
-            raise NotImplementedError(f"MODEL.DYHEAD.SCORE_AGG = {agg}: only MEAN (the reference default) is implemented in "
-                                      "mq_align_scores_fwd; MAX / POWER / ONEHOT (rpn/inference.py:772-824) are not")
+        mdetr = cfg.TEST.MDETR_STYLE_AGGREGATE_CLASS_NUM != -1
+        if agg not in ("MEAN", "MAX", "ONEHOT") + (("POWER",) if mdetr else ()):
+            # the reference's own rule: convert_grounding_to_od_logits (rpn/inference.py:772-792) knows MEAN / MAX / ONEHOT,
+            # only the MDETR-style _v2 (:795-824) adds POWER; anything else raises NotImplementedError there too
+            raise NotImplementedError(f"MODEL.DYHEAD.SCORE_AGG = {agg}: MEAN / MAX / ONEHOT"
+                                      + (" / POWER" if mdetr else " (POWER only with TEST.MDETR_STYLE_AGGREGATE_CLASS_NUM != -1)"))
         if M.LANGUAGE_BACKBONE.MAX_QUERY_LEN > 256 or M.LANGUAGE_BACKBONE.MAX_QUERY_LEN % 8:
             raise NotImplementedError("MODEL.LANGUAGE_BACKBONE.MAX_QUERY_LEN must be a multiple of 8 and <= 256 (VLFuse kernels)")
         if not M.LANGUAGE_BACKBONE.PAD_MAX:
@@ -322,11 +325,18 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
             vision, idx = self.query_selector.select_cached(pm_key, labels_in_caption, positive_map, Bn, T, dev, dtype)
             if vision.shape[1] == 0:                              # no label of this caption has a vision query: text only
                 vision = idx = None
-        hit = self._tokidx_cache.get((pm_key, str(dev)))
+        onehot = str(cfg.MODEL.DYHEAD.get("SCORE_AGG", "MEAN")).upper() == "ONEHOT"
+        tk = (len(positive_map), "onehot", str(dev)) if onehot else (pm_key, str(dev))
+        hit = self._tokidx_cache.get(tk)
         if hit is None:
             if len(self._tokidx_cache) > 256:
                 self._tokidx_cache.clear()
-            hit = self._tokidx_cache[(pm_key, str(dev))] = build_token_index(positive_map, labels_in_caption, dev)
+            if onehot:      # scores = logits[:, :, :len(positive_map)] (rpn/inference.py:789-791): class column j is token j, label j + 1
+                n = len(positive_map)
+                hit = build_token_index({j + 1: [j] for j in range(n)}, list(range(1, n + 1)), dev)
+            else:
+                hit = build_token_index(positive_map, labels_in_caption, dev)
+            self._tokidx_cache[tk] = hit
         tokidx, label_ids = hit
         wh_key = (tuple(images.image_sizes), str(dev))
         im_wh = self._wh_cache.get(wh_key)
@@ -479,11 +489,15 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
                      "hidden": [rep(torch.cat([f["hidden"][k] for f in fronts])) for k in range(len(fronts[0]["hidden"]))],
                      "key_bias": rep(torch.cat([f["key_bias"] for f in fronts])), "kv_len": rep(torch.cat([f["kv_len"] for f in fronts])),
                      "next": fronts[0]["next"]}
-            L = max(1, max(len(l) for l in labs))
-            MT = max(1, max((len(pm[k]) for pm, l in zip(pms, labs) for k in l), default=1))
+            if str(cfg.MODEL.DYHEAD.get("SCORE_AGG", "MEAN")).upper() == "ONEHOT":      # class column j = token j, label j + 1
+                smaps = [({j + 1: [j] for j in range(len(pm))}, list(range(1, len(pm) + 1))) for pm in pms]
+            else:
+                smaps = list(zip(pms, labs))
+            L = max(1, max(len(l) for _, l in smaps))
+            MT = max(1, max((len(pm[k]) for pm, l in smaps for k in l), default=1))
             tok3 = torch.full((g, L, MT), -1, dtype=torch.int32)
             lab2 = torch.zeros(g, L, dtype=torch.int32)
-            for c, (pm, l) in enumerate(zip(pms, labs)):
+            for c, (pm, l) in enumerate(smaps):
                 for j, k in enumerate(l):
                     tok3[c, j, :len(pm[k])] = torch.tensor(pm[k], dtype=torch.int32)
                     lab2[c, j] = k

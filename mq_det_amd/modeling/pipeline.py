@@ -754,7 +754,8 @@ def postprocess(cfg, head, anchors, im_wh, tokidx, label_ids, want_cls=False):
         dot, reg, ctr, anc, k = head["dot"][l], head["bbox_reg"][l], head["centerness"][l], anchors[l], ks[l]
         HW = dot.shape[1]
         ctr_flat = ctr.permute(0, 2, 3, 1).reshape(Bn, HW).contiguous()
-        r = ops.align_scores(dot, head["tbias"], tokidx, ctr_flat, A.INFERENCE_TH, want_cls=want_cls)
+        r = ops.align_scores(dot, head["tbias"], tokidx, ctr_flat, A.INFERENCE_TH, want_cls=want_cls,
+                             agg=ops.SCORE_AGG[str(cfg.MODEL.DYHEAD.get("SCORE_AGG", "MEAN")).upper()])
         if want_cls:
             r, cls_all[l] = r
         val, flat = torch.topk(r.reshape(Bn, HW * L), k, dim=1, sorted=False)

@@ -36,7 +36,7 @@ _SIGNATURES = {
     "mq_dyconv_fuse": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _l, _vp, _i, _i, _i, _i, _vp]),
     "mq_dyrelu_coef": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mq_dyrelu_apply": (_i, [_vp, _vp, _i, _i, _i, _l, _vp]),
-    "mq_align_scores_fwd": (_i, [_vp, _i, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _l, _vp]),
+    "mq_align_scores_fwd": (_i, [_vp, _i, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _l, _i, _vp]),
     "mq_box_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _vp]),
     "mq_roi_align_fwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _f, _i, _i, _i, _vp]),
     "mq_msdeform_attn_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -554,7 +554,10 @@ def dyrelu_(x, pool, w0, b0, w2, b2):
     return x
 
 
-def align_scores(dot, tbias, tokidx, ctr, thr, want_cls=False):
+SCORE_AGG = {"MEAN": 0, "MAX": 1, "POWER": 2, "ONEHOT": 0}      # ONEHOT: MEAN over the one-token index of token_index_onehot
+
+
+def align_scores(dot, tbias, tokidx, ctr, thr, want_cls=False, agg=0):
     """dot [B,HW,T] fp16 or fp32 (contiguous rows, any batch stride), tbias [B,T] fp32, tokidx [L,MT] (one caption for the
     batch) or [B,L,MT] (one per item) int32, ctr [B,HW] fp16 -> ranked [B,HW,L] fp32 (, cls)."""
     lib = load_library()
@@ -570,7 +573,7 @@ def align_scores(dot, tbias, tokidx, ctr, thr, want_cls=False):
     with _timed("align_scores", B * HW * T * dot.element_size() + out.numel() * 4):
         _chk(lib.mq_align_scores_fwd(_ptr(dot), int(dot.dtype == torch.float32), _ptr(tbias), _ptr(tokidx),
                                      L * MT if tokidx.dim() == 3 else 0, _ptr(ctr), _ptr(out), _ptr(cls), B, HW, T, L, MT,
-                                     float(thr), dot.stride(0), _stream()), "mq_align_scores_fwd")
+                                     float(thr), dot.stride(0), int(agg), _stream()), "mq_align_scores_fwd")
     return (out, cls) if want_cls else out
 
 

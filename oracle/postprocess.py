@@ -53,14 +53,26 @@ def box_decode(preds, anchors):
     return torch.stack([pcx - 0.5 * (pw - 1), pcy - 0.5 * (ph - 1), pcx + 0.5 * (pw - 1), pcy + 0.5 * (ph - 1)], 1)
 
 
-def token_to_class_scores(prob, positive_map, num_class, minus_one=True):
-    """convert_grounding_to_od_logits(_v2), MEAN aggregation (inference.py:772-824).
-    prob: [B, HW, T] sigmoid-ed; positive_map: {label(1-based): [token idx]} -> [B, HW, num_class]."""
+def token_to_class_scores(prob, positive_map, num_class, minus_one=True, score_agg="MEAN"):
+    """convert_grounding_to_od_logits(_v2) (inference.py:772-824), every aggregation the reference has: MEAN, MAX, POWER
+    (geometric mean; the MDETR-style _v2 only), ONEHOT (class column j = token j: the first len(positive_map) token columns).
+    prob: [B, HW, T] sigmoid-ed; positive_map: {label(1-based): [token idx]} -> [B, HW, num_class] ([B, HW, len(map)] for ONEHOT)."""
+    if score_agg == "ONEHOT":
+        return prob[:, :, :len(positive_map)]
+    if score_agg not in ("MEAN", "MAX", "POWER"):
+        raise NotImplementedError(score_agg)
     scores = torch.zeros(prob.shape[0], prob.shape[1], num_class)
     for label, toks in positive_map.items():
         if isinstance(toks, int):
             toks = [toks]
-        scores[:, :, label - 1 if minus_one else label] = prob[:, :, torch.tensor(toks, dtype=torch.long)].mean(-1)
+        sel = prob[:, :, torch.tensor(toks, dtype=torch.long)]
+        if score_agg == "MEAN":
+            v = sel.mean(-1)
+        elif score_agg == "MAX":
+            v = sel.max(-1)[0]
+        else:
+            v = torch.pow(torch.prod(sel, dim=-1), 1 / len(toks))
+        scores[:, :, label - 1 if minus_one else label] = v
     return scores
 
 
@@ -97,9 +109,11 @@ def atss_postprocess(bbox_reg, centerness, logits, anchors, image_sizes, positiv
         _, _, H, W = reg.shape
         prob = logit.sigmoid()
         if spec.mdetr_class_num != -1:
-            cls = token_to_class_scores(prob, positive_map, spec.mdetr_class_num, minus_one=True)
+            cls = token_to_class_scores(prob, positive_map, spec.mdetr_class_num, minus_one=True, score_agg=spec.score_agg)
         else:
-            cls = token_to_class_scores(prob, positive_map, spec.num_classes - 1, minus_one=True)
+            if spec.score_agg == "POWER":
+                raise NotImplementedError("POWER exists in convert_grounding_to_od_logits_v2 only (inference.py:775-792)")
+            cls = token_to_class_scores(prob, positive_map, spec.num_classes - 1, minus_one=True, score_agg=spec.score_agg)
         reg = reg.permute(0, 2, 3, 1).reshape(B, -1, 4)
         cand = cls > spec.pre_nms_thresh
         topn = cand.reshape(B, -1).sum(1).clamp(max=spec.pre_nms_top_n)

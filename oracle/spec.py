@@ -57,6 +57,7 @@ class Spec:
     nms_thresh: float = 0.6
     detections_per_img: int = 300
     mdetr_class_num: int = 3000     # TEST.MDETR_STYLE_AGGREGATE_CLASS_NUM (-1 => use num_classes-1)
+    score_agg: str = "MEAN"         # MODEL.DYHEAD.SCORE_AGG: MEAN | MAX | ONEHOT | POWER (MDETR-style aggregation only)
     size_divisibility: int = 32
 
     @property

@@ -134,7 +134,7 @@ def _dcn_cols(x_nhwc, om, stride):
     return cols.reshape(B, n, 9 * C).to(x_nhwc.dtype), (Ho, Wo)
 
 
-def align_scores(dot, tbias, tokidx, ctr, thr, want_cls=False):
+def align_scores(dot, tbias, tokidx, ctr, thr, want_cls=False, agg=0):
     v = (dot.float() + tbias[:, None, :]).clamp(-50000, 50000).sigmoid()
     L, MT = tokidx.shape[-2:]
     B = dot.shape[0]
@@ -144,7 +144,8 @@ def align_scores(dot, tbias, tokidx, ctr, thr, want_cls=False):
         for l in range(L):
             toks = [int(t) for t in tix[l] if int(t) >= 0]
             if toks:
-                cls[b, :, l] = v[b][:, toks].mean(-1)
+                sel = v[b][:, toks]
+                cls[b, :, l] = sel.mean(-1) if agg == 0 else (sel.max(-1)[0] if agg == 1 else sel.prod(-1) ** (1.0 / len(toks)))
     out = torch.where(cls > thr, (cls * ctr.float().sigmoid()[..., None]).clamp(min=1.17549435e-38), torch.full_like(cls, -1.0))
     return (out, cls) if want_cls else out
 

@@ -21,7 +21,7 @@ def test_c_abi_exports_match_header():
     lib = ops.load_library()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.mq_abi_version() == 16
+    assert lib.mq_abi_version() == 17
     assert lib.mq_attn_workspace_bytes(2, 8, 256, 256, 4) == 4 * 2 * 8 * 256 * 258 * 4
     assert lib.mq_ml_nms_workspace_bytes(2, 130) == 2 * 130 * 3 * 8
 
@@ -57,11 +57,19 @@ def test_unsupported_config_is_rejected_by_name():
     cfg.MODEL.LANGUAGE_BACKBONE.QV_START = 1
     cfg.MODEL.LANGUAGE_BACKBONE.BERT_VOCAB_SIZE = 1100
     cfg.MODEL.DYHEAD.NUM_CONVS = 1
-    cfg.MODEL.DYHEAD.SCORE_AGG = "MAX"
+    cfg.MODEL.DYHEAD.SCORE_AGG = "POWER"           # the reference: POWER exists in the MDETR-style aggregation only
+    cfg.TEST.MDETR_STYLE_AGGREGATE_CLASS_NUM = -1
     model = build_detection_model(cfg, tokenizer=object())
     with pytest.raises(NotImplementedError, match="SCORE_AGG"):
         model._validate_config()
-    cfg.MODEL.DYHEAD.SCORE_AGG = "MEAN"
+    cfg.TEST.MDETR_STYLE_AGGREGATE_CLASS_NUM = 3000
+    model._validate_config()
+    cfg.MODEL.DYHEAD.SCORE_AGG = "MEDIAN"
+    with pytest.raises(NotImplementedError, match="SCORE_AGG"):
+        model._validate_config()
+    for agg in ("MAX", "ONEHOT", "MEAN"):
+        cfg.MODEL.DYHEAD.SCORE_AGG = agg
+        model._validate_config()
     cfg.MODEL.LANGUAGE_BACKBONE.PAD_MAX = False
     with pytest.raises(NotImplementedError, match="PAD_MAX"):
         model._validate_config()

@@ -145,3 +145,44 @@ def test_extract_query_host_logic(setup, emulated_ops, monkeypatch):
     from mq_det_amd.modeling.detector import expand_bbox
     lv = model.pooler.map_levels(expand_bbox(bl, cfg.VISION_QUERY.EXPAND_RATIO))
     assert len(set(lv.tolist())) >= 2
+
+
+@pytest.mark.parametrize("agg,mdetr", [("MAX", -1), ("ONEHOT", -1), ("POWER", 3000), ("ONEHOT", 3000)])
+def test_score_agg_modes_through_the_boundary(setup, monkeypatch, agg, mdetr):
+    """MODEL.DYHEAD.SCORE_AGG != MEAN through GeneralizedVLRCNN_New.forward (token index for ONEHOT = first len(positive_map)
+    token columns, label = column + 1; MAX / POWER inside the scoring op) against the oracle's ATSSPostProcessor restatement."""
+    from dataclasses import replace
+    from mq_det_amd import ops
+    from mq_det_amd.modeling import detector
+    from mq_det_amd.structures import ImageList
+    spec, sd, cfg0, _ = setup
+    for n in ("attention", "attention4", "window_attention", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores",
+              "dyconv_branch_coef", "dyconv_coef_group", "dyconv_fuse", "dyrelu_", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "vlfuse_i2t",
+              "vlfuse_t2i", "box_decode", "ml_nms", "roi_align", "swin_mlp"):
+        monkeypatch.setattr(ops, n, getattr(emu, n))
+    cfg = cfg0.clone()
+    cfg.MODEL.DYHEAD.SCORE_AGG, cfg.TEST.MDETR_STYLE_AGGREGATE_CLASS_NUM = agg, mdetr
+    cfg.MODEL.DYHEAD.LEVEL_STREAMS = False
+
+    def prepare(self, device=None):
+        self._validate_config()
+        self._plan = pipeline.build_plan(self.state_dict(), self.cfg, torch.device("cpu"), dtype=torch.float32)
+        self._plan_key, self.use_hip_graph = torch.device("cpu"), False
+        return self._plan
+    monkeypatch.setattr(detector.GeneralizedVLRCNN_New, "prepare", prepare)
+    model = detector.GeneralizedVLRCNN_New(cfg, tokenizer=object())
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    images, sizes, ids, am, pm, bank = pc.make_inputs(spec)
+    model.load_query_bank(bank)
+    sp = replace(spec, score_agg=agg, mdetr_class_num=mdetr)
+    with torch.no_grad():
+        dets = od.forward(sd, sp, images, sizes, ids, am, pm, bank)
+        out = model(ImageList(images, sizes), positive_map=pm, input_ids=ids, attention_mask=am)
+    for b, d in enumerate(dets):
+        assert len(out[b]) == len(d["boxes"]) > 0
+        o = torch.argsort(d["scores"], descending=True, stable=True)
+        close(out[b].get_field("scores"), d["scores"][o], 2e-3)
+        assert (out[b].get_field("labels") == d["labels"][o]).float().mean() > 0.98       # near-ties may swap neighbours
+    if agg == "ONEHOT":
+        assert set(torch.cat([o.get_field("labels") for o in out]).tolist()) <= set(range(1, len(pm) + 1))
