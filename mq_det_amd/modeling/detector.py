@@ -152,9 +152,6 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
                                       + (" / POWER" if mdetr else " (POWER only with TEST.MDETR_STYLE_AGGREGATE_CLASS_NUM != -1)"))
         if M.LANGUAGE_BACKBONE.MAX_QUERY_LEN > 256 or M.LANGUAGE_BACKBONE.MAX_QUERY_LEN % 8:
             raise NotImplementedError("MODEL.LANGUAGE_BACKBONE.MAX_QUERY_LEN must be a multiple of 8 and <= 256 (VLFuse kernels)")
-        if not M.LANGUAGE_BACKBONE.PAD_MAX:
-            raise NotImplementedError("MODEL.LANGUAGE_BACKBONE.PAD_MAX = False (captions padded to the longest of the batch) is not "
-                                      "supported: the attention kernels need a key count that is a multiple of 8; keep PAD_MAX = True")
         if M.BACKBONE.OUT_CHANNELS != 256 or M.DYHEAD.CHANNELS != 256:
             raise NotImplementedError("the VLDyHead kernels (VLFuse, DCNv2, DyConv epilogue) are written for 256 channels")
         if M.SWINT.WINDOW_SIZE ** 2 > 160:
@@ -212,8 +209,10 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
         hit = self._tok_cache.get(key)
         if hit is None:
             LB = self.cfg.MODEL.LANGUAGE_BACKBONE
-            tok = self.tokenizer(list(captions), max_length=LB.MAX_QUERY_LEN,
-                                 padding="max_length" if LB.PAD_MAX else "longest",
+            # PAD_MAX = False ("longest" in the reference, generalized_vl_rcnn_new.py:378-383) pads to MAX_QUERY_LEN here as well:
+            # padded positions are masked keys everywhere (BERT, GCP, VLFuse) and never scored, so the detections are the same,
+            # and the kernels skip all-padding key tiles through kv_len -- a shorter T would buy nothing and cost a new graph key
+            tok = self.tokenizer(list(captions), max_length=LB.MAX_QUERY_LEN, padding="max_length",
                                  return_special_tokens_mask=True, return_tensors="pt", truncation=True)
             am = tok["attention_mask"]
             # host-side bound of the per-caption key length (last attended position + 1): picks the kernel variant of

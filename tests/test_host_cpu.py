@@ -70,11 +70,11 @@ def test_unsupported_config_is_rejected_by_name():
     for agg in ("MAX", "ONEHOT", "MEAN"):
         cfg.MODEL.DYHEAD.SCORE_AGG = agg
         model._validate_config()
-    cfg.MODEL.LANGUAGE_BACKBONE.PAD_MAX = False
-    with pytest.raises(NotImplementedError, match="PAD_MAX"):
-        model._validate_config()
-    cfg.MODEL.LANGUAGE_BACKBONE.PAD_MAX = True
+    cfg.MODEL.LANGUAGE_BACKBONE.PAD_MAX = False            # accepted: same detections (tokenize pads to MAX_QUERY_LEN, masked)
     model._validate_config()
+    cfg.MODEL.LANGUAGE_BACKBONE.MAX_QUERY_LEN = 300
+    with pytest.raises(NotImplementedError, match="MAX_QUERY_LEN"):
+        model._validate_config()
 
 
 def test_state_dict_names_match_reference_contract():

@@ -98,3 +98,27 @@ def test_box_decode_identity_and_clamp():
     torch.testing.assert_close(out, anchors)
     big = box_decode(torch.tensor([[0.0, 0.0, 1e4, 1e4]]), anchors)
     assert abs(float(big[0, 2] - big[0, 0]) + 1 - 64 * 1000 / 16) < 1e-2
+
+
+def test_pad_max_false_gives_the_same_detections():
+    """LANGUAGE_BACKBONE.PAD_MAX = False (captions padded to the longest of the batch, generalized_vl_rcnn_new.py:378-383) vs
+    True (padded to MAX_QUERY_LEN): padding is masked everywhere, so the reference's detections do not depend on it -- the reason
+    the product pads to MAX_QUERY_LEN for both settings (detector.tokenize).  Text-only path: with vision queries the reference
+    itself needs T == MAX_QUERY_LEN (its query masks are built [.., MAX_QUERY_LEN], generalized_vl_rcnn_new.py:295-305)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import parity_checks as pc
+    from oracle import tiny_spec, detector as od
+    from oracle.weights import make_state_dict
+    spec = tiny_spec()
+    sd = make_state_dict(spec, 0)
+    images, sizes, ids, am, pm, bank = pc.make_inputs(spec)
+    n = int(am[0].sum())
+    with torch.no_grad():
+        full = od.forward(sd, spec, images, sizes, ids, am, pm, None)
+        short = od.forward(sd, spec, images, sizes, ids[:, :n], am[:, :n], pm, None)
+    for a, b in zip(full, short):
+        assert len(a["boxes"]) == len(b["boxes"]) > 0
+        assert torch.allclose(a["scores"], b["scores"], atol=2e-5) and torch.equal(a["labels"], b["labels"])
+        assert torch.allclose(a["boxes"], b["boxes"], atol=1e-2)
