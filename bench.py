@@ -53,7 +53,7 @@ HBM_PEAK_GBS = 8000.0
 GFLOP_PER_IMAGE_L = 3260.0         # MQ-GLIP-L (Swin-L 1625 + 8 fusion layers ...), BASELINE.md section 2
 
 
-def build_model(dev, caches=False, n_classes=NUM_CLASSES_IN_CAPTION, n_categories=None, large=False, words=None):
+def build_model(dev, caches=False, n_classes=NUM_CLASSES_IN_CAPTION, n_categories=None, large=False, words=None, dtype="f16"):
     from transformers import AutoTokenizer
     from mq_det_amd import get_cfg
     from mq_det_amd.modeling.detector import GeneralizedVLRCNN_New
@@ -65,6 +65,7 @@ def build_model(dev, caches=False, n_classes=NUM_CLASSES_IN_CAPTION, n_categorie
     cfg.MODEL.ATSS.DETECTIONS_PER_IMG = 300
     cfg.TEST.MDETR_STYLE_AGGREGATE_CLASS_NUM = 3000
     cfg.MODEL.BACKBONE_CACHE = bool(caches)
+    cfg.MODEL.COMPUTE_DTYPE = "bfloat16" if dtype == "bf16" else "float16"      # operand type of the kernels (fp32 accumulate)
     if large:                                                 # configs/pretrain/mq-glip-l.yaml:11-17,41
         cfg.MODEL.SWINT.EMBED_DIM, cfg.MODEL.SWINT.DEPTHS = 192, (2, 2, 18, 2)
         cfg.MODEL.SWINT.NUM_HEADS, cfg.MODEL.SWINT.WINDOW_SIZE = (6, 12, 24, 48), 12
@@ -439,6 +440,8 @@ def main():
                                                                                   "short: one token per class, 81 tokens (the round-1 caption)")
     ap.add_argument("--chunk-batch", type=int, default=0, help="lvis workload: image x chunk items stacked per launch sequence "
                                                                 "through model.forward_chunks (0 = one forward per chunk)")
+    ap.add_argument("--dtype", choices=["f16", "bf16"], default=None, help="16-bit operand type of the kernels: f16 (default; BASELINE "
+                                                                          "configs[1]) or bf16 (default of --workload mq-glip-l, configs[3])")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (for PMC profiling)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-worker-gdino", action="store_true", help=argparse.SUPPRESS)
@@ -463,8 +466,10 @@ def main():
     lvis, large = args.workload == "lvis", args.workload == "mq-glip-l"
     if large and args.batch == B_PER_GPU:
         args.batch = 4                                        # BASELINE.json configs[3]: bs = 4 / GPU
+    if args.dtype is None:
+        args.dtype = "bf16" if large else "f16"               # BASELINE.json configs[3]: "MQ-GLIP-L ... bf16 MFMA"
     cfg, model, chunks = build_model(dev, caches=lvis, n_categories=1203 if lvis else None, large=large,
-                                     words=(1,) if args.caption == "short" else None)
+                                     words=(1,) if args.caption == "short" else None, dtype=args.dtype)
     if args.no_graph:
         model.use_hip_graph = False
 
@@ -543,9 +548,9 @@ def main():
         res = {
             "metric": "images/sec MQ-GLIP-T 800×1333 5-shot vision queries, 1/2/4/8 MI355X", "value": round(ips, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": ("BASELINE.json configs[3] model: MQ-GLIP-L (Swin-L window 12 + BERT-base + GCP + 8-layer VLDyHead), fp16 operands "
-                                    f"(the config names bf16; the kernels are fp16-in / fp32-accumulate), 5 vision queries x 40 classes, {n_tok}-token "
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": ("BASELINE.json configs[3]: MQ-GLIP-L (Swin-L window 12 + BERT-base + GCP + 8-layer VLDyHead), "
+                                    f"{'bf16' if args.dtype == 'bf16' else 'fp16'} MFMA operands / fp32 accumulation, 5 vision queries x 40 classes, {n_tok}-token "
                                     "caption, every step a full forward") if large else
                                    ("BASELINE.json configs[1]: MQ-GLIP-T (Swin-T + BERT-base + GCP + 6-layer VLDyHead), 5 vision queries x "
                                     f"40 classes, {n_tok}-token caption padded to 256, LVIS-style post-processing, every step a full forward "

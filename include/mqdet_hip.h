@@ -250,6 +250,40 @@ long mq_ml_nms_workspace_bytes(int B, int N);
 int mq_ml_nms(const float* boxes, const int* labels, const int* nvalid, void* workspace, unsigned char* keep,
               int B, int N, float thr, void* stream);
 
+/* ---- bf16 operands (BASELINE.json configs[3]: "MQ-GLIP-L ... bf16 MFMA").
+ * Every entry point that reads or writes 16-bit operands exists twice: `name` as declared above (fp16, v_mfma_f32_16x16x32_f16) and
+ * `name_bf16` -- the SAME kernel source compiled with bf16 operands (v_mfma_f32_16x16x32_bf16; fp32 accumulation, fp32 side inputs and
+ * fp32 residual streams unchanged), same arguments, same return codes, "fp16" in the comments above read as "bf16".  The entry points
+ * that only see fp32 / integer data (mq_abi_version, the *_workspace_bytes / mq_dcnv2_stats_blocks size queries, mq_ml_nms) have no twin. */
+#ifdef __cplusplus
+#define MQ_BF16_TWIN(name) extern decltype(name) name##_bf16;
+#else
+#define MQ_BF16_TWIN(name) extern __typeof__(name) name##_bf16;
+#endif
+MQ_BF16_TWIN(mq_attn_fwd)
+MQ_BF16_TWIN(mq_window_attn_fwd)
+MQ_BF16_TWIN(mq_gcp_sparse_attn_fwd)
+MQ_BF16_TWIN(mq_gcp_gate_residual_fwd)
+MQ_BF16_TWIN(mq_vlfuse_i2t_fwd)
+MQ_BF16_TWIN(mq_vlfuse_t2i_fwd)
+MQ_BF16_TWIN(mq_layernorm_fwd)
+MQ_BF16_TWIN(mq_swin_mlp_fwd)
+MQ_BF16_TWIN(mq_conv3x3_fwd)
+MQ_BF16_TWIN(mq_conv3x3_nchw32_fwd)
+MQ_BF16_TWIN(mq_dcnv2_fwd)
+MQ_BF16_TWIN(mq_dcnv2_group_fwd)
+MQ_BF16_TWIN(mq_dyconv_stats)
+MQ_BF16_TWIN(mq_dyconv_coef)
+MQ_BF16_TWIN(mq_dyconv_coef_group)
+MQ_BF16_TWIN(mq_dyconv_fuse)
+MQ_BF16_TWIN(mq_dyrelu_coef)
+MQ_BF16_TWIN(mq_dyrelu_apply)
+MQ_BF16_TWIN(mq_align_scores_fwd)
+MQ_BF16_TWIN(mq_box_decode)
+MQ_BF16_TWIN(mq_roi_align_fwd)
+MQ_BF16_TWIN(mq_msdeform_attn_fwd)
+MQ_BF16_TWIN(mq_msdeform_attn_q_fwd)
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,11 +30,16 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
+    # every kernel source twice: fp16 (the entry points of include/mqdet_hip.h) and -DMQ_BF16 (the same kernels with bf16
+    # operands under the *_bf16 entry points, csrc/common.h); api.hip (the ABI version) once
     for src in SOURCES:
-        obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
-        objs.append(obj)
-        procs.append((src, subprocess.Popen([hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj],
-                                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        for suffix, defs in (("", []), ("_bf16", ["-DMQ_BF16"])):
+            if suffix and src == "api.hip":
+                continue
+            obj = os.path.join(LIB_DIR, src.replace(".hip", suffix + ".o"))
+            objs.append(obj)
+            procs.append((src + suffix, subprocess.Popen([hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), *defs, "-c", os.path.join(CSRC, src), "-o", obj],
+                                                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:

@@ -95,7 +95,7 @@ def get_cfg():
         META_ARCHITECTURE="GeneralizedVLRCNN_New", DEVICE="cuda", RPN_ONLY=True, RPN_ARCHITECTURE="VLDYHEAD",
         DEBUG=False, LINEAR_PROB=False, WEIGHT="",
         USE_HIP_GRAPH=True,       # new: replay the device forward as one HIP graph per input-shape signature
-        COMPUTE_DTYPE="float16",   # new: fp16 (configs[1]) or bfloat16 not yet; kernels are fp16-in / fp32-accumulate
+        COMPUTE_DTYPE="float16",   # new: "float16" (configs[1]) or "bfloat16" (configs[3]): operand type of the kernels, fp32 accumulate
         BACKBONE=dict(CONV_BODY="SWINT-FPN-RETINANET", OUT_CHANNELS=256, FREEZE_CONV_BODY_AT=-1, FREEZE=False,
                       USE_CHECKPOINT=False, OUT_FEATURES=("stage2", "stage3", "stage4", "stage5")),
         SWINT=dict(EMBED_DIM=96, OUT_CHANNELS=(96, 192, 384, 768), DEPTHS=(2, 2, 6, 2), NUM_HEADS=(3, 6, 12, 24),

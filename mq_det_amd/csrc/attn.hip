@@ -25,6 +25,8 @@
 // workspace and mq_attn_combine merges them.
 #include "common.h"
 
+MQ_NAMESPACE_BEGIN
+
 struct AttnParams {
   const half_t* q; const half_t* k; const half_t* vt; half_t* o;
   const float* key_bias;     // [B, Nk] or nullptr
@@ -387,11 +389,13 @@ static int launch_attn(const AttnParams& p, hipStream_t stream) {
   return 0;
 }
 
+#ifndef MQ_BF16
 extern "C" long mq_attn_workspace_bytes(int B, int H, int Nq, int D, int nsplit) {
   return nsplit > 1 ? (long)nsplit * B * H * Nq * (D + 2) * (long)sizeof(float) : 0;
 }
+#endif
 
-extern "C" int mq_attn_fwd(const void* q, const void* k, const void* vt, void* o, const float* key_bias,
+extern "C" int MQ_SYM(mq_attn_fwd)(const void* q, const void* k, const void* vt, void* o, const float* key_bias,
                            const int* kv_len, const unsigned char* qk_mask, long mask_bs, long mask_hs, long mask_rs,
                            void* workspace, int B, int H, int Nq, int Nk, int D,
                            long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs,
@@ -423,3 +427,5 @@ extern "C" int mq_attn_fwd(const void* q, const void* k, const void* vt, void* o
     default: return -1;
   }
 }
+
+MQ_NAMESPACE_END

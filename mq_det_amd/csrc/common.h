@@ -8,16 +8,37 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Element type of the 16-bit operands.  Every kernel source is compiled TWICE (mq_det_amd/build.py): as is -- half_t = fp16, the
+// entry points of include/mqdet_hip.h -- and with -DMQ_BF16 -- half_t = bf16 (v_mfma_f32_16x16x32_bf16), entry points with the
+// suffix _bf16, everything inside namespace mq_bf16 (BASELINE.json configs[3]: "MQ-GLIP-L ... bf16 MFMA").  Without the macro
+// MQ_SYM / MQ_NAMESPACE_* expand to nothing: the fp16 objects are token-for-token what they were before the switch existed.
+#ifdef MQ_BF16
+typedef __bf16 half_t;
+typedef __bf16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 half4 __attribute__((ext_vector_type(4)));
+typedef __bf16 half2_ __attribute__((ext_vector_type(2)));
+#define MQ_SYM(name) name##_bf16
+#define MQ_NAMESPACE_BEGIN namespace mq_bf16 {
+#define MQ_NAMESPACE_END }
+#else
 typedef _Float16 half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
+#define MQ_SYM(name) name
+#define MQ_NAMESPACE_BEGIN
+#define MQ_NAMESPACE_END
+#endif
 typedef float float4_ __attribute__((ext_vector_type(4)));
 
 #define MQ_NEG_BIG (-1.0e30f)
 
 __device__ __forceinline__ float4_ mfma16(half8 a, half8 b, float4_ c) {
+#ifdef MQ_BF16
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#else
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
 }
 
 __device__ __forceinline__ half8 zero8() {

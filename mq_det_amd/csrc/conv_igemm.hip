@@ -19,6 +19,8 @@
 // one barrier per step; epilogue transposes through LDS for 16-byte coalesced NHWC stores.
 #include "common.h"
 
+MQ_NAMESPACE_BEGIN
+
 struct ConvParams {
   const half_t* x;       // [B, H, W, C], batch stride x_bs (elements)
   const half_t* w;       // [BN rows][9*C]  (k = tap*C + c), rows >= N are zero
@@ -236,7 +238,7 @@ static int conv_common(ConvParams& p, const void* x, const void* w, const void* 
 }
 
 // plain 3x3 conv, pad 1.  w: [Npad, 9*C] with Npad = 256 (N <= 256, N > 32) or 32 (N <= 32), rows >= N zero.
-extern "C" int mq_conv3x3_fwd(const void* x, const void* w, const void* bias, void* out, int B, int H, int W, int C,
+extern "C" int MQ_SYM(mq_conv3x3_fwd)(const void* x, const void* w, const void* bias, void* out, int B, int H, int W, int C,
                               long x_bs, int N, int out_ld, int stride, void* stream) {
   ConvParams p;
   int rc = conv_common(p, x, w, bias, out, B, H, W, C, x_bs, N, out_ld, stride);
@@ -245,3 +247,5 @@ extern "C" int mq_conv3x3_fwd(const void* x, const void* w, const void* bias, vo
   if (N <= 256) return launch_conv<false, 256, 2, 2>(p, (hipStream_t)stream);
   return -1;
 }
+
+MQ_NAMESPACE_END

@@ -18,6 +18,8 @@
 //     permute + float() pass.
 #include "common.h"
 
+MQ_NAMESPACE_BEGIN
+
 struct ConvSmallParams {
   const half_t* x; const half_t* w; const half_t* bias; float* out;
   long x_bs;
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvSmallParams p) {
 
 // x [B,H,W,C] fp16 NHWC (batch stride x_bs, C % 32 == 0, C <= 256), w [32, 9*C] fp16 (k = tap*C + c, rows >= N zero),
 // bias [N] fp16 or NULL -> out [B, N, H, W] fp32 (NCHW), stride 1, pad 1.
-extern "C" int mq_conv3x3_nchw32_fwd(const void* x, const void* w, const void* bias, float* out, int B, int H, int W, int C,
+extern "C" int MQ_SYM(mq_conv3x3_nchw32_fwd)(const void* x, const void* w, const void* bias, float* out, int B, int H, int W, int C,
                                      long x_bs, int N, void* stream) {
   if (B <= 0) return 0;
   if (C % 32 || C > 256 || (C > 128 && C % 64) || N < 1 || N > 32) return -1;
@@ -160,3 +162,5 @@ extern "C" int mq_conv3x3_nchw32_fwd(const void* x, const void* w, const void* b
   MQ_CHECK_LAUNCH();
   return 0;
 }
+
+MQ_NAMESPACE_END

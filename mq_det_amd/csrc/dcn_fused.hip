@@ -25,6 +25,8 @@
 #include <type_traits>
 #include <cstdlib>
 
+MQ_NAMESPACE_BEGIN
+
 struct DcnFParams {
   const half_t* x; const half_t* w; const half_t* bias; const float* om; half_t* out;
   float* stats;            // optional [B, tiles_y*tiles_x, 256, 3]: per-patch (sum y, sum y^2, sum w_p y) of the fp16 output
@@ -359,10 +361,12 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
 // DCNv2 3x3, pad 1, 256 output channels.  x [B,H,W,C] fp16 NHWC (batch stride x_bs, C % 128 == 0), om [B,27,oH,oW] fp32
 // (18 offsets + 9 mask logits, NCHW), w [256, 9*C] fp16 (k = tap*C + c), bias [256] fp16 or NULL, out [B*Ho*Wo, out_ld];
 // stats (optional) [B, mq_dcnv2_stats_blocks(H, W, stride), 256, 3] fp32 with position weights wy [Ho] x wx [Wo] (or NULL).
+#ifndef MQ_BF16
 extern "C" int mq_dcnv2_stats_blocks(int H, int W, int stride) {
   const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
   return ((Ho + DCN_PH - 1) / DCN_PH) * ((Wo + DCN_PW - 1) / DCN_PW);
 }
+#endif
 
 struct mq_dcn_branch {          // mirrors include/mqdet_hip.h
   const void* x; const float* om; const void* w; const void* bias; void* out; float* stats; const float* wy; const float* wx;
@@ -370,7 +374,7 @@ struct mq_dcn_branch {          // mirrors include/mqdet_hip.h
   int B, H, W, C, oH, oW, N, out_ld, stride, reserved;
 };
 
-extern "C" int mq_dcnv2_group_fwd(const mq_dcn_branch* br, int n, void* stream) {
+extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* stream) {
   if (n <= 0) return 0;
   if (n > DCN_MAX_BRANCH) return -3;
   DcnGroup g;
@@ -411,11 +415,13 @@ extern "C" int mq_dcnv2_group_fwd(const mq_dcn_branch* br, int n, void* stream) 
   return 0;
 }
 
-extern "C" int mq_dcnv2_fwd(const void* x, const float* om, const void* w, const void* bias, void* out, float* stats,
+extern "C" int MQ_SYM(mq_dcnv2_fwd)(const void* x, const float* om, const void* w, const void* bias, void* out, float* stats,
                             const float* wy, const float* wx, int B, int H, int W, int C, long x_bs, int oH, int oW, int N,
                             int out_ld, int stride, void* stream) {
   mq_dcn_branch a;
   a.x = x; a.om = om; a.w = w; a.bias = bias; a.out = out; a.stats = stats; a.wy = wy; a.wx = wx; a.x_bs = x_bs;
   a.B = B; a.H = H; a.W = W; a.C = C; a.oH = oH; a.oW = oW; a.N = N; a.out_ld = out_ld; a.stride = stride; a.reserved = 0;
-  return mq_dcnv2_group_fwd(&a, 1, stream);
+  return MQ_SYM(mq_dcnv2_group_fwd)(&a, 1, stream);
 }
+
+MQ_NAMESPACE_END

@@ -17,6 +17,8 @@
 //   mq_dyrelu_apply   out = max(a1 x + b1, a2 x + b2) in place.
 #include "common.h"
 
+MQ_NAMESPACE_BEGIN
+
 // ---------------------------------------------------------------------------------------------- stats
 // part[b, blk, c, 0..2] = per-block (sum y, sum y^2, sum w_p y); wy/wx == nullptr -> w_p = 1/n.  Partials (not atomics)
 // keep the reduction order fixed -> bitwise reproducible statistics.
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void dyconv_stats_kernel(const half_t* __restr
   }
 }
 
-extern "C" int mq_dyconv_stats(const void* y, float* sums, const float* wy, const float* wx, int B, int n, int W, int C,
+extern "C" int MQ_SYM(mq_dyconv_stats)(const void* y, float* sums, const float* wy, const float* wx, int B, int n, int W, int C,
                                void* stream) {
   if (B <= 0 || n <= 0) return 0;
   if (C != 256) return -1;
@@ -111,7 +113,7 @@ __global__ void dyconv_coef_kernel(const float* __restrict__ part, int nblk, con
   coef[((long)b * C + c) * 2 + 1] = a * sh;
 }
 
-extern "C" int mq_dyconv_coef(const float* sums, const void* gamma, const void* beta, const float* attn_w,
+extern "C" int MQ_SYM(mq_dyconv_coef)(const float* sums, const void* gamma, const void* beta, const float* attn_w,
                               const float* attn_b, float* coef, int B, int n, int nblk, int C, int G, float eps,
                               int nbranches, void* stream) {
   if (B <= 0) return 0;
@@ -184,7 +186,7 @@ struct mq_coef_branch {          // mirrors include/mqdet_hip.h
   const float* sums; const void* gamma; const void* beta; float* coef; int nblk, n, nbranches, reserved;
 };
 
-extern "C" int mq_dyconv_coef_group(const mq_coef_branch* br, int nbr, const float* attn_w, const float* attn_b, int B, int C,
+extern "C" int MQ_SYM(mq_dyconv_coef_group)(const mq_coef_branch* br, int nbr, const float* attn_w, const float* attn_b, int B, int C,
                                     int G, float eps, void* stream) {
   if (B <= 0 || nbr <= 0) return 0;
   if (C != 256 || G > 64 || C % G || nbr > 16) return -1;
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256) void dyconv_fuse_kernel(FuseParams p) {
   }
 }
 
-extern "C" int mq_dyconv_fuse(const void* y0, const float* coef0, int hs0, int ws0, const void* y1, const float* coef1,
+extern "C" int MQ_SYM(mq_dyconv_fuse)(const void* y0, const float* coef0, int hs0, int ws0, const void* y1, const float* coef1,
                               int hs1, int ws1, const void* y2, const float* coef2, int hs2, int ws2, int nbranches,
                               void* out, long out_bs, float* pool, int B, int H, int W, int C, void* stream) {
   if (B <= 0) return 0;
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(256) void dyrelu_coef_kernel(const float* __restric
   }
 }
 
-extern "C" int mq_dyrelu_coef(const float* pool, const void* w0, const void* b0, const void* w2, const void* b2,
+extern "C" int MQ_SYM(mq_dyrelu_coef)(const float* pool, const void* w0, const void* b0, const void* w2, const void* b2,
                               float* coef, int B, int n, int C, void* stream) {
   if (B <= 0) return 0;
   if (C != 256) return -1;
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(256) void dyrelu_apply_kernel(half_t* __restrict__ 
   }
 }
 
-extern "C" int mq_dyrelu_apply(void* x, const float* coef, int B, int n, int C, long x_bs, void* stream) {
+extern "C" int MQ_SYM(mq_dyrelu_apply)(void* x, const float* coef, int B, int n, int C, long x_bs, void* stream) {
   if (B <= 0 || n <= 0) return 0;
   if (C % 8) return -1;
   long total = (long)n * (C / 8);
@@ -433,3 +435,5 @@ extern "C" int mq_dyrelu_apply(void* x, const float* coef, int B, int n, int C, 
   MQ_CHECK_LAUNCH();
   return 0;
 }
+
+MQ_NAMESPACE_END

@@ -22,6 +22,8 @@
 //   One wave per row: GELU(erf) + dot + tanh + axpy in one pass.
 #include "common.h"
 
+MQ_NAMESPACE_BEGIN
+
 template <int SMAX>
 __global__ __launch_bounds__(256) void gcp_sparse_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ kv,
                                                               const int* __restrict__ idx, half_t* __restrict__ out,
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void gcp_sparse_attn_loop_kernel(const half_t*
   *(half8*)(out + tok * HD + lane * 8) = o;
 }
 
-extern "C" int mq_gcp_sparse_attn_fwd(const void* q, const void* kv, const int* idx, void* out, int B, int T, int V,
+extern "C" int MQ_SYM(mq_gcp_sparse_attn_fwd)(const void* q, const void* kv, const int* idx, void* out, int B, int T, int V,
                                       int S, int heads, int dim_head, void* stream) {
   if (B <= 0 || T <= 0) return 0;
   if (heads * dim_head != 512 || dim_head != 64 || S < 0) return -1;
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256) void gcp_gate_residual_kernel(const half_t* __
   }
 }
 
-extern "C" int mq_gcp_gate_residual_fwd(const void* sup, const void* h, const void* w2, const void* x, int x_f32, void* out,
+extern "C" int MQ_SYM(mq_gcp_gate_residual_fwd)(const void* sup, const void* h, const void* w2, const void* x, int x_f32, void* out,
                                         float* gate_out, long M, int C, int G, void* stream) {
   if (M <= 0) return 0;
   if (C % 2) return -1;
@@ -188,3 +190,5 @@ extern "C" int mq_gcp_gate_residual_fwd(const void* sup, const void* h, const vo
   MQ_CHECK_LAUNCH();
   return 0;
 }
+
+MQ_NAMESPACE_END

@@ -16,6 +16,8 @@
 // is a coalesced 16- or 32-byte vector; torch's LayerNorm ran the C = 96 / 192 rows of Swin stage 1-2 at ~0.4 TB/s.
 #include "common.h"
 
+MQ_NAMESPACE_BEGIN
+
 template <bool F32>
 __device__ __forceinline__ void load8(const void* base, long off, float* v) {
   if constexpr (F32) {
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
   }
 }
 
-extern "C" int mq_layernorm_fwd(const void* x, int x_f32, const void* res, int res_f32, const void* gamma, const void* beta,
+extern "C" int MQ_SYM(mq_layernorm_fwd)(const void* x, int x_f32, const void* res, int res_f32, const void* gamma, const void* beta,
                                 void* y, float* y32, void* xsum, long rows, int C, float eps, void* stream) {
   if (rows <= 0) return 0;
   if (C % 8 || C > 3072) return -1;
@@ -147,3 +149,5 @@ extern "C" int mq_layernorm_fwd(const void* x, int x_f32, const void* res, int r
   MQ_CHECK_LAUNCH();
   return 0;
 }
+
+MQ_NAMESPACE_END

@@ -18,6 +18,8 @@
 #include "common.h"
 #include <cstdlib>
 
+MQ_NAMESPACE_BEGIN
+
 template <typename TV, typename TO>
 __global__ __launch_bounds__(256) void msda_kernel(const TV* __restrict__ value, const long* __restrict__ shapes,
                                                    const long* __restrict__ level_start, const float* __restrict__ loc,
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void msda_kernel(const TV* __restrict__ value,
   }
 }
 
-extern "C" int mq_msdeform_attn_fwd(const void* value, int value_f32, const long* shapes, const long* level_start, const float* loc,
+extern "C" int MQ_SYM(mq_msdeform_attn_fwd)(const void* value, int value_f32, const long* shapes, const long* level_start, const float* loc,
                                     const float* attn, void* out, int out_f32, int B, int S, int M, int D, int L, int Q, int P,
                                     void* stream) {
   if (B <= 0 || Q <= 0) return 0;
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(256) void msda_q_kernel(const TV* __restrict__ valu
   }
 }
 
-extern "C" int mq_msdeform_attn_q_fwd(const void* value, int value_f32, long value_bs, long value_ts, const long* shapes,
+extern "C" int MQ_SYM(mq_msdeform_attn_q_fwd)(const void* value, int value_f32, long value_bs, long value_ts, const long* shapes,
                                       const long* level_start, const void* qproj, const float* ref, int ref_dim,
                                       const int* valid_hw, void* out, int out_f32, int B, int S, int M, int D, int L, int Q, int P,
                                       void* stream) {
@@ -267,3 +269,5 @@ extern "C" int mq_msdeform_attn_q_fwd(const void* value, int value_f32, long val
   MQ_CHECK_LAUNCH();
   return 0;
 }
+
+MQ_NAMESPACE_END

@@ -23,6 +23,8 @@
 //   image, 64 boxes at a time (intra-chunk dependencies via wave shuffles).
 #include "common.h"
 
+MQ_NAMESPACE_BEGIN
+
 template <typename TD>
 __global__ __launch_bounds__(256) void align_scores_kernel(const TD* __restrict__ dot, const float* __restrict__ tbias,
                                                            const int* __restrict__ tokidx, const half_t* __restrict__ ctr,
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256) void align_scores_kernel(const TD* __restrict_
   }
 }
 
-extern "C" int mq_align_scores_fwd(const void* dot, int dot_f32, const float* tbias, const int* tokidx, long tok_bs,
+extern "C" int MQ_SYM(mq_align_scores_fwd)(const void* dot, int dot_f32, const float* tbias, const int* tokidx, long tok_bs,
                                    const void* ctr, float* out, float* cls_out, int B, int HW, int T, int L, int MT, float thr,
                                    long dot_bs, int agg, void* stream) {
   if (B <= 0 || HW <= 0 || L <= 0) return 0;
@@ -139,7 +141,7 @@ __global__ void box_decode_kernel(const float* __restrict__ val, const long* __r
   labels[o] = label_ids[(long)b * lab_bs + l];
 }
 
-extern "C" int mq_box_decode(const float* val, const long* flat, const void* reg, const float* anchors, const int* label_ids,
+extern "C" int MQ_SYM(mq_box_decode)(const float* val, const long* flat, const void* reg, const float* anchors, const int* label_ids,
                              long lab_bs, const float* im_wh, float* boxes, float* scores, int* labels, int B, int K, int HW,
                              int L, long out_stride, long out_off, void* stream) {
   if (B <= 0 || K <= 0) return 0;
@@ -151,6 +153,7 @@ extern "C" int mq_box_decode(const float* val, const long* flat, const void* reg
 }
 
 // ------------------------------------------------------------------------------------------------
+#ifndef MQ_BF16                                     // NMS works on fp32 boxes: one copy, in the fp16 translation unit
 __device__ __forceinline__ float ml_iou(const float* a, int la, const float* b, int lb) {
   if (la != lb) return 0.f;
   float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
@@ -372,3 +375,6 @@ extern "C" int mq_ml_nms(const float* boxes, const int* labels, const int* nvali
   MQ_CHECK_LAUNCH();
   return 0;
 }
+#endif
+
+MQ_NAMESPACE_END

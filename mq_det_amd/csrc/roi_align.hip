@@ -16,6 +16,8 @@
 //            generalized_vl_rcnn_new.py:263)
 #include "common.h"
 
+MQ_NAMESPACE_BEGIN
+
 template <typename TF>
 __global__ __launch_bounds__(256) void roi_align_kernel(const TF* __restrict__ feat, const float* __restrict__ rois,
                                                         float* __restrict__ out, int R, int C, int H, int W, long sn, long sc,
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const TF* __restrict__ f
   if (reduce_mean && live) out[(long)r * C + c] = total / (float)(PH * PW);
 }
 
-extern "C" int mq_roi_align_fwd(const void* feat, int feat_f32, const float* rois, float* out, int R, int C, int H, int W,
+extern "C" int MQ_SYM(mq_roi_align_fwd)(const void* feat, int feat_f32, const float* rois, float* out, int R, int C, int H, int W,
                                 long sn, long sc, long sh, long sw, int PH, int PW, float spatial_scale, int sampling_ratio,
                                 int aligned, int reduce_mean, void* stream) {
   if (R <= 0 || C <= 0) return 0;
@@ -92,3 +94,5 @@ extern "C" int mq_roi_align_fwd(const void* feat, int feat_f32, const float* roi
   MQ_CHECK_LAUNCH();
   return 0;
 }
+
+MQ_NAMESPACE_END

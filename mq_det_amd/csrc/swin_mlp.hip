@@ -27,6 +27,8 @@
 #include <type_traits>
 #include <cstdlib>
 
+MQ_NAMESPACE_BEGIN
+
 struct SwinMlpParams {
   const float* x; const half_t* delta;
   const half_t* g2; const half_t* be2;
@@ -297,7 +299,7 @@ static int launch_swin_mlp(const SwinMlpParams& p, hipStream_t s) {
 
 // x [M, C] fp32, delta [M, C] fp16 or NULL, LN gamma / beta [C] fp16, w1 [4C, C], b1 [4C], w2p [C, 4C] (k-slots permuted: within every
 // block of 32 hidden units slot 8g + t holds hidden unit 4g + t for t < 4 and 16 + 4g + (t - 4) for t >= 4), b2 [C] fp16 -> out [M, C] fp32 (may alias x), y [M, C] fp16 = LayerNorm(out; gn, bn, eps_n) if y != NULL.
-extern "C" int mq_swin_mlp_fwd(const float* x, const void* delta, const void* ln_g, const void* ln_b, float eps, const void* w1,
+extern "C" int MQ_SYM(mq_swin_mlp_fwd)(const float* x, const void* delta, const void* ln_g, const void* ln_b, float eps, const void* w1,
                                const void* b1, const void* w2p, const void* b2, float* out, const void* next_g, const void* next_b,
                                float eps_next, void* y, long M, int C, void* stream) {
   if (M <= 0) return 0;
@@ -324,3 +326,5 @@ extern "C" int mq_swin_mlp_fwd(const float* x, const void* delta, const void* ln
     default: return -1;                                      // other widths: library GEMM path of the caller
   }
 }
+
+MQ_NAMESPACE_END

@@ -24,6 +24,8 @@
 #include <type_traits>
 #include <cstdlib>
 
+MQ_NAMESPACE_BEGIN
+
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(8)));
 typedef __attribute__((address_space(3))) fp16x4_t* lds_fp16x4_ptr;
 
@@ -359,7 +361,7 @@ static int vlfuse_qb() {
 
 // Image side of VLFuse.  max_kv: host-known upper bound of kv_len (T if unknown) -- picks the number of 64-key tiles
 // kept in registers.  See include/mqdet_hip.h.
-extern "C" int mq_vlfuse_i2t_fwd(const void* v_ln, const void* kf, const void* vo, const float* bias, const int* kv_len,
+extern "C" int MQ_SYM(mq_vlfuse_i2t_fwd)(const void* v_ln, const void* kf, const void* vo, const float* bias, const int* kv_len,
                                  const void* out_bias, void* out, int B, int N, int T, int heads, int max_kv, float clamp,
                                  void* stream) {
   if (B <= 0 || N <= 0) return 0;
@@ -597,12 +599,14 @@ __global__ __launch_bounds__(256) void vlfuse_t2i_combine_kernel(T2IParams p) {
   *(half4*)dst = y;
 }
 
+#ifndef MQ_BF16
 extern "C" long mq_vlfuse_t2i_workspace_bytes(int B, int T, int nsplit) {
   return (long)(nsplit < 1 ? 1 : nsplit) * B * VH * T * WS_LD * (long)sizeof(float);
 }
+#endif
 
 // Text side of VLFuse (always through the split workspace + combine, nsplit >= 1).  See include/mqdet_hip.h.
-extern "C" int mq_vlfuse_t2i_fwd(const void* kf, const void* v_ln, const int* kv_len, const unsigned char* key_mask, long key_mask_bs,
+extern "C" int MQ_SYM(mq_vlfuse_t2i_fwd)(const void* kf, const void* v_ln, const int* kv_len, const unsigned char* key_mask, long key_mask_bs,
                                  void* workspace, void* out, int B, int N, int T, int heads, int nsplit, float clamp, void* stream) {
   if (B <= 0 || T <= 0) return 0;
   if (N < 1 || workspace == nullptr || heads < 1 || heads > VH) return -1;
@@ -637,3 +641,5 @@ extern "C" int mq_vlfuse_t2i_fwd(const void* kf, const void* v_ln, const int* kv
   MQ_CHECK_LAUNCH();
   return 0;
 }
+
+MQ_NAMESPACE_END

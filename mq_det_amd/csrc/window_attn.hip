@@ -24,6 +24,8 @@
 //  stored 2 bytes per lane: ~1 TB/s.  profiles/README.md.)
 #include "common.h"
 
+MQ_NAMESPACE_BEGIN
+
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(8)));
 __device__ __forceinline__ half4 win_lds_tr16(const half_t* p) {
   fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)p);
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinParams p) {
   }
 }
 
-extern "C" int mq_window_attn_fwd(const void* qkv, const void* qkv_bias, const float* rel_bias, void* out,
+extern "C" int MQ_SYM(mq_window_attn_fwd)(const void* qkv, const void* qkv_bias, const float* rel_bias, void* out,
                                   int B, int H, int W, int C, int heads, int ws, int shift, void* stream) {
   if (B <= 0) return 0;
   if (C != heads * 32 || ws * ws > 160 || shift < 0 || shift >= ws) return -1;
@@ -203,3 +205,5 @@ extern "C" int mq_window_attn_fwd(const void* qkv, const void* qkv_bias, const f
   MQ_CHECK_LAUNCH();
   return 0;
 }
+
+MQ_NAMESPACE_END

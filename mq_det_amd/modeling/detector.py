@@ -37,6 +37,17 @@ def expand_bbox(box_list, expand_ratio=1.5):
     return out
 
 
+def compute_dtype(cfg):
+    """MODEL.COMPUTE_DTYPE: the 16-bit operand type of every kernel on the path -- "float16" (default, BASELINE.json configs[1])
+    or "bfloat16" (configs[3]: the *_bf16 entry points of include/mqdet_hip.h); accumulation and residual streams are fp32 either way."""
+    name = str(cfg.MODEL.get("COMPUTE_DTYPE", "float16")).lower()
+    if name in ("float16", "fp16", "half"):
+        return torch.float16
+    if name in ("bfloat16", "bf16"):
+        return torch.bfloat16
+    raise NotImplementedError(f"MODEL.COMPUTE_DTYPE = {name}: float16 or bfloat16")
+
+
 def pool_into_bank(cfg, pooler, visual_features, targets, query_images, exclude_similar, max_query_number):
     """Shared tail of `extract_query` (generalized_vl_rcnn_new.py:264-288 == groundingdino.py:397-421): ROI-pool the (already
     expanded) target boxes -- from their own FPN level (SELECT_FPN_LEVEL) or from all five --, average the bins inside the kernel,
@@ -134,7 +145,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
         from .. import ops
         ops.load_library()
         self._validate_config()
-        self._plan = pipeline.build_plan(self.state_dict(), self.cfg, device)
+        self._plan = pipeline.build_plan(self.state_dict(), self.cfg, device, dtype=compute_dtype(self.cfg))
         self._plan_key = device
         return self._plan
 

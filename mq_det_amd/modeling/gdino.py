@@ -16,7 +16,7 @@ from torch import nn
 
 from ..structures import BoxList, to_image_list
 from . import gdino_pipeline as gp
-from .detector import expand_bbox, pool_into_bank
+from .detector import compute_dtype, expand_bbox, pool_into_bank
 from .graph_runner import GraphRunner
 from .params import build_param_tree, gdino_param_specs, gdino_swin_cfg
 from .poolers import CustomPooler, Pooler
@@ -111,7 +111,7 @@ class GroundingDINO(GraphRunner, nn.Module):
             raise RuntimeError("mq_det_amd runs on MI355X only (HIP kernels, no CPU fallback); got device " + str(device))
         from .. import ops
         ops.load_library()
-        self._plan = gp.build_gdino_plan(self.state_dict(), self.cfg, device, self._swin)
+        self._plan = gp.build_gdino_plan(self.state_dict(), self.cfg, device, self._swin, dtype=compute_dtype(self.cfg))
         self._plan_key = device
         return self._plan
 

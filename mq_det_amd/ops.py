@@ -44,6 +44,13 @@ _SIGNATURES = {
     "mq_ml_nms_workspace_bytes": (_l, [_i, _i]),
     "mq_ml_nms": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
 }
+# entry points with 16-bit operands also exist as <name>_bf16 (same signature; include/mqdet_hip.h MQ_BF16_TWIN)
+BF16_TWINS = ("mq_attn_fwd", "mq_window_attn_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
+              "mq_layernorm_fwd", "mq_swin_mlp_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
+              "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyrelu_apply",
+              "mq_align_scores_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
+for _n in BF16_TWINS:
+    _SIGNATURES[_n + "_bf16"] = _SIGNATURES[_n]
 EXPORTS = tuple(_SIGNATURES)
 
 
@@ -123,6 +130,18 @@ def _chk(rc, name):
         raise RuntimeError(f"{name} failed with code {rc}")
 
 
+_H16 = (torch.float16, torch.bfloat16)
+
+
+def _fn(lib, name, *ts):
+    """The entry point for the 16-bit type of the operands `ts`: `name` (fp16) or `name_bf16` (the same kernel compiled with bf16
+    operands, include/mqdet_hip.h MQ_BF16_TWIN).  All 16-bit operands of one call must have the same type."""
+    kinds = {t.dtype for t in ts if t is not None and t.dtype in _H16}
+    if len(kinds) > 1:
+        raise TypeError(f"{name}: fp16 and bf16 operands in one call")
+    return getattr(lib, name + "_bf16") if torch.bfloat16 in kinds else getattr(lib, name)
+
+
 def _need_gpu(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -141,7 +160,7 @@ def attention4(q4, k4, vt4, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=N
         assert kv_len.dtype == torch.int32 and kv_len.shape == (B,) and kv_len.is_contiguous()
     Nk = k4.shape[1] if nk is None else nk
     assert k4.shape[0] == B and k4.shape[2:] == (H, D) and vt4.shape[:3] == (B, H, D) and vt4.shape[3] >= Nk
-    assert q4.dtype == k4.dtype == vt4.dtype == torch.float16
+    assert q4.dtype == k4.dtype == vt4.dtype and q4.dtype in _H16
     assert q4.stride(3) == 1 and k4.stride(3) == 1 and vt4.stride(3) == 1
     bias_bs = bias_hs = 0
     if key_bias is not None:
@@ -159,12 +178,12 @@ def attention4(q4, k4, vt4, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=N
             qk_mask = qk_mask.view(torch.uint8)
         assert qk_mask.dtype == torch.uint8 and qk_mask.shape == (B, H, Nq, Nk) and qk_mask.stride(3) == 1
         mask_bs, mask_hs, mask_rs = qk_mask.stride(0), qk_mask.stride(1), qk_mask.stride(2)
-    o = torch.empty(B, Nq, H * D, dtype=torch.float16, device=q4.device)
+    o = torch.empty(B, Nq, H * D, dtype=q4.dtype, device=q4.device)
     ws = None
     if nsplit > 1:
         ws = torch.empty(lib.mq_attn_workspace_bytes(B, H, Nq, D, nsplit) // 4, dtype=torch.float32, device=q4.device)
     with _timed(f"attn_d{D}_nq{Nq}_nk{Nk}_s{nsplit}"):
-        rc = lib.mq_attn_fwd(_ptr(q4), _ptr(k4), _ptr(vt4), _ptr(o), _ptr(key_bias), _ptr(kv_len), _ptr(qk_mask), mask_bs, mask_hs,
+        rc = _fn(lib, "mq_attn_fwd", q4)(_ptr(q4), _ptr(k4), _ptr(vt4), _ptr(o), _ptr(key_bias), _ptr(kv_len), _ptr(qk_mask), mask_bs, mask_hs,
                              mask_rs, _ptr(ws), B, H, Nq, Nk, D,
                              q4.stride(0), q4.stride(1), q4.stride(2), k4.stride(0), k4.stride(1), k4.stride(2),
                              vt4.stride(0), vt4.stride(2), vt4.stride(1), o.stride(0), o.stride(1), bias_bs, bias_hs,
@@ -210,13 +229,13 @@ def window_attention(qkv, qkv_bias, rel_bias, heads, ws, shift):
     B, H, W, C3 = qkv.shape
     C = C3 // 3
     NP = window_pad(ws)
-    assert qkv.is_contiguous() and qkv.dtype == torch.float16 and qkv_bias.dtype == torch.float16
+    assert qkv.is_contiguous() and qkv.dtype in _H16 and qkv_bias.dtype == qkv.dtype
     if rel_bias.shape == (heads, ws * ws, ws * ws) and ws * ws != NP:
         rel_bias = pad_rel_bias(rel_bias, ws)
     assert rel_bias.dtype == torch.float32 and rel_bias.is_contiguous() and rel_bias.shape == (heads, NP, NP)
-    out = torch.empty(B, H, W, C, dtype=torch.float16, device=qkv.device)
+    out = torch.empty(B, H, W, C, dtype=qkv.dtype, device=qkv.device)
     with _timed(f"window_attn_c{C}", qkv.numel() * 2 + out.numel() * 2):
-        _chk(lib.mq_window_attn_fwd(_ptr(qkv), _ptr(qkv_bias), _ptr(rel_bias), _ptr(out), B, H, W, C, heads, ws, shift,
+        _chk(_fn(lib, "mq_window_attn_fwd", qkv)(_ptr(qkv), _ptr(qkv_bias), _ptr(rel_bias), _ptr(out), B, H, W, C, heads, ws, shift,
                                     _stream()), "mq_window_attn_fwd")
     return out
 
@@ -228,10 +247,10 @@ def gcp_sparse_attention(q, kv, idx, heads=8, dim_head=64):
     B, T, HD = q.shape
     V, S = kv.shape[1], idx.shape[2]
     assert q.is_contiguous() and kv.is_contiguous() and idx.is_contiguous() and idx.dtype == torch.int32
-    assert q.dtype == kv.dtype == torch.float16 and kv.shape[2] == 2 * HD
+    assert q.dtype == kv.dtype and q.dtype in _H16 and kv.shape[2] == 2 * HD
     out = torch.empty_like(q)
     with _timed(f"gcp_sparse_attn_s{S}", q.numel() * 4 + kv.numel() * 2):
-        _chk(lib.mq_gcp_sparse_attn_fwd(_ptr(q), _ptr(kv), _ptr(idx), _ptr(out), B, T, V, S, heads, dim_head, _stream()),
+        _chk(_fn(lib, "mq_gcp_sparse_attn_fwd", q)(_ptr(q), _ptr(kv), _ptr(idx), _ptr(out), B, T, V, S, heads, dim_head, _stream()),
              "mq_gcp_sparse_attn_fwd")
     return out
 
@@ -244,10 +263,10 @@ def gcp_gate_residual(sup, h, w2, x, want_gate=False):
     C, G = sup.shape[-1], h.shape[-1]
     M = sup.numel() // C
     assert sup.is_contiguous() and h.is_contiguous() and x.is_contiguous() and w2.is_contiguous()
-    assert sup.dtype == h.dtype == w2.dtype == torch.float16 and x.dtype in (torch.float16, torch.float32)
+    assert sup.dtype == h.dtype == w2.dtype and sup.dtype in _H16 and x.dtype in (sup.dtype, torch.float32)
     out = torch.empty_like(x)
     gate = torch.empty(M, dtype=torch.float32, device=x.device) if want_gate else None
-    _chk(lib.mq_gcp_gate_residual_fwd(_ptr(sup), _ptr(h), _ptr(w2), _ptr(x), int(x.dtype == torch.float32), _ptr(out), _ptr(gate),
+    _chk(_fn(lib, "mq_gcp_gate_residual_fwd", sup)(_ptr(sup), _ptr(h), _ptr(w2), _ptr(x), int(x.dtype == torch.float32), _ptr(out), _ptr(gate),
                                       M, C, G, _stream()), "mq_gcp_gate_residual_fwd")
     return (out, gate) if want_gate else out
 
@@ -262,14 +281,14 @@ def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.
     Hh, T = kf.shape[1], kf.shape[2]
     assert C == 256 and kf.shape == (B, Hh, T, 256) and vo.shape == kf.shape and T <= 256 and 1 <= Hh <= 8
     assert v_ln.is_contiguous() and kf.is_contiguous() and vo.is_contiguous() and out_bias.is_contiguous()
-    assert v_ln.dtype == kf.dtype == vo.dtype == out_bias.dtype == torch.float16
+    assert v_ln.dtype == kf.dtype == vo.dtype == out_bias.dtype and v_ln.dtype in _H16
     if bias is not None:
         assert bias.shape == (B, Hh, T) and bias.dtype == torch.float32 and bias.is_contiguous()
     if kv_len is not None:
         assert kv_len.dtype == torch.int32 and kv_len.numel() == B and kv_len.is_contiguous()
     out = torch.empty_like(v_ln)
     with _timed(f"vlfuse_i2t_n{N}_t{T}"):
-        _chk(lib.mq_vlfuse_i2t_fwd(_ptr(v_ln), _ptr(kf), _ptr(vo), _ptr(bias), _ptr(kv_len), _ptr(out_bias), _ptr(out),
+        _chk(_fn(lib, "mq_vlfuse_i2t_fwd", v_ln)(_ptr(v_ln), _ptr(kf), _ptr(vo), _ptr(bias), _ptr(kv_len), _ptr(out_bias), _ptr(out),
                                    B, N, T, Hh, int(max_kv), float(clamp), _stream()), "mq_vlfuse_i2t_fwd")
     return out
 
@@ -289,14 +308,14 @@ def vlfuse_t2i(kf, v_ln, nsplit, clamp=50000.0, kv_len=None, key_mask=None):
         assert key_mask.dtype == torch.uint8 and key_mask.dim() == 2 and key_mask.shape[0] == B and key_mask.stride(1) == 1
         km_bs = key_mask.stride(0)
         assert km_bs % 4 == 0 and key_mask.shape[1] >= -(-N // 64) * 64
-    assert kf.dtype == v_ln.dtype == torch.float16
+    assert kf.dtype == v_ln.dtype and kf.dtype in _H16
     nsplit = max(1, int(nsplit))
     if kv_len is not None:
         assert kv_len.dtype == torch.int32 and kv_len.numel() == B and kv_len.is_contiguous()
     ws = torch.empty(lib.mq_vlfuse_t2i_workspace_bytes(B, T, nsplit) // 4, dtype=torch.float32, device=kf.device)
-    out = torch.empty(B, T, Hh * 256, dtype=torch.float16, device=kf.device)
+    out = torch.empty(B, T, Hh * 256, dtype=kf.dtype, device=kf.device)
     with _timed(f"vlfuse_t2i_n{N}_t{T}_s{nsplit}"):
-        _chk(lib.mq_vlfuse_t2i_fwd(_ptr(kf), _ptr(v_ln), _ptr(kv_len), _ptr(key_mask), km_bs, _ptr(ws), _ptr(out), B, N, T, Hh,
+        _chk(_fn(lib, "mq_vlfuse_t2i_fwd", kf)(_ptr(kf), _ptr(v_ln), _ptr(kv_len), _ptr(key_mask), km_bs, _ptr(ws), _ptr(out), B, N, T, Hh,
                                    nsplit, float(clamp), _stream()), "mq_vlfuse_t2i_fwd")
     return out
 
@@ -319,21 +338,22 @@ def layer_norm(x, gamma, beta, eps=1e-5, residual=None, want_sum=True, want_y32=
     lib = load_library()
     _need_gpu(x, gamma, beta, residual)
     C = x.shape[-1]
-    assert x.is_contiguous() and x.dtype in (torch.float16, torch.float32)
-    assert gamma.dtype == torch.float16 and beta.dtype == torch.float16
+    h16 = gamma.dtype                                    # the 16-bit type of this call: fp16 or bf16 (weights decide)
+    assert x.is_contiguous() and x.dtype in (h16, torch.float32)
+    assert h16 in _H16 and beta.dtype == h16
     rows = x.numel() // C
     xf = x.dtype == torch.float32
     rf = False
-    y = torch.empty(x.shape, dtype=torch.float16, device=x.device) if want_y else None
+    y = torch.empty(x.shape, dtype=h16, device=x.device) if want_y else None
     y32 = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_y32 else None
     xsum = None
     if residual is not None:
-        assert residual.shape == x.shape and residual.is_contiguous() and residual.dtype in (torch.float16, torch.float32)
+        assert residual.shape == x.shape and residual.is_contiguous() and residual.dtype in (h16, torch.float32)
         rf = residual.dtype == torch.float32
         if want_sum:
-            xsum = torch.empty(x.shape, dtype=torch.float32 if (xf or rf) else torch.float16, device=x.device)
+            xsum = torch.empty(x.shape, dtype=torch.float32 if (xf or rf) else h16, device=x.device)
     with _timed(f"layernorm_c{C}", sum(t.numel() * t.element_size() for t in (x, residual, y, y32, xsum) if t is not None)):
-        _chk(lib.mq_layernorm_fwd(_ptr(x), int(xf), _ptr(residual), int(rf), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(y32), _ptr(xsum),
+        _chk(_fn(lib, "mq_layernorm_fwd", gamma)(_ptr(x), int(xf), _ptr(residual), int(rf), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(y32), _ptr(xsum),
                                   rows, C, float(eps), _stream()), "mq_layernorm_fwd")
     out = [t for t in (y, y32, xsum) if t is not None]
     return out[0] if len(out) == 1 else tuple(out)
@@ -358,16 +378,16 @@ def swin_mlp(x, delta, ln_g, ln_b, eps, w1, b1, w2p, b2, next_ln=None):
     C = x.shape[-1]
     M = x.numel() // C
     assert C in SWIN_MLP_WIDTHS and x.dtype == torch.float32 and x.is_contiguous()
-    assert delta is None or (delta.dtype == torch.float16 and delta.is_contiguous() and delta.shape == x.shape)
+    assert delta is None or (delta.dtype == w1.dtype and delta.is_contiguous() and delta.shape == x.shape)
     assert w1.shape == (4 * C, C) and w2p.shape == (C, 4 * C) and w1.is_contiguous() and w2p.is_contiguous()
-    assert w1.dtype == w2p.dtype == b1.dtype == b2.dtype == ln_g.dtype == torch.float16
+    assert w1.dtype == w2p.dtype == b1.dtype == b2.dtype == ln_g.dtype and w1.dtype in _H16
     out = torch.empty_like(x)
     y, ng, nb, ne = None, None, None, 0.0
     if next_ln is not None:
         ng, nb, ne = next_ln
-        y = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+        y = torch.empty(x.shape, dtype=w1.dtype, device=x.device)
     with _timed(f"swin_mlp_c{C}", M * C * (4 + 4 + (2 if delta is not None else 0) + (2 if y is not None else 0))):
-        _chk(lib.mq_swin_mlp_fwd(_ptr(x), _ptr(delta), _ptr(ln_g), _ptr(ln_b), float(eps), _ptr(w1), _ptr(b1), _ptr(w2p), _ptr(b2),
+        _chk(_fn(lib, "mq_swin_mlp_fwd", w1)(_ptr(x), _ptr(delta), _ptr(ln_g), _ptr(ln_b), float(eps), _ptr(w1), _ptr(b1), _ptr(w2p), _ptr(b2),
                                  _ptr(out), _ptr(ng), _ptr(nb), float(ne), _ptr(y), M, C, _stream()), "mq_swin_mlp_fwd")
     return (out, y) if y is not None else out
 
@@ -378,13 +398,13 @@ def conv3x3(x_nhwc, w_packed, bias, n_out, stride=1):
     lib = load_library()
     _need_gpu(x_nhwc, w_packed, bias)
     B, H, W, C = x_nhwc.shape
-    assert x_nhwc.dtype == torch.float16 and x_nhwc.stride(3) == 1 and x_nhwc.stride(2) == C and x_nhwc.stride(1) == W * C
-    assert w_packed.is_contiguous() and w_packed.shape == (32 if n_out <= 32 else 256, 9 * C)
+    assert x_nhwc.dtype in _H16 and x_nhwc.stride(3) == 1 and x_nhwc.stride(2) == C and x_nhwc.stride(1) == W * C
+    assert w_packed.is_contiguous() and w_packed.shape == (32 if n_out <= 32 else 256, 9 * C) and w_packed.dtype == x_nhwc.dtype
     Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
     ld = n_out if n_out % 8 == 0 else (n_out + 7) // 8 * 8
-    out = torch.empty(B, Ho, Wo, ld, dtype=torch.float16, device=x_nhwc.device)
+    out = torch.empty(B, Ho, Wo, ld, dtype=x_nhwc.dtype, device=x_nhwc.device)
     with _timed("conv3x3"):
-        _chk(lib.mq_conv3x3_fwd(_ptr(x_nhwc), _ptr(w_packed), _ptr(bias), _ptr(out), B, H, W, C, x_nhwc.stride(0), n_out, ld,
+        _chk(_fn(lib, "mq_conv3x3_fwd", x_nhwc)(_ptr(x_nhwc), _ptr(w_packed), _ptr(bias), _ptr(out), B, H, W, C, x_nhwc.stride(0), n_out, ld,
                                 stride, _stream()), "mq_conv3x3_fwd")
     return out if ld == n_out else out[..., :n_out]
 
@@ -395,11 +415,11 @@ def conv3x3_nchw32(x_nhwc, w_packed, bias, n_out):
     lib = load_library()
     _need_gpu(x_nhwc, w_packed, bias)
     B, H, W, C = x_nhwc.shape
-    assert x_nhwc.dtype == torch.float16 and x_nhwc.stride(3) == 1 and x_nhwc.stride(2) == C and x_nhwc.stride(1) == W * C
-    assert w_packed.is_contiguous() and w_packed.shape == (32, 9 * C) and w_packed.dtype == torch.float16 and n_out <= 32
+    assert x_nhwc.dtype in _H16 and x_nhwc.stride(3) == 1 and x_nhwc.stride(2) == C and x_nhwc.stride(1) == W * C
+    assert w_packed.is_contiguous() and w_packed.shape == (32, 9 * C) and w_packed.dtype == x_nhwc.dtype and n_out <= 32
     out = torch.empty(B, n_out, H, W, dtype=torch.float32, device=x_nhwc.device)
     with _timed("conv3x3_small", B * H * W * C * 2 + out.numel() * 4):
-        _chk(lib.mq_conv3x3_nchw32_fwd(_ptr(x_nhwc), _ptr(w_packed), _ptr(bias), _ptr(out), B, H, W, C, x_nhwc.stride(0), n_out,
+        _chk(_fn(lib, "mq_conv3x3_nchw32_fwd", x_nhwc)(_ptr(x_nhwc), _ptr(w_packed), _ptr(bias), _ptr(out), B, H, W, C, x_nhwc.stride(0), n_out,
                                        _stream()), "mq_conv3x3_nchw32_fwd")
     return out
 
@@ -411,18 +431,18 @@ def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None
     lib = load_library()
     _need_gpu(x_nhwc, om, w_packed, bias, wy, wx)
     B, H, W, C = x_nhwc.shape
-    assert x_nhwc.dtype == torch.float16 and x_nhwc.stride(3) == 1 and x_nhwc.stride(2) == C and x_nhwc.stride(1) == W * C
+    assert x_nhwc.dtype in _H16 and x_nhwc.stride(3) == 1 and x_nhwc.stride(2) == C and x_nhwc.stride(1) == W * C
     assert om.is_contiguous() and om.dtype == torch.float32 and om.shape[1] == 27
-    assert w_packed.is_contiguous() and w_packed.shape == (256, 9 * C) and w_packed.dtype == torch.float16
+    assert w_packed.is_contiguous() and w_packed.shape == (256, 9 * C) and w_packed.dtype == x_nhwc.dtype
     Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
-    y = torch.empty(B, Ho * Wo, 256, dtype=torch.float16, device=x_nhwc.device)
+    y = torch.empty(B, Ho * Wo, 256, dtype=x_nhwc.dtype, device=x_nhwc.device)
     sums = None
     if want_stats:
         sums = torch.empty(B, lib.mq_dcnv2_stats_blocks(H, W, stride), 256, 3, dtype=torch.float32, device=y.device)
         if wy is not None:
             assert wy.dtype == wx.dtype == torch.float32 and wy.numel() == Ho and wx.numel() == Wo
     with _timed("dcnv2_fused"):
-        _chk(lib.mq_dcnv2_fwd(_ptr(x_nhwc), _ptr(om), _ptr(w_packed), _ptr(bias), _ptr(y), _ptr(sums), _ptr(wy), _ptr(wx),
+        _chk(_fn(lib, "mq_dcnv2_fwd", x_nhwc)(_ptr(x_nhwc), _ptr(om), _ptr(w_packed), _ptr(bias), _ptr(y), _ptr(sums), _ptr(wy), _ptr(wx),
                               B, H, W, C, x_nhwc.stride(0), om.shape[2], om.shape[3], 256, 256, stride, _stream()), "mq_dcnv2_fwd")
     return (y, (Ho, Wo), sums) if want_stats else (y, (Ho, Wo))
 
@@ -445,11 +465,11 @@ def dcnv2_group(branches, want_stats=True):
         wy, wx = br.get("wy"), br.get("wx")
         _need_gpu(x, om, w, bias, wy, wx)
         B, H, W, C = x.shape
-        assert x.dtype == torch.float16 and x.stride(3) == 1 and x.stride(2) == C and x.stride(1) == W * C
+        assert x.dtype in _H16 and x.stride(3) == 1 and x.stride(2) == C and x.stride(1) == W * C
         assert om.is_contiguous() and om.dtype == torch.float32 and om.shape[1] == 27
-        assert w.is_contiguous() and w.shape == (256, 9 * C) and w.dtype == torch.float16
+        assert w.is_contiguous() and w.shape == (256, 9 * C) and w.dtype == x.dtype
         Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
-        y = torch.empty(B, Ho * Wo, 256, dtype=torch.float16, device=x.device)
+        y = torch.empty(B, Ho * Wo, 256, dtype=x.dtype, device=x.device)
         sums = None
         if want_stats:
             sums = torch.empty(B, lib.mq_dcnv2_stats_blocks(H, W, stride), 256, 3, dtype=torch.float32, device=y.device)
@@ -463,7 +483,7 @@ def dcnv2_group(branches, want_stats=True):
         a.N, a.out_ld, a.stride, a.reserved = 256, 256, stride, 0
         outs.append((y, (Ho, Wo), sums))
     with _timed("dcnv2_fused"):
-        _chk(lib.mq_dcnv2_group_fwd(ctypes.cast(arr, _vp), len(branches), _stream()), "mq_dcnv2_group_fwd")
+        _chk(_fn(lib, "mq_dcnv2_group_fwd", *[br["x"] for br in branches])(ctypes.cast(arr, _vp), len(branches), _stream()), "mq_dcnv2_group_fwd")
     return outs
 
 
@@ -473,18 +493,18 @@ def dyconv_branch_coef(y, Wsrc, gamma, beta, attn_w, attn_b, groups, eps, nbranc
     lib = load_library()
     _need_gpu(y, gamma, beta, attn_w, attn_b, wy, wx)
     B, n, C = y.shape
-    assert y.is_contiguous() and y.dtype == torch.float16 and gamma.dtype == torch.float16
+    assert y.is_contiguous() and y.dtype in _H16 and gamma.dtype == y.dtype
     assert attn_w.dtype == torch.float32 and attn_b.dtype == torch.float32
     coef = torch.empty(B, C, 2, dtype=torch.float32, device=y.device)
     nblk = 0
     if sums is None:
         sums = torch.empty(B, (n + 255) // 256, C, 3, dtype=torch.float32, device=y.device)
         with _timed("dyconv_stats"):
-            _chk(lib.mq_dyconv_stats(_ptr(y), _ptr(sums), _ptr(wy), _ptr(wx), B, n, Wsrc, C, _stream()), "mq_dyconv_stats")
+            _chk(_fn(lib, "mq_dyconv_stats", y)(_ptr(y), _ptr(sums), _ptr(wy), _ptr(wx), B, n, Wsrc, C, _stream()), "mq_dyconv_stats")
     else:
         assert sums.dtype == torch.float32 and sums.is_contiguous() and sums.shape[0] == B and sums.shape[2:] == (C, 3)
         nblk = sums.shape[1]
-    _chk(lib.mq_dyconv_coef(_ptr(sums), _ptr(gamma), _ptr(beta), _ptr(attn_w), _ptr(attn_b), _ptr(coef), B, n, nblk, C, groups,
+    _chk(_fn(lib, "mq_dyconv_coef", gamma)(_ptr(sums), _ptr(gamma), _ptr(beta), _ptr(attn_w), _ptr(attn_b), _ptr(coef), B, n, nblk, C, groups,
                             float(eps), nbranches, _stream()), "mq_dyconv_coef")
     return coef
 
@@ -510,7 +530,7 @@ def dyconv_coef_group(items, attn_w, attn_b, groups, eps):
         a.sums, a.gamma, a.beta, a.coef = sums.data_ptr(), it["gamma"].data_ptr(), it["beta"].data_ptr(), coef.data_ptr()
         a.nblk, a.n, a.nbranches, a.reserved = sums.shape[1], int(it["n"]), int(it["nbranches"]), 0
         outs.append(coef)
-    _chk(lib.mq_dyconv_coef_group(ctypes.cast(arr, _vp), len(items), _ptr(attn_w), _ptr(attn_b), B, C, groups, float(eps), _stream()),
+    _chk(_fn(lib, "mq_dyconv_coef_group", *[it["gamma"] for it in items])(ctypes.cast(arr, _vp), len(items), _ptr(attn_w), _ptr(attn_b), B, C, groups, float(eps), _stream()),
          "mq_dyconv_coef_group")
     return outs
 
@@ -523,8 +543,8 @@ def dyconv_fuse(branches, H, W, out=None):
     y0 = branches[0][0]
     B, _, C = y0.shape
     if out is None:
-        out = torch.empty(B, H * W, C, dtype=torch.float16, device=y0.device)
-    assert out.shape == (B, H * W, C) and out.dtype == torch.float16 and out.stride(2) == 1 and out.stride(1) == C
+        out = torch.empty(B, H * W, C, dtype=y0.dtype, device=y0.device)
+    assert out.shape == (B, H * W, C) and out.dtype == y0.dtype and y0.dtype in _H16 and out.stride(2) == 1 and out.stride(1) == C
     pool = torch.empty(B, (H * W + 127) // 128, C, dtype=torch.float32, device=y0.device)
     args = []
     for k in range(3):
@@ -536,7 +556,7 @@ def dyconv_fuse(branches, H, W, out=None):
         else:
             args += [_ptr(None), _ptr(None), 0, 0]
     with _timed("dyconv_fuse", sum(b_[0].numel() * 2 for b_ in branches) + out.shape[0] * out.shape[1] * C * 2):
-        _chk(lib.mq_dyconv_fuse(*args, len(branches), _ptr(out), out.stride(0), _ptr(pool), B, H, W, C, _stream()), "mq_dyconv_fuse")
+        _chk(_fn(lib, "mq_dyconv_fuse", *[b_[0] for b_ in branches])(*args, len(branches), _ptr(out), out.stride(0), _ptr(pool), B, H, W, C, _stream()), "mq_dyconv_fuse")
     return out, pool
 
 
@@ -545,12 +565,12 @@ def dyrelu_(x, pool, w0, b0, w2, b2):
     lib = load_library()
     _need_gpu(x, pool, w0, b0, w2, b2)
     B, n, C = x.shape
-    assert x.stride(2) == 1 and x.stride(1) == C and w0.is_contiguous() and w2.is_contiguous() and w0.dtype == torch.float16
+    assert x.stride(2) == 1 and x.stride(1) == C and w0.is_contiguous() and w2.is_contiguous() and w0.dtype == x.dtype and x.dtype in _H16
     coef = torch.empty(B, 4, C, dtype=torch.float32, device=x.device)
-    _chk(lib.mq_dyrelu_coef(_ptr(pool), _ptr(w0), _ptr(b0), _ptr(w2), _ptr(b2), _ptr(coef), B, n, C, _stream()),
+    _chk(_fn(lib, "mq_dyrelu_coef", w0)(_ptr(pool), _ptr(w0), _ptr(b0), _ptr(w2), _ptr(b2), _ptr(coef), B, n, C, _stream()),
          "mq_dyrelu_coef")
     with _timed("dyrelu_apply", 2 * B * n * C * 2):
-        _chk(lib.mq_dyrelu_apply(_ptr(x), _ptr(coef), B, n, C, x.stride(0), _stream()), "mq_dyrelu_apply")
+        _chk(_fn(lib, "mq_dyrelu_apply", x)(_ptr(x), _ptr(coef), B, n, C, x.stride(0), _stream()), "mq_dyrelu_apply")
     return x
 
 
@@ -564,14 +584,14 @@ def align_scores(dot, tbias, tokidx, ctr, thr, want_cls=False, agg=0):
     _need_gpu(dot, tbias, tokidx, ctr)
     B, HW, T = dot.shape
     L, MT = tokidx.shape[-2:]
-    assert dot.stride(2) == 1 and dot.stride(1) == T and dot.dtype in (torch.float16, torch.float32)
-    assert ctr.dtype == torch.float16 and ctr.is_contiguous()
+    assert dot.stride(2) == 1 and dot.stride(1) == T and dot.dtype in (ctr.dtype, torch.float32)
+    assert ctr.dtype in _H16 and ctr.is_contiguous()
     assert tbias.dtype == torch.float32 and tbias.is_contiguous() and tokidx.dtype == torch.int32 and tokidx.is_contiguous()
     assert tokidx.dim() == 2 or tokidx.shape[0] == B
     out = torch.empty(B, HW, L, dtype=torch.float32, device=dot.device)
     cls = torch.empty_like(out) if want_cls else None
     with _timed("align_scores", B * HW * T * dot.element_size() + out.numel() * 4):
-        _chk(lib.mq_align_scores_fwd(_ptr(dot), int(dot.dtype == torch.float32), _ptr(tbias), _ptr(tokidx),
+        _chk(_fn(lib, "mq_align_scores_fwd", ctr)(_ptr(dot), int(dot.dtype == torch.float32), _ptr(tbias), _ptr(tokidx),
                                      L * MT if tokidx.dim() == 3 else 0, _ptr(ctr), _ptr(out), _ptr(cls), B, HW, T, L, MT,
                                      float(thr), dot.stride(0), int(agg), _stream()), "mq_align_scores_fwd")
     return (out, cls) if want_cls else out
@@ -583,11 +603,11 @@ def box_decode(val, flat, reg, anchors, label_ids, im_wh, boxes, scores, labels,
     lib = load_library()
     _need_gpu(val, flat, reg, anchors, label_ids, im_wh, boxes, scores, labels)
     B, K = val.shape
-    assert val.dtype == torch.float32 and flat.dtype == torch.int64 and reg.dtype == torch.float16
+    assert val.dtype == torch.float32 and flat.dtype == torch.int64 and reg.dtype in _H16
     assert val.is_contiguous() and flat.is_contiguous() and reg.is_contiguous() and anchors.is_contiguous()
     assert boxes.dtype == torch.float32 and scores.dtype == torch.float32 and labels.dtype == torch.int32
     assert label_ids.is_contiguous() and label_ids.dtype == torch.int32 and (label_ids.dim() == 1 or label_ids.shape[0] == B)
-    _chk(lib.mq_box_decode(_ptr(val), _ptr(flat), _ptr(reg), _ptr(anchors), _ptr(label_ids), L if label_ids.dim() == 2 else 0,
+    _chk(_fn(lib, "mq_box_decode", reg)(_ptr(val), _ptr(flat), _ptr(reg), _ptr(anchors), _ptr(label_ids), L if label_ids.dim() == 2 else 0,
                            _ptr(im_wh), _ptr(boxes), _ptr(scores), _ptr(labels), B, K, HW, L, boxes.shape[1], out_off, _stream()),
          "mq_box_decode")
 
@@ -599,11 +619,11 @@ def roi_align(feat, rois, output_size, spatial_scale, sampling_ratio, aligned=Tr
     _need_gpu(feat, rois)
     N, C, H, W = feat.shape
     PH, PW = (output_size, output_size) if isinstance(output_size, int) else output_size
-    assert feat.dtype in (torch.float16, torch.float32) and rois.dtype == torch.float32 and rois.shape[1] == 5
+    assert feat.dtype in _H16 + (torch.float32,) and rois.dtype == torch.float32 and rois.shape[1] == 5
     rois = rois.contiguous()
     R = rois.shape[0]
     out = torch.empty((R, C) if reduce_mean else (R, C, PH, PW), dtype=torch.float32, device=feat.device)
-    _chk(lib.mq_roi_align_fwd(_ptr(feat), int(feat.dtype == torch.float32), _ptr(rois), _ptr(out), R, C, H, W, feat.stride(0),
+    _chk(_fn(lib, "mq_roi_align_fwd", feat)(_ptr(feat), int(feat.dtype == torch.float32), _ptr(rois), _ptr(out), R, C, H, W, feat.stride(0),
                               feat.stride(1), feat.stride(2), feat.stride(3), PH, PW, float(spatial_scale), int(sampling_ratio),
                               int(bool(aligned)), int(bool(reduce_mean)), _stream()), "mq_roi_align_fwd")
     return out
@@ -621,7 +641,7 @@ def ms_deform_attn(value, spatial_shapes, sampling_locations, attention_weights,
     _, Q, _, L, P, _ = sampling_locations.shape
     shapes = tuple((int(h), int(w)) for h, w in spatial_shapes)
     assert len(shapes) == L and sum(h * w for h, w in shapes) == S
-    assert value.is_contiguous() and value.dtype in (torch.float16, torch.float32)
+    assert value.is_contiguous() and value.dtype in _H16 + (torch.float32,)
     assert sampling_locations.dtype == attention_weights.dtype == torch.float32
     assert sampling_locations.is_contiguous() and attention_weights.is_contiguous() and attention_weights.shape == (B, Q, M, L, P)
     hw, start = _msda_shapes(shapes, value.device)
@@ -629,7 +649,7 @@ def ms_deform_attn(value, spatial_shapes, sampling_locations, attention_weights,
     out = torch.empty(B, Q, M * D, dtype=out_dtype, device=value.device)
     nb = value.numel() * value.element_size() + sampling_locations.numel() * 4 + attention_weights.numel() * 4 + out.numel() * out.element_size()
     with _timed(f"msdeform_attn_q{Q}", nb):
-        _chk(lib.mq_msdeform_attn_fwd(_ptr(value), int(value.dtype == torch.float32), _ptr(hw), _ptr(start), _ptr(sampling_locations),
+        _chk(_fn(lib, "mq_msdeform_attn_fwd", value, out)(_ptr(value), int(value.dtype == torch.float32), _ptr(hw), _ptr(start), _ptr(sampling_locations),
                                       _ptr(attention_weights), _ptr(out), int(out_dtype == torch.float32), B, S, M, D, L, Q, P, _stream()),
              "mq_msdeform_attn_fwd")
     return out
@@ -656,8 +676,8 @@ def ms_deform_attn_q(value, spatial_shapes, qproj, ref, heads, out_dtype=None, v
     Q = qproj.shape[1]
     shapes = tuple((int(h), int(w)) for h, w in spatial_shapes)
     L, P = len(shapes), 4
-    assert sum(h * w for h, w in shapes) == S and value.stride(2) == 1 and value.dtype in (torch.float16, torch.float32)
-    assert qproj.dtype == torch.float16 and qproj.is_contiguous() and qproj.shape == (B, Q, heads * L * P * 3)
+    assert sum(h * w for h, w in shapes) == S and value.stride(2) == 1 and value.dtype in _H16 + (torch.float32,)
+    assert qproj.dtype in _H16 and qproj.is_contiguous() and qproj.shape == (B, Q, heads * L * P * 3)
     assert ref.dtype == torch.float32 and ref.is_contiguous() and ref.shape[:3] == (B, Q, L) and ref.shape[3] in (2, 4)
     if valid_hw is not None:
         _need_gpu(valid_hw)
@@ -667,7 +687,7 @@ def ms_deform_attn_q(value, spatial_shapes, qproj, ref, heads, out_dtype=None, v
     out = torch.empty(B, Q, C, dtype=out_dtype, device=value.device)
     nb = B * S * C * value.element_size() + qproj.numel() * 2 + ref.numel() * 4 + out.numel() * out.element_size()
     with _timed(f"msdeform_attn_q{Q}", nb):
-        _chk(lib.mq_msdeform_attn_q_fwd(_ptr(value), int(value.dtype == torch.float32), value.stride(0), value.stride(1), _ptr(hw),
+        _chk(_fn(lib, "mq_msdeform_attn_q_fwd", value, qproj, out)(_ptr(value), int(value.dtype == torch.float32), value.stride(0), value.stride(1), _ptr(hw),
                                         _ptr(start), _ptr(qproj), _ptr(ref), ref.shape[3], _ptr(valid_hw), _ptr(out),
                                         int(out_dtype == torch.float32), B, S, heads, D, L, Q, P, _stream()),
              "mq_msdeform_attn_q_fwd")

@@ -9,6 +9,7 @@ import os
 import torch
 import torch.nn.functional as F
 
+import parity_checks as pc
 from parity_checks import _stat
 
 _CACHE = {}
@@ -23,7 +24,7 @@ def check_attention_qk_mask(dev):
     g = torch.Generator().manual_seed(77)
     res = []
     for B, H, D, T, per_head in ((2, 12, 64, 256, False), (3, 4, 64, 256, True), (1, 4, 64, 100, False)):
-        q, k, v = (torch.randn(B, T, H * D, generator=g).half() for _ in range(3))
+        q, k, v = (torch.randn(B, T, H * D, generator=g).to(pc.H16) for _ in range(3))
         blocks = torch.randint(0, 9, (B, H if per_head else 1, T), generator=g).cumsum(-1) // 12   # random sub-sentences
         mask = (blocks[..., :, None] != blocks[..., None, :])
         mask = mask if per_head else mask.expand(B, H, T, T)
@@ -35,13 +36,13 @@ def check_attention_qk_mask(dev):
         res.append(_stat(f"attn qk_mask B={B} H={H} D={D} T={T} per_head={per_head}", got, ref))
     # decoder: self-attention over 900 queries, text cross-attention with key padding
     B, H, D, Nq = 2, 8, 32, 900
-    q, k, v = (torch.randn(B, Nq, H * D, generator=g).half() for _ in range(3))
+    q, k, v = (torch.randn(B, Nq, H * D, generator=g).to(pc.H16) for _ in range(3))
     vt = F.pad(v, (0, 0, 0, (-Nq) % 8)).transpose(1, 2).contiguous()
     ref = emu.attention(q.float(), k.float(), vt.float(), H, D, nk=Nq)
     got = ops.attention(q.to(dev), k.to(dev), vt.to(dev), H, D, nk=Nq)
     res.append(_stat("attn decoder self-attention 8 x 32, 900 queries", got, ref))
     T = 256
-    kt, vtx = torch.randn(B, T, 6 * H * D, generator=g).half(), torch.randn(B, 6 * H * D, T, generator=g).half()
+    kt, vtx = torch.randn(B, T, 6 * H * D, generator=g).to(pc.H16), torch.randn(B, 6 * H * D, T, generator=g).to(pc.H16)
     kb = torch.zeros(B, T)
     kb[0, 31:] = -1e30
     kb[1, 200:] = -1e30
@@ -63,11 +64,11 @@ def check_vlfuse_heads_mask(dev):
     res = []
     for B, N, T, kv, ns in ((2, 3000, 256, [40, 256], 3), (1, 22323, 256, [141], 8), (3, 426, 64, None, 1)):
         Hh = 4
-        v_ln = torch.randn(B, N, 256, generator=g).half()
-        kf = (torch.randn(B, Hh, T, 256, generator=g) / 8).half()
-        vo = torch.randn(B, Hh, T, 256, generator=g).half()
+        v_ln = torch.randn(B, N, 256, generator=g).to(pc.H16)
+        kf = (torch.randn(B, Hh, T, 256, generator=g) / 8).to(pc.H16)
+        vo = torch.randn(B, Hh, T, 256, generator=g).to(pc.H16)
         bias = torch.randn(B, Hh, T, generator=g)
-        ob = torch.randn(256, generator=g).half()
+        ob = torch.randn(256, generator=g).to(pc.H16)
         kv_len = None if kv is None else torch.tensor(kv, dtype=torch.int32)
         ref = emu.vlfuse_i2t(v_ln.float(), kf.float(), vo.float(), bias, ob.float(), kv_len, 0)
         got = ops.vlfuse_i2t(v_ln.to(dev), kf.to(dev), vo.to(dev), bias.to(dev), ob.to(dev), None if kv is None else kv_len.to(dev),
@@ -99,8 +100,8 @@ def check_msdeform_attn_q(dev):
     S = sum(h * w for h, w in shapes)
     for B, Q, nd, slices in ((1, S, 2, 1), (2, 900, 4, 6), (1, 37, 4, 1)):
         M, D = 8, 32
-        val_all = torch.randn(B, S, slices * M * D, generator=g).half()
-        qp = torch.cat([torch.randn(B, Q, M * 16 * 2, generator=g) * 2.0, torch.randn(B, Q, M * 16, generator=g)], -1).half()
+        val_all = torch.randn(B, S, slices * M * D, generator=g).to(pc.H16)
+        qp = torch.cat([torch.randn(B, Q, M * 16 * 2, generator=g) * 2.0, torch.randn(B, Q, M * 16, generator=g)], -1).to(pc.H16)
         ref_pts = torch.rand(B, Q, 4, nd, generator=g)
         if nd == 4:
             ref_pts[..., 2:] = ref_pts[..., 2:] * 0.3 + 0.02
@@ -153,10 +154,11 @@ def gdino_model(dev, spec, seed=0):
     from test_gdino_glue_cpu import gdino_cfg
     from mq_det_amd.modeling.detector import build_detection_model
     from oracle.weights import make_gdino_state_dict
-    key = ("model", spec, seed)
+    key = ("model", spec, seed, pc.H16)
     if key not in _CACHE:
         sd = make_gdino_state_dict(spec, seed=seed)
         cfg = gdino_cfg(spec, _tokenizer_dir(spec.vocab))
+        cfg.MODEL.COMPUTE_DTYPE = "bfloat16" if pc.H16 == torch.bfloat16 else "float16"
         model = build_detection_model(cfg)
         model.load_state_dict(sd, strict=True)
         model.to(dev)
@@ -202,7 +204,7 @@ def check_gdino_model(dev, vq=True, B=1, hw=((120, 150),), spec=None, n_classes=
     bank = make_query_bank(labels, spec, seed=1, scales=1) if vq else None
     model.query_selector.query_bank = None if bank is None else {k: v.to(dev) for k, v in bank.items()}
     g = torch.Generator().manual_seed(11)
-    imgs = [torch.randn(3, h, w, generator=g).half().float() for (h, w) in hw]
+    imgs = [torch.randn(3, h, w, generator=g).to(pc.H16).float() for (h, w) in hw]
     il = to_image_list(imgs, 32)
     sizes = [tuple(s) for s in il.image_sizes]
     tok = model.tokenizer([caption + "."] * B, padding="max_length", return_tensors="pt")
@@ -212,7 +214,7 @@ def check_gdino_model(dev, vq=True, B=1, hw=((120, 150),), spec=None, n_classes=
         det = model(ild, captions=[caption] * B, positive_map=pmap)
         # the oracle decodes the DEVICE's selection (see oracle.gdino.transformer: rank-dependent, discontinuous); its own
         # selection is compared as a set below
-        o = og.forward({k: (v.half().float() if v.dtype.is_floating_point else v) for k, v in sd.items()}, spec, il.tensors, sizes,
+        o = og.forward({k: (v.to(pc.H16).float() if v.dtype.is_floating_point else v) for k, v in sd.items()}, spec, il.tensors, sizes,
                        tok["input_ids"], tok["attention_mask"], pmap, model.specical_tokens, bank, topk_override=tr["topk"].cpu())
         for _ in range(2 if graph else 0):                        # warm call -> capture -> replay must reproduce the eager result
             det2 = model(ild, captions=[caption] * B, positive_map=pmap)

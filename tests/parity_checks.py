@@ -18,9 +18,25 @@ TOL = 2e-3
 # reference's own device kernels (oracle/_ref needs a GPU).  On the GPU box both keep their defaults.
 QUICK = False
 PINS = True
+# The 16-bit operand type under test: fp16 (default; the entry points of include/mqdet_hip.h) or bf16 (their *_bf16 twins,
+# MODEL.COMPUTE_DTYPE = "bfloat16", BASELINE.json configs[3]).  `use_dtype(torch.bfloat16)` switches every check below: inputs and
+# weights are rounded to bf16, the product runs its bf16 kernels, and every tolerance is multiplied by 8 = 2^(11 - 8), the ratio of
+# the two formats' rounding steps (fp16: 11 significant bits, bf16: 8).
+H16 = torch.float16
+TOL_SCALE = 1.0
+
+
+def use_dtype(dtype):
+    global H16, TOL_SCALE
+    assert dtype in (torch.float16, torch.bfloat16)
+    H16, TOL_SCALE = dtype, (1.0 if dtype == torch.float16 else 8.0)
+    _CACHE.clear()
 
 
 def _stat(name, got, ref, tol=TOL):
+    tol = tol * TOL_SCALE
+    if H16 == torch.bfloat16:
+        name = "[bf16] " + name
     got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
     err = (got - ref).abs().max().item() if ref.numel() else 0.0
     scale = max(1.0, ref.abs().max().item() if ref.numel() else 1.0)
@@ -48,9 +64,9 @@ def check_attention(dev, B, H, D, Nq, Nk, mask=False, clamp=0.0, nsplit=1, scale
     from mq_det_amd import ops
     g = torch.Generator().manual_seed(seed)
     amp = 4.0 if big else 1.0
-    q = (torch.randn(B, Nq, H * D, generator=g) * amp).half()
-    k = torch.randn(B, Nk, H * D, generator=g).half()
-    v = torch.randn(B, Nk, H * D, generator=g).half()
+    q = (torch.randn(B, Nq, H * D, generator=g) * amp).to(H16)
+    k = torch.randn(B, Nk, H * D, generator=g).to(H16)
+    v = torch.randn(B, Nk, H * D, generator=g).to(H16)
     kb = kl = None
     if mask:
         kb = torch.zeros(B, Nk)
@@ -71,8 +87,8 @@ def check_attention_strided(dev):
     from mq_det_amd import ops
     g = torch.Generator().manual_seed(5)
     B, T, H, D = 2, 256, 12, 64
-    qk = torch.randn(B, T, 2 * H * D, generator=g).half()
-    v = torch.randn(B, T, H * D, generator=g).half()
+    qk = torch.randn(B, T, 2 * H * D, generator=g).to(H16)
+    v = torch.randn(B, T, H * D, generator=g).to(H16)
     ref = _ref_attention(qk[:, :, :H * D], qk[:, :, H * D:], v, H)
     qkd = qk.to(dev)
     out = ops.attention(qkd[:, :, :H * D], qkd[:, :, H * D:], v.transpose(1, 2).contiguous().to(dev), H, D)
@@ -98,6 +114,7 @@ def _tiny(dev, image_hw=(160, 192), B=2, seed=0, spec=None):
     cfg.MODEL.DYHEAD.NUM_CONVS = spec.dyhead_convs
     cfg.MODEL.DYHEAD.NUM_CLASSES = spec.num_classes
     cfg.MODEL.ATSS.DETECTIONS_PER_IMG = spec.detections_per_img
+    cfg.MODEL.COMPUTE_DTYPE = "bfloat16" if H16 == torch.bfloat16 else "float16"
     model = GeneralizedVLRCNN_New(cfg, tokenizer=object())
     model.load_state_dict(sd, strict=True)
     model.to(dev)
@@ -121,7 +138,7 @@ def check_swin_fpn(dev, large=False):
     from oracle import backbone as ob
     from mq_det_amd.modeling import pipeline
     spec, sd, cfg, model, P = tiny(dev, large)
-    img = torch.randn(2, 3, 90, 122, generator=torch.Generator().manual_seed(1)).half()
+    img = torch.randn(2, 3, 90, 122, generator=torch.Generator().manual_seed(1)).to(H16)
     with torch.no_grad():
         c = ob.swin_forward(sd, "backbone.body", img.float(), spec)
         p = ob.fpn_forward(sd, "backbone.fpn", c)
@@ -146,7 +163,7 @@ def check_window_attention(dev, large=False):
         for shift in (0, ws // 2):
             b = f"backbone.body.layers.{stage}.blocks.{1 if shift else 0}.attn"
             g = torch.Generator().manual_seed(7 + shift)
-            y = torch.randn(2, H, W, C, generator=g).half()            # = norm1(x)
+            y = torch.randn(2, H, W, C, generator=g).to(H16)            # = norm1(x)
             # oracle: pad, roll, partition, attention (without proj), reverse, roll back, crop
             yf = y.float()
             pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
@@ -155,9 +172,9 @@ def check_window_attention(dev, large=False):
             if shift:
                 yp = torch.roll(yp, (-shift, -shift), (1, 2))
             xw = ob.to_windows(yp, ws)
-            qkv = F.linear(xw, sd[b + ".qkv.weight"].half().float(), sd[b + ".qkv.bias"].half().float())
+            qkv = F.linear(xw, sd[b + ".qkv.weight"].to(H16).float(), sd[b + ".qkv.bias"].to(H16).float())
             Bw, N, _ = qkv.shape
-            qkv = qkv.half().float().reshape(Bw, N, 3, heads, 32).permute(2, 0, 3, 1, 4)
+            qkv = qkv.to(H16).float().reshape(Bw, N, 3, heads, 32).permute(2, 0, 3, 1, 4)
             attn = (qkv[0] * 32 ** -0.5) @ qkv[1].transpose(-1, -2)
             bias = sd[b + ".relative_position_bias_table"][ob.rel_pos_index(ws).reshape(-1)].reshape(N, N, heads).permute(2, 0, 1)
             attn = attn + bias[None]
@@ -179,8 +196,8 @@ def check_window_attention(dev, large=False):
 def _gcp_inputs(spec, T=40):
     g = torch.Generator().manual_seed(11)
     B, C = 2, spec.bert_hidden
-    x = torch.randn(B, T, C, generator=g).half()
-    vis = torch.randn(B, 15, C, generator=g).half()
+    x = torch.randn(B, T, C, generator=g).to(H16)
+    vis = torch.randn(B, 15, C, generator=g).to(H16)
     vis[1, 10:] = 0
     tok = {0: [2], 1: [5, 6, 7], 2: [10, 11]}
     vmask = torch.zeros(B, 15, T)
@@ -219,8 +236,8 @@ def check_pre_select(dev):
     from mq_det_amd.modeling import pipeline
     spec, sd, cfg, model, P = tiny(dev)
     g = torch.Generator().manual_seed(12)
-    vis = torch.randn(2, 15, spec.fpn_out, generator=g).half()
-    img = torch.randn(2, 333, spec.fpn_out, generator=g).half()
+    vis = torch.randn(2, 15, spec.fpn_out, generator=g).to(H16)
+    img = torch.randn(2, 333, spec.fpn_out, generator=g).to(H16)
     p = "language_backbone.body.model.pre_select"
     with torch.no_grad():
         ref = ol.pre_select(sd, p, vis.float(), img.float(), spec)
@@ -234,7 +251,7 @@ def check_bert_layer(dev, clamp):
     spec, sd, cfg, model, P = tiny(dev)
     g = torch.Generator().manual_seed(13)
     T = 64
-    x = torch.randn(2, T, spec.bert_hidden, generator=g).half()
+    x = torch.randn(2, T, spec.bert_hidden, generator=g).to(H16)
     am = torch.ones(2, T, dtype=torch.long)
     am[0, 25:] = 0
     am[1, 50:] = 0
@@ -252,8 +269,8 @@ def check_vl_fuse(dev):
     spec, sd, cfg, model, P = tiny(dev)
     g = torch.Generator().manual_seed(14)
     sizes = [(20, 24), (10, 12), (5, 6), (3, 3), (2, 2)]
-    feats = [torch.randn(2, 256, h, w, generator=g).half() for h, w in sizes]
-    l = torch.randn(2, 64, spec.bert_hidden, generator=g).half()
+    feats = [torch.randn(2, 256, h, w, generator=g).to(H16) for h, w in sizes]
+    l = torch.randn(2, 64, spec.bert_hidden, generator=g).to(H16)
     am = torch.ones(2, 64, dtype=torch.long)
     am[0, 30:] = 0
     b = "rpn.head.dyhead_tower.0.b_attn"
@@ -276,12 +293,12 @@ def check_vlfuse_kernels(dev):
     res = []
     for B, N, T, kv in ((2, 645, 64, None), (3, 300, 100, [100, 37, 70]), (2, 200, 160, [131, 160]), (1, 130, 256, [256]),
                         (9, 128, 40, None))[1 if QUICK else 0:4 if QUICK else 5]:
-        v_ln = torch.randn(B, N, 256, generator=g).half()
-        kf = (torch.randn(B, 8, T, 256, generator=g) / 8).half()
-        vo = torch.randn(B, 8, T, 256, generator=g).half()
+        v_ln = torch.randn(B, N, 256, generator=g).to(H16)
+        kf = (torch.randn(B, 8, T, 256, generator=g) / 8).to(H16)
+        vo = torch.randn(B, 8, T, 256, generator=g).to(H16)
         bias = torch.randn(B, 8, T, generator=g)
         bias[:, :, T // 3] = -1e30                       # a masked key in the middle of the valid range
-        ob = torch.randn(256, generator=g).half()
+        ob = torch.randn(256, generator=g).to(H16)
         kv_len = None if kv is None else torch.tensor(kv, dtype=torch.int32)
         ref = emu.vlfuse_i2t(v_ln.float(), kf.float(), vo.float(), bias, ob.float(), kv_len, 0)
         got = ops.vlfuse_i2t(v_ln.to(dev), kf.to(dev), vo.to(dev), bias.to(dev), ob.to(dev),
@@ -289,8 +306,8 @@ def check_vlfuse_kernels(dev):
         res.append(_stat(f"vlfuse image side B={B} N={N} T={T} kv_len={kv}", got, ref, tol=2e-3))
     for B, N, T, ns, kv in ((2, 645, 64, 1, None), (1, 22400, 256, 6, None), (3, 1000, 100, 3, None), (2, 130, 160, 2, [160, 90]),
                             (9, 70, 40, 1, None), (3, 500, 256, 4, [256, 128, 77]))[3 if QUICK else 0:]:
-        v_ln = torch.randn(B, N, 256, generator=g).half()
-        kf = (torch.randn(B, 8, T, 256, generator=g) / 8).half()
+        v_ln = torch.randn(B, N, 256, generator=g).to(H16)
+        kf = (torch.randn(B, 8, T, 256, generator=g) / 8).to(H16)
         kv_len = None if kv is None else torch.tensor(kv, dtype=torch.int32)
         ref = emu.vlfuse_t2i(kf.float(), v_ln.float(), ns, kv_len=kv_len)
         got = ops.vlfuse_t2i(kf.to(dev), v_ln.to(dev), ns, kv_len=None if kv is None else kv_len.to(dev))
@@ -308,10 +325,10 @@ def check_dcn(dev):
     group, refs = [], []
     for name, (H, W), (oH, oW), stride in (("same level s1", (13, 17), (13, 17), 1), ("from level-1 s2", (26, 33), (13, 17), 2),
                                            ("from level+1 (quirk)", (7, 9), (13, 17), 1)):
-        x = torch.randn(2, 256, H, W, generator=g).half()
+        x = torch.randn(2, 256, H, W, generator=g).to(H16)
         om = torch.randn(2, 27, oH, oW, generator=g) * 1.5
-        w = (torch.randn(256, 256, 3, 3, generator=g) / 48).half()
-        bias = torch.randn(256, generator=g).half()
+        w = (torch.randn(256, 256, 3, 3, generator=g) / 48).to(H16)
+        bias = torch.randn(256, generator=g).to(H16)
         ref = oh.dcn_v2(x.float(), om[:, :18], om[:, 18:].sigmoid(), w.float(), bias.float(), stride)
         wp = w.permute(0, 2, 3, 1).reshape(256, -1).to(dev)
         Ho, Wo = ref.shape[-2:]
@@ -332,7 +349,7 @@ def check_dcn(dev):
         res.append(_stat(f"dcnv2 grouped launch == single launch: {name}", yg, y2.float(), tol=0.0))
         res.append(_stat(f"dcnv2 grouped launch statistics: {name}", sg, sums, tol=0.0))
     # GroupNorm / scale-attention coefficients: grouped launch (4 parallel reducers) vs the single-branch kernel
-    gam, bet = (torch.randn(256, generator=g) * 0.1 + 1).half().to(dev), (torch.randn(256, generator=g) * 0.1).half().to(dev)
+    gam, bet = (torch.randn(256, generator=g) * 0.1 + 1).to(H16).to(dev), (torch.randn(256, generator=g) * 0.1).to(H16).to(dev)
     aw, ab = (torch.randn(256, generator=g) * 0.1).to(dev), torch.randn(1, generator=g).to(dev)
     items = [{"sums": sg, "n": yg.shape[1], "gamma": gam, "beta": bet, "nbranches": 3} for (yg, _, sg) in grouped]
     for (name, _, _), (yg, (Ho, Wo), sg), cg in zip(refs, grouped, ops.dyconv_coef_group(items, aw, ab, 16, 1e-5)):
@@ -352,10 +369,10 @@ def check_ref_pins(dev):
     for name, (H, W), (oH, oW), stride, amp in (("same level s1", (13, 17), (13, 17), 1, 1.5), ("from level-1 s2", (26, 33), (13, 17), 2, 1.5),
                                                 ("from level+1 (quirk 1)", (7, 9), (13, 17), 1, 1.5), ("large offsets", (20, 24), (20, 24), 1, 6.0),
                                                 ("P3-like 50x84", (50, 84), (50, 84), 1, 0.7)):
-        x = torch.randn(2, 256, H, W, generator=g).half()
+        x = torch.randn(2, 256, H, W, generator=g).to(H16)
         om = torch.randn(2, 27, oH, oW, generator=g) * amp
-        w = (torch.randn(256, 256, 3, 3, generator=g) / 48).half()
-        bias = torch.randn(256, generator=g).half()
+        w = (torch.randn(256, 256, 3, 3, generator=g) / 48).to(H16)
+        bias = torch.randn(256, generator=g).to(H16)
         off, msk = om[:, :18].contiguous(), om[:, 18:].sigmoid().contiguous()
         pin = rn.dcn_v2(x.float().to(dev), off.to(dev), msk.to(dev), w.float().to(dev), bias.float().to(dev), stride)
         ora = oh.dcn_v2(x.float(), off, msk, w.float(), bias.float(), stride)
@@ -412,7 +429,7 @@ def check_post_golden(dev, golden_dir=None):
         T = gd["dot.0"].shape[2]
         head = {"dot": [], "bbox_reg": [], "centerness": [], "tbias": torch.zeros(B, T, device=dev)}
         for l in range(5):
-            dot, reg, ctr = t(f"dot.{l}"), t(f"bbox_reg.{l}").half(), t(f"centerness.{l}").half()
+            dot, reg, ctr = t(f"dot.{l}"), t(f"bbox_reg.{l}").to(H16), t(f"centerness.{l}").to(H16)
             head["dot"].append(dot.to(dev).contiguous())                        # fp32 logits straight into the kernel
             head["bbox_reg"].append(reg.to(dev))
             head["centerness"].append(ctr.to(dev))
@@ -435,7 +452,7 @@ def check_post_golden(dev, golden_dir=None):
         from dataclasses import replace
         from oracle import tiny_spec
         sp = replace(tiny_spec(), mdetr_class_num=mdetr, detections_per_img=ndet)
-        odets = op.atss_postprocess([t(f"bbox_reg.{l}").half().float() for l in range(5)], [t(f"centerness.{l}").half().float() for l in range(5)],
+        odets = op.atss_postprocess([t(f"bbox_reg.{l}").to(H16).float() for l in range(5)], [t(f"centerness.{l}").to(H16).float() for l in range(5)],
                                     [t(f"dot.{l}") for l in range(5)], [t(f"anchors.{l}") for l in range(5)], sizes, pm, sp)
         for b in range(B):
             n = int(post["counts"][b])
@@ -496,7 +513,7 @@ def check_score_agg(dev, golden_dir=None):
     for fam, aggs in (("dyhead", ("MEAN", "MAX", "ONEHOT")), ("mdetr", ("MEAN", "MAX", "ONEHOT", "POWER"))):
         for agg in aggs:
             (tokidx, _), labels = index_for(pm, agg)
-            _, cls = ops.align_scores(logits.to(dev).contiguous(), tb, tokidx, ctr.half().to(dev).contiguous(), 0.05, want_cls=True,
+            _, cls = ops.align_scores(logits.to(dev).contiguous(), tb, tokidx, ctr.to(H16).to(dev).contiguous(), 0.05, want_cls=True,
                                       agg=ops.SCORE_AGG[agg])
             ref = torch.from_numpy(gd[f"{fam}_{agg}"])[:, :, [k - 1 for k in labels]]
             res.append(_stat(f"score_agg {agg} ({fam}): mq_align_scores class scores vs reference fixture", cls, ref, tol=1e-5))
@@ -510,11 +527,11 @@ def check_score_agg(dev, golden_dir=None):
             cfg = get_cfg()
             cfg.MODEL.ATSS.DETECTIONS_PER_IMG, cfg.TEST.MDETR_STYLE_AGGREGATE_CLASS_NUM, cfg.MODEL.DYHEAD.SCORE_AGG = 100, mdetr, agg
             (tokidx, label_ids), _ = index_for(pm, agg)
-            head = {"dot": [t(f"dot.{l}").to(dev).contiguous() for l in range(5)], "bbox_reg": [t(f"bbox_reg.{l}").half().to(dev) for l in range(5)],
-                    "centerness": [t(f"centerness.{l}").half().to(dev) for l in range(5)], "tbias": torch.zeros(B, T, device=dev)}
+            head = {"dot": [t(f"dot.{l}").to(dev).contiguous() for l in range(5)], "bbox_reg": [t(f"bbox_reg.{l}").to(H16).to(dev) for l in range(5)],
+                    "centerness": [t(f"centerness.{l}").to(H16).to(dev) for l in range(5)], "tbias": torch.zeros(B, T, device=dev)}
             post = pipeline.postprocess(cfg, head, [t(f"anchors.{l}").to(dev) for l in range(5)], sizes, tokidx, label_ids)
             sp = replace(tiny_spec(), mdetr_class_num=mdetr, detections_per_img=100, score_agg=agg)
-            odets = op.atss_postprocess([t(f"bbox_reg.{l}").half().float() for l in range(5)], [t(f"centerness.{l}").half().float() for l in range(5)],
+            odets = op.atss_postprocess([t(f"bbox_reg.{l}").to(H16).float() for l in range(5)], [t(f"centerness.{l}").to(H16).float() for l in range(5)],
                                         [t(f"dot.{l}") for l in range(5)], [t(f"anchors.{l}") for l in range(5)], sizes, pm, sp)
             for b in range(B):
                 n = int(post["counts"][b])
@@ -536,12 +553,12 @@ def check_layernorm(dev):
     g = torch.Generator().manual_seed(22)
     res = []
     for rows, C, eps in ((1000, 96, 1e-5), (777, 192, 1e-5), (130, 384, 1e-5), (65, 768, 1e-12), (50, 1536, 1e-5), (300, 256, 1e-5)):
-        x = (torch.randn(rows, C, generator=g) * 2 + 0.5).half()
-        w, b = (torch.randn(C, generator=g) * 0.1 + 1).half(), (torch.randn(C, generator=g) * 0.1).half()
+        x = (torch.randn(rows, C, generator=g) * 2 + 0.5).to(H16)
+        w, b = (torch.randn(C, generator=g) * 0.1 + 1).to(H16), (torch.randn(C, generator=g) * 0.1).to(H16)
         ref = F.layer_norm(x.float(), (C,), w.float(), b.float(), eps)
         res.append(_stat(f"layernorm rows={rows} C={C}", ops.layer_norm(x.to(dev), w.to(dev), b.to(dev), eps), ref))
-        r = torch.randn(rows, C, generator=g).half()                 # fp16 + fp16: LN(fp16(x + r)), sum returned in fp16
-        xs = (x.float() + r.float()).half()
+        r = torch.randn(rows, C, generator=g).to(H16)                 # fp16 + fp16: LN(fp16(x + r)), sum returned in fp16
+        xs = (x.float() + r.float()).to(H16)
         y, s_out = ops.layer_norm(x.to(dev), w.to(dev), b.to(dev), eps, residual=r.to(dev))
         res.append(_stat(f"add+layernorm rows={rows} C={C}: y", y, F.layer_norm(xs.float(), (C,), w.float(), b.float(), eps)))
         res.append(_stat(f"add+layernorm rows={rows} C={C}: fp16 sum (bit-exact)", s_out, xs.float(), tol=0.0))
@@ -565,9 +582,9 @@ def check_conv3x3(dev):
     for (B, H, W, N, stride) in ((2, 13, 21, 256, 1), (3, 25, 42, 256, 2), (2, 100, 168, 27, 1), (1, 7, 11, 27, 1), (2, 50, 84, 256, 1)):
         if QUICK and H * W > 2000:
             continue
-        x = torch.randn(B, 256, H, W, generator=g).half()
-        w = (torch.randn(N, 256, 3, 3, generator=g) / 48).half()
-        bias = torch.randn(N, generator=g).half()
+        x = torch.randn(B, 256, H, W, generator=g).to(H16)
+        w = (torch.randn(N, 256, 3, 3, generator=g) / 48).to(H16)
+        bias = torch.randn(N, generator=g).to(H16)
         ref = F.conv2d(x.float(), w.float(), bias.float(), stride=stride, padding=1)
         wp = w.permute(0, 2, 3, 1).reshape(N, -1)
         rows = 32 if N <= 32 else 256
@@ -577,7 +594,7 @@ def check_conv3x3(dev):
         if N <= 32 and stride == 1:       # LDS-window kernel of the offset conv: fp32 NCHW out; also from a strided level view
             y2 = ops.conv3x3_nchw32(x.permute(0, 2, 3, 1).contiguous().to(dev), wp.to(dev), bias.to(dev), N)
             res.append(_stat(f"conv3x3 LDS-window (fp32 NCHW) B={B} {H}x{W} N={N}", y2, ref, tol=2e-3))
-            big = torch.zeros(B, H * W + 37, 256, dtype=torch.float16, device=dev)
+            big = torch.zeros(B, H * W + 37, 256, dtype=H16, device=dev)
             big[:, 5:5 + H * W] = x.permute(0, 2, 3, 1).reshape(B, H * W, 256).to(dev)
             y3 = ops.conv3x3_nchw32(big[:, 5:5 + H * W].reshape(B, H, W, 256), wp.to(dev), bias.to(dev), N)
             res.append(_stat(f"conv3x3 LDS-window, level view of a token buffer B={B} {H}x{W}", y3, ref, tol=2e-3))
@@ -590,7 +607,7 @@ def check_dyconv(dev):
     spec, sd, cfg, model, P = tiny(dev)
     g = torch.Generator().manual_seed(16)
     sizes = [(20, 24), (10, 12), (5, 6), (3, 3), (2, 2)]
-    feats = [torch.randn(2, 256, h, w, generator=g).half() for h, w in sizes]
+    feats = [torch.randn(2, 256, h, w, generator=g).to(H16) for h, w in sizes]
     b = "rpn.head.dyhead_tower.2"
     with torch.no_grad():
         ref = oh.dyconv(sd, b, [f.float() for f in feats], spec)
@@ -634,7 +651,7 @@ def make_inputs(spec, B=2, hw=((150, 190), (160, 170)), nvalid=30, seed=3):
     from oracle import detector as od
     from oracle.weights import make_query_bank
     g = torch.Generator().manual_seed(seed)
-    imgs = [torch.randn(3, h, w, generator=g).half().float() for (h, w) in hw[:B]]
+    imgs = [torch.randn(3, h, w, generator=g).to(H16).float() for (h, w) in hw[:B]]
     images, sizes = od.pad_images(imgs, spec.size_divisibility)
     T = spec.max_query_len
     ids = torch.zeros(B, T, dtype=torch.long)
@@ -698,10 +715,11 @@ def check_full_model(dev, vision_queries=True, large=False):
             a2 = (rb[i, 2] - rb[i, 0] + 1) * (rb[i, 3] - rb[i, 1] + 1)
             iou = torch.where(same, inter_a / (a1 + a2 - inter_a), torch.zeros_like(a1))
             j = int(iou.argmax())
-            if iou[j] > 0.9 and abs(float(gs[j] - rs[i])) < 0.02:
+            # bf16: scores drift 8x further (3 fewer significant bits per operand), boxes move with them
+            if iou[j] > (0.9 if TOL_SCALE == 1.0 else 0.8) and abs(float(gs[j] - rs[i])) < 0.02 * TOL_SCALE:
                 matched += 1
         frac = matched / max(1, len(top))
-        res.append({"name": f"full: top-50 detections matched (IoU>0.9, |ds|<0.02) img{b} n_hip={n} n_ref={len(rb)}",
+        res.append({"name": f"full: top-50 detections matched (IoU>{0.9 if TOL_SCALE == 1.0 else 0.8}, |ds|<{0.02 * TOL_SCALE:g}) img{b} n_hip={n} n_ref={len(rb)}",
                     "max_err": 1 - frac, "mean_err": 0.0, "ref_absmax": 1.0, "norm_err": 1 - frac, "tol": 0.2, "ok": frac >= 0.8})
     return res
 
@@ -843,7 +861,7 @@ def check_benchmark_config(dev, caption="long", hw=((800, 1333),), residual_fp32
     words = {"short": (1,), "long": (1, 2, 3, 4, 3, 2), "xlong": (4,)}[caption]
     ids, am, pm, nv = caption_ids(spec, B, 40, words)
     g = torch.Generator().manual_seed(7)
-    imgs = [torch.randn(3, h, w, generator=g).half().float() for (h, w) in hw]
+    imgs = [torch.randn(3, h, w, generator=g).to(H16).float() for (h, w) in hw]
     images, sizes = od.pad_images(imgs, spec.size_divisibility)
     bank = make_query_bank(pm.keys(), spec)
     model.load_query_bank(bank)
@@ -859,7 +877,7 @@ def check_benchmark_config(dev, caption="long", hw=((800, 1333),), residual_fp32
                 _, fl = od.forward(sd, spec, images, sizes, ids, am, pm, bank, return_intermediates=True)
         raw = model(ImageList(images.to(dev), sizes), captions=None, positive_map=pm, return_raw=True,
                     input_ids=ids.to(dev), attention_mask=am.to(dev))
-        x = images.to(dev).half().contiguous(memory_format=torch.channels_last)
+        x = images.to(dev).to(H16).contiguous(memory_format=torch.channels_last)
         cg = pipeline.swin_forward(P, cfg, x)
     res = []
 
@@ -951,7 +969,7 @@ def check_roi_align(dev):
     feat = torch.randn(N, C, H, W, generator=g)
     rois = torch.tensor([[0, 10., 20., 300., 190.], [1, 0., 0., 671., 399.], [0, 50., 50., 50.5, 50.2], [1, 600., 350., 700., 420.],
                          [0, -20., -10., 40., 30.], [1, 333.3, 111.1, 444.4, 222.2]])
-    f16 = feat.half()
+    f16 = feat.to(H16)
     nhwc = f16.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)           # NHWC memory, NCHW view (the product's layout)
     for aligned in (False, True):
         for sr in (0, 2):
@@ -969,7 +987,7 @@ def check_roi_align(dev):
     # Pooler with boxes on several FPN levels (LevelMapper) vs the oracle pooler, NHWC fp16 pyramid
     from mq_det_amd.modeling.poolers import Pooler
     sizes = [(640, 800), (600, 720)]
-    feats = [torch.randn(2, 256, -(-640 // s), -(-800 // s), generator=g).half() for s in (8, 16, 32, 64, 128)]
+    feats = [torch.randn(2, 256, -(-640 // s), -(-800 // s), generator=g).to(H16) for s in (8, 16, 32, 64, 128)]
     bl, tup = _query_targets(sizes, dev)
     scales = (0.125, 0.0625, 0.03125, 0.015625, 0.0078125)
     pl = Pooler((7, 7), scales, 0, use_v2=True)
@@ -1053,16 +1071,16 @@ def check_swin_mlp(dev):
     for C, M, use_delta, use_next in ((96, 1000, True, True), (96, 128, False, False), (192, 777, True, True), (384, 333, True, True),
                                       (384, 64, True, False), (96, 67200 * 2 + 5, True, True))[:5 if QUICK else 6]:
         x = torch.randn(M, C, generator=g) * 1.5
-        delta = (torch.randn(M, C, generator=g) * 0.5).half() if use_delta else None
-        lg, lb = (torch.randn(C, generator=g) * 0.1 + 1).half(), (torch.randn(C, generator=g) * 0.1).half()
-        w1 = (torch.randn(4 * C, C, generator=g) / math.sqrt(C)).half()
-        b1 = (torch.randn(4 * C, generator=g) * 0.1).half()
-        w2 = (torch.randn(C, 4 * C, generator=g) / math.sqrt(4 * C)).half()
-        b2 = (torch.randn(C, generator=g) * 0.1).half()
-        ng, nb = (torch.randn(C, generator=g) * 0.1 + 1).half(), (torch.randn(C, generator=g) * 0.1).half()
+        delta = (torch.randn(M, C, generator=g) * 0.5).to(H16) if use_delta else None
+        lg, lb = (torch.randn(C, generator=g) * 0.1 + 1).to(H16), (torch.randn(C, generator=g) * 0.1).to(H16)
+        w1 = (torch.randn(4 * C, C, generator=g) / math.sqrt(C)).to(H16)
+        b1 = (torch.randn(4 * C, generator=g) * 0.1).to(H16)
+        w2 = (torch.randn(C, 4 * C, generator=g) / math.sqrt(4 * C)).to(H16)
+        b2 = (torch.randn(C, generator=g) * 0.1).to(H16)
+        ng, nb = (torch.randn(C, generator=g) * 0.1 + 1).to(H16), (torch.randn(C, generator=g) * 0.1).to(H16)
         xp = x + (delta.float() if use_delta else 0.0)
-        h = F.layer_norm(xp, (C,), lg.float(), lb.float(), 1e-5).half().float()          # the kernel feeds fp16 to the MFMAs
-        hid = F.gelu(F.linear(h, w1.float(), b1.float())).half().float()
+        h = F.layer_norm(xp, (C,), lg.float(), lb.float(), 1e-5).to(H16).float()          # the kernel feeds fp16 to the MFMAs
+        hid = F.gelu(F.linear(h, w1.float(), b1.float())).to(H16).float()
         ref = xp + F.linear(hid, w2.float(), b2.float())
         w2p = w2[:, ops.swin_mlp_w2_perm(4 * C)].contiguous()
         r = ops.swin_mlp(x.to(dev), None if delta is None else delta.to(dev), lg.to(dev), lb.to(dev), 1e-5, w1.to(dev), b1.to(dev),
@@ -1104,7 +1122,7 @@ def check_msdeform_attn(dev, golden_dir=None):
     g = torch.Generator().manual_seed(61)
     shapes = [(100, 168), (50, 84), (25, 42), (13, 21)]
     S = sum(h * w for h, w in shapes)
-    v = torch.randn(1, S, 8, 32, generator=g).half()
+    v = torch.randn(1, S, 8, 32, generator=g).to(H16)
     Q = 2001
     loc = torch.rand(1, Q, 8, 4, 4, 2, generator=g) * 1.1 - 0.05
     attn = torch.rand(1, Q, 8, 16, generator=g).softmax(-1).reshape(1, Q, 8, 4, 4)
@@ -1113,11 +1131,11 @@ def check_msdeform_attn(dev, golden_dir=None):
     res.append(_stat(f"msdeform fp16 values, 4 levels of 800x1344, Q={Q}", got, ref, tol=1e-3))
     # module forward
     sd = gdino.make_msda_weights(prefix="attn")
-    W = msdeform.pack_msda(sd, "attn", dev)
-    sdh = {k: t.half().float() for k, t in sd.items()}
+    W = msdeform.pack_msda(sd, "attn", dev, dtype=H16)
+    sdh = {k: t.to(H16).float() for k, t in sd.items()}
     shapes = [(20, 24), (10, 12), (5, 6), (3, 3)]
     S = sum(h * w for h, w in shapes)
-    x = torch.randn(2, S, 256, generator=g).half()
+    x = torch.randn(2, S, 256, generator=g).to(H16)
     mask = torch.zeros(2, S, dtype=torch.bool)
     mask[1, S - 40:] = True
     for nd in (2, 4):

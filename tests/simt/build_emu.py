@@ -58,9 +58,14 @@ def build(force=False, verbose=False, sources=None):
     procs, objs = [], []
     units = [os.path.join(src_dir, f.replace(".hip", ".cpp")) for f in names if f.endswith(".hip")] + [os.path.join(HERE, "simt_runtime.cpp")]
     for u in units:
-        obj = os.path.join(BUILD, os.path.basename(u).replace(".cpp", ".o"))
-        objs.append(obj)
-        procs.append((u, subprocess.Popen([CXX, *FLAGS, "-I", src_dir, "-c", u, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        # like mq_det_amd/build.py: every kernel source twice, fp16 and -DMQ_BF16 (the *_bf16 entry points)
+        for suffix, defs in (("", []), ("_bf16", ["-DMQ_BF16"])):
+            if suffix and os.path.basename(u) in ("api.cpp", "simt_runtime.cpp"):
+                continue
+            obj = os.path.join(BUILD, os.path.basename(u).replace(".cpp", suffix + ".o"))
+            objs.append(obj)
+            procs.append((u + suffix, subprocess.Popen([CXX, *FLAGS, *defs, "-I", src_dir, "-c", u, "-o", obj], stdout=subprocess.PIPE,
+                                                       stderr=subprocess.STDOUT)))
     for u, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:

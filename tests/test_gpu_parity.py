@@ -323,3 +323,33 @@ def test_integration_md_operator_stubs_run_as_written(dev):
     start = torch.cat([hw.new_zeros(1), (hw[:, 0] * hw[:, 1]).cumsum(0)[:-1]])
     out = ns["ms_deform_attn_forward"](value.to(dev), hw.to(dev), start.to(dev), loc.to(dev), attn.to(dev)).cpu()
     torch.testing.assert_close(out, og.ms_deform_attn_core(value, shapes, loc, attn), atol=1e-4, rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ bf16 operands (configs[3])
+@pytest.fixture()
+def bf16():
+    """The *_bf16 entry points: the same kernel sources compiled with bf16 operands (csrc/common.h, -DMQ_BF16).  Every check runs
+    with inputs / weights rounded to bf16 and 8x the fp16 tolerance (3 fewer significant bits), tests/parity_checks.py."""
+    import parity_checks as pc
+    pc.use_dtype(torch.bfloat16)
+    yield pc
+    pc.use_dtype(torch.float16)
+
+
+@pytest.mark.parametrize("name", ["check_attention_strided", "check_window_attention", "check_gcp_block", "check_pre_select", "check_vlfuse_kernels",
+                                  "check_vl_fuse", "check_dcn", "check_dyconv", "check_conv3x3", "check_layernorm", "check_swin_mlp", "check_post_golden",
+                                  "check_roi_align", "check_msdeform_attn", "check_full_model"])
+def test_bf16_block(dev, bf16, name):
+    _assert(getattr(bf16, name)(dev))
+
+
+def test_bf16_mq_glip_l_family(dev, bf16):
+    """BASELINE configs[3] as named: MQ-GLIP-L (Swin-L window 12, tiny depth) on bf16 MFMA."""
+    _assert(bf16.check_window_attention(dev, large=True))
+    _assert(bf16.check_full_model(dev, large=True))
+
+
+def test_bf16_groundingdino(dev, bf16):
+    import gdino_checks as gc
+    _assert(gc.check_msdeform_attn_q(dev))
+    _assert(gc.check_gdino_model(dev, vq=True))

@@ -16,7 +16,9 @@ def test_c_abi_exports_match_header():
     from mq_det_amd import build, ops
     build.build()
     hdr = open(os.path.join(ROOT, "include", "mqdet_hip.h")).read()
-    declared = set(re.findall(r"\b(mq_[a-z0-9_]+)\s*\(", hdr))
+    twins = set(re.findall(r"^MQ_BF16_TWIN\((mq_[a-z0-9_]+)\)", hdr, re.M))
+    assert twins == set(ops.BF16_TWINS), twins ^ set(ops.BF16_TWINS)
+    declared = set(re.findall(r"\b(mq_[a-z0-9_]+)\s*\(", hdr)) | {n + "_bf16" for n in twins}
     assert declared == set(ops.EXPORTS), declared ^ set(ops.EXPORTS)
     lib = ops.load_library()
     for name in declared:
@@ -169,6 +171,9 @@ def test_ctypes_signatures_match_header():
     text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
     text = re.sub(r"typedef struct.*?}\s*\w+;", " ", text, flags=re.S)
     decls = dict((m.group(2), (m.group(1), m.group(3))) for m in re.finditer(r"\b(int|long)\s+(mq_\w+)\s*\(([^)]*)\)\s*;", text))
+    twins = re.findall(r"^MQ_BF16_TWIN\((mq_\w+)\)", text, re.M)              # `extern decltype(name) name_bf16;`: same signature
+    for n in twins:
+        decls[n + "_bf16"] = decls[n]
     assert set(decls) == set(ops._SIGNATURES), set(decls) ^ set(ops._SIGNATURES)
 
     def kind(arg):

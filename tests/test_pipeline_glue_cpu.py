@@ -42,6 +42,7 @@ def emulated_ops(monkeypatch):
         "dyconv_branch_coef", "dyconv_coef_group", "dyconv_fuse", "dyrelu_", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "vlfuse_i2t", "vlfuse_t2i",
         "box_decode", "ml_nms", "roi_align", "swin_mlp")})
     fake.SWIN_MLP_WIDTHS = (96, 192, 384)
+    fake.SCORE_AGG = {"MEAN": 0, "MAX": 1, "POWER": 2, "ONEHOT": 0}
     monkeypatch.setattr(pipeline, "ops", fake)
     return fake
 

@@ -27,12 +27,12 @@ def kernels():
 
     def prepare(self, device=None):
         self._validate_config()
-        self._plan = pipeline.build_plan(self.state_dict(), self.cfg, CPU)
+        self._plan = pipeline.build_plan(self.state_dict(), self.cfg, CPU, dtype=detector.compute_dtype(self.cfg))
         self._plan_key, self.use_hip_graph = CPU, False
         return self._plan
 
     def prepare_gdino(self, device=None):
-        self._plan = gp.build_gdino_plan(self.state_dict(), self.cfg, CPU, self._swin)
+        self._plan = gp.build_gdino_plan(self.state_dict(), self.cfg, CPU, self._swin, dtype=detector.compute_dtype(self.cfg))
         self._plan_key, self.use_hip_graph = CPU, False
         return self._plan
 
@@ -114,3 +114,33 @@ def test_slow_blocks(kernels, name):
         _assert_ok(kernels.check_window_attention(CPU, large=True) + kernels.check_swin_fpn(CPU, large=True))
     else:
         _assert_ok(_no_graph_rows(getattr(kernels if hasattr(kernels, name) else gc, name)(CPU)))
+
+
+# ---- bf16 operands: the *_bf16 entry points (the same kernel sources compiled with -DMQ_BF16, BASELINE.json configs[3])
+@pytest.fixture()
+def bf16(kernels):
+    kernels.use_dtype(torch.bfloat16)
+    yield kernels
+    kernels.use_dtype(torch.float16)
+
+
+@pytest.mark.parametrize("name", ["check_window_attention", "check_gcp_block", "check_pre_select", "check_vlfuse_kernels", "check_dcn",
+                                  "check_post_golden", "check_layernorm", "check_swin_mlp", "check_conv3x3", "check_msdeform_attn",
+                                  "check_attention_strided"])
+def test_bf16_kernel_block(bf16, name):
+    res = getattr(bf16, name)(CPU)
+    _assert_ok(res)
+    assert all(r["name"].startswith("[bf16]") or r["tol"] == 0.0 or "count" in r["name"] or "(exact)" in r["name"] or "(px)" in r["name"]
+               for r in (res if isinstance(res, list) else [res]))
+
+
+def test_bf16_full_model(bf16):
+    """MODEL.COMPUTE_DTYPE = "bfloat16": the tiny-depth MQ-GLIP-T forward on the bf16 kernels, every stage within 8x the fp16 tolerance"""
+    _assert_ok(bf16.check_full_model(CPU))
+
+
+def test_mixed_16bit_operands_are_rejected(kernels):
+    from mq_det_amd import ops
+    q = torch.zeros(1, 8, 64, dtype=torch.float16)
+    with pytest.raises(TypeError, match="fp16 and bf16"):
+        ops._fn(ops._LIB, "mq_attn_fwd", q, q.to(torch.bfloat16))
