@@ -17,8 +17,15 @@ def library():
         for name, (res, args) in ops._SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        lib.simt_set_schedule.restype, lib.simt_set_schedule.argtypes = None, [ctypes.c_int, ctypes.c_ulong]
         _LIB = lib
     return _LIB
+
+
+def set_schedule(mode="ascending", seed=0):
+    """Order in which the emulation resumes runnable fibers: "ascending" thread ids (default), "descending", or "random" (seeded).
+    A race-free kernel is insensitive to it; a missing barrier between a producer and a consumer wave is not."""
+    library().simt_set_schedule({"ascending": 0, "descending": 1, "random": 2}[mode], seed)
 
 
 @contextlib.contextmanager

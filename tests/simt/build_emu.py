@@ -43,7 +43,7 @@ def build(force=False, verbose=False, sources=None):
     """-> path of the emulation library (rebuilt when any input changed)."""
     os.makedirs(BUILD, exist_ok=True)
     names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
-    inputs = [os.path.join(CSRC, f) for f in names] + [os.path.join(HERE, "simt_runtime.cpp"), os.path.join(HERE, "include", "hip", "hip_runtime.h"),
+    inputs = [os.path.join(CSRC, f) for f in names] + [os.path.join(HERE, "simt_runtime.cpp"), os.path.join(HERE, "selftest.cpp"), os.path.join(HERE, "include", "hip", "hip_runtime.h"),
                                                         os.path.abspath(__file__)]
     stamp, dig = os.path.join(BUILD, "stamp"), _digest(inputs)
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
@@ -56,11 +56,11 @@ def build(force=False, verbose=False, sources=None):
         with open(os.path.join(src_dir, f.replace(".hip", ".cpp")), "w") as fh:
             fh.write(text)
     procs, objs = [], []
-    units = [os.path.join(src_dir, f.replace(".hip", ".cpp")) for f in names if f.endswith(".hip")] + [os.path.join(HERE, "simt_runtime.cpp")]
+    units = [os.path.join(src_dir, f.replace(".hip", ".cpp")) for f in names if f.endswith(".hip")] + [os.path.join(HERE, "simt_runtime.cpp"), os.path.join(HERE, "selftest.cpp")]
     for u in units:
         # like mq_det_amd/build.py: every kernel source twice, fp16 and -DMQ_BF16 (the *_bf16 entry points)
         for suffix, defs in (("", []), ("_bf16", ["-DMQ_BF16"])):
-            if suffix and os.path.basename(u) in ("api.cpp", "simt_runtime.cpp"):
+            if suffix and os.path.basename(u) in ("api.cpp", "simt_runtime.cpp", "selftest.cpp"):
                 continue
             obj = os.path.join(BUILD, os.path.basename(u).replace(".cpp", suffix + ".o"))
             objs.append(obj)

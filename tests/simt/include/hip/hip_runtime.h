@@ -48,7 +48,7 @@ void wave_sync();                                    // all live lanes of the wa
 void block_sync();                                   // all live threads of the workgroup
 uint64_t* xslot(int lane, int buf);                  // exchange slots of the current wave: [2][64][4] x 8 bytes
 int next_buf();                                      // alternating buffer index per collective
-bool lane_live(int lane);
+long op_seq();                                       // sequence number of the collective next_buf() was just called for (>= 1)
 typedef void (*BodyFn)(void*);
 void launch(dim3 grid, dim3 block, size_t shmem, BodyFn fn, void* ctx);
 
@@ -88,24 +88,24 @@ inline void __syncthreads() { simt::block_sync(); }
 template <class T> inline T __shfl_xor(T v, int mask, int width = 64) { (void)width; return simt::shfl_idx(v, simt::lane() ^ mask); }
 template <class T> inline T __shfl(T v, int src, int width = 64) { (void)width; return simt::shfl_idx(v, src); }
 template <class T> inline T __shfl_down(T v, unsigned d, int width = 64) { (void)width; int s = simt::lane() + (int)d; return simt::shfl_idx(v, s < 64 ? s : simt::lane()); }
+// Participation is decided when the lanes meet, not when a lane later reads the exchange slots (another lane may have run on and
+// finished by then): every participant tags its slot with the operation's sequence number.
 inline unsigned long long __ballot(int pred) {
   const int b = simt::next_buf();
-  *simt::xslot(simt::lane(), b) = pred ? 1 : 0;
+  const uint64_t tag = (uint64_t)simt::op_seq();
+  uint64_t* s = simt::xslot(simt::lane(), b);
+  s[0] = pred ? 1 : 0;
+  s[1] = tag;
   simt::wave_sync();
   unsigned long long m = 0;
-  for (int l = 0; l < 64; ++l)
-    if (simt::lane_live(l) && *simt::xslot(l, b)) m |= 1ull << l;
+  for (int l = 0; l < 64; ++l) {
+    const uint64_t* o = simt::xslot(l, b);
+    if (o[1] == tag && o[0]) m |= 1ull << l;
+  }
   return m;
 }
 inline int __any(int pred) { return __ballot(pred) != 0; }
-inline int __all(int pred) {
-  const int b = simt::next_buf();
-  *simt::xslot(simt::lane(), b) = pred ? 1 : 0;
-  simt::wave_sync();
-  for (int l = 0; l < 64; ++l)
-    if (simt::lane_live(l) && !*simt::xslot(l, b)) return 0;
-  return 1;
-}
+inline int __all(int pred) { return __ballot(!pred) == 0; }
 inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 inline int __ffs(unsigned v) { return __builtin_ffs((int)v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }

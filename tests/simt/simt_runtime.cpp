@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <sys/mman.h>
 #include <vector>
+#include <algorithm>
 
 extern "C" void simt_switch(void** save_sp, void* load_sp);
 asm(R"(
@@ -46,7 +47,8 @@ struct Fiber {
   void* sp;
   char* stack;
   uint3_ tid;
-  int lin, lane, wave, state, seq;
+  int lin, lane, wave, state;
+  long seq;
 };
 
 Fiber* cur = nullptr;
@@ -64,37 +66,53 @@ static int block_live, block_arrived;
 static std::vector<char> smem;
 static BodyFn body;
 static void* body_ctx;
+// Order in which runnable fibers are resumed: 0 = ascending thread id, 1 = descending, 2 = pseudo-random (seeded).  A kernel
+// without data races gives the same result under every order; a missing barrier between a producer and a consumer wave shows up
+// as a difference (the fixed ascending order alone would always run the producer first).
+static int sched_mode = 0;
+static uint64_t sched_state = 0x9E3779B97F4A7C15ull;
+static uint64_t next_rand() {
+  sched_state ^= sched_state << 13; sched_state ^= sched_state >> 7; sched_state ^= sched_state << 17;
+  return sched_state;
+}
+static void push_batch(std::vector<int>& ids) {           // ids: fibers that became runnable together
+  if (sched_mode == 1) std::reverse(ids.begin(), ids.end());
+  else if (sched_mode == 2)
+    for (size_t i = ids.size(); i > 1; --i) std::swap(ids[i - 1], ids[next_rand() % i]);
+  runq.insert(runq.end(), ids.begin(), ids.end());
+}
 
 const uint3_& tid() { return cur->tid; }
 int lane() { return cur->lane; }
 void* dyn_smem() { return (void*)(((uintptr_t)smem.data() + 63) & ~(uintptr_t)63); }
 uint64_t* xslot(int l, int buf) { return waves[cur->wave].x[buf][l]; }
 int next_buf() { return (cur->seq++) & 1; }
-bool lane_live(int l) {
-  size_t i = (size_t)cur->wave * 64 + l;
-  return i < fibers.size() && fibers[i].state != DONE;
-}
+long op_seq() { return (long)cur->seq; }
 
 static void yield_to_scheduler() { simt_switch(&cur->sp, sched_sp); }
 
 static void release_wave(int w) {
   Wave& wv = waves[w];
   wv.arrived = 0;
+  std::vector<int> ids;
   for (int l = 0; l < 64; ++l) {
     size_t i = (size_t)w * 64 + l;
     if (i < fibers.size() && fibers[i].state == WAIT_WAVE) {
       fibers[i].state = RUNNABLE;
-      runq.push_back((int)i);
+      ids.push_back((int)i);
     }
   }
+  push_batch(ids);
 }
 static void release_block() {
   block_arrived = 0;
+  std::vector<int> ids;
   for (auto& f : fibers)
     if (f.state == WAIT_BLOCK) {
       f.state = RUNNABLE;
-      runq.push_back(f.lin);
+      ids.push_back(f.lin);
     }
+  push_batch(ids);
 }
 
 void wave_sync() {
@@ -164,7 +182,11 @@ static bool run_block(unsigned nthreads) {
     s[7] = nullptr;
     f.sp = (void*)s;
     waves[f.wave].live++;
-    runq.push_back((int)i);
+  }
+  {
+    std::vector<int> ids(nthreads);
+    for (unsigned i = 0; i < nthreads; ++i) ids[i] = (int)i;
+    push_batch(ids);
   }
   while (true) {
     if (rq_head == runq.size()) break;
@@ -205,3 +227,9 @@ void launch(dim3 grid, dim3 block, size_t shmem, BodyFn fn, void* ctx) {
 }
 
 }  // namespace simt
+
+// test control: order in which runnable fibers are resumed (0 ascending, 1 descending, 2 pseudo-random with `seed`)
+extern "C" void simt_set_schedule(int mode, unsigned long seed) {
+  simt::sched_mode = mode;
+  simt::sched_state = 0x9E3779B97F4A7C15ull ^ ((uint64_t)seed * 0xD1B54A32D192ED03ull + 1);
+}

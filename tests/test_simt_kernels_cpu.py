@@ -63,6 +63,56 @@ def test_emulation_library_exports_the_whole_c_abi():
     assert ops._LIB is None or ops._LIB is not lib
 
 
+def test_emulation_unit_kernels():
+    """The emulation's own semantics: one MFMA against a plain matmul in the documented fragment layout, shuffles / ballot, a
+    deliberate LDS race that the schedule permutations expose (and the barrier-ed version they do not), a divergent barrier that
+    is reported as a failed launch instead of hanging."""
+    import ctypes
+    import simt
+    lib = simt.library()
+    vp = ctypes.c_void_p
+    g = torch.Generator().manual_seed(0)
+    A, Bt = torch.randn(16, 32, generator=g).half(), torch.randn(16, 32, generator=g).half()
+    C = torch.zeros(16, 16)
+    assert lib.simt_selftest_mfma(vp(A.data_ptr()), vp(Bt.data_ptr()), vp(C.data_ptr())) == 0
+    assert torch.allclose(C, A.float() @ Bt.float().t(), atol=1e-5)
+    x, y, m = torch.randn(64, generator=g), torch.zeros(64), torch.zeros(1, dtype=torch.int64)
+    assert lib.simt_selftest_shfl(vp(x.data_ptr()), vp(y.data_ptr()), vp(m.data_ptr())) == 0
+    idx = torch.arange(64)
+    assert torch.equal(y, x[idx ^ 1] + x[(idx + 5) & 63])
+    assert int(m) & (2 ** 64 - 1) == sum(1 << i for i in range(64) if x[i] > 0) or int(m) == sum(1 << i for i in range(64) if x[i] > 0) - 2 ** 64
+    seen = {}
+    for barrier in (1, 0):
+        outs = set()
+        for mode, seed in (("ascending", 0), ("descending", 0), ("random", 1), ("random", 2)):
+            simt.set_schedule(mode, seed)
+            o = torch.full((64,), -7, dtype=torch.int32)
+            assert lib.simt_selftest_race(vp(o.data_ptr()), barrier) == 0
+            outs.add(tuple(o.tolist()))
+        seen[barrier] = outs
+    simt.set_schedule("ascending")
+    assert seen[1] == {tuple(range(64))}                       # race-free: one answer under every schedule
+    assert len(seen[0]) > 1                                    # missing barrier: the schedules disagree
+    o = torch.zeros(64, dtype=torch.int32)
+    assert lib.simt_selftest_deadlock(vp(o.data_ptr())) != 0   # hipErrorLaunchFailure instead of a hang
+
+
+@pytest.mark.parametrize("schedule,names", [
+    (("descending", 0), ("check_attention_strided", "check_window_attention", "check_gcp_block", "check_layernorm", "check_swin_mlp",
+                         "check_nms", "check_post_golden", "check_msdeform_attn")),
+    (("random", 1), ("check_dcn", "check_vlfuse_kernels", "check_conv3x3"))])
+def test_kernels_are_insensitive_to_the_wave_schedule(kernels, schedule, names):
+    """Race check of the shipped kernels: the same parity checks with the fibers resumed in descending / pseudo-random order
+    (a consumer wave then runs before its producer unless a barrier orders them).  MQ_SIMT_FULL=1: every check under both."""
+    import simt
+    simt.set_schedule(*schedule)
+    try:
+        for name in names:
+            _assert_ok(getattr(kernels, name)(CPU))
+    finally:
+        simt.set_schedule("ascending")
+
+
 @pytest.mark.parametrize("cfg", [
     dict(B=2, H=12, D=64, Nq=256, Nk=256, mask=True),
     dict(B=2, H=12, D=64, Nq=256, Nk=256, mask=True, clamp=50000.0, big=True),
