@@ -45,6 +45,16 @@ int mq_attn_fwd(const void* q, const void* k, const void* vt, void* o, const flo
                 long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long vt_bs, long vt_rs, long vt_hs,
                 long o_bs, long o_rs, long bias_bs, long bias_hs, float scale, float clamp, int nsplit, void* stream);
 
+/* The same operator for SHORT key sequences (Nk <= 256: every attention over the text tokens): all keys of a (batch, head) resident
+ * in LDS, S^T = K Q^T so that P stays in registers, exact two-pass softmax (csrc/attn_resident.hip).  Arguments as mq_attn_fwd
+ * without the key split; additionally o_rs % 4 == 0 and, with a qk_mask, Nk % 4 == 0, mask strides % 4 == 0 and a 4-byte aligned
+ * mask base (the mask is read one 32-bit word = 4 keys at a time; -3 otherwise).  Returns -1 for Nk > 256 or D not in {32, 64}.  Opt-in from the host
+ * (MQ_ATTN_RESIDENT=1, mq_det_amd/ops.py): written after the round's GPU budget was spent -- checked through tests/simt only so far. */
+int mq_attn_resident_fwd(const void* q, const void* k, const void* vt, void* o, const float* key_bias, const int* kv_len,
+                         const unsigned char* qk_mask, long mask_bs, long mask_hs, long mask_rs, int B, int H, int Nq, int Nk, int D,
+                         long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long vt_bs, long vt_rs, long vt_hs,
+                         long o_bs, long o_rs, long bias_bs, long bias_hs, float scale, float clamp, void* stream);
+
 /* Swin (shifted-)window attention with pad / roll / window partition folded into addressing.
  *   qkv [B,H,W,3C] fp16, qkv_bias [3C] fp16 (pad tokens), rel_bias [heads,NP,NP] fp32 (rows = query, cols = key,
  *   zero-padded from N = ws*ws to NP = 64 when N <= 64 -- window 7 -- or 160 when N <= 160 -- Swin-L, window 12),
@@ -261,6 +271,7 @@ int mq_ml_nms(const float* boxes, const int* labels, const int* nvalid, void* wo
 #define MQ_BF16_TWIN(name) extern __typeof__(name) name##_bf16;
 #endif
 MQ_BF16_TWIN(mq_attn_fwd)
+MQ_BF16_TWIN(mq_attn_resident_fwd)
 MQ_BF16_TWIN(mq_window_attn_fwd)
 MQ_BF16_TWIN(mq_gcp_sparse_attn_fwd)
 MQ_BF16_TWIN(mq_gcp_gate_residual_fwd)

@@ -17,6 +17,7 @@ _SIGNATURES = {
     "mq_abi_version": (_i, []),
     "mq_attn_workspace_bytes": (_l, [_i, _i, _i, _i, _i]),
     "mq_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _vp, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _i, _vp]),
+    "mq_attn_resident_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _vp]),
     "mq_window_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_gcp_sparse_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_gcp_gate_residual_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _l, _i, _i, _vp]),
@@ -45,7 +46,7 @@ _SIGNATURES = {
     "mq_ml_nms": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
 }
 # entry points with 16-bit operands also exist as <name>_bf16 (same signature; include/mqdet_hip.h MQ_BF16_TWIN)
-BF16_TWINS = ("mq_attn_fwd", "mq_window_attn_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
+BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_window_attn_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
               "mq_layernorm_fwd", "mq_swin_mlp_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
               "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyrelu_apply",
               "mq_align_scores_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
@@ -179,6 +180,17 @@ def attention4(q4, k4, vt4, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=N
         assert qk_mask.dtype == torch.uint8 and qk_mask.shape == (B, H, Nq, Nk) and qk_mask.stride(3) == 1
         mask_bs, mask_hs, mask_rs = qk_mask.stride(0), qk_mask.stride(1), qk_mask.stride(2)
     o = torch.empty(B, Nq, H * D, dtype=q4.dtype, device=q4.device)
+    mask_ok = qk_mask is None or (Nk % 4 == 0 and mask_bs % 4 == 0 and mask_hs % 4 == 0 and mask_rs % 4 == 0 and qk_mask.data_ptr() % 4 == 0)
+    if nsplit <= 1 and Nk <= 256 and D in (32, 64) and mask_ok and o.stride(1) % 4 == 0 and os.environ.get("MQ_ATTN_RESIDENT", "0") == "1":
+        # text-sized attention on the resident-key kernel (csrc/attn_resident.hip); off by default until it is measured on the device
+        with _timed(f"attn_res_d{D}_nq{Nq}_nk{Nk}"):
+            rc = _fn(lib, "mq_attn_resident_fwd", q4)(
+                _ptr(q4), _ptr(k4), _ptr(vt4), _ptr(o), _ptr(key_bias), _ptr(kv_len), _ptr(qk_mask), mask_bs, mask_hs, mask_rs,
+                B, H, Nq, Nk, D, q4.stride(0), q4.stride(1), q4.stride(2), k4.stride(0), k4.stride(1), k4.stride(2),
+                vt4.stride(0), vt4.stride(2), vt4.stride(1), o.stride(0), o.stride(1), bias_bs, bias_hs,
+                float(scale if scale is not None else 1.0 / math.sqrt(D)), float(clamp), _stream())
+        _chk(rc, "mq_attn_resident_fwd")
+        return o
     ws = None
     if nsplit > 1:
         ws = torch.empty(lib.mq_attn_workspace_bytes(B, H, Nq, D, nsplit) // 4, dtype=torch.float32, device=q4.device)

@@ -45,6 +45,8 @@ const uint3_& tid();
 int lane();
 void* dyn_smem();
 void wave_sync();                                    // all live lanes of the wave
+void wave_sync_then(void (*fn)(void*), void* ctx);   // the same; the LAST lane to arrive runs fn(ctx) before anybody continues
+float* wave_tile(int buf);                           // [256] fp32 result buffer of the current wave (per exchange buffer)
 void block_sync();                                   // all live threads of the workgroup
 uint64_t* xslot(int lane, int buf);                  // exchange slots of the current wave: [2][64][4] x 8 bytes
 int next_buf();                                      // alternating buffer index per collective
@@ -126,25 +128,43 @@ typedef __fp16 simt_fp16x4 __attribute__((__vector_size__(8)));
 typedef short simt_short4 __attribute__((__vector_size__(8)));
 
 // v_mfma_f32_16x16x32_{f16,bf16}: A lane l = A[l & 15][8 (l >> 4) ..], B lane l = B[8 (l >> 4) ..][l & 15], D lane l = D[4 (l >> 4) + r][l & 15]
+// The last lane to arrive multiplies the whole tile once (plain loops over the deposited fragments) into the wave's result buffer;
+// every lane then picks up its four values.
+template <class V8>
+inline void simt_mfma_tile(void* ctx) {
+  const int buf = (int)(intptr_t)ctx;
+  float A[16][32], B[32][16];
+  for (int l = 0; l < 64; ++l) {
+    V8 a, b;
+    const uint64_t* s = simt::xslot(l, buf);
+    memcpy(&a, s, 16);
+    memcpy(&b, s + 2, 16);
+    for (int j = 0; j < 8; ++j) {
+      A[l & 15][8 * (l >> 4) + j] = (float)a[j];
+      B[8 * (l >> 4) + j][l & 15] = (float)b[j];
+    }
+  }
+  float* D = simt::wave_tile(buf);
+  for (int i = 0; i < 16; ++i) {
+    float acc[16];
+    for (int n = 0; n < 16; ++n) acc[n] = 0.f;
+    for (int k = 0; k < 32; ++k) {
+      const float a = A[i][k];
+      for (int n = 0; n < 16; ++n) acc[n] += a * B[k][n];
+    }
+    for (int n = 0; n < 16; ++n) D[i * 16 + n] = acc[n];
+  }
+}
 template <class V8>
 inline simt_float4 simt_mfma_16x16x32(V8 a, V8 b, simt_float4 c) {
   const int buf = simt::next_buf(), l = simt::lane();
   uint64_t* s = simt::xslot(l, buf);
   memcpy(s, &a, 16);
   memcpy(s + 2, &b, 16);
-  simt::wave_sync();
+  simt::wave_sync_then(&simt_mfma_tile<V8>, (void*)(intptr_t)buf);
+  const float* D = simt::wave_tile(buf);
   const int col = l & 15, r0 = 4 * (l >> 4);
-  V8 bk[4];
-  for (int g = 0; g < 4; ++g) memcpy(&bk[g], simt::xslot(col + 16 * g, buf) + 2, 16);
-  for (int r = 0; r < 4; ++r) {
-    float acc = c[r];
-    for (int g = 0; g < 4; ++g) {
-      V8 ak;
-      memcpy(&ak, simt::xslot(r0 + r + 16 * g, buf), 16);
-      for (int j = 0; j < 8; ++j) acc += (float)ak[j] * (float)bk[g][j];
-    }
-    c[r] = acc;
-  }
+  for (int r = 0; r < 4; ++r) c[r] += D[(r0 + r) * 16 + col];
   return c;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) simt_mfma_16x16x32<simt_half8>((a), (b), (c))
@@ -171,5 +191,8 @@ inline simt_fp16x4 simt_ds_read_tr16(uintptr_t addr) {
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
+inline float simt_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
+#define __builtin_amdgcn_fmed3f(a, b, c) simt_fmed3f((a), (b), (c))
 #define __builtin_amdgcn_s_barrier() simt::block_sync()
 #define SIMT_ASM(...) ((void)0)

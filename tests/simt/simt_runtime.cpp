@@ -40,7 +40,10 @@ enum State { RUNNABLE, WAIT_WAVE, WAIT_BLOCK, DONE };
 
 struct Wave {
   int live, arrived;
+  void (*then_fn)(void*);
+  void* then_ctx;
   uint64_t x[2][64][4];
+  float tile[2][256];
 };
 
 struct Fiber {
@@ -115,10 +118,34 @@ static void release_block() {
   push_batch(ids);
 }
 
+float* wave_tile(int buf) { return waves[cur->wave].tile[buf]; }
+
+static void complete_wave(int w) {                       // every live lane has arrived
+  Wave& wv = waves[w];
+  if (wv.then_fn) {
+    void (*fn)(void*) = wv.then_fn;
+    wv.then_fn = nullptr;
+    fn(wv.then_ctx);
+  }
+  release_wave(w);
+}
+
+void wave_sync_then(void (*fn)(void*), void* ctx) {
+  Wave& wv = waves[cur->wave];
+  wv.then_fn = fn;
+  wv.then_ctx = ctx;
+  if (++wv.arrived == wv.live) {
+    complete_wave(cur->wave);
+    return;
+  }
+  cur->state = WAIT_WAVE;
+  yield_to_scheduler();
+}
+
 void wave_sync() {
   Wave& wv = waves[cur->wave];
   if (++wv.arrived == wv.live) {
-    release_wave(cur->wave);
+    complete_wave(cur->wave);
     return;
   }
   cur->state = WAIT_WAVE;
@@ -141,7 +168,11 @@ static void fiber_main() {
   Wave& wv = waves[f->wave];
   --wv.live;
   --block_live;
-  if (wv.live > 0 && wv.arrived == wv.live) release_wave(f->wave);
+  if (wv.live > 0 && wv.arrived == wv.live) {
+    Fiber* self = cur;                                  // the completion callback addresses the wave through `cur`
+    complete_wave(f->wave);
+    cur = self;
+  }
   if (block_live > 0 && block_arrived == block_live) release_block();
   yield_to_scheduler();
   abort();                                           // a finished fiber is never resumed

@@ -353,3 +353,22 @@ def test_bf16_groundingdino(dev, bf16):
     import gdino_checks as gc
     _assert(gc.check_msdeform_attn_q(dev))
     _assert(gc.check_gdino_model(dev, vq=True))
+
+
+# ------------------------------------------------------------------------------------------------ resident-key attention (opt-in)
+def test_resident_attention_kernel(dev, monkeypatch):
+    """csrc/attn_resident.hip (MQ_ATTN_RESIDENT=1: text-sized attentions with all keys in LDS, S^T formulation) -- written after the
+    round-2 GPU budget was spent and checked through tests/simt only; this is its first run on the device."""
+    import parity_checks as pc
+    import gdino_checks as gc
+    monkeypatch.setenv("MQ_ATTN_RESIDENT", "1")
+    for cfg in (dict(B=2, H=12, D=64, Nq=256, Nk=256, mask=True), dict(B=2, H=12, D=64, Nq=256, Nk=256, mask=True, clamp=50000.0, big=True),
+                dict(B=1, H=8, D=32, Nq=37, Nk=61), dict(B=2, H=8, D=32, Nq=1, Nk=9), dict(B=3, H=2, D=64, Nq=130, Nk=141, mask=True, kvlen=True),
+                dict(B=64, H=12, D=64, Nq=256, Nk=256, mask=True, kvlen=True), dict(B=1, H=4, D=32, Nq=900, Nk=200)):
+        _assert(pc.check_attention(dev, **cfg))
+    _assert(pc.check_attention_strided(dev))
+    _assert(gc.check_attention_qk_mask(dev))
+    _assert(pc.check_bert_layer(dev, True))
+    pc._CACHE.clear()
+    _assert(pc.check_full_model(dev))
+    pc._CACHE.clear()

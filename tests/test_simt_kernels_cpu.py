@@ -156,9 +156,11 @@ def _no_graph_rows(results):
     return [r for r in results if "HIP-graph" not in r["name"]]
 
 
-@pytest.mark.skipif(os.environ.get("MQ_SIMT_FULL", "0") != "1", reason="minutes on the emulator: MQ_SIMT_FULL=1")
-@pytest.mark.parametrize("name", ["check_extract_query", "check_vlfuse_heads_mask", "check_gdino_tiny", "large"])
-def test_slow_blocks(kernels, name):
+@pytest.mark.parametrize("name", ["check_extract_query", "check_gdino_tiny", "large",
+                                  pytest.param("check_vlfuse_heads_mask", marks=pytest.mark.skipif(
+                                      os.environ.get("MQ_SIMT_FULL", "0") != "1", reason="a minute on the emulator: MQ_SIMT_FULL=1"))])
+def test_model_blocks(kernels, name):
+    """vision-query extraction (ROIAlign + poolers), the tiny MQ-GroundingDINO model stage by stage, Swin-L (window 12) blocks"""
     import gdino_checks as gc
     if name == "large":
         _assert_ok(kernels.check_window_attention(CPU, large=True) + kernels.check_swin_fpn(CPU, large=True))
@@ -194,3 +196,66 @@ def test_mixed_16bit_operands_are_rejected(kernels):
     q = torch.zeros(1, 8, 64, dtype=torch.float16)
     with pytest.raises(TypeError, match="fp16 and bf16"):
         ops._fn(ops._LIB, "mq_attn_fwd", q, q.to(torch.bfloat16))
+
+
+# ---- the resident-key attention kernel for text-sized key sequences (csrc/attn_resident.hip, opt-in: MQ_ATTN_RESIDENT=1)
+@pytest.fixture()
+def resident(kernels, monkeypatch):
+    monkeypatch.setenv("MQ_ATTN_RESIDENT", "1")
+    from mq_det_amd import ops
+    calls = []
+    orig = ops._fn
+
+    def spy(lib, name, *ts):
+        calls.append(name)
+        return orig(lib, name, *ts)
+    monkeypatch.setattr(ops, "_fn", spy)
+    yield kernels, calls
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, H=12, D=64, Nq=256, Nk=256, mask=True),
+    dict(B=2, H=12, D=64, Nq=256, Nk=256, mask=True, clamp=50000.0, big=True),
+    dict(B=1, H=8, D=32, Nq=37, Nk=61),
+    dict(B=2, H=8, D=32, Nq=1, Nk=9),
+    dict(B=3, H=2, D=64, Nq=130, Nk=141, mask=True, kvlen=True),
+    dict(B=1, H=4, D=32, Nq=900, Nk=200),
+])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_resident_attention_kernel(resident, cfg, dtype):
+    pc, calls = resident
+    pc.use_dtype(dtype)
+    try:
+        _assert_ok(pc.check_attention(CPU, **cfg))
+    finally:
+        pc.use_dtype(torch.float16)
+    assert "mq_attn_resident_fwd" in calls and "mq_attn_fwd" not in calls
+
+
+def test_resident_attention_masks_views_and_schedules(resident):
+    import gdino_checks as gc
+    import simt
+    pc, calls = resident
+    _assert_ok(pc.check_attention_strided(CPU))
+    _assert_ok(gc.check_attention_qk_mask(CPU))            # byte masks (shared / per head), T = 100, strided K / V^T slices, kv_len
+    assert calls.count("mq_attn_resident_fwd") >= 5
+    for mode in (("descending", 0), ("random", 3)):
+        simt.set_schedule(*mode)
+        try:
+            _assert_ok(pc.check_attention(CPU, B=2, H=3, D=64, Nq=200, Nk=256, mask=True, kvlen=True))
+            _assert_ok(pc.check_bert_layer(CPU, True))
+        finally:
+            simt.set_schedule("ascending")
+    # long key sequences and key splits stay on the streaming kernel
+    del calls[:]
+    _assert_ok(pc.check_attention(CPU, B=1, H=8, D=32, Nq=64, Nk=1333, nsplit=4))
+    assert "mq_attn_fwd" in calls and "mq_attn_resident_fwd" not in calls
+
+
+def test_resident_attention_full_model(resident):
+    """every text-sized attention of the tiny MQ-GLIP-T forward (BERT layers, VLDyHead BERT copies with the clamp) on the resident
+    kernel: the smoke() check end to end"""
+    pc, calls = resident
+    pc._CACHE.clear()
+    _assert_ok(pc.check_full_model(CPU))
+    assert calls.count("mq_attn_resident_fwd") >= 4

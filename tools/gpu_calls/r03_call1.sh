@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round 3, GPU call 1 (prepared at the end of round 2, when no GPU minutes were left): first run ON THE DEVICE of everything that was
+# only checked through tests/simt -- the bf16 builds of all kernels, SCORE_AGG modes, the resident-key attention kernel -- then the A/Bs.
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+rm -rf gpurun_out/*; mkdir -p gpurun_out
+export TMPDIR=/tmp
+# 1. the whole GPU suite (new this call: test_bf16_*, check_score_agg, test_resident_attention_kernel)
+timeout 600 python -m pytest tests -q -m gpu > gpurun_out/r03_pytest1.log 2>&1; tail -6 gpurun_out/r03_pytest1.log | cut -c1-300
+# 2. headline bench, then the same with the text-sized attentions on the resident-key kernel (lang_path_b64 carries the north-star number)
+timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r03_bench1_default.log 2>&1; tail -1 gpurun_out/r03_bench1_default.log | cut -c1-200
+MQ_ATTN_RESIDENT=1 timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r03_bench1_resident.log 2>&1; tail -1 gpurun_out/r03_bench1_resident.log | cut -c1-200
+for f in default resident; do python - <<PY
+import json
+d = json.loads(open("gpurun_out/r03_bench1_$f.log").read().strip().splitlines()[-1])
+lp = d.get("lang_path_b64", {})
+print("$f", d["value"], {k: lp.get(k) for k in ("ms_language_path", "attention_kernels_ms", "attention_mfma_utilisation")}, lp.get("kernels_ms"))
+PY
+done
+# 3. BASELINE configs[3]: MQ-GLIP-L on bf16 MFMA (default of the workload) next to fp16
+timeout 200 python bench.py --workload mq-glip-l --steps 10 --warmup 3 > gpurun_out/r03_bench1_glipl_bf16.log 2>&1; tail -1 gpurun_out/r03_bench1_glipl_bf16.log | cut -c1-200
+timeout 200 python bench.py --workload mq-glip-l --dtype f16 --steps 10 --warmup 3 > gpurun_out/r03_bench1_glipl_f16.log 2>&1; tail -1 gpurun_out/r03_bench1_glipl_f16.log | cut -c1-200
+# 4. MQ-GroundingDINO with the resident kernel (text enhancer 4 x 64, decoder text cross-attention 8 x 32)
+MQ_ATTN_RESIDENT=1 timeout 200 python bench.py --workload mq-gdino-t --steps 10 --warmup 3 > gpurun_out/r03_bench1_gdino_resident.log 2>&1; tail -1 gpurun_out/r03_bench1_gdino_resident.log | cut -c1-200
