@@ -191,6 +191,8 @@ def check_gdino_model(dev, vq=True, B=1, hw=((120, 150),), spec=None, n_classes=
     from mq_det_amd.utils.tokenizer import positive_map_from_spans
     spec = replace(spec or tiny_gdino_spec(), vision_query=vq)
     sd, cfg, model = gdino_model(dev, replace(spec, vision_query=True))
+    if vq and not cfg.VISION_QUERY.ENABLED:
+        model._plan = None              # a plan packed while the switch was off has no GCP / pre-select tensors: pack again
     cfg.VISION_QUERY.ENABLED = vq
     # measured on MI355X (GPU call 7, profiles/r02_gdino_parity.txt), normalised max error, full depth at 800 x 1333: input
     # projections 1.9e-3, BERT 3.6e-3, encoder memory 2.7e-3, encoder text 3.8e-3, decoder output 2.8e-3, boxes 5e-4, token

@@ -39,12 +39,17 @@ def kernels():
     saved = (detector.GeneralizedVLRCNN_New.prepare, gdino.GroundingDINO.prepare, pc.QUICK, pc.PINS, dict(pc._CACHE))
     detector.GeneralizedVLRCNN_New.prepare, gdino.GroundingDINO.prepare = prepare, prepare_gdino
     pc.QUICK, pc.PINS = os.environ.get("MQ_SIMT_FULL", "0") != "1", False
+    import gdino_checks as gc
+    saved_gc = dict(gc._CACHE)
     pc._CACHE.clear()
+    gc._CACHE.clear()                  # models cached by other test modules carry plans built by THEIR prepare() stand-ins
     with simt.installed():
         yield pc
     detector.GeneralizedVLRCNN_New.prepare, gdino.GroundingDINO.prepare, pc.QUICK, pc.PINS = saved[:4]
     pc._CACHE.clear()
     pc._CACHE.update(saved[4])
+    gc._CACHE.clear()
+    gc._CACHE.update(saved_gc)
 
 
 def _assert_ok(results):
