@@ -412,7 +412,7 @@ def lang_path_b64(model, cfg, dev, chunks, iters=5):
     fl_bert = 12 * 4.0 * Bn * 12 * 256 * nk_vis * 64
     fl_pre = 2 * 4.0 * Bn * 8 * V * 5577 * 32
     fl_gcp = 6 * 4.0 * Bn * 8 * 256 * S * 64
-    att_ms = sum(v[1] for k, v in kern.items() if k.startswith(("attn_d", "attn_res_d", "gcp_sparse"))) / iters
+    att_ms = sum(v[1] for k, v in kern.items() if k.startswith(("attn_d", "attn_res_d", "attn_chk_d", "gcp_sparse"))) / iters
     att_tf = (fl_bert + fl_pre + fl_gcp) / (att_ms * 1e-3) / 1e12
     # whole language path: SURVEY.md 8(d) per image BERT 45.9 + pre-select 7.5 + GCP 29.9 GF
     path_tf = Bn * (45.9 + 7.5 + 29.9) * 1e9 / (ms_path * 1e-3) / 1e12

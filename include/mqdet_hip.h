@@ -55,6 +55,15 @@ int mq_attn_resident_fwd(const void* q, const void* k, const void* vt, void* o, 
                          long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long vt_bs, long vt_rs, long vt_hs,
                          long o_bs, long o_rs, long bias_bs, long bias_hs, float scale, float clamp, void* stream);
 
+/* ... and for LONG key sequences without a per-(query, key) mask (GCP pre-select, MQ-GroundingDINO decoder self-attention): the
+ * same S^T formulation over chunks of 256 keys with a running (max, sum, O) rescaled once per chunk, register prefetch of the next
+ * chunk, one barrier per chunk; key split like mq_attn_fwd (same workspace size, mq_attn_workspace_bytes).  Arguments as mq_attn_fwd
+ * without the qk_mask; o_rs % 4 == 0.  Opt-in together with mq_attn_resident_fwd (MQ_ATTN_RESIDENT=1). */
+int mq_attn_chunked_fwd(const void* q, const void* k, const void* vt, void* o, const float* key_bias, const int* kv_len,
+                        void* workspace, int B, int H, int Nq, int Nk, int D,
+                        long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long vt_bs, long vt_rs, long vt_hs,
+                        long o_bs, long o_rs, long bias_bs, long bias_hs, float scale, float clamp, int nsplit, void* stream);
+
 /* Swin (shifted-)window attention with pad / roll / window partition folded into addressing.
  *   qkv [B,H,W,3C] fp16, qkv_bias [3C] fp16 (pad tokens), rel_bias [heads,NP,NP] fp32 (rows = query, cols = key,
  *   zero-padded from N = ws*ws to NP = 64 when N <= 64 -- window 7 -- or 160 when N <= 160 -- Swin-L, window 12),
@@ -272,6 +281,7 @@ int mq_ml_nms(const float* boxes, const int* labels, const int* nvalid, void* wo
 #endif
 MQ_BF16_TWIN(mq_attn_fwd)
 MQ_BF16_TWIN(mq_attn_resident_fwd)
+MQ_BF16_TWIN(mq_attn_chunked_fwd)
 MQ_BF16_TWIN(mq_window_attn_fwd)
 MQ_BF16_TWIN(mq_gcp_sparse_attn_fwd)
 MQ_BF16_TWIN(mq_gcp_gate_residual_fwd)

@@ -18,6 +18,7 @@ _SIGNATURES = {
     "mq_attn_workspace_bytes": (_l, [_i, _i, _i, _i, _i]),
     "mq_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _vp, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _i, _vp]),
     "mq_attn_resident_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _vp]),
+    "mq_attn_chunked_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _i, _vp]),
     "mq_window_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_gcp_sparse_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_gcp_gate_residual_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _l, _i, _i, _vp]),
@@ -46,7 +47,7 @@ _SIGNATURES = {
     "mq_ml_nms": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
 }
 # entry points with 16-bit operands also exist as <name>_bf16 (same signature; include/mqdet_hip.h MQ_BF16_TWIN)
-BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_window_attn_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
+BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
               "mq_layernorm_fwd", "mq_swin_mlp_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
               "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyrelu_apply",
               "mq_align_scores_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
@@ -194,6 +195,16 @@ def attention4(q4, k4, vt4, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=N
     ws = None
     if nsplit > 1:
         ws = torch.empty(lib.mq_attn_workspace_bytes(B, H, Nq, D, nsplit) // 4, dtype=torch.float32, device=q4.device)
+    if qk_mask is None and D in (32, 64) and o.stride(1) % 4 == 0 and os.environ.get("MQ_ATTN_RESIDENT", "0") == "1":
+        # long key sequences / key splits on the chunked S^T kernel (csrc/attn_resident.hip); opt-in, see above
+        with _timed(f"attn_chk_d{D}_nq{Nq}_nk{Nk}_s{nsplit}"):
+            rc = _fn(lib, "mq_attn_chunked_fwd", q4)(
+                _ptr(q4), _ptr(k4), _ptr(vt4), _ptr(o), _ptr(key_bias), _ptr(kv_len), _ptr(ws), B, H, Nq, Nk, D,
+                q4.stride(0), q4.stride(1), q4.stride(2), k4.stride(0), k4.stride(1), k4.stride(2),
+                vt4.stride(0), vt4.stride(2), vt4.stride(1), o.stride(0), o.stride(1), bias_bs, bias_hs,
+                float(scale if scale is not None else 1.0 / math.sqrt(D)), float(clamp), int(nsplit), _stream())
+        _chk(rc, "mq_attn_chunked_fwd")
+        return o
     with _timed(f"attn_d{D}_nq{Nq}_nk{Nk}_s{nsplit}"):
         rc = _fn(lib, "mq_attn_fwd", q4)(_ptr(q4), _ptr(k4), _ptr(vt4), _ptr(o), _ptr(key_bias), _ptr(kv_len), _ptr(qk_mask), mask_bs, mask_hs,
                              mask_rs, _ptr(ws), B, H, Nq, Nk, D,

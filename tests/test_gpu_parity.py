@@ -336,8 +336,9 @@ def test_score_aggregation_modes(dev):
 
 # ------------------------------------------------------------------------------------------------ resident-key attention (opt-in)
 def test_resident_attention_kernel(dev, monkeypatch):
-    """csrc/attn_resident.hip (MQ_ATTN_RESIDENT=1: text-sized attentions with all keys in LDS, S^T formulation) -- written after the
-    round-2 GPU budget was spent and checked through tests/simt only; this is its first run on the device."""
+    """csrc/attn_resident.hip (MQ_ATTN_RESIDENT=1: S^T formulation; text-sized attentions with all keys resident in LDS, long key
+    sequences in chunks of 256) -- written after the round-2 GPU budget was spent and checked through tests/simt only; this is its
+    first run on the device."""
     import parity_checks as pc
     import gdino_checks as gc
     monkeypatch.setenv("MQ_ATTN_RESIDENT", "1")
@@ -348,6 +349,12 @@ def test_resident_attention_kernel(dev, monkeypatch):
     _assert(pc.check_attention_strided(dev))
     _assert(gc.check_attention_qk_mask(dev))
     _assert(pc.check_bert_layer(dev, True))
+    # long key sequences: the chunked kernel (GCP pre-select shape with and without key split, decoder self-attention, ragged tails)
+    for cfg in (dict(B=1, H=8, D=32, Nq=200, Nk=5577, nsplit=4), dict(B=8, H=8, D=32, Nq=200, Nk=5577), dict(B=2, H=8, D=32, Nq=70, Nk=700, mask=True, nsplit=2),
+                dict(B=2, H=2, D=64, Nq=130, Nk=600, mask=True, kvlen=True, clamp=50000.0, big=True), dict(B=1, H=8, D=32, Nq=900, Nk=900),
+                dict(B=1, H=2, D=32, Nq=37, Nk=257, nsplit=2), dict(B=1, H=2, D=32, Nq=37, Nk=100, nsplit=3)):
+        _assert(pc.check_attention(dev, **cfg))
+    _assert(pc.check_pre_select(dev))
     pc._CACHE.clear()
     _assert(pc.check_full_model(dev))
     pc._CACHE.clear()

@@ -251,10 +251,43 @@ def test_resident_attention_masks_views_and_schedules(resident):
             _assert_ok(pc.check_bert_layer(CPU, True))
         finally:
             simt.set_schedule("ascending")
-    # long key sequences and key splits stay on the streaming kernel
+    # long key sequences and key splits: the chunked S^T kernel; a per-(query, key) mask over a long sequence: mq_attn_fwd
     del calls[:]
     _assert_ok(pc.check_attention(CPU, B=1, H=8, D=32, Nq=64, Nk=1333, nsplit=4))
-    assert "mq_attn_fwd" in calls and "mq_attn_resident_fwd" not in calls
+    assert calls == ["mq_attn_chunked_fwd"]
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=1, H=8, D=32, Nq=200, Nk=5577, nsplit=4),                                   # the GCP pre-select shape, split over keys
+    dict(B=2, H=8, D=32, Nq=70, Nk=700, mask=True, nsplit=2),
+    dict(B=2, H=2, D=64, Nq=130, Nk=600, mask=True, kvlen=True, clamp=50000.0, big=True),
+    dict(B=1, H=8, D=32, Nq=900, Nk=900),                                              # MQ-GroundingDINO decoder self-attention
+    dict(B=1, H=2, D=32, Nq=37, Nk=257, nsplit=2),                                     # second chunk holds one key
+    dict(B=1, H=2, D=32, Nq=37, Nk=100, nsplit=3),                                     # splits without any chunk
+])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_chunked_attention_kernel(resident, cfg, dtype):
+    pc, calls = resident
+    pc.use_dtype(dtype)
+    try:
+        _assert_ok(pc.check_attention(CPU, **cfg))
+    finally:
+        pc.use_dtype(torch.float16)
+    assert calls == ["mq_attn_chunked_fwd"]
+
+
+def test_chunked_attention_pre_select_and_schedules(resident):
+    import simt
+    pc, calls = resident
+    _assert_ok(pc.check_pre_select(CPU))
+    assert "mq_attn_chunked_fwd" in calls
+    for mode in (("descending", 0), ("random", 5)):
+        simt.set_schedule(*mode)
+        try:
+            _assert_ok(pc.check_attention(CPU, B=1, H=4, D=32, Nq=200, Nk=1400, nsplit=2))     # 6 chunks: the LDS double buffer wraps twice
+            _assert_ok(pc.check_attention(CPU, B=1, H=2, D=64, Nq=100, Nk=800, mask=True))
+        finally:
+            simt.set_schedule("ascending")
 
 
 def test_resident_attention_full_model(resident):
