@@ -97,7 +97,7 @@ def build_model(dev, caches=False, n_classes=NUM_CLASSES_IN_CAPTION, n_categorie
 GFLOP_PER_IMAGE_GDINO = 1112.0     # Swin-T 198 + BERT 46 + GCP 37 + encoder 6 x 129 + two-stage 12 + decoder 6 x 7
 
 
-def build_gdino_model(dev, n_classes=NUM_CLASSES_IN_CAPTION):
+def build_gdino_model(dev, n_classes=NUM_CLASSES_IN_CAPTION, dtype="f16"):
     """BASELINE.json configs[4]: MQ-GroundingDINO-T (configs/pretrain/mq-groundingdino-t.yaml), seeded random weights."""
     from mq_det_amd.config import get_gdino_cfg
     from mq_det_amd.modeling.detector import build_detection_model
@@ -105,6 +105,7 @@ def build_gdino_model(dev, n_classes=NUM_CLASSES_IN_CAPTION):
     from mq_det_amd.utils.tokenizer import build_synthetic_tokenizer, synthetic_caption, positive_map_from_spans
     cfg = get_gdino_cfg()
     cfg.MODEL.BACKBONE_CACHE = False          # every step a full forward (the synthetic loop re-sends the same tensor)
+    cfg.MODEL.COMPUTE_DTYPE = "bfloat16" if dtype == "bf16" else "float16"
     cfg.GROUNDINGDINO.text_encoder_type = build_synthetic_tokenizer(tempfile.mkdtemp(prefix="mqdet_tok_"))
     model = build_detection_model(cfg)
     randomize_(model, seed=0)
@@ -122,7 +123,7 @@ def main_gdino(args, rank, world, dev):
     16 images 800 x 1333 per GPU; images shard across ranks, no data-path collective besides the gather of detections."""
     from mq_det_amd import ops, parallel
     from mq_det_amd.structures import ImageList
-    cfg, model, caption, pmap = build_gdino_model(dev)
+    cfg, model, caption, pmap = build_gdino_model(dev, dtype=args.dtype or "f16")
     if args.no_graph:
         model.use_hip_graph = False
     Bn = 16 if args.batch == B_PER_GPU else args.batch
@@ -172,7 +173,7 @@ def main_gdino(args, rank, world, dev):
         ips = world * Bn * args.steps / dt
         res = {"metric": "images/sec MQ-GroundingDINO-T 800×1333 5-shot vision queries", "value": round(ips, 3), "unit": "images/sec",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype or "f16", "data": "synthetic",
                "config": {"workload": "BASELINE.json configs[4]: MQ-GroundingDINO-T (Swin-T + BERT-base + GCP + 6 + 6 deformable "
                                       "transformer layers, 900 queries), 5 vision queries x 40 classes, every step a full forward",
                           "global_batch": world * Bn, "batch_per_gpu": Bn, "image": "800x1333 -> 800x1344", "parallelism": f"dp{world}",
