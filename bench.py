@@ -463,7 +463,7 @@ def _experimental_attention_worker():
     print(json.dumps(res), flush=True)
 
 
-def experimental_attention(timeout=300):
+def experimental_attention(timeout=180):
     import subprocess
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--experimental-attention-worker"], capture_output=True, text=True,
