@@ -493,6 +493,22 @@ def experimental_bf16_glip_l(timeout=200):
         return {"error": f"worker exceeded {timeout} s"}
 
 
+def experimental_e2e_resident(timeout=150):
+    """The headline workload once more with MQ_ATTN_RESIDENT=1 (10 timed steps in a subprocess): does the step get shorter when the text
+    chain's attentions do?  (The text chain runs beside the image chain)"""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--no-experimental", "--no-lang-b64",
+                            "--no-cpu-baseline"], env=dict(os.environ, MQ_ATTN_RESIDENT="1"), capture_output=True, text=True, timeout=timeout)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                d = json.loads(line)
+                return {k: d.get(k) for k in ("value", "unit", "ms_per_step", "steps", "hip_graph", "detections_img0")}
+        return {"error": (r.stderr or r.stdout)[-400:]}
+    except subprocess.TimeoutExpired:
+        return {"error": f"worker exceeded {timeout} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -660,6 +676,8 @@ def main():
                 res["lang_path_b64_resident"] = experimental_attention()
                 if time.perf_counter() - t_start < 240:       # keep the default run within a few minutes
                     res["mq_glip_l_bf16"] = experimental_bf16_glip_l()
+                if time.perf_counter() - t_start < 300:
+                    res["with_resident_attention"] = experimental_e2e_resident()
             if world == 1 and not args.no_cpu_baseline and not large:
                 try:
                     res["cpu_baseline"] = cpu_baseline()
