@@ -187,3 +187,14 @@ def test_score_agg_modes_through_the_boundary(setup, monkeypatch, agg, mdetr):
         assert (out[b].get_field("labels") == d["labels"][o]).float().mean() > 0.98       # near-ties may swap neighbours
     if agg == "ONEHOT":
         assert set(torch.cat([o.get_field("labels") for o in out]).tolist()) <= set(range(1, len(pm) + 1))
+    # chunk batching builds its own per-item token index: same detections as the per-call path
+    kv = int(am[0].sum())
+    model.tokenize = lambda caps, dev: (ids[:1].expand(len(caps), -1).contiguous(), am[:1].expand(len(caps), -1).contiguous(), kv)
+    with torch.no_grad():
+        chunked = model.forward_chunks(ImageList(images, sizes), [("caption a", pm), ("caption b", pm)])
+    assert len(chunked) == 2
+    for res in chunked:
+        for b in range(len(dets)):
+            assert len(res[b]) == len(out[b])
+            assert torch.allclose(res[b].get_field("scores"), out[b].get_field("scores"), atol=1e-5)
+            assert torch.equal(res[b].get_field("labels"), out[b].get_field("labels"))
