@@ -493,20 +493,21 @@ def experimental_bf16_glip_l(timeout=200):
         return {"error": f"worker exceeded {timeout} s"}
 
 
-def experimental_e2e_resident(timeout=150):
-    """The headline workload once more with MQ_ATTN_RESIDENT=1 (10 timed steps in a subprocess): does the step get shorter when the text
-    chain's attentions do?  (The text chain runs beside the image chain)"""
+def experimental_e2e(env, timeout=150):
+    """The headline workload once more (10 timed steps in a subprocess) with opt-in kernels switched on through `env`:
+    MQ_LN_VARIANT=2 (load-batched LayerNorm, bit-identical results) / MQ_ATTN_RESIDENT=1 (S^T attention kernels; the text chain runs
+    beside the image chain).  A/B against `value` of this line, same box, same process environment otherwise."""
     import subprocess
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--no-experimental", "--no-lang-b64",
-                            "--no-cpu-baseline"], env=dict(os.environ, MQ_ATTN_RESIDENT="1"), capture_output=True, text=True, timeout=timeout)
+                            "--no-cpu-baseline"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=timeout)
         for line in reversed(r.stdout.strip().splitlines()):
             if line.startswith("{"):
                 d = json.loads(line)
-                return {k: d.get(k) for k in ("value", "unit", "ms_per_step", "steps", "hip_graph", "detections_img0")}
-        return {"error": (r.stderr or r.stdout)[-400:]}
+                return {k: d.get(k) for k in ("value", "unit", "ms_per_step", "steps", "hip_graph", "detections_img0")} | {"env": env}
+        return {"error": (r.stderr or r.stdout)[-400:], "env": env}
     except subprocess.TimeoutExpired:
-        return {"error": f"worker exceeded {timeout} s"}
+        return {"error": f"worker exceeded {timeout} s", "env": env}
 
 
 def main():
@@ -671,13 +672,17 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     res["lang_path_b64"] = {"error": repr(e)[:300]}
             if world == 1 and not args.no_lang_b64 and not args.no_experimental and not large and args.dtype == "f16" and \
-                    os.environ.get("MQ_ATTN_RESIDENT", "0") != "1":
+                    os.environ.get("MQ_ATTN_RESIDENT", "0") != "1" and os.environ.get("MQ_LN_VARIANT", "1") != "2":
                 # first device numbers of the opt-in S^T attention kernels, isolated in a subprocess
                 res["lang_path_b64_resident"] = experimental_attention()
-                if time.perf_counter() - t_start < 240:       # keep the default run within a few minutes
+                # e2e A/B of the opt-in kernels, most likely gain first; each only while the whole run stays within a few minutes
+                ab = []
+                for env, limit in (({"MQ_LN_VARIANT": "2"}, 170), ({"MQ_ATTN_RESIDENT": "1"}, 150)):
+                    if time.perf_counter() - t_start < limit:
+                        ab.append(experimental_e2e(env))
+                res["opt_in_kernels_ab"] = ab
+                if time.perf_counter() - t_start < 140:
                     res["mq_glip_l_bf16"] = experimental_bf16_glip_l()
-                if time.perf_counter() - t_start < 300:
-                    res["with_resident_attention"] = experimental_e2e_resident()
             if world == 1 and not args.no_cpu_baseline and not large:
                 try:
                     res["cpu_baseline"] = cpu_baseline()

@@ -128,6 +128,13 @@ int mq_vlfuse_t2i_fwd(const void* kf, const void* v_ln, const int* kv_len, const
 int mq_layernorm_fwd(const void* x, int x_f32, const void* res, int res_f32, const void* gamma, const void* beta, void* y,
                      float* y32, void* xsum, long rows, int C, float eps, void* stream);
 
+/* The same operator, arguments and results (bit-identical: the summation order is kept) with a different load schedule: chunk count
+ * per lane fixed at compile time, gamma / beta in registers for the whole block, up to 4 rows per lane group in flight, every load of
+ * an iteration issued before the first is consumed (csrc/layernorm2.hip).  Opt-in from the host (MQ_LN_VARIANT=2): written after
+ * round 2's GPU budget was spent, checked bit for bit against mq_layernorm_fwd through tests/simt. */
+int mq_layernorm2_fwd(const void* x, int x_f32, const void* res, int res_f32, const void* gamma, const void* beta, void* y,
+                     float* y32, void* xsum, long rows, int C, float eps, void* stream);
+
 /* MLP half of a Swin block in one kernel (LayerNorm prologue, fc1, exact GELU, fc2, residual; the 4C-wide hidden activation
  * stays in registers), C in {96, 192, 384}:
  *   x' = x + delta;  out = x' + fc2(gelu(fc1(LN(x'; ln_g, ln_b, eps))));  y = LN(out; next_g, next_b, eps_next) (optional)
@@ -288,6 +295,7 @@ MQ_BF16_TWIN(mq_gcp_gate_residual_fwd)
 MQ_BF16_TWIN(mq_vlfuse_i2t_fwd)
 MQ_BF16_TWIN(mq_vlfuse_t2i_fwd)
 MQ_BF16_TWIN(mq_layernorm_fwd)
+MQ_BF16_TWIN(mq_layernorm2_fwd)
 MQ_BF16_TWIN(mq_swin_mlp_fwd)
 MQ_BF16_TWIN(mq_conv3x3_fwd)
 MQ_BF16_TWIN(mq_conv3x3_nchw32_fwd)

@@ -1,0 +1,179 @@
+// mq_layernorm2_fwd: the same operator as mq_layernorm_fwd (layernorm.hip: row LayerNorm with the residual add fused in, fp16 / fp32
+// streams), same arguments, bit-identical results (the summation order is kept) -- a different load schedule.
+//
+// tools/isa_wait_scan.py on layernorm.hip: 4 - 12 of the 16 - 36 global loads of a row iteration are followed by `s_waitcnt vmcnt(0)`
+// at once.  The chunk loop there always spans 4 (6) chunks with `ch < nch` guards although C <= 512 needs ONE chunk per lane, x and
+// residual are loaded and consumed chunk by chunk, and gamma / beta are fetched again for every row right before they are used: a
+// row costs several dependent memory round trips, which is what a 2.8 TB/s (35 % of HBM) LayerNorm looks like.
+// Here: the chunk count per lane is a template parameter (1, 2, 3, 4, 6), gamma / beta live in registers for the whole block, and
+// R rows per lane group are in flight together (R = 4 for one chunk per lane, 2 for two, 1 above): every load of an iteration is
+// issued before the first one is consumed.
+// Opt-in from the host (MQ_LN_VARIANT=2, mq_det_amd/ops.py): written after round 2's GPU budget was spent; checked bit for bit
+// against mq_layernorm_fwd through tests/simt, to be measured in round 3.
+#include "common.h"
+
+MQ_NAMESPACE_BEGIN
+
+namespace {
+template <bool F32>
+__device__ __forceinline__ void ln2_load8(const void* base, long off, float* v) {
+  if constexpr (F32) {
+    const float4_ a = *(const float4_*)((const float*)base + off), b = *(const float4_*)((const float*)base + off + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+  } else {
+    const half8 a = *(const half8*)((const half_t*)base + off);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)a[j];
+  }
+}
+__device__ __forceinline__ void ln2_store8f(float* base, long off, const float* v) {
+  float4_ a, b;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { a[j] = v[j]; b[j] = v[4 + j]; }
+  *(float4_*)(base + off) = a;
+  *(float4_*)(base + off + 4) = b;
+}
+}  // namespace
+
+template <int LPR, int MAXC, int R, bool XF32, bool RF32, bool HAS_RES>
+__global__ __launch_bounds__(256) void layernorm2_kernel(const void* __restrict__ x, const void* __restrict__ res,
+                                                         const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
+                                                         half_t* __restrict__ y, float* __restrict__ y32, void* __restrict__ xsum,
+                                                         long rows, int C, float eps, int RPB) {
+  constexpr int GROUPS = 256 / LPR;                 // lane groups (rows) per pass of a workgroup
+  constexpr bool SUM32 = XF32 || RF32;
+  const int sub = threadIdx.x % LPR, rg = threadIdx.x / LPR;
+  const int nch = C / 8;
+  const long r0 = (long)blockIdx.x * RPB;
+  // chunk k of this lane: clamped to a valid chunk for the loads (no guards around them), `live` decides what is used / stored
+  int chk[MAXC];
+  bool live[MAXC];
+  half8 g[MAXC], bt[MAXC];
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    const int ch = sub + k * LPR;
+    live[k] = ch < nch;
+    chk[k] = live[k] ? ch : nch - 1;
+    g[k] = *(const half8*)(gamma + chk[k] * 8);
+    bt[k] = *(const half8*)(beta + chk[k] * 8);
+  }
+  for (int rr = rg * R; rr < RPB; rr += GROUPS * R) {
+    float v[R][MAXC][8];
+    float rv[HAS_RES ? R : 1][MAXC][8];
+    bool ok[R];
+    long rowc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const long row = r0 + rr + i;
+      ok[i] = rr + i < RPB && row < rows;
+      rowc[i] = min(row, rows - 1);                  // out-of-range rows re-read the last row and store nothing
+    }
+    // ---- every load of this iteration, then the arithmetic
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+      for (int k = 0; k < MAXC; ++k) {
+        ln2_load8<XF32>(x, rowc[i] * C + chk[k] * 8, v[i][k]);
+        if constexpr (HAS_RES) ln2_load8<RF32>(res, rowc[i] * C + chk[k] * 8, rv[i][k]);
+      }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXC; ++k) {
+        if constexpr (HAS_RES) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[i][k][j] += rv[i][k][j];
+          if constexpr (!SUM32) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][k][j] = (float)(half_t)v[i][k][j];
+          }
+          if (xsum && ok[i] && live[k]) {
+            if constexpr (SUM32) {
+              ln2_store8f((float*)xsum, rowc[i] * C + chk[k] * 8, v[i][k]);
+            } else {
+              half8 o;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) o[j] = (half_t)v[i][k][j];
+              *(half8*)((half_t*)xsum + rowc[i] * C + chk[k] * 8) = o;
+            }
+          }
+        }
+        if (!live[k]) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[i][k][j] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[i][k][j];
+      }
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      const float mean = s / (float)C;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXC; ++k) {
+        if (live[k]) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { float d = v[i][k][j] - mean; q += d * d; }
+        }
+      }
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
+      const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+      for (int k = 0; k < MAXC; ++k) {
+        if (ok[i] && live[k]) {
+          half8 o;
+          float of[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            of[j] = (v[i][k][j] - mean) * rstd * (float)g[k][j] + (float)bt[k][j];
+            o[j] = (half_t)of[j];
+          }
+          if (y) *(half8*)(y + rowc[i] * C + chk[k] * 8) = o;
+          if (y32) ln2_store8f(y32, rowc[i] * C + chk[k] * 8, of);
+        }
+      }
+    }
+  }
+}
+
+template <int LPR, int MAXC, int R>
+static void launch_ln2(const void* x, bool xf, const void* res, bool rf, const void* gamma, const void* beta, void* y, float* y32, void* xsum,
+                       long rows, int C, float eps, hipStream_t stream) {
+  constexpr int per_pass = (256 / LPR) * R;
+  // small inputs (BERT / GCP: 2048 rows): one pass per block so that the launch still covers the chip
+  const int rpb = rows >= 64 * 2048 ? (64 > per_pass ? 64 : per_pass) : per_pass;
+  const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
+#define MQ_LN2(XF, RF, HR)                                                                                                     \
+  hipLaunchKernelGGL((layernorm2_kernel<LPR, MAXC, R, XF, RF, HR>), dim3(grid), dim3(256), 0, stream, x, res, (const half_t*)gamma, \
+                     (const half_t*)beta, (half_t*)y, y32, xsum, rows, C, eps, rpb)
+  if (!res) { if (xf) MQ_LN2(true, false, false); else MQ_LN2(false, false, false); }
+  else if (xf && rf) MQ_LN2(true, true, true);
+  else if (xf) MQ_LN2(true, false, true);
+  else if (rf) MQ_LN2(false, true, true);
+  else MQ_LN2(false, false, true);
+#undef MQ_LN2
+}
+
+extern "C" int MQ_SYM(mq_layernorm2_fwd)(const void* x, int x_f32, const void* res, int res_f32, const void* gamma, const void* beta,
+                                         void* y, float* y32, void* xsum, long rows, int C, float eps, void* stream) {
+  if (rows <= 0) return 0;
+  if (C % 8 || C > 3072) return -1;
+  if (!res && xsum) return -2;
+  const int nch = C / 8;
+  const bool xf = x_f32 != 0, rf = res && res_f32 != 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (nch <= 16) launch_ln2<16, 1, 4>(x, xf, res, rf, gamma, beta, y, y32, xsum, rows, C, eps, s);
+  else if (nch <= 32) launch_ln2<32, 1, 4>(x, xf, res, rf, gamma, beta, y, y32, xsum, rows, C, eps, s);
+  else if (nch <= 64) launch_ln2<64, 1, 4>(x, xf, res, rf, gamma, beta, y, y32, xsum, rows, C, eps, s);
+  else if (nch <= 128) launch_ln2<64, 2, 2>(x, xf, res, rf, gamma, beta, y, y32, xsum, rows, C, eps, s);
+  else if (nch <= 192) launch_ln2<64, 3, 1>(x, xf, res, rf, gamma, beta, y, y32, xsum, rows, C, eps, s);
+  else if (nch <= 256) launch_ln2<64, 4, 1>(x, xf, res, rf, gamma, beta, y, y32, xsum, rows, C, eps, s);
+  else launch_ln2<64, 6, 1>(x, xf, res, rf, gamma, beta, y, y32, xsum, rows, C, eps, s);
+  MQ_CHECK_LAUNCH();
+  return 0;
+}
+
+MQ_NAMESPACE_END

@@ -26,6 +26,7 @@ _SIGNATURES = {
     "mq_vlfuse_t2i_workspace_bytes": (_l, [_i, _i, _i]),
     "mq_vlfuse_t2i_fwd": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "mq_layernorm_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
+    "mq_layernorm2_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
     "mq_swin_mlp_fwd": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _l, _i, _vp]),
     "mq_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _vp]),
     "mq_conv3x3_nchw32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _vp]),
@@ -48,7 +49,7 @@ _SIGNATURES = {
 }
 # entry points with 16-bit operands also exist as <name>_bf16 (same signature; include/mqdet_hip.h MQ_BF16_TWIN)
 BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
-              "mq_layernorm_fwd", "mq_swin_mlp_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
+              "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_swin_mlp_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
               "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyrelu_apply",
               "mq_align_scores_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
 for _n in BF16_TWINS:
@@ -376,8 +377,10 @@ def layer_norm(x, gamma, beta, eps=1e-5, residual=None, want_sum=True, want_y32=
         if want_sum:
             xsum = torch.empty(x.shape, dtype=torch.float32 if (xf or rf) else h16, device=x.device)
     with _timed(f"layernorm_c{C}", sum(t.numel() * t.element_size() for t in (x, residual, y, y32, xsum) if t is not None)):
-        _chk(_fn(lib, "mq_layernorm_fwd", gamma)(_ptr(x), int(xf), _ptr(residual), int(rf), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(y32), _ptr(xsum),
-                                  rows, C, float(eps), _stream()), "mq_layernorm_fwd")
+        # MQ_LN_VARIANT=2: the load-batched kernel of csrc/layernorm2.hip (same results bit for bit; opt-in until measured on the device)
+        name = "mq_layernorm2_fwd" if os.environ.get("MQ_LN_VARIANT", "1") == "2" else "mq_layernorm_fwd"
+        _chk(_fn(lib, name, gamma)(_ptr(x), int(xf), _ptr(residual), int(rf), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(y32), _ptr(xsum),
+                                   rows, C, float(eps), _stream()), name)
     out = [t for t in (y, y32, xsum) if t is not None]
     return out[0] if len(out) == 1 else tuple(out)
 

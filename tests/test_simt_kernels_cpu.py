@@ -297,3 +297,36 @@ def test_resident_attention_full_model(resident):
     pc._CACHE.clear()
     _assert_ok(pc.check_full_model(CPU))
     assert calls.count("mq_attn_resident_fwd") >= 4
+
+
+# ---- the load-batched LayerNorm (csrc/layernorm2.hip, opt-in: MQ_LN_VARIANT=2)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_layernorm2_is_bit_identical_to_layernorm(kernels, monkeypatch, dtype):
+    """every width class (one .. six chunks per lane), every stream combination (fp16 / fp32 input, residual, second output, sum),
+    ragged row counts incl. fewer rows than one pass and the 64-rows-per-block regime: the outputs of the two kernels are EQUAL"""
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(7)
+    for rows, C in ((1000, 96), (5, 192), (777, 256), (130, 384), (65, 768), (50, 1536), (9, 2048), (7, 3072), (64 * 2048 + 3, 96)):
+        x32 = torch.randn(rows, C, generator=g) * 2 + 0.5
+        r32 = torch.randn(rows, C, generator=g)
+        w, b = (torch.randn(C, generator=g) * 0.1 + 1).to(dtype), (torch.randn(C, generator=g) * 0.1).to(dtype)
+        for x, res in ((x32.to(dtype), None), (x32, None), (x32.to(dtype), r32.to(dtype)), (x32, r32.to(dtype)), (x32.to(dtype), r32), (x32, r32)):
+            if rows > 100000 and (res is None or x.dtype != torch.float32):
+                continue                                     # the large case once (fp32 stream + residual: the Swin stage-1 call)
+            outs = {}
+            for variant in ("1", "2"):
+                monkeypatch.setenv("MQ_LN_VARIANT", variant)
+                outs[variant] = ops.layer_norm(x, w, b, 1e-5, residual=res, want_sum=True, want_y32=True)
+            a, c = outs["1"], outs["2"]
+            a, c = (a if isinstance(a, tuple) else (a,)), (c if isinstance(c, tuple) else (c,))
+            assert len(a) == len(c) == (3 if res is not None else 2)
+            for t1, t2 in zip(a, c):
+                assert t1.dtype == t2.dtype and torch.equal(t1, t2), (rows, C, x.dtype, None if res is None else res.dtype)
+
+
+def test_layernorm2_through_the_model(kernels, monkeypatch):
+    monkeypatch.setenv("MQ_LN_VARIANT", "2")
+    kernels._CACHE.clear()
+    _assert_ok(kernels.check_layernorm(CPU))
+    _assert_ok(kernels.check_bert_layer(CPU, True))
+    _assert_ok(kernels.check_swin_fpn(CPU))
