@@ -360,6 +360,31 @@ def test_resident_attention_kernel(dev, monkeypatch):
     pc._CACHE.clear()
 
 
+def test_layernorm2_kernel(dev, monkeypatch):
+    """csrc/layernorm2.hip (MQ_LN_VARIANT=2: load-batched LayerNorm): the LayerNorm checks and a BERT layer on it, and its outputs next
+    to mq_layernorm_fwd's on the same inputs (bit-identical through tests/simt; on the device the two kernels are separate
+    compilations of the same expressions, so one rounding step of slack is allowed)."""
+    import parity_checks as pc
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(7)
+    for rows, C in ((1000, 96), (5, 192), (777, 256), (130, 384), (65, 768), (50, 1536), (7, 3072), (64 * 2048 + 3, 96), (8 * 22400, 256)):
+        x32, r32 = torch.randn(rows, C, generator=g) * 2 + 0.5, torch.randn(rows, C, generator=g)
+        w, b = (torch.randn(C, generator=g) * 0.1 + 1).half().to(dev), (torch.randn(C, generator=g) * 0.1).half().to(dev)
+        for x, res in ((x32.half(), None), (x32, r32.half()), (x32.half(), r32.half()), (x32, r32)):
+            x, res = x.to(dev), None if res is None else res.to(dev)
+            outs = {}
+            for variant in ("1", "2"):
+                monkeypatch.setenv("MQ_LN_VARIANT", variant)
+                o = ops.layer_norm(x, w, b, 1e-5, residual=res, want_sum=True, want_y32=True)
+                outs[variant] = o if isinstance(o, tuple) else (o,)
+            for t1, t2 in zip(outs["1"], outs["2"]):
+                assert t1.dtype == t2.dtype and t1.shape == t2.shape
+                assert torch.allclose(t1.float(), t2.float(), rtol=1e-3 if t1.dtype == torch.float16 else 1e-5, atol=1e-3 if t1.dtype == torch.float16 else 1e-5), (rows, C)
+    monkeypatch.setenv("MQ_LN_VARIANT", "2")
+    _assert(pc.check_layernorm(dev))
+    _assert(pc.check_bert_layer(dev, True))
+
+
 # ------------------------------------------------------------------------------------------------ bf16 operands (configs[3])
 @pytest.fixture()
 def bf16():

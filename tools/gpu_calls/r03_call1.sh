@@ -7,8 +7,8 @@ export TMPDIR=/tmp
 # 1. the whole GPU suite (new this call: test_bf16_*, check_score_agg, test_resident_attention_kernel)
 timeout 600 python -m pytest tests -q -m gpu > gpurun_out/r03_pytest1.log 2>&1; tail -6 gpurun_out/r03_pytest1.log | cut -c1-300
 # 2. headline bench, then the same with the text-sized attentions on the resident-key kernel (lang_path_b64 carries the north-star number)
-timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r03_bench1_default.log 2>&1; tail -1 gpurun_out/r03_bench1_default.log | cut -c1-200
-MQ_ATTN_RESIDENT=1 timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r03_bench1_resident.log 2>&1; tail -1 gpurun_out/r03_bench1_resident.log | cut -c1-200
+timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-experimental > gpurun_out/r03_bench1_default.log 2>&1; tail -1 gpurun_out/r03_bench1_default.log | cut -c1-200
+MQ_ATTN_RESIDENT=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r03_bench1_resident.log 2>&1; tail -1 gpurun_out/r03_bench1_resident.log | cut -c1-200
 for f in default resident; do python - <<PY
 import json
 d = json.loads(open("gpurun_out/r03_bench1_$f.log").read().strip().splitlines()[-1])
@@ -16,6 +16,7 @@ lp = d.get("lang_path_b64", {})
 print("$f", d["value"], {k: lp.get(k) for k in ("ms_language_path", "attention_kernels_ms", "attention_mfma_utilisation")}, lp.get("kernels_ms"))
 PY
 done
+MQ_LN_VARIANT=2 timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-lang-b64 --no-experimental > gpurun_out/r03_bench1_ln2.log 2>&1; tail -1 gpurun_out/r03_bench1_ln2.log | cut -c1-200
 # 3. BASELINE configs[3]: MQ-GLIP-L on bf16 MFMA (default of the workload) next to fp16
 timeout 200 python bench.py --workload mq-glip-l --steps 10 --warmup 3 > gpurun_out/r03_bench1_glipl_bf16.log 2>&1; tail -1 gpurun_out/r03_bench1_glipl_bf16.log | cut -c1-200
 timeout 200 python bench.py --workload mq-glip-l --dtype f16 --steps 10 --warmup 3 > gpurun_out/r03_bench1_glipl_f16.log 2>&1; tail -1 gpurun_out/r03_bench1_glipl_f16.log | cut -c1-200
