@@ -168,6 +168,12 @@ int mq_conv3x3_fwd(const void* x, const void* w, const void* bias, void* out, in
  * in LDS.  Replaces nn.Conv2d(256, 27, 3) + the fp32 offset/mask split of rpn/vldyhead.py:186,214-216. */
 int mq_conv3x3_nchw32_fwd(const void* x, const void* w, const void* bias, float* out, int B, int H, int W, int C, long x_bs,
                           int N, void* stream);
+
+/* The same operator, arguments and results (bit-identical) with an unconditional, fully in-flight load schedule for the input window
+ * and the weight prefetch (csrc/conv_small2.hip).  Opt-in from the host (MQ_OFFSET_CONV_VARIANT=2): written after round 2's GPU
+ * budget was spent, checked for equality with mq_conv3x3_nchw32_fwd through tests/simt. */
+int mq_conv3x3_nchw32_v2_fwd(const void* x, const void* w, const void* bias, float* out, int B, int H, int W, int C, long x_bs,
+                          int N, void* stream);
 int mq_dcnv2_stats_blocks(int H, int W, int stride);
 /* One launch for up to 16 DCNv2 calls (the 13 branches of one DyConv layer): `branches` is a HOST array, copied into the
  * kernel arguments; fields as the arguments of mq_dcnv2_fwd.  The tiles of all branches form one work list, so small
@@ -299,6 +305,7 @@ MQ_BF16_TWIN(mq_layernorm2_fwd)
 MQ_BF16_TWIN(mq_swin_mlp_fwd)
 MQ_BF16_TWIN(mq_conv3x3_fwd)
 MQ_BF16_TWIN(mq_conv3x3_nchw32_fwd)
+MQ_BF16_TWIN(mq_conv3x3_nchw32_v2_fwd)
 MQ_BF16_TWIN(mq_dcnv2_fwd)
 MQ_BF16_TWIN(mq_dcnv2_group_fwd)
 MQ_BF16_TWIN(mq_dyconv_stats)

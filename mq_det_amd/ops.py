@@ -30,6 +30,7 @@ _SIGNATURES = {
     "mq_swin_mlp_fwd": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _l, _i, _vp]),
     "mq_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _vp]),
     "mq_conv3x3_nchw32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _vp]),
+    "mq_conv3x3_nchw32_v2_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _vp]),
     "mq_dcnv2_stats_blocks": (_i, [_i, _i, _i]),
     "mq_dcnv2_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _vp]),
     "mq_dcnv2_group_fwd": (_i, [_vp, _i, _vp]),
@@ -49,7 +50,7 @@ _SIGNATURES = {
 }
 # entry points with 16-bit operands also exist as <name>_bf16 (same signature; include/mqdet_hip.h MQ_BF16_TWIN)
 BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
-              "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_swin_mlp_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
+              "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_swin_mlp_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
               "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyrelu_apply",
               "mq_align_scores_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
 for _n in BF16_TWINS:
@@ -445,8 +446,9 @@ def conv3x3_nchw32(x_nhwc, w_packed, bias, n_out):
     assert w_packed.is_contiguous() and w_packed.shape == (32, 9 * C) and w_packed.dtype == x_nhwc.dtype and n_out <= 32
     out = torch.empty(B, n_out, H, W, dtype=torch.float32, device=x_nhwc.device)
     with _timed("conv3x3_small", B * H * W * C * 2 + out.numel() * 4):
-        _chk(_fn(lib, "mq_conv3x3_nchw32_fwd", x_nhwc)(_ptr(x_nhwc), _ptr(w_packed), _ptr(bias), _ptr(out), B, H, W, C, x_nhwc.stride(0), n_out,
-                                       _stream()), "mq_conv3x3_nchw32_fwd")
+        # MQ_OFFSET_CONV_VARIANT=2: unconditional / in-flight loads (csrc/conv_small2.hip), same results; opt-in until measured
+        name = "mq_conv3x3_nchw32_v2_fwd" if os.environ.get("MQ_OFFSET_CONV_VARIANT", "1") == "2" else "mq_conv3x3_nchw32_fwd"
+        _chk(_fn(lib, name, x_nhwc)(_ptr(x_nhwc), _ptr(w_packed), _ptr(bias), _ptr(out), B, H, W, C, x_nhwc.stride(0), n_out, _stream()), name)
     return out
 
 

@@ -385,6 +385,27 @@ def test_layernorm2_kernel(dev, monkeypatch):
     _assert(pc.check_bert_layer(dev, True))
 
 
+def test_offset_conv_v2_kernel(dev, monkeypatch):
+    """csrc/conv_small2.hip (MQ_OFFSET_CONV_VARIANT=2: the DyConv offset conv with unconditional in-flight loads): equal to
+    mq_conv3x3_nchw32_fwd on the same inputs (same MFMA order: the results must not differ at all), conv and DyConv checks on it."""
+    import parity_checks as pc
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for B, H, W, C in ((2, 13, 21, 256), (1, 7, 11, 256), (1, 3, 5, 128), (2, 17, 33, 64), (8, 100, 168, 256), (8, 7, 11, 256)):
+        x = torch.randn(B, H, W, C, generator=g).half().to(dev)
+        w = torch.zeros(32, 9 * C, dtype=torch.float16)
+        w[:27] = (torch.randn(27, 9 * C, generator=g) / 48).half()
+        w, bias = w.to(dev), torch.randn(27, generator=g).half().to(dev)
+        outs = {}
+        for variant in ("1", "2"):
+            monkeypatch.setenv("MQ_OFFSET_CONV_VARIANT", variant)
+            outs[variant] = ops.conv3x3_nchw32(x, w, bias, 27)
+        assert torch.equal(outs["1"], outs["2"]), (B, H, W, C)
+    monkeypatch.setenv("MQ_OFFSET_CONV_VARIANT", "2")
+    _assert(pc.check_conv3x3(dev))
+    _assert(pc.check_dyconv(dev))
+
+
 # ------------------------------------------------------------------------------------------------ bf16 operands (configs[3])
 @pytest.fixture()
 def bf16():

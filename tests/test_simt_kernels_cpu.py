@@ -330,3 +330,33 @@ def test_layernorm2_through_the_model(kernels, monkeypatch):
     _assert_ok(kernels.check_layernorm(CPU))
     _assert_ok(kernels.check_bert_layer(CPU, True))
     _assert_ok(kernels.check_swin_fpn(CPU))
+
+
+# ---- the offset conv with unconditional in-flight loads (csrc/conv_small2.hip, opt-in: MQ_OFFSET_CONV_VARIANT=2)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_offset_conv_v2_equals_v1(kernels, monkeypatch, dtype):
+    """patches at every image border, ragged sizes smaller than a patch, 1 / 2 channel passes (C = 64, 128, 256), level views of a
+    token buffer: the two kernels' outputs are EQUAL; plus the DyConv block on it"""
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for B, H, W, C in ((2, 13, 21, 256), (1, 7, 11, 256), (1, 3, 5, 128), (2, 17, 33, 64), (1, 25, 42, 256)):
+        x = torch.randn(B, H, W, C, generator=g).to(dtype)
+        w = torch.zeros(32, 9 * C, dtype=dtype)
+        w[:27] = (torch.randn(27, 9 * C, generator=g) / 48).to(dtype)
+        bias = torch.randn(27, generator=g).to(dtype)
+        outs = {}
+        for variant in ("1", "2"):
+            monkeypatch.setenv("MQ_OFFSET_CONV_VARIANT", variant)
+            outs[variant] = ops.conv3x3_nchw32(x, w, bias, 27)
+        assert torch.equal(outs["1"], outs["2"]), (B, H, W, C)
+        big = torch.zeros(B, H * W + 37, C, dtype=dtype)                       # a pyramid level inside a larger token buffer
+        big[:, 5:5 + H * W] = x.reshape(B, H * W, C)
+        assert torch.equal(ops.conv3x3_nchw32(big[:, 5:5 + H * W].reshape(B, H, W, C), w, bias, 27), outs["1"])
+    monkeypatch.setenv("MQ_OFFSET_CONV_VARIANT", "2")
+    kernels.use_dtype(dtype)
+    try:
+        _assert_ok(kernels.check_conv3x3(CPU))
+        if dtype == torch.float16:
+            _assert_ok(kernels.check_dyconv(CPU))
+    finally:
+        kernels.use_dtype(torch.float16)
