@@ -135,6 +135,14 @@ int mq_layernorm_fwd(const void* x, int x_f32, const void* res, int res_f32, con
 int mq_layernorm2_fwd(const void* x, int x_f32, const void* res, int res_f32, const void* gamma, const void* beta, void* y,
                      float* y32, void* xsum, long rows, int C, float eps, void* stream);
 
+/* Swin PatchMerging up to its LayerNorm in one kernel: y[b,i,j,:] = LayerNorm_{4C}(concat(x[b,2i,2j], x[b,2i+1,2j], x[b,2i,2j+1],
+ *   x[b,2i+1,2j+1])), zero beyond an odd H / W.  x [B,H,W,C] fp16 or fp32 (x_f32), contiguous; gamma / beta [4C] fp16; y fp16
+ *   [B, ceil(H/2)*ceil(W/2), 4C]; C % 8 == 0, 4C <= 3072.  Bit-identical to F.pad + torch.cat + mq_layernorm_fwd.
+ * Replaces maskrcnn_benchmark/modeling/backbone/swint.py:264-281 (pad, four strided slices, cat, norm).  Opt-in from the host
+ * (MQ_PATCH_MERGE_FUSED=1): written after round 2's GPU budget was spent, checked for equality through tests/simt. */
+int mq_patch_merge_ln_fwd(const void* x, int x_f32, const void* gamma, const void* beta, void* y, int B, int H, int W, int C, float eps,
+                          void* stream);
+
 /* MLP half of a Swin block in one kernel (LayerNorm prologue, fc1, exact GELU, fc2, residual; the 4C-wide hidden activation
  * stays in registers), C in {96, 192, 384}:
  *   x' = x + delta;  out = x' + fc2(gelu(fc1(LN(x'; ln_g, ln_b, eps))));  y = LN(out; next_g, next_b, eps_next) (optional)
@@ -302,6 +310,7 @@ MQ_BF16_TWIN(mq_vlfuse_i2t_fwd)
 MQ_BF16_TWIN(mq_vlfuse_t2i_fwd)
 MQ_BF16_TWIN(mq_layernorm_fwd)
 MQ_BF16_TWIN(mq_layernorm2_fwd)
+MQ_BF16_TWIN(mq_patch_merge_ln_fwd)
 MQ_BF16_TWIN(mq_swin_mlp_fwd)
 MQ_BF16_TWIN(mq_conv3x3_fwd)
 MQ_BF16_TWIN(mq_conv3x3_nchw32_fwd)

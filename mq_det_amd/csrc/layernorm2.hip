@@ -176,4 +176,126 @@ extern "C" int MQ_SYM(mq_layernorm2_fwd)(const void* x, int x_f32, const void* r
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// mq_patch_merge_ln_fwd: Swin PatchMerging up to its LayerNorm (backbone/swint.py:258-284) in one kernel:
+//   y[b, i, j, :] = LayerNorm_{4C}( concat( x[b, 2i, 2j], x[b, 2i+1, 2j], x[b, 2i, 2j+1], x[b, 2i+1, 2j+1] ) )   (zero beyond an odd H / W)
+// The host path does F.pad + four strided slices + torch.cat (a 0.24 ms / step CatArrayBatchedCopy pass that writes the gathered
+// [B, H/2, W/2, 4C] fp32 tensor, profiles/r02_call5) and then mq_layernorm_fwd reads it back; here the LayerNorm reads the four
+// C-wide segments of a row straight from x.  Same lane <-> chunk assignment and summation order as mq_layernorm_fwd on the
+// concatenated row: the result equals cat + LayerNorm bit for bit.  x: [B, H, W, C] fp16 or fp32 (x_f32), contiguous; y: fp16
+// [B, ceil(H/2) * ceil(W/2), 4C]; C % 8 == 0, 4C <= 3072.  Opt-in from the host (MQ_PATCH_MERGE_FUSED=1), see the header of this file.
+template <int LPR, int MAXC, int R, bool XF32>
+__global__ __launch_bounds__(256) void patch_merge_ln_kernel(const void* __restrict__ x, const half_t* __restrict__ gamma,
+                                                             const half_t* __restrict__ beta, half_t* __restrict__ y, int B, int H, int W,
+                                                             int C, float eps, int RPB) {
+  constexpr int GROUPS = 256 / LPR;
+  const int sub = threadIdx.x % LPR, rg = threadIdx.x / LPR;
+  const int C4 = 4 * C, nch = C4 / 8;
+  const int H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
+  const long rows = (long)B * H2 * W2;
+  const long r0 = (long)blockIdx.x * RPB;
+  int chk[MAXC], seg_dy[MAXC], seg_dx[MAXC], seg_off[MAXC];
+  bool live[MAXC];
+  half8 g[MAXC], bt[MAXC];
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    const int ch = sub + k * LPR;
+    live[k] = ch < nch;
+    chk[k] = live[k] ? ch : nch - 1;
+    const int e = chk[k] * 8, seg = e / C;                 // a chunk never straddles two segments (C % 8 == 0)
+    seg_dy[k] = seg & 1;                                   // concat order x0 (0,0), x1 (1,0), x2 (0,1), x3 (1,1): (dy, dx)
+    seg_dx[k] = seg >> 1;
+    seg_off[k] = e - seg * C;
+    g[k] = *(const half8*)(gamma + chk[k] * 8);
+    bt[k] = *(const half8*)(beta + chk[k] * 8);
+  }
+  for (int rr = rg * R; rr < RPB; rr += GROUPS * R) {
+    float v[R][MAXC][8];
+    bool ok[R], in[R][MAXC];
+    long rowc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const long row = r0 + rr + i;
+      ok[i] = rr + i < RPB && row < rows;
+      rowc[i] = min(row, rows - 1);
+      const int b = (int)(rowc[i] / ((long)H2 * W2)), rem = (int)(rowc[i] % ((long)H2 * W2));
+      const int hi = rem / W2, wi = rem % W2;
+#pragma unroll
+      for (int k = 0; k < MAXC; ++k) {
+        const int hh = 2 * hi + seg_dy[k], ww = 2 * wi + seg_dx[k];
+        in[i][k] = hh < H && ww < W;                       // beyond an odd H / W: the zero padding of swint.py:270-272
+        const long pix = ((long)b * H + min(hh, H - 1)) * W + min(ww, W - 1);
+        ln2_load8<XF32>(x, pix * C + seg_off[k], v[i][k]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXC; ++k) {
+        if (!live[k] || !in[i][k]) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[i][k][j] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[i][k][j];
+      }
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      const float mean = s / (float)C4;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXC; ++k) {
+        if (live[k]) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { float d = v[i][k][j] - mean; q += d * d; }
+        }
+      }
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
+      const float rstd = rsqrtf(q / (float)C4 + eps);
+#pragma unroll
+      for (int k = 0; k < MAXC; ++k) {
+        if (ok[i] && live[k]) {
+          half8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (half_t)((v[i][k][j] - mean) * rstd * (float)g[k][j] + (float)bt[k][j]);
+          *(half8*)(y + rowc[i] * C4 + chk[k] * 8) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int LPR, int MAXC, int R>
+static void launch_pm(const void* x, bool xf, const void* gamma, const void* beta, void* y, int B, int H, int W, int C, float eps, hipStream_t stream) {
+  constexpr int per_pass = (256 / LPR) * R;
+  const long rows = (long)B * ((H + 1) / 2) * ((W + 1) / 2);
+  const int rpb = rows >= 64 * 2048 ? (64 > per_pass ? 64 : per_pass) : per_pass;
+  const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
+  if (xf) hipLaunchKernelGGL((patch_merge_ln_kernel<LPR, MAXC, R, true>), dim3(grid), dim3(256), 0, stream, x, (const half_t*)gamma,
+                             (const half_t*)beta, (half_t*)y, B, H, W, C, eps, rpb);
+  else hipLaunchKernelGGL((patch_merge_ln_kernel<LPR, MAXC, R, false>), dim3(grid), dim3(256), 0, stream, x, (const half_t*)gamma,
+                          (const half_t*)beta, (half_t*)y, B, H, W, C, eps, rpb);
+}
+
+extern "C" int MQ_SYM(mq_patch_merge_ln_fwd)(const void* x, int x_f32, const void* gamma, const void* beta, void* y, int B, int H, int W, int C,
+                                             float eps, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  if (C % 8 || 4 * C > 3072) return -1;
+  const int nch = 4 * C / 8;
+  const bool xf = x_f32 != 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (nch <= 16) launch_pm<16, 1, 4>(x, xf, gamma, beta, y, B, H, W, C, eps, s);
+  else if (nch <= 32) launch_pm<32, 1, 4>(x, xf, gamma, beta, y, B, H, W, C, eps, s);
+  else if (nch <= 64) launch_pm<64, 1, 4>(x, xf, gamma, beta, y, B, H, W, C, eps, s);
+  else if (nch <= 128) launch_pm<64, 2, 2>(x, xf, gamma, beta, y, B, H, W, C, eps, s);
+  else if (nch <= 192) launch_pm<64, 3, 1>(x, xf, gamma, beta, y, B, H, W, C, eps, s);
+  else if (nch <= 256) launch_pm<64, 4, 1>(x, xf, gamma, beta, y, B, H, W, C, eps, s);
+  else launch_pm<64, 6, 1>(x, xf, gamma, beta, y, B, H, W, C, eps, s);
+  MQ_CHECK_LAUNCH();
+  return 0;
+}
+
 MQ_NAMESPACE_END

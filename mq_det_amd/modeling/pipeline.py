@@ -271,12 +271,18 @@ def swin_forward(P, cfg, img, p="backbone.body", SW=None):
             x = x + pend
         if i < len(M.DEPTHS) - 1:                      # PatchMerging, swint.py:258-284
             d = f"{p}.layers.{i}.downsample"
-            y = x.reshape(B, H, W, C)
-            if H % 2 or W % 2:
-                y = F.pad(y, (0, 0, 0, W % 2, 0, H % 2))
-            y = torch.cat([y[:, 0::2, 0::2], y[:, 1::2, 0::2], y[:, 0::2, 1::2], y[:, 1::2, 1::2]], -1)
-            H, W = (H + 1) // 2, (W + 1) // 2
-            x = F.linear(_ln(P, d + ".norm", y.reshape(B, H * W, 4 * C)), P[d + ".reduction.weight"])
+            if os.environ.get("MQ_PATCH_MERGE_FUSED", "0") == "1" and hasattr(ops, "patch_merge_ln"):
+                # gather + LayerNorm in one kernel (csrc/layernorm2.hip): no pad / cat pass; same values bit for bit; opt-in until measured
+                yn = ops.patch_merge_ln(x.reshape(B, H, W, C).contiguous(), P[d + ".norm.weight"], P[d + ".norm.bias"], 1e-5)
+                H, W = (H + 1) // 2, (W + 1) // 2
+            else:
+                y = x.reshape(B, H, W, C)
+                if H % 2 or W % 2:
+                    y = F.pad(y, (0, 0, 0, W % 2, 0, H % 2))
+                y = torch.cat([y[:, 0::2, 0::2], y[:, 1::2, 0::2], y[:, 0::2, 1::2], y[:, 1::2, 1::2]], -1)
+                H, W = (H + 1) // 2, (W + 1) // 2
+                yn = _ln(P, d + ".norm", y.reshape(B, H * W, 4 * C))
+            x = F.linear(yn, P[d + ".reduction.weight"])
             if r32:
                 x = x.float()
     return outs

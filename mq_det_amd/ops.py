@@ -27,6 +27,7 @@ _SIGNATURES = {
     "mq_vlfuse_t2i_fwd": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "mq_layernorm_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
     "mq_layernorm2_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
+    "mq_patch_merge_ln_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mq_swin_mlp_fwd": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _l, _i, _vp]),
     "mq_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _vp]),
     "mq_conv3x3_nchw32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _vp]),
@@ -50,7 +51,7 @@ _SIGNATURES = {
 }
 # entry points with 16-bit operands also exist as <name>_bf16 (same signature; include/mqdet_hip.h MQ_BF16_TWIN)
 BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
-              "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_swin_mlp_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
+              "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_patch_merge_ln_fwd", "mq_swin_mlp_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
               "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyrelu_apply",
               "mq_align_scores_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
 for _n in BF16_TWINS:
@@ -384,6 +385,22 @@ def layer_norm(x, gamma, beta, eps=1e-5, residual=None, want_sum=True, want_y32=
                                    rows, C, float(eps), _stream()), name)
     out = [t for t in (y, y32, xsum) if t is not None]
     return out[0] if len(out) == 1 else tuple(out)
+
+
+def patch_merge_ln(x, gamma, beta, eps=1e-5):
+    """Swin PatchMerging gather + LayerNorm in one kernel (mq_patch_merge_ln_fwd): x [B,H,W,C] fp16 / bf16 / fp32 contiguous,
+    gamma / beta [4C] -> y [B, ceil(H/2)*ceil(W/2), 4C] in gamma's dtype (= F.pad + four strided slices + cat + LayerNorm)."""
+    lib = load_library()
+    _need_gpu(x, gamma, beta)
+    B, H, W, C = x.shape
+    h16 = gamma.dtype
+    assert x.is_contiguous() and x.dtype in (h16, torch.float32) and h16 in _H16 and beta.dtype == h16
+    assert gamma.numel() == 4 * C and beta.numel() == 4 * C and C % 8 == 0 and 4 * C <= 3072
+    y = torch.empty(B, ((H + 1) // 2) * ((W + 1) // 2), 4 * C, dtype=h16, device=x.device)
+    with _timed(f"patch_merge_ln_c{C}", x.numel() * x.element_size() + y.numel() * 2):
+        _chk(_fn(lib, "mq_patch_merge_ln_fwd", gamma)(_ptr(x), int(x.dtype == torch.float32), _ptr(gamma), _ptr(beta), _ptr(y), B, H, W, C,
+                                                     float(eps), _stream()), "mq_patch_merge_ln_fwd")
+    return y
 
 
 SWIN_MLP_WIDTHS = (96, 192, 384)

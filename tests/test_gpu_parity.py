@@ -406,6 +406,28 @@ def test_offset_conv_v2_kernel(dev, monkeypatch):
     _assert(pc.check_dyconv(dev))
 
 
+def test_patch_merge_ln_kernel(dev, monkeypatch):
+    """mq_patch_merge_ln_fwd (MQ_PATCH_MERGE_FUSED=1: Swin PatchMerging gather + LayerNorm in one kernel) next to F.pad + cat +
+    mq_layernorm_fwd on the same inputs, then Swin + FPN with the switch on."""
+    import torch.nn.functional as F
+    import parity_checks as pc
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(11)
+    for B, H, W, C in ((2, 8, 12, 96), (1, 7, 11, 96), (2, 5, 6, 192), (1, 9, 4, 384), (1, 3, 3, 768), (8, 200, 336, 96), (8, 25, 42, 384)):
+        for xd in (torch.float32, torch.float16):
+            x = (torch.randn(B, H, W, C, generator=g) * 2 + 0.3).to(xd).to(dev)
+            w, b = (torch.randn(4 * C, generator=g) * 0.1 + 1).half().to(dev), (torch.randn(4 * C, generator=g) * 0.1).half().to(dev)
+            y = F.pad(x, (0, 0, 0, W % 2, 0, H % 2)) if (H % 2 or W % 2) else x
+            y = torch.cat([y[:, 0::2, 0::2], y[:, 1::2, 0::2], y[:, 0::2, 1::2], y[:, 1::2, 1::2]], -1)
+            ref = ops.layer_norm(y.reshape(B, -1, 4 * C).contiguous(), w, b, 1e-5)
+            got = ops.patch_merge_ln(x, w, b, 1e-5)
+            assert got.shape == ref.shape and torch.allclose(got.float(), ref.float(), rtol=1e-3, atol=1e-3), (B, H, W, C, xd)
+    monkeypatch.setenv("MQ_PATCH_MERGE_FUSED", "1")
+    pc._CACHE.clear()
+    _assert(pc.check_swin_fpn(dev))
+    pc._CACHE.clear()
+
+
 # ------------------------------------------------------------------------------------------------ bf16 operands (configs[3])
 @pytest.fixture()
 def bf16():

@@ -360,3 +360,30 @@ def test_offset_conv_v2_equals_v1(kernels, monkeypatch, dtype):
             _assert_ok(kernels.check_dyconv(CPU))
     finally:
         kernels.use_dtype(torch.float16)
+
+
+# ---- Swin PatchMerging gather + LayerNorm in one kernel (csrc/layernorm2.hip, opt-in: MQ_PATCH_MERGE_FUSED=1)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_patch_merge_ln_equals_cat_plus_layernorm(kernels, monkeypatch, dtype):
+    """even / odd H and W (zero padding), every Swin width (C = 96 .. 768: 4C up to 3072), fp32 and 16-bit input: EQUAL to
+    F.pad + four strided slices + cat + mq_layernorm_fwd; then the Swin + FPN check with the switch on"""
+    import torch.nn.functional as F
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(11)
+    for B, H, W, C in ((2, 8, 12, 96), (1, 7, 11, 96), (2, 5, 6, 192), (1, 9, 4, 384), (1, 3, 3, 768), (1, 1, 1, 96)):
+        for xd in (torch.float32, dtype):
+            x = (torch.randn(B, H, W, C, generator=g) * 2 + 0.3).to(xd)
+            w, b = (torch.randn(4 * C, generator=g) * 0.1 + 1).to(dtype), (torch.randn(4 * C, generator=g) * 0.1).to(dtype)
+            y = F.pad(x, (0, 0, 0, W % 2, 0, H % 2)) if (H % 2 or W % 2) else x
+            y = torch.cat([y[:, 0::2, 0::2], y[:, 1::2, 0::2], y[:, 0::2, 1::2], y[:, 1::2, 1::2]], -1)
+            ref = ops.layer_norm(y.reshape(B, -1, 4 * C).contiguous(), w, b, 1e-5)
+            got = ops.patch_merge_ln(x, w, b, 1e-5)
+            assert got.shape == ref.shape and got.dtype == ref.dtype and torch.equal(got, ref), (B, H, W, C, xd)
+    monkeypatch.setenv("MQ_PATCH_MERGE_FUSED", "1")
+    kernels.use_dtype(dtype)
+    kernels._CACHE.clear()
+    try:
+        _assert_ok(kernels.check_swin_fpn(CPU))
+    finally:
+        kernels.use_dtype(torch.float16)
+        kernels._CACHE.clear()
