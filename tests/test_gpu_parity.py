@@ -355,9 +355,10 @@ def test_resident_attention_kernel(dev, monkeypatch):
                 dict(B=1, H=2, D=32, Nq=37, Nk=257, nsplit=2), dict(B=1, H=2, D=32, Nq=37, Nk=100, nsplit=3)):
         _assert(pc.check_attention(dev, **cfg))
     _assert(pc.check_pre_select(dev))
-    pc._CACHE.clear()
-    _assert(pc.check_full_model(dev))
-    pc._CACHE.clear()
+    if _FULL:
+        pc._CACHE.clear()
+        _assert(pc.check_full_model(dev))
+        pc._CACHE.clear()
 
 
 def test_layernorm2_kernel(dev, monkeypatch):
@@ -439,9 +440,14 @@ def bf16():
     pc.use_dtype(torch.float16)
 
 
-@pytest.mark.parametrize("name", ["check_attention_strided", "check_window_attention", "check_gcp_block", "check_pre_select", "check_vlfuse_kernels",
-                                  "check_vl_fuse", "check_dcn", "check_dyconv", "check_conv3x3", "check_layernorm", "check_swin_mlp", "check_post_golden",
-                                  "check_roi_align", "check_msdeform_attn", "check_full_model"])
+_FULL = os.environ.get("MQ_GPU_FULL", "0") == "1"        # the complete bf16 list (every kernel family): + ~2 min on the device
+_slow = pytest.mark.skipif(not _FULL, reason="MQ_GPU_FULL=1: the remaining kernel families in bf16 (all of them run through tests/simt)")
+
+
+@pytest.mark.parametrize("name", ["check_attention_strided", "check_window_attention", "check_vlfuse_kernels", "check_dcn", "check_layernorm",
+                                  "check_swin_mlp", "check_full_model"] +
+                         [pytest.param(n, marks=_slow) for n in ("check_gcp_block", "check_pre_select", "check_vl_fuse", "check_dyconv", "check_conv3x3",
+                                                                 "check_post_golden", "check_roi_align", "check_msdeform_attn")])
 def test_bf16_block(dev, bf16, name):
     _assert(getattr(bf16, name)(dev))
 
@@ -455,4 +461,5 @@ def test_bf16_mq_glip_l_family(dev, bf16):
 def test_bf16_groundingdino(dev, bf16):
     import gdino_checks as gc
     _assert(gc.check_msdeform_attn_q(dev))
-    _assert(gc.check_gdino_model(dev, vq=True))
+    if _FULL:
+        _assert(gc.check_gdino_model(dev, vq=True))

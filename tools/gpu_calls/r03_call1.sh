@@ -5,7 +5,7 @@ cd ${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf gpurun_out/*; mkdir -p gpurun_out
 export TMPDIR=/tmp
 # 1. the whole GPU suite (new this call: test_bf16_*, check_score_agg, test_resident_attention_kernel)
-timeout 600 python -m pytest tests -q -m gpu > gpurun_out/r03_pytest1.log 2>&1; tail -6 gpurun_out/r03_pytest1.log | cut -c1-300
+MQ_GPU_FULL=1 timeout 900 python -m pytest tests -q -m gpu > gpurun_out/r03_pytest1.log 2>&1; tail -6 gpurun_out/r03_pytest1.log | cut -c1-300
 # 2. headline bench, then the same with the text-sized attentions on the resident-key kernel (lang_path_b64 carries the north-star number)
 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-experimental > gpurun_out/r03_bench1_default.log 2>&1; tail -1 gpurun_out/r03_bench1_default.log | cut -c1-200
 MQ_ATTN_RESIDENT=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r03_bench1_resident.log 2>&1; tail -1 gpurun_out/r03_bench1_resident.log | cut -c1-200
