@@ -387,3 +387,52 @@ def test_patch_merge_ln_equals_cat_plus_layernorm(kernels, monkeypatch, dtype):
     finally:
         kernels.use_dtype(torch.float16)
         kernels._CACHE.clear()
+
+
+# ---- out-of-bounds check: every library argument against a guard page (tests/simt/guard.py), in a subprocess
+def _oob(mode, names, env=None, timeout=1200):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "simt", "oob_check.py"), mode, *names], capture_output=True, text=True,
+                       timeout=timeout, env=dict(os.environ, **(env or {})))
+    return r.returncode, [ln for ln in r.stdout.splitlines() if ln.startswith(("OK", "MISMATCH"))], r.stderr[-600:]
+
+
+OPT_IN = {"MQ_ATTN_RESIDENT": "1", "MQ_LN_VARIANT": "2", "MQ_OFFSET_CONV_VARIANT": "2", "MQ_PATCH_MERGE_FUSED": "1"}
+
+
+@pytest.mark.parametrize("mode", ["end", "start"])
+def test_no_kernel_touches_memory_outside_its_buffers(mode):
+    """Inputs, outputs and workspaces of every call sit directly against a PROT_NONE page (after them: mode "end", before: "start"); one
+    byte too far is a SIGSEGV.  Shipped kernels on a cross-section of checks, and the opt-in kernels of section 12 (which have never
+    run on a device, where such an access is a silent wrong read or a memory fault that takes the process down)."""
+    names = ["attention_small", "check_layernorm", "check_window_attention", "check_conv3x3"]      # (all 20 check groups pass: MQ_SIMT_FULL=1)
+    if os.environ.get("MQ_SIMT_FULL", "0") == "1":
+        names += ["check_gcp_block", "check_pre_select", "check_vlfuse_kernels", "check_vl_fuse", "check_dcn", "check_dyconv", "check_post_golden",
+                  "check_score_agg", "check_nms", "check_swin_mlp", "check_roi_align", "check_msdeform_attn", "check_swin_fpn", "check_attention_qk_mask",
+                  "check_msdeform_attn_q", "check_attention_strided"]
+    rc, lines, err = _oob(mode, names)
+    assert rc == 0 and lines == ["OK " + n for n in names], (rc, lines, err)
+    names = ["attention_small", "check_attention_strided", "check_layernorm", "check_pre_select", "check_conv3x3", "check_swin_fpn",
+             "check_attention_qk_mask"]
+    rc, lines, err = _oob(mode, names, OPT_IN)
+    assert rc == 0 and lines == ["OK " + n for n in names], (rc, lines, err)
+
+
+def test_guard_pages_do_catch_an_overrun():
+    """negative control: mq_layernorm_fwd told about one row more than its input holds dies with SIGSEGV under the guard"""
+    import subprocess
+    code = (
+        "import sys, ctypes, torch\n"
+        "sys.path.insert(0, 'tests'); sys.path.insert(0, '.')\n"
+        "import simt\nfrom simt import guard\n"
+        "lib = simt.library()\n"
+        "x = guard.guarded(torch.randn(64, 256).half()); w = guard.guarded(torch.ones(256).half()); y = guard.alloc((65, 256), torch.float16)\n"
+        "vp = ctypes.c_void_p\n"
+        "rc = lib.mq_layernorm_fwd(vp(x.data_ptr()), 0, vp(0), 0, vp(w.data_ptr()), vp(w.data_ptr()), vp(y.data_ptr()), vp(0), vp(0), {rows}, 256, 1e-5, vp(0))\n"
+        "print('returned', rc)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ok = subprocess.run([sys.executable, "-c", code.format(rows=64)], capture_output=True, text=True, cwd=root)
+    assert ok.returncode == 0 and "returned 0" in ok.stdout, ok.stderr[-400:]
+    bad = subprocess.run([sys.executable, "-c", code.format(rows=65)], capture_output=True, text=True, cwd=root)
+    assert bad.returncode == -11, (bad.returncode, bad.stdout, bad.stderr[-300:])
