@@ -187,7 +187,13 @@ static char* get_stack(size_t i) {
   return stacks[i];
 }
 
+static size_t smem_bytes = 0;                       // dynamic LDS of the current launch
+
 static bool run_block(unsigned nthreads) {
+  // A workgroup starts with UNDEFINED LDS contents on the device.  Here every byte of the dynamic LDS is set to 0xFF first (a NaN as
+  // fp16 / bf16 / fp32, -1 as an integer): a kernel whose result depends on LDS it never wrote fails its parity check instead of
+  // passing on the leftovers of the previous workgroup.
+  if (smem_bytes) memset(dyn_smem(), 0xFF, smem_bytes);
   fibers.assign(nthreads, Fiber());
   const unsigned nw = (nthreads + 63) / 64;
   waves.assign(nw, Wave());
@@ -247,6 +253,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, BodyFn fn, void* ctx) {
   body = fn;
   body_ctx = ctx;
   if (smem.size() < shmem + 64) smem.resize(shmem + 64);
+  smem_bytes = shmem;
   const unsigned nthreads = block.x * block.y * block.z;
   if (nthreads == 0 || nthreads > 1024 || shmem > (160u << 10)) { g_error = 1; return; }       // hipErrorInvalidValue
   for (unsigned z = 0; z < grid.z; ++z)
