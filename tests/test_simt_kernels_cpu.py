@@ -290,6 +290,7 @@ def test_chunked_attention_pre_select_and_schedules(resident):
             simt.set_schedule("ascending")
 
 
+@pytest.mark.skipif(os.environ.get("MQ_SIMT_FULL", "0") != "1", reason="MQ_SIMT_FULL=1 (the BERT layer, pre-select and attention checks above cover the kernels)")
 def test_resident_attention_full_model(resident):
     """every text-sized attention of the tiny MQ-GLIP-T forward (BERT layers, VLDyHead BERT copies with the clamp) on the resident
     kernel: the smoke() check end to end"""
