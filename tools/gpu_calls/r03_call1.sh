@@ -22,3 +22,8 @@ timeout 200 python bench.py --workload mq-glip-l --steps 10 --warmup 3 > gpurun_
 timeout 200 python bench.py --workload mq-glip-l --dtype f16 --steps 10 --warmup 3 > gpurun_out/r03_bench1_glipl_f16.log 2>&1; tail -1 gpurun_out/r03_bench1_glipl_f16.log | cut -c1-200
 # 4. MQ-GroundingDINO with the resident kernel (text enhancer 4 x 64, decoder text cross-attention 8 x 32)
 MQ_ATTN_RESIDENT=1 timeout 200 python bench.py --workload mq-gdino-t --steps 10 --warmup 3 > gpurun_out/r03_bench1_gdino_resident.log 2>&1; tail -1 gpurun_out/r03_bench1_gdino_resident.log | cut -c1-200
+# 5. library GEMMs are 5.3 ms of the 24.3 ms step: what does PyTorch's TunableOp (rocBLAS / hipBLASLt solution
+#    search per GEMM shape, results kept in a CSV that later runs re-use) buy?  Bounded tuning time per shape.
+PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1 PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS=50 PYTORCH_TUNABLEOP_MAX_WARMUP_DURATION_MS=5 \
+  PYTORCH_TUNABLEOP_FILENAME=gpurun_out/r03_tunableop.csv timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-lang-b64 --no-experimental \
+  > gpurun_out/r03_bench1_tunableop.log 2>&1; tail -1 gpurun_out/r03_bench1_tunableop.log | cut -c1-200; wc -l gpurun_out/r03_tunableop*.csv 2>/dev/null
