@@ -463,7 +463,7 @@ def _experimental_attention_worker():
     print(json.dumps(res), flush=True)
 
 
-def experimental_attention(timeout=180):
+def experimental_attention(timeout=120):
     import subprocess
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--experimental-attention-worker"], capture_output=True, text=True,
@@ -476,7 +476,7 @@ def experimental_attention(timeout=180):
         return {"error": f"worker exceeded {timeout} s"}
 
 
-def experimental_bf16_glip_l(timeout=200):
+def experimental_bf16_glip_l(timeout=150):
     """BASELINE.json configs[3] as named (MQ-GLIP-L, bs = 4, bf16 MFMA) -- the bf16 builds were added after round 2's GPU budget was
     spent: the default run takes their first device number in a subprocess (5 timed steps) and keeps a summary of its line."""
     import subprocess
@@ -493,7 +493,7 @@ def experimental_bf16_glip_l(timeout=200):
         return {"error": f"worker exceeded {timeout} s"}
 
 
-def experimental_e2e(env, timeout=150):
+def experimental_e2e(env, timeout=100):
     """The headline workload once more (10 timed steps in a subprocess) with opt-in kernels switched on through `env`:
     MQ_LN_VARIANT=2 + MQ_OFFSET_CONV_VARIANT=2 + MQ_PATCH_MERGE_FUSED=1 (load-batched LayerNorm / offset conv, patch merging without the
     cat pass: bit-identical results) / MQ_ATTN_RESIDENT=1 (S^T attention kernels; the text chain runs
@@ -679,12 +679,12 @@ def main():
                 res["lang_path_b64_resident"] = experimental_attention()
                 # e2e A/B of the opt-in kernels, most likely gain first; each only while the whole run stays within a few minutes
                 ab = []
-                for env, limit in (({"MQ_LN_VARIANT": "2", "MQ_OFFSET_CONV_VARIANT": "2", "MQ_PATCH_MERGE_FUSED": "1"}, 170),
-                                   ({"MQ_ATTN_RESIDENT": "1"}, 150)):
+                for env, limit in (({"MQ_LN_VARIANT": "2", "MQ_OFFSET_CONV_VARIANT": "2", "MQ_PATCH_MERGE_FUSED": "1"}, 150),
+                                   ({"MQ_ATTN_RESIDENT": "1"}, 130)):
                     if time.perf_counter() - t_start < limit:
                         ab.append(experimental_e2e(env))
                 res["opt_in_kernels_ab"] = ab
-                if time.perf_counter() - t_start < 140:
+                if time.perf_counter() - t_start < 110:
                     res["mq_glip_l_bf16"] = experimental_bf16_glip_l()
             if world == 1 and not args.no_cpu_baseline and not large:
                 try:
