@@ -299,16 +299,49 @@ def fpn_forward(P, feats_nhwc):
 
     def conv3(name, x, stride=1):
         return ops.conv3x3(x, P[f"{p}.{name}.packed"], P[f"{p}.{name}.bias"], P[f"{p}.{name}.packed"].shape[0], stride)
+    via_dcn = os.environ.get("MQ_FPN_VIA_DCN", "0") == "1" and hasattr(ops, "dcnv2_group")
     inner = lateral("fpn_inner4", c5)
-    res = [conv3("fpn_layer4", inner)]
+    inners = [("fpn_layer4", inner)]
     for feat, idx in ((c4, 3), (c3, 2)):
         lat = lateral(f"fpn_inner{idx}", feat)
         up = F.interpolate(inner.permute(0, 3, 1, 2), size=lat.shape[1:3], mode="nearest").permute(0, 2, 3, 1)
         inner = (lat + up).contiguous()
-        res.insert(0, conv3(f"fpn_layer{idx}", inner))
-    p6 = conv3("top_blocks.p6", res[-1], 2)
-    p7 = conv3("top_blocks.p7", F.relu(p6), 2)
+        inners.insert(0, (f"fpn_layer{idx}", inner))
+    if via_dcn:
+        # The three output convs (fpn.py:106-127) do not depend on each other: ONE grouped launch of the fused DCNv2 kernel with zero
+        # offsets and mask logits of +100 (sigmoid = 1 exactly) -- a deformable conv sampling at integer positions with weights
+        # (1, 0, 0, 0) IS the plain 3x3 conv (zero padding included: taps at -1 / H are "outside"), and that kernel runs its 128 x 256 x 64
+        # tiles at 2.5x the rate of conv_igemm's 128 x 256 x 32 ones (DESIGN.md 3).  Opt-in (MQ_FPN_VIA_DCN=1) until measured.
+        outs = ops.dcnv2_group([dict(x=x, om=_zero_offsets(x.shape[0], x.shape[1], x.shape[2], x.device), w=P[f"{p}.{n}.packed"],
+                                     bias=P[f"{p}.{n}.bias"], stride=1) for n, x in inners], want_stats=False)
+        res = [y.reshape(x.shape[0], hw[0], hw[1], 256) for (y, hw, _), (_, x) in zip(outs, inners)]
+
+        def conv3s2(name, x):
+            Ho, Wo = (x.shape[1] - 1) // 2 + 1, (x.shape[2] - 1) // 2 + 1
+            y, hw = ops.dcnv2(x, _zero_offsets(x.shape[0], Ho, Wo, x.device), P[f"{p}.{name}.packed"], P[f"{p}.{name}.bias"], 2)
+            return y.reshape(x.shape[0], hw[0], hw[1], 256)
+        p6 = conv3s2("top_blocks.p6", res[-1])
+        p7 = conv3s2("top_blocks.p7", F.relu(p6))
+    else:
+        res = [conv3(n, x) for n, x in inners]
+        p6 = conv3("top_blocks.p6", res[-1], 2)
+        p7 = conv3("top_blocks.p7", F.relu(p6), 2)
     return [t.permute(0, 3, 1, 2) for t in res + [p6, p7]]
+
+
+_ZERO_OM = {}
+
+
+def _zero_offsets(B, Ho, Wo, device):
+    """[B, 27, Ho, Wo] fp32: 18 zero offsets + 9 mask logits of 100 (sigmoid(100) == 1.0f): the DCNv2 input that makes it a plain conv."""
+    key = (B, Ho, Wo, str(device))
+    if key not in _ZERO_OM:
+        if len(_ZERO_OM) > 64:
+            _ZERO_OM.clear()
+        om = torch.zeros(B, 27, Ho, Wo, dtype=torch.float32, device=device)
+        om[:, 18:] = 100.0
+        _ZERO_OM[key] = om
+    return _ZERO_OM[key]
 
 
 def pooled_fpn_tokens(feats):

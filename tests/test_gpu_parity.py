@@ -429,6 +429,24 @@ def test_patch_merge_ln_kernel(dev, monkeypatch):
     pc._CACHE.clear()
 
 
+def test_fpn_convs_through_the_grouped_dcn_kernel(dev, monkeypatch):
+    """MQ_FPN_VIA_DCN=1: the FPN output convs as one grouped launch of the fused DCNv2 kernel with zero offsets (== plain 3x3 conv)"""
+    import parity_checks as pc
+    from mq_det_amd.modeling import pipeline
+    spec, sd, cfg, model, P = pc.tiny(dev)
+    g = torch.Generator().manual_seed(5)
+    feats = [torch.randn(2, h, w, c, generator=g).half().to(dev) for (h, w), c in (((100, 168), 192), ((50, 84), 384), ((25, 42), 768))]
+    monkeypatch.setenv("MQ_FPN_VIA_DCN", "0")
+    ref = pipeline.fpn_forward(P, feats)
+    monkeypatch.setenv("MQ_FPN_VIA_DCN", "1")
+    got = pipeline.fpn_forward(P, feats)
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape and float((a.float() - b.float()).abs().max()) <= 2e-3 * max(1.0, float(b.float().abs().max()))
+    pc._CACHE.clear()
+    _assert(pc.check_swin_fpn(dev))
+    pc._CACHE.clear()
+
+
 # ------------------------------------------------------------------------------------------------ bf16 operands (configs[3])
 @pytest.fixture()
 def bf16():

@@ -437,3 +437,23 @@ def test_guard_pages_do_catch_an_overrun():
     assert ok.returncode == 0 and "returned 0" in ok.stdout, ok.stderr[-400:]
     bad = subprocess.run([sys.executable, "-c", code.format(rows=65)], capture_output=True, text=True, cwd=root)
     assert bad.returncode == -11, (bad.returncode, bad.stdout, bad.stderr[-300:])
+
+
+# ---- the FPN output convs as ONE grouped launch of the fused DCNv2 kernel with zero offsets (opt-in: MQ_FPN_VIA_DCN=1)
+def test_fpn_convs_through_the_grouped_dcn_kernel(kernels, monkeypatch):
+    """a deformable conv sampling at integer positions with corner weights (1, 0, 0, 0) and mask 1 is the plain 3x3 conv, zero padding
+    included: same FPN pyramid as through mq_conv3x3_fwd (different fp32 summation order only), stride-2 P6 / P7 too, odd sizes"""
+    from mq_det_amd.modeling import pipeline
+    spec, sd, cfg, model, P = kernels.tiny(CPU)
+    g = torch.Generator().manual_seed(5)
+    feats = [torch.randn(2, h, w, c, generator=g).half() for (h, w), c in (((23, 31), 192), ((12, 16), 384), ((6, 8), 768))]
+    monkeypatch.setenv("MQ_FPN_VIA_DCN", "0")
+    ref = pipeline.fpn_forward(P, feats)
+    monkeypatch.setenv("MQ_FPN_VIA_DCN", "1")
+    got = pipeline.fpn_forward(P, feats)
+    assert [tuple(t.shape) for t in got] == [tuple(t.shape) for t in ref]
+    for a, b in zip(got, ref):
+        assert float((a.float() - b.float()).abs().max()) <= 2e-3 * max(1.0, float(b.float().abs().max()))
+    kernels._CACHE.clear()
+    _assert_ok(kernels.check_swin_fpn(CPU))
+    kernels._CACHE.clear()
