@@ -496,7 +496,7 @@ def experimental_bf16_glip_l(timeout=150):
 def experimental_e2e(env, timeout=100):
     """The headline workload once more (10 timed steps in a subprocess) with opt-in kernels switched on through `env`:
     MQ_LN_VARIANT=2 + MQ_OFFSET_CONV_VARIANT=2 + MQ_PATCH_MERGE_FUSED=1 (load-batched LayerNorm / offset conv, patch merging without the
-    cat pass: bit-identical results) + MQ_FPN_VIA_DCN=1 (the FPN output convs as one grouped launch of the fused DCNv2 kernel) / MQ_ATTN_RESIDENT=1 (S^T attention kernels; the text chain runs
+    cat pass: bit-identical results) + MQ_FPN_VIA_DCN=1 (the FPN output convs as one grouped launch of the fused DCNv2 kernel) + MQ_NMS_EARLY_STOP=1 (NMS sweep ends at 300 kept) / MQ_ATTN_RESIDENT=1 (S^T attention kernels; the text chain runs
     beside the image chain).  A/B against `value` of this line, same box, same process environment otherwise."""
     import subprocess
     try:
@@ -675,12 +675,13 @@ def main():
             if world == 1 and not args.no_lang_b64 and not args.no_experimental and not large and args.dtype == "f16" and \
                     os.environ.get("MQ_ATTN_RESIDENT", "0") != "1" and os.environ.get("MQ_LN_VARIANT", "1") != "2" and \
                     os.environ.get("MQ_OFFSET_CONV_VARIANT", "1") != "2" and os.environ.get("MQ_PATCH_MERGE_FUSED", "0") != "1" and \
-                    os.environ.get("MQ_FPN_VIA_DCN", "0") != "1":
+                    os.environ.get("MQ_FPN_VIA_DCN", "0") != "1" and os.environ.get("MQ_NMS_EARLY_STOP", "0") != "1":
                 # first device numbers of the opt-in S^T attention kernels, isolated in a subprocess
                 res["lang_path_b64_resident"] = experimental_attention()
                 # e2e A/B of the opt-in kernels, most likely gain first; each only while the whole run stays within a few minutes
                 ab = []
-                for env, limit in (({"MQ_LN_VARIANT": "2", "MQ_OFFSET_CONV_VARIANT": "2", "MQ_PATCH_MERGE_FUSED": "1", "MQ_FPN_VIA_DCN": "1"}, 150),
+                for env, limit in (({"MQ_LN_VARIANT": "2", "MQ_OFFSET_CONV_VARIANT": "2", "MQ_PATCH_MERGE_FUSED": "1", "MQ_FPN_VIA_DCN": "1",
+                                    "MQ_NMS_EARLY_STOP": "1"}, 150),
                                    ({"MQ_ATTN_RESIDENT": "1"}, 130)):
                     if time.perf_counter() - t_start < limit:
                         ab.append(experimental_e2e(env))

@@ -290,6 +290,13 @@ long mq_ml_nms_workspace_bytes(int B, int N);
 int mq_ml_nms(const float* boxes, const int* labels, const int* nvalid, void* workspace, unsigned char* keep,
               int B, int N, float thr, void* stream);
 
+/* The same NMS that stops sweeping an image once max_keep of its boxes are kept: with score-sorted input the first max_keep survivors
+ * are the max_keep highest-scoring ones, all the caller uses (rpn/inference.py:757-766); keep[] is 0 behind the stopping chunk.
+ * N <= 6656 (-1 beyond: use mq_ml_nms).  Opt-in from the host (MQ_NMS_EARLY_STOP=1): written after round 2's GPU budget was spent,
+ * checked through tests/simt (csrc/nms2.hip). */
+int mq_ml_nms_topk(const float* boxes, const int* labels, const int* nvalid, void* workspace, unsigned char* keep,
+                   int B, int N, float thr, int max_keep, void* stream);
+
 /* ---- bf16 operands (BASELINE.json configs[3]: "MQ-GLIP-L ... bf16 MFMA").
  * Every entry point that reads or writes 16-bit operands exists twice: `name` as declared above (fp16, v_mfma_f32_16x16x32_f16) and
  * `name_bf16` -- the SAME kernel source compiled with bf16 operands (v_mfma_f32_16x16x32_bf16; fp32 accumulation, fp32 side inputs and

@@ -821,7 +821,7 @@ def postprocess(cfg, head, anchors, im_wh, tokidx, label_ids, want_cls=False):
     labels = torch.gather(labels, 1, order.to(torch.int64)).contiguous()
     boxes = torch.gather(boxes, 1, order[:, :, None].expand(-1, -1, 4)).contiguous()
     nvalid = (scores > 0).sum(1).to(torch.int32)
-    keep = ops.ml_nms(boxes, labels, nvalid, A.NMS_TH)
+    keep = ops.ml_nms(boxes, labels, nvalid, A.NMS_TH, max_keep=max(0, int(A.DETECTIONS_PER_IMG)))
     kept_scores = torch.where(keep, scores, torch.full_like(scores, -1.0))
     K = min(A.DETECTIONS_PER_IMG, tot) if A.DETECTIONS_PER_IMG > 0 else tot
     top, ti = torch.topk(kept_scores, K, dim=1, sorted=True)

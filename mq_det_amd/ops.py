@@ -47,6 +47,7 @@ _SIGNATURES = {
     "mq_msdeform_attn_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_msdeform_attn_q_fwd": (_i, [_vp, _i, _l, _l, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_ml_nms_workspace_bytes": (_l, [_i, _i]),
+    "mq_ml_nms_topk": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
     "mq_ml_nms": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
 }
 # entry points with 16-bit operands also exist as <name>_bf16 (same signature; include/mqdet_hip.h MQ_BF16_TWIN)
@@ -739,8 +740,10 @@ def ms_deform_attn_q(value, spatial_shapes, qproj, ref, heads, out_dtype=None, v
     return out
 
 
-def ml_nms(boxes, labels, nvalid, thresh):
-    """boxes [B,N,4] fp32 sorted by score desc, labels [B,N] int32, nvalid [B] int32 -> keep [B,N] bool."""
+def ml_nms(boxes, labels, nvalid, thresh, max_keep=0):
+    """boxes [B,N,4] fp32 sorted by score desc, labels [B,N] int32, nvalid [B] int32 -> keep [B,N] bool.
+    max_keep > 0 together with MQ_NMS_EARLY_STOP=1: the sweep of an image ends once max_keep boxes are kept (mq_ml_nms_topk; the
+    max_keep highest-scoring survivors are the same, later boxes read as not kept)."""
     lib = load_library()
     _need_gpu(boxes, labels, nvalid)
     B, N, _ = boxes.shape
@@ -748,6 +751,10 @@ def ml_nms(boxes, labels, nvalid, thresh):
     assert labels.dtype == torch.int32 and nvalid.dtype == torch.int32
     ws = torch.empty(max(lib.mq_ml_nms_workspace_bytes(B, N), 8), dtype=torch.uint8, device=boxes.device)
     keep = torch.empty(B, N, dtype=torch.uint8, device=boxes.device)
+    if max_keep > 0 and N <= 6656 and os.environ.get("MQ_NMS_EARLY_STOP", "0") == "1":
+        _chk(lib.mq_ml_nms_topk(_ptr(boxes), _ptr(labels), _ptr(nvalid), _ptr(ws), _ptr(keep), B, N, float(thresh), int(max_keep), _stream()),
+             "mq_ml_nms_topk")
+        return keep.bool()
     _chk(lib.mq_ml_nms(_ptr(boxes), _ptr(labels), _ptr(nvalid), _ptr(ws), _ptr(keep), B, N, float(thresh), _stream()),
          "mq_ml_nms")
     return keep.bool()

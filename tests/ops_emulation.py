@@ -170,7 +170,7 @@ def box_decode(val, flat, reg, anchors, label_ids, im_wh, boxes, scores, labels,
     labels[:, out_off:out_off + K] = torch.where(ok, lab, torch.zeros_like(lab))
 
 
-def ml_nms(boxes, labels, nvalid, thresh):
+def ml_nms(boxes, labels, nvalid, thresh, max_keep=0):
     from oracle.postprocess import ml_nms as ref
     B, N, _ = boxes.shape
     keep = torch.zeros(B, N, dtype=torch.bool)

@@ -447,6 +447,28 @@ def test_fpn_convs_through_the_grouped_dcn_kernel(dev, monkeypatch):
     pc._CACHE.clear()
 
 
+def test_nms_early_stop(dev, monkeypatch):
+    """mq_ml_nms_topk (MQ_NMS_EARLY_STOP=1): the max_keep best survivors equal mq_ml_nms's, nothing else is kept; post-processing on it"""
+    import parity_checks as pc
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(13)
+    B, N = 8, 5000
+    xy = torch.rand(B, N, 2, generator=g) * 600
+    boxes = torch.cat([xy, xy + 15 + torch.rand(B, N, 2, generator=g) * 60], -1).contiguous().to(dev)
+    labels = torch.randint(1, 41, (B, N), generator=g, dtype=torch.int32).to(dev)
+    nvalid = torch.tensor([5000, 4100, 3000, 700, 130, 64, 1, 0], dtype=torch.int32).to(dev)
+    monkeypatch.setenv("MQ_NMS_EARLY_STOP", "0")
+    full = ops.ml_nms(boxes, labels, nvalid, 0.6).cpu()
+    monkeypatch.setenv("MQ_NMS_EARLY_STOP", "1")
+    for K in (1, 100, 300, 6000):
+        part = ops.ml_nms(boxes, labels, nvalid, 0.6, max_keep=K).cpu()
+        for b in range(B):
+            kf, kp = full[b].nonzero().flatten(), part[b].nonzero().flatten()
+            n = min(K, len(kf))
+            assert len(kp) >= n and torch.equal(kp[:n], kf[:n]) and bool((part[b] <= full[b]).all()), (K, b)
+    _assert(pc.check_post_golden(dev))
+
+
 # ------------------------------------------------------------------------------------------------ bf16 operands (configs[3])
 @pytest.fixture()
 def bf16():

@@ -399,7 +399,8 @@ def _oob(mode, names, env=None, timeout=1200):
     return r.returncode, [ln for ln in r.stdout.splitlines() if ln.startswith(("OK", "MISMATCH"))], r.stderr[-600:]
 
 
-OPT_IN = {"MQ_ATTN_RESIDENT": "1", "MQ_LN_VARIANT": "2", "MQ_OFFSET_CONV_VARIANT": "2", "MQ_PATCH_MERGE_FUSED": "1"}
+OPT_IN = {"MQ_ATTN_RESIDENT": "1", "MQ_LN_VARIANT": "2", "MQ_OFFSET_CONV_VARIANT": "2", "MQ_PATCH_MERGE_FUSED": "1", "MQ_FPN_VIA_DCN": "1",
+          "MQ_NMS_EARLY_STOP": "1"}
 
 
 @pytest.mark.parametrize("mode", ["end", "start"])
@@ -415,7 +416,7 @@ def test_no_kernel_touches_memory_outside_its_buffers(mode):
     rc, lines, err = _oob(mode, names)
     assert rc == 0 and lines == ["OK " + n for n in names], (rc, lines, err)
     names = ["attention_small", "check_attention_strided", "check_layernorm", "check_pre_select", "check_conv3x3", "check_swin_fpn",
-             "check_attention_qk_mask"]
+             "check_attention_qk_mask", "check_post_golden"]
     rc, lines, err = _oob(mode, names, OPT_IN)
     assert rc == 0 and lines == ["OK " + n for n in names], (rc, lines, err)
 
@@ -457,3 +458,38 @@ def test_fpn_convs_through_the_grouped_dcn_kernel(kernels, monkeypatch):
     kernels._CACHE.clear()
     _assert_ok(kernels.check_swin_fpn(CPU))
     kernels._CACHE.clear()
+
+
+# ---- NMS that stops once max_keep boxes of an image are kept (csrc/nms2.hip, opt-in: MQ_NMS_EARLY_STOP=1)
+def test_nms_early_stop_keeps_the_same_top_detections(kernels, monkeypatch):
+    """score-sorted input: the first max_keep survivors of mq_ml_nms_topk are those of mq_ml_nms, nothing is kept behind the stopping
+    chunk, images of one batch stop at different chunks; under permuted wave schedules (the stop flag is read by all five waves of the
+    workgroup); then the golden post-processing and the tiny full model with the switch on"""
+    import simt
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(13)
+    B, N = 3, 1500
+    xy = torch.rand(B, N, 2, generator=g) * 300
+    boxes = torch.cat([xy, xy + 15 + torch.rand(B, N, 2, generator=g) * 50], -1).contiguous()
+    labels = torch.randint(1, 5, (B, N), generator=g, dtype=torch.int32)
+    nvalid = torch.tensor([1500, 700, 130], dtype=torch.int32)
+    monkeypatch.setenv("MQ_NMS_EARLY_STOP", "0")
+    full = ops.ml_nms(boxes, labels, nvalid, 0.6)
+    for mode in (("ascending", 0), ("descending", 0), ("random", 7)):
+        simt.set_schedule(*mode)
+        try:
+            for K in (1, 50, 100, 300, 5000):
+                monkeypatch.setenv("MQ_NMS_EARLY_STOP", "1")
+                part = ops.ml_nms(boxes, labels, nvalid, 0.6, max_keep=K)
+                for b in range(B):
+                    kf, kp = full[b].nonzero().flatten(), part[b].nonzero().flatten()
+                    n = min(K, len(kf))
+                    assert len(kp) >= n and torch.equal(kp[:n], kf[:n]), (mode, K, b)          # the K best survivors are the same
+                    assert bool((part[b] <= full[b]).all())                                      # and nothing else is ever kept
+                    if len(kf) > K:
+                        assert len(kp) < len(kf) or K >= len(kf) - 63                            # the sweep really stopped early
+        finally:
+            simt.set_schedule("ascending")
+    monkeypatch.setenv("MQ_NMS_EARLY_STOP", "1")
+    _assert_ok(kernels.check_post_golden(CPU))
+    _assert_ok(kernels.check_score_agg(CPU))

@@ -16,7 +16,7 @@ lp = d.get("lang_path_b64", {})
 print("$f", d["value"], {k: lp.get(k) for k in ("ms_language_path", "attention_kernels_ms", "attention_mfma_utilisation")}, lp.get("kernels_ms"))
 PY
 done
-MQ_LN_VARIANT=2 MQ_OFFSET_CONV_VARIANT=2 MQ_PATCH_MERGE_FUSED=1 MQ_FPN_VIA_DCN=1 timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-lang-b64 --no-experimental > gpurun_out/r03_bench1_ln2.log 2>&1; tail -1 gpurun_out/r03_bench1_ln2.log | cut -c1-200
+MQ_LN_VARIANT=2 MQ_OFFSET_CONV_VARIANT=2 MQ_PATCH_MERGE_FUSED=1 MQ_FPN_VIA_DCN=1 MQ_NMS_EARLY_STOP=1 timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-lang-b64 --no-experimental > gpurun_out/r03_bench1_ln2.log 2>&1; tail -1 gpurun_out/r03_bench1_ln2.log | cut -c1-200
 # 3. BASELINE configs[3]: MQ-GLIP-L on bf16 MFMA (default of the workload) next to fp16
 timeout 200 python bench.py --workload mq-glip-l --steps 10 --warmup 3 > gpurun_out/r03_bench1_glipl_bf16.log 2>&1; tail -1 gpurun_out/r03_bench1_glipl_bf16.log | cut -c1-200
 timeout 200 python bench.py --workload mq-glip-l --dtype f16 --steps 10 --warmup 3 > gpurun_out/r03_bench1_glipl_f16.log 2>&1; tail -1 gpurun_out/r03_bench1_glipl_f16.log | cut -c1-200
