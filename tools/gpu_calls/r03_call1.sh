@@ -27,3 +27,13 @@ MQ_ATTN_RESIDENT=1 timeout 200 python bench.py --workload mq-gdino-t --steps 10 
 PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1 PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS=50 PYTORCH_TUNABLEOP_MAX_WARMUP_DURATION_MS=5 \
   PYTORCH_TUNABLEOP_FILENAME=gpurun_out/r03_tunableop.csv timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-lang-b64 --no-experimental \
   > gpurun_out/r03_bench1_tunableop.log 2>&1; tail -1 gpurun_out/r03_bench1_tunableop.log | cut -c1-200; wc -l gpurun_out/r03_tunableop*.csv 2>/dev/null
+# 6. the opt-in variants one by one (attribution; the default bench run of round 2 only A/B'd them as a group)
+for v in MQ_LN_VARIANT=2 MQ_OFFSET_CONV_VARIANT=2 MQ_PATCH_MERGE_FUSED=1 MQ_FPN_VIA_DCN=1 MQ_NMS_EARLY_STOP=1; do
+  env $v timeout 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-lang-b64 --no-experimental > gpurun_out/r03_bench1_$v.log 2>&1
+  echo "$v: $(tail -1 gpurun_out/r03_bench1_$v.log | cut -c1-120)"
+done
+# 7. kernel statistics of the default step and of the step with every variant on
+export TMPDIR=/tmp
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/r03_prof_default -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-graph --no-cpu-baseline --no-lang-b64 --no-experimental > /dev/null 2>&1)
+(cd /tmp && MQ_LN_VARIANT=2 MQ_OFFSET_CONV_VARIANT=2 MQ_PATCH_MERGE_FUSED=1 MQ_FPN_VIA_DCN=1 MQ_NMS_EARLY_STOP=1 MQ_ATTN_RESIDENT=1 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/r03_prof_variants -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-graph --no-cpu-baseline --no-lang-b64 --no-experimental > /dev/null 2>&1)
+find gpurun_out -name "*kernel_stats.csv" | head
