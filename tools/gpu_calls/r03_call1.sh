@@ -32,8 +32,14 @@ for v in MQ_LN_VARIANT=2 MQ_OFFSET_CONV_VARIANT=2 MQ_PATCH_MERGE_FUSED=1 MQ_FPN_
   env $v timeout 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-lang-b64 --no-experimental > gpurun_out/r03_bench1_$v.log 2>&1
   echo "$v: $(tail -1 gpurun_out/r03_bench1_$v.log | cut -c1-120)"
 done
-# 7. kernel statistics of the default step and of the step with every variant on
+# 7. kernel statistics of the default step and of the step with every variant on (eager launches; only the stats CSVs are kept)
 export TMPDIR=/tmp
-(cd /tmp && rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/r03_prof_default -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-graph --no-cpu-baseline --no-lang-b64 --no-experimental > /dev/null 2>&1)
-(cd /tmp && MQ_LN_VARIANT=2 MQ_OFFSET_CONV_VARIANT=2 MQ_PATCH_MERGE_FUSED=1 MQ_FPN_VIA_DCN=1 MQ_NMS_EARLY_STOP=1 MQ_ATTN_RESIDENT=1 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/r03_prof_variants -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-graph --no-cpu-baseline --no-lang-b64 --no-experimental > /dev/null 2>&1)
-find gpurun_out -name "*kernel_stats.csv" | head
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_default -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-graph \
+  --no-cpu-baseline --no-lang-b64 --no-experimental > $R/gpurun_out/r03_prof_default.log 2>&1
+MQ_LN_VARIANT=2 MQ_OFFSET_CONV_VARIANT=2 MQ_PATCH_MERGE_FUSED=1 MQ_FPN_VIA_DCN=1 MQ_NMS_EARLY_STOP=1 MQ_ATTN_RESIDENT=1 \
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_variants -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-graph \
+  --no-cpu-baseline --no-lang-b64 --no-experimental > $R/gpurun_out/r03_prof_variants.log 2>&1
+cd $R
+for t in default variants; do f=$(find /tmp/prof_$t -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f gpurun_out/r03_call1_${t}_kernel_stats.csv && head -25 $f | cut -c1-160; done
