@@ -47,6 +47,7 @@ void* dyn_smem();
 void wave_sync();                                    // all live lanes of the wave
 void wave_sync_then(void (*fn)(void*), void* ctx);   // the same; the LAST lane to arrive runs fn(ctx) before anybody continues
 float* wave_tile(int buf);                           // [256] fp32 result buffer of the current wave (per exchange buffer)
+float* wave_tile32();                                // [1024] fp32 result buffer of the current wave (32 x 32 MFMA)
 void block_sync();                                   // all live threads of the workgroup
 uint64_t* xslot(int lane, int buf);                  // exchange slots of the current wave: [2][64][4] x 8 bytes
 int next_buf();                                      // alternating buffer index per collective
@@ -167,6 +168,48 @@ inline simt_float4 simt_mfma_16x16x32(V8 a, V8 b, simt_float4 c) {
   for (int r = 0; r < 4; ++r) c[r] += D[(r0 + r) * 16 + col];
   return c;
 }
+// v_mfma_f32_32x32x16_{f16,bf16} (for the kernels of the next round; layout assumed from the 32x32x8 family, to be confirmed on the
+// device with tools/mfma_layout_probe.hip): A lane l = A[l & 31][8 (l >> 5) ..], B lane l = B[8 (l >> 5) ..][l & 31],
+// D lane l, register 4 i + j = D[8 i + 4 (l >> 5) + j][l & 31]
+typedef float simt_float16 __attribute__((ext_vector_type(16)));
+template <class V8>
+inline void simt_mfma32_tile(void* ctx) {
+  const int buf = (int)(intptr_t)ctx;
+  float A[32][16], B[16][32];
+  for (int l = 0; l < 64; ++l) {
+    V8 a, b;
+    const uint64_t* s = simt::xslot(l, buf);
+    memcpy(&a, s, 16);
+    memcpy(&b, s + 2, 16);
+    for (int j = 0; j < 8; ++j) {
+      A[l & 31][8 * (l >> 5) + j] = (float)a[j];
+      B[8 * (l >> 5) + j][l & 31] = (float)b[j];
+    }
+  }
+  float* D = simt::wave_tile32();
+  for (int i = 0; i < 32; ++i)
+    for (int n = 0; n < 32; ++n) {
+      float acc = 0.f;
+      for (int k = 0; k < 16; ++k) acc += A[i][k] * B[k][n];
+      D[i * 32 + n] = acc;
+    }
+}
+template <class V8>
+inline simt_float16 simt_mfma_32x32x16(V8 a, V8 b, simt_float16 c) {
+  const int buf = simt::next_buf(), l = simt::lane();
+  uint64_t* s = simt::xslot(l, buf);
+  memcpy(s, &a, 16);
+  memcpy(s + 2, &b, 16);
+  simt::wave_sync_then(&simt_mfma32_tile<V8>, (void*)(intptr_t)buf);
+  const float* D = simt::wave_tile32();
+  const int col = l & 31, h = l >> 5;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) c[4 * i + j] += D[(8 * i + 4 * h + j) * 32 + col];
+  simt::wave_sync();                                    // the single 32x32 result buffer is free again only when every lane has read it
+  return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) simt_mfma_32x32x16<simt_half8>((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) simt_mfma_32x32x16<simt_bf16x8>((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) simt_mfma_16x16x32<simt_half8>((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) simt_mfma_16x16x32<simt_bf16x8>((a), (b), (c))
 

@@ -19,6 +19,23 @@ extern "C" int simt_selftest_mfma(const void* A, const void* Bt, float* C) {
   return hipGetLastError();
 }
 
+// C[32][32] = A[32][16] . B[16][32] with ONE v_mfma_f32_32x32x16_f16 in the layout the emulation assumes (see hip_runtime.h)
+typedef float f16v __attribute__((ext_vector_type(16)));
+__global__ void st_mfma32_kernel(const _Float16* A, const _Float16* Bt, float* C) {
+  const int l = threadIdx.x, r = l & 31, h = l >> 5;
+  h8 a, b;
+  for (int j = 0; j < 8; ++j) { a[j] = A[r * 16 + 8 * h + j]; b[j] = Bt[r * 16 + 8 * h + j]; }   // Bt = B transposed: [32][16]
+  f16v c;
+  for (int i = 0; i < 16; ++i) c[i] = 0.f;
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) C[(8 * i + 4 * h + j) * 32 + r] = c[4 * i + j];
+}
+extern "C" int simt_selftest_mfma32(const void* A, const void* Bt, float* C) {
+  hipLaunchKernelGGL(st_mfma32_kernel, dim3(1), dim3(64), 0, nullptr, (const _Float16*)A, (const _Float16*)Bt, C);
+  return hipGetLastError();
+}
+
 // cross-lane: out[l] = in[l ^ 1] + in[(l + 5) & 63];  ballot of (in[l] > 0) into out64
 __global__ void st_shfl_kernel(const float* in, float* out, unsigned long long* out64) {
   const int l = threadIdx.x;

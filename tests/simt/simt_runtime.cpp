@@ -44,6 +44,7 @@ struct Wave {
   void* then_ctx;
   uint64_t x[2][64][4];
   float tile[2][256];
+  float tile32[1024];
 };
 
 struct Fiber {
@@ -119,6 +120,7 @@ static void release_block() {
 }
 
 float* wave_tile(int buf) { return waves[cur->wave].tile[buf]; }
+float* wave_tile32() { return waves[cur->wave].tile32; }
 
 static void complete_wave(int w) {                       // every live lane has arrived
   Wave& wv = waves[w];

@@ -81,6 +81,10 @@ def test_emulation_unit_kernels():
     C = torch.zeros(16, 16)
     assert lib.simt_selftest_mfma(vp(A.data_ptr()), vp(Bt.data_ptr()), vp(C.data_ptr())) == 0
     assert torch.allclose(C, A.float() @ Bt.float().t(), atol=1e-5)
+    A, Bt = torch.randn(32, 16, generator=g).half(), torch.randn(32, 16, generator=g).half()
+    C = torch.zeros(32, 32)
+    assert lib.simt_selftest_mfma32(vp(A.data_ptr()), vp(Bt.data_ptr()), vp(C.data_ptr())) == 0
+    assert torch.allclose(C, A.float() @ Bt.float().t(), atol=1e-5)
     x, y, m = torch.randn(64, generator=g), torch.zeros(64), torch.zeros(1, dtype=torch.int64)
     assert lib.simt_selftest_shfl(vp(x.data_ptr()), vp(y.data_ptr()), vp(m.data_ptr())) == 0
     idx = torch.arange(64)
