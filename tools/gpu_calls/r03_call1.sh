@@ -45,4 +45,4 @@ cd $R
 for t in default variants; do f=$(find /tmp/prof_$t -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f gpurun_out/r03_call1_${t}_kernel_stats.csv && head -25 $f | cut -c1-160; done
 
 # 0. lane layouts the emulation assumes (32x32x16 MFMA is not used by a shipped kernel yet)
-hipcc --offload-arch=gfx950 -O2 tools/mfma_layout_probe.hip -o /tmp/mfma_probe && /tmp/mfma_probe
+hipcc --offload-arch=gfx950 -O2 -Wno-unused-value tools/mfma_layout_probe.hip -o /tmp/mfma_probe 2>/dev/null && /tmp/mfma_probe
