@@ -46,3 +46,4 @@ for t in default variants; do f=$(find /tmp/prof_$t -name "*kernel_stats.csv" | 
 
 # 0. lane layouts the emulation assumes (32x32x16 MFMA is not used by a shipped kernel yet)
 hipcc --offload-arch=gfx950 -O2 -Wno-unused-value tools/mfma_layout_probe.hip -o /tmp/mfma_probe 2>/dev/null && /tmp/mfma_probe
+hipcc --offload-arch=gfx950 -O3 tools/mfma_lds_microbench.hip -o /tmp/mfma_lds 2>/dev/null && /tmp/mfma_lds | tee gpurun_out/r03_mfma_lds_microbench.txt
