@@ -18,6 +18,11 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 CPU = torch.device("cpu")
 
+# the emulation library is built with the host clang of the ROCm toolchain (tests/simt/build_emu.py); an image without it cannot run
+# these tests at all (a build that FAILS with the compiler present is an error, not a skip)
+_CXX = os.environ.get("SIMT_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+pytestmark = pytest.mark.skipif(not os.path.exists(_CXX), reason=f"{_CXX} not found: the kernel-source emulation cannot be built here")
+
 
 @pytest.fixture(scope="module")
 def kernels():
