@@ -463,7 +463,7 @@ def _experimental_attention_worker():
     print(json.dumps(res), flush=True)
 
 
-def experimental_attention(timeout=120):
+def experimental_attention(timeout=100):
     import subprocess
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--experimental-attention-worker"], capture_output=True, text=True,
@@ -493,7 +493,7 @@ def experimental_bf16_glip_l(timeout=150):
         return {"error": f"worker exceeded {timeout} s"}
 
 
-def experimental_e2e(env, timeout=100):
+def experimental_e2e(env, timeout=90):
     """The headline workload once more (10 timed steps in a subprocess) with opt-in kernels switched on through `env`:
     MQ_LN_VARIANT=2 + MQ_OFFSET_CONV_VARIANT=2 + MQ_PATCH_MERGE_FUSED=1 (load-batched LayerNorm / offset conv, patch merging without the
     cat pass: bit-identical results) + MQ_FPN_VIA_DCN=1 (the FPN output convs as one grouped launch of the fused DCNv2 kernel) + MQ_NMS_EARLY_STOP=1 (NMS sweep ends at 300 kept) / MQ_ATTN_RESIDENT=1 (S^T attention kernels; the text chain runs
