@@ -457,8 +457,10 @@ def _experimental_attention_worker():
     diff = float((outs["0"] - outs["1"])[live].abs().max())
     scale = float(outs["0"][live].abs().max())
     os.environ["MQ_ATTN_RESIDENT"] = "1"
+    os.environ["MQ_LN_VARIANT"] = "2"                        # bit-identical results; its time shows up under the layernorm_c* tags
     res = lang_path_b64(model, cfg, dev, chunks)
-    res["kernels"] = "MQ_ATTN_RESIDENT=1: mq_attn_resident_fwd (Nk <= 256) + mq_attn_chunked_fwd (pre-select) instead of mq_attn_fwd"
+    res["kernels"] = ("MQ_ATTN_RESIDENT=1: mq_attn_resident_fwd (Nk <= 256) + mq_attn_chunked_fwd (pre-select) instead of mq_attn_fwd; "
+                      "MQ_LN_VARIANT=2: mq_layernorm2_fwd (kernels_ms: layernorm_c*)")
     res["hidden_state_max_abs_diff_vs_default_kernels"] = {"max_abs_diff": round(diff, 6), "ref_absmax": round(scale, 4), "batch": Bn}
     print(json.dumps(res), flush=True)
 
