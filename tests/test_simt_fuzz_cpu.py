@@ -1,0 +1,228 @@
+"""Random-shape sweep of the kernel SOURCES (through tests/simt, on CPU) against the plain torch restatement of each operator
+(tests/ops_emulation.py): shapes the fixed parity checks do not visit -- single rows, lengths around every tile boundary, strides,
+masks that empty whole tiles, key splits with empty splits -- drawn from a seeded generator (reproducible; MQ_SIMT_FULL=1: 5x the
+draws).  Shipped kernels and the opt-in ones (MQ_ATTN_RESIDENT, MQ_LN_VARIANT, MQ_OFFSET_CONV_VARIANT) go through the same draws.
+TEST INFRASTRUCTURE ONLY (see tests/test_simt_kernels_cpu.py)."""
+import os
+import random
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+_CXX = os.environ.get("SIMT_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+pytestmark = pytest.mark.skipif(not os.path.exists(_CXX), reason=f"{_CXX} not found: the kernel-source emulation cannot be built here")
+N_DRAWS = int(os.environ.get("MQ_SIMT_DRAWS", "5" if os.environ.get("MQ_SIMT_FULL", "0") == "1" else "1"))     # multiplier of the draw counts
+TOL = 2e-3
+SEED = int(os.environ.get("MQ_SIMT_SEED", "0"))                                # offset of every generator seed: other draws
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import simt
+    with simt.installed() as o:
+        yield o
+
+
+def _close(got, ref, what, tol=TOL):
+    got, ref = got.float(), ref.float()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = float((got - ref).abs().max()) if ref.numel() else 0.0
+    scale = max(1.0, float(ref.abs().max()) if ref.numel() else 1.0)
+    assert err == err and err <= tol * scale, f"{what}: max |err| {err:.3e} vs scale {scale:.3e}"
+
+
+def _edge(rng, tiles, hi):
+    """a length at or next to a multiple of one of `tiles`, or anything in [1, hi]"""
+    if rng.random() < 0.6:
+        t = rng.choice(tiles)
+        return max(1, min(hi, t * rng.randint(1, max(1, hi // t)) + rng.choice((-1, 0, 1))))
+    return rng.randint(1, hi)
+
+
+@pytest.mark.parametrize("variant", ["streaming", "resident+chunked"])
+def test_attention_random_shapes(ops, monkeypatch, variant):
+    import ops_emulation as emu
+    monkeypatch.setenv("MQ_ATTN_RESIDENT", "1" if variant != "streaming" else "0")
+    rng = random.Random(101 + SEED)
+    g = torch.Generator().manual_seed(101 + SEED)
+    for it in range(14 * N_DRAWS):
+        B, H, D = rng.randint(1, 3), rng.randint(1, 4), rng.choice((32, 64))
+        Nq, Nk = _edge(rng, (16, 32, 128), 300), _edge(rng, (8, 16, 64, 256), 700)
+        nsplit = rng.choice((1, 1, 2, 3, 5)) if Nk > 64 else 1
+        clamp = rng.choice((0.0, 0.0, 50000.0))
+        q = (torch.randn(B, Nq, H * D, generator=g) * rng.choice((1.0, 3.0))).half()
+        k, v = torch.randn(B, Nk, H * D, generator=g).half(), torch.randn(B, Nk, H * D, generator=g).half()
+        kb = kl = None
+        if rng.random() < 0.6:                                       # padding-style mask: a tail of masked keys per batch item
+            kb, kl = torch.zeros(B, Nk), torch.zeros(B, dtype=torch.int32)
+            for b in range(B):
+                n = rng.randint(1, Nk)
+                kb[b, n:] = -1e30
+                kl[b] = n
+            if rng.random() < 0.5 and Nk > 1:
+                kb[:, rng.randrange(1, Nk)] = -1e30                  # one more masked key, possibly inside the valid range (key 0 stays)
+                kl = None if rng.random() < 0.5 else kl              # (kv_len only promises that keys >= kv_len are masked by the bias)
+            if kl is not None and rng.random() < 0.3:
+                kl = None
+        vt = F.pad(v, (0, 0, 0, (-Nk) % 8)).transpose(1, 2).contiguous()
+        ref = emu.attention4(q.view(B, Nq, H, D), k.view(B, Nk, H, D), vt.view(B, H, D, -1), kb, None, clamp, nk=Nk)
+        got = ops.attention(q, k, vt, H, D, key_bias=kb, clamp=clamp, nsplit=nsplit, nk=Nk, kv_len=kl)
+        _close(got, ref, f"attention[{variant}] draw {it}: B={B} H={H} D={D} Nq={Nq} Nk={Nk} nsplit={nsplit} clamp={clamp} mask={kb is not None} kvlen={kl is not None}")
+
+
+@pytest.mark.parametrize("variant", ["1", "2"])
+def test_layernorm_random_shapes(ops, monkeypatch, variant):
+    import ops_emulation as emu
+    monkeypatch.setenv("MQ_LN_VARIANT", variant)
+    rng = random.Random(202 + SEED)
+    g = torch.Generator().manual_seed(202 + SEED)
+    for it in range(16 * N_DRAWS):
+        C = 8 * rng.choice((1, 2, 12, 16, 17, 24, 32, 33, 48, 64, 65, 96, 128, 129, 192, 256, 257, 384))
+        rows = _edge(rng, (4, 8, 16, 64), 300)
+        x = torch.randn(rows, C, generator=g) * 2 + 0.3
+        x = x if rng.random() < 0.5 else x.half()
+        res = None
+        if rng.random() < 0.6:
+            res = torch.randn(rows, C, generator=g)
+            res = res if rng.random() < 0.5 else res.half()
+        w, b = (torch.randn(C, generator=g) * 0.1 + 1).half(), (torch.randn(C, generator=g) * 0.1).half()
+        kw = dict(residual=res, want_sum=rng.random() < 0.7, want_y32=rng.random() < 0.5)
+        ref, got = emu.layer_norm(x, w, b, 1e-5, **kw), ops.layer_norm(x, w, b, 1e-5, **kw)
+        ref, got = (ref if isinstance(ref, tuple) else (ref,)), (got if isinstance(got, tuple) else (got,))
+        assert len(ref) == len(got)
+        for i, (r, o) in enumerate(zip(ref, got)):
+            assert r.dtype == o.dtype
+            _close(o, r, f"layer_norm[v{variant}] draw {it} out {i}: rows={rows} C={C} x={x.dtype} res={None if res is None else res.dtype}")
+
+
+def test_vlfuse_random_shapes(ops):
+    import ops_emulation as emu
+    rng = random.Random(303 + SEED)
+    g = torch.Generator().manual_seed(303 + SEED)
+    for it in range(6 * N_DRAWS):
+        B, Hh = rng.randint(1, 3), rng.choice((4, 8))
+        N, T = _edge(rng, (16, 64, 128), 400), 8 * rng.randint(1, 32)
+        kv = None if rng.random() < 0.4 else torch.tensor([rng.randint(1, T) for _ in range(B)], dtype=torch.int32)
+        v_ln = torch.randn(B, N, 256, generator=g).half()
+        kf = (torch.randn(B, Hh, T, 256, generator=g) / 8).half()
+        vo = torch.randn(B, Hh, T, 256, generator=g).half()
+        bias = torch.randn(B, Hh, T, generator=g)
+        if kv is not None:
+            for b in range(B):
+                bias[b, :, int(kv[b]):] = -1e30                      # the caller's bias masks the keys beyond kv_len
+        if T > 2:
+            bias[:, :, rng.randrange(T // 2)] = -1e30               # and one key inside the valid range
+            bias[:, :, T // 2 if (kv is None or int(kv.min()) > T // 2) else 0] = 0.0
+            if kv is not None:
+                for b in range(B):
+                    if bool((bias[b, :, :int(kv[b])] < -1e29).all()):
+                        bias[b, :, 0] = 0.0
+        ob = torch.randn(256, generator=g).half()
+        ref = emu.vlfuse_i2t(v_ln.float(), kf.float(), vo.float(), bias, ob.float(), kv, 0)
+        got = ops.vlfuse_i2t(v_ln, kf, vo, bias, ob, kv, max_kv=0 if kv is None else int(kv.max()))
+        _close(got, ref, f"vlfuse_i2t draw {it}: B={B} heads={Hh} N={N} T={T} kv={None if kv is None else kv.tolist()}")
+        ns = rng.randint(1, 4)
+        ref = emu.vlfuse_t2i(kf.float(), v_ln.float(), ns, kv_len=kv)
+        got = ops.vlfuse_t2i(kf, v_ln, ns, kv_len=kv)
+        live = torch.ones(B, T, dtype=torch.bool)
+        if kv is not None:                                            # rows of all-padding 128-row tiles come back as zeros by contract
+            for b in range(B):
+                live[b, -(-int(kv[b]) // 128) * 128:] = False
+        _close(got[live], ref[live], f"vlfuse_t2i draw {it}: B={B} heads={Hh} N={N} T={T} nsplit={ns}")
+
+
+@pytest.mark.parametrize("variant", ["1", "2"])
+def test_conv_and_dcn_random_shapes(ops, monkeypatch, variant):
+    import ops_emulation as emu
+    monkeypatch.setenv("MQ_OFFSET_CONV_VARIANT", variant)
+    rng = random.Random(404 + SEED)
+    g = torch.Generator().manual_seed(404 + SEED)
+    for it in range(5 * N_DRAWS):
+        B, H, W = rng.randint(1, 2), _edge(rng, (8,), 27), _edge(rng, (16,), 37)
+        C = rng.choice((64, 128, 256))
+        x = torch.randn(B, H, W, C, generator=g).half()
+        w27 = torch.zeros(32, 9 * C, dtype=torch.float16)
+        w27[:27] = (torch.randn(27, 9 * C, generator=g) / 48).half()
+        b27 = torch.randn(27, generator=g).half()
+        _close(ops.conv3x3_nchw32(x, w27, b27, 27), emu.conv3x3_nchw32(x, w27, b27, 27), f"offset conv[v{variant}] draw {it}: {B}x{H}x{W}x{C}")
+        if variant == "2" or C != 256:
+            continue
+        stride = rng.choice((1, 2))
+        w = (torch.randn(256, 9 * C, generator=g) / 48).half()
+        bias = torch.randn(256, generator=g).half()
+        _close(ops.conv3x3(x, w, bias, 256, stride), emu.conv3x3(x, w, bias, 256, stride), f"conv3x3 draw {it}: {B}x{H}x{W} s{stride}", 3e-3)
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        om = torch.randn(B, 27, Ho, Wo, generator=g) * rng.choice((0.3, 2.0, 40.0))      # up to offsets far outside the image
+        y, hw = ops.dcnv2(x, om.contiguous(), w, bias, stride)
+        yr, hwr = emu.dcnv2(x, om, w, bias, stride)
+        assert tuple(hw) == tuple(hwr)
+        _close(y, yr, f"dcnv2 draw {it}: {B}x{H}x{W} s{stride}", 4e-3)
+
+
+def test_scoring_and_nms_random_shapes(ops, monkeypatch):
+    import ops_emulation as emu
+    rng = random.Random(505 + SEED)
+    g = torch.Generator().manual_seed(505 + SEED)
+    for it in range(8 * N_DRAWS):
+        B, HW, T = rng.randint(1, 3), _edge(rng, (4, 64), 200), rng.choice((16, 100, 255, 256))
+        L, MT = _edge(rng, (64,), 90), rng.randint(1, 5)
+        dot = (torch.randn(B, HW, T, generator=g) * 2)
+        dot = dot if rng.random() < 0.5 else dot.half()
+        tb, ctr = torch.randn(B, T, generator=g), torch.randn(B, HW, generator=g).half()
+        tok = torch.full((L, MT), -1, dtype=torch.int32)
+        for l in range(L):
+            n = rng.randint(0, MT)
+            tok[l, :n] = torch.tensor(rng.sample(range(T), n), dtype=torch.int32)
+        for agg in (0, 1, 2):
+            r, c = ops.align_scores(dot, tb, tok, ctr, 0.05, want_cls=True, agg=agg)
+            rr, cr = emu.align_scores(dot, tb, tok, ctr, 0.05, want_cls=True, agg=agg)
+            _close(c, cr, f"align_scores cls draw {it} agg={agg}: B={B} HW={HW} T={T} L={L} MT={MT}", 1e-5)
+            far = (cr - 0.05).abs() > 1e-5
+            _close(r[far], rr[far], f"align_scores ranked draw {it} agg={agg}", 1e-5)
+    for it in range(4 * N_DRAWS):
+        B, N = rng.randint(1, 3), _edge(rng, (64,), 900)
+        xy = torch.rand(B, N, 2, generator=g) * 200
+        boxes = torch.cat([xy, xy + 10 + torch.rand(B, N, 2, generator=g) * 60], -1).contiguous()
+        labels = torch.randint(1, 4, (B, N), generator=g, dtype=torch.int32)
+        nvalid = torch.tensor([rng.randint(0, N) for _ in range(B)], dtype=torch.int32)
+        monkeypatch.setenv("MQ_NMS_EARLY_STOP", "0")
+        keep = ops.ml_nms(boxes, labels, nvalid, 0.6)
+        ref = emu.ml_nms(boxes, labels, nvalid, 0.6)
+        assert torch.equal(keep, ref), f"ml_nms draw {it}: B={B} N={N} nvalid={nvalid.tolist()}"
+        monkeypatch.setenv("MQ_NMS_EARLY_STOP", "1")
+        K = rng.randint(1, 200)
+        part = ops.ml_nms(boxes, labels, nvalid, 0.6, max_keep=K)
+        for b in range(B):
+            kf, kp = keep[b].nonzero().flatten(), part[b].nonzero().flatten()
+            n = min(K, len(kf))
+            assert torch.equal(kp[:n], kf[:n]) and bool((part[b] <= keep[b]).all()), f"ml_nms_topk draw {it} K={K}"
+
+
+def test_sparse_attention_and_window_attention_random_shapes(ops):
+    import ops_emulation as emu
+    rng = random.Random(606 + SEED)
+    g = torch.Generator().manual_seed(606 + SEED)
+    for it in range(5 * N_DRAWS):
+        B, T, V, S = rng.randint(1, 2), _edge(rng, (32,), 80), rng.randint(1, 60), rng.choice((1, 5, 8, 9, 16, 17, 25))
+        q, kv = torch.randn(B, T, 512, generator=g).half(), torch.randn(B, V, 1024, generator=g).half()
+        idx = torch.full((B, T, S), -1, dtype=torch.int32)
+        for b in range(B):
+            for t in range(T):
+                n = rng.choice((0, 0, S, rng.randint(0, S)))
+                n = min(n, V)
+                idx[b, t, :n] = torch.tensor(rng.sample(range(V), n), dtype=torch.int32)
+        _close(ops.gcp_sparse_attention(q, kv, idx), emu.gcp_sparse_attention(q, kv, idx), f"gcp_sparse draw {it}: B={B} T={T} V={V} S={S}")
+    for it in range(4 * N_DRAWS):
+        ws, heads = rng.choice(((7, 3), (7, 6), (12, 3)))
+        C = heads * 32
+        B, H, W = rng.randint(1, 2), rng.randint(1, 2 * ws + 3), rng.randint(1, 2 * ws + 3)
+        shift = rng.choice((0, ws // 2))
+        qkv = torch.randn(B, H, W, 3 * C, generator=g).half()
+        qb = torch.randn(3 * C, generator=g).half()
+        rel = torch.randn(heads, ws * ws, ws * ws, generator=g)
+        _close(ops.window_attention(qkv, qb, rel, heads, ws, shift), emu.window_attention(qkv, qb, rel, heads, ws, shift),
+               f"window_attention draw {it}: B={B} {H}x{W} ws={ws} heads={heads} shift={shift}", 3e-3)
