@@ -226,3 +226,80 @@ def test_sparse_attention_and_window_attention_random_shapes(ops):
         rel = torch.randn(heads, ws * ws, ws * ws, generator=g)
         _close(ops.window_attention(qkv, qb, rel, heads, ws, shift), emu.window_attention(qkv, qb, rel, heads, ws, shift),
                f"window_attention draw {it}: B={B} {H}x{W} ws={ws} heads={heads} shift={shift}", 3e-3)
+
+
+def test_swin_mlp_roi_align_and_msdeform_random_shapes(ops):
+    import math
+    import ops_emulation as emu
+    rng = random.Random(707 + SEED)
+    g = torch.Generator().manual_seed(707 + SEED)
+    for it in range(4 * N_DRAWS):
+        C, M = rng.choice((96, 192, 384)), _edge(rng, (16, 32, 64, 128), 400)
+        x = torch.randn(M, C, generator=g) * 1.5
+        delta = (torch.randn(M, C, generator=g) * 0.5).half() if rng.random() < 0.7 else None
+        lg, lb = (torch.randn(C, generator=g) * 0.1 + 1).half(), (torch.randn(C, generator=g) * 0.1).half()
+        w1, b1 = (torch.randn(4 * C, C, generator=g) / math.sqrt(C)).half(), (torch.randn(4 * C, generator=g) * 0.1).half()
+        w2, b2 = (torch.randn(C, 4 * C, generator=g) / math.sqrt(4 * C)).half(), (torch.randn(C, generator=g) * 0.1).half()
+        w2p = w2[:, ops.swin_mlp_w2_perm(4 * C)].contiguous()
+        nxt = ((torch.randn(C, generator=g) * 0.1 + 1).half(), (torch.randn(C, generator=g) * 0.1).half(), 1e-5) if rng.random() < 0.6 else None
+        got, ref = ops.swin_mlp(x, delta, lg, lb, 1e-5, w1, b1, w2p, b2, next_ln=nxt), emu.swin_mlp(x, delta, lg, lb, 1e-5, w1, b1, w2p, b2, next_ln=nxt)
+        got, ref = (got if isinstance(got, tuple) else (got,)), (ref if isinstance(ref, tuple) else (ref,))
+        for i, (a, b) in enumerate(zip(got, ref)):
+            _close(a, b, f"swin_mlp draw {it} out {i}: C={C} M={M} delta={delta is not None} next={nxt is not None}", 2e-3 if i else 1e-3)
+    for it in range(4 * N_DRAWS):
+        N, C, H, W = rng.randint(1, 2), rng.choice((8, 64, 256)), rng.randint(1, 30), rng.randint(1, 40)
+        feat = torch.randn(N, C, H, W, generator=g)
+        f16 = feat.half().permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)                 # NHWC memory, NCHW view
+        R = rng.randint(1, 9)
+        x1, y1 = torch.rand(R, generator=g) * W * 16 - 24, torch.rand(R, generator=g) * H * 16 - 24     # partly outside the image
+        rois = torch.stack([torch.randint(0, N, (R,), generator=g).float(), x1, y1, x1 + torch.rand(R, generator=g) * 200,
+                            y1 + torch.rand(R, generator=g) * 200], 1)
+        for aligned in (False, True):
+            sr = rng.choice((0, 2))
+            for f in (f16, feat):
+                _close(ops.roi_align(f, rois, 7, 1.0 / 16, sr, aligned=aligned), emu.roi_align(f, rois, 7, 1.0 / 16, sr, aligned=aligned),
+                       f"roi_align draw {it}: {N}x{C}x{H}x{W} R={R} aligned={aligned} sr={sr} {f.dtype}", 1e-4)
+    for it in range(3 * N_DRAWS):
+        B, M, D = rng.randint(1, 2), 8, 32
+        shapes = [(rng.randint(2, 14), rng.randint(2, 18)) for _ in range(4)]
+        S, Q = sum(h * w for h, w in shapes), _edge(rng, (4, 64), 150)
+        value = torch.randn(B, S, M * D, generator=g).half()
+        qp = torch.cat([torch.randn(B, Q, M * 16 * 2, generator=g) * 3.0, torch.randn(B, Q, M * 16, generator=g)], -1).half()
+        nd = rng.choice((2, 4))
+        ref_pts = torch.rand(B, Q, 4, nd, generator=g) * 1.2 - 0.1                                   # some reference points outside [0, 1]
+        if nd == 4:
+            ref_pts[..., 2:] = ref_pts[..., 2:].abs() * 0.3 + 0.02
+        vhw = None
+        if rng.random() < 0.5:
+            vhw = torch.tensor([[[rng.randint(1, h), rng.randint(1, w)] for (h, w) in shapes] for _ in range(B)], dtype=torch.int32)
+        _close(ops.ms_deform_attn_q(value, shapes, qp, ref_pts, M, valid_hw=vhw), emu.ms_deform_attn_q(value, shapes, qp, ref_pts, M, valid_hw=vhw),
+               f"ms_deform_attn_q draw {it}: B={B} shapes={shapes} Q={Q} ref_dim={nd} valid_hw={vhw is not None}")
+
+
+def test_bf16_twins_random_shapes(ops, monkeypatch):
+    """the *_bf16 entry points on a few of the same draws (tolerance x 8)"""
+    import ops_emulation as emu
+    rng = random.Random(808 + SEED)
+    g = torch.Generator().manual_seed(808 + SEED)
+    bf = torch.bfloat16
+    for res_attn in ("0", "1"):
+        monkeypatch.setenv("MQ_ATTN_RESIDENT", res_attn)
+        for it in range(5 * N_DRAWS):
+            B, H, D = rng.randint(1, 2), rng.randint(1, 3), rng.choice((32, 64))
+            Nq, Nk = _edge(rng, (16, 32, 128), 200), _edge(rng, (8, 16, 64, 256), 500)
+            q, k, v = (torch.randn(B, n, H * D, generator=g).to(bf) for n in (Nq, Nk, Nk))
+            vt = F.pad(v, (0, 0, 0, (-Nk) % 8)).transpose(1, 2).contiguous()
+            ref = emu.attention4(q.view(B, Nq, H, D), k.view(B, Nk, H, D), vt.view(B, H, D, -1), None, None, 0.0, nk=Nk)
+            got = ops.attention(q, k, vt, H, D, nk=Nk)
+            assert got.dtype == bf
+            _close(got, ref, f"attention bf16 (resident={res_attn}) draw {it}: B={B} H={H} D={D} Nq={Nq} Nk={Nk}", 8 * TOL)
+    for variant in ("1", "2"):
+        monkeypatch.setenv("MQ_LN_VARIANT", variant)
+        for it in range(5 * N_DRAWS):
+            C, rows = 8 * rng.choice((12, 24, 32, 48, 96, 192)), _edge(rng, (4, 16), 200)
+            x, res = torch.randn(rows, C, generator=g) * 2, torch.randn(rows, C, generator=g).to(bf)
+            w, b = (torch.randn(C, generator=g) * 0.1 + 1).to(bf), (torch.randn(C, generator=g) * 0.1).to(bf)
+            ref, got = emu.layer_norm(x, w, b, 1e-5, residual=res, want_y32=True), ops.layer_norm(x, w, b, 1e-5, residual=res, want_y32=True)
+            for i, (r, o) in enumerate(zip(ref, got)):
+                assert r.dtype == o.dtype
+                _close(o, r, f"layer_norm bf16 [v{variant}] draw {it} out {i}: rows={rows} C={C}", 8 * TOL)
