@@ -335,7 +335,7 @@ def test_score_aggregation_modes(dev):
 
 
 # ------------------------------------------------------------------------------------------------ resident-key attention (opt-in)
-def test_resident_attention_kernel(dev, monkeypatch):
+def _body_resident_attention_kernel(dev, monkeypatch):
     """csrc/attn_resident.hip (MQ_ATTN_RESIDENT=1: S^T formulation; text-sized attentions with all keys resident in LDS, long key
     sequences in chunks of 256) -- written after the round-2 GPU budget was spent and checked through tests/simt only; this is its
     first run on the device."""
@@ -361,7 +361,7 @@ def test_resident_attention_kernel(dev, monkeypatch):
         pc._CACHE.clear()
 
 
-def test_layernorm2_kernel(dev, monkeypatch):
+def _body_layernorm2_kernel(dev, monkeypatch):
     """csrc/layernorm2.hip (MQ_LN_VARIANT=2: load-batched LayerNorm): the LayerNorm checks and a BERT layer on it, and its outputs next
     to mq_layernorm_fwd's on the same inputs (bit-identical through tests/simt; on the device the two kernels are separate
     compilations of the same expressions, so one rounding step of slack is allowed)."""
@@ -386,7 +386,7 @@ def test_layernorm2_kernel(dev, monkeypatch):
     _assert(pc.check_bert_layer(dev, True))
 
 
-def test_offset_conv_v2_kernel(dev, monkeypatch):
+def _body_offset_conv_v2_kernel(dev, monkeypatch):
     """csrc/conv_small2.hip (MQ_OFFSET_CONV_VARIANT=2: the DyConv offset conv with unconditional in-flight loads): equal to
     mq_conv3x3_nchw32_fwd on the same inputs (same MFMA order: the results must not differ at all), conv and DyConv checks on it."""
     import parity_checks as pc
@@ -407,7 +407,7 @@ def test_offset_conv_v2_kernel(dev, monkeypatch):
     _assert(pc.check_dyconv(dev))
 
 
-def test_patch_merge_ln_kernel(dev, monkeypatch):
+def _body_patch_merge_ln_kernel(dev, monkeypatch):
     """mq_patch_merge_ln_fwd (MQ_PATCH_MERGE_FUSED=1: Swin PatchMerging gather + LayerNorm in one kernel) next to F.pad + cat +
     mq_layernorm_fwd on the same inputs, then Swin + FPN with the switch on."""
     import torch.nn.functional as F
@@ -429,7 +429,7 @@ def test_patch_merge_ln_kernel(dev, monkeypatch):
     pc._CACHE.clear()
 
 
-def test_fpn_convs_through_the_grouped_dcn_kernel(dev, monkeypatch):
+def _body_fpn_convs_through_the_grouped_dcn_kernel(dev, monkeypatch):
     """MQ_FPN_VIA_DCN=1: the FPN output convs as one grouped launch of the fused DCNv2 kernel with zero offsets (== plain 3x3 conv)"""
     import parity_checks as pc
     from mq_det_amd.modeling import pipeline
@@ -447,7 +447,7 @@ def test_fpn_convs_through_the_grouped_dcn_kernel(dev, monkeypatch):
     pc._CACHE.clear()
 
 
-def test_nms_early_stop(dev, monkeypatch):
+def _body_nms_early_stop(dev, monkeypatch):
     """mq_ml_nms_topk (MQ_NMS_EARLY_STOP=1): the max_keep best survivors equal mq_ml_nms's, nothing else is kept; post-processing on it"""
     import parity_checks as pc
     from mq_det_amd import ops
@@ -467,6 +467,28 @@ def test_nms_early_stop(dev, monkeypatch):
             n = min(K, len(kf))
             assert len(kp) >= n and torch.equal(kp[:n], kf[:n]) and bool((part[b] <= full[b]).all()), (K, b)
     _assert(pc.check_post_golden(dev))
+
+
+class _Env:
+    """monkeypatch.setenv for the isolated bodies (plain os.environ: the process ends with the body)"""
+    @staticmethod
+    def setenv(k, v):
+        os.environ[k] = v
+
+
+def _isolated(body, timeout=900):
+    """The bodies above drive kernels that have NEVER run on a device (written after the last GPU call of round 2; checked through
+    tests/simt: parity, guard pages, permuted schedules).  A wrong address on the device is not a Python exception but a memory fault
+    that kills the process -- so each body runs in a process of its own: a fault there fails one test, not the session."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), body], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, f"{body}: rc {r.returncode}\n{(r.stdout + r.stderr)[-3000:]}"
+
+
+@pytest.mark.parametrize("body", ["resident_attention_kernel", "layernorm2_kernel", "offset_conv_v2_kernel", "patch_merge_ln_kernel",
+                                  "fpn_convs_through_the_grouped_dcn_kernel", "nms_early_stop"])
+def test_opt_in_kernel(dev, body):
+    _isolated(body)
 
 
 # ------------------------------------------------------------------------------------------------ bf16 operands (configs[3])
@@ -503,3 +525,14 @@ def test_bf16_groundingdino(dev, bf16):
     _assert(gc.check_msdeform_attn_q(dev))
     if _FULL:
         _assert(gc.check_gdino_model(dev, vq=True))
+
+
+
+if __name__ == "__main__":                       # python tests/test_gpu_parity.py <body>: one isolated body (see _isolated)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    _dev = torch.device("cuda:0")
+    from mq_det_amd import ops as _ops
+    _ops.load_library()
+    globals()["_body_" + sys.argv[1]](_dev, _Env)
+    torch.cuda.synchronize()
+    print("body ok:", sys.argv[1])
