@@ -47,11 +47,16 @@ class FixedAPAccumulator:
             self._fold()
 
     def update_boxlist(self, image_id, boxlist):
-        """One reference-style prediction: BoxList in xyxy -> xywh with the legacy +1 (BoxList.convert('xywh'), what
-        `prepare` does, lvis_eval.py:812-835)."""
-        b = boxlist.convert("xywh").bbox
+        """One reference-style prediction (engine/inference.py:643-648: `output.bbox` in xyxy after `resize_box` to the original
+        image size) -> rows with the bbox exactly as `LvisEvaluatorFixedAP.prepare` builds it (lvis_eval.py:810-835 through
+        `convert_to_xywh` :998-1000): (xmin, ymin, xmax - xmin, ymax - ymin) -- NO legacy +1 (that is BoxList.convert("xywh"),
+        which the LVIS path never calls)."""
+        if boxlist.mode != "xyxy":
+            boxlist = boxlist.convert("xyxy")
+        b = boxlist.bbox
         n = len(b)
-        self.update(torch.full((n,), float(image_id)), boxlist.get_field("labels"), boxlist.get_field("scores"), b)
+        xywh = torch.stack((b[:, 0], b[:, 1], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]), 1) if n else b.reshape(0, 4)
+        self.update(torch.full((n,), float(image_id)), boxlist.get_field("labels"), boxlist.get_field("scores"), xywh)
 
     def _fold(self):
         if self._pending:

@@ -306,7 +306,12 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
 
     @torch.no_grad()
     def forward(self, images, targets=None, captions=None, positive_map=None, greenlight_map=None,
-                return_backbone_features=False, return_raw=False, input_ids=None, attention_mask=None):
+                return_backbone_features=False, return_raw=False, input_ids=None, attention_mask=None, reuse_backbone=None):
+        """generalized_vl_rcnn_new.py:307-519, eval.  `reuse_backbone` (not in the reference; keyword only in spirit): None = follow
+        MODEL.BACKBONE_CACHE; False = this call recomputes Swin / FPN whatever the cache holds.  The cache (f1) recognises the
+        previous call's pixels by OBJECT IDENTITY + torch's version counter of `images.tensors`: a producer that refills the same
+        tensor WITHOUT bumping the counter (numpy / DLPack views of its memory, `.data` writes, IPC or custom-kernel writers) must
+        pass reuse_backbone=False (or call `clear_caches()` / set MODEL.BACKBONE_CACHE False) -- nothing else can see such a write."""
         if self.training:
             raise NotImplementedError("training forward is out of scope")
         images = to_image_list(images)
@@ -365,7 +370,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
         # f1: the pixels of the previous call (same tensor object, not modified since) -> cached Swin / FPN features;
         # a caption seen before -> cached image-independent BERT layers.  The strong reference to the input tensor keeps
         # its storage alive, so object identity + version counter cannot alias a different batch.
-        fc = self._feat_cache if self.backbone_cache else None
+        fc = self._feat_cache if (self.backbone_cache and reuse_backbone is not False) else None
         src = images.tensors
         if fc is not None and fc["src"] is src and fc["version"] == src._version and (vision is None or fc["pooled"] is not None):
             self.cache_stats["backbone_hit"] += 1

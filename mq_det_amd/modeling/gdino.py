@@ -229,7 +229,9 @@ class GroundingDINO(GraphRunner, nn.Module):
         use_graph = self.use_hip_graph and not ops.timing_active()
         # f1: the pixels of the previous call (same tensor object, not modified since) -> cached projected levels; the strong
         # reference to the input tensor keeps its storage alive, so identity + version counter cannot alias another batch
-        fc, src = (self._feat_cache if self.backbone_cache else None), images.tensors
+        # (a writer that refills `images.tensors` without bumping its version counter must pass reuse_backbone=False -- see
+        # GeneralizedVLRCNN_New.forward)
+        fc, src = (self._feat_cache if (self.backbone_cache and kw.get("reuse_backbone") is not False) else None), images.tensors
         if fc is not None and fc["src"] is src and fc["version"] == src._version:
             self.cache_stats["backbone_hit"] += 1
             out = self._run("_program_rest", (fc["src32"],) + inputs[1:], use_graph)

@@ -5,8 +5,13 @@ Reference: groundingdino_new/models/GroundingDINO/groundingdino.py:438-661 (Grou
 fuse_modules.py:146-297 (BiAttentionBlock), transformer_vanilla.py:92-123 (text enhancer layer), ms_deform_attn.py:232-359,
 utils.py (proposals, sine embeddings, MLP, ContrastiveEmbed), bertwarper.py:60-215,273-320, backbone/position_encoding.py:76-125.
 
-What runs where (same rules as pipeline.py: fp16 MFMA operands, fp32 accumulation and fp32 residual streams, nothing on the CPU,
-nothing from the oracle):
+What runs where (same rules as pipeline.py: fp16 MFMA operands, fp32 accumulation, nothing on the CPU, nothing from the oracle).
+Residual streams: the TEXT stream and the DECODER query stream are fp32 end to end.  The IMAGE token stream of the six encoder
+layers is fp32 inside a layer (norm1 -> FFN -> norm2 carry `m32`) but crosses the fusion step in 16 bits: mq_vlfuse_i2t_fwd reads
+and writes the [B, S, 256] tokens as fp16 / bf16 (like MQ-GLIP's pyramid token buffer), so the residual that enters
+norm1 of `deformable_encoder_layer` is the fusion kernel's 16-bit output -- ONE extra rounding of the image stream per layer
+(ADVICE r2).  Its weight is measured, not assumed: tests/gdino_checks.py compares the encoder memory after all six layers with the
+fp32 oracle (2.7e-3 of the tensor's range at full depth, profiles/r02_gdino_parity.txt), inside the gate of that check:
   * Swin backbone: the MQ-GLIP kernels (window attention, fused MLP, LayerNorm) under the `backbone.0` names;
   * feature-enhancer fusion (4 heads x 256 between ~22 k image tokens and 256 text tokens): the VLFuse kernels with the
     image-side projections folded into the text operands (the 1024-wide image tensors of the reference never exist), the

@@ -38,6 +38,12 @@ class QuerySelector(nn.Module):
         super().__init__()
         self.cfg = cfg
         self.num_query_per_class = cfg.VISION_QUERY.NUM_QUERY_PER_CLASS
+        # VISION_QUERY.REFERENCE_RNG_STREAM (not a reference key; default False): consume numpy's global generator once per label
+        # on EVERY forward exactly like the reference (query_selector.py:74) -- also when every draw is the identity -- so that a
+        # run seeded like a reference run keeps the SAME generator state call for call.  Off: identity draws are
+        # skipped and memoised (same selections, no per-forward host work), and the generator state then differs from a
+        # reference run's as soon as one caption did not need a real draw.
+        self.reference_rng = bool(cfg.VISION_QUERY.get("REFERENCE_RNG_STREAM", False))
         self.query_bank = None
         self._dev_bank = {}
         self._sel_cache = {}
@@ -66,7 +72,10 @@ class QuerySelector(nn.Module):
     def deterministic(self, labels):
         """True when no label of `labels` holds more bank rows than NUM_QUERY_PER_CLASS: the reference's eval-mode draw
         `sorted(np.random.choice(len, n, replace=False))` (query_selector.py:74-76) is then the identity, and the
-        selection may be memoised.  Otherwise every forward draws again, from numpy's global generator like the reference."""
+        selection may be memoised.  Otherwise every forward draws again, from numpy's global generator like the reference.
+        (With VISION_QUERY.REFERENCE_RNG_STREAM nothing is memoised: every label of every forward consumes its draw.)"""
+        if self.reference_rng:
+            return False
         for lab in labels:
             cand = self._candidates(lab)
             if cand is not None and len(cand) > self.num_query_per_class:

@@ -141,7 +141,7 @@ def build(force=False):
     with tempfile.TemporaryDirectory(prefix="mqdet_ref_") as tmp:     # extracted reference text never lands in the repo
         f = os.path.join(tmp, "ref_kernels.hip")
         open(f, "w").write(src)
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-value", f, "-o", OUT]
+        cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-value", f, "-o", OUT]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed on the extracted reference kernels:\n" + r.stderr[-4000:])

@@ -61,6 +61,34 @@ def test_query_selector_short_bank_and_ragged_batch():
     assert idx.shape[2] == k                                  # widest token owns one label's rows (label 4 capped at k)
 
 
+def test_query_selector_reference_rng_stream():
+    """with VISION_QUERY.REFERENCE_RNG_STREAM every label of every forward consumes numpy's global generator like the
+    reference (query_selector.py:74), identity draws included: after a caption that needed NO real draw the generator is where the
+    reference's is, so a later caption that does need one selects the same rows."""
+    import numpy as np
+    cfg = get_cfg()
+    cfg.VISION_QUERY.REFERENCE_RNG_STREAM = True
+    C, k, T = cfg.MODEL.BACKBONE.OUT_CHANNELS, cfg.VISION_QUERY.NUM_QUERY_PER_CLASS, 16
+    g = torch.Generator().manual_seed(8)
+    bank = {1: torch.randn(k, 1, C, generator=g), 2: torch.randn(2, 1, C, generator=g), 3: torch.randn(k + 4, 1, C, generator=g)}
+    pm_easy, pm_hard = {1: [1], 2: [3]}, {3: [2, 4], 1: [6]}
+    qs = QuerySelector(cfg)
+    qs.load_query_bank(bank)
+    np.random.seed(21)
+    qs.select_cached("easy", list(pm_easy), pm_easy, 1, T, torch.device("cpu"), torch.float32)        # identity draws only
+    qs.select_cached("easy", list(pm_easy), pm_easy, 1, T, torch.device("cpu"), torch.float32)        # ... and NOT memoised
+    v, _ = qs.select_cached("hard", list(pm_hard), pm_hard, 1, T, torch.device("cpu"), torch.float32)
+    np.random.seed(21)
+    for pm in (pm_easy, pm_easy):
+        od.select_queries(bank, [list(pm)], [od.labels_and_maps(pm, T)[1]], k)
+    ref_v, _ = od.select_queries(bank, [list(pm_hard)], [od.labels_and_maps(pm_hard, T)[1]], k)
+    assert torch.equal(v, ref_v)
+    cfg.VISION_QUERY.REFERENCE_RNG_STREAM = False                        # default: identity draws are skipped -> the state differs
+    qs2 = QuerySelector(cfg)
+    qs2.load_query_bank(bank)
+    assert qs2.deterministic(list(pm_easy)) and not qs.deterministic(list(pm_easy))
+
+
 def test_query_selector_defaultdict_bank_with_empty_labels():
     """reference banks are `defaultdict(list)` (engine/inference.py:401); a caption label without queries reads
     as `[]` and contributes no vision rows (query_selector.py:77-78) -- text-only for that label, no exception; a plain

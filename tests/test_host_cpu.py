@@ -161,6 +161,45 @@ def test_gloo_world2_evaluator_gather_matches_reference():
     assert r.stdout.count("EVAL_GATHER_OK") == 2
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="compares with reference code executed in place")
+def test_evaluator_update_boxlist_matches_reference_prepare():
+    """a detection handed over as a BoxList must reach the LVIS API with the bbox `LvisEvaluatorFixedAP.prepare` builds
+    (lvis_eval.py:810-835 via convert_to_xywh :998-1000: no legacy +1), from the (image id, dict) pairs of engine/inference.py:643-648."""
+    import torch
+    from mq_det_amd.evaluation import FixedAPAccumulator
+    from mq_det_amd.structures import BoxList
+    from oracle import _refload
+    ev = _refload.reference_classes("maskrcnn_benchmark/data/datasets/evaluation/lvis/lvis_eval.py", ["LvisEvaluatorFixedAP"],
+                                    ["_merge_lists", "convert_to_xywh"], {"LVIS": object})
+    ref = ev["LvisEvaluatorFixedAP"](gt=None, topk=50)
+    acc = FixedAPAccumulator(topk=50)
+    g = torch.Generator().manual_seed(5)
+    preds = []
+    for img in (11, 12, 13):
+        n = 9
+        xy = torch.rand(n, 2, generator=g) * 300
+        wh = torch.rand(n, 2, generator=g) * 200 + 0.25
+        boxes = torch.cat([xy, xy + wh], 1)
+        labels, scores = torch.randint(1, 4, (n,), generator=g), torch.rand(n, generator=g)
+        preds.append((img, {"scores": scores, "labels": labels, "boxes": boxes}))
+        bl = BoxList(boxes, (640, 480), mode="xyxy")
+        bl.add_field("scores", scores)
+        bl.add_field("labels", labels)
+        acc.update_boxlist(img, bl)
+    preds.append((14, {"scores": torch.zeros(0), "labels": torch.zeros(0, dtype=torch.long), "boxes": torch.zeros(0, 4)}))
+    empty = BoxList(torch.zeros(0, 4), (640, 480), mode="xyxy")
+    empty.add_field("scores", torch.zeros(0))
+    empty.add_field("labels", torch.zeros(0, dtype=torch.long))
+    acc.update_boxlist(14, empty)
+    ref.update(preds)                                     # update() -> prepare() -> convert_to_xywh
+    mine = acc.by_cat()
+    assert set(mine) == set(ref.by_cat)
+    for cat, anns in ref.by_cat.items():
+        a = sorted((x["image_id"], round(x["score"], 6), tuple(round(v, 4) for v in x["bbox"])) for x in anns)
+        b = sorted((x["image_id"], round(x["score"], 6), tuple(round(v, 4) for v in x["bbox"])) for x in mine[cat])
+        assert a == b, (cat, a[:2], b[:2])
+
+
 def test_ctypes_signatures_match_header():
     """every `_SIGNATURES` entry of mq_det_amd/ops.py has the argument kinds of its declaration in
     include/mqdet_hip.h (pointer / int / long / float, in order) -- parsed from the header text."""
