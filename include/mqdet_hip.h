@@ -156,6 +156,18 @@ int mq_swin_mlp_fwd(const float* x, const void* delta, const void* ln_g, const v
                     const void* b1, const void* w2p, const void* b2, float* out, const void* next_g, const void* next_b,
                     float eps_next, void* y, long M, int C, void* stream);
 
+/* Second generation of the same operator (csrc/swin_mlp2.hip; same arguments, same results up to the fp32 summation order of the
+ * hidden chunks): the weights arrive FRAGMENT-MAJOR so that staging is a linear copy (flags bit 0: by LDS-DMA) and every
+ * LDS read is conflict-free; GELU(chunk j), fc1(chunk j + 1) and fc2(chunk j - 1) are issued together (software pipeline);
+ * flags bit 1: GELU through a 768-entry interpolation table of Phi (|error| < 8e-6) instead of the 14-instruction erf formula.
+ *   w1f [(4C/32 + 2) * (C/16) * 512] fp16: block (chunk j, hb in {0,1}, ks) holds for lane l  fc1.weight[32j + 16hb + (l & 15)][32ks + 8(l >> 4) .. +7];
+ *        two all-zero chunks follow the last one (the pipeline reads two chunks ahead);
+ *   w2f [(4C/32) * (C/16) * 512] fp16: block (chunk j, ct) holds for lane l  w2p[16ct + (l & 15)][32j + 8(l >> 4) .. +7], w2p = fc2.weight with
+ *        the k-slot permutation of mq_swin_mlp_fwd.   (Python: ops.swin_mlp2_pack(fc1.weight, fc2.weight).) */
+int mq_swin_mlp2_fwd(const float* x, const void* delta, const void* ln_g, const void* ln_b, float eps, const void* w1f,
+                     const void* b1, const void* w2f, const void* b2, float* out, const void* next_g, const void* next_b,
+                     float eps_next, void* y, long M, int C, int flags, void* stream);
+
 /* 3x3 convolution (pad 1, stride 1|2) and DCNv2 (modulated deformable 3x3) as one implicit-GEMM MFMA kernel,
  * NHWC fp16, fp32 accumulation over the whole K = 9*C in a fixed order (bitwise reproducible).
  *   x [B,H,W,C] (batch stride x_bs elements, C % 32 == 0), w [Npad, 9*C] fp16 with k = tap*C + c (Npad = 32 if
@@ -319,6 +331,7 @@ MQ_BF16_TWIN(mq_layernorm_fwd)
 MQ_BF16_TWIN(mq_layernorm2_fwd)
 MQ_BF16_TWIN(mq_patch_merge_ln_fwd)
 MQ_BF16_TWIN(mq_swin_mlp_fwd)
+MQ_BF16_TWIN(mq_swin_mlp2_fwd)
 MQ_BF16_TWIN(mq_conv3x3_fwd)
 MQ_BF16_TWIN(mq_conv3x3_nchw32_fwd)
 MQ_BF16_TWIN(mq_conv3x3_nchw32_v2_fwd)

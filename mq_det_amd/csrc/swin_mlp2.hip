@@ -1,0 +1,453 @@
+// mq_swin_mlp2_fwd: the MLP half of a Swin block as ONE kernel for gfx950 -- second generation (round 3).
+//
+//     x'   = x + delta                       (delta = attention projection output, swint.py:236; optional)
+//     out  = x' + fc2( GELU( fc1( LayerNorm(x') ) ) )        (swint.py:240, Mlp :13-31, exact erf GELU)
+//     y    = LayerNorm_next(out)             (optional: the next block's norm1 / the stage's output norm, 16-bit)
+//
+// Same mathematics and register-chained transposed GEMM pair as swin_mlp.hip (H^T = W1 LN(x)^T, OUT^T = W2 H^T; the accumulator of the
+// first product IS the B fragment of the second).  What round 3's counters said about that kernel (profiles/r03_call1_swin_mlp_sq*.csv,
+// MI355X): MFMA pipe 9 % busy; 6.4 / 12.6 / 24 VALU instructions per MFMA at C = 384 / 192 / 96 -- the exact GELU was ~23 VALU per
+// value (__frcp_rn expands to the IEEE division sequence); 46 % of the LDS cycles were bank conflicts (padded row-major weight
+// chunks); per 32-hidden chunk a barrier, with GEMM1 -> GELU -> GEMM2 strictly one after the other inside every wave, so the two
+// waves of a SIMD were always in the same phase (both on the matrix pipe, then both on the VALU).  This kernel changes four things:
+//
+//   1. weights arrive FRAGMENT-MAJOR (packed once on the host, ops.swin_mlp2_pack): every 1 KB block is one MFMA A fragment in lane
+//      order.  Staging is a linear copy (optionally LDS-DMA, global_load_lds_dwordx4: no VGPRs, no ds_write), fragment reads are
+//      `base + lane * 16 + immediate` -- conflict-free by construction, no address arithmetic;
+//   2. a three-deep SOFTWARE PIPELINE over the hidden chunks inside each wave: iteration j issues GELU(chunk j) [VALU] together with
+//      GEMM1(chunk j + 1) and GEMM2(chunk j - 1) [MFMA], all mutually independent, so the matrix pipe and the VALU overlap within
+//      one instruction stream (W1 runs two chunks ahead of W2 through two small LDS rings; one barrier per iteration);
+//   3. a GELU of 14 VALU instructions per value (v_rcp_f32 + v_exp_f32 + v_bfi, fc1 bias folded into the accumulator's initial
+//      value), or 7 + one ds_read_b64 with the interpolation table variant (768 x (Phi, dPhi) over [-6, 6), |error| < 8e-6);
+//   4. nothing in the loop is conditional: the packed W1 carries two zero chunks behind the last one.
+// Algorithmic HBM bytes per token: C * (4 + 2 + 4 [+ 2]).  MFMA work 16 M C^2.
+#include "common.h"
+#include <type_traits>
+#include <cstdlib>
+
+MQ_NAMESPACE_BEGIN
+
+struct SwinMlp2Params {
+  const float* x; const half_t* delta;
+  const half_t* g2; const half_t* be2;
+  const half_t* w1f; const half_t* b1; const half_t* w2f; const half_t* b2;
+  float* out;
+  const half_t* gn; const half_t* bn; half_t* y;
+  long M; float eps, eps_n;
+};
+
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7): erf(|v| / sqrt 2) = 1 - poly(t) exp(-v^2 / 2), t = 1 / (1 + p |v| / sqrt 2)
+__device__ __forceinline__ float erf_abs_scaled(float v) {
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, fabsf(v), 1.f));
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float ex = __builtin_amdgcn_exp2f((-0.5f * 1.4426950408889634f) * v * v);
+  return fmaf(-poly, ex, 1.f);
+}
+// exact-erf GELU, 14 VALU instructions (2 of them transcendental)
+__device__ __forceinline__ float gelu_erf2(float v) {
+  const float hv = 0.5f * v;
+  return fmaf(hv, __builtin_copysignf(erf_abs_scaled(v), v), hv);
+}
+
+typedef float float2_ __attribute__((ext_vector_type(2)));
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_impl(F& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for_impl<I + 1, N>(f);
+  }
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F f) { static_for_impl<0, N>(f); }
+
+// GELU piece q of an iteration (8 values x GS stages in stage-diagonal order: value k = d - stage on diagonal d, so that a value's
+// stages are a few steps apart): its value index (want_k) or its stage
+constexpr int gelu_piece_of(int q, int GS, bool want_k) {
+  int c = 0;
+  for (int d = 0; d < 8 + GS - 1; ++d)
+    for (int st = 0; st < GS; ++st) {
+      const int k = d - st;
+      if (k < 0 || k >= 8) continue;
+      if (c == q) return want_k ? k : st;
+      ++c;
+    }
+  return -1;
+}
+#define MQ_GELU_TAB_N 768            // Phi on [-6, 6) in steps of 1 / 64: linear interpolation error <= h^2 / 8 max|Phi''| = 7.4e-6
+
+template <int C, int NW, bool DMA, bool TABLE>
+__global__ __launch_bounds__(64 * NW, (C <= 96 ? (DMA ? 4 : 3) : C <= 192 ? (DMA ? 3 : 2) : 2)) void swin_mlp2_kernel(SwinMlp2Params p) {
+  constexpr int NT = 64 * NW, BM = 16 * NW, HID = 4 * C, KS = C / 32, CT = C / 16, NCHUNK = HID / 32;
+  constexpr int FR = 512;                                     // halfs per fragment block (64 lanes x 8)
+  constexpr int W1_FR = 2 * KS, W2_FR = CT, IT_FR = W1_FR + W2_FR;   // fragment blocks of one chunk of W1 / W2 / staged per iteration
+  constexpr int FPW = IT_FR / NW;                             // fragment blocks a wave stages per iteration
+  static_assert(C % 32 == 0 && IT_FR % NW == 0 && NCHUNK % 2 == 0, "tile shapes");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* w1s = (half_t*)smem;                                // [2][W1_FR][FR]   W1 ring: chunk c lives in stage c & 1
+  half_t* w2s = w1s + 2 * W1_FR * FR;                         // [2][W2_FR][FR]   W2 ring
+  float* tab = (float*)(w2s + 2 * W2_FR * FR);                // [MQ_GELU_TAB_N][2] (TABLE)
+
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: staging addresses in SGPRs
+  const long row0 = (long)blockIdx.x * BM + wave * 16;        // this wave's 16 tokens
+
+  // ---- staging of one iteration's weights: W1 chunk c1 -> W1 stage c1 & 1, W2 chunk c2 -> W2 stage c2 & 1.  Block f of the
+  // iteration (f < W1_FR: W1, else W2) is copied by wave f % NW as one 1 KB piece: source and destination are both lane-linear.
+  half8 wreg[DMA ? 1 : FPW];
+  auto stage_src = [&](int f, int c1, int c2) -> const half_t* {
+    return f < W1_FR ? p.w1f + ((long)c1 * W1_FR + f) * FR : p.w2f + ((long)c2 * W2_FR + (f - W1_FR)) * FR;
+  };
+  auto stage_dst = [&](int f, int c1, int c2) -> half_t* {
+    return f < W1_FR ? w1s + ((c1 & 1) * W1_FR + f) * FR : w2s + ((c2 & 1) * W2_FR + (f - W1_FR)) * FR;
+  };
+  auto stage_issue = [&](int c1, int c2) {
+#pragma unroll
+    for (int i = 0; i < FPW; ++i) {
+      const int f = wave + i * NW;
+      const half_t* src = stage_src(f, c1, c2) + lane * 8;
+      if constexpr (DMA) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)stage_dst(f, c1, c2), 16, 0, 0);
+      } else {
+        wreg[i] = *(const half8*)src;
+      }
+    }
+  };
+  auto stage_commit = [&](int c1, int c2) {
+    if constexpr (!DMA) {
+#pragma unroll
+      for (int i = 0; i < FPW; ++i) {
+        const int f = wave + i * NW;
+        *(half8*)(stage_dst(f, c1, c2) + lane * 8) = wreg[i];
+      }
+    }
+  };
+  // chunk 0 of W1 (+ a W2 block that is overwritten before use) now; chunk 1 right after: both W1 stages are full at the first barrier
+  stage_issue(0, 0);
+  if constexpr (TABLE) {
+    // Phi(x_i), Phi(x_i+1) - Phi(x_i) at x_i = -6 + i / 64
+    for (int i = tid; i < MQ_GELU_TAB_N; i += NT) {
+      const float x0 = -6.f + (float)i * (1.f / 64.f), x1 = x0 + (1.f / 64.f);
+      const float p0 = fmaf(0.5f, __builtin_copysignf(erf_abs_scaled(x0), x0), 0.5f);
+      const float p1 = fmaf(0.5f, __builtin_copysignf(erf_abs_scaled(x1), x1), 0.5f);
+      tab[2 * i] = p0;
+      tab[2 * i + 1] = p1 - p0;
+    }
+  }
+
+  // ---- prologue: LayerNorm straight into MFMA B fragments (as swin_mlp.hip: lane (g, token l15) loads x[token][32 ks + 8 g .. + 7],
+  // the four g-lanes of a token cover one 128-byte line per ks; statistics = in-lane sum + two shuffles; rows beyond M are clamped)
+  half8 xf[KS];
+  auto prologue = [&](auto HAS_DELTA) {
+    constexpr bool has_delta = decltype(HAS_DELTA)::value;
+    const long row = min(row0 + l15, p.M - 1);
+    const float* xr = p.x + row * C + g * 8;
+    float4_ va[KS], vb[KS];
+    half8 vd[has_delta ? KS : 1];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      va[ks] = *(const float4_*)(xr + ks * 32);
+      vb[ks] = *(const float4_*)(xr + ks * 32 + 4);
+      if constexpr (has_delta) vd[ks] = *(const half8*)(p.delta + row * C + ks * 32 + g * 8);
+    }
+    float v[KS][8];
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[ks][j] = va[ks][j]; v[ks][4 + j] = vb[ks][j]; }
+      if constexpr (has_delta) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[ks][j] += (float)vd[ks][j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[ks][j];
+    }
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    const float mean = s * (1.f / (float)C);
+    float q = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[ks][j] - mean; q += d * d; }
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    const float rstd = rsqrtf(q * (1.f / (float)C) + p.eps);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = ks * 32 + g * 8;
+      const half8 gm = *(const half8*)(p.g2 + c), bt = *(const half8*)(p.be2 + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xf[ks][j] = (half_t)((v[ks][j] - mean) * rstd * (float)gm[j] + (float)bt[j]);
+    }
+  };
+  if (p.delta) prologue(std::true_type{}); else prologue(std::false_type{});
+
+  stage_commit(0, 0);
+  stage_issue(1, 0);
+  stage_commit(1, 0);
+  __syncthreads();                                            // W1 chunks 0 and 1 (and the table) visible
+
+  float4_ acc2[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) acc2[ct] = (float4_){0.f, 0.f, 0.f, 0.f};
+
+  // fc1 bias of a chunk = the initial value of its accumulators (lane holds hidden units 4 g + r and 16 + 4 g + r of the chunk).  It is
+  // loaded ONE ITERATION AHEAD and before the iteration's LDS-DMA pieces: VMEM results return in order, so a bias loaded behind the
+  // DMAs would make its first use wait for all of them (s_waitcnt vmcnt(0) at the top of the iteration instead of at its barrier).
+  half4 bq0, bq1;
+  auto bias_load = [&](int c) {
+    const int hb = min(c, NCHUNK - 1) * 32 + 4 * g;
+    bq0 = *(const half4*)(p.b1 + hb);
+    bq1 = *(const half4*)(p.b1 + hb + 16);
+  };
+  auto h_init = [&](float4_ (&h)[2]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { h[0][r] = (float)bq0[r]; h[1][r] = (float)bq1[r]; }
+  };
+  // GEMM 1 (transposed) of one chunk from W1 stage `st`: H^T[32 hidden, 16 tokens] over K = C (pipeline fill only)
+  auto gemm1 = [&](int st, float4_ (&h)[2]) {
+    const half_t* a = w1s + st * W1_FR * FR + lane * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      h[0] = mfma16(*(const half8*)(a + ks * FR), xf[ks], h[0]);
+      h[1] = mfma16(*(const half8*)(a + (KS + ks) * FR), xf[ks], h[1]);
+    }
+  };
+  // GEMM 2 (transposed) of one chunk from W2 stage `st`: OUT^T[C, 16 tokens] += W2p[:, 32 k-slots] . H^T (pipeline drain only)
+  auto gemm2 = [&](int st, const half8& hf) {
+    const half_t* a = w2s + st * W2_FR * FR + lane * 8;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc2[ct] = mfma16(*(const half8*)(a + ct * FR), hf, acc2[ct]);
+  };
+
+  // ---- one pipelined iteration.  Its MFMAs form ONE sequence of N = 2 KS + CT steps that alternates GEMM1(chunk j + 1) -- a
+  // dependent chain on two accumulators -- with GEMM2(chunk j - 1), whose CT accumulators are independent; their A fragments come
+  // through a register ring RD reads deep (LDS latency, ~100+ cycles, against ~30 per step).  GELU(chunk j) is cut into 8 values x
+  // GS stages (~5 VALU each, erf: {rcp + exp2 | polynomial | sign, scale, round}; table: {index + ds_read | interpolate}) that are
+  // dealt out over the steps.  The source order IS the issue order: a scheduling fence closes every step -- left alone, the
+  // compiler emits the whole GELU first and then MFMA after MFMA, each waiting for a fragment read issued one step earlier (ISA).
+  constexpr int RD = DMA ? 6 : 4, GS = TABLE ? 2 : 3, NPIECE = 8 * GS;      // (register staging holds FPW more fragments: shorter ring)
+  // MQ_PIN(x): an empty volatile asm that reads and "writes" x.  Instruction selection linearises a block's DAG on its own: arithmetic
+  // that hangs on no side-effecting node is placed wherever it likes relative to the scheduling fences.  A piece's input and result
+  // both pass through a pin, which chains the piece between the two fences of its step.
+#define MQ_PIN(x) asm volatile("" : "+v"(x))
+  float gt0 = 0.f, gt1 = 0.f, gt2 = 0.f, gt3 = 0.f, gt4 = 0.f, gt5 = 0.f, gt6 = 0.f, gt7 = 0.f;      // GELU state between stages: named
+  float ge0 = 0.f, ge1 = 0.f, ge2 = 0.f, ge3 = 0.f, ge4 = 0.f, ge5 = 0.f, ge6 = 0.f, ge7 = 0.f;      // scalars (pins take their address)
+  auto gsel = [&](auto kc, float& s0, float& s1, float& s2, float& s3, float& s4, float& s5, float& s6, float& s7) -> float& {
+    constexpr int k = decltype(kc)::value;
+    if constexpr (k == 0) return s0; else if constexpr (k == 1) return s1; else if constexpr (k == 2) return s2;
+    else if constexpr (k == 3) return s3; else if constexpr (k == 4) return s4; else if constexpr (k == 5) return s5;
+    else if constexpr (k == 6) return s6; else return s7;
+  };
+  auto gelu_piece = [&](auto kc, auto stc, const float4_ (&hin)[2], half8& hf) {
+    constexpr int k = decltype(kc)::value, stage = decltype(stc)::value;
+    float& gt = gsel(kc, gt0, gt1, gt2, gt3, gt4, gt5, gt6, gt7);
+    float& ge = gsel(kc, ge0, ge1, ge2, ge3, ge4, ge5, ge6, ge7);
+    float v = hin[k >> 2][k & 3];
+    MQ_PIN(v);
+    if constexpr (TABLE) {
+      if constexpr (stage == 0) {
+        const float pos = fmaf(__builtin_amdgcn_fmed3f(v, -6.f, 5.9921875f), 64.f, 384.f);        // in [0, 768)
+        const int idx = (int)pos;
+        gt = pos - (float)idx;
+        const float2_ e = *(const float2_*)(tab + 2 * idx);
+        ge = e[0];
+        gt = fmaf(gt, e[1], 0.f) ;                            // (frac * dPhi); Phi_i added in stage 1 -- two scalars carry the state
+        MQ_PIN(gt);
+        MQ_PIN(ge);
+      } else {
+        float o = v * (gt + ge);
+        MQ_PIN(o);
+        hf[k] = (half_t)o;
+      }
+    } else {
+      if constexpr (stage == 0) {
+        gt = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, fabsf(v), 1.f));
+        ge = __builtin_amdgcn_exp2f((-0.5f * 1.4426950408889634f) * v * v);
+        MQ_PIN(gt);
+        MQ_PIN(ge);
+      } else if constexpr (stage == 1) {
+        const float t = gt;
+        gt = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+        MQ_PIN(gt);
+      } else {
+        const float hv = 0.5f * v;
+        float o = fmaf(hv, __builtin_copysignf(fmaf(-gt, ge, 1.f), v), hv);
+        MQ_PIN(o);
+        hf[k] = (half_t)o;
+      }
+    }
+  };
+  auto step = [&](int j, auto PARc, auto FIRSTc, float4_ (&hin)[2], float4_ (&hout)[2], half8& hf_old, half8& hf_new) {
+    constexpr int PAR = decltype(PARc)::value;                // j & 1
+    constexpr bool FIRST = decltype(FIRSTc)::value;           // j == 0: no GEMM2 yet
+    constexpr int N = FIRST ? 2 * KS : 2 * KS + CT;
+    h_init(hout);                                             // bias of chunk j + 1, loaded during iteration j - 1
+    bias_load(j + 2);
+    stage_issue(j + 2, j);
+    const half_t* a1 = w1s + (1 - PAR) * W1_FR * FR + lane * 8;        // W1 chunk j + 1 (for j = NCHUNK - 1: a zero chunk)
+    const half_t* a2 = w2s + (1 - PAR) * W2_FR * FR + lane * 8;        // W2 chunk j - 1
+    // step i of the sequence: even -> GEMM1 fragment (hb = m & 1, ks = m >> 1), m = i / 2; odd -> GEMM2 fragment ct = i / 2
+    auto frag = [&](int i) -> half8 {
+      if (FIRST) return *(const half8*)(a1 + ((i & 1) * KS + (i >> 1)) * FR);
+      const int m = i >> 1;
+      return (i & 1) ? *(const half8*)(a2 + m * FR) : *(const half8*)(a1 + ((m & 1) * KS + (m >> 1)) * FR);
+    };
+    half8 ring[RD];
+#pragma unroll
+    for (int i = 0; i < RD && i < N; ++i) ring[i] = frag(i);
+    static_for<N>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      static_for<NPIECE>([&](auto qc) {                       // the GELU pieces of this step: piece q belongs to step q N / NPIECE
+        constexpr int q = decltype(qc)::value;
+        if constexpr (q * N / NPIECE == i)
+          gelu_piece(std::integral_constant<int, gelu_piece_of(q, GS, true)>{}, std::integral_constant<int, gelu_piece_of(q, GS, false)>{},
+                     hin, hf_new);
+      });
+      const half8 a = ring[i % RD];
+      if constexpr (FIRST || !(i & 1)) {
+        constexpr int m = FIRST ? i : i >> 1;
+        hout[m & 1] = mfma16(a, xf[m >> 1], hout[m & 1]);
+      } else {
+        acc2[i >> 1] = mfma16(a, hf_old, acc2[i >> 1]);
+      }
+      if constexpr (i + RD < N) ring[i % RD] = frag(i + RD);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    stage_commit(j + 2, j);
+    __syncthreads();
+  };
+  float4_ hA[2], hB[2];
+  half8 hfA, hfB;
+  bias_load(0);
+  h_init(hA);
+  bias_load(1);
+  gemm1(0, hA);                                               // pipeline fill: H^T of chunk 0
+  __syncthreads();                                            // every wave is done with W1 stage 0 before chunk 2 lands there
+  step(0, std::integral_constant<int, 0>{}, std::true_type{}, hA, hB, hfB, hfA);
+  for (int j = 1; j < NCHUNK - 1; j += 2) {
+    step(j, std::integral_constant<int, 1>{}, std::false_type{}, hB, hA, hfA, hfB);
+    step(j + 1, std::integral_constant<int, 0>{}, std::false_type{}, hA, hB, hfB, hfA);
+  }
+  step(NCHUNK - 1, std::integral_constant<int, 1>{}, std::false_type{}, hB, hA, hfA, hfB);
+  gemm2((NCHUNK - 1) & 1, hfB);                               // pipeline drain: the last chunk's GEMM 2
+
+  // ---- epilogue: lane holds OUT^T[c = 16 ct + 4 g + r][token = l15]; + bias + residual (x' re-read: L2-hot), fp32 out; loads of a
+  // group of EG channel blocks all in flight before the first add / store (`out` may alias `x`: a lane only re-reads what it writes)
+  {
+    const long row = row0 + l15;
+    const bool live = row < p.M;
+    float s = 0.f;
+    constexpr int EG = 6;
+    static_assert(CT % EG == 0, "channel blocks per group");
+    const long rrow = min(row, p.M - 1);
+#pragma unroll
+    for (int ct0 = 0; ct0 < CT; ct0 += EG) {
+      float4_ xr[EG];
+      half4 dl[EG], b2[EG];
+#pragma unroll
+      for (int i = 0; i < EG; ++i) {
+        const int c = (ct0 + i) * 16 + 4 * g;
+        xr[i] = *(const float4_*)(p.x + rrow * C + c);
+        b2[i] = *(const half4*)(p.b2 + c);
+      }
+      if (p.delta) {
+#pragma unroll
+        for (int i = 0; i < EG; ++i) dl[i] = *(const half4*)(p.delta + rrow * C + (ct0 + i) * 16 + 4 * g);
+      } else {
+#pragma unroll
+        for (int i = 0; i < EG; ++i) dl[i] = (half4){(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+      }
+#pragma unroll
+      for (int i = 0; i < EG; ++i) {
+        const int ct = ct0 + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc2[ct][r] += (float)b2[i][r] + (xr[i][r] + (float)dl[i][r]); s += acc2[ct][r]; }
+      }
+#pragma unroll
+      for (int i = 0; i < EG; ++i)
+        if (live) *(float4_*)(p.out + row * C + (ct0 + i) * 16 + 4 * g) = acc2[ct0 + i];
+    }
+    if (p.y) {                                                 // fused LayerNorm of the result (next norm1 / stage norm)
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      const float mean = s * (1.f / (float)C);
+      float q = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = acc2[ct][r] - mean; q += d * d; }
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      const float rstd = rsqrtf(q * (1.f / (float)C) + p.eps_n);
+      if (live) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int c = ct * 16 + 4 * g;
+          const half4 gm = *(const half4*)(p.gn + c), bt = *(const half4*)(p.bn + c);
+          half4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (half_t)((acc2[ct][r] - mean) * rstd * (float)gm[r] + (float)bt[r]);
+          *(half4*)(p.y + row * C + c) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int C, int NW, bool DMA, bool TABLE>
+static int launch_swin_mlp2(const SwinMlp2Params& p, hipStream_t s) {
+  constexpr size_t smem = (size_t)2 * (2 * (C / 32) + C / 16) * 512 * sizeof(half_t) + (TABLE ? MQ_GELU_TAB_N * 2 * sizeof(float) : 0);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)swin_mlp2_kernel<C, NW, DMA, TABLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  constexpr int BM = 16 * NW;
+  const unsigned grid = (unsigned)((p.M + BM - 1) / BM);
+  hipLaunchKernelGGL((swin_mlp2_kernel<C, NW, DMA, TABLE>), dim3(grid), dim3(64 * NW), smem, s, p);
+  MQ_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int C, int NW>
+static int dispatch_swin_mlp2(const SwinMlp2Params& p, int flags, hipStream_t s) {
+  switch (flags & 3) {
+    case 0: return launch_swin_mlp2<C, NW, false, false>(p, s);
+    case 1: return launch_swin_mlp2<C, NW, true, false>(p, s);
+    case 2: return launch_swin_mlp2<C, NW, false, true>(p, s);
+    default: return launch_swin_mlp2<C, NW, true, true>(p, s);
+  }
+}
+
+// x [M, C] fp32, delta [M, C] 16-bit or NULL, LN gamma / beta [C], b1 [4C], b2 [C] 16-bit;
+// w1f [(4C / 32 + 2) * (C / 16) * 512]: fc1.weight fragment-major -- block (chunk j, hb in {0, 1}, ks) holds for lane l the 8 values
+//     W1[32 j + 16 hb + (l & 15)][32 ks + 8 (l >> 4) .. + 7]; two all-zero chunks behind the last one;
+// w2f [(4C / 32) * (C / 16) * 512]: fc2.weight with the k-slot permutation of mq_swin_mlp_fwd (slot 8 g + t of a 32-block <- hidden unit
+//     4 g + t for t < 4, 16 + 4 g + t - 4 for t >= 4), fragment-major -- block (chunk j, ct) holds for lane l W2p[16 ct + (l & 15)][32 j + 8 (l >> 4) .. + 7];
+// out [M, C] fp32 (may alias x), y [M, C] 16-bit = LayerNorm(out; next_g, next_b, eps_next) if y != NULL.
+// flags: bit 0 = stage the weights with LDS-DMA (global_load_lds_dwordx4) instead of through registers; bit 1 = table GELU.
+extern "C" int MQ_SYM(mq_swin_mlp2_fwd)(const float* x, const void* delta, const void* ln_g, const void* ln_b, float eps, const void* w1f,
+                                const void* b1, const void* w2f, const void* b2, float* out, const void* next_g, const void* next_b,
+                                float eps_next, void* y, long M, int C, int flags, void* stream) {
+  if (M <= 0) return 0;
+  SwinMlp2Params p;
+  p.x = x; p.delta = (const half_t*)delta; p.g2 = (const half_t*)ln_g; p.be2 = (const half_t*)ln_b; p.eps = eps;
+  p.w1f = (const half_t*)w1f; p.b1 = (const half_t*)b1; p.w2f = (const half_t*)w2f; p.b2 = (const half_t*)b2; p.out = out;
+  p.gn = (const half_t*)next_g; p.bn = (const half_t*)next_b; p.eps_n = eps_next; p.y = (half_t*)y; p.M = M;
+  if (y && (!next_g || !next_b)) return -2;
+  hipStream_t s = (hipStream_t)stream;
+  switch (C) {
+    case 96: return dispatch_swin_mlp2<96, 4>(p, flags, s);
+    case 192: return dispatch_swin_mlp2<192, 4>(p, flags, s);
+    case 384: return dispatch_swin_mlp2<384, 8>(p, flags, s);
+    default: return -1;                                      // other widths: library GEMM path of the caller
+  }
+}
+
+MQ_NAMESPACE_END

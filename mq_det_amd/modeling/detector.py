@@ -144,6 +144,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
             raise RuntimeError("mq_det_amd runs on MI355X only (HIP kernels, no CPU fallback); got device " + str(device))
         from .. import ops
         ops.load_library()
+        ops.configure(self.cfg)                                    # kernel selection: read once per plan, not per call
         self._validate_config()
         self._plan = pipeline.build_plan(self.state_dict(), self.cfg, device, dtype=compute_dtype(self.cfg))
         self._plan_key = device

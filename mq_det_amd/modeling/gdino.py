@@ -111,6 +111,7 @@ class GroundingDINO(GraphRunner, nn.Module):
             raise RuntimeError("mq_det_amd runs on MI355X only (HIP kernels, no CPU fallback); got device " + str(device))
         from .. import ops
         ops.load_library()
+        ops.configure(self.cfg)                                    # kernel selection: read once per plan, not per call
         self._plan = gp.build_gdino_plan(self.state_dict(), self.cfg, device, self._swin, dtype=compute_dtype(self.cfg))
         self._plan_key = device
         return self._plan

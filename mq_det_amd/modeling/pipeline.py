@@ -46,8 +46,11 @@ def _pack_swin(P, sd, SW, p, device, dtype):
         if P["_swin_fused_mlp"] and Ci in P["_swin_fused_widths"]:
             perm = ops.swin_mlp_w2_perm(4 * Ci, device)
             for j in range(depth):
-                b = f"{p}.layers.{i}.blocks.{j}.mlp.fc2"
-                P[b + ".w2p"] = h(b + ".weight")[:, perm].contiguous()
+                b = f"{p}.layers.{i}.blocks.{j}.mlp"
+                if ops.KERNELS["SWIN_MLP_VARIANT"] == 2:         # mq_swin_mlp2_fwd: both weights fragment-major
+                    P[b + ".w1f"], P[b + ".w2f"] = ops.swin_mlp2_pack(h(b + ".fc1.weight"), h(b + ".fc2.weight"))
+                else:
+                    P[b + ".fc2.w2p"] = h(b + ".fc2.weight")[:, perm].contiguous()
     # patch embedding (4x4 stride-4 conv) as a GEMM over (kh, kw, c)-ordered patches
     w = sd[p + ".patch_embed.proj.weight"].detach().to(device=device, dtype=torch.float32)
     P[p + ".patch_embed.lin"] = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dtype).contiguous()
@@ -252,9 +255,13 @@ def swin_forward(P, cfg, img, p="backbone.body", SW=None):
                 # one kernel: x += proj (swint.py:236); x += fc2(gelu(fc1(norm2(x)))) (:240); and the LayerNorm that reads
                 # the result next (the following block's norm1, or the stage's output norm :611)
                 nxt = f"{p}.layers.{i}.blocks.{j + 1}.norm1" if j + 1 < depth else (f"{p}.norm{i}" if i > 0 else None)
-                r = ops.swin_mlp(x.contiguous(), proj.contiguous(), P[b + ".norm2.weight"], P[b + ".norm2.bias"], 1e-5,
-                                 P[b + ".mlp.fc1.weight"], P[b + ".mlp.fc1.bias"], P[b + ".mlp.fc2.w2p"], P[b + ".mlp.fc2.bias"],
-                                 next_ln=None if nxt is None else (P[nxt + ".weight"], P[nxt + ".bias"], 1e-5))
+                nln = None if nxt is None else (P[nxt + ".weight"], P[nxt + ".bias"], 1e-5)
+                if (b + ".mlp.w1f") in P:
+                    r = ops.swin_mlp2(x.contiguous(), proj.contiguous(), P[b + ".norm2.weight"], P[b + ".norm2.bias"], 1e-5,
+                                      P[b + ".mlp.w1f"], P[b + ".mlp.fc1.bias"], P[b + ".mlp.w2f"], P[b + ".mlp.fc2.bias"], next_ln=nln)
+                else:
+                    r = ops.swin_mlp(x.contiguous(), proj.contiguous(), P[b + ".norm2.weight"], P[b + ".norm2.bias"], 1e-5,
+                                     P[b + ".mlp.fc1.weight"], P[b + ".mlp.fc1.bias"], P[b + ".mlp.fc2.w2p"], P[b + ".mlp.fc2.bias"], next_ln=nln)
                 x, h1 = r if nxt is not None else (r, None)
                 pend = None
             else:
@@ -271,8 +278,8 @@ def swin_forward(P, cfg, img, p="backbone.body", SW=None):
             x = x + pend
         if i < len(M.DEPTHS) - 1:                      # PatchMerging, swint.py:258-284
             d = f"{p}.layers.{i}.downsample"
-            if os.environ.get("MQ_PATCH_MERGE_FUSED", "0") == "1" and hasattr(ops, "patch_merge_ln"):
-                # gather + LayerNorm in one kernel (csrc/layernorm2.hip): no pad / cat pass; same values bit for bit; opt-in until measured
+            if ops.KERNELS["PATCH_MERGE_FUSED"] == 1:
+                # gather + LayerNorm in one kernel (csrc/layernorm2.hip): no pad / cat pass; same values bit for bit
                 yn = ops.patch_merge_ln(x.reshape(B, H, W, C).contiguous(), P[d + ".norm.weight"], P[d + ".norm.bias"], 1e-5)
                 H, W = (H + 1) // 2, (W + 1) // 2
             else:
@@ -299,7 +306,7 @@ def fpn_forward(P, feats_nhwc):
 
     def conv3(name, x, stride=1):
         return ops.conv3x3(x, P[f"{p}.{name}.packed"], P[f"{p}.{name}.bias"], P[f"{p}.{name}.packed"].shape[0], stride)
-    via_dcn = os.environ.get("MQ_FPN_VIA_DCN", "0") == "1" and hasattr(ops, "dcnv2_group")
+    via_dcn = ops.KERNELS["FPN_VIA_DCN"] == 1
     inner = lateral("fpn_inner4", c5)
     inners = [("fpn_layer4", inner)]
     for feat, idx in ((c4, 3), (c3, 2)):
@@ -311,7 +318,7 @@ def fpn_forward(P, feats_nhwc):
         # The three output convs (fpn.py:106-127) do not depend on each other: ONE grouped launch of the fused DCNv2 kernel with zero
         # offsets and mask logits of +100 (sigmoid = 1 exactly) -- a deformable conv sampling at integer positions with weights
         # (1, 0, 0, 0) IS the plain 3x3 conv (zero padding included: taps at -1 / H are "outside"), and that kernel runs its 128 x 256 x 64
-        # tiles at 2.5x the rate of conv_igemm's 128 x 256 x 32 ones.  Opt-in (MQ_FPN_VIA_DCN=1) until measured.
+        # tiles at 2.5x the rate of conv_igemm's 128 x 256 x 32 ones: +3.8 % end to end (round 3, GPU call 1).
         outs = ops.dcnv2_group([dict(x=x, om=_zero_offsets(x.shape[0], x.shape[1], x.shape[2], x.device), w=P[f"{p}.{n}.packed"],
                                      bias=P[f"{p}.{n}.bias"], stride=1) for n, x in inners], want_stats=False)
         res = [y.reshape(x.shape[0], hw[0], hw[1], 256) for (y, hw, _), (_, x) in zip(outs, inners)]

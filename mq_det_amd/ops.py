@@ -29,6 +29,7 @@ _SIGNATURES = {
     "mq_layernorm2_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
     "mq_patch_merge_ln_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mq_swin_mlp_fwd": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _l, _i, _vp]),
+    "mq_swin_mlp2_fwd": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _l, _i, _i, _vp]),
     "mq_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _vp]),
     "mq_conv3x3_nchw32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _vp]),
     "mq_conv3x3_nchw32_v2_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _vp]),
@@ -52,12 +53,46 @@ _SIGNATURES = {
 }
 # entry points with 16-bit operands also exist as <name>_bf16 (same signature; include/mqdet_hip.h MQ_BF16_TWIN)
 BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
-              "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_patch_merge_ln_fwd", "mq_swin_mlp_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
+              "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_patch_merge_ln_fwd", "mq_swin_mlp_fwd", "mq_swin_mlp2_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
               "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyrelu_apply",
               "mq_align_scores_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
 for _n in BF16_TWINS:
     _SIGNATURES[_n + "_bf16"] = _SIGNATURES[_n]
 EXPORTS = tuple(_SIGNATURES)
+
+
+# Kernel selection: which of two implementations of an operator runs.  Every variant was A/B'd one by one on the
+# MI355X (round 3, GPU call 1, 30 steps each, same box: profiles/r03_call1_switch_ab.txt) and the winners are the defaults below.
+# Read ONCE -- `configure()` is called by the detectors' prepare() -- never per call: cfg.MODEL.KERNELS.<NAME> first, then the
+# environment variable MQ_<NAME> (A/B runs, tests).
+KERNEL_DEFAULTS = {
+    "LN_VARIANT": 2,             # 2: mq_layernorm2_fwd (rows in flight, gamma / beta in registers; bit-identical results)      +1.2 %
+    "OFFSET_CONV_VARIANT": 2,    # 2: mq_conv3x3_nchw32_v2_fwd (window loads unconditional and in flight; bit-identical)         +4.4 %
+    "PATCH_MERGE_FUSED": 1,      # 1: mq_patch_merge_ln_fwd (Swin PatchMerging gather + LayerNorm, no pad / cat pass)            +1.6 %
+    "FPN_VIA_DCN": 1,            # 1: the three FPN output convs as ONE grouped launch of the fused DCNv2 kernel, zero offsets    +3.8 %
+    "NMS_EARLY_STOP": 1,         # 1: mq_ml_nms_topk (the sweep of an image ends once DETECTIONS_PER_IMG boxes are kept)          +0.9 %
+    "ATTN_RESIDENT": 1,          # 1: mq_attn_resident_fwd / mq_attn_chunked_fwd (S^T form, keys resident / 256-key chunks)       +4.7 %
+    "SWIN_MLP_VARIANT": 2,       # 2: mq_swin_mlp2_fwd (fragment-major weights, 3-deep software pipeline, 14-VALU GELU); 1: mq_swin_mlp_fwd
+    "SWIN_MLP2_FLAGS": 1,        # mq_swin_mlp2_fwd flags: bit 0 = LDS-DMA staging, bit 1 = table GELU
+}
+KERNELS = dict(KERNEL_DEFAULTS)
+
+
+def configure(cfg=None):
+    """(Re)read the kernel selection: defaults <- cfg.MODEL.KERNELS <- environment MQ_<NAME>.  Returns the active table."""
+    sel = dict(KERNEL_DEFAULTS)
+    node = None
+    if cfg is not None:
+        node = cfg.MODEL.get("KERNELS", None) if hasattr(cfg.MODEL, "get") else getattr(cfg.MODEL, "KERNELS", None)
+    for k in sel:
+        if node is not None and k in node:
+            sel[k] = int(node[k])
+        v = os.environ.get("MQ_" + k)
+        if v is not None:
+            sel[k] = int(v)
+    KERNELS.clear()
+    KERNELS.update(sel)
+    return KERNELS
 
 
 def lib_path():
@@ -186,8 +221,8 @@ def attention4(q4, k4, vt4, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=N
         mask_bs, mask_hs, mask_rs = qk_mask.stride(0), qk_mask.stride(1), qk_mask.stride(2)
     o = torch.empty(B, Nq, H * D, dtype=q4.dtype, device=q4.device)
     mask_ok = qk_mask is None or (Nk % 4 == 0 and mask_bs % 4 == 0 and mask_hs % 4 == 0 and mask_rs % 4 == 0 and qk_mask.data_ptr() % 4 == 0)
-    if nsplit <= 1 and Nk <= 256 and D in (32, 64) and mask_ok and o.stride(1) % 4 == 0 and os.environ.get("MQ_ATTN_RESIDENT", "0") == "1":
-        # text-sized attention on the resident-key kernel (csrc/attn_resident.hip); off by default until it is measured on the device
+    if nsplit <= 1 and Nk <= 256 and D in (32, 64) and mask_ok and o.stride(1) % 4 == 0 and KERNELS["ATTN_RESIDENT"] == 1:
+        # text-sized attention on the resident-key kernel (csrc/attn_resident.hip): 1.9x faster on its launches than mq_attn_fwd
         with _timed(f"attn_res_d{D}_nq{Nq}_nk{Nk}"):
             rc = _fn(lib, "mq_attn_resident_fwd", q4)(
                 _ptr(q4), _ptr(k4), _ptr(vt4), _ptr(o), _ptr(key_bias), _ptr(kv_len), _ptr(qk_mask), mask_bs, mask_hs, mask_rs,
@@ -199,8 +234,8 @@ def attention4(q4, k4, vt4, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=N
     ws = None
     if nsplit > 1:
         ws = torch.empty(lib.mq_attn_workspace_bytes(B, H, Nq, D, nsplit) // 4, dtype=torch.float32, device=q4.device)
-    if qk_mask is None and D in (32, 64) and o.stride(1) % 4 == 0 and os.environ.get("MQ_ATTN_RESIDENT", "0") == "1":
-        # long key sequences / key splits on the chunked S^T kernel (csrc/attn_resident.hip); opt-in, see above
+    if qk_mask is None and D in (32, 64) and o.stride(1) % 4 == 0 and KERNELS["ATTN_RESIDENT"] == 1:
+        # long key sequences / key splits on the chunked S^T kernel (csrc/attn_resident.hip)
         with _timed(f"attn_chk_d{D}_nq{Nq}_nk{Nk}_s{nsplit}"):
             rc = _fn(lib, "mq_attn_chunked_fwd", q4)(
                 _ptr(q4), _ptr(k4), _ptr(vt4), _ptr(o), _ptr(key_bias), _ptr(kv_len), _ptr(ws), B, H, Nq, Nk, D,
@@ -380,8 +415,8 @@ def layer_norm(x, gamma, beta, eps=1e-5, residual=None, want_sum=True, want_y32=
         if want_sum:
             xsum = torch.empty(x.shape, dtype=torch.float32 if (xf or rf) else h16, device=x.device)
     with _timed(f"layernorm_c{C}", sum(t.numel() * t.element_size() for t in (x, residual, y, y32, xsum) if t is not None)):
-        # MQ_LN_VARIANT=2: the load-batched kernel of csrc/layernorm2.hip (same results bit for bit; opt-in until measured on the device)
-        name = "mq_layernorm2_fwd" if os.environ.get("MQ_LN_VARIANT", "1") == "2" else "mq_layernorm_fwd"
+        # LN_VARIANT 2: the load-batched kernel of csrc/layernorm2.hip (same results bit for bit as mq_layernorm_fwd)
+        name = "mq_layernorm2_fwd" if KERNELS["LN_VARIANT"] == 2 else "mq_layernorm_fwd"
         _chk(_fn(lib, name, gamma)(_ptr(x), int(xf), _ptr(residual), int(rf), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(y32), _ptr(xsum),
                                    rows, C, float(eps), _stream()), name)
     out = [t for t in (y, y32, xsum) if t is not None]
@@ -437,6 +472,43 @@ def swin_mlp(x, delta, ln_g, ln_b, eps, w1, b1, w2p, b2, next_ln=None):
     return (out, y) if y is not None else out
 
 
+def swin_mlp2_pack(w1, w2):
+    """fc1.weight [4C, C], fc2.weight [C, 4C] -> (w1f, w2f), the fragment-major operands of mq_swin_mlp2_fwd (include/mqdet_hip.h):
+    every 512-element block is one MFMA A fragment in lane order (lane = 16 g + l15 holds row l15, k-slots 8 g .. 8 g + 7); w1f carries
+    two zero chunks behind the last one, w2f the k-slot permutation of swin_mlp_w2_perm."""
+    HID, C = w1.shape
+    assert w2.shape == (C, HID) and C % 32 == 0 and HID % 32 == 0
+    KS, CT, NCH = C // 32, C // 16, HID // 32
+    w1f = w1.reshape(NCH, 2, 16, KS, 4, 8).permute(0, 1, 3, 4, 2, 5).reshape(NCH, -1)           # [j][hb][ks][g][l15][8]
+    w1f = torch.cat([w1f, w1f.new_zeros(2, w1f.shape[1])], 0).reshape(-1).contiguous()
+    w2p = w2[:, swin_mlp_w2_perm(HID, w2.device)]
+    w2f = w2p.reshape(CT, 16, NCH, 4, 8).permute(2, 0, 3, 1, 4).reshape(-1).contiguous()         # [j][ct][g][l15][8]
+    return w1f, w2f
+
+
+def swin_mlp2(x, delta, ln_g, ln_b, eps, w1f, b1, w2f, b2, next_ln=None, flags=None):
+    """Fused Swin MLP half, second generation (mq_swin_mlp2_fwd): arguments as swin_mlp but (w1f, w2f) = swin_mlp2_pack(fc1.weight,
+    fc2.weight); flags (default KERNELS["SWIN_MLP2_FLAGS"]): bit 0 LDS-DMA staging, bit 1 table GELU."""
+    lib = load_library()
+    _need_gpu(x, delta, ln_g, ln_b, w1f, b1, w2f, b2)
+    C = x.shape[-1]
+    M = x.numel() // C
+    assert C in SWIN_MLP_WIDTHS and x.dtype == torch.float32 and x.is_contiguous()
+    assert delta is None or (delta.dtype == w1f.dtype and delta.is_contiguous() and delta.shape == x.shape)
+    assert w1f.numel() == (4 * C // 32 + 2) * (C // 16) * 512 and w2f.numel() == (4 * C // 32) * (C // 16) * 512
+    assert w1f.is_contiguous() and w2f.is_contiguous() and w1f.dtype == w2f.dtype == b1.dtype == b2.dtype == ln_g.dtype and w1f.dtype in _H16
+    out = torch.empty_like(x)
+    y, ng, nb, ne = None, None, None, 0.0
+    if next_ln is not None:
+        ng, nb, ne = next_ln
+        y = torch.empty(x.shape, dtype=w1f.dtype, device=x.device)
+    flags = KERNELS["SWIN_MLP2_FLAGS"] if flags is None else int(flags)
+    with _timed(f"swin_mlp_c{C}", M * C * (4 + 4 + (2 if delta is not None else 0) + (2 if y is not None else 0))):
+        _chk(_fn(lib, "mq_swin_mlp2_fwd", w1f)(_ptr(x), _ptr(delta), _ptr(ln_g), _ptr(ln_b), float(eps), _ptr(w1f), _ptr(b1), _ptr(w2f), _ptr(b2),
+                                               _ptr(out), _ptr(ng), _ptr(nb), float(ne), _ptr(y), M, C, flags, _stream()), "mq_swin_mlp2_fwd")
+    return (out, y) if y is not None else out
+
+
 def conv3x3(x_nhwc, w_packed, bias, n_out, stride=1):
     """x [B,H,W,C] fp16 (NHWC, contiguous H,W,C; any batch stride), w_packed [32|256, 9*C] fp16 (k = tap*C + c),
     bias [n_out] fp16 -> [B, Ho, Wo, n_out] fp16."""
@@ -464,8 +536,8 @@ def conv3x3_nchw32(x_nhwc, w_packed, bias, n_out):
     assert w_packed.is_contiguous() and w_packed.shape == (32, 9 * C) and w_packed.dtype == x_nhwc.dtype and n_out <= 32
     out = torch.empty(B, n_out, H, W, dtype=torch.float32, device=x_nhwc.device)
     with _timed("conv3x3_small", B * H * W * C * 2 + out.numel() * 4):
-        # MQ_OFFSET_CONV_VARIANT=2: unconditional / in-flight loads (csrc/conv_small2.hip), same results; opt-in until measured
-        name = "mq_conv3x3_nchw32_v2_fwd" if os.environ.get("MQ_OFFSET_CONV_VARIANT", "1") == "2" else "mq_conv3x3_nchw32_fwd"
+        # OFFSET_CONV_VARIANT 2: unconditional / in-flight loads (csrc/conv_small2.hip), same results bit for bit
+        name = "mq_conv3x3_nchw32_v2_fwd" if KERNELS["OFFSET_CONV_VARIANT"] == 2 else "mq_conv3x3_nchw32_fwd"
         _chk(_fn(lib, name, x_nhwc)(_ptr(x_nhwc), _ptr(w_packed), _ptr(bias), _ptr(out), B, H, W, C, x_nhwc.stride(0), n_out, _stream()), name)
     return out
 
@@ -742,7 +814,7 @@ def ms_deform_attn_q(value, spatial_shapes, qproj, ref, heads, out_dtype=None, v
 
 def ml_nms(boxes, labels, nvalid, thresh, max_keep=0):
     """boxes [B,N,4] fp32 sorted by score desc, labels [B,N] int32, nvalid [B] int32 -> keep [B,N] bool.
-    max_keep > 0 together with MQ_NMS_EARLY_STOP=1: the sweep of an image ends once max_keep boxes are kept (mq_ml_nms_topk; the
+    max_keep > 0 with KERNELS["NMS_EARLY_STOP"] (default): the sweep of an image ends once max_keep boxes are kept (mq_ml_nms_topk; the
     max_keep highest-scoring survivors are the same, later boxes read as not kept)."""
     lib = load_library()
     _need_gpu(boxes, labels, nvalid)
@@ -751,7 +823,7 @@ def ml_nms(boxes, labels, nvalid, thresh, max_keep=0):
     assert labels.dtype == torch.int32 and nvalid.dtype == torch.int32
     ws = torch.empty(max(lib.mq_ml_nms_workspace_bytes(B, N), 8), dtype=torch.uint8, device=boxes.device)
     keep = torch.empty(B, N, dtype=torch.uint8, device=boxes.device)
-    if max_keep > 0 and N <= 6656 and os.environ.get("MQ_NMS_EARLY_STOP", "0") == "1":
+    if max_keep > 0 and N <= 6656 and KERNELS["NMS_EARLY_STOP"] == 1:
         _chk(lib.mq_ml_nms_topk(_ptr(boxes), _ptr(labels), _ptr(nvalid), _ptr(ws), _ptr(keep), B, N, float(thresh), int(max_keep), _stream()),
              "mq_ml_nms_topk")
         return keep.bool()

@@ -287,6 +287,18 @@ def layer_norm(x, gamma, beta, eps=1e-5, residual=None, want_sum=True, want_y32=
     return out[0] if len(out) == 1 else tuple(out)
 
 
+def patch_merge_ln(x, gamma, beta, eps=1e-5):
+    """mq_patch_merge_ln_fwd: Swin PatchMerging gather (swint.py:264-281: zero pad to even H / W, the four 2x2 phases concatenated
+    along the channels in the order (0,0), (1,0), (0,1), (1,1)) + LayerNorm over 4C."""
+    B, H, W, C = x.shape
+    y = x.float()
+    if H % 2 or W % 2:
+        y = F.pad(y, (0, 0, 0, W % 2, 0, H % 2))
+    y = torch.cat([y[:, 0::2, 0::2], y[:, 1::2, 0::2], y[:, 0::2, 1::2], y[:, 1::2, 1::2]], -1)
+    y = F.layer_norm(y, (4 * C,), gamma.float(), beta.float(), eps)
+    return y.reshape(B, -1, 4 * C).to(gamma.dtype)
+
+
 def dcnv2_group(branches, want_stats=True):
     return [dcnv2(br["x"], br["om"], br["w"], br["bias"], br["stride"], want_stats=True, wy=br.get("wy"), wx=br.get("wx"))
             for br in branches]
@@ -352,6 +364,33 @@ def swin_mlp(x, delta, ln_g, ln_b, eps, w1, b1, w2p, b2, next_ln=None):
     return out, F.layer_norm(out, (x.shape[-1],), ng.float(), nb.float(), ne).to(act)
 
 
+def swin_mlp2_unpack(w1f, w2f, C):
+    """Inverse of ops.swin_mlp2_pack: fragment-major (w1f, w2f) -> (fc1.weight [4C, C], fc2.weight [C, 4C])."""
+    from mq_det_amd.ops import swin_mlp_w2_perm
+    HID, KS, CT, NCH = 4 * C, C // 32, C // 16, 4 * C // 32
+    w1 = w1f.reshape(NCH + 2, 2, KS, 4, 16, 8)[:NCH].permute(0, 1, 4, 2, 3, 5).reshape(HID, C)
+    assert float(w1f.reshape(NCH + 2, -1)[NCH:].float().abs().max()) == 0.0          # the two zero chunks the pipeline reads ahead
+    w2p = w2f.reshape(NCH, CT, 4, 16, 8).permute(1, 3, 0, 2, 4).reshape(C, HID)
+    w2 = torch.empty_like(w2p)
+    w2[:, swin_mlp_w2_perm(HID)] = w2p
+    return w1.contiguous(), w2.contiguous()
+
+
+def swin_mlp2(x, delta, ln_g, ln_b, eps, w1f, b1, w2f, b2, next_ln=None, flags=None):
+    """Plain-torch statement of mq_swin_mlp2_fwd (un-packs the fragment-major weights first)."""
+    C = x.shape[-1]
+    w1, w2 = swin_mlp2_unpack(w1f, w2f, C)
+    act = ln_g.dtype
+    xp = x.float() + (delta.float() if delta is not None else 0.0)
+    h = F.layer_norm(xp, (C,), ln_g.float(), ln_b.float(), eps).to(act)
+    hid = F.gelu(F.linear(h.float(), w1.float(), b1.float())).to(act)
+    out = xp + F.linear(hid.float(), w2.float(), b2.float())
+    if next_ln is None:
+        return out
+    ng, nb, ne = next_ln
+    return out, F.layer_norm(out, (C,), ng.float(), nb.float(), ne).to(act)
+
+
 def ms_deform_attn(value, spatial_shapes, sampling_locations, attention_weights, out_dtype=None):
     from oracle.gdino import ms_deform_attn_core
     out = ms_deform_attn_core(value.float(), spatial_shapes, sampling_locations.float(), attention_weights.float())
@@ -359,8 +398,11 @@ def ms_deform_attn(value, spatial_shapes, sampling_locations, attention_weights,
 
 
 def image_key_mask(mask):
-    from mq_det_amd.ops import image_key_mask as f
-    return f(mask)
+    """Pure tensor code in the product (no kernel): restated so that patching it over itself cannot recurse."""
+    B, N = mask.shape
+    out = torch.ones(B, -(-N // 64) * 64, dtype=torch.uint8, device=mask.device)
+    out[:, :N] = mask.to(torch.uint8)
+    return out
 
 
 def ms_deform_attn_q(value, spatial_shapes, qproj, ref, heads, out_dtype=None, valid_hw=None):
@@ -395,3 +437,29 @@ def dyconv_coef_group(items, attn_w, attn_b, groups, eps):
         y_shape = torch.empty(B, int(it["n"]), C, device="meta")          # only its shape is read on the fused-statistics path
         out.append(dyconv_branch_coef(y_shape, 0, it["gamma"], it["beta"], attn_w, attn_b, groups, eps, it["nbranches"], sums=it["sums"]))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# every emulated entry point, in one place: tests patch them into mq_det_amd.ops (or into a stand-in namespace) with these helpers
+NAMES = ("attention", "attention4", "window_attention", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores",
+         "dyconv_branch_coef", "dyconv_coef_group", "dyconv_fuse", "dyrelu_", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "vlfuse_i2t",
+         "vlfuse_t2i", "box_decode", "ml_nms", "roi_align", "swin_mlp", "swin_mlp2", "patch_merge_ln", "ms_deform_attn", "ms_deform_attn_q", "image_key_mask")
+
+
+def patch_into(monkeypatch, ops_module):
+    """monkeypatch every emulated entry point into the REAL mq_det_amd.ops module (wrappers that need a GPU are replaced)."""
+    g = globals()
+    for n in NAMES:
+        monkeypatch.setattr(ops_module, n, g[n])
+
+
+def namespace(real_ops):
+    """A stand-in for the `ops` module of pipeline.py / gdino_pipeline.py: emulated entry points + the real module's host-side
+    helpers and tables (kernel selection defaults, pad sizes, weight permutations)."""
+    import types
+    g = globals()
+    fake = types.SimpleNamespace(**{n: g[n] for n in NAMES})
+    for n in ("SWIN_MLP_WIDTHS", "SCORE_AGG", "window_pad", "pad_rel_bias", "swin_mlp_w2_perm", "swin_mlp2_pack", "timing_active"):
+        setattr(fake, n, getattr(real_ops, n))
+    fake.KERNELS = dict(real_ops.KERNEL_DEFAULTS)       # the default kernel selection: the glue of the promoted variants is what runs
+    return fake

@@ -784,7 +784,33 @@ def all_checks(dev):
 # Class scores live in [0, 1]: their MAX error is one worst location (floor: 0.09 on P7), the mean error is 3e-4 ... 1e-2.
 BENCH_TOL = {"swin": 5e-3, "fpn": 5e-3, "pooled": 5e-3, "lang": 3e-2, "text": 3e-2, "feat": 5e-2, "box": 6e-2, "dot": 7e-2,
              "cls": 0.2}
+# THE GATE.  tests/golden/floor_bench.json holds, per benchmark case and stage, the error of the fp16- (bf16-)
+# OPERAND FLOOR against the fp32 oracle (oracle/gen_golden_floor.py: the oracle with only its contraction operands rounded,
+# oracle/precision.py -- the smallest error any MFMA path with 16-bit operands can have on these weights).  A stage passes when
+#       mean|hip - ref| <= FLOOR_RATIO_MEAN * mean|floor - ref|      and      max|hip - ref| <= FLOOR_RATIO_MAX * max|floor - ref|
+# i.e. the product may add at most half the floor's own mean error on top of it at ANY stage of the full-depth model; a real 2x
+# regression of any kernel fails.  (The max is ONE worst element out of 10^5 .. 10^7 and moves by up to 2x between two equally
+# good roundings -- hence the wider factor.)  Rows with fewer than FLOOR_SMALL_N elements (the prediction maps of P6 / P7: 273 and
+# 77 positions per image) are small samples: their mean ratio scatters by +-0.3 around the large rows' and gets FLOOR_RATIO_SMALL.
+# BENCH_TOL above stays as an absolute backstop (product error <= measured x 2, as in round 2).
+FLOOR_RATIO_MEAN, FLOOR_RATIO_MAX, FLOOR_RATIO_SMALL, FLOOR_SMALL_N = 1.5, 2.5, 2.0, 4096
 _LADDER = {}
+_FLOOR = None
+
+
+def bench_case_key(family, caption, hw, dtype=None):
+    dtype = dtype or H16
+    return f"{family}|{caption}|" + "+".join(f"{h}x{w}" for h, w in hw) + "|" + str(dtype).replace("torch.", "")
+
+
+def floor_fixture():
+    global _FLOOR
+    if _FLOOR is None:
+        import json
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "floor_bench.json")
+        _FLOOR = json.load(open(path)) if os.path.exists(path) else {}
+    return _FLOOR
 
 
 def caption_ids(spec, B, n_classes=40, words=(1, 2, 3, 4, 3, 2), seed=5):
@@ -804,22 +830,69 @@ def caption_ids(spec, B, n_classes=40, words=(1, 2, 3, 4, 3, 2), seed=5):
     return ids, am, pm, nvalid
 
 
-def _bench_model(dev, residual_fp32=True):
-    key = ("bench", residual_fp32)
+def bench_spec(family):
+    from oracle import glip_l_spec, glip_t_spec
+    return glip_l_spec() if family == "l" else glip_t_spec()
+
+
+def bench_inputs(spec, caption, hw):
+    """Seeded inputs of one benchmark case (shared by the product check and oracle/gen_golden_floor.py)."""
+    from oracle import detector as od
+    from oracle.weights import make_query_bank
+    B = len(hw)
+    words = {"short": (1,), "long": (1, 2, 3, 4, 3, 2), "xlong": (4,)}[caption]
+    ids, am, pm, nv = caption_ids(spec, B, 40, words)
+    g = torch.Generator().manual_seed(7)
+    imgs = [torch.randn(3, h, w, generator=g).to(H16).float() for (h, w) in hw]
+    images, sizes = od.pad_images(imgs, spec.size_divisibility)
+    bank = make_query_bank(pm.keys(), spec)
+    return images, sizes, ids, am, pm, nv, bank
+
+
+def oracle_rows(inter, am, pm, nv):
+    """Ordered {stage name: (kind, tensor)} of an oracle forward's intermediates -- the stages the ladder compares."""
+    rows = {}
+    live = am.bool()
+    for i in range(3):
+        rows[f"swin c{i + 3}"] = ("swin", inter["swin"][i + 1])
+    for i in range(5):
+        rows[f"fpn p{i + 3}"] = ("fpn", inter["fpn"][i])
+    if inter.get("pooled") is not None:
+        rows["pooled fpn tokens"] = ("pooled", inter["pooled"])
+    rows["language hidden (caption tokens)"] = ("lang", inter["lang"]["hidden"][live])
+    for i, o in enumerate(inter["head_trace"]):
+        rows[f"head layer {i}: image tokens after VLFuse"] = ("feat", torch.cat([f.flatten(2).transpose(1, 2) for f in o["fuse_feats"]], 1))
+        rows[f"head layer {i}: text hidden after BERT layer"] = ("text", o["bert_hidden"][live])
+        rows[f"head layer {i}: image tokens after DyConv"] = ("feat", torch.cat([f.flatten(2).transpose(1, 2) for f in o["dyconv_feats"]], 1))
+    h = inter["head"]
+    for l in range(5):
+        rows[f"bbox_reg lvl{l}"] = ("box", h["bbox_reg"][l])
+        rows[f"centerness lvl{l}"] = ("box", h["centerness"][l])
+        rows[f"dot-product logits lvl{l}"] = ("dot", h["dot_product_logits"][l][:, :, :nv])
+        rows[f"class scores lvl{l}"] = ("cls", torch.stack([h["dot_product_logits"][l].sigmoid()[:, :, torch.tensor(pm[k])].mean(-1) for k in pm], -1))
+    return rows
+
+
+def _bench_model(dev, residual_fp32=True, family="t"):
+    key = ("bench", residual_fp32, family)
     if key not in _CACHE:
-        from oracle import glip_t_spec
         from oracle.weights import make_state_dict
         from mq_det_amd import get_cfg
         from mq_det_amd.modeling.detector import GeneralizedVLRCNN_New
-        spec = glip_t_spec()
-        sd = _CACHE.get("bench_sd")
+        spec = bench_spec(family)
+        sd = _CACHE.get(("bench_sd", family))
         if sd is None:
-            sd = _CACHE["bench_sd"] = make_state_dict(spec, 0)
+            sd = _CACHE[("bench_sd", family)] = make_state_dict(spec, 0)
         cfg = get_cfg()
+        cfg.MODEL.SWINT.EMBED_DIM, cfg.MODEL.SWINT.NUM_HEADS = spec.swin_embed, spec.swin_heads
+        cfg.MODEL.SWINT.WINDOW_SIZE, cfg.MODEL.SWINT.OUT_CHANNELS = spec.window, spec.swin_dims
+        cfg.MODEL.SWINT.DEPTHS = spec.swin_depths
+        cfg.MODEL.DYHEAD.NUM_CONVS = spec.dyhead_convs
         cfg.MODEL.DYHEAD.NUM_CLASSES = spec.num_classes
         cfg.MODEL.ATSS.DETECTIONS_PER_IMG = spec.detections_per_img
         cfg.TEST.MDETR_STYLE_AGGREGATE_CLASS_NUM = spec.mdetr_class_num
         cfg.MODEL.RESIDUAL_FP32 = residual_fp32
+        cfg.MODEL.COMPUTE_DTYPE = "bfloat16" if H16 == torch.bfloat16 else "float16"
         model = GeneralizedVLRCNN_New(cfg, tokenizer=object())
         model.load_state_dict(sd, strict=True)
         model.to(dev)
@@ -846,80 +919,77 @@ def _match_detections(gb, gs, gl, rb, rs, rl, top=100, iou_thr=0.9, ds=0.03):
     return hit / max(1, len(order))
 
 
-def check_benchmark_config(dev, caption="long", hw=((800, 1333),), residual_fp32=True, floor=False):
-    """caption: 'short' = 81 tokens (NT = 2 VLFuse kernels), 'long' = 141 tokens (NT = 3), 'xlong' = 201 tokens (NT = 4).
-    floor: also run the fp16-operand floor emulation of the oracle (slow; gpu_diag only) and attach it to every row."""
+def check_benchmark_config(dev, caption="long", hw=((800, 1333),), residual_fp32=True, floor=False, family="t"):
+    """Full-depth model at the benchmark geometry vs the fp32 oracle, gated by the committed operand floor (see FLOOR_RATIO_*).
+    caption: 'short' = 81 tokens (NT = 2 VLFuse kernels), 'long' = 141 tokens (NT = 3), 'xlong' = 201 tokens (NT = 4).
+    family: 't' = MQ-GLIP-T (BASELINE configs[1]), 'l' = MQ-GLIP-L (configs[3]: Swin-L 2-2-18-2, window 12, 8 fusion layers).
+    floor: recompute the floor here instead of reading tests/golden/floor_bench.json (slow; tests/gpu_diag.py --ladder)."""
     from dataclasses import replace
     from oracle import detector as od, postprocess as opp
-    from oracle.weights import make_query_bank
     from mq_det_amd.modeling import pipeline
     from mq_det_amd.modeling.query_selector import build_token_index
     from mq_det_amd.structures import ImageList
-    spec, sd, cfg, model = _bench_model(dev, residual_fp32)
+    spec, sd, cfg, model = _bench_model(dev, residual_fp32, family)
     P = model._plan
     B = len(hw)
-    words = {"short": (1,), "long": (1, 2, 3, 4, 3, 2), "xlong": (4,)}[caption]
-    ids, am, pm, nv = caption_ids(spec, B, 40, words)
-    g = torch.Generator().manual_seed(7)
-    imgs = [torch.randn(3, h, w, generator=g).to(H16).float() for (h, w) in hw]
-    images, sizes = od.pad_images(imgs, spec.size_divisibility)
-    bank = make_query_bank(pm.keys(), spec)
+    images, sizes, ids, am, pm, nv, bank = bench_inputs(spec, caption, hw)
     model.load_query_bank(bank)
-    okey = ("bench_oracle", caption, tuple(hw))
+    okey = ("bench_oracle", family, caption, tuple(hw))
     with torch.no_grad():
         if okey not in _CACHE:                         # the oracle does not depend on the product's precision switches
             _CACHE[okey] = od.forward(sd, spec, images, sizes, ids, am, pm, bank, return_intermediates=True)
         dets, inter = _CACHE[okey]
-        fl = None
+        ref_rows = oracle_rows(inter, am, pm, nv)
+        fl = fl_rows = None
         if floor:
             from oracle.precision import RoundGemmOperands
-            with RoundGemmOperands(torch.float16):
+            with RoundGemmOperands(H16):
                 _, fl = od.forward(sd, spec, images, sizes, ids, am, pm, bank, return_intermediates=True)
+            fl_rows = oracle_rows(fl, am, pm, nv)
         raw = model(ImageList(images.to(dev), sizes), captions=None, positive_map=pm, return_raw=True,
                     input_ids=ids.to(dev), attention_mask=am.to(dev))
         x = images.to(dev).to(H16).contiguous(memory_format=torch.channels_last)
         cg = pipeline.swin_forward(P, cfg, x)
-    res = []
-
-    def row(kind, name, got, ref, floor_val=None):
-        r = _stat(f"bench[{caption},B={B}{'' if residual_fp32 else ',fp16 streams'}] {name}", got, ref, tol=BENCH_TOL[kind])
-        if floor_val is not None:
-            f = _stat("floor", floor_val, ref)
-            r["floor_norm_err"], r["floor_mean_err"] = f["norm_err"], f["mean_err"]
-        res.append(r)
-
-    F_ = (lambda path: None) if fl is None else (lambda path: path(fl))
-    for i in range(3):
-        row("swin", f"swin c{i + 3}", cg[i].permute(0, 3, 1, 2), inter["swin"][i + 1], F_(lambda t: t["swin"][i + 1]))
-    for i in range(5):
-        row("fpn", f"fpn p{i + 3}", raw["feats"][i], inter["fpn"][i], F_(lambda t: t["fpn"][i]))
-    row("pooled", "pooled fpn tokens", raw["pooled"], inter["pooled"], F_(lambda t: t["pooled"]))
+    # ---- the product's tensors under the oracle's stage names
     live = am.bool()
+    got = {}
+    for i in range(3):
+        got[f"swin c{i + 3}"] = cg[i].permute(0, 3, 1, 2)
+    for i in range(5):
+        got[f"fpn p{i + 3}"] = raw["feats"][i]
+    got["pooled fpn tokens"] = raw["pooled"]
     lh = raw["lang"]["hidden32"] if raw["lang"].get("hidden32") is not None else raw["lang"]["hidden"]
-    row("lang", "language hidden (caption tokens)", lh.cpu()[live], inter["lang"]["hidden"][live], F_(lambda t: t["lang"]["hidden"][live]))
-    tr, otr = raw["head_trace"], inter["head_trace"]
-    for i, (a, o) in enumerate(zip(tr, otr)):
-        oa = torch.cat([f.flatten(2).transpose(1, 2) for f in o["fuse_feats"]], 1)
-        ob = torch.cat([f.flatten(2).transpose(1, 2) for f in o["dyconv_feats"]], 1)
-        fa = fb = fh = None
-        if fl is not None:
-            fo = fl["head_trace"][i]
-            fa = torch.cat([f.flatten(2).transpose(1, 2) for f in fo["fuse_feats"]], 1)
-            fb = torch.cat([f.flatten(2).transpose(1, 2) for f in fo["dyconv_feats"]], 1)
-            fh = fo["bert_hidden"][live]
-        row("feat", f"head layer {i}: image tokens after VLFuse", a["fuse_tok"], oa, fa)
-        row("text", f"head layer {i}: text hidden after BERT layer", a["bert_hidden"].cpu()[live], o["bert_hidden"][live], fh)
-        row("feat", f"head layer {i}: image tokens after DyConv", a["dyconv_tok"], ob, fb)
-    h = inter["head"]
+    got["language hidden (caption tokens)"] = lh.cpu()[live]
+    for i, a in enumerate(raw["head_trace"]):
+        got[f"head layer {i}: image tokens after VLFuse"] = a["fuse_tok"]
+        got[f"head layer {i}: text hidden after BERT layer"] = a["bert_hidden"].cpu()[live]
+        got[f"head layer {i}: image tokens after DyConv"] = a["dyconv_tok"]
     for l in range(5):
-        row("box", f"bbox_reg lvl{l}", raw["head"]["bbox_reg"][l], h["bbox_reg"][l], F_(lambda t: t["head"]["bbox_reg"][l]))
-        row("box", f"centerness lvl{l}", raw["head"]["centerness"][l], h["centerness"][l], F_(lambda t: t["head"]["centerness"][l]))
-        logit = raw["head"]["dot"][l].float() + raw["head"]["tbias"][:, None, :]
-        row("dot", f"dot-product logits lvl{l}", logit[:, :, :nv], h["dot_product_logits"][l][:, :, :nv],
-            F_(lambda t: t["head"]["dot_product_logits"][l][:, :, :nv]))
-        cls_ref = torch.stack([h["dot_product_logits"][l].sigmoid()[:, :, torch.tensor(pm[k])].mean(-1) for k in pm], -1)
-        fc = None if fl is None else torch.stack([fl["head"]["dot_product_logits"][l].sigmoid()[:, :, torch.tensor(pm[k])].mean(-1) for k in pm], -1)
-        row("cls", f"class scores lvl{l}", raw["post"]["cls"][l], cls_ref, fc)
+        got[f"bbox_reg lvl{l}"] = raw["head"]["bbox_reg"][l]
+        got[f"centerness lvl{l}"] = raw["head"]["centerness"][l]
+        got[f"dot-product logits lvl{l}"] = (raw["head"]["dot"][l].float() + raw["head"]["tbias"][:, None, :])[:, :, :nv]
+        got[f"class scores lvl{l}"] = raw["post"]["cls"][l]
+    case = bench_case_key(family, caption, hw)
+    fixture = floor_fixture().get(case, {}) if residual_fp32 else {}
+    tag = f"bench[{'MQ-GLIP-L,' if family == 'l' else ''}{caption},B={B}{'' if residual_fp32 else ',fp16 streams'}]"
+    res = []
+    for name, (kind, ref) in ref_rows.items():
+        r = _stat(f"{tag} {name}", got[name], ref, tol=BENCH_TOL[kind])
+        fx = fixture.get(name)
+        if fl_rows is not None:
+            f = _stat("floor", fl_rows[name][1], ref)
+            fx = {"max": f["max_err"], "mean": f["mean_err"], "norm": f["norm_err"], "n": ref.numel()}
+        if fx is not None:
+            r["floor_norm_err"], r["floor_mean_err"] = fx["norm"], fx["mean"]
+            rm = FLOOR_RATIO_MEAN if fx["n"] >= FLOOR_SMALL_N else FLOOR_RATIO_SMALL
+            r["ratio_mean"] = r["mean_err"] / max(fx["mean"], 1e-12)
+            r["ratio_max"] = r["max_err"] / max(fx["max"], 1e-12)
+            r["gate"] = f"mean <= {rm} x floor, max <= {FLOOR_RATIO_MAX} x floor"
+            r["ok"] = bool(r["ok"] and r["ratio_mean"] <= rm and r["ratio_max"] <= FLOOR_RATIO_MAX)
+        elif residual_fp32:
+            r["ok"], r["gate"] = False, f"no floor fixture for case {case!r} / stage {name!r}: run python -m oracle.gen_golden_floor"
+        res.append(r)
+    h = inter["head"]
     # ---- detections, both score-aggregation widths of the boundary (SURVEY.md 8b): LVIS-style
     # TEST.MDETR_STYLE_AGGREGATE_CLASS_NUM = 3000 with 300 detections, and the default -1 (DYHEAD.NUM_CLASSES - 1) with 100
     labels = [k for k, v in pm.items() if len(v)]
@@ -942,17 +1012,21 @@ def check_benchmark_config(dev, caption="long", hw=((800, 1333),), residual_fp32
             n = int(post["counts"][b])
             frac = _match_detections(post["boxes"][b, :n].cpu(), post["scores"][b, :n].cpu(), post["labels"][b, :n].cpu(),
                                      odets[b]["boxes"], odets[b]["scores"], odets[b]["labels"], top=top)
-            r = {"name": f"bench[{caption},B={B}] {mode}: top-{top} detections matched (IoU>0.9, |ds|<0.03) img{b} "
+            need = 0.95 if H16 == torch.float16 else 0.85          # bf16: 8x the rounding step, see use_dtype
+            r = {"name": f"{tag} {mode}: top-{top} detections matched (IoU>0.9, |ds|<0.03) img{b} "
                          f"n_hip={n} n_ref={len(odets[b]['boxes'])}", "max_err": 1 - frac, "mean_err": 0.0, "ref_absmax": 1.0,
-                 "norm_err": 1 - frac, "tol": 0.05, "ok": frac >= 0.95}
-            if fl is not None:                         # what the fp16-operand floor itself reproduces
+                 "norm_err": 1 - frac, "tol": 1 - need, "ok": frac >= need}
+            fxd = fixture.get(f"{mode}: detections img{b}")
+            if fl is not None:                         # what the operand floor itself reproduces
                 fh = fl["head"]
                 fdets = opp.atss_postprocess(fh["bbox_reg"], fh["centerness"], fh["dot_product_logits"], inter["anchors"], sizes, pm, spec2)
                 r["floor_norm_err"] = 1 - _match_detections(fdets[b]["boxes"], fdets[b]["scores"], fdets[b]["labels"], odets[b]["boxes"],
                                                             odets[b]["scores"], odets[b]["labels"], top=top)
                 r["floor_mean_err"] = 0.0
+            elif fxd is not None:
+                r["floor_norm_err"], r["floor_mean_err"] = fxd["norm"], 0.0
             res.append(r)
-    _LADDER[(caption, B, residual_fp32)] = res
+    _LADDER[(family, caption, B, residual_fp32)] = res
     return res
 
 
@@ -1062,34 +1136,45 @@ def check_extract_query(dev):
     return res
 
 
-def check_swin_mlp(dev):
-    """mq_swin_mlp_fwd (LN prologue + fc1 + exact GELU + fc2 + residual + fused next LayerNorm in one kernel) vs a plain fp32
-    statement on the same fp16-rounded weights: every supported width, ragged token counts, with / without delta / next-LN."""
+def check_swin_mlp(dev, variants=None):
+    """The fused Swin MLP half (LN prologue + fc1 + exact GELU + fc2 + residual + fused next LayerNorm in one kernel) vs a plain fp32
+    statement on the same fp16-rounded weights: every supported width, ragged token counts, with / without delta / next-LN.
+    variants: ("v1",) = mq_swin_mlp_fwd; ("v2", flags) = mq_swin_mlp2_fwd with flags (bit 0 LDS-DMA staging, bit 1 table GELU);
+    default: v1 and all four v2 flag combinations."""
     from mq_det_amd import ops
-    g = torch.Generator().manual_seed(51)
     res = []
-    for C, M, use_delta, use_next in ((96, 1000, True, True), (96, 128, False, False), (192, 777, True, True), (384, 333, True, True),
-                                      (384, 64, True, False), (96, 67200 * 2 + 5, True, True))[:5 if QUICK else 6]:
-        x = torch.randn(M, C, generator=g) * 1.5
-        delta = (torch.randn(M, C, generator=g) * 0.5).to(H16) if use_delta else None
-        lg, lb = (torch.randn(C, generator=g) * 0.1 + 1).to(H16), (torch.randn(C, generator=g) * 0.1).to(H16)
-        w1 = (torch.randn(4 * C, C, generator=g) / math.sqrt(C)).to(H16)
-        b1 = (torch.randn(4 * C, generator=g) * 0.1).to(H16)
-        w2 = (torch.randn(C, 4 * C, generator=g) / math.sqrt(4 * C)).to(H16)
-        b2 = (torch.randn(C, generator=g) * 0.1).to(H16)
-        ng, nb = (torch.randn(C, generator=g) * 0.1 + 1).to(H16), (torch.randn(C, generator=g) * 0.1).to(H16)
-        xp = x + (delta.float() if use_delta else 0.0)
-        h = F.layer_norm(xp, (C,), lg.float(), lb.float(), 1e-5).to(H16).float()          # the kernel feeds fp16 to the MFMAs
-        hid = F.gelu(F.linear(h, w1.float(), b1.float())).to(H16).float()
-        ref = xp + F.linear(hid, w2.float(), b2.float())
-        w2p = w2[:, ops.swin_mlp_w2_perm(4 * C)].contiguous()
-        r = ops.swin_mlp(x.to(dev), None if delta is None else delta.to(dev), lg.to(dev), lb.to(dev), 1e-5, w1.to(dev), b1.to(dev),
-                         w2p.to(dev), b2.to(dev), next_ln=(ng.to(dev), nb.to(dev), 1e-5) if use_next else None)
-        out, y = r if use_next else (r, None)
-        tag = f"swin_mlp C={C} M={M} delta={use_delta}"
-        res.append(_stat(f"{tag}: out (fp32 stream)", out, ref, tol=1e-3))
-        if use_next:
-            res.append(_stat(f"{tag}: fused next LayerNorm", y, F.layer_norm(ref, (C,), ng.float(), nb.float(), 1e-5), tol=2e-3))
+    variants = variants or (("v1",), ("v2", 0), ("v2", 1), ("v2", 2), ("v2", 3))
+    for var in variants:
+        g = torch.Generator().manual_seed(51)
+        for C, M, use_delta, use_next in ((96, 1000, True, True), (96, 128, False, False), (192, 777, True, True), (384, 333, True, True),
+                                          (384, 64, True, False), (96, 67200 * 2 + 5, True, True))[:5 if QUICK else 6]:
+            x = torch.randn(M, C, generator=g) * 1.5
+            delta = (torch.randn(M, C, generator=g) * 0.5).to(H16) if use_delta else None
+            lg, lb = (torch.randn(C, generator=g) * 0.1 + 1).to(H16), (torch.randn(C, generator=g) * 0.1).to(H16)
+            w1 = (torch.randn(4 * C, C, generator=g) / math.sqrt(C)).to(H16)
+            b1 = (torch.randn(4 * C, generator=g) * 0.1).to(H16)
+            w2 = (torch.randn(C, 4 * C, generator=g) / math.sqrt(4 * C)).to(H16)
+            b2 = (torch.randn(C, generator=g) * 0.1).to(H16)
+            ng, nb = (torch.randn(C, generator=g) * 0.1 + 1).to(H16), (torch.randn(C, generator=g) * 0.1).to(H16)
+            xp = x + (delta.float() if use_delta else 0.0)
+            h = F.layer_norm(xp, (C,), lg.float(), lb.float(), 1e-5).to(H16).float()          # the kernel feeds fp16 to the MFMAs
+            hid = F.gelu(F.linear(h, w1.float(), b1.float())).to(H16).float()
+            ref = xp + F.linear(hid, w2.float(), b2.float())
+            nln = (ng.to(dev), nb.to(dev), 1e-5) if use_next else None
+            dl = None if delta is None else delta.to(dev)
+            if var[0] == "v1":
+                w2p = w2[:, ops.swin_mlp_w2_perm(4 * C)].contiguous()
+                r = ops.swin_mlp(x.to(dev), dl, lg.to(dev), lb.to(dev), 1e-5, w1.to(dev), b1.to(dev), w2p.to(dev), b2.to(dev), next_ln=nln)
+                tag = f"swin_mlp C={C} M={M} delta={use_delta}"
+            else:
+                w1f, w2f = ops.swin_mlp2_pack(w1, w2)
+                r = ops.swin_mlp2(x.to(dev), dl, lg.to(dev), lb.to(dev), 1e-5, w1f.to(dev), b1.to(dev), w2f.to(dev), b2.to(dev), next_ln=nln,
+                                  flags=var[1])
+                tag = f"swin_mlp2[{'dma' if var[1] & 1 else 'regs'},{'table' if var[1] & 2 else 'erf'}] C={C} M={M} delta={use_delta}"
+            out, y = r if use_next else (r, None)
+            res.append(_stat(f"{tag}: out (fp32 stream)", out, ref, tol=1e-3))
+            if use_next:
+                res.append(_stat(f"{tag}: fused next LayerNorm", y, F.layer_norm(ref, (C,), ng.float(), nb.float(), 1e-5), tol=2e-3))
     return res
 
 

@@ -235,6 +235,10 @@ inline simt_fp16x4 simt_ds_read_tr16(uintptr_t addr) {
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+// global_load_lds_dword{,x4}: every lane copies `size` bytes from ITS global address to  (wave-uniform LDS base) + lane * size
+inline void simt_global_load_lds(const void* g, void* lds, unsigned size) { memcpy((char*)lds + (size_t)simt::lane() * size, g, size); }
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) simt_global_load_lds((const void*)(g), (void*)(l), (unsigned)(size))
 inline float simt_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 #define __builtin_amdgcn_fmed3f(a, b, c) simt_fmed3f((a), (b), (c))
 #define __builtin_amdgcn_s_barrier() simt::block_sync()

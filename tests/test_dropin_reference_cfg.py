@@ -61,10 +61,7 @@ def test_reference_cfg_tree_and_caller_sequence(monkeypatch):
     sd = make_state_dict(spec, 0)
 
     # ---- test-only: emulated HIP entry points, CPU plan (the product refuses CPU by design)
-    for n in ("attention", "attention4", "window_attention", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores",
-              "dyconv_branch_coef", "dyconv_coef_group", "dyconv_fuse", "dyrelu_", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "vlfuse_i2t",
-              "vlfuse_t2i", "box_decode", "ml_nms", "roi_align", "swin_mlp"):
-        monkeypatch.setattr(ops, n, getattr(emu, n))
+    emu.patch_into(monkeypatch, ops)
 
     def prepare(self, device=None):
         self._plan = pipeline.build_plan(self.state_dict(), self.cfg, torch.device("cpu"), dtype=torch.float32)
@@ -179,9 +176,7 @@ def test_groundingdino_reference_cfg_and_caller_sequence(monkeypatch):
     cfg.VISION_QUERY.QUERY_BANK_PATH = ""
     sd = make_gdino_state_dict(spec, 0)
 
-    for n in ("attention", "attention4", "window_attention", "gcp_sparse_attention", "gcp_gate_residual", "layer_norm", "vlfuse_i2t",
-              "vlfuse_t2i", "swin_mlp", "conv3x3", "ms_deform_attn_q", "roi_align"):
-        monkeypatch.setattr(ops, n, getattr(emu, n))
+    emu.patch_into(monkeypatch, ops)
 
     def prepare(self, device=None):
         self._plan = gp.build_gdino_plan(self.state_dict(), self.cfg, torch.device("cpu"), self._swin, dtype=torch.float32)
@@ -275,10 +270,7 @@ def test_glipdemo_caller_sequence(monkeypatch):
     spec = Spec(swin_depths=(2, 2, 2, 2), dyhead_convs=2, vocab=4000, num_classes=cfg.MODEL.DYHEAD.NUM_CLASSES, mdetr_class_num=-1,
                 detections_per_img=cfg.MODEL.ATSS.DETECTIONS_PER_IMG, vision_query=False)
     sd = make_state_dict(Spec(swin_depths=(2, 2, 2, 2), dyhead_convs=2, vocab=4000, num_classes=cfg.MODEL.DYHEAD.NUM_CLASSES), 0)
-    for n in ("attention", "attention4", "window_attention", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores",
-              "dyconv_branch_coef", "dyconv_coef_group", "dyconv_fuse", "dyrelu_", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "vlfuse_i2t",
-              "vlfuse_t2i", "box_decode", "ml_nms", "roi_align", "swin_mlp"):
-        monkeypatch.setattr(ops, n, getattr(emu, n))
+    emu.patch_into(monkeypatch, ops)
 
     def prepare(self, device=None):
         self._plan = pipeline.build_plan(self.state_dict(), self.cfg, torch.device("cpu"), dtype=torch.float32)

@@ -38,13 +38,8 @@ def gdino_cfg(spec, tok_dir=None):
 
 @pytest.fixture()
 def emulated_ops(monkeypatch):
-    fake = types.SimpleNamespace(**{n: getattr(emu, n) for n in (
-        "attention", "attention4", "window_attention", "gcp_sparse_attention", "gcp_gate_residual", "layer_norm", "vlfuse_i2t",
-        "vlfuse_t2i", "swin_mlp", "conv3x3", "ms_deform_attn_q", "image_key_mask")})
-    fake.SWIN_MLP_WIDTHS = (96, 192, 384)
-    fake.SCORE_AGG = {"MEAN": 0, "MAX": 1, "POWER": 2, "ONEHOT": 0}
     from mq_det_amd import ops as real
-    fake.window_pad, fake.swin_mlp_w2_perm = real.window_pad, real.swin_mlp_w2_perm
+    fake = emu.namespace(real)
     monkeypatch.setattr(pipeline, "ops", fake)
     monkeypatch.setattr(gp, "ops", fake)
     return fake
