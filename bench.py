@@ -19,6 +19,10 @@ Rank 0 prints ONE JSON line with the contract fields plus
                  ALGORITHMIC and the EXECUTED flop counts side by side, HBM-bound (algorithmic GB/s vs 8 TB/s)
   lang_path_b64  north-star target line: the language path (12 BERT + 6 GCP + pre-select) at B = 64 on one GPU, with the
                  MFMA utilisation of its attention kernels
+  kernel_set_ab  the same workload once more (bounded subprocess) on the ROUND-2 kernel set -- every operator with two
+                 implementations on the one that is not the default (ops.KERNEL_DEFAULTS) -- i.e. what round 3's selection buys
+  other_configs  the other BASELINE.json configurations as bounded subprocess lines of this same script: configs[2] shape
+                 (--workload lvis, chunk batching), configs[3] (--workload mq-glip-l, bf16), configs[4] (--workload mq-gdino-t, B = 16)
   cpu_baseline   (N = 1) BASELINE.md section 3 / configs[0]: the fp32 CPU oracle, GLIP-T without vision queries, one 800x1333
                  image, 20-token caption, 2 warm-up + 5 timed forwards, median.
 
@@ -51,6 +55,20 @@ HBM_PEAK_GBS = 8000.0
 
 
 GFLOP_PER_IMAGE_L = 3260.0         # MQ-GLIP-L (Swin-L 1625 + 8 fusion layers ...), BASELINE.md section 2
+
+
+def executed_gflop_per_image(n_tok, layers=6, swin=198.2):
+    """FLOPs this implementation EXECUTES per image-forward (2 * MAC, MFMA + library GEMMs), as opposed to the reference's un-folded
+    algorithmic 1451 GF (SURVEY.md 8d, T = 256):  Swin + FPN 29.3 + BERT 45.9 + pre-select 7.5 + GCP 17.9 (K / V projected once per
+    unique vision token: 6 x 2.0 GF less) + per fusion layer {VLFuse: image-side projections folded into the text operands (70.5 GF gone;
+    folded text GEMMs 2.4), QK^T computed by both directions over the live key blocks; BERT layer 3.8; DyConv 42.4} + heads over the live
+    text blocks."""
+    N = sum(h * w for h, w in LEVELS)
+    k16, k32 = -(-n_tok // 16) * 16, -(-n_tok // 32) * 32
+    vlfuse_attn = (2.0 * 8 * N * 256 * (k16 + k32) + 4.0 * 8 * N * 256 * k16) / 1e9
+    per_layer = vlfuse_attn + 2.4 + 3.83 + 42.4
+    heads = 2.0 * N * 256 * (k16 + 16) / 1e9
+    return swin + 29.3 + 45.9 + 7.5 + 17.9 + layers * per_layer + heads
 
 
 def build_model(dev, caches=False, n_classes=NUM_CLASSES_IN_CAPTION, n_categories=None, large=False, words=None, dtype="f16"):
@@ -186,6 +204,16 @@ def main_gdino(args, rank, world, dev):
                "stages_ms_per_step": {k: round(v / max(prof_steps, 1), 3) for k, v in stages.items()},
                "timing": "kernels_ms_per_step: HIP events around each hand-written launch in an eager pass of the same step; "
                          "stages_ms_per_step: HIP events between pipeline stages in an eager pass (host launch gaps included)"}
+        msda = [(k, v) for k, v in kern.items() if k.startswith("msdeform_attn_q")]
+        if msda:                                   # the gather kernel of the deformable attention: bound by 64-byte corner rows through L2
+            k, v = max(msda, key=lambda kv: kv[1][1])
+            gathered = Bn * int(k[len("msdeform_attn_q"):]) * 8 * 16 * 4 * 64.0 * v[0]
+            res["roofline"] = {"bound": "hbm", "kernel": "msda_q_kernel (MSDeformAttn: softmax + sampling locations + bilinear gather), encoder shape",
+                               "achieved": round(v[2] / (v[1] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(v[2] / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                               "avg_launch_ms": round(v[1] / v[0], 4), "l2_gather_GBs": round(gathered / (v[1] * 1e-3) / 1e9, 1),
+                               "note": "achieved = ALGORITHMIC bytes (value once + projection + output) / time; l2_gather_GBs = bytes of the 64-byte "
+                                       "corner rows the gather pulls through L2 -> L1 (the real bound, DESIGN.md 11)"}
         if world == 1 and args.cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(timeout=300, flag="--cpu-baseline-worker-gdino")
         print(json.dumps(res), flush=True)
@@ -314,7 +342,7 @@ def _pmc():
     return {}
 
 
-def kernel_rooflines(kern, steps, Bn, n_tok):
+def kernel_rooflines(kern, steps, Bn, n_tok, embed=96):
     """kern: ops.stop_timing() of `steps` eager single-stream forwards -> per-kernel roofline records (per step)."""
     pmc = _pmc()
     N_img = sum(h * w for h, w in LEVELS)
@@ -346,22 +374,33 @@ def kernel_rooflines(kern, steps, Bn, n_tok):
                          f"direction recomputes QK^T ({k16} / {k32} keys image side, {r16} query rows text side); traffic: PMC bytes per "
                          "launch, mean of the two directions (text side incl. its merge)", pmc.get("vlfuse")))
     # ---- generic attention kernel (BERT self-attention 12 x 64; GCP pre-select 8 x 32): QK^T + PV over the visited keys
-    att = [(k, v) for k, v in per.items() if k.startswith("attn_d")]
+    att = [(k, v) for k, v in per.items() if k.startswith(("attn_d", "attn_res_d", "attn_chk_d"))]
     if att:
         fl = 0.0
         for k, (n, ms, _) in att:
-            d, nq, nk = (int(x[1:] if x[0] == "d" else x[2:]) for x in k.split("_")[1:4])
+            f = [x for x in k.split("_") if x[:1] == "d" or x[:2] in ("nq", "nk")]
+            d, nq, nk = int(f[0][1:]), int(f[1][2:]), int(f[2][2:])
             heads = 12 if d == 64 else 8
             nk_eff = min(nk, -(-n_tok // 64) * 64) if d == 64 else nk
             fl += n * 4.0 * Bn * heads * nq * nk_eff * d
-        out.append(_mfma("attn_fwd_kernel (BERT self-attention 12 x 64, T = 256; GCP pre-select 8 x 32 over 5577 image tokens)", fl, fl,
-                         sum(v[0] for _, v in att), sum(v[1] for _, v in att), "flops = 4 * B * heads * Nq * Nk_visited * D"))
+        out.append(_mfma("attn_resident_kernel / attn_chunked_kernel (BERT self-attention 12 x 64, T = 256; GCP pre-select 8 x 32 over 5577 "
+                         "image tokens)", fl, fl, sum(v[0] for _, v in att), sum(v[1] for _, v in att), "flops = 4 * B * heads * Nq * Nk_visited * D"))
+    # ---- fused Swin MLP (swin_mlp2.hip): 16 M C^2 per launch (fc1 + fc2), M = tokens of the stage
+    mlp = [(k, v) for k, v in per.items() if k.startswith("swin_mlp_c")]
+    if mlp:
+        fl = 0.0
+        for k, (n, ms, nbytes) in mlp:
+            C = int(k[len("swin_mlp_c"):])
+            M = Bn * (IMG_HW[0] // 4) * (-(-IMG_HW[1] // 32) * 32 // 4) * (embed / C) ** 2       # tokens of the stage whose width is C
+            fl += n * 16.0 * M * C * C
+        out.append(_mfma("swin_mlp2_kernel (LN + fc1 + exact GELU + fc2 + residual + next LN in one kernel; VALU (GELU) bound at C = 96)", fl, fl,
+                         sum(v[0] for _, v in mlp), sum(v[1] for _, v in mlp), "flops = 16 * M * C^2 per launch (fc1 + fc2, hidden 4C)"))
     # ---- HBM-bound kernels: algorithmic bytes (every input read once, every output written once) / time
     groups = (("layernorm_kernel (all LayerNorms, residual add fused)", "layernorm_c"), ("window_attn_kernel (Swin W-MSA / SW-MSA)", "window_attn_c"),
               ("dyconv_fuse_kernel (GroupNorm affine + up-sampling + scale attention + branch mean)", "dyconv_fuse"),
-              ("swin_mlp_kernel (LN + fc1 + GELU + fc2 + residual + next LN; HBM-bound at C = 96 / 192)", "swin_mlp_c"),
               ("dyrelu_apply_kernel", "dyrelu_apply"), ("conv3x3_small_kernel (27-channel DyConv offset conv)", "conv3x3_small"),
-              ("align_scores_kernel (sigmoid + token->class mean + threshold)", "align_scores"))
+              ("align_scores_kernel (sigmoid + token->class mean + threshold)", "align_scores"),
+              ("align_fused_kernel (box / centerness heads + dot-product alignment + sigmoid + class aggregation + threshold, all levels)", "align_fused"))
     for name, prefix in groups:
         sel = [v for k, v in per.items() if k.startswith(prefix)]
         if sel:
@@ -428,89 +467,29 @@ def lang_path_b64(model, cfg, dev, chunks, iters=5):
             "timing": "eager, single stream, HIP events; attention = the attn_fwd / gcp_sparse launches only"}
 
 
-def _experimental_attention_worker():
-    """`lang_path_b64` once more with the text-sized / long-sequence attentions on the S^T kernels of csrc/attn_resident.hip
-    (MQ_ATTN_RESIDENT=1): written after round 2's GPU budget was spent, so the default bench run takes their FIRST device numbers --
-    in a subprocess with a hard time limit, so that nothing this code does can cost the headline line.  Also reports how far the
-    language path's output moves between the two kernel families on the device (max |difference| of the hidden state)."""
-    from mq_det_amd import ops
-    from mq_det_amd.modeling import pipeline
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(dev)
-    ops.load_library()
-    cfg, model, chunks = build_model(dev)
-    P = model._plan
-    caption, pmap = chunks[0]
-    Bn = 8
-    ids, am, _ = model.tokenize([caption] * Bn, dev)
-    labels = [k for k, v in pmap.items() if len(v)]
-    pm_key = tuple((k, tuple(pmap[k])) for k in labels)
-    dtype = P["backbone.body.patch_embed.proj.weight"].dtype
-    vision, idx = model.query_selector.select_cached(pm_key, labels, pmap, Bn, ids.shape[1], dev, dtype)
-    pooled = torch.randn(Bn, 5577, 256, generator=torch.Generator().manual_seed(3)).to(dev, dtype)
-    outs = {}
-    for flag in ("0", "1"):
-        os.environ["MQ_ATTN_RESIDENT"] = flag
-        outs[flag] = pipeline.language_backbone(P, cfg, ids, am, vision, pooled, idx)["hidden"].float()
-    torch.cuda.synchronize()
-    live = am.bool()
-    diff = float((outs["0"] - outs["1"])[live].abs().max())
-    scale = float(outs["0"][live].abs().max())
-    os.environ["MQ_ATTN_RESIDENT"] = "1"
-    os.environ["MQ_LN_VARIANT"] = "2"                        # bit-identical results; its time shows up under the layernorm_c* tags
-    res = lang_path_b64(model, cfg, dev, chunks)
-    res["kernels"] = ("MQ_ATTN_RESIDENT=1: mq_attn_resident_fwd (Nk <= 256) + mq_attn_chunked_fwd (pre-select) instead of mq_attn_fwd; "
-                      "MQ_LN_VARIANT=2: mq_layernorm2_fwd (kernels_ms: layernorm_c*)")
-    res["hidden_state_max_abs_diff_vs_default_kernels"] = {"max_abs_diff": round(diff, 6), "ref_absmax": round(scale, 4), "batch": Bn}
-    print(json.dumps(res), flush=True)
-
-
-def experimental_attention(timeout=100):
+def _sub_bench(argv, env=None, timeout=150, keep=()):
+    """One more invocation of this script in a subprocess with a hard time limit (so that nothing it does can cost the headline line);
+    returns a summary of the JSON line it printed."""
     import subprocess
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--experimental-attention-worker"], capture_output=True, text=True,
-                           timeout=timeout)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), *argv, "--no-extras"], env=dict(os.environ, **(env or {})),
+                           capture_output=True, text=True, timeout=timeout)
         for line in reversed(r.stdout.strip().splitlines()):
             if line.startswith("{"):
-                return json.loads(line)
+                d = json.loads(line)
+                out = {k: d.get(k) for k in ("metric", "value", "unit", "ms_per_step", "dtype", "steps", "hip_graph", "detections_img0") + tuple(keep)
+                       if d.get(k) is not None}
+                out["workload"] = d.get("config", {}).get("workload")
+                out["batch_per_gpu"] = d.get("config", {}).get("batch_per_gpu")
+                return out
         return {"error": (r.stderr or r.stdout)[-400:]}
     except subprocess.TimeoutExpired:
         return {"error": f"worker exceeded {timeout} s"}
 
 
-def experimental_bf16_glip_l(timeout=150):
-    """BASELINE.json configs[3] as named (MQ-GLIP-L, bs = 4, bf16 MFMA) -- the bf16 builds were added after round 2's GPU budget was
-    spent: the default run takes their first device number in a subprocess (5 timed steps) and keeps a summary of its line."""
-    import subprocess
-    try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "mq-glip-l", "--dtype", "bf16", "--steps", "5",
-                            "--warmup", "2", "--no-experimental"], capture_output=True, text=True, timeout=timeout)
-        for line in reversed(r.stdout.strip().splitlines()):
-            if line.startswith("{"):
-                d = json.loads(line)
-                return {k: d.get(k) for k in ("value", "unit", "ms_per_step", "dtype", "steps", "hip_graph", "detections_img0", "model_tflops")} | \
-                       {"workload": d.get("config", {}).get("workload"), "batch_per_gpu": d.get("config", {}).get("batch_per_gpu")}
-        return {"error": (r.stderr or r.stdout)[-400:]}
-    except subprocess.TimeoutExpired:
-        return {"error": f"worker exceeded {timeout} s"}
-
-
-def experimental_e2e(env, timeout=90):
-    """The headline workload once more (10 timed steps in a subprocess) with opt-in kernels switched on through `env`:
-    MQ_LN_VARIANT=2 + MQ_OFFSET_CONV_VARIANT=2 + MQ_PATCH_MERGE_FUSED=1 (load-batched LayerNorm / offset conv, patch merging without the
-    cat pass: bit-identical results) + MQ_FPN_VIA_DCN=1 (the FPN output convs as one grouped launch of the fused DCNv2 kernel) + MQ_NMS_EARLY_STOP=1 (NMS sweep ends at 300 kept) / MQ_ATTN_RESIDENT=1 (S^T attention kernels; the text chain runs
-    beside the image chain).  A/B against `value` of this line, same box, same process environment otherwise."""
-    import subprocess
-    try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--no-experimental", "--no-lang-b64",
-                            "--no-cpu-baseline"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=timeout)
-        for line in reversed(r.stdout.strip().splitlines()):
-            if line.startswith("{"):
-                d = json.loads(line)
-                return {k: d.get(k) for k in ("value", "unit", "ms_per_step", "steps", "hip_graph", "detections_img0")} | {"env": env}
-        return {"error": (r.stderr or r.stdout)[-400:], "env": env}
-    except subprocess.TimeoutExpired:
-        return {"error": f"worker exceeded {timeout} s", "env": env}
+# every operator with two implementations on the one that was the default at the end of round 2 (ops.KERNEL_DEFAULTS lists today's)
+ROUND2_KERNEL_SET = {"MQ_LN_VARIANT": "1", "MQ_OFFSET_CONV_VARIANT": "1", "MQ_PATCH_MERGE_FUSED": "0", "MQ_FPN_VIA_DCN": "0", "MQ_NMS_EARLY_STOP": "0",
+                     "MQ_ATTN_RESIDENT": "0", "MQ_SWIN_MLP_VARIANT": "1", "MQ_ALIGN_FUSED": "0"}
 
 
 def main():
@@ -531,16 +510,16 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (for PMC profiling)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-worker-gdino", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--experimental-attention-worker", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--no-experimental", action="store_true", help="skip the subprocess that measures the opt-in attention kernels")
+    ap.add_argument("--no-experimental", action="store_true", help="skip the kernel-set A/B and the other BASELINE configs (subprocesses)")
+    ap.add_argument("--no-extras", action="store_true", help="the contract fields + rooflines only (what the subprocess lines use)")
     ap.add_argument("--cpu-baseline", action="store_true", help="mq-gdino-t workload: also time the CPU oracle (off by default there)")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         return _cpu_baseline_worker()
     if args.cpu_baseline_worker_gdino:
         return _cpu_baseline_worker_gdino()
-    if args.experimental_attention_worker:
-        return _experimental_attention_worker()
+    if args.no_extras:
+        args.no_experimental = args.no_lang_b64 = args.no_cpu_baseline = True
 
     from mq_det_amd import parallel
     from mq_det_amd import ops
@@ -633,7 +612,7 @@ def main():
     if rank == 0:
         fwd_per_step = len(chunks) if lvis else 1
         ips = world * Bn * args.steps * fwd_per_step / dt
-        roofs = kernel_rooflines(kern, max(prof_steps, 1), Bn, n_tok) if kern else []
+        roofs = kernel_rooflines(kern, max(prof_steps, 1), Bn, n_tok, embed=192 if large else 96) if kern else []
         hot = [r for r in roofs if r["bound"] == "mfma"]
         roof = max(hot, key=lambda r: r["ms_per_step"]) if hot else None
         res = {
@@ -663,33 +642,37 @@ def main():
             res["lvis_style_images_per_sec"] = round(ips / fwd_per_step, 3)
         else:
             gf = GFLOP_PER_IMAGE_L if large else GFLOP_PER_IMAGE
-            res["model_tflops"] = round(ips * gf / 1e3, 2)
-            res["model_frac_of_mfma_peak"] = round(ips * gf / 1e3 / (MFMA_PEAK_TFLOPS * world), 4)
+            gx = executed_gflop_per_image(n_tok, layers=8 if large else 6, swin=1625.0 if large else 198.2)
+            res["model_tflops"] = round(ips * gx / 1e3, 2)
+            res["model_frac_of_mfma_peak"] = round(ips * gx / 1e3 / (MFMA_PEAK_TFLOPS * world), 4)
+            res["model_flops"] = {"executed_gflop_per_image": round(gx, 1), "reference_algorithmic_gflop_per_image": gf,
+                                  "reference_algorithmic_tflops": round(ips * gf / 1e3, 2),
+                                  "note": "model_tflops = EXECUTED flops (bench.executed_gflop_per_image: projections folded, K / V per unique vision "
+                                          "token, live text blocks only) x images/s; the reference's un-folded count at T = 256 beside it"}
             res["roofline"] = roof
             res["rooflines"] = roofs
             res["kernels_ms_per_step"] = {k: round(v[1] / max(prof_steps, 1), 3) for k, v in sorted(kern.items())}
+            res["kernel_selection"] = dict(ops.KERNELS)
             res["timing"] = "roofline records: HIP events on the launch stream around each launch, eager single-stream pass of the same steps"
             if world == 1 and not args.no_lang_b64 and not large:
                 try:
                     res["lang_path_b64"] = lang_path_b64(model, cfg, dev, chunks)
                 except Exception as e:  # noqa: BLE001
                     res["lang_path_b64"] = {"error": repr(e)[:300]}
-            if world == 1 and not args.no_lang_b64 and not args.no_experimental and not large and args.dtype == "f16" and \
-                    os.environ.get("MQ_ATTN_RESIDENT", "0") != "1" and os.environ.get("MQ_LN_VARIANT", "1") != "2" and \
-                    os.environ.get("MQ_OFFSET_CONV_VARIANT", "1") != "2" and os.environ.get("MQ_PATCH_MERGE_FUSED", "0") != "1" and \
-                    os.environ.get("MQ_FPN_VIA_DCN", "0") != "1" and os.environ.get("MQ_NMS_EARLY_STOP", "0") != "1":
-                # first device numbers of the opt-in S^T attention kernels, isolated in a subprocess
-                res["lang_path_b64_resident"] = experimental_attention()
-                # e2e A/B of the opt-in kernels, most likely gain first; each only while the whole run stays within a few minutes
-                ab = []
-                for env, limit in (({"MQ_LN_VARIANT": "2", "MQ_OFFSET_CONV_VARIANT": "2", "MQ_PATCH_MERGE_FUSED": "1", "MQ_FPN_VIA_DCN": "1",
-                                    "MQ_NMS_EARLY_STOP": "1"}, 150),
-                                   ({"MQ_ATTN_RESIDENT": "1"}, 130)):
+            if world == 1 and not args.no_experimental and not large and args.dtype == "f16" and not any(k in os.environ for k in ROUND2_KERNEL_SET):
+                # bounded subprocess lines, most informative first; each only while the whole run stays within a few minutes
+                if time.perf_counter() - t_start < 120:
+                    res["kernel_set_ab"] = {"round2_kernel_set": _sub_bench(["--steps", "10", "--warmup", "3"], ROUND2_KERNEL_SET, 120),
+                                            "env_of_the_round2_set": ROUND2_KERNEL_SET,
+                                            "note": "A/B against `value` of this line: same box, same workload, every two-way operator on its "
+                                                    "round-2 implementation (per-switch A/Bs: profiles/r03_call1_switch_ab.txt)"}
+                other = {}
+                for key, argv, limit in (("configs[3] mq-glip-l bf16 B=4", ["--workload", "mq-glip-l", "--dtype", "bf16", "--steps", "5", "--warmup", "2"], 160),
+                                         ("configs[4] mq-gdino-t B=16", ["--workload", "mq-gdino-t", "--steps", "5", "--warmup", "2"], 200),
+                                         ("configs[2] lvis B=8 chunk-batch 32", ["--workload", "lvis", "--chunk-batch", "32", "--steps", "2", "--warmup", "2"], 240)):
                     if time.perf_counter() - t_start < limit:
-                        ab.append(experimental_e2e(env))
-                res["opt_in_kernels_ab"] = ab
-                if time.perf_counter() - t_start < 110:
-                    res["mq_glip_l_bf16"] = experimental_bf16_glip_l()
+                        other[key] = _sub_bench(argv, None, 150, keep=("roofline", "model_tflops", "lvis_style_images_per_sec", "forwards_per_step"))
+                res["other_configs"] = other
             if world == 1 and not args.no_cpu_baseline and not large:
                 try:
                     res["cpu_baseline"] = cpu_baseline()

@@ -252,6 +252,21 @@ int mq_align_scores_fwd(const void* dot, int dot_f32, const float* tbias, const 
                         float* out, float* cls_out, int B, int HW, int T, int L, int MT, float thr, long dot_bs, int agg,
                         void* stream);
 
+/* Prediction heads + alignment + per-location scoring in ONE kernel (csrc/align_fused.hip): bbox_pred / centerness 1x1 convs with the
+ * per-level Scale, dot-product region-word logits (+ bias, clamp), sigmoid, token -> class aggregation, threshold, x sigmoid(centerness).
+ * The [B, N, T] logits are never written (logits != NULL: fp32 dot products WITHOUT the bias, for parity tests).
+ *   tok [B,N,256] fp16 (all pyramid levels concatenated), tk [B,T,256] fp16 = projected text tokens / exp(log_scale), tbias [B,T] fp32,
+ *   wbc [16,256] fp16 (rows 0-3 bbox_pred.weight, 4 centerness.weight, 5-15 zero), bbc [8] fp32 biases, scales [NL] fp32,
+ *   tokidx [L,MT] (tok_bs = 0) or [B,L,MT] (tok_bs = L*MT) int32 (-1 padded), lvl_off [NL+1] HOST ints (token offset of every level, last = N),
+ *   kv_max = upper bound of the live text tokens (0: T); agg 0 MEAN / 1 MAX / 2 POWER.
+ *   Outputs are LEVEL-MAJOR (level l contiguous at element offset lvl_off[l]*B*width): ranked / cls_out (or NULL) [B,HW_l,L] fp32,
+ *   reg [B,HW_l,4] fp16; ctr_out [B,N] fp32 centerness logits.
+ * Replaces VLDyHead.forward's head part (rpn/vldyhead.py:853-888) + ATSSPostProcessor.forward_for_single_feature_map's scoring
+ * (rpn/inference.py:656-683, convert_grounding_to_od_logits[_v2] :772-824) for all levels. */
+int mq_align_fused_fwd(const void* tok, const void* tk, const float* tbias, const void* wbc, const float* bbc, const float* scales,
+                       const int* tokidx, long tok_bs, const int* lvl_off, float* ranked, float* cls_out, void* reg, float* ctr_out,
+                       float* logits, int B, int N, int T, int kv_max, int L, int MT, int NL, float thr, int agg, void* stream);
+
 /* Decode + clip the top-K candidates of one level into the per-image candidate arrays (at column out_off).
  *   val/flat [B,K] (score, flat index loc*L + l), reg [B,HW,4] fp16, anchors [HW,4] fp32, label_ids [L] int32 (batch
  *   stride lab_bs elements, 0 = shared), im_wh [B,2] fp32 (w,h) -> boxes [B,out_stride,4] fp32, scores [B,out_stride]
@@ -344,6 +359,7 @@ MQ_BF16_TWIN(mq_dyconv_fuse)
 MQ_BF16_TWIN(mq_dyrelu_coef)
 MQ_BF16_TWIN(mq_dyrelu_apply)
 MQ_BF16_TWIN(mq_align_scores_fwd)
+MQ_BF16_TWIN(mq_align_fused_fwd)
 MQ_BF16_TWIN(mq_box_decode)
 MQ_BF16_TWIN(mq_roi_align_fwd)
 MQ_BF16_TWIN(mq_msdeform_attn_fwd)

@@ -181,6 +181,11 @@ def build_plan(sd, cfg, device, dtype=torch.float16):
         P[f"rpn.head.boxctr.{l}.weight"] = torch.cat([wb, wc, wb.new_zeros(3, wb.shape[1])], 0).to(dtype).contiguous()
         P[f"rpn.head.boxctr.{l}.bias"] = torch.cat([f32("rpn.head.bbox_pred.bias") * s, f32("rpn.head.centerness.bias"),
                                                     wb.new_zeros(3)], 0).to(dtype).contiguous()
+    # the same rows level-independent for mq_align_fused_fwd (the level's Scale is applied in its epilogue): [16, 256] + biases + scales
+    wbc = torch.cat([f32("rpn.head.bbox_pred.weight").reshape(4, -1), f32("rpn.head.centerness.weight").reshape(1, -1)], 0)
+    P["rpn.head.wbc"] = torch.cat([wbc, wbc.new_zeros(11, wbc.shape[1])], 0).to(dtype).contiguous()
+    P["rpn.head.bbc"] = torch.cat([f32("rpn.head.bbox_pred.bias"), f32("rpn.head.centerness.bias"), wbc.new_zeros(3)], 0).contiguous()
+    P["rpn.head.scales"] = torch.cat([f32(f"rpn.head.scales.{l}.scale").reshape(1) for l in range(5)], 0).contiguous()
     P["rpn.head.tok.weight"] = f32("rpn.head.dot_product_projection_text.weight")
     P["rpn.head.tok.bias"] = f32("rpn.head.dot_product_projection_text.bias")
     P["rpn.head.bias_lang32"] = f32("rpn.head.bias_lang")
@@ -747,6 +752,11 @@ def vldyhead(P, cfg, feats, lang, trace=None):
     emb = F.normalize((hidden if h32 is None else h32).float(), p=2, dim=-1)
     tk = F.linear(emb / 2.0, P[p + ".tok.weight"], P[p + ".tok.bias"]) * P[p + ".inv_scale"]       # [B, T, 256]
     tbias = (emb @ P[p + ".bias_lang32"] + P[p + ".bias0_32"]).contiguous()                           # [B, T]
+    if ops.KERNELS["ALIGN_FUSED"] == 1:
+        # heads + alignment + scoring happen in ONE kernel inside postprocess() (mq_align_fused_fwd): hand over its operands
+        return {"tok": tok, "sizes": sizes, "tk16": tk.to(tok.dtype).contiguous(), "tbias": tbias, "max_kv": max_kv,
+                "wbc": P[p + ".wbc"], "bbc": P[p + ".bbc"], "scales": P[p + ".scales"],
+                "feats": _level_views(tok, sizes), "hidden": hidden if h32 is None else h32}
     tok16_t = tk.to(tok.dtype).transpose(1, 2)
     Bn, N, C = tok.shape
     dots_all = torch.bmm(tok, tok16_t)                                                               # [B, N, T], all levels
@@ -786,7 +796,24 @@ def postprocess(cfg, head, anchors, im_wh, tokidx, label_ids, want_cls=False):
     L = tokidx.shape[-2]
     if not torch.is_tensor(im_wh):                       # list of (h, w) -> [B, 2] (w, h)
         im_wh = torch.tensor([[w, h] for (h, w) in im_wh], dtype=torch.float32, device=dev)
-    ks = [min(A.PRE_NMS_TOP_N, d.shape[1] * L) for d in head["dot"]]
+    agg = ops.SCORE_AGG[str(cfg.MODEL.DYHEAD.get("SCORE_AGG", "MEAN")).upper()]
+    fused = None
+    if "tok" in head:
+        # prediction heads, region-word alignment and per-location scoring of ALL levels: one launch, logits never written
+        fused = ops.align_fused(head["tok"], head["tk16"], head["tbias"], head["wbc"], head["bbc"], head["scales"], tokidx, head["sizes"],
+                                A.INFERENCE_TH, agg=agg, kv_max=head.get("max_kv", 0), want_cls=want_cls, want_logits=want_cls)
+        hws = [h * w for (h, w) in head["sizes"]]
+        if want_cls:                                     # raw mode: the reference's head outputs as views, for the parity ladder
+            T = head["tbias"].shape[1]
+            offs_ = [0]
+            for n_ in hws:
+                offs_.append(offs_[-1] + n_)
+            head["dot"] = [fused["logits"][:, offs_[l]:offs_[l + 1]] for l in range(len(hws))]                        # without the bias
+            head["bbox_reg"] = [fused["reg"][l].reshape(Bn, h, w, 4).permute(0, 3, 1, 2) for l, (h, w) in enumerate(head["sizes"])]
+            head["centerness"] = [fused["ctr"][:, offs_[l]:offs_[l + 1]].reshape(Bn, 1, h, w) for l, (h, w) in enumerate(head["sizes"])]
+    else:
+        hws = [d.shape[1] for d in head["dot"]]
+    ks = [min(A.PRE_NMS_TOP_N, hw * L) for hw in hws]
     tot = sum(ks)
     boxes = torch.empty(Bn, tot, 4, dtype=torch.float32, device=dev)
     scores = torch.empty(Bn, tot, dtype=torch.float32, device=dev)
@@ -797,15 +824,19 @@ def postprocess(cfg, head, anchors, im_wh, tokidx, label_ids, want_cls=False):
         offs.append(offs[-1] + k)
 
     def level(l):
-        dot, reg, ctr, anc, k = head["dot"][l], head["bbox_reg"][l], head["centerness"][l], anchors[l], ks[l]
-        HW = dot.shape[1]
-        ctr_flat = ctr.permute(0, 2, 3, 1).reshape(Bn, HW).contiguous()
-        r = ops.align_scores(dot, head["tbias"], tokidx, ctr_flat, A.INFERENCE_TH, want_cls=want_cls,
-                             agg=ops.SCORE_AGG[str(cfg.MODEL.DYHEAD.get("SCORE_AGG", "MEAN")).upper()])
-        if want_cls:
-            r, cls_all[l] = r
+        anc, k, HW = anchors[l], ks[l], hws[l]
+        if fused is not None:
+            r, reg_nhwc = fused["ranked"][l], fused["reg"][l]
+            if want_cls:
+                cls_all[l] = fused["cls"][l]
+        else:
+            dot, reg, ctr = head["dot"][l], head["bbox_reg"][l], head["centerness"][l]
+            ctr_flat = ctr.permute(0, 2, 3, 1).reshape(Bn, HW).contiguous()
+            r = ops.align_scores(dot, head["tbias"], tokidx, ctr_flat, A.INFERENCE_TH, want_cls=want_cls, agg=agg)
+            if want_cls:
+                r, cls_all[l] = r
+            reg_nhwc = reg.permute(0, 2, 3, 1).reshape(Bn, HW, 4).contiguous()
         val, flat = torch.topk(r.reshape(Bn, HW * L), k, dim=1, sorted=False)
-        reg_nhwc = reg.permute(0, 2, 3, 1).reshape(Bn, HW, 4).contiguous()
         ops.box_decode(val.contiguous(), flat.contiguous(), reg_nhwc, anc, label_ids, im_wh, boxes, scores, labels, HW, L, offs[l])
 
     # the five levels are independent until the sort: one HIP stream each (the small levels are pure launch latency)

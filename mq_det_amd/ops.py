@@ -43,6 +43,7 @@ _SIGNATURES = {
     "mq_dyrelu_coef": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mq_dyrelu_apply": (_i, [_vp, _vp, _i, _i, _i, _l, _vp]),
     "mq_align_scores_fwd": (_i, [_vp, _i, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _l, _i, _vp]),
+    "mq_align_fused_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "mq_box_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _vp]),
     "mq_roi_align_fwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _f, _i, _i, _i, _vp]),
     "mq_msdeform_attn_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -55,7 +56,7 @@ _SIGNATURES = {
 BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
               "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_patch_merge_ln_fwd", "mq_swin_mlp_fwd", "mq_swin_mlp2_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
               "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyrelu_apply",
-              "mq_align_scores_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
+              "mq_align_scores_fwd", "mq_align_fused_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
 for _n in BF16_TWINS:
     _SIGNATURES[_n + "_bf16"] = _SIGNATURES[_n]
 EXPORTS = tuple(_SIGNATURES)
@@ -74,6 +75,7 @@ KERNEL_DEFAULTS = {
     "ATTN_RESIDENT": 1,          # 1: mq_attn_resident_fwd / mq_attn_chunked_fwd (S^T form, keys resident / 256-key chunks)       +4.7 %
     "SWIN_MLP_VARIANT": 2,       # 2: mq_swin_mlp2_fwd (fragment-major weights, 3-deep software pipeline, 14-VALU GELU); 1: mq_swin_mlp_fwd
     "SWIN_MLP2_FLAGS": 1,        # mq_swin_mlp2_fwd flags: bit 0 = LDS-DMA staging, bit 1 = table GELU
+    "ALIGN_FUSED": 1,            # 1: mq_align_fused_fwd (heads + alignment + scoring, logits never written); 0: bmm + 5 GEMMs + 5 x mq_align_scores_fwd
 }
 KERNELS = dict(KERNEL_DEFAULTS)
 
@@ -713,6 +715,50 @@ def align_scores(dot, tbias, tokidx, ctr, thr, want_cls=False, agg=0):
                                      L * MT if tokidx.dim() == 3 else 0, _ptr(ctr), _ptr(out), _ptr(cls), B, HW, T, L, MT,
                                      float(thr), dot.stride(0), int(agg), _stream()), "mq_align_scores_fwd")
     return (out, cls) if want_cls else out
+
+
+def align_fused(tok, tk, tbias, wbc, bbc, scales, tokidx, sizes, thr, agg=0, kv_max=0, want_cls=False, want_logits=False):
+    """Prediction heads + region-word alignment + per-location scoring for ALL pyramid levels in one launch (mq_align_fused_fwd).
+    tok [B,N,256] 16-bit (levels concatenated in `sizes` order), tk [B,T,256] 16-bit (projected text tokens / exp(log_scale)), tbias [B,T]
+    fp32, wbc [16,256] 16-bit / bbc [8] fp32 (box + centerness rows), scales [NL] fp32, tokidx [L,MT] or [B,L,MT] int32, sizes [(H, W)],
+    kv_max: host-side upper bound of the live text tokens (0 = T).
+    -> dict: ranked [NL x [B,HW,L] fp32], reg [NL x [B,HW,4] 16-bit], ctr [B,N] fp32 (centerness logits), cls (want_cls), logits
+    [B,N,T] fp32 dot products without the bias (want_logits; columns beyond the live text blocks are zero)."""
+    lib = load_library()
+    _need_gpu(tok, tk, tbias, wbc, bbc, scales, tokidx)
+    B, N, C = tok.shape
+    T = tk.shape[1]
+    L, MT = tokidx.shape[-2:]
+    NL = len(sizes)
+    offs = [0]
+    for (h, w) in sizes:
+        offs.append(offs[-1] + int(h) * int(w))
+    assert C == 256 and offs[-1] == N and tk.shape == (B, T, 256) and tok.is_contiguous() and tk.is_contiguous()
+    assert tok.dtype == tk.dtype == wbc.dtype and tok.dtype in _H16 and wbc.shape == (16, 256) and wbc.is_contiguous()
+    assert tbias.dtype == torch.float32 and tbias.shape == (B, T) and tbias.is_contiguous()
+    assert bbc.dtype == scales.dtype == torch.float32 and bbc.numel() >= 8 and scales.numel() >= NL
+    assert tokidx.dtype == torch.int32 and tokidx.is_contiguous() and (tokidx.dim() == 2 or tokidx.shape[0] == B)
+    dev = tok.device
+    ranked = torch.empty(B * N * L, dtype=torch.float32, device=dev)
+    cls = torch.empty(B * N * L, dtype=torch.float32, device=dev) if want_cls else None
+    reg = torch.empty(B * N * 4, dtype=tok.dtype, device=dev)
+    ctr = torch.empty(B, N, dtype=torch.float32, device=dev)
+    logits = torch.zeros(B, N, T, dtype=torch.float32, device=dev) if want_logits else None
+    lvl = (ctypes.c_int * (NL + 1))(*offs)
+    with _timed("align_fused", tok.numel() * 2 + ranked.numel() * 4 + reg.numel() * 2):
+        _chk(_fn(lib, "mq_align_fused_fwd", tok)(_ptr(tok), _ptr(tk), _ptr(tbias), _ptr(wbc), _ptr(bbc), _ptr(scales), _ptr(tokidx),
+                                                 L * MT if tokidx.dim() == 3 else 0, ctypes.cast(lvl, _vp), _ptr(ranked), _ptr(cls), _ptr(reg),
+                                                 _ptr(ctr), _ptr(logits), B, N, T, int(kv_max), L, MT, NL, float(thr), int(agg), _stream()),
+             "mq_align_fused_fwd")
+
+    def levels(flat, width):
+        return [flat[offs[l] * B * width:offs[l + 1] * B * width].view(B, offs[l + 1] - offs[l], width) for l in range(NL)]
+    out = {"ranked": levels(ranked, L), "reg": levels(reg, 4), "ctr": ctr}
+    if want_cls:
+        out["cls"] = levels(cls, L)
+    if want_logits:
+        out["logits"] = logits
+    return out
 
 
 def box_decode(val, flat, reg, anchors, label_ids, im_wh, boxes, scores, labels, HW, L, out_off):

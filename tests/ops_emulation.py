@@ -150,6 +150,30 @@ def align_scores(dot, tbias, tokidx, ctr, thr, want_cls=False, agg=0):
     return (out, cls) if want_cls else out
 
 
+def align_fused(tok, tk, tbias, wbc, bbc, scales, tokidx, sizes, thr, agg=0, kv_max=0, want_cls=False, want_logits=False):
+    """Plain-torch statement of mq_align_fused_fwd (per level: heads, logits, the align_scores emulation)."""
+    B, N, C = tok.shape
+    T = tk.shape[1]
+    dots = torch.bmm(tok.float(), tk.float().transpose(1, 2))                                  # [B, N, T]
+    bc = tok.float() @ wbc.float().t()[:, :8] + bbc[:8].float()                               # [B, N, 8]
+    out = {"ranked": [], "reg": [], "ctr": bc[..., 4].contiguous()}
+    cls_all = []
+    off = 0
+    for l, (h, w) in enumerate(sizes):
+        hw = int(h) * int(w)
+        d = dots[:, off:off + hw].contiguous()
+        r = align_scores(d, tbias, tokidx, bc[:, off:off + hw, 4].contiguous(), thr, want_cls=True, agg=agg)      # centerness stays fp32
+        out["ranked"].append(r[0])
+        cls_all.append(r[1])
+        out["reg"].append((bc[:, off:off + hw, :4] * scales[l].float()).to(tok.dtype))
+        off += hw
+    if want_cls:
+        out["cls"] = cls_all
+    if want_logits:
+        out["logits"] = dots
+    return out
+
+
 def box_decode(val, flat, reg, anchors, label_ids, im_wh, boxes, scores, labels, HW, L, out_off):
     B, K = val.shape
     loc, l = flat // L, flat % L
@@ -441,7 +465,7 @@ def dyconv_coef_group(items, attn_w, attn_b, groups, eps):
 
 # ---------------------------------------------------------------------------------------------------------------------------------
 # every emulated entry point, in one place: tests patch them into mq_det_amd.ops (or into a stand-in namespace) with these helpers
-NAMES = ("attention", "attention4", "window_attention", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores",
+NAMES = ("attention", "attention4", "window_attention", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores", "align_fused",
          "dyconv_branch_coef", "dyconv_coef_group", "dyconv_fuse", "dyrelu_", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "vlfuse_i2t",
          "vlfuse_t2i", "box_decode", "ml_nms", "roi_align", "swin_mlp", "swin_mlp2", "patch_merge_ln", "ms_deform_attn", "ms_deform_attn_q", "image_key_mask")
 

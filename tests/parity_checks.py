@@ -477,6 +477,65 @@ def check_post_golden(dev, golden_dir=None):
     return res
 
 
+def check_align_fused(dev):
+    """mq_align_fused_fwd (box / centerness heads + dot-product alignment + sigmoid + token -> class aggregation + threshold + x centerness
+    in one kernel, all levels) against a plain fp32 statement on the same 16-bit operands: ragged level sizes (tiles that straddle
+    levels, a last tile with 3 rows), one caption per batch and one per item, every aggregation, live-token bounds that cut the
+    text operand (kv_max) and T not a multiple of 16."""
+    from mq_det_amd import ops
+    res = []
+    g = torch.Generator().manual_seed(77)
+    cases = [dict(B=2, sizes=[(9, 13), (5, 7), (3, 4), (2, 2), (1, 2)], T=256, kv=141, L=40, MT=4, agg=0, per_item=False),
+             dict(B=3, sizes=[(11, 12), (1, 3)], T=256, kv=0, L=7, MT=3, agg=1, per_item=True),
+             dict(B=1, sizes=[(16, 8), (7, 5), (2, 1)], T=72, kv=50, L=5, MT=2, agg=2, per_item=False),
+             dict(B=2, sizes=[(40, 50)], T=256, kv=17, L=3, MT=1, agg=0, per_item=False)][:3 if QUICK else 4]
+    for c in cases:
+        B, sizes, T, L, MT = c["B"], c["sizes"], c["T"], c["L"], c["MT"]
+        N = sum(h * w for h, w in sizes)
+        nv = c["kv"] if c["kv"] else T
+        tok = (torch.randn(B, N, 256, generator=g) * 0.7).to(H16)
+        tk = (torch.randn(B, T, 256, generator=g) * 0.12).to(H16)
+        tbias = torch.randn(B, T, generator=g) * 0.5 - 1.0
+        wbc = torch.zeros(16, 256)
+        wbc[:5] = torch.randn(5, 256, generator=g) * 0.05
+        wbc = wbc.to(H16)
+        bbc = torch.cat([torch.randn(5, generator=g) * 0.1, torch.zeros(3)])
+        scales = torch.rand(len(sizes), generator=g) + 0.5
+        shape = (B, L, MT) if c["per_item"] else (L, MT)
+        tokidx = torch.randint(0, nv, shape, generator=g).to(torch.int32)
+        tokidx[..., 1:][torch.rand(tokidx[..., 1:].shape, generator=g) < 0.4] = -1                  # ragged label spans
+        if L > 4:
+            tokidx[..., 3, :] = -1                                                                  # a label without tokens: never scored
+        out = ops.align_fused(tok.to(dev), tk.to(dev), tbias.to(dev), wbc.to(dev), bbc.to(dev), scales.to(dev), tokidx.to(dev), sizes, 0.05,
+                              agg=c["agg"], kv_max=c["kv"], want_cls=True, want_logits=True)
+        dots = torch.bmm(tok.float(), tk.float().transpose(1, 2))
+        bc = tok.float() @ wbc.float().t()[:, :8] + bbc
+        sig = (dots + tbias[:, None]).clamp(-50000, 50000).sigmoid()
+        cls = torch.zeros(B, N, L)
+        for b in range(B):
+            tix = tokidx[b] if c["per_item"] else tokidx
+            for l in range(L):
+                toks = [int(t) for t in tix[l] if int(t) >= 0]
+                if toks:
+                    sel = sig[b][:, toks]
+                    cls[b, :, l] = sel.mean(-1) if c["agg"] == 0 else (sel.max(-1)[0] if c["agg"] == 1 else sel.prod(-1) ** (1.0 / len(toks)))
+        ranked = torch.where(cls > 0.05, (cls * bc[..., 4].sigmoid()[..., None]).clamp(min=1.17549435e-38), torch.full_like(cls, -1.0))
+        tag = f"align_fused B={B} levels={len(sizes)} N={N} T={T} kv={c['kv']} L={L} agg={c['agg']} per_item={c['per_item']}"
+        nvb = -(-nv // 16) * 16
+        res.append(_stat(f"{tag}: logits (live text blocks)", out["logits"][:, :, :min(nvb, T)], dots[:, :, :min(nvb, T)], tol=1e-3))
+        res.append(_stat(f"{tag}: centerness logits", out["ctr"], bc[..., 4], tol=1e-3))
+        off = 0
+        for l, (h, w) in enumerate(sizes):
+            hw = h * w
+            res.append(_stat(f"{tag}: level {l} box deltas", out["reg"][l], bc[:, off:off + hw, :4] * scales[l], tol=2e-3))
+            res.append(_stat(f"{tag}: level {l} class scores", out["cls"][l], cls[:, off:off + hw], tol=1e-3))
+            got, ref = out["ranked"][l].cpu(), ranked[:, off:off + hw]
+            edge = (cls[:, off:off + hw] - 0.05).abs() < 1e-3                                         # a score ON the threshold may fall either way
+            res.append(_stat(f"{tag}: level {l} ranked scores", torch.where(edge, ref, got), ref, tol=1e-3))
+            off += hw
+    return res
+
+
 def check_score_agg(dev, golden_dir=None):
     """MODEL.DYHEAD.SCORE_AGG = MAX / ONEHOT / POWER (rpn/inference.py:772-824): mq_align_scores_fwd's class scores against the
     REFERENCE-generated fixture tests/golden/score_agg.npz (oracle/gen_golden_score_agg.py), and the whole product
@@ -749,6 +808,7 @@ def all_checks(dev):
             ("ref-pin", lambda: check_ref_pins(dev)),
             ("post", lambda: check_post_golden(dev)),
             ("post", lambda: check_score_agg(dev)),
+            ("post", lambda: check_align_fused(dev)),
             ("swin", lambda: check_swin_mlp(dev)),
             ("gdino", lambda: check_msdeform_attn(dev)),
             ("roi", lambda: check_roi_align(dev)),

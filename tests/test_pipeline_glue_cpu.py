@@ -74,15 +74,18 @@ def test_full_pipeline_glue(setup, emulated_ops):
             nb = int(am[bi].sum())          # VLFuse skips their 128-row tiles, so only real caption tokens are compared
             close(head["hidden"][bi, :nb], h["hidden"][bi, :nb], 1e-3)
         nv = int(am[0].sum())
+        anchors = pipeline.grid_anchors(P, [f.shape[-2:] for f in feats], cfg.MODEL.RPN.ANCHOR_STRIDE, torch.device("cpu"))
+        for a, b in zip(anchors, inter["anchors"]):
+            close(a, b, 0)
+        tokidx, label_ids = build_token_index(pm, labels, torch.device("cpu"))
+        # heads + alignment + scoring are one operator inside postprocess() (mq_align_fused_fwd); raw mode exposes the reference's
+        # head outputs as views of its results
+        pipeline.postprocess(cfg, head, anchors, sizes, tokidx, label_ids, want_cls=True)
         for l in range(5):
             close(head["feats"][l], h["feats"][l], 1e-3)
             close(head["bbox_reg"][l], h["bbox_reg"][l], 1e-3)
             close(head["centerness"][l], h["centerness"][l], 1e-3)
             close((head["dot"][l] + head["tbias"][:, None])[:, :, :nv], h["dot_product_logits"][l][:, :, :nv], 2e-3)
-        anchors = pipeline.grid_anchors(P, [f.shape[-2:] for f in feats], cfg.MODEL.RPN.ANCHOR_STRIDE, torch.device("cpu"))
-        for a, b in zip(anchors, inter["anchors"]):
-            close(a, b, 0)
-        tokidx, label_ids = build_token_index(pm, labels, torch.device("cpu"))
         # feed the ORACLE head outputs to the product post-processing -> detections must agree as sets
         ohead = {"dot": [d - head["tbias"][:, None] for d in h["dot_product_logits"]], "tbias": head["tbias"],
                  "bbox_reg": h["bbox_reg"], "centerness": h["centerness"]}

@@ -38,6 +38,8 @@ def main():
         msda(dev, g, out)
     if only in ("", "swin"):
         swin(dev, g, out)
+    if only in ("", "align"):
+        align(dev, g, out)
     if only in ("", "window"):
         window(dev, g, out)
     for r in out:
@@ -64,20 +66,61 @@ def msda(dev, g, out):
 
 
 def swin(dev, g, out):
-    # ---- fused Swin MLP per stage (B = 8, 800x1344)
+    # ---- fused Swin MLP per stage (B = 8, 800x1344): the first kernel (mq_swin_mlp_fwd) and the four flag combinations of mq_swin_mlp2_fwd
     for C, M in ((96, 8 * 67200), (192, 8 * 16800), (384, 8 * 4200)):
         x = torch.randn(M, C, generator=g).to(dev)
         d = torch.randn(M, C, generator=g).half().to(dev)
         lg, lb = torch.ones(C).half().to(dev), torch.zeros(C).half().to(dev)
-        w1 = (torch.randn(4 * C, C, generator=g) / C ** 0.5).half().to(dev)
-        b1 = torch.zeros(4 * C).half().to(dev)
-        w2p = (torch.randn(C, 4 * C, generator=g) / (4 * C) ** 0.5).half().to(dev)
+        w1 = (torch.randn(4 * C, C, generator=g) / C ** 0.5).half()
+        b1 = (torch.randn(4 * C, generator=g) * 0.1).half().to(dev)
+        w2 = (torch.randn(C, 4 * C, generator=g) / (4 * C) ** 0.5).half()
         b2 = torch.zeros(C).half().to(dev)
-        ms = timeit(lambda: ops.swin_mlp(x, d, lg, lb, 1e-5, w1, b1, w2p, b2, next_ln=(lg, lb, 1e-5)))
+        w2p = w2[:, ops.swin_mlp_w2_perm(4 * C)].contiguous().to(dev)
+        w1d = w1.to(dev)
+        w1f, w2f = (t.to(dev) for t in ops.swin_mlp2_pack(w1, w2))
         fl, nb = 16.0 * M * C * C, M * C * (4 + 2 + 4 + 2)
-        out.append({"kernel": f"swin_mlp_kernel C={C} M={M} variant={os.environ.get('MQ_SWIN_MLP_VARIANT', 'default')}", "ms": round(ms, 3), "TFLOPs": round(fl / ms / 1e9, 1),
-                    "frac_of_mfma_peak": round(fl / ms / 1e9 / 2500, 3), "algorithmic_GBs": round(nb / ms / 1e6, 1),
+        runs = [("v1", lambda: ops.swin_mlp(x, d, lg, lb, 1e-5, w1d, b1, w2p, b2, next_ln=(lg, lb, 1e-5)))]
+        for flags in (0, 1, 2, 3):
+            runs.append((f"v2[{'dma' if flags & 1 else 'regs'},{'table' if flags & 2 else 'erf'}]",
+                         lambda flags=flags: ops.swin_mlp2(x, d, lg, lb, 1e-5, w1f, b1, w2f, b2, next_ln=(lg, lb, 1e-5), flags=flags)))
+        ref = None
+        for name, fn in runs:
+            ms = timeit(fn)
+            o = fn()[0].float()
+            ref = o if ref is None else ref
+            out.append({"kernel": f"swin_mlp {name} C={C} M={M}", "ms": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1),
+                        "frac_of_mfma_peak": round(fl / ms / 1e9 / 2500, 3), "algorithmic_GBs": round(nb / ms / 1e6, 1),
+                        "max_abs_diff_vs_v1": round(float((o - ref).abs().max()), 6)})
+
+
+def align(dev, g, out):
+    # ---- heads + alignment + scoring at the bench shape (B = 8, N = 22400, 141 live text tokens, 40 labels)
+    sizes = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    B, N, T, L, MT = 8, sum(h * w for h, w in sizes), 256, 40, 4
+    tok = (torch.randn(B, N, 256, generator=g) * 0.5).half().to(dev)
+    tk = (torch.randn(B, T, 256, generator=g) * 0.1).half().to(dev)
+    tbias = (torch.randn(B, T, generator=g) * 0.3 - 2.0).to(dev)
+    wbc = torch.zeros(16, 256)
+    wbc[:5] = torch.randn(5, 256, generator=g) * 0.05
+    wbc = wbc.half().to(dev)
+    bbc, scales = torch.zeros(8).to(dev), torch.ones(5).to(dev)
+    tokidx = torch.randint(0, 141, (L, MT), generator=g).to(torch.int32).to(dev)
+    for kv in (141, 0):
+        ms = timeit(lambda: ops.align_fused(tok, tk, tbias, wbc, bbc, scales, tokidx, sizes, 0.05, kv_max=kv))
+        nb = tok.numel() * 2 + B * N * L * 4 + B * N * 8 + B * N * 4
+        out.append({"kernel": f"align_fused B={B} N={N} T={T} live={kv or T} L={L}", "ms": round(ms, 4), "algorithmic_GBs": round(nb / ms / 1e6, 1),
                     "frac_of_hbm_peak": round(nb / ms / 1e6 / 8000, 3)})
+    # the round-2 path it replaces: bmm (fp16 logits to HBM) + box / centerness GEMM + 5 x align_scores
+    w8 = wbc[:8].contiguous()
+
+    def old():
+        dots = torch.bmm(tok, tk.transpose(1, 2))
+        bc = torch.nn.functional.linear(tok, w8)
+        off = 0
+        for (h, w) in sizes:
+            ops.align_scores(dots[:, off:off + h * w], tbias, tokidx, bc[:, off:off + h * w, 4].contiguous(), 0.05)
+            off += h * w
+    out.append({"kernel": "round-2 path: bmm + head GEMM + 5 x align_scores (same shape)", "ms": round(timeit(old), 4)})
 
 
 def window(dev, g, out):
