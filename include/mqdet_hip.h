@@ -260,19 +260,19 @@ int mq_align_scores_fwd(const void* dot, int dot_f32, const float* tbias, const 
  *   tokidx [L,MT] (tok_bs = 0) or [B,L,MT] (tok_bs = L*MT) int32 (-1 padded), lvl_off [NL+1] HOST ints (token offset of every level, last = N),
  *   kv_max = upper bound of the live text tokens (0: T); agg 0 MEAN / 1 MAX / 2 POWER.
  *   Outputs are LEVEL-MAJOR (level l contiguous at element offset lvl_off[l]*B*width): ranked / cls_out (or NULL) [B,HW_l,L] fp32,
- *   reg [B,HW_l,4] fp16; ctr_out [B,N] fp32 centerness logits.
+ *   reg [B,HW_l,4] fp32; ctr_out [B,N] fp32 centerness logits.
  * Replaces VLDyHead.forward's head part (rpn/vldyhead.py:853-888) + ATSSPostProcessor.forward_for_single_feature_map's scoring
  * (rpn/inference.py:656-683, convert_grounding_to_od_logits[_v2] :772-824) for all levels. */
 int mq_align_fused_fwd(const void* tok, const void* tk, const float* tbias, const void* wbc, const float* bbc, const float* scales,
-                       const int* tokidx, long tok_bs, const int* lvl_off, float* ranked, float* cls_out, void* reg, float* ctr_out,
+                       const int* tokidx, long tok_bs, const int* lvl_off, float* ranked, float* cls_out, float* reg, float* ctr_out,
                        float* logits, int B, int N, int T, int kv_max, int L, int MT, int NL, float thr, int agg, void* stream);
 
 /* Decode + clip the top-K candidates of one level into the per-image candidate arrays (at column out_off).
- *   val/flat [B,K] (score, flat index loc*L + l), reg [B,HW,4] fp16, anchors [HW,4] fp32, label_ids [L] int32 (batch
+ *   val/flat [B,K] (score, flat index loc*L + l), reg [B,HW,4] fp16 or (reg_f32) fp32, anchors [HW,4] fp32, label_ids [L] int32 (batch
  *   stride lab_bs elements, 0 = shared), im_wh [B,2] fp32 (w,h) -> boxes [B,out_stride,4] fp32, scores [B,out_stride]
  *   fp32 (sqrt), labels int32; val <= 0 marks an empty slot.
  * Replaces BoxCoder.decode (vldyhead.py:78-108), clip_to_image, rpn/inference.py:696-708. */
-int mq_box_decode(const float* val, const long* flat, const void* reg, const float* anchors, const int* label_ids, long lab_bs,
+int mq_box_decode(const float* val, const long* flat, const void* reg, int reg_f32, const float* anchors, const int* label_ids, long lab_bs,
                   const float* im_wh, float* boxes, float* scores, int* labels, int B, int K, int HW, int L,
                   long out_stride, long out_off, void* stream);
 

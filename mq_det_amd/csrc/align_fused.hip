@@ -11,7 +11,7 @@
 //   * v_mfma_f32_16x16x32: logits of 16 tokens x 16 text tokens per step, fp32 accumulators for all live text columns at once;
 //   * epilogue in registers / LDS: + bias, clamp, sigmoid -> the wave's [16, T] probabilities overwrite the (no longer needed) text
 //     operand in LDS; lanes then aggregate each (token, label) pair over the label's token positions, threshold, multiply by
-//     sigmoid(centerness) and write the ranked score; box deltas get their level's Scale and go out in 16 bits.
+//     sigmoid(centerness) and write the ranked score; box deltas get their level's Scale (fp32 out).
 // The logits never reach HBM (optional fp32 debug output for the parity ladder).  Outputs are LEVEL-MAJOR (level l: [B, HW_l, ...]
 // contiguous at token offset lvl_off[l] * B) so that the per-level top-k / box decode downstream read contiguous tensors.
 // Algorithmic HBM bytes per token: 512 (features) + 4 L (scores) + 8 (box) [+ 4 L class scores] vs 512 + 2 * 512 + ... before.
@@ -31,7 +31,7 @@ struct AlignFusedParams {
   long tok_bs;
   float* ranked;            // level-major [sum_l B * HW_l * L]
   float* cls_out;           // same layout or NULL
-  half_t* reg;              // level-major [sum_l B * HW_l * 4]
+  float* reg;               // level-major [sum_l B * HW_l * 4] box deltas, fp32 (a 16-bit store here was +55 % on the floor ratio of bbox_reg)
   float* ctr_out;           // [B, N] centerness logits
   float* logits;            // [B, N, T] fp32 dot products (without bias) or NULL
   int lvl_off[AF_MAXLVL + 1];
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64 * AF_NW) void align_fused_kernel(AlignFusedParam
         const float v = bc[r] + bias;
         if (l15 < 4) {
           const long hw = p.lvl_off[lv + 1] - p.lvl_off[lv];
-          p.reg[((long)p.lvl_off[lv] * p.B + (long)b * hw + (n - p.lvl_off[lv])) * 4 + l15] = (half_t)(v * p.scales[lv]);
+          p.reg[((long)p.lvl_off[lv] * p.B + (long)b * hw + (n - p.lvl_off[lv])) * 4 + l15] = v * p.scales[lv];
         } else {
           p.ctr_out[(long)b * p.N + n] = v;
           cw[4 * g + r] = 1.f / (1.f + __expf(-v));
@@ -169,17 +169,17 @@ __global__ __launch_bounds__(64 * AF_NW) void align_fused_kernel(AlignFusedParam
 // tok [B, N, 256], tk [B, T, 256] 16-bit; tbias [B, T] fp32; wbc [16, 256] 16-bit, bbc [8] / scales [NL] fp32; tokidx [L, MT] (tok_bs 0) or
 // [B, L, MT] (tok_bs = L * MT) int32; lvl_off [NL + 1] HOST ints (token offsets of the levels, lvl_off[NL] = N); kv_max: upper bound of the
 // live text tokens (0 = T): text columns >= 16 ceil(kv_max / 16) are never scored.  Outputs (caller-allocated): ranked / cls_out (or NULL)
-// level-major fp32 [sum_l B HW_l L], reg level-major 16-bit [sum_l B HW_l 4], ctr_out [B, N] fp32, logits [B, N, T] fp32 or NULL.
+// level-major fp32 [sum_l B HW_l L], reg level-major fp32 [sum_l B HW_l 4], ctr_out [B, N] fp32, logits [B, N, T] fp32 or NULL.
 // agg: 0 MEAN, 1 MAX, 2 POWER.  Returns -1 for unsupported shapes (T > 256, NL > 8, L * MT == 0).
 extern "C" int MQ_SYM(mq_align_fused_fwd)(const void* tok, const void* tk, const float* tbias, const void* wbc, const float* bbc,
                                   const float* scales, const int* tokidx, long tok_bs, const int* lvl_off, float* ranked, float* cls_out,
-                                  void* reg, float* ctr_out, float* logits, int B, int N, int T, int kv_max, int L, int MT, int NL,
+                                  float* reg, float* ctr_out, float* logits, int B, int N, int T, int kv_max, int L, int MT, int NL,
                                   float thr, int agg, void* stream) {
   if (B <= 0 || N <= 0) return 0;
   if (T <= 0 || T > 16 * AF_NBMAX || NL < 1 || NL > AF_MAXLVL || L <= 0 || MT <= 0 || agg < 0 || agg > 2) return -1;
   AlignFusedParams p;
   p.tok = (const half_t*)tok; p.tk = (const half_t*)tk; p.tbias = tbias; p.wbc = (const half_t*)wbc; p.bbc = bbc; p.scales = scales;
-  p.tokidx = tokidx; p.tok_bs = tok_bs; p.ranked = ranked; p.cls_out = cls_out; p.reg = (half_t*)reg; p.ctr_out = ctr_out; p.logits = logits;
+  p.tokidx = tokidx; p.tok_bs = tok_bs; p.ranked = ranked; p.cls_out = cls_out; p.reg = reg; p.ctr_out = ctr_out; p.logits = logits;
   for (int i = 0; i <= AF_MAXLVL; ++i) p.lvl_off[i] = lvl_off[i < NL ? i : NL];
   if (p.lvl_off[0] != 0 || p.lvl_off[NL] != N) return -1;
   const int live = (kv_max > 0 && kv_max < T) ? kv_max : T;

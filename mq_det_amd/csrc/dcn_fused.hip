@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
         for (int q = 0; q < 4; ++q) {
           const int hh = h0 + (q >> 1), ww = w0 + (q & 1);
           const bool ok = inside && hh >= 0 && hh <= p.H - 1 && ww >= 0 && ww <= p.W - 1;
-          st.off[q] = ok ? (unsigned)((hh * p.W + ww) * p.C) * 2u : 0u;  // invalid corners: harmless address, zero weight
+          st.off[q] = ok ? (unsigned)((hh * p.W + ww) * p.C) * (unsigned)sizeof(half_t) : 0u;  // invalid corners: harmless address, zero weight
           st.w[q] = ok ? wq[q] * mk : 0.f;
         }
         Ts[t] = st;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
 #pragma unroll
   for (int j = 0; j < JB; ++j) {
     const int c = tid + j * NTH, row = c >> 3, ch = c & 7;
-    b_goff[j] = (unsigned)(row * K + ch * 8) * 2u;
+    b_goff[j] = (unsigned)(row * K + ch * 8) * (unsigned)sizeof(half_t);
     b_lds[j] = (unsigned)(row * BK + ((ch ^ (row & 7)) << 3));
   }
 
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
     constexpr int s = decltype(SLOT)::value;
     ks = min(ks, ksteps - 1);                                // tail: re-load the last step (one code path, no branches)
     const int slice = ks / 9, tap = ks - slice * 9;
-    const unsigned cb = (unsigned)(slice * BK + ac * 8) * 2u;
+    const unsigned cb = (unsigned)(slice * BK + ac * 8) * (unsigned)sizeof(half_t);
 #pragma unroll
     for (int rr = 0; rr < RA; ++rr) {
       const TapState st = Ts[(ar + rr * (NTH / 8)) * 9 + tap];
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   auto issue_b = [&](int ks) {                               // weight tile of k-step ks
     ks = min(ks, ksteps - 1);
     const int slice = ks / 9, tap = ks - slice * 9;
-    const unsigned kb = (unsigned)(tap * p.C + slice * BK) * 2u;
+    const unsigned kb = (unsigned)(tap * p.C + slice * BK) * (unsigned)sizeof(half_t);
 #pragma unroll
     for (int j = 0; j < JB; ++j) b_raw[j] = *(const half8*)(wb + (b_goff[j] + kb));
   };

@@ -107,7 +107,8 @@ extern "C" int MQ_SYM(mq_align_scores_fwd)(const void* dot, int dot_f32, const f
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void box_decode_kernel(const float* __restrict__ val, const long* __restrict__ flat, const half_t* __restrict__ reg,
+template <typename TR>
+__global__ void box_decode_kernel(const float* __restrict__ val, const long* __restrict__ flat, const TR* __restrict__ reg,
                                   const float* __restrict__ anchors, const int* __restrict__ label_ids,
                                   const float* __restrict__ im_wh, float* __restrict__ boxes, float* __restrict__ scores,
                                   int* __restrict__ labels, int B, int K, int HW, int L, long out_stride, long out_off, long lab_bs) {
@@ -123,7 +124,7 @@ __global__ void box_decode_kernel(const float* __restrict__ val, const long* __r
   }
   const long f = flat[i];
   const int loc = f / L, l = f % L;
-  const half_t* r = reg + ((long)b * HW + loc) * 4;
+  const TR* r = reg + ((long)b * HW + loc) * 4;
   const float* a = anchors + (long)loc * 4;
   const float w = a[2] - a[0] + 1.f, h = a[3] - a[1] + 1.f;
   const float cx = (a[2] + a[0]) * 0.5f, cy = (a[3] + a[1]) * 0.5f;
@@ -141,13 +142,17 @@ __global__ void box_decode_kernel(const float* __restrict__ val, const long* __r
   labels[o] = label_ids[(long)b * lab_bs + l];
 }
 
-extern "C" int MQ_SYM(mq_box_decode)(const float* val, const long* flat, const void* reg, const float* anchors, const int* label_ids,
+extern "C" int MQ_SYM(mq_box_decode)(const float* val, const long* flat, const void* reg, int reg_f32, const float* anchors, const int* label_ids,
                              long lab_bs, const float* im_wh, float* boxes, float* scores, int* labels, int B, int K, int HW,
                              int L, long out_stride, long out_off, void* stream) {
   if (B <= 0 || K <= 0) return 0;
   long n = (long)B * K;
-  hipLaunchKernelGGL(box_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, val, flat,
-                     (const half_t*)reg, anchors, label_ids, im_wh, boxes, scores, labels, B, K, HW, L, out_stride, out_off, lab_bs);
+  if (reg_f32)
+    hipLaunchKernelGGL(box_decode_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, val, flat,
+                       (const float*)reg, anchors, label_ids, im_wh, boxes, scores, labels, B, K, HW, L, out_stride, out_off, lab_bs);
+  else
+    hipLaunchKernelGGL(box_decode_kernel<half_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, val, flat,
+                       (const half_t*)reg, anchors, label_ids, im_wh, boxes, scores, labels, B, K, HW, L, out_stride, out_off, lab_bs);
   MQ_CHECK_LAUNCH();
   return 0;
 }

@@ -44,7 +44,7 @@ _SIGNATURES = {
     "mq_dyrelu_apply": (_i, [_vp, _vp, _i, _i, _i, _l, _vp]),
     "mq_align_scores_fwd": (_i, [_vp, _i, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _l, _i, _vp]),
     "mq_align_fused_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
-    "mq_box_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _vp]),
+    "mq_box_decode": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _vp]),
     "mq_roi_align_fwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _f, _i, _i, _i, _vp]),
     "mq_msdeform_attn_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_msdeform_attn_q_fwd": (_i, [_vp, _i, _l, _l, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -722,7 +722,7 @@ def align_fused(tok, tk, tbias, wbc, bbc, scales, tokidx, sizes, thr, agg=0, kv_
     tok [B,N,256] 16-bit (levels concatenated in `sizes` order), tk [B,T,256] 16-bit (projected text tokens / exp(log_scale)), tbias [B,T]
     fp32, wbc [16,256] 16-bit / bbc [8] fp32 (box + centerness rows), scales [NL] fp32, tokidx [L,MT] or [B,L,MT] int32, sizes [(H, W)],
     kv_max: host-side upper bound of the live text tokens (0 = T).
-    -> dict: ranked [NL x [B,HW,L] fp32], reg [NL x [B,HW,4] 16-bit], ctr [B,N] fp32 (centerness logits), cls (want_cls), logits
+    -> dict: ranked [NL x [B,HW,L] fp32], reg [NL x [B,HW,4] fp32], ctr [B,N] fp32 (centerness logits), cls (want_cls), logits
     [B,N,T] fp32 dot products without the bias (want_logits; columns beyond the live text blocks are zero)."""
     lib = load_library()
     _need_gpu(tok, tk, tbias, wbc, bbc, scales, tokidx)
@@ -741,11 +741,11 @@ def align_fused(tok, tk, tbias, wbc, bbc, scales, tokidx, sizes, thr, agg=0, kv_
     dev = tok.device
     ranked = torch.empty(B * N * L, dtype=torch.float32, device=dev)
     cls = torch.empty(B * N * L, dtype=torch.float32, device=dev) if want_cls else None
-    reg = torch.empty(B * N * 4, dtype=tok.dtype, device=dev)
+    reg = torch.empty(B * N * 4, dtype=torch.float32, device=dev)
     ctr = torch.empty(B, N, dtype=torch.float32, device=dev)
     logits = torch.zeros(B, N, T, dtype=torch.float32, device=dev) if want_logits else None
     lvl = (ctypes.c_int * (NL + 1))(*offs)
-    with _timed("align_fused", tok.numel() * 2 + ranked.numel() * 4 + reg.numel() * 2):
+    with _timed("align_fused", tok.numel() * 2 + ranked.numel() * 4 + reg.numel() * 4):
         _chk(_fn(lib, "mq_align_fused_fwd", tok)(_ptr(tok), _ptr(tk), _ptr(tbias), _ptr(wbc), _ptr(bbc), _ptr(scales), _ptr(tokidx),
                                                  L * MT if tokidx.dim() == 3 else 0, ctypes.cast(lvl, _vp), _ptr(ranked), _ptr(cls), _ptr(reg),
                                                  _ptr(ctr), _ptr(logits), B, N, T, int(kv_max), L, MT, NL, float(thr), int(agg), _stream()),
@@ -767,11 +767,11 @@ def box_decode(val, flat, reg, anchors, label_ids, im_wh, boxes, scores, labels,
     lib = load_library()
     _need_gpu(val, flat, reg, anchors, label_ids, im_wh, boxes, scores, labels)
     B, K = val.shape
-    assert val.dtype == torch.float32 and flat.dtype == torch.int64 and reg.dtype in _H16
+    assert val.dtype == torch.float32 and flat.dtype == torch.int64 and reg.dtype in _H16 + (torch.float32,)
     assert val.is_contiguous() and flat.is_contiguous() and reg.is_contiguous() and anchors.is_contiguous()
     assert boxes.dtype == torch.float32 and scores.dtype == torch.float32 and labels.dtype == torch.int32
     assert label_ids.is_contiguous() and label_ids.dtype == torch.int32 and (label_ids.dim() == 1 or label_ids.shape[0] == B)
-    _chk(_fn(lib, "mq_box_decode", reg)(_ptr(val), _ptr(flat), _ptr(reg), _ptr(anchors), _ptr(label_ids), L if label_ids.dim() == 2 else 0,
+    _chk(_fn(lib, "mq_box_decode", reg)(_ptr(val), _ptr(flat), _ptr(reg), int(reg.dtype == torch.float32), _ptr(anchors), _ptr(label_ids), L if label_ids.dim() == 2 else 0,
                            _ptr(im_wh), _ptr(boxes), _ptr(scores), _ptr(labels), B, K, HW, L, boxes.shape[1], out_off, _stream()),
          "mq_box_decode")
 

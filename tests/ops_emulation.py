@@ -165,7 +165,7 @@ def align_fused(tok, tk, tbias, wbc, bbc, scales, tokidx, sizes, thr, agg=0, kv_
         r = align_scores(d, tbias, tokidx, bc[:, off:off + hw, 4].contiguous(), thr, want_cls=True, agg=agg)      # centerness stays fp32
         out["ranked"].append(r[0])
         cls_all.append(r[1])
-        out["reg"].append((bc[:, off:off + hw, :4] * scales[l].float()).to(tok.dtype))
+        out["reg"].append((bc[:, off:off + hw, :4] * scales[l].float()).contiguous())
         off += hw
     if want_cls:
         out["cls"] = cls_all

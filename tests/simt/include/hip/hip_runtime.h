@@ -49,7 +49,7 @@ void wave_sync_then(void (*fn)(void*), void* ctx);   // the same; the LAST lane 
 float* wave_tile(int buf);                           // [256] fp32 result buffer of the current wave (per exchange buffer)
 float* wave_tile32();                                // [1024] fp32 result buffer of the current wave (32 x 32 MFMA)
 void block_sync();                                   // all live threads of the workgroup
-uint64_t* xslot(int lane, int buf);                  // exchange slots of the current wave: [2][64][4] x 8 bytes
+uint64_t* xslot(int lane, int buf);                  // exchange slots of the current wave: [2][64][8] x 8 bytes
 int next_buf();                                      // alternating buffer index per collective
 long op_seq();                                       // sequence number of the collective next_buf() was just called for (>= 1)
 typedef void (*BodyFn)(void*);
@@ -138,8 +138,8 @@ inline void simt_mfma_tile(void* ctx) {
   for (int l = 0; l < 64; ++l) {
     V8 a, b;
     const uint64_t* s = simt::xslot(l, buf);
-    memcpy(&a, s, 16);
-    memcpy(&b, s + 2, 16);
+    memcpy(&a, s, sizeof(V8));
+    memcpy(&b, s + sizeof(V8) / 8, sizeof(V8));
     for (int j = 0; j < 8; ++j) {
       A[l & 15][8 * (l >> 4) + j] = (float)a[j];
       B[8 * (l >> 4) + j][l & 15] = (float)b[j];
@@ -160,8 +160,8 @@ template <class V8>
 inline simt_float4 simt_mfma_16x16x32(V8 a, V8 b, simt_float4 c) {
   const int buf = simt::next_buf(), l = simt::lane();
   uint64_t* s = simt::xslot(l, buf);
-  memcpy(s, &a, 16);
-  memcpy(s + 2, &b, 16);
+  memcpy(s, &a, sizeof(V8));
+  memcpy(s + sizeof(V8) / 8, &b, sizeof(V8));
   simt::wave_sync_then(&simt_mfma_tile<V8>, (void*)(intptr_t)buf);
   const float* D = simt::wave_tile(buf);
   const int col = l & 15, r0 = 4 * (l >> 4);
@@ -179,8 +179,8 @@ inline void simt_mfma32_tile(void* ctx) {
   for (int l = 0; l < 64; ++l) {
     V8 a, b;
     const uint64_t* s = simt::xslot(l, buf);
-    memcpy(&a, s, 16);
-    memcpy(&b, s + 2, 16);
+    memcpy(&a, s, sizeof(V8));
+    memcpy(&b, s + sizeof(V8) / 8, sizeof(V8));
     for (int j = 0; j < 8; ++j) {
       A[l & 31][8 * (l >> 5) + j] = (float)a[j];
       B[8 * (l >> 5) + j][l & 31] = (float)b[j];
@@ -198,8 +198,8 @@ template <class V8>
 inline simt_float16 simt_mfma_32x32x16(V8 a, V8 b, simt_float16 c) {
   const int buf = simt::next_buf(), l = simt::lane();
   uint64_t* s = simt::xslot(l, buf);
-  memcpy(s, &a, 16);
-  memcpy(s + 2, &b, 16);
+  memcpy(s, &a, sizeof(V8));
+  memcpy(s + sizeof(V8) / 8, &b, sizeof(V8));
   simt::wave_sync_then(&simt_mfma32_tile<V8>, (void*)(intptr_t)buf);
   const float* D = simt::wave_tile32();
   const int col = l & 31, h = l >> 5;
@@ -208,10 +208,12 @@ inline simt_float16 simt_mfma_32x32x16(V8 a, V8 b, simt_float16 c) {
   simt::wave_sync();                                    // the single 32x32 result buffer is free again only when every lane has read it
   return c;
 }
-#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) simt_mfma_32x32x16<simt_half8>((a), (b), (c))
-#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) simt_mfma_32x32x16<simt_bf16x8>((a), (b), (c))
-#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) simt_mfma_16x16x32<simt_half8>((a), (b), (c))
-#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) simt_mfma_16x16x32<simt_bf16x8>((a), (b), (c))
+// the element type of the operands is taken from the arguments: _Float16, __bf16, or -- the fp32-OPERAND build of the kernel sources
+// (tests/simt/build_emu.py, entry points *_f32: every `half_t` is a float) -- float, multiplied exactly as given
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) simt_mfma_32x32x16((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) simt_mfma_32x32x16((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) simt_mfma_16x16x32((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) simt_mfma_16x16x32((a), (b), (c))
 
 // ds_read_b64_tr_b16: inside each 16-lane group the 16 x 4 block of 16-bit elements addressed by the lanes (lane i: row i >> 2,
 // columns 4 (i & 3) .. + 3 of a [4][16] matrix) comes back transposed: lane i receives column i, rows 0..3
@@ -229,6 +231,22 @@ inline simt_fp16x4 simt_ds_read_tr16(uintptr_t addr) {
   return o;
 }
 #define __builtin_amdgcn_ds_read_tr16_b64_v4f16(p) simt_ds_read_tr16((uintptr_t)(p))
+// the same exchange for elements of any size (fp32-operand build: 4-byte "halfs"): lane i of a 16-lane group passes the address of 4
+// contiguous elements (row i >> 2, columns 4 (i & 3) .. + 3) and receives column i, rows 0..3
+template <class V4>
+inline V4 simt_ds_read_tr_elems(const void* p) {
+  constexpr size_t E = sizeof(V4) / 4;
+  const int buf = simt::next_buf(), l = simt::lane();
+  *simt::xslot(l, buf) = (uint64_t)(uintptr_t)p;
+  simt::wave_sync();
+  const int base = l & ~15, i = l & 15;
+  V4 o;
+  for (int j = 0; j < 4; ++j) {
+    const char* src = (const char*)(uintptr_t)(*simt::xslot(base + 4 * j + (i >> 2), buf));
+    memcpy((char*)&o + E * j, src + E * (i & 3), E);
+  }
+  return o;
+}
 #define __builtin_amdgcn_wave_barrier() simt::wave_sync()
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
@@ -238,7 +256,14 @@ inline simt_fp16x4 simt_ds_read_tr16(uintptr_t addr) {
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 // global_load_lds_dword{,x4}: every lane copies `size` bytes from ITS global address to  (wave-uniform LDS base) + lane * size
 inline void simt_global_load_lds(const void* g, void* lds, unsigned size) { memcpy((char*)lds + (size_t)simt::lane() * size, g, size); }
-#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) simt_global_load_lds((const void*)(g), (void*)(l), (unsigned)(size))
+// (the size argument must be a literal in the product source -- hipcc crashes on sizeof(half8) there --, so the fp32-operand build,
+// whose "16-bit" fragments are twice as wide, scales it here)
+#ifdef MQ_SIMT_F32
+#define SIMT_DMA_SCALE 2
+#else
+#define SIMT_DMA_SCALE 1
+#endif
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) simt_global_load_lds((const void*)(g), (void*)(l), (unsigned)(size) * SIMT_DMA_SCALE)
 inline float simt_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 #define __builtin_amdgcn_fmed3f(a, b, c) simt_fmed3f((a), (b), (c))
 #define __builtin_amdgcn_s_barrier() simt::block_sync()

@@ -42,7 +42,7 @@ struct Wave {
   int live, arrived;
   void (*then_fn)(void*);
   void* then_ctx;
-  uint64_t x[2][64][4];
+  uint64_t x[2][64][8];                     // 64 bytes per lane: two 8 x fp32 MFMA operands in the fp32-operand build
   float tile[2][256];
   float tile32[1024];
 };
@@ -190,6 +190,7 @@ static char* get_stack(size_t i) {
 }
 
 static size_t smem_bytes = 0;                       // dynamic LDS of the current launch
+static size_t lds_limit = 160u << 10;               // 160 KB per workgroup on gfx950; the fp32-operand build doubles every 16-bit tile
 
 static bool run_block(unsigned nthreads) {
   // A workgroup starts with UNDEFINED LDS contents on the device.  Here every byte of the dynamic LDS is set to 0xFF first (a NaN as
@@ -257,7 +258,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, BodyFn fn, void* ctx) {
   if (smem.size() < shmem + 64) smem.resize(shmem + 64);
   smem_bytes = shmem;
   const unsigned nthreads = block.x * block.y * block.z;
-  if (nthreads == 0 || nthreads > 1024 || shmem > (160u << 10)) { g_error = 1; return; }       // hipErrorInvalidValue
+  if (nthreads == 0 || nthreads > 1024 || shmem > lds_limit) { g_error = 1; return; }       // hipErrorInvalidValue
   for (unsigned z = 0; z < grid.z; ++z)
     for (unsigned y = 0; y < grid.y; ++y)
       for (unsigned x = 0; x < grid.x; ++x) {
@@ -269,6 +270,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, BodyFn fn, void* ctx) {
 }  // namespace simt
 
 // test control: order in which runnable fibers are resumed (0 ascending, 1 descending, 2 pseudo-random with `seed`)
+extern "C" void simt_set_lds_limit(unsigned long bytes) { simt::lds_limit = bytes; }
 extern "C" void simt_set_schedule(int mode, unsigned long seed) {
   simt::sched_mode = mode;
   simt::sched_state = 0x9E3779B97F4A7C15ull ^ ((uint64_t)seed * 0xD1B54A32D192ED03ull + 1);

@@ -1,0 +1,79 @@
+"""the kernel SOURCES with fp32 operands, end to end, against the fp32 oracle at the north-star tolerance 1e-3.
+
+On the device the product differs from the fp32 oracle by 2e-3 (backbone) ... 3e-2 (alignment logits) of the tensors' range -- DESIGN.md
+section 7 attributes all of it to 16-bit operand rounding amplified by a randomly initialised network (the "operand floor").  This test
+removes the rounding and nothing else: tests/simt compiles every kernel source a third time with `half_t = float` (entry points *_f32;
+the emulated MFMA multiplies the floats exactly), the product's own host code (pipeline.py, ops.py wrappers, weight folding, plans) runs
+unchanged on float32 tensors, and every stage of the tiny-depth full model, of the Swin / FPN stack and of one fusion layer at the FULL
+800 x 1333 geometry must agree with the oracle to 1e-3.  Whatever error the device shows above that is therefore rounding, not logic.
+
+TEST INFRASTRUCTURE ONLY (emulation library; the product raises without a GPU)."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+CPU = torch.device("cpu")
+_CXX = os.environ.get("SIMT_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+pytestmark = pytest.mark.skipif(not os.path.exists(_CXX), reason=f"{_CXX} not found: the kernel-source emulation cannot be built here")
+
+
+@pytest.fixture(scope="module")
+def f32():
+    import simt
+    import parity_checks as pc
+    from mq_det_amd.modeling import detector, pipeline
+
+    def prepare(self, device=None):
+        from mq_det_amd import ops
+        ops.configure(self.cfg)
+        self._validate_config()
+        self._plan = pipeline.build_plan(self.state_dict(), self.cfg, CPU, dtype=torch.float32)
+        self._plan_key, self.use_hip_graph = CPU, False
+        return self._plan
+    saved = (detector.GeneralizedVLRCNN_New.prepare, pc.QUICK, pc.PINS, dict(pc._CACHE))
+    detector.GeneralizedVLRCNN_New.prepare = prepare
+    pc.QUICK, pc.PINS = True, False
+    pc.use_dtype(torch.float32)
+    with simt.installed(f32=True):
+        yield pc
+    pc.use_dtype(torch.float16)
+    detector.GeneralizedVLRCNN_New.prepare, pc.QUICK, pc.PINS = saved[:3]
+    pc._CACHE.clear()
+    pc._CACHE.update(saved[3])
+
+
+def _assert_ok(results, tol=1e-3):
+    results = results if isinstance(results, list) else [results]
+    assert results, "no results"
+    bad = [f"{r['name']}: norm_err {r['norm_err']:.2e} (tol {r['tol']:.1e})" for r in results if not r["ok"] or (r["tol"] > tol and "detections" not in r["name"])]
+    assert not bad, "\n".join(bad)
+    return max(r["norm_err"] for r in results if "detections" not in r["name"])
+
+
+def test_tiny_full_model_meets_1e_3_with_fp32_operands(f32):
+    """Swin -> FPN -> BERT + GCP -> 2 fusion layers (VLFuse, BERT, DyConv / DCNv2) -> heads -> class scores: every stage of
+    check_full_model (the smoke() check) at 1e-3 of the reference's range, detections matched."""
+    worst = _assert_ok(f32.check_full_model(CPU))
+    print(f"worst normalised stage error with fp32 operands: {worst:.2e}")
+
+
+@pytest.mark.parametrize("name", ["check_swin_fpn", "check_window_attention", "check_gcp_block", "check_pre_select", "check_vl_fuse", "check_dyconv",
+                                  "check_align_fused"])
+def test_blocks_meet_1e_3_with_fp32_operands(f32, name):
+    _assert_ok(getattr(f32, name)(CPU))
+
+
+def test_bert_layers_meet_1e_3_with_fp32_operands(f32):
+    _assert_ok([f32.check_bert_layer(CPU, False), f32.check_bert_layer(CPU, True)])
+
+
+def test_one_fusion_layer_at_the_full_800x1333_geometry_meets_1e_3_with_fp32_operands(f32):
+    """VLFuse + clamped BERT layer + DyConv on the 22 400 pyramid tokens of an 800 x 1333 image (every tile / level boundary of the benchmark
+    shape), 141 live text tokens: 1e-3 at every output."""
+    import time
+    t0 = time.time()
+    worst = _assert_ok(f32.check_fusion_layer(CPU))
+    print(f"fusion layer at full geometry: worst normalised error {worst:.2e} ({time.time() - t0:.0f} s through the emulation)")
