@@ -172,7 +172,8 @@ int mq_swin_mlp2_fwd(const float* x, const void* delta, const void* ln_g, const 
  * NHWC fp16, fp32 accumulation over the whole K = 9*C in a fixed order (bitwise reproducible).
  *   x [B,H,W,C] (batch stride x_bs elements, C % 32 == 0), w [Npad, 9*C] fp16 with k = tap*C + c (Npad = 32 if
  *   N <= 32 else 256; rows >= N zero), bias [N] fp16 or NULL, out [B*Ho*Wo, out_ld] fp16 (first N columns written).
- *   mq_dcnv2_fwd additionally takes om [B,27,oH,oW] fp32 NCHW = 18 offsets + 9 mask LOGITS, indexed flat by the output
+ *   mq_dcnv2_fwd additionally takes om [B,27,oH,oW] fp32 NCHW = 18 offsets + 9 mask LOGITS (flags bit 0 set: mask PROBABILITIES, the
+ *   argument of the reference operator -- no sigmoid is applied then), indexed flat by the output
  *   dims like the reference kernel (the buffer may come from another pyramid level); N must be 256.  With stats != NULL it
  *   also emits the GroupNorm / scale-attention statistics of its output (layout of mq_dyconv_stats with
  *   mq_dcnv2_stats_blocks(H, W, stride) blocks per image; wy [Ho], wx [Wo] position weights or NULL for 1/(Ho*Wo)).
@@ -201,12 +202,12 @@ int mq_dcnv2_stats_blocks(int H, int W, int stride);
 typedef struct mq_dcn_branch {
   const void* x; const float* om; const void* w; const void* bias; void* out; float* stats; const float* wy; const float* wx;
   long x_bs;
-  int B, H, W, C, oH, oW, N, out_ld, stride, reserved;
+  int B, H, W, C, oH, oW, N, out_ld, stride, flags;          /* flags bit 0: om[:, 18:27] are probabilities, not logits */
 } mq_dcn_branch;
 int mq_dcnv2_group_fwd(const mq_dcn_branch* branches, int n, void* stream);
 int mq_dcnv2_fwd(const void* x, const float* om, const void* w, const void* bias, void* out, float* stats, const float* wy,
                  const float* wx, int B, int H, int W, int C, long x_bs, int oH, int oW, int N, int out_ld, int stride,
-                 void* stream);
+                 int flags, void* stream);
 
 /* DyConv epilogue (GroupNorm(16) + bilinear up-sampling of the level+1 branch + scale attention + branch mean,
  * then DYReLU), NHWC fp16 with fp32 statistics; C == 256.

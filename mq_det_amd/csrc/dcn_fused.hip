@@ -33,6 +33,7 @@ struct DcnFParams {
   const float* wy; const float* wx;    // position weights w_p = wy[ho]*wx[wo] of the third statistic; NULL -> 1/(Ho*Wo)
   long x_bs;
   int B, H, W, C, Ho, Wo, stride, oH, oW, out_ld, tiles_x, tiles_y, tiles_total;
+  int mask_prob;           // 1: om[18..26] holds mask PROBABILITIES (the reference operator's argument), 0: logits (sigmoid here)
 };
 
 // per (output position, tap): BYTE offsets of the 4 bilinear corners inside the image, and corner weight x mask
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
         const int row = t / 9, tap = t - row * 9;
         const int ho = ho0 + row / DCN_PW, wo = wo0 + row % DCN_PW;
         const bool ok_row = ho < p.Ho && wo < p.Wo;
-        const float mk = 1.f / (1.f + __expf(-ml[i]));
+        const float mk = p.mask_prob ? ml[i] : 1.f / (1.f + __expf(-ml[i]));
         const float hf = (float)(ho * p.stride - 1 + tap / 3) + dh[i], wf = (float)(wo * p.stride - 1 + tap % 3) + dw[i];
         const bool inside = ok_row && hf > -1.f && wf > -1.f && hf < (float)p.H && wf < (float)p.W;
         const int h0 = (int)floorf(hf), w0 = (int)floorf(wf);
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
 }
 
 // DCNv2 3x3, pad 1, 256 output channels.  x [B,H,W,C] fp16 NHWC (batch stride x_bs, C % 128 == 0), om [B,27,oH,oW] fp32
-// (18 offsets + 9 mask logits, NCHW), w [256, 9*C] fp16 (k = tap*C + c), bias [256] fp16 or NULL, out [B*Ho*Wo, out_ld];
+// (18 offsets + 9 mask logits -- or probabilities with flags bit 0 --, NCHW), w [256, 9*C] fp16 (k = tap*C + c), bias [256] fp16 or NULL, out [B*Ho*Wo, out_ld];
 // stats (optional) [B, mq_dcnv2_stats_blocks(H, W, stride), 256, 3] fp32 with position weights wy [Ho] x wx [Wo] (or NULL).
 #ifndef MQ_BF16
 extern "C" int mq_dcnv2_stats_blocks(int H, int W, int stride) {
@@ -371,7 +372,7 @@ extern "C" int mq_dcnv2_stats_blocks(int H, int W, int stride) {
 struct mq_dcn_branch {          // mirrors include/mqdet_hip.h
   const void* x; const float* om; const void* w; const void* bias; void* out; float* stats; const float* wy; const float* wx;
   long x_bs;
-  int B, H, W, C, oH, oW, N, out_ld, stride, reserved;
+  int B, H, W, C, oH, oW, N, out_ld, stride, flags;
 };
 
 extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* stream) {
@@ -387,7 +388,7 @@ extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* 
     DcnFParams& p = g.br[g.n];
     p.x = (const half_t*)a.x; p.w = (const half_t*)a.w; p.bias = (const half_t*)a.bias; p.om = a.om; p.out = (half_t*)a.out;
     p.stats = a.stats; p.wy = a.wy; p.wx = a.wx;
-    p.x_bs = a.x_bs; p.B = a.B; p.H = a.H; p.W = a.W; p.C = a.C; p.stride = a.stride; p.oH = a.oH; p.oW = a.oW; p.out_ld = a.out_ld;
+    p.x_bs = a.x_bs; p.B = a.B; p.H = a.H; p.W = a.W; p.C = a.C; p.stride = a.stride; p.oH = a.oH; p.oW = a.oW; p.out_ld = a.out_ld; p.mask_prob = a.flags & 1;
     p.Ho = (a.H + 2 - 3) / a.stride + 1; p.Wo = (a.W + 2 - 3) / a.stride + 1;
     if ((long)p.Ho * p.Wo > (long)a.oH * a.oW) return -2;    // flat reads must stay inside the om buffer
     p.tiles_y = (p.Ho + DCN_PH - 1) / DCN_PH; p.tiles_x = (p.Wo + DCN_PW - 1) / DCN_PW;
@@ -417,10 +418,10 @@ extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* 
 
 extern "C" int MQ_SYM(mq_dcnv2_fwd)(const void* x, const float* om, const void* w, const void* bias, void* out, float* stats,
                             const float* wy, const float* wx, int B, int H, int W, int C, long x_bs, int oH, int oW, int N,
-                            int out_ld, int stride, void* stream) {
+                            int out_ld, int stride, int flags, void* stream) {
   mq_dcn_branch a;
   a.x = x; a.om = om; a.w = w; a.bias = bias; a.out = out; a.stats = stats; a.wy = wy; a.wx = wx; a.x_bs = x_bs;
-  a.B = B; a.H = H; a.W = W; a.C = C; a.oH = oH; a.oW = oW; a.N = N; a.out_ld = out_ld; a.stride = stride; a.reserved = 0;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.oH = oH; a.oW = oW; a.N = N; a.out_ld = out_ld; a.stride = stride; a.flags = flags;
   return MQ_SYM(mq_dcnv2_group_fwd)(&a, 1, stream);
 }
 

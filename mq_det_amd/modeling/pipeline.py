@@ -786,10 +786,14 @@ def grid_anchors(P, sizes, strides, device):
     return out
 
 
+TIE_SLOTS = 16      # output slots behind DETECTIONS_PER_IMG for detections tied with the last kept score (more ties than this are cut)
+
+
 def postprocess(cfg, head, anchors, im_wh, tokidx, label_ids, want_cls=False):
     """ATSSPostProcessor.forward (rpn/inference.py:620-769) without per-image Python loops or host syncs:
-    fixed-shape top-k per level, one sort, device-side NMS, fixed-shape top-`DETECTIONS_PER_IMG`.
-    Returns boxes [B,K,4], scores [B,K] (<= 0 => empty slot), labels [B,K], counts [B] -- all on device."""
+    fixed-shape top-k per level, one sort, device-side NMS, fixed-shape top-(`DETECTIONS_PER_IMG` + TIE_SLOTS).
+    Returns boxes [B,K2,4], scores [B,K2] (<= 0 => empty slot), labels [B,K2], counts [B] -- all on device; live slots are contiguous
+    from slot 0 (scores sorted descending, ties behind slot K - 1 directly follow it)."""
     A = cfg.MODEL.ATSS
     dev = head["tbias"].device
     Bn = head["tbias"].shape[0]
@@ -859,10 +863,18 @@ def postprocess(cfg, head, anchors, im_wh, tokidx, label_ids, want_cls=False):
     labels = torch.gather(labels, 1, order.to(torch.int64)).contiguous()
     boxes = torch.gather(boxes, 1, order[:, :, None].expand(-1, -1, 4)).contiguous()
     nvalid = (scores > 0).sum(1).to(torch.int32)
-    keep = ops.ml_nms(boxes, labels, nvalid, A.NMS_TH, max_keep=max(0, int(A.DETECTIONS_PER_IMG)))
+    # Final selection, rpn/inference.py:757-766: with more than DETECTIONS_PER_IMG survivors the reference keeps every detection whose
+    # score is >= the K-th best one (torch.kthvalue + `>=`) -- detections TIED with the K-th are all kept, so an image can return more
+    # than K.  Fixed shapes here: K + TIE_SLOTS output slots; the slots behind K are live only for scores equal to the K-th.
+    Kd = int(A.DETECTIONS_PER_IMG)
+    K = min(Kd, tot) if Kd > 0 else tot
+    K2 = min(K + TIE_SLOTS, tot) if Kd > 0 else tot
+    keep = ops.ml_nms(boxes, labels, nvalid, A.NMS_TH, max_keep=K2 if Kd > 0 else 0)
     kept_scores = torch.where(keep, scores, torch.full_like(scores, -1.0))
-    K = min(A.DETECTIONS_PER_IMG, tot) if A.DETECTIONS_PER_IMG > 0 else tot
-    top, ti = torch.topk(kept_scores, K, dim=1, sorted=True)
+    top, ti = torch.topk(kept_scores, K2, dim=1, sorted=True)
+    if K2 > K:
+        tie = top[:, K:] == top[:, K - 1:K]
+        top = torch.cat([top[:, :K], torch.where(tie, top[:, K:], torch.full_like(top[:, K:], -1.0))], 1)
     out = {"boxes": torch.gather(boxes, 1, ti[:, :, None].expand(-1, -1, 4)), "scores": top,
            "labels": torch.gather(labels, 1, ti).to(torch.int64), "counts": (top > 0).sum(1),
            "pre_nms": {"boxes": boxes, "scores": scores, "labels": labels, "nvalid": nvalid, "keep": keep}}

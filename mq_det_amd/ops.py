@@ -34,7 +34,7 @@ _SIGNATURES = {
     "mq_conv3x3_nchw32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _vp]),
     "mq_conv3x3_nchw32_v2_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _vp]),
     "mq_dcnv2_stats_blocks": (_i, [_i, _i, _i]),
-    "mq_dcnv2_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _vp]),
+    "mq_dcnv2_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_dcnv2_group_fwd": (_i, [_vp, _i, _vp]),
     "mq_dyconv_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mq_dyconv_coef": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
@@ -544,7 +544,7 @@ def conv3x3_nchw32(x_nhwc, w_packed, bias, n_out):
     return out
 
 
-def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None):
+def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None, mask_prob=False):
     """Fused DCNv2: x [B,H,W,C] fp16 NHWC, om [B,27,oH,oW] fp32, w_packed [256, 9*C] -> y [B, Ho*Wo, 256] fp16, (Ho, Wo)
     (, sums [B, nblk, 256, 3] fp32 = per-patch GroupNorm / scale-attention statistics of y when want_stats; wy [Ho] /
     wx [Wo] fp32 weight the third statistic, None -> 1/(Ho*Wo))."""
@@ -563,14 +563,14 @@ def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None
             assert wy.dtype == wx.dtype == torch.float32 and wy.numel() == Ho and wx.numel() == Wo
     with _timed("dcnv2_fused"):
         _chk(_fn(lib, "mq_dcnv2_fwd", x_nhwc)(_ptr(x_nhwc), _ptr(om), _ptr(w_packed), _ptr(bias), _ptr(y), _ptr(sums), _ptr(wy), _ptr(wx),
-                              B, H, W, C, x_nhwc.stride(0), om.shape[2], om.shape[3], 256, 256, stride, _stream()), "mq_dcnv2_fwd")
+                              B, H, W, C, x_nhwc.stride(0), om.shape[2], om.shape[3], 256, 256, stride, int(bool(mask_prob)), _stream()), "mq_dcnv2_fwd")
     return (y, (Ho, Wo), sums) if want_stats else (y, (Ho, Wo))
 
 
 class _DcnBranch(ctypes.Structure):
     """mq_dcn_branch of include/mqdet_hip.h."""
     _fields_ = [(n, _vp) for n in ("x", "om", "w", "bias", "out", "stats", "wy", "wx")] + [("x_bs", _l)] + \
-               [(n, _i) for n in ("B", "H", "W", "C", "oH", "oW", "N", "out_ld", "stride", "reserved")]
+               [(n, _i) for n in ("B", "H", "W", "C", "oH", "oW", "N", "out_ld", "stride", "flags")]
 
 
 def dcnv2_group(branches, want_stats=True):
@@ -600,7 +600,7 @@ def dcnv2_group(branches, want_stats=True):
         a.wy = wy.data_ptr() if wy is not None else None
         a.wx = wx.data_ptr() if wx is not None else None
         a.x_bs, a.B, a.H, a.W, a.C, a.oH, a.oW = x.stride(0), B, H, W, C, om.shape[2], om.shape[3]
-        a.N, a.out_ld, a.stride, a.reserved = 256, 256, stride, 0
+        a.N, a.out_ld, a.stride, a.flags = 256, 256, stride, int(bool(br.get("mask_prob", False)))
         outs.append((y, (Ho, Wo), sums))
     with _timed("dcnv2_fused"):
         _chk(_fn(lib, "mq_dcnv2_group_fwd", *[br["x"] for br in branches])(ctypes.cast(arr, _vp), len(branches), _stream()), "mq_dcnv2_group_fwd")

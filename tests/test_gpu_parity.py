@@ -322,9 +322,16 @@ def test_integration_md_operator_stubs_run_as_written(dev):
     mask = torch.sigmoid(torch.randn(2, 9, 20, 24, generator=g))
     w = (torch.randn(256, 256, 3, 3, generator=g) * 0.02).half().float()
     b = (torch.randn(256, generator=g) * 0.1).half().float()
-    y = ns["modulated_deform_conv_forward"](x.to(dev), off.to(dev), mask.to(dev), w.to(dev), b.to(dev), 1).float().cpu()
-    ref = ohead.dcn_v2(x, off, mask, w, b, 1)
-    assert float((y - ref).abs().max()) <= 4e-3 * max(1.0, float(ref.abs().max()))
+    mask[0, 3, 5, 6], mask[1, 0, 0, 0] = 0.0, 1.0                # probabilities AT the ends: a logit round trip would give +-inf
+    for stride in (1, 2):                                        # the reference's own call, layers/deform_conv.py:184-204 (19 arguments)
+        Ho, Wo = (20 - 1) // stride + 1, (24 - 1) // stride + 1
+        output = x.new_empty(2, 256, Ho, Wo).to(dev)
+        ones, columns = torch.empty(0, device=dev), torch.empty(0, device=dev)
+        ret = ns["modulated_deform_conv_forward"](x.to(dev), w.to(dev), b.to(dev), ones, off[:, :, :Ho, :Wo].contiguous().to(dev),
+                                                  mask[:, :, :Ho, :Wo].contiguous().to(dev), output, columns, 3, 3, stride, stride, 1, 1, 1, 1, 1, 1, True)
+        assert ret is output
+        ref = ohead.dcn_v2(x, off[:, :, :Ho, :Wo].contiguous(), mask[:, :, :Ho, :Wo].contiguous(), w, b, stride)
+        assert float((output.float().cpu() - ref).abs().max()) <= 4e-3 * max(1.0, float(ref.abs().max()))
     # _C.roi_align_forward (ROIAlignV2)
     feat = torch.randn(2, 64, 30, 40, generator=g)
     rois = torch.tensor([[0, 3.0, 4.0, 30.0, 25.0], [1, 10.5, 2.25, 39.0, 29.0], [0, 0.0, 0.0, 8.0, 8.0]])

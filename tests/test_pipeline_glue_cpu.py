@@ -99,6 +99,51 @@ def test_full_pipeline_glue(setup, emulated_ops):
         assert torch.equal(post["labels"][b, :n], d["labels"][o])
 
 
+def test_final_selection_keeps_detections_tied_with_the_kth_score(setup, emulated_ops):
+    """rpn/inference.py:757-766: with more than DETECTIONS_PER_IMG survivors every detection whose score is >= the K-th best is kept
+    (torch.kthvalue + `>=`) -- ties at the cut are ALL kept.  Scores built from three distinct logit values so that the cut falls inside
+    a group of equal scores; product post-processing (fixed shapes, K + TIE_SLOTS slots) vs the oracle's ATSSPostProcessor restatement."""
+    from dataclasses import replace
+    from oracle import postprocess as opost
+    spec, sd, cfg0, P = setup
+    cfg = cfg0.clone()
+    cfg.MODEL.ATSS.DETECTIONS_PER_IMG = 6
+    cfg.MODEL.DYHEAD.LEVEL_STREAMS = False
+    sp = replace(spec, detections_per_img=6, mdetr_class_num=-1)
+    B, T = 2, 64
+    sizes_hw = [(3, 4), (2, 2)]
+    pm = {k: [2 * k - 1] for k in range(1, 17)}                         # 16 labels, one token each
+    g = torch.Generator().manual_seed(9)
+    logits, regs, ctrs = [], [], []
+    for (h, w) in sizes_hw:
+        lg = torch.full((B, h * w, T), -9.0)
+        for b in range(B):
+            for loc in range(h * w):
+                lab_tok = pm[1 + (loc + 3 * b + (12 if h == 2 else 0)) % 16][0]   # a label of its own per location: NMS (per class) keeps all
+                lg[b, loc, lab_tok] = (2.0, 0.5, 0.5, 0.5, -0.3)[loc % 5]   # three distinct score values, the middle one three times in five
+        logits.append(lg)
+        regs.append(torch.zeros(B, 4, h, w))
+        ctrs.append(torch.zeros(B, 1, h, w))
+    anchors = pipeline.grid_anchors(P, sizes_hw, cfg.MODEL.RPN.ANCHOR_STRIDE[:2], torch.device("cpu"))
+    sizes = [(64, 64)] * B
+    labels = list(pm)
+    tokidx, label_ids = build_token_index(pm, labels, torch.device("cpu"))
+    with torch.no_grad():
+        odets = opost.atss_postprocess(regs, ctrs, logits, [a.clone() for a in anchors], sizes, pm, sp)
+        head = {"dot": logits, "tbias": torch.zeros(B, T), "bbox_reg": regs, "centerness": ctrs}
+        post = pipeline.postprocess(cfg, head, anchors, sizes, tokidx, label_ids)
+    assert post["scores"].shape[1] <= 6 + pipeline.TIE_SLOTS
+    more_than_k = False
+    for b, d in enumerate(odets):
+        n = int(post["counts"][b])
+        assert n == len(d["scores"]), (b, n, len(d["scores"]))
+        more_than_k |= n > 6
+        got = sorted((int(l), round(float(s), 5)) for l, s in zip(post["labels"][b, :n], post["scores"][b, :n]))
+        ref = sorted((int(l), round(float(s), 5)) for l, s in zip(d["labels"], d["scores"]))
+        assert got == ref, (b, got, ref)
+    assert more_than_k                                                  # the case exercises the tie rule (more kept than DETECTIONS_PER_IMG)
+
+
 def test_gcp_index_matches_reference_topk_trick(setup):
     """The host-built gather index == the reference's mask -> topk index (modeling_bert_new.py:40-63)."""
     from oracle.language import padded_nonzero_index
