@@ -157,8 +157,8 @@ int mq_swin_mlp_fwd(const float* x, const void* delta, const void* ln_g, const v
                     float eps_next, void* y, long M, int C, void* stream);
 
 /* Second generation of the same operator (csrc/swin_mlp2.hip; same arguments, same results up to the fp32 summation order of the
- * hidden chunks): the weights arrive FRAGMENT-MAJOR so that staging is a linear copy (flags bit 0: by LDS-DMA) and every
- * LDS read is conflict-free; GELU(chunk j), fc1(chunk j + 1) and fc2(chunk j - 1) are issued together (software pipeline);
+ * hidden chunks): the weights arrive FRAGMENT-MAJOR so that staging is a linear LDS-DMA copy (flags bit 0: two iterations ahead of
+ * its use through three-stage rings, else one) and every LDS read is conflict-free; GELU(chunk j), fc1(chunk j + 1) and fc2(chunk j - 1) are issued together (software pipeline);
  * flags bit 1: GELU through a 768-entry interpolation table of Phi (|error| < 8e-6) instead of the 14-instruction erf formula.
  *   w1f [(4C/32 + 2) * (C/16) * 512] fp16: block (chunk j, hb in {0,1}, ks) holds for lane l  fc1.weight[32j + 16hb + (l & 15)][32ks + 8(l >> 4) .. +7];
  *        two all-zero chunks follow the last one (the pipeline reads two chunks ahead);

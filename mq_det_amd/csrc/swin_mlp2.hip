@@ -12,7 +12,7 @@
 // waves of a SIMD were always in the same phase (both on the matrix pipe, then both on the VALU).  This kernel changes four things:
 //
 //   1. weights arrive FRAGMENT-MAJOR (packed once on the host, ops.swin_mlp2_pack): every 1 KB block is one MFMA A fragment in lane
-//      order.  Staging is a linear copy (optionally LDS-DMA, global_load_lds_dwordx4: no VGPRs, no ds_write), fragment reads are
+//      order.  Staging is a linear LDS-DMA copy (global_load_lds_dwordx4: no VGPRs, no ds_write), fragment reads are
 //      `base + lane * 16 + immediate` -- conflict-free by construction, no address arithmetic;
 //   2. a three-deep SOFTWARE PIPELINE over the hidden chunks inside each wave: iteration j issues GELU(chunk j) [VALU] together with
 //      GEMM1(chunk j + 1) and GEMM2(chunk j - 1) [MFMA], all mutually independent, so the matrix pipe and the VALU overlap within
@@ -77,55 +77,46 @@ constexpr int gelu_piece_of(int q, int GS, bool want_k) {
 }
 #define MQ_GELU_TAB_N 768            // Phi on [-6, 6) in steps of 1 / 64: linear interpolation error <= h^2 / 8 max|Phi''| = 7.4e-6
 
-template <int C, int NW, bool DMA, bool TABLE>
-__global__ __launch_bounds__(64 * NW, (C <= 96 ? (DMA ? 4 : 3) : C <= 192 ? (DMA ? 3 : 2) : 2)) void swin_mlp2_kernel(SwinMlp2Params p) {
+// DEEP: weights travel D = 2 iterations ahead of their use through three-stage LDS rings (D = 1, two stages, otherwise).  An LDS-DMA piece
+// takes 1 - 2 us from issue to landing when every CU streams (MI355X_MICROARCH.md "ldsdma-fill"); with D = 1 the barrier that ends
+// iteration j waits for pieces issued at its top, so an iteration cannot be shorter than that latency (measured round 3, GPU call 2:
+// 5.5 k cycles per iteration at C = 384 against ~1.6 k of MFMA issue).  With D = 2 the barrier waits for the PREVIOUS iteration's pieces
+// only (counted s_waitcnt vmcnt, raw s_barrier) and the current ones stay in flight across it.
+template <int C, int NW, bool DEEP, bool TABLE>
+__global__ __launch_bounds__(64 * NW, (C <= 96 ? 4 : C <= 192 ? (DEEP ? 2 : 3) : 2)) void swin_mlp2_kernel(SwinMlp2Params p) {
   constexpr int NT = 64 * NW, BM = 16 * NW, HID = 4 * C, KS = C / 32, CT = C / 16, NCHUNK = HID / 32;
   constexpr int FR = 512;                                     // halfs per fragment block (64 lanes x 8)
   constexpr int W1_FR = 2 * KS, W2_FR = CT, IT_FR = W1_FR + W2_FR;   // fragment blocks of one chunk of W1 / W2 / staged per iteration
   constexpr int FPW = IT_FR / NW;                             // fragment blocks a wave stages per iteration
-  static_assert(C % 32 == 0 && IT_FR % NW == 0 && NCHUNK % 2 == 0, "tile shapes");
+  constexpr int D = DEEP ? 2 : 1, NS = D + 1, U = DEEP ? 6 : 2;       // prefetch distance, ring stages, unroll = lcm(2, NS)
+  static_assert(C % 32 == 0 && IT_FR % NW == 0 && NCHUNK % U == 0, "tile shapes");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  half_t* w1s = (half_t*)smem;                                // [2][W1_FR][FR]   W1 ring: chunk c lives in stage c & 1
-  half_t* w2s = w1s + 2 * W1_FR * FR;                         // [2][W2_FR][FR]   W2 ring
-  float* tab = (float*)(w2s + 2 * W2_FR * FR);                // [MQ_GELU_TAB_N][2] (TABLE)
+  half_t* w1s = (half_t*)smem;                                // [NS][W1_FR][FR]   W1 ring: chunk c lives in stage c % NS
+  half_t* w2s = w1s + NS * W1_FR * FR;                        // [NS][W2_FR][FR]   W2 ring
+  half_t* b1s = w2s + NS * W2_FR * FR;                        // [HID]             fc1 bias (no ordinary global load inside the loop)
+  float* tab = (float*)(b1s + HID);                           // [MQ_GELU_TAB_N][2] (TABLE)
 
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: staging addresses in SGPRs
   const long row0 = (long)blockIdx.x * BM + wave * 16;        // this wave's 16 tokens
 
-  // ---- staging of one iteration's weights: W1 chunk c1 -> W1 stage c1 & 1, W2 chunk c2 -> W2 stage c2 & 1.  Block f of the
-  // iteration (f < W1_FR: W1, else W2) is copied by wave f % NW as one 1 KB piece: source and destination are both lane-linear.
-  half8 wreg[DMA ? 1 : FPW];
-  auto stage_src = [&](int f, int c1, int c2) -> const half_t* {
-    return f < W1_FR ? p.w1f + ((long)c1 * W1_FR + f) * FR : p.w2f + ((long)c2 * W2_FR + (f - W1_FR)) * FR;
-  };
-  auto stage_dst = [&](int f, int c1, int c2) -> half_t* {
-    return f < W1_FR ? w1s + ((c1 & 1) * W1_FR + f) * FR : w2s + ((c2 & 1) * W2_FR + (f - W1_FR)) * FR;
-  };
-  auto stage_issue = [&](int c1, int c2) {
+  // ---- staging of one iteration's weights by LDS-DMA: W1 chunk c1 -> W1 stage s1, W2 chunk c2 -> W2 stage s2.  Block f of the iteration
+  // (f < W1_FR: W1, else W2) is copied by wave f % NW as one 1 KB piece: source and destination are both lane-linear.
+  auto stage_issue = [&](int c1, int s1, int c2, int s2) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < FPW; ++i) {
       const int f = wave + i * NW;
-      const half_t* src = stage_src(f, c1, c2) + lane * 8;
-      if constexpr (DMA) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)stage_dst(f, c1, c2), 16, 0, 0);
-      } else {
-        wreg[i] = *(const half8*)src;
-      }
+      const half_t* src = (f < W1_FR ? p.w1f + ((long)c1 * W1_FR + f) * FR : p.w2f + ((long)c2 * W2_FR + (f - W1_FR)) * FR) + lane * 8;
+      half_t* dst = f < W1_FR ? w1s + (s1 * W1_FR + f) * FR : w2s + (s2 * W2_FR + (f - W1_FR)) * FR;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
   };
-  auto stage_commit = [&](int c1, int c2) {
-    if constexpr (!DMA) {
+  // chunks 0 .. D of W1 and chunk 0 of W2 -- into its own stage 0 and into stage NS - 1, which iteration 0 reads for its GEMM2 of the
+  // (all-zero) H of "chunk -1": finite weights x 0 = 0, so iteration 0 needs no special case -- : everything the fill and the first
+  // iterations read before their own pieces land
 #pragma unroll
-      for (int i = 0; i < FPW; ++i) {
-        const int f = wave + i * NW;
-        *(half8*)(stage_dst(f, c1, c2) + lane * 8) = wreg[i];
-      }
-    }
-  };
-  // chunk 0 of W1 (+ a W2 block that is overwritten before use) now; chunk 1 right after: both W1 stages are full at the first barrier
-  stage_issue(0, 0);
+  for (int c = 0; c <= D; ++c) stage_issue(c, c % NS, 0, c == 0 ? 0 : NS - 1);
+  for (int i = tid; i < HID / 8; i += NT) *(half8*)(b1s + i * 8) = *(const half8*)(p.b1 + i * 8);
   if constexpr (TABLE) {
     // Phi(x_i), Phi(x_i+1) - Phi(x_i) at x_i = -6 + i / 64
     for (int i = tid; i < MQ_GELU_TAB_N; i += NT) {
@@ -186,27 +177,19 @@ __global__ __launch_bounds__(64 * NW, (C <= 96 ? (DMA ? 4 : 3) : C <= 192 ? (DMA
   };
   if (p.delta) prologue(std::true_type{}); else prologue(std::false_type{});
 
-  stage_commit(0, 0);
-  stage_issue(1, 0);
-  stage_commit(1, 0);
-  __syncthreads();                                            // W1 chunks 0 and 1 (and the table) visible
+  __syncthreads();                                            // (drains the DMAs: vmcnt(0)) W1 chunks 0 .. D, W2 chunk 0, bias, table visible
 
   float4_ acc2[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) acc2[ct] = (float4_){0.f, 0.f, 0.f, 0.f};
 
-  // fc1 bias of a chunk = the initial value of its accumulators (lane holds hidden units 4 g + r and 16 + 4 g + r of the chunk).  It is
-  // loaded ONE ITERATION AHEAD and before the iteration's LDS-DMA pieces: VMEM results return in order, so a bias loaded behind the
-  // DMAs would make its first use wait for all of them (s_waitcnt vmcnt(0) at the top of the iteration instead of at its barrier).
-  half4 bq0, bq1;
-  auto bias_load = [&](int c) {
+  // fc1 bias of chunk c = the initial value of its accumulators (lane holds hidden units 4 g + r and 16 + 4 g + r of the chunk); from LDS:
+  // an ordinary global load inside the loop would make hipcc drain the LDS-DMA queue at its first use (VMEM returns in order)
+  auto h_init = [&](int c, float4_ (&h)[2]) __attribute__((always_inline)) {
     const int hb = min(c, NCHUNK - 1) * 32 + 4 * g;
-    bq0 = *(const half4*)(p.b1 + hb);
-    bq1 = *(const half4*)(p.b1 + hb + 16);
-  };
-  auto h_init = [&](float4_ (&h)[2]) {
+    const half4 b0 = *(const half4*)(b1s + hb), b1 = *(const half4*)(b1s + hb + 16);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { h[0][r] = (float)bq0[r]; h[1][r] = (float)bq1[r]; }
+    for (int r = 0; r < 4; ++r) { h[0][r] = (float)b0[r]; h[1][r] = (float)b1[r]; }
   };
   // GEMM 1 (transposed) of one chunk from W1 stage `st`: H^T[32 hidden, 16 tokens] over K = C (pipeline fill only)
   auto gemm1 = [&](int st, float4_ (&h)[2]) {
@@ -230,23 +213,16 @@ __global__ __launch_bounds__(64 * NW, (C <= 96 ? (DMA ? 4 : 3) : C <= 192 ? (DMA
   // GS stages (~5 VALU each, erf: {rcp + exp2 | polynomial | sign, scale, round}; table: {index + ds_read | interpolate}) that are
   // dealt out over the steps.  The source order IS the issue order: a scheduling fence closes every step -- left alone, the
   // compiler emits the whole GELU first and then MFMA after MFMA, each waiting for a fragment read issued one step earlier (ISA).
-  constexpr int RD = DMA ? 6 : 4, GS = TABLE ? 2 : 3, NPIECE = 8 * GS;      // (register staging holds FPW more fragments: shorter ring)
+  constexpr int RD = 6, GS = TABLE ? 2 : 3, NPIECE = 8 * GS;
   // MQ_PIN(x): an empty volatile asm that reads and "writes" x.  Instruction selection linearises a block's DAG on its own: arithmetic
   // that hangs on no side-effecting node is placed wherever it likes relative to the scheduling fences.  A piece's input and result
   // both pass through a pin, which chains the piece between the two fences of its step.
 #define MQ_PIN(x) asm volatile("" : "+v"(x))
-  float gt0 = 0.f, gt1 = 0.f, gt2 = 0.f, gt3 = 0.f, gt4 = 0.f, gt5 = 0.f, gt6 = 0.f, gt7 = 0.f;      // GELU state between stages: named
-  float ge0 = 0.f, ge1 = 0.f, ge2 = 0.f, ge3 = 0.f, ge4 = 0.f, ge5 = 0.f, ge6 = 0.f, ge7 = 0.f;      // scalars (pins take their address)
-  auto gsel = [&](auto kc, float& s0, float& s1, float& s2, float& s3, float& s4, float& s5, float& s6, float& s7) -> float& {
-    constexpr int k = decltype(kc)::value;
-    if constexpr (k == 0) return s0; else if constexpr (k == 1) return s1; else if constexpr (k == 2) return s2;
-    else if constexpr (k == 3) return s3; else if constexpr (k == 4) return s4; else if constexpr (k == 5) return s5;
-    else if constexpr (k == 6) return s6; else return s7;
-  };
-  auto gelu_piece = [&](auto kc, auto stc, const float4_ (&hin)[2], half8& hf) {
+  // (gts / ges: the iteration's GELU state between stages, local to the step -- every value's stages begin and end inside one step)
+  auto gelu_piece = [&](auto kc, auto stc, const float4_ (&hin)[2], half8& hf, float (&gts)[8], float (&ges)[8]) __attribute__((always_inline)) {
     constexpr int k = decltype(kc)::value, stage = decltype(stc)::value;
-    float& gt = gsel(kc, gt0, gt1, gt2, gt3, gt4, gt5, gt6, gt7);
-    float& ge = gsel(kc, ge0, ge1, ge2, ge3, ge4, ge5, ge6, ge7);
+    float& gt = gts[k];
+    float& ge = ges[k];
     float v = hin[k >> 2][k & 3];
     MQ_PIN(v);
     if constexpr (TABLE) {
@@ -282,35 +258,37 @@ __global__ __launch_bounds__(64 * NW, (C <= 96 ? (DMA ? 4 : 3) : C <= 192 ? (DMA
       }
     }
   };
-  auto step = [&](int j, auto PARc, auto FIRSTc, float4_ (&hin)[2], float4_ (&hout)[2], half8& hf_old, half8& hf_new) {
-    constexpr int PAR = decltype(PARc)::value;                // j & 1
-    constexpr bool FIRST = decltype(FIRSTc)::value;           // j == 0: no GEMM2 yet
-    constexpr int N = FIRST ? 2 * KS : 2 * KS + CT;
-    h_init(hout);                                             // bias of chunk j + 1, loaded during iteration j - 1
-    bias_load(j + 2);
-    stage_issue(j + 2, j);
-    const half_t* a1 = w1s + (1 - PAR) * W1_FR * FR + lane * 8;        // W1 chunk j + 1 (for j = NCHUNK - 1: a zero chunk)
-    const half_t* a2 = w2s + (1 - PAR) * W2_FR * FR + lane * 8;        // W2 chunk j - 1
+  auto step = [&](int j, auto PHc, auto PARc, float4_ (&hin)[2], float4_ (&hout)[2], half8& hf_old, half8& hf_new)
+      __attribute__((always_inline)) {
+    constexpr int PH = decltype(PHc)::value;                  // j % NS
+    constexpr int N = 2 * KS + CT;
+    constexpr int S1 = (PH + 1) % NS, S2 = (PH + NS - 1) % NS;          // stages of W1 chunk j + 1 / W2 chunk j - 1 (read now)
+    // pieces for iteration j + D: W1 chunk j + 1 + D -> the stage W1 chunk j left (read in iteration j - 1), W2 chunk j - 1 + D -> the stage
+    // of W2 chunk j - 2 (ditto).  Past the end the chunk index is clamped (valid memory, results unused).
+    stage_issue(min(j + 1 + D, NCHUNK + 1), PH, min(j - 1 + D, NCHUNK - 1), (PH + NS - 2) % NS);
+    h_init(j + 1, hout);
+    const half_t* a1 = w1s + S1 * W1_FR * FR + lane * 8;      // W1 chunk j + 1 (for j = NCHUNK - 1: a zero chunk)
+    const half_t* a2 = w2s + S2 * W2_FR * FR + lane * 8;      // W2 chunk j - 1
     // step i of the sequence: even -> GEMM1 fragment (hb = m & 1, ks = m >> 1), m = i / 2; odd -> GEMM2 fragment ct = i / 2
-    auto frag = [&](int i) -> half8 {
-      if (FIRST) return *(const half8*)(a1 + ((i & 1) * KS + (i >> 1)) * FR);
+    auto frag = [&](int i) __attribute__((always_inline)) -> half8 {
       const int m = i >> 1;
       return (i & 1) ? *(const half8*)(a2 + m * FR) : *(const half8*)(a1 + ((m & 1) * KS + (m >> 1)) * FR);
     };
     half8 ring[RD];
+    float gts[8], ges[8];
 #pragma unroll
     for (int i = 0; i < RD && i < N; ++i) ring[i] = frag(i);
-    static_for<N>([&](auto ic) {
+    static_for<N>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
-      static_for<NPIECE>([&](auto qc) {                       // the GELU pieces of this step: piece q belongs to step q N / NPIECE
+      static_for<NPIECE>([&](auto qc) __attribute__((always_inline)) {                       // the GELU pieces of this step: piece q belongs to step q N / NPIECE
         constexpr int q = decltype(qc)::value;
         if constexpr (q * N / NPIECE == i)
           gelu_piece(std::integral_constant<int, gelu_piece_of(q, GS, true)>{}, std::integral_constant<int, gelu_piece_of(q, GS, false)>{},
-                     hin, hf_new);
+                     hin, hf_new, gts, ges);
       });
       const half8 a = ring[i % RD];
-      if constexpr (FIRST || !(i & 1)) {
-        constexpr int m = FIRST ? i : i >> 1;
+      if constexpr (!(i & 1)) {
+        constexpr int m = i >> 1;
         hout[m & 1] = mfma16(a, xf[m >> 1], hout[m & 1]);
       } else {
         acc2[i >> 1] = mfma16(a, hf_old, acc2[i >> 1]);
@@ -318,23 +296,26 @@ __global__ __launch_bounds__(64 * NW, (C <= 96 ? (DMA ? 4 : 3) : C <= 192 ? (DMA
       if constexpr (i + RD < N) ring[i % RD] = frag(i + RD);
       __builtin_amdgcn_sched_barrier(0);
     });
-    stage_commit(j + 2, j);
-    __syncthreads();
+    // end of iteration j: the pieces issued in iteration j - (D - 1) must have landed before anybody reads them in iteration j + 1 -- the
+    // (D - 1) * FPW younger ones of this wave stay in flight across the barrier (counted wait; __syncthreads() would drain them all)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * FPW) : "memory");
+    __builtin_amdgcn_s_barrier();
   };
   float4_ hA[2], hB[2];
-  half8 hfA, hfB;
-  bias_load(0);
-  h_init(hA);
-  bias_load(1);
+  half8 hfA, hfB = zero8();                                   // hfB: H of "chunk -1" = 0 (iteration 0's GEMM2 adds nothing)
+  h_init(0, hA);
   gemm1(0, hA);                                               // pipeline fill: H^T of chunk 0
-  __syncthreads();                                            // every wave is done with W1 stage 0 before chunk 2 lands there
-  step(0, std::integral_constant<int, 0>{}, std::true_type{}, hA, hB, hfB, hfA);
-  for (int j = 1; j < NCHUNK - 1; j += 2) {
-    step(j, std::integral_constant<int, 1>{}, std::false_type{}, hB, hA, hfA, hfB);
-    step(j + 1, std::integral_constant<int, 0>{}, std::false_type{}, hA, hB, hfB, hfA);
-  }
-  step(NCHUNK - 1, std::integral_constant<int, 1>{}, std::false_type{}, hB, hA, hfA, hfB);
-  gemm2((NCHUNK - 1) & 1, hfB);                               // pipeline drain: the last chunk's GEMM 2
+  __syncthreads();                                            // every wave is done with W1 stage 0 before chunk NS lands there
+  for (int jb = 0; jb < NCHUNK; jb += U)                      // U iterations: every (stage phase, register set) combination once
+    static_for<U>([&](auto uc) __attribute__((always_inline)) {
+      constexpr int u = decltype(uc)::value;
+      if constexpr (u % 2 == 0)
+        step(jb + u, std::integral_constant<int, u % NS>{}, std::integral_constant<int, 0>{}, hA, hB, hfB, hfA);
+      else
+        step(jb + u, std::integral_constant<int, u % NS>{}, std::integral_constant<int, 1>{}, hB, hA, hfA, hfB);
+    });
+  gemm2((NCHUNK - 1) % NS, hfB);                              // pipeline drain: the last chunk's GEMM 2 (NCHUNK is even: hfB holds it)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the clamped pieces of the last iterations land before the LDS is released
 
   // ---- epilogue: lane holds OUT^T[c = 16 ct + 4 g + r][token = l15]; + bias + residual (x' re-read: L2-hot), fp32 out; loads of a
   // group of EG channel blocks all in flight before the first add / store (`out` may alias `x`: a lane only re-reads what it writes)
@@ -399,18 +380,19 @@ __global__ __launch_bounds__(64 * NW, (C <= 96 ? (DMA ? 4 : 3) : C <= 192 ? (DMA
   }
 }
 
-template <int C, int NW, bool DMA, bool TABLE>
+template <int C, int NW, bool DEEP, bool TABLE>
 static int launch_swin_mlp2(const SwinMlp2Params& p, hipStream_t s) {
-  constexpr size_t smem = (size_t)2 * (2 * (C / 32) + C / 16) * 512 * sizeof(half_t) + (TABLE ? MQ_GELU_TAB_N * 2 * sizeof(float) : 0);
+  constexpr size_t smem = (size_t)(DEEP ? 3 : 2) * (2 * (C / 32) + C / 16) * 512 * sizeof(half_t) + (size_t)4 * C * sizeof(half_t) +
+                          (TABLE ? MQ_GELU_TAB_N * 2 * sizeof(float) : 0);
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)swin_mlp2_kernel<C, NW, DMA, TABLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)swin_mlp2_kernel<C, NW, DEEP, TABLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
   constexpr int BM = 16 * NW;
   const unsigned grid = (unsigned)((p.M + BM - 1) / BM);
-  hipLaunchKernelGGL((swin_mlp2_kernel<C, NW, DMA, TABLE>), dim3(grid), dim3(64 * NW), smem, s, p);
+  hipLaunchKernelGGL((swin_mlp2_kernel<C, NW, DEEP, TABLE>), dim3(grid), dim3(64 * NW), smem, s, p);
   MQ_CHECK_LAUNCH();
   return 0;
 }
@@ -431,7 +413,7 @@ static int dispatch_swin_mlp2(const SwinMlp2Params& p, int flags, hipStream_t s)
 // w2f [(4C / 32) * (C / 16) * 512]: fc2.weight with the k-slot permutation of mq_swin_mlp_fwd (slot 8 g + t of a 32-block <- hidden unit
 //     4 g + t for t < 4, 16 + 4 g + t - 4 for t >= 4), fragment-major -- block (chunk j, ct) holds for lane l W2p[16 ct + (l & 15)][32 j + 8 (l >> 4) .. + 7];
 // out [M, C] fp32 (may alias x), y [M, C] 16-bit = LayerNorm(out; next_g, next_b, eps_next) if y != NULL.
-// flags: bit 0 = stage the weights with LDS-DMA (global_load_lds_dwordx4) instead of through registers; bit 1 = table GELU.
+// flags: bit 0 = weights travel two iterations ahead through three-stage LDS rings (else one / two); bit 1 = table GELU.
 extern "C" int MQ_SYM(mq_swin_mlp2_fwd)(const float* x, const void* delta, const void* ln_g, const void* ln_b, float eps, const void* w1f,
                                 const void* b1, const void* w2f, const void* b2, float* out, const void* next_g, const void* next_b,
                                 float eps_next, void* y, long M, int C, int flags, void* stream) {

@@ -74,7 +74,7 @@ KERNEL_DEFAULTS = {
     "NMS_EARLY_STOP": 1,         # 1: mq_ml_nms_topk (the sweep of an image ends once DETECTIONS_PER_IMG boxes are kept)          +0.9 %
     "ATTN_RESIDENT": 1,          # 1: mq_attn_resident_fwd / mq_attn_chunked_fwd (S^T form, keys resident / 256-key chunks)       +4.7 %
     "SWIN_MLP_VARIANT": 2,       # 2: mq_swin_mlp2_fwd (fragment-major weights, 3-deep software pipeline, 14-VALU GELU); 1: mq_swin_mlp_fwd
-    "SWIN_MLP2_FLAGS": 1,        # mq_swin_mlp2_fwd flags: bit 0 = LDS-DMA staging, bit 1 = table GELU
+    "SWIN_MLP2_FLAGS": 1,        # mq_swin_mlp2_fwd flags: bit 0 = weights two iterations ahead (3-stage LDS rings), bit 1 = table GELU
     "ALIGN_FUSED": 1,            # 1: mq_align_fused_fwd (heads + alignment + scoring, logits never written); 0: bmm + 5 GEMMs + 5 x mq_align_scores_fwd
 }
 KERNELS = dict(KERNEL_DEFAULTS)
@@ -490,7 +490,7 @@ def swin_mlp2_pack(w1, w2):
 
 def swin_mlp2(x, delta, ln_g, ln_b, eps, w1f, b1, w2f, b2, next_ln=None, flags=None):
     """Fused Swin MLP half, second generation (mq_swin_mlp2_fwd): arguments as swin_mlp but (w1f, w2f) = swin_mlp2_pack(fc1.weight,
-    fc2.weight); flags (default KERNELS["SWIN_MLP2_FLAGS"]): bit 0 LDS-DMA staging, bit 1 table GELU."""
+    fc2.weight); flags (default KERNELS["SWIN_MLP2_FLAGS"]): bit 0 deep prefetch (3-stage rings), bit 1 table GELU."""
     lib = load_library()
     _need_gpu(x, delta, ln_g, ln_b, w1f, b1, w2f, b2)
     C = x.shape[-1]

@@ -1274,7 +1274,7 @@ def check_swin_mlp(dev, variants=None):
                 w1f, w2f = ops.swin_mlp2_pack(w1, w2)
                 r = ops.swin_mlp2(x.to(dev), dl, lg.to(dev), lb.to(dev), 1e-5, w1f.to(dev), b1.to(dev), w2f.to(dev), b2.to(dev), next_ln=nln,
                                   flags=var[1])
-                tag = f"swin_mlp2[{'dma' if var[1] & 1 else 'regs'},{'table' if var[1] & 2 else 'erf'}] C={C} M={M} delta={use_delta}"
+                tag = f"swin_mlp2[{'deep' if var[1] & 1 else 'd1'},{'table' if var[1] & 2 else 'erf'}] C={C} M={M} delta={use_delta}"
             out, y = r if use_next else (r, None)
             res.append(_stat(f"{tag}: out (fp32 stream)", out, ref, tol=1e-3))
             if use_next:

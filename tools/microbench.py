@@ -81,7 +81,7 @@ def swin(dev, g, out):
         fl, nb = 16.0 * M * C * C, M * C * (4 + 2 + 4 + 2)
         runs = [("v1", lambda: ops.swin_mlp(x, d, lg, lb, 1e-5, w1d, b1, w2p, b2, next_ln=(lg, lb, 1e-5)))]
         for flags in (0, 1, 2, 3):
-            runs.append((f"v2[{'dma' if flags & 1 else 'regs'},{'table' if flags & 2 else 'erf'}]",
+            runs.append((f"v2[{'deep' if flags & 1 else 'd1'},{'table' if flags & 2 else 'erf'}]",
                          lambda flags=flags: ops.swin_mlp2(x, d, lg, lb, 1e-5, w1f, b1, w2f, b2, next_ln=(lg, lb, 1e-5), flags=flags)))
         ref = None
         for name, fn in runs:
