@@ -357,6 +357,12 @@ def kernel_rooflines(kern, steps, Bn, n_tok, embed=96):
         out.append(_mfma("dcn_igemm8_kernel (DCNv2: bilinear gather + blend + MFMA + GroupNorm statistics, 13 branches of a DyConv "
                          "layer per launch)", fl, fl, n, ms, "flops = 2 * 33600 * B * 2304 * 256 per layer (SURVEY.md 8d: 42.4 GF / image / layer); "
                          "traffic: PMC bytes per launch (profiles/r02_pmc_traffic.json)", pmc.get("dcn_igemm8_kernel")))
+    if "dcnv2_fpn" in per:                       # the FPN output convs (3 levels, one grouped launch) + P6 / P7 through the same kernel
+        n, ms, _ = per["dcnv2_fpn"]
+        pos = sum(h * w for h, w in LEVELS)      # 16800 + 4200 + 1050 (stride 1) + 273 + 77 (stride 2) output positions
+        fl = 2.0 * pos * Bn * 2304 * 256
+        out.append(_mfma("dcn_igemm8_kernel as plain 3x3 conv (FPN output convs, zero offsets)", fl, fl, n, ms,
+                         "flops = 2 * 22400 * B * 2304 * 256 (fpn_layer2-4 + P6 + P7); 3 launches"))
     # ---- VLFuse attention (vlfuse_attn.hip), 8 heads x 256.  SURVEY.md 8(d) / fuse_helper.py:233 compute QK^T ONCE and two
     # PV products: algorithmic = 3 * 2 * B * 8 * N * T_vis * 256 per layer with T_vis = the 64-key tiles that hold caption
     # tokens.  The two kernels each recompute the logits (executed = 4 * ...); the text side only computes 128-row query tiles.

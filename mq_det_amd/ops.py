@@ -544,7 +544,7 @@ def conv3x3_nchw32(x_nhwc, w_packed, bias, n_out):
     return out
 
 
-def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None, mask_prob=False):
+def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None, mask_prob=False, tag="dcnv2_fused"):
     """Fused DCNv2: x [B,H,W,C] fp16 NHWC, om [B,27,oH,oW] fp32, w_packed [256, 9*C] -> y [B, Ho*Wo, 256] fp16, (Ho, Wo)
     (, sums [B, nblk, 256, 3] fp32 = per-patch GroupNorm / scale-attention statistics of y when want_stats; wy [Ho] /
     wx [Wo] fp32 weight the third statistic, None -> 1/(Ho*Wo))."""
@@ -561,7 +561,7 @@ def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None
         sums = torch.empty(B, lib.mq_dcnv2_stats_blocks(H, W, stride), 256, 3, dtype=torch.float32, device=y.device)
         if wy is not None:
             assert wy.dtype == wx.dtype == torch.float32 and wy.numel() == Ho and wx.numel() == Wo
-    with _timed("dcnv2_fused"):
+    with _timed(tag):
         _chk(_fn(lib, "mq_dcnv2_fwd", x_nhwc)(_ptr(x_nhwc), _ptr(om), _ptr(w_packed), _ptr(bias), _ptr(y), _ptr(sums), _ptr(wy), _ptr(wx),
                               B, H, W, C, x_nhwc.stride(0), om.shape[2], om.shape[3], 256, 256, stride, int(bool(mask_prob)), _stream()), "mq_dcnv2_fwd")
     return (y, (Ho, Wo), sums) if want_stats else (y, (Ho, Wo))
@@ -573,7 +573,7 @@ class _DcnBranch(ctypes.Structure):
                [(n, _i) for n in ("B", "H", "W", "C", "oH", "oW", "N", "out_ld", "stride", "flags")]
 
 
-def dcnv2_group(branches, want_stats=True):
+def dcnv2_group(branches, want_stats=True, tag="dcnv2_fused"):
     """ONE launch for several DCNv2 calls (mq_dcnv2_group_fwd).  branches: list of dicts with x [B,H,W,C] fp16 NHWC view,
     om [B,27,oH,oW] fp32, w [256, 9*C] fp16, bias [256] fp16, stride, wy / wx (or None)
     -> list of (y [B, Ho*Wo, 256] fp16, (Ho, Wo), sums or None) in the same order."""
@@ -602,7 +602,7 @@ def dcnv2_group(branches, want_stats=True):
         a.x_bs, a.B, a.H, a.W, a.C, a.oH, a.oW = x.stride(0), B, H, W, C, om.shape[2], om.shape[3]
         a.N, a.out_ld, a.stride, a.flags = 256, 256, stride, int(bool(br.get("mask_prob", False)))
         outs.append((y, (Ho, Wo), sums))
-    with _timed("dcnv2_fused"):
+    with _timed(tag):
         _chk(_fn(lib, "mq_dcnv2_group_fwd", *[br["x"] for br in branches])(ctypes.cast(arr, _vp), len(branches), _stream()), "mq_dcnv2_group_fwd")
     return outs
 

@@ -277,7 +277,7 @@ def conv3x3_nchw32(x_nhwc, w_packed, bias, n_out):
     return conv3x3(x_nhwc, w_packed, bias, n_out).permute(0, 3, 1, 2).float().contiguous()
 
 
-def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None):
+def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None, mask_prob=False, tag=None):
     cols, hw = _dcn_cols(x_nhwc.contiguous(), om, stride)
     y = F.linear(cols.float(), w_packed.float(), bias.float()).to(x_nhwc.dtype)
     if not want_stats:
@@ -323,7 +323,7 @@ def patch_merge_ln(x, gamma, beta, eps=1e-5):
     return y.reshape(B, -1, 4 * C).to(gamma.dtype)
 
 
-def dcnv2_group(branches, want_stats=True):
+def dcnv2_group(branches, want_stats=True, tag=None):
     return [dcnv2(br["x"], br["om"], br["w"], br["bias"], br["stride"], want_stats=True, wy=br.get("wy"), wx=br.get("wx"))
             for br in branches]
 
