@@ -8,7 +8,7 @@ contractions rounded to the 16-bit type (oracle/precision.py RoundGemmOperands -
 softmaxes and GEMM outputs stay fp32).  The difference between the two is the smallest error ANY MFMA implementation with 16-bit
 operands can have against the fp32 reference on these weights.  Stored per stage: max |err|, mean |err|, max normalised by
 max(1, max |ref|), element count -- plus the fraction of the oracle's top detections the floor itself reproduces.
-`parity_checks.check_benchmark_config` gates the product on these numbers (FLOOR_RATIO_MEAN / FLOOR_RATIO_MAX there):
+`parity_checks.check_benchmark_config` gates the product on these numbers (FLOOR_RATIO_MEDIAN / FLOOR_RATIO_ROW there):
 the product's error may exceed the floor's by a stated factor and no more.  No reference code is involved (the oracle is pinned to
 the reference elsewhere: tests/test_oracle_golden.py); the script that made the file is this one.
 """
