@@ -99,7 +99,11 @@ int mq_gcp_gate_residual_fwd(const void* sup, const void* h, const void* w2, con
  *   (maskrcnn_benchmark/utils/fuse_helper.py:221-279,290-300,424; heads = 8), and the same branch of MQ-GroundingDINO's
  *   feature-enhancer fusion (groundingdino_new/models/GroundingDINO/fuse_modules.py:146-249,286-296; heads = 4). */
 int mq_vlfuse_i2t_fwd(const void* v_ln, const void* kf, const void* vo, const float* bias, const int* kv_len,
-                      const void* out_bias, void* out, int B, int N, int T, int heads, int max_kv, float clamp, void* stream);
+                      const void* out_bias, void* out, int B, int N, int T, int heads, int max_kv, float clamp, int variant,
+                      void* stream);
+/* variant: 2 = pair-split kernel (two waves share 32 query rows: one takes every second 16-key block of the logits and half of
+ *   the 256 output channels, Q fragments in registers; softmax statistics and P cross the pair through LDS -- half the LDS
+ *   fragment reads of variant 1); 1 = first kernel (a wave owns 16 query rows).  Same results up to fp32 summation order. */
 
 /* VLFuse text side: keys = values = image tokens, split over the keys (nsplit >= 1) + merge:
  *   out[b,t,h*256:(h+1)*256] = sum_n softmax_n( clamp(kf[b,h,t,:] . v_ln[b,n,:], +-clamp) ) v_ln[b,n,:]
@@ -157,9 +161,12 @@ int mq_swin_mlp_fwd(const float* x, const void* delta, const void* ln_g, const v
                     float eps_next, void* y, long M, int C, void* stream);
 
 /* Second generation of the same operator (csrc/swin_mlp2.hip; same arguments, same results up to the fp32 summation order of the
- * hidden chunks): the weights arrive FRAGMENT-MAJOR so that staging is a linear LDS-DMA copy (flags bit 0: two iterations ahead of
- * its use through three-stage rings, else one) and every LDS read is conflict-free; GELU(chunk j), fc1(chunk j + 1) and fc2(chunk j - 1) are issued together (software pipeline);
- * flags bit 1: GELU through a 768-entry interpolation table of Phi (|error| < 8e-6) instead of the 14-instruction erf formula.
+ * hidden chunks): the weights arrive FRAGMENT-MAJOR so that staging is a linear LDS-DMA copy and every LDS read is conflict-free;
+ * GELU(chunk j), fc1(chunk j + 1) and fc2(chunk j - 1) are issued together (software pipeline).  A launch lasts a whole number of
+ * passes of the chip (one 16-token block per wave); when only a few blocks remain beyond the last full pass they go to a second
+ * kernel that splits the hidden dimension of ONE block over the waves of a workgroup (1 / 8 of a pass instead of a whole one).
+ * flags bit 1: GELU through a 768-entry interpolation table of Phi (|error| < 8e-6) instead of the 14-instruction erf formula;
+ * bit 0: no pass / tail split; bit 2: every block through the tail kernel (tests).
  *   w1f [(4C/32 + 2) * (C/16) * 512] fp16: block (chunk j, hb in {0,1}, ks) holds for lane l  fc1.weight[32j + 16hb + (l & 15)][32ks + 8(l >> 4) .. +7];
  *        two all-zero chunks follow the last one (the pipeline reads two chunks ahead);
  *   w2f [(4C/32) * (C/16) * 512] fp16: block (chunk j, ct) holds for lane l  w2p[16ct + (l & 15)][32j + 8(l >> 4) .. +7], w2p = fc2.weight with

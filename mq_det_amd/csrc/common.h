@@ -30,6 +30,7 @@ typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
 #define MQ_NAMESPACE_END
 #endif
 typedef float float4_ __attribute__((ext_vector_type(4)));
+typedef float float2_ __attribute__((ext_vector_type(2)));
 
 #define MQ_NEG_BIG (-1.0e30f)
 

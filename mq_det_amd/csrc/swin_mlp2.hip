@@ -49,8 +49,6 @@ __device__ __forceinline__ float gelu_erf2(float v) {
   return fmaf(hv, __builtin_copysignf(erf_abs_scaled(v), v), hv);
 }
 
-typedef float float2_ __attribute__((ext_vector_type(2)));
-
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for_impl(F& f) {
@@ -77,18 +75,65 @@ constexpr int gelu_piece_of(int q, int GS, bool want_k) {
 }
 #define MQ_GELU_TAB_N 768            // Phi on [-6, 6) in steps of 1 / 64: linear interpolation error <= h^2 / 8 max|Phi''| = 7.4e-6
 
-// DEEP: weights travel D = 2 iterations ahead of their use through three-stage LDS rings (D = 1, two stages, otherwise).  An LDS-DMA piece
-// takes 1 - 2 us from issue to landing when every CU streams (MI355X_MICROARCH.md "ldsdma-fill"); with D = 1 the barrier that ends
-// iteration j waits for pieces issued at its top, so an iteration cannot be shorter than that latency (measured round 3, GPU call 2:
-// 5.5 k cycles per iteration at C = 384 against ~1.6 k of MFMA issue).  With D = 2 the barrier waits for the PREVIOUS iteration's pieces
-// only (counted s_waitcnt vmcnt, raw s_barrier) and the current ones stay in flight across it.
-template <int C, int NW, bool DEEP, bool TABLE>
-__global__ __launch_bounds__(64 * NW, (C <= 96 ? 4 : C <= 192 ? (DEEP ? 2 : 3) : 2)) void swin_mlp2_kernel(SwinMlp2Params p) {
+// LayerNorm of the wave's 16 tokens straight into MFMA B fragments (as swin_mlp.hip: lane (g, token l15) loads x[token][32 ks + 8 g .. + 7],
+// the four g-lanes of a token cover one 128-byte line per ks; statistics = in-lane sum + two shuffles; rows beyond M are clamped)
+template <int C, bool HAS_DELTA>
+__device__ __forceinline__ void ln_fragments(const SwinMlp2Params& p, long row0, int l15, int g, half8 (&xf)[C / 32]) {
+  constexpr int KS = C / 32;
+  const long row = min(row0 + l15, p.M - 1);
+  const float* xr = p.x + row * C + g * 8;
+  float4_ va[KS], vb[KS];
+  half8 vd[HAS_DELTA ? KS : 1];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    va[ks] = *(const float4_*)(xr + ks * 32);
+    vb[ks] = *(const float4_*)(xr + ks * 32 + 4);
+    if constexpr (HAS_DELTA) vd[ks] = *(const half8*)(p.delta + row * C + ks * 32 + g * 8);
+  }
+  float v[KS][8];
+  float s = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[ks][j] = va[ks][j]; v[ks][4 + j] = vb[ks][j]; }
+    if constexpr (HAS_DELTA) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[ks][j] += (float)vd[ks][j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[ks][j];
+  }
+  s += __shfl_xor(s, 16);
+  s += __shfl_xor(s, 32);
+  const float mean = s * (1.f / (float)C);
+  float q = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = v[ks][j] - mean; q += d * d; }
+  q += __shfl_xor(q, 16);
+  q += __shfl_xor(q, 32);
+  const float rstd = rsqrtf(q * (1.f / (float)C) + p.eps);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int c = ks * 32 + g * 8;
+    const half8 gm = *(const half8*)(p.g2 + c), bt = *(const half8*)(p.be2 + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xf[ks][j] = (half_t)((v[ks][j] - mean) * rstd * (float)gm[j] + (float)bt[j]);
+  }
+}
+
+// Weights travel D = 1 iteration ahead of their use through two-stage LDS rings.  (A D = 2 / three-stage variant, with a counted
+// s_waitcnt vmcnt that kept the youngest pieces in flight across the barrier, was built and measured in round 3 -- GPU calls 2 / 3,
+// profiles/r03_call3_microbench_swin_mlp.json: 0.2207 vs 0.2199 ms at C = 384, 0.206 vs 0.189 at C = 192 (one wave per SIMD less) --
+// the DMA latency is not what bounds an iteration; removed.)
+template <int C, int NW, bool TABLE>
+__global__ __launch_bounds__(64 * NW, (C <= 96 ? 4 : C <= 192 ? 3 : 2)) void swin_mlp2_kernel(SwinMlp2Params p) {
   constexpr int NT = 64 * NW, BM = 16 * NW, HID = 4 * C, KS = C / 32, CT = C / 16, NCHUNK = HID / 32;
   constexpr int FR = 512;                                     // halfs per fragment block (64 lanes x 8)
   constexpr int W1_FR = 2 * KS, W2_FR = CT, IT_FR = W1_FR + W2_FR;   // fragment blocks of one chunk of W1 / W2 / staged per iteration
   constexpr int FPW = IT_FR / NW;                             // fragment blocks a wave stages per iteration
-  constexpr int D = DEEP ? 2 : 1, NS = D + 1, U = DEEP ? 6 : 2;       // prefetch distance, ring stages, unroll = lcm(2, NS)
+  constexpr int D = 1, NS = D + 1, U = 2;                     // prefetch distance, ring stages, unroll = lcm(2, NS)
   static_assert(C % 32 == 0 && IT_FR % NW == 0 && NCHUNK % U == 0, "tile shapes");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* w1s = (half_t*)smem;                                // [NS][W1_FR][FR]   W1 ring: chunk c lives in stage c % NS
@@ -128,54 +173,8 @@ __global__ __launch_bounds__(64 * NW, (C <= 96 ? 4 : C <= 192 ? (DEEP ? 2 : 3) :
     }
   }
 
-  // ---- prologue: LayerNorm straight into MFMA B fragments (as swin_mlp.hip: lane (g, token l15) loads x[token][32 ks + 8 g .. + 7],
-  // the four g-lanes of a token cover one 128-byte line per ks; statistics = in-lane sum + two shuffles; rows beyond M are clamped)
   half8 xf[KS];
-  auto prologue = [&](auto HAS_DELTA) {
-    constexpr bool has_delta = decltype(HAS_DELTA)::value;
-    const long row = min(row0 + l15, p.M - 1);
-    const float* xr = p.x + row * C + g * 8;
-    float4_ va[KS], vb[KS];
-    half8 vd[has_delta ? KS : 1];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      va[ks] = *(const float4_*)(xr + ks * 32);
-      vb[ks] = *(const float4_*)(xr + ks * 32 + 4);
-      if constexpr (has_delta) vd[ks] = *(const half8*)(p.delta + row * C + ks * 32 + g * 8);
-    }
-    float v[KS][8];
-    float s = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { v[ks][j] = va[ks][j]; v[ks][4 + j] = vb[ks][j]; }
-      if constexpr (has_delta) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[ks][j] += (float)vd[ks][j];
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s += v[ks][j];
-    }
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    const float mean = s * (1.f / (float)C);
-    float q = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { const float d = v[ks][j] - mean; q += d * d; }
-    q += __shfl_xor(q, 16);
-    q += __shfl_xor(q, 32);
-    const float rstd = rsqrtf(q * (1.f / (float)C) + p.eps);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int c = ks * 32 + g * 8;
-      const half8 gm = *(const half8*)(p.g2 + c), bt = *(const half8*)(p.be2 + c);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) xf[ks][j] = (half_t)((v[ks][j] - mean) * rstd * (float)gm[j] + (float)bt[j]);
-    }
-  };
-  if (p.delta) prologue(std::true_type{}); else prologue(std::false_type{});
+  if (p.delta) ln_fragments<C, true>(p, row0, l15, g, xf); else ln_fragments<C, false>(p, row0, l15, g, xf);
 
   __syncthreads();                                            // (drains the DMAs: vmcnt(0)) W1 chunks 0 .. D, W2 chunk 0, bias, table visible
 
@@ -296,8 +295,7 @@ __global__ __launch_bounds__(64 * NW, (C <= 96 ? 4 : C <= 192 ? (DEEP ? 2 : 3) :
       if constexpr (i + RD < N) ring[i % RD] = frag(i + RD);
       __builtin_amdgcn_sched_barrier(0);
     });
-    // end of iteration j: the pieces issued in iteration j - (D - 1) must have landed before anybody reads them in iteration j + 1 -- the
-    // (D - 1) * FPW younger ones of this wave stay in flight across the barrier (counted wait; __syncthreads() would drain them all)
+    // end of iteration j: the pieces issued at its top must have landed before anybody reads them in iteration j + 1
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * FPW) : "memory");
     __builtin_amdgcn_s_barrier();
   };
@@ -380,31 +378,208 @@ __global__ __launch_bounds__(64 * NW, (C <= 96 ? 4 : C <= 192 ? (DEEP ? 2 : 3) :
   }
 }
 
-template <int C, int NW, bool DEEP, bool TABLE>
-static int launch_swin_mlp2(const SwinMlp2Params& p, hipStream_t s) {
-  constexpr size_t smem = (size_t)(DEEP ? 3 : 2) * (2 * (C / 32) + C / 16) * 512 * sizeof(half_t) + (size_t)4 * C * sizeof(half_t) +
+// ---- the TAIL kernel.  swin_mlp2_kernel gives a 16-token block to ONE wave for the whole hidden dimension: a launch lasts
+// ceil(blocks / (waves the chip holds)) full passes, and a few blocks over a multiple cost a whole extra pass -- the benchmark's
+// C = 384 stage is 8 x 4200 tokens = 2100 blocks on 256 CUs x 8 waves = 2048 slots: 52 blocks too many, two passes, the second one
+// on 7 CUs (measured: 0.22 ms; MFMA pipe ~30 % busy within a pass, 14 % over the launch).  Those blocks go to this kernel instead: ONE
+// 16-token block per WORKGROUP, the hidden dimension split over its NWT waves (wave w: chunks [w CPW, (w + 1) CPW)), so a block
+// takes 1 / NWT of a pass.  Every wave normalises the same 16 tokens, streams ITS chunks' fragment blocks straight from global
+// memory (each block is read by exactly one wave of the workgroup: nothing to share, no LDS staging; a register ring keeps RDT
+// loads in flight), and holds a partial OUT^T over all C channels; the partials are summed through LDS in a fixed order
+// (deterministic), wave w ending up with channel tiles {w, NWT + w, ...}; bias + residual + store + the fused next LayerNorm
+// (row statistics across the waves through LDS) follow as in the main kernel.
+template <int C, int NWT>
+__global__ __launch_bounds__(64 * NWT) void swin_mlp2_tail_kernel(SwinMlp2Params p) {
+  constexpr int HID = 4 * C, KS = C / 32, CT = C / 16, NCHUNK = HID / 32, FR = 512;
+  constexpr int W1_FR = 2 * KS, W2_FR = CT, N = W1_FR + W2_FR;
+  constexpr int CPW = NCHUNK / NWT, TPW = CT / NWT;           // hidden chunks per wave; channel tiles a wave finishes
+  constexpr int RDT = 8;
+  static_assert(NCHUNK % NWT == 0 && CT % NWT == 0, "tail split");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4_* red = (float4_*)smem;                              // [NWT src][NWT tile of the phase][64 lanes]
+  float* stat = (float*)(red + NWT * NWT * 64);               // [2][NWT][16]: per-wave partial row sums / squared deviations
+
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long row0 = (long)blockIdx.x * 16;
+
+  half8 xf[KS];
+  if (p.delta) ln_fragments<C, true>(p, row0, l15, g, xf); else ln_fragments<C, false>(p, row0, l15, g, xf);
+
+  float4_ acc2[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) acc2[ct] = (float4_){0.f, 0.f, 0.f, 0.f};
+
+  // fragment t of this wave's stream: chunk wave * CPW + t / N; within a chunk first W1 (hb = m & 1, ks = m >> 1), then W2 (ct)
+  const half_t* w1 = p.w1f + (long)wave * CPW * W1_FR * FR + lane * 8;
+  const half_t* w2 = p.w2f + (long)wave * CPW * W2_FR * FR + lane * 8;
+  auto frag = [&](int t) __attribute__((always_inline)) -> half8 {
+    const int cc = t / N, i = t % N;
+    if (i < W1_FR) return *(const half8*)(w1 + ((long)cc * W1_FR + (i & 1) * KS + (i >> 1)) * FR);
+    return *(const half8*)(w2 + ((long)cc * W2_FR + (i - W1_FR)) * FR);
+  };
+  half8 ring[RDT];
+#pragma unroll
+  for (int t = 0; t < RDT; ++t) ring[t] = frag(t);
+  static_for<CPW>([&](auto ccc) __attribute__((always_inline)) {
+    constexpr int cc = decltype(ccc)::value;
+    float4_ h[2];
+    {
+      const int hb = (wave * CPW + cc) * 32 + 4 * g;
+      const half4 b0 = *(const half4*)(p.b1 + hb), b1 = *(const half4*)(p.b1 + hb + 16);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { h[0][r] = (float)b0[r]; h[1][r] = (float)b1[r]; }
+    }
+    static_for<W1_FR>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value, t = cc * N + i;
+      h[i & 1] = mfma16(ring[t % RDT], xf[i >> 1], h[i & 1]);
+      if constexpr (t + RDT < CPW * N) ring[t % RDT] = frag(t + RDT);
+    });
+    half8 hf;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) hf[k] = (half_t)gelu_erf2(h[k >> 2][k & 3]);
+    static_for<W2_FR>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int ct = decltype(ic)::value, t = cc * N + W1_FR + ct;
+      acc2[ct] = mfma16(ring[t % RDT], hf, acc2[ct]);
+      if constexpr (t + RDT < CPW * N) ring[t % RDT] = frag(t + RDT);
+    });
+  });
+
+  // ---- the partials of the NWT waves, summed in wave order; after phase ph wave w holds channel tile ph * NWT + w
+  float4_ fin[TPW];
+#pragma unroll
+  for (int ph = 0; ph < TPW; ++ph) {
+    if (ph) __syncthreads();
+#pragma unroll
+    for (int d = 0; d < NWT; ++d) red[(wave * NWT + d) * 64 + lane] = acc2[ph * NWT + d];
+    __syncthreads();
+    float4_ a = red[wave * 64 + lane];
+#pragma unroll
+    for (int src = 1; src < NWT; ++src) {
+      const float4_ b = red[(src * NWT + wave) * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[r] += b[r];
+    }
+    fin[ph] = a;
+  }
+
+  // ---- epilogue: lane holds OUT^T[c = 16 (ph NWT + wave) + 4 g + r][token l15]
+  const long row = row0 + l15;
+  const bool live = row < p.M;
+  const long rrow = min(row, p.M - 1);
+  float s = 0.f;
+#pragma unroll
+  for (int ph = 0; ph < TPW; ++ph) {
+    const int c = (ph * NWT + wave) * 16 + 4 * g;
+    const float4_ xr = *(const float4_*)(p.x + rrow * C + c);
+    const half4 b2 = *(const half4*)(p.b2 + c);
+    half4 dl = (half4){(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+    if (p.delta) dl = *(const half4*)(p.delta + rrow * C + c);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { fin[ph][r] += (float)b2[r] + (xr[r] + (float)dl[r]); s += fin[ph][r]; }
+    if (live) *(float4_*)(p.out + row * C + c) = fin[ph];
+  }
+  if (p.y) {
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (g == 0) stat[wave * 16 + l15] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWT; ++w) tot += stat[w * 16 + l15];
+    const float mean = tot * (1.f / (float)C);
+    float q = 0.f;
+#pragma unroll
+    for (int ph = 0; ph < TPW; ++ph)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float d = fin[ph][r] - mean; q += d * d; }
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    if (g == 0) stat[(NWT + wave) * 16 + l15] = q;
+    __syncthreads();
+    float qt = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWT; ++w) qt += stat[(NWT + w) * 16 + l15];
+    const float rstd = rsqrtf(qt * (1.f / (float)C) + p.eps_n);
+    if (live) {
+#pragma unroll
+      for (int ph = 0; ph < TPW; ++ph) {
+        const int c = (ph * NWT + wave) * 16 + 4 * g;
+        const half4 gm = *(const half4*)(p.gn + c), bt = *(const half4*)(p.bn + c);
+        half4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (half_t)((fin[ph][r] - mean) * rstd * (float)gm[r] + (float)bt[r]);
+        *(half4*)(p.y + row * C + c) = o;
+      }
+    }
+  }
+}
+
+static int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus = n;
+  }
+  return cus;
+}
+
+template <int C, int NW, bool TABLE>
+static int launch_swin_mlp2_main(const SwinMlp2Params& p, hipStream_t s) {
+  constexpr size_t smem = (size_t)2 * (2 * (C / 32) + C / 16) * 512 * sizeof(half_t) + (size_t)4 * C * sizeof(half_t) +
                           (TABLE ? MQ_GELU_TAB_N * 2 * sizeof(float) : 0);
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)swin_mlp2_kernel<C, NW, DEEP, TABLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)swin_mlp2_kernel<C, NW, TABLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
   constexpr int BM = 16 * NW;
   const unsigned grid = (unsigned)((p.M + BM - 1) / BM);
-  hipLaunchKernelGGL((swin_mlp2_kernel<C, NW, DEEP, TABLE>), dim3(grid), dim3(64 * NW), smem, s, p);
+  hipLaunchKernelGGL((swin_mlp2_kernel<C, NW, TABLE>), dim3(grid), dim3(64 * NW), smem, s, p);
   MQ_CHECK_LAUNCH();
   return 0;
 }
 
-template <int C, int NW>
-static int dispatch_swin_mlp2(const SwinMlp2Params& p, int flags, hipStream_t s) {
-  switch (flags & 3) {
-    case 0: return launch_swin_mlp2<C, NW, false, false>(p, s);
-    case 1: return launch_swin_mlp2<C, NW, true, false>(p, s);
-    case 2: return launch_swin_mlp2<C, NW, false, true>(p, s);
-    default: return launch_swin_mlp2<C, NW, true, true>(p, s);
+template <int C, int NWT>
+static int launch_swin_mlp2_tail(const SwinMlp2Params& p, hipStream_t s) {
+  constexpr size_t smem = (size_t)NWT * NWT * 64 * sizeof(float4_) + (size_t)2 * NWT * 16 * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)swin_mlp2_tail_kernel<C, NWT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
   }
+  hipLaunchKernelGGL((swin_mlp2_tail_kernel<C, NWT>), dim3((unsigned)((p.M + 15) / 16)), dim3(64 * NWT), smem, s, p);
+  MQ_CHECK_LAUNCH();
+  return 0;
+}
+
+// WPC: workgroups of the main kernel a CU holds (its launch bounds / LDS).  The blocks beyond the last FULL pass go to the tail kernel
+// when they are few (at most two rounds of it: 2 x CUs blocks); flags bit 0 switches the split off, bit 2 sends everything to the tail
+// kernel (tests).
+template <int C, int NW, int NWT, int WPC>
+static int dispatch_swin_mlp2(const SwinMlp2Params& p, int flags, hipStream_t s) {
+  constexpr int BM = 16 * NW;
+  SwinMlp2Params pm = p, pt = p;
+  long m_main = p.M;
+  if (flags & 4) {
+    m_main = 0;
+  } else if (!(flags & 1)) {
+    const long wgs = (p.M + BM - 1) / BM, slots = (long)device_cus() * WPC, rem = wgs % slots;
+    if (wgs > slots && rem > 0 && rem * NW <= 2L * device_cus()) m_main = (wgs - rem) * BM;
+  }
+  if (m_main < p.M) {
+    pt.x = p.x + m_main * C; pt.out = p.out + m_main * C; pt.M = p.M - m_main;
+    if (p.delta) pt.delta = p.delta + m_main * C;
+    if (p.y) pt.y = p.y + m_main * C;
+    pm.M = m_main;
+    const int e = launch_swin_mlp2_tail<C, NWT>(pt, s);
+    if (e) return e;
+  }
+  if (pm.M <= 0) return 0;
+  return (flags & 2) ? launch_swin_mlp2_main<C, NW, true>(pm, s) : launch_swin_mlp2_main<C, NW, false>(pm, s);
 }
 
 // x [M, C] fp32, delta [M, C] 16-bit or NULL, LN gamma / beta [C], b1 [4C], b2 [C] 16-bit;
@@ -413,7 +588,7 @@ static int dispatch_swin_mlp2(const SwinMlp2Params& p, int flags, hipStream_t s)
 // w2f [(4C / 32) * (C / 16) * 512]: fc2.weight with the k-slot permutation of mq_swin_mlp_fwd (slot 8 g + t of a 32-block <- hidden unit
 //     4 g + t for t < 4, 16 + 4 g + t - 4 for t >= 4), fragment-major -- block (chunk j, ct) holds for lane l W2p[16 ct + (l & 15)][32 j + 8 (l >> 4) .. + 7];
 // out [M, C] fp32 (may alias x), y [M, C] 16-bit = LayerNorm(out; next_g, next_b, eps_next) if y != NULL.
-// flags: bit 0 = weights travel two iterations ahead through three-stage LDS rings (else one / two); bit 1 = table GELU.
+// flags: bit 1 = table GELU in the main kernel; bit 0 = no tail split; bit 2 = every block through the tail kernel (see dispatch_swin_mlp2).
 extern "C" int MQ_SYM(mq_swin_mlp2_fwd)(const float* x, const void* delta, const void* ln_g, const void* ln_b, float eps, const void* w1f,
                                 const void* b1, const void* w2f, const void* b2, float* out, const void* next_g, const void* next_b,
                                 float eps_next, void* y, long M, int C, int flags, void* stream) {
@@ -425,9 +600,9 @@ extern "C" int MQ_SYM(mq_swin_mlp2_fwd)(const float* x, const void* delta, const
   if (y && (!next_g || !next_b)) return -2;
   hipStream_t s = (hipStream_t)stream;
   switch (C) {
-    case 96: return dispatch_swin_mlp2<96, 4>(p, flags, s);
-    case 192: return dispatch_swin_mlp2<192, 4>(p, flags, s);
-    case 384: return dispatch_swin_mlp2<384, 8>(p, flags, s);
+    case 96: return dispatch_swin_mlp2<96, 4, 6, 4>(p, flags, s);
+    case 192: return dispatch_swin_mlp2<192, 4, 6, 3>(p, flags, s);
+    case 384: return dispatch_swin_mlp2<384, 8, 8, 1>(p, flags, s);
     default: return -1;                                      // other widths: library GEMM path of the caller
   }
 }

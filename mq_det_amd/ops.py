@@ -22,7 +22,7 @@ _SIGNATURES = {
     "mq_window_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_gcp_sparse_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_gcp_gate_residual_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _l, _i, _i, _vp]),
-    "mq_vlfuse_i2t_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "mq_vlfuse_i2t_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "mq_vlfuse_t2i_workspace_bytes": (_l, [_i, _i, _i]),
     "mq_vlfuse_t2i_fwd": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "mq_layernorm_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
@@ -74,7 +74,9 @@ KERNEL_DEFAULTS = {
     "NMS_EARLY_STOP": 1,         # 1: mq_ml_nms_topk (the sweep of an image ends once DETECTIONS_PER_IMG boxes are kept)          +0.9 %
     "ATTN_RESIDENT": 1,          # 1: mq_attn_resident_fwd / mq_attn_chunked_fwd (S^T form, keys resident / 256-key chunks)       +4.7 %
     "SWIN_MLP_VARIANT": 2,       # 2: mq_swin_mlp2_fwd (fragment-major weights, 3-deep software pipeline, 14-VALU GELU); 1: mq_swin_mlp_fwd
-    "SWIN_MLP2_FLAGS": 1,        # mq_swin_mlp2_fwd flags: bit 0 = weights two iterations ahead (3-stage LDS rings), bit 1 = table GELU
+    "SWIN_MLP2_FLAGS": -1,       # mq_swin_mlp2_fwd flags: -1 = per width (table GELU at C = 96, erf above; tail split on); else bit 1 = table
+                                 # GELU, bit 0 = no tail split, bit 2 = everything through the tail kernel
+    "VLFUSE_I2T_VARIANT": 2,     # mq_vlfuse_i2t_fwd: 2 = pair-split kernel (round 3), 1 = first kernel
     "ALIGN_FUSED": 1,            # 1: mq_align_fused_fwd (heads + alignment + scoring, logits never written); 0: bmm + 5 GEMMs + 5 x mq_align_scores_fwd
 }
 KERNELS = dict(KERNEL_DEFAULTS)
@@ -335,7 +337,7 @@ def gcp_gate_residual(sup, h, w2, x, want_gate=False):
     return (out, gate) if want_gate else out
 
 
-def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.0):
+def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.0, variant=None):
     """VLFuse image side (mq_vlfuse_i2t_fwd).  v_ln [B,N,256], kf / vo [B,heads,T,256] fp16 (heads <= 8), bias [B,heads,T] fp32 or None,
     out_bias [256] fp16, kv_len [B] int32 or None (max_kv: host-side upper bound, 0 = T) -> [B,N,256] fp16:
     v_ln + out_bias + sum_h softmax_t(clamp(v_ln.kf_h + bias_h)) vo_h."""
@@ -353,7 +355,8 @@ def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.
     out = torch.empty_like(v_ln)
     with _timed(f"vlfuse_i2t_n{N}_t{T}"):
         _chk(_fn(lib, "mq_vlfuse_i2t_fwd", v_ln)(_ptr(v_ln), _ptr(kf), _ptr(vo), _ptr(bias), _ptr(kv_len), _ptr(out_bias), _ptr(out),
-                                   B, N, T, Hh, int(max_kv), float(clamp), _stream()), "mq_vlfuse_i2t_fwd")
+                                   B, N, T, Hh, int(max_kv), float(clamp), int(KERNELS["VLFUSE_I2T_VARIANT"] if variant is None else variant),
+                                   _stream()), "mq_vlfuse_i2t_fwd")
     return out
 
 
@@ -490,7 +493,8 @@ def swin_mlp2_pack(w1, w2):
 
 def swin_mlp2(x, delta, ln_g, ln_b, eps, w1f, b1, w2f, b2, next_ln=None, flags=None):
     """Fused Swin MLP half, second generation (mq_swin_mlp2_fwd): arguments as swin_mlp but (w1f, w2f) = swin_mlp2_pack(fc1.weight,
-    fc2.weight); flags (default KERNELS["SWIN_MLP2_FLAGS"]): bit 0 deep prefetch (3-stage rings), bit 1 table GELU."""
+    fc2.weight); flags (default KERNELS["SWIN_MLP2_FLAGS"]): bit 1 = table GELU in the main kernel, bit 0 = no pass / tail split, bit 2 =
+    every block through the tail kernel; negative = the measured choice per width (profiles/r03_call3_microbench_swin_mlp.json)."""
     lib = load_library()
     _need_gpu(x, delta, ln_g, ln_b, w1f, b1, w2f, b2)
     C = x.shape[-1]
@@ -505,6 +509,8 @@ def swin_mlp2(x, delta, ln_g, ln_b, eps, w1f, b1, w2f, b2, next_ln=None, flags=N
         ng, nb, ne = next_ln
         y = torch.empty(x.shape, dtype=w1f.dtype, device=x.device)
     flags = KERNELS["SWIN_MLP2_FLAGS"] if flags is None else int(flags)
+    if flags < 0:
+        flags = 2 if C <= 96 else 0
     with _timed(f"swin_mlp_c{C}", M * C * (4 + 4 + (2 if delta is not None else 0) + (2 if y is not None else 0))):
         _chk(_fn(lib, "mq_swin_mlp2_fwd", w1f)(_ptr(x), _ptr(delta), _ptr(ln_g), _ptr(ln_b), float(eps), _ptr(w1f), _ptr(b1), _ptr(w2f), _ptr(b2),
                                                _ptr(out), _ptr(ng), _ptr(nb), float(ne), _ptr(y), M, C, flags, _stream()), "mq_swin_mlp2_fwd")

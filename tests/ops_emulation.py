@@ -328,7 +328,7 @@ def dcnv2_group(branches, want_stats=True, tag=None):
             for br in branches]
 
 
-def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.0):
+def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.0, variant=None):
     B, N, C = v_ln.shape
     T = kf.shape[2]
     s = torch.einsum("bnc,bhtc->bhnt", v_ln.float(), kf.float())

@@ -332,8 +332,11 @@ def check_vlfuse_kernels(dev):
     from mq_det_amd import ops
     g = torch.Generator().manual_seed(21)
     res = []
+    # (141 tokens: NT = 3 tiles with ONE live 16-key block in the last; kv_len = 1: the second wave of a pair of the pair-split kernel
+    # sees masked keys only; 83 / 110 / 177 keys: 2 / 3 / 4 live blocks in the last tile)
     for B, N, T, kv in ((2, 645, 64, None), (3, 300, 100, [100, 37, 70]), (2, 200, 160, [131, 160]), (1, 130, 256, [256]),
-                        (9, 128, 40, None))[1 if QUICK else 0:4 if QUICK else 5]:
+                        (2, 100, 141, [141, 1]), (1, 70, 96, [83]), (1, 70, 110, [110]), (1, 70, 200, [177]),
+                        (9, 128, 40, None))[1 if QUICK else 0:6 if QUICK else 9]:
         v_ln = torch.randn(B, N, 256, generator=g).to(H16)
         kf = (torch.randn(B, 8, T, 256, generator=g) / 8).to(H16)
         vo = torch.randn(B, 8, T, 256, generator=g).to(H16)
@@ -342,9 +345,10 @@ def check_vlfuse_kernels(dev):
         ob = torch.randn(256, generator=g).to(H16)
         kv_len = None if kv is None else torch.tensor(kv, dtype=torch.int32)
         ref = emu.vlfuse_i2t(v_ln.float(), kf.float(), vo.float(), bias, ob.float(), kv_len, 0)
-        got = ops.vlfuse_i2t(v_ln.to(dev), kf.to(dev), vo.to(dev), bias.to(dev), ob.to(dev),
-                             None if kv_len is None else kv_len.to(dev), max_kv=0 if kv is None else max(kv))
-        res.append(_stat(f"vlfuse image side B={B} N={N} T={T} kv_len={kv}", got, ref, tol=2e-3))
+        for variant in (2, 1):
+            got = ops.vlfuse_i2t(v_ln.to(dev), kf.to(dev), vo.to(dev), bias.to(dev), ob.to(dev),
+                                 None if kv_len is None else kv_len.to(dev), max_kv=0 if kv is None else max(kv), variant=variant)
+            res.append(_stat(f"vlfuse image side [{'pair-split' if variant == 2 else 'first kernel'}] B={B} N={N} T={T} kv_len={kv}", got, ref, tol=2e-3))
     for B, N, T, ns, kv in ((2, 645, 64, 1, None), (1, 22400, 256, 6, None), (3, 1000, 100, 3, None), (2, 130, 160, 2, [160, 90]),
                             (9, 70, 40, 1, None), (3, 500, 256, 4, [256, 128, 77]))[3 if QUICK else 0:]:
         v_ln = torch.randn(B, N, 256, generator=g).to(H16)
@@ -1262,15 +1266,20 @@ def check_extract_query(dev):
 def check_swin_mlp(dev, variants=None):
     """The fused Swin MLP half (LN prologue + fc1 + exact GELU + fc2 + residual + fused next LayerNorm in one kernel) vs a plain fp32
     statement on the same fp16-rounded weights: every supported width, ragged token counts, with / without delta / next-LN.
-    variants: ("v1",) = mq_swin_mlp_fwd; ("v2", flags) = mq_swin_mlp2_fwd with flags (bit 0 LDS-DMA staging, bit 1 table GELU);
-    default: v1 and all four v2 flag combinations."""
+    variants: ("v1",) = mq_swin_mlp_fwd; ("v2", flags) = mq_swin_mlp2_fwd with flags (bit 1 table GELU, bit 0 no pass / tail split, bit 2
+    everything through the tail kernel); default: v1, v2 erf / table / tail-only / unsplit.  The two long cases cross the pass / tail
+    split on the device (C = 384: 33 600 tokens = 263 workgroups on 256 CUs; C = 192: 773 on 768 slots); 1030 / 777 / 562 tokens cross it on
+    the emulator's 4-CU "chip" (tests/simt/include/hip/hip_runtime.h)."""
     from mq_det_amd import ops
     res = []
-    variants = variants or (("v1",), ("v2", 0), ("v2", 1), ("v2", 2), ("v2", 3))
+    variants = variants or (("v1",), ("v2", 0), ("v2", 2), ("v2", 4), ("v2", 1))
     for var in variants:
         g = torch.Generator().manual_seed(51)
-        for C, M, use_delta, use_next in ((96, 1000, True, True), (96, 128, False, False), (192, 777, True, True), (384, 333, True, True),
-                                          (384, 64, True, False), (96, 67200 * 2 + 5, True, True))[:5 if QUICK else 6]:
+        for C, M, use_delta, use_next in ((96, 1030, True, True), (96, 128, False, False), (192, 777, True, True), (384, 562, True, True),
+                                          (384, 64, True, False), (96, 67200 * 2 + 5, True, True), (384, 33600, True, True),
+                                          (192, 49452, True, True))[:5 if QUICK else 8]:
+            if M > 30000 and (var[0] == "v1" or var[1] & 4):
+                continue
             x = torch.randn(M, C, generator=g) * 1.5
             delta = (torch.randn(M, C, generator=g) * 0.5).to(H16) if use_delta else None
             lg, lb = (torch.randn(C, generator=g) * 0.1 + 1).to(H16), (torch.randn(C, generator=g) * 0.1).to(H16)
@@ -1293,7 +1302,8 @@ def check_swin_mlp(dev, variants=None):
                 w1f, w2f = ops.swin_mlp2_pack(w1, w2)
                 r = ops.swin_mlp2(x.to(dev), dl, lg.to(dev), lb.to(dev), 1e-5, w1f.to(dev), b1.to(dev), w2f.to(dev), b2.to(dev), next_ln=nln,
                                   flags=var[1])
-                tag = f"swin_mlp2[{'deep' if var[1] & 1 else 'd1'},{'table' if var[1] & 2 else 'erf'}] C={C} M={M} delta={use_delta}"
+                tag = (f"swin_mlp2[{'tail only' if var[1] & 4 else 'unsplit' if var[1] & 1 else 'split'},{'table' if var[1] & 2 else 'erf'}] "
+                       f"C={C} M={M} delta={use_delta}")
             out, y = r if use_next else (r, None)
             res.append(_stat(f"{tag}: out (fp32 stream)", out, ref, tol=1e-3))
             if use_next:

@@ -42,6 +42,8 @@ def main():
         align(dev, g, out)
     if only in ("", "window"):
         window(dev, g, out)
+    if only in ("", "vlfuse"):
+        vlfuse(dev, g, out)
     for r in out:
         print(json.dumps(r))
     if len(sys.argv) > 1:
@@ -66,8 +68,8 @@ def msda(dev, g, out):
 
 
 def swin(dev, g, out):
-    # ---- fused Swin MLP per stage (B = 8, 800x1344): the first kernel (mq_swin_mlp_fwd) and the four flag combinations of mq_swin_mlp2_fwd
-    for C, M in ((96, 8 * 67200), (192, 8 * 16800), (384, 8 * 4200)):
+    # ---- fused Swin MLP per stage (B = 8, 800x1344): the first kernel (mq_swin_mlp_fwd) and mq_swin_mlp2_fwd: erf / table GELU, with and without the pass / tail split; one exact pass (256 x 128 tokens) at C = 384
+    for C, M in ((96, 8 * 67200), (192, 8 * 16800), (384, 8 * 4200), (384, 256 * 128), (384, 52 * 16)):
         x = torch.randn(M, C, generator=g).to(dev)
         d = torch.randn(M, C, generator=g).half().to(dev)
         lg, lb = torch.ones(C).half().to(dev), torch.zeros(C).half().to(dev)
@@ -80,8 +82,10 @@ def swin(dev, g, out):
         w1f, w2f = (t.to(dev) for t in ops.swin_mlp2_pack(w1, w2))
         fl, nb = 16.0 * M * C * C, M * C * (4 + 2 + 4 + 2)
         runs = [("v1", lambda: ops.swin_mlp(x, d, lg, lb, 1e-5, w1d, b1, w2p, b2, next_ln=(lg, lb, 1e-5)))]
-        for flags in (0, 1, 2, 3):
-            runs.append((f"v2[{'deep' if flags & 1 else 'd1'},{'table' if flags & 2 else 'erf'}]",
+        for flags in (0, 1, 2, 3, 4):
+            if flags & 4 and M > 40000:
+                continue
+            runs.append((f"v2[{'tail only' if flags & 4 else 'unsplit' if flags & 1 else 'split'},{'table' if flags & 2 else 'erf'}]",
                          lambda flags=flags: ops.swin_mlp2(x, d, lg, lb, 1e-5, w1f, b1, w2f, b2, next_ln=(lg, lb, 1e-5), flags=flags)))
         ref = None
         for name, fn in runs:
@@ -121,6 +125,31 @@ def align(dev, g, out):
             ops.align_scores(dots[:, off:off + h * w], tbias, tokidx, bc[:, off:off + h * w, 4].contiguous(), 0.05)
             off += h * w
     out.append({"kernel": "round-2 path: bmm + head GEMM + 5 x align_scores (same shape)", "ms": round(timeit(old), 4)})
+
+
+def vlfuse(dev, g, out):
+    # ---- VLFuse image side at the bench shape (B = 8, N = 22 400 image tokens, 8 heads x 256, T = 256 with 141 / 81 / 256 live keys):
+    # the first kernel (a wave owns 16 query rows) against the pair-split kernel.  flops = 4 * B * heads * N * keys_visited * 256
+    B, N, T = 8, 22400, 256
+    v = torch.randn(B, N, 256, generator=g).half().to(dev)
+    kf = (torch.randn(B, 8, T, 256, generator=g) / 8).half().to(dev)
+    vo = torch.randn(B, 8, T, 256, generator=g).half().to(dev)
+    bias = torch.randn(B, 8, T, generator=g).to(dev)
+    ob = torch.zeros(256).half().to(dev)
+    for live in (141, 81, 256):
+        kv = torch.full((B,), live, dtype=torch.int32, device=dev)
+        ref = None
+        for variant in (1, 2):
+            fn = lambda variant=variant: ops.vlfuse_i2t(v, kf, vo, bias, ob, kv_len=kv, max_kv=live, variant=variant)  # noqa: E731
+            ms = timeit(fn)
+            o = fn().float()
+            ref = o if ref is None else ref
+            visited = -(-live // 16) * 16
+            fl = 4.0 * B * 8 * N * visited * 256
+            nb = v.numel() * 2 * 2 + kf.numel() * 2 * 2
+            out.append({"kernel": f"vlfuse_i2t {'first kernel' if variant == 1 else 'pair-split'} B={B} N={N} live keys={live}", "ms": round(ms, 4),
+                        "TFLOPs": round(fl / ms / 1e9, 1), "frac_of_mfma_peak": round(fl / ms / 1e9 / 2500, 3),
+                        "algorithmic_GBs": round(nb / ms / 1e6, 1), "max_abs_diff_vs_first": round(float((o - ref).abs().max()), 6)})
 
 
 def window(dev, g, out):
