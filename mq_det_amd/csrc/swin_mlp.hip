@@ -309,20 +309,12 @@ extern "C" int MQ_SYM(mq_swin_mlp_fwd)(const float* x, const void* delta, const 
   p.gn = (const half_t*)next_g; p.bn = (const half_t*)next_b; p.eps_n = eps_next; p.y = (half_t*)y; p.M = M;
   if (y && (!next_g || !next_b)) return -2;
   hipStream_t s = (hipStream_t)stream;
-  // tile variant: default = the fastest measured per width (profiles/README.md); MQ_SWIN_MLP_VARIANT = 0..2 forces one (A/B runs)
-  static const int variant = [] { const char* e = getenv("MQ_SWIN_MLP_VARIANT"); return e ? atoi(e) : -1; }();
+  // tile shapes: the fastest measured per width in round 2 (profiles/README.md; the slower ones -- 64-token chunks, T = 2, 4 waves at
+  // C = 384 -- are gone with their A/B switch)
   switch (C) {
-    case 96:
-      if (variant == 0) return launch_swin_mlp<96, 64, 2, 8>(p, s);
-      if (variant == 1) return launch_swin_mlp<96, 32, 2, 4>(p, s);
-      return launch_swin_mlp<96, 32, 1, 4>(p, s);
-    case 192:
-      if (variant == 0) return launch_swin_mlp<192, 32, 2, 8>(p, s);
-      if (variant == 1) return launch_swin_mlp<192, 32, 2, 4>(p, s);
-      return launch_swin_mlp<192, 32, 1, 4>(p, s);
-    case 384:                                                // 8 waves: 0.33 ms per launch vs 0.38 with 4 (profiles/README.md)
-      if (variant == 1 || variant == 2) return launch_swin_mlp<384, 32, 1, 4>(p, s);
-      return launch_swin_mlp<384, 32, 1, 8>(p, s);
+    case 96: return launch_swin_mlp<96, 32, 1, 4>(p, s);
+    case 192: return launch_swin_mlp<192, 32, 1, 4>(p, s);
+    case 384: return launch_swin_mlp<384, 32, 1, 8>(p, s);  // 8 waves: 0.33 ms per launch vs 0.38 with 4
     default: return -1;                                      // other widths: library GEMM path of the caller
   }
 }

@@ -629,7 +629,7 @@ static int launch_i2t2(const I2TParams& p, hipStream_t stream) {
   return 0;
 }
 
-// waves x rows shape of both VLFuse kernels: 8 waves x 16 query rows (default) or 4 waves x 32 (MQ_VLFUSE_QB=2, A/B switch)
+// waves x rows shape of the text-side kernel: 8 waves x 16 query rows (default) or 4 waves x 32 (MQ_VLFUSE_QB=2, A/B switch)
 static int vlfuse_qb() {
   static const int qb = [] { const char* e = getenv("MQ_VLFUSE_QB"); return (e && e[0] == '2') ? 2 : 1; }();
   return qb;
@@ -665,28 +665,20 @@ extern "C" int MQ_SYM(mq_vlfuse_i2t_fwd)(const void* v_ln, const void* kf, const
     }
 #undef MQ_I2T2
   }
-  if (vlfuse_qb() == 1) {
 #define MQ_I2T(NT_)                                                        \
-    switch (nbl) {                                                         \
-      case 1: return launch_i2t<NT_, 1, 1>(p, st);                         \
-      case 2: return launch_i2t<NT_, 1, 2>(p, st);                         \
-      case 3: return launch_i2t<NT_, 1, 3>(p, st);                         \
-      default: return launch_i2t<NT_, 1, 4>(p, st);                        \
-    }
-    switch (nt) {
-      case 1: MQ_I2T(1)
-      case 2: MQ_I2T(2)
-      case 3: MQ_I2T(3)
-      default: MQ_I2T(4)
-    }
+  switch (nbl) {                                                           \
+    case 1: return launch_i2t<NT_, 1, 1>(p, st);                           \
+    case 2: return launch_i2t<NT_, 1, 2>(p, st);                           \
+    case 3: return launch_i2t<NT_, 1, 3>(p, st);                           \
+    default: return launch_i2t<NT_, 1, 4>(p, st);                          \
+  }
+  switch (nt) {
+    case 1: MQ_I2T(1)
+    case 2: MQ_I2T(2)
+    case 3: MQ_I2T(3)
+    default: MQ_I2T(4)
+  }
 #undef MQ_I2T
-  }
-  switch (nt) {                                                            // 4 waves x 32 rows (A/B switch): whole tiles only
-    case 1: return launch_i2t<1, 2, 4>(p, st);
-    case 2: return launch_i2t<2, 2, 4>(p, st);
-    case 3: return launch_i2t<3, 2, 4>(p, st);
-    default: return launch_i2t<4, 2, 4>(p, st);
-  }
 }
 
 // ------------------------------------------------------------------------------------------------ text side
@@ -701,6 +693,7 @@ struct T2IParams {
   int H;                  // heads, <= VH
   int B, N, T, nsplit;
   int wr;                 // rows per wave of the main kernel (16 QB): granularity at which all-padding rows are skipped
+  int members;            // workgroups per (image, key split): ceil(heads * ceil(max live rows / wr) / waves per workgroup)
   float clamp;
 };
 namespace { constexpr int WS_LD = VD + 4; }               // 260 floats: rows stay 16-byte aligned
@@ -713,22 +706,26 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l15 = lane & 15, lg = lane >> 4;
-  // XCD-aware order: the 8 heads x q-tiles of one (image, key split) stream the SAME image tokens -> one XCD, adjacent
-  const int qtiles = (p.T + BM - 1) / BM;
-  const int members = p.H * qtiles;
+  // XCD-aware order: the workgroups of one (image, key split) stream the SAME image tokens -> one XCD, adjacent
+  const int members = p.members;
   const int seq = blockIdx.x >> 3;
   const int group = (seq / members) * 8 + (blockIdx.x & 7);
   if (group >= p.B * p.nsplit) return;
-  const int wq = seq % members, h = wq % p.H, qtile = wq / p.H;
+  const int wq = seq % members;
   const int b = group / p.nsplit, split = group % p.nsplit;
-  // padded caption tokens: as keys they are masked everywhere downstream and the post-processor never reads their
-  // logits, so their rows of this attention are dead -- whole q-tiles of padding are skipped (the merge writes zeros)
+  // Work units = (head, block of WR text rows), LIVE blocks only, packed densely over the waves of the group's workgroups: padded
+  // caption tokens are masked as keys everywhere downstream and the post-processor never reads their logits, so their rows of this
+  // attention are dead (the merge writes zeros).  (Round 2 gave a workgroup 128 rows of one head: a 141-token caption -- 9 live blocks
+  // per head -- took 2 x 8 workgroups per group, 8 of them with ONE live wave, each streaming every key tile: 3 passes of the chip
+  // instead of 2.)  A wave beyond the last unit only helps to stage the key tiles.
   const int kv_rows = p.kv_len ? max(1, min(p.T, p.kv_len[b])) : p.T;
-  if (qtile * BM >= kv_rows) return;
-  const int row0 = qtile * BM + wave * WR;
-  // the same at wave granularity: a wave whose WR rows are all padding only helps to stage the key tiles (loads, LDS
-  // commits, barriers) and does no MFMA / softmax work; its rows are zero-filled by the merge kernel
-  const bool wave_live = row0 < kv_rows;
+  const int nblk = (kv_rows + WR - 1) / WR, units = p.H * nblk;
+  if (wq * (NTH / 64) >= units) return;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int unit = wq * (NTH / 64) + wv;
+  const bool wave_live = unit < units;
+  const int h = wave_live ? unit / nblk : 0;
+  const int row0 = (wave_live ? unit % nblk : 0) * WR;
 
   const int ntiles = (p.N + TK - 1) / TK;
   const int tps = (ntiles + p.nsplit - 1) / p.nsplit;
@@ -899,7 +896,8 @@ extern "C" long mq_vlfuse_t2i_workspace_bytes(int B, int T, int nsplit) {
 
 // Text side of VLFuse (always through the split workspace + combine, nsplit >= 1).  See include/mqdet_hip.h.
 extern "C" int MQ_SYM(mq_vlfuse_t2i_fwd)(const void* kf, const void* v_ln, const int* kv_len, const unsigned char* key_mask, long key_mask_bs,
-                                 void* workspace, void* out, int B, int N, int T, int heads, int nsplit, float clamp, void* stream) {
+                                 void* workspace, void* out, int B, int N, int T, int heads, int nsplit, int max_kv, float clamp,
+                                 void* stream) {
   if (B <= 0 || T <= 0) return 0;
   if (N < 1 || workspace == nullptr || heads < 1 || heads > VH) return -1;
   if (key_mask && ((key_mask_bs % 4) || key_mask_bs < (long)((N + TK - 1) / TK) * TK)) return -3;
@@ -918,7 +916,9 @@ extern "C" int MQ_SYM(mq_vlfuse_t2i_fwd)(const void* kf, const void* v_ln, const
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  const int groups = B * nsplit, members = heads * ((T + BM - 1) / BM);
+  const int rows = (kv_len && max_kv > 0) ? min(max_kv, T) : T;          // host-known bound of the live text rows
+  const int groups = B * nsplit, members = (heads * ((rows + p.wr - 1) / p.wr) + (128 / p.wr) - 1) / (128 / p.wr);
+  p.members = members;
   const dim3 grid((unsigned)(8 * ((groups + 7) / 8) * members));
   if (vlfuse_qb() == 1) {
     if (key_mask) hipLaunchKernelGGL((vlfuse_t2i_kernel<1, true>), grid, dim3(512), smem, (hipStream_t)stream, p);

@@ -33,7 +33,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from . import pipeline
-from .pipeline import NEG, _add_ln, _lin, _ln, _nsplit
+from .pipeline import NEG, _add_ln, _lin, _ln, _nsplit, _nsplit_t2i
 
 
 # ----------------------------------------------------------------------------- plan
@@ -304,8 +304,9 @@ def fusion_layer(P, b, mem32, text32, geo, txt, max_kv=0):
     bias = (pr[..., 2 * n:2 * n + Hf].float().permute(0, 2, 1) + txt["key_bias"][:, None, :]).contiguous()
     img = ops.vlfuse_i2t(v_ln, kf, vo, bias, P[b + ".ov.bias"], txt["kv_len"], max_kv)
     N = v_ln.shape[1]
-    pooled = ops.vlfuse_t2i(kf, v_ln, _nsplit(B * Hf * (-(-T // 128)), -(-N // 64)), kv_len=txt["kv_len"],
-                            key_mask=geo["key_mask"] if geo["any_pad"] else None)
+    t_live = min(T, max_kv) if (txt["kv_len"] is not None and max_kv > 0) else T
+    pooled = ops.vlfuse_t2i(kf, v_ln, _nsplit_t2i(B, Hf, t_live, -(-N // 64)), kv_len=txt["kv_len"],
+                            key_mask=geo["key_mask"] if geo["any_pad"] else None, max_kv=t_live)
     return img, l32 + _lin(P, b + ".olc", pooled).float()
 
 

@@ -221,6 +221,22 @@ def _nsplit(n_blocks, n_key_tiles, target=None):
     return max(1, min(n_key_tiles // 4, -(-target // n_blocks), 32))
 
 
+def _nsplit_t2i(n_img, heads, t_live, n_key_tiles, cus=256):
+    """Key split of the VLFuse text side.  A group (image, split) is ceil(heads * ceil(t_live / 16) / 8) workgroups, each streaming
+    ceil(tiles / nsplit) key tiles; one workgroup per CU.  Cost model: passes of the chip x (tiles per workgroup + ~6 tile-times of fixed
+    work: Q load, partial write, its share of the merge) -- the split with the fewest tile-times wins (141-token caption, B = 8:
+    72 workgroups per split -> nsplit = 7: 504 workgroups = 2 passes of 50 tiles)."""
+    if n_key_tiles < 8:
+        return 1
+    wgs = n_img * (-(-(heads * (-(-t_live // 16))) // 8))
+    best, best_cost = 1, None
+    for ns in range(1, min(32, n_key_tiles // 4) + 1):
+        cost = (-(-(wgs * ns) // cus)) * (-(-n_key_tiles // ns) + 6)
+        if best_cost is None or cost < best_cost:
+            best, best_cost = ns, cost
+    return best
+
+
 # ----------------------------------------------------------------------------- Swin + FPN
 def swin_forward(P, cfg, img, p="backbone.body", SW=None):
     """swint.py:591-615 (and GroundingDINO's backbone/swin_transformer.py:688-741 with out_indices (1, 2, 3): same blocks,
@@ -551,7 +567,7 @@ def vl_text_side(P, b, v_ln, prep, kv_len=None, max_kv=0):
     Bn, N, _ = v_ln.shape
     T = prep["l_ln"].shape[1]
     t_live = min(T, max_kv) if (kv_len is not None and max_kv > 0) else T             # 128-row tiles of pure padding are skipped
-    out_l = ops.vlfuse_t2i(prep["kf"], v_ln, _nsplit(-(-t_live // 128) * Bn * 8, -(-N // 64)), kv_len=kv_len)
+    out_l = ops.vlfuse_t2i(prep["kf"], v_ln, _nsplit_t2i(Bn, prep["kf"].shape[1], t_live, -(-N // 64)), kv_len=kv_len, max_kv=t_live)
     return prep["l_res"] + _lin(P, b + ".olc", out_l)                  # fp32 when the text stream is fp32
 
 

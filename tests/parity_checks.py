@@ -350,13 +350,16 @@ def check_vlfuse_kernels(dev):
                                  None if kv_len is None else kv_len.to(dev), max_kv=0 if kv is None else max(kv), variant=variant)
             res.append(_stat(f"vlfuse image side [{'pair-split' if variant == 2 else 'first kernel'}] B={B} N={N} T={T} kv_len={kv}", got, ref, tol=2e-3))
     for B, N, T, ns, kv in ((2, 645, 64, 1, None), (1, 22400, 256, 6, None), (3, 1000, 100, 3, None), (2, 130, 160, 2, [160, 90]),
-                            (9, 70, 40, 1, None), (3, 500, 256, 4, [256, 128, 77]))[3 if QUICK else 0:]:
+                            (9, 70, 40, 1, None), (3, 500, 256, 4, [256, 128, 77]), (2, 300, 256, 3, [141, 1]),
+                            (3, 200, 256, 2, [17, 141, 96]))[3 if QUICK else 0:]:
         v_ln = torch.randn(B, N, 256, generator=g).to(H16)
         kf = (torch.randn(B, 8, T, 256, generator=g) / 8).to(H16)
         kv_len = None if kv is None else torch.tensor(kv, dtype=torch.int32)
         ref = emu.vlfuse_t2i(kf.float(), v_ln.float(), ns, kv_len=kv_len)
-        got = ops.vlfuse_t2i(kf.to(dev), v_ln.to(dev), ns, kv_len=None if kv is None else kv_len.to(dev))
-        res.append(_stat(f"vlfuse text side B={B} N={N} T={T} nsplit={ns} kv_len={kv}", got, ref, tol=2e-3))
+        # max_kv sizes the grid (live (head, 16-row block) units packed over the waves); without it the grid covers all T rows
+        for mk in ((0,) if kv is None else (max(kv), 0)):
+            got = ops.vlfuse_t2i(kf.to(dev), v_ln.to(dev), ns, kv_len=None if kv is None else kv_len.to(dev), max_kv=mk)
+            res.append(_stat(f"vlfuse text side B={B} N={N} T={T} nsplit={ns} kv_len={kv} max_kv={mk}", got, ref, tol=2e-3))
     return res
 
 
