@@ -138,7 +138,9 @@ __device__ __forceinline__ void pv_tile(const half_t* tile, const half8 (&pf)[2]
 // NBL = live 16-key blocks of the LAST tile (1..4), chosen by the host from max_kv: a 141-token caption is NT = 3, NBL = 1
 // (144 keys instead of 192).  Compile time on purpose: any run-time branch around the MFMA loops pushes this kernel, which
 // sits at the 256-VGPR limit, into spills.  Batch items with shorter captions are handled by the key mask as before.
-template <int NT, int QB, int NBL>
+// ABL (tools/microbench.py "vlfuse" only; results are garbage): time the kernel WITHOUT one of its parts -- bit 0: no global tile loads,
+// bit 1: no LDS tile commits, bit 2: no softmax arithmetic, bit 3: no fragment reads / MFMAs -- to see which part a step waits for.
+template <int NT, int QB, int NBL, int ABL = 0>
 __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p) {
   constexpr bool LEAN = NT >= 3;
   constexpr int NTH = 2048 / (QB * 4), WR = 16 * QB;        // threads per workgroup (512 / 256), query rows per wave
@@ -194,12 +196,16 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
   constexpr int PER_HEAD = 2 * NT;
   const int U = p.H * PER_HEAD;
   TileRegs<NTH> slot[LEAN ? 1 : 2];
+  if constexpr (ABL != 0) {
+#pragma unroll
+    for (int i = 0; i < 2048 / NTH; ++i) { slot[0].r[i] = zero8(); slot[LEAN ? 0 : 1].r[i] = zero8(); }
+  }
   auto issue = [&](auto SLOT, int u) {
     constexpr int sl = decltype(SLOT)::value;
     u = min(u, U - 1);                                     // the tail re-loads the last tile: one code path, no branches
     const int h = u / PER_HEAD, j = u % PER_HEAD;
     const half_t* src = (j < NT ? p.kf : p.vo) + ((long)b * p.H + h) * p.T * VD;
-    tile_issue(slot[sl], src, (j < NT ? j : j - NT) * TK, p.T - 1, tid);
+    if constexpr (!(ABL & 1)) tile_issue(slot[sl], src, (j < NT ? j : j - NT) * TK, p.T - 1, tid);
   };
   // begin(pos): prefetch;  end(pos): commit the next tile into the other LDS buffer + barrier
   auto begin = [&](auto POS, int u) {
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
   auto end = [&](auto POS) {
     constexpr int par = decltype(POS)::value & 1;
     __builtin_amdgcn_sched_barrier(0);
-    tile_commit(slot[LEAN ? 0 : (par ^ 1)], tiles + (par ^ 1) * TILE, tid);
+    if constexpr (!(ABL & 2)) tile_commit(slot[LEAN ? 0 : (par ^ 1)], tiles + (par ^ 1) * TILE, tid);
     __syncthreads();
   };
   issue(S0{}, 0);
@@ -226,7 +232,13 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
     auto qk_step = [&](auto J) {
       constexpr int j = decltype(J)::value;
       begin(J, u0 + j);
-      qk_tile<LEAN, QB, (j == NT - 1 ? NBL : 4)>(tiles + (j & 1) * TILE, qf, qw, s[j], l15, lg);
+      if constexpr (!(ABL & 8)) qk_tile<LEAN, QB, (j == NT - 1 ? NBL : 4)>(tiles + (j & 1) * TILE, qf, qw, s[j], l15, lg);
+      else {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) s[j][nb][qb] = (float4_){0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) {
         const float4_ kb = *(const float4_*)(bias_s + (h * NT + j) * TK + nb * 16 + 4 * lg);
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
     // ---- softmax over the text keys: a lane owns query column l15 of block qb; its keys are spread over (j, nb, r)
     // in-lane and over the 4 lane groups lg.  s <- exp(s - max) / sum
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
+    for (int qb = 0; qb < ((ABL & 4) ? 0 : QB); ++qb) {
       float mx = MQ_NEG_BIG;
 #pragma unroll
       for (int j = 0; j < NT; ++j)
@@ -297,7 +309,13 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
             pf[st][qb][r] = (half_t)s[j][2 * st][qb][r];
             pf[st][qb][4 + r] = (half_t)s[j][2 * st + 1][qb][r];
           }
-      pv_tile<QB, (j == NT - 1 ? (NBL + 1) / 2 : 2)>(tiles + ((NT + j) & 1) * TILE, pf, o, l15, lg);
+      if constexpr (!(ABL & 8)) pv_tile<QB, (j == NT - 1 ? (NBL + 1) / 2 : 2)>(tiles + ((NT + j) & 1) * TILE, pf, o, l15, lg);
+      else {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[0][qb][r] += (float)pf[0][qb][r] + (float)pf[1][qb][4 + r];
+      }
       end(POS{});
     };
     pv_step(std::integral_constant<int, 0>{});
@@ -337,18 +355,18 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
   }
 }
 
-template <int NT, int QB, int NBL>
+template <int NT, int QB, int NBL, int ABL = 0>
 static int launch_i2t(const I2TParams& p, hipStream_t stream) {
   constexpr size_t smem = (size_t)(2 * TILE + (NT >= 3 ? BM * KS : 0)) * sizeof(half_t) + (size_t)VH * NT * TK * sizeof(float);
   static_assert(4 * 32 * (VD + 8) <= 2 * TILE, "O staging must fit in the tiles");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)vlfuse_i2t_kernel<NT, QB, NBL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)vlfuse_i2t_kernel<NT, QB, NBL, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   const int qtiles = (p.N + BM - 1) / BM;
-  hipLaunchKernelGGL((vlfuse_i2t_kernel<NT, QB, NBL>), dim3((unsigned)(8 * ((p.B + 7) / 8) * qtiles)), dim3(2048 / (QB * 4)), smem, stream, p);
+  hipLaunchKernelGGL((vlfuse_i2t_kernel<NT, QB, NBL, ABL>), dim3((unsigned)(8 * ((p.B + 7) / 8) * qtiles)), dim3(2048 / (QB * 4)), smem, stream, p);
   MQ_CHECK_LAUNCH();
   return 0;
 }
@@ -665,6 +683,19 @@ extern "C" int MQ_SYM(mq_vlfuse_i2t_fwd)(const void* v_ln, const void* kf, const
     }
 #undef MQ_I2T2
   }
+#ifndef MQ_BF16
+  if (variant >= 100 && nt == 3 && nbl == 1) {                             // ablation timings (see vlfuse_i2t_kernel)
+    switch (variant - 100) {
+      case 1: return launch_i2t<3, 1, 1, 1>(p, st);
+      case 3: return launch_i2t<3, 1, 1, 3>(p, st);
+      case 4: return launch_i2t<3, 1, 1, 4>(p, st);
+      case 8: return launch_i2t<3, 1, 1, 8>(p, st);
+      case 11: return launch_i2t<3, 1, 1, 11>(p, st);
+      case 15: return launch_i2t<3, 1, 1, 15>(p, st);
+      default: return -4;
+    }
+  }
+#endif
 #define MQ_I2T(NT_)                                                        \
   switch (nbl) {                                                           \
     case 1: return launch_i2t<NT_, 1, 1>(p, st);                           \

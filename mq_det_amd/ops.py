@@ -74,9 +74,10 @@ KERNEL_DEFAULTS = {
     "NMS_EARLY_STOP": 1,         # 1: mq_ml_nms_topk (the sweep of an image ends once DETECTIONS_PER_IMG boxes are kept)          +0.9 %
     "ATTN_RESIDENT": 1,          # 1: mq_attn_resident_fwd / mq_attn_chunked_fwd (S^T form, keys resident / 256-key chunks)       +4.7 %
     "SWIN_MLP_VARIANT": 2,       # 2: mq_swin_mlp2_fwd (fragment-major weights, 3-deep software pipeline, 14-VALU GELU); 1: mq_swin_mlp_fwd
-    "SWIN_MLP2_FLAGS": -1,       # mq_swin_mlp2_fwd flags: -1 = per width (table GELU at C = 96, erf above; tail split on); else bit 1 = table
+    "SWIN_MLP2_FLAGS": -1,       # mq_swin_mlp2_fwd flags: -1 = per width (table GELU at C = 96 / 384, erf at 192; tail split on); else bit 1 = table
                                  # GELU, bit 0 = no tail split, bit 2 = everything through the tail kernel
-    "VLFUSE_I2T_VARIANT": 2,     # mq_vlfuse_i2t_fwd: 2 = pair-split kernel (round 3), 1 = first kernel
+    "VLFUSE_I2T_VARIANT": -1,    # mq_vlfuse_i2t_fwd: 1 = first kernel, 2 = pair-split kernel (round 3), -1 = pair-split up to 128 text keys
+                                 # (two key tiles: +4.6 % there; with three or four it spills 92 VGPRs and loses 1.5x -- GPU call 5)
     "ALIGN_FUSED": 1,            # 1: mq_align_fused_fwd (heads + alignment + scoring, logits never written); 0: bmm + 5 GEMMs + 5 x mq_align_scores_fwd
 }
 KERNELS = dict(KERNEL_DEFAULTS)
@@ -353,9 +354,13 @@ def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.
     if kv_len is not None:
         assert kv_len.dtype == torch.int32 and kv_len.numel() == B and kv_len.is_contiguous()
     out = torch.empty_like(v_ln)
+    variant = KERNELS["VLFUSE_I2T_VARIANT"] if variant is None else int(variant)
+    if variant < 0:
+        keys = min(int(max_kv), T) if (kv_len is not None and max_kv > 0) else T
+        variant = 2 if keys <= 128 else 1
     with _timed(f"vlfuse_i2t_n{N}_t{T}"):
         _chk(_fn(lib, "mq_vlfuse_i2t_fwd", v_ln)(_ptr(v_ln), _ptr(kf), _ptr(vo), _ptr(bias), _ptr(kv_len), _ptr(out_bias), _ptr(out),
-                                   B, N, T, Hh, int(max_kv), float(clamp), int(KERNELS["VLFUSE_I2T_VARIANT"] if variant is None else variant),
+                                   B, N, T, Hh, int(max_kv), float(clamp), int(variant),
                                    _stream()), "mq_vlfuse_i2t_fwd")
     return out
 
@@ -512,7 +517,7 @@ def swin_mlp2(x, delta, ln_g, ln_b, eps, w1f, b1, w2f, b2, next_ln=None, flags=N
         y = torch.empty(x.shape, dtype=w1f.dtype, device=x.device)
     flags = KERNELS["SWIN_MLP2_FLAGS"] if flags is None else int(flags)
     if flags < 0:
-        flags = 2 if C <= 96 else 0
+        flags = 0 if C == 192 else 2          # table GELU except at C = 192 (profiles/r03_call5_microbench_swin_mlp.json)
     with _timed(f"swin_mlp_c{C}", M * C * (4 + 4 + (2 if delta is not None else 0) + (2 if y is not None else 0))):
         _chk(_fn(lib, "mq_swin_mlp2_fwd", w1f)(_ptr(x), _ptr(delta), _ptr(ln_g), _ptr(ln_b), float(eps), _ptr(w1f), _ptr(b1), _ptr(w2f), _ptr(b2),
                                                _ptr(out), _ptr(ng), _ptr(nb), float(ne), _ptr(y), M, C, flags, _stream()), "mq_swin_mlp2_fwd")

@@ -44,6 +44,7 @@ def main():
         window(dev, g, out)
     if only in ("", "vlfuse"):
         vlfuse(dev, g, out)
+        vlfuse_text(dev, g, out)
     for r in out:
         print(json.dumps(r))
     if len(sys.argv) > 1:
@@ -139,7 +140,8 @@ def vlfuse(dev, g, out):
     for live in (141, 81, 256):
         kv = torch.full((B,), live, dtype=torch.int32, device=dev)
         ref = None
-        for variant in (1, 2):
+        # 101 ... 115: the first kernel WITHOUT global tile loads (bit 0) / LDS commits (1) / softmax (2) / fragment reads + MFMAs (3)
+        for variant in (1, 2) + ((101, 103, 104, 108, 111, 115) if live == 141 else ()):
             fn = lambda variant=variant: ops.vlfuse_i2t(v, kf, vo, bias, ob, kv_len=kv, max_kv=live, variant=variant)  # noqa: E731
             ms = timeit(fn)
             o = fn().float()
@@ -147,9 +149,27 @@ def vlfuse(dev, g, out):
             visited = -(-live // 16) * 16
             fl = 4.0 * B * 8 * N * visited * 256
             nb = v.numel() * 2 * 2 + kf.numel() * 2 * 2
-            out.append({"kernel": f"vlfuse_i2t {'first kernel' if variant == 1 else 'pair-split'} B={B} N={N} live keys={live}", "ms": round(ms, 4),
+            name = {1: "first kernel", 2: "pair-split"}.get(variant, f"first kernel, ablation bits {variant - 100:04b} (loads|commits|softmax|mfma removed)")
+            out.append({"kernel": f"vlfuse_i2t {name} B={B} N={N} live keys={live}", "ms": round(ms, 4),
                         "TFLOPs": round(fl / ms / 1e9, 1), "frac_of_mfma_peak": round(fl / ms / 1e9 / 2500, 3),
                         "algorithmic_GBs": round(nb / ms / 1e6, 1), "max_abs_diff_vs_first": round(float((o - ref).abs().max()), 6)})
+
+
+def vlfuse_text(dev, g, out):
+    # ---- VLFuse text side at the bench shape: live (head, row block) units packed (max_kv given) vs one grid row per 16 text rows of T
+    from mq_det_amd.modeling.pipeline import _nsplit, _nsplit_t2i
+    B, N, T = 8, 22400, 256
+    v = torch.randn(B, N, 256, generator=g).half().to(dev)
+    kf = (torch.randn(B, 8, T, 256, generator=g) / 8).half().to(dev)
+    for live in (141, 81, 256):
+        kv = torch.full((B,), live, dtype=torch.int32, device=dev)
+        tiles = -(-N // 64)
+        for name, ns, mk in (("packed, nsplit by passes x tiles", _nsplit_t2i(B, 8, live, tiles), live), ("packed, nsplit 6", 6, live),
+                             ("grid sized for all T rows (dead workgroups exit early), nsplit 6", 6, 0)):
+            ms = timeit(lambda: ops.vlfuse_t2i(kf, v, ns, kv_len=kv, max_kv=mk))
+            fl = 4.0 * B * 8 * (-(-live // 16) * 16) * N * 256
+            out.append({"kernel": f"vlfuse_t2i + combine, {name} (nsplit={ns}) B={B} N={N} live rows={live}", "ms": round(ms, 4),
+                        "TFLOPs": round(fl / ms / 1e9, 1), "frac_of_mfma_peak": round(fl / ms / 1e9 / 2500, 3)})
 
 
 def window(dev, g, out):
