@@ -249,6 +249,12 @@ int mq_dyconv_fuse(const void* y0, const float* coef0, int hs0, int ws0, const v
 int mq_dyrelu_coef(const float* pool, const void* w0, const void* b0, const void* w2, const void* b2, float* coef,
                    int B, int n, int C, void* stream);
 int mq_dyrelu_apply(void* x, const float* coef, int B, int n, int C, long x_bs, void* stream);
+/* y = LayerNorm(DYReLU(x)) on the head's pyramid token buffer: the DYReLU of a DyConv layer (vldyhead.py:160-188, 245) applied by the
+ * ONLY reader of that layer's output, layer_norm_v of the next fusion layer (fuse_helper.py:398).  x, y [B,N,256] 16-bit (x: batch
+ * stride x_bs elements), coef [NL][B][4][256] fp32 = mq_dyrelu_coef's output per pyramid level, row_first: NL + 1 HOST ints (level l =
+ * rows [row_first[l], row_first[l+1]) of every image; NL <= 8).  DYReLU's result is consumed in fp32. */
+int mq_dyrelu_ln_fwd(const void* x, long x_bs, const float* coef, const int* row_first, int NL, const void* gamma, const void* beta,
+                     float eps, void* y, int B, int N, int C, void* stream);
 
 /* Region-word alignment scores for the L labels of the caption.
  *   dot [B,HW,T] fp16 (fp32 when dot_f32 != 0; batch stride dot_bs elements, <= 0: HW*T), tbias [B,T] fp32,
@@ -368,6 +374,7 @@ MQ_BF16_TWIN(mq_dyconv_coef_group)
 MQ_BF16_TWIN(mq_dyconv_fuse)
 MQ_BF16_TWIN(mq_dyrelu_coef)
 MQ_BF16_TWIN(mq_dyrelu_apply)
+MQ_BF16_TWIN(mq_dyrelu_ln_fwd)
 MQ_BF16_TWIN(mq_align_scores_fwd)
 MQ_BF16_TWIN(mq_align_fused_fwd)
 MQ_BF16_TWIN(mq_box_decode)

@@ -298,4 +298,92 @@ extern "C" int MQ_SYM(mq_patch_merge_ln_fwd)(const void* x, int x_f32, const voi
   return 0;
 }
 
+// ---- mq_dyrelu_ln_fwd: y = LayerNorm(DYReLU(x)) on the pyramid token buffer of the head.
+// The only reader of a DyConv layer's output is layer_norm_v of the NEXT fusion layer (fuse_helper.py:398: both VLFuse directions and
+// the residual take the NORMED v), so DYReLU -- max(a1 x + b1, a2 x + b2) with per-(image, LEVEL, channel) coefficients
+// (vldyhead.py:160-188, 245) -- need not be a pass of its own: 25 of the 30 mq_dyrelu_apply launches of a forward and their
+// read + write of the buffer go.  The DYReLU result is consumed in fp32 (the stand-alone kernel rounds it to 16 bits first).
+// x, y [B, N, 256] 16-bit; coef [NL][B][4][256] fp32 (a1, b1, a2, b2 -- mq_dyrelu_coef's layout per level); level l = rows
+// [row_first[l], row_first[l + 1]) of every image.  A workgroup = 32 rows of ONE level (its coefficients live in registers): 8 row
+// groups of 32 lanes x 8 channels, 4 rows per group, all loads in flight before the first is consumed.
+struct DyreluLnParams {
+  const half_t* x; const float* coef; const half_t* gamma; const half_t* beta; half_t* y;
+  long x_bs;
+  int B, N, NL;
+  int row_first[9], blk_first[9];
+  float eps;
+};
+
+__global__ __launch_bounds__(256) void dyrelu_ln_kernel(DyreluLnParams p) {
+  constexpr int C = 256, RPB = 32;
+  const int b = blockIdx.y;
+  int l = 0;
+  while (l + 1 < p.NL && (int)blockIdx.x >= p.blk_first[l + 1]) ++l;
+  const int sub = threadIdx.x & 31, grp = threadIdx.x >> 5, c0 = sub * 8;
+  const int row_end = p.row_first[l + 1];
+  const int row0 = p.row_first[l] + ((int)blockIdx.x - p.blk_first[l]) * RPB + grp;
+  const half_t* xb = p.x + (long)b * p.x_bs;
+  half8 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = *(const half8*)(xb + (long)min(row0 + 8 * k, row_end - 1) * C + c0);
+  const float* cf = p.coef + ((long)l * p.B + b) * 4 * C + c0;
+  float a1[8], b1[8], a2[8], b2[8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float4_ t0 = *(const float4_*)(cf + 4 * h), t1 = *(const float4_*)(cf + C + 4 * h);
+    const float4_ t2 = *(const float4_*)(cf + 2 * C + 4 * h), t3 = *(const float4_*)(cf + 3 * C + 4 * h);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a1[4 * h + j] = t0[j]; b1[4 * h + j] = t1[j]; a2[4 * h + j] = t2[j]; b2[4 * h + j] = t3[j]; }
+  }
+  const half8 g = *(const half8*)(p.gamma + c0), bt = *(const half8*)(p.beta + c0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float f[8], s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = (float)v[k][j];
+      f[j] = fmaxf(x * a1[j] + b1[j], x * a2[j] + b2[j]);
+      s += f[j];
+    }
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) s += __shfl_xor(s, m);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = f[j] - mean; q += d * d; }
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) q += __shfl_xor(q, m);
+    const float rstd = rsqrtf(q / (float)C + p.eps);
+    const int row = row0 + 8 * k;
+    if (row < row_end) {
+      half8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (half_t)((f[j] - mean) * rstd * (float)g[j] + (float)bt[j]);
+      *(half8*)(p.y + ((long)b * p.N + row) * C + c0) = o;
+    }
+  }
+}
+
+// row_first: NL + 1 host ints (row_first[0] = 0, row_first[NL] = N).  C must be 256, NL <= 8.
+extern "C" int MQ_SYM(mq_dyrelu_ln_fwd)(const void* x, long x_bs, const float* coef, const int* row_first, int NL, const void* gamma,
+                                        const void* beta, float eps, void* y, int B, int N, int C, void* stream) {
+  if (B <= 0 || N <= 0) return 0;
+  if (C != 256 || NL < 1 || NL > 8 || row_first[0] != 0 || row_first[NL] != N) return -1;
+  DyreluLnParams p;
+  p.x = (const half_t*)x; p.coef = coef; p.gamma = (const half_t*)gamma; p.beta = (const half_t*)beta; p.y = (half_t*)y;
+  p.x_bs = x_bs; p.B = B; p.N = N; p.NL = NL; p.eps = eps;
+  int blk = 0;
+  for (int l = 0; l <= NL; ++l) {
+    p.row_first[l] = row_first[l];
+    p.blk_first[l] = blk;
+    if (l < NL) {
+      if (row_first[l + 1] <= row_first[l]) return -1;
+      blk += (row_first[l + 1] - row_first[l] + 31) / 32;
+    }
+  }
+  hipLaunchKernelGGL(dyrelu_ln_kernel, dim3((unsigned)blk, (unsigned)B), dim3(256), 0, (hipStream_t)stream, p);
+  MQ_CHECK_LAUNCH();
+  return 0;
+}
+
 MQ_NAMESPACE_END

@@ -67,19 +67,21 @@ struct I2TParams {
 // half as many MFMAs, which the LDS still sustains).
 template <int NTH> struct TileRegs { half8 r[2048 / NTH]; };
 
-template <int NTH>
+// NCH: chunk rounds to do -- round i covers tile rows [i * NTH / 32, (i + 1) * NTH / 32): a tile whose tail rows nobody reads
+// (the last key / value tile of a caption that ends inside it) is staged only as far as it is read
+template <int NTH, int NCH = 2048 / NTH>
 __device__ __forceinline__ void tile_issue(TileRegs<NTH>& t, const half_t* src, int row0, int last_row, int tid) {
 #pragma unroll
-  for (int i = 0; i < 2048 / NTH; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const int c = tid + i * NTH;
     const int row = min(row0 + (c >> 5), last_row);
     t.r[i] = *(const half8*)(src + (long)row * VD + (c & 31) * 8);
   }
 }
-template <int NTH>
+template <int NTH, int NCH = 2048 / NTH>
 __device__ __forceinline__ void tile_commit(const TileRegs<NTH>& t, half_t* dst, int tid) {
 #pragma unroll
-  for (int i = 0; i < 2048 / NTH; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const int c = tid + i * NTH;
     *(half8*)(dst + (c >> 5) * KS + (c & 31) * 8) = t.r[i];
   }
@@ -200,28 +202,36 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
 #pragma unroll
     for (int i = 0; i < 2048 / NTH; ++i) { slot[0].r[i] = zero8(); slot[LEAN ? 0 : 1].r[i] = zero8(); }
   }
-  auto issue = [&](auto SLOT, int u) {
-    constexpr int sl = decltype(SLOT)::value;
+  // chunk rounds of the tile at stream position np (0 .. 2 NT - 1; K tiles first): the last K tile is read up to its NBL live 16-key
+  // blocks, the last V tile up to the 32-key steps that hold one (rows beyond stay whatever the buffer held before: never read)
+  auto rounds_of = [](int np) constexpr {                  // np < 0: a whole tile (pipeline fill)
+    if (np < 0) return 2048 / NTH;
+    np %= 2 * NT;
+    const int j = np % NT, rows = j != NT - 1 ? 64 : (np < NT ? 16 * NBL : 32 * ((NBL + 1) / 2));
+    return (rows * 32 + NTH - 1) / NTH;
+  };
+  auto issue = [&](auto SLOT, auto NP, int u) {
+    constexpr int sl = decltype(SLOT)::value, np = decltype(NP)::value;
     u = min(u, U - 1);                                     // the tail re-loads the last tile: one code path, no branches
     const int h = u / PER_HEAD, j = u % PER_HEAD;
     const half_t* src = (j < NT ? p.kf : p.vo) + ((long)b * p.H + h) * p.T * VD;
-    if constexpr (!(ABL & 1)) tile_issue(slot[sl], src, (j < NT ? j : j - NT) * TK, p.T - 1, tid);
+    if constexpr (!(ABL & 1)) tile_issue<NTH, rounds_of(np)>(slot[sl], src, (j < NT ? j : j - NT) * TK, p.T - 1, tid);
   };
   // begin(pos): prefetch;  end(pos): commit the next tile into the other LDS buffer + barrier
   auto begin = [&](auto POS, int u) {
-    constexpr int par = decltype(POS)::value & 1;
-    if constexpr (LEAN) issue(S0{}, u + 1);
-    else issue(std::integral_constant<int, par>{}, u + 2);  // the slot of tile u was committed one step ago
+    constexpr int pos = decltype(POS)::value, par = pos & 1;
+    if constexpr (LEAN) issue(S0{}, std::integral_constant<int, pos + 1>{}, u + 1);
+    else issue(std::integral_constant<int, par>{}, std::integral_constant<int, pos + 2>{}, u + 2);  // the slot of tile u was committed one step ago
     __builtin_amdgcn_sched_barrier(0);                     // keep the prefetch ahead of everything that waits on VMEM
   };
   auto end = [&](auto POS) {
-    constexpr int par = decltype(POS)::value & 1;
+    constexpr int pos = decltype(POS)::value, par = pos & 1;
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!(ABL & 2)) tile_commit(slot[LEAN ? 0 : (par ^ 1)], tiles + (par ^ 1) * TILE, tid);
+    if constexpr (!(ABL & 2)) tile_commit<NTH, rounds_of((pos + 1) % PER_HEAD)>(slot[LEAN ? 0 : (par ^ 1)], tiles + (par ^ 1) * TILE, tid);
     __syncthreads();
   };
-  issue(S0{}, 0);
-  if constexpr (!LEAN) issue(S1{}, 1);
+  issue(S0{}, std::integral_constant<int, -1>{}, 0);       // the fill stages whole tiles
+  if constexpr (!LEAN) issue(S1{}, std::integral_constant<int, -1>{}, 1);
   tile_commit(slot[0], tiles, tid);
   __syncthreads();
 

@@ -612,14 +612,15 @@ def _upsample_pool_weights(hs, ws, H, W, device):
     return _UP_W[key]
 
 
-def dyconv_tokens(P, cfg, b, tok, sizes):
+def dyconv_tokens(P, cfg, b, tok, sizes, defer_relu=False):
     """DyConv.forward (vldyhead.py:205-247) on the pyramid token buffer tok [B, N, 256] -> new buffer of the same shape.
       1. per level: 27-channel offset / mask conv (LDS-window kernel)                       -- five streams
       2. ALL DCNv2 branches of the layer (3 per level, 13 in total) in ONE grouped launch (dcn_fused.hip): gather + bilinear
          blend + MFMA + GroupNorm statistics; offsets of the CURRENT level are re-used for the level's three branches exactly
          like the reference (flat-index quirk handled inside the gather)
       3. per level: the fused HIP epilogue (GroupNorm affine, bilinear up-sampling of the level+1 branch, scale attention,
-         branch mean, DYReLU) written straight into the level's slice of the output buffer     -- five streams"""
+         branch mean, DYReLU) written straight into the level's slice of the output buffer     -- five streams
+    defer_relu: return (buffer BEFORE DYReLU, coef [NL, B, 4, C]) -- the caller's next LayerNorm applies it (ops.dyrelu_layer_norm)."""
     G = cfg.MODEL.GROUP_NORM
     nl = len(sizes)
     Bn, N, C = tok.shape
@@ -676,15 +677,20 @@ def dyconv_tokens(P, cfg, b, tok, sizes):
         [{"sums": sums, "n": Ho * Wo, "gamma": P[f"{b}.DyConv.{k}.bn.weight"], "beta": P[f"{b}.DyConv.{k}.bn.bias"], "nbranches": nb}
          for (lvl, k, nb), (y, (Ho, Wo), sums) in zip(owner, ys)], P[b + ".attn_w"], P[b + ".attn_b"], G.NUM_GROUPS, G.EPSILON)
 
+    relu_coef = torch.empty(nl, Bn, 4, C, dtype=torch.float32, device=tok.device) if defer_relu else None
+
     def epilogue(lvl):
         H, W = sizes[lvl]
         fused = [(y, coef, Ho, Wo) for (l2, k, nb), (y, (Ho, Wo), sums), coef in zip(owner, ys, coefs) if l2 == lvl]
         o = out[:, offs[lvl]:offs[lvl + 1]]
         _, pool = ops.dyconv_fuse(fused, H, W, out=o)
-        ops.dyrelu_(o, pool, P[b + ".relu.fc.0.weight"], P[b + ".relu.fc.0.bias"], P[b + ".relu.fc.2.weight"],
-                    P[b + ".relu.fc.2.bias"])
+        rw = (P[b + ".relu.fc.0.weight"], P[b + ".relu.fc.0.bias"], P[b + ".relu.fc.2.weight"], P[b + ".relu.fc.2.bias"])
+        if defer_relu:
+            ops.dyrelu_coef(pool, H * W, *rw, out=relu_coef[lvl])
+        else:
+            ops.dyrelu_(o, pool, *rw)
     fan_out(epilogue)
-    return out
+    return (out, relu_coef) if defer_relu else out
 
 
 def dyconv(P, cfg, b, feats):
@@ -729,18 +735,42 @@ def vldyhead(P, cfg, feats, lang, trace=None):
         hnew = vl_text_side(P, b, v_ln, prep, kv_len, max_kv)
         return (hnew.to(tok.dtype), hnew) if h32 is not None else (hnew, None)
 
+    # DYReLU of layers 0 .. L-2: applied by the next layer's layer_norm_v, the only reader of those buffers (the parity ladder wants
+    # every layer's output: a trace run applies it to a COPY for the record and still takes the deferred path itself)
+    defer = ops.KERNELS["DYRELU_IN_LN"] == 1 and tok.shape[-1] == 256 and len(sizes) <= 8
+    relu_coef = None
+
+    def relu_applied_copy():
+        if relu_coef is None:
+            return tok
+        cp, off = tok.clone(), 0
+        for l, (hh, ww) in enumerate(sizes):
+            ops.dyrelu_apply_(cp[:, off:off + hh * ww], relu_coef[l])
+            off += hh * ww
+        return cp
+
+    def norm_v(b):
+        if relu_coef is not None:
+            return ops.dyrelu_layer_norm(tok, relu_coef, sizes, P[b + ".layer_norm_v.weight"], P[b + ".layer_norm_v.bias"], 1e-5)
+        return ops.layer_norm(tok, P[b + ".layer_norm_v.weight"], P[b + ".layer_norm_v.bias"], 1e-5)
+
+    def dyconv_layer(i):
+        if defer and i + 1 < L:
+            return dyconv_tokens(P, cfg, f"{t}.{3 * i + 2}", tok, sizes, defer_relu=True)
+        return dyconv_tokens(P, cfg, f"{t}.{3 * i + 2}", tok, sizes), None
+
     if not two_streams:
         for i in range(L):
             b = f"{t}.{3 * i}.b_attn"
-            v_ln = ops.layer_norm(tok, P[b + ".layer_norm_v.weight"], P[b + ".layer_norm_v.bias"], 1e-5)
+            v_ln = norm_v(b)
             prep = vl_text_prep(P, b, hidden, key_bias, h32)
             tok = vl_image_side(P, b, v_ln, prep, kv_len, max_kv)
             hidden, h32 = text_side(b, v_ln, prep)
             rec = {"fuse_tok": tok, "fuse_hidden": hidden if h32 is None else h32}
             hidden, h32 = _bert(P, f"{t}.{3 * i + 1}", hidden, h32, key_bias, True, kv_len)
-            tok = dyconv_tokens(P, cfg, f"{t}.{3 * i + 2}", tok, sizes)
+            tok, relu_coef = dyconv_layer(i)
             if trace is not None:
-                rec.update(bert_hidden=hidden if h32 is None else h32, dyconv_tok=tok)
+                rec.update(bert_hidden=hidden if h32 is None else h32, dyconv_tok=relu_applied_copy())
                 trace.append(rec)
     else:
         main, text = torch.cuda.current_stream(), _side_streams(tok.device, 1, "text")[0]
@@ -750,7 +780,7 @@ def vldyhead(P, cfg, feats, lang, trace=None):
         keep = []                                             # main-stream tensors the text stream still reads
         for i in range(L):
             b = f"{t}.{3 * i}.b_attn"
-            v_ln = ops.layer_norm(tok, P[b + ".layer_norm_v.weight"], P[b + ".layer_norm_v.bias"], 1e-5)
+            v_ln = norm_v(b)
             main.wait_stream(text)                            # operands of this layer ready; previous text chain done
             keep.clear()                                      # ... so last layer's LN(v) may be recycled now
             keep.append(v_ln)
@@ -762,7 +792,7 @@ def vldyhead(P, cfg, feats, lang, trace=None):
                 if i + 1 < L:
                     prep = vl_text_prep(P, f"{t}.{3 * (i + 1)}.b_attn", hidden, key_bias, h32)
             tok = vl_image_side(P, b, v_ln, cur, kv_len, max_kv)
-            tok = dyconv_tokens(P, cfg, f"{t}.{3 * i + 2}", tok, sizes)
+            tok, relu_coef = dyconv_layer(i)
         main.wait_stream(text)
         keep.clear()
     emb = F.normalize((hidden if h32 is None else h32).float(), p=2, dim=-1)

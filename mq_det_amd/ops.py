@@ -41,6 +41,7 @@ _SIGNATURES = {
     "mq_dyconv_coef_group": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _vp]),
     "mq_dyconv_fuse": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _l, _vp, _i, _i, _i, _i, _vp]),
     "mq_dyrelu_coef": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mq_dyrelu_ln_fwd": (_i, [_vp, _l, _vp, _vp, _i, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "mq_dyrelu_apply": (_i, [_vp, _vp, _i, _i, _i, _l, _vp]),
     "mq_align_scores_fwd": (_i, [_vp, _i, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _l, _i, _vp]),
     "mq_align_fused_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
@@ -55,7 +56,7 @@ _SIGNATURES = {
 # entry points with 16-bit operands also exist as <name>_bf16 (same signature; include/mqdet_hip.h MQ_BF16_TWIN)
 BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
               "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_patch_merge_ln_fwd", "mq_swin_mlp_fwd", "mq_swin_mlp2_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
-              "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyrelu_apply",
+              "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyrelu_apply", "mq_dyrelu_ln_fwd",
               "mq_align_scores_fwd", "mq_align_fused_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
 for _n in BF16_TWINS:
     _SIGNATURES[_n + "_bf16"] = _SIGNATURES[_n]
@@ -76,6 +77,7 @@ KERNEL_DEFAULTS = {
     "SWIN_MLP_VARIANT": 2,       # 2: mq_swin_mlp2_fwd (fragment-major weights, 3-deep software pipeline, 14-VALU GELU); 1: mq_swin_mlp_fwd
     "SWIN_MLP2_FLAGS": -1,       # mq_swin_mlp2_fwd flags: -1 = per width (table GELU at C = 96 / 384, erf at 192; tail split on); else bit 1 = table
                                  # GELU, bit 0 = no tail split, bit 2 = everything through the tail kernel
+    "DYRELU_IN_LN": 1,           # 1: the DYReLU of fusion layers 0 .. L-2 is applied by the next layer's LayerNorm (mq_dyrelu_ln_fwd); 0: own pass
     "VLFUSE_I2T_VARIANT": -1,    # mq_vlfuse_i2t_fwd: 1 = first kernel, 2 = pair-split kernel (round 3), -1 = pair-split up to 128 text keys
                                  # (two key tiles: +4.6 % there; with three or four it spills 92 VGPRs and loses 1.5x -- GPU call 5)
     "ALIGN_FUSED": 1,            # 1: mq_align_fused_fwd (heads + alignment + scoring, logits never written); 0: bmm + 5 GEMMs + 5 x mq_align_scores_fwd
@@ -705,6 +707,49 @@ def dyrelu_(x, pool, w0, b0, w2, b2):
     with _timed("dyrelu_apply", 2 * B * n * C * 2):
         _chk(_fn(lib, "mq_dyrelu_apply", x)(_ptr(x), _ptr(coef), B, n, C, x.stride(0), _stream()), "mq_dyrelu_apply")
     return x
+
+
+def dyrelu_coef(pool, n, w0, b0, w2, b2, out=None):
+    """DYReLU coefficients (mq_dyrelu_coef): pool [B, ceil(n / 128), C] fp32 = per-block sums over the n positions of a level
+    (dyconv_fuse's second result) -> [B,4,C] fp32 (a1, b1, a2, b2)."""
+    lib = load_library()
+    _need_gpu(pool, w0, b0, w2, b2)
+    B, C = pool.shape[0], pool.shape[-1]
+    assert pool.is_contiguous() and pool.dtype == torch.float32 and pool.numel() == B * ((int(n) + 127) // 128) * C
+    coef = torch.empty(B, 4, C, dtype=torch.float32, device=pool.device) if out is None else out
+    assert coef.shape == (B, 4, C) and coef.is_contiguous() and coef.dtype == torch.float32 and w0.is_contiguous() and w2.is_contiguous()
+    _chk(_fn(lib, "mq_dyrelu_coef", w0)(_ptr(pool), _ptr(w0), _ptr(b0), _ptr(w2), _ptr(b2), _ptr(coef), B, int(n), C, _stream()), "mq_dyrelu_coef")
+    return coef
+
+
+def dyrelu_apply_(x, coef):
+    """In-place DYReLU on x [B,n,C] 16-bit (contiguous rows, any batch stride) with given coefficients [B,4,C] (mq_dyrelu_apply)."""
+    lib = load_library()
+    _need_gpu(x, coef)
+    B, n, C = x.shape
+    assert x.stride(2) == 1 and x.stride(1) == C and x.dtype in _H16 and coef.shape == (B, 4, C) and coef.is_contiguous()
+    _chk(_fn(lib, "mq_dyrelu_apply", x)(_ptr(x), _ptr(coef), B, n, C, x.stride(0), _stream()), "mq_dyrelu_apply")
+    return x
+
+
+def dyrelu_layer_norm(x, coef, sizes, gamma, beta, eps):
+    """LayerNorm(DYReLU(x)) (mq_dyrelu_ln_fwd): x [B,N,256] 16-bit (rows contiguous), coef [NL,B,4,256] fp32 (dyrelu_coef per level),
+    sizes = [(H, W)] of the NL levels whose tokens are concatenated along N -> [B,N,256] 16-bit."""
+    lib = load_library()
+    _need_gpu(x, coef, gamma, beta)
+    B, N, C = x.shape
+    NL = len(sizes)
+    offs = [0]
+    for (h, w) in sizes:
+        offs.append(offs[-1] + int(h) * int(w))
+    assert C == 256 and offs[-1] == N and x.stride(2) == 1 and x.stride(1) == C and x.dtype in _H16 and gamma.dtype == x.dtype
+    assert coef.shape == (NL, B, 4, C) and coef.is_contiguous() and coef.dtype == torch.float32
+    y = torch.empty(B, N, C, dtype=x.dtype, device=x.device)
+    rf = (ctypes.c_int * (NL + 1))(*offs)
+    with _timed("layernorm_c256_dyrelu", 2 * x.numel() * 2):
+        _chk(_fn(lib, "mq_dyrelu_ln_fwd", x)(_ptr(x), x.stride(0), _ptr(coef), ctypes.cast(rf, _vp), NL, _ptr(gamma), _ptr(beta), float(eps),
+                                             _ptr(y), B, N, C, _stream()), "mq_dyrelu_ln_fwd")
+    return y
 
 
 SCORE_AGG = {"MEAN": 0, "MAX": 1, "POWER": 2, "ONEHOT": 0}      # ONEHOT: MEAN over the one-token index of token_index_onehot

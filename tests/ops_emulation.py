@@ -256,14 +256,43 @@ def dyconv_fuse(branches, H, W, out=None):
     return res, res.float().sum(1, keepdim=True)          # [B, nblk=1, C]
 
 
-def dyrelu_(x, pool, w0, b0, w2, b2):
-    B, n, C = x.shape
+def dyrelu_coef(pool, n, w0, b0, w2, b2, out=None):
+    """[B, 4, C] = (a1, b1, a2, b2) of  max(a1 x + b1, a2 x + b2)  (vldyhead.py:160-188: h_sigmoid of the two FCs, lambda_a = 2, init (1, 0))"""
+    C = pool.shape[-1]
     y = pool.sum(1) / n
     y = F.relu6(F.linear(F.relu(F.linear(y, w0.float(), b0.float())), w2.float(), b2.float()) + 3) / 6
     a1, b1, a2, b2_ = torch.split(y, C, 1)
+    coef = torch.stack([(a1 - 0.5) * 2 + 1, b1 - 0.5, (a2 - 0.5) * 2, b2_ - 0.5], 1)
+    if out is not None:
+        out.copy_(coef)
+        return out
+    return coef
+
+
+def dyrelu_(x, pool, w0, b0, w2, b2):
+    B, n, C = x.shape
+    cf = dyrelu_coef(pool, n, w0, b0, w2, b2)
     xf = x.float()
-    x.copy_(torch.max(xf * ((a1 - 0.5) * 2 + 1)[:, None] + (b1 - 0.5)[:, None], xf * ((a2 - 0.5) * 2)[:, None] + (b2_ - 0.5)[:, None]).to(x.dtype))
+    x.copy_(torch.max(xf * cf[:, 0, None] + cf[:, 1, None], xf * cf[:, 2, None] + cf[:, 3, None]).to(x.dtype))
     return x
+
+
+def dyrelu_apply_(x, coef):
+    xf = x.float()
+    x.copy_(torch.max(xf * coef[:, 0, None] + coef[:, 1, None], xf * coef[:, 2, None] + coef[:, 3, None]).to(x.dtype))
+    return x
+
+
+def dyrelu_layer_norm(x, coef, sizes, gamma, beta, eps):
+    """Plain-torch statement of mq_dyrelu_ln_fwd: per pyramid level DYReLU (consumed in fp32), then LayerNorm over the 256 channels."""
+    out, off = torch.empty_like(x), 0
+    for l, (h, w) in enumerate(sizes):
+        xf = x[:, off:off + h * w].float()
+        cf = coef[l]
+        f = torch.max(xf * cf[:, 0, None] + cf[:, 1, None], xf * cf[:, 2, None] + cf[:, 3, None])
+        out[:, off:off + h * w] = F.layer_norm(f, (x.shape[-1],), gamma.float(), beta.float(), eps).to(x.dtype)
+        off += h * w
+    return out
 
 
 def conv3x3(x_nhwc, w_packed, bias, n_out, stride=1):
@@ -466,7 +495,7 @@ def dyconv_coef_group(items, attn_w, attn_b, groups, eps):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # every emulated entry point, in one place: tests patch them into mq_det_amd.ops (or into a stand-in namespace) with these helpers
 NAMES = ("attention", "attention4", "window_attention", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores", "align_fused",
-         "dyconv_branch_coef", "dyconv_coef_group", "dyconv_fuse", "dyrelu_", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "vlfuse_i2t",
+         "dyconv_branch_coef", "dyconv_coef_group", "dyconv_fuse", "dyrelu_", "dyrelu_coef", "dyrelu_apply_", "dyrelu_layer_norm", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "vlfuse_i2t",
          "vlfuse_t2i", "box_decode", "ml_nms", "roi_align", "swin_mlp", "swin_mlp2", "patch_merge_ln", "ms_deform_attn", "ms_deform_attn_q", "image_key_mask")
 
 

@@ -720,7 +720,19 @@ def check_dyconv(dev):
         ref = oh.dyconv(sd, b, [f.float() for f in feats], spec)
         x = [f.to(dev).contiguous(memory_format=torch.channels_last) for f in feats]
         got = pipeline.dyconv(P, cfg, b, x)
-    return [_stat(f"dyconv (grouped fused DCNv2) lvl{i}", got[i], ref[i], tol=1e-2) for i in range(5)]
+        res = [_stat(f"dyconv (grouped fused DCNv2) lvl{i}", got[i], ref[i], tol=1e-2) for i in range(5)]
+        # the same layer with its DYReLU left to the next layer's LayerNorm (mq_dyrelu_ln_fwd): LN(dyconv(x)) of the oracle
+        from mq_det_amd import ops
+        tok, szs = pipeline._to_tokens(x)
+        pre, coef = pipeline.dyconv_tokens(P, cfg, b, tok.contiguous(), szs, defer_relu=True)
+        gw, gb = P["rpn.head.dyhead_tower.3.b_attn.layer_norm_v.weight"], P["rpn.head.dyhead_tower.3.b_attn.layer_norm_v.bias"]
+        got_ln = ops.dyrelu_layer_norm(pre, coef, szs, gw, gb, 1e-5)
+        ref_tok = torch.cat([r.flatten(2).transpose(1, 2) for r in ref], 1)
+        ref_ln = F.layer_norm(ref_tok, (256,), gw.float().cpu(), gb.float().cpu(), 1e-5)
+        res.append(_stat("dyconv with DYReLU applied by the next LayerNorm: LN(dyconv(x)), all levels", got_ln, ref_ln, tol=1.5e-2))
+        unf = ops.layer_norm(torch.cat([g_.flatten(2).transpose(1, 2) for g_ in got], 1).contiguous(), gw, gb, 1e-5)
+        res.append(_stat("... vs the stand-alone DYReLU pass + LayerNorm of the product", got_ln, unf.float().cpu(), tol=1e-2))
+    return res
 
 
 def check_nms(dev):

@@ -517,12 +517,13 @@ def test_opt_in_kernel(dev, body):
 def _body_alternate_kernel_selection(dev, monkeypatch):
     """Every operator that has two implementations, on the one that is NOT the default (ops.KERNEL_DEFAULTS): the streaming attention
     kernel, LayerNorm v1, the guarded-load offset conv, pad + cat patch merging, per-conv FPN launches, the full NMS sweep, the first
-    Swin MLP kernel, and bmm + mq_align_scores_fwd instead of mq_align_fused_fwd -- the tiny full model end to end against the oracle."""
+    Swin MLP kernel, bmm + mq_align_scores_fwd instead of mq_align_fused_fwd, DYReLU as a pass of its own, the first VLFuse image-side
+    kernel for every caption length -- the tiny full model end to end against the oracle."""
     import parity_checks as pc
     from mq_det_amd import ops
-    for k in ("ATTN_RESIDENT", "PATCH_MERGE_FUSED", "FPN_VIA_DCN", "NMS_EARLY_STOP", "ALIGN_FUSED"):
+    for k in ("ATTN_RESIDENT", "PATCH_MERGE_FUSED", "FPN_VIA_DCN", "NMS_EARLY_STOP", "ALIGN_FUSED", "DYRELU_IN_LN"):
         monkeypatch.setenv("MQ_" + k, "0")
-    for k in ("LN_VARIANT", "OFFSET_CONV_VARIANT", "SWIN_MLP_VARIANT"):
+    for k in ("LN_VARIANT", "OFFSET_CONV_VARIANT", "SWIN_MLP_VARIANT", "VLFUSE_I2T_VARIANT"):
         monkeypatch.setenv("MQ_" + k, "1")
     assert ops.KERNELS["ALIGN_FUSED"] == 0 and ops.KERNELS["SWIN_MLP_VARIANT"] == 1
     _assert(pc.check_full_model(dev))
