@@ -204,6 +204,10 @@ int mq_conv3x3_nchw32_fwd(const void* x, const void* w, const void* bias, float*
  * budget was spent, checked for equality with mq_conv3x3_nchw32_fwd through tests/simt. */
 int mq_conv3x3_nchw32_v2_fwd(const void* x, const void* w, const void* bias, float* out, int B, int H, int W, int C, long x_bs,
                           int N, void* stream);
+/* third version (round 3): the B fragments of the 32 x 9C weight matrix come straight from global memory through a register ring,
+ * the input window is the only LDS tile: one barrier pair per channel pass instead of ten, three workgroups per CU.  Same results. */
+int mq_conv3x3_nchw32_v3_fwd(const void* x, const void* w, const void* bias, float* out, int B, int H, int W, int C, long x_bs,
+                          int N, void* stream);
 int mq_dcnv2_stats_blocks(int H, int W, int stride);
 /* One launch for up to 16 DCNv2 calls (the 13 branches of one DyConv layer): `branches` is a HOST array, copied into the
  * kernel arguments; fields as the arguments of mq_dcnv2_fwd.  The tiles of all branches form one work list, so small
@@ -366,6 +370,7 @@ MQ_BF16_TWIN(mq_swin_mlp2_fwd)
 MQ_BF16_TWIN(mq_conv3x3_fwd)
 MQ_BF16_TWIN(mq_conv3x3_nchw32_fwd)
 MQ_BF16_TWIN(mq_conv3x3_nchw32_v2_fwd)
+MQ_BF16_TWIN(mq_conv3x3_nchw32_v3_fwd)
 MQ_BF16_TWIN(mq_dcnv2_fwd)
 MQ_BF16_TWIN(mq_dcnv2_group_fwd)
 MQ_BF16_TWIN(mq_dyconv_stats)

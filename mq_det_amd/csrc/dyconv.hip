@@ -341,29 +341,36 @@ extern "C" int MQ_SYM(mq_dyconv_fuse)(const void* y0, const float* coef0, int hs
 // ---------------------------------------------------------------------------------------------- DyReLU
 // one block (256 threads) per batch element: y = pool / n -> fc0 (C -> C/4) ReLU -> fc2 (C/4 -> 4C) -> h_sigmoid
 // coef[b, 0..3, c] = a1, b1, a2, b2  (lambda_a = 2, init_a = (1, 0), init_b = (0, 0))
-__global__ __launch_bounds__(256) void dyrelu_coef_kernel(const float* __restrict__ pool, int nblk,
-                                                          const half_t* __restrict__ w0,
-                                                          const half_t* __restrict__ b0, const half_t* __restrict__ w2,
-                                                          const half_t* __restrict__ b2, float* __restrict__ coef, int n,
-                                                          int C) {
-  __shared__ float yv[256], hv[64];
-  const int b = blockIdx.x, t = threadIdx.x;
+__global__ __launch_bounds__(1024) void dyrelu_coef_kernel(const float* __restrict__ pool, int nblk,
+                                                           const half_t* __restrict__ w0,
+                                                           const half_t* __restrict__ b0, const half_t* __restrict__ w2,
+                                                           const half_t* __restrict__ b2, float* __restrict__ coef, int n,
+                                                           int C) {
+  __shared__ float yv[256], hv[64], part[4][256];
+  const int b = blockIdx.x, t = threadIdx.x & 255, grp = threadIdx.x >> 8;
   const int S = C / 4;                                   // C == 256, S == 64 (checked by the host wrapper)
-  // spatial mean: fixed-order sum of the per-block partials, 8 independent loads in flight
-  float acc0 = 0.f;
-  const float* pb = pool + (long)b * nblk * C + t;
-  int k = 0;
-  for (; k + 8 <= nblk; k += 8) {
-    float v[8];
+  // spatial mean: fixed-order sum of the per-block partials.  The P3 level has 132 of them per image: one dependent chain of 17
+  // rounds of 8 loads was 42 us (the launch sits between the fuse kernel and the next LayerNorm, on the critical path); four
+  // row groups each take a contiguous quarter (8 loads in flight each) and are combined in group order.
+  {
+    const int q = (nblk + 3) / 4, k0 = grp * q, k1 = min(nblk, k0 + q);
+    float acc0 = 0.f;
+    const float* pb = pool + (long)b * nblk * C + t;
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+      float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = pb[(long)(k + u) * C];
+      for (int u = 0; u < 8; ++u) v[u] = pb[(long)(k + u) * C];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc0 += v[u];
+      for (int u = 0; u < 8; ++u) acc0 += v[u];
+    }
+    for (; k < k1; ++k) acc0 += pb[(long)k * C];
+    part[grp][t] = acc0;
   }
-  for (; k < nblk; ++k) acc0 += pb[(long)k * C];
-  yv[t] = acc0 / (float)n;
   __syncthreads();
-  {  // fc.0 (C -> S) + ReLU: 4 lanes per output, 16-byte weight loads, fixed-order combine
+  if (grp == 0) yv[t] = (((part[0][t] + part[1][t]) + part[2][t]) + part[3][t]) / (float)n;
+  __syncthreads();
+  if (grp == 0) {  // fc.0 (C -> S) + ReLU: 4 lanes per output, 16-byte weight loads, fixed-order combine
     const int o = t >> 2, q = t & 3;
     const half_t* wr = w0 + (long)o * C + q * (C / 4);
     float a = 0.f;
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(256) void dyrelu_coef_kernel(const float* __restric
     if (q == 0) hv[o] = fmaxf(a + (float)b0[o], 0.f);
   }
   __syncthreads();
-  for (int o = t; o < 4 * C; o += 256) {                   // fc.2 (S -> 4C) + h_sigmoid, 16-byte weight loads
+  for (int o = threadIdx.x; o < 4 * C; o += 1024) {         // fc.2 (S -> 4C) + h_sigmoid, 16-byte weight loads: one output per thread
     float acc = (float)b2[o];
     const half_t* wr = w2 + (long)o * S;
 #pragma unroll
@@ -398,7 +405,7 @@ extern "C" int MQ_SYM(mq_dyrelu_coef)(const float* pool, const void* w0, const v
                               float* coef, int B, int n, int C, void* stream) {
   if (B <= 0) return 0;
   if (C != 256) return -1;
-  hipLaunchKernelGGL(dyrelu_coef_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pool, (n + 127) / 128, (const half_t*)w0,
+  hipLaunchKernelGGL(dyrelu_coef_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, pool, (n + 127) / 128, (const half_t*)w0,
                      (const half_t*)b0, (const half_t*)w2, (const half_t*)b2, coef, n, C);
   MQ_CHECK_LAUNCH();
   return 0;

@@ -42,6 +42,8 @@ def main():
         align(dev, g, out)
     if only in ("", "window"):
         window(dev, g, out)
+    if only in ("", "dyconv"):
+        dyconv_parts(dev, g, out)
     if only in ("", "vlfuse"):
         vlfuse(dev, g, out)
         vlfuse_text(dev, g, out)
@@ -153,6 +155,46 @@ def vlfuse(dev, g, out):
             out.append({"kernel": f"vlfuse_i2t {name} B={B} N={N} live keys={live}", "ms": round(ms, 4),
                         "TFLOPs": round(fl / ms / 1e9, 1), "frac_of_mfma_peak": round(fl / ms / 1e9 / 2500, 3),
                         "algorithmic_GBs": round(nb / ms / 1e6, 1), "max_abs_diff_vs_first": round(float((o - ref).abs().max()), 6)})
+
+
+def dyconv_parts(dev, g, out):
+    # ---- DyConv side kernels at the bench shape (B = 8): the offset conv per pyramid level (variants 2 / 3), DYReLU coefficients,
+    # and LayerNorm(DYReLU(x)) fused against the two passes it replaces
+    sizes = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    B, C = 8, 256
+    w = torch.zeros(32, 9 * C)
+    w[:27] = torch.randn(27, 9 * C, generator=g) / 48
+    w, bias = w.half().to(dev), torch.randn(27, generator=g).half().to(dev)
+    for (H, W) in sizes[:3]:
+        x = torch.randn(B, H, W, C, generator=g).half().to(dev)
+        for variant in (2, 3):
+            ops.KERNELS["OFFSET_CONV_VARIANT"] = variant
+            ms = timeit(lambda: ops.conv3x3_nchw32(x, w, bias, 27))
+            nb = x.numel() * 2 + B * 27 * H * W * 4
+            out.append({"kernel": f"offset conv v{variant} B={B} {H}x{W}x{C} -> 27", "ms": round(ms, 4), "algorithmic_GBs": round(nb / ms / 1e6, 1),
+                        "frac_of_hbm_peak": round(nb / ms / 1e6 / 8000, 3)})
+    ops.KERNELS["OFFSET_CONV_VARIANT"] = ops.KERNEL_DEFAULTS["OFFSET_CONV_VARIANT"]
+    N = sum(h * w_ for h, w_ in sizes)
+    tok = torch.randn(B, N, C, generator=g).half().to(dev)
+    gam, bet = torch.ones(C).half().to(dev), torch.zeros(C).half().to(dev)
+    coef = torch.randn(len(sizes), B, 4, C, generator=g).to(dev)
+    ms = timeit(lambda: ops.dyrelu_layer_norm(tok, coef, sizes, gam, bet, 1e-5))
+    out.append({"kernel": f"LayerNorm(DYReLU(x)) fused, [B={B}, N={N}, 256]", "ms": round(ms, 4), "algorithmic_GBs": round(2 * tok.numel() * 2 / ms / 1e6, 1)})
+
+    def two_pass():
+        off = 0
+        for l, (h, w_) in enumerate(sizes):
+            ops.dyrelu_apply_(tok[:, off:off + h * w_], coef[l])
+            off += h * w_
+        return ops.layer_norm(tok, gam, bet, 1e-5)
+    ms = timeit(two_pass)
+    out.append({"kernel": "5 x dyrelu_apply + LayerNorm (the passes it replaces, one stream)", "ms": round(ms, 4)})
+    w0, b0 = (torch.randn(64, C, generator=g) / 16).half().to(dev), torch.zeros(64).half().to(dev)
+    w2, b2 = (torch.randn(4 * C, 64, generator=g) / 8).half().to(dev), torch.zeros(4 * C).half().to(dev)
+    for (H, W) in sizes[:2]:
+        pool = torch.randn(B, (H * W + 127) // 128, C, generator=g).to(dev)
+        ms = timeit(lambda: ops.dyrelu_coef(pool, H * W, w0, b0, w2, b2))
+        out.append({"kernel": f"dyrelu_coef {H}x{W} ({pool.shape[1]} partials per image)", "ms": round(ms, 4)})
 
 
 def vlfuse_text(dev, g, out):
