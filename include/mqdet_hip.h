@@ -48,8 +48,8 @@ int mq_attn_fwd(const void* q, const void* k, const void* vt, void* o, const flo
 /* The same operator for SHORT key sequences (Nk <= 256: every attention over the text tokens): all keys of a (batch, head) resident
  * in LDS, S^T = K Q^T so that P stays in registers, exact two-pass softmax (csrc/attn_resident.hip).  Arguments as mq_attn_fwd
  * without the key split; additionally o_rs % 4 == 0 and, with a qk_mask, Nk % 4 == 0, mask strides % 4 == 0 and a 4-byte aligned
- * mask base (the mask is read one 32-bit word = 4 keys at a time; -3 otherwise).  Returns -1 for Nk > 256 or D not in {32, 64}.  Opt-in from the host
- * (MQ_ATTN_RESIDENT=1, mq_det_amd/ops.py): written after the round's GPU budget was spent -- checked through tests/simt only so far. */
+ * mask base (the mask is read one 32-bit word = 4 keys at a time; -3 otherwise).  Returns -1 for Nk > 256 or D not in {32, 64}.  Default for these shapes since
+ * round 3 (KERNELS["ATTN_RESIDENT"] = 1: +4.7 % end to end on its own, profiles/r03_call1_switch_ab.txt). */
 int mq_attn_resident_fwd(const void* q, const void* k, const void* vt, void* o, const float* key_bias, const int* kv_len,
                          const unsigned char* qk_mask, long mask_bs, long mask_hs, long mask_rs, int B, int H, int Nq, int Nk, int D,
                          long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long vt_bs, long vt_rs, long vt_hs,
@@ -58,7 +58,7 @@ int mq_attn_resident_fwd(const void* q, const void* k, const void* vt, void* o, 
 /* ... and for LONG key sequences without a per-(query, key) mask (GCP pre-select, MQ-GroundingDINO decoder self-attention): the
  * same S^T formulation over chunks of 256 keys with a running (max, sum, O) rescaled once per chunk, register prefetch of the next
  * chunk, one barrier per chunk; key split like mq_attn_fwd (same workspace size, mq_attn_workspace_bytes).  Arguments as mq_attn_fwd
- * without the qk_mask; o_rs % 4 == 0.  Opt-in together with mq_attn_resident_fwd (MQ_ATTN_RESIDENT=1). */
+ * without the qk_mask; o_rs % 4 == 0.  Selected together with mq_attn_resident_fwd (KERNELS["ATTN_RESIDENT"]). */
 int mq_attn_chunked_fwd(const void* q, const void* k, const void* vt, void* o, const float* key_bias, const int* kv_len,
                         void* workspace, int B, int H, int Nq, int Nk, int D,
                         long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs, long vt_bs, long vt_rs, long vt_hs,
@@ -136,16 +136,16 @@ int mq_layernorm_fwd(const void* x, int x_f32, const void* res, int res_f32, con
 
 /* The same operator, arguments and results (bit-identical: the summation order is kept) with a different load schedule: chunk count
  * per lane fixed at compile time, gamma / beta in registers for the whole block, up to 4 rows per lane group in flight, every load of
- * an iteration issued before the first is consumed (csrc/layernorm2.hip).  Opt-in from the host (MQ_LN_VARIANT=2): written after
- * round 2's GPU budget was spent, checked bit for bit against mq_layernorm_fwd through tests/simt. */
+ * an iteration issued before the first is consumed (csrc/layernorm2.hip).  Default since round 3 (KERNELS["LN_VARIANT"] = 2);
+ * bit for bit the results of mq_layernorm_fwd (device and tests/simt). */
 int mq_layernorm2_fwd(const void* x, int x_f32, const void* res, int res_f32, const void* gamma, const void* beta, void* y,
                      float* y32, void* xsum, long rows, int C, float eps, void* stream);
 
 /* Swin PatchMerging up to its LayerNorm in one kernel: y[b,i,j,:] = LayerNorm_{4C}(concat(x[b,2i,2j], x[b,2i+1,2j], x[b,2i,2j+1],
  *   x[b,2i+1,2j+1])), zero beyond an odd H / W.  x [B,H,W,C] fp16 or fp32 (x_f32), contiguous; gamma / beta [4C] fp16; y fp16
  *   [B, ceil(H/2)*ceil(W/2), 4C]; C % 8 == 0, 4C <= 3072.  Bit-identical to F.pad + torch.cat + mq_layernorm_fwd.
- * Replaces maskrcnn_benchmark/modeling/backbone/swint.py:264-281 (pad, four strided slices, cat, norm).  Opt-in from the host
- * (MQ_PATCH_MERGE_FUSED=1): written after round 2's GPU budget was spent, checked for equality through tests/simt. */
+ * Replaces maskrcnn_benchmark/modeling/backbone/swint.py:264-281 (pad, four strided slices, cat, norm).  Default since round 3
+ * (KERNELS["PATCH_MERGE_FUSED"] = 1). */
 int mq_patch_merge_ln_fwd(const void* x, int x_f32, const void* gamma, const void* beta, void* y, int B, int H, int W, int C, float eps,
                           void* stream);
 
@@ -200,13 +200,8 @@ int mq_conv3x3_nchw32_fwd(const void* x, const void* w, const void* bias, float*
                           int N, void* stream);
 
 /* The same operator, arguments and results (bit-identical) with an unconditional, fully in-flight load schedule for the input window
- * and the weight prefetch (csrc/conv_small2.hip).  Opt-in from the host (MQ_OFFSET_CONV_VARIANT=2): written after round 2's GPU
- * budget was spent, checked for equality with mq_conv3x3_nchw32_fwd through tests/simt. */
+ * and the weight prefetch (csrc/conv_small2.hip).  Default since round 3 (KERNELS["OFFSET_CONV_VARIANT"] = 2); equal outputs. */
 int mq_conv3x3_nchw32_v2_fwd(const void* x, const void* w, const void* bias, float* out, int B, int H, int W, int C, long x_bs,
-                          int N, void* stream);
-/* third version (round 3): the B fragments of the 32 x 9C weight matrix come straight from global memory through a register ring,
- * the input window is the only LDS tile: one barrier pair per channel pass instead of ten, three workgroups per CU.  Same results. */
-int mq_conv3x3_nchw32_v3_fwd(const void* x, const void* w, const void* bias, float* out, int B, int H, int W, int C, long x_bs,
                           int N, void* stream);
 int mq_dcnv2_stats_blocks(int H, int W, int stride);
 /* One launch for up to 16 DCNv2 calls (the 13 branches of one DyConv layer): `branches` is a HOST array, copied into the
@@ -339,8 +334,7 @@ int mq_ml_nms(const float* boxes, const int* labels, const int* nvalid, void* wo
 
 /* The same NMS that stops sweeping an image once max_keep of its boxes are kept: with score-sorted input the first max_keep survivors
  * are the max_keep highest-scoring ones, all the caller uses (rpn/inference.py:757-766); keep[] is 0 behind the stopping chunk.
- * N <= 6656 (-1 beyond: use mq_ml_nms).  Opt-in from the host (MQ_NMS_EARLY_STOP=1): written after round 2's GPU budget was spent,
- * checked through tests/simt (csrc/nms2.hip). */
+ * N <= 6656 (-1 beyond: use mq_ml_nms).  Default since round 3 (KERNELS["NMS_EARLY_STOP"] = 1). */
 int mq_ml_nms_topk(const float* boxes, const int* labels, const int* nvalid, void* workspace, unsigned char* keep,
                    int B, int N, float thr, int max_keep, void* stream);
 
@@ -370,7 +364,6 @@ MQ_BF16_TWIN(mq_swin_mlp2_fwd)
 MQ_BF16_TWIN(mq_conv3x3_fwd)
 MQ_BF16_TWIN(mq_conv3x3_nchw32_fwd)
 MQ_BF16_TWIN(mq_conv3x3_nchw32_v2_fwd)
-MQ_BF16_TWIN(mq_conv3x3_nchw32_v3_fwd)
 MQ_BF16_TWIN(mq_dcnv2_fwd)
 MQ_BF16_TWIN(mq_dcnv2_group_fwd)
 MQ_BF16_TWIN(mq_dyconv_stats)

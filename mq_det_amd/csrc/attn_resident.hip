@@ -11,9 +11,9 @@
 //     lane plus 2 shuffles (there: 4), the 1 / l normalisation is a per-lane scalar;
 //   * all <= 256 logits of a query stay in registers: exact two-pass softmax, no running max / rescale;
 //   * exp2 domain: log2(e) is folded into the scale and the bias, one v_exp_f32 per logit without the multiply.
-// mq_attn_fwd stays the kernel for long key sequences (pre-select: 5577 keys, split over keys) and is the default for every call;
-// the host switches text-sized calls here with MQ_ATTN_RESIDENT=1 (mq_det_amd/ops.py) -- added in round 2 after the GPU budget was
-// spent: checked against the oracle through tests/simt only, to be measured in round 3.
+// The host routes text-sized calls here (KERNELS["ATTN_RESIDENT"] = 1, the default since round 3: +4.7 % end to end on its own,
+// profiles/r03_call1_switch_ab.txt; B = 64 language path: attention launches 5.0 -> 9.4 % MFMA); mq_attn_fwd stays the kernel for
+// per-(query, key) masks and is selectable for everything.
 //
 // Work decomposition: grid = ceil(Nq / 128) x B x H workgroups of 4 waves, a wave owns 32 queries (2 column blocks); 2 workgroups
 // fit a CU (LDS 2 x 72 KB, <= 256 VGPRs), so one workgroup's K / V fill overlaps the other's MFMAs.
@@ -286,7 +286,7 @@ extern "C" int MQ_SYM(mq_attn_resident_fwd)(const void* q, const void* k, const 
 // 256 keys -- mq_attn_fwd decides about a rescale every 64 keys and moves P through LDS.  The next chunk's K / V^T travel in a
 // register prefetch ring while the current one is on the MFMAs and are committed to the other LDS buffer: one barrier per chunk.
 // Key split (nsplit > 1) writes the same (O, m, l) partials as mq_attn_fwd; a combine kernel merges them.
-// Opt-in like the resident kernel (MQ_ATTN_RESIDENT=1), checked through tests/simt only.
+// Selected like the resident kernel (KERNELS["ATTN_RESIDENT"] = 1, default).
 template <int D, bool CLAMP>
 __global__ __launch_bounds__(256) void attn_chunked_kernel(ResAttnParams p, float* ws, int nsplit) {
   constexpr int QB = RES_QB, KS = D + 8, VS = RES_NKMAX + 8, NB = RES_NKMAX / 16, CH = RES_NKMAX;

@@ -5,8 +5,8 @@
 // 1.07 ms of the MQ-GLIP step.  Here every address is clamped into the image and loaded unconditionally, all
 // (<= 12) chunks of a thread are in flight before the first LDS store, the border test only selects zero afterwards; the weight
 // prefetch is unconditional as well.  Same lesson as the MSDeformAttn gather (2.38 -> 1.03 ms) and layernorm2.hip.
-// Opt-in from the host (MQ_OFFSET_CONV_VARIANT=2): written after round 2's GPU budget was spent, checked for equality with
-// mq_conv3x3_nchw32_fwd through tests/simt; to be measured in round 3.
+// Default since round 3 (KERNELS["OFFSET_CONV_VARIANT"] = 2): +4.4 % end to end on its own (profiles/r03_call1_switch_ab.txt), equal
+// outputs to mq_conv3x3_nchw32_fwd on the device and through tests/simt.
 #include "common.h"
 
 MQ_NAMESPACE_BEGIN
@@ -158,139 +158,9 @@ extern "C" int MQ_SYM(mq_conv3x3_nchw32_v2_fwd)(const void* x, const void* w, co
   return 0;
 }
 
-// ---- third version (round 3): no weight tile, no tap barriers.  v2's tile is two channel passes, each: window fill -> barrier -> 9 x
-// (weight slice through registers into LDS, 16 MFMAs per wave, barrier): 20 barriers and 18 exposed weight round trips for 288 MFMAs
-// per wave -- the launch sits at 10 % of the HBM rate (0.83 ms of the step, on the critical path of every DyConv layer).  Here the
-// B fragments (rows j * 16 + l15 of the 32 x 9C weight matrix, 8 k-values per lane) come STRAIGHT from global memory -- all waves
-// read the same 147 KB, the L2 serves it -- through a register ring PF steps deep; the window is the only LDS tile, read-only after
-// its fill, so a pass is one barrier pair.  LDS per workgroup 52 KB -> three per CU (768 slots for the 1522 tiles of a layer).
-// Same MFMA order as v1 / v2: equal results.
-template <int KK>                                              // 32-channel k-steps per pass (C <= 128: one pass of C; else two of C / 2)
-__global__ __launch_bounds__(256, 3) void conv3x3_small3_kernel(ConvSmall2Params p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int CP = 32 * KK, XP = CP + 16, cpr = CP / 8, PF = 6, NSTEP = 9 * KK;
-  half_t* Win = (half_t*)smem;                               // [CS2_WH * CS2_WW][XP]
-  const int C = p.C;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int l15 = lane & 15, lg = lane >> 4;
-  const int tpx = (p.tiles_total + 7) >> 3;
-  const int tile = (blockIdx.x & 7) * tpx + (blockIdx.x >> 3);
-  if (tile >= p.tiles_total) return;
-  const int b = tile / (p.tiles_x * p.tiles_y), trem = tile % (p.tiles_x * p.tiles_y);
-  const int ho0 = (trem / p.tiles_x) * CS2_PH, wo0 = (trem % p.tiles_x) * CS2_PW;
-  const half_t* xb = p.x + (long)b * p.x_bs;
-  const int K = 9 * C;
-
-  float4_ acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (float4_){0.f, 0.f, 0.f, 0.f};
-
-  for (int c0 = 0; c0 < C; c0 += CP) {                       // channel pass
-    const half_t* wl = p.w + (long)l15 * K + c0 + lg * 8;    // + j * 16 * K + tap * C + kk * 32
-    half8 ring[PF][2];
-    auto wfrag = [&](int s, half8 (&f)[2]) __attribute__((always_inline)) {   // step s = tap * KK + kk
-      const int tap = s / KK, kk = s - tap * KK;
-      f[0] = *(const half8*)(wl + tap * C + kk * 32);
-      f[1] = *(const half8*)(wl + (long)16 * K + tap * C + kk * 32);
-    };
-#pragma unroll
-    for (int s = 0; s < PF; ++s) wfrag(s, ring[s]);
-    {
-      constexpr int NU = (CS2_WH * CS2_WW * cpr + 255) / 256;
-      constexpr int total = CS2_WH * CS2_WW * cpr;
-      half8 v[NU];
-#pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        const int c = min(u * 256 + tid, total - 1);
-        const int px = c / cpr, ch = c - px * cpr;
-        const int hh = min(max(ho0 - 1 + px / CS2_WW, 0), p.H - 1), ww = min(max(wo0 - 1 + px % CS2_WW, 0), p.W - 1);
-        v[u] = *(const half8*)(xb + ((long)hh * p.W + ww) * C + c0 + ch * 8);
-      }
-#pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        const int c = u * 256 + tid;
-        const int cc = min(c, total - 1);
-        const int px = cc / cpr, ch = cc - px * cpr;
-        const int hh = ho0 - 1 + px / CS2_WW, ww = wo0 - 1 + px % CS2_WW;
-        const bool inside = hh >= 0 && hh < p.H && ww >= 0 && ww < p.W;
-        if (c < total) *(half8*)(Win + px * XP + ch * 8) = inside ? v[u] : zero8();
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
-      constexpr int dummy = 0; (void)dummy;
-      const int tap = s / KK, kk = s - tap * KK;
-      const int dy = tap / 3, dx = tap - dy * 3;
-      const half_t* a0 = Win + ((2 * wave + dy) * CS2_WW + l15 + dx) * XP + lg * 8 + kk * 32;
-      half8 af[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *(const half8*)(a0 + i * CS2_WW * XP);
-      half8 bf[2] = {ring[s % PF][0], ring[s % PF][1]};
-      if (s + PF < NSTEP) wfrag(s + PF, ring[s % PF]);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
-    }
-    __syncthreads();                                         // window free for the next pass / the output staging
-  }
-
-  float* Os = (float*)smem;                                  // [32 ch][CS2_PH * CS2_PW + 4]
-  constexpr int OP = CS2_PH * CS2_PW + 4;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = j * 16 + l15;
-    const float bv = (p.bias && n < p.N) ? (float)p.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Os[n * OP + (2 * wave + i) * CS2_PW + 4 * lg + r] = acc[i][j][r] + bv;
-  }
-  __syncthreads();
-  float* ob = p.out + (long)b * p.N * p.H * p.W;
-  for (int c = tid; c < p.N * CS2_PH * CS2_PW; c += 256) {
-    const int n = c / (CS2_PH * CS2_PW), pos = c % (CS2_PH * CS2_PW);
-    const int ho = ho0 + pos / CS2_PW, wo = wo0 + pos % CS2_PW;
-    if (ho < p.H && wo < p.W) ob[((long)n * p.H + ho) * p.W + wo] = Os[n * OP + pos];
-  }
-}
-
-template <int KK>
-static int launch_conv_small3(const ConvSmall2Params& p, hipStream_t s) {
-  constexpr size_t win = (size_t)(CS2_WH * CS2_WW) * (32 * KK + 16) * sizeof(half_t);
-  constexpr size_t ostage = (size_t)32 * (CS2_PH * CS2_PW + 4) * sizeof(float);
-  constexpr size_t smem = win > ostage ? win : ostage;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_small3_kernel<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return (int)e;
-    attr = true;
-  }
-  hipLaunchKernelGGL(conv3x3_small3_kernel<KK>, dim3((unsigned)(8 * ((p.tiles_total + 7) / 8))), dim3(256), smem, s, p);
-  MQ_CHECK_LAUNCH();
-  return 0;
-}
-
-// same arguments and results as mq_conv3x3_nchw32_fwd / _v2_fwd
-extern "C" int MQ_SYM(mq_conv3x3_nchw32_v3_fwd)(const void* x, const void* w, const void* bias, float* out, int B, int H, int W, int C,
-                                     long x_bs, int N, void* stream) {
-  if (B <= 0) return 0;
-  if (C % 32 || C > 256 || (C > 128 && C % 64) || N < 1 || N > 32) return -1;
-  ConvSmall2Params p;
-  p.x = (const half_t*)x; p.w = (const half_t*)w; p.bias = (const half_t*)bias; p.out = out;
-  p.x_bs = x_bs; p.B = B; p.H = H; p.W = W; p.C = C; p.N = N;
-  p.tiles_y = (H + CS2_PH - 1) / CS2_PH; p.tiles_x = (W + CS2_PW - 1) / CS2_PW;
-  p.tiles_total = B * p.tiles_y * p.tiles_x;
-  const int CP = C > 128 ? C / 2 : C;
-  switch (CP / 32) {
-    case 1: return launch_conv_small3<1>(p, (hipStream_t)stream);
-    case 2: return launch_conv_small3<2>(p, (hipStream_t)stream);
-    case 3: return launch_conv_small3<3>(p, (hipStream_t)stream);
-    default: return launch_conv_small3<4>(p, (hipStream_t)stream);
-  }
-}
+// (Round 3 tried a third version without the weight tile: B fragments straight from global memory through a six-step register ring,
+// the window the only LDS tile, one barrier pair per channel pass, three workgroups per CU.  Equal results, but 0.123 ms against this
+// kernel's 0.055 ms on the P3 level at B = 8 (profiles/r03_call7_microbench_dyconv.json): 72 dependent 16-byte loads per wave and pass
+// from L2 are slower than ten barriers.  Removed.)
 
 MQ_NAMESPACE_END

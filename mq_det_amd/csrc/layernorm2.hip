@@ -8,8 +8,8 @@
 // Here: the chunk count per lane is a template parameter (1, 2, 3, 4, 6), gamma / beta live in registers for the whole block, and
 // R rows per lane group are in flight together (R = 4 for one chunk per lane, 2 for two, 1 above): every load of an iteration is
 // issued before the first one is consumed.
-// Opt-in from the host (MQ_LN_VARIANT=2, mq_det_amd/ops.py): written after round 2's GPU budget was spent; checked bit for bit
-// against mq_layernorm_fwd through tests/simt, to be measured in round 3.
+// Default since round 3 (KERNELS["LN_VARIANT"] = 2: 1.39 -> 1.13 ms of LayerNorm per step, 2.8 -> 3.0 TB/s); bit for bit the results of
+// mq_layernorm_fwd on the device and through tests/simt.
 #include "common.h"
 
 MQ_NAMESPACE_BEGIN
@@ -184,7 +184,7 @@ extern "C" int MQ_SYM(mq_layernorm2_fwd)(const void* x, int x_f32, const void* r
 // [B, H/2, W/2, 4C] fp32 tensor, profiles/r02_call5) and then mq_layernorm_fwd reads it back; here the LayerNorm reads the four
 // C-wide segments of a row straight from x.  Same lane <-> chunk assignment and summation order as mq_layernorm_fwd on the
 // concatenated row: the result equals cat + LayerNorm bit for bit.  x: [B, H, W, C] fp16 or fp32 (x_f32), contiguous; y: fp16
-// [B, ceil(H/2) * ceil(W/2), 4C]; C % 8 == 0, 4C <= 3072.  Opt-in from the host (MQ_PATCH_MERGE_FUSED=1), see the header of this file.
+// [B, ceil(H/2) * ceil(W/2), 4C]; C % 8 == 0, 4C <= 3072.  Default since round 3 (KERNELS["PATCH_MERGE_FUSED"] = 1).
 template <int LPR, int MAXC, int R, bool XF32>
 __global__ __launch_bounds__(256) void patch_merge_ln_kernel(const void* __restrict__ x, const half_t* __restrict__ gamma,
                                                              const half_t* __restrict__ beta, half_t* __restrict__ y, int B, int H, int W,

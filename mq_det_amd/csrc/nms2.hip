@@ -7,7 +7,7 @@
 // per image the sweep typically ends after 10 - 20 chunks.  keep[] is 0 for every box after the stopping chunk; the selected
 // detections are identical to mq_ml_nms + top-k.  Same mask kernel and sweep as post.hip (copied: post.o stays the object that was
 // validated on the device) plus a stop flag in LDS read by all five waves after the per-chunk barrier.
-// Opt-in from the host (MQ_NMS_EARLY_STOP=1): written after round 2's GPU budget was spent, checked through tests/simt.
+// Default since round 3 (KERNELS["NMS_EARLY_STOP"] = 1; device parity: tests/test_gpu_parity.py test_opt_in_kernel[nms_early_stop]).
 #include "common.h"
 
 MQ_NAMESPACE_BEGIN

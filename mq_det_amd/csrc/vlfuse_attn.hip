@@ -142,9 +142,12 @@ __device__ __forceinline__ void pv_tile(const half_t* tile, const half8 (&pf)[2]
 // sits at the 256-VGPR limit, into spills.  Batch items with shorter captions are handled by the key mask as before.
 // ABL (tools/microbench.py "vlfuse" only; results are garbage): time the kernel WITHOUT one of its parts -- bit 0: no global tile loads,
 // bit 1: no LDS tile commits, bit 2: no softmax arithmetic, bit 3: no fragment reads / MFMAs -- to see which part a step waits for.
-template <int NT, int QB, int NBL, int ABL = 0>
+// QREG (NT = 3 with at most two live blocks in the last tile, i.e. 129 .. 160 keys -- the 141-token caption of the benchmark): the Q
+// fragments stay in registers and the prefetch ring keeps its two slots as for NT <= 2 (the 36 .. 40 live logit registers leave the
+// room: 242 / 246 VGPRs, no spill) -- no Q tile in LDS, a fifth fewer fragment reads in the QK steps, tiles two steps ahead.
+template <int NT, int QB, int NBL, int ABL = 0, bool QREG = false>
 __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p) {
-  constexpr bool LEAN = NT >= 3;
+  constexpr bool LEAN = NT >= 3 && !QREG;
   constexpr int NTH = 2048 / (QB * 4), WR = 16 * QB;        // threads per workgroup (512 / 256), query rows per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* tiles = (half_t*)smem;                           // [2][TK][KS]
@@ -365,18 +368,18 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
   }
 }
 
-template <int NT, int QB, int NBL, int ABL = 0>
+template <int NT, int QB, int NBL, int ABL = 0, bool QREG = false>
 static int launch_i2t(const I2TParams& p, hipStream_t stream) {
-  constexpr size_t smem = (size_t)(2 * TILE + (NT >= 3 ? BM * KS : 0)) * sizeof(half_t) + (size_t)VH * NT * TK * sizeof(float);
+  constexpr size_t smem = (size_t)(2 * TILE + ((NT >= 3 && !QREG) ? BM * KS : 0)) * sizeof(half_t) + (size_t)VH * NT * TK * sizeof(float);
   static_assert(4 * 32 * (VD + 8) <= 2 * TILE, "O staging must fit in the tiles");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)vlfuse_i2t_kernel<NT, QB, NBL, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)vlfuse_i2t_kernel<NT, QB, NBL, ABL, QREG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   const int qtiles = (p.N + BM - 1) / BM;
-  hipLaunchKernelGGL((vlfuse_i2t_kernel<NT, QB, NBL, ABL>), dim3((unsigned)(8 * ((p.B + 7) / 8) * qtiles)), dim3(2048 / (QB * 4)), smem, stream, p);
+  hipLaunchKernelGGL((vlfuse_i2t_kernel<NT, QB, NBL, ABL, QREG>), dim3((unsigned)(8 * ((p.B + 7) / 8) * qtiles)), dim3(2048 / (QB * 4)), smem, stream, p);
   MQ_CHECK_LAUNCH();
   return 0;
 }
@@ -706,6 +709,8 @@ extern "C" int MQ_SYM(mq_vlfuse_i2t_fwd)(const void* v_ln, const void* kf, const
     }
   }
 #endif
+  if (variant == 3 && nt == 3 && nbl <= 2)                                 // Q in registers for 129 .. 160 keys
+    return nbl == 1 ? launch_i2t<3, 1, 1, 0, true>(p, st) : launch_i2t<3, 1, 2, 0, true>(p, st);
 #define MQ_I2T(NT_)                                                        \
   switch (nbl) {                                                           \
     case 1: return launch_i2t<NT_, 1, 1>(p, st);                           \

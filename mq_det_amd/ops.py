@@ -33,7 +33,6 @@ _SIGNATURES = {
     "mq_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _vp]),
     "mq_conv3x3_nchw32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _vp]),
     "mq_conv3x3_nchw32_v2_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _vp]),
-    "mq_conv3x3_nchw32_v3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _vp]),
     "mq_dcnv2_stats_blocks": (_i, [_i, _i, _i]),
     "mq_dcnv2_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_dcnv2_group_fwd": (_i, [_vp, _i, _vp]),
@@ -56,7 +55,7 @@ _SIGNATURES = {
 }
 # entry points with 16-bit operands also exist as <name>_bf16 (same signature; include/mqdet_hip.h MQ_BF16_TWIN)
 BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
-              "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_patch_merge_ln_fwd", "mq_swin_mlp_fwd", "mq_swin_mlp2_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_conv3x3_nchw32_v3_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
+              "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_patch_merge_ln_fwd", "mq_swin_mlp_fwd", "mq_swin_mlp2_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
               "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyrelu_apply", "mq_dyrelu_ln_fwd",
               "mq_align_scores_fwd", "mq_align_fused_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
 for _n in BF16_TWINS:
@@ -70,7 +69,7 @@ EXPORTS = tuple(_SIGNATURES)
 # environment variable MQ_<NAME> (A/B runs, tests).
 KERNEL_DEFAULTS = {
     "LN_VARIANT": 2,             # 2: mq_layernorm2_fwd (rows in flight, gamma / beta in registers; bit-identical results)      +1.2 %
-    "OFFSET_CONV_VARIANT": 3,    # 3: mq_conv3x3_nchw32_v3_fwd (no weight tile, no tap barriers); 2: mq_conv3x3_nchw32_v2_fwd (window loads unconditional and in flight; bit-identical)         +4.4 %
+    "OFFSET_CONV_VARIANT": 2,    # 2: mq_conv3x3_nchw32_v2_fwd (window loads unconditional and in flight; bit-identical)         +4.4 %
     "PATCH_MERGE_FUSED": 1,      # 1: mq_patch_merge_ln_fwd (Swin PatchMerging gather + LayerNorm, no pad / cat pass)            +1.6 %
     "FPN_VIA_DCN": 1,            # 1: the three FPN output convs as ONE grouped launch of the fused DCNv2 kernel, zero offsets    +3.8 %
     "NMS_EARLY_STOP": 1,         # 1: mq_ml_nms_topk (the sweep of an image ends once DETECTIONS_PER_IMG boxes are kept)          +0.9 %
@@ -555,8 +554,7 @@ def conv3x3_nchw32(x_nhwc, w_packed, bias, n_out):
     out = torch.empty(B, n_out, H, W, dtype=torch.float32, device=x_nhwc.device)
     with _timed("conv3x3_small", B * H * W * C * 2 + out.numel() * 4):
         # OFFSET_CONV_VARIANT 2: unconditional / in-flight loads (csrc/conv_small2.hip), same results bit for bit
-        # 3: weights as B fragments straight from global memory, no tap barriers (same results again)
-        name = {2: "mq_conv3x3_nchw32_v2_fwd", 3: "mq_conv3x3_nchw32_v3_fwd"}.get(KERNELS["OFFSET_CONV_VARIANT"], "mq_conv3x3_nchw32_fwd")
+        name = "mq_conv3x3_nchw32_v2_fwd" if KERNELS["OFFSET_CONV_VARIANT"] == 2 else "mq_conv3x3_nchw32_fwd"
         _chk(_fn(lib, name, x_nhwc)(_ptr(x_nhwc), _ptr(w_packed), _ptr(bias), _ptr(out), B, H, W, C, x_nhwc.stride(0), n_out, _stream()), name)
     return out
 

@@ -345,10 +345,10 @@ def check_vlfuse_kernels(dev):
         ob = torch.randn(256, generator=g).to(H16)
         kv_len = None if kv is None else torch.tensor(kv, dtype=torch.int32)
         ref = emu.vlfuse_i2t(v_ln.float(), kf.float(), vo.float(), bias, ob.float(), kv_len, 0)
-        for variant in (2, 1):
+        for variant in (2, 1, 3):
             got = ops.vlfuse_i2t(v_ln.to(dev), kf.to(dev), vo.to(dev), bias.to(dev), ob.to(dev),
                                  None if kv_len is None else kv_len.to(dev), max_kv=0 if kv is None else max(kv), variant=variant)
-            res.append(_stat(f"vlfuse image side [{'pair-split' if variant == 2 else 'first kernel'}] B={B} N={N} T={T} kv_len={kv}", got, ref, tol=2e-3))
+            res.append(_stat(f"vlfuse image side [{ {1: 'first kernel', 2: 'pair-split', 3: 'first kernel, Q in registers where it fits'}[variant] }] B={B} N={N} T={T} kv_len={kv}", got, ref, tol=2e-3))
     for B, N, T, ns, kv in ((2, 645, 64, 1, None), (1, 22400, 256, 6, None), (3, 1000, 100, 3, None), (2, 130, 160, 2, [160, 90]),
                             (9, 70, 40, 1, None), (3, 500, 256, 4, [256, 128, 77]), (2, 300, 256, 3, [141, 1]),
                             (3, 200, 256, 2, [17, 141, 96]))[3 if QUICK else 0:]:

@@ -418,10 +418,10 @@ def _body_offset_conv_v2_kernel(dev, monkeypatch):
         w[:27] = (torch.randn(27, 9 * C, generator=g) / 48).half()
         w, bias = w.to(dev), torch.randn(27, generator=g).half().to(dev)
         outs = {}
-        for variant in ("1", "2", "3"):
+        for variant in ("1", "2"):
             monkeypatch.setenv("MQ_OFFSET_CONV_VARIANT", variant)
             outs[variant] = ops.conv3x3_nchw32(x, w, bias, 27)
-        assert torch.equal(outs["1"], outs["2"]) and torch.equal(outs["1"], outs["3"]), (B, H, W, C)
+        assert torch.equal(outs["1"], outs["2"]), (B, H, W, C)
     monkeypatch.setenv("MQ_OFFSET_CONV_VARIANT", "2")
     _assert(pc.check_conv3x3(dev))
     _assert(pc.check_dyconv(dev))

@@ -355,10 +355,10 @@ def test_offset_conv_v2_equals_v1(kernels, monkeypatch, dtype):
         w[:27] = (torch.randn(27, 9 * C, generator=g) / 48).to(dtype)
         bias = torch.randn(27, generator=g).to(dtype)
         outs = {}
-        for variant in ("1", "2", "3"):
+        for variant in ("1", "2"):
             monkeypatch.setenv("MQ_OFFSET_CONV_VARIANT", variant)
             outs[variant] = ops.conv3x3_nchw32(x, w, bias, 27)
-        assert torch.equal(outs["1"], outs["2"]) and torch.equal(outs["1"], outs["3"]), (B, H, W, C)
+        assert torch.equal(outs["1"], outs["2"]), (B, H, W, C)
         big = torch.zeros(B, H * W + 37, C, dtype=dtype)                       # a pyramid level inside a larger token buffer
         big[:, 5:5 + H * W] = x.reshape(B, H * W, C)
         assert torch.equal(ops.conv3x3_nchw32(big[:, 5:5 + H * W].reshape(B, H, W, C), w, bias, 27), outs["1"])

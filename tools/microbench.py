@@ -143,7 +143,7 @@ def vlfuse(dev, g, out):
         kv = torch.full((B,), live, dtype=torch.int32, device=dev)
         ref = None
         # 101 ... 115: the first kernel WITHOUT global tile loads (bit 0) / LDS commits (1) / softmax (2) / fragment reads + MFMAs (3)
-        for variant in (1, 2) + ((101, 103, 104, 108, 111, 115) if live == 141 else ()):
+        for variant in (1, 2, 3) + ((101, 103, 104, 108, 111, 115) if live == 141 else ()):
             fn = lambda variant=variant: ops.vlfuse_i2t(v, kf, vo, bias, ob, kv_len=kv, max_kv=live, variant=variant)  # noqa: E731
             ms = timeit(fn)
             o = fn().float()
@@ -151,7 +151,7 @@ def vlfuse(dev, g, out):
             visited = -(-live // 16) * 16
             fl = 4.0 * B * 8 * N * visited * 256
             nb = v.numel() * 2 * 2 + kf.numel() * 2 * 2
-            name = {1: "first kernel", 2: "pair-split"}.get(variant, f"first kernel, ablation bits {variant - 100:04b} (loads|commits|softmax|mfma removed)")
+            name = {1: "first kernel", 2: "pair-split", 3: "first kernel with Q in registers (129 .. 160 keys)"}.get(variant, f"first kernel, ablation bits {variant - 100:04b} (loads|commits|softmax|mfma removed)")
             out.append({"kernel": f"vlfuse_i2t {name} B={B} N={N} live keys={live}", "ms": round(ms, 4),
                         "TFLOPs": round(fl / ms / 1e9, 1), "frac_of_mfma_peak": round(fl / ms / 1e9 / 2500, 3),
                         "algorithmic_GBs": round(nb / ms / 1e6, 1), "max_abs_diff_vs_first": round(float((o - ref).abs().max()), 6)})
@@ -167,7 +167,7 @@ def dyconv_parts(dev, g, out):
     w, bias = w.half().to(dev), torch.randn(27, generator=g).half().to(dev)
     for (H, W) in sizes[:3]:
         x = torch.randn(B, H, W, C, generator=g).half().to(dev)
-        for variant in (2, 3):
+        for variant in (1, 2):
             ops.KERNELS["OFFSET_CONV_VARIANT"] = variant
             ms = timeit(lambda: ops.conv3x3_nchw32(x, w, bias, 27))
             nb = x.numel() * 2 + B * 27 * H * W * 4
