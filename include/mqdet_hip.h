@@ -118,9 +118,10 @@ int mq_vlfuse_i2t_fwd(const void* v_ln, const void* kf, const void* vo, const fl
  *   caller as one folded [768, 2048] weight. */
 long mq_vlfuse_t2i_workspace_bytes(int B, int T, int nsplit);
 int mq_vlfuse_t2i_fwd(const void* kf, const void* v_ln, const int* kv_len, const unsigned char* key_mask, long key_mask_bs,
-                      void* workspace, void* out, int B, int N, int T, int heads, int nsplit, int max_kv, float clamp, void* stream);
+                      void* workspace, void* out, int B, int N, int T, int heads, int nsplit, int max_kv, float clamp, int variant,
+                      void* stream);
 /* max_kv: host-side upper bound of kv_len (0 = T): sizes the grid -- the live (head, 16-row block) units of an image are packed
- *   densely over the waves of its workgroups. */
+ *   densely over the waves of its workgroups.  variant: 0 (values >= 100: ablation timings of tools/microbench.py, results undefined). */
 
 /* Row LayerNorm with the residual add fused in, mixed-precision streams, fp32 statistics; C % 8 == 0, C <= 3072.
  *   s = x (+ res);  x is fp32 when x_f32 != 0 else fp16, res likewise (res_f32); res may be NULL.

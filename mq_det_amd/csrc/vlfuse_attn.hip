@@ -744,7 +744,8 @@ struct T2IParams {
 };
 namespace { constexpr int WS_LD = VD + 4; }               // 260 floats: rows stay 16-byte aligned
 
-template <int QB, bool KM>
+// ABL: ablation timings as for vlfuse_i2t_kernel (bit 0 no tile loads, 1 no LDS commits, 2 no softmax arithmetic, 3 no fragment reads / MFMAs)
+template <int QB, bool KM, int ABL = 0>
 __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p) {
   constexpr int NTH = 2048 / (QB * 4), WR = 16 * QB;        // threads per workgroup (512 / 256), query rows per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -797,10 +798,14 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
 
   const half_t* vb = p.v + (long)b * p.N * VD;
   TileRegs<NTH> slot[2];
+  if constexpr (ABL != 0) {
+#pragma unroll
+    for (int i = 0; i < 2048 / NTH; ++i) { slot[0].r[i] = zero8(); slot[1].r[i] = zero8(); }
+  }
   auto issue = [&](auto SLOT, int pos) {
     constexpr int sl = decltype(SLOT)::value;
     const int t = t0 + min(pos, max(nt - 1, 0));
-    tile_issue(slot[sl], vb, t * TK, p.N - 1, tid);
+    if constexpr (!(ABL & 1)) tile_issue(slot[sl], vb, t * TK, p.N - 1, tid);
   };
   constexpr float THR = 8.0f;     // deferred rescale: O / l are rescaled only when a row max grows by more than THR
   auto body = [&](auto PAR, int pos) {
@@ -810,7 +815,13 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
     if (pos < nt && wave_live) {
       const half_t* tile = tiles + par * TILE;
       float4_ s[4][QB];
-      qk_tile<false, QB>(tile, qf, nullptr, s, l15, lg);
+      if constexpr (!(ABL & 8)) qk_tile<false, QB>(tile, qf, nullptr, s, l15, lg);
+      else {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) s[nb][qb] = (float4_){0.f, 0.f, 0.f, 0.f};
+      }
       const int key0 = (t0 + pos) * TK;
       unsigned km[4] = {0u, 0u, 0u, 0u};                   // padding flags of this lane's 4 x 4 keys (GroundingDINO batches)
       if constexpr (KM) {
@@ -861,16 +872,22 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
         for (int st = 0; st < 2; ++st)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float e0 = __expf(s[2 * st][qb][r] - m[qb]);          // <= e^THR; exact after the final 1/l
-            const float e1 = __expf(s[2 * st + 1][qb][r] - m[qb]);
+            const float e0 = (ABL & 4) ? s[2 * st][qb][r] : __expf(s[2 * st][qb][r] - m[qb]);          // <= e^THR; exact after the final 1/l
+            const float e1 = (ABL & 4) ? s[2 * st + 1][qb][r] : __expf(s[2 * st + 1][qb][r] - m[qb]);
             lsum[qb] += e0 + e1;
             pf[st][qb][r] = (half_t)e0;
             pf[st][qb][4 + r] = (half_t)e1;
           }
-      pv_tile(tile, pf, o, l15, lg);                       // the SAME tile: values = keys
+      if constexpr (!(ABL & 8)) pv_tile(tile, pf, o, l15, lg);                       // the SAME tile: values = keys
+      else {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[0][qb][r] += (float)pf[0][qb][r] + (float)pf[1][qb][4 + r];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
-    tile_commit(slot[par ^ 1], tiles + (par ^ 1) * TILE, tid);
+    if constexpr (!(ABL & 2)) tile_commit(slot[par ^ 1], tiles + (par ^ 1) * TILE, tid);
     __syncthreads();
   };
   issue(S0{}, 0);
@@ -943,7 +960,7 @@ extern "C" long mq_vlfuse_t2i_workspace_bytes(int B, int T, int nsplit) {
 // Text side of VLFuse (always through the split workspace + combine, nsplit >= 1).  See include/mqdet_hip.h.
 extern "C" int MQ_SYM(mq_vlfuse_t2i_fwd)(const void* kf, const void* v_ln, const int* kv_len, const unsigned char* key_mask, long key_mask_bs,
                                  void* workspace, void* out, int B, int N, int T, int heads, int nsplit, int max_kv, float clamp,
-                                 void* stream) {
+                                 int variant, void* stream) {
   if (B <= 0 || T <= 0) return 0;
   if (N < 1 || workspace == nullptr || heads < 1 || heads > VH) return -1;
   if (key_mask && ((key_mask_bs % 4) || key_mask_bs < (long)((N + TK - 1) / TK) * TK)) return -3;
@@ -966,6 +983,25 @@ extern "C" int MQ_SYM(mq_vlfuse_t2i_fwd)(const void* kf, const void* v_ln, const
   const int groups = B * nsplit, members = (heads * ((rows + p.wr - 1) / p.wr) + (128 / p.wr) - 1) / (128 / p.wr);
   p.members = members;
   const dim3 grid((unsigned)(8 * ((groups + 7) / 8) * members));
+#ifndef MQ_BF16
+  if (variant >= 100 && !key_mask) {                                       // ablation timings (tools/microbench.py; results are garbage)
+    hipStream_t st = (hipStream_t)stream;
+    switch (variant - 100) {
+#define MQ_T2I_ABL(A_)                                                                                                              \
+      case A_: {                                                                                                                    \
+        hipError_t e = hipFuncSetAttribute((const void*)vlfuse_t2i_kernel<1, false, A_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        if (e != hipSuccess) return (int)e;                                                                                         \
+        hipLaunchKernelGGL((vlfuse_t2i_kernel<1, false, A_>), grid, dim3(512), smem, st, p);                                        \
+        break;                                                                                                                      \
+      }
+      MQ_T2I_ABL(1) MQ_T2I_ABL(3) MQ_T2I_ABL(4) MQ_T2I_ABL(8) MQ_T2I_ABL(11) MQ_T2I_ABL(15)
+#undef MQ_T2I_ABL
+      default: return -4;
+    }
+    MQ_CHECK_LAUNCH();
+    return 0;
+  }
+#endif
   if (vlfuse_qb() == 1) {
     if (key_mask) hipLaunchKernelGGL((vlfuse_t2i_kernel<1, true>), grid, dim3(512), smem, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((vlfuse_t2i_kernel<1, false>), grid, dim3(512), smem, (hipStream_t)stream, p);

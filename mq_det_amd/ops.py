@@ -24,7 +24,7 @@ _SIGNATURES = {
     "mq_gcp_gate_residual_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _l, _i, _i, _vp]),
     "mq_vlfuse_i2t_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "mq_vlfuse_t2i_workspace_bytes": (_l, [_i, _i, _i]),
-    "mq_vlfuse_t2i_fwd": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "mq_vlfuse_t2i_fwd": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "mq_layernorm_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
     "mq_layernorm2_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
     "mq_patch_merge_ln_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
@@ -367,7 +367,7 @@ def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.
     return out
 
 
-def vlfuse_t2i(kf, v_ln, nsplit, clamp=50000.0, kv_len=None, key_mask=None, max_kv=0):
+def vlfuse_t2i(kf, v_ln, nsplit, clamp=50000.0, kv_len=None, key_mask=None, max_kv=0, variant=0):
     """VLFuse text side (mq_vlfuse_t2i_fwd).  kf [B,heads,T,256] (queries), v_ln [B,N,256] (keys = values) fp16
     -> [B,T,heads*256] fp16 = softmax_n(clamp(kf.v_ln)) v_ln per head.  kv_len [B] int32: 16-row blocks of pure padding
     (rows >= kv_len[b]) are skipped and returned as zeros; max_kv: host-side bound of kv_len (0 = T), sizes the grid.  key_mask uint8 [B, >= 64*ceil(N/64)] (row stride % 4 == 0):
@@ -392,7 +392,7 @@ def vlfuse_t2i(kf, v_ln, nsplit, clamp=50000.0, kv_len=None, key_mask=None, max_
     out = torch.empty(B, T, Hh * 256, dtype=kf.dtype, device=kf.device)
     with _timed(f"vlfuse_t2i_n{N}_t{T}_s{nsplit}"):
         _chk(_fn(lib, "mq_vlfuse_t2i_fwd", kf)(_ptr(kf), _ptr(v_ln), _ptr(kv_len), _ptr(key_mask), km_bs, _ptr(ws), _ptr(out), B, N, T, Hh,
-                                   nsplit, int(max_kv), float(clamp), _stream()), "mq_vlfuse_t2i_fwd")
+                                   nsplit, int(max_kv), float(clamp), int(variant), _stream()), "mq_vlfuse_t2i_fwd")
     return out
 
 

@@ -376,7 +376,7 @@ def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.
     return (v_ln.float() + out_bias.float() + o).to(v_ln.dtype)
 
 
-def vlfuse_t2i(kf, v_ln, nsplit, clamp=50000.0, kv_len=None, key_mask=None, max_kv=0):
+def vlfuse_t2i(kf, v_ln, nsplit, clamp=50000.0, kv_len=None, key_mask=None, max_kv=0, variant=0):
     B, N, C = v_ln.shape
     T = kf.shape[2]
     s = torch.einsum("bhtc,bnc->bhtn", kf.float(), v_ln.float())

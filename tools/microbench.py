@@ -151,7 +151,7 @@ def vlfuse(dev, g, out):
             visited = -(-live // 16) * 16
             fl = 4.0 * B * 8 * N * visited * 256
             nb = v.numel() * 2 * 2 + kf.numel() * 2 * 2
-            name = {1: "first kernel", 2: "pair-split", 3: "first kernel with Q in registers (129 .. 160 keys)"}.get(variant, f"first kernel, ablation bits {variant - 100:04b} (loads|commits|softmax|mfma removed)")
+            name = {1: "first kernel", 2: "pair-split", 3: "first kernel with Q in registers (129 .. 160 keys)"}.get(variant, f"first kernel, ablation bits {variant - 100:04b} (mfma|softmax|commits|loads removed)")
             out.append({"kernel": f"vlfuse_i2t {name} B={B} N={N} live keys={live}", "ms": round(ms, 4),
                         "TFLOPs": round(fl / ms / 1e9, 1), "frac_of_mfma_peak": round(fl / ms / 1e9 / 2500, 3),
                         "algorithmic_GBs": round(nb / ms / 1e6, 1), "max_abs_diff_vs_first": round(float((o - ref).abs().max()), 6)})
@@ -212,6 +212,11 @@ def vlfuse_text(dev, g, out):
             fl = 4.0 * B * 8 * (-(-live // 16) * 16) * N * 256
             out.append({"kernel": f"vlfuse_t2i + combine, {name} (nsplit={ns}) B={B} N={N} live rows={live}", "ms": round(ms, 4),
                         "TFLOPs": round(fl / ms / 1e9, 1), "frac_of_mfma_peak": round(fl / ms / 1e9 / 2500, 3)})
+        if live == 141:
+            ns = _nsplit_t2i(B, 8, live, tiles)
+            for abl in (1, 3, 4, 8, 11, 15):
+                ms = timeit(lambda: ops.vlfuse_t2i(kf, v, ns, kv_len=kv, max_kv=live, variant=100 + abl))
+                out.append({"kernel": f"vlfuse_t2i + combine, ablation bits {abl:04b} (mfma|softmax|commits|loads removed) nsplit={ns} live rows={live}", "ms": round(ms, 4)})
 
 
 def window(dev, g, out):
