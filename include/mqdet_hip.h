@@ -101,9 +101,8 @@ int mq_gcp_gate_residual_fwd(const void* sup, const void* h, const void* w2, con
 int mq_vlfuse_i2t_fwd(const void* v_ln, const void* kf, const void* vo, const float* bias, const int* kv_len,
                       const void* out_bias, void* out, int B, int N, int T, int heads, int max_kv, float clamp, int variant,
                       void* stream);
-/* variant: 2 = pair-split kernel (two waves share 32 query rows: one takes every second 16-key block of the logits and half of
- *   the 256 output channels, Q fragments in registers; softmax statistics and P cross the pair through LDS -- half the LDS
- *   fragment reads of variant 1); 1 = first kernel (a wave owns 16 query rows).  Same results up to fp32 summation order. */
+/* variant: 0 = default; 1 = Q tile in LDS for every caption longer than 128 tokens (A/B: by default 129 .. 160 keys keep the Q fragments
+ *   in registers); >= 100: ablation timings of tools/microbench.py (results undefined). */
 
 /* VLFuse text side: keys = values = image tokens, split over the keys (nsplit >= 1) + merge:
  *   out[b,t,h*256:(h+1)*256] = sum_n softmax_n( clamp(kf[b,h,t,:] . v_ln[b,n,:], +-clamp) ) v_ln[b,n,:]

@@ -67,6 +67,16 @@ struct I2TParams {
 // half as many MFMAs, which the LDS still sustains).
 template <int NTH> struct TileRegs { half8 r[2048 / NTH]; };
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_u_impl(F& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for_u_impl<I + 1, N>(f);
+  }
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for_u(F f) { static_for_u_impl<0, N>(f); }
+
 // NCH: chunk rounds to do -- round i covers tile rows [i * NTH / 32, (i + 1) * NTH / 32): a tile whose tail rows nobody reads
 // (the last key / value tile of a caption that ends inside it) is staged only as far as it is read
 template <int NTH, int NCH = 2048 / NTH>
@@ -384,281 +394,11 @@ static int launch_i2t(const I2TParams& p, hipStream_t stream) {
   return 0;
 }
 
-// ---- image side, second generation (round 3): PAIR-SPLIT.
-// What the counters said about vlfuse_i2t_kernel<3, 1, 1> (profiles/r03_call4_sq_summary.txt, 409 us per launch, 151 k cycles per
-// workgroup = 3.1 k per tile step): 2 LDS instructions per MFMA.  A wave owns 16 query rows and reads EVERY key / value fragment of
-// every tile for them (and its Q fragments from LDS, the logits having taken the registers): 176 KB of LDS reads per wave and head,
-// 11 MB per workgroup -- 88 k cycles of the CU's 128 B / clk LDS port against 39 k cycles of MFMA issue.  The kernel is bound by LDS
-// bandwidth, and the reuse of a fragment read is the number of 16-query blocks a wave holds, which the registers cap (192 logits +
-// 256 outputs in fp32 per query row = 7 VGPRs per row).
-// Here two waves share 32 query rows and split the OTHER dimension of each product: wave (pair, half) computes the logits of every
-// second 16-key block (blocks half, half + 2 of each tile) for all 32 rows, and the outputs of 128 of the 256 channels for all 32 rows.
-// Per wave: the same 48 logit + 64 output accumulator registers and the same MFMA count as before, Q fragments back in registers
-// (64), and HALF the fragment reads (each feeds two MFMAs).  The price is an exchange through LDS per head: the pair's softmax
-// statistics (max, sum per row: one value pair per lane) and the probabilities P (fp16, written as ready-made B fragments:
-// 10 KB per pair and head) -- one extra barrier per head.  Softmax across the pair: each wave normalises against its OWN row maximum
-// m_w (e = exp(s - m_w), l_w = sum e), publishes (m_w, l_w), and scales by exp(m_w - m) / (l_0 exp(m_0 - m) + l_1 exp(m_1 - m)),
-// m = max(m_0, m_1): one exchange instead of two.  A wave whose keys are all masked has m_w = -1e30: its factor is exp(-1e30 - m) = 0.
-template <int NT, int NBL>
-__global__ __launch_bounds__(512) void vlfuse_i2t2_kernel(I2TParams p) {
-  constexpr int NTH = 512;
-  constexpr int PFR = 512;                                 // halfs per P fragment block (64 lanes x 8)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  half_t* tiles = (half_t*)smem;                           // [2][TK][KS]
-  half_t* Pb = tiles + 2 * TILE;                           // [4 pairs][NT][2 st][2 qb][64 lanes][8]: P^T B fragments
-  float* bias_s = (float*)(Pb + 4 * NT * 4 * PFR);         // [8][NT*64]
-  float2_* stat = (float2_*)(bias_s + VH * NT * TK);       // [8 waves][2 qb][16]: (row max, row sum) of the wave's keys
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l15 = lane & 15, lg = lane >> 4;
-  const int pr = wave >> 1, half = wave & 1;
-  const int qtiles = (p.N + BM - 1) / BM;
-  const int seq = blockIdx.x >> 3;
-  const int b = (seq / qtiles) * 8 + (blockIdx.x & 7);     // XCD-aware order, as vlfuse_i2t_kernel
-  if (b >= p.B) return;
-  const int qtile = seq % qtiles;
-  const int row0 = qtile * BM + pr * 32;                   // the pair's 32 query rows
-
-  const int kv_eff = p.kv_len ? max(1, min(p.T, p.kv_len[b])) : p.T;
-  for (int i = tid; i < p.H * NT * TK; i += NTH) {
-    const int h = i / (NT * TK), t = i % (NT * TK);
-    float v = MQ_NEG_BIG;
-    if (t < kv_eff) v = p.bias ? p.bias[((long)b * p.H + h) * p.T + t] : 0.f;
-    bias_s[i] = v;
-  }
-
-  const half_t* vb = p.v + (long)b * p.N * VD;
-  half8 qf[2][8];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const int row = min(row0 + qb * 16 + l15, p.N - 1);
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = *(const half8*)(vb + (long)row * VD + kk * 32 + lg * 8);
-  }
-  float4_ o[8][2];                                         // O^T[channel block half * 8 + db][query block qb]
-#pragma unroll
-  for (int db = 0; db < 8; ++db)
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) o[db][qb] = (float4_){0.f, 0.f, 0.f, 0.f};
-
-  constexpr int PER_HEAD = 2 * NT;
-  const int U = p.H * PER_HEAD;
-  TileRegs<NTH> slot;
-  auto issue = [&](int u) {
-    u = min(u, U - 1);
-    const int h = u / PER_HEAD, j = u % PER_HEAD;
-    const half_t* src = (j < NT ? p.kf : p.vo) + ((long)b * p.H + h) * p.T * VD;
-    tile_issue(slot, src, (j < NT ? j : j - NT) * TK, p.T - 1, tid);
-  };
-  auto begin = [&](int u) {
-    issue(u + 1);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto end = [&](auto POS) {
-    constexpr int par = decltype(POS)::value & 1;
-    __builtin_amdgcn_sched_barrier(0);
-    tile_commit(slot, tiles + (par ^ 1) * TILE, tid);
-    __syncthreads();
-  };
-  issue(0);
-  tile_commit(slot, tiles, tid);
-  __syncthreads();
-
-  half_t* Pp = Pb + pr * (NT * 4 * PFR);                   // this pair's P fragments
-  for (int h = 0; h < p.H; ++h) {
-    const int u0 = h * PER_HEAD;
-    float4_ s[NT][2][2];                                   // logits of key block nb = half + 2 i of tile j, query block qb: s[j][i][qb]
-    float mw[2], lw[2];
-    auto qk_step = [&](auto J) {
-      constexpr int j = decltype(J)::value;
-      constexpr int NI = (j == NT - 1) ? (NBL + 1) / 2 : 2;         // 32-key steps of this tile with a live key (a dead block of the
-      begin(u0 + j);                                                // second wave is computed and masked: the pair stays in step)
-      const half_t* tile = tiles + (j & 1) * TILE + (half * 16 + l15) * KS + lg * 8;
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) s[j][i][qb] = (float4_){0.f, 0.f, 0.f, 0.f};
-      // fragment reads run PD steps ahead of their MFMAs through a small ring; a scheduling fence per step keeps the compiler from
-      // hoisting all 16 reads of the tile to the top (64 VGPRs this kernel does not have)
-      constexpr int PD = 2;
-      half8 kf[PD + 1][NI];
-#pragma unroll
-      for (int kk = 0; kk < PD; ++kk)
-#pragma unroll
-        for (int i = 0; i < NI; ++i) kf[kk][i] = *(const half8*)(tile + i * 32 * KS + kk * 32);
-#pragma unroll
-      for (int kk = 0; kk < VD / 32; ++kk) {
-        if (kk + PD < VD / 32) {
-#pragma unroll
-          for (int i = 0; i < NI; ++i) kf[(kk + PD) % (PD + 1)][i] = *(const half8*)(tile + i * 32 * KS + (kk + PD) * 32);
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-          for (int qb = 0; qb < 2; ++qb) s[j][i][qb] = mfma16(kf[kk % (PD + 1)][i], qf[qb][kk], s[j][i][qb]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const float4_ kb = *(const float4_*)(bias_s + (h * NT + j) * TK + (half + 2 * i) * 16 + 4 * lg);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool masked = kb[r] < -1.0e29f;
-#pragma unroll
-          for (int qb = 0; qb < 2; ++qb) {
-            float v = s[j][i][qb][r] + kb[r];
-            if (p.clamp > 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
-            s[j][i][qb][r] = masked ? MQ_NEG_BIG : v;
-          }
-        }
-      }
-      if constexpr (j == NT - 1) {
-        // ---- this wave's half of the softmax: e = exp(s - m_w) in place, (m_w, l_w) published before the step's barrier
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-          float mx = MQ_NEG_BIG;
-#pragma unroll
-          for (int jj = 0; jj < NT; ++jj)
-#pragma unroll
-            for (int i = 0; i < (jj == NT - 1 ? (NBL + 1) / 2 : 2); ++i)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[jj][i][qb][r]);
-          mx = fmaxf(mx, __shfl_xor(mx, 16));
-          mx = fmaxf(mx, __shfl_xor(mx, 32));
-          float sum = 0.f;
-#pragma unroll
-          for (int jj = 0; jj < NT; ++jj)
-#pragma unroll
-            for (int i = 0; i < (jj == NT - 1 ? (NBL + 1) / 2 : 2); ++i)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float e = __expf(s[jj][i][qb][r] - mx);
-                s[jj][i][qb][r] = e;
-                sum += e;
-              }
-          sum += __shfl_xor(sum, 16);
-          sum += __shfl_xor(sum, 32);
-          mw[qb] = mx;
-          lw[qb] = sum;
-          if (lg == 0) stat[(wave * 2 + qb) * 16 + l15] = (float2_){mx, sum};
-        }
-      }
-      end(J);
-    };
-    qk_step(std::integral_constant<int, 0>{});
-    if constexpr (NT > 1) qk_step(std::integral_constant<int, 1>{});
-    if constexpr (NT > 2) qk_step(std::integral_constant<int, 2>{});
-    if constexpr (NT > 3) qk_step(std::integral_constant<int, 3>{});
-
-    // ---- the pair's statistics -> this wave's scale; P = e * scale as fp16 into the pair's fragment blocks.  P^T fragment (j, st, qb):
-    // lane (lg, query l15) holds k-slots 0..3 = keys 4 lg + r of block 2 st, 4..7 = the same of block 2 st + 1 -- block half + 2 i is
-    // (st = i, slots 4 half ..): every lane writes 8 bytes per (j, i, qb), the partner the other 8
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      const float2_ o2 = stat[((wave ^ 1) * 2 + qb) * 16 + l15];
-      const float m = fmaxf(mw[qb], o2[0]);
-      const float aw = __expf(mw[qb] - m), ap = __expf(o2[0] - m);
-      const float scale = aw / (lw[qb] * aw + o2[1] * ap);
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int i = 0; i < ((j == NT - 1) ? (NBL + 1) / 2 : 2); ++i) {
-          half4 pv4;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) pv4[r] = (half_t)(s[j][i][qb][r] * scale);
-          *(half4*)(Pp + (((j * 2 + i) * 2 + qb) * 64 + lane) * 8 + half * 4) = pv4;
-        }
-    }
-    __syncthreads();
-
-    // ---- O^T[128 channels of this wave] += Vo_h^T P_h^T over the value tiles
-    auto pv_step = [&](auto J) {
-      constexpr int j = decltype(J)::value;
-      constexpr int STL = (j == NT - 1) ? (NBL + 1) / 2 : 2;
-      using POS = std::integral_constant<int, NT + j>;
-      begin(u0 + NT + j);
-      half8 pf[STL][2];
-#pragma unroll
-      for (int st = 0; st < STL; ++st)
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) pf[st][qb] = *(const half8*)(Pp + (((j * 2 + st) * 2 + qb) * 64 + lane) * 8);
-      const half_t* tile = tiles + ((NT + j) & 1) * TILE + half * 128;
-#pragma unroll
-      for (int st = 0; st < STL; ++st) {
-        const half_t* base = tile + (st * 32 + 4 * lg + (l15 >> 2)) * KS + (l15 & 3) * 4;
-        constexpr int PD = 3;
-        half4 lo[PD + 1], hi[PD + 1];
-#pragma unroll
-        for (int db = 0; db < PD; ++db) { lo[db] = lds_read_tr16(base + db * 16); hi[db] = lds_read_tr16(base + 16 * KS + db * 16); }
-#pragma unroll
-        for (int db = 0; db < 8; ++db) {
-          if (db + PD < 8) {
-            lo[(db + PD) % (PD + 1)] = lds_read_tr16(base + (db + PD) * 16);
-            hi[(db + PD) % (PD + 1)] = lds_read_tr16(base + 16 * KS + (db + PD) * 16);
-          }
-          half8 a;
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) { a[jj] = lo[db % (PD + 1)][jj]; a[4 + jj] = hi[db % (PD + 1)][jj]; }
-#pragma unroll
-          for (int qb = 0; qb < 2; ++qb) o[db][qb] = mfma16(a, pf[st][qb], o[db][qb]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      end(POS{});
-    };
-    pv_step(std::integral_constant<int, 0>{});
-    if constexpr (NT > 1) pv_step(std::integral_constant<int, 1>{});
-    if constexpr (NT > 2) pv_step(std::integral_constant<int, 2>{});
-    if constexpr (NT > 3) pv_step(std::integral_constant<int, 3>{});
-  }
-
-  // ---- epilogue: the pair's O^T halves -> LDS (row = query), + residual LN(v) + out-proj bias, 16-byte coalesced stores
-  constexpr int OS = VD + 8;
-  half_t* Os = tiles + pr * (32 * OS);                     // [4 pairs][32][OS] aliases the tiles (all waves passed the last barrier)
-#pragma unroll
-  for (int db = 0; db < 8; ++db)
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      half4 v4;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v4[r] = (half_t)o[db][qb][r];
-      *(half4*)(Os + (qb * 16 + l15) * OS + (half * 8 + db) * 16 + 4 * lg) = v4;
-    }
-  __syncthreads();
-  half_t* ob = p.out + (long)b * p.N * VD;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = lane + i * 64;
-    const int rr = half * 16 + (c >> 5), ch = c & 31;
-    const int row = row0 + rr;
-    if (row < p.N) {
-      const half8 a = *(const half8*)(Os + rr * OS + ch * 8);
-      const half8 res = *(const half8*)(vb + (long)row * VD + ch * 8);
-      const half8 bb = *(const half8*)(p.obias + ch * 8);
-      half8 y;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) y[j] = (half_t)((float)a[j] + (float)res[j] + (float)bb[j]);
-      *(half8*)(ob + (long)row * VD + ch * 8) = y;
-    }
-  }
-}
-
-template <int NT, int NBL>
-static int launch_i2t2(const I2TParams& p, hipStream_t stream) {
-  constexpr size_t smem = (size_t)(2 * TILE + 4 * NT * 4 * 512) * sizeof(half_t) + (size_t)VH * NT * TK * sizeof(float) + (size_t)8 * 2 * 16 * 2 * sizeof(float);
-  static_assert(4 * 32 * (VD + 8) <= 2 * TILE, "O staging must fit in the tiles");
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)vlfuse_i2t2_kernel<NT, NBL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  const int qtiles = (p.N + BM - 1) / BM;
-  hipLaunchKernelGGL((vlfuse_i2t2_kernel<NT, NBL>), dim3((unsigned)(8 * ((p.B + 7) / 8) * qtiles)), dim3(512), smem, stream, p);
-  MQ_CHECK_LAUNCH();
-  return 0;
-}
+// (Round 3 built a PAIR-SPLIT variant of the image side: two waves share 32 query rows, each computes the logits of every second
+// 16-key block and the outputs of half of the 256 channels -- Q fragments in registers, half the LDS fragment reads per MFMA,
+// softmax statistics and P exchanged through LDS.  Measured (profiles/r03_call{5,6,8}_microbench_vlfuse*.json): 1.5x slower with three
+// key tiles (Q + logits + outputs exceed 256 VGPRs: 92 spills), +4.6 % with two -- and no better than this kernel once its last tile
+// was staged only as far as it is read.  Halving the LDS reads alone does not pay here; removed.)
 
 // waves x rows shape of the text-side kernel: 8 waves x 16 query rows (default) or 4 waves x 32 (MQ_VLFUSE_QB=2, A/B switch)
 static int vlfuse_qb() {
@@ -680,22 +420,6 @@ extern "C" int MQ_SYM(mq_vlfuse_i2t_fwd)(const void* v_ln, const void* kf, const
   const int nt = (kv + TK - 1) / TK;
   const int nbl = min(4, max(1, (kv - (nt - 1) * TK + 15) / 16));       // live 16-key blocks of the last tile
   hipStream_t st = (hipStream_t)stream;
-  if (variant == 2) {                                                      // pair-split kernel
-#define MQ_I2T2(NT_)                                                       \
-    switch (nbl) {                                                         \
-      case 1: return launch_i2t2<NT_, 1>(p, st);                           \
-      case 2: return launch_i2t2<NT_, 2>(p, st);                           \
-      case 3: return launch_i2t2<NT_, 3>(p, st);                           \
-      default: return launch_i2t2<NT_, 4>(p, st);                          \
-    }
-    switch (nt) {
-      case 1: MQ_I2T2(1)
-      case 2: MQ_I2T2(2)
-      case 3: MQ_I2T2(3)
-      default: MQ_I2T2(4)
-    }
-#undef MQ_I2T2
-  }
 #ifndef MQ_BF16
   if (variant >= 100 && nt == 3 && nbl == 1) {                             // ablation timings (see vlfuse_i2t_kernel)
     switch (variant - 100) {
@@ -709,7 +433,7 @@ extern "C" int MQ_SYM(mq_vlfuse_i2t_fwd)(const void* v_ln, const void* kf, const
     }
   }
 #endif
-  if (variant == 3 && nt == 3 && nbl <= 2)                                 // Q in registers for 129 .. 160 keys
+  if (variant != 1 && nt == 3 && nbl <= 2)                                 // Q in registers for 129 .. 160 keys (variant 1: Q tile in LDS, A/B)
     return nbl == 1 ? launch_i2t<3, 1, 1, 0, true>(p, st) : launch_i2t<3, 1, 2, 0, true>(p, st);
 #define MQ_I2T(NT_)                                                        \
   switch (nbl) {                                                           \
@@ -797,10 +521,16 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
   for (int qb = 0; qb < QB; ++qb) { m[qb] = MQ_NEG_BIG; lsum[qb] = 0.f; }   // per query column (m replicated over lg, lsum a per-lane partial)
 
   const half_t* vb = p.v + (long)b * p.N * VD;
-  TileRegs<NTH> slot[2];
+  // register prefetch ring: tiles pos + 1 .. pos + RS are in flight while tile pos is on the MFMAs.  The ablation run of round 3
+  // (profiles/r03_call8_microbench_vlfuse.json) takes a third off the launch when the tile loads are removed, with two slots: a tile
+  // step is shorter than the loaded L2 latency.  16 registers per slot at 512 threads: three slots.
+  constexpr int RS = QB == 1 ? 3 : 2;
+  TileRegs<NTH> slot[RS];
   if constexpr (ABL != 0) {
 #pragma unroll
-    for (int i = 0; i < 2048 / NTH; ++i) { slot[0].r[i] = zero8(); slot[1].r[i] = zero8(); }
+    for (int r = 0; r < RS; ++r)
+#pragma unroll
+      for (int i = 0; i < 2048 / NTH; ++i) slot[r].r[i] = zero8();
   }
   auto issue = [&](auto SLOT, int pos) {
     constexpr int sl = decltype(SLOT)::value;
@@ -808,9 +538,9 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
     if constexpr (!(ABL & 1)) tile_issue(slot[sl], vb, t * TK, p.N - 1, tid);
   };
   constexpr float THR = 8.0f;     // deferred rescale: O / l are rescaled only when a row max grows by more than THR
-  auto body = [&](auto PAR, int pos) {
-    constexpr int par = decltype(PAR)::value;
-    issue(PAR, pos + 2);                                   // the slot of tile pos was committed one step ago
+  auto body = [&](auto PAR, auto SL, int pos) {            // PAR = pos % 2 (LDS buffer), SL = pos % RS (ring slot that held tile pos)
+    constexpr int par = decltype(PAR)::value, sl = decltype(SL)::value;
+    issue(SL, pos + RS);                                   // the slot of tile pos was committed one step ago
     __builtin_amdgcn_sched_barrier(0);
     if (pos < nt && wave_live) {
       const half_t* tile = tiles + par * TILE;
@@ -887,16 +617,24 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!(ABL & 2)) tile_commit(slot[par ^ 1], tiles + (par ^ 1) * TILE, tid);
+    if constexpr (!(ABL & 2)) tile_commit(slot[(sl + 1) % RS], tiles + (par ^ 1) * TILE, tid);
     __syncthreads();
   };
   issue(S0{}, 0);
   issue(S1{}, 1);
+  if constexpr (RS == 3) issue(std::integral_constant<int, 2>{}, 2);
   tile_commit(slot[0], tiles, tid);
   __syncthreads();
-  for (int pos = 0; pos < nt; pos += 2) {
-    body(S0{}, pos);
-    body(S1{}, pos + 1);
+  constexpr int U = RS == 3 ? 6 : 2;                       // lcm(2, RS) steps: every (buffer, slot) combination once
+  for (int pos = 0; pos < nt; pos += U) {
+    bool done = false;
+    static_for_u<U>([&](auto uc) __attribute__((always_inline)) {
+      constexpr int u = decltype(uc)::value;
+      if (!done) {
+        body(std::integral_constant<int, u & 1>{}, std::integral_constant<int, u % RS>{}, pos + u);
+        done = pos + u + 1 >= nt;                          // workgroup-uniform: every wave runs the same number of steps
+      }
+    });
   }
 
   // ---- partials -> workspace (O^T: lane owns 4 consecutive d of one query row -> one 16-byte store)

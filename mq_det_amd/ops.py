@@ -78,8 +78,8 @@ KERNEL_DEFAULTS = {
     "SWIN_MLP2_FLAGS": -1,       # mq_swin_mlp2_fwd flags: -1 = per width (table GELU at C = 96 / 384, erf at 192; tail split on); else bit 1 = table
                                  # GELU, bit 0 = no tail split, bit 2 = everything through the tail kernel
     "DYRELU_IN_LN": 1,           # 1: the DYReLU of fusion layers 0 .. L-2 is applied by the next layer's LayerNorm (mq_dyrelu_ln_fwd); 0: own pass
-    "VLFUSE_I2T_VARIANT": -1,    # mq_vlfuse_i2t_fwd: 1 = first kernel, 2 = pair-split kernel (round 3), -1 = pair-split up to 128 text keys
-                                 # (two key tiles: +4.6 % there; with three or four it spills 92 VGPRs and loses 1.5x -- GPU call 5)
+    "VLFUSE_I2T_VARIANT": 0,     # mq_vlfuse_i2t_fwd: 0 = Q fragments in registers where they fit (129 .. 160 keys: 0.428 -> 0.370 ms per launch),
+                                 # 1 = Q tile in LDS for every caption longer than 128 tokens
     "ALIGN_FUSED": 1,            # 1: mq_align_fused_fwd (heads + alignment + scoring, logits never written); 0: bmm + 5 GEMMs + 5 x mq_align_scores_fwd
 }
 KERNELS = dict(KERNEL_DEFAULTS)
@@ -357,9 +357,6 @@ def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.
         assert kv_len.dtype == torch.int32 and kv_len.numel() == B and kv_len.is_contiguous()
     out = torch.empty_like(v_ln)
     variant = KERNELS["VLFUSE_I2T_VARIANT"] if variant is None else int(variant)
-    if variant < 0:
-        keys = min(int(max_kv), T) if (kv_len is not None and max_kv > 0) else T
-        variant = 2 if keys <= 128 else 1
     with _timed(f"vlfuse_i2t_n{N}_t{T}"):
         _chk(_fn(lib, "mq_vlfuse_i2t_fwd", v_ln)(_ptr(v_ln), _ptr(kf), _ptr(vo), _ptr(bias), _ptr(kv_len), _ptr(out_bias), _ptr(out),
                                    B, N, T, Hh, int(max_kv), float(clamp), int(variant),

@@ -132,7 +132,7 @@ def align(dev, g, out):
 
 def vlfuse(dev, g, out):
     # ---- VLFuse image side at the bench shape (B = 8, N = 22 400 image tokens, 8 heads x 256, T = 256 with 141 / 81 / 256 live keys):
-    # the first kernel (a wave owns 16 query rows) against the pair-split kernel.  flops = 4 * B * heads * N * keys_visited * 256
+    # Q tile in LDS against Q fragments in registers (129 .. 160 keys), and the ablation variants.  flops = 4 * B * heads * N * keys_visited * 256
     B, N, T = 8, 22400, 256
     v = torch.randn(B, N, 256, generator=g).half().to(dev)
     kf = (torch.randn(B, 8, T, 256, generator=g) / 8).half().to(dev)
@@ -143,7 +143,7 @@ def vlfuse(dev, g, out):
         kv = torch.full((B,), live, dtype=torch.int32, device=dev)
         ref = None
         # 101 ... 115: the first kernel WITHOUT global tile loads (bit 0) / LDS commits (1) / softmax (2) / fragment reads + MFMAs (3)
-        for variant in (1, 2, 3) + ((101, 103, 104, 108, 111, 115) if live == 141 else ()):
+        for variant in (1, 0) + ((101, 103, 104, 108, 111, 115) if live == 141 else ()):
             fn = lambda variant=variant: ops.vlfuse_i2t(v, kf, vo, bias, ob, kv_len=kv, max_kv=live, variant=variant)  # noqa: E731
             ms = timeit(fn)
             o = fn().float()
@@ -151,7 +151,7 @@ def vlfuse(dev, g, out):
             visited = -(-live // 16) * 16
             fl = 4.0 * B * 8 * N * visited * 256
             nb = v.numel() * 2 * 2 + kf.numel() * 2 * 2
-            name = {1: "first kernel", 2: "pair-split", 3: "first kernel with Q in registers (129 .. 160 keys)"}.get(variant, f"first kernel, ablation bits {variant - 100:04b} (mfma|softmax|commits|loads removed)")
+            name = {1: "Q tile in LDS beyond 128 keys", 0: "default (Q in registers for 129 .. 160 keys)"}.get(variant, f"first kernel, ablation bits {variant - 100:04b} (mfma|softmax|commits|loads removed)")
             out.append({"kernel": f"vlfuse_i2t {name} B={B} N={N} live keys={live}", "ms": round(ms, 4),
                         "TFLOPs": round(fl / ms / 1e9, 1), "frac_of_mfma_peak": round(fl / ms / 1e9 / 2500, 3),
                         "algorithmic_GBs": round(nb / ms / 1e6, 1), "max_abs_diff_vs_first": round(float((o - ref).abs().max()), 6)})
