@@ -329,8 +329,8 @@ def _hbm(kernel, nbytes, n_launch, ms, note):
 
 def _pmc():
     """PMC traffic (HBM bytes per launch) collected by tools/pmc_traffic.sh in separate rocprofv3 passes, reduced by
-    tools/pmc_reduce.py; round 2 file first, round 1 (VLFuse only) as fallback."""
-    r2 = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    tools/pmc_reduce.py; the newest round's file first, round 1 (VLFuse only) as fallback."""
+    r2 = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(f)), "")
     if os.path.exists(r2):
         d = json.load(open(r2))
         out = {k: int(v["traffic_bytes"]) for k, v in d.get("kernels", {}).items()}
@@ -356,7 +356,7 @@ def kernel_rooflines(kern, steps, Bn, n_tok, embed=96):
         fl = n * 2.0 * pos * Bn * 2304 * 256
         out.append(_mfma("dcn_igemm8_kernel (DCNv2: bilinear gather + blend + MFMA + GroupNorm statistics, 13 branches of a DyConv "
                          "layer per launch)", fl, fl, n, ms, "flops = 2 * 33600 * B * 2304 * 256 per layer (SURVEY.md 8d: 42.4 GF / image / layer); "
-                         "traffic: PMC bytes per launch (profiles/r02_pmc_traffic.json)", pmc.get("dcn_igemm8_kernel")))
+                         "traffic: PMC bytes per launch (profiles/r0N_pmc_traffic.json, newest round)", pmc.get("dcn_igemm8_kernel")))
     if "dcnv2_fpn" in per:                       # the FPN output convs (3 levels, one grouped launch) + P6 / P7 through the same kernel
         n, ms, _ = per["dcnv2_fpn"]
         pos = sum(h * w for h, w in LEVELS)      # 16800 + 4200 + 1050 (stride 1) + 273 + 77 (stride 2) output positions

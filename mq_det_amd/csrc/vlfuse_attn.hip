@@ -522,9 +522,10 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
 
   const half_t* vb = p.v + (long)b * p.N * VD;
   // register prefetch ring: tiles pos + 1 .. pos + RS are in flight while tile pos is on the MFMAs.  The ablation run of round 3
-  // (profiles/r03_call8_microbench_vlfuse.json) takes a third off the launch when the tile loads are removed, with two slots: a tile
-  // step is shorter than the loaded L2 latency.  16 registers per slot at 512 threads: three slots.
-  constexpr int RS = QB == 1 ? 3 : 2;
+  // (profiles/r03_call8_microbench_vlfuse.json) takes a third off the launch when the tile loads are removed -- but a third slot
+  // (RS = 3) changed nothing (0.3202 vs 0.3218 ms, GPU call 9): it is the L2 -> CU ingest of 32 KB per tile and workgroup, not its
+  // latency, that the loads cost.  Two slots.
+  constexpr int RS = 2;
   TileRegs<NTH> slot[RS];
   if constexpr (ABL != 0) {
 #pragma unroll
