@@ -54,7 +54,9 @@ struct DcnGroup {
 
 // NW = waves per workgroup: 8 (two per SIMD, wave tile 64 x 64) or 16 (four per SIMD, wave tile 32 x 64, <= 128 VGPRs): the
 // staging phase is a dependent LDS -> VALU -> LDS chain, more resident waves overlap more of those chains.
-template <int NW>
+// ABL (tools/microbench.py only; results are garbage): the kernel WITHOUT one of its parts -- bit 0: no gather loads, bit 1: no bilinear
+// blend (corner 0 is staged as it is), bit 2: no weight-tile loads, bit 3: no fragment reads / MFMAs -- to see what a k-step waits for.
+template <int NW, int ABL = 0>
 __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   constexpr int BM = DCN_PH * DCN_PW, BN = 256, BK = 64;
   constexpr int NTH = 64 * NW, RA = 1024 / NTH, JB = 2048 / NTH, IM = 32 / NW;   // threads, A rows / thread, B chunks / thread, row blocks / wave
@@ -175,6 +177,16 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
 
   float c_w[2][RA][4];
   half8 a_raw[2][RA][4], b_raw[JB];
+  if constexpr (ABL != 0) {
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+      for (int rr = 0; rr < RA; ++rr)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a_raw[s_][rr][q] = zero8();
+#pragma unroll
+    for (int j = 0; j < JB; ++j) b_raw[j] = zero8();
+  }
   auto issue_a = [&](auto SLOT, int ks) {                    // gather of k-step ks
     constexpr int s = decltype(SLOT)::value;
     ks = min(ks, ksteps - 1);                                // tail: re-load the last step (one code path, no branches)
@@ -186,7 +198,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         c_w[s][rr][q] = st.w[q];
-        a_raw[s][rr][q] = *(const half8*)(xb + (st.off[q] + cb));
+        if constexpr (!(ABL & 1)) a_raw[s][rr][q] = *(const half8*)(xb + (st.off[q] + cb));
       }
     }
   };
@@ -195,7 +207,9 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
     const int slice = ks / 9, tap = ks - slice * 9;
     const unsigned kb = (unsigned)(tap * p.C + slice * BK) * (unsigned)sizeof(half_t);
 #pragma unroll
-    for (int j = 0; j < JB; ++j) b_raw[j] = *(const half8*)(wb + (b_goff[j] + kb));
+    for (int j = 0; j < JB; ++j) {
+      if constexpr (!(ABL & 4)) b_raw[j] = *(const half8*)(wb + (b_goff[j] + kb));
+    }
   };
   // staging of one k-step by this thread: bilinear blend of its gathered slot (fp32 accumulate like the im2col kernel,
   // one rounding to fp16) -> its two A-tile rows, and its four weight chunks -> B tile
@@ -205,6 +219,8 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
 #pragma unroll
     for (int rr = 0; rr < RA; ++rr) {
       half8 v;
+      if constexpr (ABL & 2) v = a_raw[s][rr][0];
+      else
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float t = c_w[s][rr][0] * (float)a_raw[s][rr][0][j];
@@ -229,6 +245,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   const unsigned fa = (unsigned)((wr * IM * 16 + l15) * BK), fb = (unsigned)((wc * 64 + l15) * BK);
   const unsigned sw0 = (unsigned)((lg ^ (l15 & 7)) << 3), sw1 = (unsigned)(((4 + lg) ^ (l15 & 7)) << 3);
   auto mfma_phase = [&](int cur) {                           // this wave's 64 x 64 block of one k-step (32 MFMAs)
+    if constexpr (ABL & 8) return;
     const half_t* At = As + cur * BM * BK + fa;
     const half_t* Bt = Bs + cur * BN * BK + fb;
 #pragma unroll
@@ -410,6 +427,24 @@ extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* 
   }
   static const int nw = [] { const char* e = getenv("MQ_DCN_WAVES"); return (e && e[0] == '8') ? 8 : 16; }();   // A/B switch
   const dim3 grid((unsigned)(8 * ((g.tiles_all + 7) / 8)));
+#ifndef MQ_BF16
+  if (const int abl = (br[0].flags >> 8) & 15) {             // ablation timings (tools/microbench.py)
+    switch (abl) {
+#define MQ_DCN_ABL(A_)                                                                                                             \
+      case A_: {                                                                                                                   \
+        hipError_t e = hipFuncSetAttribute((const void*)dcn_igemm8_kernel<16, A_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        if (e != hipSuccess) return (int)e;                                                                                        \
+        hipLaunchKernelGGL((dcn_igemm8_kernel<16, A_>), grid, dim3(1024), smem, (hipStream_t)stream, g);                            \
+        break;                                                                                                                     \
+      }
+      MQ_DCN_ABL(1) MQ_DCN_ABL(2) MQ_DCN_ABL(3) MQ_DCN_ABL(4) MQ_DCN_ABL(8) MQ_DCN_ABL(7) MQ_DCN_ABL(15)
+#undef MQ_DCN_ABL
+      default: return -4;
+    }
+    MQ_CHECK_LAUNCH();
+    return 0;
+  }
+#endif
   if (nw == 16) hipLaunchKernelGGL(dcn_igemm8_kernel<16>, grid, dim3(1024), smem, (hipStream_t)stream, g);
   else hipLaunchKernelGGL(dcn_igemm8_kernel<8>, grid, dim3(512), smem, (hipStream_t)stream, g);
   MQ_CHECK_LAUNCH();

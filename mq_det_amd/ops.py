@@ -585,14 +585,14 @@ class _DcnBranch(ctypes.Structure):
                [(n, _i) for n in ("B", "H", "W", "C", "oH", "oW", "N", "out_ld", "stride", "flags")]
 
 
-def dcnv2_group(branches, want_stats=True, tag="dcnv2_fused"):
+def dcnv2_group(branches, want_stats=True, tag="dcnv2_fused", ablation=0):
     """ONE launch for several DCNv2 calls (mq_dcnv2_group_fwd).  branches: list of dicts with x [B,H,W,C] fp16 NHWC view,
     om [B,27,oH,oW] fp32, w [256, 9*C] fp16, bias [256] fp16, stride, wy / wx (or None)
     -> list of (y [B, Ho*Wo, 256] fp16, (Ho, Wo), sums or None) in the same order."""
     lib = load_library()
     arr = (_DcnBranch * len(branches))()
     outs = []
-    for a, br in zip(arr, branches):
+    for i, (a, br) in enumerate(zip(arr, branches)):
         x, om, w, bias, stride = br["x"], br["om"], br["w"], br["bias"], br["stride"]
         wy, wx = br.get("wy"), br.get("wx")
         _need_gpu(x, om, w, bias, wy, wx)
@@ -612,7 +612,7 @@ def dcnv2_group(branches, want_stats=True, tag="dcnv2_fused"):
         a.wy = wy.data_ptr() if wy is not None else None
         a.wx = wx.data_ptr() if wx is not None else None
         a.x_bs, a.B, a.H, a.W, a.C, a.oH, a.oW = x.stride(0), B, H, W, C, om.shape[2], om.shape[3]
-        a.N, a.out_ld, a.stride, a.flags = 256, 256, stride, int(bool(br.get("mask_prob", False)))
+        a.N, a.out_ld, a.stride, a.flags = 256, 256, stride, int(bool(br.get("mask_prob", False))) | ((int(ablation) & 15) << 8 if i == 0 else 0)
         outs.append((y, (Ho, Wo), sums))
     with _timed(tag):
         _chk(_fn(lib, "mq_dcnv2_group_fwd", *[br["x"] for br in branches])(ctypes.cast(arr, _vp), len(branches), _stream()), "mq_dcnv2_group_fwd")

@@ -44,6 +44,8 @@ def main():
         window(dev, g, out)
     if only in ("", "dyconv"):
         dyconv_parts(dev, g, out)
+    if only in ("", "dcn"):
+        dcn(dev, g, out)
     if only in ("", "vlfuse"):
         vlfuse(dev, g, out)
         vlfuse_text(dev, g, out)
@@ -195,6 +197,29 @@ def dyconv_parts(dev, g, out):
         pool = torch.randn(B, (H * W + 127) // 128, C, generator=g).to(dev)
         ms = timeit(lambda: ops.dyrelu_coef(pool, H * W, w0, b0, w2, b2))
         out.append({"kernel": f"dyrelu_coef {H}x{W} ({pool.shape[1]} partials per image)", "ms": round(ms, 4)})
+
+
+def dcn(dev, g, out):
+    # ---- the grouped DCNv2 launch of one DyConv layer at the bench shape (B = 8, five levels, 13 branches) and its ablation variants
+    # (the kernel without its gather loads / blend / weight-tile loads / fragment reads + MFMAs: results garbage, timing only)
+    sizes = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    B, C = 8, 256
+    lv = [torch.randn(B, h, w, C, generator=g).half().to(dev) for h, w in sizes]
+    om = [(torch.randn(B, 27, h, w, generator=g) * 1.5).to(dev) for h, w in sizes]
+    wts = [(torch.randn(256, 9 * C, generator=g) / 48).half().to(dev) for _ in range(3)]
+    bias = torch.zeros(256).half().to(dev)
+    branches = []
+    for l in range(5):
+        spec = [(1, lv[l], 1)] + ([(2, lv[l - 1], 2)] if l > 0 else []) + ([(0, lv[l + 1], 1)] if l < 4 else [])
+        for k, x, stride in spec:
+            branches.append({"x": x, "om": om[l], "w": wts[k], "bias": bias, "stride": stride, "wy": None, "wx": None})
+    fl = sum(2.0 * B * (((b_["x"].shape[1] - 1) // b_["stride"] + 1) * ((b_["x"].shape[2] - 1) // b_["stride"] + 1)) * 2304 * 256 for b_ in branches)
+    names = {0: "full", 1: "no gather loads", 2: "no blend", 3: "no gather loads, no blend", 4: "no weight-tile loads", 7: "no loads, no blend",
+             8: "no fragment reads / MFMAs", 15: "skeleton (barriers, sampling state, LDS stores, epilogue)"}
+    for abl in (0, 1, 2, 3, 4, 7, 8, 15):
+        ms = timeit(lambda: ops.dcnv2_group(branches, want_stats=True, ablation=abl))
+        out.append({"kernel": f"dcn_igemm8_kernel<16>, 13 branches, B={B}: {names[abl]}", "ms": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1),
+                    "frac_of_mfma_peak": round(fl / ms / 1e9 / 2500, 3)})
 
 
 def vlfuse_text(dev, g, out):
