@@ -73,6 +73,12 @@ int mq_attn_chunked_fwd(const void* q, const void* k, const void* vt, void* o, c
  *   per-forward SW-MSA mask construction of BasicLayer.forward (:354-373). */
 int mq_window_attn_fwd(const void* qkv, const void* qkv_bias, const float* rel_bias, void* out,
                        int B, int H, int W, int C, int heads, int ws, int shift, void* stream);
+/* The same operator with the qkv projection INSIDE (csrc/window_attn.hip, round 3): x [B,H,W,C] fp16 = norm1(x) on the unpadded tokens,
+ * w [3C, C] / bias [3C] fp16 = attn.qkv (nn.Linear layout; swint.py:97,111-117), rel_bias / out as above -- the [B,H,W,3C] qkv tensor
+ * (310 MB per block at stage 1, B = 8) is never written.  One wave per window; Q^T / K^T / V come out of the projection MFMAs in the
+ * fragment layouts of the attention MFMAs.  C = 96 (heads = 3), windows of at most 64 tokens; -1 otherwise. */
+int mq_window_attn_qkv_fwd(const void* x, const void* w, const void* bias, const float* rel_bias, void* out,
+                           int B, int H, int W, int C, int heads, int ws, int shift, void* stream);
 
 /* GCP sparse cross-attention: text token t attends to the vision rows idx[b,t,0..S) (-1 = none).
  *   q [B,T,512] fp16, kv [B,V,1024] fp16 (k|v of the UNIQUE vision tokens), idx [B,T,S] int32 (any S >= 0), out [B,T,512].
@@ -352,6 +358,7 @@ MQ_BF16_TWIN(mq_attn_fwd)
 MQ_BF16_TWIN(mq_attn_resident_fwd)
 MQ_BF16_TWIN(mq_attn_chunked_fwd)
 MQ_BF16_TWIN(mq_window_attn_fwd)
+MQ_BF16_TWIN(mq_window_attn_qkv_fwd)
 MQ_BF16_TWIN(mq_gcp_sparse_attn_fwd)
 MQ_BF16_TWIN(mq_gcp_gate_residual_fwd)
 MQ_BF16_TWIN(mq_vlfuse_i2t_fwd)

@@ -206,4 +206,237 @@ extern "C" int MQ_SYM(mq_window_attn_fwd)(const void* qkv, const void* qkv_bias,
   return 0;
 }
 
+// ---- mq_window_attn_qkv_fwd: the qkv projection INSIDE the window attention (round 3).
+// At Swin stage 1 (C = 96, 537 600 tokens at B = 8) the qkv tensor is 310 MB per block: the library GEMM writes it (88 us, HBM bound)
+// and mq_window_attn_fwd reads it back (144 us at 2.9 TB/s) -- 620 MB of the block's traffic for a tensor nobody else reads.  Here one
+// wave owns one WINDOW for all its heads: the 64 x C normalised tokens are loaded once as MFMA fragments (A and B fragments of
+// 16x16x32 have the same lane layout: token l15, channels 8 lg .. + 7), and per head
+//     Q^T = Wq X^T,  K^T = Wk X^T   (A = weight rows from LDS, B = X fragments; accumulator rows = head channel 4 lg + r, cols = token l15)
+//     V   = X Wv^T                  (A = X fragments, B = weight rows; accumulator rows = token, cols = channel)
+// whose accumulators ARE, after rounding to 16 bits (the rounding point of the reference's qkv tensor), the fragments of
+//     S^T = K Q^T                   (A = K, B = Q: a lane holds the 8 k-slots (d = 4 lg + t, 16 + 4 lg + t) of token l15 -- the same
+//                                    permutation of d in both operands cancels in the contraction)
+//     O^T = V^T P^T                 (A = V^T: row = channel l15, k-slots = keys 4 lg + t of two adjacent 16-token blocks -- the key
+//                                    order of the P^T fragment the softmax leaves in registers, as in mq_window_attn_fwd)
+// -- no LDS round trip for Q, K, V or P.  The 3C x C weight matrix lives in LDS for the life of the (persistent) workgroup
+// (55 KB at C = 96).  Pad tokens (pad happens after norm1) are exact zero rows of X: their q / k / v equal the bias, as the
+// reference's are.  Everything after the projections is mq_window_attn_fwd's code.  Algorithmic HBM bytes: x in, out out (4 C per token).
+struct WinQkvParams {
+  const half_t* x; const half_t* w; const half_t* bias; const float* rel_bias; half_t* out;
+  int B, H, W, heads, ws, shift, Hp, Wp, nWx, nWy;
+  long windows;
+  float scale;
+};
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void window_attn_qkv_kernel(WinQkvParams p) {
+  constexpr int NB = 4, NP = 64, KS = C / 32, HEADS = C / 32, WP = C + 8;       // weight row pitch (halfs): conflict-free b128 rows
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* Ws = (half_t*)smem;                              // [3C][WP]
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int c = tid; c < 3 * C * (C / 8); c += 256) {
+    const int row = c / (C / 8), ch = c % (C / 8);
+    *(half8*)(Ws + row * WP + ch * 8) = *(const half8*)(p.w + (long)row * C + ch * 8);
+  }
+  __syncthreads();
+  const int N = p.ws * p.ws;
+
+  for (long win = (long)blockIdx.x * 4 + wave; win < p.windows; win += (long)gridDim.x * 4) {
+    long t = win;
+    const int wx = t % p.nWx; t /= p.nWx;
+    const int wy = t % p.nWy;
+    const int b = t / p.nWy;
+    auto region_of = [&](int i) {
+      const int ii = min(i, N - 1);
+      const int ys = wy * p.ws + ii / p.ws, xs = wx * p.ws + ii % p.ws;
+      const int ry = ys < p.Hp - p.ws ? 0 : (ys < p.Hp - p.shift ? 1 : 2);
+      const int rx = xs < p.Wp - p.ws ? 0 : (xs < p.Wp - p.shift ? 1 : 2);
+      return ry * 3 + rx;
+    };
+    // ---- X fragments: token blk * 16 + l15, channels 32 ks + 8 lg .. + 7; tokens >= N copy token N - 1 (masked as keys, not stored)
+    half8 xf[NB][KS];
+    int out_off[NB];                                       // element offset of the token's row (B * H * W * C < 2^31: checked by the host), -1: none
+    int region_q[NB];
+    {
+      int rows[NB];
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk) {
+        const int i = blk * 16 + l15, ii = min(i, N - 1);
+        const int ys = wy * p.ws + ii / p.ws, xs = wx * p.ws + ii % p.ws;
+        int y = ys + p.shift; if (y >= p.Hp) y -= p.Hp;
+        int x = xs + p.shift; if (x >= p.Wp) x -= p.Wp;
+        const bool real = (y < p.H) && (x < p.W);
+        const int tok = (b * p.H + y) * p.W + x;
+        rows[blk] = real ? tok * C + lg * 8 : -1;
+        out_off[blk] = (real && i < N) ? tok * C : -1;
+        region_q[blk] = region_of(i);
+      }
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[blk][ks] = rows[blk] >= 0 ? *(const half8*)(p.x + rows[blk] + ks * 32) : zero8();
+    }
+    int region_k[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      region_k[nb] = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) region_k[nb] |= region_of(nb * 16 + 4 * lg + r) << (4 * r);
+    }
+
+#pragma unroll 1
+    for (int head = 0; head < HEADS; ++head) {
+      // ---- projections of this head.  m = 0 (q), 1 (k): transposed; 2 (v): plain.  bias: row (d) for q / k, column (d) for v
+      half8 qf[NB], kf[NB], vf[NB / 2][2];                  // vf[st][db]: V^T A-fragment of 32-key step st, channel block db
+      {
+        auto wrow = [&](int m, int db) { return Ws + (m * C + head * 32 + db * 16 + l15) * WP + lg * 8; };
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          float4_ acc[2][NB];
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            const half4 bv = *(const half4*)(p.bias + m * C + head * 32 + db * 16 + 4 * lg);
+#pragma unroll
+            for (int tb = 0; tb < NB; ++tb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[db][tb][r] = (float)bv[r];
+          }
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+              const half8 wf = *(const half8*)(wrow(m, db) + ks * 32);
+#pragma unroll
+              for (int tb = 0; tb < NB; ++tb) acc[db][tb] = mfma16(wf, xf[tb][ks], acc[db][tb]);
+            }
+#pragma unroll
+          for (int tb = 0; tb < NB; ++tb) {
+            half8 f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { f[r] = (half_t)acc[0][tb][r]; f[4 + r] = (half_t)acc[1][tb][r]; }
+            if (m == 0) qf[tb] = f; else kf[tb] = f;
+          }
+          __builtin_amdgcn_sched_barrier(0);                 // one projection at a time: their accumulators must not be live together
+        }
+        float4_ acc[NB][2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const float bv = (float)p.bias[2 * C + head * 32 + db * 16 + l15];
+#pragma unroll
+          for (int tb = 0; tb < NB; ++tb) acc[tb][db] = (float4_){bv, bv, bv, bv};
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            const half8 wf = *(const half8*)(wrow(2, db) + ks * 32);
+#pragma unroll
+            for (int tb = 0; tb < NB; ++tb) acc[tb][db] = mfma16(xf[tb][ks], wf, acc[tb][db]);
+          }
+#pragma unroll
+        for (int st = 0; st < NB / 2; ++st)
+#pragma unroll
+          for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { vf[st][db][r] = (half_t)acc[2 * st][db][r]; vf[st][db][4 + r] = (half_t)acc[2 * st + 1][db][r]; }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const float* rel = p.rel_bias + (long)head * NP * NP;
+#pragma unroll
+      for (int qb = 0; qb < NB; ++qb) {
+        if (qb * 16 >= N) break;
+        float4_ s[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) s[nb] = mfma16(kf[nb], qf[qb], (float4_){0.f, 0.f, 0.f, 0.f});
+        const float* relq = rel + (qb * 16 + l15) * NP + 4 * lg;
+        float4_ rb[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) rb[nb] = *(const float4_*)(relq + nb * 16);
+        const float pen = p.shift > 0 ? -100.0f : 0.0f;
+        float mx = MQ_NEG_BIG;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = s[nb][r] * p.scale + rb[nb][r];
+            v += (((region_k[nb] >> (4 * r)) & 15) != region_q[qb]) ? pen : 0.0f;
+            if (nb * 16 + 4 * lg + r >= N) v = MQ_NEG_BIG;
+            s[nb][r] = v;
+            mx = fmaxf(mx, v);
+          }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __expf(s[nb][r] - mx);
+            s[nb][r] = e;
+            sum += e;
+          }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.f / sum;
+        float4_ o[2] = {(float4_){0.f, 0.f, 0.f, 0.f}, (float4_){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int st = 0; st < NB / 2; ++st) {
+          half8 pf;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { pf[r] = (half_t)(s[2 * st][r] * inv); pf[4 + r] = (half_t)(s[2 * st + 1][r] * inv); }
+#pragma unroll
+          for (int db = 0; db < 2; ++db) o[db] = mfma16(vf[st][db], pf, o[db]);
+        }
+        if (out_off[qb] >= 0) {
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            half4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (half_t)o[db][r];
+            *(half4*)(p.out + out_off[qb] + head * 32 + db * 16 + 4 * lg) = v;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);                   // one query block at a time (bias rows of the next are not hoisted)
+      }
+    }
+  }
+}
+
+template <int C>
+static int launch_window_attn_qkv(const WinQkvParams& p, hipStream_t s) {
+  constexpr size_t smem = (size_t)3 * C * (C + 8) * sizeof(half_t);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)window_attn_qkv_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  int cus = 256, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  const long wgs_needed = (p.windows + 3) / 4;
+  const long wgs = wgs_needed < (long)cus * 2 ? wgs_needed : (long)cus * 2;          // persistent: two workgroups per CU share its LDS
+  hipLaunchKernelGGL(window_attn_qkv_kernel<C>, dim3((unsigned)wgs), dim3(256), smem, s, p);
+  MQ_CHECK_LAUNCH();
+  return 0;
+}
+
+// x [B,H,W,C] 16-bit = norm1(x) on the UNPADDED tokens, w [3C, C] / bias [3C] = attn.qkv (nn.Linear layout), rel_bias as
+// mq_window_attn_fwd, out [B,H,W,C].  C = heads * 32 in {96}; windows of at most 64 tokens.  Returns -1 otherwise (callers use the
+// GEMM + mq_window_attn_fwd pair).
+extern "C" int MQ_SYM(mq_window_attn_qkv_fwd)(const void* x, const void* w, const void* bias, const float* rel_bias, void* out,
+                                      int B, int H, int W, int C, int heads, int ws, int shift, void* stream) {
+  if (B <= 0) return 0;
+  if (C != heads * 32 || ws * ws > 64 || shift < 0 || shift >= ws || C != 96 || (long)B * H * W * C >= (1L << 31)) return -1;
+  WinQkvParams p;
+  p.x = (const half_t*)x; p.w = (const half_t*)w; p.bias = (const half_t*)bias; p.rel_bias = rel_bias; p.out = (half_t*)out;
+  p.B = B; p.H = H; p.W = W; p.heads = heads; p.ws = ws; p.shift = shift;
+  p.Hp = (H + ws - 1) / ws * ws; p.Wp = (W + ws - 1) / ws * ws;
+  p.nWy = p.Hp / ws; p.nWx = p.Wp / ws;
+  p.windows = (long)B * p.nWy * p.nWx;
+  p.scale = 1.0f / sqrtf(32.0f);
+  return launch_window_attn_qkv<96>(p, (hipStream_t)stream);
+}
+
 MQ_NAMESPACE_END

@@ -269,8 +269,12 @@ def swin_forward(P, cfg, img, p="backbone.body", SW=None):
                     h1 = _ln(P, b + ".norm1", x)
                 else:
                     h1, x = _add_ln(P, b + ".norm1", pend, x)                               # x = x + mlp(...)  (swint.py:240)
-            qkv = _lin(P, b + ".attn.qkv", h1).reshape(B, H, W, 3 * C)
-            a = ops.window_attention(qkv, P[b + ".attn.qkv.bias"], P[b + ".attn.rel_bias"], heads, ws, shift)
+            if ops.KERNELS["SWIN_QKV_FUSED"] == 1 and C in ops.WINDOW_QKV_WIDTHS and ws * ws <= 64:
+                a = ops.window_attention_qkv(h1.reshape(B, H, W, C), P[b + ".attn.qkv.weight"], P[b + ".attn.qkv.bias"],
+                                             P[b + ".attn.rel_bias"], heads, ws, shift)               # the qkv tensor is never written
+            else:
+                qkv = _lin(P, b + ".attn.qkv", h1).reshape(B, H, W, 3 * C)
+                a = ops.window_attention(qkv, P[b + ".attn.qkv.bias"], P[b + ".attn.rel_bias"], heads, ws, shift)
             proj = _lin(P, b + ".attn.proj", a.reshape(B, H * W, C))
             if fused:
                 # one kernel: x += proj (swint.py:236); x += fc2(gelu(fc1(norm2(x)))) (:240); and the LayerNorm that reads

@@ -20,6 +20,7 @@ _SIGNATURES = {
     "mq_attn_resident_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _vp]),
     "mq_attn_chunked_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _i, _vp]),
     "mq_window_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "mq_window_attn_qkv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_gcp_sparse_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_gcp_gate_residual_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _l, _i, _i, _vp]),
     "mq_vlfuse_i2t_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
@@ -54,7 +55,7 @@ _SIGNATURES = {
     "mq_ml_nms": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
 }
 # entry points with 16-bit operands also exist as <name>_bf16 (same signature; include/mqdet_hip.h MQ_BF16_TWIN)
-BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
+BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_window_attn_qkv_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
               "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_patch_merge_ln_fwd", "mq_swin_mlp_fwd", "mq_swin_mlp2_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
               "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyrelu_apply", "mq_dyrelu_ln_fwd",
               "mq_align_scores_fwd", "mq_align_fused_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
@@ -77,6 +78,7 @@ KERNEL_DEFAULTS = {
     "SWIN_MLP_VARIANT": 2,       # 2: mq_swin_mlp2_fwd (fragment-major weights, 3-deep software pipeline, 14-VALU GELU); 1: mq_swin_mlp_fwd
     "SWIN_MLP2_FLAGS": -1,       # mq_swin_mlp2_fwd flags: -1 = per width (table GELU at C = 96 / 384, erf at 192; tail split on); else bit 1 = table
                                  # GELU, bit 0 = no tail split, bit 2 = everything through the tail kernel
+    "SWIN_QKV_FUSED": 1,         # 1: the Swin qkv projection inside the window attention where it is built (C = 96: mq_window_attn_qkv_fwd)
     "DYRELU_IN_LN": 1,           # 1: the DYReLU of fusion layers 0 .. L-2 is applied by the next layer's LayerNorm (mq_dyrelu_ln_fwd); 0: own pass
     "VLFUSE_I2T_VARIANT": 0,     # mq_vlfuse_i2t_fwd: 0 = Q fragments in registers where they fit (129 .. 160 keys: 0.428 -> 0.370 ms per launch),
                                  # 1 = Q tile in LDS for every caption longer than 128 tokens
@@ -306,6 +308,28 @@ def window_attention(qkv, qkv_bias, rel_bias, heads, ws, shift):
     with _timed(f"window_attn_c{C}", qkv.numel() * 2 + out.numel() * 2):
         _chk(_fn(lib, "mq_window_attn_fwd", qkv)(_ptr(qkv), _ptr(qkv_bias), _ptr(rel_bias), _ptr(out), B, H, W, C, heads, ws, shift,
                                     _stream()), "mq_window_attn_fwd")
+    return out
+
+
+WINDOW_QKV_WIDTHS = (96,)          # widths mq_window_attn_qkv_fwd is instantiated for
+
+
+def window_attention_qkv(x, w, bias, rel_bias, heads, ws, shift):
+    """Window attention with the qkv projection inside (mq_window_attn_qkv_fwd): x [B,H,W,C] 16-bit = norm1(x), w [3C,C] / bias [3C] =
+    attn.qkv, rel_bias as window_attention -> [B,H,W,C].  C in WINDOW_QKV_WIDTHS, ws * ws <= 64."""
+    lib = load_library()
+    _need_gpu(x, w, bias, rel_bias)
+    B, H, W, C = x.shape
+    NP = window_pad(ws)
+    assert C in WINDOW_QKV_WIDTHS and NP == 64 and heads * 32 == C
+    assert x.is_contiguous() and x.dtype in _H16 and w.dtype == x.dtype == bias.dtype and w.is_contiguous() and w.shape == (3 * C, C)
+    if rel_bias.shape == (heads, ws * ws, ws * ws) and ws * ws != NP:
+        rel_bias = pad_rel_bias(rel_bias, ws)
+    assert rel_bias.dtype == torch.float32 and rel_bias.is_contiguous() and rel_bias.shape == (heads, NP, NP)
+    out = torch.empty(B, H, W, C, dtype=x.dtype, device=x.device)
+    with _timed(f"window_attn_qkv_c{C}", 2 * x.numel() * 2):
+        _chk(_fn(lib, "mq_window_attn_qkv_fwd", x)(_ptr(x), _ptr(w), _ptr(bias), _ptr(rel_bias), _ptr(out), B, H, W, C, heads, ws, shift,
+                                                   _stream()), "mq_window_attn_qkv_fwd")
     return out
 
 

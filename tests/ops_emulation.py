@@ -83,6 +83,13 @@ def window_attention(qkv, qkv_bias, rel_bias, heads, ws, shift):
     return o[:, :H, :W].contiguous().to(qkv.dtype)
 
 
+def window_attention_qkv(x, w, bias, rel_bias, heads, ws, shift):
+    """Plain-torch statement of mq_window_attn_qkv_fwd: the qkv Linear (output rounded to the activation dtype, as the reference's
+    tensor is) followed by the window attention restatement."""
+    qkv = F.linear(x.float(), w.float(), bias.float()).to(x.dtype)
+    return window_attention(qkv, bias, rel_bias, heads, ws, shift)
+
+
 def gcp_sparse_attention(q, kv, idx, heads=8, dim_head=64):
     B, T, HD = q.shape
     S = idx.shape[2]
@@ -494,7 +501,7 @@ def dyconv_coef_group(items, attn_w, attn_b, groups, eps):
 
 # ---------------------------------------------------------------------------------------------------------------------------------
 # every emulated entry point, in one place: tests patch them into mq_det_amd.ops (or into a stand-in namespace) with these helpers
-NAMES = ("attention", "attention4", "window_attention", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores", "align_fused",
+NAMES = ("attention", "attention4", "window_attention", "window_attention_qkv", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores", "align_fused",
          "dyconv_branch_coef", "dyconv_coef_group", "dyconv_fuse", "dyrelu_", "dyrelu_coef", "dyrelu_apply_", "dyrelu_layer_norm", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "vlfuse_i2t",
          "vlfuse_t2i", "box_decode", "ml_nms", "roi_align", "swin_mlp", "swin_mlp2", "patch_merge_ln", "ms_deform_attn", "ms_deform_attn_q", "image_key_mask")
 
@@ -512,7 +519,7 @@ def namespace(real_ops):
     import types
     g = globals()
     fake = types.SimpleNamespace(**{n: g[n] for n in NAMES})
-    for n in ("SWIN_MLP_WIDTHS", "SCORE_AGG", "window_pad", "pad_rel_bias", "swin_mlp_w2_perm", "swin_mlp2_pack", "timing_active"):
+    for n in ("SWIN_MLP_WIDTHS", "WINDOW_QKV_WIDTHS", "SCORE_AGG", "window_pad", "pad_rel_bias", "swin_mlp_w2_perm", "swin_mlp2_pack", "timing_active"):
         setattr(fake, n, getattr(real_ops, n))
     fake.KERNELS = dict(real_ops.KERNEL_DEFAULTS)       # the default kernel selection: the glue of the promoted variants is what runs
     return fake

@@ -197,6 +197,10 @@ def check_window_attention(dev, large=False):
             qkv_dev = F.linear(y.to(dev), P[b + ".qkv.weight"], P[b + ".qkv.bias"]).reshape(2, H, W, 3 * C)
             got = ops.window_attention(qkv_dev, P[b + ".qkv.bias"], P[b + ".rel_bias"], heads, ws, shift)
             res.append(_stat(f"window_attn ws={ws} stage{stage} {H}x{W} shift={shift}", got, ref, tol=4e-3))
+            if C in ops.WINDOW_QKV_WIDTHS and ws * ws <= 64:            # the qkv projection inside the kernel (mq_window_attn_qkv_fwd)
+                got2 = ops.window_attention_qkv(y.to(dev), P[b + ".qkv.weight"], P[b + ".qkv.bias"], P[b + ".rel_bias"], heads, ws, shift)
+                res.append(_stat(f"window_attn with the qkv projection inside ws={ws} stage{stage} {H}x{W} shift={shift}", got2, ref, tol=4e-3))
+                res.append(_stat("... vs GEMM + mq_window_attn_fwd", got2, got.float().cpu(), tol=2e-3))
     return res
 
 

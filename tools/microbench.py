@@ -42,6 +42,8 @@ def main():
         align(dev, g, out)
     if only in ("", "window"):
         window(dev, g, out)
+    if only in ("", "window_qkv"):
+        window_qkv(dev, g, out)
     if only in ("", "dyconv"):
         dyconv_parts(dev, g, out)
     if only in ("", "dcn"):
@@ -242,6 +244,25 @@ def vlfuse_text(dev, g, out):
             for abl in (1, 3, 4, 8, 11, 15):
                 ms = timeit(lambda: ops.vlfuse_t2i(kf, v, ns, kv_len=kv, max_kv=live, variant=100 + abl))
                 out.append({"kernel": f"vlfuse_t2i + combine, ablation bits {abl:04b} (mfma|softmax|commits|loads removed) nsplit={ns} live rows={live}", "ms": round(ms, 4)})
+
+
+def window_qkv(dev, g, out):
+    # ---- Swin stage 1 (C = 96, B = 8, 200 x 336 tokens): qkv GEMM + window attention against the kernel with the projection inside
+    import torch.nn.functional as F
+    B, H, W, C, heads, ws = 8, 200, 336, 96, 3, 7
+    x = torch.randn(B, H, W, C, generator=g).half().to(dev)
+    w = (torch.randn(3 * C, C, generator=g) / C ** 0.5).half().to(dev)
+    bias = (torch.randn(3 * C, generator=g) * 0.1).half().to(dev)
+    rel = ops.pad_rel_bias((torch.randn(heads, ws * ws, ws * ws, generator=g) * 0.1).to(dev), ws)
+    for shift in (0, 3):
+        two = lambda: ops.window_attention(F.linear(x, w, bias), bias, rel, heads, ws, shift)  # noqa: E731
+        one = lambda: ops.window_attention_qkv(x, w, bias, rel, heads, ws, shift)              # noqa: E731
+        t2, t1 = timeit(two), timeit(one)
+        d = float((one().float() - two().float()).abs().max())
+        nb = 2 * x.numel() * 2
+        out.append({"kernel": f"Swin stage 1 attention, shift={shift}: qkv GEMM + window_attn", "ms": round(t2, 4), "hbm_bytes_incl_qkv_tensor": 2 * x.numel() * 2 + 2 * 3 * x.numel() * 2})
+        out.append({"kernel": f"Swin stage 1 attention, shift={shift}: window_attn_qkv (projection inside)", "ms": round(t1, 4), "algorithmic_GBs": round(nb / t1 / 1e6, 1),
+                    "TFLOPs": round((2.0 * B * H * W * C * 3 * C + 4.0 * B * H * W * 49 * C) / t1 / 1e9, 1), "max_abs_diff": round(d, 5)})
 
 
 def window(dev, g, out):
