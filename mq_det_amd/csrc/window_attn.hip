@@ -228,21 +228,48 @@ struct WinQkvParams {
   float scale;
 };
 
-template <int C>
-__global__ __launch_bounds__(256, 2) void window_attn_qkv_kernel(WinQkvParams p) {
-  constexpr int NB = 4, NP = 64, KS = C / 32, HEADS = C / 32, WP = C + 8;       // weight row pitch (halfs): conflict-free b128 rows
+// STREAM (C = 192: the 221 KB of weights do not fit): the 96 weight rows of ONE head (q, k, v: 3 x 32 rows, 36 KB) are staged per head
+// by LDS-DMA into a double buffer while the previous head computes; the four waves of a workgroup (four windows) walk the heads in
+// step, one barrier per head.  Rows are unpadded (a DMA piece is 1 KB of consecutive LDS bytes); the 16-byte chunk c of row r sits at
+// chunk position (c & ~7) | ((c ^ r) & 7): conflict-free for the fragment reads (16 rows x one chunk).  The X fragments (96 VGPRs at
+// C = 192) leave room for one wave per SIMD only.
+template <int C, bool STREAM>
+__global__ __launch_bounds__(256, STREAM ? 1 : 2) void window_attn_qkv_kernel(WinQkvParams p) {
+  constexpr int NB = 4, NP = 64, KS = C / 32, HEADS = C / 32, WP = STREAM ? C : C + 8;       // weight row pitch (halfs)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  half_t* Ws = (half_t*)smem;                              // [3C][WP]
+  half_t* Ws = (half_t*)smem;                              // resident: [3C][WP]; STREAM: [2][96][C]
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int c = tid; c < 3 * C * (C / 8); c += 256) {
-    const int row = c / (C / 8), ch = c % (C / 8);
-    *(half8*)(Ws + row * WP + ch * 8) = *(const half8*)(p.w + (long)row * C + ch * 8);
+  // STREAM: the pieces of head h (36 x 1 KB = 96 rows x C halfs, 9 per wave) -> buffer `buf`
+  auto stage_head = [&](int h, int buf) __attribute__((always_inline)) {
+    if constexpr (STREAM) {
+      constexpr int PIECES = 96 * C / 512;
+#pragma unroll
+      for (int i = 0; i < PIECES / 4; ++i) {
+        const int pc = wave + 4 * i;
+        const int off = pc * 512 + lane * 8, row = off / C, posn = (off % C) >> 3;
+        const int c = (posn & ~7) | ((posn ^ row) & 7);
+        const half_t* src = p.w + ((long)(row >> 5) * C + h * 32 + (row & 31)) * C + c * 8;
+        half_t* dst = Ws + buf * 96 * C + pc * 512;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    }
+  };
+  if constexpr (!STREAM) {
+    for (int c = tid; c < 3 * C * (C / 8); c += 256) {
+      const int row = c / (C / 8), ch = c % (C / 8);
+      *(half8*)(Ws + row * WP + ch * 8) = *(const half8*)(p.w + (long)row * C + ch * 8);
+    }
+    __syncthreads();
+  } else {
+    stage_head(0, 0);
   }
-  __syncthreads();
   const int N = p.ws * p.ws;
+  int seq = 0;                                             // STREAM: heads processed so far by this workgroup (buffer parity)
 
-  for (long win = (long)blockIdx.x * 4 + wave; win < p.windows; win += (long)gridDim.x * 4) {
+  for (long base = (long)blockIdx.x * 4; base < p.windows; base += (long)gridDim.x * 4) {      // workgroup-uniform trip count
+    const bool active = base + wave < p.windows;           // an idle wave of the last group repeats the last window without storing
+    const long win = active ? base + wave : p.windows - 1;
     long t = win;
     const int wx = t % p.nWx; t /= p.nWx;
     const int wy = t % p.nWy;
@@ -269,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void window_attn_qkv_kernel(WinQkvParams p)
         const bool real = (y < p.H) && (x < p.W);
         const int tok = (b * p.H + y) * p.W + x;
         rows[blk] = real ? tok * C + lg * 8 : -1;
-        out_off[blk] = (real && i < N) ? tok * C : -1;
+        out_off[blk] = (real && i < N && active) ? tok * C : -1;
         region_q[blk] = region_of(i);
       }
 #pragma unroll
@@ -287,10 +314,26 @@ __global__ __launch_bounds__(256, 2) void window_attn_qkv_kernel(WinQkvParams p)
 
 #pragma unroll 1
     for (int head = 0; head < HEADS; ++head) {
+      if constexpr (STREAM) {
+        // this head's pieces (issued one head ago) have landed for every wave, and every wave is done with the other buffer
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const bool last = head + 1 == HEADS && base + (long)gridDim.x * 4 >= p.windows;
+        if (!last) stage_head((head + 1) % HEADS, (seq + 1) & 1);
+      }
+      const half_t* Wb = STREAM ? Ws + (seq & 1) * 96 * C : Ws;
       // ---- projections of this head.  m = 0 (q), 1 (k): transposed; 2 (v): plain.  bias: row (d) for q / k, column (d) for v
       half8 qf[NB], kf[NB], vf[NB / 2][2];                  // vf[st][db]: V^T A-fragment of 32-key step st, channel block db
       {
-        auto wrow = [&](int m, int db) { return Ws + (m * C + head * 32 + db * 16 + l15) * WP + lg * 8; };
+        // A / B fragment of weight rows (matrix m, channel block db) for k-step ks: row l15, channels 32 ks + 8 lg .. + 7
+        auto wfrag = [&](int m, int db, int ks) __attribute__((always_inline)) -> half8 {
+          if constexpr (STREAM) {
+            const int row = m * 32 + db * 16 + l15, c = ks * 4 + lg;
+            return *(const half8*)(Wb + row * C + (((c & ~7) | ((c ^ row) & 7)) << 3));
+          } else {
+            return *(const half8*)(Wb + (m * C + head * 32 + db * 16 + l15) * WP + lg * 8 + ks * 32);
+          }
+        };
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
           float4_ acc[2][NB];
@@ -306,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void window_attn_qkv_kernel(WinQkvParams p)
           for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-              const half8 wf = *(const half8*)(wrow(m, db) + ks * 32);
+              const half8 wf = wfrag(m, db, ks);
 #pragma unroll
               for (int tb = 0; tb < NB; ++tb) acc[db][tb] = mfma16(wf, xf[tb][ks], acc[db][tb]);
             }
@@ -330,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void window_attn_qkv_kernel(WinQkvParams p)
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
           for (int db = 0; db < 2; ++db) {
-            const half8 wf = *(const half8*)(wrow(2, db) + ks * 32);
+            const half8 wf = wfrag(2, db, ks);
 #pragma unroll
             for (int tb = 0; tb < NB; ++tb) acc[tb][db] = mfma16(xf[tb][ks], wf, acc[tb][db]);
           }
@@ -400,35 +443,36 @@ __global__ __launch_bounds__(256, 2) void window_attn_qkv_kernel(WinQkvParams p)
         }
         __builtin_amdgcn_sched_barrier(0);                   // one query block at a time (bias rows of the next are not hoisted)
       }
+      ++seq;
     }
   }
 }
 
-template <int C>
+template <int C, bool STREAM>
 static int launch_window_attn_qkv(const WinQkvParams& p, hipStream_t s) {
-  constexpr size_t smem = (size_t)3 * C * (C + 8) * sizeof(half_t);
+  constexpr size_t smem = STREAM ? (size_t)2 * 96 * C * sizeof(half_t) : (size_t)3 * C * (C + 8) * sizeof(half_t);
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)window_attn_qkv_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)window_attn_qkv_kernel<C, STREAM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
   int cus = 256, dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  const long wgs_needed = (p.windows + 3) / 4;
-  const long wgs = wgs_needed < (long)cus * 2 ? wgs_needed : (long)cus * 2;          // persistent: two workgroups per CU share its LDS
-  hipLaunchKernelGGL(window_attn_qkv_kernel<C>, dim3((unsigned)wgs), dim3(256), smem, s, p);
+  const long wgs_needed = (p.windows + 3) / 4, slots = (long)cus * (STREAM ? 1 : 2);  // persistent workgroups: as many as the chip holds
+  const long wgs = wgs_needed < slots ? wgs_needed : slots;
+  hipLaunchKernelGGL((window_attn_qkv_kernel<C, STREAM>), dim3((unsigned)wgs), dim3(256), smem, s, p);
   MQ_CHECK_LAUNCH();
   return 0;
 }
 
 // x [B,H,W,C] 16-bit = norm1(x) on the UNPADDED tokens, w [3C, C] / bias [3C] = attn.qkv (nn.Linear layout), rel_bias as
-// mq_window_attn_fwd, out [B,H,W,C].  C = heads * 32 in {96}; windows of at most 64 tokens.  Returns -1 otherwise (callers use the
-// GEMM + mq_window_attn_fwd pair).
+// mq_window_attn_fwd, out [B,H,W,C].  C = heads * 32 in {96, 192}; windows of at most 64 tokens.  Returns -1 otherwise (callers use the
+// GEMM + mq_window_attn_fwd pair).  C = 192 streams the weights per head (see the kernel).
 extern "C" int MQ_SYM(mq_window_attn_qkv_fwd)(const void* x, const void* w, const void* bias, const float* rel_bias, void* out,
                                       int B, int H, int W, int C, int heads, int ws, int shift, void* stream) {
   if (B <= 0) return 0;
-  if (C != heads * 32 || ws * ws > 64 || shift < 0 || shift >= ws || C != 96 || (long)B * H * W * C >= (1L << 31)) return -1;
+  if (C != heads * 32 || ws * ws > 64 || shift < 0 || shift >= ws || (C != 96 && C != 192) || (long)B * H * W * C >= (1L << 31)) return -1;
   WinQkvParams p;
   p.x = (const half_t*)x; p.w = (const half_t*)w; p.bias = (const half_t*)bias; p.rel_bias = rel_bias; p.out = (half_t*)out;
   p.B = B; p.H = H; p.W = W; p.heads = heads; p.ws = ws; p.shift = shift;
@@ -436,7 +480,7 @@ extern "C" int MQ_SYM(mq_window_attn_qkv_fwd)(const void* x, const void* w, cons
   p.nWy = p.Hp / ws; p.nWx = p.Wp / ws;
   p.windows = (long)B * p.nWy * p.nWx;
   p.scale = 1.0f / sqrtf(32.0f);
-  return launch_window_attn_qkv<96>(p, (hipStream_t)stream);
+  return C == 96 ? launch_window_attn_qkv<96, false>(p, (hipStream_t)stream) : launch_window_attn_qkv<192, true>(p, (hipStream_t)stream);
 }
 
 MQ_NAMESPACE_END

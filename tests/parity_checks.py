@@ -165,7 +165,8 @@ def check_window_attention(dev, large=False):
     from mq_det_amd import ops
     spec, sd, cfg, model, P = tiny(dev, large)
     res = []
-    for stage, (H, W) in (((0, (29, 41)), (1, (12, 16)), (3, (5, 7))) if large else ((0, (23, 31)), (1, (12, 16)))):
+    # (stage 1 at 29 x 43: 70 windows -- several trips of the persistent workgroups of mq_window_attn_qkv_fwd and idle waves in the last)
+    for stage, (H, W) in (((0, (29, 41)), (1, (12, 16)), (3, (5, 7))) if large else ((0, (23, 31)), (1, (12, 16)), (1, (29, 43)), (0, (40, 57)))):
         C, heads, ws = spec.swin_dims[stage], spec.swin_heads[stage], spec.window
         for shift in (0, ws // 2):
             b = f"backbone.body.layers.{stage}.blocks.{1 if shift else 0}.attn"

@@ -247,9 +247,13 @@ def vlfuse_text(dev, g, out):
 
 
 def window_qkv(dev, g, out):
-    # ---- Swin stage 1 (C = 96, B = 8, 200 x 336 tokens): qkv GEMM + window attention against the kernel with the projection inside
+    # ---- Swin stages 1 / 2 (C = 96 / 192, B = 8): qkv GEMM + window attention against the kernel with the projection inside
     import torch.nn.functional as F
-    B, H, W, C, heads, ws = 8, 200, 336, 96, 3, 7
+    for (H, W, C, heads) in ((200, 336, 96, 3), (100, 168, 192, 6)):
+        _window_qkv_one(dev, g, out, F, 8, H, W, C, heads, 7)
+
+
+def _window_qkv_one(dev, g, out, F, B, H, W, C, heads, ws):
     x = torch.randn(B, H, W, C, generator=g).half().to(dev)
     w = (torch.randn(3 * C, C, generator=g) / C ** 0.5).half().to(dev)
     bias = (torch.randn(3 * C, generator=g) * 0.1).half().to(dev)
@@ -260,8 +264,8 @@ def window_qkv(dev, g, out):
         t2, t1 = timeit(two), timeit(one)
         d = float((one().float() - two().float()).abs().max())
         nb = 2 * x.numel() * 2
-        out.append({"kernel": f"Swin stage 1 attention, shift={shift}: qkv GEMM + window_attn", "ms": round(t2, 4), "hbm_bytes_incl_qkv_tensor": 2 * x.numel() * 2 + 2 * 3 * x.numel() * 2})
-        out.append({"kernel": f"Swin stage 1 attention, shift={shift}: window_attn_qkv (projection inside)", "ms": round(t1, 4), "algorithmic_GBs": round(nb / t1 / 1e6, 1),
+        out.append({"kernel": f"Swin C={C} attention, shift={shift}: qkv GEMM + window_attn", "ms": round(t2, 4), "hbm_bytes_incl_qkv_tensor": 2 * x.numel() * 2 + 2 * 3 * x.numel() * 2})
+        out.append({"kernel": f"Swin C={C} attention, shift={shift}: window_attn_qkv (projection inside)", "ms": round(t1, 4), "algorithmic_GBs": round(nb / t1 / 1e6, 1),
                     "TFLOPs": round((2.0 * B * H * W * C * 3 * C + 4.0 * B * H * W * 49 * C) / t1 / 1e9, 1), "max_abs_diff": round(d, 5)})
 
 
