@@ -401,6 +401,18 @@ def kernel_rooflines(kern, steps, Bn, n_tok, embed=96):
             fl += n * 16.0 * M * C * C
         out.append(_mfma("swin_mlp2_kernel (LN + fc1 + exact GELU + fc2 + residual + next LN in one kernel; VALU (GELU) bound at C = 96)", fl, fl,
                          sum(v[0] for _, v in mlp), sum(v[1] for _, v in mlp), "flops = 16 * M * C^2 per launch (fc1 + fc2, hidden 4C)"))
+    # ---- window attention with the qkv projection inside (window_attn.hip): projection 6 M C^2 + attention 4 M N C per launch
+    wq = [(k, v) for k, v in per.items() if k.startswith("window_attn_qkv_c")]
+    if wq:
+        fl = fe = 0.0
+        for k, (n, ms, nbytes) in wq:
+            C = int(k[len("window_attn_qkv_c"):])
+            M = Bn * (IMG_HW[0] // 4) * (-(-IMG_HW[1] // 32) * 32 // 4) * (embed / C) ** 2
+            fl += n * (6.0 * M * C * C + 4.0 * M * 49 * C)
+            fe += n * (6.0 * M * C * C + 4.0 * M * 64 * C) * 64 / 49            # 49-token windows run as 64 padded tokens
+        out.append(_mfma("window_attn_qkv_kernel (Swin qkv projection + W-MSA / SW-MSA in one kernel; the qkv tensor is never written)", fl, fe,
+                         sum(v[0] for _, v in wq), sum(v[1] for _, v in wq),
+                         "flops = 6 * M * C^2 (qkv) + 4 * M * 49 * C (QK^T, PV) per launch; HBM bytes 4 * M * C (x in, out out)"))
     # ---- HBM-bound kernels: algorithmic bytes (every input read once, every output written once) / time
     groups = (("layernorm_kernel (all LayerNorms, residual add fused)", "layernorm_c"), ("window_attn_kernel (Swin W-MSA / SW-MSA)", "window_attn_c"),
               ("dyconv_fuse_kernel (GroupNorm affine + up-sampling + scale attention + branch mean)", "dyconv_fuse"),
@@ -495,7 +507,7 @@ def _sub_bench(argv, env=None, timeout=150, keep=()):
 
 # every operator with two implementations on the one that was the default at the end of round 2 (ops.KERNEL_DEFAULTS lists today's)
 ROUND2_KERNEL_SET = {"MQ_LN_VARIANT": "1", "MQ_OFFSET_CONV_VARIANT": "1", "MQ_PATCH_MERGE_FUSED": "0", "MQ_FPN_VIA_DCN": "0", "MQ_NMS_EARLY_STOP": "0",
-                     "MQ_ATTN_RESIDENT": "0", "MQ_SWIN_MLP_VARIANT": "1", "MQ_ALIGN_FUSED": "0", "MQ_DYRELU_IN_LN": "0", "MQ_VLFUSE_I2T_VARIANT": "1"}
+                     "MQ_ATTN_RESIDENT": "0", "MQ_SWIN_MLP_VARIANT": "1", "MQ_ALIGN_FUSED": "0", "MQ_DYRELU_IN_LN": "0", "MQ_VLFUSE_I2T_VARIANT": "1", "MQ_SWIN_QKV_FUSED": "0"}
 
 
 def main():

@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256, STREAM ? 1 : 2) void window_attn_qkv_kernel(Wi
   constexpr int NB = 4, NP = 64, KS = C / 32, HEADS = C / 32, WP = STREAM ? C : C + 8;       // weight row pitch (halfs)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* Ws = (half_t*)smem;                              // resident: [3C][WP]; STREAM: [2][96][C]
+  half_t* Bsm = Ws + (STREAM ? 2 * 96 * C : 3 * C * WP);   // [3C] qkv bias (a global load per use would be waited for on the spot)
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // STREAM: the pieces of head h (36 x 1 KB = 96 rows x C halfs, 9 per wave) -> buffer `buf`
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(256, STREAM ? 1 : 2) void window_attn_qkv_kernel(Wi
       }
     }
   };
+  for (int c = tid; c < 3 * C / 8; c += 256) *(half8*)(Bsm + c * 8) = *(const half8*)(p.bias + c * 8);
   if constexpr (!STREAM) {
     for (int c = tid; c < 3 * C * (C / 8); c += 256) {
       const int row = c / (C / 8), ch = c % (C / 8);
@@ -295,14 +297,18 @@ __global__ __launch_bounds__(256, STREAM ? 1 : 2) void window_attn_qkv_kernel(Wi
         int x = xs + p.shift; if (x >= p.Wp) x -= p.Wp;
         const bool real = (y < p.H) && (x < p.W);
         const int tok = (b * p.H + y) * p.W + x;
-        rows[blk] = real ? tok * C + lg * 8 : -1;
+        rows[blk] = real ? tok * C + lg * 8 : -1;                  // pad token: X row = 0
         out_off[blk] = (real && i < N && active) ? tok * C : -1;
         region_q[blk] = region_of(i);
       }
 #pragma unroll
       for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) xf[blk][ks] = rows[blk] >= 0 ? *(const half8*)(p.x + rows[blk] + ks * 32) : zero8();
+        for (int ks = 0; ks < KS; ++ks) xf[blk][ks] = *(const half8*)(p.x + max(rows[blk], 0) + ks * 32);       // unconditional, in flight together
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[blk][ks] = rows[blk] >= 0 ? xf[blk][ks] : zero8();
     }
     int region_k[NB];
 #pragma unroll
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(256, STREAM ? 1 : 2) void window_attn_qkv_kernel(Wi
           float4_ acc[2][NB];
 #pragma unroll
           for (int db = 0; db < 2; ++db) {
-            const half4 bv = *(const half4*)(p.bias + m * C + head * 32 + db * 16 + 4 * lg);
+            const half4 bv = *(const half4*)(Bsm + m * C + head * 32 + db * 16 + 4 * lg);
 #pragma unroll
             for (int tb = 0; tb < NB; ++tb)
 #pragma unroll
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(256, STREAM ? 1 : 2) void window_attn_qkv_kernel(Wi
         float4_ acc[NB][2];
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-          const float bv = (float)p.bias[2 * C + head * 32 + db * 16 + l15];
+          const float bv = (float)Bsm[2 * C + head * 32 + db * 16 + l15];
 #pragma unroll
           for (int tb = 0; tb < NB; ++tb) acc[tb][db] = (float4_){bv, bv, bv, bv};
         }
@@ -450,7 +456,7 @@ __global__ __launch_bounds__(256, STREAM ? 1 : 2) void window_attn_qkv_kernel(Wi
 
 template <int C, bool STREAM>
 static int launch_window_attn_qkv(const WinQkvParams& p, hipStream_t s) {
-  constexpr size_t smem = STREAM ? (size_t)2 * 96 * C * sizeof(half_t) : (size_t)3 * C * (C + 8) * sizeof(half_t);
+  constexpr size_t smem = (STREAM ? (size_t)2 * 96 * C : (size_t)3 * C * (C + 8)) * sizeof(half_t) + (size_t)3 * C * sizeof(half_t);
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void*)window_attn_qkv_kernel<C, STREAM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

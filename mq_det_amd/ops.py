@@ -78,8 +78,8 @@ KERNEL_DEFAULTS = {
     "SWIN_MLP_VARIANT": 2,       # 2: mq_swin_mlp2_fwd (fragment-major weights, 3-deep software pipeline, 14-VALU GELU); 1: mq_swin_mlp_fwd
     "SWIN_MLP2_FLAGS": -1,       # mq_swin_mlp2_fwd flags: -1 = per width (table GELU at C = 96 / 384, erf at 192; tail split on); else bit 1 = table
                                  # GELU, bit 0 = no tail split, bit 2 = everything through the tail kernel
-    "SWIN_QKV_FUSED": 1,         # the Swin qkv projection inside the window attention (mq_window_attn_qkv_fwd): 1 = at C = 96 (0.372 -> 0.137 ms
-                                 # per block), 2 = also at C = 192 (weights streamed per head), 0 = GEMM + mq_window_attn_fwd
+    "SWIN_QKV_FUSED": 2,         # the Swin qkv projection inside the window attention (mq_window_attn_qkv_fwd): 1 = at C = 96 (0.372 -> 0.137 ms
+                                 # per block), 2 = also at C = 192 (weights streamed per head: 0.20 -> 0.137), 0 = GEMM + mq_window_attn_fwd
     "DYRELU_IN_LN": 1,           # 1: the DYReLU of fusion layers 0 .. L-2 is applied by the next layer's LayerNorm (mq_dyrelu_ln_fwd); 0: own pass
     "VLFUSE_I2T_VARIANT": 0,     # mq_vlfuse_i2t_fwd: 0 = Q fragments in registers where they fit (129 .. 160 keys: 0.428 -> 0.370 ms per launch),
                                  # 1 = Q tile in LDS for every caption longer than 128 tokens
