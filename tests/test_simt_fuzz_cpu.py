@@ -228,6 +228,55 @@ def test_sparse_attention_and_window_attention_random_shapes(ops):
                f"window_attention draw {it}: B={B} {H}x{W} ws={ws} heads={heads} shift={shift}", 3e-3)
 
 
+def test_round3_fused_operators_random_shapes(ops):
+    """mq_window_attn_qkv_fwd (both widths: resident and streamed weights; images smaller than a window, several trips of the persistent
+    workgroups, idle waves), mq_dyrelu_ln_fwd (1 .. 6 levels of ragged sizes) and mq_swin_mlp2_fwd across the pass / tail split."""
+    import math
+    import ops_emulation as emu
+    rng = random.Random(909 + SEED)
+    g = torch.Generator().manual_seed(909 + SEED)
+    for it in range(6 * N_DRAWS):
+        heads = rng.choice((3, 6))
+        C, ws = heads * 32, 7
+        B, H, W = rng.randint(1, 3), rng.randint(1, 5 * ws + 3), rng.randint(1, 5 * ws + 3)
+        shift = rng.choice((0, ws // 2))
+        x = torch.randn(B, H, W, C, generator=g).half()
+        w = (torch.randn(3 * C, C, generator=g) / math.sqrt(C)).half()
+        bias = (torch.randn(3 * C, generator=g) * 0.2).half()
+        rel = torch.randn(heads, ws * ws, ws * ws, generator=g) * 0.3
+        _close(ops.window_attention_qkv(x, w, bias, rel, heads, ws, shift), emu.window_attention_qkv(x, w, bias, rel, heads, ws, shift),
+               f"window_attention_qkv draw {it}: B={B} {H}x{W} C={C} shift={shift}", 4e-3)
+    for it in range(6 * N_DRAWS):
+        nl = rng.randint(1, 6)
+        sizes = [(rng.randint(1, 9), rng.randint(1, 11)) for _ in range(nl)]
+        B, N = rng.randint(1, 3), sum(h * w_ for h, w_ in sizes)
+        big = torch.randn(B, N + 5, 256, generator=g).half() * 2          # rows of a larger buffer: batch stride != N * C
+        x = big[:, 2:2 + N]
+        coef = torch.randn(nl, B, 4, 256, generator=g)
+        gam, bet = (torch.randn(256, generator=g) * 0.1 + 1).half(), (torch.randn(256, generator=g) * 0.1).half()
+        _close(ops.dyrelu_layer_norm(x, coef, sizes, gam, bet, 1e-5), emu.dyrelu_layer_norm(x, coef, sizes, gam, bet, 1e-5),
+               f"dyrelu_layer_norm draw {it}: B={B} sizes={sizes}", 4e-3)
+    for it in range(4 * N_DRAWS):
+        C = rng.choice((96, 192, 384))
+        # the emulator's "chip" has 4 CUs: 16 / 12 / 4 workgroup slots of 64 / 64 / 128 tokens -> lengths around one and two passes
+        slot = {96: 16 * 64, 192: 12 * 64, 384: 4 * 128}[C]
+        M = max(1, slot * rng.choice((1, 1, 2)) + rng.choice((-17, -1, 0, 1, 15, 16, 33, 70)))
+        x = torch.randn(M, C, generator=g)
+        delta = (torch.randn(M, C, generator=g) * 0.5).half() if rng.random() < 0.7 else None
+        lg_, lb_ = (torch.randn(C, generator=g) * 0.1 + 1).half(), (torch.randn(C, generator=g) * 0.1).half()
+        w1, b1 = (torch.randn(4 * C, C, generator=g) / math.sqrt(C)).half(), (torch.randn(4 * C, generator=g) * 0.1).half()
+        w2, b2 = (torch.randn(C, 4 * C, generator=g) / math.sqrt(4 * C)).half(), (torch.randn(C, generator=g) * 0.1).half()
+        w1f, w2f = ops.swin_mlp2_pack(w1, w2)
+        nln = (lg_, lb_, 1e-5) if rng.random() < 0.7 else None
+        flags = rng.choice((0, 2, 1, 4))
+        got = ops.swin_mlp2(x, delta, lg_, lb_, 1e-5, w1f, b1, w2f, b2, next_ln=nln, flags=flags)
+        ref = emu.swin_mlp2(x, delta, lg_, lb_, 1e-5, w1f, b1, w2f, b2, next_ln=nln)
+        if nln is None:
+            got, ref = (got,), (ref,)
+        for a_, b_, what in zip(got, ref, ("out", "next LN")):
+            _close(a_, b_, f"swin_mlp2 draw {it}: C={C} M={M} flags={flags} delta={delta is not None}: {what}", 3e-3)
+
+
 def test_swin_mlp_roi_align_and_msdeform_random_shapes(ops):
     import math
     import ops_emulation as emu
