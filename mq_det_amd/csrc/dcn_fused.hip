@@ -56,7 +56,13 @@ struct DcnGroup {
 // staging phase is a dependent LDS -> VALU -> LDS chain, more resident waves overlap more of those chains.
 // ABL (tools/microbench.py only; results are garbage): the kernel WITHOUT one of its parts -- bit 0: no gather loads, bit 1: no bilinear
 // blend (corner 0 is staged as it is), bit 2: no weight-tile loads, bit 3: no fragment reads / MFMAs -- to see what a k-step waits for.
-template <int NW, int ABL = 0>
+// SYNC = barriers per k-step.  2: one after each half step (round 1 .. 3: the two wave groups swap roles in lock step).  1: only the one
+// that ends a step.  Within a step group 0 runs [MFMAs of step k, then its share of the staging of step k + 1] and group 1 the same two
+// in the opposite order: the MFMAs only READ buffer k & 1, the staging only WRITES buffer (k + 1) & 1, each thread its own rows -- nothing
+// inside a step depends on the other group, only the step boundary does (everybody's share of step k + 1 must be visible before its
+// MFMAs, everybody must be done reading buffer k & 1 before step k + 2 is staged into it).  The ablation of round 3 (GPU call 10) put
+// the kernel's skeleton -- mostly its 72 barriers of 1024 threads per tile -- at a third of the launch.
+template <int NW, int ABL = 0, int SYNC = 2>
 __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   constexpr int BM = DCN_PH * DCN_PW, BN = 256, BK = 64;
   constexpr int NTH = 64 * NW, RA = 1024 / NTH, JB = 2048 / NTH, IM = 32 / NW;   // threads, A rows / thread, B chunks / thread, row blocks / wave
@@ -292,22 +298,22 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   if (wave < NW / 2) {
     for (int ks = 0; ks < ksteps; ks += 2) {                 // ksteps = 9 * C/64 is even (C % 128 == 0)
       mfma_phase(0);
-      __syncthreads();
+      if constexpr (SYNC == 2) __syncthreads();
       stage_next(S1{}, ks);
       __syncthreads();
       mfma_phase(1);
-      __syncthreads();
+      if constexpr (SYNC == 2) __syncthreads();
       stage_next(S0{}, ks + 1);
       __syncthreads();
     }
   } else {
     for (int ks = 0; ks < ksteps; ks += 2) {
       stage_next(S1{}, ks);
-      __syncthreads();
+      if constexpr (SYNC == 2) __syncthreads();
       mfma_phase(0);
       __syncthreads();
       stage_next(S0{}, ks + 1);
-      __syncthreads();
+      if constexpr (SYNC == 2) __syncthreads();
       mfma_phase(1);
       __syncthreads();
     }
@@ -422,6 +428,7 @@ extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* 
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)dcn_igemm8_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dcn_igemm8_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dcn_igemm8_kernel<16, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
@@ -445,7 +452,9 @@ extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* 
     return 0;
   }
 #endif
-  if (nw == 16) hipLaunchKernelGGL(dcn_igemm8_kernel<16>, grid, dim3(1024), smem, (hipStream_t)stream, g);
+  static const int sync = [] { const char* e = getenv("MQ_DCN_SYNC"); return (e && e[0] == '1') ? 1 : 2; }();    // A/B switch
+  if (nw == 16 && sync == 1) hipLaunchKernelGGL((dcn_igemm8_kernel<16, 0, 1>), grid, dim3(1024), smem, (hipStream_t)stream, g);
+  else if (nw == 16) hipLaunchKernelGGL(dcn_igemm8_kernel<16>, grid, dim3(1024), smem, (hipStream_t)stream, g);
   else hipLaunchKernelGGL(dcn_igemm8_kernel<8>, grid, dim3(512), smem, (hipStream_t)stream, g);
   MQ_CHECK_LAUNCH();
   return 0;

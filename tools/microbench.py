@@ -218,7 +218,8 @@ def dcn(dev, g, out):
     fl = sum(2.0 * B * (((b_["x"].shape[1] - 1) // b_["stride"] + 1) * ((b_["x"].shape[2] - 1) // b_["stride"] + 1)) * 2304 * 256 for b_ in branches)
     names = {0: "full", 1: "no gather loads", 2: "no blend", 3: "no gather loads, no blend", 4: "no weight-tile loads", 7: "no loads, no blend",
              8: "no fragment reads / MFMAs", 15: "skeleton (barriers, sampling state, LDS stores, epilogue)"}
-    for abl in (0, 1, 2, 3, 4, 7, 8, 15):
+    abls = tuple(int(a) for a in os.environ.get("MQ_DCN_ABL_LIST", "0,1,2,3,4,7,8,15").split(","))
+    for abl in abls:
         ms = timeit(lambda: ops.dcnv2_group(branches, want_stats=True, ablation=abl))
         out.append({"kernel": f"dcn_igemm8_kernel<16>, 13 branches, B={B}: {names[abl]}", "ms": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1),
                     "frac_of_mfma_peak": round(fl / ms / 1e9 / 2500, 3)})
