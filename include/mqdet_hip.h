@@ -254,6 +254,9 @@ int mq_dyconv_fuse(const void* y0, const float* coef0, int hs0, int ws0, const v
 int mq_dyrelu_coef(const float* pool, const void* w0, const void* b0, const void* w2, const void* b2, float* coef,
                    int B, int n, int C, void* stream);
 int mq_dyrelu_apply(void* x, const float* coef, int B, int n, int C, long x_bs, void* stream);
+/* FPN top-down step (backbone/fpn.py:82-95) in place: dst [B,H,W,C] += nearest-up-sampled src [B,Hc,Wc,C] (NHWC 16-bit, C % 8 == 0;
+ * source index = min(floor(i * (float)(in / out)), in - 1) as F.interpolate(mode="nearest", size=(H, W))). */
+int mq_add_upsample_nearest(void* dst, const void* src, int B, int H, int W, int Hc, int Wc, int C, void* stream);
 /* y = LayerNorm(DYReLU(x)) on the head's pyramid token buffer: the DYReLU of a DyConv layer (vldyhead.py:160-188, 245) applied by the
  * ONLY reader of that layer's output, layer_norm_v of the next fusion layer (fuse_helper.py:398).  x, y [B,N,256] 16-bit (x: batch
  * stride x_bs elements), coef [NL][B][4][256] fp32 = mq_dyrelu_coef's output per pyramid level, row_first: NL + 1 HOST ints (level l =
@@ -379,6 +382,7 @@ MQ_BF16_TWIN(mq_dyconv_coef_group)
 MQ_BF16_TWIN(mq_dyconv_fuse)
 MQ_BF16_TWIN(mq_dyrelu_coef)
 MQ_BF16_TWIN(mq_dyrelu_apply)
+MQ_BF16_TWIN(mq_add_upsample_nearest)
 MQ_BF16_TWIN(mq_dyrelu_ln_fwd)
 MQ_BF16_TWIN(mq_align_scores_fwd)
 MQ_BF16_TWIN(mq_align_fused_fwd)

@@ -443,4 +443,38 @@ extern "C" int MQ_SYM(mq_dyrelu_apply)(void* x, const float* coef, int B, int n,
   return 0;
 }
 
+// ---- FPN top-down step (fpn.py:82-95): dst[b, h, w, :] += src[b, nearest(h), nearest(w), :] in place, NHWC 16-bit.
+// F.interpolate(mode="nearest", size=...) + add were three passes (the up-sampled tensor written, read back with the lateral, the sum
+// written); here the lateral is read and written once and the coarse level is read through the cache.  Source index as ATen's
+// nearest_neighbor_compute_source_index: min(floor(dst * (float)(in / out)), in - 1); the sum is rounded once, as torch's add does.
+__global__ __launch_bounds__(256) void add_upsample_nearest_kernel(half_t* __restrict__ dst, const half_t* __restrict__ src, int H, int W,
+                                                                   int Hc, int Wc, int C, float sh, float sw) {
+  const int b = blockIdx.y, cpt = C / 8;
+  const long total = (long)H * W * cpt;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ch = (int)(i % cpt);
+    const long pix = i / cpt;
+    const int w = (int)(pix % W), h = (int)(pix / W);
+    const int hs = min((int)floorf((float)h * sh), Hc - 1), wsrc = min((int)floorf((float)w * sw), Wc - 1);
+    half_t* pd = dst + (((long)b * H + h) * W + w) * C + ch * 8;
+    const half8 a = *(const half8*)pd;
+    const half8 u = *(const half8*)(src + (((long)b * Hc + hs) * Wc + wsrc) * C + ch * 8);
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)a[j] + (float)u[j]);
+    *(half8*)pd = o;
+  }
+}
+
+extern "C" int MQ_SYM(mq_add_upsample_nearest)(void* dst, const void* src, int B, int H, int W, int Hc, int Wc, int C, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  if (C % 8 || Hc < 1 || Wc < 1) return -1;
+  long blocks = ((long)H * W * (C / 8) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(add_upsample_nearest_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, (hipStream_t)stream, (half_t*)dst,
+                     (const half_t*)src, H, W, Hc, Wc, C, (float)Hc / (float)H, (float)Wc / (float)W);
+  MQ_CHECK_LAUNCH();
+  return 0;
+}
+
 MQ_NAMESPACE_END

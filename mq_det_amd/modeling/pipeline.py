@@ -336,8 +336,11 @@ def fpn_forward(P, feats_nhwc):
     inners = [("fpn_layer4", inner)]
     for feat, idx in ((c4, 3), (c3, 2)):
         lat = lateral(f"fpn_inner{idx}", feat)
-        up = F.interpolate(inner.permute(0, 3, 1, 2), size=lat.shape[1:3], mode="nearest").permute(0, 2, 3, 1)
-        inner = (lat + up).contiguous()
+        if ops.KERNELS["FPN_TOPDOWN_FUSED"] == 1:
+            inner = ops.add_upsample_nearest_(lat.contiguous(), inner.contiguous())           # one pass instead of three
+        else:
+            up = F.interpolate(inner.permute(0, 3, 1, 2), size=lat.shape[1:3], mode="nearest").permute(0, 2, 3, 1)
+            inner = (lat + up).contiguous()
         inners.insert(0, (f"fpn_layer{idx}", inner))
     if via_dcn:
         # The three output convs (fpn.py:106-127) do not depend on each other: ONE grouped launch of the fused DCNv2 kernel with zero

@@ -42,6 +42,7 @@ _SIGNATURES = {
     "mq_dyconv_coef_group": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _vp]),
     "mq_dyconv_fuse": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _l, _vp, _i, _i, _i, _i, _vp]),
     "mq_dyrelu_coef": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mq_add_upsample_nearest": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_dyrelu_ln_fwd": (_i, [_vp, _l, _vp, _vp, _i, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "mq_dyrelu_apply": (_i, [_vp, _vp, _i, _i, _i, _l, _vp]),
     "mq_align_scores_fwd": (_i, [_vp, _i, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _l, _i, _vp]),
@@ -57,7 +58,7 @@ _SIGNATURES = {
 # entry points with 16-bit operands also exist as <name>_bf16 (same signature; include/mqdet_hip.h MQ_BF16_TWIN)
 BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_window_attn_qkv_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
               "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_patch_merge_ln_fwd", "mq_swin_mlp_fwd", "mq_swin_mlp2_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
-              "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyrelu_apply", "mq_dyrelu_ln_fwd",
+              "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyrelu_apply", "mq_dyrelu_ln_fwd", "mq_add_upsample_nearest",
               "mq_align_scores_fwd", "mq_align_fused_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
 for _n in BF16_TWINS:
     _SIGNATURES[_n + "_bf16"] = _SIGNATURES[_n]
@@ -80,6 +81,8 @@ KERNEL_DEFAULTS = {
                                  # GELU, bit 0 = no tail split, bit 2 = everything through the tail kernel
     "SWIN_QKV_FUSED": 2,         # the Swin qkv projection inside the window attention (mq_window_attn_qkv_fwd): 1 = at C = 96 (0.372 -> 0.137 ms
                                  # per block), 2 = also at C = 192 (weights streamed per head: 0.20 -> 0.137), 0 = GEMM + mq_window_attn_fwd
+    "FPN_TOPDOWN_FUSED": 0,      # 1: mq_add_upsample_nearest (lateral += up-sampled coarser level, in place: one pass instead of three); 0: F.interpolate
+                                 # + add.  Written after round 3's GPU budget was spent: equal results through tests/simt, NOT run on a device yet -> off
     "DYRELU_IN_LN": 1,           # 1: the DYReLU of fusion layers 0 .. L-2 is applied by the next layer's LayerNorm (mq_dyrelu_ln_fwd); 0: own pass
     "VLFUSE_I2T_VARIANT": 0,     # mq_vlfuse_i2t_fwd: 0 = Q fragments in registers where they fit (129 .. 160 keys: 0.428 -> 0.370 ms per launch),
                                  # 1 = Q tile in LDS for every caption longer than 128 tokens
@@ -750,6 +753,19 @@ def dyrelu_coef(pool, n, w0, b0, w2, b2, out=None):
     assert coef.shape == (B, 4, C) and coef.is_contiguous() and coef.dtype == torch.float32 and w0.is_contiguous() and w2.is_contiguous()
     _chk(_fn(lib, "mq_dyrelu_coef", w0)(_ptr(pool), _ptr(w0), _ptr(b0), _ptr(w2), _ptr(b2), _ptr(coef), B, int(n), C, _stream()), "mq_dyrelu_coef")
     return coef
+
+
+def add_upsample_nearest_(dst, src):
+    """FPN top-down step in place (mq_add_upsample_nearest): dst [B,H,W,C] += nearest-up-sampled src [B,Hc,Wc,C], both NHWC 16-bit
+    contiguous = dst + F.interpolate(src, size=(H, W), mode="nearest") with one rounding."""
+    lib = load_library()
+    _need_gpu(dst, src)
+    B, H, W, C = dst.shape
+    assert src.shape[0] == B and src.shape[3] == C and dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and dst.dtype in _H16
+    with _timed("fpn_topdown", 2 * dst.numel() * 2 + src.numel() * 2):
+        _chk(_fn(lib, "mq_add_upsample_nearest", dst)(_ptr(dst), _ptr(src), B, H, W, src.shape[1], src.shape[2], C, _stream()),
+             "mq_add_upsample_nearest")
+    return dst
 
 
 def dyrelu_apply_(x, coef):

@@ -284,6 +284,12 @@ def dyrelu_(x, pool, w0, b0, w2, b2):
     return x
 
 
+def add_upsample_nearest_(dst, src):
+    up = F.interpolate(src.permute(0, 3, 1, 2).float(), size=dst.shape[1:3], mode="nearest").permute(0, 2, 3, 1)
+    dst.copy_((dst.float() + up).to(dst.dtype))
+    return dst
+
+
 def dyrelu_apply_(x, coef):
     xf = x.float()
     x.copy_(torch.max(xf * coef[:, 0, None] + coef[:, 1, None], xf * coef[:, 2, None] + coef[:, 3, None]).to(x.dtype))
@@ -502,7 +508,7 @@ def dyconv_coef_group(items, attn_w, attn_b, groups, eps):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # every emulated entry point, in one place: tests patch them into mq_det_amd.ops (or into a stand-in namespace) with these helpers
 NAMES = ("attention", "attention4", "window_attention", "window_attention_qkv", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores", "align_fused",
-         "dyconv_branch_coef", "dyconv_coef_group", "dyconv_fuse", "dyrelu_", "dyrelu_coef", "dyrelu_apply_", "dyrelu_layer_norm", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "vlfuse_i2t",
+         "dyconv_branch_coef", "dyconv_coef_group", "dyconv_fuse", "dyrelu_", "dyrelu_coef", "dyrelu_apply_", "dyrelu_layer_norm", "add_upsample_nearest_", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "vlfuse_i2t",
          "vlfuse_t2i", "box_decode", "ml_nms", "roi_align", "swin_mlp", "swin_mlp2", "patch_merge_ln", "ms_deform_attn", "ms_deform_attn_q", "image_key_mask")
 
 

@@ -13,6 +13,7 @@ import sys
 
 import pytest
 import torch
+import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
@@ -147,6 +148,22 @@ def test_attention_strided_views(kernels):
                                   "check_conv3x3", "check_roi_align", "check_msdeform_attn", "check_swin_fpn", "check_align_fused"])
 def test_kernel_block(kernels, name):
     _assert_ok(getattr(kernels, name)(CPU))
+
+
+def test_fpn_topdown_fused_equals_interpolate_plus_add(kernels, monkeypatch):
+    """mq_add_upsample_nearest (KERNELS["FPN_TOPDOWN_FUSED"] = 1, off by default: not run on a device yet) against F.interpolate(mode="nearest")
+    + add on even and odd size pairs (the reference's top-down step, fpn.py:82-95): EQUAL outputs; and the Swin + FPN check with it on."""
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(12)
+    for dt in (torch.float16, torch.bfloat16):
+        for (H, W), (Hc, Wc) in (((100, 168), (50, 84)), ((25, 42), (13, 21)), ((13, 21), (7, 11)), ((7, 9), (4, 5)), ((5, 5), (1, 1))):
+            lat = torch.randn(2, H, W, 256, generator=g).to(dt)
+            coarse = torch.randn(2, Hc, Wc, 256, generator=g).to(dt)
+            ref = (lat.float() + F.interpolate(coarse.permute(0, 3, 1, 2).float(), size=(H, W), mode="nearest").permute(0, 2, 3, 1)).to(dt)
+            got = ops.add_upsample_nearest_(lat.clone(), coarse)
+            assert torch.equal(got, ref), (dt, H, W, Hc, Wc)
+    monkeypatch.setenv("MQ_FPN_TOPDOWN_FUSED", "1")
+    _assert_ok(kernels.check_swin_fpn(CPU))
 
 
 @pytest.mark.parametrize("clamp", [False, True])
