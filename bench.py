@@ -507,7 +507,7 @@ def _sub_bench(argv, env=None, timeout=150, keep=()):
 
 # every operator with two implementations on the one that was the default at the end of round 2 (ops.KERNEL_DEFAULTS lists today's)
 ROUND2_KERNEL_SET = {"MQ_LN_VARIANT": "1", "MQ_OFFSET_CONV_VARIANT": "1", "MQ_PATCH_MERGE_FUSED": "0", "MQ_FPN_VIA_DCN": "0", "MQ_NMS_EARLY_STOP": "0",
-                     "MQ_ATTN_RESIDENT": "0", "MQ_SWIN_MLP_VARIANT": "1", "MQ_ALIGN_FUSED": "0", "MQ_DYRELU_IN_LN": "0", "MQ_VLFUSE_I2T_VARIANT": "1", "MQ_SWIN_QKV_FUSED": "0"}
+                     "MQ_ATTN_RESIDENT": "0", "MQ_SWIN_MLP_VARIANT": "1", "MQ_ALIGN_FUSED": "0", "MQ_DYRELU_IN_LN": "0", "MQ_VLFUSE_I2T_VARIANT": "1", "MQ_SWIN_QKV_FUSED": "0", "MQ_FPN_TOPDOWN_FUSED": "0", "MQ_DCN_SYNC": "2"}
 
 
 def main():

@@ -81,8 +81,8 @@ KERNEL_DEFAULTS = {
                                  # GELU, bit 0 = no tail split, bit 2 = everything through the tail kernel
     "SWIN_QKV_FUSED": 2,         # the Swin qkv projection inside the window attention (mq_window_attn_qkv_fwd): 1 = at C = 96 (0.372 -> 0.137 ms
                                  # per block), 2 = also at C = 192 (weights streamed per head: 0.20 -> 0.137), 0 = GEMM + mq_window_attn_fwd
-    "FPN_TOPDOWN_FUSED": 0,      # 1: mq_add_upsample_nearest (lateral += up-sampled coarser level, in place: one pass instead of three); 0: F.interpolate
-                                 # + add.  Written after round 3's GPU budget was spent: equal results through tests/simt, NOT run on a device yet -> off
+    "FPN_TOPDOWN_FUSED": 1,      # 1: mq_add_upsample_nearest (lateral += up-sampled coarser level, in place: 25.6 us against 135 us for F.interpolate
+                                 # + add on P3 at B = 8, equal outputs on the device -- GPU call 16 of round 3); 0: F.interpolate + add
     "DYRELU_IN_LN": 1,           # 1: the DYReLU of fusion layers 0 .. L-2 is applied by the next layer's LayerNorm (mq_dyrelu_ln_fwd); 0: own pass
     "VLFUSE_I2T_VARIANT": 0,     # mq_vlfuse_i2t_fwd: 0 = Q fragments in registers where they fit (129 .. 160 keys: 0.428 -> 0.370 ms per launch),
                                  # 1 = Q tile in LDS for every caption longer than 128 tokens

@@ -521,7 +521,7 @@ def _body_alternate_kernel_selection(dev, monkeypatch):
     kernel for every caption length -- the tiny full model end to end against the oracle."""
     import parity_checks as pc
     from mq_det_amd import ops
-    for k in ("ATTN_RESIDENT", "PATCH_MERGE_FUSED", "FPN_VIA_DCN", "NMS_EARLY_STOP", "ALIGN_FUSED", "DYRELU_IN_LN", "SWIN_QKV_FUSED"):
+    for k in ("ATTN_RESIDENT", "PATCH_MERGE_FUSED", "FPN_VIA_DCN", "NMS_EARLY_STOP", "ALIGN_FUSED", "DYRELU_IN_LN", "SWIN_QKV_FUSED", "FPN_TOPDOWN_FUSED"):
         monkeypatch.setenv("MQ_" + k, "0")
     for k in ("LN_VARIANT", "OFFSET_CONV_VARIANT", "SWIN_MLP_VARIANT", "VLFUSE_I2T_VARIANT"):
         monkeypatch.setenv("MQ_" + k, "1")

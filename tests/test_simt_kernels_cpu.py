@@ -151,7 +151,7 @@ def test_kernel_block(kernels, name):
 
 
 def test_fpn_topdown_fused_equals_interpolate_plus_add(kernels, monkeypatch):
-    """mq_add_upsample_nearest (KERNELS["FPN_TOPDOWN_FUSED"] = 1, off by default: not run on a device yet) against F.interpolate(mode="nearest")
+    """mq_add_upsample_nearest (KERNELS["FPN_TOPDOWN_FUSED"] = 1) against F.interpolate(mode="nearest")
     + add on even and odd size pairs (the reference's top-down step, fpn.py:82-95): EQUAL outputs; and the Swin + FPN check with it on."""
     from mq_det_amd import ops
     g = torch.Generator().manual_seed(12)

@@ -9,9 +9,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 #    DCN checks only)
 MQ_LADDER_OUT=$R/gpurun_out/r04c1_ladder.jsonl timeout 1200 python -m pytest tests -q -m gpu --durations=5 > gpurun_out/r04c1_pytest.log 2>&1; tail -8 gpurun_out/r04c1_pytest.log | cut -c1-300
 # 2. end-to-end A/Bs, one switch per run, default twice (boxes differ by +-2 % run to run)
-# (MQ_FPN_TOPDOWN_FUSED=1: mq_add_upsample_nearest, written after round 3's GPU budget was spent -- off by default, equal results through tests/simt)
-MQ_FPN_TOPDOWN_FUSED=1 timeout 300 python -m pytest tests -q -m gpu -k "swin_fpn or check_full_model" 2>&1 | tail -2
-for v in NONE=0 MQ_FPN_TOPDOWN_FUSED=1 MQ_DCN_SYNC=2 MQ_SWIN_QKV_FUSED=1 MQ_SWIN_QKV_FUSED=0 MQ_VLFUSE_I2T_VARIANT=1 NONE=1; do
+for v in NONE=0 MQ_FPN_TOPDOWN_FUSED=0 MQ_DCN_SYNC=2 MQ_SWIN_QKV_FUSED=1 MQ_SWIN_QKV_FUSED=0 MQ_VLFUSE_I2T_VARIANT=1 NONE=1; do
   env $v timeout 200 python bench.py --steps 30 --warmup 3 --no-extras > gpurun_out/r04c1_ab_$v.log 2>&1
   echo "$v: $(tail -1 gpurun_out/r04c1_ab_$v.log | cut -c1-140)"
 done
