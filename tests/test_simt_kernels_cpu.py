@@ -150,6 +150,28 @@ def test_kernel_block(kernels, name):
     _assert_ok(getattr(kernels, name)(CPU))
 
 
+def test_dcn_barrier_schedules_are_equal():
+    """MQ_DCN_SYNC: one barrier per k-step (default since round 3) and the former two produce EQUAL outputs (same MFMA order) -- the switch
+    is read once per process, so each schedule runs in a process of its own; the descending / random wave orders of
+    test_kernels_are_insensitive_to_the_wave_schedule cover the default."""
+    import subprocess
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import simt; from mq_det_amd import ops\n"
+            "g = torch.Generator().manual_seed(5)\n"
+            "x = torch.randn(2, 19, 23, 256, generator=g).half(); om = torch.randn(2, 27, 19, 23, generator=g) * 1.5\n"
+            "w = (torch.randn(256, 9 * 256, generator=g) / 48).half(); b = torch.zeros(256).half()\n"
+            "with simt.installed():\n    y = ops.dcnv2(x, om, w, b, 1)[0]\n"
+            "torch.save(y, sys.argv[1])\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    outs = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for sync in ("1", "2"):
+            f = os.path.join(tmp, f"y{sync}.pt")
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, MQ_DCN_SYNC=sync), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-400:]
+            outs.append(torch.load(f))
+    assert torch.equal(outs[0], outs[1]) and float(outs[0].float().abs().mean()) > 0.01
+
+
 def test_fpn_topdown_fused_equals_interpolate_plus_add(kernels, monkeypatch):
     """mq_add_upsample_nearest (KERNELS["FPN_TOPDOWN_FUSED"] = 1) against F.interpolate(mode="nearest")
     + add on even and odd size pairs (the reference's top-down step, fpn.py:82-95): EQUAL outputs; and the Swin + FPN check with it on."""
