@@ -269,7 +269,7 @@ def swin_forward(P, cfg, img, p="backbone.body", SW=None):
                     h1 = _ln(P, b + ".norm1", x)
                 else:
                     h1, x = _add_ln(P, b + ".norm1", pend, x)                               # x = x + mlp(...)  (swint.py:240)
-            if ops.window_qkv_fused(C, ws):
+            if ops.window_qkv_fused(C, ws, h1.numel()):
                 a = ops.window_attention_qkv(h1.reshape(B, H, W, C), P[b + ".attn.qkv.weight"], P[b + ".attn.qkv.bias"],
                                              P[b + ".attn.rel_bias"], heads, ws, shift)               # the qkv tensor is never written
             else:

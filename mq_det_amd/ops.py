@@ -318,11 +318,12 @@ def window_attention(qkv, qkv_bias, rel_bias, heads, ws, shift):
 WINDOW_QKV_WIDTHS = (96, 192)      # widths mq_window_attn_qkv_fwd is instantiated for (192: weights streamed per head)
 
 
-def window_qkv_fused(C, ws):
+def window_qkv_fused(C, ws, numel=0):
     """Does the kernel selection route a Swin block of width C / window ws through mq_window_attn_qkv_fwd?  SWIN_QKV_FUSED: 0 never,
-    1 the resident-weight width (96), 2 also the streamed one (192)."""
+    1 the resident-weight width (96), 2 also the streamed one (192).  numel: elements of the [B,H,W,C] input (the kernel addresses it
+    with 32-bit offsets)."""
     k = KERNELS["SWIN_QKV_FUSED"]
-    return ws * ws <= 64 and ((k >= 1 and C == 96) or (k >= 2 and C == 192))
+    return ws * ws <= 64 and numel < 2 ** 31 and ((k >= 1 and C == 96) or (k >= 2 and C == 192))
 
 
 
