@@ -187,11 +187,11 @@ extern "C" int MQ_SYM(mq_align_fused_fwd)(const void* tok, const void* tk, const
   const size_t text = (size_t)p.TL * AF_PITCH * sizeof(half_t);
   const size_t prob = ((size_t)AF_NW * 16 * p.TL + AF_NW * 16) * sizeof(float);
   const size_t smem = text > prob ? text : prob;
-  static bool attr = false;
-  if (!attr) {
+  static MqOncePerDevice attr;
+  if (attr.first()) {
     hipError_t e = hipFuncSetAttribute((const void*)align_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    attr.done();
   }
   const unsigned grid = (unsigned)(B * ((N + AF_BM - 1) / AF_BM));
   hipLaunchKernelGGL(align_fused_kernel, dim3(grid), dim3(64 * AF_NW), smem, (hipStream_t)stream, p);

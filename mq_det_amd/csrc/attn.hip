@@ -370,12 +370,12 @@ template <int D, int RB, bool MASK>
 static int launch_attn(const AttnParams& p, hipStream_t stream) {
   constexpr int BM = 4 * RB * 16, BN = 64;
   constexpr size_t smem = (size_t)(BN * (D + 8) + D * (BN + 8) + 4 * RB * 16 * (BN + 8) + (D >= 256 ? BM * (D + 8) : 0)) * sizeof(half_t) + BN * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static MqOncePerDevice attr_set;
+  if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<D, RB, MASK>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set.done();
   }
   const int groups = p.B * p.nsplit, members = p.H * ((p.Nq + BM - 1) / BM);
   dim3 grid((unsigned)(8 * ((groups + 7) / 8) * members));

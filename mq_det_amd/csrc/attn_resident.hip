@@ -227,11 +227,11 @@ __global__ __launch_bounds__(256) void attn_resident_kernel(ResAttnParams p) {
 template <int D, bool MASK, bool CLAMP>
 static int launch_resident_c(const ResAttnParams& p, hipStream_t stream) {
   constexpr size_t smem = (size_t)(RES_NKMAX * (D + 8) + D * (RES_NKMAX + 8)) * sizeof(half_t) + 2 * RES_NKMAX * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static MqOncePerDevice attr_set;
+  if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_resident_kernel<D, MASK, CLAMP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set.done();
   }
   const int qtiles = (p.Nq + RES_BM - 1) / RES_BM;
   hipLaunchKernelGGL((attn_resident_kernel<D, MASK, CLAMP>), dim3((unsigned)(qtiles * p.B * p.H)), dim3(256), smem, stream, p);
@@ -519,11 +519,11 @@ __global__ __launch_bounds__(256) void attn_chunked_combine_kernel(ResAttnParams
 template <int D, bool CLAMP>
 static int launch_chunked_c(const ResAttnParams& p, float* ws, int nsplit, hipStream_t stream) {
   constexpr size_t smem = (size_t)2 * (RES_NKMAX * (D + 8) + D * (RES_NKMAX + 8)) * sizeof(half_t) + 4 * RES_NKMAX * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static MqOncePerDevice attr_set;
+  if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_chunked_kernel<D, CLAMP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set.done();
   }
   const int qtiles = (p.Nq + RES_BM - 1) / RES_BM;
   hipLaunchKernelGGL((attn_chunked_kernel<D, CLAMP>), dim3((unsigned)(qtiles * p.B * p.H * nsplit)), dim3(256), smem, stream, p, ws, nsplit);

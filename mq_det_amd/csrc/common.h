@@ -82,6 +82,28 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// hipFuncSetAttribute (LDS above 64 KB) and the CU count are per-DEVICE properties: a process that drives several GPUs sets / reads them
+// once per device, not once per process.
+struct MqOncePerDevice {
+  bool set_[32] = {};
+  int dev_ = -1;
+  bool first() {
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 32) { dev_ = -1; return true; }
+    return !set_[dev_];
+  }
+  void done() { if (dev_ >= 0) set_[dev_] = true; }
+};
+static inline int mq_device_cus() {
+  static int cus[32] = {};
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return 256;
+  if (!cus[dev]) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
 #define MQ_CHECK_LAUNCH()                                   \
   do {                                                      \
     hipError_t e__ = hipGetLastError();                     \

@@ -213,12 +213,12 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
   constexpr size_t tiles = (size_t)(2 * BM * LP + 2 * BN * LP) * sizeof(half_t);
   constexpr size_t ostage = (size_t)BM * (BN + 8) * sizeof(half_t);
   constexpr size_t smem = tiles > ostage ? tiles : ostage;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static MqOncePerDevice attr_set;
+  if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<DEFORM, BN, WM, WN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set.done();
   }
   long M = (long)p.B * p.Ho * p.Wo;
   hipLaunchKernelGGL((conv_igemm_kernel<DEFORM, BN, WM, WN>), dim3((unsigned)(8 * (((M + BM - 1) / BM + 7) / 8))), dim3(256), smem, stream, p);

@@ -424,13 +424,13 @@ extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* 
   constexpr size_t tiles = (size_t)(2 * 128 * 64 + 2 * 256 * 64) * sizeof(half_t) + 128 * 9 * sizeof(TapState);
   constexpr size_t ostage = (size_t)128 * (256 + 8) * sizeof(half_t) + (size_t)16 * 32 * 24 * sizeof(float);
   constexpr size_t smem = tiles > ostage ? tiles : ostage;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static MqOncePerDevice attr_set;
+  if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute((const void*)dcn_igemm8_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dcn_igemm8_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dcn_igemm8_kernel<16, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set.done();
   }
   static const int nw = [] { const char* e = getenv("MQ_DCN_WAVES"); return (e && e[0] == '8') ? 8 : 16; }();   // A/B switch
   const dim3 grid((unsigned)(8 * ((g.tiles_all + 7) / 8)));

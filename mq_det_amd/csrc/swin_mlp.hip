@@ -284,11 +284,11 @@ __global__ __launch_bounds__(64 * NW) void swin_mlp_kernel(SwinMlpParams p) {
 template <int C, int HS, int T, int NW>
 static int launch_swin_mlp(const SwinMlpParams& p, hipStream_t s) {
   constexpr size_t smem = (size_t)2 * (HS * (C + 8) + C * (HS + 8)) * 2;
-  static bool attr = false;
-  if (!attr) {
+  static MqOncePerDevice attr;
+  if (attr.first()) {
     hipError_t e = hipFuncSetAttribute((const void*)swin_mlp_kernel<C, HS, T, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    attr.done();
   }
   constexpr int BM = 16 * T * NW;
   const unsigned grid = (unsigned)((p.M + BM - 1) / BM);

@@ -515,25 +515,17 @@ __global__ __launch_bounds__(64 * NWT) void swin_mlp2_tail_kernel(SwinMlp2Params
   }
 }
 
-static int device_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cus = n;
-  }
-  return cus;
-}
+static int device_cus() { return mq_device_cus(); }
 
 template <int C, int NW, bool TABLE>
 static int launch_swin_mlp2_main(const SwinMlp2Params& p, hipStream_t s) {
   constexpr size_t smem = (size_t)2 * (2 * (C / 32) + C / 16) * 512 * sizeof(half_t) + (size_t)4 * C * sizeof(half_t) +
                           (TABLE ? MQ_GELU_TAB_N * 2 * sizeof(float) : 0);
-  static bool attr = false;
-  if (!attr) {
+  static MqOncePerDevice attr;
+  if (attr.first()) {
     hipError_t e = hipFuncSetAttribute((const void*)swin_mlp2_kernel<C, NW, TABLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    attr.done();
   }
   constexpr int BM = 16 * NW;
   const unsigned grid = (unsigned)((p.M + BM - 1) / BM);
@@ -545,11 +537,11 @@ static int launch_swin_mlp2_main(const SwinMlp2Params& p, hipStream_t s) {
 template <int C, int NWT>
 static int launch_swin_mlp2_tail(const SwinMlp2Params& p, hipStream_t s) {
   constexpr size_t smem = (size_t)NWT * NWT * 64 * sizeof(float4_) + (size_t)2 * NWT * 16 * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
+  static MqOncePerDevice attr;
+  if (attr.first()) {
     hipError_t e = hipFuncSetAttribute((const void*)swin_mlp2_tail_kernel<C, NWT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    attr.done();
   }
   hipLaunchKernelGGL((swin_mlp2_tail_kernel<C, NWT>), dim3((unsigned)((p.M + 15) / 16)), dim3(64 * NWT), smem, s, p);
   MQ_CHECK_LAUNCH();

@@ -382,11 +382,11 @@ template <int NT, int QB, int NBL, int ABL = 0, bool QREG = false>
 static int launch_i2t(const I2TParams& p, hipStream_t stream) {
   constexpr size_t smem = (size_t)(2 * TILE + ((NT >= 3 && !QREG) ? BM * KS : 0)) * sizeof(half_t) + (size_t)VH * NT * TK * sizeof(float);
   static_assert(4 * 32 * (VD + 8) <= 2 * TILE, "O staging must fit in the tiles");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static MqOncePerDevice attr_set;
+  if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute((const void*)vlfuse_i2t_kernel<NT, QB, NBL, ABL, QREG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set.done();
   }
   const int qtiles = (p.N + BM - 1) / BM;
   hipLaunchKernelGGL((vlfuse_i2t_kernel<NT, QB, NBL, ABL, QREG>), dim3((unsigned)(8 * ((p.B + 7) / 8) * qtiles)), dim3(2048 / (QB * 4)), smem, stream, p);
@@ -709,14 +709,14 @@ extern "C" int MQ_SYM(mq_vlfuse_t2i_fwd)(const void* kf, const void* v_ln, const
   p.B = B; p.N = N; p.T = T; p.H = heads; p.nsplit = nsplit; p.clamp = clamp; p.wr = 16 * vlfuse_qb();
   p.kmask = key_mask; p.kmask_bs = key_mask_bs;
   constexpr size_t smem = (size_t)2 * TILE * sizeof(half_t);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static MqOncePerDevice attr_set;
+  if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute((const void*)vlfuse_t2i_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)vlfuse_t2i_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)vlfuse_t2i_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)vlfuse_t2i_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set.done();
   }
   const int rows = (kv_len && max_kv > 0) ? min(max_kv, T) : T;          // host-known bound of the live text rows
   const int groups = B * nsplit, members = (heads * ((rows + p.wr - 1) / p.wr) + (128 / p.wr) - 1) / (128 / p.wr);

@@ -457,11 +457,11 @@ __global__ __launch_bounds__(256, STREAM ? 1 : 2) void window_attn_qkv_kernel(Wi
 template <int C, bool STREAM>
 static int launch_window_attn_qkv(const WinQkvParams& p, hipStream_t s) {
   constexpr size_t smem = (STREAM ? (size_t)2 * 96 * C : (size_t)3 * C * (C + 8)) * sizeof(half_t) + (size_t)3 * C * sizeof(half_t);
-  static bool attr = false;
-  if (!attr) {
+  static MqOncePerDevice attr;
+  if (attr.first()) {
     hipError_t e = hipFuncSetAttribute((const void*)window_attn_qkv_kernel<C, STREAM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    attr.done();
   }
   int cus = 256, dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;

@@ -15,6 +15,7 @@ from collections import OrderedDict
 import torch
 from torch import nn
 
+from .. import ops as _ops
 from ..structures import BoxList, to_image_list
 from . import pipeline
 from .poolers import CustomPooler, Pooler
@@ -94,6 +95,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
         self.tokenizer = tokenizer if tokenizer is not None else self._load_tokenizer(cfg)
         self._plan = None
         self._plan_key = None
+        self._kernels = None                                      # kernel selection of the plan (ops.configure), set by prepare()
         self._anchor_cache = {}
         self._graphs = OrderedDict()                              # LRU of captured HIP graphs, keyed by static shapes only
         self._graph_pool = None                                   # one memory pool shared by every captured graph
@@ -144,7 +146,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
             raise RuntimeError("mq_det_amd runs on MI355X only (HIP kernels, no CPU fallback); got device " + str(device))
         from .. import ops
         ops.load_library()
-        ops.configure(self.cfg)                                    # kernel selection: read once per plan, not per call
+        self._kernels = dict(ops.configure(self.cfg))              # kernel selection: read once per plan, kept WITH the plan
         self._validate_config()
         self._plan = pipeline.build_plan(self.state_dict(), self.cfg, device, dtype=compute_dtype(self.cfg))
         self._plan_key = device
@@ -201,6 +203,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
             images = to_image_list(images)
             if self._plan is None or self._plan_key != images.tensors.device:
                 self.prepare(images.tensors.device)
+            _ops.activate(self._kernels)
             dtype = self._plan["backbone.body.patch_embed.proj.weight"].dtype
             x = images.tensors.to(dtype).contiguous(memory_format=torch.channels_last)
             visual_features, _ = self._backbone_stage(x)
@@ -269,7 +272,17 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
         gates = lang["vision_query_gates"]
         if gates is not None:                                     # reference: attn_gate.mean().item() per GCP layer (a float)
             gates = torch.stack([g.float().mean() for g in gates])
-        return {"packed": packed, "counts": post["counts"], "gates": gates}
+        # one int per image for the single device->host transfer: live slots, bit 16 = more ties with the K-th score than tie slots
+        return {"packed": packed, "counts": post["counts"] + post["tie_overflow"].to(post["counts"].dtype) * 65536, "gates": gates}
+
+    def _split_counts(self, counts):
+        """Packed per-image counts -> live slots; remembers (and warns about) images whose ties with the K-th score did not fit."""
+        self.last_tie_overflow = [bool(c >> 16) for c in counts]
+        if any(self.last_tie_overflow):
+            import warnings
+            warnings.warn(f"{sum(self.last_tie_overflow)} image(s) had more detections tied with the DETECTIONS_PER_IMG-th score than "
+                          "MODEL.ATSS.TIE_SLOTS output slots: the reference would return all of them (rpn/inference.py:757-766)")
+        return [c & 0xFFFF for c in counts]
 
     def _full_program(self, x, input_ids, attention_mask, vision, idx, tokidx, label_ids, im_wh, max_kv=0, want_raw=False):
         """Whole device forward.  The image-independent part of the language backbone (embeddings + BERT layers below
@@ -319,6 +332,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
         dev = images.tensors.device
         if self._plan is None or self._plan_key != dev:
             self.prepare(dev)
+        _ops.activate(self._kernels)
         P, cfg = self._plan, self.cfg
         dtype = P["backbone.body.patch_embed.proj.weight"].dtype
         Bn = images.tensors.shape[0]
@@ -354,6 +368,11 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
                 hit = build_token_index(positive_map, labels_in_caption, dev)
             self._tokidx_cache[tk] = hit
         tokidx, label_ids = hit
+        if max_kv > 0:
+            # the alignment kernel scores text columns below 16 ceil(max_kv / 16) only: a positive_map that names a token behind the
+            # caption's last live one (abnormal, but legal for the reference, which scores all T columns) widens the bound instead of
+            # being scored as 0 inside a MEAN
+            max_kv = max(max_kv, len(positive_map) if onehot else 1 + max((t for k in labels_in_caption for t in positive_map[k]), default=-1))
         wh_key = (tuple(images.image_sizes), str(dev))
         im_wh = self._wh_cache.get(wh_key)
         if im_wh is None:
@@ -407,6 +426,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
             counts, gates = [int(c) for c in counts[:Bn]], counts[Bn:]
         else:
             counts = out["counts"].tolist()                       # the one device->host sync of the forward
+        counts = self._split_counts(counts)
         result = []
         for b, (h, w) in enumerate(images.image_sizes):
             n = counts[b]
@@ -426,6 +446,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
         dev = images.tensors.device
         if self._plan is None or self._plan_key != dev:
             self.prepare(dev)
+        _ops.activate(self._kernels)
         src = images.tensors
         fc = self._feat_cache if self.backbone_cache else None
         if fc is not None and fc["src"] is src and fc["version"] == src._version and (fc["pooled"] is not None or not self._use_vq()):
@@ -487,7 +508,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
                     pm = {k: [t for t in (v if not isinstance(v, int) else [v]) if t < T] for k, v in pm.items()}
                 ids.append(i)
                 ams.append(a)
-                kvs.append(kv)
+                kvs.append(max(kv, 1 + max((t for v in pm.values() for t in (v if not isinstance(v, int) else [v])), default=-1)) if kv > 0 else kv)
                 pms.append(pm)
                 labs.append([k for k, v in pm.items() if len(v) != 0])
             T = ids[0].shape[1]
@@ -523,7 +544,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
                       rep(torch.cat(ams)), vision, idx, tok3, lab2, im_wh.repeat(g, 1), max(kvs))
             out = self._run("_rest_program", inputs, use_graph)
             packed = out["packed"].clone()
-            counts = out["counts"].tolist()
+            counts = self._split_counts(out["counts"].tolist())
             for c in range(g):
                 res = []
                 for b, (h, w) in enumerate(images.image_sizes):

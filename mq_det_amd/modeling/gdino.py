@@ -14,6 +14,7 @@ from collections import OrderedDict
 import torch
 from torch import nn
 
+from .. import ops as _ops
 from ..structures import BoxList, to_image_list
 from . import gdino_pipeline as gp
 from .detector import compute_dtype, expand_bbox, pool_into_bank
@@ -47,6 +48,7 @@ class GroundingDINO(GraphRunner, nn.Module):
         self.specical_tokens = self.tokenizer.convert_tokens_to_ids(["[CLS]", "[SEP]", ".", "?"])      # (sic) groundingdino.py:194
         self._swin = gdino_swin_cfg(cfg)
         self._plan = self._plan_key = None
+        self._kernels = None                                      # kernel selection of the plan (ops.configure), set by prepare()
         self._graphs = OrderedDict()
         self._geo_cache, self._txt_cache, self._map_cache = OrderedDict(), OrderedDict(), OrderedDict()
         self._feat_cache = None                                   # projected levels of the last image batch
@@ -111,7 +113,7 @@ class GroundingDINO(GraphRunner, nn.Module):
             raise RuntimeError("mq_det_amd runs on MI355X only (HIP kernels, no CPU fallback); got device " + str(device))
         from .. import ops
         ops.load_library()
-        ops.configure(self.cfg)                                    # kernel selection: read once per plan, not per call
+        self._kernels = dict(ops.configure(self.cfg))              # kernel selection: read once per plan, kept WITH the plan
         self._plan = gp.build_gdino_plan(self.state_dict(), self.cfg, device, self._swin, dtype=compute_dtype(self.cfg))
         self._plan_key = device
         return self._plan
@@ -203,6 +205,7 @@ class GroundingDINO(GraphRunner, nn.Module):
         dev = images.tensors.device
         if self._plan is None or self._plan_key != dev:
             self.prepare(dev)
+        _ops.activate(self._kernels)
         P = self._plan
         dtype = P["backbone.0.patch_embed.proj.weight"].dtype
         Bn, _, H, W = images.tensors.shape
@@ -273,6 +276,7 @@ class GroundingDINO(GraphRunner, nn.Module):
             images = to_image_list(samples)
             if self._plan is None or self._plan_key != images.tensors.device:
                 self.prepare(images.tensors.device)
+            _ops.activate(self._kernels)
             from . import pipeline
             P = self._plan
             x = images.tensors.to(P["backbone.0.patch_embed.proj.weight"].dtype).contiguous(memory_format=torch.channels_last)

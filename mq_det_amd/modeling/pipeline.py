@@ -805,7 +805,8 @@ def vldyhead(P, cfg, feats, lang, trace=None):
     emb = F.normalize((hidden if h32 is None else h32).float(), p=2, dim=-1)
     tk = F.linear(emb / 2.0, P[p + ".tok.weight"], P[p + ".tok.bias"]) * P[p + ".inv_scale"]       # [B, T, 256]
     tbias = (emb @ P[p + ".bias_lang32"] + P[p + ".bias0_32"]).contiguous()                           # [B, T]
-    if ops.KERNELS["ALIGN_FUSED"] == 1:
+    if ops.KERNELS["ALIGN_FUSED"] == 1 and tk.shape[1] <= 256 and tok.shape[-1] == 256 and len(sizes) <= 8:
+        # (shapes the fused kernel does not take -- more than 256 text tokens, other widths, more than 8 levels -- use the GEMM path below)
         # heads + alignment + scoring happen in ONE kernel inside postprocess() (mq_align_fused_fwd): hand over its operands
         return {"tok": tok, "sizes": sizes, "tk16": tk.to(tok.dtype).contiguous(), "tbias": tbias, "max_kv": max_kv,
                 "wbc": P[p + ".wbc"], "bbc": P[p + ".bbc"], "scales": P[p + ".scales"],
@@ -839,7 +840,8 @@ def grid_anchors(P, sizes, strides, device):
     return out
 
 
-TIE_SLOTS = 16      # output slots behind DETECTIONS_PER_IMG for detections tied with the last kept score (more ties than this are cut)
+TIE_SLOTS = 16      # output slots behind DETECTIONS_PER_IMG for detections tied with the last kept score; cfg.MODEL.ATSS.TIE_SLOTS overrides.
+                    # More ties than slots are cut AND flagged: `tie_overflow` [B] in the result (bit 16 of the packed counts the detector reads)
 
 
 def postprocess(cfg, head, anchors, im_wh, tokidx, label_ids, want_cls=False):
@@ -921,15 +923,18 @@ def postprocess(cfg, head, anchors, im_wh, tokidx, label_ids, want_cls=False):
     # than K.  Fixed shapes here: K + TIE_SLOTS output slots; the slots behind K are live only for scores equal to the K-th.
     Kd = int(A.DETECTIONS_PER_IMG)
     K = min(Kd, tot) if Kd > 0 else tot
-    K2 = min(K + TIE_SLOTS, tot) if Kd > 0 else tot
+    K2 = min(K + int(A.get("TIE_SLOTS", TIE_SLOTS)), tot) if Kd > 0 else tot
     keep = ops.ml_nms(boxes, labels, nvalid, A.NMS_TH, max_keep=K2 if Kd > 0 else 0)
     kept_scores = torch.where(keep, scores, torch.full_like(scores, -1.0))
     top, ti = torch.topk(kept_scores, K2, dim=1, sorted=True)
     if K2 > K:
         tie = top[:, K:] == top[:, K - 1:K]
         top = torch.cat([top[:, :K], torch.where(tie, top[:, K:], torch.full_like(top[:, K:], -1.0))], 1)
+    # every tie slot taken by a score equal to the K-th: the NMS sweep stopped at K2 kept boxes, more ties may exist behind them (the
+    # reference would return them all) -- detectable, not silent
+    overflow = ((top[:, K2 - 1] == top[:, K - 1]) & (top[:, K - 1] > 0)) if 0 < K < K2 < tot else torch.zeros(Bn, dtype=torch.bool, device=dev)
     out = {"boxes": torch.gather(boxes, 1, ti[:, :, None].expand(-1, -1, 4)), "scores": top,
-           "labels": torch.gather(labels, 1, ti).to(torch.int64), "counts": (top > 0).sum(1),
+           "labels": torch.gather(labels, 1, ti).to(torch.int64), "counts": (top > 0).sum(1), "tie_overflow": overflow,
            "pre_nms": {"boxes": boxes, "scores": scores, "labels": labels, "nvalid": nvalid, "keep": keep}}
     if want_cls:
         out["cls"] = cls_all

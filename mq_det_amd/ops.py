@@ -13,6 +13,7 @@ _LIB = None
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmqdet_hip.so")
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+EXPECTED_ABI = 20        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
 _SIGNATURES = {
     "mq_abi_version": (_i, []),
     "mq_attn_workspace_bytes": (_l, [_i, _i, _i, _i, _i]),
@@ -88,7 +89,7 @@ KERNEL_DEFAULTS = {
                                  # 1 = Q tile in LDS for every caption longer than 128 tokens
     "ALIGN_FUSED": 1,            # 1: mq_align_fused_fwd (heads + alignment + scoring, logits never written); 0: bmm + 5 GEMMs + 5 x mq_align_scores_fwd
 }
-KERNELS = dict(KERNEL_DEFAULTS)
+KERNELS = dict(KERNEL_DEFAULTS)       # filled from the environment right below configure() (import time), from cfg in prepare()
 
 
 def configure(cfg=None):
@@ -108,6 +109,18 @@ def configure(cfg=None):
     return KERNELS
 
 
+def activate(sel):
+    """Make `sel` (the table a model's prepare() got from configure()) the live selection again.  Every model keeps ITS selection with its
+    plan and activates it at the top of each forward, so building a second model with another cfg.MODEL.KERNELS cannot change which
+    kernels the first one launches eagerly (its captured HIP graphs hold the selection they were recorded with anyway) -- ADVICE r3."""
+    if sel is not None and KERNELS != sel:
+        KERNELS.clear()
+        KERNELS.update(sel)
+
+
+configure()        # import time: defaults <- environment MQ_<NAME>, so direct users of ops.* that never call configure() see the env too
+
+
 def lib_path():
     return _LIB_PATH
 
@@ -123,6 +136,12 @@ def load_library():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)           # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
+        got = lib.mq_abi_version()
+        if got != EXPECTED_ABI:
+            # a library from another revision of csrc/ exports the same names with other argument lists: calling it would pass shifted
+            # pointers / ints -- refuse instead
+            raise RuntimeError(f"{_LIB_PATH} has ABI version {got}, these bindings are written for {EXPECTED_ABI}: "
+                               "rebuild it (python -m mq_det_amd.build --force)")
         _LIB = lib
     return _LIB
 

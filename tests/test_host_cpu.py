@@ -148,6 +148,30 @@ def test_gloo_world2_detection_gather():
     assert r.stdout.count("GATHER_OK") == 2
 
 
+def test_bench_gpus_flag_starts_the_ranks():
+    """`python bench.py --gpus 2` (no launcher around it) starts 2 ranks itself; the line says n_gpus = 2 and the one
+    fixed-shape gather of the data path ran across them (--dry-launch: no kernels, gloo).  A rank count that differs from --gpus is
+    refused with a non-zero status instead of reporting a number for the wrong world size."""
+    import json
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-launch", "--steps", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                       # rank 0 only
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["comm"]["ranks"] == 2 and d["gather_ok"] and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
+    # the driver's explicit form, same result
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29537", bench, "--gpus", "2", "--dry-launch"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert [json.loads(ln)["n_gpus"] for ln in r.stdout.splitlines() if ln.startswith("{")] == [2]
+    # mismatch: 1 rank in the environment, 2 asked for
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-launch"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "refusing" in r.stderr and "{" not in r.stdout
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="compares with reference code executed in place")
 def test_gloo_world2_evaluator_gather_matches_reference():
     """per-category top-k accumulation + cross-rank gather as tensors == the reference's LvisEvaluatorFixedAP

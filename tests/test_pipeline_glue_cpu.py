@@ -142,6 +142,14 @@ def test_final_selection_keeps_detections_tied_with_the_kth_score(setup, emulate
         ref = sorted((int(l), round(float(s), 5)) for l, s in zip(d["labels"], d["scores"]))
         assert got == ref, (b, got, ref)
     assert more_than_k                                                  # the case exercises the tie rule (more kept than DETECTIONS_PER_IMG)
+    assert not bool(post["tie_overflow"].any())                         # ... and every tie found a slot
+    # fewer tie slots than ties: the cut is FLAGGED per image, and the slots that exist still hold ties only
+    cfg.MODEL.ATSS.TIE_SLOTS = 1
+    with torch.no_grad():
+        cut = pipeline.postprocess(cfg, head, anchors, sizes, tokidx, label_ids)
+    assert cut["scores"].shape[1] == 7
+    for b, d in enumerate(odets):
+        assert bool(cut["tie_overflow"][b]) == (len(d["scores"]) > 7), (b, len(d["scores"]))
 
 
 def test_gcp_index_matches_reference_topk_trick(setup):
