@@ -38,12 +38,35 @@ def use_dtype(dtype):
     _CACHE.clear()
 
 
+# VERDICT r3 item 8 -- every gate at max(1e-3, 2 x measured): tests/golden/device_measured.json holds, per row name, the normalised error
+# the MI355X produced (tools/measured_gate.py from the ladder file of a whole GPU-suite run).  ON THE DEVICE a row found there is gated at
+# min(stated tolerance, max(1e-3 x dtype scale, 2 x measured)): a kernel that gets 3 x worse than its last measurement fails whatever the
+# stated per-family tolerance allows.  (The CPU emulation of the kernel sources rounds differently in exp / rcp: it keeps the stated values.)
+MEASURED_GATE = torch.cuda.is_available()
+MEASURED_MARGIN, MEASURED_FLOOR = 2.0, 1e-3
+_MEASURED = None
+
+
+def _measured(name):
+    global _MEASURED
+    if _MEASURED is None:
+        import json
+        import os
+        f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "device_measured.json")
+        _MEASURED = json.load(open(f))["norm_err"] if os.path.exists(f) else {}
+    return _MEASURED.get(name)
+
+
 def _stat(name, got, ref, tol=TOL):
     tol = tol * TOL_SCALE
     if H16 == torch.bfloat16:
         name = "[bf16] " + name
     elif H16 == torch.float32:
         name, tol = "[fp32 operands] " + name, min(tol, F32_TOL)
+    if MEASURED_GATE and tol > 0 and H16 != torch.float32:
+        m = _measured(name)
+        if m is not None:
+            tol = min(tol, max(MEASURED_FLOOR * TOL_SCALE, MEASURED_MARGIN * m))
     got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
     err = (got - ref).abs().max().item() if ref.numel() else 0.0
     scale = max(1.0, ref.abs().max().item() if ref.numel() else 1.0)
@@ -197,10 +220,10 @@ def check_window_attention(dev, large=False):
             ref = o[:, :H, :W]
             qkv_dev = F.linear(y.to(dev), P[b + ".qkv.weight"], P[b + ".qkv.bias"]).reshape(2, H, W, 3 * C)
             got = ops.window_attention(qkv_dev, P[b + ".qkv.bias"], P[b + ".rel_bias"], heads, ws, shift)
-            res.append(_stat(f"window_attn ws={ws} stage{stage} {H}x{W} shift={shift}", got, ref, tol=4e-3))
+            res.append(_stat(f"window_attn ws={ws} stage{stage} {H}x{W} shift={shift}", got, ref, tol=1.5e-3))
             if C in ops.WINDOW_QKV_WIDTHS and ws * ws <= 64:            # the qkv projection inside the kernel (mq_window_attn_qkv_fwd)
                 got2 = ops.window_attention_qkv(y.to(dev), P[b + ".qkv.weight"], P[b + ".qkv.bias"], P[b + ".rel_bias"], heads, ws, shift)
-                res.append(_stat(f"window_attn with the qkv projection inside ws={ws} stage{stage} {H}x{W} shift={shift}", got2, ref, tol=4e-3))
+                res.append(_stat(f"window_attn with the qkv projection inside ws={ws} stage{stage} {H}x{W} shift={shift}", got2, ref, tol=1.5e-3))
                 res.append(_stat("... vs GEMM + mq_window_attn_fwd", got2, got.float().cpu(), tol=2e-3))
     return res
 
@@ -240,7 +263,7 @@ def check_gcp_block(dev):
         sup = ops.gcp_sparse_attention(q, kv, idx.to(dev))
     noq = (vmask.sum(1) == 0)
     z = _stat("gcp sparse attn: zero rows for tokens w/o query", sup.cpu()[noq], torch.zeros_like(sup.cpu()[noq]), tol=0.0)
-    return [_stat("gcp gated cross-attention block", got, ref, tol=6e-3), z]
+    return [_stat("gcp gated cross-attention block", got, ref, tol=2.5e-3), z]
 
 
 def check_pre_select(dev):
@@ -254,7 +277,7 @@ def check_pre_select(dev):
     with torch.no_grad():
         ref = ol.pre_select(sd, p, vis.float(), img.float(), spec)
         got = pipeline.pre_select(P, p, vis.to(dev), img.to(dev), 1.0)
-    return _stat("gcp pre-select (2 layers, Nk=333 ragged)", got, ref, tol=1e-2)
+    return _stat("gcp pre-select (2 layers, Nk=333 ragged)", got, ref, tol=2.5e-3)
 
 
 def check_bert_layer(dev, clamp):
@@ -272,7 +295,7 @@ def check_bert_layer(dev, clamp):
         ref = ol.bert_layer(sd, b, x.float(), ol.extended_mask(am), spec.bert_heads, spec.bert_eps, clamp=clamp)
         kb = ((1.0 - am.float()) * -1e30).to(dev)
         got = pipeline.bert_layer(P, b, x.to(dev), kb, clamp)
-    return _stat(f"bert layer clamp={clamp}", got, ref, tol=8e-3)
+    return _stat(f"bert layer clamp={clamp}", got, ref, tol=2.5e-3)
 
 
 def check_vl_fuse(dev):
@@ -290,8 +313,8 @@ def check_vl_fuse(dev):
         rv, rl = oh.vl_fuse(sd, b, [f.float() for f in feats], l.float(), am, spec)
         kb = ((1.0 - am.float()) * -1e30).to(dev)
         gv, gl = pipeline.vl_fuse(P, b, [f.to(dev).contiguous(memory_format=torch.channels_last) for f in feats], l.to(dev), kb)
-    out = [_stat(f"vlfuse image side lvl{i}", gv[i], rv[i], tol=8e-3) for i in range(5)]
-    out.append(_stat("vlfuse text side", gl, rl, tol=8e-3))
+    out = [_stat(f"vlfuse image side lvl{i}", gv[i], rv[i], tol=2.5e-3) for i in range(5)]
+    out.append(_stat("vlfuse text side", gl, rl, tol=2.5e-3))
     return out
 
 
@@ -725,7 +748,7 @@ def check_dyconv(dev):
         ref = oh.dyconv(sd, b, [f.float() for f in feats], spec)
         x = [f.to(dev).contiguous(memory_format=torch.channels_last) for f in feats]
         got = pipeline.dyconv(P, cfg, b, x)
-        res = [_stat(f"dyconv (grouped fused DCNv2) lvl{i}", got[i], ref[i], tol=1e-2) for i in range(5)]
+        res = [_stat(f"dyconv (grouped fused DCNv2) lvl{i}", got[i], ref[i], tol=2.5e-3) for i in range(5)]
         # the same layer with its DYReLU left to the next layer's LayerNorm (mq_dyrelu_ln_fwd): LN(dyconv(x)) of the oracle
         from mq_det_amd import ops
         tok, szs = pipeline._to_tokens(x)
@@ -734,7 +757,7 @@ def check_dyconv(dev):
         got_ln = ops.dyrelu_layer_norm(pre, coef, szs, gw, gb, 1e-5)
         ref_tok = torch.cat([r.flatten(2).transpose(1, 2) for r in ref], 1)
         ref_ln = F.layer_norm(ref_tok, (256,), gw.float().cpu(), gb.float().cpu(), 1e-5)
-        res.append(_stat("dyconv with DYReLU applied by the next LayerNorm: LN(dyconv(x)), all levels", got_ln, ref_ln, tol=1.5e-2))
+        res.append(_stat("dyconv with DYReLU applied by the next LayerNorm: LN(dyconv(x)), all levels", got_ln, ref_ln, tol=2.5e-3))
         unf = ops.layer_norm(torch.cat([g_.flatten(2).transpose(1, 2) for g_ in got], 1).contiguous(), gw, gb, 1e-5)
         res.append(_stat("... vs the stand-alone DYReLU pass + LayerNorm of the product", got_ln, unf.float().cpu(), tol=1e-2))
     return res
@@ -804,22 +827,22 @@ def check_full_model(dev, vision_queries=True, large=False):
         dets, inter = od.forward(sd, spec, images, sizes, ids, am, pm, bank, return_intermediates=True)
         raw = model(ImageList(images.to(dev), sizes), captions=None, positive_map=pm, return_raw=True,
                     input_ids=ids.to(dev), attention_mask=am.to(dev))
-    res = [_stat(f"full: fpn p{i + 3}", raw["feats"][i], inter["fpn"][i], tol=1.5e-2) for i in range(5)]
+    res = [_stat(f"full: fpn p{i + 3}", raw["feats"][i], inter["fpn"][i], tol=6e-3) for i in range(5)]
     res.append(_stat("full: language hidden", raw["lang"]["hidden"], inter["lang"]["hidden"], tol=2e-2))
     h = inter["head"]
     # padding-token rows are dead (never keys, never scored; VLFuse's text side skips their 128-row tiles): compare live rows
     live = am.bool()
-    res.append(_stat("full: head text hidden (caption tokens)", raw["head"]["hidden"].cpu()[live], h["hidden"][live], tol=3e-2))
+    res.append(_stat("full: head text hidden (caption tokens)", raw["head"]["hidden"].cpu()[live], h["hidden"][live], tol=1.5e-2))
     nv = int(am[0].sum())
     for l in range(5):
-        res.append(_stat(f"full: head feats lvl{l}", raw["head"]["feats"][l], h["feats"][l], tol=3e-2))
-        res.append(_stat(f"full: bbox_reg lvl{l}", raw["head"]["bbox_reg"][l], h["bbox_reg"][l], tol=3e-2))
-        res.append(_stat(f"full: centerness lvl{l}", raw["head"]["centerness"][l], h["centerness"][l], tol=3e-2))
+        res.append(_stat(f"full: head feats lvl{l}", raw["head"]["feats"][l], h["feats"][l], tol=2.6e-2))
+        res.append(_stat(f"full: bbox_reg lvl{l}", raw["head"]["bbox_reg"][l], h["bbox_reg"][l], tol=2e-2))
+        res.append(_stat(f"full: centerness lvl{l}", raw["head"]["centerness"][l], h["centerness"][l], tol=1.5e-2))
         logit = raw["head"]["dot"][l].float() + raw["head"]["tbias"][:, None, :]
-        res.append(_stat(f"full: dot logits lvl{l}", logit[:, :, :nv], h["dot_product_logits"][l][:, :, :nv], tol=3e-2))
+        res.append(_stat(f"full: dot logits lvl{l}", logit[:, :, :nv], h["dot_product_logits"][l][:, :, :nv], tol=1.8e-2))
         cls_ref = torch.stack([h["dot_product_logits"][l].sigmoid()[:, :, torch.tensor(pm[k])].mean(-1) for k in pm], -1)
         # sigmoid scores in [0, 1]: logits drift ~0.1-0.2 (fp16 through the whole stack) x slope 0.25
-        res.append(_stat(f"full: class scores lvl{l}", raw["post"]["cls"][l], cls_ref, tol=4e-2))
+        res.append(_stat(f"full: class scores lvl{l}", raw["post"]["cls"][l], cls_ref, tol=3.3e-2))
     # final detections: match by IoU against the oracle's detections
     post = raw["post"]
     for b in range(len(dets)):
@@ -905,7 +928,9 @@ def all_checks(dev):
 # relative perturbation ~300x: fp32 and fp64 oracles differ by 1e-5).  Measured on MI355X (profiles/r02_error_ladder.txt):
 # with fp32 residual streams the product sits at 1.2 - 1.4x that floor at EVERY stage (mean error), i.e. 10 - 35x above
 # 1e-3 at the heads and 2 - 3x above it after the backbone; what remains above the floor is fp16 storage of GEMM outputs.
-# The tolerances below are the measured normalised errors (max |err| / max(1, max |ref|)) plus a ~2x margin.
+# The tolerances below are the measured normalised errors (max |err| / max(1, max |ref|)) plus a ~2x margin; every per-kernel / tiny-model
+# tolerance in this file was reset in round 4 to max(1e-3, ~2 x the device measurement of round 3), and the measured-gate of _stat()
+# applies the same rule row by row from tests/golden/device_measured.json.
 # Class scores live in [0, 1]: their MAX error is one worst location (floor: 0.09 on P7), the mean error is 3e-4 ... 1e-2.
 BENCH_TOL = {"swin": 5e-3, "fpn": 5e-3, "pooled": 5e-3, "lang": 3e-2, "text": 3e-2, "feat": 5e-2, "box": 6e-2, "dot": 7e-2,
              "cls": 0.2}
@@ -932,8 +957,8 @@ BENCH_TOL = {"swin": 5e-3, "fpn": 5e-3, "pooled": 5e-3, "lang": 3e-2, "text": 3e
 # 1e-5 through the whole model (tests/test_simt_fp32_operands_cpu.py).  bf16 carries 8 mantissa bits in every STORED tensor as
 # well (the floor only rounds operands), its factors are wider: _BF16_GATE.
 # BENCH_TOL above stays as an absolute backstop (product error <= measured x 2, as in round 2).
-FLOOR_RATIO_MEDIAN, FLOOR_RATIO_ROW, FLOOR_RATIO_ROW_MAX = 1.75, 3.0, 5.0
-_BF16_GATE = (2.0, 4.5, 6.0)
+FLOOR_RATIO_MEDIAN, FLOOR_RATIO_ROW, FLOOR_RATIO_ROW_MAX = 1.55, 3.0, 5.0      # median: measured 1.23 / 1.41 / 1.24 (round 3: 1.75)
+_BF16_GATE = (1.9, 4.5, 6.0)            # median measured 1.55
 _LADDER = {}
 _FLOOR = None
 
@@ -1260,7 +1285,7 @@ def check_extract_query(dev):
     got = model.extract_query(images=ImageList(images.to(dev), sizes), targets=bl, query_images=defaultdict(list))
     assert sorted(got) == sorted(ref) == [1, 2, 3]
     for lab in ref:
-        res.append(_stat(f"extract_query (from pixels) label {lab} [n, 1, C]", got[lab], ref[lab], tol=1.5e-2))
+        res.append(_stat(f"extract_query (from pixels) label {lab} [n, 1, C]", got[lab], ref[lab], tol=4e-3))
     # second pass with exclude_similar on the same boxes: every candidate is a duplicate of a bank row -> bank unchanged
     got2 = model.extract_query(images=ImageList(images.to(dev), sizes), targets=bl, query_images={k: v.clone() for k, v in got.items()},
                                exclude_similar=True)
