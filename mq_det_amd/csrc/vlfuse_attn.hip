@@ -166,12 +166,17 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l15 = lane & 15, lg = lane >> 4;
-  // XCD-aware order: workgroup i runs on XCD i % 8; XCD x takes images x, x + 8, ... (their text operands stay in its L2)
+  // XCD-aware order: workgroup i runs on XCD i % 8.  The (image, q-tile) list is cut into 8 CONTIGUOUS chunks, one per XCD: with B = 8
+  // XCD x takes exactly image x (its text operands stay in that L2), with B = 4 two XCDs share an image, with B = 16 an XCD takes two --
+  // every XCD is busy for any B (round 3 mapped image b to XCD b % 8: at B = 4, the batch of BASELINE configs[3], half of the chip idled)
   const int qtiles = (p.N + BM - 1) / BM;
-  const int seq = blockIdx.x >> 3;
-  const int b = (seq / qtiles) * 8 + (blockIdx.x & 7);
-  if (b >= p.B) return;
-  const int qtile = seq % qtiles;
+  const long total = (long)p.B * qtiles;
+  const int per = (int)((total + 7) >> 3);
+  const int wslot = blockIdx.x >> 3;
+  const long w = (long)(blockIdx.x & 7) * per + wslot;
+  if (wslot >= per || w >= total) return;
+  const int b = (int)(w / qtiles);
+  const int qtile = (int)(w - (long)b * qtiles);
   const int row0 = qtile * BM + wave * WR;
 
   const int kv_eff = p.kv_len ? max(1, min(p.T, p.kv_len[b])) : p.T;
@@ -389,7 +394,8 @@ static int launch_i2t(const I2TParams& p, hipStream_t stream) {
     attr_set.done();
   }
   const int qtiles = (p.N + BM - 1) / BM;
-  hipLaunchKernelGGL((vlfuse_i2t_kernel<NT, QB, NBL, ABL, QREG>), dim3((unsigned)(8 * ((p.B + 7) / 8) * qtiles)), dim3(2048 / (QB * 4)), smem, stream, p);
+  const long per = ((long)p.B * qtiles + 7) / 8;
+  hipLaunchKernelGGL((vlfuse_i2t_kernel<NT, QB, NBL, ABL, QREG>), dim3((unsigned)(8 * per)), dim3(2048 / (QB * 4)), smem, stream, p);
   MQ_CHECK_LAUNCH();
   return 0;
 }

@@ -103,6 +103,8 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
         self._feat_cache = None                                   # Swin + FPN + pooled tokens of the last image batch (f1)
         self._front_cache = OrderedDict()                         # image-independent BERT layers per caption (f1)
         self.use_hip_graph = bool(cfg.MODEL.get("USE_HIP_GRAPH", True))
+        # lanes of the staggered schedule (_staggered_program); 1 = the whole batch as one lane.  MQ_MICRO_BATCHES overrides (A/B runs)
+        self.micro_batches = int(os.environ.get("MQ_MICRO_BATCHES", cfg.MODEL.get("MICRO_BATCHES", 1)))
         self.graph_cache_size = int(cfg.MODEL.get("HIP_GRAPH_CACHE", 8))
         self.graph_warm_calls = int(cfg.MODEL.get("HIP_GRAPH_WARM_CALLS", 1))
         self.backbone_cache = bool(cfg.MODEL.get("BACKBONE_CACHE", True))
@@ -305,6 +307,75 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
             out.update(feats=feats, pooled=pooled, front=front)
         return out
 
+    def _staggered_program(self, x, input_ids, attention_mask, vision, idx, tokidx, label_ids, im_wh, max_kv=0):
+        """The whole device forward with the batch cut into MODEL.MICRO_BATCHES lanes whose stages are issued as a SOFTWARE PIPELINE.
+        Why: a forward is two runs of chip-filling kernels (Swin + FPN; the VLDyHead layers) separated / followed by long CHAINS of
+        small launches that cannot use the chip -- the image-dependent half of the language backbone (pre-select, 6 GCP blocks + 6 BERT
+        layers on B x 256 tokens: ~170 launches between FPN and the first fusion layer, ~2 ms at B = 8) and the post-processing (~145
+        launches after the last one, ~1 ms).  With lanes a stage apart the chains of one lane run under the big kernels of another:
+
+            main stream :  Swin/FPN(0)  Swin/FPN(1)  ...  head(0)        head(1)        ...
+            stream L_m  :               language rest(0) | language rest(1)  (waits for FPN(m), feeds head(m))
+            stream P_m  :                                                post(0) under head(1) ...   (the last lane's runs exposed)
+
+        Every side stream forks from the CAPTURING stream (a fork from a forked stream crashes hipStreamEndCapture on ROCm 7.0 --
+        tools/graph_probe.py, GPU call 4 of round 4), lanes only meet through events between streams that are already in the capture.
+        Per-image results do not depend on the lane split: no kernel mixes batch items."""
+        P, cfg = self._plan, self.cfg
+        M = self.micro_batches
+        Bn = x.shape[0]
+        per = -(-Bn // M)
+        cuts = [(a, min(a + per, Bn)) for a in range(0, Bn, per)]
+        n = len(cuts)
+        cut = lambda t, a, b, batched=True: t[a:b] if (t is not None and batched) else t      # noqa: E731
+        dev = x.device
+        main = torch.cuda.current_stream()
+        S = pipeline._side_streams
+        Fs, Ls, Ps = S(dev, n, "lane_front"), S(dev, n, "lane_lang"), S(dev, n, "lane_post")
+        hold = []                                            # tensors that cross streams stay alive until every stream has joined `main`
+        args = [dict(ids=cut(input_ids, a, b), am=cut(attention_mask, a, b), vision=cut(vision, a, b), idx=cut(idx, a, b),
+                     tokidx=cut(tokidx, a, b, tokidx.dim() == 3), labels=cut(label_ids, a, b, label_ids.dim() == 2), wh=im_wh[a:b])
+                for (a, b) in cuts]
+        fronts, langs, outs = [None] * n, [None] * n, [None] * n
+        for m in range(n):                                   # image-independent BERT layers: tiny launches beside the first Swin
+            Fs[m].wait_stream(main)
+            with torch.cuda.stream(Fs[m]):
+                fronts[m] = pipeline.language_front(P, cfg, args[m]["ids"], args[m]["am"], vision is not None)
+        feats = [None] * n
+        for m, (a, b) in enumerate(cuts):
+            f, pooled = self._backbone_stage(x[a:b])
+            feats[m] = f
+            Ls[m].wait_stream(main)                          # FPN(m) done
+            Ls[m].wait_stream(Fs[m])
+            with torch.cuda.stream(Ls[m]):
+                langs[m] = pipeline.language_backbone(P, cfg, args[m]["ids"], args[m]["am"], args[m]["vision"], pooled, args[m]["idx"],
+                                                      want_gates=False, front=fronts[m])
+                langs[m]["max_kv"] = max_kv
+            hold.append((f, pooled, fronts[m], langs[m]))
+        sizes = tuple(tuple(t.shape[-2:]) for t in feats[0])
+        if sizes not in self._anchor_cache:
+            self._anchor_cache[sizes] = pipeline.grid_anchors(P, sizes, cfg.MODEL.RPN.ANCHOR_STRIDE, dev)
+        anchors = self._anchor_cache[sizes]
+        for m in range(n):
+            main.wait_stream(Ls[m])
+            head = pipeline.vldyhead(P, cfg, feats[m], langs[m])
+            hold.append(head)
+            last = m == n - 1
+            st = main if last else Ps[m]
+            if not last:
+                st.wait_stream(main)
+            with torch.cuda.stream(st):                      # on a side stream: levels one after the other (no fork from a forked stream)
+                post = pipeline.postprocess(cfg, head, anchors, args[m]["wh"], args[m]["tokidx"], args[m]["labels"], level_streams=last)
+                packed = torch.cat([post["boxes"], post["scores"][..., None], post["labels"].float()[..., None]], -1)
+                outs[m] = (packed, post["counts"] + post["tie_overflow"].to(post["counts"].dtype) * 65536)
+            hold.append(post)
+        for m in range(n - 1):
+            main.wait_stream(Ps[m])
+        for m in range(n):
+            main.wait_stream(Fs[m])
+        res = {"packed": torch.cat([o[0] for o in outs]), "counts": torch.cat([o[1] for o in outs]), "gates": None, "_hold": hold}
+        return res
+
     def _rest_program(self, feats, pooled, front, input_ids, attention_mask, vision, idx, tokidx, label_ids, im_wh, max_kv=0):
         """Device forward from cached Swin / FPN features and a cached language front (the LVIS protocol
         sends the same pixels 31 times, engine/inference.py:605-625, and the same 31 captions for every image)."""
@@ -409,7 +480,10 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
             out = self._run("_rest_program", (fc["feats"], fc["pooled"], front) + tail, use_graph)
         else:
             x = src.to(dtype).contiguous(memory_format=torch.channels_last)
-            out = self._run("_full_program", (x,) + tail, use_graph)
+            staggered = (self.micro_batches > 1 and Bn > 1 and not self.backbone_cache and x.is_cuda
+                         and not cfg.VISION_QUERY.RETURN_ATTN_GATE_VALUE and not return_backbone_features
+                         and cfg.MODEL.DYHEAD.get("LEVEL_STREAMS", True))
+            out = self._run("_staggered_program" if staggered else "_full_program", (x,) + tail, use_graph)
             if self.backbone_cache:
                 self.cache_stats["backbone_miss"] += 1
                 keep = self._tree_map(lambda t: t.clone(), {"feats": out["feats"], "pooled": out["pooled"], "front": out["front"]})

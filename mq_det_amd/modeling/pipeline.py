@@ -844,7 +844,7 @@ TIE_SLOTS = 16      # output slots behind DETECTIONS_PER_IMG for detections tied
                     # More ties than slots are cut AND flagged: `tie_overflow` [B] in the result (bit 16 of the packed counts the detector reads)
 
 
-def postprocess(cfg, head, anchors, im_wh, tokidx, label_ids, want_cls=False):
+def postprocess(cfg, head, anchors, im_wh, tokidx, label_ids, want_cls=False, level_streams=None):
     """ATSSPostProcessor.forward (rpn/inference.py:620-769) without per-image Python loops or host syncs:
     fixed-shape top-k per level, one sort, device-side NMS, fixed-shape top-(`DETECTIONS_PER_IMG` + TIE_SLOTS).
     Returns boxes [B,K2,4], scores [B,K2] (<= 0 => empty slot), labels [B,K2], counts [B] -- all on device; live slots are contiguous
@@ -899,7 +899,9 @@ def postprocess(cfg, head, anchors, im_wh, tokidx, label_ids, want_cls=False):
         ops.box_decode(val.contiguous(), flat.contiguous(), reg_nhwc, anc, label_ids, im_wh, boxes, scores, labels, HW, L, offs[l])
 
     # the five levels are independent until the sort: one HIP stream each (the small levels are pure launch latency)
-    if boxes.is_cuda and cfg.MODEL.DYHEAD.get("LEVEL_STREAMS", True) and len(ks) > 1:
+    if level_streams is None:
+        level_streams = cfg.MODEL.DYHEAD.get("LEVEL_STREAMS", True)
+    if boxes.is_cuda and level_streams and len(ks) > 1:
         main = torch.cuda.current_stream()
         side = _side_streams(dev, len(ks) - 1)
         for s_ in side:

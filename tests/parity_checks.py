@@ -1084,6 +1084,58 @@ def _match_detections(gb, gs, gl, rb, rs, rl, top=100, iou_thr=0.9, ds=0.03):
     return hit / max(1, len(order))
 
 
+def _bench_got(raw, cg, am, nv, item=None):
+    """The product's tensors (a return_raw forward + the Swin stages) under the oracle's stage names; item: keep one batch item."""
+    live = am.bool()
+    sl = (lambda t: t) if item is None else (lambda t: t[item:item + 1])
+    got = {}
+    for i in range(3):
+        got[f"swin c{i + 3}"] = sl(cg[i]).permute(0, 3, 1, 2)
+    for i in range(5):
+        got[f"fpn p{i + 3}"] = sl(raw["feats"][i])
+    got["pooled fpn tokens"] = sl(raw["pooled"])
+    lh = raw["lang"]["hidden32"] if raw["lang"].get("hidden32") is not None else raw["lang"]["hidden"]
+    got["language hidden (caption tokens)"] = sl(lh).cpu()[sl(live)]
+    for i, a in enumerate(raw["head_trace"]):
+        got[f"head layer {i}: image tokens after VLFuse"] = sl(a["fuse_tok"])
+        got[f"head layer {i}: text hidden after BERT layer"] = sl(a["bert_hidden"]).cpu()[sl(live)]
+        got[f"head layer {i}: image tokens after DyConv"] = sl(a["dyconv_tok"])
+    for l in range(5):
+        got[f"bbox_reg lvl{l}"] = sl(raw["head"]["bbox_reg"][l])
+        got[f"centerness lvl{l}"] = sl(raw["head"]["centerness"][l])
+        got[f"dot-product logits lvl{l}"] = (sl(raw["head"]["dot"][l]).float() + sl(raw["head"]["tbias"])[:, None, :])[:, :, :nv]
+        got[f"class scores lvl{l}"] = sl(raw["post"]["cls"][l])
+    return got
+
+
+def _bench_gate(tag, got, ref_rows, fixture, fl_rows, residual_fp32, case):
+    """Stage rows vs the oracle under the floor gate (FLOOR_RATIO_*): per-row records + the median record."""
+    res, ratios = [], []
+    med_gate, row_gate, row_max_gate = (FLOOR_RATIO_MEDIAN, FLOOR_RATIO_ROW, FLOOR_RATIO_ROW_MAX) if H16 == torch.float16 else _BF16_GATE
+    for name, (kind, ref) in ref_rows.items():
+        r = _stat(f"{tag} {name}", got[name], ref, tol=BENCH_TOL[kind])
+        fx = fixture.get(name)
+        if fl_rows is not None:
+            f = _stat("floor", fl_rows[name][1], ref)
+            fx = {"max": f["max_err"], "mean": f["mean_err"], "norm": f["norm_err"], "n": ref.numel()}
+        if fx is not None:
+            r["floor_norm_err"], r["floor_mean_err"] = fx["norm"], fx["mean"]
+            r["ratio_mean"] = r["mean_err"] / max(fx["mean"], 1e-12)
+            r["ratio_max"] = r["max_err"] / max(fx["max"], 1e-12)
+            r["gate"] = f"mean <= {row_gate} x floor, max <= {row_max_gate} x floor"
+            r["ok"] = bool(r["ok"] and r["ratio_mean"] <= row_gate and r["ratio_max"] <= row_max_gate)
+            ratios.append(r["ratio_mean"])
+        elif residual_fp32:
+            r["ok"], r["gate"] = False, f"no floor fixture for case {case!r} / stage {name!r}: run python -m oracle.gen_golden_floor"
+        res.append(r)
+    if ratios:
+        med = float(torch.tensor(ratios).median())
+        res.append({"name": f"{tag} MEDIAN over {len(ratios)} stages of mean|hip - ref| / mean|floor - ref|", "max_err": med, "mean_err": med,
+                    "ref_absmax": 1.0, "norm_err": med, "tol": med_gate, "ok": med <= med_gate, "ratio_mean": med, "ratio_max": med,
+                    "gate": f"median <= {med_gate}"})
+    return res
+
+
 def check_benchmark_config(dev, caption="long", hw=((800, 1333),), residual_fp32=True, floor=False, family="t"):
     """Full-depth model at the benchmark geometry vs the fp32 oracle, gated by the committed operand floor (see FLOOR_RATIO_*).
     caption: 'short' = 81 tokens (NT = 2 VLFuse kernels), 'long' = 141 tokens (NT = 3), 'xlong' = 201 tokens (NT = 4).
@@ -1115,51 +1167,11 @@ def check_benchmark_config(dev, caption="long", hw=((800, 1333),), residual_fp32
                     input_ids=ids.to(dev), attention_mask=am.to(dev))
         x = images.to(dev).to(H16).contiguous(memory_format=torch.channels_last)
         cg = pipeline.swin_forward(P, cfg, x)
-    # ---- the product's tensors under the oracle's stage names
-    live = am.bool()
-    got = {}
-    for i in range(3):
-        got[f"swin c{i + 3}"] = cg[i].permute(0, 3, 1, 2)
-    for i in range(5):
-        got[f"fpn p{i + 3}"] = raw["feats"][i]
-    got["pooled fpn tokens"] = raw["pooled"]
-    lh = raw["lang"]["hidden32"] if raw["lang"].get("hidden32") is not None else raw["lang"]["hidden"]
-    got["language hidden (caption tokens)"] = lh.cpu()[live]
-    for i, a in enumerate(raw["head_trace"]):
-        got[f"head layer {i}: image tokens after VLFuse"] = a["fuse_tok"]
-        got[f"head layer {i}: text hidden after BERT layer"] = a["bert_hidden"].cpu()[live]
-        got[f"head layer {i}: image tokens after DyConv"] = a["dyconv_tok"]
-    for l in range(5):
-        got[f"bbox_reg lvl{l}"] = raw["head"]["bbox_reg"][l]
-        got[f"centerness lvl{l}"] = raw["head"]["centerness"][l]
-        got[f"dot-product logits lvl{l}"] = (raw["head"]["dot"][l].float() + raw["head"]["tbias"][:, None, :])[:, :, :nv]
-        got[f"class scores lvl{l}"] = raw["post"]["cls"][l]
+    got = _bench_got(raw, cg, am, nv)
     case = bench_case_key(family, caption, hw)
     fixture = floor_fixture().get(case, {}) if residual_fp32 else {}
     tag = f"bench[{'MQ-GLIP-L,' if family == 'l' else ''}{caption},B={B}{'' if residual_fp32 else ',fp16 streams'}]"
-    res, ratios = [], []
-    med_gate, row_gate, row_max_gate = (FLOOR_RATIO_MEDIAN, FLOOR_RATIO_ROW, FLOOR_RATIO_ROW_MAX) if H16 == torch.float16 else _BF16_GATE
-    for name, (kind, ref) in ref_rows.items():
-        r = _stat(f"{tag} {name}", got[name], ref, tol=BENCH_TOL[kind])
-        fx = fixture.get(name)
-        if fl_rows is not None:
-            f = _stat("floor", fl_rows[name][1], ref)
-            fx = {"max": f["max_err"], "mean": f["mean_err"], "norm": f["norm_err"], "n": ref.numel()}
-        if fx is not None:
-            r["floor_norm_err"], r["floor_mean_err"] = fx["norm"], fx["mean"]
-            r["ratio_mean"] = r["mean_err"] / max(fx["mean"], 1e-12)
-            r["ratio_max"] = r["max_err"] / max(fx["max"], 1e-12)
-            r["gate"] = f"mean <= {row_gate} x floor, max <= {row_max_gate} x floor"
-            r["ok"] = bool(r["ok"] and r["ratio_mean"] <= row_gate and r["ratio_max"] <= row_max_gate)
-            ratios.append(r["ratio_mean"])
-        elif residual_fp32:
-            r["ok"], r["gate"] = False, f"no floor fixture for case {case!r} / stage {name!r}: run python -m oracle.gen_golden_floor"
-        res.append(r)
-    if ratios:
-        med = float(torch.tensor(ratios).median())
-        res.append({"name": f"{tag} MEDIAN over {len(ratios)} stages of mean|hip - ref| / mean|floor - ref|", "max_err": med, "mean_err": med,
-                    "ref_absmax": 1.0, "norm_err": med, "tol": med_gate, "ok": med <= med_gate, "ratio_mean": med, "ratio_max": med,
-                    "gate": f"median <= {med_gate}"})
+    res = _bench_gate(tag, got, ref_rows, fixture, fl_rows, residual_fp32, case)
     h = inter["head"]
     # ---- detections, both score-aggregation widths of the boundary: LVIS-style
     # TEST.MDETR_STYLE_AGGREGATE_CLASS_NUM = 3000 with 300 detections, and the default -1 (DYHEAD.NUM_CLASSES - 1) with 100
@@ -1201,6 +1213,72 @@ def check_benchmark_config(dev, caption="long", hw=((800, 1333),), residual_fp32
                 r["floor_norm_err"], r["floor_mean_err"] = fxd["norm"], 0.0
             res.append(r)
     _LADDER[(family, caption, B, residual_fp32)] = res
+    return res
+
+
+def check_benchmark_b8_graph(dev, B=8):
+    """THE TIMED CONFIGURATION (bench.py / BASELINE configs[1]: B = 8 images 800x1333, 141-token caption, HIP-graph replay) against the
+    oracle.  Image 0 of the batch is the image of the 'long, B = 1' case, so that case's oracle forward and its committed
+    floor fixture apply to batch item 0 unchanged: (a) every stage row of item 0 of an eager B = 8 forward under the floor gate,
+    (b) the detections the REPLAYED graph returns for item 0 against the oracle's (top-100, >= 95 %), (c) the replayed graph against the
+    eager forward of the same batch for every image, (d) batch invariance: items 3 and 7 of the replayed batch against a B = 1 forward
+    of that image alone (other grids, other key splits: same detections)."""
+    from oracle import detector as od, postprocess as opp
+    from mq_det_amd.modeling import pipeline
+    from mq_det_amd.structures import ImageList
+    spec, sd, cfg, model = _bench_model(dev)
+    P = model._plan
+    hw = ((800, 1333),)
+    images1, sizes1, ids, am, pm, nv, bank = bench_inputs(spec, "long", hw)
+    model.load_query_bank(bank)
+    g = torch.Generator().manual_seed(70)
+    images = torch.zeros(B, *images1.shape[1:])
+    images[0] = images1[0]
+    images[1:, :, :800, :1333] = torch.randn(B - 1, 3, 800, 1333, generator=g).to(H16).float()
+    sizes = [sizes1[0]] * B
+    ids8, am8 = ids.expand(B, -1).contiguous(), am.expand(B, -1).contiguous()
+    okey = ("bench_oracle", "t", "long", tuple(hw))
+    kw = dict(captions=None, positive_map=pm, input_ids=ids8.to(dev), attention_mask=am8.to(dev))
+    il = ImageList(images.to(dev), sizes)
+    graph_was = model.use_hip_graph
+    res = []
+    try:
+        with torch.no_grad():
+            if okey not in _CACHE:
+                _CACHE[okey] = od.forward(sd, spec, images1, sizes1, ids, am, pm, bank, return_intermediates=True)
+            dets, inter = _CACHE[okey]
+            ref_rows = oracle_rows(inter, am, pm, nv)
+            model.use_hip_graph = False
+            model.clear_caches()
+            eager = model(il, **kw)
+            raw = model(il, return_raw=True, **kw)
+            cg = pipeline.swin_forward(P, cfg, images.to(dev).to(H16).contiguous(memory_format=torch.channels_last))
+            model.use_hip_graph = True
+            model.clear_caches()
+            outs = [model(il, **kw) for _ in range(3)]
+            captured = any(e.get("stage") == 2 for e in model._graphs.values())
+            model.use_hip_graph = False
+            singles = {b: model(ImageList(images[b:b + 1].to(dev), sizes[b:b + 1]), captions=None, positive_map=pm, input_ids=ids.to(dev),
+                                attention_mask=am.to(dev))[0] for b in (3, B - 1)}
+    finally:
+        model.use_hip_graph = graph_was
+    tag = f"bench[long,B={B},graph]"
+    case = bench_case_key("t", "long", hw)
+    res += _bench_gate(tag + " item 0:", _bench_got(raw, cg, am8, nv, item=0), ref_rows, floor_fixture().get(case, {}), None, True, case)
+    res.append({"name": f"{tag} the third forward is a HIP-graph replay", "max_err": 0.0, "mean_err": 0.0, "ref_absmax": 1.0,
+                "norm_err": 0.0 if captured else 1.0, "tol": 0.0, "ok": bool(captured)})
+
+    def match(a, rb, rs, rl, what, top=100, need=0.95):
+        frac = _match_detections(a.bbox.cpu(), a.get_field("scores").cpu(), a.get_field("labels").cpu(), rb, rs, rl, top=top)
+        res.append({"name": f"{tag} {what} (top-{top}, IoU>0.9, |ds|<0.03) n={len(a)}", "max_err": 1 - frac, "mean_err": 0.0, "ref_absmax": 1.0,
+                    "norm_err": 1 - frac, "tol": round(1 - need, 3), "ok": frac >= need})
+    d0 = dets[0]
+    match(outs[2][0], d0["boxes"], d0["scores"], d0["labels"], "replayed detections of item 0 vs the ORACLE")
+    for b in range(B):
+        e = eager[b]
+        match(outs[2][b], e.bbox.cpu(), e.get_field("scores").cpu(), e.get_field("labels").cpu(), f"replay vs eager forward, item {b}", need=0.99)
+    for b, sgl in singles.items():
+        match(outs[2][b], sgl.bbox.cpu(), sgl.get_field("scores").cpu(), sgl.get_field("labels").cpu(), f"item {b} of the batch vs the B = 1 forward of that image")
     return res
 
 

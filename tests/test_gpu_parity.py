@@ -150,6 +150,39 @@ def test_hip_graph_replay_matches_eager(dev):
         assert _same_detections(a, b)
 
 
+def test_staggered_micro_batches_match_the_single_lane_forward(dev):
+    """MODEL.MICRO_BATCHES = 2 (the batch as two lanes staggered one stage apart, detector._staggered_program): same detections per image as
+    the single-lane forward, eagerly and from the replayed HIP graph; odd batch sizes split 2 + 1."""
+    import parity_checks as pc
+    from mq_det_amd.structures import ImageList
+    spec, sd, cfg, model, P = pc.tiny(dev)
+    images, sizes, ids, am, pm, bank = pc.make_inputs(spec)
+    model.load_query_bank(bank)
+    prev_mb, prev_cache, prev_graph = model.micro_batches, model.backbone_cache, model.use_hip_graph
+    try:
+        for reps in (2, 3):                                  # B = 4 (2 + 2) and B = 6 ... (tiny inputs hold 2 images)
+            imgs = torch.cat([images] + [torch.flip(images, dims=[3 - (r % 2)]) * (1.0 - 0.1 * r) for r in range(1, reps)])
+            il = ImageList(imgs.to(dev), list(sizes) * reps)
+            kw = dict(captions=None, positive_map=pm, input_ids=ids.repeat(reps, 1).to(dev), attention_mask=am.repeat(reps, 1).to(dev))
+            model.backbone_cache, model.use_hip_graph, model.micro_batches = False, False, 1
+            model.clear_caches()
+            ref = model(il, **kw)
+            model.micro_batches = 2 if reps == 2 else 4       # 4 lanes over 6 images: 2 + 2 + 2 (per = ceil(6 / 4) = 2)
+            lanes = model(il, **kw)
+            assert model.cache_stats["eager"] > 0
+            for a, b in zip(lanes, ref):
+                assert _same_detections(a, b, frac=0.95)
+            model.use_hip_graph = True
+            model.clear_caches()
+            outs = [model(il, **kw) for _ in range(3)]
+            assert any(k[0] == "_staggered_program" and e.get("stage") == 2 for k, e in model._graphs.items()), "staggered program was not captured"
+            for a, b in zip(outs[2], ref):
+                assert _same_detections(a, b, frac=0.95)
+    finally:
+        model.micro_batches, model.backbone_cache, model.use_hip_graph = prev_mb, prev_cache, prev_graph
+        model.clear_caches()
+
+
 def test_hip_graph_capture_with_process_group(dev):
     """bench.py --gpus N initialises torch.distributed before the first forward: the HIP-graph capture must survive the
     RCCL watchdog thread (capture_error_mode="thread_local"); world size 1 here, one GPU."""
@@ -197,6 +230,13 @@ def test_benchmark_configuration_parity(dev, caption, hw):
     committed fp16-operand floor of that stage (tests/golden/floor_bench.json; parity_checks.FLOOR_RATIO_*)."""
     import parity_checks as pc
     _assert(pc.check_benchmark_config(dev, caption, hw))
+
+
+def test_benchmark_configuration_b8_graph_replay(dev):
+    """The configuration bench.py TIMES -- B = 8 images 800x1333, 141-token caption, the forward replayed from a HIP graph -- against the
+    oracle: stage rows of batch item 0 under the floor gate, replayed detections vs the oracle / the eager forward / B = 1 forwards."""
+    import parity_checks as pc
+    _assert(pc.check_benchmark_b8_graph(dev))
 
 
 def test_mq_glip_l_benchmark_configuration_parity_fp16(dev):
