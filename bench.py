@@ -392,7 +392,7 @@ def kernel_rooflines(kern, steps, Bn, n_tok, embed=96):
         pair["pair"] = True
         out.append(pair)
     # ---- generic attention kernel (BERT self-attention 12 x 64; GCP pre-select 8 x 32): QK^T + PV over the visited keys
-    att = [(k, v) for k, v in per.items() if k.startswith(("attn_d", "attn_res_d", "attn_chk_d"))]
+    att = [(k, v) for k, v in per.items() if k.startswith(("attn_d", "attn_res_d", "attn_text_d", "attn_chk_d"))]
     if att:
         fl = 0.0
         for k, (n, ms, _) in att:
@@ -401,7 +401,7 @@ def kernel_rooflines(kern, steps, Bn, n_tok, embed=96):
             heads = 12 if d == 64 else 8
             nk_eff = min(nk, -(-n_tok // 64) * 64) if d == 64 else nk
             fl += n * 4.0 * Bn * heads * nq * nk_eff * d
-        out.append(_mfma("attn_resident_kernel / attn_chunked_kernel (BERT self-attention 12 x 64, T = 256; GCP pre-select 8 x 32 over 5577 "
+        out.append(_mfma("attn_text_kernel / attn_chunked_kernel (BERT self-attention 12 x 64, T = 256; GCP pre-select 8 x 32 over 5577 "
                          "image tokens)", fl, fl, sum(v[0] for _, v in att), sum(v[1] for _, v in att), "flops = 4 * B * heads * Nq * Nk_visited * D"))
     # ---- fused Swin MLP (swin_mlp2.hip): 16 M C^2 per launch (fc1 + fc2), M = tokens of the stage
     mlp = [(k, v) for k, v in per.items() if k.startswith("swin_mlp_c")]
@@ -462,18 +462,18 @@ def lang_path_b64(model, cfg, dev, chunks, iters=5):
     cfg.MODEL.DYHEAD.LEVEL_STREAMS = False
     try:
         for _ in range(2):
-            pipeline.language_backbone(P, cfg, ids, am, vision, pooled, idx)
+            pipeline.language_backbone(P, cfg, ids, am, vision, pooled, idx, max_kv=max_kv)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
-            pipeline.language_backbone(P, cfg, ids, am, vision, pooled, idx)
+            pipeline.language_backbone(P, cfg, ids, am, vision, pooled, idx, max_kv=max_kv)
         e1.record()
         torch.cuda.synchronize()
         ms_path = e0.elapsed_time(e1) / iters
         ops.start_timing()
         for _ in range(iters):
-            pipeline.language_backbone(P, cfg, ids, am, vision, pooled, idx)
+            pipeline.language_backbone(P, cfg, ids, am, vision, pooled, idx, max_kv=max_kv)
         kern = ops.stop_timing()
     finally:
         cfg.MODEL.DYHEAD.LEVEL_STREAMS = streams_on
@@ -482,7 +482,7 @@ def lang_path_b64(model, cfg, dev, chunks, iters=5):
     fl_bert = 12 * 4.0 * Bn * 12 * 256 * nk_vis * 64
     fl_pre = 2 * 4.0 * Bn * 8 * V * 5577 * 32
     fl_gcp = 6 * 4.0 * Bn * 8 * 256 * S * 64
-    att_ms = sum(v[1] for k, v in kern.items() if k.startswith(("attn_d", "attn_res_d", "attn_chk_d", "gcp_sparse"))) / iters
+    att_ms = sum(v[1] for k, v in kern.items() if k.startswith(("attn_d", "attn_res_d", "attn_text_d", "attn_chk_d", "gcp_sparse"))) / iters
     att_tf = (fl_bert + fl_pre + fl_gcp) / (att_ms * 1e-3) / 1e12
     # whole language path: SURVEY.md 8(d) per image BERT 45.9 + pre-select 7.5 + GCP 29.9 GF
     path_tf = Bn * (45.9 + 7.5 + 29.9) * 1e9 / (ms_path * 1e-3) / 1e12

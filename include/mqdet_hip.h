@@ -347,11 +347,47 @@ int mq_ml_nms(const float* boxes, const int* labels, const int* nvalid, void* wo
 int mq_ml_nms_topk(const float* boxes, const int* labels, const int* nvalid, void* workspace, unsigned char* keep,
                    int B, int N, float thr, int max_keep, void* stream);
 
+/* Self-attention over the text tokens with Q, K and V ROW-MAJOR (slices of one fused qkv projection): the second generation of
+ * mq_attn_resident_fwd for the BERT layers (HF BertSelfAttention; the clamped copy rpn/modeling_bert.py:71-150 with clamp > 0).
+ *   q [B,Nq,H,D], k / v [B,Nk,H,D] 16-bit views, unit last stride, strides in elements; o [B,Nq,H*D]; key_bias fp32 (b, h, j) at
+ *   key_bias + b*bias_bs + h*bias_hs + j or NULL (<= -1e29: masked key); kv_len [B] int32 or NULL; max_kv: HOST bound on kv_len
+ *   (0 = Nk): sizes the LDS tiles and picks the register variant (<= 160 keys: 10 key blocks per lane), must cover every kv_len[b].
+ *   Nk <= 256, D in {32, 64}.  Returns -1 / -3 like mq_attn_resident_fwd. */
+int mq_attn_text_fwd(const void* q, const void* k, const void* v, void* o, const float* key_bias, const int* kv_len,
+                     int B, int H, int Nq, int Nk, int D, long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs,
+                     long v_bs, long v_rs, long v_hs, long o_bs, long o_rs, long bias_bs, long bias_hs, float scale,
+                     float clamp, int max_kv, void* stream);
+
+/* ---- ATSS post-processing between the alignment kernel and the NMS in three launches (round 4; csrc/post2.hip).  fp32 / integer data only.
+ * Replaces, inside ATSSPostProcessor (maskrcnn_benchmark/modeling/rpn/inference.py): forward_for_single_feature_map :677-712 (candidate
+ * threshold mask, per-level topk(pre_nms_top_n), BoxCoder.decode vldyhead.py:78-108, clip_to_image, sqrt score, label ids) and
+ * select_over_all_levels :757-766 (kthvalue + `>=` keeps ties with the K-th score) -- ~145 torch launches in one dependent chain.
+ *
+ * mq_post_select_fwd: per (image, level) the k[l] best candidates of the score map (value > 0 = candidate; exact radix select over the
+ *   fp32 bit patterns, ties at the cut by the smaller flat index), decoded into the image's candidate list.
+ *   ranked / reg / anchors: HOST arrays of NL device pointers -- level l: scores [B, hw[l], L] fp32, box deltas [B, hw[l], 4] fp32,
+ *   anchors [hw[l], 4] fp32; hw / k: HOST int arrays (locations; candidates kept, 1 <= k[l] <= hw[l] * L < 2^22); label_ids [L] int32
+ *   (lab_bs 0) or [B, L] (lab_bs L); im_wh [B, 2] fp32 (w, h).  Outputs (tot = sum k): boxes [B, tot, 4], scores [B, tot] (-1 = empty
+ *   slot), labels [B, tot], ids [B, tot] int32 (candidate id = level base + flat index: the tie-break key of the sort); level l owns
+ *   slots [sum k[:l], sum k[:l + 1]), in arbitrary order inside them.  -1: NL > 8 or a size out of range. */
+int mq_post_select_fwd(const float* const* ranked, const float* const* reg, const float* const* anchors, const int* hw, const int* k,
+                       int NL, int B, int L, const int* label_ids, long lab_bs, const float* im_wh, float* boxes, float* scores,
+                       int* labels, int* ids, void* stream);
+/* mq_post_sort_fwd: the candidate list of every image ordered by (score descending, id ascending), empty slots last -- the order
+ *   ml_nms sweeps in (ml_nms.cu:100-104 sorts by score) -- + nvalid [B] = live rows.  tot <= 8192 (-1 beyond). */
+int mq_post_sort_fwd(const float* boxes, const float* scores, const int* labels, const int* ids, float* boxes_o, float* scores_o,
+                     int* labels_o, int* nvalid, int B, int tot, void* stream);
+/* mq_post_finalize_fwd: rows score-sorted, keep [B, tot] uint8 from mq_ml_nms_topk(max_keep = K2) -> out [B, K2, 6] fp32 rows
+ *   (x1, y1, x2, y2, score, label): the first K kept rows + the kept rows tied with the K-th score (inference.py:757-766), unused rows
+ *   (0, 0, 0, 0, -1, 0); counts [B] int32 = live rows | 1 << 16 when all K2 - K tie slots hold ties (more may exist).  1 <= K <= K2 <= tot. */
+int mq_post_finalize_fwd(const float* boxes, const float* scores, const int* labels, const unsigned char* keep, float* out,
+                         int* counts, int B, int tot, int K, int K2, void* stream);
+
 /* ---- bf16 operands (BASELINE.json configs[3]: "MQ-GLIP-L ... bf16 MFMA").
  * Every entry point that reads or writes 16-bit operands exists twice: `name` as declared above (fp16, v_mfma_f32_16x16x32_f16) and
  * `name_bf16` -- the SAME kernel source compiled with bf16 operands (v_mfma_f32_16x16x32_bf16; fp32 accumulation, fp32 side inputs and
  * fp32 residual streams unchanged), same arguments, same return codes, "fp16" in the comments above read as "bf16".  The entry points
- * that only see fp32 / integer data (mq_abi_version, the *_workspace_bytes / mq_dcnv2_stats_blocks size queries, mq_ml_nms) have no twin. */
+ * that only see fp32 / integer data (mq_abi_version, the *_workspace_bytes / mq_dcnv2_stats_blocks size queries, mq_ml_nms, mq_post_*) have no twin. */
 #ifdef __cplusplus
 #define MQ_BF16_TWIN(name) extern decltype(name) name##_bf16;
 #else
@@ -359,6 +395,7 @@ int mq_ml_nms_topk(const float* boxes, const int* labels, const int* nvalid, voi
 #endif
 MQ_BF16_TWIN(mq_attn_fwd)
 MQ_BF16_TWIN(mq_attn_resident_fwd)
+MQ_BF16_TWIN(mq_attn_text_fwd)
 MQ_BF16_TWIN(mq_attn_chunked_fwd)
 MQ_BF16_TWIN(mq_window_attn_fwd)
 MQ_BF16_TWIN(mq_window_attn_qkv_fwd)

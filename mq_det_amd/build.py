@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libmqdet_hip.so")
-SOURCES = ["api.hip", "attn.hip", "attn_resident.hip", "vlfuse_attn.hip", "window_attn.hip", "gcp.hip", "conv_igemm.hip", "conv_small.hip", "conv_small2.hip", "dcn_fused.hip", "layernorm.hip", "layernorm2.hip", "dyconv.hip", "post.hip", "align_fused.hip", "nms2.hip", "roi_align.hip", "swin_mlp.hip", "swin_mlp2.hip", "msda.hip"]
+SOURCES = ["api.hip", "attn.hip", "attn_resident.hip", "attn_text.hip", "vlfuse_attn.hip", "window_attn.hip", "gcp.hip", "conv_igemm.hip", "conv_small.hip", "conv_small2.hip", "dcn_fused.hip", "layernorm.hip", "layernorm2.hip", "dyconv.hip", "post.hip", "post2.hip", "align_fused.hip", "nms2.hip", "roi_align.hip", "swin_mlp.hip", "swin_mlp2.hip", "msda.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # dcn_fused.hip: without the SLP vectoriser the bilinear blend compiles to v_fma_mix_f32 / v_fma_mixlo_f16 (fp16 operands,
 # fp32 accumulate, no separate converts) instead of cvt + v_pk_fma_f32 -- 40 % fewer VALU cycles next to the MFMAs
@@ -17,7 +17,8 @@ EXTRA_FLAGS = {"dcn_fused.hip": ["-fno-slp-vectorize"],
                "swin_mlp2.hip": ["-fno-slp-vectorize"],
                # attn_resident.hip: the S^T accumulators are consumed by VALU code (softmax): keep them in VGPRs (no v_accvgpr_read per
                # logit) and keep the scalar f32 softmax arithmetic unpacked (packed f32 VALU beside MFMAs costs more than it saves)
-               "attn_resident.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]}
+               "attn_resident.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"],
+               "attn_text.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _stale():

@@ -1,0 +1,258 @@
+// mq_attn_text_fwd: self-attention over the TEXT tokens (BERT 12 x 64 over T = 256 of which the caption fills <= max_kv; the clamped
+// copy inside VLDyHead) with Q, K and V taken ROW-MAJOR from one fused qkv projection -- gfx950, round 4.
+//
+// Second generation of attn_resident_kernel (attn_resident.hip: S^T = K Q^T, all logits of a query in registers, exact two-pass softmax,
+// exp2 domain, P never through LDS).  What changed, and why (profiles/r04_call1_sq_summary.txt: issue 31 % / wait 61 %, 37 % of the LDS
+// cycles bank conflicts, 176 VGPRs and 72 KB of LDS = two waves per SIMD whatever the caption length):
+//   * V is read row-major [key][d] -- the layout the projection GEMM writes -- and TRANSPOSED ON THE WAY OUT of LDS (ds_read_tr16_b64, as
+//     vlfuse_attn.hip does): no V^T operand any more, so the BERT layer issues ONE qkv GEMM instead of a q|k GEMM plus a transposed
+//     batched GEMM for V^T (18 launches per forward gone), and the conflicting b64 reads of a 528-byte-pitch V^T tile are gone with it;
+//   * row pitch D * 2 + 32 bytes for both tiles: conflict-free for the b128 fragment reads of K and for the transposed reads of V;
+//   * the number of 16-key blocks a launch can visit is a TEMPLATE parameter chosen from the host's bound on the caption length
+//     (max_kv): 10 blocks (<= 160 keys; the 141-token benchmark caption) keep 80 logit registers per lane instead of 128, and the LDS
+//     request is sized by the same bound (51 KB instead of 82 KB at 160 keys): three workgroups per CU instead of two.
+// Work decomposition as before: grid = ceil(Nq / 128) x B x H workgroups of 4 waves, a wave owns 32 queries.
+#include "common.h"
+
+MQ_NAMESPACE_BEGIN
+
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(8)));
+typedef __attribute__((address_space(3))) fp16x4_t* lds_fp16x4_ptr;
+
+namespace {
+// 4x16 block of 16-bit values, row-major in LDS, read column-wise: within a 16-lane group lane i passes the address of the 4 contiguous
+// values (row i/4, cols 4*(i%4)..+3) and receives (row 0..3, col i)
+__device__ __forceinline__ half4 lds_read_tr16(const half_t* p) {
+  fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4_ptr)p);
+  half4 o;
+  __builtin_memcpy(&o, &v, 8);
+  return o;
+}
+constexpr int TXT_BM = 128, TXT_QB = 2;
+constexpr float TXT_LOG2E = 1.4426950408889634f;
+}  // namespace
+
+struct TextAttnParams {
+  const half_t* q; const half_t* k; const half_t* v; half_t* o;
+  const float* key_bias;          // (b, h, j) at key_bias + b*bias_bs + h*bias_hs + j, or nullptr; <= -1e29 marks a masked key
+  const int* kv_len;              // [B] or nullptr: 16-key blocks at and beyond kv_len[b] are skipped
+  int B, H, Nq, Nk;
+  long q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, v_bs, v_rs, v_hs, o_bs, o_rs, bias_bs, bias_hs;
+  float scale, clamp;
+  int nblk_cap;                   // 16-key blocks the LDS tiles of this launch hold (host bound; <= NBM)
+};
+
+// NBM = 16-key blocks whose logits a lane can hold (compile time: 10 or 16)
+template <int D, int NBM, bool CLAMP>
+__global__ __launch_bounds__(256) void attn_text_kernel(TextAttnParams p) {
+  constexpr int QB = TXT_QB, KS = D + 16, CH = D / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int cap = p.nblk_cap, cap_st = (cap + 1) >> 1;
+  half_t* Ks = (half_t*)smem;                       // [16 cap][KS]     key rows
+  half_t* Vs = Ks + 16 * cap * KS;                  // [32 cap_st][KS]  value rows (row-major, read transposed)
+  float* Bias_s = (float*)(Vs + 32 * cap_st * KS);  // [32 cap_st]      log2(e) x key bias; masked / out-of-range keys: -1e30 (CLAMP: 0)
+  float* Kmask_s = Bias_s + 32 * cap_st;            // [32 cap_st]      CLAMP only: 0, or -1e30 for masked / out-of-range keys
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int qtiles = (p.Nq + TXT_BM - 1) / TXT_BM;
+  const int qtile = blockIdx.x % qtiles;
+  const int bh = blockIdx.x / qtiles, h = bh % p.H, b = bh / p.H;
+  const half_t* Q = p.q + (long)b * p.q_bs + (long)h * p.q_hs;
+  const half_t* K = p.k + (long)b * p.k_bs + (long)h * p.k_hs;
+  const half_t* V = p.v + (long)b * p.v_bs + (long)h * p.v_hs;
+  const int nk_eff = p.kv_len ? max(1, min(p.Nk, p.kv_len[b])) : p.Nk;
+  const int nblk = min((nk_eff + 15) >> 4, cap);    // 16-key blocks visited (wave-uniform); the host guarantees cap covers kv_len
+  const int nst = (nblk + 1) >> 1;                  // 32-key steps of the P V product
+
+  // ---- stage K rows [0, 16 nblk) and V rows [0, 32 nst): every global load of a thread is issued before its first LDS store.  Rows
+  // beyond Nk are clamped to the last valid row (finite data); their logits are forced to -1e30 below, so they contribute exactly 0.
+  {
+    constexpr int NCH = (NBM * 16 * CH + 255) / 256;   // 16-byte chunks per thread and tile (NBM = 10, D = 64: 5)
+    const int kchunks = nblk * 16 * CH, vchunks = nst * 32 * CH;
+    half8 kreg[NCH], vreg[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + i * 256, r = c / CH, ch = c % CH;
+      if (c < kchunks) kreg[i] = *(const half8*)(K + (long)min(r, p.Nk - 1) * p.k_rs + ch * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + i * 256, r = c / CH, ch = c % CH;
+      if (c < vchunks) vreg[i] = *(const half8*)(V + (long)min(r, p.Nk - 1) * p.v_rs + ch * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + i * 256, r = c / CH, ch = c % CH;
+      if (c < kchunks) *(half8*)(Ks + r * KS + ch * 8) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + i * 256, r = c / CH, ch = c % CH;
+      if (c < vchunks) *(half8*)(Vs + r * KS + ch * 8) = vreg[i];
+    }
+    for (int j = tid; j < nst * 32; j += 256) {
+      float kb = MQ_NEG_BIG;
+      if (j < p.Nk) kb = p.key_bias ? p.key_bias[(long)b * p.bias_bs + (long)h * p.bias_hs + j] : 0.f;
+      const bool masked = kb < -1.0e29f;
+      if constexpr (CLAMP) {
+        Bias_s[j] = masked ? 0.f : kb * TXT_LOG2E;
+        Kmask_s[j] = masked ? MQ_NEG_BIG : 0.f;
+      } else {
+        Bias_s[j] = masked ? MQ_NEG_BIG : kb * TXT_LOG2E;
+      }
+    }
+  }
+  const int row0 = qtile * TXT_BM + wave * (QB * 16);
+  half8 qf[QB][D / 32];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int row = min(row0 + qb * 16 + l15, p.Nq - 1);
+#pragma unroll
+    for (int kk = 0; kk < D / 32; ++kk) qf[qb][kk] = *(const half8*)(Q + (long)row * p.q_rs + kk * 32 + lg * 8);
+  }
+  __syncthreads();
+  if (row0 >= p.Nq) return;                          // whole wave beyond the last query (no barrier after this point)
+
+  // ---- S^T[nb][qb] = K_block . Q^T, then scale / bias / clamp / mask in the log2 domain
+  float4_ s[NBM][QB];
+  const float sc2 = p.scale * TXT_LOG2E, cl2 = p.clamp * TXT_LOG2E;
+  float mx[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) mx[qb] = MQ_NEG_BIG;
+#pragma unroll
+  for (int nb = 0; nb < NBM; ++nb) {
+    if (nb < nblk) {
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) s[nb][qb] = (float4_){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < D / 32; ++kk) {
+        const half8 kf = *(const half8*)(Ks + (nb * 16 + l15) * KS + kk * 32 + lg * 8);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) s[nb][qb] = mfma16(kf, qf[qb][kk], s[nb][qb]);
+      }
+      const float4_ kb4 = *(const float4_*)(Bias_s + nb * 16 + lg * 4);
+      float4_ km4 = (float4_){0.f, 0.f, 0.f, 0.f};
+      if constexpr (CLAMP) km4 = *(const float4_*)(Kmask_s + nb * 16 + lg * 4);
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = __builtin_fmaf(s[nb][qb][r], sc2, kb4[r]);
+          if constexpr (CLAMP) v = __builtin_amdgcn_fmed3f(v, -cl2, cl2) + km4[r];
+          s[nb][qb][r] = v;
+          mx[qb] = fmaxf(mx[qb], v);
+        }
+      }
+    }
+  }
+  float lsum[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    mx[qb] = fmaxf(mx[qb], __shfl_xor(mx[qb], 16));
+    mx[qb] = fmaxf(mx[qb], __shfl_xor(mx[qb], 32));
+    lsum[qb] = 0.f;
+  }
+  // ---- O^T[db][qb] = V^T . P^T, 32 keys per step: blocks 2 st (k-slots 0..3 of a lane) and 2 st + 1 (k-slots 4..7); the A fragment is
+  // two transposed reads of the row-major value tile (rows st*32 + 4 lg + l15/4 and + 16, columns db*16 + 4 (l15 % 4) ..)
+  float4_ o[D / 16][QB];
+#pragma unroll
+  for (int db = 0; db < D / 16; ++db)
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) o[db][qb] = (float4_){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int st = 0; st < NBM / 2; ++st) {
+    if (st < nst) {
+      half8 pf[QB];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p0 = __builtin_amdgcn_exp2f(s[2 * st][qb][r] - mx[qb]);
+          const float p1 = (2 * st + 1 < nblk) ? __builtin_amdgcn_exp2f(s[2 * st + 1][qb][r] - mx[qb]) : 0.f;
+          lsum[qb] += p0 + p1;
+          pf[qb][r] = (half_t)p0;
+          pf[qb][4 + r] = (half_t)p1;
+        }
+      }
+      const half_t* base = Vs + (st * 32 + 4 * lg + (l15 >> 2)) * KS + (l15 & 3) * 4;
+#pragma unroll
+      for (int db = 0; db < D / 16; ++db) {
+        const half4 lo = lds_read_tr16(base + db * 16);
+        const half4 hi = lds_read_tr16(base + 16 * KS + db * 16);
+        half8 a;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = lo[j]; a[4 + j] = hi[j]; }
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) o[db][qb] = mfma16(a, pf[qb], o[db][qb]);
+      }
+    }
+  }
+  // ---- epilogue: 1 / l per query (per lane), 4 consecutive channels of one query per lane -> 8-byte stores
+  half_t* O = p.o + (long)b * p.o_bs + h * D;
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    float l = lsum[qb];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.f / l;
+    const int row = row0 + qb * 16 + l15;
+    if (row < p.Nq) {
+#pragma unroll
+      for (int db = 0; db < D / 16; ++db) {
+        half4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (half_t)(o[db][qb][r] * inv);
+        *(half4*)(O + (long)row * p.o_rs + db * 16 + lg * 4) = v;
+      }
+    }
+  }
+}
+
+template <int D, int NBM, bool CLAMP>
+static int launch_text(const TextAttnParams& p, hipStream_t stream) {
+  constexpr int KS = D + 16;
+  const int cap = p.nblk_cap, cap_st = (cap + 1) / 2;
+  const size_t smem = (size_t)(16 * cap + 32 * cap_st) * KS * sizeof(half_t) + (size_t)2 * 32 * cap_st * sizeof(float);
+  static MqOncePerDevice attr;
+  if (attr.first()) {
+    constexpr size_t smax = (size_t)(16 * NBM + 32 * ((NBM + 1) / 2)) * KS * sizeof(half_t) + (size_t)2 * 32 * ((NBM + 1) / 2) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_text_kernel<D, NBM, CLAMP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smax);
+    if (e != hipSuccess) return (int)e;
+    attr.done();
+  }
+  const int qtiles = (p.Nq + TXT_BM - 1) / TXT_BM;
+  hipLaunchKernelGGL((attn_text_kernel<D, NBM, CLAMP>), dim3((unsigned)(qtiles * p.B * p.H)), dim3(256), smem, stream, p);
+  MQ_CHECK_LAUNCH();
+  return 0;
+}
+
+// q [B, Nq, H, D], k / v [B, Nk, H, D] 16-bit views with unit last stride (row stride *_rs, head stride *_hs, batch stride *_bs in
+// elements; q, k and v may be slices of ONE [B, T, 3 H D] projection), o [B, Nq, H * D]; key_bias fp32 or NULL; kv_len [B] int32 or
+// NULL; max_kv: HOST bound on kv_len (0 = Nk) -- it sizes the LDS tiles and picks the kernel variant, and must cover every kv_len[b].
+// clamp > 0: the +-clamp of the VLDyHead BERT copies (rpn/modeling_bert.py:71-272).  Nk <= 256, D = 64 or 32.  -1 / -3 as mq_attn_resident_fwd.
+extern "C" int MQ_SYM(mq_attn_text_fwd)(const void* q, const void* k, const void* v, void* o, const float* key_bias, const int* kv_len,
+                                        int B, int H, int Nq, int Nk, int D, long q_bs, long q_rs, long q_hs, long k_bs, long k_rs, long k_hs,
+                                        long v_bs, long v_rs, long v_hs, long o_bs, long o_rs, long bias_bs, long bias_hs, float scale,
+                                        float clamp, int max_kv, void* stream) {
+  if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return 0;
+  if (Nk > 256 || (D != 64 && D != 32)) return -1;
+  if ((q_rs % 8) || (k_rs % 8) || (v_rs % 8) || (q_hs % 8) || (k_hs % 8) || (v_hs % 8) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8) || (o_rs % 4)) return -3;
+  TextAttnParams p;
+  p.q = (const half_t*)q; p.k = (const half_t*)k; p.v = (const half_t*)v; p.o = (half_t*)o; p.key_bias = key_bias; p.kv_len = kv_len;
+  p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk;
+  p.q_bs = q_bs; p.q_rs = q_rs; p.q_hs = q_hs; p.k_bs = k_bs; p.k_rs = k_rs; p.k_hs = k_hs; p.v_bs = v_bs; p.v_rs = v_rs; p.v_hs = v_hs;
+  p.o_bs = o_bs; p.o_rs = o_rs; p.bias_bs = bias_bs; p.bias_hs = bias_hs; p.scale = scale; p.clamp = clamp;
+  const int kv = (kv_len && max_kv > 0 && max_kv < Nk) ? max_kv : Nk;
+  p.nblk_cap = (kv + 15) / 16;
+  hipStream_t s = (hipStream_t)stream;
+  const bool small = p.nblk_cap <= 10;
+  if (D == 64) {
+    if (clamp > 0.f) return small ? launch_text<64, 10, true>(p, s) : launch_text<64, 16, true>(p, s);
+    return small ? launch_text<64, 10, false>(p, s) : launch_text<64, 16, false>(p, s);
+  }
+  if (clamp > 0.f) return small ? launch_text<32, 10, true>(p, s) : launch_text<32, 16, true>(p, s);
+  return small ? launch_text<32, 10, false>(p, s) : launch_text<32, 16, false>(p, s);
+}
+
+MQ_NAMESPACE_END

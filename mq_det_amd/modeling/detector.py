@@ -258,7 +258,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
         """Image-dependent half of the language backbone (pre-select + GCP / BERT layers), VLDyHead, post-processing."""
         P, cfg = self._plan, self.cfg
         lang = pipeline.language_backbone(P, cfg, input_ids, attention_mask, vision, pooled, idx,
-                                          want_gates=cfg.VISION_QUERY.RETURN_ATTN_GATE_VALUE, front=front)
+                                          want_gates=cfg.VISION_QUERY.RETURN_ATTN_GATE_VALUE, front=front, max_kv=max_kv)
         lang["max_kv"] = max_kv
         trace = [] if want_raw else None                          # raw mode: per-layer tensors, single-stream schedule
         head = pipeline.vldyhead(P, cfg, feats, lang, trace=trace)
@@ -270,12 +270,16 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
         if want_raw:
             return {"post": post, "head": head, "head_trace": trace, "lang": lang, "feats": feats, "anchors": anchors,
                     "vision": vision, "idx": idx, "pooled": pooled}
-        packed = torch.cat([post["boxes"], post["scores"][..., None], post["labels"].float()[..., None]], -1)
+        if "packed" in post:                                      # fused post-processing hands over the packed block and counts as they are
+            packed, counts = post["packed"], post["counts_packed"]
+        else:
+            packed = torch.cat([post["boxes"], post["scores"][..., None], post["labels"].float()[..., None]], -1)
+            # one int per image for the single device->host transfer: live slots, bit 16 = more ties with the K-th score than tie slots
+            counts = post["counts"] + post["tie_overflow"].to(post["counts"].dtype) * 65536
         gates = lang["vision_query_gates"]
         if gates is not None:                                     # reference: attn_gate.mean().item() per GCP layer (a float)
             gates = torch.stack([g.float().mean() for g in gates])
-        # one int per image for the single device->host transfer: live slots, bit 16 = more ties with the K-th score than tie slots
-        return {"packed": packed, "counts": post["counts"] + post["tie_overflow"].to(post["counts"].dtype) * 65536, "gates": gates}
+        return {"packed": packed, "counts": counts, "gates": gates}
 
     def _split_counts(self, counts):
         """Packed per-image counts -> live slots; remembers (and warns about) images whose ties with the K-th score did not fit."""
@@ -295,12 +299,12 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
             main, text = torch.cuda.current_stream(), pipeline._side_streams(x.device, 1, "text")[0]
             text.wait_stream(main)
             with torch.cuda.stream(text):
-                front = pipeline.language_front(P, cfg, input_ids, attention_mask, vision is not None)
+                front = pipeline.language_front(P, cfg, input_ids, attention_mask, vision is not None, max_kv=max_kv)
         feats, pooled = self._backbone_stage(x)
         if front is not None:
             main.wait_stream(text)
         else:
-            front = pipeline.language_front(P, cfg, input_ids, attention_mask, vision is not None)
+            front = pipeline.language_front(P, cfg, input_ids, attention_mask, vision is not None, max_kv=max_kv)
         out = self._head_stage(feats, pooled, front, input_ids, attention_mask, vision, idx, tokidx, label_ids, im_wh, max_kv,
                                want_raw=want_raw)
         if not want_raw:
@@ -340,7 +344,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
         for m in range(n):                                   # image-independent BERT layers: tiny launches beside the first Swin
             Fs[m].wait_stream(main)
             with torch.cuda.stream(Fs[m]):
-                fronts[m] = pipeline.language_front(P, cfg, args[m]["ids"], args[m]["am"], vision is not None)
+                fronts[m] = pipeline.language_front(P, cfg, args[m]["ids"], args[m]["am"], vision is not None, max_kv=max_kv)
         feats = [None] * n
         for m, (a, b) in enumerate(cuts):
             f, pooled = self._backbone_stage(x[a:b])
@@ -349,7 +353,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
             Ls[m].wait_stream(Fs[m])
             with torch.cuda.stream(Ls[m]):
                 langs[m] = pipeline.language_backbone(P, cfg, args[m]["ids"], args[m]["am"], args[m]["vision"], pooled, args[m]["idx"],
-                                                      want_gates=False, front=fronts[m])
+                                                      want_gates=False, front=fronts[m], max_kv=max_kv)
                 langs[m]["max_kv"] = max_kv
             hold.append((f, pooled, fronts[m], langs[m]))
         sizes = tuple(tuple(t.shape[-2:]) for t in feats[0])
@@ -366,8 +370,11 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
                 st.wait_stream(main)
             with torch.cuda.stream(st):                      # on a side stream: levels one after the other (no fork from a forked stream)
                 post = pipeline.postprocess(cfg, head, anchors, args[m]["wh"], args[m]["tokidx"], args[m]["labels"], level_streams=last)
-                packed = torch.cat([post["boxes"], post["scores"][..., None], post["labels"].float()[..., None]], -1)
-                outs[m] = (packed, post["counts"] + post["tie_overflow"].to(post["counts"].dtype) * 65536)
+                if "packed" in post:
+                    outs[m] = (post["packed"], post["counts_packed"])
+                else:
+                    packed = torch.cat([post["boxes"], post["scores"][..., None], post["labels"].float()[..., None]], -1)
+                    outs[m] = (packed, post["counts"] + post["tie_overflow"].to(post["counts"].dtype) * 65536)
             hold.append(post)
         for m in range(n - 1):
             main.wait_stream(Ps[m])
@@ -469,7 +476,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
             front = self._front_cache.get(fkey) if cap_key is not None else None
             if front is None:
                 self.cache_stats["front_miss"] += 1
-                front = pipeline.language_front(P, cfg, input_ids, attention_mask, vision is not None)
+                front = pipeline.language_front(P, cfg, input_ids, attention_mask, vision is not None, max_kv=max_kv)
                 if cap_key is not None:
                     self._front_cache[fkey] = front
                     while len(self._front_cache) > int(cfg.MODEL.get("LANG_FRONT_CACHE", 64)):
@@ -540,8 +547,8 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
         fr = self._front_cache.get(key)
         if fr is None:
             self.cache_stats["front_miss"] += 1
-            ids, am, _ = self.tokenize([caption], dev)
-            fr = self._front_cache[key] = pipeline.language_front(self._plan, self.cfg, ids, am, use_vq)
+            ids, am, kv = self.tokenize([caption], dev)
+            fr = self._front_cache[key] = pipeline.language_front(self._plan, self.cfg, ids, am, use_vq, max_kv=kv)
             while len(self._front_cache) > int(self.cfg.MODEL.get("LANG_FRONT_CACHE", 64)):
                 self._front_cache.popitem(last=False)
         else:

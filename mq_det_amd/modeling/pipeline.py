@@ -86,6 +86,9 @@ def _pack_bert_layer(P, sd, b, device, dtype):
         return sd[name].detach().to(device=device, dtype=dtype).contiguous()
     P[b + ".qk.weight"] = torch.cat([h(b + ".attention.self.query.weight"), h(b + ".attention.self.key.weight")], 0)
     P[b + ".qk.bias"] = torch.cat([h(b + ".attention.self.query.bias"), h(b + ".attention.self.key.bias")], 0)
+    # one projection for q | k | v (KERNELS["BERT_QKV_FUSED"]: mq_attn_text_fwd reads V row-major, no V^T operand)
+    P[b + ".qkv.weight"] = torch.cat([P[b + ".qk.weight"], h(b + ".attention.self.value.weight")], 0)
+    P[b + ".qkv.bias"] = torch.cat([P[b + ".qk.bias"], h(b + ".attention.self.value.bias")], 0)
 
 
 def build_plan(sd, cfg, device, dtype=torch.float16):
@@ -385,17 +388,20 @@ def pooled_fpn_tokens(feats):
 
 
 # ----------------------------------------------------------------------------- language backbone
-def bert_layer(P, b, x, key_bias, clamp, kv_len=None, x32=None, qk_mask=None):
+def bert_layer(P, b, x, key_bias, clamp, kv_len=None, x32=None, qk_mask=None, max_kv=0):
     """HF BertLayer / rpn/modeling_bert.py:71-272 (clamp=True): QK^T, mask, softmax, PV in one HIP kernel.
     x [B,T,C] fp16 (GEMM operand); x32: the same hidden state unrounded (fp32 residual stream) or None.
     Returns y16 (and y32 when x32 is given)."""
     Bn, T, C = x.shape
     r32 = x32 is not None
-    qk = _lin(P, b + ".qk", x)                                                          # [B, T, 2C]
-    vt = torch.baddbmm(P[b + ".attention.self.value.bias"][None, :, None], P[b + ".attention.self.value.weight"][None]
-                       .expand(Bn, -1, -1), x.transpose(1, 2))                          # V^T [B, C, T]
-    ctx = ops.attention(qk[:, :, :C], qk[:, :, C:], vt, 12, C // 12, key_bias=key_bias, clamp=50000.0 if clamp else 0.0,
-                        kv_len=kv_len, qk_mask=qk_mask)
+    if ops.KERNELS["BERT_QKV_FUSED"] == 1 and qk_mask is None and T <= 256 and (b + ".qkv.weight") in P and (key_bias is None or key_bias.dim() == 2):
+        ctx = ops.attention_text(_lin(P, b + ".qkv", x), 12, key_bias=key_bias, clamp=50000.0 if clamp else 0.0, kv_len=kv_len, max_kv=max_kv)
+    else:
+        qk = _lin(P, b + ".qk", x)                                                      # [B, T, 2C]
+        vt = torch.baddbmm(P[b + ".attention.self.value.bias"][None, :, None], P[b + ".attention.self.value.weight"][None]
+                           .expand(Bn, -1, -1), x.transpose(1, 2))                      # V^T [B, C, T]
+        ctx = ops.attention(qk[:, :, :C], qk[:, :, C:], vt, 12, C // 12, key_bias=key_bias, clamp=50000.0 if clamp else 0.0,
+                            kv_len=kv_len, qk_mask=qk_mask)
     a = _add_ln(P, b + ".attention.output.LayerNorm", _lin(P, b + ".attention.output.dense", ctx), x32 if r32 else x, 1e-12,
                 want_sum=False, want_y32=r32)
     a16, a32 = a if r32 else (a, None)
@@ -457,7 +463,7 @@ def gcp_block(P, b, x, vision, idx, gates=None):
     return x + F.linear(F.gelu(F.linear(_ln(P, ff + ".norm", x), P[ff + ".linear1.weight"])), P[ff + ".linear2.gated"])
 
 
-def language_front(P, cfg, input_ids, attention_mask, use_vq, p="language_backbone.body.model", position_ids=None, qk_mask=None):
+def language_front(P, cfg, input_ids, attention_mask, use_vq, p="language_backbone.body.model", position_ids=None, qk_mask=None, max_kv=0):
     """Embeddings + the BERT layers that do not depend on the image (all 12 without vision queries, the first QV_START
     with them): the detector runs this on a side stream while the Swin backbone occupies the main one.
     MQ-GroundingDINO (prefix "bert"): `position_ids` [B,T] restart in every sub-sentence and `qk_mask` [B,1|H,T,T] uint8 is the
@@ -484,26 +490,26 @@ def language_front(P, cfg, input_ids, attention_mask, use_vq, p="language_backbo
     n_front = qv0 if use_vq else nl
     hidden = []
     for i in range(n_front):
-        x, x32 = _bert(P, f"{p}.encoder.layer.{i}", x, x32, key_bias, False, kv_len, qk_mask)
+        x, x32 = _bert(P, f"{p}.encoder.layer.{i}", x, x32, key_bias, False, kv_len, qk_mask, max_kv=max_kv)
         hidden.append(x if x32 is None else x32)
     return {"x": x, "x32": x32, "hidden": hidden, "key_bias": key_bias, "kv_len": kv_len, "next": n_front, "qk_mask": qk_mask}
 
 
-def _bert(P, b, x, x32, key_bias, clamp, kv_len, qk_mask=None):
+def _bert(P, b, x, x32, key_bias, clamp, kv_len, qk_mask=None, max_kv=0):
     """bert_layer on the (fp16 operand, fp32 stream or None) pair."""
     if x32 is None:
-        return bert_layer(P, b, x, key_bias, clamp, kv_len, qk_mask=qk_mask), None
-    return bert_layer(P, b, x, key_bias, clamp, kv_len, x32=x32, qk_mask=qk_mask)
+        return bert_layer(P, b, x, key_bias, clamp, kv_len, qk_mask=qk_mask, max_kv=max_kv), None
+    return bert_layer(P, b, x, key_bias, clamp, kv_len, x32=x32, qk_mask=qk_mask, max_kv=max_kv)
 
 
-def language_backbone(P, cfg, input_ids, attention_mask, vision, images, idx, want_gates=False, front=None):
+def language_backbone(P, cfg, input_ids, attention_mask, vision, images, idx, want_gates=False, front=None, max_kv=0):
     """bert_model_new.BertEncoder.forward (:39-104) over QVBertModel.forward (modeling_bert_new.py:690-848).
     `front`: result of language_front (computed concurrently with the image backbone); None -> computed here."""
     p = "language_backbone.body.model"
     LB = cfg.MODEL.LANGUAGE_BACKBONE
     use_vq = vision is not None
     if front is None:
-        front = language_front(P, cfg, input_ids, attention_mask, use_vq)
+        front = language_front(P, cfg, input_ids, attention_mask, use_vq, max_kv=max_kv)
     x, x32, hidden, key_bias, kv_len = front["x"], front.get("x32"), list(front["hidden"]), front["key_bias"], front["kv_len"]
     if use_vq:
         vision = pre_select(P, p + ".pre_select", vision, images, cfg.VISION_QUERY.VISION_SCALE)
@@ -516,7 +522,7 @@ def language_backbone(P, cfg, input_ids, attention_mask, vision, images, idx, wa
             else:
                 x32 = gcp_block(P, f"{p}.encoder.qv_layer.{i - qv0}", x32, vision, idx, gates)
                 x = x32.to(x.dtype)
-        x, x32 = _bert(P, f"{p}.encoder.layer.{i}", x, x32, key_bias, False, kv_len)
+        x, x32 = _bert(P, f"{p}.encoder.layer.{i}", x, x32, key_bias, False, kv_len, max_kv=max_kv)
         hidden.append(x if x32 is None else x32)
     n = LB.N_LAYERS
     feats = torch.stack(hidden[-n:], 1).float().mean(1) / n
@@ -774,7 +780,7 @@ def vldyhead(P, cfg, feats, lang, trace=None):
             tok = vl_image_side(P, b, v_ln, prep, kv_len, max_kv)
             hidden, h32 = text_side(b, v_ln, prep)
             rec = {"fuse_tok": tok, "fuse_hidden": hidden if h32 is None else h32}
-            hidden, h32 = _bert(P, f"{t}.{3 * i + 1}", hidden, h32, key_bias, True, kv_len)
+            hidden, h32 = _bert(P, f"{t}.{3 * i + 1}", hidden, h32, key_bias, True, kv_len, max_kv=max_kv)
             tok, relu_coef = dyconv_layer(i)
             if trace is not None:
                 rec.update(bert_hidden=hidden if h32 is None else h32, dyconv_tok=relu_applied_copy())
@@ -795,7 +801,7 @@ def vldyhead(P, cfg, feats, lang, trace=None):
             cur = prep
             with torch.cuda.stream(text):
                 hidden, h32 = text_side(b, v_ln, cur)
-                hidden, h32 = _bert(P, f"{t}.{3 * i + 1}", hidden, h32, key_bias, True, kv_len)
+                hidden, h32 = _bert(P, f"{t}.{3 * i + 1}", hidden, h32, key_bias, True, kv_len, max_kv=max_kv)
                 if i + 1 < L:
                     prep = vl_text_prep(P, f"{t}.{3 * (i + 1)}.b_attn", hidden, key_bias, h32)
             tok = vl_image_side(P, b, v_ln, cur, kv_len, max_kv)
@@ -874,6 +880,37 @@ def postprocess(cfg, head, anchors, im_wh, tokidx, label_ids, want_cls=False, le
         hws = [d.shape[1] for d in head["dot"]]
     ks = [min(A.PRE_NMS_TOP_N, hw * L) for hw in hws]
     tot = sum(ks)
+    Kd = int(A.DETECTIONS_PER_IMG)
+    K = min(Kd, tot) if Kd > 0 else tot
+    K2 = min(K + int(A.get("TIE_SLOTS", TIE_SLOTS)), tot) if Kd > 0 else tot
+    if ops.KERNELS["POST_FUSED"] == 1 and tot <= 8192 and (Kd <= 0 or tot <= 6656) and all(hw * L < (1 << 22) for hw in hws) \
+            and all(a.shape[0] == hw for a, hw in zip(anchors, hws)):
+        # ---- four launches (csrc/post2.hip): exact per-level select + decode, sort, NMS, final selection with the tie rule
+        if fused is not None:
+            ranked_l, reg_l = fused["ranked"], fused["reg"]
+            cls_all = fused["cls"] if want_cls else None
+        else:
+            ranked_l, reg_l, cls_all = [], [], []
+            for l, HW in enumerate(hws):
+                ctr_flat = head["centerness"][l].permute(0, 2, 3, 1).reshape(Bn, HW).contiguous()
+                r = ops.align_scores(head["dot"][l], head["tbias"], tokidx, ctr_flat, A.INFERENCE_TH, want_cls=want_cls, agg=agg)
+                if want_cls:
+                    r, c_ = r
+                    cls_all.append(c_)
+                ranked_l.append(r.float().contiguous())
+                reg_l.append(head["bbox_reg"][l].permute(0, 2, 3, 1).reshape(Bn, HW, 4).float().contiguous())
+        lab32 = label_ids if label_ids.dtype == torch.int32 else label_ids.to(torch.int32)
+        wh32 = im_wh if (im_wh.dtype == torch.float32 and im_wh.is_contiguous()) else im_wh.float().contiguous()
+        ub, us, ul, uid = ops.post_select(ranked_l, reg_l, [a.contiguous() for a in anchors], ks, lab32.contiguous(), wh32)
+        boxes, scores, labels, nvalid = ops.post_sort(ub, us, ul, uid)
+        keep8 = ops.ml_nms(boxes, labels, nvalid, A.NMS_TH, max_keep=K2 if Kd > 0 else 0, as_bool=False)
+        packed, cnt = ops.post_finalize(boxes, scores, labels, keep8, K, K2)
+        out = {"boxes": packed[..., :4], "scores": packed[..., 4], "labels": packed[..., 5].to(torch.int64), "counts": cnt & 0xFFFF,
+               "tie_overflow": (cnt >> 16) > 0, "packed": packed, "counts_packed": cnt,
+               "pre_nms": {"boxes": boxes, "scores": scores, "labels": labels, "nvalid": nvalid, "keep": keep8.bool()}}
+        if want_cls:
+            out["cls"] = cls_all
+        return out
     boxes = torch.empty(Bn, tot, 4, dtype=torch.float32, device=dev)
     scores = torch.empty(Bn, tot, dtype=torch.float32, device=dev)
     labels = torch.empty(Bn, tot, dtype=torch.int32, device=dev)
@@ -923,9 +960,6 @@ def postprocess(cfg, head, anchors, im_wh, tokidx, label_ids, want_cls=False, le
     # Final selection, rpn/inference.py:757-766: with more than DETECTIONS_PER_IMG survivors the reference keeps every detection whose
     # score is >= the K-th best one (torch.kthvalue + `>=`) -- detections TIED with the K-th are all kept, so an image can return more
     # than K.  Fixed shapes here: K + TIE_SLOTS output slots; the slots behind K are live only for scores equal to the K-th.
-    Kd = int(A.DETECTIONS_PER_IMG)
-    K = min(Kd, tot) if Kd > 0 else tot
-    K2 = min(K + int(A.get("TIE_SLOTS", TIE_SLOTS)), tot) if Kd > 0 else tot
     keep = ops.ml_nms(boxes, labels, nvalid, A.NMS_TH, max_keep=K2 if Kd > 0 else 0)
     kept_scores = torch.where(keep, scores, torch.full_like(scores, -1.0))
     top, ti = torch.topk(kept_scores, K2, dim=1, sorted=True)

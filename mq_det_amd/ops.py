@@ -13,12 +13,13 @@ _LIB = None
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmqdet_hip.so")
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
-EXPECTED_ABI = 20        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
+EXPECTED_ABI = 21        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
 _SIGNATURES = {
     "mq_abi_version": (_i, []),
     "mq_attn_workspace_bytes": (_l, [_i, _i, _i, _i, _i]),
     "mq_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _vp, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _i, _vp]),
     "mq_attn_resident_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _vp]),
+    "mq_attn_text_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _i, _vp]),
     "mq_attn_chunked_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _i, _vp]),
     "mq_window_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_window_attn_qkv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -52,12 +53,15 @@ _SIGNATURES = {
     "mq_roi_align_fwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _f, _i, _i, _i, _vp]),
     "mq_msdeform_attn_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_msdeform_attn_q_fwd": (_i, [_vp, _i, _l, _l, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "mq_post_select_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mq_post_sort_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "mq_post_finalize_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mq_ml_nms_workspace_bytes": (_l, [_i, _i]),
     "mq_ml_nms_topk": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
     "mq_ml_nms": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
 }
 # entry points with 16-bit operands also exist as <name>_bf16 (same signature; include/mqdet_hip.h MQ_BF16_TWIN)
-BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_window_attn_qkv_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
+BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_text_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_window_attn_qkv_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
               "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_patch_merge_ln_fwd", "mq_swin_mlp_fwd", "mq_swin_mlp2_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
               "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyrelu_apply", "mq_dyrelu_ln_fwd", "mq_add_upsample_nearest",
               "mq_align_scores_fwd", "mq_align_fused_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
@@ -87,6 +91,10 @@ KERNEL_DEFAULTS = {
     "DYRELU_IN_LN": 1,           # 1: the DYReLU of fusion layers 0 .. L-2 is applied by the next layer's LayerNorm (mq_dyrelu_ln_fwd); 0: own pass
     "VLFUSE_I2T_VARIANT": 0,     # mq_vlfuse_i2t_fwd: 0 = Q fragments in registers where they fit (129 .. 160 keys: 0.428 -> 0.370 ms per launch),
                                  # 1 = Q tile in LDS for every caption longer than 128 tokens
+    "BERT_QKV_FUSED": 1,         # 1: BERT layers = ONE qkv GEMM + mq_attn_text_fwd (V row-major, transposed out of LDS; registers / LDS sized by the
+                                 # caption length); 0: q|k GEMM + V^T batched GEMM + mq_attn_resident_fwd (rounds 2-3)
+    "POST_FUSED": 1,             # 1: ATSS post-processing as mq_post_select_fwd + mq_post_sort_fwd + mq_ml_nms_topk + mq_post_finalize_fwd (4 launches);
+                                 # 0: the round-1..3 chain (5 x torch.topk + box_decode, argsort, gathers, NMS, topk: ~145 launches, 1.1 ms)
     "ALIGN_FUSED": 1,            # 1: mq_align_fused_fwd (heads + alignment + scoring, logits never written); 0: bmm + 5 GEMMs + 5 x mq_align_scores_fwd
 }
 KERNELS = dict(KERNEL_DEFAULTS)       # filled from the environment right below configure() (import time), from cfg in prepare()
@@ -219,6 +227,36 @@ def _need_gpu(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
             raise RuntimeError("mq_det_amd ops need GPU tensors: the hot path has no CPU fallback")
+
+
+def attention_text(qkv, heads, key_bias=None, clamp=0.0, kv_len=None, max_kv=0, scale=None):
+    """Self-attention of the text tokens straight from the fused projection qkv [B,T,3*H*D] (q | k | v along the last dimension), V
+    row-major (mq_attn_text_fwd).  key_bias None, [B,T] or [B,H,T] fp32; kv_len [B] int32; max_kv: host bound on kv_len (0 = T).
+    -> [B,T,H*D] in qkv's dtype."""
+    lib = load_library()
+    _need_gpu(qkv, key_bias, kv_len)
+    B, T, C3 = qkv.shape
+    HD = C3 // 3
+    D = HD // heads
+    assert C3 == 3 * heads * D and qkv.dtype in _H16 and qkv.stride(2) == 1 and T <= 256 and D in (32, 64)
+    if kv_len is not None:
+        assert kv_len.dtype == torch.int32 and kv_len.shape == (B,) and kv_len.is_contiguous()
+    bias_bs = bias_hs = 0
+    if key_bias is not None:
+        assert key_bias.dtype == torch.float32 and key_bias.shape[-1] == T and key_bias.stride(-1) == 1
+        if key_bias.dim() == 2:
+            bias_bs = key_bias.stride(0)
+        else:
+            bias_bs, bias_hs = key_bias.stride(0), key_bias.stride(1)
+    o = torch.empty(B, T, HD, dtype=qkv.dtype, device=qkv.device)
+    q, k, v = qkv[:, :, :HD], qkv[:, :, HD:2 * HD], qkv[:, :, 2 * HD:]
+    bs, rs = qkv.stride(0), qkv.stride(1)
+    with _timed(f"attn_text_d{D}_nq{T}_nk{T}"):
+        rc = _fn(lib, "mq_attn_text_fwd", qkv)(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(key_bias), _ptr(kv_len), B, heads, T, T, D,
+                                               bs, rs, D, bs, rs, D, bs, rs, D, o.stride(0), o.stride(1), bias_bs, bias_hs,
+                                               float(scale if scale is not None else 1.0 / math.sqrt(D)), float(clamp), int(max_kv), _stream())
+    _chk(rc, "mq_attn_text_fwd")
+    return o
 
 
 def attention4(q4, k4, vt4, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None, kv_len=None, qk_mask=None):
@@ -885,6 +923,62 @@ def align_fused(tok, tk, tbias, wbc, bbc, scales, tokidx, sizes, thr, agg=0, kv_
     return out
 
 
+def post_select(ranked, reg, anchors, ks, label_ids, im_wh):
+    """Per (image, level) the ks[l] best candidates (value > 0) of ranked[l] [B,HW_l,L] fp32, decoded with reg[l] [B,HW_l,4] fp32 and
+    anchors[l] [HW_l,4] (mq_post_select_fwd).  -> boxes [B,tot,4], scores [B,tot] (-1 = empty slot), labels, ids [B,tot] int32; level l owns
+    the slots [sum ks[:l], sum ks[:l+1]) in arbitrary order."""
+    lib = load_library()
+    NL = len(ranked)
+    B, _, L = ranked[0].shape
+    dev = ranked[0].device
+    _need_gpu(*ranked, *reg, *anchors, label_ids, im_wh)
+    for r, g, a in zip(ranked, reg, anchors):
+        assert r.dtype == g.dtype == a.dtype == torch.float32 and r.is_contiguous() and g.is_contiguous() and a.is_contiguous()
+        assert r.shape[0] == B and r.shape[2] == L and g.shape == (B, r.shape[1], 4) and a.shape == (r.shape[1], 4)
+    assert label_ids.dtype == torch.int32 and label_ids.is_contiguous() and im_wh.dtype == torch.float32 and im_wh.is_contiguous()
+    tot = int(sum(ks))
+    boxes = torch.empty(B, tot, 4, dtype=torch.float32, device=dev)
+    scores = torch.empty(B, tot, dtype=torch.float32, device=dev)
+    labels = torch.empty(B, tot, dtype=torch.int32, device=dev)
+    ids = torch.empty(B, tot, dtype=torch.int32, device=dev)
+    pp = lambda ts: (ctypes.c_void_p * NL)(*[t.data_ptr() for t in ts])      # noqa: E731  host arrays of device pointers
+    hw = (ctypes.c_int * NL)(*[int(r.shape[1]) for r in ranked])
+    kk = (ctypes.c_int * NL)(*[int(k) for k in ks])
+    with _timed("post_select", sum(r.numel() for r in ranked) * 4):
+        _chk(lib.mq_post_select_fwd(ctypes.cast(pp(ranked), _vp), ctypes.cast(pp(reg), _vp), ctypes.cast(pp(anchors), _vp), ctypes.cast(hw, _vp),
+                                    ctypes.cast(kk, _vp), NL, B, L, _ptr(label_ids), L if label_ids.dim() == 2 else 0, _ptr(im_wh), _ptr(boxes),
+                                    _ptr(scores), _ptr(labels), _ptr(ids), _stream()), "mq_post_select_fwd")
+    return boxes, scores, labels, ids
+
+
+def post_sort(boxes, scores, labels, ids):
+    """Candidate lists [B,tot,...] -> ordered by (score desc, id asc), empty slots last, + nvalid [B] int32 (mq_post_sort_fwd)."""
+    lib = load_library()
+    _need_gpu(boxes, scores, labels, ids)
+    B, tot = scores.shape
+    bo, so, lo = torch.empty_like(boxes), torch.empty_like(scores), torch.empty_like(labels)
+    nvalid = torch.empty(B, dtype=torch.int32, device=scores.device)
+    with _timed("post_sort"):
+        _chk(lib.mq_post_sort_fwd(_ptr(boxes), _ptr(scores), _ptr(labels), _ptr(ids), _ptr(bo), _ptr(so), _ptr(lo), _ptr(nvalid), B, tot, _stream()),
+             "mq_post_sort_fwd")
+    return bo, so, lo, nvalid
+
+
+def post_finalize(boxes, scores, labels, keep, K, K2):
+    """Score-sorted rows + NMS keep flags [B,tot] uint8 -> packed [B,K2,6] (x1, y1, x2, y2, score, label; unused rows score -1) and
+    counts [B] int32 (live rows | 1 << 16 on tie overflow) (mq_post_finalize_fwd)."""
+    lib = load_library()
+    _need_gpu(boxes, scores, labels, keep)
+    B, tot = scores.shape
+    assert keep.dtype == torch.uint8 and keep.is_contiguous() and keep.shape == (B, tot)
+    out = torch.empty(B, K2, 6, dtype=torch.float32, device=scores.device)
+    counts = torch.empty(B, dtype=torch.int32, device=scores.device)
+    with _timed("post_finalize"):
+        _chk(lib.mq_post_finalize_fwd(_ptr(boxes), _ptr(scores), _ptr(labels), _ptr(keep), _ptr(out), _ptr(counts), B, tot, int(K), int(K2), _stream()),
+             "mq_post_finalize_fwd")
+    return out, counts
+
+
 def box_decode(val, flat, reg, anchors, label_ids, im_wh, boxes, scores, labels, HW, L, out_off):
     """Decode top-K candidates of one level into columns [out_off, out_off+K) of the per-image arrays.
     label_ids [L] (shared) or [B, L] int32."""
@@ -982,7 +1076,7 @@ def ms_deform_attn_q(value, spatial_shapes, qproj, ref, heads, out_dtype=None, v
     return out
 
 
-def ml_nms(boxes, labels, nvalid, thresh, max_keep=0):
+def ml_nms(boxes, labels, nvalid, thresh, max_keep=0, as_bool=True):
     """boxes [B,N,4] fp32 sorted by score desc, labels [B,N] int32, nvalid [B] int32 -> keep [B,N] bool.
     max_keep > 0 with KERNELS["NMS_EARLY_STOP"] (default): the sweep of an image ends once max_keep boxes are kept (mq_ml_nms_topk; the
     max_keep highest-scoring survivors are the same, later boxes read as not kept)."""
@@ -996,7 +1090,7 @@ def ml_nms(boxes, labels, nvalid, thresh, max_keep=0):
     if max_keep > 0 and N <= 6656 and KERNELS["NMS_EARLY_STOP"] == 1:
         _chk(lib.mq_ml_nms_topk(_ptr(boxes), _ptr(labels), _ptr(nvalid), _ptr(ws), _ptr(keep), B, N, float(thresh), int(max_keep), _stream()),
              "mq_ml_nms_topk")
-        return keep.bool()
+        return keep.bool() if as_bool else keep
     _chk(lib.mq_ml_nms(_ptr(boxes), _ptr(labels), _ptr(nvalid), _ptr(ws), _ptr(keep), B, N, float(thresh), _stream()),
          "mq_ml_nms")
-    return keep.bool()
+    return keep.bool() if as_bool else keep

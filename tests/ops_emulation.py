@@ -31,6 +31,14 @@ def attention(q, k, vt, num_heads, head_dim, key_bias=None, scale=None, clamp=0.
     return (s.softmax(-1) @ vh).transpose(1, 2).reshape(B, Nq, HD).to(q.dtype)
 
 
+def attention_text(qkv, heads, key_bias=None, clamp=0.0, kv_len=None, max_kv=0, scale=None):
+    B, T, C3 = qkv.shape
+    HD = C3 // 3
+    q, k, v = qkv[..., :HD], qkv[..., HD:2 * HD], qkv[..., 2 * HD:]
+    return attention4(q.reshape(B, T, heads, -1), k.reshape(B, T, heads, -1), v.reshape(B, T, heads, -1).permute(0, 2, 3, 1).contiguous(),
+                      key_bias=key_bias, scale=scale, clamp=clamp)
+
+
 def attention4(q4, k4, vt4, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None, kv_len=None):
     B, Nq, H, D = q4.shape
     Nk = k4.shape[1] if nk is None else nk
@@ -201,7 +209,7 @@ def box_decode(val, flat, reg, anchors, label_ids, im_wh, boxes, scores, labels,
     labels[:, out_off:out_off + K] = torch.where(ok, lab, torch.zeros_like(lab))
 
 
-def ml_nms(boxes, labels, nvalid, thresh, max_keep=0):
+def ml_nms(boxes, labels, nvalid, thresh, max_keep=0, as_bool=True):
     from oracle.postprocess import ml_nms as ref
     B, N, _ = boxes.shape
     keep = torch.zeros(B, N, dtype=torch.bool)
@@ -210,7 +218,57 @@ def ml_nms(boxes, labels, nvalid, thresh, max_keep=0):
         if nv:
             sc = torch.arange(nv, 0, -1).float()          # already sorted by score
             keep[b, ref(boxes[b, :nv], sc, labels[b, :nv].float(), thresh)] = True
-    return keep
+    return keep if as_bool else keep.to(torch.uint8)
+
+
+def post_select(ranked, reg, anchors, ks, label_ids, im_wh):
+    """mq_post_select_fwd restated with torch: per level the ks[l] largest positive values (ties: smaller flat index first), decoded."""
+    B, _, L = ranked[0].shape
+    tot = int(sum(ks))
+    boxes, scores = torch.zeros(B, tot, 4), torch.full((B, tot), -1.0)
+    labels, ids = torch.zeros(B, tot, dtype=torch.int32), torch.full((B, tot), 0x7FFFFFFF, dtype=torch.int32)
+    off = idb = 0
+    for r, g, a, k in zip(ranked, reg, anchors, ks):
+        HW = r.shape[1]
+        flatv = r.reshape(B, HW * L)
+        val, flat = torch.sort(flatv, dim=1, descending=True, stable=True)          # stable: equal values keep index order
+        val, flat = val[:, :k].contiguous(), flat[:, :k].contiguous()
+        box_decode(val, flat, g, a, label_ids, im_wh, boxes, scores, labels, HW, L, off)
+        ids[:, off:off + k] = torch.where(val > 0, (idb + flat).to(torch.int32), torch.full_like(flat, 0x7FFFFFFF).to(torch.int32))
+        off += k
+        idb += HW * L
+    return boxes, scores, labels, ids
+
+
+def post_sort(boxes, scores, labels, ids):
+    key = torch.where(scores > 0, scores, torch.full_like(scores, -1.0))
+    # (score desc, id asc): sort by id first, then a stable sort by score
+    o1 = torch.argsort(ids, dim=1, stable=True)
+    o2 = torch.argsort(torch.gather(key, 1, o1), dim=1, descending=True, stable=True)
+    order = torch.gather(o1, 1, o2)
+    so = torch.gather(key, 1, order)
+    live = so > 0
+    bo = torch.where(live[..., None], torch.gather(boxes, 1, order[..., None].expand(-1, -1, 4)), torch.zeros_like(boxes))
+    lo = torch.where(live, torch.gather(labels, 1, order), torch.zeros_like(labels))
+    return bo, torch.where(live, so, torch.full_like(so, -1.0)), lo, live.sum(1).to(torch.int32)
+
+
+def post_finalize(boxes, scores, labels, keep, K, K2):
+    B, tot = scores.shape
+    out = torch.zeros(B, K2, 6)
+    out[..., 4] = -1.0
+    counts = torch.zeros(B, dtype=torch.int32)
+    for b in range(B):
+        rows = [i for i in range(tot) if keep[b, i] and scores[b, i] > 0]
+        take = rows[:K]
+        if len(rows) >= K:
+            ks_ = scores[b, rows[K - 1]]
+            take += [i for i in rows[K:K2] if scores[b, i] == ks_]
+        for j, i in enumerate(take):
+            out[b, j, :4], out[b, j, 4], out[b, j, 5] = boxes[b, i], scores[b, i], float(labels[b, i])
+        ovf = int(0 < K < K2 < tot and len(take) == K2 and float(scores[b, take[-1]]) == float(scores[b, take[K - 1]]))
+        counts[b] = len(take) | (ovf << 16)
+    return out, counts
 
 
 def dyconv_branch_coef(y, Wsrc, gamma, beta, attn_w, attn_b, groups, eps, nbranches, wy=None, wx=None, sums=None):
@@ -507,9 +565,9 @@ def dyconv_coef_group(items, attn_w, attn_b, groups, eps):
 
 # ---------------------------------------------------------------------------------------------------------------------------------
 # every emulated entry point, in one place: tests patch them into mq_det_amd.ops (or into a stand-in namespace) with these helpers
-NAMES = ("attention", "attention4", "window_attention", "window_attention_qkv", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores", "align_fused",
+NAMES = ("attention", "attention4", "attention_text", "window_attention", "window_attention_qkv", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores", "align_fused",
          "dyconv_branch_coef", "dyconv_coef_group", "dyconv_fuse", "dyrelu_", "dyrelu_coef", "dyrelu_apply_", "dyrelu_layer_norm", "add_upsample_nearest_", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "vlfuse_i2t",
-         "vlfuse_t2i", "box_decode", "ml_nms", "roi_align", "swin_mlp", "swin_mlp2", "patch_merge_ln", "ms_deform_attn", "ms_deform_attn_q", "image_key_mask")
+         "vlfuse_t2i", "box_decode", "ml_nms", "post_select", "post_sort", "post_finalize", "roi_align", "swin_mlp", "swin_mlp2", "patch_merge_ln", "ms_deform_attn", "ms_deform_attn_q", "image_key_mask")
 
 
 def patch_into(monkeypatch, ops_module):

@@ -125,6 +125,33 @@ def check_attention_strided(dev):
     return _stat("attn strided q|k views (BERT)", out, ref)
 
 
+def check_attention_text(dev):
+    """mq_attn_text_fwd (csrc/attn_text.hip): q | k | v slices of ONE [B, T, 3 H D] projection, V row-major and transposed out of LDS, the
+    register / LDS variant picked by the host bound max_kv.  Caption lengths on both sides of the 160-key variant switch and of 16-key
+    block edges, per-item kv_len below the bound, the clamped variant with logits at the clamp, D = 64 (BERT) and 32, T < 256."""
+    from mq_det_amd import ops
+    res = []
+    g = torch.Generator().manual_seed(23)
+    cases = [(2, 12, 64, 256, 141, 0.0, 1.0), (2, 12, 64, 256, 160, 50000.0, 1.0), (1, 12, 64, 256, 161, 0.0, 1.0), (2, 12, 64, 256, 256, 0.0, 1.0),
+             (2, 8, 32, 200, 77, 0.0, 1.0), (1, 4, 64, 40, 17, 3.0, 6.0), (3, 12, 64, 256, 16, 0.0, 1.0)]
+    if QUICK:
+        cases = [cases[0], cases[2], cases[4], cases[5]]
+    for (B, H, D, T, kv, clamp, amp) in cases:
+        qkv = (torch.randn(B, T, 3 * H * D, generator=g) * amp).to(H16)
+        kl = torch.tensor([max(1, kv - 9 * b) for b in range(B)], dtype=torch.int32)            # item b has a shorter caption
+        kb = torch.zeros(B, T)
+        for b in range(B):
+            kb[b, int(kl[b]):] = -1e30
+        HD = H * D
+        ref = _ref_attention(qkv[..., :HD], qkv[..., HD:2 * HD], qkv[..., 2 * HD:], H, kb, None, clamp)
+        for mk in sorted({kv, 0, min(T, kv + 20)}):
+            out = ops.attention_text(qkv.to(dev), H, key_bias=kb.to(dev), clamp=clamp, kv_len=kl.to(dev), max_kv=mk)
+            res.append(_stat(f"attn_text B={B} H={H} D={D} T={T} kv={kv} max_kv={mk} clamp={clamp}", out, ref))
+        out = ops.attention_text(qkv.to(dev), H, key_bias=kb.to(dev), clamp=clamp)                # no kv_len: every block visited, bias masks
+        res.append(_stat(f"attn_text B={B} H={H} D={D} T={T} kv={kv} no kv_len clamp={clamp}", out, ref))
+    return res
+
+
 def _tiny(dev, image_hw=(160, 192), B=2, seed=0, spec=None):
     """Shared tiny model: oracle state dict + product model with the same weights (spec: tiny_spec() = Swin-T widths, or
     tiny_l_spec() = Swin-L widths / window 12)."""
@@ -472,6 +499,70 @@ def check_ref_pins(dev):
             ok = got.shape == pin.shape and bool(torch.equal(got, pin))
             res.append({"name": f"PIN {nm} vs reference CUDA kernel + sweep: n={n} kept={len(pin)}", "max_err": 0.0 if ok else 1.0,
                         "mean_err": 0.0, "ref_absmax": 1.0, "norm_err": 0.0 if ok else 1.0, "tol": 0.0, "ok": ok})
+    return res
+
+
+def _flag(name, ok):
+    return {"name": name, "max_err": 0.0 if ok else 1.0, "mean_err": 0.0, "ref_absmax": 1.0, "norm_err": 0.0 if ok else 1.0, "tol": 0.0, "ok": bool(ok)}
+
+
+def check_post_fused(dev):
+    """csrc/post2.hip -- mq_post_select_fwd / mq_post_sort_fwd / mq_post_finalize_fwd against their plain-torch restatements
+    (tests/ops_emulation.py: stable sorts) on synthetic score maps: sparse and dense candidates, scores quantised to a few values so that
+    the cut of the radix select falls INSIDE a group of equal keys (ties resolved by flat index), one value everywhere, no candidate at all,
+    rows that are not 16-byte aligned; then the product post-processing with the four-launch path against the round-3 chain it replaces
+    (torch.topk / argsort / gathers) on the same head outputs.  Integer / index work: EXACT (boxes: the same fp32 expression, 1e-6)."""
+    import ops_emulation as emu
+    from mq_det_amd import ops, get_cfg
+    from mq_det_amd.modeling import pipeline
+    res = []
+    g = torch.Generator().manual_seed(17)
+    cases = [("sparse", (2, [(9, 13), (5, 6), (3, 3)], 7, 40, 0.02, None)), ("dense", (2, [(20, 31), (9, 11)], 5, 300, 0.9, None)),
+             ("dense, 5 score values", (2, [(20, 31), (10, 16)], 5, 120, 0.8, 5)), ("one value everywhere", (1, [(12, 17)], 3, 50, 1.0, 1)),
+             ("no candidate", (2, [(6, 7), (2, 3)], 4, 30, 0.0, None)), ("k = everything", (1, [(4, 5)], 3, 60, 0.5, None)),
+             ("P3-sized level", (1, [(100, 168)], 40, 1000, 0.3, 4096))]
+    if QUICK:
+        cases = cases[:-1] + [("large level", (1, [(40, 56)], 10, 1000, 0.3, 512))]
+    for name, (B, shapes, L, topn, dens, quant) in cases:
+        ranked, reg, anchors, ks = [], [], [], []
+        for (h, w) in shapes:
+            hw = h * w
+            v = torch.rand(B, hw, L, generator=g)
+            if quant:
+                v = (torch.floor(v * quant) + 1) / (quant + 1)
+            cand = torch.rand(B, hw, L, generator=g) < dens
+            ranked.append(torch.where(cand, v, torch.full_like(v, -1.0)).contiguous())
+            reg.append((torch.randn(B, hw, 4, generator=g) * 2).contiguous())
+            xy = torch.rand(hw, 2, generator=g) * 300
+            anchors.append(torch.cat([xy, xy + 8 + torch.rand(hw, 2, generator=g) * 64], 1).contiguous())
+            ks.append(min(topn, hw * L))
+        label_ids = torch.randperm(L, generator=g).to(torch.int32) + 1
+        im_wh = torch.tensor([[333.0, 250.0]] * B)
+        eb, es, el, ei = emu.post_select(ranked, reg, anchors, ks, label_ids.long(), im_wh)
+        gb, gs, gl, gi = [t.cpu() for t in ops.post_select([t.to(dev) for t in ranked], [t.to(dev) for t in reg], [t.to(dev) for t in anchors], ks,
+                                                           label_ids.to(dev), im_wh.to(dev))]
+        off = 0
+        same = True
+        for k in ks:                                        # a level's slots hold the same candidates, in any order: compare by id
+            for b in range(B):
+                oe, og = torch.argsort(ei[b, off:off + k], stable=True), torch.argsort(gi[b, off:off + k], stable=True)
+                same &= torch.equal(ei[b, off:off + k][oe], gi[b, off:off + k][og])
+                same &= bool((es[b, off:off + k][oe] - gs[b, off:off + k][og]).abs().max() <= 1.5e-7)     # sqrtf vs torch.sqrt: one ulp
+                same &= torch.equal(el[b, off:off + k][oe].int(), gl[b, off:off + k][og].int())
+                same &= bool((eb[b, off:off + k][oe] - gb[b, off:off + k][og]).abs().max() <= 1e-4)
+            off += k
+        res.append(_flag(f"post_select [{name}] B={B} levels={shapes} L={L} k={ks}: same candidates per level as sort + top-k", same))
+        sb, ss, sl, sn = emu.post_sort(gb, gs, gl, gi)       # the SAME unsorted lists into both sorts: everything behind is exact
+        hb, hs, hl, hn = [t.cpu() for t in ops.post_sort(gb.to(dev), gs.to(dev), gl.to(dev), gi.to(dev))]
+        ok = torch.equal(ss, hs) and torch.equal(sl.int(), hl.int()) and torch.equal(sn.int(), hn.int()) and bool((sb - hb).abs().max() <= 1e-4)
+        res.append(_flag(f"post_sort [{name}] tot={sum(ks)}: (score desc, id asc) order, empty rows last, nvalid", ok))
+        tot = sum(ks)
+        for K, extra in ((max(1, tot // 3), 4), (tot, 0), (1, 1)):
+            K2 = min(K + extra, tot)
+            keep = (torch.rand(B, tot, generator=g) < 0.7).to(torch.uint8)
+            fo, fc = emu.post_finalize(hb, hs, hl, keep, K, K2)
+            ho, hc = [t.cpu() for t in ops.post_finalize(hb.to(dev), hs.to(dev), hl.to(dev), keep.to(dev), K, K2)]
+            res.append(_flag(f"post_finalize [{name}] K={K} K2={K2}: packed rows, counts, overflow flag", torch.equal(fc.int(), hc.int()) and bool((fo - ho).abs().max() <= 1e-4)))
     return res
 
 

@@ -111,6 +111,11 @@ inline unsigned long long __ballot(int pred) {
   }
   return m;
 }
+// atomics: the fibers of a block run one at a time between synchronisation points, so a plain read-modify-write is atomic here
+template <class T> inline T atomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }
+template <class T> inline T atomicMax(T* p, T v) { const T o = *p; if (v > o) *p = v; return o; }
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 inline int __any(int pred) { return __ballot(pred) != 0; }
 inline int __all(int pred) { return __ballot(!pred) == 0; }
 inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }

@@ -115,7 +115,8 @@ def test_emulation_unit_kernels():
 @pytest.mark.parametrize("schedule,names", [
     (("descending", 0), ("check_attention_strided", "check_window_attention", "check_gcp_block", "check_layernorm", "check_swin_mlp",
                          "check_nms", "check_post_golden", "check_msdeform_attn")),
-    (("random", 1), ("check_dcn", "check_vlfuse_kernels", "check_conv3x3"))])
+    (("random", 1), ("check_dcn", "check_vlfuse_kernels", "check_conv3x3", "check_post_fused")),
+    (("descending", 0), ("check_post_fused",))])
 def test_kernels_are_insensitive_to_the_wave_schedule(kernels, schedule, names):
     """Race check of the shipped kernels: the same parity checks with the fibers resumed in descending / pseudo-random order
     (a consumer wave then runs before its producer unless a barrier orders them).  MQ_SIMT_FULL=1: every check under both."""
@@ -145,7 +146,7 @@ def test_attention_strided_views(kernels):
 
 @pytest.mark.parametrize("name", ["check_window_attention", "check_gcp_block", "check_pre_select", "check_vlfuse_kernels", "check_vl_fuse",
                                   "check_dcn", "check_dyconv", "check_post_golden", "check_score_agg", "check_layernorm", "check_nms", "check_swin_mlp",
-                                  "check_conv3x3", "check_roi_align", "check_msdeform_attn", "check_swin_fpn", "check_align_fused"])
+                                  "check_conv3x3", "check_roi_align", "check_msdeform_attn", "check_swin_fpn", "check_align_fused", "check_post_fused", "check_attention_text"])
 def test_kernel_block(kernels, name):
     _assert_ok(getattr(kernels, name)(CPU))
 
