@@ -347,6 +347,15 @@ int mq_ml_nms(const float* boxes, const int* labels, const int* nvalid, void* wo
 int mq_ml_nms_topk(const float* boxes, const int* labels, const int* nvalid, void* workspace, unsigned char* keep,
                    int B, int N, float thr, int max_keep, void* stream);
 
+/* Swin PatchEmbed (4x4 stride-4 convolution as a 48 -> C projection, maskrcnn_benchmark/modeling/backbone/swint.py:447-471) +
+ * patch_embed.norm + the first block's norm1 (swint.py:186-242) in one pass over the pixels:
+ *   img: [B, Hi, Wi, 3] 16-bit channels-last pixels (img_f32 == 0) or the caller's [B, 3, Hi, Wi] fp32 tensor (img_f32 != 0: rounded to the
+ *   operand type in the kernel -- no cast / layout pass before it); Hi, Wi multiples of 4.  w [C, 64] 16-bit = the conv weight in the k order
+ *   of that layout (ops.patch_embed_pack; k 48..63 zero), bias / g0 / b0 (patch_embed.norm) / g1 / b1 (norm1 of layers.0.blocks.0) fp32 [C];
+ *   x32 [B, Hi/4 * Wi/4, C] fp32 = LN_0(proj) (the residual stream), h1 (same shape, 16-bit) = LN_1(x32).  C in {96, 192} (-1 otherwise). */
+int mq_patch_embed_fwd(const void* img, int img_f32, const void* w, const float* bias, const float* g0, const float* b0, const float* g1,
+                       const float* b1, float* x32, void* h1, int B, int Hi, int Wi, int C, float eps, void* stream);
+
 /* Self-attention over the text tokens with Q, K and V ROW-MAJOR (slices of one fused qkv projection): the second generation of
  * mq_attn_resident_fwd for the BERT layers (HF BertSelfAttention; the clamped copy rpn/modeling_bert.py:71-150 with clamp > 0).
  *   q [B,Nq,H,D], k / v [B,Nk,H,D] 16-bit views, unit last stride, strides in elements; o [B,Nq,H*D]; key_bias fp32 (b, h, j) at
@@ -396,6 +405,7 @@ int mq_post_finalize_fwd(const float* boxes, const float* scores, const int* lab
 MQ_BF16_TWIN(mq_attn_fwd)
 MQ_BF16_TWIN(mq_attn_resident_fwd)
 MQ_BF16_TWIN(mq_attn_text_fwd)
+MQ_BF16_TWIN(mq_patch_embed_fwd)
 MQ_BF16_TWIN(mq_attn_chunked_fwd)
 MQ_BF16_TWIN(mq_window_attn_fwd)
 MQ_BF16_TWIN(mq_window_attn_qkv_fwd)

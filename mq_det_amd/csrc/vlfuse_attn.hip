@@ -162,7 +162,7 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* tiles = (half_t*)smem;                           // [2][TK][KS]
   half_t* Qs = tiles + 2 * TILE;                           // [BM][KS] (LEAN only)
-  float* bias_s = (float*)(Qs + (LEAN ? BM * KS : 0));     // [8][NT*64]
+  float* bias_s = (float*)(Qs + (LEAN ? BM * KS : 0));     // [8][NT*64], + the additive key mask [8][NT*64] behind it
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -179,13 +179,20 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
   const int qtile = (int)(w - (long)b * qtiles);
   const int row0 = qtile * BM + wave * WR;
 
+  // bias_s = bias, 0 for a masked key; mask_s = 0 or -1e30 -- added AFTER the clamp, like the reference's attention mask behind torch.clamp
+  // (fuse_helper.py:236-262): logit = med3(s + bias, -c, c) + mask, three VALU operations (round 3: add, min, max, compare, two selects).
+  // (Not in the log2 domain: with the raw v_exp_f32 builtin hipcc 7.0 spills 237 VGPRs in this kernel; __expf costs one multiply more.)
+  float* mask_s = bias_s + VH * NT * TK;
   const int kv_eff = p.kv_len ? max(1, min(p.T, p.kv_len[b])) : p.T;
   for (int i = tid; i < p.H * NT * TK; i += NTH) {
     const int h = i / (NT * TK), t = i % (NT * TK);
     float v = MQ_NEG_BIG;
     if (t < kv_eff) v = p.bias ? p.bias[((long)b * p.H + h) * p.T + t] : 0.f;
-    bias_s[i] = v;
+    const bool masked = v < -1.0e29f;
+    bias_s[i] = masked ? 0.f : v;
+    mask_s[i] = masked ? MQ_NEG_BIG : 0.f;
   }
+  const float cl2 = p.clamp > 0.f ? p.clamp : 3.0e38f;                   // no clamp: a bound no logit reaches (one v_med3 either way)
 
   half8 qf[QB][8];
   const half_t* vb = p.v + (long)b * p.N * VD;
@@ -268,18 +275,14 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
           for (int qb = 0; qb < QB; ++qb) s[j][nb][qb] = (float4_){0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) {
+      for (int nb = 0; nb < (j == NT - 1 ? NBL : 4); ++nb) {           // live key blocks only (the others never reach the softmax)
         const float4_ kb = *(const float4_*)(bias_s + (h * NT + j) * TK + nb * 16 + 4 * lg);
+        const float4_ km = *(const float4_*)(mask_s + (h * NT + j) * TK + nb * 16 + 4 * lg);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool masked = kb[r] < -1.0e29f;
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int qb = 0; qb < QB; ++qb) {
-            float v = s[j][nb][qb][r] + kb[r];
-            if (p.clamp > 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
-            s[j][nb][qb][r] = masked ? MQ_NEG_BIG : v;
-          }
-        }
+          for (int qb = 0; qb < QB; ++qb)
+            s[j][nb][qb][r] = __builtin_amdgcn_fmed3f(s[j][nb][qb][r] + kb[r], -cl2, cl2) + km[r];
       }
       end(J);
     };
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
+        for (int nb = 0; nb < (j == NT - 1 ? NBL : 4); ++nb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[j][nb][qb][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16));
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
+        for (int nb = 0; nb < (j == NT - 1 ? NBL : 4); ++nb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float e = __expf(s[j][nb][qb][r] - mx);
@@ -314,11 +317,11 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
           }
       sum += __shfl_xor(sum, 16);
       sum += __shfl_xor(sum, 32);
-      const float inv = 1.f / sum;
+      const float inv = __builtin_amdgcn_rcpf(sum);                       // sum >= 1 (the row maximum contributes 1): no denormal / zero case
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
+        for (int nb = 0; nb < (j == NT - 1 ? NBL : 4); ++nb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) s[j][nb][qb][r] *= inv;
     }
@@ -334,8 +337,9 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
         for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            pf[st][qb][r] = (half_t)s[j][2 * st][qb][r];
-            pf[st][qb][4 + r] = (half_t)s[j][2 * st + 1][qb][r];
+            constexpr int live = (j == NT - 1 ? NBL : 4);
+            pf[st][qb][r] = 2 * st < live ? (half_t)s[j][2 * st][qb][r] : (half_t)0.f;
+            pf[st][qb][4 + r] = 2 * st + 1 < live ? (half_t)s[j][2 * st + 1][qb][r] : (half_t)0.f;
           }
       if constexpr (!(ABL & 8)) pv_tile<QB, (j == NT - 1 ? (NBL + 1) / 2 : 2)>(tiles + ((NT + j) & 1) * TILE, pf, o, l15, lg);
       else {
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
 
 template <int NT, int QB, int NBL, int ABL = 0, bool QREG = false>
 static int launch_i2t(const I2TParams& p, hipStream_t stream) {
-  constexpr size_t smem = (size_t)(2 * TILE + ((NT >= 3 && !QREG) ? BM * KS : 0)) * sizeof(half_t) + (size_t)VH * NT * TK * sizeof(float);
+  constexpr size_t smem = (size_t)(2 * TILE + ((NT >= 3 && !QREG) ? BM * KS : 0)) * sizeof(half_t) + (size_t)2 * VH * NT * TK * sizeof(float);
   static_assert(4 * 32 * (VD + 8) <= 2 * TILE, "O staging must fit in the tiles");
   static MqOncePerDevice attr_set;
   if (attr_set.first()) {
@@ -544,6 +548,7 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
     const int t = t0 + min(pos, max(nt - 1, 0));
     if constexpr (!(ABL & 1)) tile_issue(slot[sl], vb, t * TK, p.N - 1, tid);
   };
+  const float cl = p.clamp > 0.f ? p.clamp : 3.0e38f;
   constexpr float THR = 8.0f;     // deferred rescale: O / l are rescaled only when a row max grows by more than THR
   auto body = [&](auto PAR, auto SL, int pos) {            // PAR = pos % 2 (LDS buffer), SL = pos % RS (ring slot that held tile pos)
     constexpr int par = decltype(PAR)::value, sl = decltype(SL)::value;
@@ -575,8 +580,7 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
           const bool valid = key0 + nb * 16 + 4 * lg + r < p.N && (!KM || ((km[nb] >> (8 * r)) & 0xffu) == 0u);
 #pragma unroll
           for (int qb = 0; qb < QB; ++qb) {
-            float v = s[nb][qb][r];
-            if (p.clamp > 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
+            float v = __builtin_amdgcn_fmed3f(s[nb][qb][r], -cl, cl);         // one v_med3 (no clamp: cl = 3e38)
             v = valid ? v : MQ_NEG_BIG;
             s[nb][qb][r] = v;
             mx[qb] = fmaxf(mx[qb], v);

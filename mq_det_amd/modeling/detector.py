@@ -281,6 +281,15 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
             gates = torch.stack([g.float().mean() for g in gates])
         return {"packed": packed, "counts": counts, "gates": gates}
 
+    def _pixels(self, src, dtype):
+        """The pixel tensor the device program takes: the caller's fp32 NCHW tensor AS IT IS when the patch-embedding kernel can read it
+        (mq_patch_embed_fwd rounds to the operand type itself: no cast pass, no channels-last copy), else 16-bit channels-last pixels."""
+        P = self._plan
+        if _ops.KERNELS["PATCH_EMBED_FUSED"] == 1 and P.get("_r32") and src.dtype == torch.float32 and src.is_contiguous() \
+                and src.shape[1] == 3 and "backbone.body.patch_embed.wpk_nchw" in P:
+            return src
+        return src.to(dtype).contiguous(memory_format=torch.channels_last)
+
     def _split_counts(self, counts):
         """Packed per-image counts -> live slots; remembers (and warns about) images whose ties with the K-th score did not fit."""
         self.last_tie_overflow = [bool(c >> 16) for c in counts]
@@ -486,7 +495,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
                 self._front_cache.move_to_end(fkey)
             out = self._run("_rest_program", (fc["feats"], fc["pooled"], front) + tail, use_graph)
         else:
-            x = src.to(dtype).contiguous(memory_format=torch.channels_last)
+            x = self._pixels(src, dtype)
             staggered = (self.micro_batches > 1 and Bn > 1 and not self.backbone_cache and x.is_cuda
                          and not cfg.VISION_QUERY.RETURN_ATTN_GATE_VALUE and not return_backbone_features
                          and cfg.MODEL.DYHEAD.get("LEVEL_STREAMS", True))
@@ -535,7 +544,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
             return fc["feats"], fc["pooled"]
         self.cache_stats["backbone_miss"] += 1
         dtype = self._plan["backbone.body.patch_embed.proj.weight"].dtype
-        x = src.to(dtype).contiguous(memory_format=torch.channels_last)
+        x = self._pixels(src, dtype)
         feats, pooled = self._backbone_stage(x)
         if self.backbone_cache:
             self._feat_cache = {"src": src, "version": src._version, "feats": feats, "pooled": pooled}

@@ -54,6 +54,12 @@ def _pack_swin(P, sd, SW, p, device, dtype):
     # patch embedding (4x4 stride-4 conv) as a GEMM over (kh, kw, c)-ordered patches
     w = sd[p + ".patch_embed.proj.weight"].detach().to(device=device, dtype=torch.float32)
     P[p + ".patch_embed.lin"] = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dtype).contiguous()
+    if w.shape[0] in (96, 192) and tuple(w.shape[1:]) == (3, 4, 4):          # operands of mq_patch_embed_fwd (projection + both LayerNorms)
+        P[p + ".patch_embed.wpk"] = ops.patch_embed_pack(w).to(dtype).contiguous()
+        P[p + ".patch_embed.wpk_nchw"] = ops.patch_embed_pack(w, nchw=True).to(dtype).contiguous()     # for fp32 NCHW pixels (the caller's tensor)
+        P[p + ".patch_embed.f32"] = [sd[n].detach().to(device=device, dtype=torch.float32).contiguous() for n in
+                                     (p + ".patch_embed.proj.bias", p + ".patch_embed.norm.weight", p + ".patch_embed.norm.bias",
+                                      p + ".layers.0.blocks.0.norm1.weight", p + ".layers.0.blocks.0.norm1.bias")]
 
 
 def _pack_language(P, sd, cfg, p, device, dtype):
@@ -252,18 +258,31 @@ def swin_forward(P, cfg, img, p="backbone.body", SW=None):
         img = F.pad(img, (0, (4 - W0 % 4) % 4, 0, (4 - H0 % 4) % 4))
     B, Cin, Hi, Wi = img.shape
     H, W = Hi // 4, Wi // 4
-    patches = img.permute(0, 2, 3, 1).reshape(B, H, 4, W, 4, Cin).permute(0, 1, 3, 2, 4, 5).reshape(B, H * W, 16 * Cin)
     r32 = P["_r32"]
-    x = F.linear(patches, P[p + ".patch_embed.lin"], P[p + ".patch_embed.proj.bias"])      # PatchEmbed.proj, swint.py:447-471
-    # x is the residual stream of the stage: fp32 with RESIDUAL_FP32 (the LayerNorm kernel reads / writes it in fp32 and
-    # hands fp16 to the GEMMs), fp16 otherwise
-    x = _ln(P, p + ".patch_embed.norm", x, want_y=not r32, want_y32=r32)
+    h1_first = None
+    nhwc = img.permute(0, 2, 3, 1)
+    pe = ops.KERNELS["PATCH_EMBED_FUSED"] == 1 and r32 and Cin == 3 and (p + ".patch_embed.wpk") in P
+    if pe and img.dtype == torch.float32 and img.is_contiguous():
+        # projection + patch_embed.norm + norm1 of the first block in one pass over the caller's fp32 NCHW pixels (mq_patch_embed_fwd)
+        x, h1_first = ops.patch_embed(img, P[p + ".patch_embed.wpk_nchw"], *P[p + ".patch_embed.f32"], eps=1e-5)
+    elif pe and img.dtype != torch.float32 and nhwc.is_contiguous():
+        x, h1_first = ops.patch_embed(nhwc, P[p + ".patch_embed.wpk"], *P[p + ".patch_embed.f32"], eps=1e-5)
+    else:
+        if img.dtype == torch.float32:
+            nhwc = nhwc.to(P[p + ".patch_embed.lin"].dtype)
+        patches = nhwc.reshape(B, H, 4, W, 4, Cin).permute(0, 1, 3, 2, 4, 5).reshape(B, H * W, 16 * Cin)
+        x = F.linear(patches, P[p + ".patch_embed.lin"], P[p + ".patch_embed.proj.bias"])  # PatchEmbed.proj, swint.py:447-471
+        # x is the residual stream of the stage: fp32 with RESIDUAL_FP32 (the LayerNorm kernel reads / writes it in fp32 and
+        # hands fp16 to the GEMMs), fp16 otherwise
+        x = _ln(P, p + ".patch_embed.norm", x, want_y=not r32, want_y32=r32)
     outs = []
     for i, (depth, heads) in enumerate(zip(M.DEPTHS, M.NUM_HEADS)):
         C = x.shape[-1]
         fused = P["_swin_fused_mlp"] and C in P["_swin_fused_widths"] and x.dtype == torch.float32
         pend = None                                    # MLP output whose residual add is fused into the next LayerNorm
         h1 = None                                      # norm1 of the current block when the previous fused MLP produced it
+        if i == 0 and h1_first is not None:
+            h1 = h1_first                              # ... or the patch-embedding kernel, for the very first block
         for j in range(depth):
             b = f"{p}.layers.{i}.blocks.{j}"
             shift = 0 if j % 2 == 0 else ws // 2

@@ -19,6 +19,7 @@ _SIGNATURES = {
     "mq_attn_workspace_bytes": (_l, [_i, _i, _i, _i, _i]),
     "mq_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _vp, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _i, _vp]),
     "mq_attn_resident_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _vp]),
+    "mq_patch_embed_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mq_attn_text_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _i, _vp]),
     "mq_attn_chunked_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _i, _vp]),
     "mq_window_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -61,7 +62,7 @@ _SIGNATURES = {
     "mq_ml_nms": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
 }
 # entry points with 16-bit operands also exist as <name>_bf16 (same signature; include/mqdet_hip.h MQ_BF16_TWIN)
-BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_text_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_window_attn_qkv_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
+BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_text_fwd", "mq_patch_embed_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_window_attn_qkv_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
               "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_patch_merge_ln_fwd", "mq_swin_mlp_fwd", "mq_swin_mlp2_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
               "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyrelu_apply", "mq_dyrelu_ln_fwd", "mq_add_upsample_nearest",
               "mq_align_scores_fwd", "mq_align_fused_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
@@ -91,6 +92,8 @@ KERNEL_DEFAULTS = {
     "DYRELU_IN_LN": 1,           # 1: the DYReLU of fusion layers 0 .. L-2 is applied by the next layer's LayerNorm (mq_dyrelu_ln_fwd); 0: own pass
     "VLFUSE_I2T_VARIANT": 0,     # mq_vlfuse_i2t_fwd: 0 = Q fragments in registers where they fit (129 .. 160 keys: 0.428 -> 0.370 ms per launch),
                                  # 1 = Q tile in LDS for every caption longer than 128 tokens
+    "PATCH_EMBED_FUSED": 1,      # 1: mq_patch_embed_fwd (Swin PatchEmbed projection + patch_embed.norm + the first norm1 in one pass over the pixels);
+                                 # 0: permute copies + library GEMM (K = 48) + two LayerNorm launches (354 us at B = 8)
     "BERT_QKV_FUSED": 1,         # 1: BERT layers = ONE qkv GEMM + mq_attn_text_fwd (V row-major, transposed out of LDS; registers / LDS sized by the
                                  # caption length); 0: q|k GEMM + V^T batched GEMM + mq_attn_resident_fwd (rounds 2-3)
     "POST_FUSED": 1,             # 1: ATSS post-processing as mq_post_select_fwd + mq_post_sort_fwd + mq_ml_nms_topk + mq_post_finalize_fwd (4 launches);
@@ -227,6 +230,38 @@ def _need_gpu(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
             raise RuntimeError("mq_det_amd ops need GPU tensors: the hot path has no CPU fallback")
+
+
+def patch_embed_pack(w, nchw=False):
+    """PatchEmbed.proj weight [C, 3, 4, 4] (any float type) -> [C, 64] in the k order of mq_patch_embed_fwd: the 48 inputs of a patch as 12
+    chunks of 4 values at k-slots 4 c .. 4 c + 3, k 48 .. 63 zero.  Channels-last pixels (nchw False): chunk c = image row c // 3, values
+    4 (c % 3) .. of the row's 12 (px, channel) pairs.  fp32 NCHW pixels (nchw True): chunk c = (channel c // 4, image row c % 4), 4 pixels."""
+    C = w.shape[0]
+    out = w.new_zeros(C, 64)
+    out[:, :48] = w.reshape(C, 48) if nchw else w.permute(0, 2, 3, 1).reshape(C, 48)
+    return out.contiguous()
+
+
+def patch_embed(img, wpk, bias, g0, b0, g1, b1, eps=1e-5):
+    """img: [B,Hi,Wi,3] 16-bit contiguous (channels-last pixels, wpk packed with nchw=False) or [B,3,Hi,Wi] fp32 contiguous (wpk packed with
+    nchw=True) -> (x32 [B,Hi/4*Wi/4,C] fp32 = LN_0(proj(patches)), h1 16-bit = LN_1(x32)); mq_patch_embed_fwd."""
+    lib = load_library()
+    _need_gpu(img, wpk, bias, g0, b0, g1, b1)
+    f32 = img.dtype == torch.float32
+    if f32:
+        B, Cin, Hi, Wi = img.shape
+    else:
+        B, Hi, Wi, Cin = img.shape
+    C = wpk.shape[0]
+    assert Cin == 3 and img.is_contiguous() and (f32 or img.dtype == wpk.dtype) and wpk.dtype in _H16 and wpk.shape == (C, 64) and wpk.is_contiguous()
+    assert all(t.dtype == torch.float32 and t.is_contiguous() and t.numel() == C for t in (bias, g0, b0, g1, b1))
+    n = (Hi // 4) * (Wi // 4)
+    x32 = torch.empty(B, n, C, dtype=torch.float32, device=img.device)
+    h1 = torch.empty(B, n, C, dtype=wpk.dtype, device=img.device)
+    with _timed(f"patch_embed_c{C}", img.numel() * img.element_size() + x32.numel() * 4 + h1.numel() * 2):
+        _chk(_fn(lib, "mq_patch_embed_fwd", wpk)(_ptr(img), int(f32), _ptr(wpk), _ptr(bias), _ptr(g0), _ptr(b0), _ptr(g1), _ptr(b1), _ptr(x32), _ptr(h1),
+                                                 B, Hi, Wi, C, float(eps), _stream()), "mq_patch_embed_fwd")
+    return x32, h1
 
 
 def attention_text(qkv, heads, key_bias=None, clamp=0.0, kv_len=None, max_kv=0, scale=None):

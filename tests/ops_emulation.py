@@ -31,6 +31,19 @@ def attention(q, k, vt, num_heads, head_dim, key_bias=None, scale=None, clamp=0.
     return (s.softmax(-1) @ vh).transpose(1, 2).reshape(B, Nq, HD).to(q.dtype)
 
 
+def patch_embed(img, wpk, bias, g0, b0, g1, b1, eps=1e-5):
+    C = wpk.shape[0]
+    if img.dtype == torch.float32:                         # [B, 3, Hi, Wi] fp32, rounded to the operand type; k = (channel, py, px)
+        x = img.to(wpk.dtype).float()
+        w4 = wpk.float()[:, :48].reshape(C, 3, 4, 4)
+    else:                                                  # [B, Hi, Wi, 3] 16-bit; k = (py, px, channel)
+        x = img.float().permute(0, 3, 1, 2)
+        w4 = wpk.float()[:, :48].reshape(C, 4, 4, 3).permute(0, 3, 1, 2)
+    y = F.conv2d(x, w4, bias, stride=4).flatten(2).transpose(1, 2)
+    x32 = F.layer_norm(y, (C,), g0, b0, eps)
+    return x32, F.layer_norm(x32, (C,), g1, b1, eps).to(wpk.dtype)
+
+
 def attention_text(qkv, heads, key_bias=None, clamp=0.0, kv_len=None, max_kv=0, scale=None):
     B, T, C3 = qkv.shape
     HD = C3 // 3
@@ -565,7 +578,7 @@ def dyconv_coef_group(items, attn_w, attn_b, groups, eps):
 
 # ---------------------------------------------------------------------------------------------------------------------------------
 # every emulated entry point, in one place: tests patch them into mq_det_amd.ops (or into a stand-in namespace) with these helpers
-NAMES = ("attention", "attention4", "attention_text", "window_attention", "window_attention_qkv", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores", "align_fused",
+NAMES = ("attention", "attention4", "attention_text", "patch_embed", "window_attention", "window_attention_qkv", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores", "align_fused",
          "dyconv_branch_coef", "dyconv_coef_group", "dyconv_fuse", "dyrelu_", "dyrelu_coef", "dyrelu_apply_", "dyrelu_layer_norm", "add_upsample_nearest_", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "vlfuse_i2t",
          "vlfuse_t2i", "box_decode", "ml_nms", "post_select", "post_sort", "post_finalize", "roi_align", "swin_mlp", "swin_mlp2", "patch_merge_ln", "ms_deform_attn", "ms_deform_attn_q", "image_key_mask")
 
@@ -583,7 +596,7 @@ def namespace(real_ops):
     import types
     g = globals()
     fake = types.SimpleNamespace(**{n: g[n] for n in NAMES})
-    for n in ("SWIN_MLP_WIDTHS", "WINDOW_QKV_WIDTHS", "window_qkv_fused", "SCORE_AGG", "window_pad", "pad_rel_bias", "swin_mlp_w2_perm", "swin_mlp2_pack", "timing_active"):
+    for n in ("patch_embed_pack", "SWIN_MLP_WIDTHS", "WINDOW_QKV_WIDTHS", "window_qkv_fused", "SCORE_AGG", "window_pad", "pad_rel_bias", "swin_mlp_w2_perm", "swin_mlp2_pack", "timing_active"):
         setattr(fake, n, getattr(real_ops, n))
     fake.KERNELS = dict(real_ops.KERNEL_DEFAULTS)       # the default kernel selection: the glue of the promoted variants is what runs
     return fake

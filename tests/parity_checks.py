@@ -125,6 +125,31 @@ def check_attention_strided(dev):
     return _stat("attn strided q|k views (BERT)", out, ref)
 
 
+def check_patch_embed(dev):
+    """mq_patch_embed_fwd (csrc/patch_embed.hip): Swin PatchEmbed projection + patch_embed.norm + the first norm1 vs F.conv2d + two
+    F.layer_norm on the same 16-bit-rounded pixels / weights; C = 96 and 192, widths that are / are not multiples of 16 patches."""
+    from mq_det_amd import ops
+    res = []
+    g = torch.Generator().manual_seed(29)
+    for (B, Hi, Wi, C) in ((2, 32, 64, 96), (1, 20, 76, 96), (2, 16, 132, 192)) + (() if QUICK else ((8, 800, 1344, 96),)):
+        img = torch.randn(B, 3, Hi, Wi, generator=g).to(H16)
+        w = (torch.randn(C, 3, 4, 4, generator=g) * 0.2).to(H16)
+        bias, g0, b0, g1, b1 = [torch.randn(C, generator=g) * s_ + o_ for s_, o_ in ((0.1, 0), (0.2, 1), (0.1, 0), (0.2, 1), (0.1, 0))]
+        y = F.conv2d(img.float(), w.float(), bias, stride=4).flatten(2).transpose(1, 2)
+        x_ref = F.layer_norm(y, (C,), g0, b0, 1e-5)
+        h_ref = F.layer_norm(x_ref, (C,), g1, b1, 1e-5)
+        nhwc = img.to(dev).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        x32, h1 = ops.patch_embed(nhwc, ops.patch_embed_pack(w.float()).to(H16).to(dev), *[t.to(dev) for t in (bias, g0, b0, g1, b1)])
+        res.append(_stat(f"patch_embed B={B} {Hi}x{Wi} C={C}: fp32 stream LN_0(proj)", x32, x_ref, tol=1e-3))
+        res.append(_stat(f"patch_embed B={B} {Hi}x{Wi} C={C}: norm1 output", h1, h_ref, tol=2e-3))
+        # the caller's fp32 NCHW pixels, rounded in the kernel: the same numbers (the values above are 16-bit-representable already)
+        x32b, h1b = ops.patch_embed(img.float().to(dev).contiguous(), ops.patch_embed_pack(w.float(), nchw=True).to(H16).to(dev),
+                                    *[t.to(dev) for t in (bias, g0, b0, g1, b1)])
+        res.append(_stat(f"patch_embed B={B} {Hi}x{Wi} C={C}: fp32 NCHW pixels == channels-last 16-bit pixels (stream)", x32b, x32.float().cpu(), tol=2e-6))
+        res.append(_stat(f"patch_embed B={B} {Hi}x{Wi} C={C}: fp32 NCHW pixels == channels-last 16-bit pixels (norm1: one 16-bit ulp, other k order)", h1b, h1.float().cpu(), tol=1e-3))
+    return res
+
+
 def check_attention_text(dev):
     """mq_attn_text_fwd (csrc/attn_text.hip): q | k | v slices of ONE [B, T, 3 H D] projection, V row-major and transposed out of LDS, the
     register / LDS variant picked by the host bound max_kv.  Caption lengths on both sides of the 160-key variant switch and of 16-key

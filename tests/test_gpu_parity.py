@@ -58,7 +58,7 @@ def test_attention_strided_views(dev):
 @pytest.mark.parametrize("name", ["check_window_attention", "check_swin_fpn", "check_gcp_block", "check_pre_select",
                                   "check_vlfuse_kernels", "check_vl_fuse", "check_dcn", "check_conv3x3", "check_layernorm", "check_dyconv", "check_nms", "check_full_model",
                                   "check_ref_pins", "check_post_golden", "check_roi_align", "check_extract_query", "check_swin_mlp", "check_msdeform_attn",
-                                  "check_align_fused", "check_fusion_layer", "check_post_fused", "check_attention_text"])
+                                  "check_align_fused", "check_fusion_layer", "check_post_fused", "check_attention_text", "check_patch_embed"])
 def test_block(dev, name):
     import parity_checks as pc
     _assert(getattr(pc, name)(dev))
