@@ -373,18 +373,23 @@ int mq_attn_text_fwd(const void* q, const void* k, const void* v, void* o, const
  * select_over_all_levels :757-766 (kthvalue + `>=` keeps ties with the K-th score) -- ~145 torch launches in one dependent chain.
  *
  * mq_post_select_fwd: per (image, level) the k[l] best candidates of the score map (value > 0 = candidate; exact radix select over the
- *   fp32 bit patterns, ties at the cut by the smaller flat index), decoded into the image's candidate list.
+ *   fp32 bit patterns, ties at the cut by the smaller flat index), decoded into the image's candidate list.  Two launches: the levels are
+ *   cut into slices of 32768 scores whose k best go to a scratch list each, then one workgroup per (image, level) selects among them.
  *   ranked / reg / anchors: HOST arrays of NL device pointers -- level l: scores [B, hw[l], L] fp32, box deltas [B, hw[l], 4] fp32,
- *   anchors [hw[l], 4] fp32; hw / k: HOST int arrays (locations; candidates kept, 1 <= k[l] <= hw[l] * L < 2^22); label_ids [L] int32
- *   (lab_bs 0) or [B, L] (lab_bs L); im_wh [B, 2] fp32 (w, h).  Outputs (tot = sum k): boxes [B, tot, 4], scores [B, tot] (-1 = empty
- *   slot), labels [B, tot], ids [B, tot] int32 (candidate id = level base + flat index: the tie-break key of the sort); level l owns
- *   slots [sum k[:l], sum k[:l + 1]), in arbitrary order inside them.  -1: NL > 8 or a size out of range. */
+ *   anchors [hw[l], 4] fp32; hw / k: HOST int arrays (locations; candidates kept, 1 <= k[l] <= min(2048, hw[l] * L), hw[l] * L < 2^22);
+ *   label_ids [L] int32 (lab_bs 0) or [B, L] (lab_bs L); im_wh [B, 2] fp32 (w, h); workspace: mq_post_select_workspace_bytes(...) bytes.
+ *   Outputs (tot = sum k): boxes [B, tot, 4], scores [B, tot] (-1 = empty slot), labels [B, tot], ids [B, tot] int32 (candidate id = level
+ *   base + flat index); level l owns slots [sum k[:l], sum k[:l + 1]), sorted by (score descending, flat index ascending), empty slots
+ *   last.  -1: NL > 8 or a size out of range (mq_post_select_workspace_bytes returns -1 for the same inputs). */
+long mq_post_select_workspace_bytes(const int* hw, const int* k, int NL, int B, int L);
 int mq_post_select_fwd(const float* const* ranked, const float* const* reg, const float* const* anchors, const int* hw, const int* k,
-                       int NL, int B, int L, const int* label_ids, long lab_bs, const float* im_wh, float* boxes, float* scores,
-                       int* labels, int* ids, void* stream);
-/* mq_post_sort_fwd: the candidate list of every image ordered by (score descending, id ascending), empty slots last -- the order
- *   ml_nms sweeps in (ml_nms.cu:100-104 sorts by score) -- + nvalid [B] = live rows.  tot <= 8192 (-1 beyond). */
-int mq_post_sort_fwd(const float* boxes, const float* scores, const int* labels, const int* ids, float* boxes_o, float* scores_o,
+                       int NL, int B, int L, const int* label_ids, long lab_bs, const float* im_wh, void* workspace, float* boxes,
+                       float* scores, int* labels, int* ids, void* stream);
+/* mq_post_sort_fwd: the NL per-level lists of every image (list l = slots [off[l], off[l + 1]), HOST ints, off[NL] = tot; each sorted by
+ *   score descending with its empty slots last, as mq_post_select_fwd writes them) merged into ONE list ordered by (score descending,
+ *   level ascending, position ascending), empty slots last -- the order ml_nms sweeps in (ml_nms.cu:100-104 sorts by score) -- + nvalid [B]
+ *   = live rows.  tot <= 16384, NL <= 8 (-1 beyond). */
+int mq_post_sort_fwd(const float* boxes, const float* scores, const int* labels, const int* off, int NL, float* boxes_o, float* scores_o,
                      int* labels_o, int* nvalid, int B, int tot, void* stream);
 /* mq_post_finalize_fwd: rows score-sorted, keep [B, tot] uint8 from mq_ml_nms_topk(max_keep = K2) -> out [B, K2, 6] fp32 rows
  *   (x1, y1, x2, y2, score, label): the first K kept rows + the kept rows tied with the K-th score (inference.py:757-766), unused rows

@@ -902,9 +902,9 @@ def postprocess(cfg, head, anchors, im_wh, tokidx, label_ids, want_cls=False, le
     Kd = int(A.DETECTIONS_PER_IMG)
     K = min(Kd, tot) if Kd > 0 else tot
     K2 = min(K + int(A.get("TIE_SLOTS", TIE_SLOTS)), tot) if Kd > 0 else tot
-    if ops.KERNELS["POST_FUSED"] == 1 and tot <= 8192 and (Kd <= 0 or tot <= 6656) and all(hw * L < (1 << 22) for hw in hws) \
-            and all(a.shape[0] == hw for a, hw in zip(anchors, hws)):
-        # ---- four launches (csrc/post2.hip): exact per-level select + decode, sort, NMS, final selection with the tie rule
+    if ops.KERNELS["POST_FUSED"] == 1 and tot <= 16384 and (Kd <= 0 or tot <= 6656) and all(a.shape[0] == hw for a, hw in zip(anchors, hws)) \
+            and ops.post_select_supported(hws, ks, Bn, L):
+        # ---- csrc/post2.hip: exact per-level select + decode (slices, then levels), merge of the sorted level lists, NMS, final selection
         if fused is not None:
             ranked_l, reg_l = fused["ranked"], fused["reg"]
             cls_all = fused["cls"] if want_cls else None
@@ -921,7 +921,7 @@ def postprocess(cfg, head, anchors, im_wh, tokidx, label_ids, want_cls=False, le
         lab32 = label_ids if label_ids.dtype == torch.int32 else label_ids.to(torch.int32)
         wh32 = im_wh if (im_wh.dtype == torch.float32 and im_wh.is_contiguous()) else im_wh.float().contiguous()
         ub, us, ul, uid = ops.post_select(ranked_l, reg_l, [a.contiguous() for a in anchors], ks, lab32.contiguous(), wh32)
-        boxes, scores, labels, nvalid = ops.post_sort(ub, us, ul, uid)
+        boxes, scores, labels, nvalid = ops.post_sort(ub, us, ul, ks)
         keep8 = ops.ml_nms(boxes, labels, nvalid, A.NMS_TH, max_keep=K2 if Kd > 0 else 0, as_bool=False)
         packed, cnt = ops.post_finalize(boxes, scores, labels, keep8, K, K2)
         out = {"boxes": packed[..., :4], "scores": packed[..., 4], "labels": packed[..., 5].to(torch.int64), "counts": cnt & 0xFFFF,

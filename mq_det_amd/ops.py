@@ -13,7 +13,7 @@ _LIB = None
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmqdet_hip.so")
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
-EXPECTED_ABI = 21        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
+EXPECTED_ABI = 22        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
 _SIGNATURES = {
     "mq_abi_version": (_i, []),
     "mq_attn_workspace_bytes": (_l, [_i, _i, _i, _i, _i]),
@@ -54,8 +54,9 @@ _SIGNATURES = {
     "mq_roi_align_fwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _f, _i, _i, _i, _vp]),
     "mq_msdeform_attn_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_msdeform_attn_q_fwd": (_i, [_vp, _i, _l, _l, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "mq_post_select_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "mq_post_sort_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "mq_post_select_workspace_bytes": (_l, [_vp, _vp, _i, _i, _i]),
+    "mq_post_select_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mq_post_sort_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mq_post_finalize_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mq_ml_nms_workspace_bytes": (_l, [_i, _i]),
     "mq_ml_nms_topk": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
@@ -958,10 +959,20 @@ def align_fused(tok, tk, tbias, wbc, bbc, scales, tokidx, sizes, thr, agg=0, kv_
     return out
 
 
+def post_select_supported(hws, ks, B, L):
+    """Can mq_post_select_fwd take these level sizes?  (host-side query of its slicing plan; no device work)"""
+    NL = len(hws)
+    if NL < 1 or NL > 8:
+        return False
+    hw = (ctypes.c_int * NL)(*[int(h) for h in hws])
+    kk = (ctypes.c_int * NL)(*[int(k) for k in ks])
+    return load_library().mq_post_select_workspace_bytes(ctypes.cast(hw, _vp), ctypes.cast(kk, _vp), NL, int(B), int(L)) >= 0
+
+
 def post_select(ranked, reg, anchors, ks, label_ids, im_wh):
     """Per (image, level) the ks[l] best candidates (value > 0) of ranked[l] [B,HW_l,L] fp32, decoded with reg[l] [B,HW_l,4] fp32 and
     anchors[l] [HW_l,4] (mq_post_select_fwd).  -> boxes [B,tot,4], scores [B,tot] (-1 = empty slot), labels, ids [B,tot] int32; level l owns
-    the slots [sum ks[:l], sum ks[:l+1]) in arbitrary order."""
+    the slots [sum ks[:l], sum ks[:l+1]), sorted by (score desc, flat index asc), empty slots last."""
     lib = load_library()
     NL = len(ranked)
     B, _, L = ranked[0].shape
@@ -979,23 +990,34 @@ def post_select(ranked, reg, anchors, ks, label_ids, im_wh):
     pp = lambda ts: (ctypes.c_void_p * NL)(*[t.data_ptr() for t in ts])      # noqa: E731  host arrays of device pointers
     hw = (ctypes.c_int * NL)(*[int(r.shape[1]) for r in ranked])
     kk = (ctypes.c_int * NL)(*[int(k) for k in ks])
+    wsb = lib.mq_post_select_workspace_bytes(ctypes.cast(hw, _vp), ctypes.cast(kk, _vp), NL, B, L)
+    if wsb < 0:
+        raise RuntimeError("mq_post_select_fwd: level sizes out of range (ops.post_select_supported)")
+    ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=dev)
     with _timed("post_select", sum(r.numel() for r in ranked) * 4):
         _chk(lib.mq_post_select_fwd(ctypes.cast(pp(ranked), _vp), ctypes.cast(pp(reg), _vp), ctypes.cast(pp(anchors), _vp), ctypes.cast(hw, _vp),
-                                    ctypes.cast(kk, _vp), NL, B, L, _ptr(label_ids), L if label_ids.dim() == 2 else 0, _ptr(im_wh), _ptr(boxes),
+                                    ctypes.cast(kk, _vp), NL, B, L, _ptr(label_ids), L if label_ids.dim() == 2 else 0, _ptr(im_wh), _ptr(ws), _ptr(boxes),
                                     _ptr(scores), _ptr(labels), _ptr(ids), _stream()), "mq_post_select_fwd")
     return boxes, scores, labels, ids
 
 
-def post_sort(boxes, scores, labels, ids):
-    """Candidate lists [B,tot,...] -> ordered by (score desc, id asc), empty slots last, + nvalid [B] int32 (mq_post_sort_fwd)."""
+def post_sort(boxes, scores, labels, ks):
+    """Per-level candidate lists [B,tot,...] (list l = ks[l] slots, each sorted by score, as post_select writes them) -> ONE list per image
+    ordered by (score desc, level asc, position asc), empty slots last, + nvalid [B] int32 (mq_post_sort_fwd)."""
     lib = load_library()
-    _need_gpu(boxes, scores, labels, ids)
+    _need_gpu(boxes, scores, labels)
     B, tot = scores.shape
+    NL = len(ks)
+    offs = [0]
+    for k in ks:
+        offs.append(offs[-1] + int(k))
+    assert offs[-1] == tot
+    off = (ctypes.c_int * (NL + 1))(*offs)
     bo, so, lo = torch.empty_like(boxes), torch.empty_like(scores), torch.empty_like(labels)
     nvalid = torch.empty(B, dtype=torch.int32, device=scores.device)
     with _timed("post_sort"):
-        _chk(lib.mq_post_sort_fwd(_ptr(boxes), _ptr(scores), _ptr(labels), _ptr(ids), _ptr(bo), _ptr(so), _ptr(lo), _ptr(nvalid), B, tot, _stream()),
-             "mq_post_sort_fwd")
+        _chk(lib.mq_post_sort_fwd(_ptr(boxes), _ptr(scores), _ptr(labels), ctypes.cast(off, _vp), NL, _ptr(bo), _ptr(so), _ptr(lo), _ptr(nvalid), B, tot,
+                                  _stream()), "mq_post_sort_fwd")
     return bo, so, lo, nvalid
 
 

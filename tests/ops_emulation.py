@@ -253,13 +253,14 @@ def post_select(ranked, reg, anchors, ks, label_ids, im_wh):
     return boxes, scores, labels, ids
 
 
-def post_sort(boxes, scores, labels, ids):
+def post_select_supported(hws, ks, B, L):
+    return len(hws) <= 8 and all(h * L < (1 << 22) and k <= 2048 for h, k in zip(hws, ks)) and sum(-(-h * L // 32768) for h in hws) <= 64
+
+
+def post_sort(boxes, scores, labels, ks):
+    """Merge of the per-level sorted lists: (score desc, level asc, position asc) = a STABLE descending sort of the concatenated lists."""
     key = torch.where(scores > 0, scores, torch.full_like(scores, -1.0))
-    # (score desc, id asc): sort by id first, then a stable sort by score
-    o1 = torch.argsort(ids, dim=1, stable=True)
-    o2 = torch.argsort(torch.gather(key, 1, o1), dim=1, descending=True, stable=True)
-    order = torch.gather(o1, 1, o2)
-    so = torch.gather(key, 1, order)
+    so, order = torch.sort(key, dim=1, descending=True, stable=True)
     live = so > 0
     bo = torch.where(live[..., None], torch.gather(boxes, 1, order[..., None].expand(-1, -1, 4)), torch.zeros_like(boxes))
     lo = torch.where(live, torch.gather(labels, 1, order), torch.zeros_like(labels))
@@ -580,7 +581,7 @@ def dyconv_coef_group(items, attn_w, attn_b, groups, eps):
 # every emulated entry point, in one place: tests patch them into mq_det_amd.ops (or into a stand-in namespace) with these helpers
 NAMES = ("attention", "attention4", "attention_text", "patch_embed", "window_attention", "window_attention_qkv", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores", "align_fused",
          "dyconv_branch_coef", "dyconv_coef_group", "dyconv_fuse", "dyrelu_", "dyrelu_coef", "dyrelu_apply_", "dyrelu_layer_norm", "add_upsample_nearest_", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "vlfuse_i2t",
-         "vlfuse_t2i", "box_decode", "ml_nms", "post_select", "post_sort", "post_finalize", "roi_align", "swin_mlp", "swin_mlp2", "patch_merge_ln", "ms_deform_attn", "ms_deform_attn_q", "image_key_mask")
+         "vlfuse_t2i", "box_decode", "ml_nms", "post_select", "post_select_supported", "post_sort", "post_finalize", "roi_align", "swin_mlp", "swin_mlp2", "patch_merge_ln", "ms_deform_attn", "ms_deform_attn_q", "image_key_mask")
 
 
 def patch_into(monkeypatch, ops_module):

@@ -545,6 +545,7 @@ def check_post_fused(dev):
     cases = [("sparse", (2, [(9, 13), (5, 6), (3, 3)], 7, 40, 0.02, None)), ("dense", (2, [(20, 31), (9, 11)], 5, 300, 0.9, None)),
              ("dense, 5 score values", (2, [(20, 31), (10, 16)], 5, 120, 0.8, 5)), ("one value everywhere", (1, [(12, 17)], 3, 50, 1.0, 1)),
              ("no candidate", (2, [(6, 7), (2, 3)], 4, 30, 0.0, None)), ("k = everything", (1, [(4, 5)], 3, 60, 0.5, None)),
+             ("two slices, ties across them", (1, [(60, 70), (9, 9)], 10, 300, 0.5, 64)), ("k = 1500", (1, [(50, 60)], 8, 1500, 0.9, None)),
              ("P3-sized level", (1, [(100, 168)], 40, 1000, 0.3, 4096))]
     if QUICK:
         cases = cases[:-1] + [("large level", (1, [(40, 56)], 10, 1000, 0.3, 512))]
@@ -566,21 +567,13 @@ def check_post_fused(dev):
         eb, es, el, ei = emu.post_select(ranked, reg, anchors, ks, label_ids.long(), im_wh)
         gb, gs, gl, gi = [t.cpu() for t in ops.post_select([t.to(dev) for t in ranked], [t.to(dev) for t in reg], [t.to(dev) for t in anchors], ks,
                                                            label_ids.to(dev), im_wh.to(dev))]
-        off = 0
-        same = True
-        for k in ks:                                        # a level's slots hold the same candidates, in any order: compare by id
-            for b in range(B):
-                oe, og = torch.argsort(ei[b, off:off + k], stable=True), torch.argsort(gi[b, off:off + k], stable=True)
-                same &= torch.equal(ei[b, off:off + k][oe], gi[b, off:off + k][og])
-                same &= bool((es[b, off:off + k][oe] - gs[b, off:off + k][og]).abs().max() <= 1.5e-7)     # sqrtf vs torch.sqrt: one ulp
-                same &= torch.equal(el[b, off:off + k][oe].int(), gl[b, off:off + k][og].int())
-                same &= bool((eb[b, off:off + k][oe] - gb[b, off:off + k][og]).abs().max() <= 1e-4)
-            off += k
-        res.append(_flag(f"post_select [{name}] B={B} levels={shapes} L={L} k={ks}: same candidates per level as sort + top-k", same))
-        sb, ss, sl, sn = emu.post_sort(gb, gs, gl, gi)       # the SAME unsorted lists into both sorts: everything behind is exact
-        hb, hs, hl, hn = [t.cpu() for t in ops.post_sort(gb.to(dev), gs.to(dev), gl.to(dev), gi.to(dev))]
+        # every level's slots: the same candidates in the same order -- (value desc, flat index asc) = a stable descending sort
+        same = torch.equal(ei, gi) and torch.equal(el.int(), gl.int()) and bool((es - gs).abs().max() <= 1.5e-7) and bool((eb - gb).abs().max() <= 1e-4)
+        res.append(_flag(f"post_select [{name}] B={B} levels={shapes} L={L} k={ks}: the sorted top-k of every level, decoded", same))
+        sb, ss, sl, sn = emu.post_sort(gb, gs, gl, ks)        # the SAME lists into both merges: everything behind is exact
+        hb, hs, hl, hn = [t.cpu() for t in ops.post_sort(gb.to(dev), gs.to(dev), gl.to(dev), ks)]
         ok = torch.equal(ss, hs) and torch.equal(sl.int(), hl.int()) and torch.equal(sn.int(), hn.int()) and bool((sb - hb).abs().max() <= 1e-4)
-        res.append(_flag(f"post_sort [{name}] tot={sum(ks)}: (score desc, id asc) order, empty rows last, nvalid", ok))
+        res.append(_flag(f"post_sort [{name}] tot={sum(ks)}: merge of the level lists (score desc, level, position), empty rows last, nvalid", ok))
         tot = sum(ks)
         for K, extra in ((max(1, tot // 3), 4), (tot, 0), (1, 1)):
             K2 = min(K + extra, tot)
