@@ -430,7 +430,9 @@ def kernel_rooflines(kern, steps, Bn, n_tok, embed=96):
               ("dyconv_fuse_kernel (GroupNorm affine + up-sampling + scale attention + branch mean)", "dyconv_fuse"),
               ("dyrelu_apply_kernel", "dyrelu_apply"), ("conv3x3_small_kernel (27-channel DyConv offset conv)", "conv3x3_small"),
               ("align_scores_kernel (sigmoid + token->class mean + threshold)", "align_scores"),
-              ("align_fused_kernel (box / centerness heads + dot-product alignment + sigmoid + class aggregation + threshold, all levels)", "align_fused"))
+              ("align_fused_kernel (box / centerness heads + dot-product alignment + sigmoid + class aggregation + threshold, all levels)", "align_fused"),
+              ("patch_embed_kernel (Swin PatchEmbed projection + patch_embed.norm + first norm1, fp32 NCHW pixels in)", "patch_embed_c"),
+              ("post_select_kernel (exact top-1000 per level: radix select over the score maps, slices then levels, + box decode)", "post_select"))
     for name, prefix in groups:
         sel = [v for k, v in per.items() if k.startswith(prefix)]
         if sel:
@@ -517,9 +519,9 @@ def _sub_bench(argv, env=None, timeout=150, keep=()):
         return {"error": f"worker exceeded {timeout} s"}
 
 
-# every operator with two implementations on the one that was the default at the end of round 2 (ops.KERNEL_DEFAULTS lists today's)
-ROUND2_KERNEL_SET = {"MQ_LN_VARIANT": "1", "MQ_OFFSET_CONV_VARIANT": "1", "MQ_PATCH_MERGE_FUSED": "0", "MQ_FPN_VIA_DCN": "0", "MQ_NMS_EARLY_STOP": "0",
-                     "MQ_ATTN_RESIDENT": "0", "MQ_SWIN_MLP_VARIANT": "1", "MQ_ALIGN_FUSED": "0", "MQ_DYRELU_IN_LN": "0", "MQ_VLFUSE_I2T_VARIANT": "1", "MQ_SWIN_QKV_FUSED": "0", "MQ_FPN_TOPDOWN_FUSED": "0", "MQ_DCN_SYNC": "2"}
+# every operator with two implementations on the one that was the default at the end of ROUND 3 (ops.KERNEL_DEFAULTS lists today's), and the
+# runtime default of the hardware queues: what round 4's switchable changes buy (not switchable, so inside both runs: the VLFuse softmax diet)
+ROUND3_KERNEL_SET = {"MQ_POST_FUSED": "0", "MQ_BERT_QKV_FUSED": "0", "MQ_PATCH_EMBED_FUSED": "0", "GPU_MAX_HW_QUEUES": "4"}
 
 
 def _free_port():
@@ -769,13 +771,13 @@ def main():
                     res["lang_path_b64"] = lang_path_b64(model, cfg, dev, chunks)
                 except Exception as e:  # noqa: BLE001
                     res["lang_path_b64"] = {"error": repr(e)[:300]}
-            if world == 1 and not args.no_experimental and not large and args.dtype == "f16" and not any(k in os.environ for k in ROUND2_KERNEL_SET):
+            if world == 1 and not args.no_experimental and not large and args.dtype == "f16" and not any(k in os.environ for k in ROUND3_KERNEL_SET if k.startswith("MQ_")):
                 # bounded subprocess lines, most informative first; each only while the whole run stays within a few minutes
                 if time.perf_counter() - t_start < 120:
-                    res["kernel_set_ab"] = {"round2_kernel_set": _sub_bench(["--steps", "10", "--warmup", "3"], ROUND2_KERNEL_SET, 120),
-                                            "env_of_the_round2_set": ROUND2_KERNEL_SET,
-                                            "note": "A/B against `value` of this line: same box, same workload, every two-way operator on its "
-                                                    "round-2 implementation (per-switch A/Bs: profiles/r03_call1_switch_ab.txt)"}
+                    res["kernel_set_ab"] = {"round3_kernel_set": _sub_bench(["--steps", "10", "--warmup", "3"], ROUND3_KERNEL_SET, 120),
+                                            "env_of_the_round3_set": ROUND3_KERNEL_SET,
+                                            "note": "A/B against `value` of this line: same box, same workload, the operators that got a second "
+                                                    "implementation in round 4 on their round-3 one + 4 hardware queues (per-switch A/Bs: profiles/r04_*_ab.txt)"}
                 other = {}
                 for key, argv, limit in (("configs[3] mq-glip-l bf16 B=4", ["--workload", "mq-glip-l", "--dtype", "bf16", "--steps", "5", "--warmup", "2"], 160),
                                          ("configs[4] mq-gdino-t B=16", ["--workload", "mq-gdino-t", "--steps", "5", "--warmup", "2"], 200),

@@ -230,17 +230,21 @@ def _nsplit(n_blocks, n_key_tiles, target=None):
     return max(1, min(n_key_tiles // 4, -(-target // n_blocks), 32))
 
 
-def _nsplit_t2i(n_img, heads, t_live, n_key_tiles, cus=256):
+def _nsplit_t2i(n_img, heads, t_live, n_key_tiles, cus_per_xcd=32):
     """Key split of the VLFuse text side.  A group (image, split) is ceil(heads * ceil(t_live / 16) / 8) workgroups, each streaming
-    ceil(tiles / nsplit) key tiles; one workgroup per CU.  Cost model: passes of the chip x (tiles per workgroup + ~6 tile-times of fixed
-    work: Q load, partial write, its share of the merge) -- the split with the fewest tile-times wins (141-token caption, B = 8:
-    72 workgroups per split -> nsplit = 7: 504 workgroups = 2 passes of 50 tiles)."""
+    ceil(tiles / nsplit) key tiles; one workgroup per CU; group g runs on XCD g % 8 (its workgroups stream the same tiles out of that
+    XCD's L2).  Cost model: passes of an XCD's 32 CUs over the workgroups of ITS groups x (tiles per workgroup + ~6 tile-times of fixed
+    work: Q load, partial write, its share of the merge) -- the split with the fewest tile-times wins.  141-token caption, 9 workgroups
+    per group: B = 8 -> nsplit 7 (7 groups = 63 workgroups per XCD: 2 passes of 50 tiles); B = 4 -> nsplit 14 (the same 63 per XCD,
+    25 tiles each: 0.151 ms against 0.231 ms for nsplit 7, whose 4 groups = 36 workgroups per XCD are 2 badly filled passes -- GPU call 10
+    of round 4, profiles/r04_call10_t2i_sweep.json; round 3 counted passes of the whole chip and picked 7)."""
     if n_key_tiles < 8:
         return 1
-    wgs = n_img * (-(-(heads * (-(-t_live // 16))) // 8))
+    members = -(-(heads * (-(-t_live // 16))) // 8)
     best, best_cost = 1, None
     for ns in range(1, min(32, n_key_tiles // 4) + 1):
-        cost = (-(-(wgs * ns) // cus)) * (-(-n_key_tiles // ns) + 6)
+        per_xcd = -(-(n_img * ns) // 8) * members
+        cost = (-(-per_xcd // cus_per_xcd)) * (-(-n_key_tiles // ns) + 6)
         if best_cost is None or cost < best_cost:
             best, best_cost = ns, cost
     return best

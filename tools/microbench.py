@@ -51,6 +51,8 @@ def main():
     if only in ("", "vlfuse"):
         vlfuse(dev, g, out)
         vlfuse_text(dev, g, out)
+    if only == "t2i_sweep":
+        t2i_sweep(dev, g, out)
     for r in out:
         print(json.dumps(r))
     if len(sys.argv) > 1:
@@ -245,6 +247,21 @@ def vlfuse_text(dev, g, out):
             for abl in (1, 3, 4, 8, 11, 15):
                 ms = timeit(lambda: ops.vlfuse_t2i(kf, v, ns, kv_len=kv, max_kv=live, variant=100 + abl))
                 out.append({"kernel": f"vlfuse_t2i + combine, ablation bits {abl:04b} (mfma|softmax|commits|loads removed) nsplit={ns} live rows={live}", "ms": round(ms, 4)})
+
+
+def t2i_sweep(dev, g, out):
+    # ---- VLFuse text side: key split sweep at B = 4 (BASELINE configs[3]) and B = 8 -- what does the cost model of _nsplit_t2i miss?
+    from mq_det_amd.modeling.pipeline import _nsplit_t2i
+    N, T, live = 22400, 256, 141
+    for B in (4, 8):
+        v = torch.randn(B, N, 256, generator=g).half().to(dev)
+        kf = (torch.randn(B, 8, T, 256, generator=g) / 8).half().to(dev)
+        kv = torch.full((B,), live, dtype=torch.int32, device=dev)
+        chosen = _nsplit_t2i(B, 8, live, -(-N // 64))
+        for ns in sorted({chosen, 2, 3, 4, 5, 7, 10, 14, 20, 28}):
+            ms = timeit(lambda: ops.vlfuse_t2i(kf, v, ns, kv_len=kv, max_kv=live))
+            out.append({"kernel": f"vlfuse_t2i + combine B={B} nsplit={ns}{' (chosen)' if ns == chosen else ''}", "ms": round(ms, 4),
+                        "workgroups": B * ns * 9})
 
 
 def window_qkv(dev, g, out):
