@@ -396,8 +396,9 @@ __global__ __launch_bounds__(64 * NWT) void swin_mlp2_tail_kernel(SwinMlp2Params
   constexpr int RDT = 8;
   static_assert(NCHUNK % NWT == 0 && CT % NWT == 0, "tail split");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float4_* red = (float4_*)smem;                              // [NWT src][NWT tile of the phase][64 lanes]
-  float* stat = (float*)(red + NWT * NWT * 64);               // [2][NWT][16]: per-wave partial row sums / squared deviations
+  constexpr int NH = NWT / 2;                                 // destination waves per half phase
+  float4_* red = (float4_*)smem;                              // [NWT src][NH tiles of the half phase][64 lanes]
+  float* stat = (float*)(red + NWT * NH * 64);                // [2][NWT][16]: per-wave partial row sums / squared deviations
 
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -446,21 +447,29 @@ __global__ __launch_bounds__(64 * NWT) void swin_mlp2_tail_kernel(SwinMlp2Params
   });
 
   // ---- the partials of the NWT waves, summed in wave order; after phase ph wave w holds channel tile ph * NWT + w
+  // (two half phases of NWT / 2 destination waves each: the exchange buffer is 32 KB instead of 64 KB, so that a tail workgroup fits on
+  // a CU NEXT TO a workgroup of the main kernel -- 107 KB at C = 384 -- when the two run side by side on two streams; same summation order)
   float4_ fin[TPW];
 #pragma unroll
   for (int ph = 0; ph < TPW; ++ph) {
-    if (ph) __syncthreads();
 #pragma unroll
-    for (int d = 0; d < NWT; ++d) red[(wave * NWT + d) * 64 + lane] = acc2[ph * NWT + d];
-    __syncthreads();
-    float4_ a = red[wave * 64 + lane];
+    for (int hh = 0; hh < 2; ++hh) {
+      if (ph || hh) __syncthreads();
 #pragma unroll
-    for (int src = 1; src < NWT; ++src) {
-      const float4_ b = red[(src * NWT + wave) * 64 + lane];
+      for (int d = 0; d < NH; ++d) red[(wave * NH + d) * 64 + lane] = acc2[ph * NWT + hh * NH + d];
+      __syncthreads();
+      if (wave / NH == hh) {                                  // wave-uniform
+        const int wl = wave - hh * NH;
+        float4_ a = red[wl * 64 + lane];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) a[r] += b[r];
+        for (int src = 1; src < NWT; ++src) {
+          const float4_ b = red[(src * NH + wl) * 64 + lane];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[r] += b[r];
+        }
+        fin[ph] = a;
+      }
     }
-    fin[ph] = a;
   }
 
   // ---- epilogue: lane holds OUT^T[c = 16 (ph NWT + wave) + 4 g + r][token l15]
@@ -536,7 +545,7 @@ static int launch_swin_mlp2_main(const SwinMlp2Params& p, hipStream_t s) {
 
 template <int C, int NWT>
 static int launch_swin_mlp2_tail(const SwinMlp2Params& p, hipStream_t s) {
-  constexpr size_t smem = (size_t)NWT * NWT * 64 * sizeof(float4_) + (size_t)2 * NWT * 16 * sizeof(float);
+  constexpr size_t smem = (size_t)NWT * (NWT / 2) * 64 * sizeof(float4_) + (size_t)2 * NWT * 16 * sizeof(float);
   static MqOncePerDevice attr;
   if (attr.first()) {
     hipError_t e = hipFuncSetAttribute((const void*)swin_mlp2_tail_kernel<C, NWT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -567,10 +576,12 @@ static int dispatch_swin_mlp2(const SwinMlp2Params& p, int flags, hipStream_t s)
     if (p.delta) pt.delta = p.delta + m_main * C;
     if (p.y) pt.y = p.y + m_main * C;
     pm.M = m_main;
-    const int e = launch_swin_mlp2_tail<C, NWT>(pt, s);
-    if (e) return e;
+    if (!(flags & 8)) {                                        // bit 3: the caller runs the tail part in a call of its own (other stream)
+      const int e = launch_swin_mlp2_tail<C, NWT>(pt, s);
+      if (e) return e;
+    }
   }
-  if (pm.M <= 0) return 0;
+  if (pm.M <= 0 || (flags & 16)) return 0;                     // bit 4: tail part only
   return (flags & 2) ? launch_swin_mlp2_main<C, NW, true>(pm, s) : launch_swin_mlp2_main<C, NW, false>(pm, s);
 }
 
@@ -580,7 +591,9 @@ static int dispatch_swin_mlp2(const SwinMlp2Params& p, int flags, hipStream_t s)
 // w2f [(4C / 32) * (C / 16) * 512]: fc2.weight with the k-slot permutation of mq_swin_mlp_fwd (slot 8 g + t of a 32-block <- hidden unit
 //     4 g + t for t < 4, 16 + 4 g + t - 4 for t >= 4), fragment-major -- block (chunk j, ct) holds for lane l W2p[16 ct + (l & 15)][32 j + 8 (l >> 4) .. + 7];
 // out [M, C] fp32 (may alias x), y [M, C] 16-bit = LayerNorm(out; next_g, next_b, eps_next) if y != NULL.
-// flags: bit 1 = table GELU in the main kernel; bit 0 = no tail split; bit 2 = every block through the tail kernel (see dispatch_swin_mlp2).
+// flags: bit 1 = table GELU in the main kernel; bit 0 = no tail split; bit 2 = every block through the tail kernel (see dispatch_swin_mlp2);
+// bit 3 = only the blocks of the main kernel, bit 4 = only the tail blocks: two calls on two streams run the two parts side by side (they
+// touch disjoint rows; a tail workgroup fits beside a main one on a CU).
 extern "C" int MQ_SYM(mq_swin_mlp2_fwd)(const float* x, const void* delta, const void* ln_g, const void* ln_b, float eps, const void* w1f,
                                 const void* b1, const void* w2f, const void* b2, float* out, const void* next_g, const void* next_b,
                                 float eps_next, void* y, long M, int C, int flags, void* stream) {

@@ -93,6 +93,10 @@ KERNEL_DEFAULTS = {
     "DYRELU_IN_LN": 1,           # 1: the DYReLU of fusion layers 0 .. L-2 is applied by the next layer's LayerNorm (mq_dyrelu_ln_fwd); 0: own pass
     "VLFUSE_I2T_VARIANT": 0,     # mq_vlfuse_i2t_fwd: 0 = Q fragments in registers where they fit (129 .. 160 keys: 0.428 -> 0.370 ms per launch),
                                  # 1 = Q tile in LDS for every caption longer than 128 tokens
+    "SWIN_MLP_TAIL_STREAM": 0,   # 1: the tail blocks of mq_swin_mlp2_fwd (those beyond the last full pass of the chip: 52 of 2100 at C = 384, B = 8,
+                                 # 64 us in FRONT of the 130 us main kernel) on a side stream BESIDE the main kernel (a tail workgroup fits on a CU next
+                                 # to a main one); 0: one after the other.  A/B on the MI355X (GPU call 12): 437 vs 441 images/s over two runs each --
+                                 # no gain (the main kernel leaves the tail's waves no issue slots), stays off
     "PATCH_EMBED_FUSED": 1,      # 1: mq_patch_embed_fwd (Swin PatchEmbed projection + patch_embed.norm + the first norm1 in one pass over the pixels);
                                  # 0: permute copies + library GEMM (K = 48) + two LayerNorm launches (354 us at B = 8)
     "BERT_QKV_FUSED": 1,         # 1: BERT layers = ONE qkv GEMM + mq_attn_text_fwd (V row-major, transposed out of LDS; registers / LDS sized by the
@@ -627,10 +631,11 @@ def swin_mlp2_pack(w1, w2):
     return w1f, w2f
 
 
-def swin_mlp2(x, delta, ln_g, ln_b, eps, w1f, b1, w2f, b2, next_ln=None, flags=None):
+def swin_mlp2(x, delta, ln_g, ln_b, eps, w1f, b1, w2f, b2, next_ln=None, flags=None, into=None):
     """Fused Swin MLP half, second generation (mq_swin_mlp2_fwd): arguments as swin_mlp but (w1f, w2f) = swin_mlp2_pack(fc1.weight,
     fc2.weight); flags (default KERNELS["SWIN_MLP2_FLAGS"]): bit 1 = table GELU in the main kernel, bit 0 = no pass / tail split, bit 2 =
-    every block through the tail kernel; negative = the measured choice per width (profiles/r03_call3_microbench_swin_mlp.json)."""
+    every block through the tail kernel, bit 3 / bit 4 = only the main-kernel / only the tail blocks (`into` = (out, y) of an earlier call:
+    the other part's rows are already there); negative = the measured choice per width (profiles/r03_call3_microbench_swin_mlp.json)."""
     lib = load_library()
     _need_gpu(x, delta, ln_g, ln_b, w1f, b1, w2f, b2)
     C = x.shape[-1]
@@ -639,18 +644,43 @@ def swin_mlp2(x, delta, ln_g, ln_b, eps, w1f, b1, w2f, b2, next_ln=None, flags=N
     assert delta is None or (delta.dtype == w1f.dtype and delta.is_contiguous() and delta.shape == x.shape)
     assert w1f.numel() == (4 * C // 32 + 2) * (C // 16) * 512 and w2f.numel() == (4 * C // 32) * (C // 16) * 512
     assert w1f.is_contiguous() and w2f.is_contiguous() and w1f.dtype == w2f.dtype == b1.dtype == b2.dtype == ln_g.dtype and w1f.dtype in _H16
-    out = torch.empty_like(x)
+    out = torch.empty_like(x) if into is None else into[0]
     y, ng, nb, ne = None, None, None, 0.0
     if next_ln is not None:
         ng, nb, ne = next_ln
-        y = torch.empty(x.shape, dtype=w1f.dtype, device=x.device)
+        y = torch.empty(x.shape, dtype=w1f.dtype, device=x.device) if into is None else into[1]
     flags = KERNELS["SWIN_MLP2_FLAGS"] if flags is None else int(flags)
     if flags < 0:
         flags = 0 if C == 192 else 2          # table GELU except at C = 192 (profiles/r03_call5_microbench_swin_mlp.json)
+    fn = _fn(lib, "mq_swin_mlp2_fwd", w1f)
+
+    def call(fl):
+        _chk(fn(_ptr(x), _ptr(delta), _ptr(ln_g), _ptr(ln_b), float(eps), _ptr(w1f), _ptr(b1), _ptr(w2f), _ptr(b2),
+                _ptr(out), _ptr(ng), _ptr(nb), float(ne), _ptr(y), M, C, fl, _stream()), "mq_swin_mlp2_fwd")
+    side = _tail_stream(x.device) if (KERNELS["SWIN_MLP_TAIL_STREAM"] == 1 and x.is_cuda and not (flags & 29) and _TIMING is None) else None
     with _timed(f"swin_mlp_c{C}", M * C * (4 + 4 + (2 if delta is not None else 0) + (2 if y is not None else 0))):
-        _chk(_fn(lib, "mq_swin_mlp2_fwd", w1f)(_ptr(x), _ptr(delta), _ptr(ln_g), _ptr(ln_b), float(eps), _ptr(w1f), _ptr(b1), _ptr(w2f), _ptr(b2),
-                                               _ptr(out), _ptr(ng), _ptr(nb), float(ne), _ptr(y), M, C, flags, _stream()), "mq_swin_mlp2_fwd")
+        if side is None:
+            call(flags)
+        else:
+            # the few blocks beyond the last full pass of the chip (tail kernel) BESIDE the main kernel instead of in front of it: a
+            # fork from the current stream (inside a HIP-graph capture: a parallel branch); the two parts touch disjoint rows
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                call(flags | 16)
+            call(flags | 8)
+            main.wait_stream(side)
     return (out, y) if y is not None else out
+
+
+_TAIL_STREAMS = {}
+
+
+def _tail_stream(device):
+    s = _TAIL_STREAMS.get(device.index)
+    if s is None:
+        s = _TAIL_STREAMS[device.index] = torch.cuda.Stream(device=device)
+    return s
 
 
 def conv3x3(x_nhwc, w_packed, bias, n_out, stride=1):

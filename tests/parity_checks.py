@@ -1539,6 +1539,15 @@ def check_swin_mlp(dev, variants=None):
                 tag = (f"swin_mlp2[{'tail only' if var[1] & 4 else 'unsplit' if var[1] & 1 else 'split'},{'table' if var[1] & 2 else 'erf'}] "
                        f"C={C} M={M} delta={use_delta}")
             out, y = r if use_next else (r, None)
+            if var[0] == "v2" and not (var[1] & 5) and use_next:
+                # the two parts as two calls (flags bit 3 = main blocks only, bit 4 = tail blocks only; on the device they run on two
+                # streams side by side): together bit for bit the single call
+                a = ops.swin_mlp2(x.to(dev), dl, lg.to(dev), lb.to(dev), 1e-5, w1f.to(dev), b1.to(dev), w2f.to(dev), b2.to(dev), next_ln=nln,
+                                  flags=var[1] | 8, into=(torch.full_like(out, float("nan")), torch.full_like(y, float("nan"))))
+                a = ops.swin_mlp2(x.to(dev), dl, lg.to(dev), lb.to(dev), 1e-5, w1f.to(dev), b1.to(dev), w2f.to(dev), b2.to(dev), next_ln=nln,
+                                  flags=var[1] | 16, into=a)
+                res.append(_stat(f"{tag}: main-only + tail-only calls == one call (out)", a[0], out.float().cpu(), tol=0.0))
+                res.append(_stat(f"{tag}: main-only + tail-only calls == one call (next LayerNorm)", a[1], y.float().cpu(), tol=0.0))
             res.append(_stat(f"{tag}: out (fp32 stream)", out, ref, tol=1e-3))
             if use_next:
                 res.append(_stat(f"{tag}: fused next LayerNorm", y, F.layer_norm(ref, (C,), ng.float(), nb.float(), 1e-5), tol=2e-3))
