@@ -152,6 +152,16 @@ def main_gdino(args, rank, world, dev):
     imgs[:, :, :H, :W] = torch.randn(Bn, 3, H, W, generator=g)
     images = ImageList(imgs.to(dev), [(H, W)] * Bn)
     captions = [caption] * Bn
+    # With seeded random weights no query reaches the yaml's box_threshold, and a step without survivors would not time the conversion /
+    # gather of real rows: one probe forward with the threshold at 0, then the threshold = the MEDIAN best-class score
+    # of the 900 queries -- about half of them survive, like a confident model on a crowded image.
+    yaml_thr, graph_on = float(cfg.GROUNDINGDINO.box_threshold), model.use_hip_graph
+    cfg.GROUNDINGDINO.box_threshold, model.use_hip_graph = 0.0, False
+    model(ImageList(imgs[:2].to(dev), [(H, W)] * 2), captions=captions[:2], positive_map=pmap)
+    sc = model.last_packed[..., 4]
+    bench_thr = float(sc[sc > 0].median()) if bool((sc > 0).any()) else yaml_thr
+    cfg.GROUNDINGDINO.box_threshold, model.use_hip_graph = bench_thr, graph_on
+    model.clear_caches()
 
     def step():
         out = model(images, captions=captions, positive_map=pmap)
@@ -195,7 +205,8 @@ def main_gdino(args, rank, world, dev):
                "config": {"workload": "BASELINE.json configs[4]: MQ-GroundingDINO-T (Swin-T + BERT-base + GCP + 6 + 6 deformable "
                                       "transformer layers, 900 queries), 5 vision queries x 40 classes, every step a full forward",
                           "global_batch": world * Bn, "batch_per_gpu": Bn, "image": "800x1333 -> 800x1344", "parallelism": f"dp{world}",
-                          "weights": "seeded random init (no checkpoints offline)"},
+                          "weights": "seeded random init (no checkpoints offline)",
+                          "box_threshold": f"{bench_thr:.4f} = median query score of a probe forward (the yaml's {yaml_thr} leaves no survivor with random weights)"},
                "detections_img0": len(out[0]), "hip_graph": bool(model.use_hip_graph and any(e.get("stage") == 2 for e in model._graphs.values())),
                "cache_stats": dict(model.cache_stats), "model_tflops": round(ips * GFLOP_PER_IMAGE_GDINO / 1e3, 2),
                "model_frac_of_mfma_peak": round(ips * GFLOP_PER_IMAGE_GDINO / 1e3 / (MFMA_PEAK_TFLOPS * world), 4),
@@ -253,8 +264,26 @@ def _cpu_baseline_worker():
         if i >= 2:
             times.append(time.time() - t)
     med = statistics.median(times)
+    # BASELINE.md section 3 asks for ALL host cores: a second, shorter sample with every core (1 warm-up + up to 3 timed forwards, stopped
+    # once 60 s are spent) -- the better of the two is `value`, both are reported with their thread counts
+    all_cores, extra = os.cpu_count() or threads, None
+    if all_cores > threads:
+        torch.set_num_threads(all_cores)
+        t_x, tx = time.time(), []
+        for i in range(4):
+            t = time.time()
+            od.forward(sd, spec, images, sizes, ids, am, pm, None)
+            if i >= 1:
+                tx.append(time.time() - t)
+            if time.time() - t_x > 60:
+                break
+        if tx:
+            extra = {"cores": all_cores, "median_s_per_forward": round(statistics.median(tx), 3), "value": round(1.0 / statistics.median(tx), 4),
+                     "timed_forwards": len(tx)}
+            if statistics.median(tx) < med:
+                med, threads = statistics.median(tx), all_cores
     print(json.dumps({"value": round(1.0 / med, 4), "unit": "images/sec", "cores": threads, "kind": "port",
-                      "median_s_per_forward": round(med, 3),
+                      "median_s_per_forward": round(med, 3), "all_cores_sample": extra,
                       "sample": f"GLIP-T (no vision queries), one 800x1333 image (padded 800x1344), 20-token caption; 2 warm-up + "
                                 f"5 timed forwards of the fp32 CPU oracle, median; {time.time() - t_all:.1f} s in total, {threads} torch "
                                 f"threads on a {os.cpu_count()}-core host"}), flush=True)
@@ -298,7 +327,7 @@ def _cpu_baseline_worker_gdino():
 def cpu_baseline(timeout=420, flag="--cpu-baseline-worker"):
     """Run the worker in a subprocess with a hard time limit so the default bench run stays bounded."""
     import subprocess
-    env = dict(os.environ, OMP_NUM_THREADS=str(CPU_BASELINE_THREADS), MKL_NUM_THREADS=str(CPU_BASELINE_THREADS),
+    env = dict({k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "MKL_NUM_THREADS")},
                HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), flag], env=env,
