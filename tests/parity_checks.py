@@ -42,8 +42,13 @@ def use_dtype(dtype):
 # the MI355X produced (tools/measured_gate.py from the ladder file of a whole GPU-suite run).  ON THE DEVICE a row found there is gated at
 # min(stated tolerance, max(1e-3 x dtype scale, 2 x measured)): a kernel that gets 3 x worse than its last measurement fails whatever the
 # stated per-family tolerance allows.  (The CPU emulation of the kernel sources rounds differently in exp / rcp: it keeps the stated values.)
+# DEEP-STACK rows (whole models, whole fusion layers) get 4 x instead of 2 x: their max-norm error is a chaotic statistic -- between the round-3
+# and the round-4 ladder (every per-kernel row equal or better) 75 of them moved DOWN by 30 % ... 10 x and a handful UP by up to 3.3 x
+# ("[bf16] gdino[vq ...] BERT (+GCP) last hidden" 1.7e-2 -> 5.7e-2 with no kernel of its path changed: the Swin front feeding the
+# pre-select rounds differently).  Per-kernel rows keep 2 x.
 MEASURED_GATE = torch.cuda.is_available()
-MEASURED_MARGIN, MEASURED_FLOOR = 2.0, 1e-3
+MEASURED_MARGIN, MEASURED_MARGIN_DEEP, MEASURED_FLOOR = 2.0, 4.0, 1e-3
+_DEEP_ROWS = ("full:", "bench[", "gdino[", "fusion layer", "extract_query")
 _MEASURED = None
 
 
@@ -66,7 +71,8 @@ def _stat(name, got, ref, tol=TOL):
     if MEASURED_GATE and tol > 0 and H16 != torch.float32:
         m = _measured(name)
         if m is not None:
-            tol = min(tol, max(MEASURED_FLOOR * TOL_SCALE, MEASURED_MARGIN * m))
+            margin = MEASURED_MARGIN_DEEP if any(t in name for t in _DEEP_ROWS) else MEASURED_MARGIN
+            tol = min(tol, max(MEASURED_FLOOR * TOL_SCALE, margin * m))
     got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
     err = (got - ref).abs().max().item() if ref.numel() else 0.0
     scale = max(1.0, ref.abs().max().item() if ref.numel() else 1.0)

@@ -1,6 +1,6 @@
 """tests/golden/device_measured.json from a ladder file of the GPU suite (MQ_LADDER_OUT=<file> python -m pytest tests -m gpu):
 per check row name the normalised error max|hip - ref| / max(1, max|ref|) MEASURED ON THE MI355X.  tests/parity_checks.py gates every
-row it finds here at max(1e-3, 2 x measured) (bf16 rows: the floor x 8) on top of its stated tolerance -- VERDICT r3 item 8: a kernel
+row it finds here at max(1e-3, 2 x measured) (deep-stack rows 4 x; bf16 rows: the floor x 8) on top of its stated tolerance -- VERDICT r3 item 8: a kernel
 that becomes 3 x worse than what was measured fails, whatever the stated per-family tolerance allows.
 
     python tools/measured_gate.py gpurun_out/r04cN_ladder.jsonl [more ladders ...]        (rewrites tests/golden/device_measured.json)

@@ -16,7 +16,8 @@ GROUPS = (("vlfuse_i2t", "vlfuse_i2t_kernel"), ("vlfuse_t2i_combine", "vlfuse_t2
           ("dyrelu_ln", "dyrelu_ln_kernel"), ("layernorm2_kernel", "layernorm2_kernel"), ("layernorm_kernel", "layernorm_kernel"),
           ("window_attn_qkv_kernel<96", "window_attn_qkv_kernel<96>"), ("window_attn_qkv_kernel<192", "window_attn_qkv_kernel<192>"),
           ("window_attn_qkv_kernel<384", "window_attn_qkv_kernel<384>"), ("window_attn_qkv", "window_attn_qkv_kernel"),
-          ("attn_resident", "attn_resident_kernel"), ("attn_chunked", "attn_chunked_kernel"),
+          ("attn_resident", "attn_resident_kernel"), ("attn_text", "attn_text_kernel"), ("attn_chunked", "attn_chunked_kernel"),
+          ("patch_embed", "patch_embed_kernel"), ("post_select", "post_select_kernel"), ("post_merge", "post_merge_kernel"),
           ("window_attn", "window_attn_kernel"), ("align_fused", "align_fused_kernel"), ("conv3x3_small2", "conv3x3_small2_kernel"))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
