@@ -224,6 +224,37 @@ def test_evaluator_update_boxlist_matches_reference_prepare():
         assert a == b, (cat, a[:2], b[:2])
 
 
+def test_bench_roofline_records_are_per_kernel_and_read_the_newest_pmc_file():
+    """`roofline` = the SINGLE hand-written kernel with the most time per step (the two-kernel VLFuse record is kept for
+    continuity but flagged and never chosen); PMC traffic comes from the newest profiles/r0N_pmc_traffic.json."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    pmc = bench._pmc()
+    assert pmc.get("_file", "").startswith("profiles/r04") and pmc.get("dcn_igemm8_kernel", 0) > 1e8
+    kern = {"dcnv2_fused": (18, 9.9, 0), "vlfuse_i2t_n22400_t256": (18, 6.0, 0), "vlfuse_t2i_n22400_t256_s7": (18, 4.5, 0),
+            "swin_mlp_c384": (18, 3.5, 10 ** 9)}
+    roofs = bench.kernel_rooflines(kern, 3, 8, 141)
+    pair = [r for r in roofs if r.get("pair")]
+    assert len(pair) == 1 and abs(pair[0]["ms_per_step"] - 3.5) < 1e-6
+    single = [r for r in roofs if r["bound"] == "mfma" and not r.get("pair")]
+    best = max(single, key=lambda r: r["ms_per_step"])
+    assert best["kernel"].startswith("dcn_igemm8_kernel") and best["traffic"] == pmc["dcn_igemm8_kernel"]
+    assert {r["kernel"].split(" ")[0] for r in single} >= {"dcn_igemm8_kernel", "vlfuse_i2t_kernel", "vlfuse_t2i_kernel", "swin_mlp2_kernel"}
+
+
+def test_vlfuse_text_side_key_split_counts_passes_per_xcd():
+    """The key split of mq_vlfuse_t2i_fwd is chosen by passes of an XCD's 32 CUs over ITS groups (group g runs on XCD g % 8): B = 8 -> 7 (7 groups
+    x 9 workgroups = 63 per XCD, two passes), B = 4 -> 14 (the same 63; nsplit 7 would be 36 = two badly filled passes: 0.231 vs 0.151 ms on
+    the MI355X, profiles/r04_call10_t2i_sweep.json)."""
+    from mq_det_amd.modeling.pipeline import _nsplit_t2i
+    assert _nsplit_t2i(8, 8, 141, 350) == 7 and _nsplit_t2i(4, 8, 141, 350) == 14
+    assert _nsplit_t2i(8, 8, 141, 6) == 1                               # short key ranges are never split
+    for B in (1, 2, 3, 5, 16, 31):
+        ns = _nsplit_t2i(B, 8, 141, 350)
+        assert 1 <= ns <= 32 and -(-350 // ns) >= 4
+
+
 def test_ctypes_signatures_match_header():
     """every `_SIGNATURES` entry of mq_det_amd/ops.py has the argument kinds of its declaration in
     include/mqdet_hip.h (pointer / int / long / float, in order) -- parsed from the header text."""
