@@ -738,10 +738,15 @@ def dyconv(P, cfg, b, feats):
 _SIDE_STREAMS = {}
 
 
+# priority of the side streams by tag (A/B switch MQ_STREAM_PRIORITY = "text:-1,levels:0": -1 = high): the text chain of a fusion layer is
+# ~25 small launches that the next layer's image-side attention waits for; its kernels queue behind the workgroups of the DCNv2 launch
+_STREAM_PRIORITY = dict((kv.split(":")[0], int(kv.split(":")[1])) for kv in os.environ.get("MQ_STREAM_PRIORITY", "").split(",") if ":" in kv)
+
+
 def _side_streams(device, n, tag="levels"):
     key = (device.index, n, tag)
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+        _SIDE_STREAMS[key] = [torch.cuda.Stream(device=device, priority=_STREAM_PRIORITY.get(tag, 0)) for _ in range(n)]
     return _SIDE_STREAMS[key]
 
 
