@@ -675,11 +675,11 @@ def dyconv_tokens(P, cfg, b, tok, sizes, defer_relu=False):
                 fn(l)
             return
         main = torch.cuda.current_stream()
-        side = _side_streams(tok.device, nl - 1)
+        side = _side_streams(tok.device, max(1, min(nl - 1, _LEVEL_SIDE_STREAMS)))
         for s_ in side:
             s_.wait_stream(main)
         for l in range(1, nl):
-            with torch.cuda.stream(side[l - 1]):
+            with torch.cuda.stream(side[(l - 1) % len(side)]):
                 fn(l)
         fn(0)
         for s_ in side:
@@ -736,6 +736,7 @@ def dyconv(P, cfg, b, feats):
 
 
 _SIDE_STREAMS = {}
+_LEVEL_SIDE_STREAMS = int(os.environ.get("MQ_LEVEL_SIDE_STREAMS", "4"))      # side streams of the per-level DyConv work (P4 .. P7; P3 runs on the main one)
 
 
 # priority of the side streams by tag (A/B switch MQ_STREAM_PRIORITY = "text:-1,levels:0": -1 = high): the text chain of a fusion layer is
