@@ -277,6 +277,80 @@ def test_round3_fused_operators_random_shapes(ops):
             _close(a_, b_, f"swin_mlp2 draw {it}: C={C} M={M} flags={flags} delta={delta is not None}: {what}", 3e-3)
 
 
+def test_round4_operators_random_shapes(ops):
+    """mq_attn_text_fwd (caption lengths around every 16-key block and the 160-key variant switch, per-item kv_len, max_kv above / at / absent,
+    clamp, D = 32 / 64), mq_patch_embed_fwd (both pixel layouts, widths around multiples of 16 patches, C = 96 / 192), and the
+    post-processing kernels (mq_post_select_fwd over one / several slices with scores quantised so that ties straddle every cut,
+    mq_post_sort_fwd, mq_post_finalize_fwd) against their torch restatements."""
+    import ops_emulation as emu
+    rng = random.Random(4004 + SEED)
+    g = torch.Generator().manual_seed(4004 + SEED)
+    for it in range(8 * N_DRAWS):
+        B, H, D = rng.randint(1, 3), rng.randint(1, 4), rng.choice((32, 64))
+        T = rng.choice((256, 256, 8 * rng.randint(1, 32)))
+        kv = max(1, min(T, _edge(rng, (16, 32, 160), T)))
+        clamp = rng.choice((0.0, 0.0, 50000.0, 2.5))
+        qkv = (torch.randn(B, T, 3 * H * D, generator=g) * rng.choice((1.0, 4.0))).half()
+        kl = torch.tensor([max(1, kv - rng.randint(0, 20) * (b > 0)) for b in range(B)], dtype=torch.int32)
+        kb = torch.zeros(B, T)
+        for b in range(B):
+            kb[b, int(kl[b]):] = -1e30
+        mk = rng.choice((0, kv, min(T, kv + rng.randint(0, 40))))
+        got = ops.attention_text(qkv, H, key_bias=kb, clamp=clamp, kv_len=kl if rng.random() < 0.8 else None, max_kv=mk)
+        _close(got, emu.attention_text(qkv, H, key_bias=kb, clamp=clamp), f"attention_text draw {it}: B={B} H={H} D={D} T={T} kv={kv} max_kv={mk} clamp={clamp}")
+    for it in range(6 * N_DRAWS):
+        C = rng.choice((96, 192))
+        B, Hi, Wi = rng.randint(1, 2), 4 * rng.randint(1, 9), 4 * _edge(rng, (16,), 70)
+        img = torch.randn(B, 3, Hi, Wi, generator=g).half()
+        w = (torch.randn(C, 3, 4, 4, generator=g) * 0.2).half()
+        prm = [torch.randn(C, generator=g) * s_ + o_ for s_, o_ in ((0.1, 0), (0.2, 1), (0.1, 0), (0.2, 1), (0.1, 0))]
+        if rng.random() < 0.5:
+            pix, wpk = img.float().contiguous(), ops.patch_embed_pack(w.float(), nchw=True).half()
+        else:
+            pix, wpk = img.permute(0, 2, 3, 1).contiguous(), ops.patch_embed_pack(w.float()).half()
+        for a_, b_, what in zip(ops.patch_embed(pix, wpk, *prm), emu.patch_embed(pix, wpk, *prm), ("stream", "norm1")):
+            _close(a_, b_, f"patch_embed draw {it}: B={B} {Hi}x{Wi} C={C} {'fp32 NCHW' if pix.dtype == torch.float32 else 'NHWC'}: {what}", 2e-3)
+    for it in range(5 * N_DRAWS):
+        B, L, nl = rng.randint(1, 2), rng.randint(1, 12), rng.randint(1, 4)
+        shapes = [(rng.randint(1, 40), rng.randint(1, 90)) for _ in range(nl)]
+        if it % 2 == 0:
+            shapes[0] = (rng.randint(60, 75), rng.randint(60, 75))           # > 32768 scores with L >= 8: several slices
+            L = max(L, 8)
+        topn = rng.choice((1, 17, 300, 1000, 1500))
+        quant = rng.choice((None, 3, 40))
+        dens = rng.choice((0.0, 0.02, 0.5, 1.0))
+        ranked, reg, anchors, ks = [], [], [], []
+        for (h, w_) in shapes:
+            hw = h * w_
+            v = torch.rand(B, hw, L, generator=g)
+            if quant:
+                v = (torch.floor(v * quant) + 1) / (quant + 1)
+            ranked.append(torch.where(torch.rand(B, hw, L, generator=g) < dens, v, torch.full_like(v, -1.0)).contiguous())
+            reg.append((torch.randn(B, hw, 4, generator=g) * 2).contiguous())
+            xy = torch.rand(hw, 2, generator=g) * 300
+            anchors.append(torch.cat([xy, xy + 8 + torch.rand(hw, 2, generator=g) * 64], 1).contiguous())
+            ks.append(min(topn, hw * L))
+        lab = torch.randperm(L, generator=g).to(torch.int32) + 1
+        wh = torch.tensor([[333.0, 250.0]] * B)
+        assert ops.post_select_supported([h * w_ for h, w_ in shapes], ks, B, L)
+        gb, gs, gl, gi = ops.post_select(ranked, reg, anchors, ks, lab, wh)
+        eb, es, el, ei = emu.post_select(ranked, reg, anchors, ks, lab.long(), wh)
+        what = f"post draw {it}: B={B} shapes={shapes} L={L} k={ks} quant={quant} dens={dens}"
+        assert torch.equal(gi, ei) and torch.equal(gl.int(), el.int()), what + ": candidate ids / labels"
+        _close(gs, es, what + ": scores", 2e-7)
+        _close(gb, eb, what + ": boxes", 1e-6)
+        hb, hs, hl, hn = ops.post_sort(gb, gs, gl, ks)
+        sb, ss, sl, sn = emu.post_sort(gb, gs, gl, ks)
+        assert torch.equal(hs, ss) and torch.equal(hl.int(), sl.int()) and torch.equal(hn.int(), sn.int()) and torch.equal(hb, sb), what + ": merge"
+        tot = sum(ks)
+        K = rng.randint(1, tot)
+        K2 = min(tot, K + rng.choice((0, 1, 16)))
+        keep = (torch.rand(B, tot, generator=g) < rng.choice((0.1, 0.7, 1.0))).to(torch.uint8)
+        ho, hc = ops.post_finalize(hb, hs, hl, keep, K, K2)
+        fo, fc = emu.post_finalize(hb, hs, hl, keep, K, K2)
+        assert torch.equal(hc.int(), fc.int()) and torch.equal(ho, fo), what + f": finalize K={K} K2={K2}"
+
+
 def test_swin_mlp_roi_align_and_msdeform_random_shapes(ops):
     import math
     import ops_emulation as emu
