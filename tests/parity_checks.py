@@ -999,6 +999,9 @@ def all_checks(dev):
     for s in specs:
         out.append(("attention", lambda s=s: check_attention(dev, **s)))
     out += [("attention", lambda: check_attention_strided(dev)),
+            ("attention", lambda: check_attention_text(dev)),
+            ("swin", lambda: check_patch_embed(dev)),
+            ("post", lambda: check_post_fused(dev)),
             ("window_attn", lambda: check_window_attention(dev)),
             ("swin_fpn", lambda: check_swin_fpn(dev)),
             ("gcp", lambda: check_gcp_block(dev)),

@@ -592,7 +592,8 @@ def bf16():
 # the complete bf16 list runs by default since round 3 (all 17 passed on the MI355X in GPU call 1: + ~65 s)
 @pytest.mark.parametrize("name", ["check_attention_strided", "check_window_attention", "check_vlfuse_kernels", "check_dcn", "check_layernorm",
                                   "check_swin_mlp", "check_full_model", "check_gcp_block", "check_pre_select", "check_vl_fuse", "check_dyconv",
-                                  "check_conv3x3", "check_post_golden", "check_roi_align", "check_msdeform_attn", "check_align_fused"])
+                                  "check_conv3x3", "check_post_golden", "check_roi_align", "check_msdeform_attn", "check_align_fused",
+                                  "check_attention_text", "check_patch_embed"])
 def test_bf16_block(dev, bf16, name):
     _assert(getattr(bf16, name)(dev))
 

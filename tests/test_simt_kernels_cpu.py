@@ -232,7 +232,7 @@ def bf16(kernels):
 
 @pytest.mark.parametrize("name", ["check_window_attention", "check_gcp_block", "check_pre_select", "check_vlfuse_kernels", "check_dcn",
                                   "check_post_golden", "check_layernorm", "check_swin_mlp", "check_conv3x3", "check_msdeform_attn",
-                                  "check_attention_strided"])
+                                  "check_attention_strided", "check_attention_text", "check_patch_embed"])
 def test_bf16_kernel_block(bf16, name):
     res = getattr(bf16, name)(CPU)
     _assert_ok(res)
