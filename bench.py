@@ -443,6 +443,7 @@ def kernel_rooflines(kern, steps, Bn, n_tok, embed=96):
     groups = (("layernorm_kernel (all LayerNorms, residual add fused)", "layernorm_c"), ("window_attn_kernel (Swin W-MSA / SW-MSA)", "window_attn_c"),
               ("dyconv_fuse_kernel (GroupNorm affine + up-sampling + scale attention + branch mean)", "dyconv_fuse"),
               ("dyrelu_apply_kernel", "dyrelu_apply"), ("conv3x3_small_kernel (27-channel DyConv offset conv)", "conv3x3_small"),
+              ("conv3x3_group_kernel (27-channel DyConv offset conv, all levels of a layer in one launch, weights in registers)", "conv3x3_group"),
               ("align_scores_kernel (sigmoid + token->class mean + threshold)", "align_scores"),
               ("align_fused_kernel (box / centerness heads + dot-product alignment + sigmoid + class aggregation + threshold, all levels)", "align_fused"),
               ("patch_embed_kernel (Swin PatchEmbed projection + patch_embed.norm + first norm1, fp32 NCHW pixels in)", "patch_embed_c"),
@@ -535,7 +536,7 @@ def _sub_bench(argv, env=None, timeout=150, keep=()):
 
 # every operator with two implementations on the one that was the default at the end of ROUND 3 (ops.KERNEL_DEFAULTS lists today's), and the
 # runtime default of the hardware queues: what round 4's switchable changes buy (not switchable, so inside both runs: the VLFuse softmax diet)
-ROUND3_KERNEL_SET = {"MQ_POST_FUSED": "0", "MQ_BERT_QKV_FUSED": "0", "MQ_PATCH_EMBED_FUSED": "0", "GPU_MAX_HW_QUEUES": "4"}
+ROUND3_KERNEL_SET = {"MQ_POST_FUSED": "0", "MQ_BERT_QKV_FUSED": "0", "MQ_PATCH_EMBED_FUSED": "0", "MQ_OFFSET_CONV_VARIANT": "2", "GPU_MAX_HW_QUEUES": "4"}
 
 
 def _free_port():

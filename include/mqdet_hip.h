@@ -209,6 +209,17 @@ int mq_conv3x3_nchw32_fwd(const void* x, const void* w, const void* bias, float*
  * and the weight prefetch (csrc/conv_small2.hip).  Default since round 3 (KERNELS["OFFSET_CONV_VARIANT"] = 2); equal outputs. */
 int mq_conv3x3_nchw32_v2_fwd(const void* x, const void* w, const void* bias, float* out, int B, int H, int W, int C, long x_bs,
                           int N, void* stream);
+/* The offset / mask conv of ONE DyConv layer for all pyramid levels in one launch (csrc/conv_small3.hip; rpn/vldyhead.py:205-215 applies the
+ * same nn.Conv2d(256, 27, 3) to every level).  `levels` is a HOST array of <= 8 entries copied into the kernel arguments: x [B,H,W,256]
+ * 16-bit NHWC (batch stride x_bs elements), out [B,N,H,W] fp32 NCHW.  w [32, 9*256] / bias [N] as mq_conv3x3_nchw32_fwd.  Persistent
+ * workgroups (one per CU) hold the weights in registers and walk the tiles of all levels; the contraction is split over the 8 waves by
+ * channel and summed in a fixed order, so results equal mq_conv3x3_nchw32_fwd's to fp32 rounding (not bit for bit).
+ * Returns -1 for C != 256, N > 32, more than 8 levels (callers then use mq_conv3x3_nchw32_v2_fwd per level).
+ * KERNELS["OFFSET_CONV_VARIANT"] = 3. */
+typedef struct mq_conv_level {
+  const void* x; float* out; long x_bs; int H, W;
+} mq_conv_level;
+int mq_conv3x3_nchw32_group_fwd(const mq_conv_level* levels, int nl, const void* w, const void* bias, int B, int C, int N, void* stream);
 int mq_dcnv2_stats_blocks(int H, int W, int stride);
 /* One launch for up to 16 DCNv2 calls (the 13 branches of one DyConv layer): `branches` is a HOST array, copied into the
  * kernel arguments; fields as the arguments of mq_dcnv2_fwd.  The tiles of all branches form one work list, so small
@@ -426,6 +437,7 @@ MQ_BF16_TWIN(mq_swin_mlp2_fwd)
 MQ_BF16_TWIN(mq_conv3x3_fwd)
 MQ_BF16_TWIN(mq_conv3x3_nchw32_fwd)
 MQ_BF16_TWIN(mq_conv3x3_nchw32_v2_fwd)
+MQ_BF16_TWIN(mq_conv3x3_nchw32_group_fwd)
 MQ_BF16_TWIN(mq_dcnv2_fwd)
 MQ_BF16_TWIN(mq_dcnv2_group_fwd)
 MQ_BF16_TWIN(mq_dyconv_stats)

@@ -689,7 +689,11 @@ def dyconv_tokens(P, cfg, b, tok, sizes, defer_relu=False):
 
     def offsets(lvl):
         om[lvl] = ops.conv3x3_nchw32(lv[lvl], P[b + ".offset.packed"], P[b + ".offset.bias"], 27)      # [B, 27, H, W] fp32
-    fan_out(offsets)
+    if ops.KERNELS["OFFSET_CONV_VARIANT"] == 3 and ops.conv3x3_nchw32_group_supported(lv, 27):
+        # one conv for every level (vldyhead.py:205-215): one launch over the tiles of all levels, no fork / join
+        om = ops.conv3x3_nchw32_group(lv, P[b + ".offset.packed"], P[b + ".offset.bias"], 27)
+    else:
+        fan_out(offsets)
 
     branches, owner = [], []
     for lvl in range(nl):

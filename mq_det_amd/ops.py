@@ -13,7 +13,7 @@ _LIB = None
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmqdet_hip.so")
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
-EXPECTED_ABI = 22        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
+EXPECTED_ABI = 23        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
 _SIGNATURES = {
     "mq_abi_version": (_i, []),
     "mq_attn_workspace_bytes": (_l, [_i, _i, _i, _i, _i]),
@@ -37,6 +37,7 @@ _SIGNATURES = {
     "mq_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _vp]),
     "mq_conv3x3_nchw32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _vp]),
     "mq_conv3x3_nchw32_v2_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _vp]),
+    "mq_conv3x3_nchw32_group_fwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "mq_dcnv2_stats_blocks": (_i, [_i, _i, _i]),
     "mq_dcnv2_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_dcnv2_group_fwd": (_i, [_vp, _i, _vp]),
@@ -64,7 +65,7 @@ _SIGNATURES = {
 }
 # entry points with 16-bit operands also exist as <name>_bf16 (same signature; include/mqdet_hip.h MQ_BF16_TWIN)
 BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_text_fwd", "mq_patch_embed_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_window_attn_qkv_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
-              "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_patch_merge_ln_fwd", "mq_swin_mlp_fwd", "mq_swin_mlp2_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
+              "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_patch_merge_ln_fwd", "mq_swin_mlp_fwd", "mq_swin_mlp2_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_conv3x3_nchw32_group_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
               "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyrelu_apply", "mq_dyrelu_ln_fwd", "mq_add_upsample_nearest",
               "mq_align_scores_fwd", "mq_align_fused_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
 for _n in BF16_TWINS:
@@ -78,7 +79,9 @@ EXPORTS = tuple(_SIGNATURES)
 # environment variable MQ_<NAME> (A/B runs, tests).
 KERNEL_DEFAULTS = {
     "LN_VARIANT": 2,             # 2: mq_layernorm2_fwd (rows in flight, gamma / beta in registers; bit-identical results)      +1.2 %
-    "OFFSET_CONV_VARIANT": 2,    # 2: mq_conv3x3_nchw32_v2_fwd (window loads unconditional and in flight; bit-identical)         +4.4 %
+    "OFFSET_CONV_VARIANT": 3,    # 2: mq_conv3x3_nchw32_v2_fwd (window loads unconditional and in flight; bit-identical to 1)    +4.4 %
+                                 # 3: mq_conv3x3_nchw32_group_fwd (all levels of a DyConv layer in ONE launch of persistent workgroups,
+                                 #    weights in registers; per-level calls and other shapes: the v2 kernel)   +3.3 % over 2 (r04 call 21)
     "PATCH_MERGE_FUSED": 1,      # 1: mq_patch_merge_ln_fwd (Swin PatchMerging gather + LayerNorm, no pad / cat pass)            +1.6 %
     "FPN_VIA_DCN": 1,            # 1: the three FPN output convs as ONE grouped launch of the fused DCNv2 kernel, zero offsets    +3.8 %
     "NMS_EARLY_STOP": 1,         # 1: mq_ml_nms_topk (the sweep of an image ends once DETECTIONS_PER_IMG boxes are kept)          +0.9 %
@@ -710,10 +713,43 @@ def conv3x3_nchw32(x_nhwc, w_packed, bias, n_out):
     assert w_packed.is_contiguous() and w_packed.shape == (32, 9 * C) and w_packed.dtype == x_nhwc.dtype and n_out <= 32
     out = torch.empty(B, n_out, H, W, dtype=torch.float32, device=x_nhwc.device)
     with _timed("conv3x3_small", B * H * W * C * 2 + out.numel() * 4):
-        # OFFSET_CONV_VARIANT 2: unconditional / in-flight loads (csrc/conv_small2.hip), same results bit for bit
-        name = "mq_conv3x3_nchw32_v2_fwd" if KERNELS["OFFSET_CONV_VARIANT"] == 2 else "mq_conv3x3_nchw32_fwd"
+        # OFFSET_CONV_VARIANT >= 2: unconditional / in-flight loads (csrc/conv_small2.hip), same results bit for bit
+        name = "mq_conv3x3_nchw32_v2_fwd" if KERNELS["OFFSET_CONV_VARIANT"] >= 2 else "mq_conv3x3_nchw32_fwd"
         _chk(_fn(lib, name, x_nhwc)(_ptr(x_nhwc), _ptr(w_packed), _ptr(bias), _ptr(out), B, H, W, C, x_nhwc.stride(0), n_out, _stream()), name)
     return out
+
+
+class _ConvLevel(ctypes.Structure):
+    """mq_conv_level of include/mqdet_hip.h."""
+    _fields_ = [("x", _vp), ("out", _vp), ("x_bs", _l), ("H", _i), ("W", _i)]
+
+
+def conv3x3_nchw32_group_supported(levels, n_out):
+    """Shapes mq_conv3x3_nchw32_group_fwd takes (else: conv3x3_nchw32 per level)."""
+    return 0 < len(levels) <= 8 and n_out <= 32 and all(x.shape[3] == 256 and x.shape[1] * x.shape[2] * 256 < 2 ** 31 for x in levels)
+
+
+def conv3x3_nchw32_group(levels, w_packed, bias, n_out):
+    """conv3x3_nchw32 of every pyramid level with the SAME weights in one launch (csrc/conv_small3.hip): levels = list of x [B,H,W,256]
+    16-bit NHWC views -> list of [B, n_out, H, W] fp32.  Equal to the per-level operator up to fp32 summation order."""
+    lib = load_library()
+    _need_gpu(w_packed, bias, *levels)
+    assert conv3x3_nchw32_group_supported(levels, n_out)
+    B, C = levels[0].shape[0], levels[0].shape[3]
+    assert w_packed.is_contiguous() and w_packed.shape == (32, 9 * C) and w_packed.dtype == levels[0].dtype
+    arr = (_ConvLevel * len(levels))()
+    outs, nbytes = [], 0
+    for a, x in zip(arr, levels):
+        Bx, H, W, Cx = x.shape
+        assert Bx == B and Cx == C and x.dtype == levels[0].dtype and x.stride(3) == 1 and x.stride(2) == C and x.stride(1) == W * C
+        out = torch.empty(B, n_out, H, W, dtype=torch.float32, device=x.device)
+        a.x, a.out, a.x_bs, a.H, a.W = x.data_ptr(), out.data_ptr(), x.stride(0), H, W
+        outs.append(out)
+        nbytes += B * H * W * C * 2 + out.numel() * 4
+    with _timed("conv3x3_group", nbytes):
+        _chk(_fn(lib, "mq_conv3x3_nchw32_group_fwd", levels[0])(ctypes.cast(arr, _vp), len(levels), _ptr(w_packed), _ptr(bias), B, C, n_out, _stream()),
+             "mq_conv3x3_nchw32_group_fwd")
+    return outs
 
 
 def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None, mask_prob=False, tag="dcnv2_fused"):

@@ -391,6 +391,14 @@ def conv3x3_nchw32(x_nhwc, w_packed, bias, n_out):
     return conv3x3(x_nhwc, w_packed, bias, n_out).permute(0, 3, 1, 2).float().contiguous()
 
 
+def conv3x3_nchw32_group_supported(levels, n_out):
+    return 0 < len(levels) <= 8 and n_out <= 32 and all(x.shape[3] == 256 for x in levels)
+
+
+def conv3x3_nchw32_group(levels, w_packed, bias, n_out):
+    return [conv3x3_nchw32(x, w_packed, bias, n_out) for x in levels]
+
+
 def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None, mask_prob=False, tag=None):
     cols, hw = _dcn_cols(x_nhwc.contiguous(), om, stride)
     y = F.linear(cols.float(), w_packed.float(), bias.float()).to(x_nhwc.dtype)
@@ -580,7 +588,7 @@ def dyconv_coef_group(items, attn_w, attn_b, groups, eps):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # every emulated entry point, in one place: tests patch them into mq_det_amd.ops (or into a stand-in namespace) with these helpers
 NAMES = ("attention", "attention4", "attention_text", "patch_embed", "window_attention", "window_attention_qkv", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores", "align_fused",
-         "dyconv_branch_coef", "dyconv_coef_group", "dyconv_fuse", "dyrelu_", "dyrelu_coef", "dyrelu_apply_", "dyrelu_layer_norm", "add_upsample_nearest_", "conv3x3", "conv3x3_nchw32", "dcnv2", "layer_norm", "vlfuse_i2t",
+         "dyconv_branch_coef", "dyconv_coef_group", "dyconv_fuse", "dyrelu_", "dyrelu_coef", "dyrelu_apply_", "dyrelu_layer_norm", "add_upsample_nearest_", "conv3x3", "conv3x3_nchw32", "conv3x3_nchw32_group", "conv3x3_nchw32_group_supported", "dcnv2", "layer_norm", "vlfuse_i2t",
          "vlfuse_t2i", "box_decode", "ml_nms", "post_select", "post_select_supported", "post_sort", "post_finalize", "roi_align", "swin_mlp", "swin_mlp2", "patch_merge_ln", "ms_deform_attn", "ms_deform_attn_q", "image_key_mask")
 
 

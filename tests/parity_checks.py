@@ -848,6 +848,39 @@ def check_conv3x3(dev):
             big[:, 5:5 + H * W] = x.permute(0, 2, 3, 1).reshape(B, H * W, 256).to(dev)
             y3 = ops.conv3x3_nchw32(big[:, 5:5 + H * W].reshape(B, H, W, 256), wp.to(dev), bias.to(dev), N)
             res.append(_stat(f"conv3x3 LDS-window, level view of a token buffer B={B} {H}x{W}", y3, ref, tol=2e-3))
+    res += check_conv3x3_group(dev)
+    return res
+
+
+def check_conv3x3_group(dev):
+    """mq_conv3x3_nchw32_group_fwd (csrc/conv_small3.hip): the 27-channel offset conv of every level of a pyramid in one launch (levels =
+    slices of ONE token buffer, as dyconv_tokens passes them) vs F.conv2d per level, and vs the per-level kernel (same products, other
+    fp32 summation order).  Pyramids: the tiny model's, one with tile-edge sizes (8 x 16 tiles: 8 / 9 rows, 16 / 17 columns), a single
+    level, and B = 3 so that the workgroups' tile runs cross image and level boundaries."""
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(31)
+    res = []
+    pyramids = [(2, [(20, 24), (10, 12), (5, 6), (3, 3), (2, 2)]), (3, [(9, 17), (8, 16), (1, 1)]), (1, [(7, 11)])]
+    if not QUICK:
+        pyramids.append((2, [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]))
+    for B, sizes in pyramids:
+        n = sum(h * w for h, w in sizes)
+        tok = torch.randn(B, n, 256, generator=g).to(H16)
+        w = (torch.randn(27, 256, 3, 3, generator=g) / 48).to(H16)
+        bias = torch.randn(27, generator=g).to(H16)
+        wp = w.permute(0, 2, 3, 1).reshape(27, -1)
+        wp = torch.cat([wp, wp.new_zeros(5, wp.shape[1])], 0).contiguous()
+        td, off, lv = tok.to(dev), 0, []
+        for (h, ww) in sizes:
+            lv.append(td[:, off:off + h * ww].reshape(B, h, ww, 256))
+            off += h * ww
+        assert ops.conv3x3_nchw32_group_supported(lv, 27)
+        got = ops.conv3x3_nchw32_group(lv, wp.to(dev), bias.to(dev), 27)
+        for l, (x, y) in enumerate(zip(lv, got)):
+            ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float(), bias.float(), padding=1)
+            res.append(_stat(f"conv3x3 group B={B} level {l} {sizes[l][0]}x{sizes[l][1]}: vs F.conv2d", y, ref, tol=2e-3))
+            one = ops.conv3x3_nchw32(x, wp.to(dev), bias.to(dev), 27)
+            res.append(_stat(f"conv3x3 group B={B} level {l} {sizes[l][0]}x{sizes[l][1]}: vs the per-level kernel (fp32 summation order)", y, one.float().cpu(), tol=2e-6))
     return res
 
 

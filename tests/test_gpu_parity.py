@@ -471,6 +471,17 @@ def _body_offset_conv_v2_kernel(dev, monkeypatch):
     _assert(pc.check_dyconv(dev))
 
 
+def _body_offset_conv_group_kernel(dev, monkeypatch):
+    """csrc/conv_small3.hip (MQ_OFFSET_CONV_VARIANT=3: the offset conv of every pyramid level in one launch of persistent workgroups that keep
+    the weights in registers): against F.conv2d and the per-level kernel, at the benchmark pyramid too; the DyConv block and the tiny
+    model on it."""
+    import parity_checks as pc
+    monkeypatch.setenv("MQ_OFFSET_CONV_VARIANT", "3")
+    _assert(pc.check_conv3x3_group(dev))
+    _assert(pc.check_dyconv(dev))
+    _assert(pc.check_full_model(dev))
+
+
 def _body_patch_merge_ln_kernel(dev, monkeypatch):
     """mq_patch_merge_ln_fwd (MQ_PATCH_MERGE_FUSED=1: Swin PatchMerging gather + LayerNorm in one kernel) next to F.pad + cat +
     mq_layernorm_fwd on the same inputs, then Swin + FPN with the switch on."""
@@ -552,7 +563,7 @@ def _isolated(body, timeout=900):
     assert r.returncode == 0, f"{body}: rc {r.returncode}\n{(r.stdout + r.stderr)[-3000:]}"
 
 
-@pytest.mark.parametrize("body", ["resident_attention_kernel", "layernorm2_kernel", "offset_conv_v2_kernel", "patch_merge_ln_kernel",
+@pytest.mark.parametrize("body", ["resident_attention_kernel", "layernorm2_kernel", "offset_conv_v2_kernel", "offset_conv_group_kernel", "patch_merge_ln_kernel",
                                   "fpn_convs_through_the_grouped_dcn_kernel", "nms_early_stop"])
 def test_opt_in_kernel(dev, body):
     _isolated(body)

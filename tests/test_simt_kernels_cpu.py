@@ -439,6 +439,44 @@ def test_patch_merge_ln_equals_cat_plus_layernorm(kernels, monkeypatch, dtype):
         kernels._CACHE.clear()
 
 
+# ---- the offset conv of all pyramid levels in one launch, weights in registers (csrc/conv_small3.hip, MQ_OFFSET_CONV_VARIANT=3: the default since round 4)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_offset_conv_group_kernel(kernels, monkeypatch, dtype):
+    """every level of a pyramid from one launch: against F.conv2d and against the per-level kernel (parity_checks.check_conv3x3_group:
+    tile-edge sizes, runs of tiles that cross image / level boundaries), then the DyConv block and the tiny model's head through it;
+    the ascending / descending / random wave orders of the emulator give the same bits (the exchange buffer aliases the window: barriers)"""
+    from mq_det_amd import ops
+    monkeypatch.setenv("MQ_OFFSET_CONV_VARIANT", "3")
+    assert ops.KERNELS["OFFSET_CONV_VARIANT"] == 3
+    kernels.use_dtype(dtype)
+    calls = []
+    real = ops.conv3x3_nchw32_group
+    monkeypatch.setattr(ops, "conv3x3_nchw32_group", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    try:
+        _assert_ok(kernels.check_conv3x3_group(CPU))
+        n0 = len(calls)
+        _assert_ok(kernels.check_dyconv(CPU))
+        assert len(calls) > n0, "the DyConv layer did not take the grouped offset conv"
+    finally:
+        kernels.use_dtype(torch.float16)
+    if dtype == torch.float16:
+        g = torch.Generator().manual_seed(8)
+        sizes = [(9, 17), (5, 9), (3, 5)]
+        lv = [torch.randn(2, h, w, 256, generator=g).half() for h, w in sizes]
+        wp = torch.zeros(32, 9 * 256, dtype=torch.float16)
+        wp[:27] = (torch.randn(27, 9 * 256, generator=g) / 48).half()
+        bias = torch.randn(27, generator=g).half()
+        import simt
+        base = real(lv, wp, bias, 27)
+        try:
+            for sched in (("descending", 0), ("random", 5), ("random", 11)):        # wave orders inside a workgroup: a missing barrier shows
+                simt.set_schedule(*sched)
+                for a, b_ in zip(base, real(lv, wp, bias, 27)):
+                    assert torch.equal(a, b_), sched
+        finally:
+            simt.set_schedule("ascending")
+
+
 # ---- out-of-bounds check: every library argument against a guard page (tests/simt/guard.py), in a subprocess
 def _oob(mode, names, env=None, timeout=1200):
     import subprocess

@@ -53,6 +53,8 @@ def main():
         vlfuse_text(dev, g, out)
     if only == "t2i_sweep":
         t2i_sweep(dev, g, out)
+    if only == "offset_conv":
+        offset_conv(dev, g, out)
     for r in out:
         print(json.dumps(r))
     if len(sys.argv) > 1:
@@ -161,6 +163,52 @@ def vlfuse(dev, g, out):
             out.append({"kernel": f"vlfuse_i2t {name} B={B} N={N} live keys={live}", "ms": round(ms, 4),
                         "TFLOPs": round(fl / ms / 1e9, 1), "frac_of_mfma_peak": round(fl / ms / 1e9 / 2500, 3),
                         "algorithmic_GBs": round(nb / ms / 1e6, 1), "max_abs_diff_vs_first": round(float((o - ref).abs().max()), 6)})
+
+
+def offset_conv(dev, g, out):
+    # ---- the offset conv of ONE DyConv layer at the bench pyramid (B = 8, five levels as slices of one token buffer): the per-level
+    # kernel on one stream and forked over five streams (what dyconv_tokens does), against the grouped launch (OFFSET_CONV_VARIANT 3)
+    sizes = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    B, C = 8, 256
+    w = torch.zeros(32, 9 * C)
+    w[:27] = torch.randn(27, 9 * C, generator=g) / 48
+    w, bias = w.half().to(dev), torch.randn(27, generator=g).half().to(dev)
+    tok = torch.randn(B, sum(h * w_ for h, w_ in sizes), C, generator=g).half().to(dev)
+    lv, off = [], 0
+    for (h, w_) in sizes:
+        lv.append(tok[:, off:off + h * w_].reshape(B, h, w_, C))
+        off += h * w_
+    nb = tok.numel() * 2 + B * 27 * 4 * sum(h * w_ for h, w_ in sizes)
+    side = [torch.cuda.Stream() for _ in range(4)]
+
+    def per_level():
+        return [ops.conv3x3_nchw32(x, w, bias, 27) for x in lv]
+
+    def forked():
+        main = torch.cuda.current_stream()
+        for s_ in side:
+            s_.wait_stream(main)
+        res = [None] * 5
+        for l in range(1, 5):
+            with torch.cuda.stream(side[l - 1]):
+                res[l] = ops.conv3x3_nchw32(lv[l], w, bias, 27)
+        res[0] = ops.conv3x3_nchw32(lv[0], w, bias, 27)
+        for s_ in side:
+            main.wait_stream(s_)
+        return res
+
+    ref = per_level()
+    got = ops.conv3x3_nchw32_group(lv, w, bias, 27)
+    diff = max(float((a - b_).abs().max()) for a, b_ in zip(ref, got))
+    for name, fn in (("per-level kernel v2, one stream (5 launches)", per_level), ("per-level kernel v2, five streams (5 launches + fork / join)", forked),
+                     ("grouped launch v3 (1 launch, persistent workgroups, weights in registers)", lambda: ops.conv3x3_nchw32_group(lv, w, bias, 27))):
+        ms = timeit(fn, n=50, warm=5)
+        out.append({"kernel": f"offset conv of one DyConv layer, B={B}, 5 levels: {name}", "ms": round(ms, 4), "algorithmic_GBs": round(nb / ms / 1e6, 1),
+                    "frac_of_hbm_peak": round(nb / ms / 1e6 / 8000, 3), "max_abs_diff_grouped_vs_per_level": diff})
+    for l, x in enumerate(lv[:2]):
+        ms = timeit(lambda: ops.conv3x3_nchw32_group([x], w, bias, 27), n=50, warm=5)
+        ms2 = timeit(lambda: ops.conv3x3_nchw32(x, w, bias, 27), n=50, warm=5)
+        out.append({"kernel": f"offset conv, level {l} alone {sizes[l]}: grouped kernel / per-level kernel", "ms": round(ms, 4), "ms_per_level_kernel": round(ms2, 4)})
 
 
 def dyconv_parts(dev, g, out):
