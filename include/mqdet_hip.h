@@ -264,6 +264,18 @@ int mq_dyconv_fuse(const void* y0, const float* coef0, int hs0, int ws0, const v
                    float* pool, int B, int H, int W, int C, void* stream);
 int mq_dyrelu_coef(const float* pool, const void* w0, const void* b0, const void* w2, const void* b2, float* coef,
                    int B, int n, int C, void* stream);
+/* The epilogue of a DyConv layer for ALL pyramid levels in two launches (`levels` is a HOST array of <= 8 entries copied into the kernel
+ * arguments): mq_dyconv_fuse of every level as one work list, then mq_dyrelu_coef of every level (grid B x levels).  Per level: the
+ * arguments of those two entry points -- y / coef / hs / ws of its 1 .. 3 branches, out (batch stride out_bs), pool [B, ceil(H*W/128), C]
+ * fp32 workspace, relu_coef [B,4,C] fp32 out.  Same arithmetic and summation order as the per-level entry points: equal results.
+ * C == 256.  KERNELS["DYCONV_EPILOGUE_GROUPED"]. */
+typedef struct mq_fuse_level {
+  const void* y[3]; const float* coef[3]; int hs[3], ws[3];
+  int nbranches, H, W, reserved;
+  void* out; long out_bs; float* pool; float* relu_coef;
+} mq_fuse_level;
+int mq_dyconv_epilogue_group(const mq_fuse_level* levels, int nl, const void* w0, const void* b0, const void* w2, const void* b2,
+                             int B, int C, void* stream);
 int mq_dyrelu_apply(void* x, const float* coef, int B, int n, int C, long x_bs, void* stream);
 /* FPN top-down step (backbone/fpn.py:82-95) in place: dst [B,H,W,C] += nearest-up-sampled src [B,Hc,Wc,C] (NHWC 16-bit, C % 8 == 0;
  * source index = min(floor(i * (float)(in / out)), in - 1) as F.interpolate(mode="nearest", size=(H, W))). */
@@ -445,6 +457,7 @@ MQ_BF16_TWIN(mq_dyconv_coef)
 MQ_BF16_TWIN(mq_dyconv_coef_group)
 MQ_BF16_TWIN(mq_dyconv_fuse)
 MQ_BF16_TWIN(mq_dyrelu_coef)
+MQ_BF16_TWIN(mq_dyconv_epilogue_group)
 MQ_BF16_TWIN(mq_dyrelu_apply)
 MQ_BF16_TWIN(mq_add_upsample_nearest)
 MQ_BF16_TWIN(mq_dyrelu_ln_fwd)

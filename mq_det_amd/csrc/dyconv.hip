@@ -221,16 +221,16 @@ struct FuseParams {
 // align_corners = True) -- host order: direct branches first.  Every thread walks its positions U = 4 at a time and issues
 // ALL loads of the four positions (<= 24 x 16 B) before the first use: the first version consumed each position's loads
 // before issuing the next one's -- one dependent chain per thread, 1.3 TB/s on an HBM-bound pass.
-template <int ND, bool HB>
-__global__ __launch_bounds__(256) void dyconv_fuse_kernel(FuseParams p) {
-  constexpr int U = 4, NBR = ND + (HB ? 1 : 0);
-  __shared__ float red[256 * 8];
-  const int b = blockIdx.y;
+// (body shared by the per-level kernel and the grouped one: b = image, blk / nblk = this workgroup's 128-position block of the level)
+// U = positions whose loads are in flight together (the visiting order of a thread's positions, hence every sum, does not depend on it)
+template <int ND, bool HB, int U = 4>
+__device__ __forceinline__ void dyconv_fuse_body(const FuseParams& p, int b, int blk, int nblk, float* red) {
+  constexpr int NBR = ND + (HB ? 1 : 0);
   const int cpt = p.C / 8;
   const int lane_c = threadIdx.x % cpt, rg = threadIdx.x / cpt, nrg = 256 / cpt;
   const int c0 = lane_c * 8;
   const int n = p.H * p.W;
-  const int p0 = blockIdx.x * p.rows_per_block, p1 = min(n, p0 + p.rows_per_block);
+  const int p0 = blk * p.rows_per_block, p1 = min(n, p0 + p.rows_per_block);
   float A[NBR][8], Bc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) Bc[j] = 0.f;
@@ -304,8 +304,55 @@ __global__ __launch_bounds__(256) void dyconv_fuse_kernel(FuseParams p) {
   for (int c = threadIdx.x; c < p.C; c += 256) {
     float acc = 0.f;
     for (int g = 0; g < nrg; ++g) acc += red[(g * cpt + c / 8) * 8 + (c % 8)];
-    p.pool[((long)b * gridDim.x + blockIdx.x) * p.C + c] = acc;
+    p.pool[((long)b * nblk + blk) * p.C + c] = acc;
   }
+}
+
+template <int ND, bool HB>
+__global__ __launch_bounds__(256) void dyconv_fuse_kernel(FuseParams p) {
+  __shared__ float red[256 * 8];
+  dyconv_fuse_body<ND, HB>(p, blockIdx.y, blockIdx.x, gridDim.x, red);
+}
+
+// Grouped form: the epilogues of ALL levels of a DyConv layer in one launch (KERNELS["DYCONV_EPILOGUE_GROUPED"]).  Per level they were a
+// launch each on five streams (P5 .. P7: 72 / 24 / 8 workgroups) behind a fork / join; the blocks of all levels form one work list,
+// the branch mix of a level (1 .. 3 direct branches, one bilinear) picks the body.
+static constexpr int FUSE_MAX_LEVELS = 8;
+struct FuseGroup {
+  FuseParams lv[FUSE_MAX_LEVELS];
+  int first_block[FUSE_MAX_LEVELS + 1];
+  int nblk[FUSE_MAX_LEVELS], kind[FUSE_MAX_LEVELS];          // kind = 2 * nd + (bilinear branch ? 1 : 0)
+  int n;
+};
+__global__ __launch_bounds__(256, 3) void dyconv_fuse_group_kernel(FuseGroup g) {
+  __shared__ float red[256 * 8];
+  int L = 0;
+  while (L + 1 < g.n && (int)blockIdx.x >= g.first_block[L + 1]) ++L;
+  const FuseParams& p = g.lv[L];
+  const int t = blockIdx.x - g.first_block[L], nblk = g.nblk[L];
+  const int b = t / nblk, blk = t - b * nblk;
+  switch (g.kind[L]) {
+    case 2: dyconv_fuse_body<1, false>(p, b, blk, nblk, red); break;
+    case 4: dyconv_fuse_body<2, false>(p, b, blk, nblk, red); break;
+    case 6: dyconv_fuse_body<3, false>(p, b, blk, nblk, red); break;
+    case 1: dyconv_fuse_body<0, true>(p, b, blk, nblk, red); break;
+    case 3: dyconv_fuse_body<1, true>(p, b, blk, nblk, red); break;
+    default: dyconv_fuse_body<2, true, 3>(p, b, blk, nblk, red); break;     // U = 3: <= 168 VGPRs, three waves per SIMD like the P3 body
+  }
+}
+
+// direct branches first, the (single) coarser one last; false: more than one coarser branch
+static bool fuse_params(FuseParams& p, const FuseBranch* in, int nbranches, void* out, long out_bs, float* pool, int B, int H, int W, int C,
+                        int& nd, int& nbil) {
+  nd = nbil = 0;
+  for (int k = 0; k < nbranches; ++k)
+    if (in[k].hs == H && in[k].ws == W) p.br[nd++] = in[k];
+  for (int k = 0; k < nbranches; ++k)
+    if (!(in[k].hs == H && in[k].ws == W)) { p.br[nd + nbil] = in[k]; ++nbil; }
+  for (int k = nbranches; k < 3; ++k) p.br[k] = in[0];
+  p.nbr = nbranches; p.out = (half_t*)out; p.out_bs = out_bs; p.pool = pool; p.B = B; p.H = H; p.W = W; p.C = C;
+  p.rows_per_block = 128;
+  return nbil <= 1;
 }
 
 extern "C" int MQ_SYM(mq_dyconv_fuse)(const void* y0, const float* coef0, int hs0, int ws0, const void* y1, const float* coef1,
@@ -316,13 +363,7 @@ extern "C" int MQ_SYM(mq_dyconv_fuse)(const void* y0, const float* coef0, int hs
   FuseParams p;
   const FuseBranch in[3] = {{(const half_t*)y0, coef0, hs0, ws0}, {(const half_t*)y1, coef1, hs1, ws1}, {(const half_t*)y2, coef2, hs2, ws2}};
   int nd = 0, nbil = 0;
-  for (int k = 0; k < nbranches; ++k)                        // direct branches first, the (single) coarser one last
-    if (in[k].hs == H && in[k].ws == W) p.br[nd++] = in[k];
-  for (int k = 0; k < nbranches; ++k)
-    if (!(in[k].hs == H && in[k].ws == W)) { p.br[nd + nbil] = in[k]; ++nbil; }
-  if (nbil > 1) return -2;
-  p.nbr = nbranches; p.out = (half_t*)out; p.out_bs = out_bs; p.pool = pool; p.B = B; p.H = H; p.W = W; p.C = C;
-  p.rows_per_block = 128;
+  if (!fuse_params(p, in, nbranches, out, out_bs, pool, B, H, W, C, nd, nbil)) return -2;
   dim3 grid((H * W + p.rows_per_block - 1) / p.rows_per_block, B);
   hipStream_t st = (hipStream_t)stream;
   if (nbil == 0) {
@@ -341,13 +382,11 @@ extern "C" int MQ_SYM(mq_dyconv_fuse)(const void* y0, const float* coef0, int hs
 // ---------------------------------------------------------------------------------------------- DyReLU
 // one block (256 threads) per batch element: y = pool / n -> fc0 (C -> C/4) ReLU -> fc2 (C/4 -> 4C) -> h_sigmoid
 // coef[b, 0..3, c] = a1, b1, a2, b2  (lambda_a = 2, init_a = (1, 0), init_b = (0, 0))
-__global__ __launch_bounds__(1024) void dyrelu_coef_kernel(const float* __restrict__ pool, int nblk,
-                                                           const half_t* __restrict__ w0,
-                                                           const half_t* __restrict__ b0, const half_t* __restrict__ w2,
-                                                           const half_t* __restrict__ b2, float* __restrict__ coef, int n,
-                                                           int C) {
-  __shared__ float yv[256], hv[64], part[4][256];
-  const int b = blockIdx.x, t = threadIdx.x & 255, grp = threadIdx.x >> 8;
+__device__ __forceinline__ void dyrelu_coef_body(const float* __restrict__ pool, int nblk, const half_t* __restrict__ w0,
+                                                 const half_t* __restrict__ b0, const half_t* __restrict__ w2,
+                                                 const half_t* __restrict__ b2, float* __restrict__ coef, int n, int C, int b,
+                                                 float* yv, float* hv, float (*part)[256]) {
+  const int t = threadIdx.x & 255, grp = threadIdx.x >> 8;
   const int S = C / 4;                                   // C == 256, S == 64 (checked by the host wrapper)
   // spatial mean: fixed-order sum of the per-block partials.  The P3 level has 132 of them per image: one dependent chain of 17
   // rounds of 8 loads was 42 us (the launch sits between the fuse kernel and the next LayerNorm, on the critical path); four
@@ -399,6 +438,70 @@ __global__ __launch_bounds__(1024) void dyrelu_coef_kernel(const float* __restri
     float v = which == 0 ? (hs - 0.5f) * 2.f + 1.f : (which == 2 ? (hs - 0.5f) * 2.f : hs - 0.5f);
     coef[((long)b * 4 + which) * C + c] = v;
   }
+}
+
+__global__ __launch_bounds__(1024) void dyrelu_coef_kernel(const float* __restrict__ pool, int nblk,
+                                                           const half_t* __restrict__ w0,
+                                                           const half_t* __restrict__ b0, const half_t* __restrict__ w2,
+                                                           const half_t* __restrict__ b2, float* __restrict__ coef, int n,
+                                                           int C) {
+  __shared__ float yv[256], hv[64], part[4][256];
+  dyrelu_coef_body(pool, nblk, w0, b0, w2, b2, coef, n, C, blockIdx.x, yv, hv, part);
+}
+
+// all levels of a layer: grid (B, levels) -- the five launches of 8 workgroups each were a chain link of ~20 us apiece on five streams
+struct ReluGroup {
+  const float* pool[FUSE_MAX_LEVELS]; float* coef[FUSE_MAX_LEVELS];
+  int nblk[FUSE_MAX_LEVELS], n[FUSE_MAX_LEVELS];
+  const half_t* w0; const half_t* b0; const half_t* w2; const half_t* b2;
+  int C;
+};
+__global__ __launch_bounds__(1024) void dyrelu_coef_group_kernel(ReluGroup g) {
+  __shared__ float yv[256], hv[64], part[4][256];
+  const int L = blockIdx.y;
+  dyrelu_coef_body(g.pool[L], g.nblk[L], g.w0, g.b0, g.w2, g.b2, g.coef[L], g.n[L], g.C, blockIdx.x, yv, hv, part);
+}
+
+struct mq_fuse_level {          // mirrors include/mqdet_hip.h
+  const void* y[3]; const float* coef[3]; int hs[3], ws[3];
+  int nbranches, H, W, reserved;
+  void* out; long out_bs; float* pool; float* relu_coef;
+};
+
+// The epilogue of a DyConv layer for all pyramid levels in two launches: mq_dyconv_fuse of every level (one work list), then
+// mq_dyrelu_coef of every level.  levels[i]: the arguments of those two entry points (pool [B, ceil(H*W/128), C] workspace,
+// relu_coef [B,4,C] out).  C == 256, <= 8 levels.
+extern "C" int MQ_SYM(mq_dyconv_epilogue_group)(const mq_fuse_level* levels, int nl, const void* w0, const void* b0, const void* w2,
+                                                const void* b2, int B, int C, void* stream) {
+  if (B <= 0 || nl <= 0) return 0;
+  if (C != 256 || nl > FUSE_MAX_LEVELS) return -1;
+  FuseGroup g;
+  ReluGroup r;
+  g.n = 0;
+  g.first_block[0] = 0;
+  for (int i = 0; i < nl; ++i) {
+    const mq_fuse_level& a = levels[i];
+    if (a.nbranches < 1 || a.nbranches > 3 || a.H <= 0 || a.W <= 0) return -1;
+    FuseBranch in[3];
+    for (int k = 0; k < 3; ++k) in[k] = FuseBranch{(const half_t*)a.y[k], a.coef[k], a.hs[k], a.ws[k]};
+    int nd = 0, nbil = 0;
+    if (!fuse_params(g.lv[g.n], in, a.nbranches, a.out, a.out_bs, a.pool, B, a.H, a.W, C, nd, nbil)) return -2;
+    g.kind[g.n] = 2 * nd + nbil;
+    g.nblk[g.n] = (a.H * a.W + 127) / 128;
+    g.first_block[g.n + 1] = g.first_block[g.n] + B * g.nblk[g.n];
+    r.pool[g.n] = a.pool; r.coef[g.n] = a.relu_coef; r.nblk[g.n] = g.nblk[g.n]; r.n[g.n] = a.H * a.W;
+    ++g.n;
+  }
+  for (int i = g.n; i < FUSE_MAX_LEVELS; ++i) {
+    g.lv[i] = g.lv[0]; g.nblk[i] = g.nblk[0]; g.kind[i] = g.kind[0]; g.first_block[i + 1] = g.first_block[g.n];
+    r.pool[i] = r.pool[0]; r.coef[i] = r.coef[0]; r.nblk[i] = r.nblk[0]; r.n[i] = r.n[0];
+  }
+  r.w0 = (const half_t*)w0; r.b0 = (const half_t*)b0; r.w2 = (const half_t*)w2; r.b2 = (const half_t*)b2; r.C = C;
+  hipLaunchKernelGGL(dyconv_fuse_group_kernel, dim3((unsigned)g.first_block[g.n]), dim3(256), 0, (hipStream_t)stream, g);
+  MQ_CHECK_LAUNCH();
+  hipLaunchKernelGGL(dyrelu_coef_group_kernel, dim3(B, g.n), dim3(1024), 0, (hipStream_t)stream, r);
+  MQ_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int MQ_SYM(mq_dyrelu_coef)(const float* pool, const void* w0, const void* b0, const void* w2, const void* b2,

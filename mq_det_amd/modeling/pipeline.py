@@ -729,7 +729,17 @@ def dyconv_tokens(P, cfg, b, tok, sizes, defer_relu=False):
             ops.dyrelu_coef(pool, H * W, *rw, out=relu_coef[lvl])
         else:
             ops.dyrelu_(o, pool, *rw)
-    fan_out(epilogue)
+    if ops.KERNELS["DYCONV_EPILOGUE_GROUPED"] == 1 and C == 256 and nl <= 8:
+        # all levels in two launches on this stream: fuse (one work list), DYReLU coefficients (grid B x levels)
+        rw = (P[b + ".relu.fc.0.weight"], P[b + ".relu.fc.0.bias"], P[b + ".relu.fc.2.weight"], P[b + ".relu.fc.2.bias"])
+        rc = relu_coef if defer_relu else torch.empty(nl, Bn, 4, C, dtype=torch.float32, device=tok.device)
+        ops.dyconv_epilogue_group(
+            [([(y, coef, Ho, Wo) for (l2, k, nb), (y, (Ho, Wo), sums), coef in zip(owner, ys, coefs) if l2 == lvl], sizes[lvl][0], sizes[lvl][1],
+              out[:, offs[lvl]:offs[lvl + 1]]) for lvl in range(nl)], *rw, rc)
+        if not defer_relu:
+            fan_out(lambda lvl: ops.dyrelu_apply_(out[:, offs[lvl]:offs[lvl + 1]], rc[lvl]))
+    else:
+        fan_out(epilogue)
     return (out, relu_coef) if defer_relu else out
 
 

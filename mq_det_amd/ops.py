@@ -13,7 +13,7 @@ _LIB = None
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmqdet_hip.so")
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
-EXPECTED_ABI = 23        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
+EXPECTED_ABI = 24        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
 _SIGNATURES = {
     "mq_abi_version": (_i, []),
     "mq_attn_workspace_bytes": (_l, [_i, _i, _i, _i, _i]),
@@ -46,6 +46,7 @@ _SIGNATURES = {
     "mq_dyconv_coef_group": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _vp]),
     "mq_dyconv_fuse": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _l, _vp, _i, _i, _i, _i, _vp]),
     "mq_dyrelu_coef": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mq_dyconv_epilogue_group": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mq_add_upsample_nearest": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_dyrelu_ln_fwd": (_i, [_vp, _l, _vp, _vp, _i, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "mq_dyrelu_apply": (_i, [_vp, _vp, _i, _i, _i, _l, _vp]),
@@ -66,7 +67,7 @@ _SIGNATURES = {
 # entry points with 16-bit operands also exist as <name>_bf16 (same signature; include/mqdet_hip.h MQ_BF16_TWIN)
 BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_text_fwd", "mq_patch_embed_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_window_attn_qkv_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
               "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_patch_merge_ln_fwd", "mq_swin_mlp_fwd", "mq_swin_mlp2_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_conv3x3_nchw32_group_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
-              "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyrelu_apply", "mq_dyrelu_ln_fwd", "mq_add_upsample_nearest",
+              "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyconv_epilogue_group", "mq_dyrelu_apply", "mq_dyrelu_ln_fwd", "mq_add_upsample_nearest",
               "mq_align_scores_fwd", "mq_align_fused_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
 for _n in BF16_TWINS:
     _SIGNATURES[_n + "_bf16"] = _SIGNATURES[_n]
@@ -100,6 +101,8 @@ KERNEL_DEFAULTS = {
                                  # 64 us in FRONT of the 130 us main kernel) on a side stream BESIDE the main kernel (a tail workgroup fits on a CU next
                                  # to a main one); 0: one after the other.  A/B on the MI355X (GPU call 12): 437 vs 441 images/s over two runs each --
                                  # no gain (the main kernel leaves the tail's waves no issue slots), stays off
+    "DYCONV_EPILOGUE_GROUPED": 0,  # 1: mq_dyconv_epilogue_group -- the fuse pass and the DYReLU coefficients of ALL levels of a DyConv layer in two launches
+                                 # on the main stream (were 10 launches on five streams behind a fork / join); equal results
     "PATCH_EMBED_FUSED": 1,      # 1: mq_patch_embed_fwd (Swin PatchEmbed projection + patch_embed.norm + the first norm1 in one pass over the pixels);
                                  # 0: permute copies + library GEMM (K = 48) + two LayerNorm launches (354 us at B = 8)
     "BERT_QKV_FUSED": 1,         # 1: BERT layers = ONE qkv GEMM + mq_attn_text_fwd (V row-major, transposed out of LDS; registers / LDS sized by the
@@ -886,6 +889,42 @@ def dyconv_fuse(branches, H, W, out=None):
     with _timed("dyconv_fuse", sum(b_[0].numel() * 2 for b_ in branches) + out.shape[0] * out.shape[1] * C * 2):
         _chk(_fn(lib, "mq_dyconv_fuse", *[b_[0] for b_ in branches])(*args, len(branches), _ptr(out), out.stride(0), _ptr(pool), B, H, W, C, _stream()), "mq_dyconv_fuse")
     return out, pool
+
+
+class _FuseLevel(ctypes.Structure):
+    """mq_fuse_level of include/mqdet_hip.h."""
+    _fields_ = [("y", _vp * 3), ("coef", _vp * 3), ("hs", _i * 3), ("ws", _i * 3), ("nbranches", _i), ("H", _i), ("W", _i), ("reserved", _i),
+                ("out", _vp), ("out_bs", _l), ("pool", _vp), ("relu_coef", _vp)]
+
+
+def dyconv_epilogue_group(levels, w0, b0, w2, b2, relu_coef):
+    """dyconv_fuse + dyrelu_coef of every pyramid level of a DyConv layer in two launches (mq_dyconv_epilogue_group).
+    levels: list of (branches, H, W, out) with the arguments of dyconv_fuse; relu_coef [NL, B, 4, C] fp32 receives the DYReLU
+    coefficients of every level.  Same arithmetic as the per-level calls (equal results)."""
+    lib = load_library()
+    _need_gpu(w0, b0, w2, b2, relu_coef)
+    y0 = levels[0][0][0][0]
+    B, _, C = y0.shape
+    assert 0 < len(levels) <= 8 and C == 256 and relu_coef.shape == (len(levels), B, 4, C) and relu_coef.is_contiguous() and relu_coef.dtype == torch.float32
+    assert w0.is_contiguous() and w2.is_contiguous() and w0.dtype == y0.dtype and y0.dtype in _H16
+    arr = (_FuseLevel * len(levels))()
+    keep, nbytes = [], 0
+    for l, (a, (branches, H, W, out)) in enumerate(zip(arr, levels)):
+        assert out.shape == (B, H * W, C) and out.dtype == y0.dtype and out.stride(2) == 1 and out.stride(1) == C and 1 <= len(branches) <= 3
+        pool = torch.empty(B, (H * W + 127) // 128, C, dtype=torch.float32, device=y0.device)
+        keep.append(pool)
+        for k, (y, cf, hs, ws) in enumerate(branches):
+            _need_gpu(y, cf)
+            assert y.is_contiguous() and cf.is_contiguous() and y.shape == (B, hs * ws, C) and y.dtype == y0.dtype and cf.dtype == torch.float32
+            a.y[k], a.coef[k], a.hs[k], a.ws[k] = y.data_ptr(), cf.data_ptr(), hs, ws
+            nbytes += y.numel() * 2
+        a.nbranches, a.H, a.W, a.reserved = len(branches), H, W, 0
+        a.out, a.out_bs, a.pool, a.relu_coef = out.data_ptr(), out.stride(0), pool.data_ptr(), relu_coef[l].data_ptr()
+        nbytes += B * H * W * C * 2
+    with _timed("dyconv_epilogue_group", nbytes):
+        _chk(_fn(lib, "mq_dyconv_epilogue_group", y0)(ctypes.cast(arr, _vp), len(levels), _ptr(w0), _ptr(b0), _ptr(w2), _ptr(b2), B, C, _stream()),
+             "mq_dyconv_epilogue_group")
+    return relu_coef
 
 
 def dyrelu_(x, pool, w0, b0, w2, b2):

@@ -576,6 +576,13 @@ def ms_deform_attn_q(value, spatial_shapes, qproj, ref, heads, out_dtype=None, v
                           out_dtype)
 
 
+def dyconv_epilogue_group(levels, w0, b0, w2, b2, relu_coef):
+    for l, (branches, H, W, out) in enumerate(levels):
+        _, pool = dyconv_fuse(branches, H, W, out=out)
+        dyrelu_coef(pool, H * W, w0, b0, w2, b2, out=relu_coef[l])
+    return relu_coef
+
+
 def dyconv_coef_group(items, attn_w, attn_b, groups, eps):
     out = []
     for it in items:
@@ -588,7 +595,7 @@ def dyconv_coef_group(items, attn_w, attn_b, groups, eps):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # every emulated entry point, in one place: tests patch them into mq_det_amd.ops (or into a stand-in namespace) with these helpers
 NAMES = ("attention", "attention4", "attention_text", "patch_embed", "window_attention", "window_attention_qkv", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores", "align_fused",
-         "dyconv_branch_coef", "dyconv_coef_group", "dyconv_fuse", "dyrelu_", "dyrelu_coef", "dyrelu_apply_", "dyrelu_layer_norm", "add_upsample_nearest_", "conv3x3", "conv3x3_nchw32", "conv3x3_nchw32_group", "conv3x3_nchw32_group_supported", "dcnv2", "layer_norm", "vlfuse_i2t",
+         "dyconv_branch_coef", "dyconv_coef_group", "dyconv_epilogue_group", "dyconv_fuse", "dyrelu_", "dyrelu_coef", "dyrelu_apply_", "dyrelu_layer_norm", "add_upsample_nearest_", "conv3x3", "conv3x3_nchw32", "conv3x3_nchw32_group", "conv3x3_nchw32_group_supported", "dcnv2", "layer_norm", "vlfuse_i2t",
          "vlfuse_t2i", "box_decode", "ml_nms", "post_select", "post_select_supported", "post_sort", "post_finalize", "roi_align", "swin_mlp", "swin_mlp2", "patch_merge_ln", "ms_deform_attn", "ms_deform_attn_q", "image_key_mask")
 
 

@@ -852,6 +852,36 @@ def check_conv3x3(dev):
     return res
 
 
+def check_dyconv_epilogue_group(dev):
+    """mq_dyconv_epilogue_group (csrc/dyconv.hip): a DyConv layer of the tiny model with its epilogue (GroupNorm affine + up-sampling +
+    scale attention + branch mean, DYReLU coefficients) as two launches for all levels == the same layer through the per-level launches,
+    bit for bit (same bodies, same summation order), with the DYReLU deferred and applied; pyramids with 1 .. 3 branches per level."""
+    from mq_det_amd import ops
+    from mq_det_amd.modeling import pipeline
+    spec, sd, cfg, model, P = tiny(dev)
+    g = torch.Generator().manual_seed(33)
+    res = []
+    b = "rpn.head.dyhead_tower.2"
+    saved = ops.KERNELS["DYCONV_EPILOGUE_GROUPED"]
+    try:
+        for sizes in ([(20, 24), (10, 12), (5, 6), (3, 3), (2, 2)], [(17, 9), (9, 5)], [(13, 21)]):
+            feats = [torch.randn(2, 256, h, w, generator=g).to(H16).to(dev).contiguous(memory_format=torch.channels_last) for h, w in sizes]
+            tok, szs = pipeline._to_tokens(feats)
+            outs = {}
+            with torch.no_grad():
+                for mode in (0, 1):
+                    ops.KERNELS["DYCONV_EPILOGUE_GROUPED"] = mode
+                    outs[mode] = (pipeline.dyconv_tokens(P, cfg, b, tok.contiguous(), szs, defer_relu=True), pipeline.dyconv_tokens(P, cfg, b, tok.contiguous(), szs))
+            (pre0, c0), o0 = outs[0]
+            (pre1, c1), o1 = outs[1]
+            res.append(_stat(f"dyconv epilogue grouped == per level, {len(sizes)} levels: output before DYReLU (exact)", pre1, pre0.float().cpu(), tol=0.0))
+            res.append(_stat(f"dyconv epilogue grouped == per level, {len(sizes)} levels: DYReLU coefficients (exact)", c1, c0.float().cpu(), tol=0.0))
+            res.append(_stat(f"dyconv epilogue grouped == per level, {len(sizes)} levels: output with DYReLU applied (exact)", o1, o0.float().cpu(), tol=0.0))
+    finally:
+        ops.KERNELS["DYCONV_EPILOGUE_GROUPED"] = saved
+    return res
+
+
 def check_conv3x3_group(dev):
     """mq_conv3x3_nchw32_group_fwd (csrc/conv_small3.hip): the 27-channel offset conv of every level of a pyramid in one launch (levels =
     slices of ONE token buffer, as dyconv_tokens passes them) vs F.conv2d per level, and vs the per-level kernel (same products, other
@@ -1035,6 +1065,7 @@ def all_checks(dev):
             ("attention", lambda: check_attention_text(dev)),
             ("swin", lambda: check_patch_embed(dev)),
             ("post", lambda: check_post_fused(dev)),
+            ("dyconv", lambda: check_dyconv_epilogue_group(dev)),
             ("window_attn", lambda: check_window_attention(dev)),
             ("swin_fpn", lambda: check_swin_fpn(dev)),
             ("gcp", lambda: check_gcp_block(dev)),

@@ -482,6 +482,16 @@ def _body_offset_conv_group_kernel(dev, monkeypatch):
     _assert(pc.check_full_model(dev))
 
 
+def _body_dyconv_epilogue_group(dev, monkeypatch):
+    """mq_dyconv_epilogue_group (MQ_DYCONV_EPILOGUE_GROUPED=1: fuse pass + DYReLU coefficients of all levels of a DyConv layer in two launches):
+    equal to the per-level launches bit for bit; the DyConv block and the tiny model with the switch on."""
+    import parity_checks as pc
+    _assert(pc.check_dyconv_epilogue_group(dev))
+    monkeypatch.setenv("MQ_DYCONV_EPILOGUE_GROUPED", "1")
+    _assert(pc.check_dyconv(dev))
+    _assert(pc.check_full_model(dev))
+
+
 def _body_patch_merge_ln_kernel(dev, monkeypatch):
     """mq_patch_merge_ln_fwd (MQ_PATCH_MERGE_FUSED=1: Swin PatchMerging gather + LayerNorm in one kernel) next to F.pad + cat +
     mq_layernorm_fwd on the same inputs, then Swin + FPN with the switch on."""
@@ -563,7 +573,7 @@ def _isolated(body, timeout=900):
     assert r.returncode == 0, f"{body}: rc {r.returncode}\n{(r.stdout + r.stderr)[-3000:]}"
 
 
-@pytest.mark.parametrize("body", ["resident_attention_kernel", "layernorm2_kernel", "offset_conv_v2_kernel", "offset_conv_group_kernel", "patch_merge_ln_kernel",
+@pytest.mark.parametrize("body", ["resident_attention_kernel", "layernorm2_kernel", "offset_conv_v2_kernel", "offset_conv_group_kernel", "dyconv_epilogue_group", "patch_merge_ln_kernel",
                                   "fpn_convs_through_the_grouped_dcn_kernel", "nms_early_stop"])
 def test_opt_in_kernel(dev, body):
     _isolated(body)

@@ -477,6 +477,27 @@ def test_offset_conv_group_kernel(kernels, monkeypatch, dtype):
             simt.set_schedule("ascending")
 
 
+# ---- the DyConv epilogue of all levels in two launches (csrc/dyconv.hip, opt-in: MQ_DYCONV_EPILOGUE_GROUPED=1)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_dyconv_epilogue_group(kernels, monkeypatch, dtype):
+    """grouped == per-level launches bit for bit (1 .. 5 levels, every branch mix), then the DyConv block and the tiny model with the switch on"""
+    from mq_det_amd import ops
+    kernels.use_dtype(dtype)
+    try:
+        _assert_ok(kernels.check_dyconv_epilogue_group(CPU))
+        monkeypatch.setenv("MQ_DYCONV_EPILOGUE_GROUPED", "1")
+        assert ops.KERNELS["DYCONV_EPILOGUE_GROUPED"] == 1
+        calls = []
+        real = ops.dyconv_epilogue_group
+        monkeypatch.setattr(ops, "dyconv_epilogue_group", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        _assert_ok(kernels.check_dyconv(CPU))
+        assert calls, "the DyConv layer did not take the grouped epilogue"
+        if dtype == torch.float16:
+            _assert_ok(kernels.check_full_model(CPU))
+    finally:
+        kernels.use_dtype(torch.float16)
+
+
 # ---- out-of-bounds check: every library argument against a guard page (tests/simt/guard.py), in a subprocess
 def _oob(mode, names, env=None, timeout=1200):
     import subprocess
