@@ -442,6 +442,7 @@ def kernel_rooflines(kern, steps, Bn, n_tok, embed=96):
     # ---- HBM-bound kernels: algorithmic bytes (every input read once, every output written once) / time
     groups = (("layernorm_kernel (all LayerNorms, residual add fused)", "layernorm_c"), ("window_attn_kernel (Swin W-MSA / SW-MSA)", "window_attn_c"),
               ("dyconv_fuse_kernel (GroupNorm affine + up-sampling + scale attention + branch mean)", "dyconv_fuse"),
+              ("dyconv_fuse_group_kernel + dyrelu_coef_group_kernel (the same epilogue, all levels of a layer in two launches)", "dyconv_epilogue_group"),
               ("dyrelu_apply_kernel", "dyrelu_apply"), ("conv3x3_small_kernel (27-channel DyConv offset conv)", "conv3x3_small"),
               ("conv3x3_group_kernel (27-channel DyConv offset conv, all levels of a layer in one launch, weights in registers)", "conv3x3_group"),
               ("align_scores_kernel (sigmoid + token->class mean + threshold)", "align_scores"),

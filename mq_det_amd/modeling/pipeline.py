@@ -548,7 +548,8 @@ def language_backbone(P, cfg, input_ids, attention_mask, vision, images, idx, wa
         x, x32 = _bert(P, f"{p}.encoder.layer.{i}", x, x32, key_bias, False, kv_len, max_kv=max_kv)
         hidden.append(x if x32 is None else x32)
     n = LB.N_LAYERS
-    feats = torch.stack(hidden[-n:], 1).float().mean(1) / n
+    # (one layer -- the shipped configs: mean over one tensor / 1 is the tensor; three launches of the serial language chain less)
+    feats = hidden[-1].float() if n == 1 else torch.stack(hidden[-n:], 1).float().mean(1) / n
     m = attention_mask.unsqueeze(-1).float()
     embedded = feats * m
     aggregate = embedded.sum(1) / attention_mask.sum(-1, keepdim=True).float()

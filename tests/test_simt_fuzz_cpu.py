@@ -351,6 +351,59 @@ def test_round4_operators_random_shapes(ops):
         assert torch.equal(hc.int(), fc.int()) and torch.equal(ho, fo), what + f": finalize K={K} K2={K2}"
 
 
+def test_grouped_dyconv_kernels_random_pyramids(ops):
+    """mq_conv3x3_nchw32_group_fwd and mq_dyconv_epilogue_group on random pyramids (1 .. 6 levels, level sizes around the 8 x 16 tile and
+    the 128-position block edges, levels as slices of one token buffer, B = 1 .. 3): the conv against the per-level kernel (fp32 summation
+    order apart) and F.conv2d; the epilogue against the per-level launches (bit for bit) with every branch mix (1 .. 3 direct branches,
+    with / without a coarser bilinear one)."""
+    import torch.nn.functional as F
+    rng = random.Random(5005 + SEED)
+    g = torch.Generator().manual_seed(5005 + SEED)
+    for it in range(3 * N_DRAWS):
+        B, nl = rng.randint(1, 3), rng.randint(1, 6)
+        sizes = [(_edge(rng, (8, 16), 24), _edge(rng, (16, 32), 40)) for _ in range(nl)]
+        tok = torch.randn(B, sum(h * w_ for h, w_ in sizes) + 3, 256, generator=g).half()
+        w = (torch.randn(27, 256, 3, 3, generator=g) / 48).half()
+        bias = torch.randn(27, generator=g).half()
+        wp = torch.cat([w.permute(0, 2, 3, 1).reshape(27, -1), torch.zeros(5, 9 * 256, dtype=torch.float16)], 0).contiguous()
+        lv, off = [], 3
+        for (h, w_) in sizes:
+            lv.append(tok[:, off:off + h * w_].reshape(B, h, w_, 256))
+            off += h * w_
+        got = ops.conv3x3_nchw32_group(lv, wp, bias, 27)
+        for l, (x, y) in enumerate(zip(lv, got)):
+            what = f"offset conv group draw {it}: B={B} sizes={sizes} level {l}"
+            _close(y, ops.conv3x3_nchw32(x, wp, bias, 27), what + " vs the per-level kernel", 2e-6)
+            _close(y, F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias.float(), padding=1), what + " vs F.conv2d", 1e-5)
+    for it in range(3 * N_DRAWS):
+        B, nl = rng.randint(1, 3), rng.randint(1, 5)
+        sizes = [(rng.randint(1, 14), _edge(rng, (16,), 20)) for _ in range(nl)]
+        out_g = torch.zeros(B, sum(h * w_ for h, w_ in sizes), 256, dtype=torch.float16)
+        out_p = torch.zeros_like(out_g)
+        w0, b0 = (torch.randn(64, 256, generator=g) / 16).half(), (torch.randn(64, generator=g) * 0.1).half()
+        w2, b2 = (torch.randn(1024, 64, generator=g) / 8).half(), (torch.randn(1024, generator=g) * 0.1).half()
+        levels, off = [], 0
+        for (h, w_) in sizes:
+            branches = []
+            for _ in range(rng.randint(0, 3) if rng.random() < 0.7 else 0):
+                branches.append(((torch.randn(B, h * w_, 256, generator=g)).half(), torch.randn(B, 256, 2, generator=g) * 0.5, h, w_))
+            if not branches or (len(branches) < 3 and rng.random() < 0.6):
+                hs, ws = max(1, (h + 1) // 2), max(1, (w_ + 1) // 2)
+                if (hs, ws) == (h, w_) or len(branches) == 0 and rng.random() < 0.3:
+                    branches.append((torch.randn(B, h * w_, 256, generator=g).half(), torch.randn(B, 256, 2, generator=g) * 0.5, h, w_))
+                else:
+                    branches.insert(rng.randint(0, len(branches)), (torch.randn(B, hs * ws, 256, generator=g).half(), torch.randn(B, 256, 2, generator=g) * 0.5, hs, ws))
+            levels.append((branches, h, w_, off))
+            off += h * w_
+        rc = torch.zeros(nl, B, 4, 256)
+        ops.dyconv_epilogue_group([(br, h, w_, out_g[:, o:o + h * w_]) for br, h, w_, o in levels], w0, b0, w2, b2, rc)
+        for l, (br, h, w_, o) in enumerate(levels):
+            _, pool = ops.dyconv_fuse(br, h, w_, out=out_p[:, o:o + h * w_])
+            ref = ops.dyrelu_coef(pool, h * w_, w0, b0, w2, b2)
+            assert torch.equal(rc[l], ref), f"epilogue group draw {it}: sizes={sizes} level {l}: DYReLU coefficients"
+        assert torch.equal(out_g, out_p), f"epilogue group draw {it}: sizes={sizes} branches={[len(lv_[0]) for lv_ in levels]}"
+
+
 def test_swin_mlp_roi_align_and_msdeform_random_shapes(ops):
     import math
     import ops_emulation as emu

@@ -12,13 +12,13 @@ GROUPS = (("vlfuse_i2t", "vlfuse_i2t_kernel"), ("vlfuse_t2i_combine", "vlfuse_t2
           ("dcn_igemm8", "dcn_igemm8_kernel"), ("swin_mlp_kernel<96", "swin_mlp_kernel<96>"), ("swin_mlp_kernel<192", "swin_mlp_kernel<192>"),
           ("swin_mlp_kernel<384", "swin_mlp_kernel<384>"), ("swin_mlp_kernelILi96", "swin_mlp_kernel<96>"), ("swin_mlp_kernelILi192", "swin_mlp_kernel<192>"),
           ("swin_mlp_kernelILi384", "swin_mlp_kernel<384>"), ("swin_mlp2_tail_kernel", "swin_mlp2_tail_kernel"), ("swin_mlp2_kernel<96", "swin_mlp2_kernel<96>"),
-          ("swin_mlp2_kernel<192", "swin_mlp2_kernel<192>"), ("swin_mlp2_kernel<384", "swin_mlp2_kernel<384>"), ("dyconv_fuse", "dyconv_fuse_kernel"),
+          ("swin_mlp2_kernel<192", "swin_mlp2_kernel<192>"), ("swin_mlp2_kernel<384", "swin_mlp2_kernel<384>"), ("dyconv_fuse_group", "dyconv_fuse_group_kernel"), ("dyconv_fuse", "dyconv_fuse_kernel"),
           ("dyrelu_ln", "dyrelu_ln_kernel"), ("layernorm2_kernel", "layernorm2_kernel"), ("layernorm_kernel", "layernorm_kernel"),
           ("window_attn_qkv_kernel<96", "window_attn_qkv_kernel<96>"), ("window_attn_qkv_kernel<192", "window_attn_qkv_kernel<192>"),
           ("window_attn_qkv_kernel<384", "window_attn_qkv_kernel<384>"), ("window_attn_qkv", "window_attn_qkv_kernel"),
           ("attn_resident", "attn_resident_kernel"), ("attn_text", "attn_text_kernel"), ("attn_chunked", "attn_chunked_kernel"),
           ("patch_embed", "patch_embed_kernel"), ("post_select", "post_select_kernel"), ("post_merge", "post_merge_kernel"),
-          ("window_attn", "window_attn_kernel"), ("align_fused", "align_fused_kernel"), ("conv3x3_small2", "conv3x3_small2_kernel"))
+          ("window_attn", "window_attn_kernel"), ("align_fused", "align_fused_kernel"), ("conv3x3_small2", "conv3x3_small2_kernel"), ("conv3x3_group", "conv3x3_group_kernel"))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(f"{src}/{counter}.csv")):
