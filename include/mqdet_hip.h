@@ -146,6 +146,14 @@ int mq_layernorm_fwd(const void* x, int x_f32, const void* res, int res_f32, con
  * bit for bit the results of mq_layernorm_fwd (device and tests/simt). */
 int mq_layernorm2_fwd(const void* x, int x_f32, const void* res, int res_f32, const void* gamma, const void* beta, void* y,
                      float* y32, void* xsum, long rows, int C, float eps, void* stream);
+/* mq_layernorm_fwd with the three clamps of the VLDyHead BERT copies inside (rpn/modeling_bert.py:242-272: the output of the dense layer,
+ * then the LayerNorm output): s = med3(x, +-clamp) (+ res), y = clamp(round16(LN(s))), y32 = clamp(LN(s)); equal to clamp -> mq_layernorm_fwd
+ * -> clamp, clamp bit for bit.  clamp > 0.  KERNELS["BERT_CLAMP_FUSED"]. */
+int mq_layernorm_clamp_fwd(const void* x, int x_f32, const void* res, int res_f32, const void* gamma, const void* beta, void* y, float* y32,
+                           void* xsum, long rows, int C, float eps, float clamp, void* stream);
+/* out = clamp(gelu(clamp(x))) elementwise on n 16-bit values (n % 8 == 0), exact (erf) GELU in fp32 rounded once: the intermediate
+ * activation of the clamped BERT copies (rpn/modeling_bert.py:255-259) in one pass instead of torch's three. */
+int mq_clamp_gelu_clamp(const void* x, void* out, long n, float clamp, void* stream);
 
 /* Swin PatchMerging up to its LayerNorm in one kernel: y[b,i,j,:] = LayerNorm_{4C}(concat(x[b,2i,2j], x[b,2i+1,2j], x[b,2i,2j+1],
  *   x[b,2i+1,2j+1])), zero beyond an odd H / W.  x [B,H,W,C] fp16 or fp32 (x_f32), contiguous; gamma / beta [4C] fp16; y fp16
@@ -443,6 +451,8 @@ MQ_BF16_TWIN(mq_vlfuse_i2t_fwd)
 MQ_BF16_TWIN(mq_vlfuse_t2i_fwd)
 MQ_BF16_TWIN(mq_layernorm_fwd)
 MQ_BF16_TWIN(mq_layernorm2_fwd)
+MQ_BF16_TWIN(mq_layernorm_clamp_fwd)
+MQ_BF16_TWIN(mq_clamp_gelu_clamp)
 MQ_BF16_TWIN(mq_patch_merge_ln_fwd)
 MQ_BF16_TWIN(mq_swin_mlp_fwd)
 MQ_BF16_TWIN(mq_swin_mlp2_fwd)

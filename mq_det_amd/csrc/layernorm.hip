@@ -43,7 +43,9 @@ template <int LPR, bool XF32, bool RF32>
 __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ x, const void* __restrict__ res,
                                                         const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
                                                         half_t* __restrict__ y, float* __restrict__ y32, void* __restrict__ xsum,
-                                                        long rows, int C, float eps, int RPB) {
+                                                        long rows, int C, float eps, int RPB, float clamp) {
+  // clamp > 0 (mq_layernorm_clamp_fwd: the VLDyHead BERT copies, rpn/modeling_bert.py:242-272): x is clamped to +-clamp before the
+  // residual add and both outputs after the affine -- the three torch.clamp passes around this LayerNorm, inside it
   constexpr int ROWS_PER_PASS = 256 / LPR;          // RPB = rows per block: 64 (big inputs) or one pass
   constexpr bool SUM32 = XF32 || RF32;
   const int sub = threadIdx.x % LPR, rg = threadIdx.x / LPR;
@@ -62,6 +64,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
       for (int j = 0; j < 8; ++j) v[k][j] = 0.f;
       if (ok && ch < nch) {
         load8<XF32>(x, row * C + ch * 8, v[k]);
+        if (clamp > 0.f) {                                  // a 16-bit x is clamped at the 16-bit value of the bound, as torch.clamp on it does
+          const float cx = XF32 ? clamp : (float)(half_t)clamp;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[k][j] = __builtin_amdgcn_fmed3f(v[k][j], -cx, cx);
+        }
         if (res) {
           float r[8];
           load8<RF32>(res, row * C + ch * 8, r);
@@ -113,6 +120,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
           of[j] = (v[k][j] - mean) * rstd * (float)g[j] + (float)bb[j];
           o[j] = (half_t)of[j];
         }
+        if (clamp > 0.f) {                                  // the 16-bit output: clamp of the ROUNDED value at the rounded bound, as y16.clamp() does
+          const float ch_ = (float)(half_t)clamp;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            o[j] = (half_t)__builtin_amdgcn_fmed3f((float)o[j], -ch_, ch_);
+            of[j] = __builtin_amdgcn_fmed3f(of[j], -clamp, clamp);
+          }
+        }
         if (y) *(half8*)(y + row * C + ch * 8) = o;
         if (y32) store8f(y32, row * C + ch * 8, of);
       }
@@ -120,8 +135,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
   }
 }
 
-extern "C" int MQ_SYM(mq_layernorm_fwd)(const void* x, int x_f32, const void* res, int res_f32, const void* gamma, const void* beta,
-                                void* y, float* y32, void* xsum, long rows, int C, float eps, void* stream) {
+static int layernorm_launch(const void* x, int x_f32, const void* res, int res_f32, const void* gamma, const void* beta,
+                            void* y, float* y32, void* xsum, long rows, int C, float eps, float clamp, void* stream) {
   if (rows <= 0) return 0;
   if (C % 8 || C > 3072) return -1;
   if (!res && xsum) return -2;
@@ -133,7 +148,7 @@ extern "C" int MQ_SYM(mq_layernorm_fwd)(const void* x, int x_f32, const void* re
   const bool xf = x_f32 != 0, rf = res && res_f32 != 0;
 #define MQ_LN3(L, XF, RF)                                                                                               \
   hipLaunchKernelGGL((layernorm_kernel<L, XF, RF>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, res,              \
-                     (const half_t*)gamma, (const half_t*)beta, (half_t*)y, y32, xsum, rows, C, eps, rpb)
+                     (const half_t*)gamma, (const half_t*)beta, (half_t*)y, y32, xsum, rows, C, eps, rpb, clamp)
 #define MQ_LN(L)                                                                                                        \
   do {                                                                                                                  \
     if (xf && rf) MQ_LN3(L, true, true);                                                                                \
@@ -146,6 +161,47 @@ extern "C" int MQ_SYM(mq_layernorm_fwd)(const void* x, int x_f32, const void* re
   else MQ_LN(64);
 #undef MQ_LN
 #undef MQ_LN3
+  MQ_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int MQ_SYM(mq_layernorm_fwd)(const void* x, int x_f32, const void* res, int res_f32, const void* gamma, const void* beta,
+                                void* y, float* y32, void* xsum, long rows, int C, float eps, void* stream) {
+  return layernorm_launch(x, x_f32, res, res_f32, gamma, beta, y, y32, xsum, rows, C, eps, 0.f, stream);
+}
+
+// LayerNorm(clamp(x) (+ res)) with both outputs clamped: y = clamp(round16(LN)), y32 = clamp(LN) -- equal to
+// x.clamp(-c, c) -> mq_layernorm_fwd -> y.clamp(-c, c), y32.clamp(-c, c) bit for bit (same kernel, same order), three passes less.
+extern "C" int MQ_SYM(mq_layernorm_clamp_fwd)(const void* x, int x_f32, const void* res, int res_f32, const void* gamma, const void* beta,
+                                      void* y, float* y32, void* xsum, long rows, int C, float eps, float clamp, void* stream) {
+  if (!(clamp > 0.f)) return -1;
+  return layernorm_launch(x, x_f32, res, res_f32, gamma, beta, y, y32, xsum, rows, C, eps, clamp, stream);
+}
+
+// out = clamp(gelu(clamp(x))) elementwise, 16-bit in / out, exact (erf) GELU evaluated in fp32 and rounded once like torch's kernel:
+// F.gelu(h.clamp(-c, c)).clamp(-c, c) of the clamped BERT copies (rpn/modeling_bert.py:255-259) in one pass instead of three.
+__global__ __launch_bounds__(256) void clamp_gelu_clamp_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, long n8, float clamp) {
+  clamp = (float)(half_t)clamp;                              // torch.clamp on a 16-bit tensor compares with the 16-bit value of the bound
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const half8 v = *(const half8*)(x + i * 8);
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float a = __builtin_amdgcn_fmed3f((float)v[j], -clamp, clamp);
+      const float gl = a * 0.5f * (1.f + erff(a * 0.70710678118654752440f));
+      o[j] = (half_t)__builtin_amdgcn_fmed3f((float)(half_t)gl, -clamp, clamp);
+    }
+    *(half8*)(out + i * 8) = o;
+  }
+}
+
+extern "C" int MQ_SYM(mq_clamp_gelu_clamp)(const void* x, void* out, long n, float clamp, void* stream) {
+  if (n <= 0) return 0;
+  if (n % 8 || !(clamp > 0.f)) return -1;
+  const long n8 = n / 8;
+  const long blocks = (n8 + 255) / 256;
+  hipLaunchKernelGGL(clamp_gelu_clamp_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)x, (half_t*)out, n8, clamp);
   MQ_CHECK_LAUNCH();
   return 0;
 }

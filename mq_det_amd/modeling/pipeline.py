@@ -429,6 +429,11 @@ def bert_layer(P, b, x, key_bias, clamp, kv_len=None, x32=None, qk_mask=None, ma
                 want_sum=False, want_y32=r32)
     a16, a32 = a if r32 else (a, None)
     hmid = _lin(P, b + ".intermediate.dense", a16)
+    if clamp and ops.KERNELS["BERT_CLAMP_FUSED"] == 1 and hmid.numel() % 8 == 0:
+        # the five torch.clamp passes and the GELU of this half inside two kernels (equal results)
+        o = _lin(P, b + ".output.dense", ops.clamp_gelu_clamp(hmid.contiguous(), 50000.0))
+        return ops.layer_norm(o.contiguous(), P[b + ".output.LayerNorm.weight"], P[b + ".output.LayerNorm.bias"], 1e-12,
+                              residual=(a32 if r32 else a16).contiguous(), want_sum=False, want_y32=r32, clamp=50000.0)
     if clamp:
         hmid = F.gelu(hmid.clamp(-50000, 50000)).clamp(-50000, 50000)
         o = _lin(P, b + ".output.dense", hmid).clamp(-50000, 50000)

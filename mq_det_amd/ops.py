@@ -13,7 +13,7 @@ _LIB = None
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmqdet_hip.so")
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
-EXPECTED_ABI = 24        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
+EXPECTED_ABI = 25        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
 _SIGNATURES = {
     "mq_abi_version": (_i, []),
     "mq_attn_workspace_bytes": (_l, [_i, _i, _i, _i, _i]),
@@ -31,6 +31,8 @@ _SIGNATURES = {
     "mq_vlfuse_t2i_fwd": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "mq_layernorm_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
     "mq_layernorm2_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
+    "mq_layernorm_clamp_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _f, _vp]),
+    "mq_clamp_gelu_clamp": (_i, [_vp, _vp, _l, _f, _vp]),
     "mq_patch_merge_ln_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mq_swin_mlp_fwd": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _l, _i, _vp]),
     "mq_swin_mlp2_fwd": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _l, _i, _i, _vp]),
@@ -66,7 +68,7 @@ _SIGNATURES = {
 }
 # entry points with 16-bit operands also exist as <name>_bf16 (same signature; include/mqdet_hip.h MQ_BF16_TWIN)
 BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_text_fwd", "mq_patch_embed_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_window_attn_qkv_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
-              "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_patch_merge_ln_fwd", "mq_swin_mlp_fwd", "mq_swin_mlp2_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_conv3x3_nchw32_group_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
+              "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_layernorm_clamp_fwd", "mq_clamp_gelu_clamp", "mq_patch_merge_ln_fwd", "mq_swin_mlp_fwd", "mq_swin_mlp2_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_conv3x3_nchw32_group_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
               "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyconv_epilogue_group", "mq_dyrelu_apply", "mq_dyrelu_ln_fwd", "mq_add_upsample_nearest",
               "mq_align_scores_fwd", "mq_align_fused_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
 for _n in BF16_TWINS:
@@ -103,6 +105,9 @@ KERNEL_DEFAULTS = {
                                  # no gain (the main kernel leaves the tail's waves no issue slots), stays off
     "DYCONV_EPILOGUE_GROUPED": 0,  # 1: mq_dyconv_epilogue_group -- the fuse pass and the DYReLU coefficients of ALL levels of a DyConv layer in two launches
                                  # on the main stream (were 10 launches on five streams behind a fork / join); equal results
+    "BERT_CLAMP_FUSED": 0,       # 1: the +-50000 clamps of the fusion-layer BERT copies inside the kernels around them (mq_clamp_gelu_clamp: clamp -> GELU
+                                 # -> clamp in one pass; mq_layernorm_clamp_fwd: clamp of the dense output, LayerNorm, clamp of both outputs): 7 torch
+                                 # launches per layer -> 1, equal results; 0: torch.clamp / F.gelu passes
     "PATCH_EMBED_FUSED": 1,      # 1: mq_patch_embed_fwd (Swin PatchEmbed projection + patch_embed.norm + the first norm1 in one pass over the pixels);
                                  # 0: permute copies + library GEMM (K = 48) + two LayerNorm launches (354 us at B = 8)
     "BERT_QKV_FUSED": 1,         # 1: BERT layers = ONE qkv GEMM + mq_attn_text_fwd (V row-major, transposed out of LDS; registers / LDS sized by the
@@ -541,12 +546,13 @@ def image_key_mask(mask):
     return out
 
 
-def layer_norm(x, gamma, beta, eps=1e-5, residual=None, want_sum=True, want_y32=False, want_y=True):
+def layer_norm(x, gamma, beta, eps=1e-5, residual=None, want_sum=True, want_y32=False, want_y=True, clamp=0.0):
     """LayerNorm over the last dim (mq_layernorm_fwd).  x: contiguous fp16 or fp32; residual (optional, same shape):
     fp16 or fp32, s = x + residual is normalised.  Returns, in this order and only those asked for:
       y   fp16  (want_y)              -- GEMM operand
       y32 fp32  (want_y32)            -- unrounded, the post-LN residual stream
       sum       (residual given and want_sum) -- s: fp32 if x or residual is fp32, else fp16 (s rounded before the statistics)
+    clamp > 0 (mq_layernorm_clamp_fwd): x is clamped to +-clamp before the residual add, y / y32 after the affine.
     A single result is returned bare, several as a tuple."""
     lib = load_library()
     _need_gpu(x, gamma, beta, residual)
@@ -568,10 +574,25 @@ def layer_norm(x, gamma, beta, eps=1e-5, residual=None, want_sum=True, want_y32=
     with _timed(f"layernorm_c{C}", sum(t.numel() * t.element_size() for t in (x, residual, y, y32, xsum) if t is not None)):
         # LN_VARIANT 2: the load-batched kernel of csrc/layernorm2.hip (same results bit for bit as mq_layernorm_fwd)
         name = "mq_layernorm2_fwd" if KERNELS["LN_VARIANT"] == 2 else "mq_layernorm_fwd"
-        _chk(_fn(lib, name, gamma)(_ptr(x), int(xf), _ptr(residual), int(rf), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(y32), _ptr(xsum),
-                                   rows, C, float(eps), _stream()), name)
+        if clamp > 0:
+            _chk(_fn(lib, "mq_layernorm_clamp_fwd", gamma)(_ptr(x), int(xf), _ptr(residual), int(rf), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(y32), _ptr(xsum),
+                                                           rows, C, float(eps), float(clamp), _stream()), "mq_layernorm_clamp_fwd")
+        else:
+            _chk(_fn(lib, name, gamma)(_ptr(x), int(xf), _ptr(residual), int(rf), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(y32), _ptr(xsum),
+                                       rows, C, float(eps), _stream()), name)
     out = [t for t in (y, y32, xsum) if t is not None]
     return out[0] if len(out) == 1 else tuple(out)
+
+
+def clamp_gelu_clamp(x, clamp):
+    """clamp(gelu(clamp(x))) elementwise on a contiguous 16-bit tensor (mq_clamp_gelu_clamp): exact GELU in fp32, rounded once."""
+    lib = load_library()
+    _need_gpu(x)
+    assert x.is_contiguous() and x.dtype in _H16 and x.numel() % 8 == 0 and clamp > 0
+    out = torch.empty_like(x)
+    with _timed("clamp_gelu_clamp", 2 * x.numel() * 2):
+        _chk(_fn(lib, "mq_clamp_gelu_clamp", x)(_ptr(x), _ptr(out), x.numel(), float(clamp), _stream()), "mq_clamp_gelu_clamp")
+    return out
 
 
 def patch_merge_ln(x, gamma, beta, eps=1e-5):

@@ -410,11 +410,13 @@ def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None
     return y, hw, sums
 
 
-def layer_norm(x, gamma, beta, eps=1e-5, residual=None, want_sum=True, want_y32=False, want_y=True):
+def layer_norm(x, gamma, beta, eps=1e-5, residual=None, want_sum=True, want_y32=False, want_y=True, clamp=0.0):
     """ops.layer_norm: y in the plan's activation dtype (gamma's), y32 fp32, sum fp32 when x or residual is fp32 (else the
-    activation dtype, rounded BEFORE the statistics)."""
+    activation dtype, rounded BEFORE the statistics); clamp > 0: x clamped before the add, y / y32 after the affine."""
     act = gamma.dtype
     s = x.float()
+    if clamp > 0:
+        s = s.clamp(-clamp, clamp)
     sum_dt = torch.float32 if x.dtype == torch.float32 else act
     if residual is not None:
         s = s + residual.float()
@@ -425,12 +427,16 @@ def layer_norm(x, gamma, beta, eps=1e-5, residual=None, want_sum=True, want_y32=
     yf = F.layer_norm(s, (x.shape[-1],), gamma.float(), beta.float(), eps)
     out = []
     if want_y:
-        out.append(yf.to(act))
+        out.append(yf.to(act).clamp(-clamp, clamp) if clamp > 0 else yf.to(act))
     if want_y32:
-        out.append(yf)
+        out.append(yf.clamp(-clamp, clamp) if clamp > 0 else yf)
     if residual is not None and want_sum:
         out.append(s.to(sum_dt))
     return out[0] if len(out) == 1 else tuple(out)
+
+
+def clamp_gelu_clamp(x, clamp):
+    return F.gelu(x.float().clamp(-clamp, clamp)).to(x.dtype).clamp(-clamp, clamp)
 
 
 def patch_merge_ln(x, gamma, beta, eps=1e-5):
@@ -595,7 +601,7 @@ def dyconv_coef_group(items, attn_w, attn_b, groups, eps):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # every emulated entry point, in one place: tests patch them into mq_det_amd.ops (or into a stand-in namespace) with these helpers
 NAMES = ("attention", "attention4", "attention_text", "patch_embed", "window_attention", "window_attention_qkv", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores", "align_fused",
-         "dyconv_branch_coef", "dyconv_coef_group", "dyconv_epilogue_group", "dyconv_fuse", "dyrelu_", "dyrelu_coef", "dyrelu_apply_", "dyrelu_layer_norm", "add_upsample_nearest_", "conv3x3", "conv3x3_nchw32", "conv3x3_nchw32_group", "conv3x3_nchw32_group_supported", "dcnv2", "layer_norm", "vlfuse_i2t",
+         "dyconv_branch_coef", "dyconv_coef_group", "dyconv_epilogue_group", "dyconv_fuse", "dyrelu_", "dyrelu_coef", "dyrelu_apply_", "dyrelu_layer_norm", "add_upsample_nearest_", "conv3x3", "conv3x3_nchw32", "conv3x3_nchw32_group", "conv3x3_nchw32_group_supported", "dcnv2", "layer_norm", "clamp_gelu_clamp", "vlfuse_i2t",
          "vlfuse_t2i", "box_decode", "ml_nms", "post_select", "post_select_supported", "post_sort", "post_finalize", "roi_align", "swin_mlp", "swin_mlp2", "patch_merge_ln", "ms_deform_attn", "ms_deform_attn_q", "image_key_mask")
 
 

@@ -356,6 +356,55 @@ def check_bert_layer(dev, clamp):
     return _stat(f"bert layer clamp={clamp}", got, ref, tol=2.5e-3)
 
 
+def check_bert_clamp_fused(dev):
+    """KERNELS["BERT_CLAMP_FUSED"]: mq_clamp_gelu_clamp and mq_layernorm_clamp_fwd against the torch passes they replace -- on values that DO
+    reach the clamp (the +-50000 of the reference and a small one), fp16 / fp32 input x residual, with and without the fp32 output;
+    then the clamped BERT layer of the tiny model with the switch on against the oracle and against the switch off."""
+    from oracle import language as ol
+    from mq_det_amd import ops
+    from mq_det_amd.modeling import pipeline
+    spec, sd, cfg, model, P = tiny(dev)
+    g = torch.Generator().manual_seed(37)
+    res = []
+    for cl, amp in ((50000.0, 60000.0), (2.5, 4.0), (50000.0, 1.0)):
+        x = ((torch.rand(3, 40, 768, generator=g) * 2 - 1) * amp).to(H16)        # finite in fp16 (|x| <= 60000), a sixth beyond the clamp
+        ref = F.gelu(x.float().clamp(-cl, cl)).to(H16).clamp(-cl, cl)
+        res.append(_stat(f"clamp_gelu_clamp clamp={cl} |x|~{amp}", ops.clamp_gelu_clamp(x.to(dev), cl), ref.float(), tol=1e-3))
+        gam, bet = (torch.randn(768, generator=g) * 0.2 + 1).to(H16), (torch.randn(768, generator=g) * 0.1).to(H16)
+        if amp > 10:
+            gam, bet = gam * 25000, bet * 25000                         # LayerNorm outputs beyond the clamp as well
+        for xf in (False, True):
+            for rf in (False, True):
+                xx = (x.float() if xf else x).to(dev)
+                rr = torch.randn(3, 40, 768, generator=g) * min(amp, 100.0)
+                rr = (rr if rf else rr.to(H16)).to(dev)
+                a16, a32 = ops.layer_norm(xx, gam.to(dev), bet.to(dev), 1e-12, residual=rr, want_sum=False, want_y32=True, clamp=cl)
+                b16, b32 = ops.layer_norm(xx.clamp(-cl, cl), gam.to(dev), bet.to(dev), 1e-12, residual=rr, want_sum=False, want_y32=True)
+                # (equal bit for bit through the emulation; the bounds leave room for one rounding step should the two LayerNorm kernels
+                # contract a multiply-add differently on the device, where this pair has not run side by side yet)
+                res.append(_stat(f"layer_norm clamp={cl} |x|~{amp} x fp32={xf} res fp32={rf}: y vs clamp -> LayerNorm -> clamp", a16, b16.clamp(-cl, cl).float().cpu(), tol=1e-3))
+                res.append(_stat(f"layer_norm clamp={cl} |x|~{amp} x fp32={xf} res fp32={rf}: y32 vs clamp -> LayerNorm -> clamp", a32, b32.clamp(-cl, cl).float().cpu(), tol=2e-6))
+    T = 64
+    x = torch.randn(2, T, spec.bert_hidden, generator=g).to(H16)
+    am = torch.ones(2, T, dtype=torch.long)
+    am[0, 25:] = 0
+    b = "rpn.head.dyhead_tower.1"
+    saved = ops.KERNELS["BERT_CLAMP_FUSED"]
+    try:
+        with torch.no_grad():
+            ref = ol.bert_layer(sd, b, x.float(), ol.extended_mask(am), spec.bert_heads, spec.bert_eps, clamp=True)
+            kb = ((1.0 - am.float()) * -1e30).to(dev)
+            outs = {}
+            for mode in (0, 1):
+                ops.KERNELS["BERT_CLAMP_FUSED"] = mode
+                outs[mode] = pipeline.bert_layer(P, b, x.to(dev), kb, True)
+        res.append(_stat("bert layer clamp=True, clamps inside the kernels: vs the oracle", outs[1], ref, tol=2.5e-3))
+        res.append(_stat("bert layer clamp=True, clamps inside the kernels: vs the torch passes", outs[1], outs[0].float().cpu(), tol=1e-3))
+    finally:
+        ops.KERNELS["BERT_CLAMP_FUSED"] = saved
+    return res
+
+
 def check_vl_fuse(dev):
     from oracle import head as oh
     from mq_det_amd.modeling import pipeline
@@ -1072,6 +1121,7 @@ def all_checks(dev):
             ("gcp", lambda: check_pre_select(dev)),
             ("bert", lambda: check_bert_layer(dev, False)),
             ("bert", lambda: check_bert_layer(dev, True)),
+            ("bert", lambda: check_bert_clamp_fused(dev)),
             ("vlfuse", lambda: check_vlfuse_kernels(dev)),
             ("vlfuse", lambda: check_vl_fuse(dev)),
             ("dcn", lambda: check_dcn(dev)),

@@ -146,7 +146,7 @@ def test_attention_strided_views(kernels):
 
 @pytest.mark.parametrize("name", ["check_window_attention", "check_gcp_block", "check_pre_select", "check_vlfuse_kernels", "check_vl_fuse",
                                   "check_dcn", "check_dyconv", "check_post_golden", "check_score_agg", "check_layernorm", "check_nms", "check_swin_mlp",
-                                  "check_conv3x3", "check_roi_align", "check_msdeform_attn", "check_swin_fpn", "check_align_fused", "check_post_fused", "check_attention_text", "check_patch_embed"])
+                                  "check_conv3x3", "check_roi_align", "check_msdeform_attn", "check_swin_fpn", "check_align_fused", "check_post_fused", "check_attention_text", "check_patch_embed", "check_bert_clamp_fused"])
 def test_kernel_block(kernels, name):
     _assert_ok(getattr(kernels, name)(CPU))
 
@@ -232,7 +232,7 @@ def bf16(kernels):
 
 @pytest.mark.parametrize("name", ["check_window_attention", "check_gcp_block", "check_pre_select", "check_vlfuse_kernels", "check_dcn",
                                   "check_post_golden", "check_layernorm", "check_swin_mlp", "check_conv3x3", "check_msdeform_attn",
-                                  "check_attention_strided", "check_attention_text", "check_patch_embed"])
+                                  "check_attention_strided", "check_attention_text", "check_patch_embed", "check_bert_clamp_fused"])
 def test_bf16_kernel_block(bf16, name):
     res = getattr(bf16, name)(CPU)
     _assert_ok(res)
