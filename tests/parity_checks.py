@@ -913,19 +913,22 @@ def check_dyconv_epilogue_group(dev):
     b = "rpn.head.dyhead_tower.2"
     saved = ops.KERNELS["DYCONV_EPILOGUE_GROUPED"]
     try:
-        for sizes in ([(20, 24), (10, 12), (5, 6), (3, 3), (2, 2)], [(17, 9), (9, 5)], [(13, 21)]):
+        pyramids = ([(20, 24), (10, 12), (5, 6), (3, 3), (2, 2)], [(17, 9), (9, 5)], [(13, 21)])
+        for pi, sizes in enumerate(pyramids[:1 if (QUICK and H16 != torch.float16) else (2 if QUICK else 3)]):
             feats = [torch.randn(2, 256, h, w, generator=g).to(H16).to(dev).contiguous(memory_format=torch.channels_last) for h, w in sizes]
             tok, szs = pipeline._to_tokens(feats)
             outs = {}
             with torch.no_grad():
                 for mode in (0, 1):
                     ops.KERNELS["DYCONV_EPILOGUE_GROUPED"] = mode
-                    outs[mode] = (pipeline.dyconv_tokens(P, cfg, b, tok.contiguous(), szs, defer_relu=True), pipeline.dyconv_tokens(P, cfg, b, tok.contiguous(), szs))
+                    outs[mode] = (pipeline.dyconv_tokens(P, cfg, b, tok.contiguous(), szs, defer_relu=True),
+                                  pipeline.dyconv_tokens(P, cfg, b, tok.contiguous(), szs) if (pi == 0 or not QUICK) else None)
             (pre0, c0), o0 = outs[0]
             (pre1, c1), o1 = outs[1]
             res.append(_stat(f"dyconv epilogue grouped == per level, {len(sizes)} levels: output before DYReLU (exact)", pre1, pre0.float().cpu(), tol=0.0))
             res.append(_stat(f"dyconv epilogue grouped == per level, {len(sizes)} levels: DYReLU coefficients (exact)", c1, c0.float().cpu(), tol=0.0))
-            res.append(_stat(f"dyconv epilogue grouped == per level, {len(sizes)} levels: output with DYReLU applied (exact)", o1, o0.float().cpu(), tol=0.0))
+            if o0 is not None:
+                res.append(_stat(f"dyconv epilogue grouped == per level, {len(sizes)} levels: output with DYReLU applied (exact)", o1, o0.float().cpu(), tol=0.0))
     finally:
         ops.KERNELS["DYCONV_EPILOGUE_GROUPED"] = saved
     return res
