@@ -93,6 +93,16 @@ struct MqOncePerDevice {
   }
   void done() { if (dev_ >= 0) set_[dev_] = true; }
 };
+// the same for launchers whose dynamic LDS size depends on the call: the largest size the attribute was set to, per device
+struct MqMaxPerDevice {
+  size_t max_[32] = {};
+  int dev_ = -1;
+  bool need(size_t bytes) {
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 32) { dev_ = -1; return true; }
+    return bytes > max_[dev_];
+  }
+  void done(size_t bytes) { if (dev_ >= 0) max_[dev_] = bytes; }
+};
 static inline int mq_device_cus() {
   static int cus[32] = {};
   int dev = 0, n = 0;

@@ -147,11 +147,11 @@ extern "C" int MQ_SYM(mq_conv3x3_nchw32_v2_fwd)(const void* x, const void* w, co
   const size_t tiles = (size_t)(CS2_WH * CS2_WW + 2 * 32) * (CP + 16) * sizeof(half_t);
   const size_t ostage = (size_t)32 * (CS2_PH * CS2_PW + 4) * sizeof(float);
   const size_t smem = tiles > ostage ? tiles : ostage;
-  static size_t attr_set = 0;
-  if (smem > attr_set) {
+  static MqMaxPerDevice attr_set;
+  if (attr_set.need(smem)) {
     hipError_t e = hipFuncSetAttribute((const void*)conv3x3_small2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    attr_set = smem;
+    attr_set.done(smem);
   }
   hipLaunchKernelGGL(conv3x3_small2_kernel, dim3((unsigned)(8 * ((p.tiles_total + 7) / 8))), dim3(256), smem, (hipStream_t)stream, p);
   MQ_CHECK_LAUNCH();

@@ -344,11 +344,11 @@ template <int SLOTS>
 static int launch_sweep_lds(const unsigned long long* mask, const int* nvalid, unsigned char* keep, int B, int N, int col_blocks,
                             hipStream_t stream) {
   const size_t smem = (size_t)3 * 64 * col_blocks * sizeof(unsigned long long);
-  static size_t attr_set = 0;
-  if (smem > attr_set) {
+  static MqMaxPerDevice attr_set;
+  if (attr_set.need(smem)) {
     hipError_t e = hipFuncSetAttribute((const void*)nms_sweep_lds_kernel<SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    attr_set = smem;
+    attr_set.done(smem);
   }
   hipLaunchKernelGGL((nms_sweep_lds_kernel<SLOTS>), dim3(B), dim3(320), smem, stream, mask, nvalid, keep, N, col_blocks);
   MQ_CHECK_LAUNCH();
