@@ -478,6 +478,55 @@ MQ_BF16_TWIN(mq_roi_align_fwd)
 MQ_BF16_TWIN(mq_msdeform_attn_fwd)
 MQ_BF16_TWIN(mq_msdeform_attn_q_fwd)
 
+/* ---- fp32 operands: the PRECISE mode (MODEL.COMPUTE_DTYPE = "float32"; BASELINE.json north_star: "outputs ... match the reference ...
+ * within 1e-3").  `name_f32` is the SAME kernel source compiled a third time with every 16-bit operand a float (csrc/common.h under
+ * -DMQ_F32: one 16x16x32 MFMA = eight v_mfma_f32_16x16x4_f32 on the same lane layout; ds_read_b64_tr_b16 and the LDS-DMA copies replaced by
+ * their element-size-independent forms), same arguments and return codes with "fp16" read as "fp32" and every 16-bit LDS tile twice as
+ * large -- a launch whose tiles exceed the 160 KB of a CU returns hipErrorInvalidValue (1); mq_det_amd/ops.py picks the shapes / variants
+ * that fit.  A quarter of the MFMA rate: this build exists to SHOW parity with the fp32 reference on the device (tests/, bench.py
+ * `precise_mode`), not for throughput.  No twin: the operators whose inputs may already be fp32 in the 16-bit builds (mq_roi_align_fwd,
+ * mq_msdeform_attn_*) and the superseded mq_swin_mlp_fwd. */
+#ifdef __cplusplus
+#define MQ_F32_TWIN(name) extern decltype(name) name##_f32;
+#else
+#define MQ_F32_TWIN(name) extern __typeof__(name) name##_f32;
+#endif
+MQ_F32_TWIN(mq_attn_fwd)
+MQ_F32_TWIN(mq_attn_resident_fwd)
+MQ_F32_TWIN(mq_attn_text_fwd)
+MQ_F32_TWIN(mq_patch_embed_fwd)
+MQ_F32_TWIN(mq_attn_chunked_fwd)
+MQ_F32_TWIN(mq_window_attn_fwd)
+MQ_F32_TWIN(mq_window_attn_qkv_fwd)
+MQ_F32_TWIN(mq_gcp_sparse_attn_fwd)
+MQ_F32_TWIN(mq_gcp_gate_residual_fwd)
+MQ_F32_TWIN(mq_vlfuse_i2t_fwd)
+MQ_F32_TWIN(mq_vlfuse_t2i_fwd)
+MQ_F32_TWIN(mq_layernorm_fwd)
+MQ_F32_TWIN(mq_layernorm2_fwd)
+MQ_F32_TWIN(mq_layernorm_clamp_fwd)
+MQ_F32_TWIN(mq_clamp_gelu_clamp)
+MQ_F32_TWIN(mq_patch_merge_ln_fwd)
+MQ_F32_TWIN(mq_swin_mlp2_fwd)
+MQ_F32_TWIN(mq_conv3x3_fwd)
+MQ_F32_TWIN(mq_conv3x3_nchw32_fwd)
+MQ_F32_TWIN(mq_conv3x3_nchw32_v2_fwd)
+MQ_F32_TWIN(mq_conv3x3_nchw32_group_fwd)
+MQ_F32_TWIN(mq_dcnv2_fwd)
+MQ_F32_TWIN(mq_dcnv2_group_fwd)
+MQ_F32_TWIN(mq_dyconv_stats)
+MQ_F32_TWIN(mq_dyconv_coef)
+MQ_F32_TWIN(mq_dyconv_coef_group)
+MQ_F32_TWIN(mq_dyconv_fuse)
+MQ_F32_TWIN(mq_dyrelu_coef)
+MQ_F32_TWIN(mq_dyconv_epilogue_group)
+MQ_F32_TWIN(mq_dyrelu_apply)
+MQ_F32_TWIN(mq_dyrelu_ln_fwd)
+MQ_F32_TWIN(mq_add_upsample_nearest)
+MQ_F32_TWIN(mq_align_scores_fwd)
+MQ_F32_TWIN(mq_align_fused_fwd)
+MQ_F32_TWIN(mq_box_decode)
+
 #ifdef __cplusplus
 }
 #endif

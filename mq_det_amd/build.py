@@ -8,6 +8,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libmqdet_hip.so")
 SOURCES = ["api.hip", "attn.hip", "attn_resident.hip", "attn_text.hip", "vlfuse_attn.hip", "window_attn.hip", "patch_embed.hip", "gcp.hip", "conv_igemm.hip", "conv_small.hip", "conv_small2.hip", "conv_small3.hip", "dcn_fused.hip", "layernorm.hip", "layernorm2.hip", "dyconv.hip", "post.hip", "post2.hip", "align_fused.hip", "nms2.hip", "roi_align.hip", "swin_mlp.hip", "swin_mlp2.hip", "msda.hip"]
+# no fp32-operand twin (include/mqdet_hip.h MQ_F32_TWIN): operators whose inputs may already be fp32, the superseded first Swin MLP kernel,
+# and the sources that only hold fp32 / integer code (one copy, in the fp16 unit)
+F32_SKIP = ("msda.hip", "roi_align.hip", "swin_mlp.hip", "nms2.hip", "post2.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # dcn_fused.hip: without the SLP vectoriser the bilinear blend compiles to v_fma_mix_f32 / v_fma_mixlo_f16 (fp16 operands,
 # fp32 accumulate, no separate converts) instead of cvt + v_pk_fma_f32 -- 40 % fewer VALU cycles next to the MFMAs
@@ -37,11 +40,13 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
-    # every kernel source twice: fp16 (the entry points of include/mqdet_hip.h) and -DMQ_BF16 (the same kernels with bf16
-    # operands under the *_bf16 entry points, csrc/common.h); api.hip (the ABI version) once
+    # every kernel source three times: fp16 (the entry points of include/mqdet_hip.h), -DMQ_BF16 (the same kernels with bf16 operands
+    # under the *_bf16 entry points, csrc/common.h) and -DMQ_F32 (fp32 operands, *_f32: the precise mode); api.hip (the ABI version) once
     for src in SOURCES:
-        for suffix, defs in (("", []), ("_bf16", ["-DMQ_BF16"])):
+        for suffix, defs in (("", []), ("_bf16", ["-DMQ_BF16"]), ("_f32", ["-DMQ_F32"])):
             if suffix and src == "api.hip":
+                continue
+            if suffix == "_f32" and src in F32_SKIP:
                 continue
             obj = os.path.join(LIB_DIR, src.replace(".hip", suffix + ".o"))
             objs.append(obj)

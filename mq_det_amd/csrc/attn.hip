@@ -389,7 +389,7 @@ static int launch_attn(const AttnParams& p, hipStream_t stream) {
   return 0;
 }
 
-#ifndef MQ_BF16
+#ifdef MQ_PRIMARY_UNIT
 extern "C" long mq_attn_workspace_bytes(int B, int H, int Nq, int D, int nsplit) {
   return nsplit > 1 ? (long)nsplit * B * H * Nq * (D + 2) * (long)sizeof(float) : 0;
 }

@@ -16,18 +16,7 @@
 
 MQ_NAMESPACE_BEGIN
 
-typedef __fp16 fp16x4_t __attribute__((__vector_size__(8)));
-typedef __attribute__((address_space(3))) fp16x4_t* lds_fp16x4_ptr;
-
 namespace {
-// 4x16 block of 16-bit values, row-major in LDS, read column-wise: within a 16-lane group lane i passes the address of the 4 contiguous
-// values (row i/4, cols 4*(i%4)..+3) and receives (row 0..3, col i)
-__device__ __forceinline__ half4 lds_read_tr16(const half_t* p) {
-  fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4_ptr)p);
-  half4 o;
-  __builtin_memcpy(&o, &v, 8);
-  return o;
-}
 constexpr int TXT_BM = 128, TXT_QB = 2;
 constexpr float TXT_LOG2E = 1.4426950408889634f;
 }  // namespace

@@ -12,7 +12,18 @@
 // entry points of include/mqdet_hip.h -- and with -DMQ_BF16 -- half_t = bf16 (v_mfma_f32_16x16x32_bf16), entry points with the
 // suffix _bf16, everything inside namespace mq_bf16 (BASELINE.json configs[3]: "MQ-GLIP-L ... bf16 MFMA").  Without the macro
 // MQ_SYM / MQ_NAMESPACE_* expand to nothing: the fp16 objects are token-for-token what they were before the switch existed.
-#ifdef MQ_BF16
+#if defined(MQ_F32)
+// fp32-OPERAND build (the "precise mode", MODEL.COMPUTE_DTYPE = "float32"; entry points *_f32, namespace mq_f32): every 16-bit operand of
+// the kernel sources is a float and one 16x16x32 MFMA is eight v_mfma_f32_16x16x4_f32 on the same lane layout (mfma16 below).  What is
+// left between such a run and the fp32 reference is summation order, not operand rounding: the north-star's 1e-3 end to end.
+typedef float half_t;
+typedef float half8 __attribute__((ext_vector_type(8)));
+typedef float half4 __attribute__((ext_vector_type(4)));
+typedef float half2_ __attribute__((ext_vector_type(2)));
+#define MQ_SYM(name) name##_f32
+#define MQ_NAMESPACE_BEGIN namespace mq_f32 {
+#define MQ_NAMESPACE_END }
+#elif defined(MQ_BF16)
 typedef __bf16 half_t;
 typedef __bf16 half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 half4 __attribute__((ext_vector_type(4)));
@@ -29,13 +40,23 @@ typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
 #define MQ_NAMESPACE_BEGIN
 #define MQ_NAMESPACE_END
 #endif
+// code that sees no 16-bit data (NMS, selection, size queries) exists once, in the fp16 translation unit
+#if !defined(MQ_BF16) && !defined(MQ_F32)
+#define MQ_PRIMARY_UNIT 1
+#endif
 typedef float float4_ __attribute__((ext_vector_type(4)));
 typedef float float2_ __attribute__((ext_vector_type(2)));
 
 #define MQ_NEG_BIG (-1.0e30f)
 
 __device__ __forceinline__ float4_ mfma16(half8 a, half8 b, float4_ c) {
-#ifdef MQ_BF16
+#if defined(MQ_F32)
+  // v_mfma_f32_16x16x4_f32: lane l holds A[l & 15][k = l >> 4] and B[k = l >> 4][l & 15]; step j contracts the k values 8 g + j (g = l >> 4)
+  // of the 16x16x32 fragments, so the eight steps together are the same 32-deep contraction with exact fp32 products
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+  return c;
+#elif defined(MQ_BF16)
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 #else
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
@@ -47,6 +68,41 @@ __device__ __forceinline__ half8 zero8() {
 #pragma unroll
   for (int i = 0; i < 8; ++i) z[i] = (half_t)0.f;
   return z;
+}
+
+// 4 x 16 block of operand elements, row-major in LDS (row pitch free), read column-wise: within a 16-lane group lane i passes the address of
+// the 4 contiguous elements (row i / 4, columns 4 (i % 4) .. + 3) and receives (rows 0 .. 3, column i).  16-bit builds: ds_read_b64_tr_b16;
+// fp32-operand build: the same exchange for 4-byte elements -- the addresses cross the lanes by shuffle, four scalar LDS reads.
+typedef __fp16 mq_fp16x4_t __attribute__((__vector_size__(8)));
+__device__ __forceinline__ half4 lds_read_tr16(const half_t* p) {
+#if defined(MQ_F32)
+  const int l = __lane_id(), base = l & ~15, i = l & 15;
+  half4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const half_t* src = (const half_t*)__shfl((unsigned long long)p, base + 4 * j + (i >> 2));
+    o[j] = src[i & 3];
+  }
+  return o;
+#else
+  mq_fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) mq_fp16x4_t*)p);
+  half4 o;
+  __builtin_memcpy(&o, &v, 8);
+  return o;
+#endif
+}
+
+// One 8-element operand fragment per lane, global -> LDS: lane l's fragment `src_lane` lands at dst_base + 8 l (dst_base wave-uniform).
+// 16-bit builds: LDS-DMA (global_load_lds_dwordx4: no VGPRs, asynchronous -- the caller waits with vmcnt before its barrier);
+// fp32-operand build: a 32-byte copy through registers that is complete when the call returns (a legal refinement of the asynchronous copy).
+__device__ __forceinline__ void lds_stage_frag8(const half_t* src_lane, half_t* dst_base, int lane) {
+#if defined(MQ_F32)
+  *(half8*)(dst_base + lane * 8) = *(const half8*)src_lane;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+  (void)lane;
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lane, (__attribute__((address_space(3))) void*)dst_base, 16, 0, 0);
+#endif
 }
 
 // reduce across the 16 lanes that share (lane >> 4): lanes differ in their low 4 bits

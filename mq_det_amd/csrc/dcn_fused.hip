@@ -67,14 +67,17 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   constexpr int BM = DCN_PH * DCN_PW, BN = 256, BK = 64;
   constexpr int NTH = 64 * NW, RA = 1024 / NTH, JB = 2048 / NTH, IM = 32 / NW;   // threads, A rows / thread, B chunks / thread, row blocks / wave
   static_assert(BM == 128, "tile is 128 positions");
+  // tile buffers: two (ping-pong) with 16-bit operands; ONE in the fp32-operand build (two would be 196 KB), where every wave runs
+  // MFMAs -> barrier -> staging -> barrier (the precise mode is not built for speed)
+  constexpr int NBUF = sizeof(half_t) == 4 ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // LDS tiles: rows of 64 halfs = 128 B = 8 chunks of 16 B, NO padding; chunk c of row r is stored at chunk position
   // c ^ (r & 7): conflict-free for the ds_read_b128 fragment reads (16 rows x one chunk) AND for the row-wise
   // ds_write_b128 of the staging pass (8 lanes = one row).  (The padded 144-byte pitch of v3 lost 39 % of the LDS
   // cycles to bank conflicts, profiles/r01_pmc_dcn_v3.txt.)
   half_t* As = (half_t*)smem;                                // [2][BM][BK]
-  half_t* Bs = As + 2 * BM * BK;                             // [2][BN][BK]
-  TapState* Ts = (TapState*)(Bs + 2 * BN * BK);              // [BM][9]
+  half_t* Bs = As + NBUF * BM * BK;                          // [NBUF][BN][BK]
+  TapState* Ts = (TapState*)(Bs + NBUF * BN * BK);           // [BM][9]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -221,6 +224,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   // one rounding to fp16) -> its two A-tile rows, and its four weight chunks -> B tile
   auto stage = [&](auto SLOT, int buf) {
     constexpr int s = decltype(SLOT)::value;
+    buf &= NBUF - 1;
     half_t* a = As + buf * BM * BK + a_lds;
 #pragma unroll
     for (int rr = 0; rr < RA; ++rr) {
@@ -252,6 +256,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   const unsigned sw0 = (unsigned)((lg ^ (l15 & 7)) << 3), sw1 = (unsigned)(((4 + lg) ^ (l15 & 7)) << 3);
   auto mfma_phase = [&](int cur) {                           // this wave's 64 x 64 block of one k-step (32 MFMAs)
     if constexpr (ABL & 8) return;
+    cur &= NBUF - 1;
     const half_t* At = As + cur * BM * BK + fa;
     const half_t* Bt = Bs + cur * BN * BK + fb;
 #pragma unroll
@@ -295,7 +300,18 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   // One loop per wave group (the branch is wave-uniform; s_barrier only counts arrivals, and both groups execute the
   // same number of barriers).  A single loop with `if (grp == ...)` around the phases makes hipcc merge the two paths'
   // VMEM bookkeeping and wait with vmcnt(0), which throws away one step of prefetch distance.
-  if (wave < NW / 2) {
+  if constexpr (NBUF == 1) {
+    for (int ks = 0; ks < ksteps; ks += 2) {
+      mfma_phase(0);
+      __syncthreads();                                       // everybody has read step ks before step ks + 1 overwrites the one buffer
+      stage_next(S1{}, ks);
+      __syncthreads();
+      mfma_phase(1);
+      __syncthreads();
+      stage_next(S0{}, ks + 1);
+      __syncthreads();
+    }
+  } else if (wave < NW / 2) {
     for (int ks = 0; ks < ksteps; ks += 2) {                 // ksteps = 9 * C/64 is even (C % 128 == 0)
       mfma_phase(0);
       if constexpr (SYNC == 2) __syncthreads();
@@ -365,7 +381,12 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
     for (int j = 0; j < 8; ++j) {                            // lanes l and l ^ 32 hold the same channels
       s1[j] += __shfl_xor(s1[j], 32); s2[j] += __shfl_xor(s2[j], 32); s3[j] += __shfl_xor(s3[j], 32);
     }
+#if defined(MQ_F32)
+    __syncthreads();                                         // fp32 O staging fills the LDS: the partials go over it once every row has been read
+    float* red = (float*)smem;
+#else
     float* red = (float*)(smem + (size_t)BM * OS * sizeof(half_t));      // [NW waves][32 chunks][24], behind the O staging
+#endif
     if (lane < 32) {
       float* r = red + (wave * 32 + chunk) * 24;
 #pragma unroll
@@ -385,7 +406,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
 // DCNv2 3x3, pad 1, 256 output channels.  x [B,H,W,C] fp16 NHWC (batch stride x_bs, C % 128 == 0), om [B,27,oH,oW] fp32
 // (18 offsets + 9 mask logits -- or probabilities with flags bit 0 --, NCHW), w [256, 9*C] fp16 (k = tap*C + c), bias [256] fp16 or NULL, out [B*Ho*Wo, out_ld];
 // stats (optional) [B, mq_dcnv2_stats_blocks(H, W, stride), 256, 3] fp32 with position weights wy [Ho] x wx [Wo] (or NULL).
-#ifndef MQ_BF16
+#ifdef MQ_PRIMARY_UNIT
 extern "C" int mq_dcnv2_stats_blocks(int H, int W, int stride) {
   const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
   return ((Ho + DCN_PH - 1) / DCN_PH) * ((Wo + DCN_PW - 1) / DCN_PW);
@@ -421,8 +442,9 @@ extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* 
   }
   if (g.n == 0) return 0;
   g.tiles_all = g.first_tile[g.n];
-  constexpr size_t tiles = (size_t)(2 * 128 * 64 + 2 * 256 * 64) * sizeof(half_t) + 128 * 9 * sizeof(TapState);
-  constexpr size_t ostage = (size_t)128 * (256 + 8) * sizeof(half_t) + (size_t)16 * 32 * 24 * sizeof(float);
+  constexpr size_t nbuf = sizeof(half_t) == 4 ? 1 : 2;
+  constexpr size_t tiles = (size_t)(nbuf * 128 * 64 + nbuf * 256 * 64) * sizeof(half_t) + 128 * 9 * sizeof(TapState);
+  constexpr size_t ostage = (size_t)128 * (256 + 8) * sizeof(half_t) + (sizeof(half_t) == 4 ? 0 : (size_t)16 * 32 * 24 * sizeof(float));
   constexpr size_t smem = tiles > ostage ? tiles : ostage;
   static MqOncePerDevice attr_set;
   if (attr_set.first()) {
@@ -434,7 +456,7 @@ extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* 
   }
   static const int nw = [] { const char* e = getenv("MQ_DCN_WAVES"); return (e && e[0] == '8') ? 8 : 16; }();   // A/B switch
   const dim3 grid((unsigned)(8 * ((g.tiles_all + 7) / 8)));
-#ifndef MQ_BF16
+#ifdef MQ_PRIMARY_UNIT
   if (const int abl = (br[0].flags >> 8) & 15) {             // ablation timings (tools/microbench.py)
     switch (abl) {
 #define MQ_DCN_ABL(A_)                                                                                                             \

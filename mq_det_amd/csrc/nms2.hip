@@ -11,7 +11,7 @@
 #include "common.h"
 
 MQ_NAMESPACE_BEGIN
-#ifndef MQ_BF16                                     // NMS works on fp32 boxes: one copy, in the fp16 translation unit
+#ifdef MQ_PRIMARY_UNIT                                     // NMS works on fp32 boxes: one copy, in the fp16 translation unit
 
 __device__ __forceinline__ float ml_iou2(const float* a, int la, const float* b, int lb) {
   if (la != lb) return 0.f;

@@ -158,7 +158,7 @@ extern "C" int MQ_SYM(mq_box_decode)(const float* val, const long* flat, const v
 }
 
 // ------------------------------------------------------------------------------------------------
-#ifndef MQ_BF16                                     // NMS works on fp32 boxes: one copy, in the fp16 translation unit
+#ifdef MQ_PRIMARY_UNIT                                     // NMS works on fp32 boxes: one copy, in the fp16 translation unit
 __device__ __forceinline__ float ml_iou(const float* a, int la, const float* b, int lb) {
   if (la != lb) return 0.f;
   float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);

@@ -15,7 +15,7 @@
 // topk / sort are not stable there either); here that order is fixed by the candidate id, so results are reproducible run to run.
 #include "common.h"
 
-#ifndef MQ_BF16      // fp32 / integer data only: one copy, in the fp16 translation unit
+#ifdef MQ_PRIMARY_UNIT      // fp32 / integer data only: one copy, in the fp16 translation unit
 
 namespace {
 constexpr int PS_MAXLVL = 8, PS_NT = 1024, PS_NW = PS_NT / 64;

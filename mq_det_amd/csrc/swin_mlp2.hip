@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64 * NW, (C <= 96 ? 4 : C <= 192 ? 3 : 2)) void swi
       const int f = wave + i * NW;
       const half_t* src = (f < W1_FR ? p.w1f + ((long)c1 * W1_FR + f) * FR : p.w2f + ((long)c2 * W2_FR + (f - W1_FR)) * FR) + lane * 8;
       half_t* dst = f < W1_FR ? w1s + (s1 * W1_FR + f) * FR : w2s + (s2 * W2_FR + (f - W1_FR)) * FR;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      lds_stage_frag8(src, dst, lane);
     }
   };
   // chunks 0 .. D of W1 and chunk 0 of W2 -- into its own stage 0 and into stage NS - 1, which iteration 0 reads for its GEMM2 of the

@@ -26,18 +26,6 @@
 
 MQ_NAMESPACE_BEGIN
 
-typedef __fp16 fp16x4_t __attribute__((__vector_size__(8)));
-typedef __attribute__((address_space(3))) fp16x4_t* lds_fp16x4_ptr;
-
-// 4x16 fp16 block, row-major in LDS (row pitch free), read column-wise: within a 16-lane group lane i passes the
-// address of the 4 contiguous halfs (row i/4, cols 4*(i%4)..+3) and receives (row 0..3, col i).
-__device__ __forceinline__ half4 lds_read_tr16(const half_t* p) {
-  fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4_ptr)p);
-  half4 o;
-  __builtin_memcpy(&o, &v, 8);
-  return o;
-}
-
 namespace {
 constexpr int VH = 8, VD = 256;            // max heads (run-time count in the params), head dim
 constexpr int BM = 128;                    // query rows per workgroup (4 waves x 32)
@@ -430,7 +418,7 @@ extern "C" int MQ_SYM(mq_vlfuse_i2t_fwd)(const void* v_ln, const void* kf, const
   const int nt = (kv + TK - 1) / TK;
   const int nbl = min(4, max(1, (kv - (nt - 1) * TK + 15) / 16));       // live 16-key blocks of the last tile
   hipStream_t st = (hipStream_t)stream;
-#ifndef MQ_BF16
+#ifdef MQ_PRIMARY_UNIT
   if (variant >= 100 && nt == 3 && nbl == 1) {                             // ablation timings (see vlfuse_i2t_kernel)
     switch (variant - 100) {
       case 1: return launch_i2t<3, 1, 1, 1>(p, st);
@@ -700,7 +688,7 @@ __global__ __launch_bounds__(256) void vlfuse_t2i_combine_kernel(T2IParams p) {
   *(half4*)dst = y;
 }
 
-#ifndef MQ_BF16
+#ifdef MQ_PRIMARY_UNIT
 extern "C" long mq_vlfuse_t2i_workspace_bytes(int B, int T, int nsplit) {
   return (long)(nsplit < 1 ? 1 : nsplit) * B * VH * T * WS_LD * (long)sizeof(float);
 }
@@ -732,7 +720,7 @@ extern "C" int MQ_SYM(mq_vlfuse_t2i_fwd)(const void* kf, const void* v_ln, const
   const int groups = B * nsplit, members = (heads * ((rows + p.wr - 1) / p.wr) + (128 / p.wr) - 1) / (128 / p.wr);
   p.members = members;
   const dim3 grid((unsigned)(8 * ((groups + 7) / 8) * members));
-#ifndef MQ_BF16
+#ifdef MQ_PRIMARY_UNIT
   if (variant >= 100 && !key_mask) {                                       // ablation timings (tools/microbench.py; results are garbage)
     hipStream_t st = (hipStream_t)stream;
     switch (variant - 100) {

@@ -26,13 +26,6 @@
 
 MQ_NAMESPACE_BEGIN
 
-typedef __fp16 fp16x4_t __attribute__((__vector_size__(8)));
-__device__ __forceinline__ half4 win_lds_tr16(const half_t* p) {
-  fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)p);
-  half4 o;
-  __builtin_memcpy(&o, &v, 8);
-  return o;
-}
 
 struct WinParams {
   const half_t* qkv; const half_t* qkv_bias; const float* rel_bias; half_t* out;
@@ -166,8 +159,8 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinParams p) {
       const half_t* base = Vs + (st * 32 + 4 * lg + (l15 >> 2)) * VP + (l15 & 3) * 4;
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
-        const half4 lo = win_lds_tr16(base + db * 16);
-        const half4 hi = win_lds_tr16(base + 16 * VP + db * 16);
+        const half4 lo = lds_read_tr16(base + db * 16);
+        const half4 hi = lds_read_tr16(base + 16 * VP + db * 16);
         half8 a;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { a[j] = lo[j]; a[4 + j] = hi[j]; }
@@ -252,7 +245,7 @@ __global__ __launch_bounds__(256, STREAM ? 1 : 2) void window_attn_qkv_kernel(Wi
         const int c = (posn & ~7) | ((posn ^ row) & 7);
         const half_t* src = p.w + ((long)(row >> 5) * C + h * 32 + (row & 31)) * C + c * 8;
         half_t* dst = Ws + buf * 96 * C + pc * 512;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        lds_stage_frag8(src, dst, lane);
       }
     }
   };

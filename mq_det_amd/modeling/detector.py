@@ -39,14 +39,18 @@ def expand_bbox(box_list, expand_ratio=1.5):
 
 
 def compute_dtype(cfg):
-    """MODEL.COMPUTE_DTYPE: the 16-bit operand type of every kernel on the path -- "float16" (default, BASELINE.json configs[1])
-    or "bfloat16" (configs[3]: the *_bf16 entry points of include/mqdet_hip.h); accumulation and residual streams are fp32 either way."""
+    """MODEL.COMPUTE_DTYPE: the operand type of every kernel on the path -- "float16" (default, BASELINE.json configs[1]),
+    "bfloat16" (configs[3]: the *_bf16 entry points of include/mqdet_hip.h) or "float32" (the precise mode: the *_f32 entry points, the
+    same kernel sources with fp32 operands, and fp32 library GEMMs -- a quarter of the MFMA rate, for parity at the north-star's 1e-3 end
+    to end, not for throughput); accumulation and residual streams are fp32 in every mode."""
     name = str(cfg.MODEL.get("COMPUTE_DTYPE", "float16")).lower()
     if name in ("float16", "fp16", "half"):
         return torch.float16
     if name in ("bfloat16", "bf16"):
         return torch.bfloat16
-    raise NotImplementedError(f"MODEL.COMPUTE_DTYPE = {name}: float16 or bfloat16")
+    if name in ("float32", "fp32", "float"):
+        return torch.float32
+    raise NotImplementedError(f"MODEL.COMPUTE_DTYPE = {name}: float16, bfloat16 or float32")
 
 
 def pool_into_bank(cfg, pooler, visual_features, targets, query_images, exclude_similar, max_query_number):

@@ -417,7 +417,8 @@ def bert_layer(P, b, x, key_bias, clamp, kv_len=None, x32=None, qk_mask=None, ma
     Returns y16 (and y32 when x32 is given)."""
     Bn, T, C = x.shape
     r32 = x32 is not None
-    if ops.KERNELS["BERT_QKV_FUSED"] == 1 and qk_mask is None and T <= 256 and (b + ".qkv.weight") in P and (key_bias is None or key_bias.dim() == 2):
+    if ops.KERNELS["BERT_QKV_FUSED"] == 1 and qk_mask is None and ops.attention_text_fits(T, kv_len, max_kv) and (b + ".qkv.weight") in P \
+            and (key_bias is None or key_bias.dim() == 2):
         ctx = ops.attention_text(_lin(P, b + ".qkv", x), 12, key_bias=key_bias, clamp=50000.0 if clamp else 0.0, kv_len=kv_len, max_kv=max_kv)
     else:
         qk = _lin(P, b + ".qk", x)                                                      # [B, T, 2C]
@@ -860,7 +861,10 @@ def vldyhead(P, cfg, feats, lang, trace=None):
     emb = F.normalize((hidden if h32 is None else h32).float(), p=2, dim=-1)
     tk = F.linear(emb / 2.0, P[p + ".tok.weight"], P[p + ".tok.bias"]) * P[p + ".inv_scale"]       # [B, T, 256]
     tbias = (emb @ P[p + ".bias_lang32"] + P[p + ".bias0_32"]).contiguous()                           # [B, T]
-    if ops.KERNELS["ALIGN_FUSED"] == 1 and tk.shape[1] <= 256 and tok.shape[-1] == 256 and len(sizes) <= 8:
+    live = min(tk.shape[1], max_kv) if max_kv > 0 else tk.shape[1]
+    # (precise mode on the device: the text tile of the fused kernel is 264 floats per live token -- captions of up to 144 tokens fit the LDS)
+    fits = ops.f32_operands() != 1 or -(-live // 16) * 16 <= 144
+    if ops.KERNELS["ALIGN_FUSED"] == 1 and tk.shape[1] <= 256 and tok.shape[-1] == 256 and len(sizes) <= 8 and fits:
         # (shapes the fused kernel does not take -- more than 256 text tokens, other widths, more than 8 levels -- use the GEMM path below)
         # heads + alignment + scoring happen in ONE kernel inside postprocess() (mq_align_fused_fwd): hand over its operands
         return {"tok": tok, "sizes": sizes, "tk16": tk.to(tok.dtype).contiguous(), "tbias": tbias, "max_kv": max_kv,

@@ -71,8 +71,13 @@ BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_text_fwd", "mq_pat
               "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_layernorm_clamp_fwd", "mq_clamp_gelu_clamp", "mq_patch_merge_ln_fwd", "mq_swin_mlp_fwd", "mq_swin_mlp2_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_conv3x3_nchw32_group_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
               "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyconv_epilogue_group", "mq_dyrelu_apply", "mq_dyrelu_ln_fwd", "mq_add_upsample_nearest",
               "mq_align_scores_fwd", "mq_align_fused_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
+# ... and as <name>_f32 (fp32 operands, the precise mode), except the operators whose inputs may already be fp32 in the 16-bit modes
+# (query extraction / MQ-GroundingDINO sampling: their two element types would coincide) and the superseded first Swin MLP kernel
+F32_TWINS = tuple(n for n in BF16_TWINS if n not in ("mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd", "mq_swin_mlp_fwd"))
 for _n in BF16_TWINS:
     _SIGNATURES[_n + "_bf16"] = _SIGNATURES[_n]
+for _n in F32_TWINS:
+    _SIGNATURES[_n + "_f32"] = _SIGNATURES[_n]
 EXPORTS = tuple(_SIGNATURES)
 
 
@@ -114,6 +119,12 @@ KERNEL_DEFAULTS = {
                                  # caption length); 0: q|k GEMM + V^T batched GEMM + mq_attn_resident_fwd (rounds 2-3)
     "POST_FUSED": 1,             # 1: ATSS post-processing as mq_post_select_fwd + mq_post_sort_fwd + mq_ml_nms_topk + mq_post_finalize_fwd (4 launches);
                                  # 0: the round-1..3 chain (5 x torch.topk + box_decode, argsort, gathers, NMS, topk: ~145 launches, 1.1 ms)
+    "F32_OPERANDS": 0,           # the PRECISE mode (MODEL.COMPUTE_DTYPE = "float32"; set by configure() from the config, or MQ_F32_OPERANDS): every kernel's
+                                 # 16-bit operands are floats -- the *_f32 entry points, the same kernel sources compiled a third time with
+                                 # half_t = float and one 16x16x32 MFMA = eight v_mfma_f32_16x16x4_f32 (csrc/common.h); library GEMMs run in fp32.
+                                 # 1 = on the device: where a kernel's LDS tiles no longer fit the 160 KB of a CU at twice the element size the
+                                 # wrappers pick the variant that does (streamed instead of resident operands, smaller tiles) or the plain
+                                 # fp32 torch form; 2 = kernel-source emulation with a 320 KB LDS limit (every kernel as in the 16-bit modes)
     "ALIGN_FUSED": 1,            # 1: mq_align_fused_fwd (heads + alignment + scoring, logits never written); 0: bmm + 5 GEMMs + 5 x mq_align_scores_fwd
 }
 KERNELS = dict(KERNEL_DEFAULTS)       # filled from the environment right below configure() (import time), from cfg in prepare()
@@ -125,12 +136,18 @@ def configure(cfg=None):
     node = None
     if cfg is not None:
         node = cfg.MODEL.get("KERNELS", None) if hasattr(cfg.MODEL, "get") else getattr(cfg.MODEL, "KERNELS", None)
+    if cfg is not None:
+        name = str(cfg.MODEL.get("COMPUTE_DTYPE", "float16") if hasattr(cfg.MODEL, "get") else getattr(cfg.MODEL, "COMPUTE_DTYPE", "float16")).lower()
+        sel["F32_OPERANDS"] = 1 if name in ("float32", "fp32", "float") else 0
     for k in sel:
         if node is not None and k in node:
             sel[k] = int(node[k])
         v = os.environ.get("MQ_" + k)
         if v is not None:
-            sel[k] = int(v)
+            try:
+                sel[k] = int(v)
+            except ValueError:
+                raise ValueError(f"environment variable MQ_{k} = {v!r}: the kernel selection takes integers") from None
     KERNELS.clear()
     KERNELS.update(sel)
     return KERNELS
@@ -230,12 +247,35 @@ def _chk(rc, name):
         raise RuntimeError(f"{name} failed with code {rc}")
 
 
-_H16 = (torch.float16, torch.bfloat16)
+class _OperandTypes:
+    """The tensor dtypes the kernels take as their MFMA operands: fp16 / bf16, or -- in the precise mode, KERNELS["F32_OPERANDS"] -- fp32."""
+
+    def _cur(self):
+        return (torch.float32,) if KERNELS.get("F32_OPERANDS", 0) else (torch.float16, torch.bfloat16)
+
+    def __contains__(self, dtype):
+        return dtype in self._cur()
+
+    def __iter__(self):
+        return iter(self._cur())
+
+    def __getitem__(self, i):
+        return self._cur()[i]
+
+
+_H16 = _OperandTypes()
+
+
+def f32_operands():
+    """0: 16-bit operands; 1: the precise mode on the device (160 KB of LDS per workgroup); 2: the same through the kernel-source emulation."""
+    return KERNELS.get("F32_OPERANDS", 0)
 
 
 def _fn(lib, name, *ts):
-    """The entry point for the 16-bit type of the operands `ts`: `name` (fp16) or `name_bf16` (the same kernel compiled with bf16
-    operands, include/mqdet_hip.h MQ_BF16_TWIN).  All 16-bit operands of one call must have the same type."""
+    """The entry point for the operand type of `ts`: `name` (fp16), `name_bf16` (the same kernel compiled with bf16 operands,
+    include/mqdet_hip.h MQ_BF16_TWIN) or, in the precise mode, `name_f32` (fp32 operands).  All operands of one call must have the same type."""
+    if KERNELS.get("F32_OPERANDS", 0):
+        return getattr(lib, name + "_f32")
     kinds = {t.dtype for t in ts if t is not None and t.dtype in _H16}
     if len(kinds) > 1:
         raise TypeError(f"{name}: fp16 and bf16 operands in one call")
@@ -280,6 +320,13 @@ def patch_embed(img, wpk, bias, g0, b0, g1, b1, eps=1e-5):
     return x32, h1
 
 
+def attention_text_fits(T, kv_len=None, max_kv=0):
+    """Does mq_attn_text_fwd take this key length?  Always in the 16-bit modes (T <= 256); in the precise mode on the device its K / V tiles are
+    80 floats per key: up to 160 live keys fit the LDS (longer captions: q|k GEMM + V^T + mq_attn_resident_fwd)."""
+    live = max_kv if (kv_len is not None and 0 < max_kv < T) else T
+    return T <= 256 and (f32_operands() != 1 or live <= 160)
+
+
 def attention_text(qkv, heads, key_bias=None, clamp=0.0, kv_len=None, max_kv=0, scale=None):
     """Self-attention of the text tokens straight from the fused projection qkv [B,T,3*H*D] (q | k | v along the last dimension), V
     row-major (mq_attn_text_fwd).  key_bias None, [B,T] or [B,H,T] fp32; kv_len [B] int32; max_kv: host bound on kv_len (0 = T).
@@ -290,8 +337,13 @@ def attention_text(qkv, heads, key_bias=None, clamp=0.0, kv_len=None, max_kv=0, 
     HD = C3 // 3
     D = HD // heads
     assert C3 == 3 * heads * D and qkv.dtype in _H16 and qkv.stride(2) == 1 and T <= 256 and D in (32, 64)
+    assert attention_text_fits(T, kv_len, max_kv), "precise mode: mq_attn_text_fwd_f32 holds up to 160 live keys in LDS"
     if kv_len is not None:
         assert kv_len.dtype == torch.int32 and kv_len.shape == (B,) and kv_len.is_contiguous()
+        # max_kv sizes the LDS tiles and the key-block loop: it must cover every kv_len[b] (a smaller bound silently drops live keys -- ADVICE r4).
+        # Checked on the host only in debug runs (MQ_DEBUG_SYNC=1): the comparison reads a device tensor
+        if max_kv > 0 and os.environ.get("MQ_DEBUG_SYNC") == "1":
+            assert int(kv_len.max()) <= max(max_kv, 1), f"attention_text: max_kv = {max_kv} < kv_len.max() = {int(kv_len.max())}"
     bias_bs = bias_hs = 0
     if key_bias is not None:
         assert key_bias.dtype == torch.float32 and key_bias.shape[-1] == T and key_bias.stride(-1) == 1
@@ -500,6 +552,21 @@ def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.
         assert bias.shape == (B, Hh, T) and bias.dtype == torch.float32 and bias.is_contiguous()
     if kv_len is not None:
         assert kv_len.dtype == torch.int32 and kv_len.numel() == B and kv_len.is_contiguous()
+    live = max_kv if (kv_len is not None and 0 < max_kv < T) else T
+    if f32_operands() == 1 and live > 160:
+        # precise mode, captions of more than 160 tokens: the Q tile the kernel then keeps in LDS beside two K / V tiles is 136 KB at fp32 --
+        # the plain fp32 statement of the same sum instead (fuse_helper.py:233-273 with the folded operands; 8 x N x T logits in HBM)
+        lg = torch.einsum("bnc,bhtc->bhnt", v_ln, kf)
+        masked = torch.zeros(B, Hh, T, dtype=torch.bool, device=v_ln.device)
+        if bias is not None:
+            masked = bias < -1.0e29
+            lg = lg + torch.where(masked, torch.zeros_like(bias), bias)[:, :, None, :]
+        if kv_len is not None:
+            masked = masked | (torch.arange(T, device=v_ln.device)[None, None, :] >= kv_len.clamp(1, T)[:, None, None])
+        if clamp > 0:
+            lg = lg.clamp(-clamp, clamp)
+        lg = lg.masked_fill(masked[:, :, None, :], -1.0e30)                  # the mask behind the clamp, as in the kernel (fuse_helper.py:236-262)
+        return v_ln + out_bias + torch.einsum("bhnt,bhtc->bnc", torch.softmax(lg, -1), vo)
     out = torch.empty_like(v_ln)
     variant = KERNELS["VLFUSE_I2T_VARIANT"] if variant is None else int(variant)
     with _timed(f"vlfuse_i2t_n{N}_t{T}"):
@@ -679,6 +746,8 @@ def swin_mlp2(x, delta, ln_g, ln_b, eps, w1f, b1, w2f, b2, next_ln=None, flags=N
     flags = KERNELS["SWIN_MLP2_FLAGS"] if flags is None else int(flags)
     if flags < 0:
         flags = 0 if C == 192 else 2          # table GELU except at C = 192 (profiles/r03_call5_microbench_swin_mlp.json)
+    if f32_operands() == 1 and C >= 384:
+        flags |= 4            # precise mode: the main kernel's weight stages are 196 KB at fp32 -- every block through the tail kernel (fragments from global memory)
     fn = _fn(lib, "mq_swin_mlp2_fwd", w1f)
 
     def call(fl):
@@ -750,6 +819,8 @@ class _ConvLevel(ctypes.Structure):
 
 def conv3x3_nchw32_group_supported(levels, n_out):
     """Shapes mq_conv3x3_nchw32_group_fwd takes (else: conv3x3_nchw32 per level)."""
+    if f32_operands() == 1:
+        return False          # precise mode: the 180-pixel window of all 256 channels is 196 KB at fp32 -- the per-level kernel (two channel passes) fits
     return 0 < len(levels) <= 8 and n_out <= 32 and all(x.shape[3] == 256 and x.shape[1] * x.shape[2] * 256 < 2 ** 31 for x in levels)
 
 
@@ -1062,6 +1133,9 @@ def align_fused(tok, tk, tbias, wbc, bbc, scales, tokidx, sizes, thr, agg=0, kv_
     assert tbias.dtype == torch.float32 and tbias.shape == (B, T) and tbias.is_contiguous()
     assert bbc.dtype == scales.dtype == torch.float32 and bbc.numel() >= 8 and scales.numel() >= NL
     assert tokidx.dtype == torch.int32 and tokidx.is_contiguous() and (tokidx.dim() == 2 or tokidx.shape[0] == B)
+    live = kv_max if 0 < kv_max < T else T
+    if f32_operands() == 1 and -(-live // 16) * 16 > 144:
+        raise RuntimeError(f"mq_align_fused_fwd_f32: the text tile of {live} live tokens does not fit the LDS at fp32 (up to 144; the GEMM path takes longer captions)")
     dev = tok.device
     ranked = torch.empty(B * N * L, dtype=torch.float32, device=dev)
     cls = torch.empty(B * N * L, dtype=torch.float32, device=dev) if want_cls else None

@@ -733,6 +733,8 @@ def check_align_fused(dev):
         B, sizes, T, L, MT = c["B"], c["sizes"], c["T"], c["L"], c["MT"]
         N = sum(h * w for h, w in sizes)
         nv = c["kv"] if c["kv"] else T
+        if ops.f32_operands() == 1 and nv > 144:
+            continue        # precise mode on the device: 264 floats of LDS per live text token -- the pipeline sends longer captions down the GEMM path
         tok = (torch.randn(B, N, 256, generator=g) * 0.7).to(H16)
         tk = (torch.randn(B, T, 256, generator=g) * 0.12).to(H16)
         tbias = torch.randn(B, T, generator=g) * 0.5 - 1.0

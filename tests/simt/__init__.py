@@ -3,6 +3,7 @@
 machine without a GPU, on CPU tensors.  Nothing under mq_det_amd/ imports this package; the product raises without a GPU."""
 import contextlib
 import ctypes
+import os
 
 from . import build_emu
 
@@ -36,20 +37,25 @@ def set_schedule(mode="ascending", seed=0):
 @contextlib.contextmanager
 def installed(f32=False):
     """with installed(): mq_det_amd.ops.* run on CPU tensors through the emulated kernels.
-    f32=True: through the fp32-OPERAND build of the kernel sources (entry points *_f32: every 16-bit operand is a float, the emulated
-    MFMA multiplies exactly) -- the wrappers then take float32 tensors wherever they take fp16 / bf16 on the device.  What is left
-    between such a run and the fp32 oracle is the kernels' logic and summation order, not operand rounding."""
-    import torch
+    f32 = 1 / True: the PRECISE mode exactly as the device runs it (KERNELS["F32_OPERANDS"] = 1: entry points *_f32 -- every operand a
+    float, one 16x16x32 MFMA = eight exact 16x16x4 fp32 MFMAs --, 160 KB of LDS per workgroup, the wrappers' choice of variants that fit);
+    f32 = 2: the same operand type with a 320 KB LDS limit, i.e. EVERY kernel in the shape the 16-bit modes launch it (kernel logic
+    against the fp32 oracle).  The wrappers then take float32 tensors wherever they take fp16 / bf16 on the device."""
     from mq_det_amd import ops
-    saved = (ops._LIB, ops._need_gpu, ops._stream, ops._fn, ops._H16)
+    saved = (ops._LIB, ops._need_gpu, ops._stream, os.environ.get("MQ_F32_OPERANDS"))
     lib = library()
     ops._LIB, ops._need_gpu, ops._stream = lib, (lambda *ts: None), (lambda: ctypes.c_void_p(0))
     if f32:
-        ops._fn = lambda lib_, name, *ts: getattr(lib_, name + "_f32")
-        ops._H16 = (torch.float32,)
-        lib.simt_set_lds_limit(320 << 10)                 # every 16-bit LDS tile is twice as large
+        os.environ["MQ_F32_OPERANDS"] = str(int(f32))
+        lib.simt_set_lds_limit((160 if int(f32) == 1 else 320) << 10)
+    ops.configure()
     try:
         yield ops
     finally:
-        ops._LIB, ops._need_gpu, ops._stream, ops._fn, ops._H16 = saved
+        ops._LIB, ops._need_gpu, ops._stream = saved[:3]
+        if saved[3] is None:
+            os.environ.pop("MQ_F32_OPERANDS", None)
+        else:
+            os.environ["MQ_F32_OPERANDS"] = saved[3]
+        ops.configure()
         lib.simt_set_lds_limit(160 << 10)

@@ -24,30 +24,14 @@ FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-fno-strict-aliasing", "-Wn
 
 # not built with fp32 operands: the MQ-GroundingDINO / query-extraction operators (their inputs may already be fp32 -- the two template
 # arguments would coincide) and the superseded first Swin MLP kernel
-F32_SKIP = ("msda.cpp", "roi_align.cpp", "swin_mlp.cpp")
+F32_SKIP = ("msda.cpp", "roi_align.cpp", "swin_mlp.cpp", "nms2.cpp", "post2.cpp")
 _SHARED = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([A-Za-z_][\w\s]*?)\s+(\w+)\s*\[\s*\]\s*;")
 
 
-_F32_TYPES = """#if defined(MQ_SIMT_F32)
-// fp32-OPERAND build (emulation only, VERDICT r2 item 1b): every 16-bit operand of the kernel sources is a float; the emulated MFMA
-// multiplies them exactly.  What differs from the fp32 oracle then is the kernels' LOGIC and summation order -- not operand rounding.
-typedef float half_t;
-typedef float half8 __attribute__((ext_vector_type(8)));
-typedef float half4 __attribute__((ext_vector_type(4)));
-typedef float half2_ __attribute__((ext_vector_type(2)));
-#define MQ_SYM(name) name##_f32
-#define MQ_NAMESPACE_BEGIN namespace mq_f32 {
-#define MQ_NAMESPACE_END }
-#elif defined(MQ_BF16)
-"""
-_TR16 = re.compile(r"fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16\([^;]*?\bp\);\s*half4 o;\s*__builtin_memcpy\(&o, &v, 8\);\s*return o;")
 
 
 def rewrite(text):
     text = _SHARED.sub(lambda m: f"{m.group(1)}* {m.group(2)} = ({m.group(1)}*)simt::dyn_smem();", text)
-    text = text.replace("#ifdef MQ_BF16\ntypedef __bf16 half_t;", _F32_TYPES + "typedef __bf16 half_t;")              # csrc/common.h
-    text = text.replace("#ifndef MQ_BF16", "#if !defined(MQ_BF16) && !defined(MQ_SIMT_F32)")         # symbols without a 16-bit twin: one copy
-    text = _TR16.sub("return simt_ds_read_tr_elems<half4>((const void*)p);", text)                 # same exchange, any element size
     text = text.replace('#include "../../include/', '#include "')                  # -I <repo>/include
     return re.sub(r"\basm\s+volatile\s*\(", "SIMT_ASM(", text)
 
@@ -80,7 +64,7 @@ def build(force=False, verbose=False, sources=None):
     units = [os.path.join(src_dir, f.replace(".hip", ".cpp")) for f in names if f.endswith(".hip")] + [os.path.join(HERE, "simt_runtime.cpp"), os.path.join(HERE, "selftest.cpp")]
     for u in units:
         # like mq_det_amd/build.py: every kernel source twice, fp16 and -DMQ_BF16 (the *_bf16 entry points)
-        for suffix, defs in (("", []), ("_bf16", ["-DMQ_BF16"]), ("_f32", ["-DMQ_SIMT_F32"])):
+        for suffix, defs in (("", []), ("_bf16", ["-DMQ_BF16"]), ("_f32", ["-DMQ_F32"])):
             if suffix and os.path.basename(u) in ("api.cpp", "simt_runtime.cpp", "selftest.cpp"):
                 continue
             if suffix == "_f32" and os.path.basename(u) in F32_SKIP:

@@ -223,6 +223,37 @@ inline simt_float16 simt_mfma_32x32x16(V8 a, V8 b, simt_float16 c) {
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) simt_mfma_32x32x16((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) simt_mfma_16x16x32((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) simt_mfma_16x16x32((a), (b), (c))
+// v_mfma_f32_16x16x4_f32 (the fp32-operand build, csrc/common.h mfma16 under MQ_F32): A lane l = A[l & 15][l >> 4], B lane l = B[l >> 4][l & 15],
+// D as above; every product is an exact fp32 multiply, the four products of an output are added in k order into the accumulator
+inline void simt_mfma4_tile(void* ctx) {
+  const int buf = (int)(intptr_t)ctx;
+  float A[16][4], B[4][16];
+  for (int l = 0; l < 64; ++l) {
+    float ab[2];
+    memcpy(ab, simt::xslot(l, buf), 8);
+    A[l & 15][l >> 4] = ab[0];
+    B[l >> 4][l & 15] = ab[1];
+  }
+  float* D = simt::wave_tile(buf);
+  for (int i = 0; i < 16; ++i)
+    for (int n = 0; n < 16; ++n) {
+      float acc = 0.f;
+      for (int k = 0; k < 4; ++k) acc += A[i][k] * B[k][n];
+      D[i * 16 + n] = acc;
+    }
+}
+inline simt_float4 simt_mfma_16x16x4_f32(float a, float b, simt_float4 c) {
+  const int buf = simt::next_buf(), l = simt::lane();
+  float ab[2] = {a, b};
+  memcpy(simt::xslot(l, buf), ab, 8);
+  simt::wave_sync_then(&simt_mfma4_tile, (void*)(intptr_t)buf);
+  const float* D = simt::wave_tile(buf);
+  const int col = l & 15, r0 = 4 * (l >> 4);
+  for (int r = 0; r < 4; ++r) c[r] += D[(r0 + r) * 16 + col];
+  return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) simt_mfma_16x16x4_f32((a), (b), (c))
+inline int __lane_id() { return simt::lane(); }
 
 // ds_read_b64_tr_b16: inside each 16-lane group the 16 x 4 block of 16-bit elements addressed by the lanes (lane i: row i >> 2,
 // columns 4 (i & 3) .. + 3 of a [4][16] matrix) comes back transposed: lane i receives column i, rows 0..3
@@ -267,12 +298,7 @@ inline V4 simt_ds_read_tr_elems(const void* p) {
 inline void simt_global_load_lds(const void* g, void* lds, unsigned size) { memcpy((char*)lds + (size_t)simt::lane() * size, g, size); }
 // (the size argument must be a literal in the product source -- hipcc crashes on sizeof(half8) there --, so the fp32-operand build,
 // whose "16-bit" fragments are twice as wide, scales it here)
-#ifdef MQ_SIMT_F32
-#define SIMT_DMA_SCALE 2
-#else
-#define SIMT_DMA_SCALE 1
-#endif
-#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) simt_global_load_lds((const void*)(g), (void*)(l), (unsigned)(size) * SIMT_DMA_SCALE)
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) simt_global_load_lds((const void*)(g), (void*)(l), (unsigned)(size))
 inline float simt_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 #define __builtin_amdgcn_fmed3f(a, b, c) simt_fmed3f((a), (b), (c))
 #define __builtin_amdgcn_s_barrier() simt::block_sync()

@@ -18,7 +18,9 @@ def test_c_abi_exports_match_header():
     hdr = open(os.path.join(ROOT, "include", "mqdet_hip.h")).read()
     twins = set(re.findall(r"^MQ_BF16_TWIN\((mq_[a-z0-9_]+)\)", hdr, re.M))
     assert twins == set(ops.BF16_TWINS), twins ^ set(ops.BF16_TWINS)
-    declared = set(re.findall(r"\b(mq_[a-z0-9_]+)\s*\(", hdr)) | {n + "_bf16" for n in twins}
+    twins32 = set(re.findall(r"^MQ_F32_TWIN\((mq_[a-z0-9_]+)\)", hdr, re.M))
+    assert twins32 == set(ops.F32_TWINS), twins32 ^ set(ops.F32_TWINS)
+    declared = set(re.findall(r"\b(mq_[a-z0-9_]+)\s*\(", hdr)) | {n + "_bf16" for n in twins} | {n + "_f32" for n in twins32}
     assert declared == set(ops.EXPORTS), declared ^ set(ops.EXPORTS)
     lib = ops.load_library()
     for name in declared:
@@ -268,6 +270,8 @@ def test_ctypes_signatures_match_header():
     twins = re.findall(r"^MQ_BF16_TWIN\((mq_\w+)\)", text, re.M)              # `extern decltype(name) name_bf16;`: same signature
     for n in twins:
         decls[n + "_bf16"] = decls[n]
+    for n in re.findall(r"^MQ_F32_TWIN\((mq_\w+)\)", text, re.M):            # ... and name_f32 (the precise mode)
+        decls[n + "_f32"] = decls[n]
     assert set(decls) == set(ops._SIGNATURES), set(decls) ^ set(ops._SIGNATURES)
 
     def kind(arg):

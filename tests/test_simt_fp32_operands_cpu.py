@@ -20,8 +20,11 @@ _CXX = os.environ.get("SIMT_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 pytestmark = pytest.mark.skipif(not os.path.exists(_CXX), reason=f"{_CXX} not found: the kernel-source emulation cannot be built here")
 
 
-@pytest.fixture(scope="module")
-def f32():
+@pytest.fixture(scope="module", params=[1, 2], ids=["device_limits", "every_kernel"])
+def f32(request):
+    """params: 1 = the precise mode exactly as the MI355X runs it (160 KB of LDS per workgroup: ops.py picks the kernel variants that fit at
+    twice the element size -- what passes here is what `MODEL.COMPUTE_DTYPE = "float32"` launches on the device); 2 = a 320 KB limit, i.e.
+    every kernel in the shape the 16-bit modes launch it (the kernel LOGIC of the shipped fp16 / bf16 path against the fp32 oracle)."""
     import simt
     import parity_checks as pc
     from mq_det_amd.modeling import detector, pipeline
@@ -29,6 +32,7 @@ def f32():
     def prepare(self, device=None):
         from mq_det_amd import ops
         ops.configure(self.cfg)
+        self._kernels = dict(ops.KERNELS)
         self._validate_config()
         self._plan = pipeline.build_plan(self.state_dict(), self.cfg, CPU, dtype=torch.float32)
         self._plan_key, self.use_hip_graph = CPU, False
@@ -37,7 +41,8 @@ def f32():
     detector.GeneralizedVLRCNN_New.prepare = prepare
     pc.QUICK, pc.PINS = True, False
     pc.use_dtype(torch.float32)
-    with simt.installed(f32=True):
+    pc._CACHE.clear()
+    with simt.installed(f32=request.param):
         yield pc
     pc.use_dtype(torch.float16)
     detector.GeneralizedVLRCNN_New.prepare, pc.QUICK, pc.PINS = saved[:3]
