@@ -5,16 +5,15 @@ inference forward (Swin + BERT/GCP + VLDyHead + ATSS post-processing) behind the
 The hot ops are hand-written HIP kernels in csrc/ (C ABI: include/mqdet_hip.h, ctypes binding: ops.py);
 PyTorch is used for device memory, streams, library GEMMs/convs and torch.distributed only.
 """
-import os as _os
+# Process environment the forward is TUNED for (never set by importing this package -- ADVICE r4: an import must not change the queue
+# behaviour of unrelated HIP users of the process, and the variable has no effect once the HIP runtime is initialised).  The forward runs
+# its text / level / image chains as parallel branches of one HIP graph; the ROCm runtime maps HIP streams onto GPU_MAX_HW_QUEUES hardware
+# queues (default 4), and branches that share a queue serialise.  8 queues: +2.8 % / +3.4 % end to end in two A/B runs on the MI355X
+# (profiles/r04_call5_lanes_ab.txt; 16 queues lose 30 %).  bench.py and INTEGRATION.md's launch line export it before the first device call.
+RECOMMENDED_ENV = {"GPU_MAX_HW_QUEUES": "8"}
 
-# The forward runs its text / level / image chains as parallel branches of one HIP graph; the ROCm runtime maps HIP streams onto
-# GPU_MAX_HW_QUEUES hardware queues (default 4), and branches that share a queue serialise.  8 queues: +2.8 % / +3.4 % end to end in two
-# A/B runs on the MI355X (profiles/r04_call5_lanes_ab.txt; 16 queues lose 30 %).  Only a default: an exported value wins, and the
-# variable is read when the HIP runtime initialises (first device call), so importing this package before that is enough.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
-from .config import CfgNode, get_cfg  # noqa: F401,E402
-from .structures import BoxList, ImageList, to_image_list, cat_boxlist  # noqa: F401,E402
+from .config import CfgNode, get_cfg  # noqa: F401
+from .structures import BoxList, ImageList, to_image_list, cat_boxlist  # noqa: F401
 
 
 def build_detection_model(cfg, **kwargs):

@@ -140,24 +140,29 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // hipFuncSetAttribute (LDS above 64 KB) and the CU count are per-DEVICE properties: a process that drives several GPUs sets / reads them
 // once per device, not once per process.
+// (the device index found by first() / need() reaches done() through a THREAD-LOCAL, not through a member of the shared static
+// object -- two host threads driving different GPUs cannot mark each other's device.)
+static thread_local int mq_tl_dev = -1;
 struct MqOncePerDevice {
-  bool set_[32] = {};
-  int dev_ = -1;
+  volatile bool set_[32] = {};
   bool first() {
-    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 32) { dev_ = -1; return true; }
-    return !set_[dev_];
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) { mq_tl_dev = -1; return true; }
+    mq_tl_dev = dev;
+    return !set_[dev];
   }
-  void done() { if (dev_ >= 0) set_[dev_] = true; }
+  void done() { if (mq_tl_dev >= 0) set_[mq_tl_dev] = true; }
 };
 // the same for launchers whose dynamic LDS size depends on the call: the largest size the attribute was set to, per device
 struct MqMaxPerDevice {
-  size_t max_[32] = {};
-  int dev_ = -1;
+  volatile size_t max_[32] = {};
   bool need(size_t bytes) {
-    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 32) { dev_ = -1; return true; }
-    return bytes > max_[dev_];
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) { mq_tl_dev = -1; return true; }
+    mq_tl_dev = dev;
+    return bytes > max_[dev];
   }
-  void done(size_t bytes) { if (dev_ >= 0) max_[dev_] = bytes; }
+  void done(size_t bytes) { if (mq_tl_dev >= 0 && bytes > max_[mq_tl_dev]) max_[mq_tl_dev] = bytes; }
 };
 static inline int mq_device_cus() {
   static int cus[32] = {};

@@ -262,6 +262,12 @@ class _OperandTypes:
     def __getitem__(self, i):
         return self._cur()[i]
 
+    def __add__(self, other):
+        return self._cur() + tuple(other)
+
+    def __radd__(self, other):
+        return tuple(other) + self._cur()
+
 
 _H16 = _OperandTypes()
 

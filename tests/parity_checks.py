@@ -26,12 +26,23 @@ H16 = torch.float16
 TOL_SCALE = 1.0
 
 
+ELEM_TOL = 1e-3      # atol = rtol of the element-wise column of _stat ("atol = rtol = 1e-3")
+ELEM_FRAC_16 = 1e-5  # 16-bit operands, per-kernel rows: at most this fraction of elements outside atol + rtol |ref|
+# ... except the kernels that round an INTERMEDIATE to 16 bits because it is the operand of their second MFMA -- the softmax probabilities P
+# of every attention kernel (and q | k | v inside the Swin attention with the projection fused: the rounding point of the reference's qkv
+# tensor).  P <= 1 carries a relative error of 2^-12; where one key holds the probability mass and the head outputs cancel in the sum over
+# heads (VLFuse image side: 8 heads x |Vo| ~ 3 summed into an output of ~ 1) single elements land at 2 - 3e-3 absolute.  The fp32-operand
+# build of the same kernels has ZERO violations in every row (the gate of the precise mode), so this is operand rounding, not logic.
+ELEM_FRAC_P16 = 1e-3
+_P16_ROWS = ("attn", "window_attn", "vlfuse", "gcp sparse", "gcp pre", "... vs GEMM + mq_window_attn_fwd")
 F32_TOL = 1e-3       # the north-star tolerance: met by every stage once the operands are not rounded (tests/test_simt_fp32_operands_cpu.py)
 
 
 def use_dtype(dtype):
-    """torch.float32: only through the fp32-operand build of the kernel sources in the emulation (tests/simt, `installed(f32=True)`):
-    nothing is rounded to 16 bits, and EVERY tolerance becomes F32_TOL = 1e-3 of the reference's range."""
+    """torch.float32: the precise mode (MODEL.COMPUTE_DTYPE = "float32", the *_f32 entry points -- on the device, or through the
+    emulation with `simt.installed(f32=...)`); the caller also selects KERNELS["F32_OPERANDS"] (environment MQ_F32_OPERANDS + ops.configure()).
+    Nothing is rounded to 16 bits, EVERY tolerance becomes F32_TOL = 1e-3 of the reference's range and no element may lie outside
+    atol = rtol = 1e-3."""
     global H16, TOL_SCALE
     assert dtype in (torch.float16, torch.bfloat16, torch.float32)
     H16, TOL_SCALE = dtype, (8.0 if dtype == torch.bfloat16 else 1.0)
@@ -62,7 +73,7 @@ def _measured(name):
     return _MEASURED.get(name)
 
 
-def _stat(name, got, ref, tol=TOL):
+def _stat(name, got, ref, tol=TOL, elem_gate=None):
     tol = tol * TOL_SCALE
     if H16 == torch.bfloat16:
         name = "[bf16] " + name
@@ -74,12 +85,27 @@ def _stat(name, got, ref, tol=TOL):
             margin = MEASURED_MARGIN_DEEP if any(t in name for t in _DEEP_ROWS) else MEASURED_MARGIN
             tol = min(tol, max(MEASURED_FLOOR * TOL_SCALE, margin * m))
     got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
-    err = (got - ref).abs().max().item() if ref.numel() else 0.0
+    diff = (got - ref).abs()
+    err = diff.max().item() if ref.numel() else 0.0
     scale = max(1.0, ref.abs().max().item() if ref.numel() else 1.0)
-    mean = (got - ref).abs().mean().item() if ref.numel() else 0.0
+    mean = diff.mean().item() if ref.numel() else 0.0
     bad = not math.isfinite(err)
-    return {"name": name, "max_err": err, "mean_err": mean, "ref_absmax": scale, "norm_err": err / scale,
-            "tol": tol, "ok": (not bad) and err <= tol * scale}
+    # SURVEY 8(c) / VERDICT r4 item 1a -- the ELEMENT-WISE statement beside the max-norm one: the fraction of elements outside
+    # |got - ref| <= atol + rtol |ref| with atol = rtol = 1e-3 (x 8 for bf16), i.e. what torch.allclose(got, ref, 1e-3, 1e-3) counts.
+    e_tol = ELEM_TOL * TOL_SCALE
+    viol = (diff > e_tol + e_tol * ref.abs()).float().mean().item() if ref.numel() else 0.0
+    # gated: (a) with fp32 operands EVERY row, at zero violations; (b) with 16-bit operands the per-KERNEL rows (stated tolerance <= 2e-3 of
+    # the range: one kernel against the oracle on the same rounded operands) at ELEM_FRAC_16 -- what a 16-bit-stored output may lose to
+    # rounding of values that cancel; deep-stack rows (whole models / layers, 16-bit storage between kernels) carry the column ungated.
+    deep = any(t_ in name for t_ in _DEEP_ROWS)
+    if H16 == torch.float32:
+        e_ok = viol == 0.0
+    else:
+        frac = ELEM_FRAC_P16 if any(name.startswith(t_) or name.startswith("[bf16] " + t_) for t_ in _P16_ROWS) else ELEM_FRAC_16
+        gated = (not deep and tol <= 2e-3 * TOL_SCALE) if elem_gate is None else bool(elem_gate)
+        e_ok = (not gated) or viol <= frac
+    return {"name": name, "max_err": err, "mean_err": mean, "ref_absmax": scale, "norm_err": err / scale, "elem_viol_frac": viol,
+            "elem_ok": e_ok, "tol": tol, "ok": (not bad) and err <= tol * scale and e_ok}
 
 
 def _ref_attention(q, k, v, H, key_bias=None, scale=None, clamp=0.0):
@@ -202,7 +228,7 @@ def _tiny(dev, image_hw=(160, 192), B=2, seed=0, spec=None):
     cfg.MODEL.DYHEAD.NUM_CONVS = spec.dyhead_convs
     cfg.MODEL.DYHEAD.NUM_CLASSES = spec.num_classes
     cfg.MODEL.ATSS.DETECTIONS_PER_IMG = spec.detections_per_img
-    cfg.MODEL.COMPUTE_DTYPE = "bfloat16" if H16 == torch.bfloat16 else "float16"
+    cfg.MODEL.COMPUTE_DTYPE = _DTYPE_NAME[H16]
     model = GeneralizedVLRCNN_New(cfg, tokenizer=object())
     model.load_state_dict(sd, strict=True)
     model.to(dev)
@@ -211,6 +237,7 @@ def _tiny(dev, image_hw=(160, 192), B=2, seed=0, spec=None):
 
 
 _CACHE = {}
+_DTYPE_NAME = {torch.float16: "float16", torch.bfloat16: "bfloat16", torch.float32: "float32"}
 
 
 def tiny(dev, large=False):
@@ -1294,7 +1321,7 @@ def _bench_model(dev, residual_fp32=True, family="t"):
         cfg.MODEL.ATSS.DETECTIONS_PER_IMG = spec.detections_per_img
         cfg.TEST.MDETR_STYLE_AGGREGATE_CLASS_NUM = spec.mdetr_class_num
         cfg.MODEL.RESIDUAL_FP32 = residual_fp32
-        cfg.MODEL.COMPUTE_DTYPE = "bfloat16" if H16 == torch.bfloat16 else "float16"
+        cfg.MODEL.COMPUTE_DTYPE = _DTYPE_NAME[H16]
         model = GeneralizedVLRCNN_New(cfg, tokenizer=object())
         model.load_state_dict(sd, strict=True)
         model.to(dev)
@@ -1351,6 +1378,12 @@ def _bench_gate(tag, got, ref_rows, fixture, fl_rows, residual_fp32, case):
     med_gate, row_gate, row_max_gate = (FLOOR_RATIO_MEDIAN, FLOOR_RATIO_ROW, FLOOR_RATIO_ROW_MAX) if H16 == torch.float16 else _BF16_GATE
     for name, (kind, ref) in ref_rows.items():
         r = _stat(f"{tag} {name}", got[name], ref, tol=BENCH_TOL[kind])
+        if H16 == torch.float32:
+            # the precise mode: no operand rounding, so no floor to relate to -- every stage at F32_TOL = 1e-3 of the range AND zero elements
+            # outside atol = rtol = 1e-3 (both inside _stat)
+            r["gate"] = "fp32 operands: norm_err <= 1e-3, no element outside 1e-3 + 1e-3 |ref|"
+            res.append(r)
+            continue
         fx = fixture.get(name)
         if fl_rows is not None:
             f = _stat("floor", fl_rows[name][1], ref)

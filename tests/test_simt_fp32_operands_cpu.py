@@ -34,6 +34,7 @@ def f32(request):
         ops.configure(self.cfg)
         self._kernels = dict(ops.KERNELS)
         self._validate_config()
+        assert detector.compute_dtype(self.cfg) == torch.float32          # parity_checks builds its models with MODEL.COMPUTE_DTYPE = "float32"
         self._plan = pipeline.build_plan(self.state_dict(), self.cfg, CPU, dtype=torch.float32)
         self._plan_key, self.use_hip_graph = CPU, False
         return self._plan

@@ -73,7 +73,9 @@ def main():
                 if "HIP-graph" in r["name"]:
                     continue                      # rows that assert an actual graph capture
                 n_bad += not r["ok"]
-                print(f"{'PASS' if r['ok'] else 'FAIL'} [{group}] {r['name']} norm_err={r['norm_err']:.2e} tol={r['tol']:.1e}", flush=True)
+                ev = r.get("elem_viol_frac", 0.0)
+                print(f"{'PASS' if r['ok'] else 'FAIL'} [{group}] {r['name']} norm_err={r['norm_err']:.2e} tol={r['tol']:.1e} elem_viol={ev:.1e}{'' if r.get('elem_ok', True) else ' (ELEM)'}",
+                      flush=True)
             print(f"   ... {time.time() - t:.1f} s", flush=True)
     return 1 if n_bad else 0
 
