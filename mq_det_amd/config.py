@@ -105,7 +105,8 @@ def get_cfg():
         GROUP_NORM=dict(DIM_PER_GP=-1, NUM_GROUPS=16, EPSILON=1e-5),                                   # :313-319
         LANGUAGE_BACKBONE=dict(FREEZE=False, TOKENIZER_TYPE="bert-base-uncased", MODEL_TYPE="bert-base-uncased",
                                LANG_DIM=768, MAX_QUERY_LEN=256, N_LAYERS=1, PAD_MAX=True, MASK_SPECIAL=False,
-                               USE_CHECKPOINT=False, VOCAB_SIZE=0, BERT_VOCAB_SIZE=0, NUM_HIDDEN_LAYERS=12),         # :264-287
+                               USE_CHECKPOINT=False, VOCAB_SIZE=0, BERT_VOCAB_SIZE=0, NUM_HIDDEN_LAYERS=12,         # :264-287
+                               COMPACT_TEXT=True),      # new: the device programs run on the first 16 ceil(live tokens / 16) text positions only
         RPN=dict(USE_FPN=True, ANCHOR_SIZES=(64, 128, 256, 512, 1024), ANCHOR_STRIDE=(8, 16, 32, 64, 128),
                  ASPECT_RATIOS=(1.0,), SCALES_PER_OCTAVE=1, OCTAVE=2.0, STRADDLE_THRESH=0, FREEZE=False,
                  FORCE_BOXES=False, RETURN_FUSED_FEATURES=False),

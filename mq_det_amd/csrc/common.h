@@ -44,6 +44,13 @@ typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
 #if !defined(MQ_BF16) && !defined(MQ_F32)
 #define MQ_PRIMARY_UNIT 1
 #endif
+#if defined(MQ_F32)
+// the precise mode also drops the hardware approximations of exp / reciprocal the 16-bit builds use beside their MFMAs (v_exp_f32 on a
+// pre-multiplied argument: a relative error of ~|x| 2^-24 per softmax term; v_rcp_f32: 1 ulp): library exp / exp2 and IEEE division
+#define __expf(x) expf(x)
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#endif
 typedef float float4_ __attribute__((ext_vector_type(4)));
 typedef float float2_ __attribute__((ext_vector_type(2)));
 

@@ -103,7 +103,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
         self._anchor_cache = {}
         self._graphs = OrderedDict()                              # LRU of captured HIP graphs, keyed by static shapes only
         self._graph_pool = None                                   # one memory pool shared by every captured graph
-        self._tok_cache, self._tokidx_cache, self._wh_cache = {}, {}, {}
+        self._tok_cache, self._tokidx_cache, self._wh_cache, self._live_cache = {}, {}, {}, {}
         self._feat_cache = None                                   # Swin + FPN + pooled tokens of the last image batch (f1)
         self._front_cache = OrderedDict()                         # image-independent BERT layers per caption (f1)
         self.use_hip_graph = bool(cfg.MODEL.get("USE_HIP_GRAPH", True))
@@ -231,8 +231,8 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
         if hit is None:
             LB = self.cfg.MODEL.LANGUAGE_BACKBONE
             # PAD_MAX = False ("longest" in the reference, generalized_vl_rcnn_new.py:378-383) pads to MAX_QUERY_LEN here as well:
-            # padded positions are masked keys everywhere (BERT, GCP, VLFuse) and never scored, so the detections are the same,
-            # and the kernels skip all-padding key tiles through kv_len -- a shorter T would buy nothing and cost a new graph key
+            # padded positions are masked keys everywhere (BERT, GCP, VLFuse) and never scored, so the detections are the same;
+            # forward() cuts the padded ROWS away again (`_live_len`: the first 16 ceil(max_kv / 16) positions go to the device programs)
             tok = self.tokenizer(list(captions), max_length=LB.MAX_QUERY_LEN, padding="max_length",
                                  return_special_tokens_mask=True, return_tensors="pt", truncation=True)
             am = tok["attention_mask"]
@@ -244,6 +244,55 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
                 self._tok_cache.clear()
             self._tok_cache[key] = hit
         return hit
+
+    def _live_len(self, T, max_kv):
+        """Text positions the device programs run on: 16 ceil(max_kv / 16) (the key-block granularity of the attention kernels; VLFuse takes
+        T % 8 == 0), or all T when the bound is unknown or MODEL.LANGUAGE_BACKBONE.COMPACT_TEXT is off."""
+        if max_kv <= 0 or not self.cfg.MODEL.LANGUAGE_BACKBONE.get("COMPACT_TEXT", True):
+            return T
+        return min(T, -(-int(max_kv) // 16) * 16)
+
+    def _live_slice(self, input_ids, attention_mask, Tl, cap_key, dev):
+        """input_ids / attention_mask cut to their first Tl columns as contiguous tensors (memoised per caption: the HIP-graph replay copies
+        its inputs into static buffers, the same two tensors serve every call of a caption)."""
+        key = (cap_key, Tl, str(dev)) if cap_key is not None else None
+        hit = self._live_cache.get(key) if key is not None else None
+        if hit is None:
+            hit = (input_ids[:, :Tl].contiguous(), attention_mask[:, :Tl].contiguous())
+            if key is not None:
+                if len(self._live_cache) > 256:
+                    self._live_cache.clear()
+                self._live_cache[key] = hit
+        return hit
+
+    @staticmethod
+    def _pad_raw_text(raw, T):
+        """return_raw (parity ladders): the per-token tensors of a compacted forward back in the caller's [.., T, ..] shapes -- zeros at the
+        padded positions (which the reference fills with values nothing reads)."""
+        import torch.nn.functional as F
+
+        def rows(t_):            # [B, Tl, C] -> [B, T, C]
+            return t_ if t_ is None or t_.shape[1] >= T else F.pad(t_, (0, 0, 0, T - t_.shape[1]))
+
+        def cols(t_):            # [.., Tl] -> [.., T]
+            return t_ if t_ is None or t_.shape[-1] >= T else F.pad(t_, (0, T - t_.shape[-1]))
+        lang, head = raw["lang"], raw["head"]
+        for k in ("hidden", "hidden32", "embedded"):
+            if torch.is_tensor(lang.get(k)):
+                lang[k] = rows(lang[k])
+        for k in ("masks", "key_bias"):
+            if torch.is_tensor(lang.get(k)):
+                lang[k] = cols(lang[k])
+        if torch.is_tensor(head.get("hidden")):
+            head["hidden"] = rows(head["hidden"])
+        if torch.is_tensor(head.get("tbias")):
+            head["tbias"] = cols(head["tbias"])
+        if "dot" in head:
+            head["dot"] = [cols(d) for d in head["dot"]]
+        for a in raw.get("head_trace") or ():
+            if torch.is_tensor(a.get("bert_hidden")):
+                a["bert_hidden"] = rows(a["bert_hidden"])
+        return raw
 
     # ------------------------------------------------------------------ device part (capturable in a HIP graph)
     def _backbone_stage(self, x):
@@ -441,12 +490,24 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
             positive_map = {k: [t for t in (v if not isinstance(v, int) else [v]) if t < T] for k, v in positive_map.items()}
         labels_in_caption = [k for k, v in positive_map.items() if len(v) != 0]
         pm_key = tuple((k, tuple(positive_map[k])) for k in labels_in_caption)
+        onehot = str(cfg.MODEL.DYHEAD.get("SCORE_AGG", "MEAN")).upper() == "ONEHOT"
+        if max_kv > 0:
+            # the alignment kernel scores text columns below 16 ceil(max_kv / 16) only: a positive_map that names a token behind the
+            # caption's last live one (abnormal, but legal for the reference, which scores all T columns) widens the bound instead of
+            # being scored as 0 inside a MEAN (ADVICE r3)
+            max_kv = max(max_kv, len(positive_map) if onehot else 1 + max((t for k in labels_in_caption for t in positive_map[k]), default=-1))
+        # LIVE-ROW COMPACTION (round 5): everything behind the tokenizer runs on the first Tl = 16 ceil(max_kv / 16) text positions instead of
+        # the MAX_QUERY_LEN = 256 the caption is padded to.  Padded positions are masked KEYS everywhere (BERT, GCP, VLFuse) and are never
+        # scored, so no live output depends on them -- but as ROWS they went through every text-side GEMM, LayerNorm and elementwise kernel
+        # (141-token caption: 44 % of those rows).  The key-length bucket is part of the HIP-graph key already, so Tl adds no graph.
+        Tl = self._live_len(T, max_kv)
+        if Tl < T:
+            input_ids, attention_mask = self._live_slice(input_ids, attention_mask, Tl, cap_key, dev)
         vision = idx = None
         if self._use_vq():
-            vision, idx = self.query_selector.select_cached(pm_key, labels_in_caption, positive_map, Bn, T, dev, dtype)
+            vision, idx = self.query_selector.select_cached(pm_key, labels_in_caption, positive_map, Bn, Tl, dev, dtype)
             if vision.shape[1] == 0:                              # no label of this caption has a vision query: text only
                 vision = idx = None
-        onehot = str(cfg.MODEL.DYHEAD.get("SCORE_AGG", "MEAN")).upper() == "ONEHOT"
         tk = (len(positive_map), "onehot", str(dev)) if onehot else (pm_key, str(dev))
         hit = self._tokidx_cache.get(tk)
         if hit is None:
@@ -459,11 +520,6 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
                 hit = build_token_index(positive_map, labels_in_caption, dev)
             self._tokidx_cache[tk] = hit
         tokidx, label_ids = hit
-        if max_kv > 0:
-            # the alignment kernel scores text columns below 16 ceil(max_kv / 16) only: a positive_map that names a token behind the
-            # caption's last live one (abnormal, but legal for the reference, which scores all T columns) widens the bound instead of
-            # being scored as 0 inside a MEAN (ADVICE r3)
-            max_kv = max(max_kv, len(positive_map) if onehot else 1 + max((t for k in labels_in_caption for t in positive_map[k]), default=-1))
         wh_key = (tuple(images.image_sizes), str(dev))
         im_wh = self._wh_cache.get(wh_key)
         if im_wh is None:
@@ -474,7 +530,8 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
         tail = (input_ids, attention_mask, vision, idx, tokidx, label_ids, im_wh, max_kv)
         if return_raw:
             x = images.tensors.to(dtype).contiguous(memory_format=torch.channels_last)
-            return self._full_program(x, *tail, want_raw=True)
+            raw = self._full_program(x, *tail, want_raw=True)
+            return self._pad_raw_text(raw, T) if Tl < T else raw
         from .. import ops
         use_graph = self.use_hip_graph and not ops.timing_active()
 
@@ -485,7 +542,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
         src = images.tensors
         if fc is not None and fc["src"] is src and fc["version"] == src._version and (vision is None or fc["pooled"] is not None):
             self.cache_stats["backbone_hit"] += 1
-            fkey = (cap_key, Bn, vision is not None)
+            fkey = (cap_key, Bn, vision is not None, Tl)
             front = self._front_cache.get(fkey) if cap_key is not None else None
             if front is None:
                 self.cache_stats["front_miss"] += 1
@@ -509,7 +566,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
                 keep = self._tree_map(lambda t: t.clone(), {"feats": out["feats"], "pooled": out["pooled"], "front": out["front"]})
                 self._feat_cache = {"src": src, "version": src._version, "feats": keep["feats"], "pooled": keep["pooled"]}
                 if cap_key is not None:
-                    self._front_cache[(cap_key, Bn, vision is not None)] = keep["front"]
+                    self._front_cache[(cap_key, Bn, vision is not None, Tl)] = keep["front"]
 
         # fixed-shape detections [B, K, 6] for the RCCL all-gather (mq_det_amd.parallel.gather_detections); cloned: under
         # HIP-graph replay `out` are the graph's static buffers, which the next forward overwrites
@@ -605,7 +662,9 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
                 kvs.append(max(kv, 1 + max((t for v in pm.values() for t in (v if not isinstance(v, int) else [v])), default=-1)) if kv > 0 else kv)
                 pms.append(pm)
                 labs.append([k for k, v in pm.items() if len(v) != 0])
-            T = ids[0].shape[1]
+            T = self._live_len(ids[0].shape[1], max(kvs) if min(kvs) > 0 else 0)          # live-row compaction (see forward): the group's longest caption
+            live = lambda t_: t_[:, :T]                           # noqa: E731
+            ids, ams = [live(i) for i in ids], [live(a) for a in ams]
             vision = idx = None
             if use_vq:                                            # item order: chunk-major (item = chunk * B + image)
                 vision, idx = self.query_selector.select([l for l in labs for _ in range(Bn)], [pm for pm in pms for _ in range(Bn)],
@@ -615,10 +674,11 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
             for cap, _ in grp:
                 fronts.append(self._front_for(cap, dev, vision is not None))
             rep = lambda t: t.repeat_interleave(Bn, 0)            # noqa: E731  [g, ...] -> [g * B, ...] chunk-major
-            front = {"x": rep(torch.cat([f["x"] for f in fronts])),
-                     "x32": None if fronts[0].get("x32") is None else rep(torch.cat([f["x32"] for f in fronts])),
-                     "hidden": [rep(torch.cat([f["hidden"][k] for f in fronts])) for k in range(len(fronts[0]["hidden"]))],
-                     "key_bias": rep(torch.cat([f["key_bias"] for f in fronts])), "kv_len": rep(torch.cat([f["kv_len"] for f in fronts])),
+            # (the cached fronts hold all MAX_QUERY_LEN positions of their caption: cut to the group's live length here)
+            front = {"x": rep(torch.cat([live(f["x"]) for f in fronts])),
+                     "x32": None if fronts[0].get("x32") is None else rep(torch.cat([live(f["x32"]) for f in fronts])),
+                     "hidden": [rep(torch.cat([live(f["hidden"][k]) for f in fronts])) for k in range(len(fronts[0]["hidden"]))],
+                     "key_bias": rep(torch.cat([live(f["key_bias"]) for f in fronts])), "kv_len": rep(torch.cat([f["kv_len"] for f in fronts])),
                      "next": fronts[0]["next"]}
             if str(cfg.MODEL.DYHEAD.get("SCORE_AGG", "MEAN")).upper() == "ONEHOT":      # class column j = token j, label j + 1
                 smaps = [({j + 1: [j] for j in range(len(pm))}, list(range(1, len(pm) + 1))) for pm in pms]

@@ -310,6 +310,8 @@ def patch_embed(img, wpk, bias, g0, b0, g1, b1, eps=1e-5):
     lib = load_library()
     _need_gpu(img, wpk, bias, g0, b0, g1, b1)
     f32 = img.dtype == torch.float32
+    if f32 and f32_operands() and img.shape[-1] == 3 and img.shape[1] != 3:
+        f32 = False           # precise mode: channels-last pixels of the operand type (= float32 there), not the caller's NCHW tensor
     if f32:
         B, Cin, Hi, Wi = img.shape
     else:
@@ -575,6 +577,8 @@ def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.
         return v_ln + out_bias + torch.einsum("bhnt,bhtc->bnc", torch.softmax(lg, -1), vo)
     out = torch.empty_like(v_ln)
     variant = KERNELS["VLFUSE_I2T_VARIANT"] if variant is None else int(variant)
+    if f32_operands() == 1:
+        variant = 0           # precise mode: Q fragments in registers (the Q tile in LDS beside two K / V tiles does not fit at fp32)
     with _timed(f"vlfuse_i2t_n{N}_t{T}"):
         _chk(_fn(lib, "mq_vlfuse_i2t_fwd", v_ln)(_ptr(v_ln), _ptr(kf), _ptr(vo), _ptr(bias), _ptr(kv_len), _ptr(out_bias), _ptr(out),
                                    B, N, T, Hh, int(max_kv), float(clamp), int(variant),
@@ -752,6 +756,8 @@ def swin_mlp2(x, delta, ln_g, ln_b, eps, w1f, b1, w2f, b2, next_ln=None, flags=N
     flags = KERNELS["SWIN_MLP2_FLAGS"] if flags is None else int(flags)
     if flags < 0:
         flags = 0 if C == 192 else 2          # table GELU except at C = 192 (profiles/r03_call5_microbench_swin_mlp.json)
+    if f32_operands():
+        flags &= ~2           # precise mode: the erf GELU (|error| <= 1.5e-7), not the interpolation table (7e-6)
     if f32_operands() == 1 and C >= 384:
         flags |= 4            # precise mode: the main kernel's weight stages are 196 KB at fp32 -- every block through the tail kernel (fragments from global memory)
     fn = _fn(lib, "mq_swin_mlp2_fwd", w1f)
