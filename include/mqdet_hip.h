@@ -428,6 +428,20 @@ int mq_post_sort_fwd(const float* boxes, const float* scores, const int* labels,
 int mq_post_finalize_fwd(const float* boxes, const float* scores, const int* labels, const unsigned char* keep, float* out,
                          int* counts, int B, int tot, int K, int K2, void* stream);
 
+/* The attention half of a BERT layer in ONE launch (round 5; north-star "fused GCP + BERT attention"): the q | k | v projection of every
+ * (batch item, head) AND its attention -- the qkv tensor is never written.  x [B, T, C] 16-bit hidden states (element (b, t, c) at
+ * x + b*x_bs + t*x_rs + c; strides % 8 == 0), w [3C, C] the layer's fused projection weight (rows q | k | v, K-contiguous), bias [3C],
+ * o [B, T, C] context with the heads concatenated (o_rs % 4 == 0); key_bias fp32 (b, j) at key_bias + b*bias_bs + j or NULL (<= -1e29
+ * marks a masked key); kv_len [B] int32 or NULL: keys at and beyond kv_len[b] are skipped in whole 16-key blocks.  C = 64 H, C % 128 == 0,
+ * T <= 256 (one workgroup holds a whole (b, h): after the live-row compaction of the text T = 16 ceil(caption / 16)); clamp > 0 = the +-clamp
+ * of the VLDyHead BERT copies, applied to the scaled logits before the mask as in the reference.  Returns -1 for other shapes, -3 for
+ * misaligned strides.  Rounding points = the unfused path's (q, k, v rounded to 16 bits, P rounded for the second contraction).
+ * Replaces BertSelfAttention.forward as a whole: query / key / value Linear + transpose_for_scores + matmul + mask + softmax + matmul
+ * (HF modeling_bert.py BertSelfAttention; maskrcnn_benchmark/modeling/rpn/modeling_bert.py:71-170 with the clamps). */
+int mq_bert_attn_qkv_fwd(const void* x, const void* w, const void* bias, void* o, const float* key_bias, const int* kv_len,
+                         int B, int T, int C, int H, long x_bs, long x_rs, long o_bs, long o_rs, long bias_bs, float scale, float clamp,
+                         void* stream);
+
 /* ---- bf16 operands (BASELINE.json configs[3]: "MQ-GLIP-L ... bf16 MFMA").
  * Every entry point that reads or writes 16-bit operands exists twice: `name` as declared above (fp16, v_mfma_f32_16x16x32_f16) and
  * `name_bf16` -- the SAME kernel source compiled with bf16 operands (v_mfma_f32_16x16x32_bf16; fp32 accumulation, fp32 side inputs and
@@ -441,6 +455,7 @@ int mq_post_finalize_fwd(const float* boxes, const float* scores, const int* lab
 MQ_BF16_TWIN(mq_attn_fwd)
 MQ_BF16_TWIN(mq_attn_resident_fwd)
 MQ_BF16_TWIN(mq_attn_text_fwd)
+MQ_BF16_TWIN(mq_bert_attn_qkv_fwd)
 MQ_BF16_TWIN(mq_patch_embed_fwd)
 MQ_BF16_TWIN(mq_attn_chunked_fwd)
 MQ_BF16_TWIN(mq_window_attn_fwd)
@@ -494,6 +509,7 @@ MQ_BF16_TWIN(mq_msdeform_attn_q_fwd)
 MQ_F32_TWIN(mq_attn_fwd)
 MQ_F32_TWIN(mq_attn_resident_fwd)
 MQ_F32_TWIN(mq_attn_text_fwd)
+MQ_F32_TWIN(mq_bert_attn_qkv_fwd)
 MQ_F32_TWIN(mq_patch_embed_fwd)
 MQ_F32_TWIN(mq_attn_chunked_fwd)
 MQ_F32_TWIN(mq_window_attn_fwd)

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libmqdet_hip.so")
-SOURCES = ["api.hip", "attn.hip", "attn_resident.hip", "attn_text.hip", "vlfuse_attn.hip", "window_attn.hip", "patch_embed.hip", "gcp.hip", "conv_igemm.hip", "conv_small.hip", "conv_small2.hip", "conv_small3.hip", "dcn_fused.hip", "layernorm.hip", "layernorm2.hip", "dyconv.hip", "post.hip", "post2.hip", "align_fused.hip", "nms2.hip", "roi_align.hip", "swin_mlp.hip", "swin_mlp2.hip", "msda.hip"]
+SOURCES = ["api.hip", "attn.hip", "attn_resident.hip", "attn_text.hip", "bert_attn.hip", "vlfuse_attn.hip", "window_attn.hip", "patch_embed.hip", "gcp.hip", "conv_igemm.hip", "conv_small.hip", "conv_small2.hip", "conv_small3.hip", "dcn_fused.hip", "layernorm.hip", "layernorm2.hip", "dyconv.hip", "post.hip", "post2.hip", "align_fused.hip", "nms2.hip", "roi_align.hip", "swin_mlp.hip", "swin_mlp2.hip", "msda.hip"]
 # no fp32-operand twin (include/mqdet_hip.h MQ_F32_TWIN): operators whose inputs may already be fp32, the superseded first Swin MLP kernel,
 # and the sources that only hold fp32 / integer code (one copy, in the fp16 unit)
 F32_SKIP = ("msda.hip", "roi_align.hip", "swin_mlp.hip", "nms2.hip", "post2.hip")
@@ -21,7 +21,8 @@ EXTRA_FLAGS = {"dcn_fused.hip": ["-fno-slp-vectorize"],
                # attn_resident.hip: the S^T accumulators are consumed by VALU code (softmax): keep them in VGPRs (no v_accvgpr_read per
                # logit) and keep the scalar f32 softmax arithmetic unpacked (packed f32 VALU beside MFMAs costs more than it saves)
                "attn_resident.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"],
-               "attn_text.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]}
+               "attn_text.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"],
+               "bert_attn.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _stale():

@@ -417,7 +417,10 @@ def bert_layer(P, b, x, key_bias, clamp, kv_len=None, x32=None, qk_mask=None, ma
     Returns y16 (and y32 when x32 is given)."""
     Bn, T, C = x.shape
     r32 = x32 is not None
-    if ops.KERNELS["BERT_QKV_FUSED"] == 1 and qk_mask is None and ops.attention_text_fits(T, kv_len, max_kv) and (b + ".qkv.weight") in P \
+    if ops.KERNELS["BERT_ATTN_QKV_FUSED"] == 1 and qk_mask is None and (b + ".qkv.weight") in P and ops.bert_attention_qkv_fits(T, C, 12, key_bias):
+        # projection + attention of every (batch item, head) in one launch: no qkv tensor (mq_bert_attn_qkv_fwd)
+        ctx = ops.bert_attention_qkv(x, P[b + ".qkv.weight"], P[b + ".qkv.bias"], 12, key_bias=key_bias, clamp=50000.0 if clamp else 0.0, kv_len=kv_len)
+    elif ops.KERNELS["BERT_QKV_FUSED"] == 1 and qk_mask is None and ops.attention_text_fits(T, kv_len, max_kv) and (b + ".qkv.weight") in P \
             and (key_bias is None or key_bias.dim() == 2):
         ctx = ops.attention_text(_lin(P, b + ".qkv", x), 12, key_bias=key_bias, clamp=50000.0 if clamp else 0.0, kv_len=kv_len, max_kv=max_kv)
     else:

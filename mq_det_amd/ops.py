@@ -13,7 +13,7 @@ _LIB = None
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmqdet_hip.so")
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
-EXPECTED_ABI = 25        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
+EXPECTED_ABI = 26        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
 _SIGNATURES = {
     "mq_abi_version": (_i, []),
     "mq_attn_workspace_bytes": (_l, [_i, _i, _i, _i, _i]),
@@ -21,6 +21,7 @@ _SIGNATURES = {
     "mq_attn_resident_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _vp]),
     "mq_patch_embed_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mq_attn_text_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _i, _vp]),
+    "mq_bert_attn_qkv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _l, _f, _f, _vp]),
     "mq_attn_chunked_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 13 + [_f, _f, _i, _vp]),
     "mq_window_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_window_attn_qkv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -67,7 +68,7 @@ _SIGNATURES = {
     "mq_ml_nms": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
 }
 # entry points with 16-bit operands also exist as <name>_bf16 (same signature; include/mqdet_hip.h MQ_BF16_TWIN)
-BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_text_fwd", "mq_patch_embed_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_window_attn_qkv_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
+BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_text_fwd", "mq_bert_attn_qkv_fwd", "mq_patch_embed_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_window_attn_qkv_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
               "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_layernorm_clamp_fwd", "mq_clamp_gelu_clamp", "mq_patch_merge_ln_fwd", "mq_swin_mlp_fwd", "mq_swin_mlp2_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_conv3x3_nchw32_group_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
               "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyconv_epilogue_group", "mq_dyrelu_apply", "mq_dyrelu_ln_fwd", "mq_add_upsample_nearest",
               "mq_align_scores_fwd", "mq_align_fused_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
@@ -117,6 +118,8 @@ KERNEL_DEFAULTS = {
                                  # 0: permute copies + library GEMM (K = 48) + two LayerNorm launches (354 us at B = 8)
     "BERT_QKV_FUSED": 1,         # 1: BERT layers = ONE qkv GEMM + mq_attn_text_fwd (V row-major, transposed out of LDS; registers / LDS sized by the
                                  # caption length); 0: q|k GEMM + V^T batched GEMM + mq_attn_resident_fwd (rounds 2-3)
+    "BERT_ATTN_QKV_FUSED": 1,    # 1: mq_bert_attn_qkv_fwd -- the q | k | v projection inside the attention launch (one workgroup per (batch item, head); the
+                                 # qkv tensor is never written); 0: one qkv GEMM + mq_attn_text_fwd (round 4)
     "POST_FUSED": 1,             # 1: ATSS post-processing as mq_post_select_fwd + mq_post_sort_fwd + mq_ml_nms_topk + mq_post_finalize_fwd (4 launches);
                                  # 0: the round-1..3 chain (5 x torch.topk + box_decode, argsort, gathers, NMS, topk: ~145 launches, 1.1 ms)
     "F32_OPERANDS": 0,           # the PRECISE mode (MODEL.COMPUTE_DTYPE = "float32"; set by configure() from the config, or MQ_F32_OPERANDS): every kernel's
@@ -333,6 +336,37 @@ def attention_text_fits(T, kv_len=None, max_kv=0):
     80 floats per key: up to 160 live keys fit the LDS (longer captions: q|k GEMM + V^T + mq_attn_resident_fwd)."""
     live = max_kv if (kv_len is not None and 0 < max_kv < T) else T
     return T <= 256 and (f32_operands() != 1 or live <= 160)
+
+
+def bert_attention_qkv_fits(T, C, heads, key_bias=None):
+    """Shapes mq_bert_attn_qkv_fwd takes: BERT-base heads of 64, up to 256 tokens (precise mode on the device: up to 160 -- the three
+    [T, 80] tiles of a head are 154 KB at fp32), one key bias per (batch item, key)."""
+    return (C == 64 * heads and C % 128 == 0 and T <= (160 if f32_operands() == 1 else 256)
+            and (key_bias is None or key_bias.dim() == 2))
+
+
+def bert_attention_qkv(x, wqkv, bqkv, heads, key_bias=None, clamp=0.0, kv_len=None, scale=None):
+    """BertSelfAttention as one launch (mq_bert_attn_qkv_fwd): x [B,T,C] 16-bit hidden states, wqkv [3C,C] / bqkv [3C] the layer's fused
+    q | k | v projection, key_bias None or [B,T] fp32, kv_len [B] int32 or None -> context [B,T,C] in x's dtype."""
+    lib = load_library()
+    _need_gpu(x, wqkv, bqkv, key_bias, kv_len)
+    B, T, C = x.shape
+    assert bert_attention_qkv_fits(T, C, heads, key_bias) and x.dtype in _H16 and x.stride(2) == 1
+    assert wqkv.shape == (3 * C, C) and wqkv.is_contiguous() and bqkv.shape == (3 * C,) and bqkv.is_contiguous() and wqkv.dtype == bqkv.dtype == x.dtype
+    bias_bs = 0
+    if key_bias is not None:
+        assert key_bias.dtype == torch.float32 and key_bias.shape == (B, T) and key_bias.stride(1) == 1
+        bias_bs = key_bias.stride(0)
+    if kv_len is not None:
+        assert kv_len.dtype == torch.int32 and kv_len.shape == (B,) and kv_len.is_contiguous()
+    o = torch.empty(B, T, C, dtype=x.dtype, device=x.device)
+    D = C // heads
+    with _timed(f"bert_attn_qkv_t{T}"):
+        rc = _fn(lib, "mq_bert_attn_qkv_fwd", x)(_ptr(x), _ptr(wqkv), _ptr(bqkv), _ptr(o), _ptr(key_bias), _ptr(kv_len), B, T, C, heads,
+                                                 x.stride(0), x.stride(1), o.stride(0), o.stride(1), bias_bs,
+                                                 float(scale if scale is not None else 1.0 / math.sqrt(D)), float(clamp), _stream())
+    _chk(rc, "mq_bert_attn_qkv_fwd")
+    return o
 
 
 def attention_text(qkv, heads, key_bias=None, clamp=0.0, kv_len=None, max_kv=0, scale=None):

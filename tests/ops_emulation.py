@@ -52,6 +52,13 @@ def attention_text(qkv, heads, key_bias=None, clamp=0.0, kv_len=None, max_kv=0, 
                       key_bias=key_bias, scale=scale, clamp=clamp)
 
 
+def bert_attention_qkv(x, wqkv, bqkv, heads, key_bias=None, clamp=0.0, kv_len=None, scale=None):
+    """ops.bert_attention_qkv: the fused projection (rounded to the operand type like the GEMM's output) + attention_text."""
+    import torch.nn.functional as F
+    qkv = F.linear(x.float(), wqkv.float(), bqkv.float()).to(x.dtype)
+    return attention_text(qkv, heads, key_bias=key_bias, clamp=clamp, kv_len=kv_len, scale=scale)
+
+
 def attention4(q4, k4, vt4, key_bias=None, scale=None, clamp=0.0, nsplit=1, nk=None, kv_len=None):
     B, Nq, H, D = q4.shape
     Nk = k4.shape[1] if nk is None else nk
@@ -600,7 +607,7 @@ def dyconv_coef_group(items, attn_w, attn_b, groups, eps):
 
 # ---------------------------------------------------------------------------------------------------------------------------------
 # every emulated entry point, in one place: tests patch them into mq_det_amd.ops (or into a stand-in namespace) with these helpers
-NAMES = ("attention", "attention4", "attention_text", "patch_embed", "window_attention", "window_attention_qkv", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores", "align_fused",
+NAMES = ("attention", "attention4", "attention_text", "bert_attention_qkv", "patch_embed", "window_attention", "window_attention_qkv", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores", "align_fused",
          "dyconv_branch_coef", "dyconv_coef_group", "dyconv_epilogue_group", "dyconv_fuse", "dyrelu_", "dyrelu_coef", "dyrelu_apply_", "dyrelu_layer_norm", "add_upsample_nearest_", "conv3x3", "conv3x3_nchw32", "conv3x3_nchw32_group", "conv3x3_nchw32_group_supported", "dcnv2", "layer_norm", "clamp_gelu_clamp", "vlfuse_i2t",
          "vlfuse_t2i", "box_decode", "ml_nms", "post_select", "post_select_supported", "post_sort", "post_finalize", "roi_align", "swin_mlp", "swin_mlp2", "patch_merge_ln", "ms_deform_attn", "ms_deform_attn_q", "image_key_mask")
 
@@ -618,7 +625,7 @@ def namespace(real_ops):
     import types
     g = globals()
     fake = types.SimpleNamespace(**{n: g[n] for n in NAMES})
-    for n in ("patch_embed_pack", "SWIN_MLP_WIDTHS", "WINDOW_QKV_WIDTHS", "window_qkv_fused", "SCORE_AGG", "window_pad", "pad_rel_bias", "swin_mlp_w2_perm", "swin_mlp2_pack", "timing_active", "attention_text_fits", "f32_operands"):
+    for n in ("patch_embed_pack", "SWIN_MLP_WIDTHS", "WINDOW_QKV_WIDTHS", "window_qkv_fused", "SCORE_AGG", "window_pad", "pad_rel_bias", "swin_mlp_w2_perm", "swin_mlp2_pack", "timing_active", "attention_text_fits", "bert_attention_qkv_fits", "f32_operands"):
         setattr(fake, n, getattr(real_ops, n))
     fake.KERNELS = dict(real_ops.KERNEL_DEFAULTS)       # the default kernel selection: the glue of the promoted variants is what runs
     return fake

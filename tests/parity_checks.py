@@ -217,6 +217,41 @@ def check_attention_text(dev):
     return res
 
 
+def check_bert_attn_qkv(dev):
+    """mq_bert_attn_qkv_fwd (csrc/bert_attn.hip): q | k | v projection + attention of every (batch item, head) in one launch, against the plain
+    statement  qkv = round16(x W^T + b);  softmax(clamp(scale q k^T) + mask) v  on the same rounded operands.  Token counts on both sides of the
+    160-token variant switch and of 16-token block edges (the compacted text is 16 ceil(caption / 16) long, but any T <= 256 is legal), per-item
+    kv_len below T, T not a multiple of 16, the clamped variant with logits AT the clamp, a hidden-state view with padded row stride."""
+    from mq_det_amd import ops
+    res = []
+    g = torch.Generator().manual_seed(31)
+    C, H = 768, 12
+    cases = [(2, 144, 141, 0.0, 1.0), (2, 160, 160, 50000.0, 1.0), (1, 176, 161, 0.0, 1.0), (2, 256, 256, 0.0, 1.0), (3, 40, 17, 3.0, 8.0),
+             (2, 23, 23, 0.0, 1.0), (8, 96, 81, 50000.0, 1.0)]
+    if QUICK:
+        cases = [cases[0], cases[2], cases[4], cases[5]]
+    for (B, T, kv, clamp, amp) in cases:
+        if not ops.bert_attention_qkv_fits(T, C, H):
+            continue              # precise mode on the device: up to 160 tokens
+        xs = torch.randn(B, T, C + 8, generator=g).to(H16)
+        x = xs[:, :, :C]                                                   # row stride C + 8: a view, as the LayerNorm kernel may hand it over
+        w = torch.randn(3 * C, C, generator=g) / math.sqrt(C)
+        w[:2 * C] *= amp                                                   # (q and k only: logits that reach the clamp, values of unit size)
+        w = w.to(H16)
+        bq = (torch.randn(3 * C, generator=g) * 0.1).to(H16)
+        kl = torch.tensor([max(1, kv - 9 * b) for b in range(B)], dtype=torch.int32)
+        kb = torch.zeros(B, T)
+        for b in range(B):
+            kb[b, int(kl[b]):] = -1e30
+        qkv = F.linear(x.float(), w.float(), bq.float()).to(H16)
+        ref = _ref_attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], H, kb, None, clamp)
+        xd = xs.to(dev)[:, :, :C]
+        for use_len in (True, False):
+            out = ops.bert_attention_qkv(xd, w.to(dev), bq.to(dev), H, key_bias=kb.to(dev), clamp=clamp, kv_len=kl.to(dev) if use_len else None)
+            res.append(_stat(f"attn bert qkv fused B={B} T={T} kv={kv} clamp={clamp} kv_len={'yes' if use_len else 'no'}", out, ref))
+    return res
+
+
 def _tiny(dev, image_hw=(160, 192), B=2, seed=0, spec=None):
     """Shared tiny model: oracle state dict + product model with the same weights (spec: tiny_spec() = Swin-T widths, or
     tiny_l_spec() = Swin-L widths / window 12)."""
@@ -1155,6 +1190,7 @@ def all_checks(dev):
         out.append(("attention", lambda s=s: check_attention(dev, **s)))
     out += [("attention", lambda: check_attention_strided(dev)),
             ("attention", lambda: check_attention_text(dev)),
+            ("attention", lambda: check_bert_attn_qkv(dev)),
             ("swin", lambda: check_patch_embed(dev)),
             ("post", lambda: check_post_fused(dev)),
             ("dyconv", lambda: check_dyconv_epilogue_group(dev)),
