@@ -93,6 +93,8 @@ def build_model(dev, caches=False, n_classes=NUM_CLASSES_IN_CAPTION, n_categorie
         cfg.MODEL.SWINT.NUM_HEADS, cfg.MODEL.SWINT.WINDOW_SIZE = (6, 12, 24, 48), 12
         cfg.MODEL.SWINT.OUT_CHANNELS = (192, 384, 768, 1536)
         cfg.MODEL.DYHEAD.NUM_CONVS = 8
+    if os.environ.get("MQ_COMPACT_TEXT") is not None:         # A/B switch (live-row compaction of the text path, detector._live_len)
+        cfg.MODEL.LANGUAGE_BACKBONE.COMPACT_TEXT = os.environ["MQ_COMPACT_TEXT"] == "1"
     if os.environ.get("MQ_RESIDUAL_FP32") is not None:        # A/B switch (precision of the residual streams)
         cfg.MODEL.RESIDUAL_FP32 = os.environ["MQ_RESIDUAL_FP32"] == "1"
     if os.environ.get("MQ_SWIN_FUSED_MLP") is not None:       # A/B switch (fused Swin MLP kernel vs library GEMMs + GELU)
@@ -477,7 +479,9 @@ def lang_path_b64(model, cfg, dev, chunks, iters=5):
     labels = [k for k, v in pmap.items() if len(v)]
     pm_key = tuple((k, tuple(pmap[k])) for k in labels)
     dtype = P["backbone.body.patch_embed.proj.weight"].dtype
-    vision, idx = model.query_selector.select_cached(pm_key, labels, pmap, Bn, ids.shape[1], dev, dtype)
+    Tl = model._live_len(ids.shape[1], max_kv)            # live-row compaction, exactly as forward() applies it
+    ids, am = ids[:, :Tl].contiguous(), am[:, :Tl].contiguous()
+    vision, idx = model.query_selector.select_cached(pm_key, labels, pmap, Bn, Tl, dev, dtype)
     g = torch.Generator(device="cpu").manual_seed(3)
     pooled = torch.randn(Bn, 5577, 256, generator=g).to(dev, dtype)
     streams_on = cfg.MODEL.DYHEAD.LEVEL_STREAMS
@@ -499,24 +503,39 @@ def lang_path_b64(model, cfg, dev, chunks, iters=5):
         kern = ops.stop_timing()
     finally:
         cfg.MODEL.DYHEAD.LEVEL_STREAMS = streams_on
-    nk_vis = min(256, -(-n_tok // 64) * 64)
+    k16 = -(-n_tok // 16) * 16                            # text keys the attention kernels visit (16-key blocks)
     V, S = vision.shape[1], idx.shape[2]
-    fl_bert = 12 * 4.0 * Bn * 12 * 256 * nk_vis * 64
+    C = 768
+    fused = any(k.startswith("bert_attn_qkv") for k in kern)
+    # ALGORITHMIC flops of the launches counted below.  BERT: with mq_bert_attn_qkv_fwd one launch IS the layer's q | k | v projection and its
+    # attention (rows = the Tl live text positions); without it only the attention launch is counted (its projection is a library GEMM).
+    fl_bert_attn = 12 * 4.0 * Bn * 12 * Tl * k16 * 64
+    fl_bert_proj = 12 * 2.0 * Bn * Tl * C * 3 * C if fused else 0.0
     fl_pre = 2 * 4.0 * Bn * 8 * V * 5577 * 32
-    fl_gcp = 6 * 4.0 * Bn * 8 * 256 * S * 64
-    att_ms = sum(v[1] for k, v in kern.items() if k.startswith(("attn_d", "attn_res_d", "attn_text_d", "attn_chk_d", "gcp_sparse"))) / iters
-    att_tf = (fl_bert + fl_pre + fl_gcp) / (att_ms * 1e-3) / 1e12
-    # whole language path: SURVEY.md 8(d) per image BERT 45.9 + pre-select 7.5 + GCP 29.9 GF
-    path_tf = Bn * (45.9 + 7.5 + 29.9) * 1e9 / (ms_path * 1e-3) / 1e12
-    return {"batch": Bn, "ms_language_path": round(ms_path, 3), "language_path_tflops": round(path_tf, 1),
+    fl_gcp = 6 * 4.0 * Bn * 8 * Tl * S * 64
+    tags = ("attn_d", "attn_res_d", "attn_text_d", "attn_chk_d", "gcp_sparse", "bert_attn_qkv")
+    att_ms = sum(v[1] for k, v in kern.items() if k.startswith(tags)) / iters
+    bert_ms = sum(v[1] for k, v in kern.items() if k.startswith(("bert_attn_qkv", "attn_text_d", "attn_res_d"))) / iters
+    att_tf = (fl_bert_attn + fl_bert_proj + fl_pre + fl_gcp) / (att_ms * 1e-3) / 1e12
+    bert_tf = (fl_bert_attn + fl_bert_proj) / max(bert_ms * 1e-3, 1e-9) / 1e12
+    # whole language path: SURVEY.md 8(d) per image BERT 45.9 + pre-select 7.5 + GCP 29.9 GF at T = 256; the text GEMMs run on Tl rows now,
+    # so the EXECUTED count scales the text-row share (everything but the pre-select and the K / V projections of the vision tokens) by Tl / 256
+    path_gf_ref = 45.9 + 7.5 + 29.9
+    path_gf_exec = (45.9 + 17.9) * Tl / 256.0 + 7.5
+    path_tf = Bn * path_gf_exec * 1e9 / (ms_path * 1e-3) / 1e12
+    return {"batch": Bn, "text_rows": Tl, "ms_language_path": round(ms_path, 3), "language_path_tflops": round(path_tf, 1),
             "language_path_frac_of_mfma_peak": round(path_tf / MFMA_PEAK_TFLOPS, 4),
+            "language_path_gflop_per_image": {"executed": round(path_gf_exec, 1), "reference_at_T256": path_gf_ref},
             "attention_kernels_ms": round(att_ms, 3), "attention_tflops": round(att_tf, 1),
             "attention_mfma_utilisation": round(att_tf / MFMA_PEAK_TFLOPS, 4), "target": 0.40,
-            "flops": {"bert_self_attention": fl_bert, "gcp_pre_select": fl_pre, "gcp_sparse": fl_gcp,
-                      "formula": f"12 x 4*B*12*256*{nk_vis}*64 + 2 x 4*B*8*{V}*5577*32 + 6 x 4*B*8*256*{S}*64, B = {Bn} "
-                                 f"({nk_vis} = visited text keys of the {n_tok}-token caption)"},
+            "bert_fused_launches": {"ms": round(bert_ms, 3), "tflops": round(bert_tf, 1), "mfma_utilisation": round(bert_tf / MFMA_PEAK_TFLOPS, 4),
+                                    "projection_inside_the_launch": fused},
+            "flops": {"bert_self_attention": fl_bert_attn, "bert_qkv_projection_inside_the_attention_launch": fl_bert_proj,
+                      "gcp_pre_select": fl_pre, "gcp_sparse": fl_gcp,
+                      "formula": f"12 x (4*B*12*{Tl}*{k16}*64" + (f" + 2*B*{Tl}*768*2304" if fused else "") + f") + 2 x 4*B*8*{V}*5577*32 + 6 x 4*B*8*{Tl}*{S}*64, "
+                                 f"B = {Bn} ({Tl} = live text rows after compaction, {k16} = visited text keys of the {n_tok}-token caption)"},
             "kernels_ms": {k: round(v[1] / iters, 3) for k, v in sorted(kern.items())},
-            "timing": "eager, single stream, HIP events; attention = the attn_fwd / gcp_sparse launches only"}
+            "timing": "eager, single stream, HIP events; attention = the bert_attn_qkv (projection + attention) / attn_* / gcp_sparse launches only"}
 
 
 def _sub_bench(argv, env=None, timeout=150, keep=()):

@@ -109,9 +109,11 @@ KERNEL_DEFAULTS = {
                                  # 64 us in FRONT of the 130 us main kernel) on a side stream BESIDE the main kernel (a tail workgroup fits on a CU next
                                  # to a main one); 0: one after the other.  A/B on the MI355X (GPU call 12): 437 vs 441 images/s over two runs each --
                                  # no gain (the main kernel leaves the tail's waves no issue slots), stays off
-    "DYCONV_EPILOGUE_GROUPED": 0,  # 1: mq_dyconv_epilogue_group -- the fuse pass and the DYReLU coefficients of ALL levels of a DyConv layer in two launches
-                                 # on the main stream (were 10 launches on five streams behind a fork / join); equal results
-    "BERT_CLAMP_FUSED": 0,       # 1: the +-50000 clamps of the fusion-layer BERT copies inside the kernels around them (mq_clamp_gelu_clamp: clamp -> GELU
+    "DYCONV_EPILOGUE_GROUPED": 1,  # 1: mq_dyconv_epilogue_group -- the fuse pass and the DYReLU coefficients of ALL levels of a DyConv layer in two launches
+                                 # on the main stream (were 10 launches on five streams behind a fork / join); equal results.  A/B of round 5
+                                 # (GPU call 1, 3 alternations x 60 steps): 439.2 / 440.8 / 437.8 against 433.7 / 439.1 / 435.0 images/s: +0.8 %, default
+    "BERT_CLAMP_FUSED": 0,       # (A/B of round 5, GPU call 1: 430.3 / 436.3 / 433.9 against 433.7 / 439.1 / 435.0 images/s -- three of three LOWER: stays off)
+                                 # 1: the +-50000 clamps of the fusion-layer BERT copies inside the kernels around them (mq_clamp_gelu_clamp: clamp -> GELU
                                  # -> clamp in one pass; mq_layernorm_clamp_fwd: clamp of the dense output, LayerNorm, clamp of both outputs): 7 torch
                                  # launches per layer -> 1, equal results; 0: torch.clamp / F.gelu passes
     "PATCH_EMBED_FUSED": 1,      # 1: mq_patch_embed_fwd (Swin PatchEmbed projection + patch_embed.norm + the first norm1 in one pass over the pixels);

@@ -51,6 +51,8 @@ def main():
     if only in ("", "vlfuse"):
         vlfuse(dev, g, out)
         vlfuse_text(dev, g, out)
+    if only in ("", "bert_attn"):
+        bert_attn(dev, g, out)
     if only == "t2i_sweep":
         t2i_sweep(dev, g, out)
     if only == "offset_conv":
@@ -59,6 +61,31 @@ def main():
         print(json.dumps(r))
     if len(sys.argv) > 1:
         json.dump(out, open(sys.argv[1], "w"), indent=1)
+
+
+def bert_attn(dev, g, out):
+    """The attention half of a BERT layer (C = 768, 12 heads) on the compacted text of the 141-token benchmark caption (T = 144): ONE launch of
+    mq_bert_attn_qkv_fwd against the round-4 path (library qkv GEMM + mq_attn_text_fwd), at the headline batch and at the north-star's B = 64;
+    the round-4 path on the uncompacted T = 256 rows beside it."""
+    import torch.nn.functional as F
+    C, H = 768, 12
+    w = (torch.randn(3 * C, C, generator=g) / C ** 0.5).half().to(dev)
+    bq = (torch.randn(3 * C, generator=g) * 0.1).half().to(dev)
+    for B in (8, 64):
+        for T, kv in ((144, 141), (256, 141)):
+            x = torch.randn(B, T, C, generator=g).half().to(dev)
+            kl = torch.full((B,), kv, dtype=torch.int32, device=dev)
+            kb = torch.zeros(B, T, device=dev)
+            kb[:, kv:] = -1e30
+            k16 = -(-kv // 16) * 16
+            fl = 2.0 * B * T * C * 3 * C + 4.0 * B * H * T * k16 * 64
+            ms_f = timeit(lambda: ops.bert_attention_qkv(x, w, bq, H, key_bias=kb, kv_len=kl))
+            ms_g = timeit(lambda: F.linear(x, w, bq))
+            qkv = F.linear(x, w, bq)
+            ms_a = timeit(lambda: ops.attention_text(qkv, H, key_bias=kb, kv_len=kl, max_kv=kv))
+            out.append({"kernel": "bert attention half", "B": B, "T": T, "live_tokens": kv, "algorithmic_gflop": round(fl / 1e9, 2),
+                        "fused_ms": round(ms_f, 4), "fused_tflops": round(fl / ms_f / 1e9, 1), "fused_frac_of_mfma_peak": round(fl / ms_f / 1e9 / 2500.0, 4),
+                        "qkv_gemm_ms": round(ms_g, 4), "attn_text_ms": round(ms_a, 4), "unfused_ms": round(ms_g + ms_a, 4)})
 
 
 def msda(dev, g, out):
