@@ -235,7 +235,9 @@ int mq_dcnv2_stats_blocks(int H, int W, int stride);
 typedef struct mq_dcn_branch {
   const void* x; const float* om; const void* w; const void* bias; void* out; float* stats; const float* wy; const float* wx;
   long x_bs;
-  int B, H, W, C, oH, oW, N, out_ld, stride, flags;          /* flags bit 0: om[:, 18:27] are probabilities, not logits */
+  int B, H, W, C, oH, oW, N, out_ld, stride, flags;          /* flags bit 0: om[:, 18:27] are probabilities, not logits; bit 1: the caller
+                                                                 promises all-zero offsets and mask 1 (a plain 3 x 3 conv: when every branch of a
+                                                                 launch says so only one corner per tap is gathered -- same results) */
 } mq_dcn_branch;
 int mq_dcnv2_group_fwd(const mq_dcn_branch* branches, int n, void* stream);
 int mq_dcnv2_fwd(const void* x, const float* om, const void* w, const void* bias, void* out, float* stats, const float* wy,

@@ -3,10 +3,10 @@
 //
 // Why (north-star "fused GCP + BERT attention"): mq_attn_text_fwd is memory- and launch-bound -- at B = 64 one launch moves
 // >= 100 MB of Q / K / V / O for 9.7 GFLOP (an HBM roofline of 31 % of the MFMA peak) behind a library GEMM that wrote those 75 MB.  Here the
-// qkv tensor never exists: a workgroup (4 waves) owns one (b, h):
+// qkv tensor never exists: a workgroup (8 waves) owns one (b, h):
 //   phase 1  [T x 192] = X_b [T x C] . W_h^T  (W_h = the head's 64 rows of Wq, Wk and Wv): X_b is staged through LDS in 64-wide k-chunks
-//            (double buffer, register prefetch, one barrier per chunk) and shared by the four waves; wave w owns output columns 48 w .. 48 w + 47,
-//            so ITS weight fragments are read by nobody else -- they go global (L2) -> registers, prefetched one chunk ahead, never through LDS.
+//            (double buffer, register prefetch, one barrier per chunk) and shared by all waves; a wave owns output columns 48 wn .. 48 wn + 47 of
+//            every second token block, so its weight fragments go global (L2) -> registers, prefetched one chunk ahead, never through LDS.
 //            Per chunk and wave: 2 x (<= 16 A-fragment reads + 3 x <= 16 MFMAs); accumulators 3 x NBM tiles.
 //   hand-over  + bias, rounded to the operand type (the rounding point of the reference's q / k / v tensors), written row-major [token][64]
 //            into three LDS tiles that alias the X stages;
@@ -14,6 +14,7 @@
 //            softmax in the exp2 domain, O^T = V^T P^T with V read transposed out of LDS (ds_read_tr16_b64) -- the loop body of mq_attn_text_fwd.
 // Text tokens are few (T <= 256, after live-row compaction T = 16 ceil(caption / 16)), so one workgroup holds a whole (b, h).
 #include "common.h"
+#include <cstdlib>
 
 MQ_NAMESPACE_BEGIN
 
@@ -36,11 +37,17 @@ struct BertAttnParams {
   int nblk_cap;                   // 16-token blocks the LDS tiles hold (host: ceil(T / 16) <= NBM)
 };
 
-// NBM = 16-token blocks a workgroup can hold (compile time: 10 -> T <= 160, 16 -> T <= 256)
-template <int NBM, bool CLAMP>
-__global__ __launch_bounds__(256, NBM <= 10 ? 2 : 1) void bert_attn_qkv_kernel(BertAttnParams p) {
-  constexpr int D = BA_D, KS = BA_KS, BK = BA_BK, XP = BA_XP;
-  constexpr int NX = (NBM * 16 * (BK / 8) + 255) / 256;          // 16-byte chunks of an X stage per thread
+// NBM = 16-token blocks a workgroup can hold (compile time: 10 -> T <= 160, 16 -> T <= 256).
+// EIGHT waves (GPU call 2 of round 5: the four-wave version ran one workgroup in 37 us -- 7x its MFMA time -- with one or two waves per SIMD
+// nothing covered the L2 round trip of a chunk's operands or the dependent QK^T -> softmax -> PV chain of a query block): wave = (wn, wm),
+// wn = column slice as above, wm = which half of the token blocks (blocks wm, wm + 2, ...) -- half the accumulators per wave, twice the
+// waves per SIMD; phase 2 deals the query blocks to eight waves (two rounds for a 141-token caption instead of three).
+// OCC = waves per SIMD the register budget is cut for: 2 (one workgroup per CU, <= 256 VGPRs, no spill) or 4 (two workgroups per CU, <= 128
+// VGPRs: ~60 spilled dwords at NBM = 10) -- MQ_BERT_ATTN_OCC picks (A/B on the device).
+template <int NBM, bool CLAMP, int OCC>
+__global__ __launch_bounds__(512, OCC) void bert_attn_qkv_kernel(BertAttnParams p) {
+  constexpr int D = BA_D, KS = BA_KS, BK = BA_BK, XP = BA_XP, NT = 512, NMB = NBM / 2;
+  constexpr int NX = (NBM * 16 * (BK / 8) + NT - 1) / NT;        // 16-byte chunks of an X stage per thread
   static_assert(NBM % 2 == 0, "two 16-key blocks per step of the P V product");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int cap = p.nblk_cap, rows = 32 * ((cap + 1) >> 1);        // tile rows (a whole number of 32-key steps of the P V product)
@@ -52,7 +59,7 @@ __global__ __launch_bounds__(256, NBM <= 10 ? 2 : 1) void bert_attn_qkv_kernel(B
   float* Kmask_s = Bias_s + rows;                    // [rows] CLAMP only: 0, or -1e30 for masked / out-of-range keys
 
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave & 3, wm = wave >> 2;
   const int h = blockIdx.x % p.H, b = blockIdx.x / p.H;
   const int T = p.T, C = p.C;
   const int mblk = (T + 15) >> 4;                    // 16-token blocks of this launch (<= cap)
@@ -61,7 +68,7 @@ __global__ __launch_bounds__(256, NBM <= 10 ? 2 : 1) void bert_attn_qkv_kernel(B
   const int nst = (nblk + 1) >> 1;
   const half_t* X = p.x + (long)b * p.x_bs;
 
-  for (int j = tid; j < rows; j += 256) {
+  for (int j = tid; j < rows; j += NT) {
     float kb = MQ_NEG_BIG;
     if (j < T) kb = p.key_bias ? p.key_bias[(long)b * p.bias_bs + j] : 0.f;
     const bool masked = kb < -1.0e29f;
@@ -74,16 +81,16 @@ __global__ __launch_bounds__(256, NBM <= 10 ? 2 : 1) void bert_attn_qkv_kernel(B
   }
 
   // ================================================================ phase 1: the projection
-  // this wave's three 16-column blocks of the head's [q | k | v] = 192 columns: block cb = 3 wave + j is columns 16 (cb & 3) .. of part cb >> 2
+  // this wave's three 16-column blocks of the head's [q | k | v] = 192 columns: block cb = 3 wn + j is columns 16 (cb & 3) .. of part cb >> 2
   const half_t* wrow[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    const int cb = 3 * wave + j;
+    const int cb = 3 * wn + j;
     wrow[j] = p.w + ((long)(cb >> 2) * C + h * D + (cb & 3) * 16 + l15) * C + lg * 8;
   }
-  float4_ acc[NBM][3];
+  float4_ acc[NMB][3];                               // token blocks wm, wm + 2, ...
 #pragma unroll
-  for (int mb = 0; mb < NBM; ++mb)
+  for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
     for (int j = 0; j < 3; ++j) acc[mb][j] = (float4_){0.f, 0.f, 0.f, 0.f};
   half8 xr[NX];
@@ -92,14 +99,14 @@ __global__ __launch_bounds__(256, NBM <= 10 ? 2 : 1) void bert_attn_qkv_kernel(B
   auto load_x = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int c = tid + i * 256, r = c >> 3, ch = c & 7;
+      const int c = tid + i * NT, r = c >> 3, ch = c & 7;
       if (c < xchunks) xr[i] = *(const half8*)(X + (long)min(r, T - 1) * p.x_rs + ks * BK + ch * 8);
     }
   };
   auto store_x = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int c = tid + i * 256, r = c >> 3, ch = c & 7;
+      const int c = tid + i * NT, r = c >> 3, ch = c & 7;
       if (c < xchunks) *(half8*)(Xs + ((long)buf * rows + r) * XP + ch * 8) = xr[i];
     }
   };
@@ -110,13 +117,13 @@ __global__ __launch_bounds__(256, NBM <= 10 ? 2 : 1) void bert_attn_qkv_kernel(B
       for (int kk = 0; kk < 2; ++kk) wf[j][kk] = *(const half8*)(wrow[j] + ks * BK + kk * 32);
   };
   auto gemm_chunk = [&](int buf, const half8 (&wf)[3][2]) __attribute__((always_inline)) {
-    const half_t* xt = Xs + (long)buf * rows * XP + l15 * XP + lg * 8;
+    const half_t* xt = Xs + (long)buf * rows * XP + (wm * 16 + l15) * XP + lg * 8;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-      for (int mb = 0; mb < NBM; ++mb) {
-        if (mb < mblk) {
-          const half8 af = *(const half8*)(xt + mb * 16 * XP + kk * 32);
+      for (int mb = 0; mb < NMB; ++mb) {
+        if (2 * mb + wm < mblk) {
+          const half8 af = *(const half8*)(xt + mb * 32 * XP + kk * 32);
 #pragma unroll
           for (int j = 0; j < 3; ++j) acc[mb][j] = mfma16(af, wf[j][kk], acc[mb][j]);
         }
@@ -146,25 +153,25 @@ __global__ __launch_bounds__(256, NBM <= 10 ? 2 : 1) void bert_attn_qkv_kernel(B
   // ================================================================ hand-over: + bias, one rounding, row-major tiles
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    const int cb = 3 * wave + j, part = cb >> 2, col = (cb & 3) * 16 + l15;
+    const int cb = 3 * wn + j, part = cb >> 2, col = (cb & 3) * 16 + l15;
     const float bv = (float)p.bias[(long)part * C + h * D + col];
     half_t* tile = (part == 0 ? Qs : part == 1 ? Ks : Vs) + col;
 #pragma unroll
-    for (int mb = 0; mb < NBM; ++mb) {
-      if (mb < mblk) {
+    for (int mb = 0; mb < NMB; ++mb) {
+      if (2 * mb + wm < mblk) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) tile[(mb * 16 + 4 * lg + r) * KS] = (half_t)(acc[mb][j][r] + bv);
+        for (int r = 0; r < 4; ++r) tile[((2 * mb + wm) * 16 + 4 * lg + r) * KS] = (half_t)(acc[mb][j][r] + bv);
       }
     }
   }
   // value rows behind the last token block that the last 32-key step still reads (its probabilities are exactly 0): finite data
-  for (int c = tid; c < (rows - 16 * mblk) * (D / 8); c += 256) *(half8*)(Vs + (16 * mblk + c / (D / 8)) * KS + (c % (D / 8)) * 8) = zero8();
+  for (int c = tid; c < (rows - 16 * mblk) * (D / 8); c += NT) *(half8*)(Vs + (16 * mblk + c / (D / 8)) * KS + (c % (D / 8)) * 8) = zero8();
   __syncthreads();
 
   // ================================================================ phase 2: attention, one 16-query block at a time
   const float sc2 = p.scale * BA_LOG2E, cl2 = p.clamp * BA_LOG2E;
   half_t* O = p.o + (long)b * p.o_bs + h * D;
-  for (int qblk = wave; qblk < mblk; qblk += 4) {
+  for (int qblk = wave; qblk < mblk; qblk += 8) {
     half8 qf[D / 32];
 #pragma unroll
     for (int kk = 0; kk < D / 32; ++kk) qf[kk] = *(const half8*)(Qs + (qblk * 16 + l15) * KS + kk * 32 + lg * 8);
@@ -237,21 +244,28 @@ __global__ __launch_bounds__(256, NBM <= 10 ? 2 : 1) void bert_attn_qkv_kernel(B
   }
 }
 
-template <int NBM, bool CLAMP>
-static int launch_bert_attn(const BertAttnParams& p, hipStream_t stream) {
+template <int NBM, bool CLAMP, int OCC>
+static int launch_bert_attn_occ(const BertAttnParams& p, hipStream_t stream) {
   auto bytes = [](int cap) {
     const size_t rows = 32 * (size_t)((cap + 1) >> 1);
     return 3 * rows * BA_KS * sizeof(half_t) + 2 * rows * sizeof(float);
   };
   static MqOncePerDevice attr;
   if (attr.first()) {
-    hipError_t e = hipFuncSetAttribute((const void*)bert_attn_qkv_kernel<NBM, CLAMP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes(NBM));
+    hipError_t e = hipFuncSetAttribute((const void*)bert_attn_qkv_kernel<NBM, CLAMP, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes(NBM));
     if (e != hipSuccess) return (int)e;
     attr.done();
   }
-  hipLaunchKernelGGL((bert_attn_qkv_kernel<NBM, CLAMP>), dim3((unsigned)(p.B * p.H)), dim3(256), bytes(p.nblk_cap), stream, p);
+  hipLaunchKernelGGL((bert_attn_qkv_kernel<NBM, CLAMP, OCC>), dim3((unsigned)(p.B * p.H)), dim3(512), bytes(p.nblk_cap), stream, p);
   MQ_CHECK_LAUNCH();
   return 0;
+}
+
+template <int NBM, bool CLAMP>
+static int launch_bert_attn(const BertAttnParams& p, hipStream_t stream) {
+  static const int occ = [] { const char* e = getenv("MQ_BERT_ATTN_OCC"); return (e && e[0] == '4') ? 4 : 2; }();
+  if (NBM <= 10 && occ == 4) return launch_bert_attn_occ<NBM, CLAMP, NBM <= 10 ? 4 : 2>(p, stream);
+  return launch_bert_attn_occ<NBM, CLAMP, 2>(p, stream);
 }
 
 // x [B, T, C] operand type (row stride x_rs, batch stride x_bs, elements; % 8), w [3 C, C] = the layer's q | k | v projection weight, bias [3 C],

@@ -62,7 +62,12 @@ struct DcnGroup {
 // inside a step depends on the other group, only the step boundary does (everybody's share of step k + 1 must be visible before its
 // MFMAs, everybody must be done reading buffer k & 1 before step k + 2 is staged into it).  The ablation of round 3 (GPU call 10) put
 // the kernel's skeleton -- mostly its 72 barriers of 1024 threads per tile -- at a third of the launch.
-template <int NW, int ABL = 0, int SYNC = 2>
+// PLAIN (round 5): every branch of the launch is a PLAIN 3 x 3 convolution handed over as a DCNv2 with all-zero offsets and mask 1 (the FPN
+// output convs, pipeline.fpn_forward; flags bit 1 of mq_dcn_branch is the caller's promise).  A tap then samples ONE pixel: corner 0 with
+// weight 1 (0 where the tap lies in the zero padding), corners 1 .. 3 with weight exactly 0 -- so only corner 0 is gathered and the blend is
+// one multiply by 0 / 1.  Same results bit for bit as the general path (w0 a + 0 b + 0 c + 0 d in the same fma order), a quarter of the gather
+// loads and none of the blend arithmetic.
+template <int NW, int ABL = 0, int SYNC = 2, bool PLAIN = false>
 __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   constexpr int BM = DCN_PH * DCN_PW, BN = 256, BK = 64;
   constexpr int NTH = 64 * NW, RA = 1024 / NTH, JB = 2048 / NTH, IM = 32 / NW;   // threads, A rows / thread, B chunks / thread, row blocks / wave
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
     for (int rr = 0; rr < RA; ++rr) {
       const TapState st = Ts[(ar + rr * (NTH / 8)) * 9 + tap];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < (PLAIN ? 1 : 4); ++q) {
         c_w[s][rr][q] = st.w[q];
         if constexpr (!(ABL & 1)) a_raw[s][rr][q] = *(const half8*)(xb + (st.off[q] + cb));
       }
@@ -234,9 +239,11 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float t = c_w[s][rr][0] * (float)a_raw[s][rr][0][j];
-        t = __builtin_fmaf(c_w[s][rr][1], (float)a_raw[s][rr][1][j], t);
-        t = __builtin_fmaf(c_w[s][rr][2], (float)a_raw[s][rr][2][j], t);
-        t = __builtin_fmaf(c_w[s][rr][3], (float)a_raw[s][rr][3][j], t);
+        if constexpr (!PLAIN) {
+          t = __builtin_fmaf(c_w[s][rr][1], (float)a_raw[s][rr][1][j], t);
+          t = __builtin_fmaf(c_w[s][rr][2], (float)a_raw[s][rr][2][j], t);
+          t = __builtin_fmaf(c_w[s][rr][3], (float)a_raw[s][rr][3][j], t);
+        }
         v[j] = (half_t)t;
       }
       *(half8*)(a + rr * (NTH / 8) * BK) = v;
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
 }
 
 // DCNv2 3x3, pad 1, 256 output channels.  x [B,H,W,C] fp16 NHWC (batch stride x_bs, C % 128 == 0), om [B,27,oH,oW] fp32
-// (18 offsets + 9 mask logits -- or probabilities with flags bit 0 --, NCHW), w [256, 9*C] fp16 (k = tap*C + c), bias [256] fp16 or NULL, out [B*Ho*Wo, out_ld];
+// (18 offsets + 9 mask logits -- or probabilities with flags bit 0 --, NCHW; flags bit 1: the caller promises all-zero offsets and mask 1, i.e. a plain conv), w [256, 9*C] fp16 (k = tap*C + c), bias [256] fp16 or NULL, out [B*Ho*Wo, out_ld];
 // stats (optional) [B, mq_dcnv2_stats_blocks(H, W, stride), 256, 3] fp32 with position weights wy [Ho] x wx [Wo] (or NULL).
 #ifdef MQ_PRIMARY_UNIT
 extern "C" int mq_dcnv2_stats_blocks(int H, int W, int stride) {
@@ -477,7 +484,18 @@ extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* 
   // one barrier per k-step by default since GPU calls 14 / 15 of round 3 (0.661 - 0.668 ms against 0.673 - 0.692 with two, three of three
   // comparisons; equal outputs); MQ_DCN_SYNC=2: the former schedule (A/B switch)
   static const int sync = [] { const char* e = getenv("MQ_DCN_SYNC"); return (e && e[0] == '2') ? 2 : 1; }();
-  if (nw == 16 && sync == 1) hipLaunchKernelGGL((dcn_igemm8_kernel<16, 0, 1>), grid, dim3(1024), smem, (hipStream_t)stream, g);
+  bool plain = true;                                          // flags bit 1 on EVERY branch: zero offsets, mask 1 (the caller's promise)
+  for (int i = 0; i < n; ++i) plain = plain && (br[i].B <= 0 || (br[i].flags & 2));
+  static const bool plain_on = [] { const char* e = getenv("MQ_DCN_PLAIN"); return !(e && e[0] == '0'); }();   // A/B switch
+  if (plain && plain_on && nw == 16 && sync == 1) {
+    static MqOncePerDevice attr_plain;
+    if (attr_plain.first()) {
+      hipError_t e = hipFuncSetAttribute((const void*)dcn_igemm8_kernel<16, 0, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return (int)e;
+      attr_plain.done();
+    }
+    hipLaunchKernelGGL((dcn_igemm8_kernel<16, 0, 1, true>), grid, dim3(1024), smem, (hipStream_t)stream, g);
+  } else if (nw == 16 && sync == 1) hipLaunchKernelGGL((dcn_igemm8_kernel<16, 0, 1>), grid, dim3(1024), smem, (hipStream_t)stream, g);
   else if (nw == 16) hipLaunchKernelGGL(dcn_igemm8_kernel<16>, grid, dim3(1024), smem, (hipStream_t)stream, g);
   else hipLaunchKernelGGL(dcn_igemm8_kernel<8>, grid, dim3(512), smem, (hipStream_t)stream, g);
   MQ_CHECK_LAUNCH();

@@ -42,7 +42,7 @@ namespace { constexpr int PE_NW = 4, PE_PER = 4; }         // waves per workgrou
 template <int C, bool F32>
 __global__ __launch_bounds__(64 * PE_NW) void patch_embed_kernel(PatchEmbedParams p) {
   constexpr int CB = C / 16, XP = C + 4, HP = C + 8;        // LDS row pitches (floats / 16-bit values) of the output transpose
-  __shared__ __attribute__((aligned(16))) float xs_all[PE_NW * 16 * XP + PE_NW * 16 * HP / 2];
+  __shared__ __attribute__((aligned(16))) float xs_all[PE_NW * 16 * XP + PE_NW * 16 * HP * (int)sizeof(half_t) / 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
   // weights: A fragments of every (channel block, k-step), resident for all blocks of this wave

@@ -285,10 +285,8 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
                 lang[k] = cols(lang[k])
         if torch.is_tensor(head.get("hidden")):
             head["hidden"] = rows(head["hidden"])
-        if torch.is_tensor(head.get("tbias")):
-            head["tbias"] = cols(head["tbias"])
-        if "dot" in head:
-            head["dot"] = [cols(d) for d in head["dot"]]
+        # (head["tbias"], head["dot"] and the alignment operands stay Tl wide: postprocess() may be called on this head again; their first
+        # max_kv columns are what the ladders read)
         for a in raw.get("head_trace") or ():
             if torch.is_tensor(a.get("bert_hidden")):
                 a["bert_hidden"] = rows(a["bert_hidden"])

@@ -374,12 +374,12 @@ def fpn_forward(P, feats_nhwc):
         # (1, 0, 0, 0) IS the plain 3x3 conv (zero padding included: taps at -1 / H are "outside"), and that kernel runs its 128 x 256 x 64
         # tiles at 2.5x the rate of conv_igemm's 128 x 256 x 32 ones: +3.8 % end to end (round 3, GPU call 1).
         outs = ops.dcnv2_group([dict(x=x, om=_zero_offsets(x.shape[0], x.shape[1], x.shape[2], x.device), w=P[f"{p}.{n}.packed"],
-                                     bias=P[f"{p}.{n}.bias"], stride=1) for n, x in inners], want_stats=False, tag="dcnv2_fpn")
+                                     bias=P[f"{p}.{n}.bias"], stride=1, plain=True) for n, x in inners], want_stats=False, tag="dcnv2_fpn")
         res = [y.reshape(x.shape[0], hw[0], hw[1], 256) for (y, hw, _), (_, x) in zip(outs, inners)]
 
         def conv3s2(name, x):
             Ho, Wo = (x.shape[1] - 1) // 2 + 1, (x.shape[2] - 1) // 2 + 1
-            y, hw = ops.dcnv2(x, _zero_offsets(x.shape[0], Ho, Wo, x.device), P[f"{p}.{name}.packed"], P[f"{p}.{name}.bias"], 2, tag="dcnv2_fpn")
+            y, hw = ops.dcnv2(x, _zero_offsets(x.shape[0], Ho, Wo, x.device), P[f"{p}.{name}.packed"], P[f"{p}.{name}.bias"], 2, tag="dcnv2_fpn", plain=True)
             return y.reshape(x.shape[0], hw[0], hw[1], 256)
         p6 = conv3s2("top_blocks.p6", res[-1])
         p7 = conv3s2("top_blocks.p7", F.relu(p6))

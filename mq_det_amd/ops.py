@@ -895,7 +895,7 @@ def conv3x3_nchw32_group(levels, w_packed, bias, n_out):
     return outs
 
 
-def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None, mask_prob=False, tag="dcnv2_fused"):
+def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None, mask_prob=False, tag="dcnv2_fused", plain=False):
     """Fused DCNv2: x [B,H,W,C] fp16 NHWC, om [B,27,oH,oW] fp32, w_packed [256, 9*C] -> y [B, Ho*Wo, 256] fp16, (Ho, Wo)
     (, sums [B, nblk, 256, 3] fp32 = per-patch GroupNorm / scale-attention statistics of y when want_stats; wy [Ho] /
     wx [Wo] fp32 weight the third statistic, None -> 1/(Ho*Wo))."""
@@ -914,7 +914,8 @@ def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None
             assert wy.dtype == wx.dtype == torch.float32 and wy.numel() == Ho and wx.numel() == Wo
     with _timed(tag):
         _chk(_fn(lib, "mq_dcnv2_fwd", x_nhwc)(_ptr(x_nhwc), _ptr(om), _ptr(w_packed), _ptr(bias), _ptr(y), _ptr(sums), _ptr(wy), _ptr(wx),
-                              B, H, W, C, x_nhwc.stride(0), om.shape[2], om.shape[3], 256, 256, stride, int(bool(mask_prob)), _stream()), "mq_dcnv2_fwd")
+                              B, H, W, C, x_nhwc.stride(0), om.shape[2], om.shape[3], 256, 256, stride, int(bool(mask_prob)) | (2 if plain else 0),
+                              _stream()), "mq_dcnv2_fwd")
     return (y, (Ho, Wo), sums) if want_stats else (y, (Ho, Wo))
 
 
@@ -951,7 +952,8 @@ def dcnv2_group(branches, want_stats=True, tag="dcnv2_fused", ablation=0):
         a.wy = wy.data_ptr() if wy is not None else None
         a.wx = wx.data_ptr() if wx is not None else None
         a.x_bs, a.B, a.H, a.W, a.C, a.oH, a.oW = x.stride(0), B, H, W, C, om.shape[2], om.shape[3]
-        a.N, a.out_ld, a.stride, a.flags = 256, 256, stride, int(bool(br.get("mask_prob", False))) | ((int(ablation) & 15) << 8 if i == 0 else 0)
+        a.N, a.out_ld, a.stride, a.flags = 256, 256, stride, (int(bool(br.get("mask_prob", False))) | (2 if br.get("plain", False) else 0)
+                                                             | ((int(ablation) & 15) << 8 if i == 0 else 0))
         outs.append((y, (Ho, Wo), sums))
     with _timed(tag):
         _chk(_fn(lib, "mq_dcnv2_group_fwd", *[br["x"] for br in branches])(ctypes.cast(arr, _vp), len(branches), _stream()), "mq_dcnv2_group_fwd")

@@ -406,7 +406,7 @@ def conv3x3_nchw32_group(levels, w_packed, bias, n_out):
     return [conv3x3_nchw32(x, w_packed, bias, n_out) for x in levels]
 
 
-def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None, mask_prob=False, tag=None):
+def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None, mask_prob=False, tag=None, plain=False):
     cols, hw = _dcn_cols(x_nhwc.contiguous(), om, stride)
     y = F.linear(cols.float(), w_packed.float(), bias.float()).to(x_nhwc.dtype)
     if not want_stats:

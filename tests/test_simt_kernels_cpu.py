@@ -567,6 +567,22 @@ def test_fpn_convs_through_the_grouped_dcn_kernel(kernels, monkeypatch):
     kernels._CACHE.clear()
     _assert_ok(kernels.check_swin_fpn(CPU))
     kernels._CACHE.clear()
+    # round 5: the PLAIN instantiation of the kernel (flags bit 1: one corner per tap gathered, no blend) == the general path, bit for bit,
+    # grouped and single launches, stride 1 and 2, patches that straddle the zero padding
+    from mq_det_amd import ops
+    xs = [torch.randn(2, h, w, 256, generator=g).half() for (h, w) in ((23, 31), (12, 16), (5, 7))]
+    wts = [(torch.randn(256, 9 * 256, generator=g) / 48).half() for _ in xs]
+    bs = [torch.randn(256, generator=g).half() for _ in xs]
+    for stride in (1, 2):
+        outs = {}
+        for plain in (False, True):
+            grp = [dict(x=x, om=pipeline._zero_offsets(2, (x.shape[1] - 1) // stride + 1, (x.shape[2] - 1) // stride + 1, CPU), w=w_, bias=b_,
+                        stride=stride, plain=plain) for x, w_, b_ in zip(xs, wts, bs)]
+            outs[plain] = [y for (y, _, _) in ops.dcnv2_group(grp, want_stats=False)]
+            y1, _ = ops.dcnv2(xs[0], grp[0]["om"], wts[0], bs[0], stride, plain=plain)
+            outs[plain].append(y1)
+        for a, b in zip(outs[True], outs[False]):
+            assert torch.equal(a, b)
 
 
 # ---- NMS that stops once max_keep boxes of an image are kept (csrc/nms2.hip, opt-in: MQ_NMS_EARLY_STOP=1)
