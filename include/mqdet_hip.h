@@ -430,6 +430,21 @@ int mq_post_sort_fwd(const float* boxes, const float* scores, const int* labels,
 int mq_post_finalize_fwd(const float* boxes, const float* scores, const int* labels, const unsigned char* keep, float* out,
                          int* counts, int B, int tot, int K, int K2, void* stream);
 
+/* The attention half of a GatedCrossAttentionBlock in ONE launch (round 5; north-star "fused GCP + BERT attention"):
+ *   x_out = x + tanh(w2 . gelu(Wg1 LN_g(sup))) * sup,  sup = Wout sparse_attn(Wq LN_a(x), kv, idx),  y = LN_f(x_out)
+ * -- LayerNorm, to_q, the sparse gather-attention of mq_gcp_sparse_attn_fwd, to_out, the gate MLP with its LayerNorm, the gated residual of
+ * mq_gcp_gate_residual_fwd and the LayerNorm in front of the feed-forward half; a workgroup owns 16 or 32 text rows, weights streamed from L2.
+ * x / x_out [M, 768] fp32 residual stream (M = B*T text rows; x_out may alias x), y [M, 768] 16-bit or NULL, gate_out [M] fp32 or NULL
+ * (VISION_QUERY.RETURN_ATTN_GATE_VALUE), kv [B, V, 1024] 16-bit = to_kv(norm_kv(vision)), idx [M, S] int32 (S <= 8, -1 = padding: a row
+ * without a vision query gets sup == 0 exactly, quirk 5), wq [512, 768], wout [768, 512], wg1 [384, 768], w2 [384], the three LayerNorms'
+ * gamma / beta [768] 16-bit; rows_per_block 16, 32 or 0 (chosen from M).  Returns -1 for other widths or S > 8.
+ * Replaces GatedCrossAttentionBlock.forward up to the feed-forward half: maskrcnn_benchmark/modeling/language_backbone/modeling_bert_new.py
+ * :298-368 (MaskedCrossAttention :162-248 with the sparse gather, attn_gate :340-359, the gated residual :368). */
+int mq_gcp_attn_fwd(const float* x, float* x_out, void* y, float* gate_out, const void* kv, const int* idx, const void* wq, const void* wout,
+                    const void* wg1, const void* w2, const void* ln_a_g, const void* ln_a_b, const void* ln_g_g, const void* ln_g_b,
+                    const void* ln_f_g, const void* ln_f_b, long M, int T, int V, int S, int C, int heads, int dim_head, int G, float eps,
+                    int rows_per_block, void* stream);
+
 /* The attention half of a BERT layer in ONE launch (round 5; north-star "fused GCP + BERT attention"): the q | k | v projection of every
  * (batch item, head) AND its attention -- the qkv tensor is never written.  x [B, T, C] 16-bit hidden states (element (b, t, c) at
  * x + b*x_bs + t*x_rs + c; strides % 8 == 0), w [3C, C] the layer's fused projection weight (rows q | k | v, K-contiguous), bias [3C],
@@ -464,6 +479,7 @@ MQ_BF16_TWIN(mq_window_attn_fwd)
 MQ_BF16_TWIN(mq_window_attn_qkv_fwd)
 MQ_BF16_TWIN(mq_gcp_sparse_attn_fwd)
 MQ_BF16_TWIN(mq_gcp_gate_residual_fwd)
+MQ_BF16_TWIN(mq_gcp_attn_fwd)
 MQ_BF16_TWIN(mq_vlfuse_i2t_fwd)
 MQ_BF16_TWIN(mq_vlfuse_t2i_fwd)
 MQ_BF16_TWIN(mq_layernorm_fwd)
@@ -518,6 +534,7 @@ MQ_F32_TWIN(mq_window_attn_fwd)
 MQ_F32_TWIN(mq_window_attn_qkv_fwd)
 MQ_F32_TWIN(mq_gcp_sparse_attn_fwd)
 MQ_F32_TWIN(mq_gcp_gate_residual_fwd)
+MQ_F32_TWIN(mq_gcp_attn_fwd)
 MQ_F32_TWIN(mq_vlfuse_i2t_fwd)
 MQ_F32_TWIN(mq_vlfuse_t2i_fwd)
 MQ_F32_TWIN(mq_layernorm_fwd)

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libmqdet_hip.so")
-SOURCES = ["api.hip", "attn.hip", "attn_resident.hip", "attn_text.hip", "bert_attn.hip", "vlfuse_attn.hip", "window_attn.hip", "patch_embed.hip", "gcp.hip", "conv_igemm.hip", "conv_small.hip", "conv_small2.hip", "conv_small3.hip", "dcn_fused.hip", "layernorm.hip", "layernorm2.hip", "dyconv.hip", "post.hip", "post2.hip", "align_fused.hip", "nms2.hip", "roi_align.hip", "swin_mlp.hip", "swin_mlp2.hip", "msda.hip"]
+SOURCES = ["api.hip", "attn.hip", "attn_resident.hip", "attn_text.hip", "bert_attn.hip", "vlfuse_attn.hip", "window_attn.hip", "patch_embed.hip", "gcp.hip", "gcp_fused.hip", "conv_igemm.hip", "conv_small.hip", "conv_small2.hip", "conv_small3.hip", "dcn_fused.hip", "layernorm.hip", "layernorm2.hip", "dyconv.hip", "post.hip", "post2.hip", "align_fused.hip", "nms2.hip", "roi_align.hip", "swin_mlp.hip", "swin_mlp2.hip", "msda.hip"]
 # no fp32-operand twin (include/mqdet_hip.h MQ_F32_TWIN): operators whose inputs may already be fp32, the superseded first Swin MLP kernel,
 # and the sources that only hold fp32 / integer code (one copy, in the fp16 unit)
 F32_SKIP = ("msda.hip", "roi_align.hip", "swin_mlp.hip", "nms2.hip", "post2.hip")

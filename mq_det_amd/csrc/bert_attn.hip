@@ -15,13 +15,25 @@
 // Text tokens are few (T <= 256, after live-row compaction T = 16 ceil(caption / 16)), so one workgroup holds a whole (b, h).
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 MQ_NAMESPACE_BEGIN
 
 namespace {
 constexpr int BA_D = 64, BA_KS = BA_D + 16;        // head width; row pitch (elements) of the Q / K / V tiles: conflict-free b128 and transposed reads
 constexpr int BA_BK = 64, BA_XP = BA_BK + 16;      // k-chunk of the projection; row pitch of an X stage
+constexpr int BA_C = 768;                          // hidden width (BERT-base; compile time: the chunk loop is unrolled completely)
 constexpr float BA_LOG2E = 1.4426950408889634f;
+
+template <int I, int N, class F>
+__device__ __forceinline__ void ba_static_for_impl(F& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    ba_static_for_impl<I + 1, N>(f);
+  }
+}
+template <int N, class F>
+__device__ __forceinline__ void ba_static_for(F f) { ba_static_for_impl<0, N>(f); }
 }  // namespace
 
 struct BertAttnParams {
@@ -42,10 +54,9 @@ struct BertAttnParams {
 // nothing covered the L2 round trip of a chunk's operands or the dependent QK^T -> softmax -> PV chain of a query block): wave = (wn, wm),
 // wn = column slice as above, wm = which half of the token blocks (blocks wm, wm + 2, ...) -- half the accumulators per wave, twice the
 // waves per SIMD; phase 2 deals the query blocks to eight waves (two rounds for a 141-token caption instead of three).
-// OCC = waves per SIMD the register budget is cut for: 2 (one workgroup per CU, <= 256 VGPRs, no spill) or 4 (two workgroups per CU, <= 128
-// VGPRs: ~60 spilled dwords at NBM = 10) -- MQ_BERT_ATTN_OCC picks (A/B on the device).
-template <int NBM, bool CLAMP, int OCC>
-__global__ __launch_bounds__(512, OCC) void bert_attn_qkv_kernel(BertAttnParams p) {
+// (Two workgroups per CU -- <= 128 VGPRs -- spilled ~60 dwords inside the chunk loop and ran 4x slower: GPU call 3 of round 5; one per CU.)
+template <int NBM, bool CLAMP>
+__global__ __launch_bounds__(512, 2) void bert_attn_qkv_kernel(BertAttnParams p) {
   constexpr int D = BA_D, KS = BA_KS, BK = BA_BK, XP = BA_XP, NT = 512, NMB = NBM / 2;
   constexpr int NX = (NBM * 16 * (BK / 8) + NT - 1) / NT;        // 16-byte chunks of an X stage per thread
   static_assert(NBM % 2 == 0, "two 16-key blocks per step of the P V product");
@@ -61,7 +72,8 @@ __global__ __launch_bounds__(512, OCC) void bert_attn_qkv_kernel(BertAttnParams 
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave & 3, wm = wave >> 2;
   const int h = blockIdx.x % p.H, b = blockIdx.x / p.H;
-  const int T = p.T, C = p.C;
+  const int T = p.T;
+  constexpr int C = BA_C;
   const int mblk = (T + 15) >> 4;                    // 16-token blocks of this launch (<= cap)
   const int nk_eff = p.kv_len ? max(1, min(T, p.kv_len[b])) : T;
   const int nblk = min((nk_eff + 15) >> 4, mblk);    // 16-key blocks visited
@@ -93,30 +105,35 @@ __global__ __launch_bounds__(512, OCC) void bert_attn_qkv_kernel(BertAttnParams 
   for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
     for (int j = 0; j < 3; ++j) acc[mb][j] = (float4_){0.f, 0.f, 0.f, 0.f};
-  half8 xr[NX];
-  half8 wf0[3][2], wf1[3][2];                        // weight fragments of the current / the next chunk (two named sets: no dynamic register index)
+  // Operands of chunk k + 2 are requested while chunk k is multiplied (GPU call 3 of round 5: with a distance of ONE chunk a chunk cost an L2
+  // round trip, ~0.7 us, against 0.4 us of MFMA work): weight fragments in three register sets, X rows one more chunk in registers before
+  // they go to their LDS stage (two stages suffice: stage (k + 1) & 1 was last read in chunk k - 1, behind a barrier).  The chunk loop is
+  // unrolled completely (C = 768: 12 chunks) -- straight-line code lets the compiler count its vmcnt waits exactly; across a loop back edge
+  // it waits for everything.
+  half8 xr[2][NX];
+  half8 wf[3][3][2];
   const int xchunks = mblk * 16 * (BK / 8);
-  auto load_x = [&](int ks) __attribute__((always_inline)) {
+  auto load_x = [&](half8 (&x)[NX], int ks) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int c = tid + i * NT, r = c >> 3, ch = c & 7;
-      if (c < xchunks) xr[i] = *(const half8*)(X + (long)min(r, T - 1) * p.x_rs + ks * BK + ch * 8);
+      if (c < xchunks) x[i] = *(const half8*)(X + (long)min(r, T - 1) * p.x_rs + ks * BK + ch * 8);
     }
   };
-  auto store_x = [&](int buf) __attribute__((always_inline)) {
+  auto store_x = [&](const half8 (&x)[NX], int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int c = tid + i * NT, r = c >> 3, ch = c & 7;
-      if (c < xchunks) *(half8*)(Xs + ((long)buf * rows + r) * XP + ch * 8) = xr[i];
+      if (c < xchunks) *(half8*)(Xs + ((long)buf * rows + r) * XP + ch * 8) = x[i];
     }
   };
-  auto load_w = [&](half8 (&wf)[3][2], int ks) __attribute__((always_inline)) {
+  auto load_w = [&](half8 (&w)[3][2], int ks) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) wf[j][kk] = *(const half8*)(wrow[j] + ks * BK + kk * 32);
+      for (int kk = 0; kk < 2; ++kk) w[j][kk] = *(const half8*)(wrow[j] + ks * BK + kk * 32);
   };
-  auto gemm_chunk = [&](int buf, const half8 (&wf)[3][2]) __attribute__((always_inline)) {
+  auto gemm_chunk = [&](int buf, const half8 (&w)[3][2]) __attribute__((always_inline)) {
     const half_t* xt = Xs + (long)buf * rows * XP + (wm * 16 + l15) * XP + lg * 8;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -125,30 +142,28 @@ __global__ __launch_bounds__(512, OCC) void bert_attn_qkv_kernel(BertAttnParams 
         if (2 * mb + wm < mblk) {
           const half8 af = *(const half8*)(xt + mb * 32 * XP + kk * 32);
 #pragma unroll
-          for (int j = 0; j < 3; ++j) acc[mb][j] = mfma16(af, wf[j][kk], acc[mb][j]);
+          for (int j = 0; j < 3; ++j) acc[mb][j] = mfma16(af, w[j][kk], acc[mb][j]);
         }
       }
     }
   };
-  const int nsteps = C / BK;                         // even (host: C % 128 == 0)
-  load_x(0);
-  load_w(wf0, 0);
-  store_x(0);
+  constexpr int NSTEPS = BA_C / BK;
+  load_x(xr[0], 0);
+  load_w(wf[0], 0);
+  load_x(xr[1], 1);
+  load_w(wf[1], 1);
+  store_x(xr[0], 0);
   __syncthreads();
-  for (int ks = 0; ks < nsteps; ks += 2) {
-    load_x(ks + 1);
-    load_w(wf1, ks + 1);
-    gemm_chunk(0, wf0);
-    store_x(1);
-    __syncthreads();
-    if (ks + 2 < nsteps) {
-      load_x(ks + 2);
-      load_w(wf0, ks + 2);
+  ba_static_for<NSTEPS>([&](auto kc) __attribute__((always_inline)) {
+    constexpr int k = decltype(kc)::value;
+    if constexpr (k + 2 < NSTEPS) {
+      load_x(xr[k & 1], k + 2);                      // (xr[k & 1] held chunk k: stored in chunk k - 1)
+      load_w(wf[(k + 2) % 3], k + 2);
     }
-    gemm_chunk(1, wf1);
-    if (ks + 2 < nsteps) store_x(0);
-    __syncthreads();                                 // (last pass: every wave is done with the X stages before the tiles overwrite them)
-  }
+    gemm_chunk(k & 1, wf[k % 3]);
+    if constexpr (k + 1 < NSTEPS) store_x(xr[(k + 1) & 1], (k + 1) & 1);
+    __syncthreads();                                 // (last chunk: every wave is done with the X stages before the tiles overwrite them)
+  });
 
   // ================================================================ hand-over: + bias, one rounding, row-major tiles
 #pragma unroll
@@ -244,39 +259,32 @@ __global__ __launch_bounds__(512, OCC) void bert_attn_qkv_kernel(BertAttnParams 
   }
 }
 
-template <int NBM, bool CLAMP, int OCC>
-static int launch_bert_attn_occ(const BertAttnParams& p, hipStream_t stream) {
+template <int NBM, bool CLAMP>
+static int launch_bert_attn(const BertAttnParams& p, hipStream_t stream) {
   auto bytes = [](int cap) {
     const size_t rows = 32 * (size_t)((cap + 1) >> 1);
     return 3 * rows * BA_KS * sizeof(half_t) + 2 * rows * sizeof(float);
   };
   static MqOncePerDevice attr;
   if (attr.first()) {
-    hipError_t e = hipFuncSetAttribute((const void*)bert_attn_qkv_kernel<NBM, CLAMP, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes(NBM));
+    hipError_t e = hipFuncSetAttribute((const void*)bert_attn_qkv_kernel<NBM, CLAMP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes(NBM));
     if (e != hipSuccess) return (int)e;
     attr.done();
   }
-  hipLaunchKernelGGL((bert_attn_qkv_kernel<NBM, CLAMP, OCC>), dim3((unsigned)(p.B * p.H)), dim3(512), bytes(p.nblk_cap), stream, p);
+  hipLaunchKernelGGL((bert_attn_qkv_kernel<NBM, CLAMP>), dim3((unsigned)(p.B * p.H)), dim3(512), bytes(p.nblk_cap), stream, p);
   MQ_CHECK_LAUNCH();
   return 0;
 }
 
-template <int NBM, bool CLAMP>
-static int launch_bert_attn(const BertAttnParams& p, hipStream_t stream) {
-  static const int occ = [] { const char* e = getenv("MQ_BERT_ATTN_OCC"); return (e && e[0] == '4') ? 4 : 2; }();
-  if (NBM <= 10 && occ == 4) return launch_bert_attn_occ<NBM, CLAMP, NBM <= 10 ? 4 : 2>(p, stream);
-  return launch_bert_attn_occ<NBM, CLAMP, 2>(p, stream);
-}
-
 // x [B, T, C] operand type (row stride x_rs, batch stride x_bs, elements; % 8), w [3 C, C] = the layer's q | k | v projection weight, bias [3 C],
 // o [B, T, C] (o_rs % 4); key_bias fp32 (b, j) at key_bias + b * bias_bs + j or NULL; kv_len [B] int32 or NULL (keys at and beyond it are
-// skipped in whole 16-key blocks; the caller's key_bias masks the rest).  C = 64 H, C % 128 == 0, T <= 256.  clamp > 0: the +-clamp of the
+// skipped in whole 16-key blocks; the caller's key_bias masks the rest).  C = 768 = 64 H (BERT-base), T <= 256.  clamp > 0: the +-clamp of the
 // VLDyHead BERT copies.  Returns -1 for shapes it does not take, -3 for misaligned strides.
 extern "C" int MQ_SYM(mq_bert_attn_qkv_fwd)(const void* x, const void* w, const void* bias, void* o, const float* key_bias, const int* kv_len,
                                             int B, int T, int C, int H, long x_bs, long x_rs, long o_bs, long o_rs, long bias_bs, float scale,
                                             float clamp, void* stream) {
   if (B <= 0 || T <= 0) return 0;
-  if (H <= 0 || C != BA_D * H || (C % 128) || T > 256) return -1;
+  if (H <= 0 || C != BA_C || C != BA_D * H || T > 256) return -1;
   if ((x_bs % 8) || (x_rs % 8) || (o_rs % 4) || (o_bs % 4)) return -3;
   BertAttnParams p;
   p.x = (const half_t*)x; p.w = (const half_t*)w; p.bias = (const half_t*)bias; p.o = (half_t*)o; p.key_bias = key_bias; p.kv_len = kv_len;

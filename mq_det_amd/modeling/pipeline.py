@@ -482,8 +482,19 @@ def gcp_block(P, b, x, vision, idx, gates=None):
     """GatedCrossAttentionBlock.forward (modeling_bert_new.py:298-374): K/V projected once per unique vision
     token, sparse gather-attention kernel, gate MLP + tanh + residual fused.  x: the text residual stream (fp32 with
     RESIDUAL_FP32, else fp16), returned in the same dtype; vision: fp16 or fp32."""
-    q = F.linear(_ln(P, b + ".attn.norm", x), P[b + ".attn.to_q.weight"])
     kv = F.linear(_ln(P, b + ".attn.norm_kv", vision), P[b + ".attn.to_kv.weight"])
+    ff = b + ".ff"
+    if ops.KERNELS["GCP_ATTN_FUSED"] == 1 and ops.gcp_attention_fits(x, idx):
+        # LayerNorm, to_q, sparse attention, to_out, gate MLP, gated residual and the feed-forward half's LayerNorm: one launch (mq_gcp_attn_fwd)
+        def ln(n):
+            return (P[n + ".weight"], P[n + ".bias"])
+        r = ops.gcp_attention(x.contiguous(), kv.contiguous(), idx, P[b + ".attn.to_q.weight"], P[b + ".attn.to_out.weight"], P[b + ".attn_gate.linear1.weight"],
+                              P[b + ".attn_gate.w2"], ln(b + ".attn.norm"), ln(b + ".attn_gate.norm"), ln(ff + ".norm"), want_gate=gates is not None)
+        x, xn = r[0], r[1]
+        if gates is not None:
+            gates.append(r[2])
+        return x + F.linear(F.gelu(F.linear(xn, P[ff + ".linear1.weight"])), P[ff + ".linear2.gated"])
+    q = F.linear(_ln(P, b + ".attn.norm", x), P[b + ".attn.to_q.weight"])
     sup = F.linear(ops.gcp_sparse_attention(q, kv, idx), P[b + ".attn.to_out.weight"])
     gh = F.linear(_ln(P, b + ".attn_gate.norm", sup), P[b + ".attn_gate.linear1.weight"])
     if gates is not None:
@@ -491,7 +502,6 @@ def gcp_block(P, b, x, vision, idx, gates=None):
         gates.append(g)
     else:
         x = ops.gcp_gate_residual(sup, gh, P[b + ".attn_gate.w2"], x.contiguous())
-    ff = b + ".ff"
     return x + F.linear(F.gelu(F.linear(_ln(P, ff + ".norm", x), P[ff + ".linear1.weight"])), P[ff + ".linear2.gated"])
 
 

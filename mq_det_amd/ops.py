@@ -13,7 +13,7 @@ _LIB = None
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmqdet_hip.so")
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
-EXPECTED_ABI = 26        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
+EXPECTED_ABI = 27        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
 _SIGNATURES = {
     "mq_abi_version": (_i, []),
     "mq_attn_workspace_bytes": (_l, [_i, _i, _i, _i, _i]),
@@ -27,6 +27,7 @@ _SIGNATURES = {
     "mq_window_attn_qkv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_gcp_sparse_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_gcp_gate_residual_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _l, _i, _i, _vp]),
+    "mq_gcp_attn_fwd": (_i, [_vp] * 16 + [_l, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "mq_vlfuse_i2t_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "mq_vlfuse_t2i_workspace_bytes": (_l, [_i, _i, _i]),
     "mq_vlfuse_t2i_fwd": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
@@ -68,7 +69,7 @@ _SIGNATURES = {
     "mq_ml_nms": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
 }
 # entry points with 16-bit operands also exist as <name>_bf16 (same signature; include/mqdet_hip.h MQ_BF16_TWIN)
-BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_text_fwd", "mq_bert_attn_qkv_fwd", "mq_patch_embed_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_window_attn_qkv_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
+BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_text_fwd", "mq_bert_attn_qkv_fwd", "mq_patch_embed_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_window_attn_qkv_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_gcp_attn_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
               "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_layernorm_clamp_fwd", "mq_clamp_gelu_clamp", "mq_patch_merge_ln_fwd", "mq_swin_mlp_fwd", "mq_swin_mlp2_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_conv3x3_nchw32_group_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
               "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyconv_epilogue_group", "mq_dyrelu_apply", "mq_dyrelu_ln_fwd", "mq_add_upsample_nearest",
               "mq_align_scores_fwd", "mq_align_fused_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
@@ -120,6 +121,8 @@ KERNEL_DEFAULTS = {
                                  # 0: permute copies + library GEMM (K = 48) + two LayerNorm launches (354 us at B = 8)
     "BERT_QKV_FUSED": 1,         # 1: BERT layers = ONE qkv GEMM + mq_attn_text_fwd (V row-major, transposed out of LDS; registers / LDS sized by the
                                  # caption length); 0: q|k GEMM + V^T batched GEMM + mq_attn_resident_fwd (rounds 2-3)
+    "GCP_ATTN_FUSED": 1,         # 1: mq_gcp_attn_fwd -- the attention half of a GCP block (LayerNorm, to_q, sparse attention, to_out, gate MLP, gated residual,
+                                 # next LayerNorm) in one launch; 0: the eight launches of rounds 2-4
     "BERT_ATTN_QKV_FUSED": 1,    # 1: mq_bert_attn_qkv_fwd -- the q | k | v projection inside the attention launch (one workgroup per (batch item, head); the
                                  # qkv tensor is never written); 0: one qkv GEMM + mq_attn_text_fwd (round 4)
     "POST_FUSED": 1,             # 1: ATSS post-processing as mq_post_select_fwd + mq_post_sort_fwd + mq_ml_nms_topk + mq_post_finalize_fwd (4 launches);
@@ -563,6 +566,37 @@ def gcp_sparse_attention(q, kv, idx, heads=8, dim_head=64):
         _chk(_fn(lib, "mq_gcp_sparse_attn_fwd", q)(_ptr(q), _ptr(kv), _ptr(idx), _ptr(out), B, T, V, S, heads, dim_head, _stream()),
              "mq_gcp_sparse_attn_fwd")
     return out
+
+
+def gcp_attention_fits(x, idx):
+    """Shapes mq_gcp_attn_fwd takes: the fp32 text stream of BERT-base width, at most 8 vision-query slots per token."""
+    return x.dtype == torch.float32 and x.shape[-1] == 768 and idx.shape[-1] <= 8
+
+
+def gcp_attention(x, kv, idx, wq, wout, wg1, w2, ln_a, ln_g, ln_f=None, eps=1e-5, want_gate=False, rows_per_block=0):
+    """The attention half of a GatedCrossAttentionBlock in one launch (mq_gcp_attn_fwd).  x [B,T,768] fp32 residual stream, kv [B,V,1024] 16-bit,
+    idx [B,T,S] int32, wq [512,768], wout [768,512], wg1 [384,768], w2 [384]; ln_a / ln_g / ln_f = (gamma, beta) of the attention-input, gate-input
+    and (optional) feed-forward-input LayerNorms -> x_out [B,T,768] fp32 (, y = LN_f(x_out) 16-bit when ln_f) (, gate [B,T] fp32 when want_gate)."""
+    lib = load_library()
+    _need_gpu(x, kv, idx, wq, wout, wg1, w2)
+    B, T, C = x.shape
+    V, S = kv.shape[1], idx.shape[2]
+    assert gcp_attention_fits(x, idx) and x.is_contiguous() and kv.shape == (B, V, 1024) and kv.is_contiguous() and kv.dtype in _H16
+    assert idx.dtype == torch.int32 and idx.shape[:2] == (B, T) and idx.is_contiguous()
+    assert wq.shape == (512, C) and wout.shape == (C, 512) and wg1.shape == (384, C) and w2.numel() == 384
+    ws = [wq, wout, wg1, w2, *ln_a, *ln_g] + (list(ln_f) if ln_f is not None else [])
+    assert all(w.dtype == kv.dtype and w.is_contiguous() for w in ws)
+    out = torch.empty_like(x)
+    y = torch.empty(B, T, C, dtype=kv.dtype, device=x.device) if ln_f is not None else None
+    gate = torch.empty(B, T, dtype=torch.float32, device=x.device) if want_gate else None
+    with _timed(f"gcp_attn_fused_s{S}"):
+        rc = _fn(lib, "mq_gcp_attn_fwd", kv)(_ptr(x), _ptr(out), _ptr(y), _ptr(gate), _ptr(kv), _ptr(idx), _ptr(wq), _ptr(wout), _ptr(wg1), _ptr(w2),
+                                            _ptr(ln_a[0]), _ptr(ln_a[1]), _ptr(ln_g[0]), _ptr(ln_g[1]),
+                                            _ptr(ln_f[0]) if ln_f is not None else _vp(0), _ptr(ln_f[1]) if ln_f is not None else _vp(0),
+                                            B * T, T, V, S, C, 8, 64, 384, float(eps), int(rows_per_block), _stream())
+    _chk(rc, "mq_gcp_attn_fwd")
+    res = (out,) + ((y,) if y is not None else ()) + ((gate,) if want_gate else ())
+    return res if len(res) > 1 else out
 
 
 def gcp_gate_residual(sup, h, w2, x, want_gate=False):

@@ -136,6 +136,21 @@ def gcp_sparse_attention(q, kv, idx, heads=8, dim_head=64):
     return out.to(q.dtype)
 
 
+def gcp_attention(x, kv, idx, wq, wout, wg1, w2, ln_a, ln_g, ln_f=None, eps=1e-5, want_gate=False, rows_per_block=0):
+    """ops.gcp_attention: the unfused chain with its rounding points (every LayerNorm / GEMM output rounded to the operand type once)."""
+    dt = kv.dtype
+
+    def ln(v, gb):
+        return F.layer_norm(v.float(), (v.shape[-1],), gb[0].float(), gb[1].float(), eps).to(dt)
+    q = F.linear(ln(x, ln_a).float(), wq.float()).to(dt)
+    sup = F.linear(gcp_sparse_attention(q, kv, idx).float(), wout.float()).to(dt)
+    gh = F.linear(ln(sup, ln_g).float(), wg1.float()).to(dt)
+    gate = torch.tanh((F.gelu(gh.float()) * w2.float().reshape(-1)).sum(-1, keepdim=True))
+    out = sup.float() * gate + x.float()
+    res = (out,) + ((ln(out, ln_f),) if ln_f is not None else ()) + ((gate.squeeze(-1),) if want_gate else ())
+    return res if len(res) > 1 else out
+
+
 def gcp_gate_residual(sup, h, w2, x, want_gate=False):
     gate = torch.tanh((F.gelu(h.float()) * w2.float()).sum(-1, keepdim=True))
     out = (sup.float() * gate + x.float()).to(x.dtype)
@@ -607,7 +622,7 @@ def dyconv_coef_group(items, attn_w, attn_b, groups, eps):
 
 # ---------------------------------------------------------------------------------------------------------------------------------
 # every emulated entry point, in one place: tests patch them into mq_det_amd.ops (or into a stand-in namespace) with these helpers
-NAMES = ("attention", "attention4", "attention_text", "bert_attention_qkv", "patch_embed", "window_attention", "window_attention_qkv", "gcp_sparse_attention", "gcp_gate_residual", "dcnv2_group", "align_scores", "align_fused",
+NAMES = ("attention", "attention4", "attention_text", "bert_attention_qkv", "patch_embed", "window_attention", "window_attention_qkv", "gcp_sparse_attention", "gcp_gate_residual", "gcp_attention", "dcnv2_group", "align_scores", "align_fused",
          "dyconv_branch_coef", "dyconv_coef_group", "dyconv_epilogue_group", "dyconv_fuse", "dyrelu_", "dyrelu_coef", "dyrelu_apply_", "dyrelu_layer_norm", "add_upsample_nearest_", "conv3x3", "conv3x3_nchw32", "conv3x3_nchw32_group", "conv3x3_nchw32_group_supported", "dcnv2", "layer_norm", "clamp_gelu_clamp", "vlfuse_i2t",
          "vlfuse_t2i", "box_decode", "ml_nms", "post_select", "post_select_supported", "post_sort", "post_finalize", "roi_align", "swin_mlp", "swin_mlp2", "patch_merge_ln", "ms_deform_attn", "ms_deform_attn_q", "image_key_mask")
 
@@ -625,7 +640,7 @@ def namespace(real_ops):
     import types
     g = globals()
     fake = types.SimpleNamespace(**{n: g[n] for n in NAMES})
-    for n in ("patch_embed_pack", "SWIN_MLP_WIDTHS", "WINDOW_QKV_WIDTHS", "window_qkv_fused", "SCORE_AGG", "window_pad", "pad_rel_bias", "swin_mlp_w2_perm", "swin_mlp2_pack", "timing_active", "attention_text_fits", "bert_attention_qkv_fits", "f32_operands"):
+    for n in ("patch_embed_pack", "SWIN_MLP_WIDTHS", "WINDOW_QKV_WIDTHS", "window_qkv_fused", "SCORE_AGG", "window_pad", "pad_rel_bias", "swin_mlp_w2_perm", "swin_mlp2_pack", "timing_active", "attention_text_fits", "bert_attention_qkv_fits", "gcp_attention_fits", "f32_operands"):
         setattr(fake, n, getattr(real_ops, n))
     fake.KERNELS = dict(real_ops.KERNEL_DEFAULTS)       # the default kernel selection: the glue of the promoted variants is what runs
     return fake

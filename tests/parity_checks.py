@@ -217,6 +217,46 @@ def check_attention_text(dev):
     return res
 
 
+def check_gcp_attn_fused(dev):
+    """mq_gcp_attn_fwd (csrc/gcp_fused.hip: LayerNorm, to_q, sparse gather-attention, to_out, gate MLP, gated residual, next LayerNorm in one
+    launch) against the unfused chain stated in plain torch with the same rounding points (tests/ops_emulation.gcp_attention).  Rows without any
+    vision query (sup == 0 exactly: x_out == x bit for bit), partly padded slots, M not a multiple of the row block, both row-block sizes, with
+    and without the trailing LayerNorm / the gate output."""
+    import ops_emulation as emu
+    from mq_det_amd import ops
+    res = []
+    g = torch.Generator().manual_seed(41)
+    for (B, T, V, S, rb, lnf) in ((2, 144, 200, 5, 16, True), (3, 23, 37, 8, 32, True), (1, 256, 200, 5, 32, False), (8, 96, 120, 5, 0, True))[:3 if QUICK else 4]:
+        if ops.f32_operands() and rb == 32:
+            rb = 16                                                       # the fp32-operand build holds 16 rows per workgroup
+        x = torch.randn(B, T, 768, generator=g) * 1.5
+        kv = torch.randn(B, V, 1024, generator=g).to(H16)
+        idx = torch.randint(0, V, (B, T, S), generator=g).to(torch.int32)
+        idx[torch.rand(B, T, S, generator=g) < 0.3] = -1                 # padded slots
+        idx[:, ::7] = -1                                                  # tokens without a vision query
+        wq = (torch.randn(512, 768, generator=g) / 768 ** 0.5).to(H16)
+        wout = (torch.randn(768, 512, generator=g) / 512 ** 0.5).to(H16)
+        wg1 = (torch.randn(384, 768, generator=g) / 768 ** 0.5).to(H16)
+        w2 = (torch.randn(384, generator=g) * 0.1).to(H16)
+        lns = [((torch.rand(768, generator=g) + 0.5).to(H16), (torch.randn(768, generator=g) * 0.1).to(H16)) for _ in range(3)]
+        ref = emu.gcp_attention(x, kv, idx, wq, wout, wg1, w2, lns[0], lns[1], lns[2] if lnf else None, want_gate=True)
+        d = lambda t_: t_.to(dev)                                        # noqa: E731
+        got = ops.gcp_attention(d(x), d(kv), d(idx), d(wq), d(wout), d(wg1), d(w2), tuple(map(d, lns[0])), tuple(map(d, lns[1])),
+                                tuple(map(d, lns[2])) if lnf else None, want_gate=True, rows_per_block=rb)
+        tag = f"gcp attention half fused B={B} T={T} V={V} S={S} rows/block={rb or 'auto'}"
+        # five 16-bit rounding points in a row (LN, q, att, sup, LN, h): where the fused kernel's fp32 sums differ from torch's in the last bit
+        # an intermediate flips by one 16-bit ulp -- a COMPOUND row (elem_gate off, like the block checks); with fp32 operands: zero violations
+        res.append(_stat(f"{tag}: x_out (fp32 stream)", got[0], ref[0], tol=2e-3, elem_gate=False))
+        if lnf:
+            res.append(_stat(f"{tag}: LN_f(x_out)", got[1], ref[1], tol=2e-3, elem_gate=False))
+        res.append(_stat(f"{tag}: gate", got[-1], ref[-1], tol=4e-3, elem_gate=False))
+        dead = (idx < 0).all(-1)
+        same = torch.equal(got[0].cpu()[dead], x[dead])
+        res.append({"name": f"{tag}: rows without a vision query pass through bit for bit", "max_err": 0.0 if same else 1.0, "mean_err": 0.0, "ref_absmax": 1.0,
+                    "norm_err": 0.0 if same else 1.0, "tol": 0.0, "ok": bool(same)})
+    return res
+
+
 def check_bert_attn_qkv(dev):
     """mq_bert_attn_qkv_fwd (csrc/bert_attn.hip): q | k | v projection + attention of every (batch item, head) in one launch, against the plain
     statement  qkv = round16(x W^T + b);  softmax(clamp(scale q k^T) + mask) v  on the same rounded operands.  Token counts on both sides of the
@@ -1191,6 +1231,7 @@ def all_checks(dev):
     out += [("attention", lambda: check_attention_strided(dev)),
             ("attention", lambda: check_attention_text(dev)),
             ("attention", lambda: check_bert_attn_qkv(dev)),
+            ("gcp", lambda: check_gcp_attn_fused(dev)),
             ("swin", lambda: check_patch_embed(dev)),
             ("post", lambda: check_post_fused(dev)),
             ("dyconv", lambda: check_dyconv_epilogue_group(dev)),

@@ -58,7 +58,7 @@ def test_attention_strided_views(dev):
 @pytest.mark.parametrize("name", ["check_window_attention", "check_swin_fpn", "check_gcp_block", "check_pre_select",
                                   "check_vlfuse_kernels", "check_vl_fuse", "check_dcn", "check_conv3x3", "check_layernorm", "check_dyconv", "check_nms", "check_full_model",
                                   "check_ref_pins", "check_post_golden", "check_roi_align", "check_extract_query", "check_swin_mlp", "check_msdeform_attn",
-                                  "check_align_fused", "check_fusion_layer", "check_post_fused", "check_attention_text", "check_bert_attn_qkv", "check_patch_embed",
+                                  "check_align_fused", "check_fusion_layer", "check_post_fused", "check_attention_text", "check_bert_attn_qkv", "check_gcp_attn_fused", "check_patch_embed",
                                   "check_bert_clamp_fused"])
 def test_block(dev, name):
     import parity_checks as pc
@@ -615,7 +615,7 @@ def bf16():
 @pytest.mark.parametrize("name", ["check_attention_strided", "check_window_attention", "check_vlfuse_kernels", "check_dcn", "check_layernorm",
                                   "check_swin_mlp", "check_full_model", "check_gcp_block", "check_pre_select", "check_vl_fuse", "check_dyconv",
                                   "check_conv3x3", "check_post_golden", "check_roi_align", "check_msdeform_attn", "check_align_fused",
-                                  "check_attention_text", "check_bert_attn_qkv", "check_patch_embed", "check_bert_clamp_fused"])
+                                  "check_attention_text", "check_bert_attn_qkv", "check_gcp_attn_fused", "check_patch_embed", "check_bert_clamp_fused"])
 def test_bf16_block(dev, bf16, name):
     _assert(getattr(bf16, name)(dev))
 
@@ -670,7 +670,7 @@ def _assert_f32(res):
 
 @pytest.mark.parametrize("name", ["check_attention_strided", "check_window_attention", "check_swin_fpn", "check_vlfuse_kernels", "check_dcn", "check_layernorm",
                                   "check_swin_mlp", "check_gcp_block", "check_pre_select", "check_vl_fuse", "check_dyconv", "check_conv3x3",
-                                  "check_align_fused", "check_attention_text", "check_bert_attn_qkv", "check_patch_embed", "check_bert_clamp_fused"])
+                                  "check_align_fused", "check_attention_text", "check_bert_attn_qkv", "check_gcp_attn_fused", "check_patch_embed", "check_bert_clamp_fused"])
 def test_f32_block(dev, f32, name):
     _assert_f32(getattr(f32, name)(dev))
 

@@ -67,7 +67,7 @@ def test_tiny_full_model_meets_1e_3_with_fp32_operands(f32):
 
 
 @pytest.mark.parametrize("name", ["check_swin_fpn", "check_window_attention", "check_gcp_block", "check_pre_select", "check_vl_fuse", "check_dyconv",
-                                  "check_align_fused", "check_bert_attn_qkv", "check_attention_text"])
+                                  "check_align_fused", "check_bert_attn_qkv", "check_attention_text", "check_gcp_attn_fused"])
 def test_blocks_meet_1e_3_with_fp32_operands(f32, name):
     _assert_ok(getattr(f32, name)(CPU))
 

@@ -116,8 +116,8 @@ def test_emulation_unit_kernels():
     (("descending", 0), ("check_attention_strided", "check_window_attention", "check_gcp_block", "check_layernorm", "check_swin_mlp",
                          "check_nms", "check_post_golden", "check_msdeform_attn")),
     (("random", 1), ("check_dcn", "check_vlfuse_kernels", "check_conv3x3", "check_post_fused")),
-    (("descending", 0), ("check_post_fused", "check_bert_attn_qkv")),
-    (("random", 3), ("check_bert_attn_qkv",))])
+    (("descending", 0), ("check_post_fused", "check_bert_attn_qkv", "check_gcp_attn_fused")),
+    (("random", 3), ("check_bert_attn_qkv", "check_gcp_attn_fused"))])
 def test_kernels_are_insensitive_to_the_wave_schedule(kernels, schedule, names):
     """Race check of the shipped kernels: the same parity checks with the fibers resumed in descending / pseudo-random order
     (a consumer wave then runs before its producer unless a barrier orders them).  MQ_SIMT_FULL=1: every check under both."""
@@ -147,7 +147,7 @@ def test_attention_strided_views(kernels):
 
 @pytest.mark.parametrize("name", ["check_window_attention", "check_gcp_block", "check_pre_select", "check_vlfuse_kernels", "check_vl_fuse",
                                   "check_dcn", "check_dyconv", "check_post_golden", "check_score_agg", "check_layernorm", "check_nms", "check_swin_mlp",
-                                  "check_conv3x3", "check_roi_align", "check_msdeform_attn", "check_swin_fpn", "check_align_fused", "check_post_fused", "check_attention_text", "check_bert_attn_qkv", "check_patch_embed", "check_bert_clamp_fused"])
+                                  "check_conv3x3", "check_roi_align", "check_msdeform_attn", "check_swin_fpn", "check_align_fused", "check_post_fused", "check_attention_text", "check_bert_attn_qkv", "check_gcp_attn_fused", "check_patch_embed", "check_bert_clamp_fused"])
 def test_kernel_block(kernels, name):
     _assert_ok(getattr(kernels, name)(CPU))
 
@@ -233,7 +233,7 @@ def bf16(kernels):
 
 @pytest.mark.parametrize("name", ["check_window_attention", "check_gcp_block", "check_pre_select", "check_vlfuse_kernels", "check_dcn",
                                   "check_post_golden", "check_layernorm", "check_swin_mlp", "check_conv3x3", "check_msdeform_attn",
-                                  "check_attention_strided", "check_attention_text", "check_bert_attn_qkv", "check_patch_embed", "check_bert_clamp_fused"])
+                                  "check_attention_strided", "check_attention_text", "check_bert_attn_qkv", "check_gcp_attn_fused", "check_patch_embed", "check_bert_clamp_fused"])
 def test_bf16_kernel_block(bf16, name):
     res = getattr(bf16, name)(CPU)
     _assert_ok(res)
@@ -517,7 +517,7 @@ def test_no_kernel_touches_memory_outside_its_buffers(mode):
     """Inputs, outputs and workspaces of every call sit directly against a PROT_NONE page (after them: mode "end", before: "start"); one
     byte too far is a SIGSEGV.  Shipped kernels on a cross-section of checks, and the opt-in kernels of section 12 (which have never
     run on a device, where such an access is a silent wrong read or a memory fault that takes the process down)."""
-    names = ["attention_small", "check_layernorm", "check_window_attention", "check_conv3x3", "check_bert_attn_qkv"]      # (all 20 check groups pass: MQ_SIMT_FULL=1)
+    names = ["attention_small", "check_layernorm", "check_window_attention", "check_conv3x3", "check_bert_attn_qkv", "check_gcp_attn_fused"]      # (all 20 check groups pass: MQ_SIMT_FULL=1)
     if os.environ.get("MQ_SIMT_FULL", "0") == "1":
         names += ["check_gcp_block", "check_pre_select", "check_vlfuse_kernels", "check_vl_fuse", "check_dcn", "check_dyconv", "check_post_golden",
                   "check_score_agg", "check_nms", "check_swin_mlp", "check_roi_align", "check_msdeform_attn", "check_swin_fpn", "check_attention_qk_mask",

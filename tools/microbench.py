@@ -53,6 +53,8 @@ def main():
         vlfuse_text(dev, g, out)
     if only in ("", "bert_attn"):
         bert_attn(dev, g, out)
+    if only in ("", "gcp_attn"):
+        gcp_attn(dev, g, out)
     if only == "t2i_sweep":
         t2i_sweep(dev, g, out)
     if only == "offset_conv":
@@ -61,6 +63,34 @@ def main():
         print(json.dumps(r))
     if len(sys.argv) > 1:
         json.dump(out, open(sys.argv[1], "w"), indent=1)
+
+
+def gcp_attn(dev, g, out):
+    """The attention half of a GCP block on the compacted text (T = 144): ONE launch of mq_gcp_attn_fwd against the eight launches it replaces
+    (LayerNorm, to_q GEMM, mq_gcp_sparse_attn_fwd, to_out GEMM, LayerNorm, gate GEMM, mq_gcp_gate_residual_fwd, LayerNorm)."""
+    import torch.nn.functional as F
+    T, V, S = 144, 200, 5
+    h = lambda *s_, sc=1.0: (torch.randn(*s_, generator=g) * sc).half().to(dev)          # noqa: E731
+    wq, wout, wg1, w2 = h(512, 768, sc=768 ** -0.5), h(768, 512, sc=512 ** -0.5), h(384, 768, sc=768 ** -0.5), h(384, sc=0.1)
+    lns = [(h(768, sc=0.1) + 1, h(768, sc=0.1)) for _ in range(3)]
+    for B in (8, 64):
+        x = torch.randn(B, T, 768, generator=g).to(dev)
+        kv = h(B, V, 1024)
+        idx = torch.randint(0, V, (B, T, S), generator=g).to(torch.int32).to(dev)
+
+        def unfused():
+            q = F.linear(ops.layer_norm(x, *lns[0], 1e-5), wq)
+            sup = F.linear(ops.gcp_sparse_attention(q, kv, idx), wout)
+            gh = F.linear(ops.layer_norm(sup, *lns[1], 1e-5), wg1)
+            xo = ops.gcp_gate_residual(sup, gh, w2, x)
+            return xo, ops.layer_norm(xo, *lns[2], 1e-5)
+        fl = 2.0 * B * T * (768 * 512 + 512 * 768 + 768 * 384)
+        rec = {"kernel": "gcp attention half", "B": B, "T": T, "algorithmic_gflop": round(fl / 1e9, 2), "unfused_8_launches_ms": round(timeit(unfused), 4)}
+        for rb in (16, 32):
+            ms = timeit(lambda: ops.gcp_attention(x, kv, idx, wq, wout, wg1, w2, lns[0], lns[1], lns[2], rows_per_block=rb))
+            rec[f"fused_rb{rb}_ms"] = round(ms, 4)
+            rec[f"fused_rb{rb}_tflops"] = round(fl / ms / 1e9, 1)
+        out.append(rec)
 
 
 def bert_attn(dev, g, out):
