@@ -512,8 +512,10 @@ def lang_path_b64(model, cfg, dev, chunks, iters=5):
     fl_bert_attn = 12 * 4.0 * Bn * 12 * Tl * k16 * 64
     fl_bert_proj = 12 * 2.0 * Bn * Tl * C * 3 * C if fused else 0.0
     fl_pre = 2 * 4.0 * Bn * 8 * V * 5577 * 32
-    fl_gcp = 6 * 4.0 * Bn * 8 * Tl * S * 64
-    tags = ("attn_d", "attn_res_d", "attn_text_d", "attn_chk_d", "gcp_sparse", "bert_attn_qkv")
+    gcp_fused = any(k.startswith("gcp_attn_fused") for k in kern)
+    # GCP: with mq_gcp_attn_fwd one launch is to_q + the sparse attention + to_out + the gate MLP (+ three LayerNorms, not counted)
+    fl_gcp = 6 * 4.0 * Bn * 8 * Tl * S * 64 + (6 * 2.0 * Bn * Tl * (C * 512 + 512 * C + C * 384) if gcp_fused else 0.0)
+    tags = ("attn_d", "attn_res_d", "attn_text_d", "attn_chk_d", "gcp_sparse", "bert_attn_qkv", "gcp_attn_fused")
     att_ms = sum(v[1] for k, v in kern.items() if k.startswith(tags)) / iters
     bert_ms = sum(v[1] for k, v in kern.items() if k.startswith(("bert_attn_qkv", "attn_text_d", "attn_res_d"))) / iters
     att_tf = (fl_bert_attn + fl_bert_proj + fl_pre + fl_gcp) / (att_ms * 1e-3) / 1e12
@@ -531,11 +533,12 @@ def lang_path_b64(model, cfg, dev, chunks, iters=5):
             "bert_fused_launches": {"ms": round(bert_ms, 3), "tflops": round(bert_tf, 1), "mfma_utilisation": round(bert_tf / MFMA_PEAK_TFLOPS, 4),
                                     "projection_inside_the_launch": fused},
             "flops": {"bert_self_attention": fl_bert_attn, "bert_qkv_projection_inside_the_attention_launch": fl_bert_proj,
-                      "gcp_pre_select": fl_pre, "gcp_sparse": fl_gcp,
-                      "formula": f"12 x (4*B*12*{Tl}*{k16}*64" + (f" + 2*B*{Tl}*768*2304" if fused else "") + f") + 2 x 4*B*8*{V}*5577*32 + 6 x 4*B*8*{Tl}*{S}*64, "
+                      "gcp_pre_select": fl_pre, "gcp_attention_launches": fl_gcp, "gcp_projections_inside_the_launch": gcp_fused,
+                      "formula": f"12 x (4*B*12*{Tl}*{k16}*64" + (f" + 2*B*{Tl}*768*2304" if fused else "") + f") + 2 x 4*B*8*{V}*5577*32 + 6 x (4*B*8*{Tl}*{S}*64" + (f" + 2*B*{Tl}*(768*512 + 512*768 + 768*384)" if gcp_fused else "") + "), "
                                  f"B = {Bn} ({Tl} = live text rows after compaction, {k16} = visited text keys of the {n_tok}-token caption)"},
             "kernels_ms": {k: round(v[1] / iters, 3) for k, v in sorted(kern.items())},
-            "timing": "eager, single stream, HIP events; attention = the bert_attn_qkv (projection + attention) / attn_* / gcp_sparse launches only"}
+            "timing": "eager, single stream, HIP events; attention = the bert_attn_qkv (projection + attention) / gcp_attn_fused (projections + sparse "
+                      "attention + gate) / attn_* / gcp_sparse launches only"}
 
 
 def _sub_bench(argv, env=None, timeout=150, keep=()):
