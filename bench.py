@@ -608,15 +608,22 @@ def _dry_launch(args, rank, local, world):
     Bn, K = args.batch, 316
     packed = torch.full((Bn, K, 6), float(rank + 1), device=dev)
     t0 = time.perf_counter()
-    for _ in range(max(args.steps, 1)):
-        allp = parallel.gather_detections(packed)
+    if args.overlap_gather:                              # the one-step-behind form: every submit but the first returns the previous block
+        og, got = parallel.OverlappedGather(), 0
+        for _ in range(max(args.steps, 1)):
+            got += og.submit(packed) is not None
+        allp = og.flush()
+        assert got == max(args.steps, 1) - 1
+    else:
+        for _ in range(max(args.steps, 1)):
+            allp = parallel.gather_detections(packed)
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     ok = allp.shape == (world * Bn, K, 6) and all(float(allp[r * Bn, 0, 0]) == r + 1 for r in range(world))
     if rank == 0:
         print(json.dumps({"metric": "images/sec MQ-GLIP-T 800×1333 5-shot vision queries, 1/2/4/8 MI355X", "value": None, "unit": "images/sec",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_launch": True, "gather_ok": bool(ok),
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_launch": True, "gather_ok": bool(ok), "overlap_gather": bool(args.overlap_gather),
                           "gather_ms": round(1e3 * dt / max(args.steps, 1), 3), "comm": _comm_info(world),
                           "config": {"workload": "launcher check only: no forward", "global_batch": world * Bn, "batch_per_gpu": Bn,
                                      "parallelism": f"dp{world}"}}), flush=True)
@@ -648,6 +655,8 @@ def main():
     ap.add_argument("--no-experimental", action="store_true", help="skip the kernel-set A/B and the other BASELINE configs (subprocesses)")
     ap.add_argument("--no-extras", action="store_true", help="the contract fields + rooflines only (what the subprocess lines use)")
     ap.add_argument("--cpu-baseline", action="store_true", help="mq-gdino-t workload: also time the CPU oracle (off by default there)")
+    ap.add_argument("--overlap-gather", action="store_true", help="N > 1: the gather of step k runs asynchronously under the forward of step k + 1 "
+                                                                  "(parallel.OverlappedGather); the last one is waited for inside the timed region")
     ap.add_argument("--dry-launch", action="store_true", help="launcher check: start the ranks, rendezvous, one fixed-shape gather of dummy "
                                                               "detections, print the line with n_gpus = ranks; no kernels (runs on CPU over gloo)")
     args = ap.parse_args()
@@ -719,9 +728,13 @@ def main():
                     parallel.gather_detections(model.last_packed)
             return out
     else:
+        og = parallel.OverlappedGather() if (world > 1 and args.overlap_gather) else None
+
         def step():
             out = model(images, captions=captions, positive_map=pmap)
-            if world > 1:
+            if og is not None:
+                og.submit(model.last_packed)                        # the collective of this step runs under the next forward
+            elif world > 1:
                 parallel.gather_detections(model.last_packed)       # [world*B, 300, 6], one fixed-shape collective
             return out
 
@@ -733,6 +746,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    if not lvis and og is not None:
+        og.flush()                                                  # the last step's gather is inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()

@@ -452,20 +452,35 @@ def bert_layer(P, b, x, key_bias, clamp, kv_len=None, x32=None, qk_mask=None, ma
     return y16, y32
 
 
-def pre_select(P, p, vision, image, scale):
-    """modeling_bert_new.py:398-409,433-448: vision queries attend to the pooled image tokens (8 x 32)."""
+def pre_select(P, p, vision, image, scale, side_ok=False):
+    """modeling_bert_new.py:398-409,433-448: vision queries attend to the pooled image tokens (8 x 32).
+    side_ok: the caller runs on the capturing / main stream -- the keys and values of the SECOND layer (they depend on the image tokens only)
+    are projected on a side stream beside the first layer instead of inside the serial chain."""
     vision, image = vision * scale, image * scale
     Bn, Np, C = image.shape
     pad = (-Np) % 8
     if pad:
         image = F.pad(image, (0, 0, 0, pad))
+
+    def image_kv(i):
+        ic = f"{p}.layers.{i}.image_condition"
+        kn = _ln(P, ic + ".norm_kv", image)
+        return F.linear(kn, P[ic + ".to_k.weight"]), torch.matmul(P[ic + ".to_v.weight"], kn.transpose(1, 2))     # k, V^T [B, 256, Np_pad]
+    ahead = None
+    if side_ok and image.is_cuda:
+        main, side = torch.cuda.current_stream(), _side_streams(image.device, 1, "pre_kv")[0]
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ahead = image_kv(1)
     for i in range(2):
         b = f"{p}.layers.{i}"
         ic = b + ".image_condition"
         q = F.linear(_ln(P, ic + ".norm", vision), P[ic + ".to_q.weight"])
-        kn = _ln(P, ic + ".norm_kv", image)
-        k = F.linear(kn, P[ic + ".to_k.weight"])
-        vt = torch.matmul(P[ic + ".to_v.weight"], kn.transpose(1, 2))                    # [B, 256, Np_pad]
+        if i == 1 and ahead is not None:
+            main.wait_stream(side)
+            k, vt = ahead
+        else:
+            k, vt = image_kv(i)
         nq_tiles = -(-q.shape[1] // 128)
         att = ops.attention(q, k, vt, 8, 32, nk=Np, nsplit=_nsplit(nq_tiles * Bn * 8, -(-Np // 64)))
         v16 = vision if vision.dtype == image.dtype else vision.to(image.dtype)
@@ -478,11 +493,17 @@ def pre_select(P, p, vision, image, scale):
     return vision
 
 
-def gcp_block(P, b, x, vision, idx, gates=None):
+def gcp_kv(P, b, vision):
+    """Keys | values of the vision queries for one GCP block: projected once per unique vision token; depend on `vision` only."""
+    return F.linear(_ln(P, b + ".attn.norm_kv", vision), P[b + ".attn.to_kv.weight"])
+
+
+def gcp_block(P, b, x, vision, idx, gates=None, kv=None):
     """GatedCrossAttentionBlock.forward (modeling_bert_new.py:298-374): K/V projected once per unique vision
     token, sparse gather-attention kernel, gate MLP + tanh + residual fused.  x: the text residual stream (fp32 with
-    RESIDUAL_FP32, else fp16), returned in the same dtype; vision: fp16 or fp32."""
-    kv = F.linear(_ln(P, b + ".attn.norm_kv", vision), P[b + ".attn.to_kv.weight"])
+    RESIDUAL_FP32, else fp16), returned in the same dtype; vision: fp16 or fp32; kv: gcp_kv(P, b, vision) computed ahead (side stream) or None."""
+    if kv is None:
+        kv = gcp_kv(P, b, vision)
     ff = b + ".ff"
     if ops.KERNELS["GCP_ATTN_FUSED"] == 1 and ops.gcp_attention_fits(x, idx):
         # LayerNorm, to_q, sparse attention, to_out, gate MLP, gated residual and the feed-forward half's LayerNorm: one launch (mq_gcp_attn_fwd)
@@ -544,7 +565,7 @@ def _bert(P, b, x, x32, key_bias, clamp, kv_len, qk_mask=None, max_kv=0):
     return bert_layer(P, b, x, key_bias, clamp, kv_len, x32=x32, qk_mask=qk_mask, max_kv=max_kv)
 
 
-def language_backbone(P, cfg, input_ids, attention_mask, vision, images, idx, want_gates=False, front=None, max_kv=0):
+def language_backbone(P, cfg, input_ids, attention_mask, vision, images, idx, want_gates=False, front=None, max_kv=0, side_ok=False):
     """bert_model_new.BertEncoder.forward (:39-104) over QVBertModel.forward (modeling_bert_new.py:690-848).
     `front`: result of language_front (computed concurrently with the image backbone); None -> computed here."""
     p = "language_backbone.body.model"
@@ -553,16 +574,30 @@ def language_backbone(P, cfg, input_ids, attention_mask, vision, images, idx, wa
     if front is None:
         front = language_front(P, cfg, input_ids, attention_mask, use_vq, max_kv=max_kv)
     x, x32, hidden, key_bias, kv_len = front["x"], front.get("x32"), list(front["hidden"]), front["key_bias"], front["kv_len"]
-    if use_vq:
-        vision = pre_select(P, p + ".pre_select", vision, images, cfg.VISION_QUERY.VISION_SCALE)
     nl, qv0 = LB.get("NUM_HIDDEN_LAYERS", 12), LB.get("QV_START", 6)
+    kv_ahead, kv_join = {}, None
+    if use_vq:
+        vision = pre_select(P, p + ".pre_select", vision, images, cfg.VISION_QUERY.VISION_SCALE, side_ok=side_ok)
+        first = max(front["next"], qv0)
+        if side_ok and vision.is_cuda and nl - first > 1:
+            # K / V of the vision queries for GCP blocks 2 .. depend on `vision` only: off the serial text chain, onto a side stream (the first
+            # block's stay in the chain: it needs them at once).  side_ok = the caller is on the capturing stream (no fork from a forked stream).
+            main, side = torch.cuda.current_stream(), _side_streams(vision.device, 1, "gcp_kv")[0]
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for i in range(first + 1, nl):
+                    kv_ahead[i] = gcp_kv(P, f"{p}.encoder.qv_layer.{i - qv0}", vision)
+            kv_join = (main, side)
     gates = [] if want_gates else None
     for i in range(front["next"], nl):
         if use_vq and i >= qv0:
+            if kv_join is not None and i in kv_ahead:
+                kv_join[0].wait_stream(kv_join[1])
+                kv_join = None
             if x32 is None:
-                x = gcp_block(P, f"{p}.encoder.qv_layer.{i - qv0}", x, vision, idx, gates)
+                x = gcp_block(P, f"{p}.encoder.qv_layer.{i - qv0}", x, vision, idx, gates, kv=kv_ahead.get(i))
             else:
-                x32 = gcp_block(P, f"{p}.encoder.qv_layer.{i - qv0}", x32, vision, idx, gates)
+                x32 = gcp_block(P, f"{p}.encoder.qv_layer.{i - qv0}", x32, vision, idx, gates, kv=kv_ahead.get(i))
                 x = x32.to(x.dtype)
         x, x32 = _bert(P, f"{p}.encoder.layer.{i}", x, x32, key_bias, False, kv_len, max_kv=max_kv)
         hidden.append(x if x32 is None else x32)

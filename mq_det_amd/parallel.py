@@ -48,6 +48,40 @@ def gather_detections(packed):
     return out
 
 
+class OverlappedGather:
+    """The same fixed-shape gather, one step behind: `submit(packed_k)` starts the collective of step k asynchronously (RCCL runs it on its
+    own stream; xGMI is idle during a forward) and hands back the gathered block of step k - 1, so the ~10 us collective and its launch
+    latency sit under the next forward instead of behind every step.  `flush()` returns the last block.  One rank: a pass-through.
+    The evaluator consumes detections image by image (engine/inference.py:643-648) -- a one-step delay changes nothing it can observe."""
+
+    def __init__(self):
+        self._pending = None                      # (work handle or None, out tensor, the packed tensor kept alive)
+
+    def _finish(self):
+        if self._pending is None:
+            return None
+        work, out, _keep = self._pending
+        self._pending = None
+        if work is not None:
+            work.wait()                           # stream-level wait on GPU backends, a host wait on gloo
+        return out
+
+    def submit(self, packed):
+        prev = self._finish()
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            self._pending = (None, packed, packed)
+            return prev
+        world = dist.get_world_size()
+        src = packed.contiguous()
+        out = src.new_empty((world * src.shape[0],) + tuple(src.shape[1:]))
+        work = dist.all_gather_into_tensor(out, src, async_op=True)
+        self._pending = (work, out, src)
+        return prev
+
+    def flush(self):
+        return self._finish()
+
+
 def unpack_detections(packed):
     """[N,K,6] -> list of dicts with the non-empty rows."""
     res = []

@@ -168,6 +168,12 @@ def test_bench_gpus_flag_starts_the_ranks():
                         "--master-port", "29537", bench, "--gpus", "2", "--dry-launch"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert [json.loads(ln)["n_gpus"] for ln in r.stdout.splitlines() if ln.startswith("{")] == [2]
+    # the world size of BASELINE.json configs[2] (8 ranks, gloo, no kernels), with the gather one step behind the "forward" (--overlap-gather)
+    r = subprocess.run([sys.executable, bench, "--gpus", "8", "--dry-launch", "--overlap-gather", "--steps", "3"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(d) == 1 and d[0]["n_gpus"] == 8 and d[0]["gather_ok"] and d[0]["overlap_gather"] and d[0]["config"]["global_batch"] == 64
     # mismatch: 1 rank in the environment, 2 asked for
     r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-launch"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
                        capture_output=True, text=True, timeout=120)
