@@ -163,21 +163,15 @@ int mq_clamp_gelu_clamp(const void* x, void* out, long n, float clamp, void* str
 int mq_patch_merge_ln_fwd(const void* x, int x_f32, const void* gamma, const void* beta, void* y, int B, int H, int W, int C, float eps,
                           void* stream);
 
-/* MLP half of a Swin block in one kernel (LayerNorm prologue, fc1, exact GELU, fc2, residual; the 4C-wide hidden activation
- * stays in registers), C in {96, 192, 384}:
+/* MLP half of a Swin block in one kernel (LayerNorm prologue, fc1, exact GELU, fc2, residual; the 4C-wide hidden activation stays in
+ * registers), C in {96, 192, 384}:
  *   x' = x + delta;  out = x' + fc2(gelu(fc1(LN(x'; ln_g, ln_b, eps))));  y = LN(out; next_g, next_b, eps_next) (optional)
- *   x [M,C] fp32 (residual stream), delta [M,C] fp16 or NULL, w1 [4C,C], b1 [4C], b2 [C] fp16, w2p [C,4C] fp16 = fc2.weight
- *   with the k-slots of every 32-block permuted (slot 8g+t <- hidden 4g+t for t < 4, 16+4g+t-4 for t >= 4: the transposed
- *   GEMM chain hands its accumulators to the second MFMA as B-fragments), out [M,C] fp32, y [M,C] fp16 or NULL.
+ *   x [M,C] fp32 (residual stream), delta [M,C] fp16 or NULL, b1 [4C], b2 [C] fp16, out [M,C] fp32, y [M,C] fp16 or NULL.
  *   Returns -1 for other C (callers fall back to library GEMMs).
- * Replaces SwinTransformerBlock's  x = x + drop_path(mlp(norm2(x)))  (backbone/swint.py:238-240, Mlp :13-31) and, through
- *   `y`, the following block's norm1 (:198) or the stage's output norm (:611). */
-int mq_swin_mlp_fwd(const float* x, const void* delta, const void* ln_g, const void* ln_b, float eps, const void* w1,
-                    const void* b1, const void* w2p, const void* b2, float* out, const void* next_g, const void* next_b,
-                    float eps_next, void* y, long M, int C, void* stream);
-
-/* Second generation of the same operator (csrc/swin_mlp2.hip; same arguments, same results up to the fp32 summation order of the
- * hidden chunks): the weights arrive FRAGMENT-MAJOR so that staging is a linear LDS-DMA copy and every LDS read is conflict-free;
+ * Replaces SwinTransformerBlock's  x = x + drop_path(mlp(norm2(x)))  (backbone/swint.py:238-240, Mlp :13-31) and, through `y`, the
+ *   following block's norm1 (:198) or the stage's output norm (:611).
+ * (csrc/swin_mlp2.hip -- the second generation; the first, mq_swin_mlp_fwd on row-major weights, was removed in round 5.)  The weights
+ * arrive FRAGMENT-MAJOR so that staging is a linear LDS-DMA copy and every LDS read is conflict-free;
  * GELU(chunk j), fc1(chunk j + 1) and fc2(chunk j - 1) are issued together (software pipeline).  A launch lasts a whole number of
  * passes of the chip (one 16-token block per wave); when only a few blocks remain beyond the last full pass they go to a second
  * kernel that splits the hidden dimension of ONE block over the waves of a workgroup (1 / 8 of a pass instead of a whole one).
@@ -186,7 +180,8 @@ int mq_swin_mlp_fwd(const float* x, const void* delta, const void* ln_g, const v
  *   w1f [(4C/32 + 2) * (C/16) * 512] fp16: block (chunk j, hb in {0,1}, ks) holds for lane l  fc1.weight[32j + 16hb + (l & 15)][32ks + 8(l >> 4) .. +7];
  *        two all-zero chunks follow the last one (the pipeline reads two chunks ahead);
  *   w2f [(4C/32) * (C/16) * 512] fp16: block (chunk j, ct) holds for lane l  w2p[16ct + (l & 15)][32j + 8(l >> 4) .. +7], w2p = fc2.weight with
- *        the k-slot permutation of mq_swin_mlp_fwd.   (Python: ops.swin_mlp2_pack(fc1.weight, fc2.weight).) */
+ *        the k-slots of every 32-block permuted (slot 8g+t <- hidden 4g+t for t < 4, 16+4g+t-4 for t >= 4: the transposed GEMM chain hands
+ *        its accumulators to the second MFMA as B fragments).   (Python: ops.swin_mlp2_pack(fc1.weight, fc2.weight).) */
 int mq_swin_mlp2_fwd(const float* x, const void* delta, const void* ln_g, const void* ln_b, float eps, const void* w1f,
                      const void* b1, const void* w2f, const void* b2, float* out, const void* next_g, const void* next_b,
                      float eps_next, void* y, long M, int C, int flags, void* stream);
@@ -487,7 +482,6 @@ MQ_BF16_TWIN(mq_layernorm2_fwd)
 MQ_BF16_TWIN(mq_layernorm_clamp_fwd)
 MQ_BF16_TWIN(mq_clamp_gelu_clamp)
 MQ_BF16_TWIN(mq_patch_merge_ln_fwd)
-MQ_BF16_TWIN(mq_swin_mlp_fwd)
 MQ_BF16_TWIN(mq_swin_mlp2_fwd)
 MQ_BF16_TWIN(mq_conv3x3_fwd)
 MQ_BF16_TWIN(mq_conv3x3_nchw32_fwd)
@@ -518,7 +512,7 @@ MQ_BF16_TWIN(mq_msdeform_attn_q_fwd)
  * large -- a launch whose tiles exceed the 160 KB of a CU returns hipErrorInvalidValue (1); mq_det_amd/ops.py picks the shapes / variants
  * that fit.  A quarter of the MFMA rate: this build exists to SHOW parity with the fp32 reference on the device (tests/, bench.py
  * `precise_mode`), not for throughput.  No twin: the operators whose inputs may already be fp32 in the 16-bit builds (mq_roi_align_fwd,
- * mq_msdeform_attn_*) and the superseded mq_swin_mlp_fwd. */
+ * mq_msdeform_attn_*). */
 #ifdef __cplusplus
 #define MQ_F32_TWIN(name) extern decltype(name) name##_f32;
 #else

@@ -4,8 +4,8 @@
 //     out  = x' + fc2( GELU( fc1( LayerNorm(x') ) ) )        (swint.py:240, Mlp :13-31, exact erf GELU)
 //     y    = LayerNorm_next(out)             (optional: the next block's norm1 / the stage's output norm, 16-bit)
 //
-// Same mathematics and register-chained transposed GEMM pair as swin_mlp.hip (H^T = W1 LN(x)^T, OUT^T = W2 H^T; the accumulator of the
-// first product IS the B fragment of the second).  What round 3's counters said about that kernel (profiles/r03_call1_swin_mlp_sq*.csv,
+// Same mathematics and register-chained transposed GEMM pair as the first-generation kernel (swin_mlp.hip, removed in round 5: H^T = W1 LN(x)^T,
+// OUT^T = W2 H^T; the accumulator of the first product IS the B fragment of the second).  What round 3's counters said about that kernel (profiles/r03_call1_swin_mlp_sq*.csv,
 // MI355X): MFMA pipe 9 % busy; 6.4 / 12.6 / 24 VALU instructions per MFMA at C = 384 / 192 / 96 -- the exact GELU was ~23 VALU per
 // value (__frcp_rn expands to the IEEE division sequence); 46 % of the LDS cycles were bank conflicts (padded row-major weight
 // chunks); per 32-hidden chunk a barrier, with GEMM1 -> GELU -> GEMM2 strictly one after the other inside every wave, so the two
@@ -75,7 +75,7 @@ constexpr int gelu_piece_of(int q, int GS, bool want_k) {
 }
 #define MQ_GELU_TAB_N 768            // Phi on [-6, 6) in steps of 1 / 64: linear interpolation error <= h^2 / 8 max|Phi''| = 7.4e-6
 
-// LayerNorm of the wave's 16 tokens straight into MFMA B fragments (as swin_mlp.hip: lane (g, token l15) loads x[token][32 ks + 8 g .. + 7],
+// LayerNorm of the wave's 16 tokens straight into MFMA B fragments (lane (g, token l15) loads x[token][32 ks + 8 g .. + 7],
 // the four g-lanes of a token cover one 128-byte line per ks; statistics = in-lane sum + two shuffles; rows beyond M are clamped)
 template <int C, bool HAS_DELTA>
 __device__ __forceinline__ void ln_fragments(const SwinMlp2Params& p, long row0, int l15, int g, half8 (&xf)[C / 32]) {
@@ -588,7 +588,7 @@ static int dispatch_swin_mlp2(const SwinMlp2Params& p, int flags, hipStream_t s)
 // x [M, C] fp32, delta [M, C] 16-bit or NULL, LN gamma / beta [C], b1 [4C], b2 [C] 16-bit;
 // w1f [(4C / 32 + 2) * (C / 16) * 512]: fc1.weight fragment-major -- block (chunk j, hb in {0, 1}, ks) holds for lane l the 8 values
 //     W1[32 j + 16 hb + (l & 15)][32 ks + 8 (l >> 4) .. + 7]; two all-zero chunks behind the last one;
-// w2f [(4C / 32) * (C / 16) * 512]: fc2.weight with the k-slot permutation of mq_swin_mlp_fwd (slot 8 g + t of a 32-block <- hidden unit
+// w2f [(4C / 32) * (C / 16) * 512]: fc2.weight with its k-slots permuted (slot 8 g + t of a 32-block <- hidden unit
 //     4 g + t for t < 4, 16 + 4 g + t - 4 for t >= 4), fragment-major -- block (chunk j, ct) holds for lane l W2p[16 ct + (l & 15)][32 j + 8 (l >> 4) .. + 7];
 // out [M, C] fp32 (may alias x), y [M, C] 16-bit = LayerNorm(out; next_g, next_b, eps_next) if y != NULL.
 // flags: bit 1 = table GELU in the main kernel; bit 0 = no tail split; bit 2 = every block through the tail kernel (see dispatch_swin_mlp2);

@@ -38,19 +38,16 @@ def _pack_swin(P, sd, SW, p, device, dtype):
             rel = rel.reshape(N, N, heads).permute(2, 0, 1)
             NP = ops.window_pad(ws)                                                        # 64 (window 7) or 160 (window 12)
             P[b + ".rel_bias"] = F.pad(rel, (0, NP - N, 0, NP - N)).contiguous()         # [heads, NP, NP], see ops.pad_rel_bias
-    # Swin MLP halves that run as one fused kernel (mq_swin_mlp_fwd): fc2.weight with the k-slots of every 32-block permuted
-    P["_swin_fused_mlp"] = bool(SW.get("FUSED_MLP", True)) and P["_r32"]
+    # Swin MLP halves that run as one fused kernel (mq_swin_mlp2_fwd): both weights fragment-major.  KERNELS["SWIN_MLP_VARIANT"] = 1 selects the
+    # library path (LayerNorm kernel + two GEMMs + GELU); the first-generation kernel mq_swin_mlp_fwd was removed in round 5 (lost its A/Bs)
+    P["_swin_fused_mlp"] = bool(SW.get("FUSED_MLP", True)) and P["_r32"] and ops.KERNELS["SWIN_MLP_VARIANT"] == 2
     P["_swin_fused_widths"] = tuple(w for w in SW.get("FUSED_MLP_WIDTHS", ops.SWIN_MLP_WIDTHS) if w in ops.SWIN_MLP_WIDTHS)
     for i, depth in enumerate(SW.DEPTHS):
         Ci = SW.EMBED_DIM * 2 ** i
         if P["_swin_fused_mlp"] and Ci in P["_swin_fused_widths"]:
-            perm = ops.swin_mlp_w2_perm(4 * Ci, device)
             for j in range(depth):
                 b = f"{p}.layers.{i}.blocks.{j}.mlp"
-                if ops.KERNELS["SWIN_MLP_VARIANT"] == 2:         # mq_swin_mlp2_fwd: both weights fragment-major
-                    P[b + ".w1f"], P[b + ".w2f"] = ops.swin_mlp2_pack(h(b + ".fc1.weight"), h(b + ".fc2.weight"))
-                else:
-                    P[b + ".fc2.w2p"] = h(b + ".fc2.weight")[:, perm].contiguous()
+                P[b + ".w1f"], P[b + ".w2f"] = ops.swin_mlp2_pack(h(b + ".fc1.weight"), h(b + ".fc2.weight"))
     # patch embedding (4x4 stride-4 conv) as a GEMM over (kh, kw, c)-ordered patches
     w = sd[p + ".patch_embed.proj.weight"].detach().to(device=device, dtype=torch.float32)
     P[p + ".patch_embed.lin"] = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dtype).contiguous()
@@ -307,12 +304,8 @@ def swin_forward(P, cfg, img, p="backbone.body", SW=None):
                 # the result next (the following block's norm1, or the stage's output norm :611)
                 nxt = f"{p}.layers.{i}.blocks.{j + 1}.norm1" if j + 1 < depth else (f"{p}.norm{i}" if i > 0 else None)
                 nln = None if nxt is None else (P[nxt + ".weight"], P[nxt + ".bias"], 1e-5)
-                if (b + ".mlp.w1f") in P:
-                    r = ops.swin_mlp2(x.contiguous(), proj.contiguous(), P[b + ".norm2.weight"], P[b + ".norm2.bias"], 1e-5,
-                                      P[b + ".mlp.w1f"], P[b + ".mlp.fc1.bias"], P[b + ".mlp.w2f"], P[b + ".mlp.fc2.bias"], next_ln=nln)
-                else:
-                    r = ops.swin_mlp(x.contiguous(), proj.contiguous(), P[b + ".norm2.weight"], P[b + ".norm2.bias"], 1e-5,
-                                     P[b + ".mlp.fc1.weight"], P[b + ".mlp.fc1.bias"], P[b + ".mlp.fc2.w2p"], P[b + ".mlp.fc2.bias"], next_ln=nln)
+                r = ops.swin_mlp2(x.contiguous(), proj.contiguous(), P[b + ".norm2.weight"], P[b + ".norm2.bias"], 1e-5,
+                                  P[b + ".mlp.w1f"], P[b + ".mlp.fc1.bias"], P[b + ".mlp.w2f"], P[b + ".mlp.fc2.bias"], next_ln=nln)
                 x, h1 = r if nxt is not None else (r, None)
                 pend = None
             else:

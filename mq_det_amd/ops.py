@@ -36,7 +36,6 @@ _SIGNATURES = {
     "mq_layernorm_clamp_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _f, _vp]),
     "mq_clamp_gelu_clamp": (_i, [_vp, _vp, _l, _f, _vp]),
     "mq_patch_merge_ln_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
-    "mq_swin_mlp_fwd": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _l, _i, _vp]),
     "mq_swin_mlp2_fwd": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _l, _i, _i, _vp]),
     "mq_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _i, _i, _vp]),
     "mq_conv3x3_nchw32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _i, _vp]),
@@ -70,12 +69,12 @@ _SIGNATURES = {
 }
 # entry points with 16-bit operands also exist as <name>_bf16 (same signature; include/mqdet_hip.h MQ_BF16_TWIN)
 BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_text_fwd", "mq_bert_attn_qkv_fwd", "mq_patch_embed_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_window_attn_qkv_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_gcp_attn_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
-              "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_layernorm_clamp_fwd", "mq_clamp_gelu_clamp", "mq_patch_merge_ln_fwd", "mq_swin_mlp_fwd", "mq_swin_mlp2_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_conv3x3_nchw32_group_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
+              "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_layernorm_clamp_fwd", "mq_clamp_gelu_clamp", "mq_patch_merge_ln_fwd", "mq_swin_mlp2_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_conv3x3_nchw32_group_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
               "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyconv_epilogue_group", "mq_dyrelu_apply", "mq_dyrelu_ln_fwd", "mq_add_upsample_nearest",
               "mq_align_scores_fwd", "mq_align_fused_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
 # ... and as <name>_f32 (fp32 operands, the precise mode), except the operators whose inputs may already be fp32 in the 16-bit modes
-# (query extraction / MQ-GroundingDINO sampling: their two element types would coincide) and the superseded first Swin MLP kernel
-F32_TWINS = tuple(n for n in BF16_TWINS if n not in ("mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd", "mq_swin_mlp_fwd"))
+# (query extraction / MQ-GroundingDINO sampling: their two element types would coincide)
+F32_TWINS = tuple(n for n in BF16_TWINS if n not in ("mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd"))
 for _n in BF16_TWINS:
     _SIGNATURES[_n + "_bf16"] = _SIGNATURES[_n]
 for _n in F32_TWINS:
@@ -96,7 +95,8 @@ KERNEL_DEFAULTS = {
     "FPN_VIA_DCN": 1,            # 1: the three FPN output convs as ONE grouped launch of the fused DCNv2 kernel, zero offsets    +3.8 %
     "NMS_EARLY_STOP": 1,         # 1: mq_ml_nms_topk (the sweep of an image ends once DETECTIONS_PER_IMG boxes are kept)          +0.9 %
     "ATTN_RESIDENT": 1,          # 1: mq_attn_resident_fwd / mq_attn_chunked_fwd (S^T form, keys resident / 256-key chunks)       +4.7 %
-    "SWIN_MLP_VARIANT": 2,       # 2: mq_swin_mlp2_fwd (fragment-major weights, 3-deep software pipeline, 14-VALU GELU); 1: mq_swin_mlp_fwd
+    "SWIN_MLP_VARIANT": 2,       # 2: mq_swin_mlp2_fwd (fragment-major weights, 3-deep software pipeline, 14-VALU GELU); 1: the library path (LayerNorm
+                                 # kernel + GEMM + GELU + GEMM); the first-generation kernel mq_swin_mlp_fwd is gone (round 5)
     "SWIN_MLP2_FLAGS": -1,       # mq_swin_mlp2_fwd flags: -1 = per width (table GELU at C = 96 / 384, erf at 192; tail split on); else bit 1 = table
                                  # GELU, bit 0 = no tail split, bit 2 = everything through the tail kernel
     "SWIN_QKV_FUSED": 2,         # the Swin qkv projection inside the window attention (mq_window_attn_qkv_fwd): 1 = at C = 96 (0.372 -> 0.137 ms
@@ -762,33 +762,12 @@ SWIN_MLP_WIDTHS = (96, 192, 384)
 
 
 def swin_mlp_w2_perm(K, device=None):
-    """Index tensor of the k-slot permutation mq_swin_mlp_fwd expects for fc2.weight: w2p = w2[:, perm]."""
+    """Index tensor of the k-slot permutation of fc2.weight inside a 32-block (the order the GELU epilogue leaves the hidden units in the
+    MFMA accumulator): w2p = w2[:, perm]; swin_mlp2_pack applies it."""
     k = torch.arange(K, device=device)
     blk, slot = k >> 5, k & 31
     g, t = slot >> 3, slot & 7
     return blk * 32 + torch.where(t < 4, 4 * g + t, 16 + 4 * g + (t - 4))
-
-
-def swin_mlp(x, delta, ln_g, ln_b, eps, w1, b1, w2p, b2, next_ln=None):
-    """Fused Swin MLP half (mq_swin_mlp_fwd).  x [..., C] fp32 residual stream, delta (same shape, fp16) or None ->
-    out fp32 = x' + fc2(gelu(fc1(LN(x')))), x' = x + delta; next_ln = (gamma, beta, eps) -> also y = LN(out) fp16."""
-    lib = load_library()
-    _need_gpu(x, delta, ln_g, ln_b, w1, b1, w2p, b2)
-    C = x.shape[-1]
-    M = x.numel() // C
-    assert C in SWIN_MLP_WIDTHS and x.dtype == torch.float32 and x.is_contiguous()
-    assert delta is None or (delta.dtype == w1.dtype and delta.is_contiguous() and delta.shape == x.shape)
-    assert w1.shape == (4 * C, C) and w2p.shape == (C, 4 * C) and w1.is_contiguous() and w2p.is_contiguous()
-    assert w1.dtype == w2p.dtype == b1.dtype == b2.dtype == ln_g.dtype and w1.dtype in _H16
-    out = torch.empty_like(x)
-    y, ng, nb, ne = None, None, None, 0.0
-    if next_ln is not None:
-        ng, nb, ne = next_ln
-        y = torch.empty(x.shape, dtype=w1.dtype, device=x.device)
-    with _timed(f"swin_mlp_c{C}", M * C * (4 + 4 + (2 if delta is not None else 0) + (2 if y is not None else 0))):
-        _chk(_fn(lib, "mq_swin_mlp_fwd", w1)(_ptr(x), _ptr(delta), _ptr(ln_g), _ptr(ln_b), float(eps), _ptr(w1), _ptr(b1), _ptr(w2p), _ptr(b2),
-                                 _ptr(out), _ptr(ng), _ptr(nb), float(ne), _ptr(y), M, C, _stream()), "mq_swin_mlp_fwd")
-    return (out, y) if y is not None else out
 
 
 def swin_mlp2_pack(w1, w2):

@@ -520,24 +520,6 @@ def roi_align(feat, rois, output_size, spatial_scale, sampling_ratio, aligned=Tr
     return out.mean((-1, -2)) if reduce_mean else out
 
 
-def swin_mlp(x, delta, ln_g, ln_b, eps, w1, b1, w2p, b2, next_ln=None):
-    """Plain-torch statement of mq_swin_mlp_fwd (un-permutes the k-slots of w2p first)."""
-    from mq_det_amd.ops import swin_mlp_w2_perm
-    K = w2p.shape[1]
-    perm = swin_mlp_w2_perm(K)
-    w2 = torch.empty_like(w2p)
-    w2[:, perm] = w2p
-    act = ln_g.dtype
-    xp = x.float() + (delta.float() if delta is not None else 0.0)
-    h = F.layer_norm(xp, (x.shape[-1],), ln_g.float(), ln_b.float(), eps).to(act)
-    hid = F.gelu(F.linear(h.float(), w1.float(), b1.float())).to(act)
-    out = xp + F.linear(hid.float(), w2.float(), b2.float())
-    if next_ln is None:
-        return out
-    ng, nb, ne = next_ln
-    return out, F.layer_norm(out, (x.shape[-1],), ng.float(), nb.float(), ne).to(act)
-
-
 def swin_mlp2_unpack(w1f, w2f, C):
     """Inverse of ops.swin_mlp2_pack: fragment-major (w1f, w2f) -> (fc1.weight [4C, C], fc2.weight [C, 4C])."""
     from mq_det_amd.ops import swin_mlp_w2_perm
@@ -624,7 +606,7 @@ def dyconv_coef_group(items, attn_w, attn_b, groups, eps):
 # every emulated entry point, in one place: tests patch them into mq_det_amd.ops (or into a stand-in namespace) with these helpers
 NAMES = ("attention", "attention4", "attention_text", "bert_attention_qkv", "patch_embed", "window_attention", "window_attention_qkv", "gcp_sparse_attention", "gcp_gate_residual", "gcp_attention", "dcnv2_group", "align_scores", "align_fused",
          "dyconv_branch_coef", "dyconv_coef_group", "dyconv_epilogue_group", "dyconv_fuse", "dyrelu_", "dyrelu_coef", "dyrelu_apply_", "dyrelu_layer_norm", "add_upsample_nearest_", "conv3x3", "conv3x3_nchw32", "conv3x3_nchw32_group", "conv3x3_nchw32_group_supported", "dcnv2", "layer_norm", "clamp_gelu_clamp", "vlfuse_i2t",
-         "vlfuse_t2i", "box_decode", "ml_nms", "post_select", "post_select_supported", "post_sort", "post_finalize", "roi_align", "swin_mlp", "swin_mlp2", "patch_merge_ln", "ms_deform_attn", "ms_deform_attn_q", "image_key_mask")
+         "vlfuse_t2i", "box_decode", "ml_nms", "post_select", "post_select_supported", "post_sort", "post_finalize", "roi_align", "swin_mlp2", "patch_merge_ln", "ms_deform_attn", "ms_deform_attn_q", "image_key_mask")
 
 
 def patch_into(monkeypatch, ops_module):

@@ -1750,21 +1750,19 @@ def check_extract_query(dev):
 def check_swin_mlp(dev, variants=None):
     """The fused Swin MLP half (LN prologue + fc1 + exact GELU + fc2 + residual + fused next LayerNorm in one kernel) vs a plain fp32
     statement on the same fp16-rounded weights: every supported width, ragged token counts, with / without delta / next-LN.
-    variants: ("v1",) = mq_swin_mlp_fwd; ("v2", flags) = mq_swin_mlp2_fwd with flags (bit 1 table GELU, bit 0 no pass / tail split, bit 2
-    everything through the tail kernel); default: v1, v2 erf / table / tail-only / unsplit.  The two long cases cross the pass / tail
+    variants: ("v2", flags) = mq_swin_mlp2_fwd with flags (bit 1 table GELU, bit 0 no pass / tail split, bit 2 everything through the tail
+    kernel); default: erf / table / tail-only / unsplit.  The two long cases cross the pass / tail
     split on the device (C = 384: 33 600 tokens = 263 workgroups on 256 CUs; C = 192: 773 on 768 slots); 1030 / 777 / 562 tokens cross it on
     the emulator's 4-CU "chip" (tests/simt/include/hip/hip_runtime.h)."""
     from mq_det_amd import ops
     res = []
-    variants = variants or (("v1",), ("v2", 0), ("v2", 2), ("v2", 4), ("v2", 1))
-    if H16 == torch.float32:
-        variants = tuple(v for v in variants if v[0] != "v1")          # the superseded first kernel has no fp32-operand twin
+    variants = variants or (("v2", 0), ("v2", 2), ("v2", 4), ("v2", 1))
     for var in variants:
         g = torch.Generator().manual_seed(51)
         for C, M, use_delta, use_next in ((96, 1030, True, True), (96, 128, False, False), (192, 777, True, True), (384, 562, True, True),
                                           (384, 64, True, False), (96, 67200 * 2 + 5, True, True), (384, 33600, True, True),
                                           (192, 49452, True, True))[:5 if QUICK else 8]:
-            if M > 30000 and (var[0] == "v1" or var[1] & 4):
+            if M > 30000 and var[1] & 4:
                 continue
             x = torch.randn(M, C, generator=g) * 1.5
             delta = (torch.randn(M, C, generator=g) * 0.5).to(H16) if use_delta else None
@@ -1780,18 +1778,13 @@ def check_swin_mlp(dev, variants=None):
             ref = xp + F.linear(hid, w2.float(), b2.float())
             nln = (ng.to(dev), nb.to(dev), 1e-5) if use_next else None
             dl = None if delta is None else delta.to(dev)
-            if var[0] == "v1":
-                w2p = w2[:, ops.swin_mlp_w2_perm(4 * C)].contiguous()
-                r = ops.swin_mlp(x.to(dev), dl, lg.to(dev), lb.to(dev), 1e-5, w1.to(dev), b1.to(dev), w2p.to(dev), b2.to(dev), next_ln=nln)
-                tag = f"swin_mlp C={C} M={M} delta={use_delta}"
-            else:
-                w1f, w2f = ops.swin_mlp2_pack(w1, w2)
-                r = ops.swin_mlp2(x.to(dev), dl, lg.to(dev), lb.to(dev), 1e-5, w1f.to(dev), b1.to(dev), w2f.to(dev), b2.to(dev), next_ln=nln,
-                                  flags=var[1])
-                tag = (f"swin_mlp2[{'tail only' if var[1] & 4 else 'unsplit' if var[1] & 1 else 'split'},{'table' if var[1] & 2 else 'erf'}] "
-                       f"C={C} M={M} delta={use_delta}")
+            w1f, w2f = ops.swin_mlp2_pack(w1, w2)
+            r = ops.swin_mlp2(x.to(dev), dl, lg.to(dev), lb.to(dev), 1e-5, w1f.to(dev), b1.to(dev), w2f.to(dev), b2.to(dev), next_ln=nln,
+                              flags=var[1])
+            tag = (f"swin_mlp2[{'tail only' if var[1] & 4 else 'unsplit' if var[1] & 1 else 'split'},{'table' if var[1] & 2 else 'erf'}] "
+                   f"C={C} M={M} delta={use_delta}")
             out, y = r if use_next else (r, None)
-            if var[0] == "v2" and not (var[1] & 5) and use_next:
+            if not (var[1] & 5) and use_next:
                 # the two parts as two calls (flags bit 3 = main blocks only, bit 4 = tail blocks only; on the device they run on two
                 # streams side by side): together bit for bit the single call
                 a = ops.swin_mlp2(x.to(dev), dl, lg.to(dev), lb.to(dev), 1e-5, w1f.to(dev), b1.to(dev), w2f.to(dev), b2.to(dev), next_ln=nln,

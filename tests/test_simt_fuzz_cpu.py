@@ -416,12 +416,13 @@ def test_swin_mlp_roi_align_and_msdeform_random_shapes(ops):
         lg, lb = (torch.randn(C, generator=g) * 0.1 + 1).half(), (torch.randn(C, generator=g) * 0.1).half()
         w1, b1 = (torch.randn(4 * C, C, generator=g) / math.sqrt(C)).half(), (torch.randn(4 * C, generator=g) * 0.1).half()
         w2, b2 = (torch.randn(C, 4 * C, generator=g) / math.sqrt(4 * C)).half(), (torch.randn(C, generator=g) * 0.1).half()
-        w2p = w2[:, ops.swin_mlp_w2_perm(4 * C)].contiguous()
+        w1f, w2f = ops.swin_mlp2_pack(w1, w2)
         nxt = ((torch.randn(C, generator=g) * 0.1 + 1).half(), (torch.randn(C, generator=g) * 0.1).half(), 1e-5) if rng.random() < 0.6 else None
-        got, ref = ops.swin_mlp(x, delta, lg, lb, 1e-5, w1, b1, w2p, b2, next_ln=nxt), emu.swin_mlp(x, delta, lg, lb, 1e-5, w1, b1, w2p, b2, next_ln=nxt)
+        flags = rng.choice((0, 1, 2, 4))
+        got, ref = ops.swin_mlp2(x, delta, lg, lb, 1e-5, w1f, b1, w2f, b2, next_ln=nxt, flags=flags), emu.swin_mlp2(x, delta, lg, lb, 1e-5, w1f, b1, w2f, b2, next_ln=nxt)
         got, ref = (got if isinstance(got, tuple) else (got,)), (ref if isinstance(ref, tuple) else (ref,))
         for i, (a, b) in enumerate(zip(got, ref)):
-            _close(a, b, f"swin_mlp draw {it} out {i}: C={C} M={M} delta={delta is not None} next={nxt is not None}", 2e-3 if i else 1e-3)
+            _close(a, b, f"swin_mlp2 draw {it} out {i}: C={C} M={M} flags={flags} delta={delta is not None} next={nxt is not None}", 2e-3 if i else 1e-3)
     for it in range(4 * N_DRAWS):
         N, C, H, W = rng.randint(1, 2), rng.choice((8, 64, 256)), rng.randint(1, 30), rng.randint(1, 40)
         feat = torch.randn(N, C, H, W, generator=g)

@@ -83,6 +83,9 @@ def main():
         out["language_rest_no_side_streams_ms"] = graph_time(lambda: pipeline.language_backbone(P, cfg, ids, am, vision, pooled, idx, front=front, max_kv=max_kv))
         out["pre_select_ms"] = graph_time(lambda: pipeline.pre_select(P, "language_backbone.body.model.pre_select", vision, pooled, cfg.VISION_QUERY.VISION_SCALE, side_ok=True))
         out["vldyhead_ms"] = graph_time(lambda: pipeline.vldyhead(P, cfg, feats, lang))
+        cfg.MODEL.DYHEAD.LEVEL_STREAMS = False              # the same head with the text chain and the level work serialised on ONE stream
+        out["vldyhead_single_stream_ms"] = graph_time(lambda: pipeline.vldyhead(P, cfg, feats, lang))
+        cfg.MODEL.DYHEAD.LEVEL_STREAMS = True
         out["postprocess_ms"] = graph_time(lambda: pipeline.postprocess(cfg, dict(head), anchors, im_wh, tokidx, label_ids))
         tail = (ids, am, vision, idx, tokidx, label_ids, im_wh, max_kv)
         out["full_program_ms"] = graph_time(lambda: model._full_program(imgs, *tail))
