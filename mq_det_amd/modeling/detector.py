@@ -310,7 +310,8 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
         P, cfg = self._plan, self.cfg
         lang = pipeline.language_backbone(P, cfg, input_ids, attention_mask, vision, pooled, idx,
                                           want_gates=cfg.VISION_QUERY.RETURN_ATTN_GATE_VALUE, front=front, max_kv=max_kv,
-                                          side_ok=bool(feats[0].is_cuda and cfg.MODEL.DYHEAD.get("LEVEL_STREAMS", True) and not want_raw))
+                                          side_ok=bool(_ops.KERNELS["LANG_SIDE_STREAMS"] == 1 and feats[0].is_cuda
+                                                       and cfg.MODEL.DYHEAD.get("LEVEL_STREAMS", True) and not want_raw))
         lang["max_kv"] = max_kv
         trace = [] if want_raw else None                          # raw mode: per-layer tensors, single-stream schedule
         head = pipeline.vldyhead(P, cfg, feats, lang, trace=trace)
