@@ -65,12 +65,19 @@ __device__ __forceinline__ void gf_rows_gemm(const half_t* At, const half_t* con
       }
     }
   };
+  // (scheduling fences: left alone the scheduler sinks a group's loads to just above their first use -- the ISA then waits with vmcnt(2) and a
+  // wave has two loads in flight instead of a group; fenced, the whole next group is requested before the current one is multiplied)
   load(w0, 0);
+  __builtin_amdgcn_sched_barrier(0);
   for (int grp = 0; grp < ngroups; grp += 2) {               // ngroups is even
     load(w1, grp + 1);
+    __builtin_amdgcn_sched_barrier(0);
     mma(w0, grp);
+    __builtin_amdgcn_sched_barrier(0);
     if (grp + 2 < ngroups) load(w0, grp + 2);
+    __builtin_amdgcn_sched_barrier(0);
     mma(w1, grp + 1);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -86,6 +93,15 @@ __global__ __launch_bounds__(GF_NT, 2) void gcp_attn_kernel(GcpAttnParams p) {
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long row0 = (long)blockIdx.x * RB;
+
+  // the vision-query slots of this wave's rows (step 2): requested first, so that their round trip hides under steps 0 / 1
+  int idr[RPW][8];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const long tok = min(row0 + wave * RPW + r, p.M - 1);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) idr[r][s] = s < p.S ? p.idx[tok * p.S + s] : -1;
+  }
 
   // ---- step 0: the block's fp32 rows -> registers (kept for step 6); LN_a -> Abuf.  Wave w owns rows w * RPW .. ; lane holds channels
   // 256 i + 4 lane .. + 3 (i = 0 .. 2): 16-byte loads / stores, a row is three 1 KB pieces.
@@ -152,8 +168,8 @@ __global__ __launch_bounds__(GF_NT, 2) void gcp_attn_kernel(GcpAttnParams p) {
   __syncthreads();
 
   // ---- step 2: sparse gather-attention, one row at a time per wave (lane = 8 consecutive channels = one eighth of a head), in place
-#pragma unroll 1
-  for (int r = 0; r < RPW; ++r) {
+#pragma unroll 2
+  for (int r = 0; r < RPW; ++r) {                              // (two rows' gathers in flight together)
     const int lr = wave * RPW + r;
     const long tok = min(row0 + lr, p.M - 1);
     const int b = (int)(tok / p.T);
@@ -168,7 +184,7 @@ __global__ __launch_bounds__(GF_NT, 2) void gcp_attn_kernel(GcpAttnParams p) {
     float mx = MQ_NEG_BIG;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      const int id = s < p.S ? p.idx[tok * p.S + s] : -1;
+      const int id = idr[r][s];
       sim[s] = MQ_NEG_BIG;
       vv[s] = zero8();
       if (id >= 0) {

@@ -393,7 +393,11 @@ __global__ __launch_bounds__(64 * NWT) void swin_mlp2_tail_kernel(SwinMlp2Params
   constexpr int HID = 4 * C, KS = C / 32, CT = C / 16, NCHUNK = HID / 32, FR = 512;
   constexpr int W1_FR = 2 * KS, W2_FR = CT, N = W1_FR + W2_FR;
   constexpr int CPW = NCHUNK / NWT, TPW = CT / NWT;           // hidden chunks per wave; channel tiles a wave finishes
-  constexpr int RDT = 8;
+  // Fragments in flight per wave.  Round 5: the ring only exists if the ISSUE ORDER is pinned -- left alone the scheduler sinks every ring load to
+  // just above its use (the ISA of rounds 3-4 waited with vmcnt(1 .. 3): two or three loads in flight, i.e. one HBM / L2 round trip per ~3 KB of
+  // a 300 KB stream per wave -- the 64 us of this kernel for a sliver of the tokens); with a scheduling fence behind every refill the waits
+  // are vmcnt(RDT).  12 = the deepest ring without a spill at C = 384 (256 VGPRs).
+  constexpr int RDT = sizeof(half_t) == 4 ? 6 : 12;
   static_assert(NCHUNK % NWT == 0 && CT % NWT == 0, "tail split");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NH = NWT / 2;                                 // destination waves per half phase
@@ -435,6 +439,7 @@ __global__ __launch_bounds__(64 * NWT) void swin_mlp2_tail_kernel(SwinMlp2Params
       constexpr int i = decltype(ic)::value, t = cc * N + i;
       h[i & 1] = mfma16(ring[t % RDT], xf[i >> 1], h[i & 1]);
       if constexpr (t + RDT < CPW * N) ring[t % RDT] = frag(t + RDT);
+      __builtin_amdgcn_sched_barrier(0);
     });
     half8 hf;
 #pragma unroll
@@ -443,6 +448,7 @@ __global__ __launch_bounds__(64 * NWT) void swin_mlp2_tail_kernel(SwinMlp2Params
       constexpr int ct = decltype(ic)::value, t = cc * N + W1_FR + ct;
       acc2[ct] = mfma16(ring[t % RDT], hf, acc2[ct]);
       if constexpr (t + RDT < CPW * N) ring[t % RDT] = frag(t + RDT);
+      __builtin_amdgcn_sched_barrier(0);
     });
   });
 
