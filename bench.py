@@ -423,6 +423,24 @@ def kernel_rooflines(kern, steps, Bn, n_tok, embed=96):
             fl += n * 4.0 * Bn * heads * nq * nk_eff * d
         out.append(_mfma("attn_text_kernel / attn_chunked_kernel (BERT self-attention 12 x 64, T = 256; GCP pre-select 8 x 32 over 5577 "
                          "image tokens)", fl, fl, sum(v[0] for _, v in att), sum(v[1] for _, v in att), "flops = 4 * B * heads * Nq * Nk_visited * D"))
+    # ---- round 5: the attention half of a BERT layer as one launch (bert_attn.hip): q | k | v projection + attention on the live text rows
+    ba = [(k, v) for k, v in per.items() if k.startswith("bert_attn_qkv_t")]
+    if ba:
+        fl = 0.0
+        for k, (n, ms, _) in ba:
+            T = int(k[len("bert_attn_qkv_t"):])
+            k16 = min(T, -(-n_tok // 16) * 16)
+            fl += n * (2.0 * Bn * T * 768 * 2304 + 4.0 * Bn * 12 * T * k16 * 64)
+        out.append(_mfma("bert_attn_qkv_kernel (BertSelfAttention in one launch: q | k | v projection + attention per (batch item, head); 18 launches per step)",
+                         fl, fl, sum(v[0] for _, v in ba), sum(v[1] for _, v in ba),
+                         "flops = 2 * B * T * 768 * 2304 (projection) + 4 * B * 12 * T * keys * 64 (QK^T, PV) per launch, T = live text rows"))
+    ga = [(k, v) for k, v in per.items() if k.startswith("gcp_attn_fused")]
+    if ga:
+        T = next((int(k[len("bert_attn_qkv_t"):]) for k, _ in ba), -(-n_tok // 16) * 16)
+        fl = sum(v[0] for _, v in ga) * 2.0 * Bn * T * (768 * 512 + 512 * 768 + 768 * 384)
+        out.append(_mfma("gcp_attn_kernel (GCP attention half in one launch: LayerNorm, to_q, sparse gather-attention, to_out, gate MLP, gated residual, "
+                         "next LayerNorm; latency-bound weight streaming at B = 8)", fl, fl, sum(v[0] for _, v in ga), sum(v[1] for _, v in ga),
+                         "flops = 2 * B * T * (768*512 + 512*768 + 768*384) per launch (the three projections; the <= 8-slot attention is negligible)"))
     # ---- fused Swin MLP (swin_mlp2.hip): 16 M C^2 per launch (fc1 + fc2), M = tokens of the stage
     mlp = [(k, v) for k, v in per.items() if k.startswith("swin_mlp_c")]
     if mlp:
@@ -564,6 +582,10 @@ def _sub_bench(argv, env=None, timeout=150, keep=()):
 # every operator with two implementations on the one that was the default at the end of ROUND 3 (ops.KERNEL_DEFAULTS lists today's), and the
 # runtime default of the hardware queues: what round 4's switchable changes buy (not switchable, so inside both runs: the VLFuse softmax diet)
 ROUND3_KERNEL_SET = {"MQ_POST_FUSED": "0", "MQ_BERT_QKV_FUSED": "0", "MQ_PATCH_EMBED_FUSED": "0", "MQ_OFFSET_CONV_VARIANT": "2", "GPU_MAX_HW_QUEUES": "4"}
+# ... and what ROUND 5's switchable changes buy: the text on all 256 padded positions, the BERT / GCP attention halves as the launches of round 4,
+# the FPN convs through the general DCNv2 instantiation, the DyConv epilogue per level on five streams (not switchable, so inside both runs: the
+# Swin MLP tail kernel with its loads in flight)
+ROUND4_KERNEL_SET = {"MQ_COMPACT_TEXT": "0", "MQ_BERT_ATTN_QKV_FUSED": "0", "MQ_GCP_ATTN_FUSED": "0", "MQ_DCN_PLAIN": "0", "MQ_DYCONV_EPILOGUE_GROUPED": "0"}
 
 
 def _free_port():
@@ -832,13 +854,14 @@ def main():
                     res["lang_path_b64"] = lang_path_b64(model, cfg, dev, chunks)
                 except Exception as e:  # noqa: BLE001
                     res["lang_path_b64"] = {"error": repr(e)[:300]}
-            if world == 1 and not args.no_experimental and not large and args.dtype == "f16" and not any(k in os.environ for k in ROUND3_KERNEL_SET if k.startswith("MQ_")):
+            if world == 1 and not args.no_experimental and not large and args.dtype == "f16" and not any(k in os.environ for k in tuple(ROUND3_KERNEL_SET) + tuple(ROUND4_KERNEL_SET) if k.startswith("MQ_")):
                 # bounded subprocess lines, most informative first; each only while the whole run stays within a few minutes
                 if time.perf_counter() - t_start < 120:
-                    res["kernel_set_ab"] = {"round3_kernel_set": _sub_bench(["--steps", "10", "--warmup", "3"], ROUND3_KERNEL_SET, 120),
-                                            "env_of_the_round3_set": ROUND3_KERNEL_SET,
-                                            "note": "A/B against `value` of this line: same box, same workload, the operators that got a second "
-                                                    "implementation in round 4 on their round-3 one + 4 hardware queues (per-switch A/Bs: profiles/r04_*_ab.txt)"}
+                    res["kernel_set_ab"] = {"round4_kernel_set": _sub_bench(["--steps", "10", "--warmup", "3"], ROUND4_KERNEL_SET, 120),
+                                            "env_of_the_round4_set": ROUND4_KERNEL_SET,
+                                            "note": "A/B against `value` of this line: same box, same workload, round 5's switchable changes off "
+                                                    "(live-row compaction of the text, fused BERT / GCP attention halves, PLAIN DCNv2 for the FPN convs, "
+                                                    "grouped DyConv epilogue; per-switch A/Bs: profiles/r05_call*_switch_ab.txt)"}
                 other = {}
                 for key, argv, limit in (("configs[3] mq-glip-l bf16 B=4", ["--workload", "mq-glip-l", "--dtype", "bf16", "--steps", "5", "--warmup", "2"], 160),
                                          ("configs[4] mq-gdino-t B=16", ["--workload", "mq-gdino-t", "--steps", "5", "--warmup", "2"], 200),

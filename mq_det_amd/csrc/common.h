@@ -60,9 +60,13 @@ __device__ __forceinline__ float4_ mfma16(half8 a, half8 b, float4_ c) {
 #if defined(MQ_F32)
   // v_mfma_f32_16x16x4_f32: lane l holds A[l & 15][k = l >> 4] and B[k = l >> 4][l & 15]; step j contracts the k values 8 g + j (g = l >> 4)
   // of the 16x16x32 fragments, so the eight steps together are the same 32-deep contraction with exact fp32 products
+#if defined(MQ_SIMT_EMULATION)
+  return simt_mfma_16x16x32_f32_8x4(a, b, c);       // tests/simt: the same eight steps in the same order, one lane exchange instead of eight
+#else
 #pragma unroll
   for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
   return c;
+#endif
 #elif defined(MQ_BF16)
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 #else

@@ -19,6 +19,7 @@
 // Weights are streamed per workgroup (2.1 MB from L2): RB = 16 rows for small batches (72 workgroups at B = 8: the chip is latency-bound
 // there anyway), RB = 32 for large ones (half the weight traffic per row).
 #include "common.h"
+#include <type_traits>
 
 MQ_NAMESPACE_BEGIN
 
@@ -43,47 +44,55 @@ struct GcpAttnParams {
   float eps, scale;
 };
 
-// acc[mb][j] += A(rows of this block, K) . W(rows = this wave's 16 j-th output columns, K)^T over ngroups x G k-steps of 32.
-// At: LDS, lane's fragment base (row l15, k offset 8 lg); wrow[j]: global, lane's weight row + 8 lg.  Weight fragments in two register sets.
-template <int NTL, int MB, int G>
-__device__ __forceinline__ void gf_rows_gemm(const half_t* At, const half_t* const (&wrow)[NTL], int ngroups, float4_ (&acc)[MB][NTL]) {
-  half8 w0[G][NTL], w1[G][NTL];
-  auto load = [&](half8 (&w)[G][NTL], int grp) __attribute__((always_inline)) {
+template <int I, int N, class F>
+__device__ __forceinline__ void gf_static_for_impl(F& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    gf_static_for_impl<I + 1, N>(f);
+  }
+}
+template <int N, class F>
+__device__ __forceinline__ void gf_static_for(F f) { gf_static_for_impl<0, N>(f); }
+
+// acc[mb][j] += A(rows of this block, K) . W(rows = this wave's 16 j-th output columns, K)^T over NG groups of G k-steps of 32 (K = 32 G NG).
+// At: LDS, lane's fragment base (row l15, k offset 8 lg); wrow[j]: global, lane's weight row + 8 lg.  The weight fragments of a wave are read
+// by nobody else: global (L2) -> registers, NSETS register sets, the groups g + 1 .. g + NSETS - 1 requested while group g is multiplied.  The
+// loop is unrolled completely and every load group sits behind a scheduling fence: left alone the scheduler sinks the loads to just above their
+// first use (the ISA then waits with vmcnt(2): two loads in flight per wave, one L2 / fabric round trip per 2 KB of a 264 KB stream).
+template <int NTL, int MB, int G, int NG, int NSETS>
+__device__ __forceinline__ void gf_rows_gemm(const half_t* At, const half_t* const (&wrow)[NTL], float4_ (&acc)[MB][NTL]) {
+  half8 w[NSETS][G][NTL];
+  auto load = [&](half8 (&ws)[G][NTL], int grp) __attribute__((always_inline)) {
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
-      for (int j = 0; j < NTL; ++j) w[g][j] = *(const half8*)(wrow[j] + (grp * G + g) * 32);
+      for (int j = 0; j < NTL; ++j) ws[g][j] = *(const half8*)(wrow[j] + (grp * G + g) * 32);
+    __builtin_amdgcn_sched_barrier(0);
   };
-  auto mma = [&](const half8 (&w)[G][NTL], int grp) __attribute__((always_inline)) {
+  gf_static_for<NSETS - 1>([&](auto sc) __attribute__((always_inline)) {
+    constexpr int s = decltype(sc)::value;
+    if constexpr (s < NG) load(w[s], s);
+  });
+  gf_static_for<NG>([&](auto gc) __attribute__((always_inline)) {
+    constexpr int grp = decltype(gc)::value;
+    if constexpr (grp + NSETS - 1 < NG) load(w[(grp + NSETS - 1) % NSETS], grp + NSETS - 1);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
         const half8 af = *(const half8*)(At + mb * 16 * GF_P + (grp * G + g) * 32);
 #pragma unroll
-        for (int j = 0; j < NTL; ++j) acc[mb][j] = mfma16(af, w[g][j], acc[mb][j]);
+        for (int j = 0; j < NTL; ++j) acc[mb][j] = mfma16(af, w[grp % NSETS][g][j], acc[mb][j]);
       }
     }
-  };
-  // (scheduling fences: left alone the scheduler sinks a group's loads to just above their first use -- the ISA then waits with vmcnt(2) and a
-  // wave has two loads in flight instead of a group; fenced, the whole next group is requested before the current one is multiplied)
-  load(w0, 0);
-  __builtin_amdgcn_sched_barrier(0);
-  for (int grp = 0; grp < ngroups; grp += 2) {               // ngroups is even
-    load(w1, grp + 1);
     __builtin_amdgcn_sched_barrier(0);
-    mma(w0, grp);
-    __builtin_amdgcn_sched_barrier(0);
-    if (grp + 2 < ngroups) load(w0, grp + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(w1, grp + 1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  });
 }
 
 template <int MB>
 __global__ __launch_bounds__(GF_NT, 2) void gcp_attn_kernel(GcpAttnParams p) {
   constexpr int C = GF_C, HD = GF_HD, P = GF_P, RB = 16 * MB, RPW = RB / GF_NW;      // rows per wave in the row-wise steps (2 or 4)
+  constexpr int NSETS = MB == 1 ? 3 : 2;         // weight-fragment register sets of the GEMM steps (MB = 2: a third set spills)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* Abuf = (half_t*)smem;                  // [RB][P]: LN_a(x), later sup
   half_t* Bbuf = Abuf + RB * P;                  // [RB][P]: q -> att (first HD columns), later LN_g(sup)
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(GF_NT, 2) void gcp_attn_kernel(GcpAttnParams p) {
     const half_t* wrow[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) wrow[j] = p.wq + (long)(64 * wave + 16 * j + l15) * C + lg * 8;
-    gf_rows_gemm<4, MB, 3>(At, wrow, C / 32 / 3, acc);
+    gf_rows_gemm<4, MB, 3, C / 32 / 3, NSETS>(At, wrow, acc);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -238,7 +247,7 @@ __global__ __launch_bounds__(GF_NT, 2) void gcp_attn_kernel(GcpAttnParams p) {
     const half_t* wrow[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) wrow[j] = p.wout + (long)(96 * wave + 16 * j + l15) * HD + lg * 8;
-    gf_rows_gemm<6, MB, 2>(Bt, wrow, HD / 32 / 2, acc);
+    gf_rows_gemm<6, MB, 2, HD / 32 / 2, NSETS>(Bt, wrow, acc);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(GF_NT, 2) void gcp_attn_kernel(GcpAttnParams p) {
     const half_t* wrow[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) wrow[j] = p.wg1 + (long)(48 * wave + 16 * j + l15) * C + lg * 8;
-    gf_rows_gemm<3, MB, 4>(Bt, wrow, C / 32 / 4, acc);
+    gf_rows_gemm<3, MB, 4, C / 32 / 4, NSETS>(Bt, wrow, acc);
     float w2v[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) w2v[j] = (float)p.w2[48 * wave + 16 * j + l15];

@@ -253,6 +253,42 @@ inline simt_float4 simt_mfma_16x16x4_f32(float a, float b, simt_float4 c) {
   return c;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) simt_mfma_16x16x4_f32((a), (b), (c))
+// mfma16 of the fp32-operand build (csrc/common.h): eight 16x16x4 steps, step j contracting the k values 8 g + j (g = 0 .. 3) -- here as ONE lane
+// exchange (eight cost 8 x the fiber switches: the fp32 tests took 9 minutes), products and additions in the order of the eight device steps
+#define MQ_SIMT_EMULATION 1
+inline void simt_mfma_8x4_tile(void* ctx) {
+  const int buf = (int)(intptr_t)ctx;
+  float* AB = simt::wave_tile32();                   // A [16][32] then B [32][16]
+  for (int l = 0; l < 64; ++l) {
+    float a[8], b[8];
+    const uint64_t* s = simt::xslot(l, buf);
+    memcpy(a, s, 32);
+    memcpy(b, s + 4, 32);
+    for (int j = 0; j < 8; ++j) {
+      AB[(l & 15) * 32 + 8 * (l >> 4) + j] = a[j];
+      AB[512 + (8 * (l >> 4) + j) * 16 + (l & 15)] = b[j];
+    }
+  }
+}
+template <class V8>
+inline simt_float4 simt_mfma_16x16x32_f32_8x4(V8 a, V8 b, simt_float4 c) {
+  static_assert(sizeof(V8) == 32, "fp32-operand fragments");
+  const int buf = simt::next_buf(), l = simt::lane();
+  uint64_t* s = simt::xslot(l, buf);
+  memcpy(s, &a, 32);
+  memcpy(s + 4, &b, 32);
+  simt::wave_sync_then(&simt_mfma_8x4_tile, (void*)(intptr_t)buf);
+  const float* A = simt::wave_tile32();
+  const float* B = A + 512;
+  const int col = l & 15, r0 = 4 * (l >> 4);
+  for (int j = 0; j < 8; ++j)                        // step j = one v_mfma_f32_16x16x4_f32: its four products as a group, then into the accumulator
+    for (int r = 0; r < 4; ++r) {
+      float acc = 0.f;
+      for (int g = 0; g < 4; ++g) acc += A[(r0 + r) * 32 + 8 * g + j] * B[(8 * g + j) * 16 + col];
+      c[r] += acc;
+    }
+  return c;                                          // (the buffer is refilled by the NEXT exchange's tile function, which runs once every lane has arrived there)
+}
 inline int __lane_id() { return simt::lane(); }
 
 // ds_read_b64_tr_b16: inside each 16-lane group the 16 x 4 block of 16-bit elements addressed by the lanes (lane i: row i >> 2,

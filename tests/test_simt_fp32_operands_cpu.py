@@ -43,6 +43,7 @@ def f32(request):
     pc.QUICK, pc.PINS = True, False
     pc.use_dtype(torch.float32)
     pc._CACHE.clear()
+    pc._f32_mode = request.param
     with simt.installed(f32=request.param):
         yield pc
     pc.use_dtype(torch.float16)
@@ -69,10 +70,16 @@ def test_tiny_full_model_meets_1e_3_with_fp32_operands(f32):
 @pytest.mark.parametrize("name", ["check_swin_fpn", "check_window_attention", "check_gcp_block", "check_pre_select", "check_vl_fuse", "check_dyconv",
                                   "check_align_fused", "check_bert_attn_qkv", "check_attention_text", "check_gcp_attn_fused"])
 def test_blocks_meet_1e_3_with_fp32_operands(f32, name):
+    # "every_kernel" only where the 16-bit modes launch something else than the device's precise mode does (the fused Swin MLP main kernel at
+    # C = 384, the grouped offset conv, the double-buffered DCNv2, the VLFuse variants): the other kernels are the same launch in both modes
+    if f32._f32_mode == 2 and name not in ("check_swin_fpn", "check_dyconv", "check_vl_fuse"):
+        pytest.skip("same launch as under device_limits")
     _assert_ok(getattr(f32, name)(CPU))
 
 
 def test_bert_layers_meet_1e_3_with_fp32_operands(f32):
+    if f32._f32_mode == 2:
+        pytest.skip("same launches as under device_limits")
     _assert_ok([f32.check_bert_layer(CPU, False), f32.check_bert_layer(CPU, True)])
 
 

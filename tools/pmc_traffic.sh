@@ -13,6 +13,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o b -- \
     python ${GRAFT_REPO_ROOT:-$OLDPWD}/bench.py --steps 1 --warmup 2 --no-extras --no-graph > $OUT/$c.log 2>&1
   f=$(find $OUT/$c -name "*counter_collection.csv" | head -1)
-  head -1 $f > $OUT/$c.csv; grep -E "vlfuse_|dcn_igemm8|swin_mlp|dyconv_fuse|layernorm|dyrelu_ln|window_attn|align_fused|conv3x3_|attn_resident|attn_text|attn_chunked|gcp_|patch_embed|post_" $f >> $OUT/$c.csv      # keep only the rows we reduce
+  head -1 $f > $OUT/$c.csv; grep -E "vlfuse_|dcn_igemm8|swin_mlp|dyconv_fuse|layernorm|dyrelu_ln|window_attn|align_fused|conv3x3_|attn_resident|attn_text|attn_chunked|bert_attn|gcp_|patch_embed|post_" $f >> $OUT/$c.csv      # keep only the rows we reduce
   rm -rf $OUT/$c
 done
