@@ -35,7 +35,8 @@ ELEM_FRAC_16 = 1e-5  # 16-bit operands, per-kernel rows: at most this fraction o
 # build of the same kernels has ZERO violations in every row (the gate of the precise mode), so this is operand rounding, not logic.
 ELEM_FRAC_P16 = 1e-3
 _P16_ROWS = ("attn", "window_attn", "vlfuse", "gcp sparse", "gcp pre", "... vs GEMM + mq_window_attn_fwd")
-ELEM_FRAC_DEEP_F32 = 5e-3   # fp32 operands, deep-stack rows: fraction of elements that may lie outside atol + rtol |ref| (per-kernel rows: none)
+ELEM_FRAC_DEEP_F32 = 1e-4   # fp32 operands, deep-stack rows: fraction of elements that may lie outside atol + rtol |ref| (per-kernel rows: none).
+                            # Measured in the final GPU suite of round 5 (profiles/r05_final_gpu_suite_ladder.jsonl): ZERO in all 413 fp32-operand rows
 F32_TOL = 1e-3       # the north-star tolerance: met by every stage once the operands are not rounded (tests/test_simt_fp32_operands_cpu.py)
 
 
@@ -101,10 +102,10 @@ def _stat(name, got, ref, tol=TOL, elem_gate=None):
     # rounding of values that cancel; deep-stack rows (whole models / layers, 16-bit storage between kernels) carry the column ungated.
     deep = any(t_ in name for t_ in _DEEP_ROWS)
     if H16 == torch.float32:
-        # per-kernel rows: none.  Deep rows (whole models / fusion layers): the first GPU call of round 5 measured ZERO violations in 48 of the 49
-        # stage rows of the full-depth benchmark configuration and 2.9e-3 of the elements of ONE (the 77 x 141 alignment logits of P7: max
-        # |err| 1.96e-3 on values up to 11.5, i.e. 1.7e-4 of the range) -- fp32 summation order through 12 + 6 layers of a randomly initialised
-        # network (the oracle's own fp32-vs-fp64 difference is amplified the same way), not a kernel's logic: stated bound
+        # per-kernel rows: none.  Deep rows (whole models / fusion layers): a stated bound of 1e-4 of the elements against box-to-box variance of
+        # the fp32 summation order through 12 + 6 layers (the first device run of round 5, still with the hardware exp / rcp approximations in the
+        # softmaxes, had 2.9e-3 of the P7 alignment logits outside -- max |err| 1.96e-3 on values up to 11.5; with library exp / IEEE division
+        # the final suite has none in any row, worst stage 9.3e-5 of the range)
         e_ok = viol == 0.0 if not deep else viol <= ELEM_FRAC_DEEP_F32
     else:
         frac = ELEM_FRAC_P16 if any(name.startswith(t_) or name.startswith("[bf16] " + t_) for t_ in _P16_ROWS) else ELEM_FRAC_16
