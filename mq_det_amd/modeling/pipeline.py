@@ -410,7 +410,7 @@ def bert_layer(P, b, x, key_bias, clamp, kv_len=None, x32=None, qk_mask=None, ma
     Returns y16 (and y32 when x32 is given)."""
     Bn, T, C = x.shape
     r32 = x32 is not None
-    if ops.KERNELS["BERT_ATTN_QKV_FUSED"] == 1 and qk_mask is None and (b + ".qkv.weight") in P and ops.bert_attention_qkv_fits(T, C, 12, key_bias):
+    if ops.KERNELS["BERT_ATTN_QKV_FUSED"] >= 1 and qk_mask is None and (b + ".qkv.weight") in P and ops.bert_attention_qkv_fits(T, C, 12, key_bias, batch=Bn):
         # projection + attention of every (batch item, head) in one launch: no qkv tensor (mq_bert_attn_qkv_fwd)
         ctx = ops.bert_attention_qkv(x, P[b + ".qkv.weight"], P[b + ".qkv.bias"], 12, key_bias=key_bias, clamp=50000.0 if clamp else 0.0, kv_len=kv_len)
     elif ops.KERNELS["BERT_QKV_FUSED"] == 1 and qk_mask is None and ops.attention_text_fits(T, kv_len, max_kv) and (b + ".qkv.weight") in P \
@@ -498,7 +498,7 @@ def gcp_block(P, b, x, vision, idx, gates=None, kv=None):
     if kv is None:
         kv = gcp_kv(P, b, vision)
     ff = b + ".ff"
-    if ops.KERNELS["GCP_ATTN_FUSED"] == 1 and ops.gcp_attention_fits(x, idx):
+    if ops.KERNELS["GCP_ATTN_FUSED"] >= 1 and ops.gcp_attention_fits(x, idx, policy=True):
         # LayerNorm, to_q, sparse attention, to_out, gate MLP, gated residual and the feed-forward half's LayerNorm: one launch (mq_gcp_attn_fwd)
         def ln(n):
             return (P[n + ".weight"], P[n + ".bias"])

@@ -125,10 +125,13 @@ KERNEL_DEFAULTS = {
                                  # Measured (round 5, GPU calls 5 / 6): the chain itself is no shorter (1.71 vs 1.68 ms as its own graph) and the WHOLE step
                                  # went from 17.3 to 21 ms -- two more streams than hardware queues (GPU_MAX_HW_QUEUES = 8), branches of the captured
                                  # forward then share queues and serialise.  Off.
-    "GCP_ATTN_FUSED": 1,         # 1: mq_gcp_attn_fwd -- the attention half of a GCP block (LayerNorm, to_q, sparse attention, to_out, gate MLP, gated residual,
-                                 # next LayerNorm) in one launch; 0: the eight launches of rounds 2-4
-    "BERT_ATTN_QKV_FUSED": 1,    # 1: mq_bert_attn_qkv_fwd -- the q | k | v projection inside the attention launch (one workgroup per (batch item, head); the
-                                 # qkv tensor is never written); 0: one qkv GEMM + mq_attn_text_fwd (round 4)
+    "GCP_ATTN_FUSED": 1,         # mq_gcp_attn_fwd -- the attention half of a GCP block (LayerNorm, to_q, sparse attention, to_out, gate MLP, gated residual,
+                                 # next LayerNorm) in one launch.  1: where it is measured not to lose -- up to FUSED_TEXT_MAX_ROWS text rows per launch (every
+                                 # workgroup streams all 2.1 MB of weights: 73 us against 128 us eager / ~56 us in a graph at B = 8, but 174 against 127 us at
+                                 # B = 64); 2: always; 0: the eight launches of rounds 2-4
+    "BERT_ATTN_QKV_FUSED": 1,    # mq_bert_attn_qkv_fwd -- the q | k | v projection inside the attention launch (one workgroup per (batch item, head); the qkv
+                                 # tensor is never written).  1: up to two workgroups per CU (B x heads <= 2 x CUs: 26 us against 39 us for the library GEMM +
+                                 # mq_attn_text_fwd at B = 8; at B = 64 three rounds of workgroups take 82 us against 69); 2: always; 0: never (round 4's pair)
     "POST_FUSED": 1,             # 1: ATSS post-processing as mq_post_select_fwd + mq_post_sort_fwd + mq_ml_nms_topk + mq_post_finalize_fwd (4 launches);
                                  # 0: the round-1..3 chain (5 x torch.topk + box_decode, argsort, gathers, NMS, topk: ~145 launches, 1.1 ms)
     "F32_OPERANDS": 0,           # the PRECISE mode (MODEL.COMPUTE_DTYPE = "float32"; set by configure() from the config, or MQ_F32_OPERANDS): every kernel's
@@ -347,11 +350,18 @@ def attention_text_fits(T, kv_len=None, max_kv=0):
     return T <= 256 and (f32_operands() != 1 or live <= 160)
 
 
-def bert_attention_qkv_fits(T, C, heads, key_bias=None):
-    """Shapes mq_bert_attn_qkv_fwd takes: BERT-base heads of 64, up to 256 tokens (precise mode on the device: up to 160 -- the three
-    [T, 80] tiles of a head are 154 KB at fp32), one key bias per (batch item, key)."""
-    return (C == 64 * heads and C % 128 == 0 and T <= (160 if f32_operands() == 1 else 256)
-            and (key_bias is None or key_bias.dim() == 2))
+FUSED_TEXT_MAX_ROWS = 4608          # text rows (B x T) up to which KERNELS["GCP_ATTN_FUSED"] = 1 takes the fused GCP kernel (B = 32 at 144 rows)
+FUSED_BERT_MAX_WORKGROUPS = 512     # (batch item, head) workgroups up to which KERNELS["BERT_ATTN_QKV_FUSED"] = 1 takes the fused BERT kernel (2 per CU)
+
+
+def bert_attention_qkv_fits(T, C, heads, key_bias=None, batch=None):
+    """Shapes mq_bert_attn_qkv_fwd takes: BERT-base (C = 768 = 12 x 64), up to 256 tokens (precise mode on the device: up to 160 -- the three
+    [T, 80] tiles of a head are 154 KB at fp32), one key bias per (batch item, key).  batch: also apply the size policy of
+    KERNELS["BERT_ATTN_QKV_FUSED"] = 1 (the kernel only where it is measured to win; the precise mode takes it at any batch)."""
+    ok = (C == 768 and C == 64 * heads and T <= (160 if f32_operands() == 1 else 256) and (key_bias is None or key_bias.dim() == 2))
+    if ok and batch is not None and KERNELS["BERT_ATTN_QKV_FUSED"] == 1 and not f32_operands():
+        ok = batch * heads <= FUSED_BERT_MAX_WORKGROUPS
+    return ok
 
 
 def bert_attention_qkv(x, wqkv, bqkv, heads, key_bias=None, clamp=0.0, kv_len=None, scale=None):
@@ -572,9 +582,13 @@ def gcp_sparse_attention(q, kv, idx, heads=8, dim_head=64):
     return out
 
 
-def gcp_attention_fits(x, idx):
-    """Shapes mq_gcp_attn_fwd takes: the fp32 text stream of BERT-base width, at most 8 vision-query slots per token."""
-    return x.dtype == torch.float32 and x.shape[-1] == 768 and idx.shape[-1] <= 8
+def gcp_attention_fits(x, idx, policy=False):
+    """Shapes mq_gcp_attn_fwd takes: the fp32 text stream of BERT-base width, at most 8 vision-query slots per token.  policy: also apply the
+    size rule of KERNELS["GCP_ATTN_FUSED"] = 1 (up to FUSED_TEXT_MAX_ROWS text rows per launch)."""
+    ok = x.dtype == torch.float32 and x.shape[-1] == 768 and idx.shape[-1] <= 8
+    if ok and policy and KERNELS["GCP_ATTN_FUSED"] == 1 and not f32_operands():
+        ok = x.numel() // 768 <= FUSED_TEXT_MAX_ROWS
+    return ok
 
 
 def gcp_attention(x, kv, idx, wq, wout, wg1, w2, ln_a, ln_g, ln_f=None, eps=1e-5, want_gate=False, rows_per_block=0):
