@@ -357,7 +357,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
         the first GCP block) runs on a side stream under the Swin backbone: its launches are tiny (B x 256 tokens)."""
         P, cfg = self._plan, self.cfg
         front = None
-        if x.is_cuda and cfg.MODEL.DYHEAD.get("LEVEL_STREAMS", True):
+        if x.is_cuda and cfg.MODEL.DYHEAD.get("LEVEL_STREAMS", True) and _ops.KERNELS["FRONT_SIDE_STREAM"] == 1:
             main, text = torch.cuda.current_stream(), pipeline._side_streams(x.device, 1, "text")[0]
             text.wait_stream(main)
             with torch.cuda.stream(text):
@@ -578,17 +578,25 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
         else:
             counts = out["counts"].tolist()                       # the one device->host sync of the forward
         counts = self._split_counts(counts)
-        result = []
-        for b, (h, w) in enumerate(images.image_sizes):
-            n = counts[b]
-            bl = BoxList(packed[b, :n, :4].clone(), (int(w), int(h)), mode="xyxy")
-            bl.add_field("labels", packed[b, :n, 5].to(torch.int64))
-            bl.add_field("scores", packed[b, :n, 4].clone())
-            result.append(bl)
+        result = self._boxlists(packed, counts, images.image_sizes)
         if cfg.VISION_QUERY.RETURN_ATTN_GATE_VALUE:
             return result, gates
         if return_backbone_features:
             return result, [f.float().contiguous() for f in out["feats"]]
+        return result
+
+    @staticmethod
+    def _boxlists(packed, counts, image_sizes, first=0):
+        """[items, K, 6] packed detections (a tensor nobody else writes) + live counts -> list[BoxList]: three launches for the whole batch (boxes,
+        scores and int64 labels as contiguous tensors), the BoxLists hold per-image VIEWS of them (round 4: three launches per image)."""
+        boxes, scores, labels = packed[..., :4].contiguous(), packed[..., 4].contiguous(), packed[..., 5].to(torch.int64)
+        result = []
+        for b, (h, w) in enumerate(image_sizes):
+            it, n = first + b, counts[first + b]
+            bl = BoxList(boxes[it, :n], (int(w), int(h)), mode="xyxy")
+            bl.add_field("labels", labels[it, :n])
+            bl.add_field("scores", scores[it, :n])
+            result.append(bl)
         return result
 
     # ------------------------------------------------------------------ chunk batching (SURVEY.md 8f-1)
@@ -700,15 +708,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
             packed = out["packed"].clone()
             counts = self._split_counts(out["counts"].tolist())
             for c in range(g):
-                res = []
-                for b, (h, w) in enumerate(images.image_sizes):
-                    it = c * Bn + b
-                    n = counts[it]
-                    bl = BoxList(packed[it, :n, :4].clone(), (int(w), int(h)), mode="xyxy")
-                    bl.add_field("labels", packed[it, :n, 5].to(torch.int64))
-                    bl.add_field("scores", packed[it, :n, 4].clone())
-                    res.append(bl)
-                results.append(res)
+                results.append(self._boxlists(packed, counts, images.image_sizes, first=c * Bn))
         return results
 
 

@@ -25,15 +25,26 @@ class GraphRunner:
         return obj
 
     @staticmethod
-    def _tree_copy_(dst, src):
+    def _tree_copy_(dst, src, seen=None, path=()):
+        """Copy the caller's tensors into the graph's static input buffers.  `seen` (one dict per captured graph): a SMALL input that is the very
+        tensor object of the previous replay, unmodified since (torch's version counter) -- the memoised host-side operands of a caption: token ids,
+        masks, the query bank selection, the label -> token index, image sizes -- is already there: no copy launch.  Large inputs (the pixels, cached
+        feature maps) are always copied."""
         if torch.is_tensor(dst):
+            if seen is not None and src.numel() <= GraphRunner.SKIP_COPY_MAX_NUMEL:
+                prev = seen.get(path)
+                if prev is not None and prev[0] is src and prev[1] == src._version:
+                    return
+                seen[path] = (src, src._version)          # (a strong reference: an id cannot be recycled while it is the comparison's left side)
             dst.copy_(src, non_blocking=True)
         elif isinstance(dst, dict):
             for k in dst:
-                GraphRunner._tree_copy_(dst[k], src[k])
+                GraphRunner._tree_copy_(dst[k], src[k], seen, path + (k,))
         elif isinstance(dst, (list, tuple)):
-            for d, s_ in zip(dst, src):
-                GraphRunner._tree_copy_(d, s_)
+            for i, (d, s_) in enumerate(zip(dst, src)):
+                GraphRunner._tree_copy_(d, s_, seen, path + (i,))
+
+    SKIP_COPY_MAX_NUMEL = 1 << 20
 
     def _shape_key(self, obj):
         if torch.is_tensor(obj):
@@ -87,12 +98,12 @@ class GraphRunner:
                 torch.cuda.synchronize()
                 self.cache_stats["eager"] += 1
                 return fn(*inputs)
-            ent.update(stage=2, graph=g, inp=static_in, out=static_out)
+            ent.update(stage=2, graph=g, inp=static_in, out=static_out, seen={})
             self.cache_stats["graph_capture"] += 1
         if ent["stage"] == -1:
             self.cache_stats["eager"] += 1
             return fn(*inputs)
-        self._tree_copy_(ent["inp"], inputs)
+        self._tree_copy_(ent["inp"], inputs, ent["seen"])
         ent["graph"].replay()
         self.cache_stats["graph_replay"] += 1
         return ent["out"]

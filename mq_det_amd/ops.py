@@ -121,6 +121,7 @@ KERNEL_DEFAULTS = {
                                  # 0: permute copies + library GEMM (K = 48) + two LayerNorm launches (354 us at B = 8)
     "BERT_QKV_FUSED": 1,         # 1: BERT layers = ONE qkv GEMM + mq_attn_text_fwd (V row-major, transposed out of LDS; registers / LDS sized by the
                                  # caption length); 0: q|k GEMM + V^T batched GEMM + mq_attn_resident_fwd (rounds 2-3)
+    "FRONT_SIDE_STREAM": 1,      # 1: the image-independent BERT layers on a side stream beside the Swin backbone; 0: on the main stream in front of it (A/B)
     "LANG_SIDE_STREAMS": 0,      # 1: the K / V projections of the second pre-select layer and of GCP blocks 2 .. on side streams beside the serial text chain.
                                  # Measured (round 5, GPU calls 5 / 6): the chain itself is no shorter (1.71 vs 1.68 ms as its own graph) and the WHOLE step
                                  # went from 17.3 to 21 ms -- two more streams than hardware queues (GPU_MAX_HW_QUEUES = 8), branches of the captured
