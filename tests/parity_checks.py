@@ -1595,6 +1595,10 @@ def check_benchmark_b8_graph(dev, B=8):
     images = torch.zeros(B, *images1.shape[1:])
     images[0] = images1[0]
     images[1:, :, :800, :1333] = torch.randn(B - 1, 3, 800, 1333, generator=g).to(H16).float()
+    # items 3 and B - 1 are compared with B = 1 forwards of the same image (batch invariance): pure noise yields ~3 detections there (VERDICT r4
+    # weak #3) -- give them the structured image of item 0 mirrored / upside down instead (hundreds of detections, other pixels than item 0)
+    images[3, :, :800, :1333] = torch.flip(images1[0, :, :800, :1333], dims=[-1])
+    images[B - 1, :, :800, :1333] = torch.flip(images1[0, :, :800, :1333], dims=[-2])
     sizes = [sizes1[0]] * B
     ids8, am8 = ids.expand(B, -1).contiguous(), am.expand(B, -1).contiguous()
     okey = ("bench_oracle", "t", "long", tuple(hw))
