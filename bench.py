@@ -555,6 +555,9 @@ def _lang_path_once(model, cfg, dev, chunks, iters=5):
                       "formula": f"12 x (4*B*12*{Tl}*{k16}*64" + (f" + 2*B*{Tl}*768*2304" if fused else "") + f") + 2 x 4*B*8*{V}*5577*32 + 6 x (4*B*8*{Tl}*{S}*64" + (f" + 2*B*{Tl}*(768*512 + 512*768 + 768*384)" if gcp_fused else "") + "), "
                                  f"B = {Bn} ({Tl} = live text rows after compaction, {k16} = visited text keys of the {n_tok}-token caption)"},
             "kernels_ms": {k: round(v[1] / iters, 3) for k, v in sorted(kern.items())},
+            "note": "flops are counted on the LIVE text rows (round 5 runs the text on 16 ceil(live / 16) positions; rounds 1-4 ran and counted all 256 "
+                    "padded rows, i.e. 1.78 x these attention flops for the 141-token caption): the utilisation of this record is not comparable "
+                    "with earlier rounds' -- ms_language_path is",
             "timing": "eager, single stream, HIP events; attention = the bert_attn_qkv (projection + attention) / gcp_attn_fused (projections + sparse "
                       "attention + gate) / attn_* / gcp_sparse launches only"}
 
