@@ -67,10 +67,12 @@ struct DcnGroup {
 // weight 1 (0 where the tap lies in the zero padding), corners 1 .. 3 with weight exactly 0 -- so only corner 0 is gathered and the blend is
 // one multiply by 0 / 1.  Same results bit for bit as the general path (w0 a + 0 b + 0 c + 0 d in the same fma order), a quarter of the gather
 // loads and none of the blend arithmetic.
-// FENCE (round 5): a scheduling fence behind every barrier of the k-loop.  A workgroup barrier orders LDS traffic, not arithmetic: without the
-// fence hipcc hoists the bilinear blend of the NEXT half step (registers only) above the barrier, and with it the wait for that step's gather
-// -- the ISA of rounds 2-4 drained its loads with vmcnt(0) once per two k-steps, i.e. the gather issued half a step ago was waited for at once
-// instead of a whole step later.  Same instructions, same results; only their order is pinned.
+// FENCE (round 5, a NEGATIVE result kept as a template switch, not instantiated by the launcher): a scheduling fence behind every barrier of the
+// k-loop.  A workgroup barrier orders LDS traffic, not arithmetic: hipcc hoists the bilinear blend of the NEXT half step (registers only) above
+// the barrier, and with it the wait for that step's gather -- the shipped ISA drains its loads with vmcnt(0) once per two k-steps.  Pinning the
+// order (waits bottom out at vmcnt(4), as the source intends) made the launch 9 % SLOWER (3.72 vs 3.40 ms per step, three of three, GPU call 13 of
+// round 5, profiles/r05_call13_dcn_fence_ab.txt; equal outputs): the hoisted blend fills the issue slots beside the other wave group's MFMAs, and the
+// gather has landed by then anyway (one k-step is ~1.7 us).
 template <int NW, int ABL = 0, int SYNC = 2, bool PLAIN = false, bool FENCE = false>
 __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   constexpr int BM = DCN_PH * DCN_PW, BN = 256, BK = 64;
@@ -468,7 +470,6 @@ extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* 
     hipError_t e = hipFuncSetAttribute((const void*)dcn_igemm8_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dcn_igemm8_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dcn_igemm8_kernel<16, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dcn_igemm8_kernel<16, 0, 1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr_set.done();
   }
@@ -495,7 +496,6 @@ extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* 
   // one barrier per k-step by default since GPU calls 14 / 15 of round 3 (0.661 - 0.668 ms against 0.673 - 0.692 with two, three of three
   // comparisons; equal outputs); MQ_DCN_SYNC=2: the former schedule (A/B switch)
   static const int sync = [] { const char* e = getenv("MQ_DCN_SYNC"); return (e && e[0] == '2') ? 2 : 1; }();
-  static const bool fence = [] { const char* e = getenv("MQ_DCN_FENCE"); return e && e[0] == '1'; }();      // A/B switch (see FENCE above)
   bool plain = true;                                          // flags bit 1 on EVERY branch: zero offsets, mask 1 (the caller's promise)
   for (int i = 0; i < n; ++i) plain = plain && (br[i].B <= 0 || (br[i].flags & 2));
   static const bool plain_on = [] { const char* e = getenv("MQ_DCN_PLAIN"); return !(e && e[0] == '0'); }();   // A/B switch
@@ -503,14 +503,11 @@ extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* 
     static MqOncePerDevice attr_plain;
     if (attr_plain.first()) {
       hipError_t e = hipFuncSetAttribute((const void*)dcn_igemm8_kernel<16, 0, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dcn_igemm8_kernel<16, 0, 1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
       attr_plain.done();
     }
-    if (fence) hipLaunchKernelGGL((dcn_igemm8_kernel<16, 0, 1, true, true>), grid, dim3(1024), smem, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL((dcn_igemm8_kernel<16, 0, 1, true>), grid, dim3(1024), smem, (hipStream_t)stream, g);
-  } else if (nw == 16 && sync == 1 && fence) hipLaunchKernelGGL((dcn_igemm8_kernel<16, 0, 1, false, true>), grid, dim3(1024), smem, (hipStream_t)stream, g);
-  else if (nw == 16 && sync == 1) hipLaunchKernelGGL((dcn_igemm8_kernel<16, 0, 1>), grid, dim3(1024), smem, (hipStream_t)stream, g);
+    hipLaunchKernelGGL((dcn_igemm8_kernel<16, 0, 1, true>), grid, dim3(1024), smem, (hipStream_t)stream, g);
+  } else if (nw == 16 && sync == 1) hipLaunchKernelGGL((dcn_igemm8_kernel<16, 0, 1>), grid, dim3(1024), smem, (hipStream_t)stream, g);
   else if (nw == 16) hipLaunchKernelGGL(dcn_igemm8_kernel<16>, grid, dim3(1024), smem, (hipStream_t)stream, g);
   else hipLaunchKernelGGL(dcn_igemm8_kernel<8>, grid, dim3(512), smem, (hipStream_t)stream, g);
   MQ_CHECK_LAUNCH();

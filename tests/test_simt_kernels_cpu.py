@@ -166,13 +166,12 @@ def test_dcn_barrier_schedules_are_equal():
     import tempfile
     outs = []
     with tempfile.TemporaryDirectory() as tmp:
-        for sync, fence in (("1", "0"), ("2", "0"), ("1", "1")):          # (round 5: MQ_DCN_FENCE pins the issue order behind the barriers -- same instructions)
-            f = os.path.join(tmp, f"y{sync}{fence}.pt")
-            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, MQ_DCN_SYNC=sync, MQ_DCN_FENCE=fence), capture_output=True, text=True,
-                               timeout=600)
+        for sync in ("1", "2"):
+            f = os.path.join(tmp, f"y{sync}.pt")
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, MQ_DCN_SYNC=sync), capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-400:]
             outs.append(torch.load(f))
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and float(outs[0].float().abs().mean()) > 0.01
+    assert torch.equal(outs[0], outs[1]) and float(outs[0].float().abs().mean()) > 0.01
 
 
 def test_fpn_topdown_fused_equals_interpolate_plus_add(kernels, monkeypatch):
