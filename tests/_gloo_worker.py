@@ -24,6 +24,14 @@ dets = parallel.unpack_detections(allp)
 assert len(dets) == world * B and len(dets[0]["boxes"]) == K - 1 and len(dets[B]["boxes"]) == K - 2
 assert parallel.shard_range(10, rank, world) == [rank * 5 + i for i in range(5)]
 assert parallel.shard_range(5, 1, 2) == [3, 4, 0]
+# the same collective one step behind the "forward" (parallel.OverlappedGather, bench.py --overlap-gather): submit(step k) returns the gathered
+# block of step k - 1, flush() the last one; every block equals the synchronous gather of its step
+og = parallel.OverlappedGather()
+steps = [packed + 10 * s for s in range(4)]
+got = [og.submit(p_) for p_ in steps] + [og.flush()]
+assert got[0] is None and og.flush() is None
+for s, g_ in enumerate(got[1:]):
+    assert torch.equal(g_, parallel.gather_detections(steps[s]))
 dist.barrier()
 print("GATHER_OK", rank, flush=True)
 dist.destroy_process_group()

@@ -139,6 +139,69 @@ def test_tokenizer_and_positive_map():
     assert 120 <= int(t["attention_mask"].sum()) <= 200
 
 
+def test_live_row_compaction_policy_and_raw_padding():
+    """detector._live_len: 16 ceil(live / 16) text positions (never more than the tokenizer's T; all T without a bound or with
+    MODEL.LANGUAGE_BACKBONE.COMPACT_TEXT off); _pad_raw_text brings the per-token tensors of a raw forward back to [.., T, ..] without touching the
+    operands postprocess() may be called on again."""
+    from mq_det_amd import get_cfg
+    from mq_det_amd.modeling.detector import GeneralizedVLRCNN_New
+    m = GeneralizedVLRCNN_New.__new__(GeneralizedVLRCNN_New)
+    m.cfg = get_cfg()
+    assert [m._live_len(256, kv) for kv in (0, 1, 16, 17, 141, 250, 256, 300)] == [256, 16, 16, 32, 144, 256, 256, 256]
+    m.cfg.MODEL.LANGUAGE_BACKBONE.COMPACT_TEXT = False
+    assert m._live_len(256, 141) == 256
+    raw = {"lang": {"hidden": torch.ones(2, 144, 8), "hidden32": None, "embedded": torch.ones(2, 144, 8), "masks": torch.ones(2, 144), "key_bias": torch.zeros(2, 144)},
+           "head": {"hidden": torch.ones(2, 144, 8), "tbias": torch.ones(2, 144), "dot": [torch.ones(2, 5, 144)]},
+           "head_trace": [{"bert_hidden": torch.ones(2, 144, 8)}]}
+    out = GeneralizedVLRCNN_New._pad_raw_text(raw, 256)
+    assert out["lang"]["hidden"].shape == (2, 256, 8) and float(out["lang"]["hidden"][:, 144:].abs().sum()) == 0 and out["lang"]["masks"].shape == (2, 256)
+    assert out["head"]["hidden"].shape == (2, 256, 8) and out["head_trace"][0]["bert_hidden"].shape == (2, 256, 8)
+    assert out["head"]["tbias"].shape == (2, 144) and out["head"]["dot"][0].shape == (2, 5, 144)
+
+
+def test_replay_input_copies_skip_only_unmodified_small_tensors():
+    """GraphRunner._tree_copy_: a small input that is the very tensor object of the previous replay, unmodified (version counter), is not copied
+    again; a modified one, another object, or a large one is."""
+    from mq_det_amd.modeling.graph_runner import GraphRunner
+    small, big = torch.arange(8.0), torch.zeros(GraphRunner.SKIP_COPY_MAX_NUMEL + 1)
+    dst = {"a": torch.zeros(8), "b": [torch.zeros_like(big)]}
+    seen = {}
+    GraphRunner._tree_copy_(dst, {"a": small, "b": [big]}, seen)
+    assert torch.equal(dst["a"], small) and ("a",) in seen and ("b", 0) not in seen
+    dst["a"].zero_()                                                   # (stands for: the static buffer already holds the value -- a skipped copy leaves it alone)
+    GraphRunner._tree_copy_(dst, {"a": small, "b": [big]}, seen)
+    assert float(dst["a"].abs().sum()) == 0                            # same object, same version: skipped
+    small.add_(1)                                                      # in-place write bumps the version counter
+    GraphRunner._tree_copy_(dst, {"a": small, "b": [big]}, seen)
+    assert torch.equal(dst["a"], small)
+    other = small.clone()
+    dst["a"].zero_()
+    GraphRunner._tree_copy_(dst, {"a": other, "b": [big]}, seen)
+    assert torch.equal(dst["a"], other)                                # another object with the same content: copied
+    big[0] = 5.0
+    GraphRunner._tree_copy_(dst, {"a": other, "b": [big]}, seen)
+    assert float(dst["b"][0][0]) == 5.0                                # large tensors: always
+
+
+def test_fused_text_kernel_size_policy():
+    """KERNELS[...] = 1: mq_bert_attn_qkv_fwd up to two workgroups per CU, mq_gcp_attn_fwd up to FUSED_TEXT_MAX_ROWS text rows; = 2 always."""
+    from mq_det_amd import ops
+    saved = dict(ops.KERNELS)
+    try:
+        ops.KERNELS["BERT_ATTN_QKV_FUSED"], ops.KERNELS["GCP_ATTN_FUSED"] = 1, 1
+        assert ops.bert_attention_qkv_fits(144, 768, 12, None, batch=8) and ops.bert_attention_qkv_fits(144, 768, 12, None, batch=42)
+        assert not ops.bert_attention_qkv_fits(144, 768, 12, None, batch=64) and not ops.bert_attention_qkv_fits(144, 1024, 16, None, batch=8)
+        x8, x64 = torch.zeros(8, 144, 768), torch.zeros(64, 144, 768)
+        idx = torch.zeros(8, 144, 5, dtype=torch.int32)
+        assert ops.gcp_attention_fits(x8, idx, policy=True) and not ops.gcp_attention_fits(x64, idx, policy=True) and ops.gcp_attention_fits(x64, idx)
+        assert not ops.gcp_attention_fits(x8, torch.zeros(8, 144, 9, dtype=torch.int32))                 # more than 8 slots: the unfused path
+        ops.KERNELS["BERT_ATTN_QKV_FUSED"], ops.KERNELS["GCP_ATTN_FUSED"] = 2, 2
+        assert ops.bert_attention_qkv_fits(144, 768, 12, None, batch=64) and ops.gcp_attention_fits(x64, idx, policy=True)
+    finally:
+        ops.KERNELS.clear()
+        ops.KERNELS.update(saved)
+
+
 def test_gloo_world2_detection_gather():
     """N > 1 path on CPU: 2 processes, gloo, fixed-shape all-gather of detections + shard ranges."""
     script = os.path.join(ROOT, "tests", "_gloo_worker.py")
