@@ -425,13 +425,22 @@ int mq_post_sort_fwd(const float* boxes, const float* scores, const int* labels,
 int mq_post_finalize_fwd(const float* boxes, const float* scores, const int* labels, const unsigned char* keep, float* out,
                          int* counts, int B, int tot, int K, int K2, void* stream);
 
-/* The attention half of a GatedCrossAttentionBlock in ONE launch (round 5; north-star "fused GCP + BERT attention"):
+/* MFMA B-FRAGMENT ORDER of a weight matrix W [N, K] (N % 16 == 0, K % 32 == 0; ABI 28): the same elements as the row-major nn.Linear weight,
+ * re-ordered ONCE when the checkpoint is loaded to [N / 16][K / 32][64][8] --
+ *     packed[((n / 16) * (K / 32) + k / 32) * 512 + ((k % 32) / 8 * 16 + n % 16) * 8 + k % 8] = W[n][k]
+ * (torch: W.view(N/16, 16, K/32, 4, 8).permute(0, 2, 3, 1, 4).contiguous(); mq_det_amd.ops.pack_b_fragments).  Lane l of a wave then finds its 8
+ * operands of (16-column tile, k-step) at 8 l: one load instruction reads 1 KiB (fp32 twins: 2 KiB) of CONSECUTIVE bytes.  The two fused text
+ * kernels below stream their weights L2 -> registers with no LDS stage; from the row-major matrix the same fragments are 16 rows x 64 B per
+ * instruction, half a cache line per row, and stream at 37 GB/s per workgroup against 136 GB/s in this order (profiles/r05_l2_weight_stream.jsonl;
+ * tools/probes/l2_weight_stream.hip).
+ *
+ * The attention half of a GatedCrossAttentionBlock in ONE launch (round 5; north-star "fused GCP + BERT attention"):
  *   x_out = x + tanh(w2 . gelu(Wg1 LN_g(sup))) * sup,  sup = Wout sparse_attn(Wq LN_a(x), kv, idx),  y = LN_f(x_out)
  * -- LayerNorm, to_q, the sparse gather-attention of mq_gcp_sparse_attn_fwd, to_out, the gate MLP with its LayerNorm, the gated residual of
  * mq_gcp_gate_residual_fwd and the LayerNorm in front of the feed-forward half; a workgroup owns 16 or 32 text rows, weights streamed from L2.
  * x / x_out [M, 768] fp32 residual stream (M = B*T text rows; x_out may alias x), y [M, 768] 16-bit or NULL, gate_out [M] fp32 or NULL
  * (VISION_QUERY.RETURN_ATTN_GATE_VALUE), kv [B, V, 1024] 16-bit = to_kv(norm_kv(vision)), idx [M, S] int32 (S <= 8, -1 = padding: a row
- * without a vision query gets sup == 0 exactly, quirk 5), wq [512, 768], wout [768, 512], wg1 [384, 768], w2 [384], the three LayerNorms'
+ * without a vision query gets sup == 0 exactly, quirk 5), wq [512, 768], wout [768, 512], wg1 [384, 768] IN B-FRAGMENT ORDER, w2 [384], the three LayerNorms'
  * gamma / beta [768] 16-bit; rows_per_block 16, 32 or 0 (chosen from M).  Returns -1 for other widths or S > 8.
  * Replaces GatedCrossAttentionBlock.forward up to the feed-forward half: maskrcnn_benchmark/modeling/language_backbone/modeling_bert_new.py
  * :298-368 (MaskedCrossAttention :162-248 with the sparse gather, attn_gate :340-359, the gated residual :368). */
@@ -442,7 +451,7 @@ int mq_gcp_attn_fwd(const float* x, float* x_out, void* y, float* gate_out, cons
 
 /* The attention half of a BERT layer in ONE launch (round 5; north-star "fused GCP + BERT attention"): the q | k | v projection of every
  * (batch item, head) AND its attention -- the qkv tensor is never written.  x [B, T, C] 16-bit hidden states (element (b, t, c) at
- * x + b*x_bs + t*x_rs + c; strides % 8 == 0), w [3C, C] the layer's fused projection weight (rows q | k | v, K-contiguous), bias [3C],
+ * x + b*x_bs + t*x_rs + c; strides % 8 == 0), w [3C, C] the layer's fused projection weight (rows q | k | v) IN B-FRAGMENT ORDER (above), bias [3C],
  * o [B, T, C] context with the heads concatenated (o_rs % 4 == 0); key_bias fp32 (b, j) at key_bias + b*bias_bs + j or NULL (<= -1e29
  * marks a masked key); kv_len [B] int32 or NULL: keys at and beyond kv_len[b] are skipped in whole 16-key blocks.  C = 64 H, C % 128 == 0,
  * T <= 256 (one workgroup holds a whole (b, h): after the live-row compaction of the text T = 16 ceil(caption / 16)); clamp > 0 = the +-clamp

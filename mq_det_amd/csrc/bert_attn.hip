@@ -38,7 +38,7 @@ __device__ __forceinline__ void ba_static_for(F f) { ba_static_for_impl<0, N>(f)
 
 struct BertAttnParams {
   const half_t* x;                // [B, T, C] hidden states (operand type), row stride x_rs, batch stride x_bs
-  const half_t* w;                // [3 C, C]: rows q | k | v (the layer's fused projection weight)
+  const half_t* w;                // [3 C, C]: rows q | k | v (the layer's fused projection weight) in MFMA B-fragment order [3 C / 16][C / 32][64][8]
   const half_t* bias;             // [3 C]
   half_t* o;                      // [B, T, C] context (heads concatenated)
   const float* key_bias;          // (b, j) at key_bias + b * bias_bs + j, or nullptr; <= -1e29 marks a masked key
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(512, 2) void bert_attn_qkv_kernel(BertAttnParams p)
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int cb = 3 * wn + j;
-    wrow[j] = p.w + ((long)(cb >> 2) * C + h * D + (cb & 3) * 16 + l15) * C + lg * 8;
+    wrow[j] = p.w + ((long)(((cb >> 2) * C + h * D) / 16 + (cb & 3)) * (C / 32) * 64 + lane) * 8;      // fragment-order weights: tile, k-step 0, lane
   }
   float4_ acc[NMB][3];                               // token blocks wm, wm + 2, ...
 #pragma unroll
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(512, 2) void bert_attn_qkv_kernel(BertAttnParams p)
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) w[j][kk] = *(const half8*)(wrow[j] + ks * BK + kk * 32);
+      for (int kk = 0; kk < 2; ++kk) w[j][kk] = *(const half8*)(wrow[j] + (ks * (BK / 32) + kk) * (64 * 8));
   };
   auto gemm_chunk = [&](int buf, const half8 (&w)[3][2]) __attribute__((always_inline)) {
     const half_t* xt = Xs + (long)buf * rows * XP + (wm * 16 + l15) * XP + lg * 8;
@@ -276,7 +276,9 @@ static int launch_bert_attn(const BertAttnParams& p, hipStream_t stream) {
   return 0;
 }
 
-// x [B, T, C] operand type (row stride x_rs, batch stride x_bs, elements; % 8), w [3 C, C] = the layer's q | k | v projection weight, bias [3 C],
+// x [B, T, C] operand type (row stride x_rs, batch stride x_bs, elements; % 8), w [3 C, C] = the layer's q | k | v projection weight in MFMA
+// B-fragment order (mqdet_hip.h; one wave instruction then reads 1 KiB of consecutive bytes -- row-major fragments stream 3.7x slower, see
+// gcp_fused.hip), bias [3 C],
 // o [B, T, C] (o_rs % 4); key_bias fp32 (b, j) at key_bias + b * bias_bs + j or NULL; kv_len [B] int32 or NULL (keys at and beyond it are
 // skipped in whole 16-key blocks; the caller's key_bias masks the rest).  C = 768 = 64 H (BERT-base), T <= 256.  clamp > 0: the +-clamp of the
 // VLDyHead BERT copies.  Returns -1 for shapes it does not take, -3 for misaligned strides.

@@ -27,6 +27,7 @@ namespace {
 constexpr int GF_C = 768, GF_HD = 512, GF_G = 384;           // hidden width, heads x dim_head of the cross attention, gate width
 constexpr int GF_P = GF_C + 8;                               // LDS row pitch (elements): consecutive rows shift by 16 bytes
 constexpr int GF_NT = 512, GF_NW = 8;
+constexpr int GF_WKS = 64 * 8;                               // elements between two k-steps of a 16-column tile of the fragment-order weights
 }  // namespace
 
 struct GcpAttnParams {
@@ -36,7 +37,7 @@ struct GcpAttnParams {
   float* gate_out;                // [M] or nullptr
   const half_t* kv;               // [B, V, 2 * HD]  k | v of the vision queries
   const int* idx;                 // [M, S] indices into V, -1 = padding
-  const half_t *wq, *wout, *wg1;  // [HD, C], [C, HD], [G, C]
+  const half_t *wq, *wout, *wg1;  // [HD, C], [C, HD], [G, C] in MFMA B-fragment order: [N / 16][K / 32][64][8]
   const half_t* w2;               // [G]
   const half_t *ga, *ba, *gg, *bg, *gf, *bf;   // LayerNorm gamma / beta: attention input, gate input, feed-forward input
   long M;
@@ -55,18 +56,25 @@ template <int N, class F>
 __device__ __forceinline__ void gf_static_for(F f) { gf_static_for_impl<0, N>(f); }
 
 // acc[mb][j] += A(rows of this block, K) . W(rows = this wave's 16 j-th output columns, K)^T over NG groups of G k-steps of 32 (K = 32 G NG).
-// At: LDS, lane's fragment base (row l15, k offset 8 lg); wrow[j]: global, lane's weight row + 8 lg.  The weight fragments of a wave are read
-// by nobody else: global (L2) -> registers, NSETS register sets, the groups g + 1 .. g + NSETS - 1 requested while group g is multiplied.  The
+// At: LDS, lane's fragment base (row l15, k offset 8 lg); wrow[j]: global, the lane's 8 elements of the first k-step of its j-th 16-column tile in
+// the FRAGMENT-ORDER weights (mqdet_hip.h "MFMA B-fragment order": [N / 16][K / 32][64 lanes][8], k-step stride GF_WKS): one wave instruction
+// reads 1 KiB of consecutive bytes.  Reading the same fragments from the row-major [N][K] matrix (16 rows x 64 B per instruction, half a cache
+// line per row) streams at 37 GB/s per workgroup against 136 GB/s (tools/probes/l2_weight_stream.hip, round 5 call 16), and the weight stream was
+// 55 of this kernel's 73 us at B = 8 (call 15: the launch without it takes 17.5 us, without the MFMAs 71 us).  The weight fragments of a wave are
+// read by nobody else: global (L2) -> registers, NSETS register sets, the groups g + 1 .. g + NSETS - 1 requested while group g is multiplied.  The
 // loop is unrolled completely and every load group sits behind a scheduling fence: left alone the scheduler sinks the loads to just above their
 // first use (the ISA then waits with vmcnt(2): two loads in flight per wave, one L2 / fabric round trip per 2 KB of a 264 KB stream).
-template <int NTL, int MB, int G, int NG, int NSETS>
+template <int NTL, int MB, int G, int NG, int NSETS, int ABL = 0>
 __device__ __forceinline__ void gf_rows_gemm(const half_t* At, const half_t* const (&wrow)[NTL], float4_ (&acc)[MB][NTL]) {
   half8 w[NSETS][G][NTL];
   auto load = [&](half8 (&ws)[G][NTL], int grp) __attribute__((always_inline)) {
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
-      for (int j = 0; j < NTL; ++j) ws[g][j] = *(const half8*)(wrow[j] + (grp * G + g) * 32);
+      for (int j = 0; j < NTL; ++j) {
+        if constexpr (ABL & 1) ws[g][j] = zero8();                 // ablation: no weight stream
+        else ws[g][j] = *(const half8*)(wrow[j] + (grp * G + g) * GF_WKS);
+      }
     __builtin_amdgcn_sched_barrier(0);
   };
   gf_static_for<NSETS - 1>([&](auto sc) __attribute__((always_inline)) {
@@ -82,14 +90,19 @@ __device__ __forceinline__ void gf_rows_gemm(const half_t* At, const half_t* con
       for (int mb = 0; mb < MB; ++mb) {
         const half8 af = *(const half8*)(At + mb * 16 * GF_P + (grp * G + g) * 32);
 #pragma unroll
-        for (int j = 0; j < NTL; ++j) acc[mb][j] = mfma16(af, w[grp % NSETS][g][j], acc[mb][j]);
+        for (int j = 0; j < NTL; ++j) {
+          if constexpr (ABL & 8) acc[mb][j][0] += (float)af[0] * (float)w[grp % NSETS][g][j][0];    // ablation: no MFMAs (operands stay live)
+          else acc[mb][j] = mfma16(af, w[grp % NSETS][g][j], acc[mb][j]);
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
   });
 }
 
-template <int MB>
+// ABL (tools/microbench.py only; results are garbage): the kernel WITHOUT one of its parts -- bit 0: no weight stream (zero fragments), bit 1: no
+// gather of the vision keys / values, bit 2: no erf / tanh gate arithmetic, bit 3: no MFMAs -- to see what the 70 us are made of.
+template <int MB, int ABL = 0>
 __global__ __launch_bounds__(GF_NT, 2) void gcp_attn_kernel(GcpAttnParams p) {
   constexpr int C = GF_C, HD = GF_HD, P = GF_P, RB = 16 * MB, RPW = RB / GF_NW;      // rows per wave in the row-wise steps (2 or 4)
   constexpr int NSETS = MB == 1 ? 3 : 2;         // weight-fragment register sets of the GEMM steps (MB = 2: a third set spills)
@@ -165,8 +178,8 @@ __global__ __launch_bounds__(GF_NT, 2) void gcp_attn_kernel(GcpAttnParams p) {
       for (int j = 0; j < 4; ++j) acc[mb][j] = (float4_){0.f, 0.f, 0.f, 0.f};
     const half_t* wrow[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wrow[j] = p.wq + (long)(64 * wave + 16 * j + l15) * C + lg * 8;
-    gf_rows_gemm<4, MB, 3, C / 32 / 3, NSETS>(At, wrow, acc);
+    for (int j = 0; j < 4; ++j) wrow[j] = p.wq + ((long)(4 * wave + j) * (C / 32) * 64 + lane) * 8;
+    gf_rows_gemm<4, MB, 3, C / 32 / 3, NSETS, ABL>(At, wrow, acc);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -193,7 +206,7 @@ __global__ __launch_bounds__(GF_NT, 2) void gcp_attn_kernel(GcpAttnParams p) {
     float mx = MQ_NEG_BIG;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      const int id = idr[r][s];
+      const int id = (ABL & 2) ? -1 : idr[r][s];
       sim[s] = MQ_NEG_BIG;
       vv[s] = zero8();
       if (id >= 0) {
@@ -246,8 +259,8 @@ __global__ __launch_bounds__(GF_NT, 2) void gcp_attn_kernel(GcpAttnParams p) {
       for (int j = 0; j < 6; ++j) acc[mb][j] = (float4_){0.f, 0.f, 0.f, 0.f};
     const half_t* wrow[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) wrow[j] = p.wout + (long)(96 * wave + 16 * j + l15) * HD + lg * 8;
-    gf_rows_gemm<6, MB, 2, HD / 32 / 2, NSETS>(Bt, wrow, acc);
+    for (int j = 0; j < 6; ++j) wrow[j] = p.wout + ((long)(6 * wave + j) * (HD / 32) * 64 + lane) * 8;
+    gf_rows_gemm<6, MB, 2, HD / 32 / 2, NSETS, ABL>(Bt, wrow, acc);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -279,8 +292,8 @@ __global__ __launch_bounds__(GF_NT, 2) void gcp_attn_kernel(GcpAttnParams p) {
       for (int j = 0; j < 3; ++j) acc[mb][j] = (float4_){0.f, 0.f, 0.f, 0.f};
     const half_t* wrow[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) wrow[j] = p.wg1 + (long)(48 * wave + 16 * j + l15) * C + lg * 8;
-    gf_rows_gemm<3, MB, 4, C / 32 / 4, NSETS>(Bt, wrow, acc);
+    for (int j = 0; j < 3; ++j) wrow[j] = p.wg1 + ((long)(3 * wave + j) * (C / 32) * 64 + lane) * 8;
+    gf_rows_gemm<3, MB, 4, C / 32 / 4, NSETS, ABL>(Bt, wrow, acc);
     float w2v[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) w2v[j] = (float)p.w2[48 * wave + 16 * j + l15];
@@ -292,7 +305,8 @@ __global__ __launch_bounds__(GF_NT, 2) void gcp_attn_kernel(GcpAttnParams p) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           const float v = (float)(half_t)acc[mb][j][r];                 // the rounding point of the gate GEMM's output
-          d += 0.5f * v * (1.f + erff(v * 0.70710678118654752f)) * w2v[j];
+          if constexpr (ABL & 4) d += v * w2v[j];
+          else d += 0.5f * v * (1.f + erff(v * 0.70710678118654752f)) * w2v[j];
         }
         d = group16_sum(d);
         if (l15 == 0) red[wave * RB + mb * 16 + 4 * lg + r] = d;
@@ -303,7 +317,7 @@ __global__ __launch_bounds__(GF_NT, 2) void gcp_attn_kernel(GcpAttnParams p) {
     float d = 0.f;
 #pragma unroll
     for (int w = 0; w < GF_NW; ++w) d += red[w * RB + tid];
-    const float gate = tanhf(d);
+    const float gate = (ABL & 4) ? d : tanhf(d);
     gate_s[tid] = gate;
     if (p.gate_out && row0 + tid < p.M) p.gate_out[row0 + tid] = gate;
   }
@@ -340,17 +354,17 @@ __global__ __launch_bounds__(GF_NT, 2) void gcp_attn_kernel(GcpAttnParams p) {
   }
 }
 
-template <int MB>
+template <int MB, int ABL = 0>
 static int launch_gcp_attn(const GcpAttnParams& p, hipStream_t stream) {
   constexpr int RB = 16 * MB;
   constexpr size_t smem = (size_t)2 * RB * GF_P * sizeof(half_t) + (size_t)(GF_NW + 1) * RB * sizeof(float);
   static MqOncePerDevice attr;
   if (attr.first()) {
-    hipError_t e = hipFuncSetAttribute((const void*)gcp_attn_kernel<MB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)gcp_attn_kernel<MB, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr.done();
   }
-  hipLaunchKernelGGL(gcp_attn_kernel<MB>, dim3((unsigned)((p.M + RB - 1) / RB)), dim3(GF_NT), smem, stream, p);
+  hipLaunchKernelGGL((gcp_attn_kernel<MB, ABL>), dim3((unsigned)((p.M + RB - 1) / RB)), dim3(GF_NT), smem, stream, p);
   MQ_CHECK_LAUNCH();
   return 0;
 }
@@ -371,6 +385,16 @@ extern "C" int MQ_SYM(mq_gcp_attn_fwd)(const float* x, float* x_out, void* y, fl
   p.ga = (const half_t*)ln_a_g; p.ba = (const half_t*)ln_a_b; p.gg = (const half_t*)ln_g_g; p.bg = (const half_t*)ln_g_b;
   p.gf = (const half_t*)ln_f_g; p.bf = (const half_t*)ln_f_b;
   p.M = M; p.T = T; p.V = V; p.S = S; p.eps = eps; p.scale = 1.0f / sqrtf((float)dim_head);
+#ifdef MQ_PRIMARY_UNIT
+  switch (rows_per_block >> 8) {      // diagnostic only (tools/microbench.py): 16 | mask << 8 launches the kernel WITHOUT the parts in the mask; the output is meaningless
+    case 1: return launch_gcp_attn<1, 1>(p, (hipStream_t)stream);
+    case 2: return launch_gcp_attn<1, 2>(p, (hipStream_t)stream);
+    case 4: return launch_gcp_attn<1, 4>(p, (hipStream_t)stream);
+    case 8: return launch_gcp_attn<1, 8>(p, (hipStream_t)stream);
+    case 15: return launch_gcp_attn<1, 15>(p, (hipStream_t)stream);
+    default: break;
+  }
+#endif
   if (rows_per_block == 0) rows_per_block = (M >= 32L * 2 * mq_device_cus() && sizeof(half_t) == 2) ? 32 : 16;
   if (rows_per_block == 32 && sizeof(half_t) == 2) return launch_gcp_attn<2>(p, (hipStream_t)stream);
   return launch_gcp_attn<1>(p, (hipStream_t)stream);

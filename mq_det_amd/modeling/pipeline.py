@@ -77,11 +77,19 @@ def _pack_language(P, sd, cfg, p, device, dtype):
             # tanh(ff_gate) folded into the last FFN projection (modeling_bert_new.py:373)
             P[b + ".ff.linear2.gated"] = (f32(b + ".ff.linear2.weight") * torch.tanh(f32(b + ".ff_gate"))).to(dtype)
             P[b + ".attn_gate.w2"] = h(b + ".attn_gate.linear2.weight").reshape(-1)
+            # the three weights mq_gcp_attn_fwd streams, in MFMA B-fragment order (one load instruction = 1 KiB of consecutive bytes)
+            for n in (".attn.to_q", ".attn.to_out", ".attn_gate.linear1"):
+                _pack_frag(P, b + n + ".frag", h(b + n + ".weight"))
         for i in range(2):
             b = f"{p}.pre_select.layers.{i}.image_condition"
             wkv = h(b + ".to_kv.weight")
             half = wkv.shape[0] // 2
             P[b + ".to_k.weight"], P[b + ".to_v.weight"] = wkv[:half].contiguous(), wkv[half:].contiguous()
+
+
+def _pack_frag(P, key, w):
+    if w.shape[0] % 16 == 0 and w.shape[1] % 32 == 0:
+        P[key] = ops.pack_b_fragments(w)
 
 
 def _pack_bert_layer(P, sd, b, device, dtype):
@@ -92,6 +100,7 @@ def _pack_bert_layer(P, sd, b, device, dtype):
     # one projection for q | k | v (KERNELS["BERT_QKV_FUSED"]: mq_attn_text_fwd reads V row-major, no V^T operand)
     P[b + ".qkv.weight"] = torch.cat([P[b + ".qk.weight"], h(b + ".attention.self.value.weight")], 0)
     P[b + ".qkv.bias"] = torch.cat([P[b + ".qk.bias"], h(b + ".attention.self.value.bias")], 0)
+    _pack_frag(P, b + ".qkv.frag", P[b + ".qkv.weight"])      # the same matrix in MFMA B-fragment order: what mq_bert_attn_qkv_fwd streams
 
 
 def build_plan(sd, cfg, device, dtype=torch.float16):
@@ -410,9 +419,9 @@ def bert_layer(P, b, x, key_bias, clamp, kv_len=None, x32=None, qk_mask=None, ma
     Returns y16 (and y32 when x32 is given)."""
     Bn, T, C = x.shape
     r32 = x32 is not None
-    if ops.KERNELS["BERT_ATTN_QKV_FUSED"] >= 1 and qk_mask is None and (b + ".qkv.weight") in P and ops.bert_attention_qkv_fits(T, C, 12, key_bias, batch=Bn):
+    if ops.KERNELS["BERT_ATTN_QKV_FUSED"] >= 1 and qk_mask is None and (b + ".qkv.frag") in P and ops.bert_attention_qkv_fits(T, C, 12, key_bias, batch=Bn):
         # projection + attention of every (batch item, head) in one launch: no qkv tensor (mq_bert_attn_qkv_fwd)
-        ctx = ops.bert_attention_qkv(x, P[b + ".qkv.weight"], P[b + ".qkv.bias"], 12, key_bias=key_bias, clamp=50000.0 if clamp else 0.0, kv_len=kv_len)
+        ctx = ops.bert_attention_qkv(x, P[b + ".qkv.frag"], P[b + ".qkv.bias"], 12, key_bias=key_bias, clamp=50000.0 if clamp else 0.0, kv_len=kv_len, packed=True)
     elif ops.KERNELS["BERT_QKV_FUSED"] == 1 and qk_mask is None and ops.attention_text_fits(T, kv_len, max_kv) and (b + ".qkv.weight") in P \
             and (key_bias is None or key_bias.dim() == 2):
         ctx = ops.attention_text(_lin(P, b + ".qkv", x), 12, key_bias=key_bias, clamp=50000.0 if clamp else 0.0, kv_len=kv_len, max_kv=max_kv)
@@ -498,12 +507,13 @@ def gcp_block(P, b, x, vision, idx, gates=None, kv=None):
     if kv is None:
         kv = gcp_kv(P, b, vision)
     ff = b + ".ff"
-    if ops.KERNELS["GCP_ATTN_FUSED"] >= 1 and ops.gcp_attention_fits(x, idx, policy=True):
+    if ops.KERNELS["GCP_ATTN_FUSED"] >= 1 and (b + ".attn.to_q.frag") in P and ops.gcp_attention_fits(x, idx, policy=True):
         # LayerNorm, to_q, sparse attention, to_out, gate MLP, gated residual and the feed-forward half's LayerNorm: one launch (mq_gcp_attn_fwd)
         def ln(n):
             return (P[n + ".weight"], P[n + ".bias"])
-        r = ops.gcp_attention(x.contiguous(), kv.contiguous(), idx, P[b + ".attn.to_q.weight"], P[b + ".attn.to_out.weight"], P[b + ".attn_gate.linear1.weight"],
-                              P[b + ".attn_gate.w2"], ln(b + ".attn.norm"), ln(b + ".attn_gate.norm"), ln(ff + ".norm"), want_gate=gates is not None)
+        r = ops.gcp_attention(x.contiguous(), kv.contiguous(), idx, P[b + ".attn.to_q.frag"], P[b + ".attn.to_out.frag"], P[b + ".attn_gate.linear1.frag"],
+                              P[b + ".attn_gate.w2"], ln(b + ".attn.norm"), ln(b + ".attn_gate.norm"), ln(ff + ".norm"), want_gate=gates is not None,
+                              packed=True)
         x, xn = r[0], r[1]
         if gates is not None:
             gates.append(r[2])

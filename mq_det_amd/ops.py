@@ -13,7 +13,7 @@ _LIB = None
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmqdet_hip.so")
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
-EXPECTED_ABI = 27        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
+EXPECTED_ABI = 28        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
 _SIGNATURES = {
     "mq_abi_version": (_i, []),
     "mq_attn_workspace_bytes": (_l, [_i, _i, _i, _i, _i]),
@@ -127,12 +127,13 @@ KERNEL_DEFAULTS = {
                                  # went from 17.3 to 21 ms -- two more streams than hardware queues (GPU_MAX_HW_QUEUES = 8), branches of the captured
                                  # forward then share queues and serialise.  Off.
     "GCP_ATTN_FUSED": 1,         # mq_gcp_attn_fwd -- the attention half of a GCP block (LayerNorm, to_q, sparse attention, to_out, gate MLP, gated residual,
-                                 # next LayerNorm) in one launch.  1: where it is measured not to lose -- up to FUSED_TEXT_MAX_ROWS text rows per launch (every
-                                 # workgroup streams all 2.1 MB of weights: 73 us against 128 us eager / ~56 us in a graph at B = 8, but 174 against 127 us at
-                                 # B = 64); 2: always; 0: the eight launches of rounds 2-4
+                                 # next LayerNorm) in one launch.  1: over the measured range -- up to FUSED_TEXT_MAX_ROWS text rows per launch (every workgroup
+                                 # streams all 2.1 MB of weights, in MFMA B-fragment order since GPU call 17: 33 us against 154 us for the eight launches at
+                                 # B = 8, 102 against 127 us at B = 64; with row-major weights it was 73 / 219 us); 2: always; 0: the eight launches of rounds 2-4
     "BERT_ATTN_QKV_FUSED": 1,    # mq_bert_attn_qkv_fwd -- the q | k | v projection inside the attention launch (one workgroup per (batch item, head); the qkv
-                                 # tensor is never written).  1: up to two workgroups per CU (B x heads <= 2 x CUs: 26 us against 39 us for the library GEMM +
-                                 # mq_attn_text_fwd at B = 8; at B = 64 three rounds of workgroups take 82 us against 69); 2: always; 0: never (round 4's pair)
+                                 # tensor is never written).  1: over the measured range, B x heads <= FUSED_BERT_MAX_WORKGROUPS (weights in MFMA B-fragment
+                                 # order since GPU call 17: 23 us against 39 us for the library GEMM + mq_attn_text_fwd at B = 8, 66 against 72 us at B = 64;
+                                 # row-major weights: 26 / 82 us); 2: always; 0: never (round 4's pair)
     "POST_FUSED": 1,             # 1: ATSS post-processing as mq_post_select_fwd + mq_post_sort_fwd + mq_ml_nms_topk + mq_post_finalize_fwd (4 launches);
                                  # 0: the round-1..3 chain (5 x torch.topk + box_decode, argsort, gathers, NMS, topk: ~145 launches, 1.1 ms)
     "F32_OPERANDS": 0,           # the PRECISE mode (MODEL.COMPUTE_DTYPE = "float32"; set by configure() from the config, or MQ_F32_OPERANDS): every kernel's
@@ -351,8 +352,8 @@ def attention_text_fits(T, kv_len=None, max_kv=0):
     return T <= 256 and (f32_operands() != 1 or live <= 160)
 
 
-FUSED_TEXT_MAX_ROWS = 4608          # text rows (B x T) up to which KERNELS["GCP_ATTN_FUSED"] = 1 takes the fused GCP kernel (B = 32 at 144 rows)
-FUSED_BERT_MAX_WORKGROUPS = 512     # (batch item, head) workgroups up to which KERNELS["BERT_ATTN_QKV_FUSED"] = 1 takes the fused BERT kernel (2 per CU)
+FUSED_TEXT_MAX_ROWS = 9216          # text rows (B x T) up to which KERNELS["GCP_ATTN_FUSED"] = 1 takes the fused GCP kernel (B = 64 at 144 rows: the largest measured)
+FUSED_BERT_MAX_WORKGROUPS = 768     # (batch item, head) workgroups up to which KERNELS["BERT_ATTN_QKV_FUSED"] = 1 takes the fused BERT kernel (B = 64: the largest measured)
 
 
 def bert_attention_qkv_fits(T, C, heads, key_bias=None, batch=None):
@@ -365,14 +366,16 @@ def bert_attention_qkv_fits(T, C, heads, key_bias=None, batch=None):
     return ok
 
 
-def bert_attention_qkv(x, wqkv, bqkv, heads, key_bias=None, clamp=0.0, kv_len=None, scale=None):
+def bert_attention_qkv(x, wqkv, bqkv, heads, key_bias=None, clamp=0.0, kv_len=None, scale=None, packed=False):
     """BertSelfAttention as one launch (mq_bert_attn_qkv_fwd): x [B,T,C] 16-bit hidden states, wqkv [3C,C] / bqkv [3C] the layer's fused
-    q | k | v projection, key_bias None or [B,T] fp32, kv_len [B] int32 or None -> context [B,T,C] in x's dtype."""
+    q | k | v projection (packed: wqkv already pack_b_fragments(...) -- the pipeline packs once; otherwise re-ordered here, one copy per call),
+    key_bias None or [B,T] fp32, kv_len [B] int32 or None -> context [B,T,C] in x's dtype."""
     lib = load_library()
     _need_gpu(x, wqkv, bqkv, key_bias, kv_len)
     B, T, C = x.shape
     assert bert_attention_qkv_fits(T, C, heads, key_bias) and x.dtype in _H16 and x.stride(2) == 1
-    assert wqkv.shape == (3 * C, C) and wqkv.is_contiguous() and bqkv.shape == (3 * C,) and bqkv.is_contiguous() and wqkv.dtype == bqkv.dtype == x.dtype
+    wqkv = _b_fragments(wqkv, 3 * C, C, packed)
+    assert bqkv.shape == (3 * C,) and bqkv.is_contiguous() and wqkv.dtype == bqkv.dtype == x.dtype
     bias_bs = 0
     if key_bias is not None:
         assert key_bias.dtype == torch.float32 and key_bias.shape == (B, T) and key_bias.stride(1) == 1
@@ -592,9 +595,32 @@ def gcp_attention_fits(x, idx, policy=False):
     return ok
 
 
-def gcp_attention(x, kv, idx, wq, wout, wg1, w2, ln_a, ln_g, ln_f=None, eps=1e-5, want_gate=False, rows_per_block=0):
+def pack_b_fragments(w):
+    """W [N, K] (an nn.Linear weight) -> the same elements in MFMA B-fragment order [N/16, K/32, 64, 8] (include/mqdet_hip.h): what the fused text
+    kernels stream.  Done once per weight when the model is packed (modeling/pipeline.py); any dtype."""
+    N, K = w.shape
+    assert N % 16 == 0 and K % 32 == 0
+    return w.view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(N // 16, K // 32, 64, 8)
+
+
+def unpack_b_fragments(wp):
+    """The inverse of pack_b_fragments: [N/16, K/32, 64, 8] -> the row-major [N, K] weight (tests, the torch stand-ins of the kernels)."""
+    nt, ks = wp.shape[:2]
+    return wp.view(nt, ks, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(nt * 16, ks * 32)
+
+
+def _b_fragments(w, N, K, packed):
+    if packed:
+        assert w.shape == (N // 16, K // 32, 64, 8) and w.is_contiguous(), "expected pack_b_fragments(weight)"
+        return w
+    assert w.shape == (N, K)
+    return pack_b_fragments(w)
+
+
+def gcp_attention(x, kv, idx, wq, wout, wg1, w2, ln_a, ln_g, ln_f=None, eps=1e-5, want_gate=False, rows_per_block=0, packed=False):
     """The attention half of a GatedCrossAttentionBlock in one launch (mq_gcp_attn_fwd).  x [B,T,768] fp32 residual stream, kv [B,V,1024] 16-bit,
-    idx [B,T,S] int32, wq [512,768], wout [768,512], wg1 [384,768], w2 [384]; ln_a / ln_g / ln_f = (gamma, beta) of the attention-input, gate-input
+    idx [B,T,S] int32, wq [512,768], wout [768,512], wg1 [384,768] (packed: each already pack_b_fragments(...) -- the pipeline packs once; otherwise
+    re-ordered here, three small copies per call), w2 [384]; ln_a / ln_g / ln_f = (gamma, beta) of the attention-input, gate-input
     and (optional) feed-forward-input LayerNorms -> x_out [B,T,768] fp32 (, y = LN_f(x_out) 16-bit when ln_f) (, gate [B,T] fp32 when want_gate)."""
     lib = load_library()
     _need_gpu(x, kv, idx, wq, wout, wg1, w2)
@@ -602,7 +628,8 @@ def gcp_attention(x, kv, idx, wq, wout, wg1, w2, ln_a, ln_g, ln_f=None, eps=1e-5
     V, S = kv.shape[1], idx.shape[2]
     assert gcp_attention_fits(x, idx) and x.is_contiguous() and kv.shape == (B, V, 1024) and kv.is_contiguous() and kv.dtype in _H16
     assert idx.dtype == torch.int32 and idx.shape[:2] == (B, T) and idx.is_contiguous()
-    assert wq.shape == (512, C) and wout.shape == (C, 512) and wg1.shape == (384, C) and w2.numel() == 384
+    wq, wout, wg1 = _b_fragments(wq, 512, C, packed), _b_fragments(wout, C, 512, packed), _b_fragments(wg1, 384, C, packed)
+    assert w2.numel() == 384
     ws = [wq, wout, wg1, w2, *ln_a, *ln_g] + (list(ln_f) if ln_f is not None else [])
     assert all(w.dtype == kv.dtype and w.is_contiguous() for w in ws)
     out = torch.empty_like(x)

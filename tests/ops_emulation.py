@@ -52,9 +52,11 @@ def attention_text(qkv, heads, key_bias=None, clamp=0.0, kv_len=None, max_kv=0, 
                       key_bias=key_bias, scale=scale, clamp=clamp)
 
 
-def bert_attention_qkv(x, wqkv, bqkv, heads, key_bias=None, clamp=0.0, kv_len=None, scale=None):
+def bert_attention_qkv(x, wqkv, bqkv, heads, key_bias=None, clamp=0.0, kv_len=None, scale=None, packed=False):
     """ops.bert_attention_qkv: the fused projection (rounded to the operand type like the GEMM's output) + attention_text."""
     import torch.nn.functional as F
+    from mq_det_amd.ops import unpack_b_fragments
+    wqkv = unpack_b_fragments(wqkv) if packed else wqkv
     qkv = F.linear(x.float(), wqkv.float(), bqkv.float()).to(x.dtype)
     return attention_text(qkv, heads, key_bias=key_bias, clamp=clamp, kv_len=kv_len, scale=scale)
 
@@ -136,9 +138,12 @@ def gcp_sparse_attention(q, kv, idx, heads=8, dim_head=64):
     return out.to(q.dtype)
 
 
-def gcp_attention(x, kv, idx, wq, wout, wg1, w2, ln_a, ln_g, ln_f=None, eps=1e-5, want_gate=False, rows_per_block=0):
+def gcp_attention(x, kv, idx, wq, wout, wg1, w2, ln_a, ln_g, ln_f=None, eps=1e-5, want_gate=False, rows_per_block=0, packed=False):
     """ops.gcp_attention: the unfused chain with its rounding points (every LayerNorm / GEMM output rounded to the operand type once)."""
     dt = kv.dtype
+    if packed:
+        from mq_det_amd.ops import unpack_b_fragments
+        wq, wout, wg1 = (unpack_b_fragments(w) for w in (wq, wout, wg1))
 
     def ln(v, gb):
         return F.layer_norm(v.float(), (v.shape[-1],), gb[0].float(), gb[1].float(), eps).to(dt)
@@ -622,7 +627,7 @@ def namespace(real_ops):
     import types
     g = globals()
     fake = types.SimpleNamespace(**{n: g[n] for n in NAMES})
-    for n in ("patch_embed_pack", "SWIN_MLP_WIDTHS", "WINDOW_QKV_WIDTHS", "window_qkv_fused", "SCORE_AGG", "window_pad", "pad_rel_bias", "swin_mlp_w2_perm", "swin_mlp2_pack", "timing_active", "attention_text_fits", "bert_attention_qkv_fits", "gcp_attention_fits", "f32_operands"):
+    for n in ("patch_embed_pack", "SWIN_MLP_WIDTHS", "WINDOW_QKV_WIDTHS", "window_qkv_fused", "SCORE_AGG", "window_pad", "pad_rel_bias", "swin_mlp_w2_perm", "swin_mlp2_pack", "timing_active", "attention_text_fits", "bert_attention_qkv_fits", "gcp_attention_fits", "f32_operands", "pack_b_fragments", "unpack_b_fragments"):
         setattr(fake, n, getattr(real_ops, n))
     fake.KERNELS = dict(real_ops.KERNEL_DEFAULTS)       # the default kernel selection: the glue of the promoted variants is what runs
     return fake

@@ -25,7 +25,7 @@ def test_c_abi_exports_match_header():
     lib = ops.load_library()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.mq_abi_version() == 27
+    assert lib.mq_abi_version() == 28
     assert lib.mq_attn_workspace_bytes(2, 8, 256, 256, 4) == 4 * 2 * 8 * 256 * 258 * 4
     assert lib.mq_ml_nms_workspace_bytes(2, 130) == 2 * 130 * 3 * 8
 
@@ -183,17 +183,36 @@ def test_replay_input_copies_skip_only_unmodified_small_tensors():
     assert float(dst["b"][0][0]) == 5.0                                # large tensors: always
 
 
+def test_b_fragment_order_is_the_headers_formula():
+    """ops.pack_b_fragments = the layout include/mqdet_hip.h states (MFMA B-fragment order), and unpack_b_fragments inverts it."""
+    import torch
+    from mq_det_amd import ops
+    N, K = 48, 96
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K)
+    p = ops.pack_b_fragments(w)
+    assert p.shape == (N // 16, K // 32, 64, 8) and p.is_contiguous()
+    flat = p.reshape(-1)
+    for n, k in ((0, 0), (5, 9), (17, 33), (47, 95), (16, 31), (31, 64)):
+        i = ((n // 16) * (K // 32) + k // 32) * 512 + ((k % 32) // 8 * 16 + n % 16) * 8 + k % 8
+        assert flat[i] == w[n, k]
+    # lane l of a wave reads 8 consecutive elements at 8 l: row n % 16 = l % 16, k offset 8 (l / 16) -- the operand layout of v_mfma_f32_16x16x32
+    assert torch.equal(p[1, 2, 37], w[16 + 37 % 16, 64 + 8 * (37 // 16):64 + 8 * (37 // 16) + 8])
+    assert torch.equal(ops.unpack_b_fragments(p), w)
+
+
 def test_fused_text_kernel_size_policy():
-    """KERNELS[...] = 1: mq_bert_attn_qkv_fwd up to two workgroups per CU, mq_gcp_attn_fwd up to FUSED_TEXT_MAX_ROWS text rows; = 2 always."""
+    """KERNELS[...] = 1: the fused text kernels over the measured range (mq_bert_attn_qkv_fwd up to FUSED_BERT_MAX_WORKGROUPS (batch item, head)
+    pairs, mq_gcp_attn_fwd up to FUSED_TEXT_MAX_ROWS text rows: B = 64 of the benchmark caption); = 2 always."""
     from mq_det_amd import ops
     saved = dict(ops.KERNELS)
     try:
         ops.KERNELS["BERT_ATTN_QKV_FUSED"], ops.KERNELS["GCP_ATTN_FUSED"] = 1, 1
-        assert ops.bert_attention_qkv_fits(144, 768, 12, None, batch=8) and ops.bert_attention_qkv_fits(144, 768, 12, None, batch=42)
-        assert not ops.bert_attention_qkv_fits(144, 768, 12, None, batch=64) and not ops.bert_attention_qkv_fits(144, 1024, 16, None, batch=8)
-        x8, x64 = torch.zeros(8, 144, 768), torch.zeros(64, 144, 768)
+        assert ops.bert_attention_qkv_fits(144, 768, 12, None, batch=8) and ops.bert_attention_qkv_fits(144, 768, 12, None, batch=64)
+        assert not ops.bert_attention_qkv_fits(144, 768, 12, None, batch=65) and not ops.bert_attention_qkv_fits(144, 1024, 16, None, batch=8)
+        x8, x64 = torch.zeros(8, 144, 768), torch.zeros(65, 144, 768)
         idx = torch.zeros(8, 144, 5, dtype=torch.int32)
         assert ops.gcp_attention_fits(x8, idx, policy=True) and not ops.gcp_attention_fits(x64, idx, policy=True) and ops.gcp_attention_fits(x64, idx)
+        assert ops.gcp_attention_fits(torch.zeros(64, 144, 768), idx, policy=True)
         assert not ops.gcp_attention_fits(x8, torch.zeros(8, 144, 9, dtype=torch.int32))                 # more than 8 slots: the unfused path
         ops.KERNELS["BERT_ATTN_QKV_FUSED"], ops.KERNELS["GCP_ATTN_FUSED"] = 2, 2
         assert ops.bert_attention_qkv_fits(144, 768, 12, None, batch=64) and ops.gcp_attention_fits(x64, idx, policy=True)

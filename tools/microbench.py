@@ -73,6 +73,7 @@ def gcp_attn(dev, g, out):
     h = lambda *s_, sc=1.0: (torch.randn(*s_, generator=g) * sc).half().to(dev)          # noqa: E731
     wq, wout, wg1, w2 = h(512, 768, sc=768 ** -0.5), h(768, 512, sc=512 ** -0.5), h(384, 768, sc=768 ** -0.5), h(384, sc=0.1)
     lns = [(h(768, sc=0.1) + 1, h(768, sc=0.1)) for _ in range(3)]
+    pq, pout, pg1 = (ops.pack_b_fragments(w_) for w_ in (wq, wout, wg1))      # packed once, as the pipeline does
     for B in (8, 64):
         x = torch.randn(B, T, 768, generator=g).to(dev)
         kv = h(B, V, 1024)
@@ -87,9 +88,14 @@ def gcp_attn(dev, g, out):
         fl = 2.0 * B * T * (768 * 512 + 512 * 768 + 768 * 384)
         rec = {"kernel": "gcp attention half", "B": B, "T": T, "algorithmic_gflop": round(fl / 1e9, 2), "unfused_8_launches_ms": round(timeit(unfused), 4)}
         for rb in (16, 32):
-            ms = timeit(lambda: ops.gcp_attention(x, kv, idx, wq, wout, wg1, w2, lns[0], lns[1], lns[2], rows_per_block=rb))
+            ms = timeit(lambda: ops.gcp_attention(x, kv, idx, pq, pout, pg1, w2, lns[0], lns[1], lns[2], rows_per_block=rb, packed=True))
             rec[f"fused_rb{rb}_ms"] = round(ms, 4)
             rec[f"fused_rb{rb}_tflops"] = round(fl / ms / 1e9, 1)
+        # what the rb16 time is made of: the same launch without the weight stream (1), the key / value gather (2), the erf / tanh arithmetic (4),
+        # the MFMAs (8), all four (15) -- rows_per_block = 16 | mask << 8, outputs meaningless
+        for mask in (1, 2, 4, 8, 15):
+            ms = timeit(lambda: ops.gcp_attention(x, kv, idx, pq, pout, pg1, w2, lns[0], lns[1], lns[2], rows_per_block=16 | mask << 8, packed=True))
+            rec[f"fused_rb16_without_{mask}_ms"] = round(ms, 4)
         out.append(rec)
 
 
@@ -101,6 +107,7 @@ def bert_attn(dev, g, out):
     C, H = 768, 12
     w = (torch.randn(3 * C, C, generator=g) / C ** 0.5).half().to(dev)
     bq = (torch.randn(3 * C, generator=g) * 0.1).half().to(dev)
+    wp = ops.pack_b_fragments(w)                                             # packed once, as the pipeline does
     for B in (8, 64):
         for T, kv in ((144, 141), (256, 141)):
             x = torch.randn(B, T, C, generator=g).half().to(dev)
@@ -109,7 +116,7 @@ def bert_attn(dev, g, out):
             kb[:, kv:] = -1e30
             k16 = -(-kv // 16) * 16
             fl = 2.0 * B * T * C * 3 * C + 4.0 * B * H * T * k16 * 64
-            ms_f = timeit(lambda: ops.bert_attention_qkv(x, w, bq, H, key_bias=kb, kv_len=kl))
+            ms_f = timeit(lambda: ops.bert_attention_qkv(x, wp, bq, H, key_bias=kb, kv_len=kl, packed=True))
             ms_g = timeit(lambda: F.linear(x, w, bq))
             qkv = F.linear(x, w, bq)
             ms_a = timeit(lambda: ops.attention_text(qkv, H, key_bias=kb, kv_len=kl, max_kv=kv))
