@@ -439,7 +439,7 @@ def kernel_rooflines(kern, steps, Bn, n_tok, embed=96):
         T = next((int(k[len("bert_attn_qkv_t"):]) for k, _ in ba), -(-n_tok // 16) * 16)
         fl = sum(v[0] for _, v in ga) * 2.0 * Bn * T * (768 * 512 + 512 * 768 + 768 * 384)
         out.append(_mfma("gcp_attn_kernel (GCP attention half in one launch: LayerNorm, to_q, sparse gather-attention, to_out, gate MLP, gated residual, "
-                         "next LayerNorm; latency-bound weight streaming at B = 8)", fl, fl, sum(v[0] for _, v in ga), sum(v[1] for _, v in ga),
+                         "next LayerNorm; weights streamed L2 -> registers in MFMA B-fragment order)", fl, fl, sum(v[0] for _, v in ga), sum(v[1] for _, v in ga),
                          "flops = 2 * B * T * (768*512 + 512*768 + 768*384) per launch (the three projections; the <= 8-slot attention is negligible)"))
     # ---- fused Swin MLP (swin_mlp2.hip): 16 M C^2 per launch (fc1 + fc2), M = tokens of the stage
     mlp = [(k, v) for k, v in per.items() if k.startswith("swin_mlp_c")]
@@ -563,18 +563,19 @@ def _lang_path_once(model, cfg, dev, chunks, iters=5):
 
 
 def lang_path_b64(model, cfg, dev, chunks, iters=5):
-    """The north-star target line at B = 64, twice: under the DEFAULT kernel policy (at this batch the size rules of
-    KERNELS["BERT_ATTN_QKV_FUSED"] / ["GCP_ATTN_FUSED"] = 1 pick the library GEMM + attention launches: the fused kernels are slower there) and
-    with the two fused text kernels FORCED (= 2): the record the north-star's "fused GCP + BERT attention" asks about."""
+    """The north-star target line at B = 64, twice: under the DEFAULT kernel policy (since the weights of the two fused text kernels are
+    streamed in MFMA B-fragment order -- GPU call 17 of round 5 -- the size rules of KERNELS["BERT_ATTN_QKV_FUSED"] / ["GCP_ATTN_FUSED"] = 1 take
+    them at this batch: the north-star's "fused GCP + BERT attention") and with both OFF (= 0: the library GEMMs + the round-4 attention
+    launches) for comparison."""
     from mq_det_amd import ops
     res = _lang_path_once(model, cfg, dev, chunks, iters)
     saved = (ops.KERNELS["BERT_ATTN_QKV_FUSED"], ops.KERNELS["GCP_ATTN_FUSED"])
     try:
-        ops.KERNELS["BERT_ATTN_QKV_FUSED"], ops.KERNELS["GCP_ATTN_FUSED"] = 2, 2
+        ops.KERNELS["BERT_ATTN_QKV_FUSED"], ops.KERNELS["GCP_ATTN_FUSED"] = 0, 0
         forced = _lang_path_once(model, cfg, dev, chunks, iters)
     finally:
         ops.KERNELS["BERT_ATTN_QKV_FUSED"], ops.KERNELS["GCP_ATTN_FUSED"] = saved
-    res["fused_text_kernels_forced"] = {k: forced[k] for k in ("ms_language_path", "language_path_frac_of_mfma_peak", "attention_kernels_ms", "attention_tflops",
+    res["fused_text_kernels_off"] = {k: forced[k] for k in ("ms_language_path", "language_path_frac_of_mfma_peak", "attention_kernels_ms", "attention_tflops",
                                                                  "attention_mfma_utilisation", "bert_fused_launches", "flops", "kernels_ms")}
     return res
 

@@ -16,8 +16,8 @@
 //   4  LN_g(sup) -> LDS;   5  h = LN_g(sup) Wg1^T (768 -> 384), gelu, dot with w2 reduced over lanes and waves in a fixed order, tanh;
 //   6  x_out = x + gate * sup (fp32 stream), and the LayerNorm the feed-forward half reads next (y, 16-bit).
 // Rounding points are those of the unfused chain (every GEMM output / LayerNorm output rounded to the operand type once).
-// Weights are streamed per workgroup (2.1 MB from L2): RB = 16 rows for small batches (72 workgroups at B = 8: the chip is latency-bound
-// there anyway), RB = 32 for large ones (half the weight traffic per row).
+// Weights are streamed per workgroup (2.1 MB from L2, in MFMA B-fragment order -- see gf_rows_gemm): RB = 16 rows for small batches (72
+// workgroups at B = 8), RB = 32 for large ones (half the weight traffic per row).
 #include "common.h"
 #include <type_traits>
 
