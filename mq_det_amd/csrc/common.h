@@ -14,8 +14,9 @@
 // MQ_SYM / MQ_NAMESPACE_* expand to nothing: the fp16 objects are token-for-token what they were before the switch existed.
 #if defined(MQ_F32)
 // fp32-OPERAND build (the "precise mode", MODEL.COMPUTE_DTYPE = "float32"; entry points *_f32, namespace mq_f32): every 16-bit operand of
-// the kernel sources is a float and one 16x16x32 MFMA is eight v_mfma_f32_16x16x4_f32 on the same lane layout (mfma16 below).  What is
-// left between such a run and the fp32 reference is summation order, not operand rounding: the north-star's 1e-3 end to end.
+// the kernel sources is a float and one 16x16x32 MFMA is THREE fp16 MFMAs on the split operands hi + lo (mfma16 below; round 5: eight
+// v_mfma_f32_16x16x4_f32, still there under -DMQ_F32_EXACT).  What is left between such a run and the fp32 reference is summation order and
+// 2^-22 per operand, not fp16 operand rounding: the north-star's 1e-3 end to end.
 typedef float half_t;
 typedef float half8 __attribute__((ext_vector_type(8)));
 typedef float half4 __attribute__((ext_vector_type(4)));
@@ -56,8 +57,45 @@ typedef float float2_ __attribute__((ext_vector_type(2)));
 
 #define MQ_NEG_BIG (-1.0e30f)
 
+#if defined(MQ_F32) && !defined(MQ_F32_EXACT)
+// The SPLIT-PRECISE contraction (round 6; VERDICT r5 #1b).  An fp32 operand x is carried through the fp16 matrix cores as x = hi + lo / 2^11:
+//   hi = fp16(x)                      (11 significant bits, round to nearest even)
+//   lo = fp16((x - hi) * 2^11)        (x - hi is exact in fp32; the power-of-two pre-scale keeps lo a NORMAL fp16 number wherever hi is one)
+// and a . b ~ hi_a hi_b + (hi_a lo_b + lo_a hi_b) / 2^11: three v_mfma_f32_16x16x32_f16 with fp32 accumulation on the SAME fragments and the
+// same accumulator layout.  Every fp16 x fp16 product is exact in fp32 (22 bits); what is dropped is lo_a lo_b (2^-22 relative) and the
+// rounding of lo (2^-22 relative): operands to ~22 bits instead of fp16's 11 -- at 3/16 of the fp16 matrix rate instead of the 1/16 of eight
+// v_mfma_f32_16x16x4_f32 (kept under -DMQ_F32_EXACT).  Range = fp16's (|x| <= 65504), like the 16-bit builds of the same kernels.
+typedef _Float16 mq_h16x8 __attribute__((ext_vector_type(8)));
+struct mq_split8 { mq_h16x8 hi, lo; };
+__device__ __forceinline__ mq_split8 mq_split(half8 x) {
+  mq_split8 s;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const _Float16 h = (_Float16)x[i];
+    s.hi[i] = h;
+    s.lo[i] = (_Float16)(__builtin_fmaf((float)h, -1.0f, x[i]) * 2048.0f);
+  }
+  return s;
+}
+__device__ __forceinline__ float4_ mfma16_split(const mq_split8& a, const mq_split8& b, float4_ c) {
+  float4_ t = {0.f, 0.f, 0.f, 0.f};
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c, 0, 0, 0);
+  t = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.lo, t, 0, 0, 0);
+  t = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.lo, b.hi, t, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[r] = __builtin_fmaf(t[r], 1.0f / 2048.0f, c[r]);
+  return c;
+}
+#endif
+
 __device__ __forceinline__ float4_ mfma16(half8 a, half8 b, float4_ c) {
-#if defined(MQ_F32)
+#if defined(MQ_F32) && !defined(MQ_F32_EXACT)
+#if defined(MQ_SIMT_EMULATION)
+  return simt_mfma_16x16x32_split(a, b, c);         // tests/simt: the same split and the same three products, one lane exchange instead of three
+#else
+  return mfma16_split(mq_split(a), mq_split(b), c); // the splits of a fragment that feeds several MFMAs are common subexpressions: computed once
+#endif
+#elif defined(MQ_F32)
   // v_mfma_f32_16x16x4_f32: lane l holds A[l & 15][k = l >> 4] and B[k = l >> 4][l & 15]; step j contracts the k values 8 g + j (g = l >> 4)
   // of the 16x16x32 fragments, so the eight steps together are the same 32-deep contraction with exact fp32 products
 #if defined(MQ_SIMT_EMULATION)

@@ -79,9 +79,10 @@ class FixedAPAccumulator:
         return rows[rank < self.topk]
 
     # ------------------------------------------------------------------ exchange
-    def synchronize_between_processes(self, group=None):
+    def synchronize_between_processes(self, group=None, force=False):
+        """`force`: run the two collectives even in a one-rank group (the one-GPU RCCL test; a one-rank job otherwise has nothing to exchange)."""
         self._fold()
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
             return
         world = dist.get_world_size(group)
         n = torch.tensor([len(self.rows)], dtype=torch.long, device=self.device)

@@ -298,8 +298,10 @@ def _fn(lib, name, *ts):
     """The entry point for the operand type of `ts`: `name` (fp16), `name_bf16` (the same kernel compiled with bf16 operands,
     include/mqdet_hip.h MQ_BF16_TWIN) or, in the precise mode, `name_f32` (fp32 operands).  All operands of one call must have the same type."""
     if KERNELS.get("F32_OPERANDS", 0):
-        return getattr(lib, name + "_f32")
-    kinds = {t.dtype for t in ts if t is not None and t.dtype in _H16}
+        # ADVICE r5: ROIAlign / MSDeformAttn have no *_f32 twin (build.py F32_SKIP) -- their base entry points take fp32 features through the
+        # is_f32 flag -- so the precise mode binds the base symbol for them instead of raising AttributeError in extract_query()
+        return getattr(lib, name + "_f32") if name in F32_TWINS else getattr(lib, name)
+    kinds = {t.dtype for t in ts if t is not None and t.dtype in (torch.float16, torch.bfloat16)}
     if len(kinds) > 1:
         raise TypeError(f"{name}: fp16 and bf16 operands in one call")
     return getattr(lib, name + "_bf16") if torch.bfloat16 in kinds else getattr(lib, name)

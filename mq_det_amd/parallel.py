@@ -38,9 +38,10 @@ def pack_detections(boxes, scores, labels):
     return torch.cat([boxes.float(), scores.float()[..., None], labels.float()[..., None]], -1).contiguous()
 
 
-def gather_detections(packed):
-    """All ranks receive [world * B_local, K, 6] (rank-major order).  Single fixed-shape collective."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+def gather_detections(packed, force=False):
+    """All ranks receive [world * B_local, K, 6] (rank-major order).  Single fixed-shape collective.  `force`: issue the collective even in a
+    one-rank group (the one-GPU RCCL test of tests/test_gpu_parity.py; a one-rank job otherwise skips it)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return packed
     world = dist.get_world_size()
     out = packed.new_empty((world * packed.shape[0],) + tuple(packed.shape[1:]))

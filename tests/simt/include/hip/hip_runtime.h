@@ -289,6 +289,40 @@ inline simt_float4 simt_mfma_16x16x32_f32_8x4(V8 a, V8 b, simt_float4 c) {
     }
   return c;                                          // (the buffer is refilled by the NEXT exchange's tile function, which runs once every lane has arrived there)
 }
+// mfma16 of the SPLIT-PRECISE build (csrc/common.h, round 6): every fp32 operand x = hi + lo / 2^11 with hi = fp16(x), lo = fp16((x - hi) 2^11);
+// the device issues v_mfma_f32_16x16x32_f16 on (hi_a, hi_b) into the accumulator and on (hi_a, lo_b), (lo_a, hi_b) into a zeroed second one that is
+// added scaled by 2^-11.  Here: ONE lane exchange of the fp32 fragments (simt_mfma_8x4_tile's buffer), the split and the three products per lane.
+template <class V8>
+inline simt_float4 simt_mfma_16x16x32_split(V8 a, V8 b, simt_float4 c) {
+  static_assert(sizeof(V8) == 32, "fp32-operand fragments");
+  const int buf = simt::next_buf(), l = simt::lane();
+  uint64_t* s = simt::xslot(l, buf);
+  memcpy(s, &a, 32);
+  memcpy(s + 4, &b, 32);
+  simt::wave_sync_then(&simt_mfma_8x4_tile, (void*)(intptr_t)buf);
+  const float* A = simt::wave_tile32();
+  const float* B = A + 512;
+  const int col = l & 15, r0 = 4 * (l >> 4);
+  float bh[32], bl[32];
+  for (int k = 0; k < 32; ++k) {
+    const float x = B[k * 16 + col];
+    const _Float16 h = (_Float16)x;
+    bh[k] = (float)h;
+    bl[k] = (float)(_Float16)((x - (float)h) * 2048.0f);
+  }
+  for (int r = 0; r < 4; ++r) {
+    float main = 0.f, cross = 0.f;
+    for (int k = 0; k < 32; ++k) {
+      const float x = A[(r0 + r) * 32 + k];
+      const _Float16 h = (_Float16)x;
+      const float ah = (float)h, al = (float)(_Float16)((x - ah) * 2048.0f);
+      main += ah * bh[k];
+      cross += ah * bl[k] + al * bh[k];
+    }
+    c[r] = (c[r] + main) + cross * (1.0f / 2048.0f);
+  }
+  return c;
+}
 inline int __lane_id() { return simt::lane(); }
 
 // ds_read_b64_tr_b16: inside each 16-lane group the 16 x 4 block of 16-bit elements addressed by the lanes (lane i: row i >> 2,

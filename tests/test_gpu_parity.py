@@ -222,6 +222,27 @@ def test_hip_graph_capture_with_process_group(dev):
             dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("world", [1, 2])
+def test_detection_and_evaluator_gather_over_rccl(dev, world):
+    """SURVEY 8(e) / 8(f-4) on the device: the fixed-shape all-gather of detections (also one step behind: OverlappedGather) and
+    the evaluator's top-k exchange run over RCCL with their state in HBM -- one rank here (the collectives are forced), and two ranks on the
+    first box that has two GPUs (skipped below that), one process per GPU under torch.distributed.run like bench.py --gpus N."""
+    import socket
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"{world} GPUs needed, {torch.cuda.device_count()} visible")
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = str(s_.getsockname()[1])
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rccl_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", port, script], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("RCCL_GATHER_OK") == world
+
+
 @pytest.mark.parametrize("caption,hw", [("short", ((800, 1333), (736, 1280))), ("long", ((800, 1333),))],
                          ids=["81-token-caption-B2", "141-token-caption-B1"])
 def test_benchmark_configuration_parity(dev, caption, hw):
@@ -670,7 +691,8 @@ def _assert_f32(res):
 
 @pytest.mark.parametrize("name", ["check_attention_strided", "check_window_attention", "check_swin_fpn", "check_vlfuse_kernels", "check_dcn", "check_layernorm",
                                   "check_swin_mlp", "check_gcp_block", "check_pre_select", "check_vl_fuse", "check_dyconv", "check_conv3x3",
-                                  "check_align_fused", "check_attention_text", "check_bert_attn_qkv", "check_gcp_attn_fused", "check_patch_embed", "check_bert_clamp_fused"])
+                                  "check_align_fused", "check_attention_text", "check_bert_attn_qkv", "check_gcp_attn_fused", "check_patch_embed", "check_bert_clamp_fused",
+                                  "check_roi_align", "check_extract_query"])
 def test_f32_block(dev, f32, name):
     _assert_f32(getattr(f32, name)(dev))
 

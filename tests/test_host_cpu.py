@@ -232,6 +232,18 @@ def test_gloo_world2_detection_gather():
     assert r.stdout.count("GATHER_OK") == 2
 
 
+def test_rccl_worker_dry_run_over_gloo():
+    """tests/_rccl_worker.py is what the GPU suite starts over RCCL (one rank on a one-GPU box, two on the first box that has two): the same script,
+    CPU tensors, gloo, two ranks -- the detection gather (also one step behind) and the evaluator exchange against per-rank expectations."""
+    script = os.path.join(ROOT, "tests", "_rccl_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", MQ_WORKER_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29543", script],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("RCCL_GATHER_OK") == 2
+
+
 def test_bench_gpus_flag_starts_the_ranks():
     """`python bench.py --gpus 2` (no launcher around it) starts 2 ranks itself; the line says n_gpus = 2 and the one
     fixed-shape gather of the data path ran across them (--dry-launch: no kernels, gloo).  A rank count that differs from --gpus is
@@ -331,6 +343,37 @@ def test_bench_roofline_records_are_per_kernel_and_read_the_newest_pmc_file():
     best = max(single, key=lambda r: r["ms_per_step"])
     assert best["kernel"].startswith("dcn_igemm8_kernel") and best["traffic"] == pmc["dcn_igemm8_kernel"]
     assert {r["kernel"].split(" ")[0] for r in single} >= {"dcn_igemm8_kernel", "vlfuse_i2t_kernel", "vlfuse_t2i_kernel", "swin_mlp2_kernel"}
+
+
+def test_bench_prints_one_short_line_and_moves_the_rest_to_the_extras_file(tmp_path):
+    """the driver could not parse round 5's 20 KB line.  The stdout line carries the contract fields, ONE roofline record and the CPU
+    baseline in < 4 KB whatever the run collected; the full record goes to bench_extras.json."""
+    import importlib
+    import json
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    with open(os.path.join(ROOT, "profiles", "r05_final_bench_default.json")) as f:        # a real, 20 KB record of the previous round
+        full = json.loads(f.read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 15000
+    full["rooflines"] = full["rooflines"] * 4                                              # and it may grow
+    extras = tmp_path / "bench_extras.json"
+    line = bench.compact_line(full, extras_path=str(extras))
+    assert "\n" not in line and len(line) < 4096
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert k in d, k
+    assert d["config"]["workload"] and "model" not in d["config"]
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["bound"] in ("mfma", "hbm") and "traffic" in d["roofline"] and d["roofline"]["peak"]
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["kind"] in ("port", "reference")
+    assert d["extras_file"] == "bench_extras.json" and json.loads(extras.read_text())["rooflines"] == full["rooflines"]
+    # a sub-run (--no-extras) neither writes nor names a file
+    os.remove(extras)
+    d2 = json.loads(bench.compact_line(full, extras_path=str(extras), write=False))
+    assert not extras.exists() and "extras_file" not in d2
+    # a pathological record still yields a parseable line under the limit
+    full["config"] = {k: "x" * 5000 for k in "abcdefgh"}
+    full["config"]["workload"] = "w" * 5000
+    assert len(bench.compact_line(full, extras_path=str(extras))) < 4096
 
 
 def test_vlfuse_text_side_key_split_counts_passes_per_xcd():
