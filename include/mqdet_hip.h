@@ -516,12 +516,12 @@ MQ_BF16_TWIN(mq_msdeform_attn_q_fwd)
 
 /* ---- fp32 operands: the PRECISE mode (MODEL.COMPUTE_DTYPE = "float32"; BASELINE.json north_star: "outputs ... match the reference ...
  * within 1e-3").  `name_f32` is the SAME kernel source compiled a third time with every 16-bit operand a float (csrc/common.h under
- * -DMQ_F32: one 16x16x32 MFMA = eight v_mfma_f32_16x16x4_f32 on the same lane layout; ds_read_b64_tr_b16 and the LDS-DMA copies replaced by
- * their element-size-independent forms), same arguments and return codes with "fp16" read as "fp32" and every 16-bit LDS tile twice as
+ * -DMQ_F32: one 16x16x32 MFMA = THREE v_mfma_f32_16x16x32_f16 on the operands split as x = hi + lo / 2^11 (hi = fp16(x), lo = fp16((x - hi) 2^11):
+ * ~22 operand bits, fp32 accumulation; round 5's eight v_mfma_f32_16x16x4_f32 are still there under -DMQ_F32_EXACT) on the same lane layout;
+ * ds_read_b64_tr_b16 and the LDS-DMA copies replaced by their element-size-independent forms), same arguments and return codes with "fp16" read as "fp32" and every 16-bit LDS tile twice as
  * large -- a launch whose tiles exceed the 160 KB of a CU returns hipErrorInvalidValue (1); mq_det_amd/ops.py picks the shapes / variants
- * that fit.  A quarter of the MFMA rate: this build exists to SHOW parity with the fp32 reference on the device (tests/, bench.py
- * `precise_mode`), not for throughput.  No twin: the operators whose inputs may already be fp32 in the 16-bit builds (mq_roi_align_fwd,
- * mq_msdeform_attn_*). */
+ * that fit.  3/16 of the fp16 MFMA rate and twice the bytes: this build is the configuration that meets the north-star's 1e-3 end to end (tests/, bench.py
+ * `split_precise`).  No twin: mq_roi_align_fwd (its features may already be fp32 in the 16-bit builds: is_f32 flag). */
 #ifdef __cplusplus
 #define MQ_F32_TWIN(name) extern decltype(name) name##_f32;
 #else
@@ -564,6 +564,8 @@ MQ_F32_TWIN(mq_add_upsample_nearest)
 MQ_F32_TWIN(mq_align_scores_fwd)
 MQ_F32_TWIN(mq_align_fused_fwd)
 MQ_F32_TWIN(mq_box_decode)
+MQ_F32_TWIN(mq_msdeform_attn_fwd)
+MQ_F32_TWIN(mq_msdeform_attn_q_fwd)
 
 #ifdef __cplusplus
 }

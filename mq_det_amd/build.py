@@ -9,7 +9,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libmqdet_hip.so")
 SOURCES = ["api.hip", "attn.hip", "attn_resident.hip", "attn_text.hip", "bert_attn.hip", "vlfuse_attn.hip", "window_attn.hip", "patch_embed.hip", "gcp.hip", "gcp_fused.hip", "conv_igemm.hip", "conv_small.hip", "conv_small2.hip", "conv_small3.hip", "dcn_fused.hip", "layernorm.hip", "layernorm2.hip", "dyconv.hip", "post.hip", "post2.hip", "align_fused.hip", "nms2.hip", "roi_align.hip", "swin_mlp2.hip", "msda.hip"]
 # no fp32-operand twin (include/mqdet_hip.h MQ_F32_TWIN): operators whose inputs may already be fp32, and the sources that only hold fp32 / integer code (one copy, in the fp16 unit)
-F32_SKIP = ("msda.hip", "roi_align.hip", "nms2.hip", "post2.hip")
+F32_SKIP = ("roi_align.hip", "nms2.hip", "post2.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # dcn_fused.hip: without the SLP vectoriser the bilinear blend compiles to v_fma_mix_f32 / v_fma_mixlo_f16 (fp16 operands,
 # fp32 accumulate, no separate converts) instead of cvt + v_pk_fma_f32 -- 40 % fewer VALU cycles next to the MFMAs

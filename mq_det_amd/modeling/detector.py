@@ -19,7 +19,7 @@ from .. import ops as _ops
 from ..structures import BoxList, to_image_list
 from . import pipeline
 from .poolers import CustomPooler, Pooler
-from .graph_runner import GraphRunner
+from .graph_runner import GraphRunner, memoised
 from .params import Container, build_param_tree
 from .query_selector import QuerySelector, labels_and_maps, build_token_index
 
@@ -239,7 +239,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
             # host-side bound of the per-caption key length (last attended position + 1): picks the kernel variant of
             # the VLFuse image-side attention, and is part of the HIP-graph key
             max_kv = int((am * torch.arange(1, am.shape[1] + 1)).max())
-            hit = (tok["input_ids"].to(device), am.to(device), max_kv)
+            hit = (memoised(tok["input_ids"].to(device)), memoised(am.to(device)), max_kv)
             if len(self._tok_cache) > 256:
                 self._tok_cache.clear()
             self._tok_cache[key] = hit
@@ -249,6 +249,10 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
         """Text positions the device programs run on: 16 ceil(max_kv / 16) (the key-block granularity of the attention kernels; VLFuse takes
         T % 8 == 0), or all T when the bound is unknown or MODEL.LANGUAGE_BACKBONE.COMPACT_TEXT is off."""
         if max_kv <= 0 or not self.cfg.MODEL.LANGUAGE_BACKBONE.get("COMPACT_TEXT", True):
+            return T
+        if self.cfg.VISION_QUERY.get("RETURN_ATTN_GATE_VALUE", False):
+            # ADVICE r5: the reference's attn_gate.mean() averages over all B x MAX_QUERY_LEN positions (padded rows contribute the constant
+            # tanh(gate(LN(0)))): the diagnostic value is only the reference's when every padded row is computed -- no compaction with it
             return T
         return min(T, -(-int(max_kv) // 16) * 16)
 
@@ -260,6 +264,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
         if hit is None:
             hit = (input_ids[:, :Tl].contiguous(), attention_mask[:, :Tl].contiguous())
             if key is not None:
+                memoised(hit)
                 if len(self._live_cache) > 256:
                     self._live_cache.clear()
                 self._live_cache[key] = hit
@@ -518,15 +523,15 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
                 hit = build_token_index({j + 1: [j] for j in range(n)}, list(range(1, n + 1)), dev)
             else:
                 hit = build_token_index(positive_map, labels_in_caption, dev)
-            self._tokidx_cache[tk] = hit
+            self._tokidx_cache[tk] = memoised(hit)
         tokidx, label_ids = hit
         wh_key = (tuple(images.image_sizes), str(dev))
         im_wh = self._wh_cache.get(wh_key)
         if im_wh is None:
             if len(self._wh_cache) > 256:
                 self._wh_cache.clear()
-            im_wh = self._wh_cache[wh_key] = torch.tensor([[w, h] for (h, w) in images.image_sizes],
-                                                          dtype=torch.float32, device=dev)
+            im_wh = self._wh_cache[wh_key] = memoised(torch.tensor([[w, h] for (h, w) in images.image_sizes],
+                                                                   dtype=torch.float32, device=dev))
         tail = (input_ids, attention_mask, vision, idx, tokidx, label_ids, im_wh, max_kv)
         if return_raw:
             x = images.tensors.to(dtype).contiguous(memory_format=torch.channels_last)
@@ -667,7 +672,10 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
                     pm = {k: [t for t in (v if not isinstance(v, int) else [v]) if t < T] for k, v in pm.items()}
                 ids.append(i)
                 ams.append(a)
-                kvs.append(max(kv, 1 + max((t for v in pm.values() for t in (v if not isinstance(v, int) else [v])), default=-1)) if kv > 0 else kv)
+                kv_pm = max(kv, 1 + max((t for v in pm.values() for t in (v if not isinstance(v, int) else [v])), default=-1))
+                if str(cfg.MODEL.DYHEAD.get("SCORE_AGG", "MEAN")).upper() == "ONEHOT":
+                    kv_pm = max(kv_pm, len(pm))                   # class column j scores token j (forward() widens the same way)
+                kvs.append(min(kv_pm, T) if kv > 0 else kv)
                 pms.append(pm)
                 labs.append([k for k, v in pm.items() if len(v) != 0])
             T = self._live_len(ids[0].shape[1], max(kvs) if min(kvs) > 0 else 0)          # live-row compaction (see forward): the group's longest caption
@@ -689,7 +697,7 @@ class GeneralizedVLRCNN_New(GraphRunner, nn.Module):
                      "key_bias": rep(torch.cat([live(f["key_bias"]) for f in fronts])), "kv_len": rep(torch.cat([f["kv_len"] for f in fronts])),
                      "next": fronts[0]["next"]}
             if str(cfg.MODEL.DYHEAD.get("SCORE_AGG", "MEAN")).upper() == "ONEHOT":      # class column j = token j, label j + 1
-                smaps = [({j + 1: [j] for j in range(len(pm))}, list(range(1, len(pm) + 1))) for pm in pms]
+                smaps = [({j + 1: [j] for j in range(min(len(pm), T))}, list(range(1, min(len(pm), T) + 1))) for pm in pms]
             else:
                 smaps = list(zip(pms, labs))
             L = max(1, max(len(l) for _, l in smaps))

@@ -114,9 +114,6 @@ class GroundingDINO(GraphRunner, nn.Module):
         from .. import ops
         ops.load_library()
         self._kernels = dict(ops.configure(self.cfg))              # kernel selection: read once per plan, kept WITH the plan
-        if compute_dtype(self.cfg) == torch.float32:
-            raise NotImplementedError("MODEL.COMPUTE_DTYPE = float32 (the precise mode) is built for the MQ-GLIP path; MQ-GroundingDINO's sampling "
-                                      "kernels (mq_msdeform_attn_*) have no fp32-operand twin")
         self._plan = gp.build_gdino_plan(self.state_dict(), self.cfg, device, self._swin, dtype=compute_dtype(self.cfg))
         self._plan_key = device
         return self._plan

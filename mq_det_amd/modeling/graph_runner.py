@@ -1,7 +1,37 @@
 """HIP-graph replay of a detector's device program, keyed by static shapes (shared by the MQ-GLIP and MQ-GroundingDINO classes)."""
 from collections import OrderedDict
 
+import weakref
+
 import torch
+
+# "same tensor object, same version counter" does not prove "same contents" for arbitrary caller tensors (writes through data_ptr
+# -- this package's own ctypes kernels --, .data, numpy-shared memory do not bump the counter; inference tensors have none).  The copy into a
+# graph's static input buffer is therefore skipped ONLY for tensors the detector itself created and memoised on the host side of a caption
+# (token ids, masks, the query-bank selection, the label -> token index, image sizes): they are registered here when they are cached and never
+# written afterwards.  id -> weak reference (Tensor.__eq__ is element-wise: no WeakSet).
+_MEMOISED = {}
+
+
+def memoised(obj):
+    """Register every tensor inside `obj` (tensor / tuple / list / dict) as an immutable, detector-owned memo; returns `obj`."""
+    if torch.is_tensor(obj):
+        if len(_MEMOISED) > 4096:
+            for k in [k for k, r in _MEMOISED.items() if r() is None]:
+                del _MEMOISED[k]
+        _MEMOISED[id(obj)] = weakref.ref(obj)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            memoised(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            memoised(v)
+    return obj
+
+
+def is_memoised(t):
+    r = _MEMOISED.get(id(t))
+    return r is not None and r() is t
 
 
 class GraphRunner:
@@ -26,16 +56,18 @@ class GraphRunner:
 
     @staticmethod
     def _tree_copy_(dst, src, seen=None, path=()):
-        """Copy the caller's tensors into the graph's static input buffers.  `seen` (one dict per captured graph): a SMALL input that is the very
-        tensor object of the previous replay, unmodified since (torch's version counter) -- the memoised host-side operands of a caption: token ids,
-        masks, the query bank selection, the label -> token index, image sizes -- is already there: no copy launch.  Large inputs (the pixels, cached
-        feature maps) are always copied."""
+        """Copy the caller's tensors into the graph's static input buffers.  `seen` (one dict per captured graph): a SMALL input that the detector itself
+        memoised (`memoised()` above: token ids, masks, the query bank selection, the label -> token index, image sizes -- never written after they
+        are cached) and that is the very tensor object of the previous replay with an unchanged version counter is already there: no copy launch.
+        Every other input (the pixels, cached feature maps, any tensor a caller hands in) is always copied."""
         if torch.is_tensor(dst):
-            if seen is not None and src.numel() <= GraphRunner.SKIP_COPY_MAX_NUMEL:
+            if seen is not None and src.numel() <= GraphRunner.SKIP_COPY_MAX_NUMEL and is_memoised(src) and not src.is_inference():
                 prev = seen.get(path)
                 if prev is not None and prev[0] is src and prev[1] == src._version:
                     return
                 seen[path] = (src, src._version)          # (a strong reference: an id cannot be recycled while it is the comparison's left side)
+            elif seen is not None:
+                seen.pop(path, None)
             dst.copy_(src, non_blocking=True)
         elif isinstance(dst, dict):
             for k in dst:

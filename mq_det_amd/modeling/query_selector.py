@@ -145,7 +145,8 @@ class QuerySelector(nn.Module):
         if hit is None:
             if len(self._sel_cache) > 128:
                 self._sel_cache.clear()
-            hit = self._sel_cache[k] = self.select([labels] * B, [positive_map] * B, T, device, dtype)
+            from .graph_runner import memoised
+            hit = self._sel_cache[k] = memoised(self.select([labels] * B, [positive_map] * B, T, device, dtype))
         return hit
 
     def forward(self, batched_label_list, batched_location_map, batched_pos_labels=None):

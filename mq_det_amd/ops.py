@@ -72,9 +72,9 @@ BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_text_fwd", "mq_ber
               "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_layernorm_clamp_fwd", "mq_clamp_gelu_clamp", "mq_patch_merge_ln_fwd", "mq_swin_mlp2_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_conv3x3_nchw32_group_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
               "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyconv_epilogue_group", "mq_dyrelu_apply", "mq_dyrelu_ln_fwd", "mq_add_upsample_nearest",
               "mq_align_scores_fwd", "mq_align_fused_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
-# ... and as <name>_f32 (fp32 operands, the precise mode), except the operators whose inputs may already be fp32 in the 16-bit modes
-# (query extraction / MQ-GroundingDINO sampling: their two element types would coincide)
-F32_TWINS = tuple(n for n in BF16_TWINS if n not in ("mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd"))
+# ... and as <name>_f32 (fp32 operands, the precise mode), except ROIAlign: its base entry point already takes fp32 features (is_f32 flag) and has
+# no other 16-bit operand.  (Round 6: the MSDeformAttn kernels have the twin -- the fused-query form reads a 16-bit `qproj`, a float there.)
+F32_TWINS = tuple(n for n in BF16_TWINS if n not in ("mq_roi_align_fwd",))
 for _n in BF16_TWINS:
     _SIGNATURES[_n + "_bf16"] = _SIGNATURES[_n]
 for _n in F32_TWINS:

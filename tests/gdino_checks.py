@@ -158,7 +158,7 @@ def gdino_model(dev, spec, seed=0):
     if key not in _CACHE:
         sd = make_gdino_state_dict(spec, seed=seed)
         cfg = gdino_cfg(spec, _tokenizer_dir(spec.vocab))
-        cfg.MODEL.COMPUTE_DTYPE = "bfloat16" if pc.H16 == torch.bfloat16 else "float16"
+        cfg.MODEL.COMPUTE_DTYPE = {torch.bfloat16: "bfloat16", torch.float32: "float32"}.get(pc.H16, "float16")
         model = build_detection_model(cfg)
         model.load_state_dict(sd, strict=True)
         model.to(dev)

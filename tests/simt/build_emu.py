@@ -24,7 +24,7 @@ FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-fno-strict-aliasing", "-Wn
 
 # not built with fp32 operands: the MQ-GroundingDINO / query-extraction operators (their inputs may already be fp32 -- the two template
 # arguments would coincide) and the superseded first Swin MLP kernel
-F32_SKIP = ("msda.cpp", "roi_align.cpp", "nms2.cpp", "post2.cpp")
+F32_SKIP = ("roi_align.cpp", "nms2.cpp", "post2.cpp")
 _SHARED = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([A-Za-z_][\w\s]*?)\s+(\w+)\s*\[\s*\]\s*;")
 
 

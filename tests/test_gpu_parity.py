@@ -683,7 +683,8 @@ def f32():
 def _assert_f32(res):
     res = res if isinstance(res, list) else [res]
     _assert(res)
-    loose = [r for r in res if r["tol"] > 1e-3 and "detections" not in r["name"]]
+    # set-valued rows (matched detections, the two-stage top-k overlap, replay-vs-eager matches) carry a fraction, not a normalised error
+    loose = [r for r in res if r["tol"] > 1e-3 and not any(t in r["name"] for t in ("detections", "two-stage top-", "HIP-graph replay"))]
     assert not loose, "rows gated above 1e-3 in the precise mode: " + ", ".join(r["name"] for r in loose)
     viol = [r for r in res if not r.get("elem_ok", True)]
     assert not viol, "elements outside atol = rtol = 1e-3: " + ", ".join(f"{r['name']} ({r['elem_viol_frac']:.1e})" for r in viol)
@@ -711,6 +712,18 @@ def test_f32_fusion_layer_at_the_benchmark_geometry(dev, f32):
     """One fusion layer (VLFuse both ways, clamped BERT layer, DyConv / DCNv2) on the 22 400 pyramid tokens of an 800 x 1333 image, 141 live
     text tokens: 1e-3 at every output, on the device."""
     _assert_f32(f32.check_fusion_layer(dev))
+
+
+def test_f32_groundingdino(dev, f32):
+    """the split-precise mode for MQ-GroundingDINO (groundingdino.py:438-661; the reference forces fp32 inside MSDeformAttn,
+    ms_deform_attn.py:330-336): sampling kernels, the shallow model and the FULL-DEPTH model at 800 x 1333 (6 + 6 layers, 900 queries, 40 classes x
+    5 vision queries) -- every stage within 1e-3 of the oracle's range, no element outside atol = rtol = 1e-3."""
+    import gdino_checks as gc
+    _assert_f32(gc.check_msdeform_attn_q(dev))
+    _assert_f32(gc.check_attention_qk_mask(dev))
+    _assert_f32(gc.check_vlfuse_heads_mask(dev))
+    _assert_f32(gc.check_gdino_model(dev, vq=True, graph=False))
+    _assert_f32(gc.check_gdino_benchmark_config(dev))
 
 
 def test_f32_benchmark_configuration_parity(dev, f32):

@@ -160,17 +160,19 @@ def test_live_row_compaction_policy_and_raw_padding():
 
 
 def test_replay_input_copies_skip_only_unmodified_small_tensors():
-    """GraphRunner._tree_copy_: a small input that is the very tensor object of the previous replay, unmodified (version counter), is not copied
-    again; a modified one, another object, or a large one is."""
-    from mq_det_amd.modeling.graph_runner import GraphRunner
-    small, big = torch.arange(8.0), torch.zeros(GraphRunner.SKIP_COPY_MAX_NUMEL + 1)
+    """GraphRunner._tree_copy_: a small input that the detector itself memoised (graph_runner.memoised: token ids, masks, selections, ...), that is
+    the very tensor object of the previous replay and unmodified (version counter) is not copied again; a modified one, another object, a large one
+    -- and ANY tensor that is not a registered memo (a caller's tensor may have been written through data_ptr / .data without a version
+    bump; inference tensors have no counter) -- is."""
+    from mq_det_amd.modeling.graph_runner import GraphRunner, memoised, is_memoised
+    small, big = memoised(torch.arange(8.0)), torch.zeros(GraphRunner.SKIP_COPY_MAX_NUMEL + 1)
     dst = {"a": torch.zeros(8), "b": [torch.zeros_like(big)]}
     seen = {}
     GraphRunner._tree_copy_(dst, {"a": small, "b": [big]}, seen)
     assert torch.equal(dst["a"], small) and ("a",) in seen and ("b", 0) not in seen
     dst["a"].zero_()                                                   # (stands for: the static buffer already holds the value -- a skipped copy leaves it alone)
     GraphRunner._tree_copy_(dst, {"a": small, "b": [big]}, seen)
-    assert float(dst["a"].abs().sum()) == 0                            # same object, same version: skipped
+    assert float(dst["a"].abs().sum()) == 0                            # same memoised object, same version: skipped
     small.add_(1)                                                      # in-place write bumps the version counter
     GraphRunner._tree_copy_(dst, {"a": small, "b": [big]}, seen)
     assert torch.equal(dst["a"], small)
@@ -181,6 +183,21 @@ def test_replay_input_copies_skip_only_unmodified_small_tensors():
     big[0] = 5.0
     GraphRunner._tree_copy_(dst, {"a": other, "b": [big]}, seen)
     assert float(dst["b"][0][0]) == 5.0                                # large tensors: always
+    # a caller's own small tensor: copied on EVERY replay, also when nothing visible changed (a .data write does not bump the counter)
+    mine = torch.arange(8.0)
+    assert not is_memoised(mine)
+    GraphRunner._tree_copy_(dst, {"a": mine, "b": [big]}, seen)
+    mine.data[0] = 77.0
+    GraphRunner._tree_copy_(dst, {"a": mine, "b": [big]}, seen)
+    assert float(dst["a"][0]) == 77.0
+    with torch.inference_mode():                                       # inference tensors have no version counter: must not raise, must copy
+        inf = torch.arange(8.0) + 3
+        GraphRunner._tree_copy_(dst, {"a": inf, "b": [big]}, seen)
+        GraphRunner._tree_copy_(dst, {"a": memoised(inf), "b": [big]}, seen)
+    assert float(dst["a"][0]) == 3.0
+    # nested memos (the query-bank selection is a tuple)
+    pair = memoised((torch.zeros(2), {"k": torch.ones(2)}))
+    assert is_memoised(pair[0]) and is_memoised(pair[1]["k"])
 
 
 def test_b_fragment_order_is_the_headers_formula():

@@ -38,8 +38,22 @@ def f32(request):
         self._plan = pipeline.build_plan(self.state_dict(), self.cfg, CPU, dtype=torch.float32)
         self._plan_key, self.use_hip_graph = CPU, False
         return self._plan
+    from mq_det_amd.modeling import gdino, gdino_pipeline as gp
+    import gdino_checks as gc
+
+    def prepare_gdino(self, device=None):
+        from mq_det_amd import ops
+        ops.configure(self.cfg)
+        self._kernels = dict(ops.KERNELS)
+        assert detector.compute_dtype(self.cfg) == torch.float32
+        self._plan = gp.build_gdino_plan(self.state_dict(), self.cfg, CPU, self._swin, dtype=torch.float32)
+        self._plan_key, self.use_hip_graph = CPU, False
+        return self._plan
     saved = (detector.GeneralizedVLRCNN_New.prepare, pc.QUICK, pc.PINS, dict(pc._CACHE))
+    saved_gd = (gdino.GroundingDINO.prepare, dict(gc._CACHE))
     detector.GeneralizedVLRCNN_New.prepare = prepare
+    gdino.GroundingDINO.prepare = prepare_gdino
+    gc._CACHE.clear()
     pc.QUICK, pc.PINS = True, False
     pc.use_dtype(torch.float32)
     pc._CACHE.clear()
@@ -48,6 +62,9 @@ def f32(request):
         yield pc
     pc.use_dtype(torch.float16)
     detector.GeneralizedVLRCNN_New.prepare, pc.QUICK, pc.PINS = saved[:3]
+    gdino.GroundingDINO.prepare = saved_gd[0]
+    gc._CACHE.clear()
+    gc._CACHE.update(saved_gd[1])
     pc._CACHE.clear()
     pc._CACHE.update(saved[3])
 
@@ -55,9 +72,10 @@ def f32(request):
 def _assert_ok(results, tol=1e-3):
     results = results if isinstance(results, list) else [results]
     assert results, "no results"
-    bad = [f"{r['name']}: norm_err {r['norm_err']:.2e} (tol {r['tol']:.1e})" for r in results if not r["ok"] or (r["tol"] > tol and "detections" not in r["name"])]
+    sets = ("detections", "two-stage top-", "HIP-graph replay")            # set-valued rows carry a matched fraction, not a normalised error
+    bad = [f"{r['name']}: norm_err {r['norm_err']:.2e} (tol {r['tol']:.1e})" for r in results if not r["ok"] or (r["tol"] > tol and not any(t in r["name"] for t in sets))]
     assert not bad, "\n".join(bad)
-    return max(r["norm_err"] for r in results if "detections" not in r["name"])
+    return max(r["norm_err"] for r in results if not any(t in r["name"] for t in sets))
 
 
 def test_tiny_full_model_meets_1e_3_with_fp32_operands(f32):
@@ -81,6 +99,20 @@ def test_bert_layers_meet_1e_3_with_fp32_operands(f32):
     if f32._f32_mode == 2:
         pytest.skip("same launches as under device_limits")
     _assert_ok([f32.check_bert_layer(CPU, False), f32.check_bert_layer(CPU, True)])
+
+
+def test_groundingdino_meets_1e_3_with_fp32_operands(f32):
+    """Round 6: MQ-GroundingDINO no longer refuses MODEL.COMPUTE_DTYPE = float32 -- the MSDeformAttn kernels have their *_f32
+    twin (the fused-query form's `qproj` is a float there) and every other kernel of the family already had one.  The sampling kernels and the
+    shallow whole model (vision queries; text only B = 2 with two image sizes) against the oracle: every stage at 1e-3 of its range."""
+    if f32._f32_mode == 2:
+        pytest.skip("same launches as under device_limits")
+    import gdino_checks as gc
+    _assert_ok(gc.check_msdeform_attn_q(CPU))
+    _assert_ok(gc.check_attention_qk_mask(CPU))
+    _assert_ok(gc.check_vlfuse_heads_mask(CPU))
+    worst = _assert_ok(gc.check_gdino_model(CPU, vq=True, graph=False) + gc.check_gdino_model(CPU, vq=False, B=2, hw=((128, 130), (100, 160)), graph=False))
+    print(f"MQ-GroundingDINO (shallow) with fp32 operands: worst normalised stage error {worst:.2e}")
 
 
 def test_one_fusion_layer_at_the_benchmark_geometry_meets_1e_3_with_fp32_operands(f32):
