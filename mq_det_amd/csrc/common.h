@@ -78,6 +78,9 @@ __device__ __forceinline__ mq_split8 mq_split(half8 x) {
   return s;
 }
 __device__ __forceinline__ float4_ mfma16_split(const mq_split8& a, const mq_split8& b, float4_ c) {
+#if defined(MQ_SIMT_EMULATION)
+  return simt_mfma_16x16x32_split_frag(a.hi, a.lo, b.hi, b.lo, c);   // tests/simt: the three products below in one lane exchange
+#else
   float4_ t = {0.f, 0.f, 0.f, 0.f};
   c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c, 0, 0, 0);
   t = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.lo, t, 0, 0, 0);
@@ -85,6 +88,18 @@ __device__ __forceinline__ float4_ mfma16_split(const mq_split8& a, const mq_spl
 #pragma unroll
   for (int r = 0; r < 4; ++r) c[r] = __builtin_fmaf(t[r], 1.0f / 2048.0f, c[r]);
   return c;
+#endif
+}
+// the same split for 4 elements (a 16-byte chunk of fp32 operands on its way into a planar hi / lo LDS tile: dcn_fused.hip, vlfuse_attn.hip)
+typedef _Float16 mq_h16x4 __attribute__((ext_vector_type(4)));
+typedef float mq_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mq_split4(mq_f32x4 x, mq_h16x4& hi, mq_h16x4& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const _Float16 h = (_Float16)x[i];
+    hi[i] = h;
+    lo[i] = (_Float16)(__builtin_fmaf((float)h, -1.0f, x[i]) * 2048.0f);
+  }
 }
 #endif
 
@@ -139,6 +154,15 @@ __device__ __forceinline__ half4 lds_read_tr16(const half_t* p) {
   __builtin_memcpy(&o, &v, 8);
   return o;
 #endif
+}
+
+// the same transposed read on an fp16 plane, in EVERY build (the planar hi / lo tiles of the split-precise kernels are fp16 whatever half_t is)
+typedef _Float16 mq_h16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mq_h16x4_t lds_read_tr16_h(const _Float16* p) {
+  mq_fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) mq_fp16x4_t*)p);
+  mq_h16x4_t o;
+  __builtin_memcpy(&o, &v, 8);
+  return o;
 }
 
 // One 8-element operand fragment per lane, global -> LDS: lane l's fragment `src_lane` lands at dst_base + 8 l (dst_base wave-uniform).

@@ -73,20 +73,39 @@ struct DcnGroup {
 // order (waits bottom out at vmcnt(4), as the source intends) made the launch 9 % SLOWER (3.72 vs 3.40 ms per step, three of three, GPU call 13 of
 // round 5, profiles/r05_call13_dcn_fence_ab.txt; equal outputs): the hoisted blend fills the issue slots beside the other wave group's MFMAs, and the
 // gather has landed by then anyway (one k-step is ~1.7 us).
+// SPLIT-PRECISE build (-DMQ_F32, round 6): the SAME byte geometry with 4-byte operands -- a k-step is 32 channels (128 B per row and corner in
+// global memory, 16-byte chunks of 4 elements), and the LDS tiles are PLANAR: every operand element is split ONCE, by the thread that stages it,
+// into hi = fp16(x) and lo = fp16((x - hi) 2^11) (csrc/common.h) stored in two fp16 planes [rows][32]; a fragment read is one ds_read_b128 per
+// plane and the MFMA phase is three v_mfma_f32_16x16x32_f16 per (row block, column block) with no conversion arithmetic next to them.  Planes
+// have a 64-byte pitch: the 16 rows x 4 chunks of a fragment read are 1 KB of consecutive bytes (no swizzle needed).  Tiles stay double-buffered
+// (2 x 48 KB) and the ping-pong of the two wave groups is the one of the 16-bit build.  (Round 5 ran this build with fp32 tiles, ONE buffer,
+// eight v_mfma_f32_16x16x4_f32 per MFMA and 117 spilled VGPRs: 6.4 ms per launch against 0.56 ms with fp16 operands.)
+#if defined(MQ_F32) && !defined(MQ_F32_EXACT)
+#define MQ_DCN_SPLIT 1
+#else
+#define MQ_DCN_SPLIT 0
+#endif
+#if MQ_DCN_SPLIT
+typedef mq_f32x4 dcn_gvec;                                   // one 16-byte chunk of operand elements in global memory
+#else
+typedef half8 dcn_gvec;
+#endif
 template <int NW, int ABL = 0, int SYNC = 2, bool PLAIN = false, bool FENCE = false>
 __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
-  constexpr int BM = DCN_PH * DCN_PW, BN = 256, BK = 64;
+  constexpr int BM = DCN_PH * DCN_PW, BN = 256, BK = MQ_DCN_SPLIT ? 32 : 64;
+  constexpr int CH = 16 / (int)sizeof(half_t);               // operand elements per 16-byte chunk (8, or 4 in the split-precise build)
   constexpr int NTH = 64 * NW, RA = 1024 / NTH, JB = 2048 / NTH, IM = 32 / NW;   // threads, A rows / thread, B chunks / thread, row blocks / wave
   static_assert(BM == 128, "tile is 128 positions");
-  // tile buffers: two (ping-pong) with 16-bit operands; ONE in the fp32-operand build (two would be 196 KB), where every wave runs
-  // MFMAs -> barrier -> staging -> barrier (the precise mode is not built for speed)
-  constexpr int NBUF = sizeof(half_t) == 4 ? 1 : 2;
+  static_assert(BK * sizeof(half_t) == 128, "a tile row is one 128-byte line per corner");
+  // tile buffers: two (ping-pong); only the exact-fp32 build (-DMQ_F32_EXACT: fp32 tiles of 64 channels) has ONE, where every wave runs
+  // MFMAs -> barrier -> staging -> barrier
+  constexpr int NBUF = (sizeof(half_t) == 4 && !MQ_DCN_SPLIT) ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // LDS tiles: rows of 64 halfs = 128 B = 8 chunks of 16 B, NO padding; chunk c of row r is stored at chunk position
   // c ^ (r & 7): conflict-free for the ds_read_b128 fragment reads (16 rows x one chunk) AND for the row-wise
   // ds_write_b128 of the staging pass (8 lanes = one row).  (The padded 144-byte pitch of v3 lost 39 % of the LDS
   // cycles to bank conflicts, profiles/r01_pmc_dcn_v3.txt.)
-  half_t* As = (half_t*)smem;                                // [2][BM][BK]
+  half_t* As = (half_t*)smem;                                // [2][BM][BK]   (split-precise: [2][hi | lo][BM][32] fp16 -- the same bytes)
   half_t* Bs = As + NBUF * BM * BK;                          // [NBUF][BN][BK]
   TapState* Ts = (TapState*)(Bs + NBUF * BN * BK);           // [BM][9]
 
@@ -121,7 +140,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   {
     const int fh = (DCN_PH - 1) * p.stride + 3 + 2 * DCN_WARM, fw = (DCN_PW - 1) * p.stride + 3 + 2 * DCN_WARM;
     const int h_lo = ho0 * p.stride - 1 - DCN_WARM, w_lo = wo0 * p.stride - 1 - DCN_WARM;
-    const int lpp = (p.C * 2) >> 7;                          // 128-byte lines per pixel
+    const int lpp = (p.C * (int)sizeof(half_t)) >> 7;        // 128-byte lines per pixel
     const int nlines = fh * fw * lpp;
     const char* xw = (const char*)(p.x + (long)b * p.x_bs);
 #pragma unroll
@@ -131,7 +150,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
       if (idx < nlines) {
         const int px = idx / lpp, ln = idx - px * lpp;
         const int hh = min(max(h_lo + px / fw, 0), p.H - 1), ww = min(max(w_lo + px % fw, 0), p.W - 1);
-        const char* a = xw + ((long)(hh * p.W + ww) * p.C * 2 + ln * 128);
+        const char* a = xw + ((long)(hh * p.W + ww) * p.C * (long)sizeof(half_t) + ln * 128);
         asm volatile("global_load_dword %0, %1, off" : "=v"(warm[i]) : "v"(a) : "memory");
       }
     }
@@ -186,39 +205,47 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   const int ar = tid >> 3, ac = tid & 7;                     // A rows ar + rr * (NTH / 8), rr < RA
   const char* xb = (const char*)(p.x + (long)b * p.x_bs);
   const char* wb = (const char*)p.w;
+#if MQ_DCN_SPLIT
+  const unsigned a_lds = (unsigned)(ar * BK + ac * CH);                                // fp16 index inside a plane (no swizzle)
+#else
   const unsigned a_lds = (unsigned)(ar * BK + ((ac ^ (ar & 7)) << 3));                 // + 64 * BK for the second row
+#endif
   unsigned b_goff[JB], b_lds[JB];
 #pragma unroll
   for (int j = 0; j < JB; ++j) {
     const int c = tid + j * NTH, row = c >> 3, ch = c & 7;
-    b_goff[j] = (unsigned)(row * K + ch * 8) * (unsigned)sizeof(half_t);
+    b_goff[j] = (unsigned)(row * K + ch * CH) * (unsigned)sizeof(half_t);
+#if MQ_DCN_SPLIT
+    b_lds[j] = (unsigned)(row * BK + ch * CH);
+#else
     b_lds[j] = (unsigned)(row * BK + ((ch ^ (row & 7)) << 3));
+#endif
   }
 
   float c_w[2][RA][4];
-  half8 a_raw[2][RA][4], b_raw[JB];
+  dcn_gvec a_raw[2][RA][4], b_raw[JB];
   if constexpr (ABL != 0) {
 #pragma unroll
     for (int s_ = 0; s_ < 2; ++s_)
 #pragma unroll
       for (int rr = 0; rr < RA; ++rr)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a_raw[s_][rr][q] = zero8();
+        for (int q = 0; q < 4; ++q) a_raw[s_][rr][q] = dcn_gvec{};
 #pragma unroll
-    for (int j = 0; j < JB; ++j) b_raw[j] = zero8();
+    for (int j = 0; j < JB; ++j) b_raw[j] = dcn_gvec{};
   }
   auto issue_a = [&](auto SLOT, int ks) {                    // gather of k-step ks
     constexpr int s = decltype(SLOT)::value;
     ks = min(ks, ksteps - 1);                                // tail: re-load the last step (one code path, no branches)
     const int slice = ks / 9, tap = ks - slice * 9;
-    const unsigned cb = (unsigned)(slice * BK + ac * 8) * (unsigned)sizeof(half_t);
+    const unsigned cb = (unsigned)(slice * BK + ac * CH) * (unsigned)sizeof(half_t);
 #pragma unroll
     for (int rr = 0; rr < RA; ++rr) {
       const TapState st = Ts[(ar + rr * (NTH / 8)) * 9 + tap];
 #pragma unroll
       for (int q = 0; q < (PLAIN ? 1 : 4); ++q) {
         c_w[s][rr][q] = st.w[q];
-        if constexpr (!(ABL & 1)) a_raw[s][rr][q] = *(const half8*)(xb + (st.off[q] + cb));
+        if constexpr (!(ABL & 1)) a_raw[s][rr][q] = *(const dcn_gvec*)(xb + (st.off[q] + cb));
       }
     }
   };
@@ -228,7 +255,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
     const unsigned kb = (unsigned)(tap * p.C + slice * BK) * (unsigned)sizeof(half_t);
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
-      if constexpr (!(ABL & 4)) b_raw[j] = *(const half8*)(wb + (b_goff[j] + kb));
+      if constexpr (!(ABL & 4)) b_raw[j] = *(const dcn_gvec*)(wb + (b_goff[j] + kb));
     }
   };
   // staging of one k-step by this thread: bilinear blend of its gathered slot (fp32 accumulate like the im2col kernel,
@@ -236,6 +263,35 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   auto stage = [&](auto SLOT, int buf) {
     constexpr int s = decltype(SLOT)::value;
     buf &= NBUF - 1;
+#if MQ_DCN_SPLIT
+    // planes of buffer `buf`: A hi, A lo, B hi, B lo (fp16); this thread's CH = 4 blended values / weights -> 8 bytes into each plane
+    _Float16* a_hi = (_Float16*)As + buf * 2 * BM * BK + a_lds;
+    _Float16* b_hi = (_Float16*)Bs + buf * 2 * BN * BK;
+#pragma unroll
+    for (int rr = 0; rr < RA; ++rr) {
+      mq_f32x4 t;
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        t[j] = c_w[s][rr][0] * a_raw[s][rr][0][j];
+        if constexpr (!PLAIN) {
+          t[j] = __builtin_fmaf(c_w[s][rr][1], a_raw[s][rr][1][j], t[j]);
+          t[j] = __builtin_fmaf(c_w[s][rr][2], a_raw[s][rr][2][j], t[j]);
+          t[j] = __builtin_fmaf(c_w[s][rr][3], a_raw[s][rr][3][j], t[j]);
+        }
+      }
+      mq_h16x4 hi, lo;
+      mq_split4(t, hi, lo);
+      *(mq_h16x4*)(a_hi + rr * (NTH / 8) * BK) = hi;
+      *(mq_h16x4*)(a_hi + BM * BK + rr * (NTH / 8) * BK) = lo;
+    }
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+      mq_h16x4 hi, lo;
+      mq_split4(b_raw[j], hi, lo);
+      *(mq_h16x4*)(b_hi + b_lds[j]) = hi;
+      *(mq_h16x4*)(b_hi + BN * BK + b_lds[j]) = lo;
+    }
+#else
     half_t* a = As + buf * BM * BK + a_lds;
 #pragma unroll
     for (int rr = 0; rr < RA; ++rr) {
@@ -256,6 +312,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
     }
 #pragma unroll
     for (int j = 0; j < JB; ++j) *(half8*)(Bs + buf * BN * BK + b_lds[j]) = b_raw[j];
+#endif
   };
 
   float4_ acc[IM][4];
@@ -266,6 +323,29 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
 
   // fragment addressing: row = w? * 64 + i * 16 + l15 (row & 7 == l15 & 7), chunk = kk * 4 + lg
   const unsigned fa = (unsigned)((wr * IM * 16 + l15) * BK), fb = (unsigned)((wc * 64 + l15) * BK);
+#if MQ_DCN_SPLIT
+  auto mfma_phase = [&](int cur) {                           // one 32-deep step: IM x 4 blocks, three fp16 MFMAs each on the planar fragments
+    if constexpr (ABL & 8) return;
+    cur &= NBUF - 1;
+    const _Float16* At = (const _Float16*)As + cur * 2 * BM * BK + fa + lg * 8;
+    const _Float16* Bt = (const _Float16*)Bs + cur * 2 * BN * BK + fb + lg * 8;
+    mq_split8 af[IM], bf[4];
+#pragma unroll
+    for (int i = 0; i < IM; ++i) {
+      af[i].hi = *(const mq_h16x8*)(At + i * 16 * BK);
+      af[i].lo = *(const mq_h16x8*)(At + BM * BK + i * 16 * BK);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf[j].hi = *(const mq_h16x8*)(Bt + j * 16 * BK);
+      bf[j].lo = *(const mq_h16x8*)(Bt + BN * BK + j * 16 * BK);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < IM; ++i) acc[i][j] = mfma16_split(af[i], bf[j], acc[i][j]);
+  };
+#else
   const unsigned sw0 = (unsigned)((lg ^ (l15 & 7)) << 3), sw1 = (unsigned)(((4 + lg) ^ (l15 & 7)) << 3);
   auto mfma_phase = [&](int cur) {                           // this wave's 64 x 64 block of one k-step (32 MFMAs)
     if constexpr (ABL & 8) return;
@@ -285,6 +365,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
         for (int i = 0; i < IM; ++i) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
     }
   };
+#endif
 
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
@@ -438,6 +519,20 @@ struct mq_dcn_branch {          // mirrors include/mqdet_hip.h
   int B, H, W, C, oH, oW, N, out_ld, stride, flags;
 };
 
+#if MQ_DCN_SPLIT
+template <int NW, int SYNC, bool PLAIN>
+static int dcn_launch(dim3 grid, size_t smem, hipStream_t stream, const DcnGroup& g) {
+  static MqOncePerDevice attr;
+  if (attr.first()) {
+    hipError_t e = hipFuncSetAttribute((const void*)dcn_igemm8_kernel<NW, 0, SYNC, PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr.done();
+  }
+  hipLaunchKernelGGL((dcn_igemm8_kernel<NW, 0, SYNC, PLAIN>), grid, dim3(64 * NW), smem, stream, g);
+  return 0;
+}
+#endif
+
 extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* stream) {
   if (n <= 0) return 0;
   if (n > DCN_MAX_BRANCH) return -3;
@@ -461,8 +556,9 @@ extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* 
   }
   if (g.n == 0) return 0;
   g.tiles_all = g.first_tile[g.n];
-  constexpr size_t nbuf = sizeof(half_t) == 4 ? 1 : 2;
-  constexpr size_t tiles = (size_t)(nbuf * 128 * 64 + nbuf * 256 * 64) * sizeof(half_t) + 128 * 9 * sizeof(TapState);
+  constexpr size_t nbuf = (sizeof(half_t) == 4 && !MQ_DCN_SPLIT) ? 1 : 2;
+  constexpr size_t bk = MQ_DCN_SPLIT ? 32 : 64;
+  constexpr size_t tiles = (size_t)(nbuf * 128 * bk + nbuf * 256 * bk) * sizeof(half_t) + 128 * 9 * sizeof(TapState);
   constexpr size_t ostage = (size_t)128 * (256 + 8) * sizeof(half_t) + (sizeof(half_t) == 4 ? 0 : (size_t)16 * 32 * 24 * sizeof(float));
   constexpr size_t smem = tiles > ostage ? tiles : ostage;
   static MqOncePerDevice attr_set;
@@ -473,7 +569,12 @@ extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* 
     if (e != hipSuccess) return (int)e;
     attr_set.done();
   }
+#if MQ_DCN_SPLIT
+  // split-precise: 8 waves (wave tile 64 x 64: the planar hi / lo fragments are twice the registers of the fp16 ones -- 16 waves at 128 VGPRs spill)
+  static const int nw = [] { const char* e = getenv("MQ_DCN_WAVES"); return (e && e[0] == '1') ? 16 : 8; }();
+#else
   static const int nw = [] { const char* e = getenv("MQ_DCN_WAVES"); return (e && e[0] == '8') ? 8 : 16; }();   // A/B switch
+#endif
   const dim3 grid((unsigned)(8 * ((g.tiles_all + 7) / 8)));
 #ifdef MQ_PRIMARY_UNIT
   if (const int abl = (br[0].flags >> 8) & 15) {             // ablation timings (tools/microbench.py)
@@ -499,6 +600,17 @@ extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* 
   bool plain = true;                                          // flags bit 1 on EVERY branch: zero offsets, mask 1 (the caller's promise)
   for (int i = 0; i < n; ++i) plain = plain && (br[i].B <= 0 || (br[i].flags & 2));
   static const bool plain_on = [] { const char* e = getenv("MQ_DCN_PLAIN"); return !(e && e[0] == '0'); }();   // A/B switch
+#if MQ_DCN_SPLIT
+  if (nw == 8) {                                              // split-precise default: 8 waves, one barrier per k-step, PLAIN for the FPN convs
+    int rc;
+    if (plain && plain_on) rc = dcn_launch<8, 1, true>(grid, smem, (hipStream_t)stream, g);
+    else if (sync == 2) rc = dcn_launch<8, 2, false>(grid, smem, (hipStream_t)stream, g);
+    else rc = dcn_launch<8, 1, false>(grid, smem, (hipStream_t)stream, g);
+    if (rc) return rc;
+    MQ_CHECK_LAUNCH();
+    return 0;
+  }
+#endif
   if (plain && plain_on && nw == 16 && sync == 1) {
     static MqOncePerDevice attr_plain;
     if (attr_plain.first()) {

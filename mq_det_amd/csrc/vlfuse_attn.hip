@@ -26,6 +26,25 @@
 
 MQ_NAMESPACE_BEGIN
 
+// SPLIT-PRECISE build (-DMQ_F32, round 6).  Round 5 compiled these kernels with fp32 tiles and split every fragment inside mfma16: 450 ... 1200 spilled
+// VGPRs, 8.0 / 6.3 ms per launch against 0.34 / 0.26 ms with fp16 operands.  Now the LDS tiles are PLANAR -- a tile of 64 rows x 256 operand
+// elements is two fp16 planes [64][KS], hi = fp16(x) and lo = fp16((x - hi) 2^11) (csrc/common.h), the same bytes as the fp32 tile -- written by
+// the thread that stages a chunk (one split per element and workgroup), so a fragment read is one ds_read_b128 per plane, the transposed value
+// reads are the native ds_read_b64_tr_b16 on each plane, the Q fragments are split once when they are loaded, the P fragments once per 32-key
+// step, and every contraction is three v_mfma_f32_16x16x32_f16 (mfma16_split).  One ring slot instead of two (the fp32 chunks of a tile are twice
+// the registers).
+#if defined(MQ_F32) && !defined(MQ_F32_EXACT)
+#define MQ_VL_SPLIT 1
+typedef mq_split8 vfrag;                   // an MFMA operand fragment: (hi, lo) fp16 x 8
+__device__ __forceinline__ vfrag vl_frag(half8 x) { return mq_split(x); }
+__device__ __forceinline__ float4_ vl_mfma(const vfrag& a, const vfrag& b, float4_ c) { return mfma16_split(a, b, c); }
+#else
+#define MQ_VL_SPLIT 0
+typedef half8 vfrag;
+__device__ __forceinline__ vfrag vl_frag(half8 x) { return x; }
+__device__ __forceinline__ float4_ vl_mfma(vfrag a, vfrag b, float4_ c) { return mfma16(a, b, c); }
+#endif
+
 namespace {
 constexpr int VH = 8, VD = 256;            // max heads (run-time count in the params), head dim
 constexpr int BM = 128;                    // query rows per workgroup (4 waves x 32)
@@ -81,7 +100,14 @@ __device__ __forceinline__ void tile_commit(const TileRegs<NTH>& t, half_t* dst,
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = tid + i * NTH;
+#if MQ_VL_SPLIT
+    const mq_split8 sp = mq_split(t.r[i]);                 // 8 fp32 operands -> 16 bytes into the hi plane, 16 into the lo plane
+    _Float16* h = (_Float16*)dst + (c >> 5) * KS + (c & 31) * 8;
+    *(mq_h16x8*)h = sp.hi;
+    *(mq_h16x8*)(h + TILE) = sp.lo;
+#else
     *(half8*)(dst + (c >> 5) * KS + (c & 31) * 8) = t.r[i];
+#endif
   }
 }
 
@@ -90,26 +116,38 @@ __device__ __forceinline__ void tile_commit(const TileRegs<NTH>& t, half_t* dst,
 // on the block count of the LAST tile only); the others keep s = 0 and are masked by the caller -- a 141-token caption
 // fills 9 of the 12 blocks of its three 64-key tiles
 template <bool QLDS, int QB, int NBL = 4>
-__device__ __forceinline__ void qk_tile(const half_t* tile, const half8 (&qf)[QB][8], const half_t* qw, float4_ (&s)[4][QB],
+__device__ __forceinline__ void qk_tile(const half_t* tile, const vfrag (&qf)[QB][8], const half_t* qw, float4_ (&s)[4][QB],
                                         int l15, int lg) {
+  static_assert(!(MQ_VL_SPLIT && QLDS), "split-precise: the Q fragments live in registers (a planar Q tile does not fit beside the key tiles)");
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) s[nb][qb] = (float4_){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int kk = 0; kk < VD / 32; ++kk) {
-    half8 kf[4], qq[QB];
+    vfrag kf[4], qq[QB];
 #pragma unroll
-    for (int nb = 0; nb < NBL; ++nb) kf[nb] = *(const half8*)(tile + (nb * 16 + l15) * KS + kk * 32 + lg * 8);
+    for (int nb = 0; nb < NBL; ++nb) {
+#if MQ_VL_SPLIT
+      const _Float16* kp = (const _Float16*)tile + (nb * 16 + l15) * KS + kk * 32 + lg * 8;
+      kf[nb].hi = *(const mq_h16x8*)kp;
+      kf[nb].lo = *(const mq_h16x8*)(kp + TILE);
+#else
+      kf[nb] = *(const half8*)(tile + (nb * 16 + l15) * KS + kk * 32 + lg * 8);
+#endif
+    }
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
+#if !MQ_VL_SPLIT
       if constexpr (QLDS) qq[qb] = *(const half8*)(qw + (qb * 16 + l15) * KS + kk * 32 + lg * 8);
-      else qq[qb] = qf[qb][kk];
+      else
+#endif
+      qq[qb] = qf[qb][kk];
     }
 #pragma unroll
     for (int nb = 0; nb < NBL; ++nb)
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb) s[nb][qb] = mfma16(kf[nb], qq[qb], s[nb][qb]);
+      for (int qb = 0; qb < QB; ++qb) s[nb][qb] = vl_mfma(kf[nb], qq[qb], s[nb][qb]);
   }
 }
 
@@ -119,6 +157,22 @@ template <int QB, int STL = 2>
 __device__ __forceinline__ void pv_tile(const half_t* tile, const half8 (&pf)[2][QB], float4_ (&o)[16][QB], int l15, int lg) {
 #pragma unroll
   for (int st = 0; st < STL; ++st) {
+#if MQ_VL_SPLIT
+    const _Float16* base = (const _Float16*)tile + (st * 32 + 4 * lg + (l15 >> 2)) * KS + (l15 & 3) * 4;
+    vfrag pq[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) pq[qb] = mq_split(pf[st][qb]);      // once per 32-key step: feeds the 16 channel blocks below
+#pragma unroll
+    for (int db = 0; db < 16; ++db) {
+      vfrag a;
+      const mq_h16x4_t h0 = lds_read_tr16_h(base + db * 16), h1 = lds_read_tr16_h(base + 16 * KS + db * 16);
+      const mq_h16x4_t l0 = lds_read_tr16_h(base + TILE + db * 16), l1 = lds_read_tr16_h(base + TILE + 16 * KS + db * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a.hi[j] = h0[j]; a.hi[4 + j] = h1[j]; a.lo[j] = l0[j]; a.lo[4 + j] = l1[j]; }
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) o[db][qb] = vl_mfma(a, pq[qb], o[db][qb]);
+    }
+#else
     const half_t* base = tile + (st * 32 + 4 * lg + (l15 >> 2)) * KS + (l15 & 3) * 4;
 #pragma unroll
     for (int db = 0; db < 16; ++db) {
@@ -130,6 +184,7 @@ __device__ __forceinline__ void pv_tile(const half_t* tile, const half8 (&pf)[2]
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) o[db][qb] = mfma16(a, pf[st][qb], o[db][qb]);
     }
+#endif
   }
 }
 
@@ -145,10 +200,11 @@ __device__ __forceinline__ void pv_tile(const half_t* tile, const half8 (&pf)[2]
 // room: 242 / 246 VGPRs, no spill) -- no Q tile in LDS, a fifth fewer fragment reads in the QK steps, tiles two steps ahead.
 template <int NT, int QB, int NBL, int ABL = 0, bool QREG = false>
 __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p) {
-  constexpr bool LEAN = NT >= 3 && !QREG;
+  constexpr bool LEAN = NT >= 3 && !QREG && !MQ_VL_SPLIT;   // (split-precise: Q always in registers)
+  constexpr bool ONE = LEAN || MQ_VL_SPLIT;                // one ring slot: the next tile only
   constexpr int NTH = 2048 / (QB * 4), WR = 16 * QB;        // threads per workgroup (512 / 256), query rows per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  half_t* tiles = (half_t*)smem;                           // [2][TK][KS]
+  half_t* tiles = (half_t*)smem;                           // [2][TK][KS]   (split-precise: [2][hi | lo][TK][KS] fp16 -- the same bytes)
   half_t* Qs = tiles + 2 * TILE;                           // [BM][KS] (LEAN only)
   float* bias_s = (float*)(Qs + (LEAN ? BM * KS : 0));     // [8][NT*64], + the additive key mask [8][NT*64] behind it
 
@@ -182,7 +238,7 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
   }
   const float cl2 = p.clamp > 0.f ? p.clamp : 3.0e38f;                   // no clamp: a bound no logit reaches (one v_med3 either way)
 
-  half8 qf[QB][8];
+  vfrag qf[QB][8];
   const half_t* vb = p.v + (long)b * p.N * VD;
   const half_t* qw = Qs + wave * WR * KS;
   if constexpr (LEAN) {
@@ -196,7 +252,7 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
     for (int qb = 0; qb < QB; ++qb) {
       const int row = min(row0 + qb * 16 + l15, p.N - 1);
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = *(const half8*)(vb + (long)row * VD + kk * 32 + lg * 8);
+      for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = vl_frag(*(const half8*)(vb + (long)row * VD + kk * 32 + lg * 8));
     }
   }
 
@@ -210,10 +266,10 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
   // position parity inside a head is also the parity of u: LDS buffer and register slot indices are compile-time.
   constexpr int PER_HEAD = 2 * NT;
   const int U = p.H * PER_HEAD;
-  TileRegs<NTH> slot[LEAN ? 1 : 2];
+  TileRegs<NTH> slot[ONE ? 1 : 2];
   if constexpr (ABL != 0) {
 #pragma unroll
-    for (int i = 0; i < 2048 / NTH; ++i) { slot[0].r[i] = zero8(); slot[LEAN ? 0 : 1].r[i] = zero8(); }
+    for (int i = 0; i < 2048 / NTH; ++i) { slot[0].r[i] = zero8(); slot[ONE ? 0 : 1].r[i] = zero8(); }
   }
   // chunk rounds of the tile at stream position np (0 .. 2 NT - 1; K tiles first): the last K tile is read up to its NBL live 16-key
   // blocks, the last V tile up to the 32-key steps that hold one (rows beyond stay whatever the buffer held before: never read)
@@ -233,18 +289,18 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
   // begin(pos): prefetch;  end(pos): commit the next tile into the other LDS buffer + barrier
   auto begin = [&](auto POS, int u) {
     constexpr int pos = decltype(POS)::value, par = pos & 1;
-    if constexpr (LEAN) issue(S0{}, std::integral_constant<int, pos + 1>{}, u + 1);
+    if constexpr (ONE) issue(S0{}, std::integral_constant<int, pos + 1>{}, u + 1);
     else issue(std::integral_constant<int, par>{}, std::integral_constant<int, pos + 2>{}, u + 2);  // the slot of tile u was committed one step ago
     __builtin_amdgcn_sched_barrier(0);                     // keep the prefetch ahead of everything that waits on VMEM
   };
   auto end = [&](auto POS) {
     constexpr int pos = decltype(POS)::value, par = pos & 1;
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!(ABL & 2)) tile_commit<NTH, rounds_of((pos + 1) % PER_HEAD)>(slot[LEAN ? 0 : (par ^ 1)], tiles + (par ^ 1) * TILE, tid);
+    if constexpr (!(ABL & 2)) tile_commit<NTH, rounds_of((pos + 1) % PER_HEAD)>(slot[ONE ? 0 : (par ^ 1)], tiles + (par ^ 1) * TILE, tid);
     __syncthreads();
   };
   issue(S0{}, std::integral_constant<int, -1>{}, 0);       // the fill stages whole tiles
-  if constexpr (!LEAN) issue(S1{}, std::integral_constant<int, -1>{}, 1);
+  if constexpr (!ONE) issue(S1{}, std::integral_constant<int, -1>{}, 1);
   tile_commit(slot[0], tiles, tid);
   __syncthreads();
 
@@ -377,7 +433,7 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
 
 template <int NT, int QB, int NBL, int ABL = 0, bool QREG = false>
 static int launch_i2t(const I2TParams& p, hipStream_t stream) {
-  constexpr size_t smem = (size_t)(2 * TILE + ((NT >= 3 && !QREG) ? BM * KS : 0)) * sizeof(half_t) + (size_t)2 * VH * NT * TK * sizeof(float);
+  constexpr size_t smem = (size_t)(2 * TILE + ((NT >= 3 && !QREG && !MQ_VL_SPLIT) ? BM * KS : 0)) * sizeof(half_t) + (size_t)2 * VH * NT * TK * sizeof(float);
   static_assert(4 * 32 * (VD + 8) <= 2 * TILE, "O staging must fit in the tiles");
   static MqOncePerDevice attr_set;
   if (attr_set.first()) {
@@ -501,13 +557,13 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
   const int t0 = split * tps, t1 = min(ntiles, t0 + tps);
   const int nt = max(t1 - t0, 0);
 
-  half8 qf[QB][8];
+  vfrag qf[QB][8];
   const half_t* qb_ = p.kf + ((long)b * p.H + h) * p.T * VD;
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int row = min(row0 + qb * 16 + l15, p.T - 1);
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = *(const half8*)(qb_ + (long)row * VD + kk * 32 + lg * 8);
+    for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = vl_frag(*(const half8*)(qb_ + (long)row * VD + kk * 32 + lg * 8));
   }
   float4_ o[16][QB];
 #pragma unroll
@@ -523,7 +579,7 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
   // (profiles/r03_call8_microbench_vlfuse.json) takes a third off the launch when the tile loads are removed -- but a third slot
   // (RS = 3) changed nothing (0.3202 vs 0.3218 ms, GPU call 9): it is the L2 -> CU ingest of 32 KB per tile and workgroup, not its
   // latency, that the loads cost.  Two slots.
-  constexpr int RS = 2;
+  constexpr int RS = MQ_VL_SPLIT ? 1 : 2;                  // (split-precise: one slot -- a tile's fp32 chunks are twice the registers)
   TileRegs<NTH> slot[RS];
   if constexpr (ABL != 0) {
 #pragma unroll
@@ -620,7 +676,7 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
     __syncthreads();
   };
   issue(S0{}, 0);
-  issue(S1{}, 1);
+  if constexpr (RS >= 2) issue(S1{}, 1);
   if constexpr (RS == 3) issue(std::integral_constant<int, 2>{}, 2);
   tile_commit(slot[0], tiles, tid);
   __syncthreads();

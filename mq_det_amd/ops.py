@@ -679,24 +679,12 @@ def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.
     if kv_len is not None:
         assert kv_len.dtype == torch.int32 and kv_len.numel() == B and kv_len.is_contiguous()
     live = max_kv if (kv_len is not None and 0 < max_kv < T) else T
-    if f32_operands() == 1 and live > 160:
-        # precise mode, captions of more than 160 tokens: the Q tile the kernel then keeps in LDS beside two K / V tiles is 136 KB at fp32 --
-        # the plain fp32 statement of the same sum instead (fuse_helper.py:233-273 with the folded operands; 8 x N x T logits in HBM)
-        lg = torch.einsum("bnc,bhtc->bhnt", v_ln, kf)
-        masked = torch.zeros(B, Hh, T, dtype=torch.bool, device=v_ln.device)
-        if bias is not None:
-            masked = bias < -1.0e29
-            lg = lg + torch.where(masked, torch.zeros_like(bias), bias)[:, :, None, :]
-        if kv_len is not None:
-            masked = masked | (torch.arange(T, device=v_ln.device)[None, None, :] >= kv_len.clamp(1, T)[:, None, None])
-        if clamp > 0:
-            lg = lg.clamp(-clamp, clamp)
-        lg = lg.masked_fill(masked[:, :, None, :], -1.0e30)                  # the mask behind the clamp, as in the kernel (fuse_helper.py:236-262)
-        return v_ln + out_bias + torch.einsum("bhnt,bhtc->bnc", torch.softmax(lg, -1), vo)
+    # (round 5's precise mode sent captions of more than 160 tokens through a plain torch statement of this sum: its fp32 Q tile did not fit the
+    # LDS beside two K / V tiles.  The split-precise kernels keep Q in registers for every caption length: one path.)
     out = torch.empty_like(v_ln)
     variant = KERNELS["VLFUSE_I2T_VARIANT"] if variant is None else int(variant)
-    if f32_operands() == 1:
-        variant = 0           # precise mode: Q fragments in registers (the Q tile in LDS beside two K / V tiles does not fit at fp32)
+    if f32_operands():
+        variant = 0           # split-precise mode: Q fragments always in registers
     with _timed(f"vlfuse_i2t_n{N}_t{T}"):
         _chk(_fn(lib, "mq_vlfuse_i2t_fwd", v_ln)(_ptr(v_ln), _ptr(kf), _ptr(vo), _ptr(bias), _ptr(kv_len), _ptr(out_bias), _ptr(out),
                                    B, N, T, Hh, int(max_kv), float(clamp), int(variant),

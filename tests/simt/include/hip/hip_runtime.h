@@ -323,6 +323,18 @@ inline simt_float4 simt_mfma_16x16x32_split(V8 a, V8 b, simt_float4 c) {
   }
   return c;
 }
+// mfma16_split on fragments that are ALREADY split (planar hi / lo LDS tiles of the split-precise kernels, csrc/common.h): the device's three
+// v_mfma_f32_16x16x32_f16 -- (hi, hi) into the accumulator, (hi, lo) + (lo, hi) into a zeroed second one that is added scaled by 2^-11
+template <class H8>
+inline simt_float4 simt_mfma_16x16x32_split_frag(H8 ahi, H8 alo, H8 bhi, H8 blo, simt_float4 c) {
+  static_assert(sizeof(H8) == 16, "fp16 fragments");
+  simt_float4 t = {0.f, 0.f, 0.f, 0.f};
+  c = simt_mfma_16x16x32(ahi, bhi, c);
+  t = simt_mfma_16x16x32(ahi, blo, t);
+  t = simt_mfma_16x16x32(alo, bhi, t);
+  for (int r = 0; r < 4; ++r) c[r] = __builtin_fmaf(t[r], 1.0f / 2048.0f, c[r]);
+  return c;
+}
 inline int __lane_id() { return simt::lane(); }
 
 // ds_read_b64_tr_b16: inside each 16-lane group the 16 x 4 block of 16-bit elements addressed by the lanes (lane i: row i >> 2,
