@@ -36,6 +36,32 @@ struct SwinMlp2Params {
   long M; float eps, eps_n;
 };
 
+// SPLIT-PRECISE build (-DMQ_F32, round 6).  Every weight fragment feeds exactly ONE MFMA per wave here, so splitting operands inside mfma16 (round 6's
+// first step) costs ~40 VALU instructions per three MFMAs -- VALU-bound at a third of the matrix rate.  Instead the host packs the weights ALREADY
+// SPLIT (ops.swin_mlp2_pack under the precise mode): every 512-element fragment block is [hi: 64 lanes x 8 fp16 | lo: 64 lanes x 8 fp16] -- the same
+// 2 KB as the fp32 block -- staged by two linear LDS-DMA pieces and read back as one ds_read_b128 per plane; the LayerNorm fragments are split once
+// per wave, the GELU output once per hidden chunk.  No conversion arithmetic is left beside the weight stream.
+#if defined(MQ_F32) && !defined(MQ_F32_EXACT)
+#define MQ_SW_SPLIT 1
+typedef mq_split8 wfrag_t;
+__device__ __forceinline__ wfrag_t sw_frag(half8 x) { return mq_split(x); }
+__device__ __forceinline__ float4_ sw_mfma(const wfrag_t& a, const wfrag_t& b, float4_ c) { return mfma16_split(a, b, c); }
+// fragment of lane `lane` out of a planar block (LDS or global): hi at fp16 index 8 lane, lo 512 fp16 further
+__device__ __forceinline__ wfrag_t sw_wfrag(const half_t* blk, int lane) {
+  const _Float16* h = (const _Float16*)blk + lane * 8;
+  wfrag_t f;
+  f.hi = *(const mq_h16x8*)h;
+  f.lo = *(const mq_h16x8*)(h + 512);
+  return f;
+}
+#else
+#define MQ_SW_SPLIT 0
+typedef half8 wfrag_t;
+__device__ __forceinline__ wfrag_t sw_frag(half8 x) { return x; }
+__device__ __forceinline__ float4_ sw_mfma(wfrag_t a, wfrag_t b, float4_ c) { return mfma16(a, b, c); }
+__device__ __forceinline__ wfrag_t sw_wfrag(const half_t* blk, int lane) { return *(const half8*)(blk + lane * 8); }
+#endif
+
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7): erf(|v| / sqrt 2) = 1 - poly(t) exp(-v^2 / 2), t = 1 / (1 + p |v| / sqrt 2)
 __device__ __forceinline__ float erf_abs_scaled(float v) {
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, fabsf(v), 1.f));
@@ -151,9 +177,16 @@ __global__ __launch_bounds__(64 * NW, (C <= 96 ? 4 : C <= 192 ? 3 : 2)) void swi
 #pragma unroll
     for (int i = 0; i < FPW; ++i) {
       const int f = wave + i * NW;
-      const half_t* src = (f < W1_FR ? p.w1f + ((long)c1 * W1_FR + f) * FR : p.w2f + ((long)c2 * W2_FR + (f - W1_FR)) * FR) + lane * 8;
+      const half_t* blk = f < W1_FR ? p.w1f + ((long)c1 * W1_FR + f) * FR : p.w2f + ((long)c2 * W2_FR + (f - W1_FR)) * FR;
       half_t* dst = f < W1_FR ? w1s + (s1 * W1_FR + f) * FR : w2s + (s2 * W2_FR + (f - W1_FR)) * FR;
-      lds_stage_frag8(src, dst, lane);
+#if MQ_SW_SPLIT
+      // the 2 KB planar block as two linear 1 KB LDS-DMA pieces (hi plane, lo plane): asynchronous like the 16-bit builds' one piece
+      const char* sb = (const char*)blk + lane * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + 1024), (__attribute__((address_space(3))) void*)((char*)dst + 1024), 16, 0, 0);
+#else
+      lds_stage_frag8(blk + lane * 8, dst, lane);
+#endif
     }
   };
   // chunks 0 .. D of W1 and chunk 0 of W2 -- into its own stage 0 and into stage NS - 1, which iteration 0 reads for its GEMM2 of the
@@ -173,8 +206,13 @@ __global__ __launch_bounds__(64 * NW, (C <= 96 ? 4 : C <= 192 ? 3 : 2)) void swi
     }
   }
 
-  half8 xf[KS];
-  if (p.delta) ln_fragments<C, true>(p, row0, l15, g, xf); else ln_fragments<C, false>(p, row0, l15, g, xf);
+  wfrag_t xf[KS];
+  {
+    half8 xr[KS];
+    if (p.delta) ln_fragments<C, true>(p, row0, l15, g, xr); else ln_fragments<C, false>(p, row0, l15, g, xr);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xf[ks] = sw_frag(xr[ks]);       // (split-precise: split once per wave; else the fragments as they are)
+  }
 
   __syncthreads();                                            // (drains the DMAs: vmcnt(0)) W1 chunks 0 .. D, W2 chunk 0, bias, table visible
 
@@ -192,18 +230,19 @@ __global__ __launch_bounds__(64 * NW, (C <= 96 ? 4 : C <= 192 ? 3 : 2)) void swi
   };
   // GEMM 1 (transposed) of one chunk from W1 stage `st`: H^T[32 hidden, 16 tokens] over K = C (pipeline fill only)
   auto gemm1 = [&](int st, float4_ (&h)[2]) {
-    const half_t* a = w1s + st * W1_FR * FR + lane * 8;
+    const half_t* a = w1s + st * W1_FR * FR;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      h[0] = mfma16(*(const half8*)(a + ks * FR), xf[ks], h[0]);
-      h[1] = mfma16(*(const half8*)(a + (KS + ks) * FR), xf[ks], h[1]);
+      h[0] = sw_mfma(sw_wfrag(a + ks * FR, lane), xf[ks], h[0]);
+      h[1] = sw_mfma(sw_wfrag(a + (KS + ks) * FR, lane), xf[ks], h[1]);
     }
   };
   // GEMM 2 (transposed) of one chunk from W2 stage `st`: OUT^T[C, 16 tokens] += W2p[:, 32 k-slots] . H^T (pipeline drain only)
   auto gemm2 = [&](int st, const half8& hf) {
-    const half_t* a = w2s + st * W2_FR * FR + lane * 8;
+    const half_t* a = w2s + st * W2_FR * FR;
+    const wfrag_t hs = sw_frag(hf);
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) acc2[ct] = mfma16(*(const half8*)(a + ct * FR), hf, acc2[ct]);
+    for (int ct = 0; ct < CT; ++ct) acc2[ct] = sw_mfma(sw_wfrag(a + ct * FR, lane), hs, acc2[ct]);
   };
 
   // ---- one pipelined iteration.  Its MFMAs form ONE sequence of N = 2 KS + CT steps that alternates GEMM1(chunk j + 1) -- a
@@ -266,14 +305,15 @@ __global__ __launch_bounds__(64 * NW, (C <= 96 ? 4 : C <= 192 ? 3 : 2)) void swi
     // of W2 chunk j - 2 (ditto).  Past the end the chunk index is clamped (valid memory, results unused).
     stage_issue(min(j + 1 + D, NCHUNK + 1), PH, min(j - 1 + D, NCHUNK - 1), (PH + NS - 2) % NS);
     h_init(j + 1, hout);
-    const half_t* a1 = w1s + S1 * W1_FR * FR + lane * 8;      // W1 chunk j + 1 (for j = NCHUNK - 1: a zero chunk)
-    const half_t* a2 = w2s + S2 * W2_FR * FR + lane * 8;      // W2 chunk j - 1
+    const half_t* a1 = w1s + S1 * W1_FR * FR;                 // W1 chunk j + 1 (for j = NCHUNK - 1: a zero chunk)
+    const half_t* a2 = w2s + S2 * W2_FR * FR;                 // W2 chunk j - 1
     // step i of the sequence: even -> GEMM1 fragment (hb = m & 1, ks = m >> 1), m = i / 2; odd -> GEMM2 fragment ct = i / 2
-    auto frag = [&](int i) __attribute__((always_inline)) -> half8 {
+    auto frag = [&](int i) __attribute__((always_inline)) -> wfrag_t {
       const int m = i >> 1;
-      return (i & 1) ? *(const half8*)(a2 + m * FR) : *(const half8*)(a1 + ((m & 1) * KS + (m >> 1)) * FR);
+      return (i & 1) ? sw_wfrag(a2 + m * FR, lane) : sw_wfrag(a1 + ((m & 1) * KS + (m >> 1)) * FR, lane);
     };
-    half8 ring[RD];
+    const wfrag_t hs_old = sw_frag(hf_old);                   // (split-precise: the GELU output of chunk j - 1, split once for its CT MFMAs)
+    wfrag_t ring[RD];
     float gts[8], ges[8];
 #pragma unroll
     for (int i = 0; i < RD && i < N; ++i) ring[i] = frag(i);
@@ -285,12 +325,12 @@ __global__ __launch_bounds__(64 * NW, (C <= 96 ? 4 : C <= 192 ? 3 : 2)) void swi
           gelu_piece(std::integral_constant<int, gelu_piece_of(q, GS, true)>{}, std::integral_constant<int, gelu_piece_of(q, GS, false)>{},
                      hin, hf_new, gts, ges);
       });
-      const half8 a = ring[i % RD];
+      const wfrag_t a = ring[i % RD];
       if constexpr (!(i & 1)) {
         constexpr int m = i >> 1;
-        hout[m & 1] = mfma16(a, xf[m >> 1], hout[m & 1]);
+        hout[m & 1] = sw_mfma(a, xf[m >> 1], hout[m & 1]);
       } else {
-        acc2[i >> 1] = mfma16(a, hf_old, acc2[i >> 1]);
+        acc2[i >> 1] = sw_mfma(a, hs_old, acc2[i >> 1]);
       }
       if constexpr (i + RD < N) ring[i % RD] = frag(i + RD);
       __builtin_amdgcn_sched_barrier(0);
@@ -408,22 +448,27 @@ __global__ __launch_bounds__(64 * NWT) void swin_mlp2_tail_kernel(SwinMlp2Params
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long row0 = (long)blockIdx.x * 16;
 
-  half8 xf[KS];
-  if (p.delta) ln_fragments<C, true>(p, row0, l15, g, xf); else ln_fragments<C, false>(p, row0, l15, g, xf);
+  wfrag_t xf[KS];
+  {
+    half8 xr[KS];
+    if (p.delta) ln_fragments<C, true>(p, row0, l15, g, xr); else ln_fragments<C, false>(p, row0, l15, g, xr);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xf[ks] = sw_frag(xr[ks]);
+  }
 
   float4_ acc2[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) acc2[ct] = (float4_){0.f, 0.f, 0.f, 0.f};
 
   // fragment t of this wave's stream: chunk wave * CPW + t / N; within a chunk first W1 (hb = m & 1, ks = m >> 1), then W2 (ct)
-  const half_t* w1 = p.w1f + (long)wave * CPW * W1_FR * FR + lane * 8;
-  const half_t* w2 = p.w2f + (long)wave * CPW * W2_FR * FR + lane * 8;
-  auto frag = [&](int t) __attribute__((always_inline)) -> half8 {
+  const half_t* w1 = p.w1f + (long)wave * CPW * W1_FR * FR;
+  const half_t* w2 = p.w2f + (long)wave * CPW * W2_FR * FR;
+  auto frag = [&](int t) __attribute__((always_inline)) -> wfrag_t {
     const int cc = t / N, i = t % N;
-    if (i < W1_FR) return *(const half8*)(w1 + ((long)cc * W1_FR + (i & 1) * KS + (i >> 1)) * FR);
-    return *(const half8*)(w2 + ((long)cc * W2_FR + (i - W1_FR)) * FR);
+    if (i < W1_FR) return sw_wfrag(w1 + ((long)cc * W1_FR + (i & 1) * KS + (i >> 1)) * FR, lane);
+    return sw_wfrag(w2 + ((long)cc * W2_FR + (i - W1_FR)) * FR, lane);
   };
-  half8 ring[RDT];
+  wfrag_t ring[RDT];
 #pragma unroll
   for (int t = 0; t < RDT; ++t) ring[t] = frag(t);
   static_for<CPW>([&](auto ccc) __attribute__((always_inline)) {
@@ -437,16 +482,17 @@ __global__ __launch_bounds__(64 * NWT) void swin_mlp2_tail_kernel(SwinMlp2Params
     }
     static_for<W1_FR>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value, t = cc * N + i;
-      h[i & 1] = mfma16(ring[t % RDT], xf[i >> 1], h[i & 1]);
+      h[i & 1] = sw_mfma(ring[t % RDT], xf[i >> 1], h[i & 1]);
       if constexpr (t + RDT < CPW * N) ring[t % RDT] = frag(t + RDT);
       __builtin_amdgcn_sched_barrier(0);
     });
-    half8 hf;
+    half8 hf8;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) hf[k] = (half_t)gelu_erf2(h[k >> 2][k & 3]);
+    for (int k = 0; k < 8; ++k) hf8[k] = (half_t)gelu_erf2(h[k >> 2][k & 3]);
+    const wfrag_t hf = sw_frag(hf8);
     static_for<W2_FR>([&](auto ic) __attribute__((always_inline)) {
       constexpr int ct = decltype(ic)::value, t = cc * N + W1_FR + ct;
-      acc2[ct] = mfma16(ring[t % RDT], hf, acc2[ct]);
+      acc2[ct] = sw_mfma(ring[t % RDT], hf, acc2[ct]);
       if constexpr (t + RDT < CPW * N) ring[t % RDT] = frag(t + RDT);
       __builtin_amdgcn_sched_barrier(0);
     });
