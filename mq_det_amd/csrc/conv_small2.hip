@@ -9,6 +9,16 @@
 // outputs to mq_conv3x3_nchw32_fwd on the device and through tests/simt.
 #include "common.h"
 
+// SPLIT-PRECISE build (-DMQ_F32, round 6): the window and the weight slices are PLANAR in LDS -- hi = fp16(x) and lo = fp16((x - hi) 2^11) planes
+// with the fp16 build's pitch, the same bytes as the fp32 tiles -- split ONCE by the thread that stages a chunk; the k-loop reads one 16-byte
+// fragment per plane and issues three fp16 MFMAs (mfma16_split).  (Splitting inside mfma16 cost ~100 VALU instructions per 12 MFMAs here: every
+// fragment feeds only two.)
+#if defined(MQ_F32) && !defined(MQ_F32_EXACT)
+#define MQ_CS_SPLIT 1
+#else
+#define MQ_CS_SPLIT 0
+#endif
+
 MQ_NAMESPACE_BEGIN
 
 struct ConvSmall2Params {
@@ -60,7 +70,16 @@ __global__ __launch_bounds__(256) void conv3x3_small2_kernel(ConvSmall2Params p)
 #pragma unroll
       for (int i = 0; i < WMAX; ++i) {
         const int c = tid + i * 256;
+#if MQ_CS_SPLIT
+        if (c < 32 * cpr) {
+          const mq_split8 sp = mq_split(wreg[i]);
+          _Float16* d = (_Float16*)Ws + (buf * 32 + c / cpr) * XP + (c % cpr) * 8;
+          *(mq_h16x8*)d = sp.hi;
+          *(mq_h16x8*)(d + 2 * 32 * XP) = sp.lo;
+        }
+#else
         if (c < 32 * cpr) *(half8*)(Ws + (buf * 32 + c / cpr) * XP + (c % cpr) * 8) = wreg[i];
+#endif
       }
     };
     w_issue(0);
@@ -84,7 +103,16 @@ __global__ __launch_bounds__(256) void conv3x3_small2_kernel(ConvSmall2Params p)
         const int px = cc / cpr, ch = cc - px * cpr;
         const int hh = ho0 - 1 + px / CS2_WW, ww = wo0 - 1 + px % CS2_WW;
         const bool inside = hh >= 0 && hh < p.H && ww >= 0 && ww < p.W;
+#if MQ_CS_SPLIT
+        if (c < total) {
+          const mq_split8 sp = mq_split(inside ? v[u] : zero8());
+          _Float16* d = (_Float16*)Win + px * XP + ch * 8;
+          *(mq_h16x8*)d = sp.hi;
+          *(mq_h16x8*)(d + CS2_WH * CS2_WW * XP) = sp.lo;
+        }
+#else
         if (c < total) *(half8*)(Win + px * XP + ch * 8) = inside ? v[u] : zero8();
+#endif
       }
     }
     w_commit(0);
@@ -93,6 +121,27 @@ __global__ __launch_bounds__(256) void conv3x3_small2_kernel(ConvSmall2Params p)
     for (int tap = 0; tap < 9; ++tap) {
       if (tap + 1 < 9) w_issue(tap + 1);
       const int dy = tap / 3, dx = tap - dy * 3;
+#if MQ_CS_SPLIT
+      const _Float16* a0 = (const _Float16*)Win + ((2 * wave + dy) * CS2_WW + l15 + dx) * XP + lg * 8;
+      const _Float16* b0 = (const _Float16*)Ws + ((tap & 1) * 32 + l15) * XP + lg * 8;
+      for (int kk = 0; kk < CP / 32; ++kk) {
+        mq_split8 af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          af[i].hi = *(const mq_h16x8*)(a0 + i * CS2_WW * XP + kk * 32);
+          af[i].lo = *(const mq_h16x8*)(a0 + CS2_WH * CS2_WW * XP + i * CS2_WW * XP + kk * 32);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bf[j].hi = *(const mq_h16x8*)(b0 + j * 16 * XP + kk * 32);
+          bf[j].lo = *(const mq_h16x8*)(b0 + 2 * 32 * XP + j * 16 * XP + kk * 32);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma16_split(af[i], bf[j], acc[i][j]);
+      }
+#else
       const half_t* a0 = Win + ((2 * wave + dy) * CS2_WW + l15 + dx) * XP + lg * 8;
       const half_t* b0 = Ws + ((tap & 1) * 32 + l15) * XP + lg * 8;
       for (int kk = 0; kk < CP / 32; ++kk) {
@@ -106,6 +155,7 @@ __global__ __launch_bounds__(256) void conv3x3_small2_kernel(ConvSmall2Params p)
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
       }
+#endif
       if (tap + 1 < 9) w_commit((tap + 1) & 1);
       __syncthreads();                                       // also: window + weights free for the next pass
     }

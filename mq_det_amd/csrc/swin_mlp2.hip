@@ -154,17 +154,27 @@ __device__ __forceinline__ void ln_fragments(const SwinMlp2Params& p, long row0,
 // profiles/r03_call3_microbench_swin_mlp.json: 0.2207 vs 0.2199 ms at C = 384, 0.206 vs 0.189 at C = 192 (one wave per SIMD less) --
 // the DMA latency is not what bounds an iteration; removed.)
 template <int C, int NW, bool TABLE>
-__global__ __launch_bounds__(64 * NW, (C <= 96 ? 4 : C <= 192 ? 3 : 2)) void swin_mlp2_kernel(SwinMlp2Params p) {
+// (split-precise: the planar fragments are twice the registers and the weight rings twice the LDS -- C = 96: two workgroups per SIMD set, C = 192:
+// one, which the 100 KB of its rings allow anyway)
+__global__ __launch_bounds__(64 * NW, MQ_SW_SPLIT ? (C <= 96 ? 2 : 1) : (C <= 96 ? 4 : C <= 192 ? 3 : 2)) void swin_mlp2_kernel(SwinMlp2Params p) {
+  static_assert(!(MQ_SW_SPLIT && C >= 384) || NW == 4, "split-precise C = 384: four waves (one per SIMD)");
   constexpr int NT = 64 * NW, BM = 16 * NW, HID = 4 * C, KS = C / 32, CT = C / 16, NCHUNK = HID / 32;
   constexpr int FR = 512;                                     // halfs per fragment block (64 lanes x 8)
   constexpr int W1_FR = 2 * KS, W2_FR = CT, IT_FR = W1_FR + W2_FR;   // fragment blocks of one chunk of W1 / W2 / staged per iteration
   constexpr int FPW = IT_FR / NW;                             // fragment blocks a wave stages per iteration
   constexpr int D = 1, NS = D + 1, U = 2;                     // prefetch distance, ring stages, unroll = lcm(2, NS)
+  // W2ONE (split-precise, C = 384): two stages of both rings would be 192 KB of planar fragments.  W1 keeps its two stages (96 KB); W2 has ONE
+  // (48 KB): chunk j is loaded at the END of iteration j -- behind the barrier that says everybody has read chunk j - 1 -- and waited for before
+  // iteration j + 1 starts: one exposed L2 -> LDS copy of 48 KB per iteration, against streaming ALL weights from L2 for every 16 tokens (the
+  // tail kernel, which is what round 5's precise mode ran this width through: 1.04 ms per launch).
+  constexpr bool W2ONE = MQ_SW_SPLIT && C >= 384;
+  constexpr int NS2 = W2ONE ? 1 : NS;
   static_assert(C % 32 == 0 && IT_FR % NW == 0 && NCHUNK % U == 0, "tile shapes");
+  static_assert(!W2ONE || (W1_FR % NW == 0 && W2_FR % NW == 0), "per-ring staging");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* w1s = (half_t*)smem;                                // [NS][W1_FR][FR]   W1 ring: chunk c lives in stage c % NS
-  half_t* w2s = w1s + NS * W1_FR * FR;                        // [NS][W2_FR][FR]   W2 ring
-  half_t* b1s = w2s + NS * W2_FR * FR;                        // [HID]             fc1 bias (no ordinary global load inside the loop)
+  half_t* w2s = w1s + NS * W1_FR * FR;                        // [NS2][W2_FR][FR]  W2 ring
+  half_t* b1s = w2s + NS2 * W2_FR * FR;                       // [HID]             fc1 bias (no ordinary global load inside the loop)
   float* tab = (float*)(b1s + HID);                           // [MQ_GELU_TAB_N][2] (TABLE)
 
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
@@ -189,11 +199,33 @@ __global__ __launch_bounds__(64 * NW, (C <= 96 ? 4 : C <= 192 ? 3 : 2)) void swi
 #endif
     }
   };
+  // (W2ONE) the two rings staged separately: `nb` fragment blocks from `g` to `l`, block f by wave f % NW
+  auto stage_ring = [&](const half_t* g, half_t* l, auto NBc) __attribute__((always_inline)) {
+    constexpr int nb = decltype(NBc)::value;
+#pragma unroll
+    for (int i = 0; i < nb / NW; ++i) {
+      const int f = wave + i * NW;
+#if MQ_SW_SPLIT
+      const char* sb = (const char*)(g + (long)f * FR) + lane * 16;
+      char* dst = (char*)(l + f * FR);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + 1024), (__attribute__((address_space(3))) void*)(dst + 1024), 16, 0, 0);
+#else
+      lds_stage_frag8(g + (long)f * FR + lane * 8, l + f * FR, lane);
+#endif
+    }
+  };
   // chunks 0 .. D of W1 and chunk 0 of W2 -- into its own stage 0 and into stage NS - 1, which iteration 0 reads for its GEMM2 of the
   // (all-zero) H of "chunk -1": finite weights x 0 = 0, so iteration 0 needs no special case -- : everything the fill and the first
   // iterations read before their own pieces land
+  if constexpr (W2ONE) {
 #pragma unroll
-  for (int c = 0; c <= D; ++c) stage_issue(c, c % NS, 0, c == 0 ? 0 : NS - 1);
+    for (int c = 0; c <= D; ++c) stage_ring(p.w1f + (long)c * W1_FR * FR, w1s + (c % NS) * W1_FR * FR, std::integral_constant<int, W1_FR>{});
+    stage_ring(p.w2f, w2s, std::integral_constant<int, W2_FR>{});
+  } else {
+#pragma unroll
+    for (int c = 0; c <= D; ++c) stage_issue(c, c % NS, 0, c == 0 ? 0 : NS - 1);
+  }
   for (int i = tid; i < HID / 8; i += NT) *(half8*)(b1s + i * 8) = *(const half8*)(p.b1 + i * 8);
   if constexpr (TABLE) {
     // Phi(x_i), Phi(x_i+1) - Phi(x_i) at x_i = -6 + i / 64
@@ -300,10 +332,11 @@ __global__ __launch_bounds__(64 * NW, (C <= 96 ? 4 : C <= 192 ? 3 : 2)) void swi
       __attribute__((always_inline)) {
     constexpr int PH = decltype(PHc)::value;                  // j % NS
     constexpr int N = 2 * KS + CT;
-    constexpr int S1 = (PH + 1) % NS, S2 = (PH + NS - 1) % NS;          // stages of W1 chunk j + 1 / W2 chunk j - 1 (read now)
+    constexpr int S1 = (PH + 1) % NS, S2 = W2ONE ? 0 : (PH + NS - 1) % NS;          // stages of W1 chunk j + 1 / W2 chunk j - 1 (read now)
     // pieces for iteration j + D: W1 chunk j + 1 + D -> the stage W1 chunk j left (read in iteration j - 1), W2 chunk j - 1 + D -> the stage
     // of W2 chunk j - 2 (ditto).  Past the end the chunk index is clamped (valid memory, results unused).
-    stage_issue(min(j + 1 + D, NCHUNK + 1), PH, min(j - 1 + D, NCHUNK - 1), (PH + NS - 2) % NS);
+    if constexpr (W2ONE) stage_ring(p.w1f + (long)min(j + 1 + D, NCHUNK + 1) * W1_FR * FR, w1s + PH * W1_FR * FR, std::integral_constant<int, W1_FR>{});
+    else stage_issue(min(j + 1 + D, NCHUNK + 1), PH, min(j - 1 + D, NCHUNK - 1), (PH + NS - 2) % NS);
     h_init(j + 1, hout);
     const half_t* a1 = w1s + S1 * W1_FR * FR;                 // W1 chunk j + 1 (for j = NCHUNK - 1: a zero chunk)
     const half_t* a2 = w2s + S2 * W2_FR * FR;                 // W2 chunk j - 1
@@ -338,6 +371,11 @@ __global__ __launch_bounds__(64 * NW, (C <= 96 ? 4 : C <= 192 ? 3 : 2)) void swi
     // end of iteration j: the pieces issued at its top must have landed before anybody reads them in iteration j + 1
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * FPW) : "memory");
     __builtin_amdgcn_s_barrier();
+    if constexpr (W2ONE) {                                    // everybody has read W2 chunk j - 1: chunk j takes its place (exposed: see above)
+      stage_ring(p.w2f + (long)min(j, NCHUNK - 1) * W2_FR * FR, w2s, std::integral_constant<int, W2_FR>{});
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
   };
   float4_ hA[2], hB[2];
   half8 hfA, hfB = zero8();                                   // hfB: H of "chunk -1" = 0 (iteration 0's GEMM2 adds nothing)
@@ -352,7 +390,7 @@ __global__ __launch_bounds__(64 * NW, (C <= 96 ? 4 : C <= 192 ? 3 : 2)) void swi
       else
         step(jb + u, std::integral_constant<int, u % NS>{}, std::integral_constant<int, 1>{}, hB, hA, hfA, hfB);
     });
-  gemm2((NCHUNK - 1) % NS, hfB);                              // pipeline drain: the last chunk's GEMM 2 (NCHUNK is even: hfB holds it)
+  gemm2(W2ONE ? 0 : (NCHUNK - 1) % NS, hfB);                  // pipeline drain: the last chunk's GEMM 2 (NCHUNK is even: hfB holds it)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the clamped pieces of the last iterations land before the LDS is released
 
   // ---- epilogue: lane holds OUT^T[c = 16 ct + 4 g + r][token = l15]; + bias + residual (x' re-read: L2-hot), fp32 out; loads of a
@@ -580,7 +618,8 @@ static int device_cus() { return mq_device_cus(); }
 
 template <int C, int NW, bool TABLE>
 static int launch_swin_mlp2_main(const SwinMlp2Params& p, hipStream_t s) {
-  constexpr size_t smem = (size_t)2 * (2 * (C / 32) + C / 16) * 512 * sizeof(half_t) + (size_t)4 * C * sizeof(half_t) +
+  constexpr bool w2one = MQ_SW_SPLIT && C >= 384;           // (see swin_mlp2_kernel: one W2 stage)
+  constexpr size_t smem = (size_t)(2 * 2 * (C / 32) + (w2one ? 1 : 2) * (C / 16)) * 512 * sizeof(half_t) + (size_t)4 * C * sizeof(half_t) +
                           (TABLE ? MQ_GELU_TAB_N * 2 * sizeof(float) : 0);
   static MqOncePerDevice attr;
   if (attr.first()) {
@@ -657,9 +696,17 @@ extern "C" int MQ_SYM(mq_swin_mlp2_fwd)(const float* x, const void* delta, const
   if (y && (!next_g || !next_b)) return -2;
   hipStream_t s = (hipStream_t)stream;
   switch (C) {
+#if MQ_SW_SPLIT
+    // split-precise: workgroups per CU by the planar rings (48 / 96 / 150 KB of LDS) and the launch bounds; C = 384 with FOUR waves (64 tokens) per
+    // workgroup: one wave per SIMD, the planar fragments of 12 k-steps + 24 accumulator tiles need more than 256 registers
+    case 96: return dispatch_swin_mlp2<96, 4, 6, 2>(p, flags, s);
+    case 192: return dispatch_swin_mlp2<192, 4, 6, 1>(p, flags, s);
+    case 384: return dispatch_swin_mlp2<384, 4, 8, 1>(p, flags, s);
+#else
     case 96: return dispatch_swin_mlp2<96, 4, 6, 4>(p, flags, s);
     case 192: return dispatch_swin_mlp2<192, 4, 6, 3>(p, flags, s);
     case 384: return dispatch_swin_mlp2<384, 8, 8, 1>(p, flags, s);
+#endif
     default: return -1;                                      // other widths: library GEMM path of the caller
   }
 }

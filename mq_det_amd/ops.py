@@ -806,6 +806,23 @@ def swin_mlp_w2_perm(K, device=None):
     return blk * 32 + torch.where(t < 4, 4 * g + t, 16 + 4 * g + (t - 4))
 
 
+def split_planar_blocks(t, block=512):
+    """The split-precise form of an fp32 operand tensor whose kernel reads it in blocks of `block` elements (csrc/common.h: x = hi + lo / 2^11,
+    hi = fp16(x), lo = fp16((x - hi) 2^11)): same shape, dtype float32, but the BYTES of every block are [hi: block fp16 | lo: block fp16] -- what a
+    kernel of the precise mode stages with two linear copies and reads back as one 16-byte fragment per plane.  Done once, at pack time."""
+    assert t.dtype == torch.float32 and t.numel() % block == 0
+    x = t.reshape(-1, block)
+    hi = x.to(torch.float16)
+    lo = ((x - hi.float()) * 2048.0).to(torch.float16)
+    return torch.cat([hi, lo], 1).contiguous().view(torch.float32).reshape(t.shape)
+
+
+def unsplit_planar_blocks(t, block=512):
+    """Inverse of split_planar_blocks (tests): the fp32 values hi + lo / 2^11."""
+    h = t.reshape(-1, block).contiguous().view(torch.float16).reshape(-1, 2, block).float()
+    return (h[:, 0] + h[:, 1] / 2048.0).reshape(t.shape)
+
+
 def swin_mlp2_pack(w1, w2):
     """fc1.weight [4C, C], fc2.weight [C, 4C] -> (w1f, w2f), the fragment-major operands of mq_swin_mlp2_fwd (include/mqdet_hip.h):
     every 512-element block is one MFMA A fragment in lane order (lane = 16 g + l15 holds row l15, k-slots 8 g .. 8 g + 7); w1f carries
@@ -817,6 +834,9 @@ def swin_mlp2_pack(w1, w2):
     w1f = torch.cat([w1f, w1f.new_zeros(2, w1f.shape[1])], 0).reshape(-1).contiguous()
     w2p = w2[:, swin_mlp_w2_perm(HID, w2.device)]
     w2f = w2p.reshape(CT, 16, NCH, 4, 8).permute(2, 0, 3, 1, 4).reshape(-1).contiguous()         # [j][ct][g][l15][8]
+    if w1f.dtype == torch.float32 and f32_operands():
+        # split-precise mode: every weight fragment feeds ONE MFMA per wave, so the operands are split HERE, once (csrc/swin_mlp2.hip MQ_SW_SPLIT)
+        w1f, w2f = split_planar_blocks(w1f), split_planar_blocks(w2f)
     return w1f, w2f
 
 
@@ -843,8 +863,8 @@ def swin_mlp2(x, delta, ln_g, ln_b, eps, w1f, b1, w2f, b2, next_ln=None, flags=N
         flags = 0 if C == 192 else 2          # table GELU except at C = 192 (profiles/r03_call5_microbench_swin_mlp.json)
     if f32_operands():
         flags &= ~2           # precise mode: the erf GELU (|error| <= 1.5e-7), not the interpolation table (7e-6)
-    if f32_operands() == 1 and C >= 384:
-        flags |= 4            # precise mode: the main kernel's weight stages are 196 KB at fp32 -- every block through the tail kernel (fragments from global memory)
+    # (round 5's precise mode sent C = 384 through the tail kernel: two stages of both fp32 weight rings were 196 KB.  The split-precise kernel keeps ONE
+    # W2 stage at that width -- 150 KB -- and four waves per workgroup: csrc/swin_mlp2.hip W2ONE.)
     fn = _fn(lib, "mq_swin_mlp2_fwd", w1f)
 
     def call(fl):

@@ -527,7 +527,9 @@ def roi_align(feat, rois, output_size, spatial_scale, sampling_ratio, aligned=Tr
 
 def swin_mlp2_unpack(w1f, w2f, C):
     """Inverse of ops.swin_mlp2_pack: fragment-major (w1f, w2f) -> (fc1.weight [4C, C], fc2.weight [C, 4C])."""
-    from mq_det_amd.ops import swin_mlp_w2_perm
+    from mq_det_amd.ops import swin_mlp_w2_perm, f32_operands, unsplit_planar_blocks
+    if w1f.dtype == torch.float32 and f32_operands():           # the split-precise pack: blocks of [hi | lo] fp16 planes
+        w1f, w2f = unsplit_planar_blocks(w1f), unsplit_planar_blocks(w2f)
     HID, KS, CT, NCH = 4 * C, C // 32, C // 16, 4 * C // 32
     w1 = w1f.reshape(NCH + 2, 2, KS, 4, 16, 8)[:NCH].permute(0, 1, 4, 2, 3, 5).reshape(HID, C)
     assert float(w1f.reshape(NCH + 2, -1)[NCH:].float().abs().max()) == 0.0          # the two zero chunks the pipeline reads ahead

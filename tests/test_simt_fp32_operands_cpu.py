@@ -87,7 +87,7 @@ def test_tiny_full_model_meets_1e_3_with_fp32_operands(f32):
 
 @pytest.mark.parametrize("name", ["check_swin_fpn", "check_window_attention", "check_gcp_block", "check_pre_select", "check_vl_fuse", "check_dyconv",
                                   "check_align_fused", "check_bert_attn_qkv", "check_attention_text", "check_gcp_attn_fused", "check_dcn",
-                                  "check_vlfuse_kernels"])
+                                  "check_vlfuse_kernels", "check_swin_mlp"])
 def test_blocks_meet_1e_3_with_fp32_operands(f32, name):
     # "every_kernel" only where the 16-bit modes launch something else than the device's precise mode does (the fused Swin MLP main kernel at
     # C = 384, the grouped offset conv, the double-buffered DCNv2, the VLFuse variants): the other kernels are the same launch in both modes
