@@ -54,12 +54,15 @@ __device__ __forceinline__ wfrag_t sw_wfrag(const half_t* blk, int lane) {
   f.lo = *(const mq_h16x8*)(h + 512);
   return f;
 }
+#define SW_LANE8 0                       // the lane offset is applied inside sw_wfrag (fp16 units of a plane)
+#define SW_WFRAG(ptr) sw_wfrag((ptr), lane)
 #else
 #define MQ_SW_SPLIT 0
 typedef half8 wfrag_t;
-__device__ __forceinline__ wfrag_t sw_frag(half8 x) { return x; }
-__device__ __forceinline__ float4_ sw_mfma(wfrag_t a, wfrag_t b, float4_ c) { return mfma16(a, b, c); }
-__device__ __forceinline__ wfrag_t sw_wfrag(const half_t* blk, int lane) { return *(const half8*)(blk + lane * 8); }
+#define sw_frag(x) (x)
+#define sw_mfma(a, b, c) mfma16((a), (b), (c))
+#define SW_LANE8 (lane * 8)              // 16-bit builds: token for token the round-5 expressions (tools/isa_diff.py: identical ISA)
+#define SW_WFRAG(ptr) (*(const half8*)(ptr))
 #endif
 
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7): erf(|v| / sqrt 2) = 1 - poly(t) exp(-v^2 / 2), t = 1 / (1 + p |v| / sqrt 2)
@@ -187,15 +190,17 @@ __global__ __launch_bounds__(64 * NW, MQ_SW_SPLIT ? (C <= 96 ? 2 : 1) : (C <= 96
 #pragma unroll
     for (int i = 0; i < FPW; ++i) {
       const int f = wave + i * NW;
-      const half_t* blk = f < W1_FR ? p.w1f + ((long)c1 * W1_FR + f) * FR : p.w2f + ((long)c2 * W2_FR + (f - W1_FR)) * FR;
-      half_t* dst = f < W1_FR ? w1s + (s1 * W1_FR + f) * FR : w2s + (s2 * W2_FR + (f - W1_FR)) * FR;
 #if MQ_SW_SPLIT
       // the 2 KB planar block as two linear 1 KB LDS-DMA pieces (hi plane, lo plane): asynchronous like the 16-bit builds' one piece
+      const half_t* blk = f < W1_FR ? p.w1f + ((long)c1 * W1_FR + f) * FR : p.w2f + ((long)c2 * W2_FR + (f - W1_FR)) * FR;
+      half_t* dst = f < W1_FR ? w1s + (s1 * W1_FR + f) * FR : w2s + (s2 * W2_FR + (f - W1_FR)) * FR;
       const char* sb = (const char*)blk + lane * 16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + 1024), (__attribute__((address_space(3))) void*)((char*)dst + 1024), 16, 0, 0);
 #else
-      lds_stage_frag8(blk + lane * 8, dst, lane);
+      const half_t* src = (f < W1_FR ? p.w1f + ((long)c1 * W1_FR + f) * FR : p.w2f + ((long)c2 * W2_FR + (f - W1_FR)) * FR) + lane * 8;
+      half_t* dst = f < W1_FR ? w1s + (s1 * W1_FR + f) * FR : w2s + (s2 * W2_FR + (f - W1_FR)) * FR;
+      lds_stage_frag8(src, dst, lane);
 #endif
     }
   };
@@ -238,13 +243,18 @@ __global__ __launch_bounds__(64 * NW, MQ_SW_SPLIT ? (C <= 96 ? 2 : 1) : (C <= 96
     }
   }
 
+#if MQ_SW_SPLIT
   wfrag_t xf[KS];
   {
     half8 xr[KS];
     if (p.delta) ln_fragments<C, true>(p, row0, l15, g, xr); else ln_fragments<C, false>(p, row0, l15, g, xr);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) xf[ks] = sw_frag(xr[ks]);       // (split-precise: split once per wave; else the fragments as they are)
+    for (int ks = 0; ks < KS; ++ks) xf[ks] = sw_frag(xr[ks]);       // split once per wave
   }
+#else
+  half8 xf[KS];
+  if (p.delta) ln_fragments<C, true>(p, row0, l15, g, xf); else ln_fragments<C, false>(p, row0, l15, g, xf);
+#endif
 
   __syncthreads();                                            // (drains the DMAs: vmcnt(0)) W1 chunks 0 .. D, W2 chunk 0, bias, table visible
 
@@ -262,19 +272,23 @@ __global__ __launch_bounds__(64 * NW, MQ_SW_SPLIT ? (C <= 96 ? 2 : 1) : (C <= 96
   };
   // GEMM 1 (transposed) of one chunk from W1 stage `st`: H^T[32 hidden, 16 tokens] over K = C (pipeline fill only)
   auto gemm1 = [&](int st, float4_ (&h)[2]) {
-    const half_t* a = w1s + st * W1_FR * FR;
+    const half_t* a = w1s + st * W1_FR * FR + SW_LANE8;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      h[0] = sw_mfma(sw_wfrag(a + ks * FR, lane), xf[ks], h[0]);
-      h[1] = sw_mfma(sw_wfrag(a + (KS + ks) * FR, lane), xf[ks], h[1]);
+      h[0] = sw_mfma(SW_WFRAG(a + ks * FR), xf[ks], h[0]);
+      h[1] = sw_mfma(SW_WFRAG(a + (KS + ks) * FR), xf[ks], h[1]);
     }
   };
   // GEMM 2 (transposed) of one chunk from W2 stage `st`: OUT^T[C, 16 tokens] += W2p[:, 32 k-slots] . H^T (pipeline drain only)
   auto gemm2 = [&](int st, const half8& hf) {
-    const half_t* a = w2s + st * W2_FR * FR;
+    const half_t* a = w2s + st * W2_FR * FR + SW_LANE8;
+#if MQ_SW_SPLIT
     const wfrag_t hs = sw_frag(hf);
+#else
+    const half8& hs = hf;
+#endif
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) acc2[ct] = sw_mfma(sw_wfrag(a + ct * FR, lane), hs, acc2[ct]);
+    for (int ct = 0; ct < CT; ++ct) acc2[ct] = sw_mfma(SW_WFRAG(a + ct * FR), hs, acc2[ct]);
   };
 
   // ---- one pipelined iteration.  Its MFMAs form ONE sequence of N = 2 KS + CT steps that alternates GEMM1(chunk j + 1) -- a
@@ -338,14 +352,18 @@ __global__ __launch_bounds__(64 * NW, MQ_SW_SPLIT ? (C <= 96 ? 2 : 1) : (C <= 96
     if constexpr (W2ONE) stage_ring(p.w1f + (long)min(j + 1 + D, NCHUNK + 1) * W1_FR * FR, w1s + PH * W1_FR * FR, std::integral_constant<int, W1_FR>{});
     else stage_issue(min(j + 1 + D, NCHUNK + 1), PH, min(j - 1 + D, NCHUNK - 1), (PH + NS - 2) % NS);
     h_init(j + 1, hout);
-    const half_t* a1 = w1s + S1 * W1_FR * FR;                 // W1 chunk j + 1 (for j = NCHUNK - 1: a zero chunk)
-    const half_t* a2 = w2s + S2 * W2_FR * FR;                 // W2 chunk j - 1
+    const half_t* a1 = w1s + S1 * W1_FR * FR + SW_LANE8;      // W1 chunk j + 1 (for j = NCHUNK - 1: a zero chunk)
+    const half_t* a2 = w2s + S2 * W2_FR * FR + SW_LANE8;      // W2 chunk j - 1
     // step i of the sequence: even -> GEMM1 fragment (hb = m & 1, ks = m >> 1), m = i / 2; odd -> GEMM2 fragment ct = i / 2
     auto frag = [&](int i) __attribute__((always_inline)) -> wfrag_t {
       const int m = i >> 1;
-      return (i & 1) ? sw_wfrag(a2 + m * FR, lane) : sw_wfrag(a1 + ((m & 1) * KS + (m >> 1)) * FR, lane);
+      return (i & 1) ? SW_WFRAG(a2 + m * FR) : SW_WFRAG(a1 + ((m & 1) * KS + (m >> 1)) * FR);
     };
-    const wfrag_t hs_old = sw_frag(hf_old);                   // (split-precise: the GELU output of chunk j - 1, split once for its CT MFMAs)
+#if MQ_SW_SPLIT
+    const wfrag_t hs_old = sw_frag(hf_old);                   // the GELU output of chunk j - 1, split once for its CT MFMAs
+#else
+    const half8& hs_old = hf_old;
+#endif
     wfrag_t ring[RD];
     float gts[8], ges[8];
 #pragma unroll
@@ -486,25 +504,30 @@ __global__ __launch_bounds__(64 * NWT) void swin_mlp2_tail_kernel(SwinMlp2Params
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long row0 = (long)blockIdx.x * 16;
 
+#if MQ_SW_SPLIT
   wfrag_t xf[KS];
   {
     half8 xr[KS];
     if (p.delta) ln_fragments<C, true>(p, row0, l15, g, xr); else ln_fragments<C, false>(p, row0, l15, g, xr);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) xf[ks] = sw_frag(xr[ks]);
+    for (int ks = 0; ks < KS; ++ks) xf[ks] = sw_frag(xr[ks]);       // split once per wave
   }
+#else
+  half8 xf[KS];
+  if (p.delta) ln_fragments<C, true>(p, row0, l15, g, xf); else ln_fragments<C, false>(p, row0, l15, g, xf);
+#endif
 
   float4_ acc2[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) acc2[ct] = (float4_){0.f, 0.f, 0.f, 0.f};
 
   // fragment t of this wave's stream: chunk wave * CPW + t / N; within a chunk first W1 (hb = m & 1, ks = m >> 1), then W2 (ct)
-  const half_t* w1 = p.w1f + (long)wave * CPW * W1_FR * FR;
-  const half_t* w2 = p.w2f + (long)wave * CPW * W2_FR * FR;
+  const half_t* w1 = p.w1f + (long)wave * CPW * W1_FR * FR + SW_LANE8;
+  const half_t* w2 = p.w2f + (long)wave * CPW * W2_FR * FR + SW_LANE8;
   auto frag = [&](int t) __attribute__((always_inline)) -> wfrag_t {
     const int cc = t / N, i = t % N;
-    if (i < W1_FR) return sw_wfrag(w1 + ((long)cc * W1_FR + (i & 1) * KS + (i >> 1)) * FR, lane);
-    return sw_wfrag(w2 + ((long)cc * W2_FR + (i - W1_FR)) * FR, lane);
+    if (i < W1_FR) return SW_WFRAG(w1 + ((long)cc * W1_FR + (i & 1) * KS + (i >> 1)) * FR);
+    return SW_WFRAG(w2 + ((long)cc * W2_FR + (i - W1_FR)) * FR);
   };
   wfrag_t ring[RDT];
 #pragma unroll
@@ -524,10 +547,16 @@ __global__ __launch_bounds__(64 * NWT) void swin_mlp2_tail_kernel(SwinMlp2Params
       if constexpr (t + RDT < CPW * N) ring[t % RDT] = frag(t + RDT);
       __builtin_amdgcn_sched_barrier(0);
     });
+#if MQ_SW_SPLIT
     half8 hf8;
 #pragma unroll
     for (int k = 0; k < 8; ++k) hf8[k] = (half_t)gelu_erf2(h[k >> 2][k & 3]);
     const wfrag_t hf = sw_frag(hf8);
+#else
+    half8 hf;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) hf[k] = (half_t)gelu_erf2(h[k >> 2][k & 3]);
+#endif
     static_for<W2_FR>([&](auto ic) __attribute__((always_inline)) {
       constexpr int ct = decltype(ic)::value, t = cc * N + W1_FR + ct;
       acc2[ct] = sw_mfma(ring[t % RDT], hf, acc2[ct]);
