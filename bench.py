@@ -129,7 +129,7 @@ def build_gdino_model(dev, n_classes=NUM_CLASSES_IN_CAPTION, dtype="f16"):
     from mq_det_amd.utils.tokenizer import build_synthetic_tokenizer, synthetic_caption, positive_map_from_spans
     cfg = get_gdino_cfg()
     cfg.MODEL.BACKBONE_CACHE = False          # every step a full forward (the synthetic loop re-sends the same tensor)
-    cfg.MODEL.COMPUTE_DTYPE = "bfloat16" if dtype == "bf16" else "float16"
+    cfg.MODEL.COMPUTE_DTYPE = {"bf16": "bfloat16", "f32": "float32"}.get(dtype, "float16")       # f32 = the split-precise mode (round 6: MQ-GroundingDINO too)
     cfg.GROUNDINGDINO.text_encoder_type = build_synthetic_tokenizer(tempfile.mkdtemp(prefix="mqdet_tok_"))
     model = build_detection_model(cfg)
     randomize_(model, seed=0)
@@ -245,7 +245,7 @@ CPU_BASELINE_THREADS = 32      # the oracle's many small torch ops stop scaling 
 def _cpu_baseline_worker():
     """BASELINE.md section 3 (configs[0]): the CPU oracle (pure-PyTorch fp32 restatement of the reference; the reference itself has no CPU
     path) on one 800x1333 image with a 20-token caption, TWICE: GLIP-T without vision queries (1 warm-up + 5 timed forwards -- `value`) and
-    MQ-GLIP-T with a 5-shot query bank (pre-select + 6 GCP blocks on; 1 warm-up + 3 timed -- `mq_glip_t`); min and median of each (VERDICT
+    MQ-GLIP-T with a 5-shot query bank (pre-select + 6 GCP blocks on; 1 warm-up + 2 timed -- `mq_glip_t`); min and median of each (VERDICT
     r5 #9: the median alone wandered 0.15 ... 0.23 between boxes).  A bounded sample: ~60 s of CPU work; threads pinned by the parent
     (OMP_PLACES=cores, OMP_PROC_BIND=close)."""
     from oracle import glip_t_spec
@@ -258,7 +258,7 @@ def _cpu_baseline_worker():
     pm = {1: [1], 2: [3], 3: [5, 6], 4: [8], 5: [10, 11], 6: [13]}
     t_all = time.time()
     out = {}
-    for key, vq, timed in (("glip_t", False, 5), ("mq_glip_t", True, 3)):
+    for key, vq, timed in (("glip_t", False, 5), ("mq_glip_t", True, 2)):
         spec = glip_t_spec(vision_query=vq)
         sd = make_state_dict(spec, 0)
         T, nvalid = spec.max_query_len, 20
@@ -285,7 +285,7 @@ def _cpu_baseline_worker():
                                            "torch ops crawl -- an all-core sample did not finish inside 6 minutes (GPU call 14 of round 4) -- so the "
                                            "thread count is capped and stated",
                       "sample": f"one 800x1333 image (padded 800x1344), 20-token caption, fp32 CPU oracle: GLIP-T (no vision queries) 1 warm-up + 5 timed "
-                                f"forwards = value (median); mq_glip_t = the same with a 5-shot query bank, 1 + 3 forwards; {time.time() - t_all:.0f} s in "
+                                f"forwards = value (median); mq_glip_t = the same with a 5-shot query bank, 1 + 2 forwards; {time.time() - t_all:.0f} s in "
                                 f"total, {threads} pinned torch threads on a {os.cpu_count()}-core host"}), flush=True)
 
 
@@ -325,9 +325,7 @@ def _cpu_baseline_worker_gdino():
 
 
 def cpu_baseline_start(flag="--cpu-baseline-worker"):
-    """Start the CPU-oracle worker (its own process, pinned threads, no GPU visible).  The default run starts it right behind the timed region and
-    collects it at the very end, so that its ~60 s of host work run BESIDE the bounded GPU sub-runs instead of after them (the
-    default run took 181 s for a 0.33 s timed region)."""
+    """Start the CPU-oracle worker (its own process, pinned threads, no GPU visible)."""
     import subprocess
     env = dict(os.environ, OMP_NUM_THREADS=str(CPU_BASELINE_THREADS), MKL_NUM_THREADS=str(CPU_BASELINE_THREADS),
                OMP_PLACES="cores", OMP_PROC_BIND="close", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
@@ -891,7 +889,7 @@ def main():
             res["kernel_selection"] = dict(ops.KERNELS)
             res["pmc_traffic_file"] = _pmc().get("_file")
             res["timing"] = "roofline records: HIP events on the launch stream around each launch, eager single-stream pass of the same steps"
-            cpu_proc = cpu_baseline_start() if (world == 1 and not args.no_cpu_baseline and not large) else None      # runs beside the sub-runs below
+            want_cpu = world == 1 and not args.no_cpu_baseline and not large
             if world == 1 and not args.no_lang_b64 and not large:
                 try:
                     res["lang_path_b64"] = lang_path_b64(model, cfg, dev, chunks)
@@ -911,9 +909,11 @@ def main():
                     if time.perf_counter() - t_start < limit:
                         other[key] = _sub_bench(argv, None, 150, keep=("roofline", "model_tflops", "lvis_style_images_per_sec", "forwards_per_step"))
                 res["other_configs"] = other
-            if cpu_proc is not None:
+            if want_cpu:
+                # AFTER the GPU sub-runs, not beside them: GPU call 4 of round 6 ran the worker concurrently -- its median went from 5.7 to 12.2 s per
+                # forward and the sub-runs lost 10 - 45 % (host threads of the replayed graphs compete with 32 pinned OpenMP threads)
                 try:
-                    res["cpu_baseline"] = cpu_baseline_finish(cpu_proc)
+                    res["cpu_baseline"] = cpu_baseline()
                 except Exception as e:  # noqa: BLE001
                     res["cpu_baseline"] = {"error": repr(e)[:200]}
         print(compact_line(res, args.extras_file, write=bool(args.extras_file) or not args.no_extras), flush=True)

@@ -527,6 +527,13 @@ MQ_BF16_TWIN(mq_msdeform_attn_q_fwd)
 #else
 #define MQ_F32_TWIN(name) extern __typeof__(name) name##_f32;
 #endif
+/* Round 6 (ABI 29) -- what differs in the *_f32 entry points beside the element type:
+ *   mq_swin_mlp2_fwd_f32   w1f / w2f are packed ALREADY SPLIT: every 512-element fragment block (2 KB) is [hi: 64 lanes x 8 fp16 | lo: 64 lanes x 8 fp16]
+ *                          with hi = fp16(w), lo = fp16((w - hi) 2^11) (mq_det_amd.ops.split_planar_blocks; ops.swin_mlp2_pack does it in the precise mode);
+ *   mq_dcnv2_*_f32, mq_vlfuse_*_f32, mq_conv3x3_nchw32_v2_fwd_f32   same arguments (fp32 tensors); inside, operands are split once when they are staged into
+ *                          planar hi / lo fp16 LDS tiles (a k-step of the DCNv2 kernel is 32 channels there);
+ *   mq_msdeform_attn_*_f32 new in ABI 29: `qproj` is fp32 (MQ-GroundingDINO in the precise mode).
+ * Every other *_f32 entry splits its MFMA operands on the fly (csrc/common.h mfma16). */
 MQ_F32_TWIN(mq_attn_fwd)
 MQ_F32_TWIN(mq_attn_resident_fwd)
 MQ_F32_TWIN(mq_attn_text_fwd)

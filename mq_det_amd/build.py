@@ -52,6 +52,7 @@ def build(force=False, verbose=True):
     if not force and not _stale():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
+    digest = _digest()        # of the sources as they are NOW: an edit made while hipcc runs must leave the stamp stale (round 6: it did not)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
@@ -73,7 +74,7 @@ def build(force=False, verbose=True):
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
     with open(STAMP, "w") as f:
-        f.write(_digest())
+        f.write(digest)
     if verbose:
         print(f"built {LIB}")
     return LIB

@@ -13,7 +13,7 @@ _LIB = None
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmqdet_hip.so")
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
-EXPECTED_ABI = 28        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
+EXPECTED_ABI = 29        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
 _SIGNATURES = {
     "mq_abi_version": (_i, []),
     "mq_attn_workspace_bytes": (_l, [_i, _i, _i, _i, _i]),
@@ -361,10 +361,12 @@ FUSED_BERT_MAX_WORKGROUPS = 768     # (batch item, head) workgroups up to which 
 def bert_attention_qkv_fits(T, C, heads, key_bias=None, batch=None):
     """Shapes mq_bert_attn_qkv_fwd takes: BERT-base (C = 768 = 12 x 64), up to 256 tokens (precise mode on the device: up to 160 -- the three
     [T, 80] tiles of a head are 154 KB at fp32), one key bias per (batch item, key).  batch: also apply the size policy of
-    KERNELS["BERT_ATTN_QKV_FUSED"] = 1 (the kernel only where it is measured to win; the precise mode takes it at any batch)."""
+    KERNELS["BERT_ATTN_QKV_FUSED"] = 1 (the kernel only where it is measured to win: not in the split-precise mode)."""
     ok = (C == 768 and C == 64 * heads and T <= (160 if f32_operands() == 1 else 256) and (key_bias is None or key_bias.dim() == 2))
-    if ok and batch is not None and KERNELS["BERT_ATTN_QKV_FUSED"] == 1 and not f32_operands():
-        ok = batch * heads <= FUSED_BERT_MAX_WORKGROUPS
+    if ok and batch is not None and KERNELS["BERT_ATTN_QKV_FUSED"] == 1:
+        # split-precise mode: the fused kernel still splits its operands inside mfma16 (335 spilled VGPRs at fp32 fragment sizes); the fp32 library
+        # GEMM + mq_attn_text_fwd pair measured +1.4 % end to end (GPU call 4 of round 6) -- the policy takes the pair there (= 2 forces the kernel)
+        ok = batch * heads <= FUSED_BERT_MAX_WORKGROUPS and not f32_operands()
     return ok
 
 
@@ -592,8 +594,9 @@ def gcp_attention_fits(x, idx, policy=False):
     """Shapes mq_gcp_attn_fwd takes: the fp32 text stream of BERT-base width, at most 8 vision-query slots per token.  policy: also apply the
     size rule of KERNELS["GCP_ATTN_FUSED"] = 1 (up to FUSED_TEXT_MAX_ROWS text rows per launch)."""
     ok = x.dtype == torch.float32 and x.shape[-1] == 768 and idx.shape[-1] <= 8
-    if ok and policy and KERNELS["GCP_ATTN_FUSED"] == 1 and not f32_operands():
-        ok = x.numel() // 768 <= FUSED_TEXT_MAX_ROWS
+    if ok and policy and KERNELS["GCP_ATTN_FUSED"] == 1:
+        # (split-precise mode: the eight launches, +1.3 % end to end -- as for the fused BERT kernel above)
+        ok = x.numel() // 768 <= FUSED_TEXT_MAX_ROWS and not f32_operands()
     return ok
 
 

@@ -104,10 +104,19 @@ def test_boundary_returns_boxlists(dev):
             assert set(o.get_field("labels").tolist()) <= set(pm.keys())
 
 
-def _same_detections(a, b, frac=0.85):
-    """Order-insensitive IoU matching (library GEMMs may pick different kernels for eager warm-up and capture, so
-    near-threshold detections are allowed to come and go; every hand-written HIP kernel is bitwise reproducible,
-    tests/determinism_diag.py)."""
+def _equal_detections(a, b):
+    """BIT-EQUAL detections.  `tools/replay_equality_probe.py` on the MI355X (GPU call 4 of round 6, profiles/r06_call4_replay_equality.txt):
+    an eager forward, the capture and every replay of its HIP graph produce identical bytes under every BLAS setting tried -- the library GEMMs pick the
+    same kernel for the same shape in and out of capture, and every hand-written kernel is bitwise reproducible (tests/determinism_diag.py) -- so
+    the same program on the same inputs is compared with torch.equal, not matched."""
+    return (len(a) == len(b) and torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("scores"), b.get_field("scores"))
+            and torch.equal(a.get_field("labels"), b.get_field("labels")))
+
+
+def _same_detections(a, b, frac=0.99, dscore=1e-3, iou_min=0.99):
+    """Order-insensitive IoU matching for comparisons ACROSS batch shapes (chunk batching, micro-batch lanes, B = 1 vs B = 8): the library GEMMs
+    pick their kernel by problem size, so the fp32 summation order -- and a near-threshold detection -- may differ; everything else must agree
+    tightly (round 5 allowed 10 - 15 % unmatched and 0.03 in the score)."""
     if len(b) == 0:
         return len(a) == 0
     ab, asc, al = a.bbox.cpu(), a.get_field("scores").cpu(), a.get_field("labels").cpu()
@@ -116,9 +125,9 @@ def _same_detections(a, b, frac=0.85):
         lt, rb = torch.max(ab[:, :2], box[:2]), torch.min(ab[:, 2:], box[2:])
         inter = (rb - lt + 1).clamp(min=0).prod(1)
         iou = inter / ((ab[:, 2] - ab[:, 0] + 1) * (ab[:, 3] - ab[:, 1] + 1) + (box[2] - box[0] + 1) * (box[3] - box[1] + 1) - inter)
-        ok = (al == lab) & (iou > 0.9) & ((asc - sc).abs() < 0.03)
+        ok = (al == lab) & (iou > iou_min) & ((asc - sc).abs() < dscore)
         hit += bool(ok.any())
-    return abs(len(a) - len(b)) <= max(3, len(b) // 20) and hit >= frac * len(b)
+    return abs(len(a) - len(b)) <= max(1, len(b) // 100) and hit >= frac * len(b)
 
 
 def test_hip_graph_replay_matches_eager(dev):
@@ -136,11 +145,11 @@ def test_hip_graph_replay_matches_eager(dev):
     model.clear_caches()
     outs = [model(il, **kw) for _ in range(4)]           # eager, capture+replay, replay, replay
     assert any(e.get("stage") == 2 for e in model._graphs.values()), "HIP graph was not captured"
-    for out in outs:
+    for out in outs:                                     # eager warm-up, capture + first replay, replays: the same bytes as the eager forward
         for a, b in zip(out, ref):
-            assert _same_detections(a, b)
+            assert _equal_detections(a, b)
     for a, b in zip(outs[2], outs[3]):                   # two replays of one graph
-        assert _same_detections(a, b, frac=0.9)
+        assert _equal_detections(a, b)
     # new pixels through the same graph
     il2 = ImageList(torch.flip(images, dims=[3]).to(dev), sizes)
     model.use_hip_graph = False
@@ -148,7 +157,7 @@ def test_hip_graph_replay_matches_eager(dev):
     model.use_hip_graph = True
     out2 = model(il2, **kw)
     for a, b in zip(out2, ref2):
-        assert _same_detections(a, b)
+        assert _equal_detections(a, b)
 
 
 def test_staggered_micro_batches_match_the_single_lane_forward(dev):
@@ -172,13 +181,15 @@ def test_staggered_micro_batches_match_the_single_lane_forward(dev):
             lanes = model(il, **kw)
             assert model.cache_stats["eager"] > 0
             for a, b in zip(lanes, ref):
-                assert _same_detections(a, b, frac=0.95)
+                assert _same_detections(a, b)
             model.use_hip_graph = True
             model.clear_caches()
             outs = [model(il, **kw) for _ in range(3)]
             assert any(k[0] == "_staggered_program" and e.get("stage") == 2 for k, e in model._graphs.items()), "staggered program was not captured"
             for a, b in zip(outs[2], ref):
-                assert _same_detections(a, b, frac=0.95)
+                assert _same_detections(a, b)
+            for a, b in zip(outs[2], outs[1]):                # capture + replay vs replay of the staggered program: the same bytes
+                assert _equal_detections(a, b)
     finally:
         model.micro_batches, model.backbone_cache, model.use_hip_graph = prev_mb, prev_cache, prev_graph
         model.clear_caches()
@@ -216,7 +227,7 @@ def test_hip_graph_capture_with_process_group(dev):
         g = parallel.gather_detections(model.last_packed)
         assert g.shape == model.last_packed.shape
         for a, b in zip(outs[1], outs[2]):
-            assert _same_detections(a, b, frac=0.9)
+            assert _equal_detections(a, b)
     finally:
         if created:
             dist.destroy_process_group()
@@ -298,7 +309,9 @@ def test_backbone_and_caption_caches(dev):
         for (cap, pm), r in zip(caps, ref):
             out = model(il, captions=[cap] * 2, positive_map=pm)
             for a, b in zip(out, r):
-                assert _same_detections(a, b, frac=0.9), (rep, cap[:20])
+                # a cache hit runs the SAME kernels on the same values (the cached features ARE the uncached forward's): the same bytes.  (The
+                # image-independent BERT layers of a cached caption were computed for ONE caption row set and repeated: same per-row arithmetic.)
+                assert _equal_detections(a, b) if os.environ.get("MQ_CACHE_EXACT", "1") == "1" else _same_detections(a, b), (rep, cap[:20])
     st = model.cache_stats
     assert st["backbone_miss"] == 4 and st["backbone_hit"] == 8, st
     assert st["front_hit"] >= 6 and st["graph_replay"] >= 4, st
@@ -309,7 +322,7 @@ def test_backbone_and_caption_caches(dev):
     assert len(batched) == len(caps)
     for out, r in zip(batched, ref):
         for a, b in zip(out, r):
-            assert _same_detections(a, b, frac=0.9)
+            assert _same_detections(a, b)
     il.tensors.add_(0.25)                                   # in-place change of the cached pixels -> version bump -> miss
     miss = model.cache_stats["backbone_miss"]
     model(il, captions=[caps[0][0]] * 2, positive_map=caps[0][1])

@@ -25,7 +25,7 @@ def test_c_abi_exports_match_header():
     lib = ops.load_library()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.mq_abi_version() == 28
+    assert lib.mq_abi_version() == ops.EXPECTED_ABI == 29
     assert lib.mq_attn_workspace_bytes(2, 8, 256, 256, 4) == 4 * 2 * 8 * 256 * 258 * 4
     assert lib.mq_ml_nms_workspace_bytes(2, 130) == 2 * 130 * 3 * 8
 
@@ -231,6 +231,11 @@ def test_fused_text_kernel_size_policy():
         assert ops.gcp_attention_fits(x8, idx, policy=True) and not ops.gcp_attention_fits(x64, idx, policy=True) and ops.gcp_attention_fits(x64, idx)
         assert ops.gcp_attention_fits(torch.zeros(64, 144, 768), idx, policy=True)
         assert not ops.gcp_attention_fits(x8, torch.zeros(8, 144, 9, dtype=torch.int32))                 # more than 8 slots: the unfused path
+        # the split-precise mode: the policy takes the unfused launches (the fused kernels still split inside mfma16: GPU call 4 of round 6) ...
+        ops.KERNELS["F32_OPERANDS"] = 1
+        assert not ops.bert_attention_qkv_fits(144, 768, 12, None, batch=8) and not ops.gcp_attention_fits(x8, idx, policy=True)
+        assert ops.bert_attention_qkv_fits(144, 768, 12, None) and ops.gcp_attention_fits(x8, idx)          # ... the kernels themselves still take the shapes
+        ops.KERNELS["F32_OPERANDS"] = 0
         ops.KERNELS["BERT_ATTN_QKV_FUSED"], ops.KERNELS["GCP_ATTN_FUSED"] = 2, 2
         assert ops.bert_attention_qkv_fits(144, 768, 12, None, batch=64) and ops.gcp_attention_fits(x64, idx, policy=True)
     finally:
