@@ -144,7 +144,46 @@ KERNEL_DEFAULTS = {
                                  # fp32 torch form; 2 = kernel-source emulation with a 320 KB LDS limit (every kernel as in the 16-bit modes)
     "ALIGN_FUSED": 1,            # 1: mq_align_fused_fwd (heads + alignment + scoring, logits never written); 0: bmm + 5 GEMMs + 5 x mq_align_scores_fwd
 }
-KERNELS = dict(KERNEL_DEFAULTS)       # filled from the environment right below configure() (import time), from cfg in prepare()
+class _ThreadLocalTable(dict):
+    """The LIVE kernel selection, one table per host thread: `activate()` at the top of a forward rewrites the table of the
+    thread that runs it, so two models with different selections driven from two host threads cannot change each other's kernels between two
+    launches.  A thread that has not activated anything sees the import-time table (defaults <- environment).  Behaves like a dict."""
+
+    def __init__(self, init):
+        super().__init__()
+        import threading
+        object.__setattr__(self, "_tl", threading.local())
+        object.__setattr__(self, "_base", dict(init))
+
+    def _cur(self):
+        t = self._tl
+        if not hasattr(t, "d"):
+            t.d = dict(self._base)
+        return t.d
+
+    def __getitem__(self, k): return self._cur()[k]
+    def __setitem__(self, k, v): self._cur()[k] = v
+    def __delitem__(self, k): del self._cur()[k]
+    def __contains__(self, k): return k in self._cur()
+    def __iter__(self): return iter(self._cur())
+    def __len__(self): return len(self._cur())
+    def __eq__(self, other): return self._cur() == (other._cur() if isinstance(other, _ThreadLocalTable) else other)
+    def __ne__(self, other): return not self.__eq__(other)
+    def __repr__(self): return repr(self._cur())
+    def get(self, k, default=None): return self._cur().get(k, default)
+    def keys(self): return self._cur().keys()
+    def values(self): return self._cur().values()
+    def items(self): return self._cur().items()
+    def clear(self): self._cur().clear()
+    def update(self, *a, **k): self._cur().update(*a, **k)
+    def copy(self): return dict(self._cur())
+
+    def set_base(self, d):
+        """What threads that never activated a selection see (import time / configure() on the main thread)."""
+        object.__setattr__(self, "_base", dict(d))
+
+
+KERNELS = _ThreadLocalTable(KERNEL_DEFAULTS)       # filled from the environment right below configure() (import time), from cfg in prepare()
 
 
 def configure(cfg=None):
@@ -167,6 +206,8 @@ def configure(cfg=None):
                 raise ValueError(f"environment variable MQ_{k} = {v!r}: the kernel selection takes integers") from None
     KERNELS.clear()
     KERNELS.update(sel)
+    if cfg is None:
+        KERNELS.set_base(sel)          # the environment-only table is also what a fresh host thread starts from
     return KERNELS
 
 

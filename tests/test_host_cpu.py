@@ -243,6 +243,35 @@ def test_fused_text_kernel_size_policy():
         ops.KERNELS.update(saved)
 
 
+def test_kernel_selection_is_per_host_thread():
+    """ops.KERNELS is the LIVE selection that activate() rewrites at the top of every forward.  It is one table per host thread:
+    a model driven from another thread (other cfg.MODEL.KERNELS, e.g. the split-precise mode) cannot flip this thread's selection between two
+    launches; a fresh thread starts from the import-time table (defaults <- environment)."""
+    import threading
+    from mq_det_amd import ops
+    base = dict(ops.KERNELS)
+    assert base and ops.KERNELS.copy() == base and len(ops.KERNELS) == len(base) and set(ops.KERNELS) == set(base)
+    seen, go, done = {}, threading.Event(), threading.Event()
+
+    def other():
+        seen["start"] = dict(ops.KERNELS)
+        ops.activate(dict(base, F32_OPERANDS=1, LN_VARIANT=1))
+        seen["mine"] = (ops.f32_operands(), ops.KERNELS["LN_VARIANT"])
+        go.set()
+        done.wait(10)
+        seen["still"] = (ops.f32_operands(), ops.KERNELS["LN_VARIANT"])
+    t = threading.Thread(target=other)
+    t.start()
+    assert go.wait(10)
+    assert ops.f32_operands() == base["F32_OPERANDS"] and ops.KERNELS["LN_VARIANT"] == base["LN_VARIANT"]        # untouched here
+    ops.activate(dict(base, LN_VARIANT=2))
+    done.set()
+    t.join()
+    assert seen["start"] == base and seen["mine"] == (1, 1) and seen["still"] == (1, 1)
+    ops.activate(base)
+    assert dict(ops.KERNELS) == base
+
+
 def test_gloo_world2_detection_gather():
     """N > 1 path on CPU: 2 processes, gloo, fixed-shape all-gather of detections + shard ranges."""
     script = os.path.join(ROOT, "tests", "_gloo_worker.py")
