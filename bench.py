@@ -351,6 +351,8 @@ def cpu_baseline(timeout=420, flag="--cpu-baseline-worker"):
 
 
 def _mfma(kernel, flops_alg, flops_exec, n_launch, ms, note, traffic=None):
+    if _PMC_SPLIT:                      # split-precise: every algorithmic MFMA is executed as three fp16 MFMAs (hi hi + hi lo + lo hi)
+        flops_exec, note = 3.0 * flops_exec, note + "; SPLIT-PRECISE: executed = 3 x (three fp16 MFMAs per contraction), achieved / frac count the ALGORITHMIC flops"
     ach = flops_alg / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "avg_launch_ms": round(ms / max(n_launch, 1), 4),
@@ -366,11 +368,16 @@ def _hbm(kernel, nbytes, n_launch, ms, note):
             "launches_per_step": n_launch, "ms_per_step": round(ms, 3), "algorithmic_bytes_per_step": nbytes, "note": note}
 
 
+_PMC_SPLIT = False       # main() sets it for --dtype f32: the split-precise kernels have their own counter file
+
+
 def _pmc():
     """PMC traffic (HBM bytes per launch) collected by tools/pmc_traffic.sh in separate rocprofv3 passes, reduced by
-    tools/pmc_reduce.py; the newest round's file first, round 1 (VLFuse only) as fallback."""
+    tools/pmc_reduce.py; the newest round's file first, round 1 (VLFuse only) as fallback.  Split-precise runs read r0N_pmc_traffic_split.json."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_traffic.json")), reverse=True)      # newest round first
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_traffic_split.json" if _PMC_SPLIT else "r0*_pmc_traffic.json")), reverse=True)      # newest round first
+    if _PMC_SPLIT and not files:
+        return {}
     if files:
         d = json.load(open(files[0]))
         out = {k: int(v["traffic_bytes"]) for k, v in d.get("kernels", {}).items()}
@@ -766,6 +773,8 @@ def main():
                                      words=(1,) if args.caption == "short" else None, dtype=args.dtype)
     if args.no_graph:
         model.use_hip_graph = False
+    global _PMC_SPLIT
+    _PMC_SPLIT = args.dtype == "f32"
 
     Bn = args.batch
     g = torch.Generator().manual_seed(1000 + rank)

@@ -337,7 +337,13 @@ struct FuseGroup {
   int nblk[FUSE_MAX_LEVELS], kind[FUSE_MAX_LEVELS];          // kind = 2 * nd + (bilinear branch ? 1 : 0)
   int n;
 };
-__global__ __launch_bounds__(256, 3) void dyconv_fuse_group_kernel(FuseGroup g) {
+// (split-precise build: the fp32 loads in flight are twice the registers -- 173 spilled VGPRs at three waves per SIMD; two per SIMD there)
+#if defined(MQ_F32)
+#define MQ_FUSE_GROUP_WAVES 2
+#else
+#define MQ_FUSE_GROUP_WAVES 3
+#endif
+__global__ __launch_bounds__(256, MQ_FUSE_GROUP_WAVES) void dyconv_fuse_group_kernel(FuseGroup g) {
   __shared__ float red[256 * 8];
   int L = 0;
   while (L + 1 < g.n && (int)blockIdx.x >= g.first_block[L + 1]) ++L;

@@ -102,6 +102,14 @@ def test_bert_layers_meet_1e_3_with_fp32_operands(f32):
     _assert_ok([f32.check_bert_layer(CPU, False), f32.check_bert_layer(CPU, True)])
 
 
+def test_mq_glip_l_blocks_meet_1e_3_with_fp32_operands(f32):
+    """Swin-L shapes (window 12, widths 192 / 384 / 768 / 1536) through the split-precise kernels: window attention and Swin + FPN at 1e-3."""
+    if f32._f32_mode == 2:
+        pytest.skip("same launches as under device_limits")
+    _assert_ok(f32.check_window_attention(CPU, large=True))
+    _assert_ok(f32.check_swin_fpn(CPU, large=True))
+
+
 def test_groundingdino_meets_1e_3_with_fp32_operands(f32):
     """Round 6: MQ-GroundingDINO no longer refuses MODEL.COMPUTE_DTYPE = float32 -- the MSDeformAttn kernels have their *_f32
     twin (the fused-query form's `qproj` is a float there) and every other kernel of the family already had one.  The sampling kernels and the

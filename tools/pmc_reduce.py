@@ -10,7 +10,9 @@ import sys
 src, dst = sys.argv[1], sys.argv[2]
 GROUPS = (("vlfuse_i2t", "vlfuse_i2t_kernel"), ("vlfuse_t2i_combine", "vlfuse_t2i_combine_kernel"), ("vlfuse_t2i", "vlfuse_t2i_kernel"),
           # (round 5: the FPN output convs run the PLAIN instantiation -- a name of its own, so the DyConv launches are no longer averaged with them)
-          ("dcn_igemm8_kernel<16, 0, 1, true>", "dcn_igemm8_kernel<plain: FPN convs>"), ("dcn_igemm8_kernelILi16ELi0ELi1ELb1E", "dcn_igemm8_kernel<plain: FPN convs>"),
+          ("dcn_igemm8_kernel<16, 0, 1, true", "dcn_igemm8_kernel<plain: FPN convs>"), ("dcn_igemm8_kernelILi16ELi0ELi1ELb1E", "dcn_igemm8_kernel<plain: FPN convs>"),
+          # (round 6: the split-precise build runs 8 waves)
+          ("dcn_igemm8_kernel<8, 0, 1, true", "dcn_igemm8_kernel<plain: FPN convs>"), ("dcn_igemm8_kernelILi8ELi0ELi1ELb1E", "dcn_igemm8_kernel<plain: FPN convs>"),
           ("dcn_igemm8", "dcn_igemm8_kernel"), ("bert_attn_qkv", "bert_attn_qkv_kernel"), ("gcp_attn_kernel", "gcp_attn_kernel"), ("swin_mlp_kernel<96", "swin_mlp_kernel<96>"), ("swin_mlp_kernel<192", "swin_mlp_kernel<192>"),
           ("swin_mlp_kernel<384", "swin_mlp_kernel<384>"), ("swin_mlp_kernelILi96", "swin_mlp_kernel<96>"), ("swin_mlp_kernelILi192", "swin_mlp_kernel<192>"),
           ("swin_mlp_kernelILi384", "swin_mlp_kernel<384>"), ("swin_mlp2_tail_kernel", "swin_mlp2_tail_kernel"), ("swin_mlp2_kernel<96", "swin_mlp2_kernel<96>"),
