@@ -328,11 +328,39 @@ inline simt_float4 simt_mfma_16x16x32_split(V8 a, V8 b, simt_float4 c) {
 template <class H8>
 inline simt_float4 simt_mfma_16x16x32_split_frag(H8 ahi, H8 alo, H8 bhi, H8 blo, simt_float4 c) {
   static_assert(sizeof(H8) == 16, "fp16 fragments");
-  simt_float4 t = {0.f, 0.f, 0.f, 0.f};
-  c = simt_mfma_16x16x32(ahi, bhi, c);
-  t = simt_mfma_16x16x32(ahi, blo, t);
-  t = simt_mfma_16x16x32(alo, bhi, t);
-  for (int r = 0; r < 4; ++r) c[r] = __builtin_fmaf(t[r], 1.0f / 2048.0f, c[r]);
+  // ONE lane exchange: the four fragments of a lane fill its 64-byte slot; after the meeting point every lane reads the rows / the column it needs
+  // straight from the other lanes' slots (the slots of this buffer are rewritten two collectives later: every lane has passed the next one by then)
+  const int buf = simt::next_buf(), l = simt::lane();
+  uint64_t* s = simt::xslot(l, buf);
+  memcpy(s, &ahi, 16);
+  memcpy(s + 2, &alo, 16);
+  memcpy(s + 4, &bhi, 16);
+  memcpy(s + 6, &blo, 16);
+  simt::wave_sync();
+  const int col = l & 15, r0 = 4 * (l >> 4);
+  float bh[32], bl[32];
+  for (int g = 0; g < 4; ++g) {
+    H8 h, o;
+    const uint64_t* t = simt::xslot(col + 16 * g, buf);
+    memcpy(&h, t + 4, 16);
+    memcpy(&o, t + 6, 16);
+    for (int j = 0; j < 8; ++j) { bh[8 * g + j] = (float)h[j]; bl[8 * g + j] = (float)o[j]; }
+  }
+  for (int r = 0; r < 4; ++r) {
+    float main = 0.f, cross = 0.f;
+    for (int g = 0; g < 4; ++g) {
+      H8 h, o;
+      const uint64_t* t = simt::xslot(r0 + r + 16 * g, buf);
+      memcpy(&h, t, 16);
+      memcpy(&o, t + 2, 16);
+      for (int j = 0; j < 8; ++j) {
+        const float ah = (float)h[j], al = (float)o[j];
+        main += ah * bh[8 * g + j];
+        cross += ah * bl[8 * g + j] + al * bh[8 * g + j];
+      }
+    }
+    c[r] = (c[r] + main) + cross * (1.0f / 2048.0f);
+  }
   return c;
 }
 inline int __lane_id() { return simt::lane(); }

@@ -384,7 +384,7 @@ def test_bench_roofline_records_are_per_kernel_and_read_the_newest_pmc_file():
     sys.path.insert(0, ROOT)
     bench = importlib.import_module("bench")
     pmc = bench._pmc()
-    assert pmc.get("_file", "").startswith("profiles/r05") and pmc.get("dcn_igemm8_kernel", 0) > 1e8          # the newest round's file
+    assert pmc.get("_file", "").startswith("profiles/r06") and pmc.get("dcn_igemm8_kernel", 0) > 1e8          # the newest round's file
     kern = {"dcnv2_fused": (18, 9.9, 0), "vlfuse_i2t_n22400_t256": (18, 6.0, 0), "vlfuse_t2i_n22400_t256_s7": (18, 4.5, 0),
             "swin_mlp_c384": (18, 3.5, 10 ** 9)}
     roofs = bench.kernel_rooflines(kern, 3, 8, 141)

@@ -20,7 +20,12 @@ _CXX = os.environ.get("SIMT_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 pytestmark = pytest.mark.skipif(not os.path.exists(_CXX), reason=f"{_CXX} not found: the kernel-source emulation cannot be built here")
 
 
-@pytest.fixture(scope="module", params=[1, 2], ids=["device_limits", "every_kernel"])
+# Round 6: the hot kernels of the split-precise build have ONE shape in both modes (planar tiles, C = 384 Swin MLP through the main kernel), so the second
+# mode only repeats launches on the grouped offset conv and a few variants: it runs on request (MQ_SIMT_F32_MODES=1,2), not in the default CPU suite.
+_MODES = [int(m) for m in os.environ.get("MQ_SIMT_F32_MODES", "1").split(",") if m]
+
+
+@pytest.fixture(scope="module", params=_MODES, ids=[{1: "device_limits", 2: "every_kernel"}[m] for m in _MODES])
 def f32(request):
     """params: 1 = the precise mode exactly as the MI355X runs it (160 KB of LDS per workgroup: ops.py picks the kernel variants that fit at
     twice the element size -- what passes here is what `MODEL.COMPUTE_DTYPE = "float32"` launches on the device); 2 = a 320 KB limit, i.e.
@@ -112,15 +117,16 @@ def test_mq_glip_l_blocks_meet_1e_3_with_fp32_operands(f32):
 
 def test_groundingdino_meets_1e_3_with_fp32_operands(f32):
     """Round 6: MQ-GroundingDINO no longer refuses MODEL.COMPUTE_DTYPE = float32 -- the MSDeformAttn kernels have their *_f32
-    twin (the fused-query form's `qproj` is a float there) and every other kernel of the family already had one.  The sampling kernels and the
-    shallow whole model (vision queries; text only B = 2 with two image sizes) against the oracle: every stage at 1e-3 of its range."""
+    twin (the fused-query form's `qproj` is a float there) and every other kernel of the family already had one.  The masked attention / fusion kernels of the
+    family and the shallow whole model with vision queries against the oracle: every stage at 1e-3 of its range."""
     if f32._f32_mode == 2:
         pytest.skip("same launches as under device_limits")
     import gdino_checks as gc
-    _assert_ok(gc.check_msdeform_attn_q(CPU))
     _assert_ok(gc.check_attention_qk_mask(CPU))
     _assert_ok(gc.check_vlfuse_heads_mask(CPU))
-    worst = _assert_ok(gc.check_gdino_model(CPU, vq=True, graph=False) + gc.check_gdino_model(CPU, vq=False, B=2, hw=((128, 130), (100, 160)), graph=False))
+    # (the shallow model with vision queries runs every kernel of the family incl. both MSDeformAttn forms; the stand-alone sampling check at the
+    # 22 323-query encoder shape and the text-only B = 2 model run in the GPU suite -- through the emulation they alone took four minutes)
+    worst = _assert_ok(gc.check_gdino_model(CPU, vq=True, graph=False))
     print(f"MQ-GroundingDINO (shallow) with fp32 operands: worst normalised stage error {worst:.2e}")
 
 
