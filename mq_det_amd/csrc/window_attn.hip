@@ -226,8 +226,15 @@ struct WinQkvParams {
 // step, one barrier per head.  Rows are unpadded (a DMA piece is 1 KB of consecutive LDS bytes); the 16-byte chunk c of row r sits at
 // chunk position (c & ~7) | ((c ^ r) & 7): conflict-free for the fragment reads (16 rows x one chunk).  The X fragments (96 VGPRs at
 // C = 192) leave room for one wave per SIMD only.
+// (split-precise build: the fp32 X fragments of a window and their split copies are twice the registers -- one workgroup per CU there: 256 VGPRs + 238
+// AGPRs and no scratch at C = 96 instead of 178 spilled VGPRs, 2.0 GB of scratch traffic per launch in profiles/r06_pmc_traffic_split.json)
+#if defined(MQ_F32)
+#define MQ_WQKV_WG_PER_CU(STREAM_) 1
+#else
+#define MQ_WQKV_WG_PER_CU(STREAM_) ((STREAM_) ? 1 : 2)
+#endif
 template <int C, bool STREAM>
-__global__ __launch_bounds__(256, STREAM ? 1 : 2) void window_attn_qkv_kernel(WinQkvParams p) {
+__global__ __launch_bounds__(256, MQ_WQKV_WG_PER_CU(STREAM)) void window_attn_qkv_kernel(WinQkvParams p) {
   constexpr int NB = 4, NP = 64, KS = C / 32, HEADS = C / 32, WP = STREAM ? C : C + 8;       // weight row pitch (halfs)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* Ws = (half_t*)smem;                              // resident: [3C][WP]; STREAM: [2][96][C]
@@ -458,7 +465,7 @@ static int launch_window_attn_qkv(const WinQkvParams& p, hipStream_t s) {
   }
   int cus = 256, dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  const long wgs_needed = (p.windows + 3) / 4, slots = (long)cus * (STREAM ? 1 : 2);  // persistent workgroups: as many as the chip holds
+  const long wgs_needed = (p.windows + 3) / 4, slots = (long)cus * MQ_WQKV_WG_PER_CU(STREAM);  // persistent workgroups: as many as the chip holds
   const long wgs = wgs_needed < slots ? wgs_needed : slots;
   hipLaunchKernelGGL((window_attn_qkv_kernel<C, STREAM>), dim3((unsigned)wgs), dim3(256), smem, s, p);
   MQ_CHECK_LAUNCH();

@@ -292,6 +292,38 @@ inline simt_float4 simt_mfma_16x16x32_f32_8x4(V8 a, V8 b, simt_float4 c) {
 // mfma16 of the SPLIT-PRECISE build (csrc/common.h, round 6): every fp32 operand x = hi + lo / 2^11 with hi = fp16(x), lo = fp16((x - hi) 2^11);
 // the device issues v_mfma_f32_16x16x32_f16 on (hi_a, hi_b) into the accumulator and on (hi_a, lo_b), (lo_a, hi_b) into a zeroed second one that is
 // added scaled by 2^-11.  Here: ONE lane exchange of the fp32 fragments (simt_mfma_8x4_tile's buffer), the split and the three products per lane.
+inline void simt_mfma_split_core(const float (&Ah)[16][32], const float (&Al)[16][32], const float (&Bh)[32][16], const float (&Bl)[32][16]) {
+  float* D = simt::wave_tile32();                    // main [16][16], then cross [16][16]
+  for (int i = 0; i < 16; ++i) {
+    float m[16], x[16];
+    for (int n = 0; n < 16; ++n) m[n] = x[n] = 0.f;
+    for (int k = 0; k < 32; ++k) {
+      const float ah = Ah[i][k], al = Al[i][k];
+      for (int n = 0; n < 16; ++n) {
+        m[n] += ah * Bh[k][n];
+        x[n] += ah * Bl[k][n] + al * Bh[k][n];
+      }
+    }
+    for (int n = 0; n < 16; ++n) { D[i * 16 + n] = m[n]; D[256 + i * 16 + n] = x[n]; }
+  }
+}
+// (the LAST lane to arrive splits the deposited fp32 fragments once and multiplies the whole tile; every lane then picks up its four values)
+inline void simt_mfma_split_tile(void* ctx) {
+  const int buf = (int)(intptr_t)ctx;
+  static float Ah[16][32], Al[16][32], Bh[32][16], Bl[32][16];      // (one OS thread runs every fiber: tests/simt/simt_runtime.cpp)
+  for (int l = 0; l < 64; ++l) {
+    float f[16];
+    memcpy(f, simt::xslot(l, buf), 64);
+    for (int j = 0; j < 8; ++j) {
+      const _Float16 ha = (_Float16)f[j], hb = (_Float16)f[8 + j];
+      Ah[l & 15][8 * (l >> 4) + j] = (float)ha;
+      Al[l & 15][8 * (l >> 4) + j] = (float)(_Float16)((f[j] - (float)ha) * 2048.0f);
+      Bh[8 * (l >> 4) + j][l & 15] = (float)hb;
+      Bl[8 * (l >> 4) + j][l & 15] = (float)(_Float16)((f[8 + j] - (float)hb) * 2048.0f);
+    }
+  }
+  simt_mfma_split_core(Ah, Al, Bh, Bl);
+}
 template <class V8>
 inline simt_float4 simt_mfma_16x16x32_split(V8 a, V8 b, simt_float4 c) {
   static_assert(sizeof(V8) == 32, "fp32-operand fragments");
@@ -299,68 +331,45 @@ inline simt_float4 simt_mfma_16x16x32_split(V8 a, V8 b, simt_float4 c) {
   uint64_t* s = simt::xslot(l, buf);
   memcpy(s, &a, 32);
   memcpy(s + 4, &b, 32);
-  simt::wave_sync_then(&simt_mfma_8x4_tile, (void*)(intptr_t)buf);
-  const float* A = simt::wave_tile32();
-  const float* B = A + 512;
+  simt::wave_sync_then(&simt_mfma_split_tile, (void*)(intptr_t)buf);
+  const float* D = simt::wave_tile32();              // (refilled by the NEXT exchange's tile function, which runs once every lane has arrived there)
   const int col = l & 15, r0 = 4 * (l >> 4);
-  float bh[32], bl[32];
-  for (int k = 0; k < 32; ++k) {
-    const float x = B[k * 16 + col];
-    const _Float16 h = (_Float16)x;
-    bh[k] = (float)h;
-    bl[k] = (float)(_Float16)((x - (float)h) * 2048.0f);
-  }
-  for (int r = 0; r < 4; ++r) {
-    float main = 0.f, cross = 0.f;
-    for (int k = 0; k < 32; ++k) {
-      const float x = A[(r0 + r) * 32 + k];
-      const _Float16 h = (_Float16)x;
-      const float ah = (float)h, al = (float)(_Float16)((x - ah) * 2048.0f);
-      main += ah * bh[k];
-      cross += ah * bl[k] + al * bh[k];
-    }
-    c[r] = (c[r] + main) + cross * (1.0f / 2048.0f);
-  }
+  for (int r = 0; r < 4; ++r) c[r] = (c[r] + D[(r0 + r) * 16 + col]) + D[256 + (r0 + r) * 16 + col] * (1.0f / 2048.0f);
   return c;
 }
 // mfma16_split on fragments that are ALREADY split (planar hi / lo LDS tiles of the split-precise kernels, csrc/common.h): the device's three
 // v_mfma_f32_16x16x32_f16 -- (hi, hi) into the accumulator, (hi, lo) + (lo, hi) into a zeroed second one that is added scaled by 2^-11
+// (one lane exchange; the LAST lane to arrive converts the 4 x 64 fragments once and multiplies the tile -- main and cross products -- into the wave's
+// 32 x 32 result buffer; per-lane conversion of its own rows / column was 7 x the fp16 -> fp32 conversions and slower than three exchanges)
+inline void simt_mfma_split_frag_tile(void* ctx) {
+  const int buf = (int)(intptr_t)ctx;
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  static float Ah[16][32], Al[16][32], Bh[32][16], Bl[32][16];      // (one OS thread runs every fiber: tests/simt/simt_runtime.cpp)
+  for (int l = 0; l < 64; ++l) {
+    h8 f[4];
+    memcpy(f, simt::xslot(l, buf), 64);
+    for (int j = 0; j < 8; ++j) {
+      Ah[l & 15][8 * (l >> 4) + j] = (float)f[0][j];
+      Al[l & 15][8 * (l >> 4) + j] = (float)f[1][j];
+      Bh[8 * (l >> 4) + j][l & 15] = (float)f[2][j];
+      Bl[8 * (l >> 4) + j][l & 15] = (float)f[3][j];
+    }
+  }
+  simt_mfma_split_core(Ah, Al, Bh, Bl);
+}
 template <class H8>
 inline simt_float4 simt_mfma_16x16x32_split_frag(H8 ahi, H8 alo, H8 bhi, H8 blo, simt_float4 c) {
   static_assert(sizeof(H8) == 16, "fp16 fragments");
-  // ONE lane exchange: the four fragments of a lane fill its 64-byte slot; after the meeting point every lane reads the rows / the column it needs
-  // straight from the other lanes' slots (the slots of this buffer are rewritten two collectives later: every lane has passed the next one by then)
   const int buf = simt::next_buf(), l = simt::lane();
   uint64_t* s = simt::xslot(l, buf);
   memcpy(s, &ahi, 16);
   memcpy(s + 2, &alo, 16);
   memcpy(s + 4, &bhi, 16);
   memcpy(s + 6, &blo, 16);
-  simt::wave_sync();
+  simt::wave_sync_then(&simt_mfma_split_frag_tile, (void*)(intptr_t)buf);
+  const float* D = simt::wave_tile32();              // (refilled by the NEXT exchange's tile function, which runs once every lane has arrived there)
   const int col = l & 15, r0 = 4 * (l >> 4);
-  float bh[32], bl[32];
-  for (int g = 0; g < 4; ++g) {
-    H8 h, o;
-    const uint64_t* t = simt::xslot(col + 16 * g, buf);
-    memcpy(&h, t + 4, 16);
-    memcpy(&o, t + 6, 16);
-    for (int j = 0; j < 8; ++j) { bh[8 * g + j] = (float)h[j]; bl[8 * g + j] = (float)o[j]; }
-  }
-  for (int r = 0; r < 4; ++r) {
-    float main = 0.f, cross = 0.f;
-    for (int g = 0; g < 4; ++g) {
-      H8 h, o;
-      const uint64_t* t = simt::xslot(r0 + r + 16 * g, buf);
-      memcpy(&h, t, 16);
-      memcpy(&o, t + 2, 16);
-      for (int j = 0; j < 8; ++j) {
-        const float ah = (float)h[j], al = (float)o[j];
-        main += ah * bh[8 * g + j];
-        cross += ah * bl[8 * g + j] + al * bh[8 * g + j];
-      }
-    }
-    c[r] = (c[r] + main) + cross * (1.0f / 2048.0f);
-  }
+  for (int r = 0; r < 4; ++r) c[r] = (c[r] + D[(r0 + r) * 16 + col]) + D[256 + (r0 + r) * 16 + col] * (1.0f / 2048.0f);
   return c;
 }
 inline int __lane_id() { return simt::lane(); }
