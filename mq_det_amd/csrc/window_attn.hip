@@ -226,6 +226,20 @@ struct WinQkvParams {
 // step, one barrier per head.  Rows are unpadded (a DMA piece is 1 KB of consecutive LDS bytes); the 16-byte chunk c of row r sits at
 // chunk position (c & ~7) | ((c ^ r) & 7): conflict-free for the fragment reads (16 rows x one chunk).  The X fragments (96 VGPRs at
 // C = 192) leave room for one wave per SIMD only.
+// Split-precise build: every fragment that feeds more than one MFMA is split ONCE into (hi, lo) fp16 x 8 -- the X fragments of the window (kept for
+// all heads: the fp32 copy dies), the weight fragment of a (matrix, channel block, k-step), q / k / v of a head, the probabilities of a key step -- and
+// the MFMAs are mfma16_split: nothing is split twice, no fp32 copy stays live beside its split form.
+#if defined(MQ_F32) && !defined(MQ_F32_EXACT)
+#define MQ_WQ_SPLIT 1
+typedef mq_split8 wq_frag;
+#define WQ_F(x) mq_split(x)
+#define WQ_MFMA(a, b, c) mfma16_split((a), (b), (c))
+#else
+#define MQ_WQ_SPLIT 0
+typedef half8 wq_frag;
+#define WQ_F(x) (x)
+#define WQ_MFMA(a, b, c) mfma16((a), (b), (c))
+#endif
 // (split-precise build: the fp32 X fragments of a window and their split copies are twice the registers -- one workgroup per CU there: 256 VGPRs + 238
 // AGPRs and no scratch at C = 96 instead of 178 spilled VGPRs, 2.0 GB of scratch traffic per launch in profiles/r06_pmc_traffic_split.json)
 #if defined(MQ_F32)
@@ -284,7 +298,7 @@ __global__ __launch_bounds__(256, MQ_WQKV_WG_PER_CU(STREAM)) void window_attn_qk
       return ry * 3 + rx;
     };
     // ---- X fragments: token blk * 16 + l15, channels 32 ks + 8 lg .. + 7; tokens >= N copy token N - 1 (masked as keys, not stored)
-    half8 xf[NB][KS];
+    wq_frag xf[NB][KS];
     int out_off[NB];                                       // element offset of the token's row (B * H * W * C < 2^31: checked by the host), -1: none
     int region_q[NB];
     {
@@ -301,6 +315,17 @@ __global__ __launch_bounds__(256, MQ_WQKV_WG_PER_CU(STREAM)) void window_attn_qk
         out_off[blk] = (real && i < N && active) ? tok * C : -1;
         region_q[blk] = region_of(i);
       }
+#if MQ_WQ_SPLIT
+      half8 xr[NB][KS];
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xr[blk][ks] = *(const half8*)(p.x + max(rows[blk], 0) + ks * 32);       // unconditional, in flight together
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[blk][ks] = mq_split(rows[blk] >= 0 ? xr[blk][ks] : zero8());
+#else
 #pragma unroll
       for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
@@ -309,6 +334,7 @@ __global__ __launch_bounds__(256, MQ_WQKV_WG_PER_CU(STREAM)) void window_attn_qk
       for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xf[blk][ks] = rows[blk] >= 0 ? xf[blk][ks] : zero8();
+#endif
     }
     int region_k[NB];
 #pragma unroll
@@ -329,7 +355,7 @@ __global__ __launch_bounds__(256, MQ_WQKV_WG_PER_CU(STREAM)) void window_attn_qk
       }
       const half_t* Wb = STREAM ? Ws + (seq & 1) * 96 * C : Ws;
       // ---- projections of this head.  m = 0 (q), 1 (k): transposed; 2 (v): plain.  bias: row (d) for q / k, column (d) for v
-      half8 qf[NB], kf[NB], vf[NB / 2][2];                  // vf[st][db]: V^T A-fragment of 32-key step st, channel block db
+      wq_frag qf[NB], kf[NB], vf[NB / 2][2];                // vf[st][db]: V^T A-fragment of 32-key step st, channel block db
       {
         // A / B fragment of weight rows (matrix m, channel block db) for k-step ks: row l15, channels 32 ks + 8 lg .. + 7
         auto wfrag = [&](int m, int db, int ks) __attribute__((always_inline)) -> half8 {
@@ -355,16 +381,16 @@ __global__ __launch_bounds__(256, MQ_WQKV_WG_PER_CU(STREAM)) void window_attn_qk
           for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-              const half8 wf = wfrag(m, db, ks);
+              const wq_frag wf = WQ_F(wfrag(m, db, ks));
 #pragma unroll
-              for (int tb = 0; tb < NB; ++tb) acc[db][tb] = mfma16(wf, xf[tb][ks], acc[db][tb]);
+              for (int tb = 0; tb < NB; ++tb) acc[db][tb] = WQ_MFMA(wf, xf[tb][ks], acc[db][tb]);
             }
 #pragma unroll
           for (int tb = 0; tb < NB; ++tb) {
             half8 f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { f[r] = (half_t)acc[0][tb][r]; f[4 + r] = (half_t)acc[1][tb][r]; }
-            if (m == 0) qf[tb] = f; else kf[tb] = f;
+            if (m == 0) qf[tb] = WQ_F(f); else kf[tb] = WQ_F(f);
           }
           __builtin_amdgcn_sched_barrier(0);                 // one projection at a time: their accumulators must not be live together
         }
@@ -379,16 +405,28 @@ __global__ __launch_bounds__(256, MQ_WQKV_WG_PER_CU(STREAM)) void window_attn_qk
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
           for (int db = 0; db < 2; ++db) {
-            const half8 wf = wfrag(2, db, ks);
+            const wq_frag wf = WQ_F(wfrag(2, db, ks));
 #pragma unroll
-            for (int tb = 0; tb < NB; ++tb) acc[tb][db] = mfma16(xf[tb][ks], wf, acc[tb][db]);
+            for (int tb = 0; tb < NB; ++tb) acc[tb][db] = WQ_MFMA(xf[tb][ks], wf, acc[tb][db]);
           }
+#if MQ_WQ_SPLIT
+#pragma unroll
+        for (int st = 0; st < NB / 2; ++st)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            half8 v8;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v8[r] = (half_t)acc[2 * st][db][r]; v8[4 + r] = (half_t)acc[2 * st + 1][db][r]; }
+            vf[st][db] = mq_split(v8);
+          }
+#else
 #pragma unroll
         for (int st = 0; st < NB / 2; ++st)
 #pragma unroll
           for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { vf[st][db][r] = (half_t)acc[2 * st][db][r]; vf[st][db][4 + r] = (half_t)acc[2 * st + 1][db][r]; }
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       const float* rel = p.rel_bias + (long)head * NP * NP;
@@ -397,7 +435,7 @@ __global__ __launch_bounds__(256, MQ_WQKV_WG_PER_CU(STREAM)) void window_attn_qk
         if (qb * 16 >= N) break;
         float4_ s[NB];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) s[nb] = mfma16(kf[nb], qf[qb], (float4_){0.f, 0.f, 0.f, 0.f});
+        for (int nb = 0; nb < NB; ++nb) s[nb] = WQ_MFMA(kf[nb], qf[qb], ((float4_){0.f, 0.f, 0.f, 0.f}));
         const float* relq = rel + (qb * 16 + l15) * NP + 4 * lg;
         float4_ rb[NB];
 #pragma unroll
@@ -435,8 +473,9 @@ __global__ __launch_bounds__(256, MQ_WQKV_WG_PER_CU(STREAM)) void window_attn_qk
           half8 pf;
 #pragma unroll
           for (int r = 0; r < 4; ++r) { pf[r] = (half_t)(s[2 * st][r] * inv); pf[4 + r] = (half_t)(s[2 * st + 1][r] * inv); }
+          const wq_frag ps = WQ_F(pf);
 #pragma unroll
-          for (int db = 0; db < 2; ++db) o[db] = mfma16(vf[st][db], pf, o[db]);
+          for (int db = 0; db < 2; ++db) o[db] = WQ_MFMA(vf[st][db], ps, o[db]);
         }
         if (out_off[qb] >= 0) {
 #pragma unroll
