@@ -676,8 +676,8 @@ def test_bf16_groundingdino(dev, bf16):
 # ------------------------------------------------------------------------------------------------ fp32 operands: the precise mode on the device
 @pytest.fixture()
 def f32():
-    """MODEL.COMPUTE_DTYPE = "float32": the *_f32 entry points (the same kernel sources, every operand a float, one 16x16x32 MFMA = eight
-    v_mfma_f32_16x16x4_f32) + fp32 library GEMMs, ON THE MI355X.  Every row is gated at the north-star tolerance: max|err| <= 1e-3 of the
+    """MODEL.COMPUTE_DTYPE = "float32", the SPLIT-PRECISE mode: the *_f32 entry points (the same kernel sources, every operand a float carried as
+    hi + lo / 2^11 through three fp16 MFMAs, csrc/common.h) + fp32 library GEMMs, ON THE MI355X.  Every row is gated at the north-star tolerance: max|err| <= 1e-3 of the
     reference's range AND no element outside atol = rtol = 1e-3 (parity_checks._stat)."""
     import parity_checks as pc
     from mq_det_amd import ops
