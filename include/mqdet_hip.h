@@ -232,7 +232,13 @@ typedef struct mq_dcn_branch {
   long x_bs;
   int B, H, W, C, oH, oW, N, out_ld, stride, flags;          /* flags bit 0: om[:, 18:27] are probabilities, not logits; bit 1: the caller
                                                                  promises all-zero offsets and mask 1 (a plain 3 x 3 conv: when every branch of a
-                                                                 launch says so only one corner per tap is gathered -- same results) */
+                                                                 launch says so only one corner per tap is gathered -- same results);
+                                                                 bit 2 (round 6, on every branch of a launch or on none: -5 otherwise): `w` is in
+                                                                 LDS-TILE ORDER -- per k-step ks = (channel slice) * 9 + tap one 32 KB block that
+                                                                 is the byte image of the kernel's B tile: 256 rows x 64 channels with the 16-byte
+                                                                 chunk c of row r at position c ^ (r & 7) (*_f32: [hi | lo] fp16 planes of 256
+                                                                 rows x 32 channels) -- and is copied global -> LDS by LDS-DMA
+                                                                 (mq_det_amd.ops.dcn_weight_tiles; same results) */
 } mq_dcn_branch;
 int mq_dcnv2_group_fwd(const mq_dcn_branch* branches, int n, void* stream);
 int mq_dcnv2_fwd(const void* x, const float* om, const void* w, const void* bias, void* out, float* stats, const float* wy,

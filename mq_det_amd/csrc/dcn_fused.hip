@@ -90,7 +90,12 @@ typedef mq_f32x4 dcn_gvec;                                   // one 16-byte chun
 #else
 typedef half8 dcn_gvec;
 #endif
-template <int NW, int ABL = 0, int SYNC = 2, bool PLAIN = false, bool FENCE = false>
+// BDMA (round 6, opt-in: flags bit 2 of every branch / KERNELS["DCN_BDMA"]): the weights arrive in LDS-TILE ORDER -- per k-step one 32 KB block that
+// is the byte image of the B tile (16-bit builds: rows of 64 with the chunk swizzle applied; split-precise: [hi plane | lo plane] of rows of 32;
+// mq_det_amd.ops.dcn_weight_tiles) -- and are copied global -> LDS by LDS-DMA: no weight registers, no ds_write, no split arithmetic for B.  The
+// step then is: DMA of B(k + 1) and the gathers of A(k + 2) at its top, MFMAs of step k and the blend / staging of A(k + 1) in the two wave
+// groups' opposite orders, `s_waitcnt vmcnt(0)` + barrier at its end (everything issued at the top has had the whole step to land).
+template <int NW, int ABL = 0, int SYNC = 2, bool PLAIN = false, bool FENCE = false, bool BDMA = false>
 __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   constexpr int BM = DCN_PH * DCN_PW, BN = 256, BK = MQ_DCN_SPLIT ? 32 : 64;
   constexpr int CH = 16 / (int)sizeof(half_t);               // operand elements per 16-byte chunk (8, or 4 in the split-precise build)
@@ -284,12 +289,14 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
       *(mq_h16x4*)(a_hi + rr * (NTH / 8) * BK) = hi;
       *(mq_h16x4*)(a_hi + BM * BK + rr * (NTH / 8) * BK) = lo;
     }
+    if constexpr (!BDMA) {
 #pragma unroll
-    for (int j = 0; j < JB; ++j) {
-      mq_h16x4 hi, lo;
-      mq_split4(b_raw[j], hi, lo);
-      *(mq_h16x4*)(b_hi + b_lds[j]) = hi;
-      *(mq_h16x4*)(b_hi + BN * BK + b_lds[j]) = lo;
+      for (int j = 0; j < JB; ++j) {
+        mq_h16x4 hi, lo;
+        mq_split4(b_raw[j], hi, lo);
+        *(mq_h16x4*)(b_hi + b_lds[j]) = hi;
+        *(mq_h16x4*)(b_hi + BN * BK + b_lds[j]) = lo;
+      }
     }
 #else
     half_t* a = As + buf * BM * BK + a_lds;
@@ -310,9 +317,28 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
       }
       *(half8*)(a + rr * (NTH / 8) * BK) = v;
     }
+    if constexpr (!BDMA) {
 #pragma unroll
-    for (int j = 0; j < JB; ++j) *(half8*)(Bs + buf * BN * BK + b_lds[j]) = b_raw[j];
+      for (int j = 0; j < JB; ++j) *(half8*)(Bs + buf * BN * BK + b_lds[j]) = b_raw[j];
+    }
 #endif
+  };
+  // BDMA: the B tile of k-step ks (a 32 KB block of the tile-ordered weights) -> buffer `buf`, issued by the waves of GROUP 1 only (2 JB linear
+  // 1 KB pieces per wave): hipcc's wait-count pass cannot count register loads and LDS-DMA pieces in one queue -- with a DMA pending, the first
+  // use of ANY gathered register waits with vmcnt(0) (ISA of the first version: `D D w0 ...` at the top of every step: the copy's whole latency
+  // exposed).  Group 1 blends / stages A FIRST in a step (its registers were gathered one step earlier, nothing else pending), then starts the
+  // copy and its gathers, then runs its MFMAs; group 0 never has a copy in flight.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto dma_b = [&](int ks, int buf) {
+    constexpr int TILE_B = BN * BK * (int)sizeof(half_t);     // 32 KB in every build
+    constexpr int HT = NTH / 2;                                // threads of group 1
+    ks = min(ks, ksteps - 1);
+    const char* src = wb + (long)ks * TILE_B + (tid - HT) * 16;
+    char* dst = (char*)Bs + (buf & (NBUF - 1)) * TILE_B + (wave_u - NW / 2) * 1024;
+#pragma unroll
+    for (int j = 0; j < 2 * JB; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * HT * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + j * HT * 16), 16, 0, 0);
   };
 
   float4_ acc[IM][4];
@@ -369,6 +395,40 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
 
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
+  if constexpr (BDMA) {
+    // ---- fill: B(0) by DMA (group 1), A(0) gathered and staged by everybody, the gathers of A(1) and A(2) in flight
+    issue_a(S0{}, 0);
+    stage(S0{}, 0);
+    if (wave >= NW / 2) dma_b(0, 0);
+    issue_a(S1{}, 1);                                        // slot s holds the tiles of its parity: consumed in step k, refilled with tile k + 3 right after
+    issue_a(S0{}, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < WARM_N; ++i) asm volatile("" ::"v"(warm[i]));     // warm-up destinations released here
+    // step ks reads buffer ks & 1 and fills the other one: group 0 = MFMAs(ks), blend + staging of A(ks + 1), gathers of A(ks + 2);
+    // group 1 = blend + staging of A(ks + 1), DMA of B(ks + 1), gathers of A(ks + 2), MFMAs(ks); end of step: this thread's copies / gathers
+    // have landed (they had its MFMA phase / the other group's to do so), barrier
+    auto step_end = [&]() {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    };
+    if (wave < NW / 2) {
+      for (int ks = 0; ks < ksteps; ks += 2) {
+        mfma_phase(0); stage(S1{}, 1); issue_a(S1{}, ks + 3);
+        step_end();
+        mfma_phase(1); stage(S0{}, 0); issue_a(S0{}, ks + 4);
+        step_end();
+      }
+    } else {
+      for (int ks = 0; ks < ksteps; ks += 2) {
+        stage(S1{}, 1); dma_b(ks + 1, 1); issue_a(S1{}, ks + 3); mfma_phase(0);
+        step_end();
+        stage(S0{}, 0); dma_b(ks + 2, 0); issue_a(S0{}, ks + 4); mfma_phase(1);
+        step_end();
+      }
+    }
+  } else {
   // ---- pipeline fill: every thread stages step 0; gathers of steps 1, 2 and the weights of step 1 are in flight
   issue_a(S0{}, 0);
   issue_b(0);
@@ -433,6 +493,8 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
       __syncthreads();
       if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
     }
+  }
+
   }
 
   // ---- epilogue: + bias, fp16, transpose through LDS, 16-byte coalesced NHWC stores
@@ -519,19 +581,17 @@ struct mq_dcn_branch {          // mirrors include/mqdet_hip.h
   int B, H, W, C, oH, oW, N, out_ld, stride, flags;
 };
 
-#if MQ_DCN_SPLIT
-template <int NW, int SYNC, bool PLAIN>
+template <int NW, int SYNC, bool PLAIN, bool BDMA = false>
 static int dcn_launch(dim3 grid, size_t smem, hipStream_t stream, const DcnGroup& g) {
   static MqOncePerDevice attr;
   if (attr.first()) {
-    hipError_t e = hipFuncSetAttribute((const void*)dcn_igemm8_kernel<NW, 0, SYNC, PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)dcn_igemm8_kernel<NW, 0, SYNC, PLAIN, false, BDMA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr.done();
   }
-  hipLaunchKernelGGL((dcn_igemm8_kernel<NW, 0, SYNC, PLAIN>), grid, dim3(64 * NW), smem, stream, g);
+  hipLaunchKernelGGL((dcn_igemm8_kernel<NW, 0, SYNC, PLAIN, false, BDMA>), grid, dim3(64 * NW), smem, stream, g);
   return 0;
 }
-#endif
 
 extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* stream) {
   if (n <= 0) return 0;
@@ -600,6 +660,20 @@ extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* 
   bool plain = true;                                          // flags bit 1 on EVERY branch: zero offsets, mask 1 (the caller's promise)
   for (int i = 0; i < n; ++i) plain = plain && (br[i].B <= 0 || (br[i].flags & 2));
   static const bool plain_on = [] { const char* e = getenv("MQ_DCN_PLAIN"); return !(e && e[0] == '0'); }();   // A/B switch
+  {
+    // flags bit 2 on EVERY branch: the weights are in LDS-tile order (ops.dcn_weight_tiles) -> the BDMA instantiations
+    int nb = 0, nt = 0;
+    for (int i = 0; i < n; ++i) if (br[i].B > 0) { ++nb; nt += (br[i].flags >> 2) & 1; }
+    if (nt != 0 && nt != nb) return -5;
+    if (nt) {
+      constexpr int BW = MQ_DCN_SPLIT ? 8 : 16;               // waves of the shipped instantiation of this build
+      const int rc = (plain && plain_on) ? dcn_launch<BW, 1, true, true>(grid, smem, (hipStream_t)stream, g)
+                                         : dcn_launch<BW, 1, false, true>(grid, smem, (hipStream_t)stream, g);
+      if (rc) return rc;
+      MQ_CHECK_LAUNCH();
+      return 0;
+    }
+  }
 #if MQ_DCN_SPLIT
   if (nw == 8) {                                              // split-precise default: 8 waves, one barrier per k-step, PLAIN for the FPN convs
     int rc;

@@ -103,6 +103,18 @@ def _pack_bert_layer(P, sd, b, device, dtype):
     _pack_frag(P, b + ".qkv.frag", P[b + ".qkv.weight"])      # the same matrix in MFMA B-fragment order: what mq_bert_attn_qkv_fwd streams
 
 
+def _dcn_tiles(P, key):
+    """DCNv2 / FPN conv weights of the plan a SECOND time in LDS-tile order (`key.tiles`) when the kernel selection streams them by LDS-DMA
+    (KERNELS["DCN_BDMA"]); `key.packed` stays row-major for mq_conv3x3_fwd and for a selection without the switch."""
+    if ops.dcn_bdma():
+        P[key + ".tiles"] = ops.dcn_weight_tiles(P[key + ".packed"])
+
+
+def _dcn_w(P, key):
+    """The DCNv2 weight operand of `key` under the ACTIVE selection."""
+    return P[key + ".tiles"] if (ops.dcn_bdma() and (key + ".tiles") in P) else P[key + ".packed"]
+
+
 def build_plan(sd, cfg, device, dtype=torch.float16):
     """Pack the fp32 state_dict into inference tensors: fp16 casts, fused / folded / re-laid-out weights."""
     P = {}
@@ -177,6 +189,7 @@ def build_plan(sd, cfg, device, dtype=torch.float16):
         for k in range(3):
             w = f32(f"{b}.DyConv.{k}.conv.weight")                                   # [O, C, 3, 3] -> [O, tap*C + c]
             P[f"{b}.DyConv.{k}.packed"] = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dtype).contiguous()
+            _dcn_tiles(P, f"{b}.DyConv.{k}")
         wo = f32(b + ".offset.weight").permute(0, 2, 3, 1).reshape(27, -1)            # 27 -> 32 zero-padded rows
         P[b + ".offset.packed"] = torch.cat([wo, wo.new_zeros(5, wo.shape[1])], 0).to(dtype).contiguous()
         P[b + ".attn_w"] = f32(b + ".AttnConv.1.weight").reshape(-1)
@@ -184,6 +197,7 @@ def build_plan(sd, cfg, device, dtype=torch.float16):
     for n in ("fpn_layer2", "fpn_layer3", "fpn_layer4", "top_blocks.p6", "top_blocks.p7"):
         w = f32(f"backbone.fpn.{n}.weight")
         P[f"backbone.fpn.{n}.packed"] = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dtype).contiguous()
+        _dcn_tiles(P, f"backbone.fpn.{n}")
     for n in ("fpn_inner2", "fpn_inner3", "fpn_inner4"):
         P[f"backbone.fpn.{n}.lin"] = h(f"backbone.fpn.{n}.weight").reshape(sd[f"backbone.fpn.{n}.weight"].shape[0], -1).contiguous()
     # patch embedding (4x4 stride-4 conv) as a GEMM over (kh, kw, c)-ordered patches; box / centerness 1x1 convs of every
@@ -375,13 +389,13 @@ def fpn_forward(P, feats_nhwc):
         # offsets and mask logits of +100 (sigmoid = 1 exactly) -- a deformable conv sampling at integer positions with weights
         # (1, 0, 0, 0) IS the plain 3x3 conv (zero padding included: taps at -1 / H are "outside"), and that kernel runs its 128 x 256 x 64
         # tiles at 2.5x the rate of conv_igemm's 128 x 256 x 32 ones: +3.8 % end to end (round 3, GPU call 1).
-        outs = ops.dcnv2_group([dict(x=x, om=_zero_offsets(x.shape[0], x.shape[1], x.shape[2], x.device), w=P[f"{p}.{n}.packed"],
+        outs = ops.dcnv2_group([dict(x=x, om=_zero_offsets(x.shape[0], x.shape[1], x.shape[2], x.device), w=_dcn_w(P, f"{p}.{n}"),
                                      bias=P[f"{p}.{n}.bias"], stride=1, plain=True) for n, x in inners], want_stats=False, tag="dcnv2_fpn")
         res = [y.reshape(x.shape[0], hw[0], hw[1], 256) for (y, hw, _), (_, x) in zip(outs, inners)]
 
         def conv3s2(name, x):
             Ho, Wo = (x.shape[1] - 1) // 2 + 1, (x.shape[2] - 1) // 2 + 1
-            y, hw = ops.dcnv2(x, _zero_offsets(x.shape[0], Ho, Wo, x.device), P[f"{p}.{name}.packed"], P[f"{p}.{name}.bias"], 2, tag="dcnv2_fpn", plain=True)
+            y, hw = ops.dcnv2(x, _zero_offsets(x.shape[0], Ho, Wo, x.device), _dcn_w(P, f"{p}.{name}"), P[f"{p}.{name}.bias"], 2, tag="dcnv2_fpn", plain=True)
             return y.reshape(x.shape[0], hw[0], hw[1], 256)
         p6 = conv3s2("top_blocks.p6", res[-1])
         p7 = conv3s2("top_blocks.p7", F.relu(p6))
@@ -766,7 +780,7 @@ def dyconv_tokens(P, cfg, b, tok, sizes, defer_relu=False):
             wy = wx = None
             if (Ho, Wo) != (H, W):
                 wy, wx = _upsample_pool_weights(Ho, Wo, H, W, tok.device)
-            branches.append({"x": x_nhwc, "om": om[lvl], "w": P[f"{b}.DyConv.{k}.packed"], "bias": P[f"{b}.DyConv.{k}.conv.bias"],
+            branches.append({"x": x_nhwc, "om": om[lvl], "w": _dcn_w(P, f"{b}.DyConv.{k}"), "bias": P[f"{b}.DyConv.{k}.conv.bias"],
                              "stride": stride, "wy": wy, "wx": wx})
             owner.append((lvl, k, len(spec)))
     ys = ops.dcnv2_group(branches, want_stats=True)

@@ -888,11 +888,59 @@ def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None
         sums = torch.empty(B, lib.mq_dcnv2_stats_blocks(H, W, stride), 256, 3, dtype=torch.float32, device=y.device)
         if wy is not None:
             assert wy.dtype == wx.dtype == torch.float32 and wy.numel() == Ho and wx.numel() == Wo
+    w_packed, wflag = _dcn_w(w_packed)
     with _timed(tag):
         _chk(_fn(lib, "mq_dcnv2_fwd", x_nhwc)(_ptr(x_nhwc), _ptr(om), _ptr(w_packed), _ptr(bias), _ptr(y), _ptr(sums), _ptr(wy), _ptr(wx),
-                              B, H, W, C, x_nhwc.stride(0), om.shape[2], om.shape[3], 256, 256, stride, int(bool(mask_prob)) | (2 if plain else 0),
+                              B, H, W, C, x_nhwc.stride(0), om.shape[2], om.shape[3], 256, 256, stride, int(bool(mask_prob)) | (2 if plain else 0) | wflag,
                               _stream()), "mq_dcnv2_fwd")
     return (y, (Ho, Wo), sums) if want_stats else (y, (Ho, Wo))
+
+
+_DCN_TILED = {}          # id(tensor) -> weak reference: weights that dcn_weight_tiles() produced (flags bit 2 of the DCNv2 entry points)
+
+
+def dcn_weight_tiles(w):
+    """DCNv2 / 3x3 conv weights [256, 9 C] (k = tap * C + c) -> the SAME shape and dtype in LDS-TILE ORDER (KERNELS["DCN_BDMA"], flags bit 2 of
+    mq_dcnv2_*): per k-step ks = slice * 9 + tap one 32 KB block that is the byte image of the kernel's B tile, copied global -> LDS by LDS-DMA --
+    16-bit builds: 256 rows x 64 channels with the 16-byte chunk c of row r at position c ^ (r & 7); split-precise build: [hi plane | lo plane] of
+    256 rows x 32 channels (fp16; x = hi + lo / 2^11).  Done once, when the model is packed."""
+    import weakref
+    N, K = w.shape
+    C = K // 9
+    assert N == 256 and K == 9 * C and C % 128 == 0 and w.is_contiguous()
+    if w.dtype == torch.float32:
+        blk = w.view(256, 9, C // 32, 32).permute(2, 1, 0, 3).reshape(-1, 256 * 32)                 # [ks][row][32]
+        hi = blk.to(torch.float16)
+        lo = ((blk - hi.float()) * 2048.0).to(torch.float16)
+        out = torch.cat([hi, lo], 1).contiguous().view(torch.float32).reshape(256, K)
+    else:
+        blk = w.view(256, 9, C // 64, 8, 8).permute(2, 1, 0, 3, 4).reshape(-1, 256, 8, 8)             # [ks][row][chunk][8]
+        r = torch.arange(256, device=w.device)[:, None]
+        pos = torch.arange(8, device=w.device)[None, :]
+        src = (pos ^ (r & 7))                                                                        # position p of row r holds chunk p ^ (r & 7)
+        out = torch.gather(blk, 2, src[None, :, :, None].expand(blk.shape[0], -1, -1, 8)).reshape(256, K).contiguous()
+    if len(_DCN_TILED) > 4096:
+        for k in [k for k, ref in _DCN_TILED.items() if ref() is None]:
+            del _DCN_TILED[k]
+    _DCN_TILED[id(out)] = weakref.ref(out)
+    return out
+
+
+def dcn_bdma():
+    """Does the active selection stream the DCNv2 weights by LDS-DMA?  KERNELS["DCN_BDMA"]: 1 always, 0 never, -1 in the split-precise mode only."""
+    k = KERNELS.get("DCN_BDMA", -1)
+    return k == 1 or (k == -1 and bool(f32_operands()))
+
+
+def _dcn_w(w):
+    """(weights to hand to the kernel, flags bit 2).  Tile-ordered weights are recognised by identity; with KERNELS["DCN_BDMA"] = 1 row-major
+    weights are re-ordered per call (tests, the operator-level wrappers: the pipeline packs once)."""
+    ref = _DCN_TILED.get(id(w))
+    if ref is not None and ref() is w:
+        return w, 4
+    if dcn_bdma():
+        return dcn_weight_tiles(w), 4
+    return w, 0
 
 
 class _DcnBranch(ctypes.Structure):
@@ -908,6 +956,7 @@ def dcnv2_group(branches, want_stats=True, tag="dcnv2_fused", ablation=0):
     lib = load_library()
     arr = (_DcnBranch * len(branches))()
     outs = []
+    keep = []                                                 # per-call re-ordered weights stay alive until the launch is issued
     for i, (a, br) in enumerate(zip(arr, branches)):
         x, om, w, bias, stride = br["x"], br["om"], br["w"], br["bias"], br["stride"]
         wy, wx = br.get("wy"), br.get("wx")
@@ -923,12 +972,14 @@ def dcnv2_group(branches, want_stats=True, tag="dcnv2_fused", ablation=0):
             sums = torch.empty(B, lib.mq_dcnv2_stats_blocks(H, W, stride), 256, 3, dtype=torch.float32, device=y.device)
             if wy is not None:
                 assert wy.dtype == wx.dtype == torch.float32 and wy.numel() == Ho and wx.numel() == Wo
+        w, wflag = _dcn_w(w)
+        keep.append(w)
         a.x, a.om, a.w, a.bias, a.out = x.data_ptr(), om.data_ptr(), w.data_ptr(), bias.data_ptr(), y.data_ptr()
         a.stats = sums.data_ptr() if sums is not None else None
         a.wy = wy.data_ptr() if wy is not None else None
         a.wx = wx.data_ptr() if wx is not None else None
         a.x_bs, a.B, a.H, a.W, a.C, a.oH, a.oW = x.stride(0), B, H, W, C, om.shape[2], om.shape[3]
-        a.N, a.out_ld, a.stride, a.flags = 256, 256, stride, (int(bool(br.get("mask_prob", False))) | (2 if br.get("plain", False) else 0)
+        a.N, a.out_ld, a.stride, a.flags = 256, 256, stride, (int(bool(br.get("mask_prob", False))) | (2 if br.get("plain", False) else 0) | wflag
                                                              | ((int(ablation) & 15) << 8 if i == 0 else 0))
         outs.append((y, (Ho, Wo), sums))
     with _timed(tag):
