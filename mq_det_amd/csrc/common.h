@@ -178,6 +178,28 @@ __device__ __forceinline__ void lds_stage_frag8(const half_t* src_lane, half_t* 
 #endif
 }
 
+// The same copy with the source as (raw buffer over the array, wave-uniform element offset `eoff`, lane-linear fragments): the 16-bit builds issue
+// the MUBUF form `buffer_load_dwordx4 ... lds`.  Why not global_load_lds: hipcc's wait-count pass books that FLAT-encoded instruction as a flat
+// access that may touch LDS AND memory ("pending flat" -- vmcnt and lgkmcnt no longer count in order for it) and from then on every s_waitcnt of
+// the loop is vmcnt(0) / lgkmcnt(0): a register ring of fragment reads "six deep" waits for its NEWEST read at every MFMA (round 6: the ISA of the
+// Swin MLP loop had no other wait than lgkmcnt(0)).  The MUBUF form is a vector-memory load to it; counted waits stay counted.
+typedef __amdgpu_buffer_rsrc_t mq_rsrc;
+__device__ __forceinline__ mq_rsrc mq_raw_buffer(const void* base) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000); }
+// lane l's fragment = base[eoff + leoff .. + 8), eoff wave-uniform (scalar offset), leoff per lane (vector offset; lane-linear sources: 8 l)
+__device__ __forceinline__ void lds_stage_frag8_buf(mq_rsrc r, const half_t* base, int eoff, int leoff, half_t* dst_base, int lane) {
+#if defined(MQ_F32)
+  (void)r;
+  lds_stage_frag8(base + eoff + leoff, dst_base, lane);
+#else
+  (void)base; (void)lane;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst_base, 16, leoff * (int)sizeof(half_t), eoff * (int)sizeof(half_t), 0, 0);
+#endif
+}
+// 16 raw bytes per lane (lane-linear destination as above), every build
+__device__ __forceinline__ void lds_stage_16b_buf(mq_rsrc r, int boff, int lboff, void* dst_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst_base, 16, lboff, boff, 0, 0);
+}
+
 // reduce across the 16 lanes that share (lane >> 4): lanes differ in their low 4 bits
 __device__ __forceinline__ float group16_max(float v) {
   v = fmaxf(v, __shfl_xor(v, 1));

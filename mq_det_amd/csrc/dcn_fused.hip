@@ -90,11 +90,22 @@ typedef mq_f32x4 dcn_gvec;                                   // one 16-byte chun
 #else
 typedef half8 dcn_gvec;
 #endif
-// BDMA (round 6, opt-in: flags bit 2 of every branch / KERNELS["DCN_BDMA"]): the weights arrive in LDS-TILE ORDER -- per k-step one 32 KB block that
-// is the byte image of the B tile (16-bit builds: rows of 64 with the chunk swizzle applied; split-precise: [hi plane | lo plane] of rows of 32;
-// mq_det_amd.ops.dcn_weight_tiles) -- and are copied global -> LDS by LDS-DMA: no weight registers, no ds_write, no split arithmetic for B.  The
-// step then is: DMA of B(k + 1) and the gathers of A(k + 2) at its top, MFMAs of step k and the blend / staging of A(k + 1) in the two wave
-// groups' opposite orders, `s_waitcnt vmcnt(0)` + barrier at its end (everything issued at the top has had the whole step to land).
+// BDMA (round 6; flags bit 2 of every branch / KERNELS["DCN_BDMA"], the default): the weights arrive in LDS-TILE ORDER -- per k-step one 32 KB block
+// that is the byte image of the B tile (16-bit builds: rows of 64 with the chunk swizzle applied; split-precise: [hi plane | lo plane] of rows of
+// 32; mq_det_amd.ops.dcn_weight_tiles) -- and are copied global -> LDS by LDS-DMA: no weight registers, no ds_write, no split arithmetic for B.
+// One barrier per k-step.  Group 0: MFMAs(k), blend + staging of A(k + 1), gathers of A(k + 3) -- no copy, plain barriers, counted waits by hipcc.
+// Group 1: blend + staging of A(k + 1), copy of B(k + 1), gathers of A(k + 3), MFMAs(k), then vmcnt(<its gathers>) = "the copy has landed".
+// Three things the compiler's wait-count pass needed (each one was a vmcnt(0) in the middle of the step; GPU calls 12 / 13: 0.603 -> 0.515 ms):
+//   * the copy as MUBUF `buffer_load ... lds`: the FLAT-encoded global_load_lds is booked as a flat access ("pending flat": every later wait of
+//     the loop becomes vmcnt(0) / lgkmcnt(0));
+//   * group 1's loop behind __restrict__ tile pointers (dcn_scoped_tiles): without alias scopes every LDS read after a copy waits for the copy;
+//   * the end-of-step wait as __builtin_amdgcn_s_waitcnt, which the pass books, not as an asm string.
+// the tiles of the two buffers and the sampling state as DISJOINT objects (alias scopes once inlined)
+template <class T, class S, class F>
+__device__ __forceinline__ void dcn_scoped_tiles(T* __restrict__ a0, T* __restrict__ a1, T* __restrict__ b0, T* __restrict__ b1, const S* __restrict__ ts, F f) {
+  f(a0, a1, b0, b1, ts);
+}
+
 template <int NW, int ABL = 0, int SYNC = 2, bool PLAIN = false, bool FENCE = false, bool BDMA = false>
 __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   constexpr int BM = DCN_PH * DCN_PW, BN = 256, BK = MQ_DCN_SPLIT ? 32 : 64;
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
 #pragma unroll
     for (int j = 0; j < JB; ++j) b_raw[j] = dcn_gvec{};
   }
-  auto issue_a = [&](auto SLOT, int ks) {                    // gather of k-step ks
+  auto issue_a_at = [&](auto SLOT, int ks, const TapState* Ts) {   // gather of k-step ks
     constexpr int s = decltype(SLOT)::value;
     ks = min(ks, ksteps - 1);                                // tail: re-load the last step (one code path, no branches)
     const int slice = ks / 9, tap = ks - slice * 9;
@@ -254,6 +265,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
       }
     }
   };
+  auto issue_a = [&](auto SLOT, int ks) { issue_a_at(SLOT, ks, Ts); };
   auto issue_b = [&](int ks) {                               // weight tile of k-step ks
     ks = min(ks, ksteps - 1);
     const int slice = ks / 9, tap = ks - slice * 9;
@@ -265,13 +277,12 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   };
   // staging of one k-step by this thread: bilinear blend of its gathered slot (fp32 accumulate like the im2col kernel,
   // one rounding to fp16) -> its two A-tile rows, and its four weight chunks -> B tile
-  auto stage = [&](auto SLOT, int buf) {
+  auto stage_at = [&](auto SLOT, half_t* a_tile, half_t* b_tile) {      // the two tiles of ONE buffer
     constexpr int s = decltype(SLOT)::value;
-    buf &= NBUF - 1;
 #if MQ_DCN_SPLIT
-    // planes of buffer `buf`: A hi, A lo, B hi, B lo (fp16); this thread's CH = 4 blended values / weights -> 8 bytes into each plane
-    _Float16* a_hi = (_Float16*)As + buf * 2 * BM * BK + a_lds;
-    _Float16* b_hi = (_Float16*)Bs + buf * 2 * BN * BK;
+    // planes of the buffer: A hi, A lo, B hi, B lo (fp16); this thread's CH = 4 blended values / weights -> 8 bytes into each plane
+    _Float16* a_hi = (_Float16*)a_tile + a_lds;
+    _Float16* b_hi = (_Float16*)b_tile;
 #pragma unroll
     for (int rr = 0; rr < RA; ++rr) {
       mq_f32x4 t;
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
       }
     }
 #else
-    half_t* a = As + buf * BM * BK + a_lds;
+    half_t* a = a_tile + a_lds;
 #pragma unroll
     for (int rr = 0; rr < RA; ++rr) {
       half8 v;
@@ -319,27 +330,34 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
     }
     if constexpr (!BDMA) {
 #pragma unroll
-      for (int j = 0; j < JB; ++j) *(half8*)(Bs + buf * BN * BK + b_lds[j]) = b_raw[j];
+      for (int j = 0; j < JB; ++j) *(half8*)(b_tile + b_lds[j]) = b_raw[j];
     }
 #endif
   };
-  // BDMA: the B tile of k-step ks (a 32 KB block of the tile-ordered weights) -> buffer `buf`, issued by the waves of GROUP 1 only (2 JB linear
-  // 1 KB pieces per wave): hipcc's wait-count pass cannot count register loads and LDS-DMA pieces in one queue -- with a DMA pending, the first
-  // use of ANY gathered register waits with vmcnt(0) (ISA of the first version: `D D w0 ...` at the top of every step: the copy's whole latency
-  // exposed).  Group 1 blends / stages A FIRST in a step (its registers were gathered one step earlier, nothing else pending), then starts the
-  // copy and its gathers, then runs its MFMAs; group 0 never has a copy in flight.
+  auto stage = [&](auto SLOT, int buf) {
+    buf &= NBUF - 1;
+    stage_at(SLOT, As + buf * BM * BK, Bs + buf * BN * BK);
+  };
+  // BDMA: the B tile of k-step ks (a 32 KB block of the tile-ordered weights) -> one B buffer, issued by the waves of GROUP 1 only (2 JB linear
+  // 1 KB pieces per wave); group 0 never has a copy in flight.
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  auto dma_b = [&](int ks, int buf) {
+  // The copy is a MUBUF `buffer_load_dwordx4 ... lds`, not `global_load_lds`: hipcc's wait-count pass books the FLAT-encoded form as a flat access
+  // that may touch LDS and memory ("pending flat"), and from then on EVERY s_waitcnt of the loop is vmcnt(0) / lgkmcnt(0) -- no counted waits for
+  // the gathers, no ds_read / MFMA overlap inside a wave.  Weights as a raw buffer (base = w, no stride); lane offset in one VGPR, tile and piece
+  // offsets in the scalar offset.
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, 0x7fffffff, 0x00020000);
+  const unsigned dma_voff = (unsigned)((tid & (NTH / 2 - 1)) * 16);
+  auto dma_b_at = [&](int ks, half_t* b_tile) {
     constexpr int TILE_B = BN * BK * (int)sizeof(half_t);     // 32 KB in every build
     constexpr int HT = NTH / 2;                                // threads of group 1
     ks = min(ks, ksteps - 1);
-    const char* src = wb + (long)ks * TILE_B + (tid - HT) * 16;
-    char* dst = (char*)Bs + (buf & (NBUF - 1)) * TILE_B + (wave_u - NW / 2) * 1024;
+    const int soff = __builtin_amdgcn_readfirstlane(ks * TILE_B);
+    char* dst = (char*)b_tile + (wave_u - NW / 2) * 1024;
 #pragma unroll
     for (int j = 0; j < 2 * JB; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * HT * 16),
-                                       (__attribute__((address_space(3))) void*)(dst + j * HT * 16), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(dst + j * HT * 16), 16, dma_voff, soff + j * HT * 16, 0, 0);
   };
+  auto dma_b = [&](int ks, int buf) { dma_b_at(ks, Bs + (buf & (NBUF - 1)) * BN * BK); };
 
   float4_ acc[IM][4];
 #pragma unroll
@@ -350,11 +368,10 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   // fragment addressing: row = w? * 64 + i * 16 + l15 (row & 7 == l15 & 7), chunk = kk * 4 + lg
   const unsigned fa = (unsigned)((wr * IM * 16 + l15) * BK), fb = (unsigned)((wc * 64 + l15) * BK);
 #if MQ_DCN_SPLIT
-  auto mfma_phase = [&](int cur) {                           // one 32-deep step: IM x 4 blocks, three fp16 MFMAs each on the planar fragments
+  auto mfma_at = [&](const half_t* a_tile, const half_t* b_tile) {   // one 32-deep step: IM x 4 blocks, three fp16 MFMAs each on the planar fragments
     if constexpr (ABL & 8) return;
-    cur &= NBUF - 1;
-    const _Float16* At = (const _Float16*)As + cur * 2 * BM * BK + fa + lg * 8;
-    const _Float16* Bt = (const _Float16*)Bs + cur * 2 * BN * BK + fb + lg * 8;
+    const _Float16* At = (const _Float16*)a_tile + fa + lg * 8;
+    const _Float16* Bt = (const _Float16*)b_tile + fb + lg * 8;
     mq_split8 af[IM], bf[4];
 #pragma unroll
     for (int i = 0; i < IM; ++i) {
@@ -373,11 +390,10 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   };
 #else
   const unsigned sw0 = (unsigned)((lg ^ (l15 & 7)) << 3), sw1 = (unsigned)(((4 + lg) ^ (l15 & 7)) << 3);
-  auto mfma_phase = [&](int cur) {                           // this wave's 64 x 64 block of one k-step (32 MFMAs)
+  auto mfma_at = [&](const half_t* a_tile, const half_t* b_tile) {   // this wave's 64 x 64 block of one k-step (32 MFMAs)
     if constexpr (ABL & 8) return;
-    cur &= NBUF - 1;
-    const half_t* At = As + cur * BM * BK + fa;
-    const half_t* Bt = Bs + cur * BN * BK + fb;
+    const half_t* At = a_tile + fa;
+    const half_t* Bt = b_tile + fb;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       half8 af[IM], bf[4];
@@ -392,6 +408,10 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
     }
   };
 #endif
+  auto mfma_phase = [&](int cur) {
+    cur &= NBUF - 1;
+    mfma_at(As + cur * BM * BK, Bs + cur * BN * BK);
+  };
 
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
@@ -402,31 +422,50 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
     if (wave >= NW / 2) dma_b(0, 0);
     issue_a(S1{}, 1);                                        // slot s holds the tiles of its parity: consumed in step k, refilled with tile k + 3 right after
     issue_a(S0{}, 2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0) as an instruction hipcc's wait-count pass SEES: nothing is pending after it
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < WARM_N; ++i) asm volatile("" ::"v"(warm[i]));     // warm-up destinations released here
-    // step ks reads buffer ks & 1 and fills the other one: group 0 = MFMAs(ks), blend + staging of A(ks + 1), gathers of A(ks + 2);
-    // group 1 = blend + staging of A(ks + 1), DMA of B(ks + 1), gathers of A(ks + 2), MFMAs(ks); end of step: this thread's copies / gathers
-    // have landed (they had its MFMA phase / the other group's to do so), barrier
+    // step ks reads buffer ks & 1 and fills the other one: group 0 = MFMAs(ks), blend + staging of A(ks + 1), gathers of A(ks + 3);
+    // group 1 = blend + staging of A(ks + 1), copy of B(ks + 1), gathers of A(ks + 3), MFMAs(ks); end of step: the copy has landed (it had the
+    // MFMA phase to do so), barrier
+    // End of a step of group 1: a COUNTED wait.  The step's copies are issued before its gathers (pinned by a sched_barrier;
+    // tests/test_host_cpu.py checks the order in the ISA), VMEM returns in order, so vmcnt(<gathers per step>) says "the copies have landed" and
+    // leaves the gathers of tile ks + 3 in flight across the barrier (vmcnt(0) here: 0.553 instead of 0.515 ms per launch, GPU call 13).  The
+    // wait is the BUILTIN, an instruction hipcc's wait-count pass sees and books (an asm string is invisible to it: it then adds its own
+    // vmcnt(0) in front of the barrier's fence and of the next blend).
+    constexpr int NG = RA * (PLAIN ? 1 : 4);                 // gather loads per thread and step
     auto step_end = [&]() {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0x0F70 | NG);               // vmcnt(NG), nothing else
       __syncthreads();
+      // the next step's blend stays below the barrier: hoisted above it, its register wait lands where a copy is still pending
+      __builtin_amdgcn_sched_barrier(0);
     };
     if (wave < NW / 2) {
+      // group 0 never has a copy in flight: plain barriers, its gathers stay in flight across them (counted waits by hipcc, two steps of distance)
       for (int ks = 0; ks < ksteps; ks += 2) {
         mfma_phase(0); stage(S1{}, 1); issue_a(S1{}, ks + 3);
-        step_end();
+        __syncthreads();
         mfma_phase(1); stage(S0{}, 0); issue_a(S0{}, ks + 4);
-        step_end();
+        __syncthreads();
       }
     } else {
-      for (int ks = 0; ks < ksteps; ks += 2) {
-        stage(S1{}, 1); dma_b(ks + 1, 1); issue_a(S1{}, ks + 3); mfma_phase(0);
-        step_end();
-        stage(S0{}, 0); dma_b(ks + 2, 0); issue_a(S0{}, ks + 4); mfma_phase(1);
-        step_end();
-      }
+      // group 1 runs its loop behind __restrict__ parameters (dcn_scoped_tiles): the accesses carry alias scopes, and hipcc's wait-count pass
+      // uses them -- WITHOUT, every LDS read after a copy was issued waits with vmcnt(0) for it (the B tile the MFMAs read and the B tile the
+      // copy fills are "the same array" to it): the copy's whole latency in front of the MFMA phase, 9 % slower than register-staged weights
+      dcn_scoped_tiles(As, As + BM * BK, Bs, Bs + BN * BK, Ts,
+                       [&](half_t* a0, half_t* a1, half_t* b0, half_t* b1, const TapState* ts) __attribute__((always_inline)) {
+        for (int ks = 0; ks < ksteps; ks += 2) {
+          stage_at(S1{}, a1, b1); dma_b_at(ks + 1, b1);
+          __builtin_amdgcn_sched_barrier(0);                  // the copy goes out HERE (hipcc sinks it below the MFMA phase otherwise)
+          issue_a_at(S1{}, ks + 3, ts); mfma_at(a0, b0);
+          step_end();
+          stage_at(S0{}, a0, b0); dma_b_at(ks + 2, b0);
+          __builtin_amdgcn_sched_barrier(0);                  // the copy goes out HERE (hipcc sinks it below the MFMA phase otherwise)
+          issue_a_at(S0{}, ks + 4, ts); mfma_at(a1, b1);
+          step_end();
+        }
+      });
     }
   } else {
   // ---- pipeline fill: every thread stages step 0; gathers of steps 1, 2 and the weights of step 1 are in flight

@@ -184,39 +184,38 @@ __global__ __launch_bounds__(64 * NW, MQ_SW_SPLIT ? (C <= 96 ? 2 : 1) : (C <= 96
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: staging addresses in SGPRs
   const long row0 = (long)blockIdx.x * BM + wave * 16;        // this wave's 16 tokens
 
+  const mq_rsrc rs_w1 = mq_raw_buffer(p.w1f), rs_w2 = mq_raw_buffer(p.w2f);
   // ---- staging of one iteration's weights by LDS-DMA: W1 chunk c1 -> W1 stage s1, W2 chunk c2 -> W2 stage s2.  Block f of the iteration
   // (f < W1_FR: W1, else W2) is copied by wave f % NW as one 1 KB piece: source and destination are both lane-linear.
   auto stage_issue = [&](int c1, int s1, int c2, int s2) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < FPW; ++i) {
       const int f = wave + i * NW;
+      // (MUBUF `buffer_load ... lds`, csrc/common.h: with the FLAT-encoded global_load_lds every wait of the loop below was lgkmcnt(0))
+      const mq_rsrc rs = f < W1_FR ? rs_w1 : rs_w2;
+      const int eoff = f < W1_FR ? (c1 * W1_FR + f) * FR : (c2 * W2_FR + (f - W1_FR)) * FR;
+      half_t* dst = f < W1_FR ? w1s + (s1 * W1_FR + f) * FR : w2s + (s2 * W2_FR + (f - W1_FR)) * FR;
 #if MQ_SW_SPLIT
       // the 2 KB planar block as two linear 1 KB LDS-DMA pieces (hi plane, lo plane): asynchronous like the 16-bit builds' one piece
-      const half_t* blk = f < W1_FR ? p.w1f + ((long)c1 * W1_FR + f) * FR : p.w2f + ((long)c2 * W2_FR + (f - W1_FR)) * FR;
-      half_t* dst = f < W1_FR ? w1s + (s1 * W1_FR + f) * FR : w2s + (s2 * W2_FR + (f - W1_FR)) * FR;
-      const char* sb = (const char*)blk + lane * 16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + 1024), (__attribute__((address_space(3))) void*)((char*)dst + 1024), 16, 0, 0);
+      lds_stage_16b_buf(rs, eoff * (int)sizeof(half_t), lane * 16, dst);
+      lds_stage_16b_buf(rs, eoff * (int)sizeof(half_t) + 1024, lane * 16, (char*)dst + 1024);
 #else
-      const half_t* src = (f < W1_FR ? p.w1f + ((long)c1 * W1_FR + f) * FR : p.w2f + ((long)c2 * W2_FR + (f - W1_FR)) * FR) + lane * 8;
-      half_t* dst = f < W1_FR ? w1s + (s1 * W1_FR + f) * FR : w2s + (s2 * W2_FR + (f - W1_FR)) * FR;
-      lds_stage_frag8(src, dst, lane);
+      lds_stage_frag8_buf(rs, nullptr, eoff, lane * 8, dst, lane);
 #endif
     }
   };
   // (W2ONE) the two rings staged separately: `nb` fragment blocks from `g` to `l`, block f by wave f % NW
-  auto stage_ring = [&](const half_t* g, half_t* l, auto NBc) __attribute__((always_inline)) {
+  auto stage_ring = [&](mq_rsrc rs, int g0, half_t* l, auto NBc) __attribute__((always_inline)) {    // g0: element offset inside the array of rs
     constexpr int nb = decltype(NBc)::value;
 #pragma unroll
     for (int i = 0; i < nb / NW; ++i) {
       const int f = wave + i * NW;
 #if MQ_SW_SPLIT
-      const char* sb = (const char*)(g + (long)f * FR) + lane * 16;
       char* dst = (char*)(l + f * FR);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + 1024), (__attribute__((address_space(3))) void*)(dst + 1024), 16, 0, 0);
+      lds_stage_16b_buf(rs, (g0 + f * FR) * (int)sizeof(half_t), lane * 16, dst);
+      lds_stage_16b_buf(rs, (g0 + f * FR) * (int)sizeof(half_t) + 1024, lane * 16, dst + 1024);
 #else
-      lds_stage_frag8(g + (long)f * FR + lane * 8, l + f * FR, lane);
+      lds_stage_frag8_buf(rs, nullptr, g0 + f * FR, lane * 8, l + f * FR, lane);
 #endif
     }
   };
@@ -225,8 +224,8 @@ __global__ __launch_bounds__(64 * NW, MQ_SW_SPLIT ? (C <= 96 ? 2 : 1) : (C <= 96
   // iterations read before their own pieces land
   if constexpr (W2ONE) {
 #pragma unroll
-    for (int c = 0; c <= D; ++c) stage_ring(p.w1f + (long)c * W1_FR * FR, w1s + (c % NS) * W1_FR * FR, std::integral_constant<int, W1_FR>{});
-    stage_ring(p.w2f, w2s, std::integral_constant<int, W2_FR>{});
+    for (int c = 0; c <= D; ++c) stage_ring(rs_w1, c * W1_FR * FR, w1s + (c % NS) * W1_FR * FR, std::integral_constant<int, W1_FR>{});
+    stage_ring(rs_w2, 0, w2s, std::integral_constant<int, W2_FR>{});
   } else {
 #pragma unroll
     for (int c = 0; c <= D; ++c) stage_issue(c, c % NS, 0, c == 0 ? 0 : NS - 1);
@@ -349,7 +348,7 @@ __global__ __launch_bounds__(64 * NW, MQ_SW_SPLIT ? (C <= 96 ? 2 : 1) : (C <= 96
     constexpr int S1 = (PH + 1) % NS, S2 = W2ONE ? 0 : (PH + NS - 1) % NS;          // stages of W1 chunk j + 1 / W2 chunk j - 1 (read now)
     // pieces for iteration j + D: W1 chunk j + 1 + D -> the stage W1 chunk j left (read in iteration j - 1), W2 chunk j - 1 + D -> the stage
     // of W2 chunk j - 2 (ditto).  Past the end the chunk index is clamped (valid memory, results unused).
-    if constexpr (W2ONE) stage_ring(p.w1f + (long)min(j + 1 + D, NCHUNK + 1) * W1_FR * FR, w1s + PH * W1_FR * FR, std::integral_constant<int, W1_FR>{});
+    if constexpr (W2ONE) stage_ring(rs_w1, min(j + 1 + D, NCHUNK + 1) * W1_FR * FR, w1s + PH * W1_FR * FR, std::integral_constant<int, W1_FR>{});
     else stage_issue(min(j + 1 + D, NCHUNK + 1), PH, min(j - 1 + D, NCHUNK - 1), (PH + NS - 2) % NS);
     h_init(j + 1, hout);
     const half_t* a1 = w1s + S1 * W1_FR * FR + SW_LANE8;      // W1 chunk j + 1 (for j = NCHUNK - 1: a zero chunk)
@@ -390,7 +389,7 @@ __global__ __launch_bounds__(64 * NW, MQ_SW_SPLIT ? (C <= 96 ? 2 : 1) : (C <= 96
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * FPW) : "memory");
     __builtin_amdgcn_s_barrier();
     if constexpr (W2ONE) {                                    // everybody has read W2 chunk j - 1: chunk j takes its place (exposed: see above)
-      stage_ring(p.w2f + (long)min(j, NCHUNK - 1) * W2_FR * FR, w2s, std::integral_constant<int, W2_FR>{});
+      stage_ring(rs_w2, min(j, NCHUNK - 1) * W2_FR * FR, w2s, std::integral_constant<int, W2_FR>{});
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }

@@ -255,6 +255,7 @@ __global__ __launch_bounds__(256, MQ_WQKV_WG_PER_CU(STREAM)) void window_attn_qk
   half_t* Bsm = Ws + (STREAM ? 2 * 96 * C : 3 * C * WP);   // [3C] qkv bias (a global load per use would be waited for on the spot)
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const mq_rsrc rs_w = mq_raw_buffer(p.w);
   // STREAM: the pieces of head h (36 x 1 KB = 96 rows x C halfs, 9 per wave) -> buffer `buf`
   auto stage_head = [&](int h, int buf) __attribute__((always_inline)) {
     if constexpr (STREAM) {
@@ -264,9 +265,9 @@ __global__ __launch_bounds__(256, MQ_WQKV_WG_PER_CU(STREAM)) void window_attn_qk
         const int pc = wave + 4 * i;
         const int off = pc * 512 + lane * 8, row = off / C, posn = (off % C) >> 3;
         const int c = (posn & ~7) | ((posn ^ row) & 7);
-        const half_t* src = p.w + ((long)(row >> 5) * C + h * 32 + (row & 31)) * C + c * 8;
         half_t* dst = Ws + buf * 96 * C + pc * 512;
-        lds_stage_frag8(src, dst, lane);
+        // (MUBUF `buffer_load ... lds`, csrc/common.h: head offset in the scalar offset, this lane's swizzled source in the vector offset)
+        lds_stage_frag8_buf(rs_w, p.w, h * 32 * C, ((row >> 5) * C + (row & 31)) * C + c * 8, dst, lane);
       }
     }
   };

@@ -927,8 +927,8 @@ def dcn_weight_tiles(w):
 
 
 def dcn_bdma():
-    """Does the active selection stream the DCNv2 weights by LDS-DMA?  KERNELS["DCN_BDMA"]: 1 always, 0 never, -1 in the split-precise mode only."""
-    k = KERNELS.get("DCN_BDMA", -1)
+    """Does the active selection stream the DCNv2 weights by LDS-DMA?  KERNELS["DCN_BDMA"]: 1 always (default), 0 never, -1 in the split-precise mode only."""
+    k = KERNELS.get("DCN_BDMA", 1)
     return k == 1 or (k == -1 and bool(f32_operands()))
 
 

@@ -63,12 +63,13 @@ KERNEL_DEFAULTS = {
                                  # 1 = on the device: where a kernel's LDS tiles no longer fit the 160 KB of a CU at twice the element size the
                                  # wrappers pick the variant that does (streamed instead of resident operands, smaller tiles) or the plain
                                  # fp32 torch form; 2 = kernel-source emulation with a 320 KB LDS limit (every kernel as in the 16-bit modes)
-    "DCN_BDMA": -1,              # DCNv2 weights in LDS-tile order (ops.dcn_weight_tiles, packed once) copied global -> LDS by LDS-DMA, one
-                                 # `s_waitcnt vmcnt(0)` + barrier per k-step (csrc/dcn_fused.hip BDMA).  -1 (default): in the split-precise mode only;
-                                 # 1: always; 0: never (weights through registers, counted waits).  Same-box A/B on the MI355X (GPU call 12 of round 6,
-                                 # 3 alternations): split-precise 1.50 -> 1.31 ms per launch, 174.6 -> 180.4 images/s (no split arithmetic and no
-                                 # ds_write for B); fp16 operands 0.553 -> 0.604 ms per launch, 490.8 -> 484.5 images/s (hipcc waits with vmcnt(0)
-                                 # behind the copy's issue: its latency is exposed once per step in one wave group) -- so not there
+    "DCN_BDMA": 1,               # DCNv2 / FPN conv weights in LDS-tile order (ops.dcn_weight_tiles, packed once beside the row-major copy) copied
+                                 # global -> LDS by LDS-DMA (`buffer_load ... lds`; csrc/dcn_fused.hip BDMA): no weight registers, no ds_write for B.
+                                 # 1 (default since GPU call 13 of round 6): every build; 0: never (weights through registers); -1: in the
+                                 # split-precise mode only (the default of GPU call 12, when the fp16 variant was 9 % slower: hipcc's wait-count
+                                 # pass turned every wait behind the FLAT-encoded copy into vmcnt(0) / lgkmcnt(0)).  Same-box A/B, 3 alternations:
+                                 # fp16 0.559 -> 0.515 ms per launch (0.227 -> 0.246 of the MFMA peak), 483 -> 493 images/s; split-precise
+                                 # 1.50 -> 1.21 ms, 174 -> 182 images/s (profiles/r06_call13_dcn_bdma_ab.txt)
     "ALIGN_FUSED": 1,            # 1: mq_align_fused_fwd (heads + alignment + scoring, logits never written); 0: bmm + 5 GEMMs + 5 x mq_align_scores_fwd
 }
 class _ThreadLocalTable(dict):

@@ -408,6 +408,7 @@ inline V4 simt_ds_read_tr_elems(const void* p) {
 }
 #define __builtin_amdgcn_wave_barrier() simt::wave_sync()
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)
@@ -418,6 +419,12 @@ inline void simt_global_load_lds(const void* g, void* lds, unsigned size) { memc
 // (the size argument must be a literal in the product source -- hipcc crashes on sizeof(half8) there --, so the fp32-operand build,
 // whose "16-bit" fragments are twice as wide, scales it here)
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) simt_global_load_lds((const void*)(g), (void*)(l), (unsigned)(size))
+// raw buffer resource (base pointer only: the kernels use stride 0 and never rely on the range check) and the MUBUF form of the LDS copy
+struct simt_buffer_rsrc { const char* base; };
+typedef simt_buffer_rsrc __amdgpu_buffer_rsrc_t;
+#define __builtin_amdgcn_make_buffer_rsrc(p, stride, num, flags) (simt_buffer_rsrc{(const char*)(p)})
+#define __builtin_amdgcn_raw_ptr_buffer_load_lds(r, l, size, voff, soff, imm, aux) \
+  simt_global_load_lds((r).base + (size_t)(voff) + (size_t)(soff) + (size_t)(imm), (void*)(l), (unsigned)(size))
 inline float simt_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 #define __builtin_amdgcn_fmed3f(a, b, c) simt_fmed3f((a), (b), (c))
 #define __builtin_amdgcn_s_barrier() simt::block_sync()

@@ -472,6 +472,56 @@ def test_ctypes_signatures_match_header():
         assert res == {"int": ctypes.c_int, "long": ctypes.c_long}[ret], name
 
 
+def _isa_of(src, extra=()):
+    import subprocess, tempfile
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "k.s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", *extra, "-S", "--cuda-device-only",
+                        os.path.join(ROOT, "mq_det_amd", "csrc", src), "-o", out], check=True, stderr=subprocess.DEVNULL)
+        return open(out).read()
+
+
+def test_lds_copies_are_buffer_loads_and_the_dcn_copy_precedes_its_gathers():
+    """Static ISA checks of the kernels that stage weights by LDS-DMA (no GPU).
+    (1) the copy is the MUBUF form `buffer_load_dwordx4 ... lds`: hipcc books the FLAT-encoded `global_load_lds` as a flat access and from then
+        on every wait of the loop is vmcnt(0) / lgkmcnt(0) (round 6: the Swin MLP loop had no other wait than lgkmcnt(0));
+    (2) the Swin MLP loop does have counted LDS waits now;
+    (3) DCNv2 with LDS-tile-ordered weights: in the loop of the wave group that copies, between two barriers, every copy is issued BEFORE every
+        gather and the interval ends with vmcnt(<gathers>) -- the counted wait that says "the copies have landed" is only true in that order."""
+    import re
+    for src, extra in (("swin_mlp2.hip", ()), ("window_attn.hip", ()), ("dcn_fused.hip", ("-fno-slp-vectorize",)),
+                       ("dcn_fused.hip", ("-fno-slp-vectorize", "-DMQ_F32"))):
+        txt = _isa_of(src, extra)
+        assert "global_load_lds" not in txt and not re.search(r"^\s*flat_(load|store)", txt, re.M), src
+        assert re.search(r"buffer_load_dwordx4 .* lds", txt), src
+        if src == "swin_mlp2.hip" and not extra:
+            body = re.search(r"^_Z16swin_mlp2_kernelILi384ELi8ELb1EEv14SwinMlp2Params:(.*?)s_endpgm", txt, re.S | re.M).group(1)
+            counted = re.findall(r"s_waitcnt lgkmcnt\(([1-9]\d*)\)", body)
+            assert len(counted) >= 8, counted
+        if src == "dcn_fused.hip":
+            f32 = "-DMQ_F32" in extra                     # split-precise build: 8 waves, two rows per thread
+            for plain, ng in (("0", 8 if f32 else 4), ("1", 2 if f32 else 1)):
+                name = (f"_ZN6mq_f3217dcn_igemm8_kernelILi8ELi0ELi1ELb{plain}ELb0ELb1EEEvNS_8DcnGroupE" if f32 else
+                        f"_Z17dcn_igemm8_kernelILi16ELi0ELi1ELb{plain}ELb0ELb1EEv8DcnGroup")
+                body = re.search(r"^" + name + r":(.*?)s_endpgm", txt, re.S | re.M).group(1)
+                # basic blocks that hold copies AND barriers = the loop of group 1 (the fill has its copies in front of one barrier, too)
+                blocks = [b for b in re.split(r"^\.LBB\d+_\d+:", body, flags=re.M) if "lds" in b and "s_barrier" in b and "v_mfma" in b]
+                assert blocks, name
+                for b in blocks:
+                    for interval in b.split("s_barrier")[:-1]:
+                        ins = [l.strip() for l in interval.split("\n")]
+                        copies = [i for i, l in enumerate(ins) if re.match(r"buffer_load_dwordx4 .* lds", l)]
+                        gathers = [i for i, l in enumerate(ins) if l.startswith("global_load_dwordx4")]
+                        if not copies:
+                            continue
+                        assert gathers and max(copies) < min(gathers), (name, "a gather is issued before the last copy")
+                        assert len(gathers) == ng, (name, len(gathers))
+                        waits = [l for l in ins[max(gathers):] if l.startswith("s_waitcnt") and "vmcnt" in l]
+                        assert waits and re.search(r"vmcnt\((\d+)\)", waits[-1]).group(1) in (str(ng), "0"), (name, waits)
+                        assert any(f"vmcnt({ng})" in w for w in waits), (name, waits)
+
+
 def test_gather_kernels_keep_their_loads_in_flight():
     """Static ISA check (tools/isa_wait_scan.py, no GPU): the MSDeformAttn and window-attention kernels must not fall back to
     one `s_waitcnt vmcnt(0)` per global load -- the pattern that made the first MSDeformAttn kernel 2.3x slower."""
