@@ -302,7 +302,9 @@ __global__ __launch_bounds__(64 * NW, MQ_SW_SPLIT ? (C <= 96 ? 2 : 1) : (C <= 96
   // both pass through a pin, which chains the piece between the two fences of its step.
 #define MQ_PIN(x) asm volatile("" : "+v"(x))
   // (gts / ges: the iteration's GELU state between stages, local to the step -- every value's stages begin and end inside one step)
-  auto gelu_piece = [&](auto kc, auto stc, const float4_ (&hin)[2], half8& hf, float (&gts)[8], float (&ges)[8]) __attribute__((always_inline)) {
+  // (table: stage 0 only ISSUES the table read -- its two words travel to stage 1 untouched.  Used in stage 0, as in round 5, the LDS read is
+  // waited for with lgkmcnt(0) on the spot: LDS returns in order, so that wait also drains the RD fragment reads just issued for the coming MFMAs)
+  auto gelu_piece = [&](auto kc, auto stc, const float4_ (&hin)[2], half8& hf, float (&gts)[8], float (&ges)[8], float (&gds)[8]) __attribute__((always_inline)) {
     constexpr int k = decltype(kc)::value, stage = decltype(stc)::value;
     float& gt = gts[k];
     float& ge = ges[k];
@@ -313,17 +315,19 @@ __global__ __launch_bounds__(64 * NW, MQ_SW_SPLIT ? (C <= 96 ? 2 : 1) : (C <= 96
         const float pos = fmaf(__builtin_amdgcn_fmed3f(v, -6.f, 5.9921875f), 64.f, 384.f);        // in [0, 768)
         const int idx = (int)pos;
         gt = pos - (float)idx;
+        MQ_PIN(gt);
         const float2_ e = *(const float2_*)(tab + 2 * idx);
         ge = e[0];
-        gt = fmaf(gt, e[1], 0.f) ;                            // (frac * dPhi); Phi_i added in stage 1 -- two scalars carry the state
-        MQ_PIN(gt);
-        MQ_PIN(ge);
+        gds[k] = e[1];
       } else {
-        float o = v * (gt + ge);
+        float t = gt * gds[k];                                // frac * dPhi, rounded, + Phi_i: the arithmetic of round 5
+        MQ_PIN(t);
+        float o = v * (t + ge);
         MQ_PIN(o);
         hf[k] = (half_t)o;
       }
     } else {
+      (void)gds;
       if constexpr (stage == 0) {
         gt = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, fabsf(v), 1.f));
         ge = __builtin_amdgcn_exp2f((-0.5f * 1.4426950408889634f) * v * v);
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(64 * NW, MQ_SW_SPLIT ? (C <= 96 ? 2 : 1) : (C <= 96
     const half8& hs_old = hf_old;
 #endif
     wfrag_t ring[RD];
-    float gts[8], ges[8];
+    float gts[8], ges[8], gds[8];
 #pragma unroll
     for (int i = 0; i < RD && i < N; ++i) ring[i] = frag(i);
     static_for<N>([&](auto ic) __attribute__((always_inline)) {
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(64 * NW, MQ_SW_SPLIT ? (C <= 96 ? 2 : 1) : (C <= 96
         constexpr int q = decltype(qc)::value;
         if constexpr (q * N / NPIECE == i)
           gelu_piece(std::integral_constant<int, gelu_piece_of(q, GS, true)>{}, std::integral_constant<int, gelu_piece_of(q, GS, false)>{},
-                     hin, hf_new, gts, ges);
+                     hin, hf_new, gts, ges, gds);
       });
       const wfrag_t a = ring[i % RD];
       if constexpr (!(i & 1)) {

@@ -356,6 +356,7 @@ __global__ __launch_bounds__(256, MQ_WQKV_WG_PER_CU(STREAM)) void window_attn_qk
       }
       const half_t* Wb = STREAM ? Ws + (seq & 1) * 96 * C : Ws;
       // ---- projections of this head.  m = 0 (q), 1 (k): transposed; 2 (v): plain.  bias: row (d) for q / k, column (d) for v
+      constexpr int WQ_RD = MQ_WQ_SPLIT ? 1 : 2;            // depth of the weight-fragment ring of the projections
       wq_frag qf[NB], kf[NB], vf[NB / 2][2];                // vf[st][db]: V^T A-fragment of 32-key step st, channel block db
       {
         // A / B fragment of weight rows (matrix m, channel block db) for k-step ks: row l15, channels 32 ks + 8 lg .. + 7
@@ -378,13 +379,21 @@ __global__ __launch_bounds__(256, MQ_WQKV_WG_PER_CU(STREAM)) void window_attn_qk
 #pragma unroll
               for (int r = 0; r < 4; ++r) acc[db][tb][r] = (float)bv[r];
           }
+          // the weight fragments come through a ring WQ_RD reads deep: read -> wait -> four MFMAs per fragment (the ISA of round 5) exposes the
+          // LDS latency once per 64 matrix cycles, with one or two waves per SIMD to cover it
+          half8 wring[WQ_RD];
+#pragma unroll
+          for (int i = 0; i < WQ_RD; ++i) wring[i] = wfrag(m, i & 1, i >> 1);
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-              const wq_frag wf = WQ_F(wfrag(m, db, ks));
+              const int i = ks * 2 + db;
+              const wq_frag wf = WQ_F(wring[i % WQ_RD]);
+              if (i + WQ_RD < 2 * KS) wring[i % WQ_RD] = wfrag(m, (i + WQ_RD) & 1, (i + WQ_RD) >> 1);
 #pragma unroll
               for (int tb = 0; tb < NB; ++tb) acc[db][tb] = WQ_MFMA(wf, xf[tb][ks], acc[db][tb]);
+              if constexpr (!MQ_WQ_SPLIT) __builtin_amdgcn_sched_barrier(0);      // source order = issue order (hipcc sinks the ring's reads to their uses)
             }
 #pragma unroll
           for (int tb = 0; tb < NB; ++tb) {
@@ -402,13 +411,19 @@ __global__ __launch_bounds__(256, MQ_WQKV_WG_PER_CU(STREAM)) void window_attn_qk
 #pragma unroll
           for (int tb = 0; tb < NB; ++tb) acc[tb][db] = (float4_){bv, bv, bv, bv};
         }
+        half8 wring[WQ_RD];
+#pragma unroll
+        for (int i = 0; i < WQ_RD; ++i) wring[i] = wfrag(2, i & 1, i >> 1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
           for (int db = 0; db < 2; ++db) {
-            const wq_frag wf = WQ_F(wfrag(2, db, ks));
+            const int i = ks * 2 + db;
+            const wq_frag wf = WQ_F(wring[i % WQ_RD]);
+            if (i + WQ_RD < 2 * KS) wring[i % WQ_RD] = wfrag(2, (i + WQ_RD) & 1, (i + WQ_RD) >> 1);
 #pragma unroll
             for (int tb = 0; tb < NB; ++tb) acc[tb][db] = WQ_MFMA(xf[tb][ks], wf, acc[tb][db]);
+            if constexpr (!MQ_WQ_SPLIT) __builtin_amdgcn_sched_barrier(0);
           }
 #if MQ_WQ_SPLIT
 #pragma unroll
