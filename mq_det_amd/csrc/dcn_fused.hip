@@ -139,8 +139,25 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   tile -= g.first_tile[bi];
   const DcnFParams p = g.br[bi];
   const int n_pos = p.Ho * p.Wo;
-  const int b = tile / (p.tiles_x * p.tiles_y), trem = tile % (p.tiles_x * p.tiles_y);
-  const int ho0 = (trem / p.tiles_x) * DCN_PH, wo0 = (trem % p.tiles_x) * DCN_PW;
+  // RASTER tiles (tiles_y == 0, the default since GPU call 18 of round 6): tile t of an image = output positions [128 t, 128 t + 128) in row-major
+  // order -- only the last tile of an image is partly empty.  8 x 16 patches (MQ_DCN_RASTER=0) round BOTH extents up: 13 x 11 patches for the
+  // 100 x 168 level (9 % empty rows), 7 x 6 for 50 x 84 (28 %), 4 x 3 for 25 x 42 (46 %) -- 15 % of the rows of a DyConv layer's launch at the
+  // bench shape were computed and thrown away.
+  const bool raster = p.tiles_y == 0;
+  const int tpi = raster ? p.tiles_x : p.tiles_x * p.tiles_y;
+  const int b = tile / tpi, trem = tile % tpi;
+  const int ho0 = raster ? 0 : (trem / p.tiles_x) * DCN_PH, wo0 = raster ? 0 : (trem % p.tiles_x) * DCN_PW;
+  const int p0 = trem * BM;                                  // raster: first position of the tile
+  // (ho, wo) of tile row `row`; false: the row is outside the image
+  auto row_pos = [&](int row, int& ho, int& wo) -> bool {
+    if (raster) {
+      const int pp = p0 + row;
+      ho = pp / p.Wo; wo = pp - ho * p.Wo;
+      return pp < n_pos;
+    }
+    ho = ho0 + row / DCN_PW; wo = wo0 + row % DCN_PW;
+    return ho < p.Ho && wo < p.Wo;
+  };
   const int K = 9 * p.C;
   const int nslice = p.C / BK;
   const int ksteps = 9 * nslice;                             // k-step ks = (slice ks / 9, tap ks % 9)
@@ -154,8 +171,16 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   constexpr int DCN_WARM = 1, WARM_N = 4096 / NTH;
   unsigned warm[WARM_N];
   {
-    const int fh = (DCN_PH - 1) * p.stride + 3 + 2 * DCN_WARM, fw = (DCN_PW - 1) * p.stride + 3 + 2 * DCN_WARM;
-    const int h_lo = ho0 * p.stride - 1 - DCN_WARM, w_lo = wo0 * p.stride - 1 - DCN_WARM;
+    int fh = (DCN_PH - 1) * p.stride + 3 + 2 * DCN_WARM, fw = (DCN_PW - 1) * p.stride + 3 + 2 * DCN_WARM;
+    int h_lo = ho0 * p.stride - 1 - DCN_WARM, w_lo = wo0 * p.stride - 1 - DCN_WARM;
+    if (raster) {
+      // rows of the tile's first .. last position; one row: its column range, several: the full width (the neighbours' tiles need the rest)
+      const int pl = min(p0 + BM, n_pos) - 1;
+      const int hf = p0 / p.Wo, hl = pl / p.Wo;
+      h_lo = hf * p.stride - 1 - DCN_WARM; fh = (hl - hf) * p.stride + 3 + 2 * DCN_WARM;
+      if (hf == hl) { w_lo = (p0 - hf * p.Wo) * p.stride - 1 - DCN_WARM; fw = (pl - p0) * p.stride + 3 + 2 * DCN_WARM; }
+      else { w_lo = 0; fw = p.W; }
+    }
     const int lpp = (p.C * (int)sizeof(half_t)) >> 7;        // 128-byte lines per pixel
     const int nlines = fh * fw * lpp;
     const char* xw = (const char*)(p.x + (long)b * p.x_bs);
@@ -182,8 +207,8 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
     for (int i = 0; i < NTASK; ++i) {
       const int t = min(tid + i * NTH, BM * 9 - 1);
       const int row = t / 9, tap = t - row * 9;
-      const int ho = ho0 + row / DCN_PW, wo = wo0 + row % DCN_PW;
-      const int pos = (ho < p.Ho && wo < p.Wo) ? ho * p.Wo + wo : 0;
+      int ho, wo;
+      const int pos = row_pos(row, ho, wo) ? ho * p.Wo + wo : 0;
       dh[i] = omb[(long)(2 * tap) * n_pos + pos];
       dw[i] = omb[(long)(2 * tap + 1) * n_pos + pos];
       ml[i] = omb[(long)18 * p.oH * p.oW + (long)tap * n_pos + pos];
@@ -193,8 +218,8 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
       const int t = tid + i * NTH;
       if (t < BM * 9) {
         const int row = t / 9, tap = t - row * 9;
-        const int ho = ho0 + row / DCN_PW, wo = wo0 + row % DCN_PW;
-        const bool ok_row = ho < p.Ho && wo < p.Wo;
+        int ho, wo;
+        const bool ok_row = row_pos(row, ho, wo);
         const float mk = p.mask_prob ? ml[i] : 1.f / (1.f + __expf(-ml[i]));
         const float hf = (float)(ho * p.stride - 1 + tap / 3) + dh[i], wf = (float)(wo * p.stride - 1 + tap % 3) + dw[i];
         const bool inside = ok_row && hf > -1.f && wf > -1.f && hf < (float)p.H && wf < (float)p.W;
@@ -551,8 +576,8 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   __syncthreads();
   for (int c = tid; c < BM * (BN / 8); c += NTH) {
     const int row = c / (BN / 8), ch = c % (BN / 8);
-    const int ho = ho0 + row / DCN_PW, wo = wo0 + row % DCN_PW;
-    if (ho < p.Ho && wo < p.Wo)
+    int ho, wo;
+    if (row_pos(row, ho, wo))
       *(half8*)(p.out + ((long)b * n_pos + ho * p.Wo + wo) * p.out_ld + ch * 8) = *(const half8*)(Os + row * OS + ch * 8);
   }
   // ---- GroupNorm / scale-attention statistics of this patch (what mq_dyconv_stats would re-read y from HBM for):
@@ -567,8 +592,8 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
       const int row = rg * RPT + k;
-      const int ho = ho0 + row / DCN_PW, wo = wo0 + row % DCN_PW;
-      if (ho < p.Ho && wo < p.Wo) {
+      int ho, wo;
+      if (row_pos(row, ho, wo)) {
         const half8 v = *(const half8*)(Os + row * OS + chunk * 8);
         const float w = p.wy ? p.wy[ho] * p.wx[wo] : inv_n;
 #pragma unroll
@@ -599,7 +624,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
       float a = 0.f;
 #pragma unroll
       for (int g = 0; g < NW; ++g) a += red[(g * 32 + lc) * 24 + k];
-      p.stats[(((long)b * (p.tiles_x * p.tiles_y) + trem) * BN + lc * 8 + (k & 7)) * 3 + (k >> 3)] = a;
+      p.stats[(((long)b * tpi + trem) * BN + lc * 8 + (k & 7)) * 3 + (k >> 3)] = a;
     }
   }
 }
@@ -607,9 +632,16 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
 // DCNv2 3x3, pad 1, 256 output channels.  x [B,H,W,C] fp16 NHWC (batch stride x_bs, C % 128 == 0), om [B,27,oH,oW] fp32
 // (18 offsets + 9 mask logits -- or probabilities with flags bit 0 --, NCHW; flags bit 1: the caller promises all-zero offsets and mask 1, i.e. a plain conv), w [256, 9*C] fp16 (k = tap*C + c), bias [256] fp16 or NULL, out [B*Ho*Wo, out_ld];
 // stats (optional) [B, mq_dcnv2_stats_blocks(H, W, stride), 256, 3] fp32 with position weights wy [Ho] x wx [Wo] (or NULL).
+// tiles of 128 consecutive output positions (default) or 8 x 16 patches (MQ_DCN_RASTER=0, the A/B switch): one process-wide choice, read once --
+// the statistics buffers of the callers are sized by it
+static bool dcn_raster_tiles() {
+  static const bool r = [] { const char* e = getenv("MQ_DCN_RASTER"); return !(e && e[0] == '0'); }();
+  return r;
+}
 #ifdef MQ_PRIMARY_UNIT
 extern "C" int mq_dcnv2_stats_blocks(int H, int W, int stride) {
   const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  if (dcn_raster_tiles()) return (Ho * Wo + DCN_PH * DCN_PW - 1) / (DCN_PH * DCN_PW);
   return ((Ho + DCN_PH - 1) / DCN_PH) * ((Wo + DCN_PW - 1) / DCN_PW);
 }
 #endif
@@ -648,8 +680,13 @@ extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* 
     p.x_bs = a.x_bs; p.B = a.B; p.H = a.H; p.W = a.W; p.C = a.C; p.stride = a.stride; p.oH = a.oH; p.oW = a.oW; p.out_ld = a.out_ld; p.mask_prob = a.flags & 1;
     p.Ho = (a.H + 2 - 3) / a.stride + 1; p.Wo = (a.W + 2 - 3) / a.stride + 1;
     if ((long)p.Ho * p.Wo > (long)a.oH * a.oW) return -2;    // flat reads must stay inside the om buffer
-    p.tiles_y = (p.Ho + DCN_PH - 1) / DCN_PH; p.tiles_x = (p.Wo + DCN_PW - 1) / DCN_PW;
-    p.tiles_total = a.B * p.tiles_y * p.tiles_x;
+    if (dcn_raster_tiles()) {
+      p.tiles_y = 0; p.tiles_x = (p.Ho * p.Wo + DCN_PH * DCN_PW - 1) / (DCN_PH * DCN_PW);      // tiles_y == 0: raster tiles, tiles_x per image
+      p.tiles_total = a.B * p.tiles_x;
+    } else {
+      p.tiles_y = (p.Ho + DCN_PH - 1) / DCN_PH; p.tiles_x = (p.Wo + DCN_PW - 1) / DCN_PW;
+      p.tiles_total = a.B * p.tiles_y * p.tiles_x;
+    }
     g.first_tile[g.n + 1] = g.first_tile[g.n] + p.tiles_total;
     ++g.n;
   }
@@ -706,8 +743,14 @@ extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* 
     if (nt != 0 && nt != nb) return -5;
     if (nt) {
       constexpr int BW = MQ_DCN_SPLIT ? 8 : 16;               // waves of the shipped instantiation of this build
-      const int rc = (plain && plain_on) ? dcn_launch<BW, 1, true, true>(grid, smem, (hipStream_t)stream, g)
-                                         : dcn_launch<BW, 1, false, true>(grid, smem, (hipStream_t)stream, g);
+      int rc;
+#if !MQ_DCN_SPLIT
+      if (nw == 8)                                            // A/B switch MQ_DCN_WAVES=8: wave tiles of 64 x 64 (a third fewer fragment reads per k-step)
+        rc = (plain && plain_on) ? dcn_launch<8, 1, true, true>(grid, smem, (hipStream_t)stream, g) : dcn_launch<8, 1, false, true>(grid, smem, (hipStream_t)stream, g);
+      else
+#endif
+      rc = (plain && plain_on) ? dcn_launch<BW, 1, true, true>(grid, smem, (hipStream_t)stream, g)
+                               : dcn_launch<BW, 1, false, true>(grid, smem, (hipStream_t)stream, g);
       if (rc) return rc;
       MQ_CHECK_LAUNCH();
       return 0;
