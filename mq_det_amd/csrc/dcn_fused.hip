@@ -139,21 +139,35 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   tile -= g.first_tile[bi];
   const DcnFParams p = g.br[bi];
   const int n_pos = p.Ho * p.Wo;
-  // RASTER tiles (tiles_y == 0, the default since GPU call 18 of round 6): tile t of an image = output positions [128 t, 128 t + 128) in row-major
-  // order -- only the last tile of an image is partly empty.  8 x 16 patches (MQ_DCN_RASTER=0) round BOTH extents up: 13 x 11 patches for the
-  // 100 x 168 level (9 % empty rows), 7 x 6 for 50 x 84 (28 %), 4 x 3 for 25 x 42 (46 %) -- 15 % of the rows of a DyConv layer's launch at the
-  // bench shape were computed and thrown away.
+  // BANDED tiles (tiles_y == 0, the default since GPU call 20 of round 6).  8 x 16 patches (MQ_DCN_RASTER=0) round BOTH extents of a level up:
+  // 13 x 11 patches for the 100 x 168 level (9 % empty rows), 7 x 6 for 50 x 84 (28 %), 4 x 3 for 25 x 42 (46 %) -- 15 % of the rows of a DyConv
+  // layer's launch at the bench shape were computed and thrown away.  Now the output positions of an image are ORDERED band by band (bands of 8
+  // rows; the last band has Ho % 8), inside a band column by column, and tile t = positions [128 t, 128 t + 128) of that order: a tile is still an
+  // 8-row x 16-column patch (or the end of one band + the start of the next), so the input footprint and its L2 / L1 reuse stay those of a patch,
+  // and only the last tile of an image is partly empty.  (Plain row-major tiles -- GPU call 18 -- have no empty rows either, but a 128-position
+  // strip of one row touches 2 x the input lines of a patch: 7 % MORE time per k-step, the launch no faster.)
   const bool raster = p.tiles_y == 0;
   const int tpi = raster ? p.tiles_x : p.tiles_x * p.tiles_y;
   const int b = tile / tpi, trem = tile % tpi;
   const int ho0 = raster ? 0 : (trem / p.tiles_x) * DCN_PH, wo0 = raster ? 0 : (trem % p.tiles_x) * DCN_PW;
-  const int p0 = trem * BM;                                  // raster: first position of the tile
+  const int p0 = trem * BM;                                  // banded: first position (in band order) of the tile
+  const int full = (p.Ho / DCN_PH) * DCN_PH * p.Wo;          // positions in the full bands
+  const int hlast = max(p.Ho % DCN_PH, 1);                   // rows of the last, partial band
+  // band order: position q -> (ho, wo)
+  auto band_pos = [&](int q, int& ho, int& wo) {
+    if (q < full) {
+      const int band = q / (DCN_PH * p.Wo), r = q - band * (DCN_PH * p.Wo);
+      ho = band * DCN_PH + (r & (DCN_PH - 1)); wo = r / DCN_PH;
+    } else {
+      const int r = q - full;
+      wo = r / hlast; ho = (p.Ho / DCN_PH) * DCN_PH + (r - wo * hlast);
+    }
+  };
   // (ho, wo) of tile row `row`; false: the row is outside the image
   auto row_pos = [&](int row, int& ho, int& wo) -> bool {
     if (raster) {
-      const int pp = p0 + row;
-      ho = pp / p.Wo; wo = pp - ho * p.Wo;
-      return pp < n_pos;
+      band_pos(min(p0 + row, n_pos - 1), ho, wo);
+      return p0 + row < n_pos;
     }
     ho = ho0 + row / DCN_PW; wo = wo0 + row % DCN_PW;
     return ho < p.Ho && wo < p.Wo;
@@ -171,26 +185,36 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
   constexpr int DCN_WARM = 1, WARM_N = 4096 / NTH;
   unsigned warm[WARM_N];
   {
+    // footprint: one rectangle for a patch; banded tiles: the piece in the first band [+ the piece in the last band, if the tile crosses]
     int fh = (DCN_PH - 1) * p.stride + 3 + 2 * DCN_WARM, fw = (DCN_PW - 1) * p.stride + 3 + 2 * DCN_WARM;
     int h_lo = ho0 * p.stride - 1 - DCN_WARM, w_lo = wo0 * p.stride - 1 - DCN_WARM;
+    int fh2 = 0, fw2 = 1, h_lo2 = 0, w_lo2 = 0;
     if (raster) {
-      // rows of the tile's first .. last position; one row: its column range, several: the full width (the neighbours' tiles need the rest)
-      const int pl = min(p0 + BM, n_pos) - 1;
-      const int hf = p0 / p.Wo, hl = pl / p.Wo;
-      h_lo = hf * p.stride - 1 - DCN_WARM; fh = (hl - hf) * p.stride + 3 + 2 * DCN_WARM;
-      if (hf == hl) { w_lo = (p0 - hf * p.Wo) * p.stride - 1 - DCN_WARM; fw = (pl - p0) * p.stride + 3 + 2 * DCN_WARM; }
-      else { w_lo = 0; fw = p.W; }
+      int ha, wa, hb, wb;
+      band_pos(p0, ha, wa);
+      band_pos(min(p0 + BM, n_pos) - 1, hb, wb);
+      const int ba = ha / DCN_PH, bb = hb / DCN_PH;                        // bands of the first / last position
+      const int ra = min(DCN_PH, p.Ho - ba * DCN_PH), rb = min(DCN_PH, p.Ho - bb * DCN_PH);
+      h_lo = ba * DCN_PH * p.stride - 1 - DCN_WARM; fh = (ra - 1) * p.stride + 3 + 2 * DCN_WARM;
+      w_lo = wa * p.stride - 1 - DCN_WARM;
+      fw = ((ba == bb ? wb : p.Wo - 1) - wa) * p.stride + 3 + 2 * DCN_WARM;
+      if (ba != bb) {
+        h_lo2 = bb * DCN_PH * p.stride - 1 - DCN_WARM; fh2 = (rb - 1) * p.stride + 3 + 2 * DCN_WARM;
+        w_lo2 = -1 - DCN_WARM; fw2 = wb * p.stride + 3 + 2 * DCN_WARM;
+      }
     }
     const int lpp = (p.C * (int)sizeof(half_t)) >> 7;        // 128-byte lines per pixel
-    const int nlines = fh * fw * lpp;
+    const int nl1 = fh * fw * lpp, nlines = nl1 + fh2 * fw2 * lpp;
     const char* xw = (const char*)(p.x + (long)b * p.x_bs);
 #pragma unroll
     for (int i = 0; i < WARM_N; ++i) {
       warm[i] = 0;
       const int idx = tid + i * NTH;
       if (idx < nlines) {
-        const int px = idx / lpp, ln = idx - px * lpp;
-        const int hh = min(max(h_lo + px / fw, 0), p.H - 1), ww = min(max(w_lo + px % fw, 0), p.W - 1);
+        const bool second = idx >= nl1;
+        const int id2 = second ? idx - nl1 : idx, fwx = second ? fw2 : fw;
+        const int px = id2 / lpp, ln = id2 - px * lpp;
+        const int hh = min(max((second ? h_lo2 : h_lo) + px / fwx, 0), p.H - 1), ww = min(max((second ? w_lo2 : w_lo) + px % fwx, 0), p.W - 1);
         const char* a = xw + ((long)(hh * p.W + ww) * p.C * (long)sizeof(half_t) + ln * 128);
         asm volatile("global_load_dword %0, %1, off" : "=v"(warm[i]) : "v"(a) : "memory");
       }
@@ -632,7 +656,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
 // DCNv2 3x3, pad 1, 256 output channels.  x [B,H,W,C] fp16 NHWC (batch stride x_bs, C % 128 == 0), om [B,27,oH,oW] fp32
 // (18 offsets + 9 mask logits -- or probabilities with flags bit 0 --, NCHW; flags bit 1: the caller promises all-zero offsets and mask 1, i.e. a plain conv), w [256, 9*C] fp16 (k = tap*C + c), bias [256] fp16 or NULL, out [B*Ho*Wo, out_ld];
 // stats (optional) [B, mq_dcnv2_stats_blocks(H, W, stride), 256, 3] fp32 with position weights wy [Ho] x wx [Wo] (or NULL).
-// tiles of 128 consecutive output positions (default) or 8 x 16 patches (MQ_DCN_RASTER=0, the A/B switch): one process-wide choice, read once --
+// tiles of 128 consecutive output positions in band order (default) or 8 x 16 patches (MQ_DCN_RASTER=0, the A/B switch): one process-wide choice, read once --
 // the statistics buffers of the callers are sized by it
 static bool dcn_raster_tiles() {
   static const bool r = [] { const char* e = getenv("MQ_DCN_RASTER"); return !(e && e[0] == '0'); }();

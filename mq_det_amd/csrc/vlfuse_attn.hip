@@ -523,8 +523,19 @@ struct T2IParams {
 namespace { constexpr int WS_LD = VD + 4; }               // 260 floats: rows stay 16-byte aligned
 
 // ABL: ablation timings as for vlfuse_i2t_kernel (bit 0 no tile loads, 1 no LDS commits, 2 no softmax arithmetic, 3 no fragment reads / MFMAs)
-template <int QB, bool KM, int ABL = 0>
+// TDMA (round 6, 16-bit builds): the key / value tiles go global -> LDS by LDS-DMA (`buffer_load ... lds`, csrc/common.h) instead of through a
+// register ring: no tile registers, no ds_write, no register wait in front of the commit.  The tile rows are PADDED in LDS (pitch 272 halfs), a
+// copy piece is 1 KB of consecutive LDS bytes: lane l of piece c writes LDS chunk g = 64 c + l, i.e. (row g / 34, position g % 34) -- positions
+// 32, 33 are the padding (they fetch the row's chunk 0; nobody reads them).  Rows past the image come back as zeros (buffer range check; the
+// keys are masked by position anyway).  Tile pos + 1 is requested at the top of step pos into the buffer step pos - 1 read, and has the whole
+// step to land.  The two buffers are handed to the loop as __restrict__ pointers (vl_scoped_tiles): without alias scopes hipcc makes every
+// LDS read behind the copy wait for it.
+template <class T, class F>
+__device__ __forceinline__ void vl_scoped_tiles(T* __restrict__ b0, T* __restrict__ b1, F f) { f(b0, b1); }
+
+template <int QB, bool KM, int ABL = 0, bool TDMA = false>
 __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p) {
+  static_assert(!TDMA || (!MQ_VL_SPLIT && ABL == 0), "the LDS-copied tiles are the 16-bit builds' (the split-precise planes are computed while staging)");
   constexpr int NTH = 2048 / (QB * 4), WR = 16 * QB;        // threads per workgroup (512 / 256), query rows per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* tiles = (half_t*)smem;                           // [2][TK][KS]
@@ -579,8 +590,27 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
   // (profiles/r03_call8_microbench_vlfuse.json) takes a third off the launch when the tile loads are removed -- but a third slot
   // (RS = 3) changed nothing (0.3202 vs 0.3218 ms, GPU call 9): it is the L2 -> CU ingest of 32 KB per tile and workgroup, not its
   // latency, that the loads cost.  Two slots.
-  constexpr int RS = MQ_VL_SPLIT ? 1 : 2;                  // (split-precise: one slot -- a tile's fp32 chunks are twice the registers)
-  TileRegs<NTH> slot[RS];
+  constexpr int RS = TDMA ? 0 : MQ_VL_SPLIT ? 1 : 2;       // (split-precise: one slot -- a tile's fp32 chunks are twice the registers)
+  TileRegs<NTH> slot[RS > 0 ? RS : 1];
+  // TDMA: pieces of a tile and this lane's source offsets (bytes inside a tile of 64 rows x 512 B)
+  constexpr int NWV = NTH / 64, NPC = TK * KS * (int)sizeof(half_t) / 1024, PR = (NPC + NWV - 1) / NWV;
+  static_assert(TK * KS * sizeof(half_t) % 1024 == 0, "a tile is a whole number of 1 KB pieces");
+  int leoff[PR];
+#pragma unroll
+  for (int i = 0; i < PR; ++i) {
+    const int gch = (wv + i * NWV) * 64 + lane, row = gch / (KS / 8), posn = gch % (KS / 8);
+    leoff[i] = (row * VD + (posn < VD / 8 ? posn : 0) * 8) * (int)sizeof(half_t);
+  }
+  const mq_rsrc v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, p.N * VD * (int)sizeof(half_t), 0x00020000);
+  auto dma_tile = [&](int pos, half_t* buf) __attribute__((always_inline)) {
+    const int t = t0 + min(pos, max(nt - 1, 0));
+    const int soff = __builtin_amdgcn_readfirstlane(t * TK * VD * (int)sizeof(half_t));
+#pragma unroll
+    for (int i = 0; i < PR; ++i) {
+      const int piece = wv + i * NWV;
+      if (piece < NPC) lds_stage_16b_buf(v_rsrc, soff, leoff[i], buf + piece * 512);
+    }
+  };
   if constexpr (ABL != 0) {
 #pragma unroll
     for (int r = 0; r < RS; ++r)
@@ -594,12 +624,13 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
   };
   const float cl = p.clamp > 0.f ? p.clamp : 3.0e38f;
   constexpr float THR = 8.0f;     // deferred rescale: O / l are rescaled only when a row max grows by more than THR
-  auto body = [&](auto PAR, auto SL, int pos) {            // PAR = pos % 2 (LDS buffer), SL = pos % RS (ring slot that held tile pos)
-    constexpr int par = decltype(PAR)::value, sl = decltype(SL)::value;
-    issue(SL, pos + RS);                                   // the slot of tile pos was committed one step ago
+  auto body = [&](auto PAR, auto SL, int pos, half_t* cur, half_t* nxt) __attribute__((always_inline)) {   // PAR = pos % 2 (LDS buffer cur), SL = pos % RS (ring slot that held tile pos)
+    constexpr int sl = decltype(SL)::value;
+    if constexpr (TDMA) dma_tile(pos + 1, nxt);            // nxt was read in step pos - 1: free since that step's barrier
+    else issue(SL, pos + RS);                              // the slot of tile pos was committed one step ago
     __builtin_amdgcn_sched_barrier(0);
     if (pos < nt && wave_live) {
-      const half_t* tile = tiles + par * TILE;
+      const half_t* tile = cur;
       float4_ s[4][QB];
       if constexpr (!(ABL & 8)) qk_tile<false, QB>(tile, qf, nullptr, s, l15, lg);
       else {
@@ -672,9 +703,21 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!(ABL & 2)) tile_commit(slot[(sl + 1) % RS], tiles + (par ^ 1) * TILE, tid);
+    if constexpr (TDMA) __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), as an instruction hipcc's wait-count pass books: the copy has landed
+    else if constexpr (!(ABL & 2)) tile_commit(slot[(sl + 1) % (RS > 0 ? RS : 1)], nxt, tid);
     __syncthreads();
   };
+  if constexpr (TDMA) {
+    dma_tile(0, tiles);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    vl_scoped_tiles(tiles, tiles + TILE, [&](half_t* b0, half_t* b1) __attribute__((always_inline)) {
+      for (int pos = 0; pos < nt; pos += 2) {
+        body(S0{}, S0{}, pos, b0, b1);
+        if (pos + 1 < nt) body(S1{}, S0{}, pos + 1, b1, b0);             // workgroup-uniform: every wave runs the same number of steps
+      }
+    });
+  } else {
   issue(S0{}, 0);
   if constexpr (RS >= 2) issue(S1{}, 1);
   if constexpr (RS == 3) issue(std::integral_constant<int, 2>{}, 2);
@@ -686,10 +729,11 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
     static_for_u<U>([&](auto uc) __attribute__((always_inline)) {
       constexpr int u = decltype(uc)::value;
       if (!done) {
-        body(std::integral_constant<int, u & 1>{}, std::integral_constant<int, u % RS>{}, pos + u);
+        body(std::integral_constant<int, u & 1>{}, std::integral_constant<int, u % (RS > 0 ? RS : 1)>{}, pos + u, tiles + (u & 1) * TILE, tiles + ((u & 1) ^ 1) * TILE);
         done = pos + u + 1 >= nt;                          // workgroup-uniform: every wave runs the same number of steps
       }
     });
+  }
   }
 
   // ---- partials -> workspace (O^T: lane owns 4 consecutive d of one query row -> one 16-byte store)
@@ -772,6 +816,8 @@ extern "C" int MQ_SYM(mq_vlfuse_t2i_fwd)(const void* kf, const void* v_ln, const
     if (e != hipSuccess) return (int)e;
     attr_set.done();
   }
+  static const bool t2i_dma = [] { const char* e = getenv("MQ_VL_T2I_DMA"); return e && e[0] == '1'; }();   // A/B switch: tiles by LDS-DMA
+  (void)t2i_dma;
   const int rows = (kv_len && max_kv > 0) ? min(max_kv, T) : T;          // host-known bound of the live text rows
   const int groups = B * nsplit, members = (heads * ((rows + p.wr - 1) / p.wr) + (128 / p.wr) - 1) / (128 / p.wr);
   p.members = members;
@@ -797,6 +843,17 @@ extern "C" int MQ_SYM(mq_vlfuse_t2i_fwd)(const void* kf, const void* v_ln, const
 #endif
   if (vlfuse_qb() == 1) {
     if (key_mask) hipLaunchKernelGGL((vlfuse_t2i_kernel<1, true>), grid, dim3(512), smem, (hipStream_t)stream, p);
+#if !MQ_VL_SPLIT
+    else if (t2i_dma && (long)N * VD * (long)sizeof(half_t) < (1l << 31)) {
+      static MqOncePerDevice attr_dma;
+      if (attr_dma.first()) {
+        hipError_t e = hipFuncSetAttribute((const void*)vlfuse_t2i_kernel<1, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_dma.done();
+      }
+      hipLaunchKernelGGL((vlfuse_t2i_kernel<1, false, 0, true>), grid, dim3(512), smem, (hipStream_t)stream, p);
+    }
+#endif
     else hipLaunchKernelGGL((vlfuse_t2i_kernel<1, false>), grid, dim3(512), smem, (hipStream_t)stream, p);
   } else {
     if (key_mask) hipLaunchKernelGGL((vlfuse_t2i_kernel<2, true>), grid, dim3(256), smem, (hipStream_t)stream, p);

@@ -419,12 +419,18 @@ inline void simt_global_load_lds(const void* g, void* lds, unsigned size) { memc
 // (the size argument must be a literal in the product source -- hipcc crashes on sizeof(half8) there --, so the fp32-operand build,
 // whose "16-bit" fragments are twice as wide, scales it here)
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) simt_global_load_lds((const void*)(g), (void*)(l), (unsigned)(size))
-// raw buffer resource (base pointer only: the kernels use stride 0 and never rely on the range check) and the MUBUF form of the LDS copy
-struct simt_buffer_rsrc { const char* base; };
+// raw buffer resource (stride 0: base + byte range) and the MUBUF form of the LDS copy; a lane whose bytes are not inside [0, num) gets zeros,
+// as the hardware's range check returns them
+struct simt_buffer_rsrc { const char* base; unsigned num; };
 typedef simt_buffer_rsrc __amdgpu_buffer_rsrc_t;
-#define __builtin_amdgcn_make_buffer_rsrc(p, stride, num, flags) (simt_buffer_rsrc{(const char*)(p)})
+#define __builtin_amdgcn_make_buffer_rsrc(p, stride, num, flags) (simt_buffer_rsrc{(const char*)(p), (unsigned)(num)})
+inline void simt_buffer_load_lds(simt_buffer_rsrc r, void* lds, unsigned size, unsigned off) {
+  char* dst = (char*)lds + (size_t)simt::lane() * size;
+  if ((unsigned long long)off + size <= r.num) memcpy(dst, r.base + off, size);
+  else memset(dst, 0, size);
+}
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds(r, l, size, voff, soff, imm, aux) \
-  simt_global_load_lds((r).base + (size_t)(voff) + (size_t)(soff) + (size_t)(imm), (void*)(l), (unsigned)(size))
+  simt_buffer_load_lds((r), (void*)(l), (unsigned)(size), (unsigned)(voff) + (unsigned)(soff) + (unsigned)(imm))
 inline float simt_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 #define __builtin_amdgcn_fmed3f(a, b, c) simt_fmed3f((a), (b), (c))
 #define __builtin_amdgcn_s_barrier() simt::block_sync()
