@@ -194,7 +194,9 @@ int mq_swin_mlp2_fwd(const float* x, const void* delta, const void* ln_g, const 
  *   argument of the reference operator -- no sigmoid is applied then), indexed flat by the output
  *   dims like the reference kernel (the buffer may come from another pyramid level); N must be 256.  With stats != NULL it
  *   also emits the GroupNorm / scale-attention statistics of its output (layout of mq_dyconv_stats with
- *   mq_dcnv2_stats_blocks(H, W, stride) blocks per image; wy [Ho], wx [Wo] position weights or NULL for 1/(Ho*Wo)).
+ *   mq_dcnv2_stats_blocks(H, W, stride) blocks per image -- one per tile of 128 output positions: ceil(Ho * Wo / 128) since round 6 (tiles are
+ *   consecutive positions in band order; with MQ_DCN_RASTER=0 in the environment: ceil(Ho / 8) * ceil(Wo / 16) patches as before); wy [Ho],
+ *   wx [Wo] position weights or NULL for 1/(Ho*Wo)).
  * mq_dcnv2_fwd replaces _C.modulated_deform_conv_forward (maskrcnn_benchmark/csrc/vision.cpp:11-12,
  *   csrc/cuda/deform_conv_cuda.cu:496-575, deform_conv_kernel_cuda.cu:578-640) without the im2col buffer;
  * mq_conv3x3_fwd replaces the nn.Conv2d 3x3 calls of backbone/fpn.py:41,141-146 and the DyConv offset conv

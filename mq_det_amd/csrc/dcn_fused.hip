@@ -100,6 +100,14 @@ typedef half8 dcn_gvec;
 //     the loop becomes vmcnt(0) / lgkmcnt(0));
 //   * group 1's loop behind __restrict__ tile pointers (dcn_scoped_tiles): without alias scopes every LDS read after a copy waits for the copy;
 //   * the end-of-step wait as __builtin_amdgcn_s_waitcnt, which the pass books, not as an asm string.
+// dynamic LDS of the kernel without the row table behind it: max(tiles + sampling state, O staging + statistics partials)
+constexpr size_t dcn_smem_main() {
+  constexpr size_t nbuf = (sizeof(half_t) == 4 && !MQ_DCN_SPLIT) ? 1 : 2;
+  constexpr size_t bk = MQ_DCN_SPLIT ? 32 : 64;
+  constexpr size_t tiles = (size_t)(nbuf * 128 * bk + nbuf * 256 * bk) * sizeof(half_t) + 128 * 9 * sizeof(TapState);
+  constexpr size_t ostage = (size_t)128 * (256 + 8) * sizeof(half_t) + (sizeof(half_t) == 4 ? 0 : (size_t)16 * 32 * 24 * sizeof(float));
+  return tiles > ostage ? tiles : ostage;
+}
 // the tiles of the two buffers and the sampling state as DISJOINT objects (alias scopes once inlined)
 template <class T, class S, class F>
 __device__ __forceinline__ void dcn_scoped_tiles(T* __restrict__ a0, T* __restrict__ a1, T* __restrict__ b0, T* __restrict__ b1, const S* __restrict__ ts, F f) {
@@ -163,11 +171,22 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
       wo = r / hlast; ho = (p.Ho / DCN_PH) * DCN_PH + (r - wo * hlast);
     }
   };
+  // the tile's 128 rows -> (ho << 16 | wo << 1 | inside), computed once (two runtime divisions per row; every later use is one LDS read)
+  int* rowtab = (int*)(smem + dcn_smem_main());
+  if (raster) {
+    if (tid < BM) {
+      int ho, wo;
+      band_pos(min(p0 + tid, n_pos - 1), ho, wo);
+      rowtab[tid] = (ho << 16) | (wo << 1) | (p0 + tid < n_pos ? 1 : 0);
+    }
+    __syncthreads();
+  }
   // (ho, wo) of tile row `row`; false: the row is outside the image
   auto row_pos = [&](int row, int& ho, int& wo) -> bool {
     if (raster) {
-      band_pos(min(p0 + row, n_pos - 1), ho, wo);
-      return p0 + row < n_pos;
+      const int v = rowtab[row];
+      ho = v >> 16; wo = (v >> 1) & 0x7fff;
+      return v & 1;
     }
     ho = ho0 + row / DCN_PW; wo = wo0 + row % DCN_PW;
     return ho < p.Ho && wo < p.Wo;
@@ -191,8 +210,8 @@ __global__ __launch_bounds__(64 * NW) void dcn_igemm8_kernel(DcnGroup g) {
     int fh2 = 0, fw2 = 1, h_lo2 = 0, w_lo2 = 0;
     if (raster) {
       int ha, wa, hb, wb;
-      band_pos(p0, ha, wa);
-      band_pos(min(p0 + BM, n_pos) - 1, hb, wb);
+      row_pos(0, ha, wa);
+      row_pos(min(BM, n_pos - p0) - 1, hb, wb);
       const int ba = ha / DCN_PH, bb = hb / DCN_PH;                        // bands of the first / last position
       const int ra = min(DCN_PH, p.Ho - ba * DCN_PH), rb = min(DCN_PH, p.Ho - bb * DCN_PH);
       h_lo = ba * DCN_PH * p.stride - 1 - DCN_WARM; fh = (ra - 1) * p.stride + 3 + 2 * DCN_WARM;
@@ -704,6 +723,7 @@ extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* 
     p.x_bs = a.x_bs; p.B = a.B; p.H = a.H; p.W = a.W; p.C = a.C; p.stride = a.stride; p.oH = a.oH; p.oW = a.oW; p.out_ld = a.out_ld; p.mask_prob = a.flags & 1;
     p.Ho = (a.H + 2 - 3) / a.stride + 1; p.Wo = (a.W + 2 - 3) / a.stride + 1;
     if ((long)p.Ho * p.Wo > (long)a.oH * a.oW) return -2;    // flat reads must stay inside the om buffer
+    if (p.Ho > 32767 || p.Wo > 32767) return -1;             // (ho, wo) of a tile row are packed into one int
     if (dcn_raster_tiles()) {
       p.tiles_y = 0; p.tiles_x = (p.Ho * p.Wo + DCN_PH * DCN_PW - 1) / (DCN_PH * DCN_PW);      // tiles_y == 0: raster tiles, tiles_x per image
       p.tiles_total = a.B * p.tiles_x;
@@ -716,11 +736,7 @@ extern "C" int MQ_SYM(mq_dcnv2_group_fwd)(const mq_dcn_branch* br, int n, void* 
   }
   if (g.n == 0) return 0;
   g.tiles_all = g.first_tile[g.n];
-  constexpr size_t nbuf = (sizeof(half_t) == 4 && !MQ_DCN_SPLIT) ? 1 : 2;
-  constexpr size_t bk = MQ_DCN_SPLIT ? 32 : 64;
-  constexpr size_t tiles = (size_t)(nbuf * 128 * bk + nbuf * 256 * bk) * sizeof(half_t) + 128 * 9 * sizeof(TapState);
-  constexpr size_t ostage = (size_t)128 * (256 + 8) * sizeof(half_t) + (sizeof(half_t) == 4 ? 0 : (size_t)16 * 32 * 24 * sizeof(float));
-  constexpr size_t smem = tiles > ostage ? tiles : ostage;
+  constexpr size_t smem = dcn_smem_main() + 128 * sizeof(int);             // + the (ho, wo) table of the tile's rows
   static MqOncePerDevice attr_set;
   if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute((const void*)dcn_igemm8_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -926,6 +926,29 @@ def dcn_weight_tiles(w):
     return out
 
 
+def dcn_weight_rows(wt):
+    """Inverse of dcn_weight_tiles: LDS-tile order -> row-major [256, 9 C] (k = tap * C + c).  16-bit dtypes: exact; float32 (the split-precise
+    planes): hi + lo / 2^11, the value the kernel multiplies with.  Used by the torch-level emulation of the tests and for inspection."""
+    N, K = wt.shape
+    C = K // 9
+    assert N == 256 and K == 9 * C and C % 128 == 0
+    if wt.dtype == torch.float32:
+        planes = wt.contiguous().view(torch.float16).reshape(-1, 2, 256, 32)                        # [ks][hi | lo][row][32]
+        blk = planes[:, 0].float() + planes[:, 1].float() / 2048.0
+        return blk.view(C // 32, 9, 256, 32).permute(2, 1, 0, 3).reshape(256, K).contiguous()
+    blk = wt.contiguous().view(-1, 256, 8, 8)                                                      # [ks][row][position][8]
+    r = torch.arange(256, device=wt.device)[:, None]
+    pos = torch.arange(8, device=wt.device)[None, :]
+    chunk = torch.gather(blk, 2, (pos ^ (r & 7))[None, :, :, None].expand(blk.shape[0], -1, -1, 8))   # chunk c sits at position c ^ (r & 7)
+    return chunk.view(C // 64, 9, 256, 8, 8).permute(2, 1, 0, 3, 4).reshape(256, K).contiguous()
+
+
+def dcn_is_tiled(w):
+    """Is `w` a tensor dcn_weight_tiles returned (recognised by identity)?"""
+    ref = _DCN_TILED.get(id(w))
+    return ref is not None and ref() is w
+
+
 def dcn_bdma():
     """Does the active selection stream the DCNv2 weights by LDS-DMA?  KERNELS["DCN_BDMA"]: 1 always (default), 0 never, -1 in the split-precise mode only."""
     k = KERNELS.get("DCN_BDMA", 1)

@@ -427,6 +427,9 @@ def conv3x3_nchw32_group(levels, w_packed, bias, n_out):
 
 
 def dcnv2(x_nhwc, om, w_packed, bias, stride, want_stats=False, wy=None, wx=None, mask_prob=False, tag=None, plain=False):
+    from mq_det_amd import ops as _real
+    if _real.dcn_is_tiled(w_packed):                 # the plan's LDS-tile-ordered copy (KERNELS["DCN_BDMA"]): back to rows for the torch form
+        w_packed = _real.dcn_weight_rows(w_packed)
     cols, hw = _dcn_cols(x_nhwc.contiguous(), om, stride)
     y = F.linear(cols.float(), w_packed.float(), bias.float()).to(x_nhwc.dtype)
     if not want_stats:
