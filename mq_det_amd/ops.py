@@ -751,7 +751,7 @@ def swin_mlp2(x, delta, ln_g, ln_b, eps, w1f, b1, w2f, b2, next_ln=None, flags=N
     """Fused Swin MLP half, second generation (mq_swin_mlp2_fwd): arguments as swin_mlp but (w1f, w2f) = swin_mlp2_pack(fc1.weight,
     fc2.weight); flags (default KERNELS["SWIN_MLP2_FLAGS"]): bit 1 = table GELU in the main kernel, bit 0 = no pass / tail split, bit 2 =
     every block through the tail kernel, bit 3 / bit 4 = only the main-kernel / only the tail blocks (`into` = (out, y) of an earlier call:
-    the other part's rows are already there); negative = the measured choice per width (profiles/r03_call3_microbench_swin_mlp.json)."""
+    the other part's rows are already there); negative = the measured choice per width (profiles/r06_call22_microbench_swin_mlp.json)."""
     lib = load_library()
     _need_gpu(x, delta, ln_g, ln_b, w1f, b1, w2f, b2)
     C = x.shape[-1]
@@ -766,10 +766,14 @@ def swin_mlp2(x, delta, ln_g, ln_b, eps, w1f, b1, w2f, b2, next_ln=None, flags=N
         ng, nb, ne = next_ln
         y = torch.empty(x.shape, dtype=w1f.dtype, device=x.device) if into is None else into[1]
     flags = KERNELS["SWIN_MLP2_FLAGS"] if flags is None else int(flags)
-    if flags < 0:
-        flags = 0 if C == 192 else 2          # table GELU except at C = 192 (profiles/r03_call5_microbench_swin_mlp.json)
+    auto = flags < 0
+    if auto:
+        # table GELU at every width, one pass (no pass / tail split) below C = 384 -- re-measured on the kernels with counted waits (GPU call 22 of
+        # round 6, profiles/r06_call22_microbench_swin_mlp.json: C = 96 0.253 ms unsplit / 0.269 split (erf 0.306), C = 192 0.186 / 0.193 (erf, the
+        # default since round 3: 0.214), C = 384 0.158 split / 0.207 unsplit)
+        flags = 3 if C < 384 else 2
     if f32_operands():
-        flags &= ~2           # precise mode: the erf GELU (|error| <= 1.5e-7), not the interpolation table (7e-6)
+        flags = 0 if auto else flags & ~2     # precise mode: the erf GELU (|error| <= 1.5e-7), not the interpolation table (7e-6); pass / tail split as measured there
     # (round 5's precise mode sent C = 384 through the tail kernel: two stages of both fp32 weight rings were 196 KB.  The split-precise kernel keeps ONE
     # W2 stage at that width -- 150 KB -- and four waves per workgroup: csrc/swin_mlp2.hip W2ONE.)
     fn = _fn(lib, "mq_swin_mlp2_fwd", w1f)

@@ -18,7 +18,7 @@ KERNEL_DEFAULTS = {
     "ATTN_RESIDENT": 1,          # 1: mq_attn_resident_fwd / mq_attn_chunked_fwd (S^T form, keys resident / 256-key chunks)       +4.7 %
     "SWIN_MLP_VARIANT": 2,       # 2: mq_swin_mlp2_fwd (fragment-major weights, 3-deep software pipeline, 14-VALU GELU); 1: the library path (LayerNorm
                                  # kernel + GEMM + GELU + GEMM); the first-generation kernel mq_swin_mlp_fwd is gone (round 5)
-    "SWIN_MLP2_FLAGS": -1,       # mq_swin_mlp2_fwd flags: -1 = per width (table GELU at C = 96 / 384, erf at 192; tail split on); else bit 1 = table
+    "SWIN_MLP2_FLAGS": -1,       # mq_swin_mlp2_fwd flags: -1 = per width (table GELU everywhere, one pass below C = 384: GPU call 22 of round 6; precise mode: erf, split); else bit 1 = table
                                  # GELU, bit 0 = no tail split, bit 2 = everything through the tail kernel
     "SWIN_QKV_FUSED": 2,         # the Swin qkv projection inside the window attention (mq_window_attn_qkv_fwd): 1 = at C = 96 (0.372 -> 0.137 ms
                                  # per block), 2 = also at C = 192 (weights streamed per head: 0.20 -> 0.137), 0 = GEMM + mq_window_attn_fwd
