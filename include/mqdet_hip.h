@@ -104,9 +104,13 @@ int mq_gcp_gate_residual_fwd(const void* sup, const void* h, const void* w2, con
  *   bmm with values_l, out_v_proj, and the gamma_v residual of BiAttentionBlock
  *   (maskrcnn_benchmark/utils/fuse_helper.py:221-279,290-300,424; heads = 8), and the same branch of MQ-GroundingDINO's
  *   feature-enhancer fusion (groundingdino_new/models/GroundingDINO/fuse_modules.py:146-249,286-296; heads = 4). */
-int mq_vlfuse_i2t_fwd(const void* v_ln, const void* kf, const void* vo, const float* bias, const int* kv_len,
+int mq_vlfuse_i2t_fwd(const void* v_ln, const void* kf, const void* vo, long kv_bs, long kv_hs, long kv_ts, const float* bias, const int* kv_len,
                       const void* out_bias, void* out, int B, int N, int T, int heads, int max_kv, float clamp, int variant,
                       void* stream);
+/* kv_bs / kv_hs / kv_ts (ABI 30): element strides of kf AND vo over (batch item, head, text token) -- element (b, h, t, :) is read at
+ *   b * kv_bs + h * kv_hs + t * kv_ts, 256 consecutive elements; all three 0: a contiguous [B,heads,T,256] tensor.  The caller of the
+ *   fusion layer passes views of the ONE projection GEMM's output [B, T, heads*256 | heads*256 | ...] (kv_hs = 256, kv_ts = its row
+ *   length): no `permute().contiguous()` copies of the folded keys / values.  Strides and both pointers must be multiples of 16 bytes. */
 /* variant: 0 = default; 1 = Q tile in LDS for every caption longer than 128 tokens (A/B: by default 129 .. 160 keys keep the Q fragments
  *   in registers); >= 100: ablation timings of tools/microbench.py (results undefined). */
 
@@ -122,9 +126,10 @@ int mq_vlfuse_i2t_fwd(const void* v_ln, const void* kf, const void* vo, const fl
  *   bmm with values_v (fuse_helper.py:246-262,281-288); values_v_proj / out_l_proj are applied to the result by the
  *   caller as one folded [768, 2048] weight. */
 long mq_vlfuse_t2i_workspace_bytes(int B, int T, int nsplit);
-int mq_vlfuse_t2i_fwd(const void* kf, const void* v_ln, const int* kv_len, const unsigned char* key_mask, long key_mask_bs,
-                      void* workspace, void* out, int B, int N, int T, int heads, int nsplit, int max_kv, float clamp, int variant,
+int mq_vlfuse_t2i_fwd(const void* kf, long kv_bs, long kv_hs, long kv_ts, const void* v_ln, const int* kv_len, const unsigned char* key_mask,
+                      long key_mask_bs, void* workspace, void* out, int B, int N, int T, int heads, int nsplit, int max_kv, float clamp, int variant,
                       void* stream);
+/* kv_bs / kv_hs / kv_ts: element strides of kf as for mq_vlfuse_i2t_fwd (0, 0, 0: contiguous). */
 /* max_kv: host-side upper bound of kv_len (0 = T): sizes the grid -- the live (head, 16-row block) units of an image are packed
  *   densely over the waves of its workgroups.  variant: 0 (values >= 100: ablation timings of tools/microbench.py, results undefined). */
 

@@ -57,8 +57,9 @@ using S1 = std::integral_constant<int, 1>;
 
 struct I2TParams {
   const half_t* v;        // [B, N, 256] LN(v): queries and residual
-  const half_t* kf;       // [B, 8, T, 256] folded text keys
-  const half_t* vo;       // [B, 8, T, 256] folded text values
+  const half_t* kf;       // [B, 8, T, 256] folded text keys    } element (b, h, t, :) at b * kv_bs + h * kv_hs + t * kv_ts (elements): a contiguous
+  const half_t* vo;       // [B, 8, T, 256] folded text values  } [B, 8, T, 256] tensor or a view of the projection GEMM's [B, T, 8 x 256 | ...] output
+  long kv_bs, kv_hs, kv_ts;
   const float* bias;      // [B, 8, T] additive logit bias; <= -1e29 marks a masked key
   const int* kv_len;      // [B] or nullptr: keys >= kv_len[b] are masked
   const half_t* obias;    // [256]
@@ -87,12 +88,12 @@ __device__ __forceinline__ void static_for_u(F f) { static_for_u_impl<0, N>(f); 
 // NCH: chunk rounds to do -- round i covers tile rows [i * NTH / 32, (i + 1) * NTH / 32): a tile whose tail rows nobody reads
 // (the last key / value tile of a caption that ends inside it) is staged only as far as it is read
 template <int NTH, int NCH = 2048 / NTH>
-__device__ __forceinline__ void tile_issue(TileRegs<NTH>& t, const half_t* src, int row0, int last_row, int tid) {
+__device__ __forceinline__ void tile_issue(TileRegs<NTH>& t, const half_t* src, int row0, int last_row, int tid, int ld = VD) {
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = tid + i * NTH;
     const int row = min(row0 + (c >> 5), last_row);
-    t.r[i] = *(const half8*)(src + (long)row * VD + (c & 31) * 8);
+    t.r[i] = *(const half8*)(src + (row * ld + (c & 31) * 8));           // ld: row pitch of the source in elements (a tile's rows: < 2^31)
   }
 }
 template <int NTH, int NCH = 2048 / NTH>
@@ -283,8 +284,8 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_i2t_kernel(I2TParams p
     constexpr int sl = decltype(SLOT)::value, np = decltype(NP)::value;
     u = min(u, U - 1);                                     // the tail re-loads the last tile: one code path, no branches
     const int h = u / PER_HEAD, j = u % PER_HEAD;
-    const half_t* src = (j < NT ? p.kf : p.vo) + ((long)b * p.H + h) * p.T * VD;
-    if constexpr (!(ABL & 1)) tile_issue<NTH, rounds_of(np)>(slot[sl], src, (j < NT ? j : j - NT) * TK, p.T - 1, tid);
+    const half_t* src = (j < NT ? p.kf : p.vo) + (long)b * p.kv_bs + (long)h * p.kv_hs;
+    if constexpr (!(ABL & 1)) tile_issue<NTH, rounds_of(np)>(slot[sl], src, (j < NT ? j : j - NT) * TK, p.T - 1, tid, (int)p.kv_ts);
   };
   // begin(pos): prefetch;  end(pos): commit the next tile into the other LDS buffer + barrier
   auto begin = [&](auto POS, int u) {
@@ -462,12 +463,16 @@ static int vlfuse_qb() {
 
 // Image side of VLFuse.  max_kv: host-known upper bound of kv_len (T if unknown) -- picks the number of 64-key tiles
 // kept in registers.  See include/mqdet_hip.h.
-extern "C" int MQ_SYM(mq_vlfuse_i2t_fwd)(const void* v_ln, const void* kf, const void* vo, const float* bias, const int* kv_len,
-                                 const void* out_bias, void* out, int B, int N, int T, int heads, int max_kv, float clamp,
+extern "C" int MQ_SYM(mq_vlfuse_i2t_fwd)(const void* v_ln, const void* kf, const void* vo, long kv_bs, long kv_hs, long kv_ts, const float* bias,
+                                 const int* kv_len, const void* out_bias, void* out, int B, int N, int T, int heads, int max_kv, float clamp,
                                  int variant, void* stream) {
   if (B <= 0 || N <= 0) return 0;
   if (T < 1 || T > 256 || heads < 1 || heads > VH) return -1;
+  if (kv_bs <= 0 && kv_hs <= 0 && kv_ts <= 0) { kv_ts = VD; kv_hs = (long)T * VD; kv_bs = (long)heads * T * VD; }      // 0, 0, 0: contiguous
+  constexpr long CH16 = 16 / (long)sizeof(half_t);                        // 16-byte chunks: every row start must be one
+  if (kv_ts < VD || kv_ts * 256 >= (1l << 31) || (kv_bs | kv_hs | kv_ts) % CH16 || ((size_t)kf | (size_t)vo) % 16) return -6;
   I2TParams p;
+  p.kv_bs = kv_bs; p.kv_hs = kv_hs; p.kv_ts = kv_ts;
   p.v = (const half_t*)v_ln; p.kf = (const half_t*)kf; p.vo = (const half_t*)vo; p.bias = bias; p.kv_len = kv_len;
   p.obias = (const half_t*)out_bias; p.out = (half_t*)out; p.B = B; p.N = N; p.T = T; p.H = heads; p.clamp = clamp;
   const int kv = (kv_len && max_kv > 0) ? min(max_kv, T) : T;
@@ -507,7 +512,8 @@ extern "C" int MQ_SYM(mq_vlfuse_i2t_fwd)(const void* v_ln, const void* kf, const
 
 // ------------------------------------------------------------------------------------------------ text side
 struct T2IParams {
-  const half_t* kf;       // [B, 8, T, 256] queries = folded text keys
+  const half_t* kf;       // [B, 8, T, 256] queries = folded text keys; element (b, h, t, :) at b * kv_bs + h * kv_hs + t * kv_ts
+  long kv_bs, kv_hs, kv_ts;
   const half_t* v;        // [B, N, 256] LN(v): keys AND values
   float* ws;              // [nsplit][B*8][T][WS_LD] fp32 partials: O (un-normalised), then m, l
   half_t* out;            // [B, T, 8*256]
@@ -569,12 +575,12 @@ __global__ __launch_bounds__(2048 / (QB * 4)) void vlfuse_t2i_kernel(T2IParams p
   const int nt = max(t1 - t0, 0);
 
   vfrag qf[QB][8];
-  const half_t* qb_ = p.kf + ((long)b * p.H + h) * p.T * VD;
+  const half_t* qb_ = p.kf + (long)b * p.kv_bs + (long)h * p.kv_hs;
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int row = min(row0 + qb * 16 + l15, p.T - 1);
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = vl_frag(*(const half8*)(qb_ + (long)row * VD + kk * 32 + lg * 8));
+    for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = vl_frag(*(const half8*)(qb_ + (row * (int)p.kv_ts + kk * 32 + lg * 8)));
   }
   float4_ o[16][QB];
 #pragma unroll
@@ -795,15 +801,19 @@ extern "C" long mq_vlfuse_t2i_workspace_bytes(int B, int T, int nsplit) {
 #endif
 
 // Text side of VLFuse (always through the split workspace + combine, nsplit >= 1).  See include/mqdet_hip.h.
-extern "C" int MQ_SYM(mq_vlfuse_t2i_fwd)(const void* kf, const void* v_ln, const int* kv_len, const unsigned char* key_mask, long key_mask_bs,
+extern "C" int MQ_SYM(mq_vlfuse_t2i_fwd)(const void* kf, long kv_bs, long kv_hs, long kv_ts, const void* v_ln, const int* kv_len,
+                                 const unsigned char* key_mask, long key_mask_bs,
                                  void* workspace, void* out, int B, int N, int T, int heads, int nsplit, int max_kv, float clamp,
                                  int variant, void* stream) {
   if (B <= 0 || T <= 0) return 0;
   if (N < 1 || workspace == nullptr || heads < 1 || heads > VH) return -1;
+  if (kv_bs <= 0 && kv_hs <= 0 && kv_ts <= 0) { kv_ts = VD; kv_hs = (long)T * VD; kv_bs = (long)heads * T * VD; }      // 0, 0, 0: contiguous
+  if (kv_ts < VD || kv_ts * 256 >= (1l << 31) || (kv_bs | kv_hs | kv_ts) % (16 / (long)sizeof(half_t)) || (size_t)kf % 16) return -6;
   if (key_mask && ((key_mask_bs % 4) || key_mask_bs < (long)((N + TK - 1) / TK) * TK)) return -3;
   if (nsplit < 1) nsplit = 1;
   T2IParams p;
   p.kf = (const half_t*)kf; p.v = (const half_t*)v_ln; p.ws = (float*)workspace; p.out = (half_t*)out; p.kv_len = kv_len;
+  p.kv_bs = kv_bs; p.kv_hs = kv_hs; p.kv_ts = kv_ts;
   p.B = B; p.N = N; p.T = T; p.H = heads; p.nsplit = nsplit; p.clamp = clamp; p.wr = 16 * vlfuse_qb();
   p.kmask = key_mask; p.kmask_bs = key_mask_bs;
   constexpr size_t smem = (size_t)2 * TILE * sizeof(half_t);

@@ -299,8 +299,8 @@ def fusion_layer(P, b, mem32, text32, geo, txt, max_kv=0):
     hd = 256
     pr = _lin(P, b + ".tprep", l16)
     n = Hf * hd
-    kf = pr[..., :n].reshape(B, T, Hf, hd).permute(0, 2, 1, 3).contiguous()
-    vo = pr[..., n:2 * n].reshape(B, T, Hf, hd).permute(0, 2, 1, 3).contiguous()
+    kf = pr[..., :n].unflatten(-1, (Hf, hd)).permute(0, 2, 1, 3)             # views of the projection output: the kernels take the strides
+    vo = pr[..., n:2 * n].unflatten(-1, (Hf, hd)).permute(0, 2, 1, 3)
     bias = (pr[..., 2 * n:2 * n + Hf].float().permute(0, 2, 1) + txt["key_bias"][:, None, :]).contiguous()
     img = ops.vlfuse_i2t(v_ln, kf, vo, bias, P[b + ".ov.bias"], txt["kv_len"], max_kv)
     N = v_ln.shape[1]

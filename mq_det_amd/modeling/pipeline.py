@@ -657,8 +657,10 @@ def vl_text_prep(P, b, hidden, key_bias, hidden32=None):
     T = l_ln.shape[1]
     C = P[b + ".Wq8"].shape[2]
     t = _lin(P, b + ".tprep", l_ln)                                                       # [B, T, 8*C | 8*C | 8 | pad]
-    kf = t[..., :8 * C].reshape(Bn, T, 8, C).permute(0, 2, 1, 3).contiguous()           # [B, 8, T, 256] folded keys
-    vo = t[..., 8 * C:16 * C].reshape(Bn, T, 8, C).permute(0, 2, 1, 3).contiguous()     # [B, 8, T, 256] folded values
+    # [B, 8, T, 256] folded keys / values as VIEWS of the projection output (head stride 256, token stride = its row length): the VLFuse kernels
+    # take the strides (ABI 30) -- round 5 made two permute().contiguous() copies per layer, 12 of the 13 layout copies of a step
+    kf = t[..., :8 * C].unflatten(-1, (8, C)).permute(0, 2, 1, 3)
+    vo = t[..., 8 * C:16 * C].unflatten(-1, (8, C)).permute(0, 2, 1, 3)
     bias = (t[..., 16 * C:16 * C + 8].float().permute(0, 2, 1) + key_bias[:, None, :]).contiguous()   # [B, 8, T] fp32
     return {"l_ln": l_ln, "l_res": l_res, "kf": kf, "vo": vo, "bias": bias}
 

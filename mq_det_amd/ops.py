@@ -13,7 +13,7 @@ _LIB = None
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmqdet_hip.so")
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
-EXPECTED_ABI = 29        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
+EXPECTED_ABI = 30        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
 _SIGNATURES = {
     "mq_abi_version": (_i, []),
     "mq_attn_workspace_bytes": (_l, [_i, _i, _i, _i, _i]),
@@ -28,9 +28,9 @@ _SIGNATURES = {
     "mq_gcp_sparse_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mq_gcp_gate_residual_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _l, _i, _i, _vp]),
     "mq_gcp_attn_fwd": (_i, [_vp] * 16 + [_l, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
-    "mq_vlfuse_i2t_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "mq_vlfuse_i2t_fwd": (_i, [_vp, _vp, _vp, _l, _l, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "mq_vlfuse_t2i_workspace_bytes": (_l, [_i, _i, _i]),
-    "mq_vlfuse_t2i_fwd": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "mq_vlfuse_t2i_fwd": (_i, [_vp, _l, _l, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "mq_layernorm_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
     "mq_layernorm2_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
     "mq_layernorm_clamp_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _f, _vp]),
@@ -570,8 +570,19 @@ def gcp_gate_residual(sup, h, w2, x, want_gate=False):
     return (out, gate) if want_gate else out
 
 
+def _kv_strides(kf, vo=None):
+    """Element strides (batch, head, token) of the folded keys / values: contiguous [B,heads,T,256] tensors or equally strided views of one
+    projection output (pipeline.vl_text_prep); rows of 256 consecutive elements, everything a multiple of 16 bytes."""
+    st = kf.stride()
+    unit = 16 // kf.element_size()
+    assert st[3] == 1 and st[2] >= 256 and all(x % unit == 0 for x in st[:3]) and kf.data_ptr() % 16 == 0, st
+    if vo is not None:
+        assert vo.stride() == st and vo.data_ptr() % 16 == 0, (vo.stride(), st)
+    return int(st[0]), int(st[1]), int(st[2])
+
+
 def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.0, variant=None):
-    """VLFuse image side (mq_vlfuse_i2t_fwd).  v_ln [B,N,256], kf / vo [B,heads,T,256] fp16 (heads <= 8), bias [B,heads,T] fp32 or None,
+    """VLFuse image side (mq_vlfuse_i2t_fwd).  v_ln [B,N,256], kf / vo [B,heads,T,256] fp16 (heads <= 8; contiguous or equally strided views, _kv_strides), bias [B,heads,T] fp32 or None,
     out_bias [256] fp16, kv_len [B] int32 or None (max_kv: host-side upper bound, 0 = T) -> [B,N,256] fp16:
     v_ln + out_bias + sum_h softmax_t(clamp(v_ln.kf_h + bias_h)) vo_h."""
     lib = load_library()
@@ -579,7 +590,8 @@ def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.
     B, N, C = v_ln.shape
     Hh, T = kf.shape[1], kf.shape[2]
     assert C == 256 and kf.shape == (B, Hh, T, 256) and vo.shape == kf.shape and T <= 256 and 1 <= Hh <= 8
-    assert v_ln.is_contiguous() and kf.is_contiguous() and vo.is_contiguous() and out_bias.is_contiguous()
+    assert v_ln.is_contiguous() and out_bias.is_contiguous()
+    kv_bs, kv_hs, kv_ts = _kv_strides(kf, vo)
     assert v_ln.dtype == kf.dtype == vo.dtype == out_bias.dtype and v_ln.dtype in _H16
     if bias is not None:
         assert bias.shape == (B, Hh, T) and bias.dtype == torch.float32 and bias.is_contiguous()
@@ -593,7 +605,7 @@ def vlfuse_i2t(v_ln, kf, vo, bias, out_bias, kv_len=None, max_kv=0, clamp=50000.
     if f32_operands():
         variant = 0           # split-precise mode: Q fragments always in registers
     with _timed(f"vlfuse_i2t_n{N}_t{T}"):
-        _chk(_fn(lib, "mq_vlfuse_i2t_fwd", v_ln)(_ptr(v_ln), _ptr(kf), _ptr(vo), _ptr(bias), _ptr(kv_len), _ptr(out_bias), _ptr(out),
+        _chk(_fn(lib, "mq_vlfuse_i2t_fwd", v_ln)(_ptr(v_ln), _ptr(kf), _ptr(vo), kv_bs, kv_hs, kv_ts, _ptr(bias), _ptr(kv_len), _ptr(out_bias), _ptr(out),
                                    B, N, T, Hh, int(max_kv), float(clamp), int(variant),
                                    _stream()), "mq_vlfuse_i2t_fwd")
     return out
@@ -608,7 +620,8 @@ def vlfuse_t2i(kf, v_ln, nsplit, clamp=50000.0, kv_len=None, key_mask=None, max_
     _need_gpu(kf, v_ln, key_mask)
     B, N, C = v_ln.shape
     Hh, T = kf.shape[1], kf.shape[2]
-    assert C == 256 and kf.shape == (B, Hh, T, 256) and kf.is_contiguous() and v_ln.is_contiguous() and 1 <= Hh <= 8
+    assert C == 256 and kf.shape == (B, Hh, T, 256) and v_ln.is_contiguous() and 1 <= Hh <= 8
+    kv_bs, kv_hs, kv_ts = _kv_strides(kf)
     km_bs = 0
     if key_mask is not None:
         assert key_mask.dtype == torch.uint8 and key_mask.dim() == 2 and key_mask.shape[0] == B and key_mask.stride(1) == 1
@@ -623,7 +636,7 @@ def vlfuse_t2i(kf, v_ln, nsplit, clamp=50000.0, kv_len=None, key_mask=None, max_
     ws = torch.empty(lib.mq_vlfuse_t2i_workspace_bytes(B, T, nsplit) // 4, dtype=torch.float32, device=kf.device)
     out = torch.empty(B, T, Hh * 256, dtype=kf.dtype, device=kf.device)
     with _timed(f"vlfuse_t2i_n{N}_t{T}_s{nsplit}"):
-        _chk(_fn(lib, "mq_vlfuse_t2i_fwd", kf)(_ptr(kf), _ptr(v_ln), _ptr(kv_len), _ptr(key_mask), km_bs, _ptr(ws), _ptr(out), B, N, T, Hh,
+        _chk(_fn(lib, "mq_vlfuse_t2i_fwd", kf)(_ptr(kf), kv_bs, kv_hs, kv_ts, _ptr(v_ln), _ptr(kv_len), _ptr(key_mask), km_bs, _ptr(ws), _ptr(out), B, N, T, Hh,
                                    nsplit, int(max_kv), float(clamp), int(variant), _stream()), "mq_vlfuse_t2i_fwd")
     return out
 

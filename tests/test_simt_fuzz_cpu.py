@@ -110,6 +110,13 @@ def test_vlfuse_random_shapes(ops):
         v_ln = torch.randn(B, N, 256, generator=g).half()
         kf = (torch.randn(B, Hh, T, 256, generator=g) / 8).half()
         vo = torch.randn(B, Hh, T, 256, generator=g).half()
+        if it % 2:                                       # the pipeline's operands: views of ONE projection output [B, T, heads*256 | heads*256 | 16]
+            pr = torch.zeros(B, T, 2 * Hh * 256 + 16, dtype=torch.float16)
+            pr[..., :Hh * 256] = kf.permute(0, 2, 1, 3).reshape(B, T, -1)
+            pr[..., Hh * 256:2 * Hh * 256] = vo.permute(0, 2, 1, 3).reshape(B, T, -1)
+            kf = pr[..., :Hh * 256].unflatten(-1, (Hh, 256)).permute(0, 2, 1, 3)
+            vo = pr[..., Hh * 256:2 * Hh * 256].unflatten(-1, (Hh, 256)).permute(0, 2, 1, 3)
+            assert not kf.is_contiguous()
         bias = torch.randn(B, Hh, T, generator=g)
         if kv is not None:
             for b in range(B):
