@@ -356,9 +356,14 @@ def swin_forward(P, cfg, img, p="backbone.body", SW=None):
                 y = torch.cat([y[:, 0::2, 0::2], y[:, 1::2, 0::2], y[:, 0::2, 1::2], y[:, 1::2, 1::2]], -1)
                 H, W = (H + 1) // 2, (W + 1) // 2
                 yn = _ln(P, d + ".norm", y.reshape(B, H * W, 4 * C))
-            x = F.linear(yn, P[d + ".reduction.weight"])
-            if r32:
-                x = x.float()
+            wr = P[d + ".reduction.weight"]
+            if r32 and yn.is_cuda and yn.dtype != torch.float32 and os.environ.get("MQ_SWIN_RED_F32OUT") == "1":
+                # A/B switch (GPU calls 26 / 27 of round 6): the reduction GEMM writing the fp32 residual stream itself instead of fp16 + a cast pass
+                x = torch.mm(yn.reshape(-1, yn.shape[-1]), wr.t(), out_dtype=torch.float32).view(B, H * W, wr.shape[0])
+            else:
+                x = F.linear(yn, wr)
+                if r32:
+                    x = x.float()
     return outs
 
 

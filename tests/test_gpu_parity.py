@@ -34,6 +34,31 @@ def _assert(res):
                               for r in bad)
 
 
+def test_vlfuse_strided_operands_equal_contiguous(dev):
+    """ABI 30: the VLFuse kernels read the folded keys / values through element strides.  The views the fusion layer passes (slices of ONE
+    projection output [B, T, heads*256 | heads*256 | pad]) must give bit for bit what contiguous [B, heads, T, 256] copies give -- same
+    arithmetic, other addresses -- at the benchmark geometry's caption length and at a short one."""
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(30)
+    for B, Hh, N, T, kv in ((2, 8, 2000, 144, (141, 97)), (1, 4, 777, 48, None)):
+        pr = (torch.randn(B, T, 2 * Hh * 256 + 16, generator=g) / 8).half().to(dev)
+        kf_v = pr[..., :Hh * 256].unflatten(-1, (Hh, 256)).permute(0, 2, 1, 3)
+        vo_v = pr[..., Hh * 256:2 * Hh * 256].unflatten(-1, (Hh, 256)).permute(0, 2, 1, 3)
+        assert not kf_v.is_contiguous()
+        kf_c, vo_c = kf_v.contiguous(), vo_v.contiguous()
+        v_ln = torch.randn(B, N, 256, generator=g).half().to(dev)
+        bias = torch.randn(B, Hh, T, generator=g).to(dev)
+        ob = torch.randn(256, generator=g).half().to(dev)
+        kv_len = None if kv is None else torch.tensor(kv, dtype=torch.int32, device=dev)
+        mk = 0 if kv is None else max(kv)
+        a = ops.vlfuse_i2t(v_ln, kf_v, vo_v, bias, ob, kv_len=kv_len, max_kv=mk)
+        b = ops.vlfuse_i2t(v_ln, kf_c, vo_c, bias, ob, kv_len=kv_len, max_kv=mk)
+        assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
+        a = ops.vlfuse_t2i(kf_v, v_ln, 3, kv_len=kv_len, max_kv=mk)
+        b = ops.vlfuse_t2i(kf_c, v_ln, 3, kv_len=kv_len, max_kv=mk)
+        assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
+
+
 ATTN = [
     dict(B=2, H=12, D=64, Nq=256, Nk=256, mask=True),
     dict(B=2, H=12, D=64, Nq=256, Nk=256, mask=True, clamp=50000.0, big=True),

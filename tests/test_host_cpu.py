@@ -472,6 +472,33 @@ def test_ctypes_signatures_match_header():
         assert res == {"int": ctypes.c_int, "long": ctypes.c_long}[ret], name
 
 
+def test_dcn_tile_order_round_trip_and_kv_strides():
+    """ops.dcn_weight_rows inverts ops.dcn_weight_tiles (the LDS-tile order of the DCNv2 weights: exact for 16-bit dtypes, hi + lo / 2^11 for the
+    split-precise planes); ops._kv_strides accepts the views the fusion layer passes to the VLFuse kernels and refuses what the kernels cannot read."""
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for dt in (torch.float16, torch.bfloat16, torch.float32):
+        for C in (128, 256):
+            w = (torch.randn(256, 9 * C, generator=g) / 48).to(dt)
+            t = ops.dcn_weight_tiles(w)
+            assert t.shape == w.shape and t.dtype == w.dtype and ops.dcn_is_tiled(t) and not ops.dcn_is_tiled(w)
+            back = ops.dcn_weight_rows(t)
+            if dt == torch.float32:
+                assert float((back - w).abs().max()) <= 2.0 ** -21 * float(w.abs().max())
+            else:
+                assert torch.equal(back, w)
+    B, T, Hh = 2, 24, 8
+    pr = torch.zeros(B, T, 2 * Hh * 256 + 16, dtype=torch.float16)
+    kf = pr[..., :Hh * 256].unflatten(-1, (Hh, 256)).permute(0, 2, 1, 3)
+    vo = pr[..., Hh * 256:2 * Hh * 256].unflatten(-1, (Hh, 256)).permute(0, 2, 1, 3)
+    assert ops._kv_strides(kf, vo) == (T * pr.shape[-1], 256, pr.shape[-1])
+    assert ops._kv_strides(kf.contiguous()) == (Hh * T * 256, T * 256, 256)
+    with pytest.raises(AssertionError):
+        ops._kv_strides(kf, vo.contiguous())                           # keys and values must share their strides
+    with pytest.raises(AssertionError):
+        ops._kv_strides(pr[..., 4:Hh * 256 + 4].unflatten(-1, (Hh, 256)).permute(0, 2, 1, 3))        # rows must start on 16 bytes
+
+
 def _isa_of(src, extra=()):
     import subprocess, tempfile
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
