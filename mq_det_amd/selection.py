@@ -34,7 +34,9 @@ KERNEL_DEFAULTS = {
     "DYCONV_EPILOGUE_GROUPED": 1,  # 1: mq_dyconv_epilogue_group -- the fuse pass and the DYReLU coefficients of ALL levels of a DyConv layer in two launches
                                  # on the main stream (were 10 launches on five streams behind a fork / join); equal results.  A/B of round 5
                                  # (GPU call 1, 3 alternations x 60 steps): 439.2 / 440.8 / 437.8 against 433.7 / 439.1 / 435.0 images/s: +0.8 %, default
-    "BERT_CLAMP_FUSED": 0,       # (A/B of round 5, GPU call 1: 430.3 / 436.3 / 433.9 against 433.7 / 439.1 / 435.0 images/s -- three of three LOWER: stays off)
+    "BERT_CLAMP_FUSED": 1,       # (round 5, GPU call 1: 0.6 % slower, three of three, and call 11 of round 6 again: off until the end of round 6.  On the final
+                                 # step -- GPU call 28 -- a tie: 503.0 against 502.8 images/s over three alternations; on since: 36 torch launches per step
+                                 # fewer, the torch-native share of an eager step 9.4 -> see profiles/r06_call29_per_step_summary.txt)
                                  # 1: the +-50000 clamps of the fusion-layer BERT copies inside the kernels around them (mq_clamp_gelu_clamp: clamp -> GELU
                                  # -> clamp in one pass; mq_layernorm_clamp_fwd: clamp of the dense output, LayerNorm, clamp of both outputs): 7 torch
                                  # launches per layer -> 1, equal results; 0: torch.clamp / F.gelu passes
