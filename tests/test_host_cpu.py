@@ -499,6 +499,52 @@ def test_dcn_tile_order_round_trip_and_kv_strides():
         ops._kv_strides(pr[..., 4:Hh * 256 + 4].unflatten(-1, (Hh, 256)).permute(0, 2, 1, 3))        # rows must start on 16 bytes
 
 
+def test_per_step_kernel_stats_removes_what_runs_once(tmp_path, capsys):
+    """tools/per_step_kernel_stats.py: two `--stats` tables that differ only in the number of timed steps -> per-step calls / microseconds; a
+    kernel that runs once per process (the model build's cast kernels) drops out, and the families add up."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import per_step_kernel_stats as ps
+
+    def table(path, steps):
+        rows = [("void dcn_igemm8_kernel<16>(DcnGroup)", 6 * steps, 500e3 * 6 * steps),
+                ("Cijk_Alik_Bljk_HHS_BH", 10 * steps, 20e3 * 10 * steps),
+                ("void at::native::vectorized_elementwise_kernel<4, at::native::float16_copy_kernel_cuda>", 900 + 3 * steps, 3e3 * (900 + 3 * steps)),
+                ("__amd_rocclr_copyBuffer", 640, 640 * 4e3)]
+        with open(path, "w") as f:
+            f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
+            for n, c, t in rows:
+                f.write(f"\"{n}\",{c},{t},{t / c},0,0,0,0\n")
+    a, b, out = tmp_path / "a.csv", tmp_path / "b.csv", tmp_path / "o.csv"
+    table(a, 4)
+    table(b, 24)
+    sys.argv = ["per_step_kernel_stats.py", str(a), "4", str(b), "24", str(out)]
+    ps.main()
+    text = capsys.readouterr().out
+    assert "in 19 launches" in text and "rocclr" in text
+    import csv
+    rows = {r["Name"]: r for r in csv.DictReader(open(out))}
+    assert "__amd_rocclr_copyBuffer" not in rows                                        # ran 640 times in both runs: not part of a step
+    assert float(rows["void dcn_igemm8_kernel<16>(DcnGroup)"]["CallsPerStep"]) == 6.0
+    assert abs(float(rows["void dcn_igemm8_kernel<16>(DcnGroup)"]["UsPerStep"]) - 3000.0) < 1e-6
+    cast = [r for n, r in rows.items() if "float16_copy" in n][0]
+    assert float(cast["CallsPerStep"]) == 3.0 and abs(float(cast["UsPerStep"]) - 9.0) < 1e-6
+
+
+def test_isa_loop_waits_reads_the_swin_mlp_loop():
+    """tools/isa_loop_waits.py on the Swin MLP kernel: the histogram of the MFMA loops has counted LDS waits (the state of rounds 3-5 -- every wait
+    lgkmcnt(0) behind a FLAT-encoded LDS copy -- would show here first) and the sequence view marks the copies."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_loop_waits as il
+    txt = il.isa("swin_mlp2.hip")
+    kern = dict(il.kernels(txt))
+    name = [n for n in kern if n.startswith("void swin_mlp2_kernel<384, 8, true>")][0]
+    nm, lg, vm = il.histogram(kern[name])
+    assert nm >= 96 and sum(lg.values()) >= 40
+    assert lg[0] <= sum(lg.values()) // 5, (lg[0], sum(lg.values()))                      # counted waits dominate
+    seq = il.sequence(kern[name])
+    assert " D " in seq and " M " in seq and "|B|" in seq
+
+
 def _isa_of(src, extra=()):
     import subprocess, tempfile
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
