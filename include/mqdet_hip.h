@@ -230,6 +230,10 @@ typedef struct mq_conv_level {
   const void* x; float* out; long x_bs; int H, W;
 } mq_conv_level;
 int mq_conv3x3_nchw32_group_fwd(const mq_conv_level* levels, int nl, const void* w, const void* bias, int B, int C, int N, void* stream);
+/* Pooled FPN tokens the GCP pre-select attends to (generalized_vl_rcnn_new.py:291-293: `torch.cat([F.avg_pool2d(f, 2) ... tokens], 1)`) in ONE
+ * launch (ABI 31): levels[i].x = NHWC 16-bit [B,H,W,C] (batch stride x_bs elements; `out` unused), out [B, sum_l (H_l/2)*(W_l/2), C] 16-bit:
+ * token (l, y, x) = mean of the 2 x 2 window (floor sizes), fp32 sum in row-major window order, one rounding -- what ATen's NHWC pool returns. */
+int mq_pool2x2_tokens_fwd(const mq_conv_level* levels, int nl, void* out, int B, int C, void* stream);
 int mq_dcnv2_stats_blocks(int H, int W, int stride);
 /* One launch for up to 16 DCNv2 calls (the 13 branches of one DyConv layer): `branches` is a HOST array, copied into the
  * kernel arguments; fields as the arguments of mq_dcnv2_fwd.  The tiles of all branches form one work list, so small
@@ -519,6 +523,7 @@ MQ_BF16_TWIN(mq_dyrelu_coef)
 MQ_BF16_TWIN(mq_dyconv_epilogue_group)
 MQ_BF16_TWIN(mq_dyrelu_apply)
 MQ_BF16_TWIN(mq_add_upsample_nearest)
+MQ_BF16_TWIN(mq_pool2x2_tokens_fwd)
 MQ_BF16_TWIN(mq_dyrelu_ln_fwd)
 MQ_BF16_TWIN(mq_align_scores_fwd)
 MQ_BF16_TWIN(mq_align_fused_fwd)
@@ -581,6 +586,7 @@ MQ_F32_TWIN(mq_dyconv_epilogue_group)
 MQ_F32_TWIN(mq_dyrelu_apply)
 MQ_F32_TWIN(mq_dyrelu_ln_fwd)
 MQ_F32_TWIN(mq_add_upsample_nearest)
+MQ_F32_TWIN(mq_pool2x2_tokens_fwd)
 MQ_F32_TWIN(mq_align_scores_fwd)
 MQ_F32_TWIN(mq_align_fused_fwd)
 MQ_F32_TWIN(mq_box_decode)

@@ -599,4 +599,57 @@ extern "C" int MQ_SYM(mq_add_upsample_nearest)(void* dst, const void* src, int B
   return 0;
 }
 
+// ---- pooled FPN tokens of the GCP pre-select (generalized_vl_rcnn_new.py:291-293): torch.cat([F.avg_pool2d(f, 2) tokens of every level], 1).
+// out[b, first[l] + y * (W_l / 2) + x, :] = mean of the 2 x 2 window of level l (floor sizes: a last odd row / column is dropped), summed in
+// fp32 in the window's row-major order and rounded once, like ATen's NHWC average pool.  One launch instead of five pools + a concat.
+struct PoolLevels {
+  const half_t* x[8];
+  long x_bs[8];
+  int H[8], W[8], first[9];          // first[l]: first output token of level l; first[n]: tokens per image
+  int n;
+};
+__global__ __launch_bounds__(256) void pool2x2_tokens_kernel(PoolLevels g, half_t* __restrict__ out, int C) {
+  const int b = blockIdx.y, cpt = C / 8;
+  const long total = (long)g.first[g.n] * cpt;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ch = (int)(i % cpt), tok = (int)(i / cpt);
+    int l = 0;
+    while (l + 1 < g.n && tok >= g.first[l + 1]) ++l;
+    const int t = tok - g.first[l], w2 = g.W[l] >> 1;
+    const int y = t / w2, x = t - y * w2;
+    const half_t* p = g.x[l] + (long)b * g.x_bs[l] + ((long)(2 * y) * g.W[l] + 2 * x) * C + ch * 8;
+    const half8 a = *(const half8*)p, c = *(const half8*)(p + C);
+    const half8 d = *(const half8*)(p + (long)g.W[l] * C), e = *(const half8*)(p + (long)g.W[l] * C + C);
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)((((float)a[j] + (float)c[j]) + (float)d[j] + (float)e[j]) * 0.25f);
+    *(half8*)(out + ((long)b * g.first[g.n] + tok) * C + ch * 8) = o;
+  }
+}
+
+struct mq_conv_level {          // mirrors include/mqdet_hip.h (as in conv_small3.hip)
+  const void* x; float* out; long x_bs; int H, W;
+};
+
+extern "C" int MQ_SYM(mq_pool2x2_tokens_fwd)(const mq_conv_level* levels, int nl, void* out, int B, int C, void* stream) {
+  if (B <= 0 || nl <= 0) return 0;
+  if (nl > 8 || C % 8) return -1;
+  PoolLevels g;
+  g.n = 0;
+  g.first[0] = 0;
+  for (int i = 0; i < nl; ++i) {
+    const int h2 = levels[i].H / 2, w2 = levels[i].W / 2;
+    if (h2 <= 0 || w2 <= 0) continue;                       // a level smaller than the window has no tokens (avg_pool2d would refuse it)
+    g.x[g.n] = (const half_t*)levels[i].x; g.x_bs[g.n] = levels[i].x_bs; g.H[g.n] = levels[i].H; g.W[g.n] = levels[i].W;
+    g.first[g.n + 1] = g.first[g.n] + h2 * w2;
+    ++g.n;
+  }
+  if (g.n == 0) return 0;
+  long blocks = ((long)g.first[g.n] * (C / 8) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pool2x2_tokens_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, (hipStream_t)stream, g, (half_t*)out, C);
+  MQ_CHECK_LAUNCH();
+  return 0;
+}
+
 MQ_NAMESPACE_END

@@ -13,7 +13,7 @@ _LIB = None
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmqdet_hip.so")
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
-EXPECTED_ABI = 30        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
+EXPECTED_ABI = 31        # mq_abi_version() of the csrc/ revision the argument lists below were written for (csrc/api.hip)
 _SIGNATURES = {
     "mq_abi_version": (_i, []),
     "mq_attn_workspace_bytes": (_l, [_i, _i, _i, _i, _i]),
@@ -51,6 +51,7 @@ _SIGNATURES = {
     "mq_dyrelu_coef": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mq_dyconv_epilogue_group": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mq_add_upsample_nearest": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "mq_pool2x2_tokens_fwd": (_i, [_vp, _i, _vp, _i, _i, _vp]),
     "mq_dyrelu_ln_fwd": (_i, [_vp, _l, _vp, _vp, _i, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "mq_dyrelu_apply": (_i, [_vp, _vp, _i, _i, _i, _l, _vp]),
     "mq_align_scores_fwd": (_i, [_vp, _i, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _l, _i, _vp]),
@@ -70,7 +71,7 @@ _SIGNATURES = {
 # entry points with 16-bit operands also exist as <name>_bf16 (same signature; include/mqdet_hip.h MQ_BF16_TWIN)
 BF16_TWINS = ("mq_attn_fwd", "mq_attn_resident_fwd", "mq_attn_text_fwd", "mq_bert_attn_qkv_fwd", "mq_patch_embed_fwd", "mq_attn_chunked_fwd", "mq_window_attn_fwd", "mq_window_attn_qkv_fwd", "mq_gcp_sparse_attn_fwd", "mq_gcp_gate_residual_fwd", "mq_gcp_attn_fwd", "mq_vlfuse_i2t_fwd", "mq_vlfuse_t2i_fwd",
               "mq_layernorm_fwd", "mq_layernorm2_fwd", "mq_layernorm_clamp_fwd", "mq_clamp_gelu_clamp", "mq_patch_merge_ln_fwd", "mq_swin_mlp2_fwd", "mq_conv3x3_fwd", "mq_conv3x3_nchw32_fwd", "mq_conv3x3_nchw32_v2_fwd", "mq_conv3x3_nchw32_group_fwd", "mq_dcnv2_fwd", "mq_dcnv2_group_fwd",
-              "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyconv_epilogue_group", "mq_dyrelu_apply", "mq_dyrelu_ln_fwd", "mq_add_upsample_nearest",
+              "mq_dyconv_stats", "mq_dyconv_coef", "mq_dyconv_coef_group", "mq_dyconv_fuse", "mq_dyrelu_coef", "mq_dyconv_epilogue_group", "mq_dyrelu_apply", "mq_dyrelu_ln_fwd", "mq_add_upsample_nearest", "mq_pool2x2_tokens_fwd",
               "mq_align_scores_fwd", "mq_align_fused_fwd", "mq_box_decode", "mq_roi_align_fwd", "mq_msdeform_attn_fwd", "mq_msdeform_attn_q_fwd")
 # ... and as <name>_f32 (fp32 operands, the precise mode), except ROIAlign: its base entry point already takes fp32 features (is_f32 flag) and has
 # no other 16-bit operand.  (Round 6: the MSDeformAttn kernels have the twin -- the fused-query form reads a 16-bit `qproj`, a float there.)
@@ -1174,6 +1175,27 @@ def add_upsample_nearest_(dst, src):
         _chk(_fn(lib, "mq_add_upsample_nearest", dst)(_ptr(dst), _ptr(src), B, H, W, src.shape[1], src.shape[2], C, _stream()),
              "mq_add_upsample_nearest")
     return dst
+
+
+def pool2x2_tokens(feats):
+    """Pooled FPN tokens of the GCP pre-select in one launch (mq_pool2x2_tokens_fwd): feats = list of [B,C,H,W] views of NHWC tensors (what the FPN
+    returns) -> [B, sum (H/2)*(W/2), C] = torch.cat([F.avg_pool2d(f, 2).permute(0, 2, 3, 1).flatten(1, 2) for f in feats], 1), bit for bit."""
+    lib = load_library()
+    _need_gpu(*feats)
+    assert 0 < len(feats) <= 8
+    B, C = feats[0].shape[0], feats[0].shape[1]
+    arr = (_ConvLevel * len(feats))()
+    n = 0
+    for a, f in zip(arr, feats):
+        x = f.permute(0, 2, 3, 1)
+        Bx, H, W, Cx = x.shape
+        assert Bx == B and Cx == C and x.dtype == feats[0].dtype and x.stride(3) == 1 and x.stride(2) == C and x.stride(1) == W * C and H >= 2 and W >= 2
+        a.x, a.out, a.x_bs, a.H, a.W = x.data_ptr(), None, x.stride(0), H, W
+        n += (H // 2) * (W // 2)
+    out = torch.empty(B, n, C, dtype=feats[0].dtype, device=feats[0].device)
+    with _timed("pool2x2_tokens", sum(f.numel() for f in feats) * 2 + out.numel() * 2):
+        _chk(_fn(lib, "mq_pool2x2_tokens_fwd", feats[0])(ctypes.cast(arr, _vp), len(feats), _ptr(out), B, C, _stream()), "mq_pool2x2_tokens_fwd")
+    return out
 
 
 def dyrelu_apply_(x, coef):

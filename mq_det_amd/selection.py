@@ -72,6 +72,10 @@ KERNEL_DEFAULTS = {
                                  # pass turned every wait behind the FLAT-encoded copy into vmcnt(0) / lgkmcnt(0)).  Same-box A/B, 3 alternations:
                                  # fp16 0.559 -> 0.515 ms per launch (0.227 -> 0.246 of the MFMA peak), 483 -> 493 images/s; split-precise
                                  # 1.50 -> 1.21 ms, 174 -> 182 images/s (profiles/r06_call13_dcn_bdma_ab.txt)
+    "POOLED_TOKENS_FUSED": 1,    # 1: the pooled FPN tokens of the GCP pre-select in one launch (mq_pool2x2_tokens_fwd: bit for bit what five F.avg_pool2d + torch.cat
+                                 # return -- torch.equal on the device at the benchmark pyramid and at odd sizes, fp16 and bf16); 0: the torch statement of
+                                 # generalized_vl_rcnn_new.py:291-293.  Six launches on the chain between the FPN and the language half -> one: same-box A/B
+                                 # (GPU call 31 of round 6, 3 alternations) 500.5 against 496.2 images/s, +0.9 %
     "ALIGN_FUSED": 1,            # 1: mq_align_fused_fwd (heads + alignment + scoring, logits never written); 0: bmm + 5 GEMMs + 5 x mq_align_scores_fwd
 }
 class _ThreadLocalTable(dict):

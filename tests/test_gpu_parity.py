@@ -59,6 +59,20 @@ def test_vlfuse_strided_operands_equal_contiguous(dev):
         assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
 
 
+def test_pooled_tokens_fused_equals_torch(dev):
+    """mq_pool2x2_tokens_fwd against the torch statement it replaces (five F.avg_pool2d + concat, generalized_vl_rcnn_new.py:291-293) on the device,
+    at the benchmark pyramid and at odd sizes: bit for bit."""
+    import torch.nn.functional as F
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(31)
+    for dt in (torch.float16, torch.bfloat16):
+        for B, sizes in ((8, ((100, 168), (50, 84), (25, 42), (13, 21), (7, 11))), (2, ((9, 7), (5, 4), (3, 2)))):
+            feats = [torch.randn(B, h, w, 256, generator=g).to(dt).to(dev).permute(0, 3, 1, 2) for h, w in sizes]
+            ref = torch.cat([F.avg_pool2d(f, 2).permute(0, 2, 3, 1).flatten(1, 2) for f in feats], 1)
+            got = ops.pool2x2_tokens(feats)
+            assert got.shape == ref.shape and torch.equal(got, ref), (dt, sizes, float((got.float() - ref.float()).abs().max()))
+
+
 ATTN = [
     dict(B=2, H=12, D=64, Nq=256, Nk=256, mask=True),
     dict(B=2, H=12, D=64, Nq=256, Nk=256, mask=True, clamp=50000.0, big=True),

@@ -25,7 +25,7 @@ def test_c_abi_exports_match_header():
     lib = ops.load_library()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.mq_abi_version() == ops.EXPECTED_ABI == 30
+    assert lib.mq_abi_version() == ops.EXPECTED_ABI == 31
     assert lib.mq_attn_workspace_bytes(2, 8, 256, 256, 4) == 4 * 2 * 8 * 256 * 258 * 4
     assert lib.mq_ml_nms_workspace_bytes(2, 130) == 2 * 130 * 3 * 8
 

@@ -190,6 +190,23 @@ def test_fpn_topdown_fused_equals_interpolate_plus_add(kernels, monkeypatch):
     _assert_ok(kernels.check_swin_fpn(CPU))
 
 
+def test_pooled_tokens_fused_equals_avg_pool_and_cat(kernels, monkeypatch):
+    """mq_pool2x2_tokens_fwd (KERNELS["POOLED_TOKENS_FUSED"] = 1) against the reference's statement (generalized_vl_rcnn_new.py:291-293: five
+    F.avg_pool2d(f, 2) + concat over the tokens) on even and odd level sizes, batch-strided inputs included: EQUAL outputs; and the full-model
+    check with it on."""
+    from mq_det_amd import ops
+    g = torch.Generator().manual_seed(13)
+    for dt in (torch.float16, torch.bfloat16):
+        for sizes in (((100, 168), (50, 84), (25, 42), (13, 21), (7, 11)), ((9, 7), (5, 4), (3, 2)), ((2, 2),)):
+            big = [torch.randn(3, h, w, 256, generator=g).to(dt) for h, w in sizes]
+            feats = [x[:2].permute(0, 3, 1, 2) for x in big]                       # [B,C,H,W] views of NHWC storage, as the FPN returns them
+            ref = torch.cat([F.avg_pool2d(f.float(), 2).to(dt).permute(0, 2, 3, 1).flatten(1, 2) for f in feats], 1)
+            got = ops.pool2x2_tokens(feats)
+            assert got.shape == ref.shape and torch.equal(got, ref), (dt, sizes)
+    monkeypatch.setenv("MQ_POOLED_TOKENS_FUSED", "1")
+    _assert_ok(kernels.check_full_model(CPU))
+
+
 @pytest.mark.parametrize("clamp", [False, True])
 def test_bert_layer(kernels, clamp):
     _assert_ok(kernels.check_bert_layer(CPU, clamp))
