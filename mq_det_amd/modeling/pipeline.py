@@ -428,7 +428,7 @@ def _zero_offsets(B, Ho, Wo, device):
 
 def pooled_fpn_tokens(feats):
     """generalized_vl_rcnn_new.py:291-293 -> [B, sum(hw/4), C]."""
-    if ops.KERNELS.get("POOLED_TOKENS_FUSED", 0) == 1 and all(f.shape[2] >= 2 and f.shape[3] >= 2 for f in feats):
+    if ops.KERNELS.get("POOLED_TOKENS_FUSED", 0) == 1 and ops.pool2x2_tokens_supported(feats):
         return ops.pool2x2_tokens(feats)                      # one launch: the same values bit for bit
     return torch.cat([F.avg_pool2d(f, 2).permute(0, 2, 3, 1).flatten(1, 2) for f in feats], 1)
 

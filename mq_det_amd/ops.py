@@ -1177,6 +1177,20 @@ def add_upsample_nearest_(dst, src):
     return dst
 
 
+def pool2x2_tokens_supported(feats):
+    """Shapes / layouts mq_pool2x2_tokens_fwd takes: up to 8 levels, [B,C,H,W] VIEWS of NHWC storage (what the FPN returns), every level at least
+    2 x 2, C a multiple of 8 -- anything else goes through the torch statement."""
+    if not (0 < len(feats) <= 8):
+        return False
+    B, C = feats[0].shape[0], feats[0].shape[1]
+    for f in feats:
+        if f.dim() != 4 or f.shape[0] != B or f.shape[1] != C or f.dtype != feats[0].dtype or f.shape[2] < 2 or f.shape[3] < 2:
+            return False
+        if f.stride(1) != 1 or f.stride(3) != C or f.stride(2) != f.shape[3] * C or f.data_ptr() % 16 or f.stride(0) % 8:
+            return False
+    return C % 8 == 0 and feats[0].dtype in (torch.float16, torch.bfloat16, torch.float32)
+
+
 def pool2x2_tokens(feats):
     """Pooled FPN tokens of the GCP pre-select in one launch (mq_pool2x2_tokens_fwd): feats = list of [B,C,H,W] views of NHWC tensors (what the FPN
     returns) -> [B, sum (H/2)*(W/2), C] = torch.cat([F.avg_pool2d(f, 2).permute(0, 2, 3, 1).flatten(1, 2) for f in feats], 1), bit for bit."""

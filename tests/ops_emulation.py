@@ -636,7 +636,7 @@ def namespace(real_ops):
     import types
     g = globals()
     fake = types.SimpleNamespace(**{n: g[n] for n in NAMES})
-    for n in ("patch_embed_pack", "SWIN_MLP_WIDTHS", "WINDOW_QKV_WIDTHS", "window_qkv_fused", "SCORE_AGG", "window_pad", "pad_rel_bias", "swin_mlp_w2_perm", "swin_mlp2_pack", "timing_active", "attention_text_fits", "bert_attention_qkv_fits", "gcp_attention_fits", "f32_operands", "pack_b_fragments", "unpack_b_fragments", "dcn_bdma", "dcn_weight_tiles"):
+    for n in ("patch_embed_pack", "SWIN_MLP_WIDTHS", "WINDOW_QKV_WIDTHS", "window_qkv_fused", "SCORE_AGG", "window_pad", "pad_rel_bias", "swin_mlp_w2_perm", "swin_mlp2_pack", "timing_active", "attention_text_fits", "bert_attention_qkv_fits", "gcp_attention_fits", "f32_operands", "pack_b_fragments", "unpack_b_fragments", "dcn_bdma", "dcn_weight_tiles", "pool2x2_tokens_supported"):
         setattr(fake, n, getattr(real_ops, n))
     fake.KERNELS = dict(real_ops.KERNEL_DEFAULTS)       # the default kernel selection: the glue of the promoted variants is what runs
     return fake
